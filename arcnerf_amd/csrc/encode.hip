@@ -1,0 +1,163 @@
+// Frequency and spherical-harmonics encoders + elementwise activations (gfx950).
+// FreqEmbedder.forward: arcnerf/models/base_modules/encoding/freq_encoder.py:65-88
+// SHEmbedder torch branch: arcnerf/models/base_modules/encoding/sh_encoder.py:101-185 (polynomials evaluated on the
+// (d+1)/2 mapped value, literally)
+// get_activation / TruncExp: base_modules/activation.py:24-50, arcnerf/ops/trunc_exp.py:7-37
+#include "common.hpp"
+
+namespace arcn {
+
+// one lane per output element: coalesced stores; sin/cos arguments x*2^k are exact scalings
+__global__ void __launch_bounds__(256) freq_fwd_kernel(const float *__restrict__ x, int D, int n_freqs, int include_input,
+                                                       float *__restrict__ out, int64_t n) {
+    const int od = D * (include_input ? 1 : 0) + 2 * D * n_freqs;
+    const int64_t total = n * od;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / od;
+        int c = (int)(i - s * od);
+        float v;
+        if (include_input) {
+            if (c < D) { out[i] = x[s * D + c]; continue; }
+            c -= D;
+        }
+        const int f = c / (2 * D);
+        const int rem = c - f * 2 * D;
+        const int k = rem % D;
+        const float a = x[s * D + k] * ldexpf(1.0f, f);
+        v = rem < D ? sinf(a) : cosf(a);
+        out[i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) freq_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dout, int D,
+                                                       int n_freqs, int include_input, float *__restrict__ dx, int64_t n) {
+    const int od = D * (include_input ? 1 : 0) + 2 * D * n_freqs;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * D; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / D;
+        const int k = (int)(i - s * D);
+        const float *g = dout + s * od;
+        float acc = 0.f;
+        int c = 0;
+        if (include_input) { acc += g[k]; c = D; }
+        const float xv = x[i];
+        for (int f = 0; f < n_freqs; ++f) {
+            const float freq = ldexpf(1.0f, f);
+            const float a = xv * freq;
+            acc += g[c + k] * cosf(a) * freq;
+            acc -= g[c + D + k] * sinf(a) * freq;
+            c += 2 * D;
+        }
+        dx[i] = acc;
+    }
+}
+
+__device__ __forceinline__ void sh_eval(float dx, float dy, float dz, int degree, float *o) {
+    const float x = (dx + 1.0f) / 2.0f, y = (dy + 1.0f) / 2.0f, z = (dz + 1.0f) / 2.0f;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    int c = 0;
+    o[c++] = 0.28209479177387814f;
+    if (degree <= 1) return;
+    o[c++] = -0.4886025119029199f * y;
+    o[c++] = 0.4886025119029199f * z;
+    o[c++] = -0.4886025119029199f * x;
+    if (degree <= 2) return;
+    o[c++] = 1.0925484305920792f * xy;
+    o[c++] = -1.0925484305920792f * yz;
+    o[c++] = 0.31539156525252005f * (3.0f * zz - 1.0f);
+    o[c++] = -1.0925484305920792f * xz;
+    o[c++] = 0.5462742152960396f * (xx - yy);
+    if (degree <= 3) return;
+    o[c++] = -0.5900435899266435f * y * (3.0f * xx - yy);
+    o[c++] = 2.890611442640554f * xy * z;
+    o[c++] = -0.4570457994644658f * y * (5.0f * zz - 1.0f);
+    o[c++] = 0.3731763325901154f * z * (5.0f * zz - 3.0f);
+    o[c++] = -0.4570457994644658f * x * (5.0f * zz - 1.0f);
+    o[c++] = 1.445305721320277f * z * (xx - yy);
+    o[c++] = -0.5900435899266435f * x * (xx - 3.0f * yy);
+    if (degree <= 4) return;
+    o[c++] = 2.5033429417967046f * xy * (xx - yy);
+    o[c++] = -1.7701307697799304f * yz * (3.0f * xx - yy);
+    o[c++] = 0.9461746957575601f * xy * (7.0f * zz - 1.0f);
+    o[c++] = -0.6690465435572892f * yz * (7.0f * zz - 3.0f);
+    o[c++] = 0.10578554691520431f * (zz * (35.0f * zz - 30.0f) + 3.0f);
+    o[c++] = -0.6690465435572892f * xz * (7.0f * zz - 3.0f);
+    o[c++] = 0.47308734787878004f * (xx - yy) * (7.0f * zz - 1.0f);
+    o[c++] = -1.7701307697799304f * xz * (xx - 3.0f * yy);
+    o[c++] = 0.6258357354491761f * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy));
+}
+
+__global__ void __launch_bounds__(256) sh_fwd_kernel(const float *__restrict__ dirs, int degree, int include_input,
+                                                     float *__restrict__ out, int64_t n) {
+    const int nsh = degree * degree;
+    const int od = nsh + (include_input ? 3 : 0);
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+        float o[25];
+        const float dx = dirs[3 * s], dy = dirs[3 * s + 1], dz = dirs[3 * s + 2];
+        sh_eval(dx, dy, dz, degree, o);
+        float *dst = out + s * od;
+        if (include_input) { dst[0] = dx; dst[1] = dy; dst[2] = dz; dst += 3; }
+        for (int c = 0; c < nsh; ++c) dst[c] = o[c];
+    }
+}
+
+__global__ void __launch_bounds__(256) act_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n, int act,
+                                                      float beta) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = act_fwd(x[i], act, beta);
+}
+
+__global__ void __launch_bounds__(256) act_bwd_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                      const float *__restrict__ dy, float *__restrict__ dx, int64_t n,
+                                                      int act, float beta) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dx[i] = dy[i] * act_grad(x[i], y ? y[i] : 0.f, act, beta);
+}
+
+inline unsigned grid_for(int64_t n) {
+    int64_t b = ceil_div<int64_t>(n, 256);
+    return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace arcn
+
+using namespace arcn;
+
+ARCN_EXPORT int arcn_freq_fwd(const float *x, int D, int n_freqs, int include_input, float *out, int64_t n, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!x || !out || D < 1 || n_freqs < 0 || (n_freqs == 0 && !include_input)) return einval("freq_fwd: bad argument");
+    const int od = D * (include_input ? 1 : 0) + 2 * D * n_freqs;
+    hipLaunchKernelGGL(freq_fwd_kernel, dim3(grid_for(n * od)), dim3(256), 0, as_stream(stream), x, D, n_freqs,
+                       include_input, out, n);
+    return check_launch("freq_fwd");
+}
+
+ARCN_EXPORT int arcn_freq_bwd(const float *x, const float *dout, int D, int n_freqs, int include_input, float *dx,
+                              int64_t n, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!x || !dout || !dx || D < 1 || n_freqs < 0) return einval("freq_bwd: bad argument");
+    hipLaunchKernelGGL(freq_bwd_kernel, dim3(grid_for(n * D)), dim3(256), 0, as_stream(stream), x, dout, D, n_freqs,
+                       include_input, dx, n);
+    return check_launch("freq_bwd");
+}
+
+ARCN_EXPORT int arcn_sh_fwd(const float *dirs, int degree, int include_input, float *out, int64_t n, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!dirs || !out || degree < 1 || degree > 5) return einval("sh_fwd: degree must be 1..5");
+    hipLaunchKernelGGL(sh_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), dirs, degree, include_input, out, n);
+    return check_launch("sh_fwd");
+}
+
+ARCN_EXPORT int arcn_act_fwd(const float *x, float *y, int64_t n, int act, float beta, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!x || !y) return einval("act_fwd: missing argument");
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, y, n, act, beta);
+    return check_launch("act_fwd");
+}
+
+ARCN_EXPORT int arcn_act_bwd(const float *x, const float *y, const float *dy, float *dx, int64_t n, int act, float beta,
+                             void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!x || !dy || !dx) return einval("act_bwd: missing argument");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, y, dy, dx, n, act, beta);
+    return check_launch("act_bwd");
+}

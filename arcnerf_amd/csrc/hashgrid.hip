@@ -1,0 +1,246 @@
+// Multiresolution hash-grid encoding for gfx950: forward gather + backward scatter.
+//
+// Restates HashGridEmbedder.hashgrid_encode_torch (arcnerf/models/base_modules/encoding/hashgrid_encoder.py:191-249)
+// with the voxel maths of Volume.get_voxel_grid_info_from_xyz (arcnerf/geometry/volume.py:486-531):
+//   per level l: v = (x-min)/((max-min)/res_l); valid iff 0 <= v < res_l; c = floor(v);
+//   8 corners in the order (x,y,z) in {000,010,100,110,001,011,101,111} (volume.py:156-182);
+//   row = ((cx*1) ^ (cy*2654435761) ^ (cz*805459861)) mod size_l + offset_l, int64 arithmetic;
+//   w = clip((x - (c*vs + min_x))/vs, 0, 1); out = sum_corner table[row] * wx*wy*wz.
+// Integer rows are bit-exact with the reference (tests compare them); power-of-two level sizes take a 32-bit mask path
+// (low bits of the xor are unaffected by the high product bits), the others an exact 64-bit modulo done with one f64
+// multiply + fix-up (h < 2^53).
+//
+// Work decomposition v1: one lane per (sample, level), level fastest -> a 64-lane wave covers 4 samples x 16 levels,
+// xyz loads broadcast, the (n, L*F) row-major output is written fully coalesced (8 B per lane, 512 B per wave).
+// Algorithmic HBM bytes per sample (NGP config, F=2, L=16, fp32): 16*8*2*4 gathered + 12 in + 128 out = 1164 B.
+#include "common.hpp"
+
+namespace arcn {
+
+struct LevelParams {
+    int32_t res;
+    uint32_t size;     // rows of this level
+    uint32_t mask;     // size-1 if size is a power of two else 0
+    int32_t pad;
+    double inv_size;   // 1.0/size
+    int64_t offset;    // first row
+};
+
+struct GridParams {
+    int32_t L, F;
+    float mn[3], mx[3];
+    LevelParams lv[ARCN_MAX_LEVELS];
+};
+
+__device__ __forceinline__ uint32_t hash_row(uint32_t cx, uint32_t cy, uint32_t cz, const LevelParams &lp) {
+    if (lp.mask) {
+        uint32_t h = cx ^ (cy * 2654435761u) ^ (cz * 805459861u);
+        return h & lp.mask;
+    }
+    uint64_t h = (uint64_t)cx ^ ((uint64_t)cy * 2654435761ull) ^ ((uint64_t)cz * 805459861ull);
+    double q = floor((double)h * lp.inv_size);
+    int64_t r = (int64_t)h - (int64_t)q * (int64_t)lp.size;
+    if (r < 0) r += lp.size;
+    else if (r >= (int64_t)lp.size) r -= lp.size;
+    return (uint32_t)r;
+}
+
+struct Cell {
+    uint32_t c[3];
+    float w[3];
+    float dw[3];  // d w / d x (0 where torch.clip blocks the gradient)
+    bool valid;
+};
+
+__device__ __forceinline__ Cell locate(const float p[3], const GridParams &g, int res) {
+    Cell cell;
+    float v[3], vs[3];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        vs[k] = (g.mx[k] - g.mn[k]) / (float)res;
+        v[k] = (p[k] - g.mn[k]) / vs[k];
+        if (!(v[k] >= 0.f) || !(v[k] < (float)res)) ok = false;
+    }
+    cell.valid = ok;
+    if (!ok) return cell;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float cf = floorf(v[k]);
+        cell.c[k] = (uint32_t)cf;
+        float a = cf * vs[k];
+        float g0 = a + g.mn[0];  // start_point[0] for every axis (volume.py:515)
+        float ww = (p[k] - g0) / vs[k];
+        cell.w[k] = ww < 0.0f ? 0.0f : (ww > 1.0f ? 1.0f : ww);
+        cell.dw[k] = (ww >= 0.0f && ww <= 1.0f) ? 1.0f / vs[k] : 0.0f;
+    }
+    return cell;
+}
+
+template <int F>
+__global__ void __launch_bounds__(256) hashgrid_fwd_kernel(const float *__restrict__ xyz, const float *__restrict__ table,
+                                                           GridParams g, float *__restrict__ out,
+                                                           int32_t *__restrict__ hash_idx, int64_t n,
+                                                           const int32_t *n_ptr) {
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= cnt * g.L) return;
+    const int64_t s = gid / g.L;
+    const int l = (int)(gid - s * g.L);
+    const LevelParams lp = g.lv[l];
+    const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
+    const Cell cell = locate(p, g, lp.res);
+    float acc[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.f;
+    if (cell.valid) {
+        uint32_t rows[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            // corner order of Volume.get_eight_permutation: x = (q>>1)&1, y = q&1, z = q>>2
+            const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
+            rows[q] = hash_row(cell.c[0] + ox, cell.c[1] + oy, cell.c[2] + oz, lp);
+        }
+        float vals[8][F];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float *src = table + ((int64_t)rows[q] + lp.offset) * F;
+            if (F == 2) {
+                float2 t2 = *reinterpret_cast<const float2 *>(src);
+                vals[q][0] = t2.x;
+                vals[q][1 % F] = t2.y;
+            } else if (F == 4) {
+                float4 t4 = *reinterpret_cast<const float4 *>(src);
+                vals[q][0] = t4.x; vals[q][1 % F] = t4.y; vals[q][2 % F] = t4.z; vals[q][3 % F] = t4.w;
+            } else {
+#pragma unroll
+                for (int f = 0; f < F; ++f) vals[q][f] = src[f];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
+            float wx = ox ? cell.w[0] : 1.0f - cell.w[0];
+            float wy = oy ? cell.w[1] : 1.0f - cell.w[1];
+            float wz = oz ? cell.w[2] : 1.0f - cell.w[2];
+            float wt = (wx * wy) * wz;
+#pragma unroll
+            for (int f = 0; f < F; ++f) { float a = vals[q][f] * wt; acc[f] = acc[f] + a; }
+            if (hash_idx) hash_idx[gid * 8 + q] = (int32_t)((int64_t)rows[q] + lp.offset);
+        }
+    } else if (hash_idx) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hash_idx[gid * 8 + q] = -1;
+    }
+    float *o = out + gid * F;
+    if (F == 2) *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1 % F]);
+    else if (F == 4) *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1 % F], acc[2 % F], acc[3 % F]);
+    else {
+#pragma unroll
+        for (int f = 0; f < F; ++f) o[f] = acc[f];
+    }
+}
+
+template <int F>
+__global__ void __launch_bounds__(256) hashgrid_bwd_kernel(const float *__restrict__ xyz, const float *__restrict__ table,
+                                                           const float *__restrict__ dout, GridParams g,
+                                                           float *__restrict__ dtable, float *__restrict__ dxyz, int64_t n,
+                                                           const int32_t *n_ptr) {
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= cnt * g.L) return;
+    const int64_t s = gid / g.L;
+    const int l = (int)(gid - s * g.L);
+    const LevelParams lp = g.lv[l];
+    const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
+    const Cell cell = locate(p, g, lp.res);
+    if (!cell.valid) return;
+    float go[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) go[f] = dout[gid * F + f];
+    float gx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
+        const int64_t row = (int64_t)hash_row(cell.c[0] + ox, cell.c[1] + oy, cell.c[2] + oz, lp) + lp.offset;
+        float wx = ox ? cell.w[0] : 1.0f - cell.w[0];
+        float wy = oy ? cell.w[1] : 1.0f - cell.w[1];
+        float wz = oz ? cell.w[2] : 1.0f - cell.w[2];
+        float wt = (wx * wy) * wz;
+        if (dtable) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) unsafeAtomicAdd(&dtable[row * F + f], go[f] * wt);
+        }
+        if (dxyz) {
+            float dot = 0.f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) dot += go[f] * table[row * F + f];
+            float sx = ox ? 1.0f : -1.0f, sy = oy ? 1.0f : -1.0f, sz = oz ? 1.0f : -1.0f;
+            gx[0] += dot * sx * wy * wz * cell.dw[0];
+            gx[1] += dot * wx * sy * wz * cell.dw[1];
+            gx[2] += dot * wx * wy * sz * cell.dw[2];
+        }
+    }
+    if (dxyz) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) unsafeAtomicAdd(&dxyz[3 * s + k], gx[k]);
+    }
+}
+
+static int build_params(const arcn_hashgrid_desc *d, GridParams &g) {
+    if (!d) return einval("hashgrid: desc is NULL");
+    if (d->n_levels < 1 || d->n_levels > ARCN_MAX_LEVELS) return einval("hashgrid: n_levels out of range");
+    if (!(d->n_feat == 1 || d->n_feat == 2 || d->n_feat == 4)) return einval("hashgrid: n_feat must be 1, 2 or 4");
+    g.L = d->n_levels;
+    g.F = d->n_feat;
+    for (int k = 0; k < 3; ++k) { g.mn[k] = d->min_xyz[k]; g.mx[k] = d->max_xyz[k]; }
+    for (int l = 0; l < g.L; ++l) {
+        int64_t size = d->offsets[l + 1] - d->offsets[l];
+        if (size <= 0 || size > 0xffffffffll || d->resolutions[l] <= 0) return einval("hashgrid: bad level table");
+        LevelParams &lp = g.lv[l];
+        lp.res = d->resolutions[l];
+        lp.size = (uint32_t)size;
+        lp.mask = ((size & (size - 1)) == 0) ? (uint32_t)(size - 1) : 0u;
+        lp.pad = 0;
+        lp.inv_size = 1.0 / (double)size;
+        lp.offset = d->offsets[l];
+    }
+    return ARCN_OK;
+}
+
+}  // namespace arcn
+
+using namespace arcn;
+
+ARCN_EXPORT int arcn_hashgrid_fwd(const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out,
+                                  int32_t *hash_idx, int64_t n, const int32_t *n_ptr, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!xyz || !table || !out) return einval("hashgrid_fwd: missing argument");
+    GridParams g;
+    int rc = build_params(desc_host, g);
+    if (rc) return rc;
+    dim3 grid((unsigned)ceil_div<int64_t>(n * g.L, 256));
+    switch (g.F) {
+    case 1: hipLaunchKernelGGL(hashgrid_fwd_kernel<1>, grid, dim3(256), 0, as_stream(stream), xyz, table, g, out, hash_idx, n, n_ptr); break;
+    case 2: hipLaunchKernelGGL(hashgrid_fwd_kernel<2>, grid, dim3(256), 0, as_stream(stream), xyz, table, g, out, hash_idx, n, n_ptr); break;
+    default: hipLaunchKernelGGL(hashgrid_fwd_kernel<4>, grid, dim3(256), 0, as_stream(stream), xyz, table, g, out, hash_idx, n, n_ptr); break;
+    }
+    return check_launch("hashgrid_fwd");
+}
+
+ARCN_EXPORT int arcn_hashgrid_bwd(const float *xyz, const float *table, const float *dout,
+                                  const arcn_hashgrid_desc *desc_host, float *dtable, float *dxyz, int64_t n,
+                                  const int32_t *n_ptr, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!xyz || !dout || (!dtable && !dxyz) || (dxyz && !table)) return einval("hashgrid_bwd: missing argument");
+    GridParams g;
+    int rc = build_params(desc_host, g);
+    if (rc) return rc;
+    dim3 grid((unsigned)ceil_div<int64_t>(n * g.L, 256));
+    switch (g.F) {
+    case 1: hipLaunchKernelGGL(hashgrid_bwd_kernel<1>, grid, dim3(256), 0, as_stream(stream), xyz, table, dout, g, dtable, dxyz, n, n_ptr); break;
+    case 2: hipLaunchKernelGGL(hashgrid_bwd_kernel<2>, grid, dim3(256), 0, as_stream(stream), xyz, table, dout, g, dtable, dxyz, n, n_ptr); break;
+    default: hipLaunchKernelGGL(hashgrid_bwd_kernel<4>, grid, dim3(256), 0, as_stream(stream), xyz, table, dout, g, dtable, dxyz, n, n_ptr); break;
+    }
+    return check_launch("hashgrid_bwd");
+}

@@ -1,0 +1,518 @@
+// Fully fused small MLP on gfx950 matrix cores (exact f32 MFMA, v_mfma_f32_16x16x4_f32).
+//
+// Replaces tcnn.Network(FullyFusedMLP) (arcnerf/models/base_modules/geo_rad_model/tcnn_fusedmlp_module.py:66-77,
+// 162-173) and skip-free GeoNet/RadianceNet stacks (linear_network_module.py:174-197,318-335):
+//     y_i = act_i(y_{i-1} W_i^T + b_i),   W_i (dims[i+1], dims[i]) row-major like torch.nn.Linear.weight.
+//
+// Orientation: every layer is computed TRANSPOSED, Y^T = W . X^T, i.e. MFMA rows = output neurons, MFMA columns =
+// samples.  With the 16x16x4 f32 MFMA the accumulator of lane (g = lane>>4, j = lane&15) holds neurons 4g..4g+3 of
+// sample j, and the B operand of a K-step wants, in lane (g, j), input-neuron k = f(g, step) of sample j.  Choosing
+// the K order k = 16t + 4g + ks (t = input tile, ks = 0..3) makes register `ks` of the previous layer's accumulator
+// tile t EXACTLY the B operand — activations never leave registers between layers, no LDS round trip, no shuffles.
+// The same permutation applied to the A operand means lane (i = lane&15, g) needs W[16mt+i][16t+4g+0..3]: 16 contiguous
+// bytes; weights are staged once per workgroup into LDS in that fragment order so each (mt, t) tile is one conflict-
+// free ds_read_b128 per lane reused by all NT sample tiles.
+// f32 MFMA is bit-for-bit an fmaf-free k-ordered f32 chain (MI355X guide §3), so results match an fp32 torch/CPU MLP to
+// summation-order noise (~1e-7 rel) — this is what lets the path meet the 1e-4 RGB parity bar without fp16.
+// Roofline: 18.8 kFLOP/sample fwd for the NGP nets; at the 1e8 samples/s target that is 1.9 TFLOP/s of the 157 TFLOP/s
+// f32 matrix peak — the MLP is bound by its operand traffic (128 B/sample features in, 16..64 B out), not by MFMA.
+#include "common.hpp"
+
+namespace arcn {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxLayers = 8;
+
+struct MlpParams {
+    int32_t n_layers;
+    int32_t dims[kMaxLayers + 1];
+    int32_t w_off[kMaxLayers];    // float offset of W_i in `weights`
+    int32_t b_off[kMaxLayers];    // float offset of b_i in `biases`
+    int32_t lds_off[kMaxLayers];  // float offset of the packed fragments of layer i in LDS
+    int32_t act_hidden, act_out, has_bias;
+    float beta;
+};
+
+__host__ __device__ inline int tiles16(int d) { return (d + 15) >> 4; }
+
+// derivative of the activation expressed through the post-activation value y
+__device__ __forceinline__ float act_grad_from_y(float y, int act, float beta) {
+    switch (act) {
+    case ARCN_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case ARCN_ACT_SIGMOID: return y * (1.0f - y);
+    case ARCN_ACT_TRUNCEXP: { float c = y < 3.0590232e-7f ? 3.0590232e-7f : (y > 3269017.4f ? 3269017.4f : y); return c; }
+    case ARCN_ACT_SOFTPLUS: return 1.0f - expf(-beta * y);
+    default: return 1.f;
+    }
+}
+
+// Stage W (rows x cols, row-major, leading dimension ld) — or its transpose — into LDS in MFMA A-fragment order:
+//   element A[r][c] -> lds[((mt*T + t)*64 + g*16 + i)*4 + ks],  r = 16mt+i, c = 16t+4g+ks, zero padded to 16 multiples.
+// TRANSPOSED: A = W^T, i.e. A[r][c] = W[c][r] with W (cols x rows).
+template <bool TRANSPOSED>
+__device__ __forceinline__ void stage_fragments(float *lds, const float *__restrict__ W, int rows, int cols) {
+    const int MT = tiles16(rows), T = tiles16(cols);
+    const int total = MT * T * 256;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        int r, c;
+        if (TRANSPOSED) { c = e / (MT * 16); r = e - c * (MT * 16); }  // walk W row-major: W row = c, W col = r
+        else { r = e / (T * 16); c = e - r * (T * 16); }
+        float v = 0.f;
+        if (r < rows && c < cols) v = TRANSPOSED ? W[(int64_t)c * rows + r] : W[(int64_t)r * cols + c];
+        const int mt = r >> 4, i = r & 15, t = c >> 4, g = (c & 15) >> 2, ks = c & 3;
+        lds[((mt * T + t) * 64 + g * 16 + i) * 4 + ks] = v;
+    }
+}
+
+// Load a (n, width) row-major tensor into the transposed-tile register layout: v[t][nt][r] = src[s0+16nt+j][16t+4g+r]
+template <int WT, int NT>
+__device__ __forceinline__ void load_tiles(f4 (&v)[WT][NT], const float *__restrict__ src, int width, int64_t s0,
+                                           int64_t cnt, int g, int j) {
+    const int T = tiles16(width);
+    const bool vec = (width & 3) == 0;
+#pragma unroll
+    for (int t = 0; t < WT; ++t) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f4 r = {0.f, 0.f, 0.f, 0.f};
+            if (t < T) {
+                const int64_t s = s0 + 16 * nt + j;
+                const int col = 16 * t + 4 * g;
+                if (s < cnt) {
+                    const float *p = src + s * width + col;
+                    if (vec && col + 3 < width) r = *reinterpret_cast<const f4 *>(p);
+                    else {
+                        if (col < width) r.x = p[0];
+                        if (col + 1 < width) r.y = p[1];
+                        if (col + 2 < width) r.z = p[2];
+                        if (col + 3 < width) r.w = p[3];
+                    }
+                }
+            }
+            v[t][nt] = r;
+        }
+    }
+}
+
+template <int WT, int NT>
+__device__ __forceinline__ void store_tiles(const f4 (&v)[WT][NT], float *__restrict__ dst, int width, int64_t s0,
+                                            int64_t cnt, int g, int j) {
+    const int T = tiles16(width);
+    const bool vec = (width & 3) == 0;
+#pragma unroll
+    for (int t = 0; t < WT; ++t) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (t < T) {
+                const int64_t s = s0 + 16 * nt + j;
+                const int col = 16 * t + 4 * g;
+                if (s < cnt) {
+                    float *p = dst + s * width + col;
+                    const f4 r = v[t][nt];
+                    if (vec && col + 3 < width) *reinterpret_cast<f4 *>(p) = r;
+                    else {
+                        if (col < width) p[0] = r.x;
+                        if (col + 1 < width) p[1] = r.y;
+                        if (col + 2 < width) p[2] = r.z;
+                        if (col + 3 < width) p[3] = r.w;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// out[mt][nt] (+)= sum_t A(mt,t) . in[t][nt]   with A fragments in LDS
+template <int WT, int NT>
+__device__ __forceinline__ void gemm_tiles(f4 (&out)[WT][NT], const f4 (&in)[WT][NT], const float *lds_frag, int MT, int T,
+                                           int lane) {
+#pragma unroll
+    for (int mt = 0; mt < WT; ++mt) {
+        if (mt < MT) {
+#pragma unroll
+            for (int t = 0; t < WT; ++t) {
+                if (t < T) {
+                    const f4 a = *reinterpret_cast<const f4 *>(lds_frag + ((mt * T + t) * 64 + lane) * 4);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) out[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, in[t][nt].x, out[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) out[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, in[t][nt].y, out[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) out[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, in[t][nt].z, out[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) out[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, in[t][nt].w, out[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+// ---- forward ------------------------------------------------------------------------------------------
+template <int WT, int NT>
+__global__ void __launch_bounds__(256)
+mlp_fwd_kernel(const float *__restrict__ x, const float *__restrict__ weights, const float *__restrict__ biases, MlpParams P,
+               float *__restrict__ out, float *__restrict__ acts, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int l = 0; l < P.n_layers; ++l) stage_fragments<false>(lds + P.lds_off[l], weights + P.w_off[l], P.dims[l + 1], P.dims[l]);
+    __syncthreads();
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+    constexpr int SPW = 16 * NT;
+    const int64_t n_tiles = ceil_div_dev(cnt, (int64_t)SPW * 4);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t s0 = tile * SPW * 4 + (int64_t)wave * SPW;
+        if (s0 >= cnt) continue;
+        f4 hin[WT][NT];
+        load_tiles<WT, NT>(hin, x, P.dims[0], s0, cnt, g, j);
+        int64_t act_off = 0;
+        for (int l = 0; l < P.n_layers; ++l) {
+            const int N = P.dims[l + 1], K = P.dims[l];
+            const int MT = tiles16(N), T = tiles16(K);
+            f4 hout[WT][NT];
+#pragma unroll
+            for (int mt = 0; mt < WT; ++mt) {
+                f4 b0 = {0.f, 0.f, 0.f, 0.f};
+                if (P.has_bias && mt < MT) {
+                    const float *bp = biases + P.b_off[l];
+                    const int row = 16 * mt + 4 * g;
+                    if (row < N) b0.x = bp[row];
+                    if (row + 1 < N) b0.y = bp[row + 1];
+                    if (row + 2 < N) b0.z = bp[row + 2];
+                    if (row + 3 < N) b0.w = bp[row + 3];
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) hout[mt][nt] = b0;
+            }
+            gemm_tiles<WT, NT>(hout, hin, lds + P.lds_off[l], MT, T, lane);
+            const bool last = (l == P.n_layers - 1);
+            const int act = last ? P.act_out : P.act_hidden;
+#pragma unroll
+            for (int mt = 0; mt < WT; ++mt) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    f4 r = hout[mt][nt];
+                    if (mt < MT && act != ARCN_ACT_NONE) {
+                        r.x = act_fwd(r.x, act, P.beta);
+                        r.y = act_fwd(r.y, act, P.beta);
+                        r.z = act_fwd(r.z, act, P.beta);
+                        r.w = act_fwd(r.w, act, P.beta);
+                    }
+                    // rows beyond N are exact zeros in W, hence zero pre-activations; keep them zero as next-layer input
+                    hin[mt][nt] = r;
+                }
+            }
+            if (last) store_tiles<WT, NT>(hin, out, N, s0, cnt, g, j);
+            else if (acts) {
+                store_tiles<WT, NT>(hin, acts + act_off, N, s0, cnt, g, j);
+                act_off += n_cap * N;
+            }
+            if (!last && (N & 15)) {
+                // padded rows must feed zeros to the next layer even when act(0) != 0 (sigmoid, exp)
+                const int row = 16 * (MT - 1) + 4 * g;
+#pragma unroll
+                for (int mt = 0; mt < WT; ++mt) {
+                    if (mt == MT - 1) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            if (row >= N) hin[mt][nt].x = 0.f;
+                            if (row + 1 >= N) hin[mt][nt].y = 0.f;
+                            if (row + 2 >= N) hin[mt][nt].z = 0.f;
+                            if (row + 3 >= N) hin[mt][nt].w = 0.f;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- backward, part 1: dpre_l for every layer (stored to scratch) and dx ----------------------------------
+template <int WT, int NT>
+__global__ void __launch_bounds__(256)
+mlp_bwd_dx_kernel(const float *__restrict__ weights, MlpParams P, const float *__restrict__ out,
+                  const float *__restrict__ acts, const float *__restrict__ dout, float *__restrict__ dx,
+                  float *__restrict__ scratch, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // A = W_l^T : rows = dims[l] (inputs), cols = dims[l+1] (outputs)
+    for (int l = 0; l < P.n_layers; ++l) stage_fragments<true>(lds + P.lds_off[l], weights + P.w_off[l], P.dims[l], P.dims[l + 1]);
+    __syncthreads();
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+    constexpr int SPW = 16 * NT;
+    const int64_t n_tiles = ceil_div_dev(cnt, (int64_t)SPW * 4);
+    // float offsets of layer l inside acts (hidden outputs) and scratch (dpre of every layer)
+    int64_t acts_off[kMaxLayers], scr_off[kMaxLayers];
+    {
+        int64_t a = 0, s = 0;
+        for (int l = 0; l < P.n_layers; ++l) {
+            acts_off[l] = a;
+            scr_off[l] = s;
+            if (l < P.n_layers - 1) a += n_cap * P.dims[l + 1];
+            s += n_cap * P.dims[l + 1];
+        }
+    }
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t s0 = tile * SPW * 4 + (int64_t)wave * SPW;
+        if (s0 >= cnt) continue;
+        f4 d[WT][NT];
+        load_tiles<WT, NT>(d, dout, P.dims[P.n_layers], s0, cnt, g, j);
+        for (int l = P.n_layers - 1; l >= 0; --l) {
+            const int N = P.dims[l + 1], K = P.dims[l];
+            const bool last = (l == P.n_layers - 1);
+            const int act = last ? P.act_out : P.act_hidden;
+            if (act != ARCN_ACT_NONE) {
+                f4 y[WT][NT];
+                load_tiles<WT, NT>(y, last ? out : acts + acts_off[l], N, s0, cnt, g, j);
+#pragma unroll
+                for (int mt = 0; mt < WT; ++mt) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        d[mt][nt].x *= act_grad_from_y(y[mt][nt].x, act, P.beta);
+                        d[mt][nt].y *= act_grad_from_y(y[mt][nt].y, act, P.beta);
+                        d[mt][nt].z *= act_grad_from_y(y[mt][nt].z, act, P.beta);
+                        d[mt][nt].w *= act_grad_from_y(y[mt][nt].w, act, P.beta);
+                    }
+                }
+            }
+            store_tiles<WT, NT>(d, scratch + scr_off[l], N, s0, cnt, g, j);
+            if (l > 0 || dx) {
+                f4 dp[WT][NT];
+#pragma unroll
+                for (int mt = 0; mt < WT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) dp[mt][nt] = f4{0.f, 0.f, 0.f, 0.f};
+                gemm_tiles<WT, NT>(dp, d, lds + P.lds_off[l], tiles16(K), tiles16(N), lane);
+#pragma unroll
+                for (int mt = 0; mt < WT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) d[mt][nt] = dp[mt][nt];
+            }
+        }
+        if (dx) store_tiles<WT, NT>(d, dx, P.dims[0], s0, cnt, g, j);
+    }
+}
+
+// ---- backward, part 2: dW_l = dpre_l^T . y_{l-1}  (reduction over samples), db_l = sum_s dpre_l ----------------
+// grid = (slabs, n_layers * quads): one workgroup owns a slab of samples for one 64x64 quadrant of one layer's dW.
+// MFMA rows = output neurons, columns = input neurons, K = samples: both operands come straight from global memory in
+// the layout the MFMA wants (lane (i, g): dpre[s+g][16mt+i]; lane (j, g): y[s+g][16nt+j]) — 64 B segments per 16 lanes.
+struct DwParams {
+    int32_t n_layers;
+    int32_t dims[kMaxLayers + 1];
+    int32_t w_off[kMaxLayers], b_off[kMaxLayers];
+    int32_t quad_first[kMaxLayers + 1];  // prefix of quadrant counts per layer
+    int32_t has_bias;
+};
+
+__global__ void __launch_bounds__(256)
+mlp_bwd_dw_kernel(const float *__restrict__ x, const float *__restrict__ acts, const float *__restrict__ scratch, DwParams P,
+                  float *__restrict__ dweights, float *__restrict__ dbiases, int64_t n_cap, int64_t n,
+                  const int32_t *n_ptr) {
+    __shared__ __attribute__((aligned(16))) float red[4][16][64][4];  // 64 KiB: per-wave accumulators
+    const int64_t cnt = dev_count(n, n_ptr);
+    // which (layer, quadrant)
+    int l = 0;
+    while (l + 1 < P.n_layers && (int)blockIdx.y >= P.quad_first[l + 1]) ++l;
+    const int q = blockIdx.y - P.quad_first[l];
+    const int N = P.dims[l + 1], K = P.dims[l];
+    const int qn = (tiles16(K) + 3) / 4;  // quadrants along the input dim
+    const int mt0 = (q / qn) * 4, nt0 = (q % qn) * 4;
+    const int MT = min(4, tiles16(N) - mt0), NTK = min(4, tiles16(K) - nt0);
+    int64_t acts_off = 0, scr_off = 0;
+    for (int k = 0; k < l; ++k) { scr_off += n_cap * P.dims[k + 1]; if (k < l - 1) acts_off += n_cap * P.dims[k + 1]; }
+    const float *dpre = scratch + scr_off;
+    const float *yprev = (l == 0) ? x : acts + acts_off;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+    f4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    const int64_t total_waves = (int64_t)gridDim.x * 4;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    // contiguous slab of 4-sample steps per wave
+    const int64_t steps = (cnt + 3) >> 2;
+    const int64_t per = (steps + total_waves - 1) / total_waves;
+    const int64_t st_lo = gw * per, st_hi = (st_lo + per < steps) ? st_lo + per : steps;
+    for (int64_t st = st_lo; st < st_hi; ++st) {
+        const int64_t s = st * 4 + g;
+        const bool ok = s < cnt;
+        float av[4], bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int row = 16 * (mt0 + a) + i;
+            av[a] = (ok && a < MT && row < N) ? dpre[s * N + row] : 0.f;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int col = 16 * (nt0 + b) + i;
+            bv[b] = (ok && b < NTK && col < K) ? yprev[s * K + col] : 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            bsum[a] += av[a];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    // cross-wave reduction in LDS, then one atomic per element per workgroup
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) *reinterpret_cast<f4 *>(&red[wave][a * 4 + b][lane][0]) = acc[a][b];
+    __syncthreads();
+    float *dW = dweights + P.w_off[l];
+    for (int e = threadIdx.x; e < 16 * 256; e += 256) {
+        const int tile = e >> 8, ln = (e >> 2) & 63, r = e & 3;
+        const int a = tile >> 2, b = tile & 3;
+        if (a >= MT || b >= NTK) continue;
+        float v = red[0][tile][ln][r] + red[1][tile][ln][r] + red[2][tile][ln][r] + red[3][tile][ln][r];
+        // accumulator layout: row = 4*(ln>>4) + r (output neuron), col = ln & 15 (input neuron)
+        const int row = 16 * (mt0 + a) + 4 * (ln >> 4) + r, col = 16 * (nt0 + b) + (ln & 15);
+        if (row < N && col < K && v != 0.f) unsafeAtomicAdd(&dW[(int64_t)row * K + col], v);
+    }
+    if (P.has_bias && dbiases && nt0 == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float v = bsum[a];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int row = 16 * (mt0 + a) + i;
+            if (g == 0 && a < MT && row < N && v != 0.f) unsafeAtomicAdd(&dbiases[P.b_off[l] + row], v);
+        }
+    }
+}
+
+static int build_mlp_params(const arcn_mlp_desc *d, MlpParams &P, bool transposed, int *lds_floats, int *max_dim) {
+    if (!d) return einval("mlp: desc is NULL");
+    if (d->n_layers < 1 || d->n_layers > kMaxLayers) return einval("mlp: 1..8 layers supported");
+    P.n_layers = d->n_layers;
+    int woff = 0, boff = 0, loff = 0, md = 0;
+    for (int l = 0; l <= d->n_layers; ++l) {
+        if (d->dims[l] < 1 || d->dims[l] > 128) return einval("mlp: layer widths must be in 1..128");
+        P.dims[l] = d->dims[l];
+        if (d->dims[l] > md) md = d->dims[l];
+    }
+    for (int l = 0; l < d->n_layers; ++l) {
+        P.w_off[l] = woff;
+        P.b_off[l] = boff;
+        P.lds_off[l] = loff;
+        woff += d->dims[l] * d->dims[l + 1];
+        boff += d->dims[l + 1];
+        loff += tiles16(d->dims[l]) * tiles16(d->dims[l + 1]) * 256;
+    }
+    (void)transposed;
+    P.act_hidden = d->act_hidden;
+    P.act_out = d->act_out;
+    P.has_bias = d->has_bias;
+    P.beta = d->softplus_beta;
+    *lds_floats = loff;
+    *max_dim = md;
+    return ARCN_OK;
+}
+
+template <typename Kern>
+static int set_lds(Kern k, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
+    }
+    return ARCN_OK;
+}
+
+inline unsigned tile_grid(int64_t n, int spb) {
+    int64_t b = ceil_div<int64_t>(n, spb);
+    const int64_t cap = 256 * 4;  // 4 resident workgroups per CU re-use the staged weights across tiles
+    return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+}  // namespace arcn
+
+using namespace arcn;
+
+ARCN_EXPORT int64_t arcn_mlp_acts_floats(const arcn_mlp_desc *d, int64_t n_cap) {
+    if (!d) return 0;
+    int64_t s = 0;
+    for (int l = 0; l < d->n_layers - 1; ++l) s += n_cap * d->dims[l + 1];
+    return s;
+}
+
+ARCN_EXPORT int64_t arcn_mlp_scratch_floats(const arcn_mlp_desc *d, int64_t n_cap) {
+    if (!d) return 0;
+    int64_t s = 0;
+    for (int l = 0; l < d->n_layers; ++l) s += n_cap * d->dims[l + 1];
+    return s;
+}
+
+ARCN_EXPORT int arcn_mlp_fwd(const float *x, const float *weights, const float *biases, const arcn_mlp_desc *desc_host,
+                             float *out, float *acts, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!x || !weights || !out) return einval("mlp_fwd: missing argument");
+    MlpParams P;
+    int lds_floats, md;
+    int rc = build_mlp_params(desc_host, P, false, &lds_floats, &md);
+    if (rc) return rc;
+    if (P.has_bias && !biases) return einval("mlp_fwd: biases required");
+    const size_t lds_bytes = sizeof(float) * (size_t)lds_floats;
+    if (lds_bytes > 144 * 1024) return einval("mlp_fwd: network too large for the LDS-resident fused kernel");
+    if (md <= 64) {
+        if ((rc = set_lds(mlp_fwd_kernel<4, 4>, lds_bytes))) return rc;
+        hipLaunchKernelGGL((mlp_fwd_kernel<4, 4>), dim3(tile_grid(n, 256)), dim3(256), lds_bytes, as_stream(stream), x, weights,
+                           biases, P, out, acts, n_cap, n, n_ptr);
+    } else {
+        if ((rc = set_lds(mlp_fwd_kernel<8, 2>, lds_bytes))) return rc;
+        hipLaunchKernelGGL((mlp_fwd_kernel<8, 2>), dim3(tile_grid(n, 128)), dim3(256), lds_bytes, as_stream(stream), x, weights,
+                           biases, P, out, acts, n_cap, n, n_ptr);
+    }
+    return check_launch("mlp_fwd");
+}
+
+ARCN_EXPORT int arcn_mlp_bwd(const float *x, const float *weights, const float *biases, const arcn_mlp_desc *desc_host,
+                             const float *out, const float *acts, const float *dout, float *dx, float *dweights,
+                             float *dbiases, float *scratch, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+    (void)biases;
+    if (n <= 0) return ARCN_OK;
+    if (!x || !weights || !out || !dout || !scratch) return einval("mlp_bwd: missing argument");
+    MlpParams P;
+    int lds_floats, md;
+    int rc = build_mlp_params(desc_host, P, true, &lds_floats, &md);
+    if (rc) return rc;
+    if (P.n_layers > 1 && !acts) return einval("mlp_bwd: saved activations required");
+    const size_t lds_bytes = sizeof(float) * (size_t)lds_floats;
+    if (lds_bytes > 144 * 1024) return einval("mlp_bwd: network too large for the LDS-resident fused kernel");
+    if (md <= 64) {
+        if ((rc = set_lds(mlp_bwd_dx_kernel<4, 4>, lds_bytes))) return rc;
+        hipLaunchKernelGGL((mlp_bwd_dx_kernel<4, 4>), dim3(tile_grid(n, 256)), dim3(256), lds_bytes, as_stream(stream), weights, P,
+                           out, acts, dout, dx, scratch, n_cap, n, n_ptr);
+    } else {
+        if ((rc = set_lds(mlp_bwd_dx_kernel<8, 2>, lds_bytes))) return rc;
+        hipLaunchKernelGGL((mlp_bwd_dx_kernel<8, 2>), dim3(tile_grid(n, 128)), dim3(256), lds_bytes, as_stream(stream), weights, P,
+                           out, acts, dout, dx, scratch, n_cap, n, n_ptr);
+    }
+    if ((rc = check_launch("mlp_bwd_dx"))) return rc;
+    if (dweights) {
+        DwParams D;
+        D.n_layers = P.n_layers;
+        D.has_bias = P.has_bias;
+        int quads = 0;
+        for (int l = 0; l <= P.n_layers; ++l) D.dims[l] = P.dims[l];
+        for (int l = 0; l < P.n_layers; ++l) {
+            D.w_off[l] = P.w_off[l];
+            D.b_off[l] = P.b_off[l];
+            D.quad_first[l] = quads;
+            quads += ((tiles16(P.dims[l + 1]) + 3) / 4) * ((tiles16(P.dims[l]) + 3) / 4);
+        }
+        D.quad_first[P.n_layers] = quads;
+        int64_t slabs = ceil_div<int64_t>(n, 2048);  // >= 512 four-sample steps per wave before the atomics
+        if (slabs > 256) slabs = 256;
+        if (slabs < 1) slabs = 1;
+        hipLaunchKernelGGL(mlp_bwd_dw_kernel, dim3((unsigned)slabs, (unsigned)quads), dim3(256), 0, as_stream(stream), x, acts,
+                           scratch, D, dweights, dbiases, n_cap, n, n_ptr);
+        if ((rc = check_launch("mlp_bwd_dw"))) return rc;
+    }
+    return ARCN_OK;
+}

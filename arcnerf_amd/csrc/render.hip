@@ -1,0 +1,425 @@
+// Alpha compositing (transmittance scan + weighted sums) and inverse-CDF resampling for gfx950.
+//
+// Replaces arcnerf/render/ray_helper.py:476-620 (ray_marching, alpha_to_weights) and :432-473 (sample_cdf).
+// One 64-lane wavefront owns one ray: samples are consumed 64 at a time, the transmittance
+// T_i = prod_{k<i}(1 - alpha_k + 1e-10) is a wave-level prefix product carried across chunks, the per-ray sums are
+// wave reductions.  The backward needs TRUE suffix sums (a total-minus-prefix form cancels catastrophically when
+// some q_k ~ 1e-10), so it walks the chunks in reverse using per-chunk carries kept in LDS.
+//
+// HBM traffic (algorithmic): fwd 20 B/sample in (sigma, rgb, z) + 20 B/ray out; bwd +16 B/sample out.
+#include "common.hpp"
+
+namespace arcn {
+
+constexpr int kRaysPerBlock = 4;  // 4 waves / 256 threads
+constexpr int kMaxChunks = 64;    // <= 4096 visited columns per ray
+
+// ---- sample views ------------------------------------------------------------------------------
+// A view exposes, for ray r, ncol(r) visited columns; column k maps to a stored sample and a delta rule.
+
+// The reference's dense (R,P) tensors.
+struct DenseView {
+    const float *sigma, *alpha_in, *radiance, *zvals, *noise;
+    int P, Pe;
+    __device__ void patch(const int32_t *) {}
+    __device__ int ncol(int64_t) const { return Pe; }
+    __device__ bool final_visited(int64_t) const { return true; }  // column Pe-1 is always visited
+    __device__ bool real(int64_t, int) const { return true; }
+    __device__ int64_t sidx(int64_t r, int k) const { return r * P + k; }
+    __device__ int64_t nidx(int64_t r, int k) const { return r * Pe + k; }
+    __device__ float delta(int64_t r, int k, bool &neg) const {
+        if (k < P - 1) {
+            float d = zvals[r * P + k + 1] - zvals[r * P + k];
+            if (fabsf(d) < 1e-5f) d = 0.0f;
+            if (d < 0.f) neg = true;
+            return d;
+        }
+        return 1e10f;
+    }
+    __device__ float z(int64_t r, int k) const { return zvals[r * P + k]; }
+};
+
+// Packed (offsets, t) form reproducing the reference's padded dense (R, P_dense) tensors: valid samples first, the
+// tail duplicates the last valid sample (fg_model.py:311-316) so its deltas are 0 and it carries no weight.  Only the
+// columns that can carry weight are visited: 0..min(n,Pe)-1 and, with add_inf_z and n < P_dense, the final 1e10
+// column (a virtual column aliasing sample n-1).
+struct PackedView {
+    const float *sigma, *alpha_in, *radiance, *zvals, *noise;
+    const int32_t *offsets;
+    int P_dense, Pe, add_inf_z;
+    __device__ void patch(const int32_t *p_dense_ptr) {
+        if (p_dense_ptr) {
+            int pd = *p_dense_ptr;
+            P_dense = pd < 2 ? 2 : pd;
+            Pe = add_inf_z ? P_dense : P_dense - 1;
+        }
+    }
+    __device__ int count(int64_t r) const { return offsets[r + 1] - offsets[r]; }
+    __device__ int ncol(int64_t r) const {
+        int n = count(r);
+        if (n <= 0) return 0;
+        int ne = n < Pe ? n : Pe;
+        return ne + ((add_inf_z && n < P_dense) ? 1 : 0);
+    }
+    __device__ bool final_visited(int64_t r) const { return add_inf_z ? true : (count(r) >= Pe); }
+    __device__ bool real(int64_t r, int k) const { return k < count(r); }
+    __device__ int64_t sidx(int64_t r, int k) const {
+        int n = count(r);
+        return (int64_t)offsets[r] + (k < n ? k : n - 1);
+    }
+    __device__ int64_t nidx(int64_t r, int k) const { return sidx(r, k); }
+    __device__ float delta(int64_t r, int k, bool &neg) const {
+        int n = count(r);
+        if (k >= n) return 1e10f;  // virtual final column
+        if (k == n - 1) return (add_inf_z && n == P_dense) ? 1e10f : 0.0f;
+        int64_t b = (int64_t)offsets[r] + k;
+        float d = zvals[b + 1] - zvals[b];
+        if (fabsf(d) < 1e-5f) d = 0.0f;
+        if (d < 0.f) neg = true;
+        return d;
+    }
+    __device__ float z(int64_t r, int k) const { return zvals[sidx(r, k)]; }
+};
+
+template <typename View>
+__device__ __forceinline__ float alpha_at(const View &v, int64_t r, int k, float delta, float *sig_eff) {
+    if (v.alpha_in) {
+        *sig_eff = 0.f;
+        return v.alpha_in[v.sidx(r, k)];
+    }
+    float s = v.sigma[v.sidx(r, k)];
+    if (v.noise) s = s + v.noise[v.nidx(r, k)];
+    *sig_eff = s;
+    float sr = s > 0.f ? s : 0.f;
+    return 1.0f - expf(-sr * delta);
+}
+
+template <typename View>
+__global__ void __launch_bounds__(256)
+composite_fwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict__ bkg, int64_t bkg_rows, int64_t R,
+                     int white_bkg, float *__restrict__ rgb, float *__restrict__ depth, float *__restrict__ mask,
+                     float *__restrict__ alpha_out, float *__restrict__ trans_out, float *__restrict__ weights_out,
+                     int32_t *status) {
+    v.patch(p_dense_ptr);
+    const int lane = lane_id();
+    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int nc = v.ncol(r);
+    float carry = 1.0f;
+    float acc_d = 0.f, acc_m = 0.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, t_last = 0.f;
+    bool neg = false;
+    for (int base = 0; base < nc; base += 64) {
+        const int k = base + lane;
+        const bool on = k < nc;
+        float a = 0.f, q = 1.f, zz = 0.f, se;
+        if (on) {
+            float dl = v.delta(r, k, neg);
+            a = alpha_at(v, r, k, dl, &se);
+            q = (1.0f - a) + 1e-10f;
+            zz = v.z(r, k);
+        }
+        float incl = wave_incl_prod(q);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        float T = carry * excl;
+        float w = a * T;
+        if (on) {
+            if (v.real(r, k)) {
+                if (alpha_out) alpha_out[v.nidx(r, k)] = a;
+                if (trans_out) trans_out[v.nidx(r, k)] = T;
+                if (weights_out) weights_out[v.nidx(r, k)] = w;
+            }
+            acc_d += w * zz;
+            acc_m += w;
+            if (v.radiance) {
+                const float *c = v.radiance + v.sidx(r, k) * 3;
+                acc_r += w * c[0];
+                acc_g += w * c[1];
+                acc_b += w * c[2];
+            }
+            if (k == nc - 1) t_last = T;
+        }
+        carry = carry * __shfl(incl, 63, 64);
+    }
+    acc_d = wave_sum(acc_d);
+    acc_m = wave_sum(acc_m);
+    acc_r = wave_sum(acc_r);
+    acc_g = wave_sum(acc_g);
+    acc_b = wave_sum(acc_b);
+    t_last = wave_sum(t_last);
+    // trans_shift[:, -1]: T at column Pe-1.  If that column is not among the visited ones every column after the
+    // visited ones has q == 1 (in fp32), so it equals the running product.
+    if (!(nc > 0 && v.final_visited(r))) t_last = carry;
+    if (neg && status && lane == 0) atomicOr(status, 1);
+    if (lane == 0) {
+        if (depth) depth[r] = acc_d;
+        if (mask) mask[r] = acc_m;
+        if (rgb && v.radiance) {
+            float o[3] = {acc_r, acc_g, acc_b};
+            for (int c = 0; c < 3; ++c) {
+                float x = o[c];
+                if (bkg && bkg_rows > 0) x = x + t_last * bkg[(bkg_rows == 1 ? 0 : r) * 3 + c];
+                else if (white_bkg) x = x + (1.0f - acc_m);
+                rgb[r * 3 + c] = x;
+            }
+        }
+    }
+}
+
+// d_geo / d_radiance are indexed like sigma / radiance.  Entries no visited column covers must be zeroed by the host
+// wrapper (dense: dropped last column; packed: sample n-1 of the longest rays).
+template <typename View>
+__global__ void __launch_bounds__(256)
+composite_bwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict__ bkg, int64_t bkg_rows, int64_t R,
+                     int white_bkg, const float *__restrict__ d_rgb, const float *__restrict__ d_depth,
+                     const float *__restrict__ d_mask, float *__restrict__ d_geo, float *__restrict__ d_radiance) {
+    __shared__ float s_carry[kRaysPerBlock][kMaxChunks];
+    v.patch(p_dense_ptr);
+    const int lane = lane_id();
+    const int wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+    if (r >= R) return;
+    const int nc = v.ncol(r);
+    const int nchunk = (nc + 63) >> 6;
+    bool neg = false;
+    // pass 1: transmittance at every chunk start
+    float carry = 1.0f;
+    for (int c = 0; c < nchunk; ++c) {
+        if (lane == 0) s_carry[wv][c] = carry;
+        const int k = c * 64 + lane;
+        float q = 1.f, se;
+        if (k < nc) {
+            float dl = v.delta(r, k, neg);
+            float a = alpha_at(v, r, k, dl, &se);
+            q = (1.0f - a) + 1e-10f;
+        }
+        float incl = wave_incl_prod(q);
+        carry = carry * __shfl(incl, 63, 64);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float g0 = d_rgb ? d_rgb[3 * r] : 0.f, g1 = d_rgb ? d_rgb[3 * r + 1] : 0.f, g2 = d_rgb ? d_rgb[3 * r + 2] : 0.f;
+    const float gd = d_depth ? d_depth[r] : 0.f;
+    float gm = d_mask ? d_mask[r] : 0.f;
+    const bool use_bkg = bkg && bkg_rows > 0 && v.radiance;
+    if (!use_bkg && white_bkg && v.radiance) gm = gm - (g0 + g1 + g2);
+    float B = 0.f;  // dL/dT_last
+    if (use_bkg) {
+        const float *bk = bkg + (bkg_rows == 1 ? 0 : r) * 3;
+        B = g0 * bk[0] + g1 * bk[1] + g2 * bk[2];
+    }
+    const bool final_visited = nc > 0 && v.final_visited(r);
+    // pass 2: reverse walk.  suffix_i = sum_{j>i} w_j g_j + (T_last*B if T_last depends on alpha_i)
+    float suffix_carry = 0.f;
+    float virt_dgeo = 0.f, virt_w = 0.f;
+    bool has_virt = false;
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const int k = c * 64 + lane;
+        const bool on = k < nc;
+        float a = 0.f, q = 1.f, dl = 0.f, se = 0.f, gi = 0.f;
+        if (on) {
+            dl = v.delta(r, k, neg);
+            a = alpha_at(v, r, k, dl, &se);
+            q = (1.0f - a) + 1e-10f;
+            gi = gd * v.z(r, k) + gm;
+            if (v.radiance) {
+                const float *cc = v.radiance + v.sidx(r, k) * 3;
+                gi += g0 * cc[0] + g1 * cc[1] + g2 * cc[2];
+            }
+        }
+        float incl = wave_incl_prod(q);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        float T = s_carry[wv][c] * excl;
+        float w = a * T;
+        float term = on ? w * gi : 0.f;
+        // when column Pe-1 is visited, T_last = T at that column: it depends on every earlier alpha only
+        if (on && k == nc - 1 && final_visited) term += T * B;
+        float sfx_incl = wave_incl_suffix_sum(term);
+        float sfx_excl = __shfl_down(sfx_incl, 1, 64);
+        if (lane == 63) sfx_excl = 0.f;
+        float suffix = sfx_excl + suffix_carry;
+        // otherwise T_last is the product over ALL visited q (== carry) and depends on every visited alpha
+        if (!final_visited) suffix += carry * B;
+        if (on) {
+            float dalpha = T * gi - suffix / q;
+            float dgeo;
+            if (v.alpha_in) dgeo = dalpha;
+            else dgeo = se > 0.f ? dalpha * dl * expf(-se * dl) : 0.f;
+            if (v.real(r, k)) {
+                int64_t si = v.sidx(r, k);
+                d_geo[si] = dgeo;
+                if (d_radiance) {
+                    d_radiance[si * 3 + 0] = w * g0;
+                    d_radiance[si * 3 + 1] = w * g1;
+                    d_radiance[si * 3 + 2] = w * g2;
+                }
+            } else {
+                has_virt = true;
+                virt_dgeo = dgeo;
+                virt_w = w;
+            }
+        }
+        suffix_carry += __shfl(sfx_incl, 0, 64);
+    }
+    // the virtual final column aliases sample n-1, whose own column (delta 0) was stored by another lane of this
+    // wave: accumulate after those stores have been issued and completed.
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    if (has_virt) {
+        int64_t si = v.sidx(r, nc - 1);
+        atomicAdd(&d_geo[si], virt_dgeo);
+        if (d_radiance) {
+            atomicAdd(&d_radiance[si * 3 + 0], virt_w * g0);
+            atomicAdd(&d_radiance[si * 3 + 1], virt_w * g1);
+            atomicAdd(&d_radiance[si * 3 + 2], virt_w * g2);
+        }
+    }
+}
+
+// zero d_sigma/d_radiance of the last sample of rays whose last sample is the dropped column (n == P_dense, no inf z)
+__global__ void packed_zero_dropped_kernel(const int32_t *offsets, int p_dense, const int32_t *p_dense_ptr, int64_t R,
+                                           float *d_sigma, float *d_radiance) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    int pd = p_dense_ptr ? *p_dense_ptr : p_dense;
+    if (pd < 2) pd = 2;
+    int n = offsets[r + 1] - offsets[r];
+    if (n >= pd && n > 0) {
+        int64_t si = (int64_t)offsets[r] + n - 1;
+        d_sigma[si] = 0.f;
+        if (d_radiance) { d_radiance[si * 3] = 0.f; d_radiance[si * 3 + 1] = 0.f; d_radiance[si * 3 + 2] = 0.f; }
+    }
+}
+
+// ---- inverse CDF resampling ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+sample_cdf_kernel(const float *__restrict__ bins, const float *__restrict__ cdf, const float *__restrict__ u, int n_pts,
+                  int n_sample, int n_pad, float eps, int do_sort, float *__restrict__ samples,
+                  int32_t *__restrict__ inds) {
+    extern __shared__ __attribute__((aligned(16))) float s_val[];
+    const int64_t r = blockIdx.x;
+    const float *b = bins + r * n_pts, *c = cdf + r * n_pts;
+    for (int k = threadIdx.x; k < n_pad; k += blockDim.x) {
+        float out = INFINITY;
+        if (k < n_sample) {
+            float uu = u[r * n_sample + k];
+            int lo = 0, hi = n_pts;  // searchsorted(right=True): first index with cdf > u
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (c[mid] <= uu) lo = mid + 1; else hi = mid;
+            }
+            if (inds) inds[r * n_sample + k] = lo;
+            int below = lo - 1 < 0 ? 0 : (lo - 1 > n_pts - 1 ? n_pts - 1 : lo - 1);
+            int above = lo > n_pts - 1 ? n_pts - 1 : lo;
+            float denom = c[above] - c[below];
+            if (denom < eps) denom = 1.0f;
+            float t = (uu - c[below]) / denom;
+            out = b[below] + t * (b[above] - b[below]);
+        }
+        s_val[k] = out;
+    }
+    __syncthreads();
+    if (do_sort) {  // bitonic sort of the padded row in LDS
+        for (int size = 2; size <= n_pad; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int i = threadIdx.x; i < n_pad; i += blockDim.x) {
+                    int j = i ^ stride;
+                    if (j > i) {
+                        bool up = (i & size) == 0;
+                        float x = s_val[i], y = s_val[j];
+                        if ((x > y) == up) { s_val[i] = y; s_val[j] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    for (int k = threadIdx.x; k < n_sample; k += blockDim.x) samples[r * n_sample + k] = s_val[k];
+}
+
+}  // namespace arcn
+
+using namespace arcn;
+
+ARCN_EXPORT int arcn_ray_marching_fwd(const float *sigma, const float *alpha_in, const float *radiance,
+                                      const float *zvals, const float *noise, const float *bkg, int64_t bkg_rows,
+                                      int64_t R, int P, int add_inf_z, int white_bkg, float *rgb, float *depth,
+                                      float *mask, float *alpha_out, float *trans_out, float *weights_out,
+                                      int32_t *status, void *stream) {
+    if (R <= 0) return ARCN_OK;
+    if ((!sigma && !alpha_in) || !zvals || P < 1) return einval("ray_marching_fwd: sigma/alpha and zvals required");
+    if (!(bkg_rows == 0 || bkg_rows == 1 || bkg_rows == R)) return einval("ray_marching_fwd: bkg rows must be 0/1/R");
+    DenseView v{sigma, alpha_in, radiance, zvals, noise, P, (add_inf_z || alpha_in) ? P : P - 1};
+    dim3 grid((unsigned)ceil_div<int64_t>(R, kRaysPerBlock));
+    hipLaunchKernelGGL(composite_fwd_kernel<DenseView>, grid, dim3(256), 0, as_stream(stream), v, nullptr, bkg, bkg_rows,
+                       R, white_bkg, rgb, depth, mask, alpha_out, trans_out, weights_out, status);
+    return check_launch("ray_marching_fwd");
+}
+
+ARCN_EXPORT int arcn_ray_marching_bwd(const float *sigma, const float *alpha_in, const float *radiance,
+                                      const float *zvals, const float *noise, const float *bkg, int64_t bkg_rows,
+                                      int64_t R, int P, int add_inf_z, int white_bkg, const float *d_rgb,
+                                      const float *d_depth, const float *d_mask, float *d_geo, float *d_radiance,
+                                      void *stream) {
+    if (R <= 0) return ARCN_OK;
+    if ((!sigma && !alpha_in) || !zvals || !d_geo || P < 1) return einval("ray_marching_bwd: missing argument");
+    const int Pe = (add_inf_z || alpha_in) ? P : P - 1;
+    if (Pe > 64 * kMaxChunks) return einval("ray_marching_bwd: at most 4096 samples per ray");
+    if (Pe < P) {  // the dropped last column receives zero gradient
+        if (hipMemsetAsync(d_geo, 0, sizeof(float) * R * P, as_stream(stream)) != hipSuccess) return check_launch("memset");
+        if (d_radiance && hipMemsetAsync(d_radiance, 0, sizeof(float) * R * P * 3, as_stream(stream)) != hipSuccess)
+            return check_launch("memset");
+    }
+    DenseView v{sigma, alpha_in, radiance, zvals, noise, P, Pe};
+    dim3 grid((unsigned)ceil_div<int64_t>(R, kRaysPerBlock));
+    hipLaunchKernelGGL(composite_bwd_kernel<DenseView>, grid, dim3(256), 0, as_stream(stream), v, nullptr, bkg, bkg_rows,
+                       R, white_bkg, d_rgb, d_depth, d_mask, d_geo, d_radiance);
+    return check_launch("ray_marching_bwd");
+}
+
+ARCN_EXPORT int arcn_composite_packed_fwd(const float *sigma, const float *radiance, const float *t_packed,
+                                          const int32_t *offsets, const float *noise, const float *bkg,
+                                          int64_t bkg_rows, int64_t R, int p_dense, const int32_t *p_dense_ptr,
+                                          int add_inf_z, int white_bkg, float *rgb, float *depth, float *mask,
+                                          float *weights_out, void *stream) {
+    if (R <= 0) return ARCN_OK;
+    if (!sigma || !t_packed || !offsets) return einval("composite_packed_fwd: missing argument");
+    if (!(bkg_rows == 0 || bkg_rows == 1 || bkg_rows == R)) return einval("composite_packed_fwd: bkg rows must be 0/1/R");
+    if (p_dense < 2) p_dense = 2;
+    PackedView v{sigma, nullptr, radiance, t_packed, noise, offsets, p_dense, add_inf_z ? p_dense : p_dense - 1, add_inf_z};
+    dim3 grid((unsigned)ceil_div<int64_t>(R, kRaysPerBlock));
+    hipLaunchKernelGGL(composite_fwd_kernel<PackedView>, grid, dim3(256), 0, as_stream(stream), v, p_dense_ptr, bkg,
+                       bkg_rows, R, white_bkg, rgb, depth, mask, nullptr, nullptr, weights_out, nullptr);
+    return check_launch("composite_packed_fwd");
+}
+
+ARCN_EXPORT int arcn_composite_packed_bwd(const float *sigma, const float *radiance, const float *t_packed,
+                                          const int32_t *offsets, const float *noise, const float *bkg,
+                                          int64_t bkg_rows, int64_t R, int p_dense, const int32_t *p_dense_ptr,
+                                          int add_inf_z, int white_bkg, const float *d_rgb, const float *d_depth,
+                                          const float *d_mask, float *d_sigma, float *d_radiance, void *stream) {
+    if (R <= 0) return ARCN_OK;
+    if (!sigma || !t_packed || !offsets || !d_sigma) return einval("composite_packed_bwd: missing argument");
+    if (p_dense < 2) p_dense = 2;
+    if (!add_inf_z) {
+        hipLaunchKernelGGL(packed_zero_dropped_kernel, dim3((unsigned)ceil_div<int64_t>(R, 256)), dim3(256), 0,
+                           as_stream(stream), offsets, p_dense, p_dense_ptr, R, d_sigma, d_radiance);
+    }
+    PackedView v{sigma, nullptr, radiance, t_packed, noise, offsets, p_dense, add_inf_z ? p_dense : p_dense - 1, add_inf_z};
+    dim3 grid((unsigned)ceil_div<int64_t>(R, kRaysPerBlock));
+    hipLaunchKernelGGL(composite_bwd_kernel<PackedView>, grid, dim3(256), 0, as_stream(stream), v, p_dense_ptr, bkg,
+                       bkg_rows, R, white_bkg, d_rgb, d_depth, d_mask, d_sigma, d_radiance);
+    return check_launch("composite_packed_bwd");
+}
+
+ARCN_EXPORT int arcn_sample_cdf(const float *bins, const float *cdf, const float *u, int64_t R, int n_pts, int n_sample,
+                                float eps, int do_sort, float *samples, int32_t *inds, void *stream) {
+    if (R <= 0 || n_sample <= 0) return ARCN_OK;
+    if (!bins || !cdf || !u || !samples || n_pts < 1) return einval("sample_cdf: missing argument");
+    int n_pad = 1;
+    while (n_pad < n_sample) n_pad <<= 1;
+    if (n_pad > 16384) return einval("sample_cdf: n_sample too large");
+    hipLaunchKernelGGL(sample_cdf_kernel, dim3((unsigned)R), dim3(256), sizeof(float) * n_pad, as_stream(stream), bins, cdf,
+                       u, n_pts, n_sample, n_pad, eps, do_sort, samples, inds);
+    return check_launch("sample_cdf");
+}

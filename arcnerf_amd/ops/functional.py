@@ -1,0 +1,406 @@
+"""Thin torch-tensor front-end of the C ABI (include/arcnerf_hip.h).  No autograd here (see ops/autograd.py).
+
+torch is used for device memory and the current HIP stream only; every numerical operation is a hand-written
+gfx950 kernel in libarcnerf_hip.so.  All functions require CUDA(HIP) tensors and raise RuntimeError otherwise —
+there is deliberately no CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _native as N
+
+
+def _req(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('arcnerf_amd ops run on the GPU only (got a {} tensor); there is no CPU fallback'.format(t.device))
+
+
+def _f32(t):
+    return None if t is None else t.contiguous().float()
+
+
+def _nptr(n_dev):
+    """optional device-side element count (int32 tensor with one element)"""
+    if n_dev is None:
+        return None
+    assert n_dev.dtype == torch.int32 and n_dev.is_cuda
+    return n_dev.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+# _volume_func
+# ------------------------------------------------------------------------------------------------
+def check_pts_in_occ_voxel(xyz, bitfield, aabb23, n_grid):
+    _req(xyz, bitfield, aabb23)
+    xyz = _f32(xyz)
+    bf = bitfield.contiguous().view(torch.uint8)
+    aabb = _f32(aabb23)
+    out = torch.zeros(xyz.shape[0], dtype=torch.bool, device=xyz.device)
+    N.check(N.lib().arcn_check_pts_in_occ_voxel(N.ptr(xyz), N.ptr(bf), N.ptr(aabb), int(n_grid), out.data_ptr(),
+                                               xyz.shape[0], N.stream()), 'check_pts_in_occ_voxel')
+    return out
+
+
+def aabb_intersection(rays_o, rays_d, aabb_v23, want_pts=True):
+    """K2 semantics, aabb (V,2,3)."""
+    _req(rays_o, rays_d, aabb_v23)
+    o, d, bb = _f32(rays_o), _f32(rays_d), _f32(aabb_v23)
+    R, V = o.shape[0], bb.shape[0]
+    near = torch.zeros((R, V), dtype=torch.float32, device=o.device)
+    far = torch.zeros((R, V), dtype=torch.float32, device=o.device)
+    pts = torch.zeros((R, V, 2, 3), dtype=torch.float32, device=o.device) if want_pts else None
+    mask = torch.zeros((R, V), dtype=torch.bool, device=o.device)
+    N.check(N.lib().arcn_aabb_intersection(N.ptr(o), N.ptr(d), N.ptr(bb), N.ptr(near), N.ptr(far), N.ptr(pts),
+                                          mask.data_ptr(), R, V, N.stream()), 'aabb_intersection')
+    return near, far, pts, mask
+
+
+def aabb_intersection_torch(rays_o, rays_d, aabb_v32, eps=1e-7, want_pts=True):
+    """torch-path semantics of geometry/ray.py:295-339, aabb (V,3,2)."""
+    _req(rays_o, rays_d, aabb_v32)
+    o, d, bb = _f32(rays_o), _f32(rays_d), _f32(aabb_v32)
+    R, V = o.shape[0], bb.shape[0]
+    near = torch.zeros((R, V), dtype=torch.float32, device=o.device)
+    far = torch.zeros((R, V), dtype=torch.float32, device=o.device)
+    pts = torch.zeros((R, V, 2, 3), dtype=torch.float32, device=o.device) if want_pts else None
+    mask = torch.zeros((R, V), dtype=torch.bool, device=o.device)
+    N.check(N.lib().arcn_aabb_intersection_torch(N.ptr(o), N.ptr(d), N.ptr(bb), float(eps), N.ptr(near), N.ptr(far),
+                                                N.ptr(pts), mask.data_ptr(), R, V, N.stream()), 'aabb_intersection_torch')
+    return near, far, pts, mask
+
+
+def sparse_volume_sampling(rays_o, rays_d, near, far, n_pts, dt, aabb23, n_grid, bitfield, near_distance, rng_state,
+                           rng_inc, want_counts=False):
+    _req(rays_o, rays_d, near, far, aabb23, bitfield)
+    o, d = _f32(rays_o), _f32(rays_d)
+    nr, fr = _f32(near).view(-1), _f32(far).view(-1)
+    aabb = _f32(aabb23)
+    bf = bitfield.contiguous().view(torch.uint8)
+    R = o.shape[0]
+    zvals = torch.zeros((R, n_pts), dtype=torch.float32, device=o.device)
+    mask = torch.zeros((R, n_pts), dtype=torch.bool, device=o.device)
+    counts = torch.zeros(R, dtype=torch.int32, device=o.device) if want_counts else None
+    N.check(N.lib().arcn_sparse_volume_sampling(N.ptr(o), N.ptr(d), N.ptr(nr), N.ptr(fr), int(n_pts), float(dt),
+                                               N.ptr(aabb), int(n_grid), N.ptr(bf), float(near_distance),
+                                               int(rng_state), int(rng_inc), N.ptr(zvals), mask.data_ptr(),
+                                               N.ptr(counts), R, N.stream()), 'sparse_volume_sampling')
+    return (zvals, mask, counts) if want_counts else (zvals, mask)
+
+
+def tensor_reduce_max(full, idx, n_group):
+    _req(full, idx)
+    full = _f32(full)
+    idx = idx.contiguous().long()
+    out = torch.zeros(n_group, dtype=torch.float32, device=full.device)
+    N.check(N.lib().arcn_tensor_reduce_max(N.ptr(full), N.ptr(idx), int(n_group), N.ptr(out), full.shape[0], N.stream()),
+            'tensor_reduce_max')
+    return out
+
+
+class Pcg32Host:
+    """The explicit (seed, call counter) replacement of the reference's file-static `pcg32 rng{9121}`
+    (arcnerf/ops/include/common.h:22-23): state before launch k is seed-state advanced k * 2^32."""
+
+    def __init__(self, seed=9121, seq=1):
+        self._si = (C.c_uint64 * 2)()
+        N.lib().arcn_pcg32_seed(seed, seq, C.addressof(self._si))
+
+    @property
+    def state(self):
+        return int(self._si[0])
+
+    @property
+    def inc(self):
+        return int(self._si[1])
+
+    def advance(self, delta=1 << 32):
+        N.lib().arcn_pcg32_advance(C.addressof(self._si), delta)
+
+
+# ------------------------------------------------------------------------------------------------
+# compacted sampler
+# ------------------------------------------------------------------------------------------------
+def march_packed(rays_o, rays_d, aabb23, n_grid, bitfield, n_pts, dt, near_distance, rng_state, rng_inc,
+                 packed_bits=False, torch_aabb=False, capacity=None, scratch=None):
+    """Bounds + occupancy marching in packed form.
+
+    Returns dict(t (cap,), ray_id (cap,), offsets (R+1,) int32 with offsets[R] = total, counts (R,), near, far).
+    No host synchronisation: `total` stays on the device (offsets[-1]); capacity defaults to R*n_pts.
+    """
+    _req(rays_o, rays_d, aabb23, bitfield)
+    o, d = _f32(rays_o), _f32(rays_d)
+    aabb = _f32(aabb23)
+    bf = bitfield.contiguous().view(torch.uint8)
+    R = o.shape[0]
+    dev = o.device
+    if scratch is None:
+        scratch = torch.empty((R, n_pts), dtype=torch.float32, device=dev)
+    counts = torch.empty(R, dtype=torch.int32, device=dev)
+    near = torch.empty(R, dtype=torch.float32, device=dev)
+    far = torch.empty(R, dtype=torch.float32, device=dev)
+    offsets = torch.empty(R + 1, dtype=torch.int32, device=dev)
+    L = N.lib()
+    N.check(L.arcn_march_count(N.ptr(o), N.ptr(d), N.ptr(aabb), int(n_grid), N.ptr(bf), int(packed_bits), int(n_pts),
+                               float(dt), float(near_distance), int(torch_aabb), int(rng_state), int(rng_inc),
+                               N.ptr(scratch), N.ptr(counts), N.ptr(near), N.ptr(far), R, N.stream()), 'march_count')
+    N.check(L.arcn_exclusive_scan_i32(N.ptr(counts), N.ptr(offsets), R, N.stream()), 'exclusive_scan_i32')
+    if capacity is None:
+        capacity = R * n_pts
+    t = torch.empty(capacity, dtype=torch.float32, device=dev)
+    ray_id = torch.empty(capacity, dtype=torch.int32, device=dev)
+    N.check(L.arcn_march_write(N.ptr(scratch), N.ptr(counts), N.ptr(offsets), int(n_pts), N.ptr(t), N.ptr(ray_id), R,
+                               capacity, N.stream()), 'march_write')
+    return {'t': t, 'ray_id': ray_id, 'offsets': offsets, 'counts': counts, 'near': near, 'far': far}
+
+
+def packed_points(rays_o, rays_d, t, ray_id, n=None, n_dev=None, want_dirs=True):
+    _req(rays_o, rays_d, t, ray_id)
+    o, d = _f32(rays_o), _f32(rays_d)
+    n = t.shape[0] if n is None else int(n)
+    xyz = torch.empty((n, 3), dtype=torch.float32, device=o.device)
+    dirs = torch.empty((n, 3), dtype=torch.float32, device=o.device) if want_dirs else None
+    N.check(N.lib().arcn_packed_points(N.ptr(o), N.ptr(d), N.ptr(t), N.ptr(ray_id), N.ptr(xyz), N.ptr(dirs), n,
+                                      _nptr(n_dev), N.stream()), 'packed_points')
+    return xyz, dirs
+
+
+# ------------------------------------------------------------------------------------------------
+# encoders
+# ------------------------------------------------------------------------------------------------
+def hashgrid_fwd(xyz, table, desc, want_idx=False, n_dev=None, out=None):
+    _req(xyz, table)
+    xyz, table = _f32(xyz), _f32(table)
+    n = xyz.shape[0]
+    LF = desc.n_levels * desc.n_feat
+    if out is None:
+        out = torch.empty((n, LF), dtype=torch.float32, device=xyz.device)
+    idx = torch.empty((n, desc.n_levels, 8), dtype=torch.int32, device=xyz.device) if want_idx else None
+    N.check(N.lib().arcn_hashgrid_fwd(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(out), N.ptr(idx), n, _nptr(n_dev),
+                                     N.stream()), 'hashgrid_fwd')
+    return (out, idx) if want_idx else out
+
+
+def hashgrid_bwd(xyz, table, dout, desc, want_dtable=True, want_dxyz=False, n_dev=None, dtable=None):
+    _req(xyz, table, dout)
+    xyz, table, dout = _f32(xyz), _f32(table), _f32(dout)
+    n = xyz.shape[0]
+    if want_dtable and dtable is None:
+        dtable = torch.zeros_like(table)
+    dxyz = torch.zeros((n, 3), dtype=torch.float32, device=xyz.device) if want_dxyz else None
+    N.check(N.lib().arcn_hashgrid_bwd(N.ptr(xyz), N.ptr(table), N.ptr(dout), C.addressof(desc),
+                                     N.ptr(dtable) if want_dtable else None, N.ptr(dxyz), n, _nptr(n_dev), N.stream()),
+            'hashgrid_bwd')
+    return dtable, dxyz
+
+
+def freq_fwd(x, n_freqs, include_input=True):
+    _req(x)
+    x = _f32(x)
+    n, D = x.shape
+    out = torch.empty((n, D * (1 if include_input else 0) + 2 * D * n_freqs), dtype=torch.float32, device=x.device)
+    N.check(N.lib().arcn_freq_fwd(N.ptr(x), D, int(n_freqs), int(include_input), N.ptr(out), n, N.stream()), 'freq_fwd')
+    return out
+
+
+def freq_bwd(x, dout, n_freqs, include_input=True):
+    _req(x, dout)
+    x, dout = _f32(x), _f32(dout)
+    n, D = x.shape
+    dx = torch.empty_like(x)
+    N.check(N.lib().arcn_freq_bwd(N.ptr(x), N.ptr(dout), D, int(n_freqs), int(include_input), N.ptr(dx), n, N.stream()),
+            'freq_bwd')
+    return dx
+
+
+def sh_fwd(dirs, degree, include_input=False):
+    _req(dirs)
+    dirs = _f32(dirs)
+    n = dirs.shape[0]
+    out = torch.empty((n, degree * degree + (3 if include_input else 0)), dtype=torch.float32, device=dirs.device)
+    N.check(N.lib().arcn_sh_fwd(N.ptr(dirs), int(degree), int(include_input), N.ptr(out), n, N.stream()), 'sh_fwd')
+    return out
+
+
+def act_fwd(x, act, beta=1.0):
+    _req(x)
+    x = _f32(x)
+    y = torch.empty_like(x)
+    N.check(N.lib().arcn_act_fwd(N.ptr(x), N.ptr(y), x.numel(), N.ACT[act], float(beta), N.stream()), 'act_fwd')
+    return y
+
+
+def act_bwd(x, y, dy, act, beta=1.0):
+    _req(x, dy)
+    x, y, dy = _f32(x), _f32(y), _f32(dy)
+    dx = torch.empty_like(x)
+    N.check(N.lib().arcn_act_bwd(N.ptr(x), N.ptr(y), N.ptr(dy), N.ptr(dx), x.numel(), N.ACT[act], float(beta), N.stream()),
+            'act_bwd')
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# fused MLP
+# ------------------------------------------------------------------------------------------------
+def mlp_acts_floats(desc, n_cap):
+    return int(N.lib().arcn_mlp_acts_floats(C.addressof(desc), int(n_cap)))
+
+
+def mlp_scratch_floats(desc, n_cap):
+    return int(N.lib().arcn_mlp_scratch_floats(C.addressof(desc), int(n_cap)))
+
+
+def mlp_fwd(x, weights, biases, desc, save_acts=False, n_dev=None, out=None, acts=None):
+    """weights: flat fp32 tensor of all W_i (row-major (out,in)) concatenated; biases likewise or None."""
+    _req(x, weights, biases)
+    x = _f32(x)
+    n = x.shape[0]
+    if out is None:
+        out = torch.empty((n, desc.dims[desc.n_layers]), dtype=torch.float32, device=x.device)
+    if save_acts and acts is None:
+        acts = torch.empty(max(1, mlp_acts_floats(desc, n)), dtype=torch.float32, device=x.device)
+    N.check(N.lib().arcn_mlp_fwd(N.ptr(x), N.ptr(weights), N.ptr(biases), C.addressof(desc), N.ptr(out),
+                                N.ptr(acts) if save_acts else None, n, n, _nptr(n_dev), N.stream()), 'mlp_fwd')
+    return (out, acts) if save_acts else out
+
+
+def mlp_bwd(x, weights, biases, desc, out, acts, dout, want_dx=True, n_dev=None, dweights=None, dbiases=None, scratch=None):
+    _req(x, weights, out, dout)
+    x, dout = _f32(x), _f32(dout)
+    n = x.shape[0]
+    dx = torch.empty_like(x) if want_dx else None
+    if dweights is None:
+        dweights = torch.zeros_like(weights)
+    if biases is not None and dbiases is None:
+        dbiases = torch.zeros_like(biases)
+    if scratch is None:
+        scratch = torch.empty(mlp_scratch_floats(desc, n), dtype=torch.float32, device=x.device)
+    N.check(N.lib().arcn_mlp_bwd(N.ptr(x), N.ptr(weights), N.ptr(biases), C.addressof(desc), N.ptr(out), N.ptr(acts),
+                                N.ptr(dout), N.ptr(dx), N.ptr(dweights), N.ptr(dbiases), N.ptr(scratch), n, n,
+                                _nptr(n_dev), N.stream()), 'mlp_bwd')
+    return dx, dweights, dbiases
+
+
+# ------------------------------------------------------------------------------------------------
+# compositing
+# ------------------------------------------------------------------------------------------------
+def _bkg(bkg_color, R):
+    if bkg_color is None:
+        return None, 0
+    b = _f32(bkg_color).view(-1, 3)
+    if b.shape[0] not in (1, R):
+        raise RuntimeError('Only bkg with N_rays/1 allowed..')
+    return b, b.shape[0]
+
+
+def ray_marching_fwd(sigma, radiance, zvals, add_inf_z=False, white_bkg=False, alpha=None, bkg_color=None, noise=None,
+                     want_samples=True, check_order=True):
+    _req(sigma, radiance, zvals, alpha, bkg_color, noise)
+    z = _f32(zvals)
+    R, P = z.shape
+    sg, al, rad, ns = _f32(sigma), _f32(alpha), _f32(radiance), _f32(noise)
+    bk, bk_rows = _bkg(bkg_color, R)
+    Pe = P if (add_inf_z or al is not None) else P - 1
+    dev = z.device
+    rgb = torch.empty((R, 3), dtype=torch.float32, device=dev) if rad is not None else None
+    depth = torch.empty(R, dtype=torch.float32, device=dev)
+    mask = torch.empty(R, dtype=torch.float32, device=dev)
+    a_o = torch.empty((R, Pe), dtype=torch.float32, device=dev) if want_samples else None
+    t_o = torch.empty((R, Pe), dtype=torch.float32, device=dev) if want_samples else None
+    w_o = torch.empty((R, Pe), dtype=torch.float32, device=dev) if want_samples else None
+    status = torch.zeros(1, dtype=torch.int32, device=dev) if check_order else None
+    N.check(N.lib().arcn_ray_marching_fwd(N.ptr(sg), N.ptr(al), N.ptr(rad), N.ptr(z), N.ptr(ns), N.ptr(bk), bk_rows, R, P,
+                                         int(add_inf_z), int(white_bkg), N.ptr(rgb), N.ptr(depth), N.ptr(mask),
+                                         N.ptr(a_o), N.ptr(t_o), N.ptr(w_o), N.ptr(status), N.stream()), 'ray_marching_fwd')
+    return {'rgb': rgb, 'depth': depth, 'mask': mask, 'alpha': a_o, 'trans_shift': t_o, 'weights': w_o, 'status': status}
+
+
+def ray_marching_bwd(sigma, radiance, zvals, d_rgb, d_depth=None, d_mask=None, add_inf_z=False, white_bkg=False,
+                     alpha=None, bkg_color=None, noise=None):
+    _req(sigma, radiance, zvals, alpha, bkg_color, noise, d_rgb, d_depth, d_mask)
+    z = _f32(zvals)
+    R, P = z.shape
+    sg, al, rad, ns = _f32(sigma), _f32(alpha), _f32(radiance), _f32(noise)
+    bk, bk_rows = _bkg(bkg_color, R)
+    d_geo = torch.empty((R, P), dtype=torch.float32, device=z.device)
+    d_rad = torch.empty((R, P, 3), dtype=torch.float32, device=z.device) if rad is not None else None
+    N.check(N.lib().arcn_ray_marching_bwd(N.ptr(sg), N.ptr(al), N.ptr(rad), N.ptr(z), N.ptr(ns), N.ptr(bk), bk_rows, R, P,
+                                         int(add_inf_z), int(white_bkg), N.ptr(_f32(d_rgb)), N.ptr(_f32(d_depth)),
+                                         N.ptr(_f32(d_mask)), N.ptr(d_geo), N.ptr(d_rad), N.stream()), 'ray_marching_bwd')
+    return d_geo, d_rad
+
+
+def composite_packed_fwd(sigma, radiance, t, offsets, p_dense=2, p_dense_dev=None, add_inf_z=False, white_bkg=False,
+                         bkg_color=None, noise=None, want_weights=False):
+    _req(sigma, radiance, t, offsets, bkg_color, noise)
+    sg, rad, t, ns = _f32(sigma), _f32(radiance), _f32(t), _f32(noise)
+    R = offsets.shape[0] - 1
+    bk, bk_rows = _bkg(bkg_color, R)
+    dev = t.device
+    rgb = torch.empty((R, 3), dtype=torch.float32, device=dev) if rad is not None else None
+    depth = torch.empty(R, dtype=torch.float32, device=dev)
+    mask = torch.empty(R, dtype=torch.float32, device=dev)
+    w = torch.zeros(sg.shape[0], dtype=torch.float32, device=dev) if want_weights else None
+    N.check(N.lib().arcn_composite_packed_fwd(N.ptr(sg), N.ptr(rad), N.ptr(t), N.ptr(offsets), N.ptr(ns), N.ptr(bk), bk_rows,
+                                             R, int(p_dense), _nptr(p_dense_dev), int(add_inf_z), int(white_bkg), N.ptr(rgb),
+                                             N.ptr(depth), N.ptr(mask), N.ptr(w), N.stream()), 'composite_packed_fwd')
+    return {'rgb': rgb, 'depth': depth, 'mask': mask, 'weights': w}
+
+
+def composite_packed_bwd(sigma, radiance, t, offsets, d_rgb, d_depth=None, d_mask=None, p_dense=2, p_dense_dev=None,
+                         add_inf_z=False, white_bkg=False, bkg_color=None, noise=None):
+    _req(sigma, radiance, t, offsets, bkg_color, noise, d_rgb, d_depth, d_mask)
+    sg, rad, t, ns = _f32(sigma), _f32(radiance), _f32(t), _f32(noise)
+    R = offsets.shape[0] - 1
+    bk, bk_rows = _bkg(bkg_color, R)
+    d_sigma = torch.zeros_like(sg)
+    d_rad = torch.zeros_like(rad) if rad is not None else None
+    N.check(N.lib().arcn_composite_packed_bwd(N.ptr(sg), N.ptr(rad), N.ptr(t), N.ptr(offsets), N.ptr(ns), N.ptr(bk), bk_rows,
+                                             R, int(p_dense), _nptr(p_dense_dev), int(add_inf_z), int(white_bkg),
+                                             N.ptr(_f32(d_rgb)), N.ptr(_f32(d_depth)), N.ptr(_f32(d_mask)), N.ptr(d_sigma),
+                                             N.ptr(d_rad), N.stream()), 'composite_packed_bwd')
+    return d_sigma, d_rad
+
+
+def sample_cdf(bins, cdf, u, eps=1e-5, sort=True, want_inds=False):
+    _req(bins, cdf, u)
+    bins, cdf, u = _f32(bins), _f32(cdf), _f32(u)
+    R, n_pts = bins.shape
+    n_sample = u.shape[1]
+    samples = torch.empty((R, n_sample), dtype=torch.float32, device=bins.device)
+    inds = torch.empty((R, n_sample), dtype=torch.int32, device=bins.device) if want_inds else None
+    N.check(N.lib().arcn_sample_cdf(N.ptr(bins), N.ptr(cdf), N.ptr(u), R, n_pts, n_sample, float(eps), int(sort),
+                                   N.ptr(samples), N.ptr(inds), N.stream()), 'sample_cdf')
+    return (samples, inds) if want_inds else samples
+
+
+# ------------------------------------------------------------------------------------------------
+# occupancy update, optimiser
+# ------------------------------------------------------------------------------------------------
+def update_opafield(opafield, flat_idx, opacity, ema=None):
+    _req(opafield, flat_idx, opacity)
+    assert opafield.is_contiguous() and opafield.dtype == torch.float32
+    idx = flat_idx.contiguous().long()
+    op = _f32(opacity)
+    N.check(N.lib().arcn_update_opafield(N.ptr(opafield), N.ptr(idx), N.ptr(op), idx.shape[0],
+                                        -1.0 if ema is None else float(ema), N.stream()), 'update_opafield')
+    return opafield
+
+
+def update_bitfield_by_opafield(opafield, bitfield, threshold):
+    _req(opafield, bitfield)
+    assert opafield.is_contiguous() and bitfield.is_contiguous()
+    ws = torch.zeros(2, dtype=torch.float32, device=opafield.device)
+    N.check(N.lib().arcn_update_bitfield_by_opafield(N.ptr(opafield), bitfield.view(torch.uint8).data_ptr(), opafield.numel(),
+                                                    float(threshold), N.ptr(ws), N.stream()), 'update_bitfield_by_opafield')
+    return bitfield
+
+
+def adam_ema_step(param, grad, exp_avg, exp_avg_sq, ema, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                  ema_decay=0.95, grad_scale=1.0):
+    _req(param, grad, exp_avg, exp_avg_sq, ema)
+    N.check(N.lib().arcn_adam_ema_step(N.ptr(param), N.ptr(grad), N.ptr(exp_avg), N.ptr(exp_avg_sq), N.ptr(ema),
+                                      param.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                      float(weight_decay), float(ema_decay), float(grad_scale), int(step), N.stream()),
+            'adam_ema_step')

@@ -1,0 +1,214 @@
+/*
+ * arcnerf_hip.h — C ABI of libarcnerf_hip.so: the MI355X (gfx950) volumetric-rendering hot path of ArcNerf.
+ *
+ * Conventions:
+ *   - plain pointers + sizes, no torch types.  All pointers are DEVICE pointers unless the name ends in `_host`.
+ *   - the CALLER owns and allocates every buffer (zero-initialised where the reference's wrapper does so);
+ *     nothing here allocates, frees or synchronises the device.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Kernels are launched on it and the
+ *     call returns immediately.
+ *   - return value: 0 = ok, ARCN_EINVAL (-1) = bad argument, ARCN_ELAUNCH (-2) = hip launch error
+ *     (arcn_last_error() returns the hip error string).
+ *   - fp32 everywhere ("dtype": "f32"); contiguous row-major tensors, same shapes as the reference ops.
+ *
+ * Each entry point cites the reference interface it replaces (file:line relative to the ArcNerf repo).
+ */
+#ifndef ARCNERF_HIP_H
+#define ARCNERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARCN_OK 0
+#define ARCN_EINVAL (-1)
+#define ARCN_ELAUNCH (-2)
+
+#define ARCN_MAX_LEVELS 32
+
+/* activation codes (tcnn names in arcnerf/models/base_modules/geo_rad_model/tcnn_fusedmlp_module.py:195-213) */
+#define ARCN_ACT_NONE 0
+#define ARCN_ACT_RELU 1
+#define ARCN_ACT_SIGMOID 2
+#define ARCN_ACT_TRUNCEXP 3 /* fwd exp(x); bwd g*exp(clamp(x,-15,15))  (arcnerf/ops/trunc_exp.py:7-37) */
+#define ARCN_ACT_SOFTPLUS 4
+
+const char *arcn_last_error(void);
+int arcn_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * _volume_func (arcnerf/ops/src/volume_func/volume_func.cpp:277-282)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* K1 check_pts_in_occ_voxel (volume_func_kernel.cu:16-68). xyz (n,3); bitfield (n_grid^3) bool bytes;
+ * aabb (2,3) = xyz_min,xyz_max; out (n) bool bytes. */
+int arcn_check_pts_in_occ_voxel(const float *xyz, const uint8_t *bitfield, const float *aabb, int n_grid, uint8_t *out,
+                                int64_t n, void *stream);
+
+/* K2 aabb_intersection (volume_func_kernel.cu:74-166). rays (n_rays,3); aabb (n_v,2,3); near/far/mask (n_rays,n_v);
+ * pts (n_rays,n_v,2,3). mask = tmin > 0. */
+int arcn_aabb_intersection(const float *rays_o, const float *rays_d, const float *aabb, float *near, float *far,
+                           float *pts, uint8_t *mask, int64_t n_rays, int64_t n_v, void *stream);
+
+/* torch-path semantics of aabb_ray_intersection (arcnerf/geometry/ray.py:295-339): aabb (n_v,3,2), eps shift, rays
+ * starting inside the box are hits with near = eps. */
+int arcn_aabb_intersection_torch(const float *rays_o, const float *rays_d, const float *aabb32, float eps, float *near,
+                                 float *far, float *pts, uint8_t *mask, int64_t n_rays, int64_t n_v, void *stream);
+
+/* K3 sparse_volume_sampling (volume_func_kernel.cu:174-291). zvals/mask (n_rays,n_pts) zero-initialised by the
+ * caller.  (rng_state, rng_inc) is the host pcg32 BEFORE the call (reference: file-static `pcg32 rng{9121}`,
+ * include/common.h:22-23, advanced 2^32 after every launch); the caller owns that bookkeeping (arcn_pcg32_*).
+ * counts (n_rays) int32 optional: emitted samples per ray. */
+int arcn_sparse_volume_sampling(const float *rays_o, const float *rays_d, const float *near, const float *far, int n_pts,
+                                float dt, const float *aabb, int n_grid, const uint8_t *bitfield, float near_distance,
+                                uint64_t rng_state, uint64_t rng_inc, float *zvals, uint8_t *mask, int32_t *counts,
+                                int64_t n_rays, void *stream);
+
+/* K4 tensor_reduce_max (volume_func_kernel.cu:297-337): uni[idx[i]] = max(uni[idx[i]], full[i]) on the uint32 bit
+ * pattern (valid for non-negative floats). uni (n_group) zero-initialised by the caller. */
+int arcn_tensor_reduce_max(const float *full, const int64_t *idx, int n_group, float *uni, int64_t n, void *stream);
+
+/* host pcg32 helpers (include/pcg32.h:50-165), HOST pointers: state_inc_host[2] = {state, inc}. */
+void arcn_pcg32_seed(uint64_t initstate, uint64_t initseq, uint64_t *state_inc_host);
+void arcn_pcg32_advance(uint64_t *state_inc_host, int64_t delta);
+
+/* ------------------------------------------------------------------------------------------------
+ * Compacted sampler: the same marching as K3 fused with K2, emitting the packed form the fast path consumes.
+ *   pass 1  arcn_march_count : near/far (K2 or torch semantics) + march, counts (n_rays) int32, optional dense scratch
+ *   pass 2  arcn_exclusive_scan_i32 : offsets (n_rays+1) int32 (offsets[n_rays] = total)
+ *   pass 3  arcn_march_write : t (S) float, ray_id (S) int32 in ray-major order; dense t scratch reused.
+ * scratch_t (n_rays,n_pts) float holds the emitted t of pass 1 (no init needed).
+ * ---------------------------------------------------------------------------------------------- */
+int arcn_march_count(const float *rays_o, const float *rays_d, const float *aabb, int n_grid, const uint8_t *bitfield,
+                     int bitfield_is_packed, int n_pts, float dt, float near_distance, int aabb_torch_semantics,
+                     uint64_t rng_state, uint64_t rng_inc, float *scratch_t, int32_t *counts, float *near_out,
+                     float *far_out, int64_t n_rays, void *stream);
+int arcn_exclusive_scan_i32(const int32_t *counts, int32_t *offsets, int64_t n, void *stream);
+int arcn_march_write(const float *scratch_t, const int32_t *counts, const int32_t *offsets, int n_pts, float *t_packed,
+                     int32_t *ray_id, int64_t n_rays, int64_t capacity, void *stream);
+
+/* pts/dirs of packed samples: xyz[s] = o[ray]+d[ray]*t[s] (geometry/ray.py:11-30), dirs[s] = d[ray].
+ * n_ptr (device, optional) overrides n with *n_ptr (device-side sample count, no host sync). */
+int arcn_packed_points(const float *rays_o, const float *rays_d, const float *t_packed, const int32_t *ray_id,
+                       float *xyz, float *dirs, int64_t n, const int32_t *n_ptr, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Encoders
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_levels;
+    int32_t n_feat;                              /* F: 1, 2 or 4 */
+    int32_t resolutions[ARCN_MAX_LEVELS];        /* hashgrid_encoder.py:144-149 */
+    int64_t offsets[ARCN_MAX_LEVELS + 1];        /* cumulative rows, offsets[L] = n_total_embed */
+    float min_xyz[3];
+    float max_xyz[3];
+} arcn_hashgrid_desc;
+
+/* HashGridEmbedder.hashgrid_encode_torch (encoding/hashgrid_encoder.py:191-249 + geometry/volume.py:486-570).
+ * xyz (n,3); table (n_total,F); out (n, L*F). desc_host is a HOST pointer (copied into the launch).
+ * hash_idx (n,L,8) int32 optional debug output (-1 for out-of-volume). */
+int arcn_hashgrid_fwd(const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out,
+                      int32_t *hash_idx, int64_t n, const int32_t *n_ptr, void *stream);
+/* backward: dtable (n_total,F) accumulated with atomics (caller zeroes), dxyz (n,3) optional. */
+int arcn_hashgrid_bwd(const float *xyz, const float *table, const float *dout, const arcn_hashgrid_desc *desc_host,
+                      float *dtable, float *dxyz, int64_t n, const int32_t *n_ptr, void *stream);
+
+/* FreqEmbedder.forward (encoding/freq_encoder.py:65-88): out (n, D*(include_input + 2*n_freqs)). */
+int arcn_freq_fwd(const float *x, int D, int n_freqs, int include_input, float *out, int64_t n, void *stream);
+int arcn_freq_bwd(const float *x, const float *dout, int D, int n_freqs, int include_input, float *dx, int64_t n,
+                  void *stream);
+/* SHEmbedder torch branch (encoding/sh_encoder.py:101-185): out (n, degree^2 + 3*include_input). */
+int arcn_sh_fwd(const float *dirs, int degree, int include_input, float *out, int64_t n, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fully fused small MLP (replaces tcnn.Network FullyFusedMLP, tcnn_fusedmlp_module.py:66-77,162-173, and
+ * GeoNet/RadianceNet stacks without skips, linear_network_module.py:174-197,318-335).
+ * Layers i = 0..n_layers-1: y_i = act_i(y_{i-1} W_i^T + b_i); W_i is (dims[i+1], dims[i]) row-major (torch Linear),
+ * concatenated in `weights`; `biases` optional (concatenated, dims[i+1] each).  hidden activation = act_hidden for
+ * i < n_layers-1, act_out for the last.  n_layers <= 8, dims[i] <= 128.
+ * acts (optional): concatenated post-activation outputs of every layer, each (n, dims[i+1]) row-major, layer-major
+ * (layer i starts at n_cap*sum_{j<=i}dims[j] ... see arcn_mlp_acts_offset) — saved for the backward.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_layers;
+    int32_t dims[10]; /* dims[0] = input, dims[n_layers] = output */
+    int32_t act_hidden;
+    int32_t act_out;
+    int32_t has_bias;
+    float softplus_beta;
+} arcn_mlp_desc;
+
+int arcn_mlp_fwd(const float *x, const float *weights, const float *biases, const arcn_mlp_desc *desc_host, float *out,
+                 float *acts, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream);
+/* backward: dout (n, dims[L]); acts as saved by fwd (hidden layers only are read, out is read from `out`).
+ * dx (n, dims[0]) optional; dweights/dbiases accumulated (caller zeroes). */
+int arcn_mlp_bwd(const float *x, const float *weights, const float *biases, const arcn_mlp_desc *desc_host,
+                 const float *out, const float *acts, const float *dout, float *dx, float *dweights, float *dbiases,
+                 float *scratch, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream);
+/* float count the caller must provide in `acts` (hidden layers) and `scratch` (bwd) for capacity n_cap */
+int64_t arcn_mlp_acts_floats(const arcn_mlp_desc *desc_host, int64_t n_cap);
+int64_t arcn_mlp_scratch_floats(const arcn_mlp_desc *desc_host, int64_t n_cap);
+
+/* elementwise activation (TruncExp F1 etc.) */
+int arcn_act_fwd(const float *x, float *y, int64_t n, int act, float beta, void *stream);
+int arcn_act_bwd(const float *x, const float *y, const float *dy, float *dx, int64_t n, int act, float beta,
+                 void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Compositing (arcnerf/render/ray_helper.py:476-620)
+ * dense form: sigma/alpha_in (R,P), radiance (R,P,3), zvals (R,P); Pe = P if (add_inf_z || alpha_in) else P-1.
+ * per-sample outputs alpha/trans/weights (R,Pe) optional.  bkg (bkg_rows,3), bkg_rows in {0,1,R}.
+ * status (device int32, optional) is set to 1 if some delta < 0 (the reference asserts, :534).
+ * ---------------------------------------------------------------------------------------------- */
+int arcn_ray_marching_fwd(const float *sigma, const float *alpha_in, const float *radiance, const float *zvals,
+                          const float *noise, const float *bkg, int64_t bkg_rows, int64_t R, int P, int add_inf_z,
+                          int white_bkg, float *rgb, float *depth, float *mask, float *alpha_out, float *trans_out,
+                          float *weights_out, int32_t *status, void *stream);
+int arcn_ray_marching_bwd(const float *sigma, const float *alpha_in, const float *radiance, const float *zvals,
+                          const float *noise, const float *bkg, int64_t bkg_rows, int64_t R, int P, int add_inf_z,
+                          int white_bkg, const float *d_rgb, const float *d_depth, const float *d_mask, float *d_geo,
+                          float *d_radiance, void *stream);
+
+/* packed form over (offsets, t): identical numbers to the dense form applied to the reference's padded (R,P') view
+ * (mask rows [T..T F..F], padded z = last z): P_dense = the dense column count the reference would have used
+ * (max(2, max count), fg_model.py:251-262) read from *p_dense_ptr (device) or p_dense if the pointer is NULL. */
+int arcn_composite_packed_fwd(const float *sigma, const float *radiance, const float *t_packed, const int32_t *offsets,
+                              const float *noise, const float *bkg, int64_t bkg_rows, int64_t R, int p_dense,
+                              const int32_t *p_dense_ptr, int add_inf_z, int white_bkg, float *rgb, float *depth,
+                              float *mask, float *weights_out, void *stream);
+int arcn_composite_packed_bwd(const float *sigma, const float *radiance, const float *t_packed, const int32_t *offsets,
+                              const float *noise, const float *bkg, int64_t bkg_rows, int64_t R, int p_dense,
+                              const int32_t *p_dense_ptr, int add_inf_z, int white_bkg, const float *d_rgb,
+                              const float *d_depth, const float *d_mask, float *d_sigma, float *d_radiance, void *stream);
+
+/* sample_cdf (ray_helper.py:432-473): bins/cdf (R,n_pts), u (R,n_sample) -> samples (R,n_sample) sorted,
+ * inds (R,n_sample) int32 optional (searchsorted right=True). */
+int arcn_sample_cdf(const float *bins, const float *cdf, const float *u, int64_t R, int n_pts, int n_sample, float eps,
+                    int do_sort, float *samples, int32_t *inds, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Occupancy update (volume_bound.py:160-212, geometry/volume.py:983-1017)
+ * ---------------------------------------------------------------------------------------------- */
+/* opafield[idx] = old>=0 ? max(old*ema, opacity) : old ; ema < 0 = no ema */
+int arcn_update_opafield(float *opafield, const int64_t *flat_idx, const float *opacity, int64_t n, float ema,
+                         void *stream);
+/* thres = min(mean(clamp(opa,0)), threshold) computed on device; bitfield (bool bytes) = opa >= thres.
+ * workspace: 2 floats (device). */
+int arcn_update_bitfield_by_opafield(const float *opafield, uint8_t *bitfield, int64_t n, float threshold,
+                                     float *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser over one flat fp32 buffer: torch.optim.Adam(lr, betas, eps, weight_decay) semantics
+ * (common/trainer/optimizer.py:6-54) + EMA.ema_step (arcnerf/trainer/ema.py:29-43), fused.
+ * step is 1-based. grad_scale multiplies the gradient first (1/world_size after all-reduce). ema may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int arcn_adam_ema_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *ema, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, float ema_decay,
+                       float grad_scale, int step, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

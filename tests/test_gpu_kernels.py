@@ -1,0 +1,487 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI, against (a) the golden vectors produced by the
+reference's torch path and (b) the CPU oracle on seeded inputs.
+
+Bars: integer / index / mask outputs bit-exact; sampler t values bit-exact (same IEEE op sequence, -ffp-contract=off on
+both sides); fp32 outputs within 1e-5 relative (north-star bar is 1e-4 on RGB/depth).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, make_table
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def F():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from arcnerf_amd.ops import functional
+    return functional
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+# ---- compositing ---------------------------------------------------------------------------------
+@pytest.mark.parametrize('P', [2, 17, 64])
+def test_ray_marching_vs_reference_golden(F, P):
+    g = load_golden('g1_compositing')
+    pre = 'P{}_'.format(P)
+    sigma, rad, z = dev(g[pre + 'sigma']), dev(g[pre + 'radiance']), dev(g[pre + 'zvals'])
+    for add_inf_z in (False, True):
+        for mode in ('none', 'white', 'bkg_full', 'bkg_one'):
+            tag = 'P{}_inf{}_{}_'.format(P, int(add_inf_z), mode)
+            bkg = dev(g[pre + mode]) if mode.startswith('bkg') else None
+            out = F.ray_marching_fwd(sigma, rad, z, add_inf_z=add_inf_z, white_bkg=(mode == 'white'), bkg_color=bkg)
+            assert int(out['status'].item()) == 0
+            for k in ('rgb', 'depth', 'mask', 'alpha', 'trans_shift', 'weights'):
+                close(host(out[k]), g[tag + k], rtol=1e-5, atol=1e-6)
+            d_sigma, d_rad = F.ray_marching_bwd(sigma, rad, z, dev(g[pre + 'g_rgb']), dev(g[pre + 'g_depth']),
+                                                dev(g[pre + 'g_mask']), add_inf_z=add_inf_z, white_bkg=(mode == 'white'),
+                                                bkg_color=bkg)
+            close(host(d_rad), g[tag + 'd_radiance'], rtol=1e-5, atol=1e-6)
+            close(host(d_sigma), g[tag + 'd_sigma'], rtol=2e-4, atol=2e-5)
+    tag = 'P{}_alpha_'.format(P)
+    out = F.ray_marching_fwd(None, rad, z, alpha=dev(g[tag + 'in']), bkg_color=dev(g[pre + 'bkg_full']))
+    for k in ('rgb', 'depth', 'mask', 'trans_shift', 'weights'):
+        close(host(out[k]), g[tag + k], rtol=1e-5, atol=1e-6)
+    d_alpha, d_rad = F.ray_marching_bwd(None, rad, z, dev(g[pre + 'g_rgb']), dev(g[pre + 'g_depth']), dev(g[pre + 'g_mask']),
+                                        alpha=dev(g[tag + 'in']), bkg_color=dev(g[pre + 'bkg_full']))
+    close(host(d_rad), g[tag + 'd_radiance'], rtol=1e-5, atol=1e-6)
+    close(host(d_alpha), g[tag + 'd_alpha'], rtol=2e-4, atol=2e-5)
+
+
+def test_ray_marching_long_rays_vs_oracle(F, oracle):
+    rng = np.random.default_rng(11)
+    R, P = 300, 1024  # multi-chunk path (16 chunks of 64), ragged valid lengths with duplicated-z tails
+    z = np.sort(rng.random((R, P)).astype(np.float32) * 4 + 0.5, axis=-1)
+    n_valid = rng.integers(1, P + 1, size=R)
+    for r in range(R):
+        z[r, n_valid[r] - 1:] = z[r, n_valid[r] - 1]
+    sigma = (rng.random((R, P)).astype(np.float32) ** 3) * 40
+    sigma[rng.random((R, P)) < 0.5] = 0
+    rad = rng.random((R, P, 3)).astype(np.float32)
+    bkg = rng.random((R, 3)).astype(np.float32)
+    g_rgb, g_d, g_m = (rng.normal(size=s).astype(np.float32) for s in ((R, 3), (R,), (R,)))
+    for add_inf_z in (False, True):
+        ref = oracle.ray_marching_fwd(sigma, rad, z, add_inf_z=add_inf_z, bkg_color=bkg)
+        out = F.ray_marching_fwd(dev(sigma), dev(rad), dev(z), add_inf_z=add_inf_z, bkg_color=dev(bkg))
+        for k in ('rgb', 'depth', 'mask', 'weights', 'trans_shift'):
+            close(host(out[k]), ref[k], rtol=2e-5, atol=2e-6)
+        rs, rr = oracle.ray_marching_bwd(sigma, rad, z, g_rgb, g_d, g_m, add_inf_z=add_inf_z, bkg_color=bkg)
+        ds, dr = F.ray_marching_bwd(dev(sigma), dev(rad), dev(z), dev(g_rgb), dev(g_d), dev(g_m), add_inf_z=add_inf_z,
+                                    bkg_color=dev(bkg))
+        close(host(dr), rr, rtol=2e-5, atol=2e-6)
+        close(host(ds), rs, rtol=5e-4, atol=5e-5)
+
+
+def test_ray_marching_flags_decreasing_z(F):
+    z = dev(np.array([[1.0, 0.5, 2.0]], np.float32))
+    out = F.ray_marching_fwd(torch.ones(1, 3).cuda(), torch.ones(1, 3, 3).cuda(), z)
+    assert int(out['status'].item()) == 1
+
+
+def _packed_case(rng, R, P_dense, force_full=True):
+    counts = rng.integers(0, P_dense + 1, size=R).astype(np.int32)
+    if force_full:
+        counts[1] = P_dense  # at least one ray as long as the dense width
+    counts[0] = 0
+    counts[2] = 1
+    offsets = np.zeros(R + 1, np.int32)
+    offsets[1:] = np.cumsum(counts)
+    S = int(offsets[-1])
+    t = np.zeros(S, np.float32)
+    for r in range(R):
+        n = counts[r]
+        t[offsets[r]:offsets[r] + n] = np.sort(rng.random(n).astype(np.float32) * 3 + 0.3)
+    sigma = (rng.random(S).astype(np.float32) ** 2) * 30
+    rad = rng.random((S, 3)).astype(np.float32)
+    return counts, offsets, t, sigma, rad
+
+
+def _dense_view(counts, offsets, t, sigma, rad, P_dense):
+    """the reference's padded tensors: FgModel.get_sigma_radiance_by_mask_pts (fg_model.py:305-316)"""
+    R = counts.shape[0]
+    z = np.zeros((R, P_dense), np.float32)
+    sg = np.zeros((R, P_dense), np.float32)
+    rd = np.zeros((R, P_dense, 3), np.float32)
+    for r in range(R):
+        n = counts[r]
+        if n == 0:
+            continue
+        sl = slice(offsets[r], offsets[r] + n)
+        z[r, :n], sg[r, :n], rd[r, :n] = t[sl], sigma[sl], rad[sl]
+        z[r, n:], sg[r, n:], rd[r, n:] = t[sl][-1], sigma[sl][-1], rad[sl][-1]
+    return z, sg, rd
+
+
+@pytest.mark.parametrize('add_inf_z', [False, True])
+@pytest.mark.parametrize('P_dense', [2, 37, 200])
+def test_composite_packed_equals_dense_reference_view(F, oracle, add_inf_z, P_dense):
+    rng = np.random.default_rng(100 + P_dense)
+    R = 64
+    counts, offsets, t, sigma, rad = _packed_case(rng, R, P_dense)
+    valid = counts > 0
+    z, sg, rd = _dense_view(counts, offsets, t, sigma, rad, P_dense)
+    bkg = rng.random((R, 3)).astype(np.float32)
+    g_rgb, g_d, g_m = (rng.normal(size=s).astype(np.float32) for s in ((R, 3), (R,), (R,)))
+    ref = oracle.ray_marching_fwd(sg[valid], rd[valid], z[valid], add_inf_z=add_inf_z, bkg_color=bkg[valid])
+    pd = torch.tensor([P_dense], dtype=torch.int32).cuda()
+    out = F.composite_packed_fwd(dev(sigma), dev(rad), dev(t), dev(offsets), p_dense=2, p_dense_dev=pd, add_inf_z=add_inf_z,
+                                 bkg_color=dev(bkg))
+    for k in ('rgb', 'depth', 'mask'):
+        close(host(out[k])[valid], ref[k], rtol=2e-5, atol=2e-6)
+    # rays without samples: rgb = bkg (T=1), depth = mask = 0
+    close(host(out['rgb'])[~valid], bkg[~valid], rtol=0, atol=0)
+    assert (host(out['mask'])[~valid] == 0).all()
+    rs, rr = oracle.ray_marching_bwd(sg[valid], rd[valid], z[valid], g_rgb[valid], g_d[valid], g_m[valid],
+                                     add_inf_z=add_inf_z, bkg_color=bkg[valid])
+    ds, dr = F.composite_packed_bwd(dev(sigma), dev(rad), dev(t), dev(offsets), dev(g_rgb), dev(g_d), dev(g_m), p_dense=2,
+                                    p_dense_dev=pd, add_inf_z=add_inf_z, bkg_color=dev(bkg))
+    ds, dr = host(ds), host(dr)
+    # scatter the dense reference gradients back onto packed samples: valid columns map 1:1, the duplicated tail
+    # columns alias the last valid sample (index_put of sigma[mask_pts] = _sigma is 1:1, the `last_sigma` fill is a
+    # gather of the last packed sample: its gradient flows to that sample)
+    want_s = np.zeros_like(sigma)
+    want_r = np.zeros_like(rad)
+    vi = np.nonzero(valid)[0]
+    for k, r in enumerate(vi):
+        n = counts[r]
+        want_s[offsets[r]:offsets[r] + n] = rs[k, :n]
+        want_r[offsets[r]:offsets[r] + n] = rr[k, :n]
+        want_s[offsets[r] + n - 1] += rs[k, n:].sum()
+        want_r[offsets[r] + n - 1] += rr[k, n:].sum(0)
+    close(dr, want_r, rtol=2e-5, atol=2e-6)
+    close(ds, want_s, rtol=5e-4, atol=5e-5)
+
+
+# ---- resampling ----------------------------------------------------------------------------------
+def test_sample_cdf_vs_reference_golden(F):
+    g = load_golden('g2_resampling')
+    s, inds = F.sample_cdf(dev(g['bins']), dev(g['cdf']), dev(g['u_det']), want_inds=True)
+    assert (host(inds) == g['inds_det']).all()
+    close(host(s), g['samples_det'], rtol=1e-6, atol=1e-6)
+    s, inds = F.sample_cdf(dev(g['bins']), dev(g['cdf']), dev(g['u']), want_inds=True)
+    assert (host(inds) == g['inds_rnd']).all()
+    close(host(s), g['samples_rnd'], rtol=1e-6, atol=1e-6)
+
+
+# ---- bounds --------------------------------------------------------------------------------------
+def test_aabb_torch_semantics_vs_reference_golden(F):
+    g = load_golden('g4_intersections')
+    near, far, pts, mask = F.aabb_intersection_torch(dev(g['rays_o']), dev(g['rays_d']), dev(g['aabb']))
+    assert (host(mask) == g['mask']).all()
+    close(host(near), g['near'], rtol=2e-6, atol=2e-6)
+    close(host(far), g['far'], rtol=2e-6, atol=2e-6)
+    close(host(pts), g['pts'], rtol=1e-5, atol=1e-5)
+
+
+def test_k2_bit_exact_vs_oracle(F, oracle):
+    g = load_golden('g4_intersections')
+    aabb23 = np.ascontiguousarray(np.transpose(g['aabb'], (0, 2, 1)))
+    ref = oracle.aabb_intersection(g['rays_o'], g['rays_d'], aabb23)
+    got = F.aabb_intersection(dev(g['rays_o']), dev(g['rays_d']), dev(aabb23))
+    for a, b in zip(got, ref):
+        assert np.array_equal(host(a), b)
+
+
+def test_k1_vs_reference_golden_and_oracle(F, oracle):
+    g = load_golden('g5_voxel')
+    aabb23 = np.array([[-1, -1, -1], [1, 1, 1]], np.float32)
+    occ = F.check_pts_in_occ_voxel(dev(g['pts']), dev(g['n8_bitfield']), dev(aabb23), 8)
+    assert (host(occ) == g['n8_pts_in_occ']).all()
+    rng = np.random.default_rng(3)
+    bf = rng.random((128, 128, 128)) < 0.1
+    pts = (rng.random((200000, 3)).astype(np.float32) - 0.5) * 2.2
+    assert np.array_equal(host(F.check_pts_in_occ_voxel(dev(pts), dev(bf), dev(aabb23), 128)),
+                          oracle.check_pts_in_occ_voxel(pts, bf, aabb23, 128))
+
+
+# ---- sampler -------------------------------------------------------------------------------------
+def _rays(rng, R, radius=2.86):
+    o = rng.normal(size=(R, 3)).astype(np.float32)
+    o = (o / np.linalg.norm(o, axis=-1, keepdims=True) * radius).astype(np.float32)
+    tgt = (rng.random((R, 3)).astype(np.float32) - 0.5) * 1.8
+    d = tgt - o
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    return o, d
+
+
+def _blob_bitfield(n_grid, rng, frac=0.06):
+    """a few boxes/spheres filling about `frac` of the grid"""
+    ax = (np.arange(n_grid) + 0.5) / n_grid * 2 - 1
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing='ij')
+    bf = np.zeros((n_grid,) * 3, bool)
+    while bf.mean() < frac:
+        c = (rng.random(3) - 0.5) * 1.2
+        r = rng.random() * 0.25 + 0.1
+        if rng.random() < 0.5:
+            bf |= ((X - c[0]) ** 2 + (Y - c[1]) ** 2 + (Z - c[2]) ** 2) < r * r
+        else:
+            bf |= (np.abs(X - c[0]) < r) & (np.abs(Y - c[1]) < r * 0.7) & (np.abs(Z - c[2]) < r * 0.5)
+    return bf
+
+
+@pytest.mark.parametrize('n_grid,n_pts,R', [(16, 256, 500), (128, 1024, 4096)])
+def test_k3_sampler_bit_exact_vs_oracle(F, oracle, n_grid, n_pts, R):
+    rng = np.random.default_rng(n_grid)
+    bf = _blob_bitfield(n_grid, rng, 0.15 if n_grid == 16 else 0.05)
+    o, d = _rays(rng, R)
+    aabb23 = np.array([[-1, -1, -1], [1, 1, 1]], np.float32)
+    near, far, _, _ = oracle.aabb_intersection(o, d, aabb23[None])
+    dt = np.float32(2 * np.sqrt(3.0) / n_pts)
+    hostrng = oracle.Pcg32(9121)
+    hostrng.advance()  # second launch of the process: state after one 2^32 jump
+    z_ref, m_ref, c_ref = oracle.sparse_volume_sampling(o, d, near, far, n_pts, dt, aabb23, n_grid, bf, 0.2, hostrng.state,
+                                                        hostrng.inc)
+    gr = F.Pcg32Host(9121)
+    gr.advance()
+    assert (gr.state, gr.inc) == (hostrng.state, hostrng.inc)
+    z, m, c = F.sparse_volume_sampling(dev(o), dev(d), dev(near), dev(far), n_pts, float(dt), dev(aabb23), n_grid, dev(bf), 0.2,
+                                       gr.state, gr.inc, want_counts=True)
+    assert np.array_equal(host(c), c_ref)
+    assert np.array_equal(host(m), m_ref)
+    assert np.array_equal(host(z).view(np.uint32), z_ref.view(np.uint32))  # t values: 0 ulp
+    assert c_ref.sum() > 10 * R / 4
+
+    # compacted form == boolean-mask compaction of the dense form (row-major), K2 bounds fused
+    pk = F.march_packed(dev(o), dev(d), dev(aabb23), n_grid, dev(bf), n_pts, float(dt), 0.2, gr.state, gr.inc)
+    total = int(pk['offsets'][-1].item())
+    assert total == int(c_ref.sum())
+    assert np.array_equal(host(pk['counts']), c_ref)
+    assert np.array_equal(host(pk['t'][:total]).view(np.uint32), z_ref[m_ref].view(np.uint32))
+    rid = np.repeat(np.arange(R, dtype=np.int32), c_ref)
+    assert np.array_equal(host(pk['ray_id'][:total]), rid)
+    assert np.array_equal(host(pk['near']), near[:, 0]) and np.array_equal(host(pk['far']), far[:, 0])
+    # packed 1-bit occupancy gives the identical result
+    bits = np.packbits(bf.reshape(-1), bitorder='little')
+    pk2 = F.march_packed(dev(o), dev(d), dev(aabb23), n_grid, dev(bits), n_pts, float(dt), 0.2, gr.state, gr.inc,
+                         packed_bits=True)
+    assert np.array_equal(host(pk2['offsets']), host(pk['offsets']))
+    assert np.array_equal(host(pk2['t'][:total]).view(np.uint32), host(pk['t'][:total]).view(np.uint32))
+    # points of packed samples
+    xyz, dirs = F.packed_points(dev(o), dev(d), pk['t'], pk['ray_id'], n=total)
+    want = o[rid] + z_ref[m_ref][:, None] * d[rid]
+    assert np.array_equal(host(xyz), want.astype(np.float32))
+    assert np.array_equal(host(dirs), d[rid])
+
+
+def test_k4_reduce_max_vs_oracle(F, oracle):
+    rng = np.random.default_rng(4)
+    n, ng = 100000, 5000
+    full = rng.random(n).astype(np.float32)
+    idx = rng.integers(0, ng, size=n)
+    assert np.array_equal(host(F.tensor_reduce_max(dev(full), dev(idx), ng)), oracle.tensor_reduce_max(full, idx, ng))
+
+
+# ---- hash grid -----------------------------------------------------------------------------------
+def _desc(F_, res, offs, n_feat):
+    from arcnerf_amd import _native as N
+    return N.make_hashgrid_desc(res, offs, n_feat, [-1, -1, -1], [1, 1, 1])
+
+
+@pytest.mark.parametrize('tag', ['ngp', 'tiny', 'f4'])
+def test_hashgrid_vs_reference_golden(F, oracle, tag):
+    g = load_golden('g6_hashgrid')
+    L, nf, T, base, mx_res = [int(v) for v in g[tag + '_cfg']]
+    res, offs = g[tag + '_resolutions'], g[tag + '_offsets']
+    table = make_table(int(offs[-1]), nf, seed=7, scale=0.5)
+    desc = _desc(F, res, offs, nf)
+    tb = dev(table)
+    out, idx = F.hashgrid_fwd(dev(g[tag + '_xyz']), tb, desc, want_idx=True)
+    assert np.array_equal(host(idx), g[tag + '_hash_idx'])  # integer hash rows: bit exact vs the reference
+    close(host(out), g[tag + '_out'], rtol=1e-5, atol=1e-6)
+    dtable, dxyz = F.hashgrid_bwd(dev(g[tag + '_xyz']), tb, dev(g[tag + '_g_out']), desc, want_dxyz=True)
+    dtable = host(dtable)
+    rows = g[tag + '_d_table_rows']
+    nz = np.nonzero(np.abs(dtable).sum(-1) > 0)[0]
+    assert set(nz.tolist()) <= set(rows.tolist())
+    close(dtable[rows], g[tag + '_d_table_vals'], rtol=1e-4, atol=1e-5)
+    scale = np.abs(g[tag + '_d_xyz']).max()
+    close(host(dxyz), g[tag + '_d_xyz'], rtol=1e-4, atol=1e-4 * scale)
+
+
+def test_hashgrid_ngp_large_vs_oracle(F, oracle):
+    rng = np.random.default_rng(6)
+    res, offs = oracle.hashgrid_levels(16, 19, 16, 2048)
+    table = make_table(int(offs[-1]), 2, seed=9, scale=0.5)
+    desc = _desc(F, res, offs, 2)
+    S = 20000
+    xyz = ((rng.random((S, 3)).astype(np.float32) - 0.5) * 2.05).astype(np.float32)
+    mn, mx = np.full(3, -1, np.float32), np.full(3, 1, np.float32)
+    ref, ref_idx = oracle.hashgrid_fwd(xyz, table, res, offs, mn, mx, with_idx=True)
+    tb = dev(table)
+    out, idx = F.hashgrid_fwd(dev(xyz), tb, desc, want_idx=True)
+    assert np.array_equal(host(idx).astype(np.int64), ref_idx)
+    close(host(out), ref, rtol=1e-6, atol=1e-7)
+    gout = rng.normal(size=ref.shape).astype(np.float32)
+    ref_dt = oracle.hashgrid_bwd(xyz, table, gout, res, offs, mn, mx)
+    dt, _ = F.hashgrid_bwd(dev(xyz), tb, dev(gout), desc)
+    close(host(dt), ref_dt, rtol=1e-4, atol=1e-5)
+    # device-side sample count: only the first n_dev samples are touched
+    n_dev = torch.tensor([1234], dtype=torch.int32).cuda()
+    out2 = torch.full((S, 32), 7.0, device='cuda')
+    F.hashgrid_fwd(dev(xyz), tb, desc, n_dev=n_dev, out=out2)
+    o2 = host(out2)
+    assert np.array_equal(o2[:1234], host(out)[:1234]) and (o2[1234:] == 7.0).all()
+
+
+# ---- freq / SH -----------------------------------------------------------------------------------
+def test_freq_sh_vs_reference_golden(F):
+    g = load_golden('g7_freq_sh')
+    for n_freqs in (10, 4, 0):
+        for inc in (True, False):
+            if n_freqs == 0 and not inc:
+                continue
+            t = 'freq{}_inc{}'.format(n_freqs, int(inc))
+            close(host(F.freq_fwd(dev(g['x']), n_freqs, inc)), g[t], rtol=0, atol=5e-6)
+            close(host(F.freq_bwd(dev(g['x']), dev(g[t + '_g']), n_freqs, inc)), g[t + '_dx'], rtol=1e-5, atol=3e-3)
+    for deg in (1, 2, 3, 4, 5):
+        for inc in (True, False):
+            close(host(F.sh_fwd(dev(g['dirs']), deg, inc)), g['sh{}_inc{}'.format(deg, int(inc))], rtol=1e-6, atol=1e-6)
+    y = F.act_fwd(dev(g_truncexp()[0]), 'truncexp')
+    close(host(y), g_truncexp()[1], rtol=2e-6, atol=0)
+    close(host(F.act_bwd(dev(g_truncexp()[0]), y, torch.ones_like(y), 'truncexp')), g_truncexp()[2], rtol=2e-6, atol=0)
+
+
+def g_truncexp():
+    g = load_golden('g8_mlps')
+    return g['truncexp_x'], g['truncexp_y'], g['truncexp_dx']
+
+
+# ---- fused MLP -----------------------------------------------------------------------------------
+def _layers(g, prefix):
+    ws = sorted([k for k in g.files if k.startswith(prefix + '.layers.') and k.endswith('weight')],
+                key=lambda k: int(k[len(prefix) + 8:].split('.')[0]))
+    return [(g[k], g[k[:-6] + 'bias'] if (k[:-6] + 'bias') in g.files else None) for k in ws]
+
+
+def _flat(layers):
+    w = np.concatenate([W.reshape(-1) for W, _ in layers]).astype(np.float32)
+    b = None if layers[0][1] is None else np.concatenate([b for _, b in layers]).astype(np.float32)
+    return w, b
+
+
+@pytest.mark.parametrize('bias', [0, 1])
+def test_fused_mlp_vs_reference_golden(F, bias):
+    """NGP-shaped geo (32->64->16) and radiance (32->64->64->3) nets against the reference's torch GeoNet/RadianceNet."""
+    from arcnerf_amd import _native as N
+    g = load_golden('g8_mlps')
+    t = 'geo_b{}'.format(bias)
+    layers = _layers(g, t)
+    w, b = _flat(layers)
+    desc = N.make_mlp_desc([32, 64, 16], 'relu', None, has_bias=bool(bias))
+    x = dev(g[t + '_x'])
+    wd, bd = dev(w), (dev(b) if bias else None)
+    out, acts = F.mlp_fwd(x, wd, bd, desc, save_acts=True)
+    o = host(out)
+    close(np.exp(o[:, :1]), g[t + '_sigma'], rtol=2e-5, atol=1e-6)
+    close(o[:, 1:], g[t + '_feat'], rtol=1e-5, atol=2e-6)
+    # backward: d out = [g_sigma * exp(clamp(o0)), g_feat]
+    do = np.concatenate([g[t + '_g_sigma'] * np.exp(np.clip(o[:, :1], -15, 15)), g[t + '_g_feat']], 1).astype(np.float32)
+    dx, dw, db = F.mlp_bwd(x, wd, bd, desc, out, acts, dev(do))
+    names = sorted(k for k in g.files if k.startswith(t + '_grad.') and k.endswith('weight'))
+    want_w = np.concatenate([g[k].reshape(-1) for k in names])
+    close(host(dw), want_w, rtol=1e-4, atol=1e-4)
+    close(host(dx), g[t + '_dx'], rtol=1e-4, atol=1e-5)
+    if bias:
+        bn = sorted(k for k in g.files if k.startswith(t + '_grad.') and k.endswith('bias'))
+        close(host(db), np.concatenate([g[k] for k in bn]), rtol=1e-4, atol=1e-4)
+
+    t = 'rad_b{}'.format(bias)
+    layers = _layers(g, t)
+    w, b = _flat(layers)
+    desc = N.make_mlp_desc([32, 64, 64, 3], 'relu', 'sigmoid', has_bias=bool(bias))
+    v = g[t + '_view']
+    v = (v / np.linalg.norm(v, axis=-1, keepdims=True)).astype(np.float32)
+    xin = torch.cat([dev(g[t + '_feat']), F.sh_fwd(dev(v), 4, False)], 1).contiguous()  # mode 'fv'
+    wd, bd = dev(w), (dev(b) if bias else None)
+    rgb, acts = F.mlp_fwd(xin, wd, bd, desc, save_acts=True)
+    close(host(rgb), g[t + '_rgb'], rtol=1e-5, atol=2e-6)
+    dx, dw, db = F.mlp_bwd(xin, wd, bd, desc, rgb, acts, dev(g[t + '_g_rgb']))
+    names = sorted(k for k in g.files if k.startswith(t + '_grad.') and k.endswith('weight'))
+    close(host(dw), np.concatenate([g[k].reshape(-1) for k in names]), rtol=1e-4, atol=1e-4)
+    close(host(dx)[:, :16], g[t + '_dfeat'], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('dims,act_out,bias,S', [([32, 64, 16], None, False, 5000), ([32, 64, 64, 3], 'sigmoid', False, 70001),
+                                                 ([27, 48, 5], 'sigmoid', True, 333), ([63, 128, 128, 17], None, True, 1000),
+                                                 ([16, 16], 'relu', False, 64)])
+def test_fused_mlp_shapes_vs_oracle(F, oracle, dims, act_out, bias, S):
+    from arcnerf_amd import _native as N
+    rng = np.random.default_rng(sum(dims))
+    Ws = [(rng.normal(size=(dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
+    bs = [(rng.normal(size=dims[i + 1]) * 0.1).astype(np.float32) for i in range(len(dims) - 1)] if bias else None
+    x = rng.normal(size=(S, dims[0])).astype(np.float32)
+    hs, pres = [x], []
+    for i, W in enumerate(Ws):
+        last = i == len(Ws) - 1
+        y, pre = oracle.linear_fwd(hs[-1], W, bs[i] if bias else None, act_out if last else 'relu', want_pre=True)
+        hs.append(y)
+        pres.append(pre)
+    desc = N.make_mlp_desc(dims, 'relu', act_out, has_bias=bias)
+    w = dev(np.concatenate([W.reshape(-1) for W in Ws]))
+    b = dev(np.concatenate(bs)) if bias else None
+    xd = dev(x)
+    out, acts = F.mlp_fwd(xd, w, b, desc, save_acts=True)
+    close(host(out), hs[-1], rtol=2e-5, atol=2e-6)
+    dout = rng.normal(size=hs[-1].shape).astype(np.float32)
+    dy = dout
+    gW, gb = [], []
+    for i in reversed(range(len(Ws))):
+        last = i == len(Ws) - 1
+        dy, dW, db = oracle.linear_bwd(hs[i], Ws[i], pres[i], hs[i + 1], dy, act_out if last else 'relu', has_bias=bias)
+        gW.insert(0, dW)
+        gb.insert(0, db)
+    dx, dw, dbb = F.mlp_bwd(xd, w, b, desc, out, acts, dev(dout))
+    close(host(dx), dy, rtol=1e-4, atol=1e-5)
+    ref_w = np.concatenate([m.reshape(-1) for m in gW])
+    close(host(dw), ref_w, rtol=2e-4, atol=2e-4 * np.abs(ref_w).max())
+    if bias:
+        ref_b = np.concatenate(gb)
+        close(host(dbb), ref_b, rtol=2e-4, atol=2e-4 * np.abs(ref_b).max())
+
+
+# ---- occupancy update / optimiser ----------------------------------------------------------------
+def test_occupancy_update_vs_reference_golden(F):
+    g = load_golden('g10_occupancy')
+    opa = dev(g['opa0'].reshape(-1).copy())
+    F.update_opafield(opa, dev(g['flat_idx'].astype(np.int64)), dev(g['new_opacity']), ema=0.95)
+    assert np.array_equal(host(opa).reshape(8, 8, 8), g['opa1'])
+    bf = torch.zeros(512, dtype=torch.bool, device='cuda')
+    F.update_bitfield_by_opafield(opa, bf, 0.01)
+    assert np.array_equal(host(bf).reshape(8, 8, 8), g['bitfield'])
+
+
+def test_adam_ema_vs_torch(F):
+    torch.manual_seed(0)
+    n = 100003
+    p0 = torch.randn(n)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=1e-1, eps=1e-15, weight_decay=1e-6)
+    p = p0.clone().cuda()
+    # 16-byte alignment is required: torch allocations are
+    m, v, ema = torch.zeros(n).cuda(), torch.zeros(n).cuda(), p0.clone().cuda()
+    ema_ref = p0.clone()
+    for step in range(1, 6):
+        gr = torch.randn(n) * (10.0 ** torch.randint(-6, 1, (n,)).float())
+        p_ref.grad = gr.clone()
+        opt.step()
+        ema_ref = 0.95 * ema_ref + (1 - 0.95) * p_ref.detach()
+        F.adam_ema_step(p, gr.cuda(), m, v, ema, step, lr=1e-1, eps=1e-15, weight_decay=1e-6, ema_decay=0.95)
+        close(host(p), p_ref.detach().numpy(), rtol=2e-5, atol=2e-6)
+        close(host(ema), ema_ref.numpy(), rtol=2e-5, atol=2e-6)
