@@ -113,6 +113,53 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const float *__restrict__ 
         dx[i] = dy[i] * act_grad(x[i], y ? y[i] : 0.f, act, beta);
 }
 
+// ---- geo -> radiance glue of Base3dModel._forward_pts_dir (arcnerf/models/base_3d_model.py:233-254) ---------------
+// sigma = out_act(geo_out[:,0]) (EncoderMLPGeoNet.handle_output / FusedMLPGeoNet.handle_output_combine);
+// rad_in = fuse_radiance_inputs(..) for modes 'fv' / 'vf' (encoder_mlp_network.py:93-118): geo feature slice and
+// SH(normalize(view_dir)) concatenated in mode order; normalize = v / (|v| + 1e-8) (geometry/transformation.py:21).
+__global__ void __launch_bounds__(256)
+ngp_glue_fwd_kernel(const float *__restrict__ geo_out, const float *__restrict__ dirs, int Wg, int feat_off, int Wf,
+                    int degree, int feat_first, int sigma_act, float *__restrict__ rad_in, float *__restrict__ sigma,
+                    int64_t n, const int32_t *n_ptr) {
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int nsh = degree * degree, W = Wf + nsh;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cnt; s += (int64_t)gridDim.x * blockDim.x) {
+        const float *g = geo_out + s * Wg;
+        if (sigma) sigma[s] = act_fwd(g[0], sigma_act, 1.0f);
+        float *dst = rad_in + s * W;
+        float *fdst = feat_first ? dst : dst + nsh;
+        float *sdst = feat_first ? dst + Wf : dst;
+        for (int c = 0; c < Wf; ++c) fdst[c] = g[feat_off + c];
+        if (nsh > 0) {
+            float dx = dirs[3 * s], dy = dirs[3 * s + 1], dz = dirs[3 * s + 2];
+            float nrm = sqrtf((dx * dx + dy * dy) + dz * dz) + 1e-8f;
+            float o[25];
+            sh_eval(dx / nrm, dy / nrm, dz / nrm, degree, o);
+            for (int c = 0; c < nsh; ++c) sdst[c] = o[c];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+ngp_glue_bwd_kernel(const float *__restrict__ geo_out, const float *__restrict__ d_rad_in, const float *__restrict__ d_sigma,
+                    int Wg, int feat_off, int Wf, int degree, int feat_first, int sigma_act,
+                    float *__restrict__ d_geo_out, int64_t n, const int32_t *n_ptr) {
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int nsh = degree * degree, W = Wf + nsh;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cnt; s += (int64_t)gridDim.x * blockDim.x) {
+        const float *src = d_rad_in + s * W + (feat_first ? 0 : nsh);
+        float *dg = d_geo_out + s * Wg;
+        for (int c = 0; c < Wg; ++c) {
+            float v = (c >= feat_off && c < feat_off + Wf) ? src[c - feat_off] : 0.f;
+            if (c == 0 && d_sigma) {
+                const float x0 = geo_out[s * Wg];
+                v += d_sigma[s] * act_grad(x0, act_fwd(x0, sigma_act, 1.0f), sigma_act, 1.0f);
+            }
+            dg[c] = v;
+        }
+    }
+}
+
 inline unsigned grid_for(int64_t n) {
     int64_t b = ceil_div<int64_t>(n, 256);
     return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -160,4 +207,26 @@ ARCN_EXPORT int arcn_act_bwd(const float *x, const float *y, const float *dy, fl
     if (!x || !dy || !dx) return einval("act_bwd: missing argument");
     hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, y, dy, dx, n, act, beta);
     return check_launch("act_bwd");
+}
+
+ARCN_EXPORT int arcn_ngp_glue_fwd(const float *geo_out, const float *dirs, int Wg, int feat_off, int Wf, int sh_degree,
+                                  int feat_first, int sigma_act, float *rad_in, float *sigma, int64_t n,
+                                  const int32_t *n_ptr, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!geo_out || !rad_in || Wg < 1 || Wf < 0 || feat_off < 0 || feat_off + Wf > Wg || sh_degree < 0 || sh_degree > 5 ||
+        (sh_degree > 0 && !dirs))
+        return einval("ngp_glue_fwd: bad argument");
+    hipLaunchKernelGGL(ngp_glue_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), geo_out, dirs, Wg, feat_off,
+                       Wf, sh_degree, feat_first, sigma_act, rad_in, sigma, n, n_ptr);
+    return check_launch("ngp_glue_fwd");
+}
+
+ARCN_EXPORT int arcn_ngp_glue_bwd(const float *geo_out, const float *d_rad_in, const float *d_sigma, int Wg, int feat_off,
+                                  int Wf, int sh_degree, int feat_first, int sigma_act, float *d_geo_out, int64_t n,
+                                  const int32_t *n_ptr, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!geo_out || !d_rad_in || !d_geo_out || Wg < 1 || feat_off + Wf > Wg) return einval("ngp_glue_bwd: bad argument");
+    hipLaunchKernelGGL(ngp_glue_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), geo_out, d_rad_in, d_sigma, Wg,
+                       feat_off, Wf, sh_degree, feat_first, sigma_act, d_geo_out, n, n_ptr);
+    return check_launch("ngp_glue_bwd");
 }

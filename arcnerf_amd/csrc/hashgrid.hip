@@ -187,6 +187,108 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(const float *__restri
     }
 }
 
+// ---- backward, owner-computes scatter through LDS -------------------------------------------------------------
+// Measured on MI355X: the chip retires only ~18-21 G scattered fp32 global atomics per second (they are served at the
+// memory side, not in the issuing XCD's L2), so the 128 atomics/sample of the plain kernel above cost 4 ms per 2^18
+// samples — 70 % of a training step — no matter how the work is arranged.  This kernel issues NO global atomics on the
+// fine levels: every workgroup OWNS a slice of <= kChunkRows rows of one level's dtable, held in LDS (128 KiB of the
+// CU's 160 KiB).  It scans the samples, recomputes each sample's cell and the 8 hashed rows for its level, and
+// accumulates the corners that fall into its slice with LDS atomics (ds_add_f32); at the end the slice is written back
+// with plain coalesced stores.  A corner hashes into a given slice with probability 1/n_chunks, so the LDS traffic is
+// tiny and the kernel is VALU-bound on the (cheap, integer) hashing; the price is that each of a level's n_chunks
+// workgroups re-derives every sample's cell.  Small (coarse) levels have few chunks but heavy same-row traffic: they are
+// additionally split over disjoint sample ranges, each split accumulating privately in LDS and merging its non-zero
+// rows with a few global atomics (n_splits * rows, negligible).
+// The cell index uses a reciprocal multiply with an exact-division fallback whenever the result is within 2e-3 of an
+// integer (error bound of the fast path 4e-4), so rows stay bit-identical to the forward/reference.
+constexpr int kChunkRows = 16384;  // x F(=2) floats = 128 KiB
+constexpr int kTiledThreads = 1024;
+
+struct TiledPlan {
+    int32_t item_first[ARCN_MAX_LEVELS + 1];  // prefix of work items per level
+    int32_t n_chunks[ARCN_MAX_LEVELS];
+    int32_t n_splits[ARCN_MAX_LEVELS];
+    int32_t chunk_rows[ARCN_MAX_LEVELS];
+};
+
+template <int F>
+__global__ void __launch_bounds__(kTiledThreads)
+hashgrid_bwd_tiled_kernel(const float *__restrict__ xyz, const float *__restrict__ dout, GridParams g, TiledPlan plan,
+                          float *__restrict__ dtable, int64_t n, const int32_t *n_ptr) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    const int64_t cnt = dev_count(n, n_ptr);
+    int l = 0;
+    while (l + 1 < g.L && (int)blockIdx.x >= plan.item_first[l + 1]) ++l;
+    const int item = blockIdx.x - plan.item_first[l];
+    const int chunk = item / plan.n_splits[l], split = item % plan.n_splits[l];
+    const LevelParams lp = g.lv[l];
+    const uint32_t row_lo = (uint32_t)chunk * (uint32_t)plan.chunk_rows[l];
+    const uint32_t row_hi_raw = row_lo + (uint32_t)plan.chunk_rows[l];
+    const uint32_t row_hi = row_hi_raw < lp.size ? row_hi_raw : lp.size;
+    const int n_rows = (int)(row_hi - row_lo);
+    for (int i = threadIdx.x; i < n_rows * F; i += kTiledThreads) acc[i] = 0.f;
+    __syncthreads();
+    const int64_t per = (cnt + plan.n_splits[l] - 1) / plan.n_splits[l];
+    const int64_t s_lo = per * split, s_hi = (s_lo + per < cnt) ? s_lo + per : cnt;
+    float vs[3], inv_vs[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { vs[k] = (g.mx[k] - g.mn[k]) / (float)lp.res; inv_vs[k] = 1.0f / vs[k]; }
+    const float fres = (float)lp.res;
+    for (int64_t s = s_lo + threadIdx.x; s < s_hi; s += kTiledThreads) {
+        const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
+        uint32_t c[3];
+        float w[3];
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float pm = p[k] - g.mn[k];
+            float v = pm * inv_vs[k];
+            float fl = floorf(v);
+            const float fr = v - fl;
+            if (!(fr >= 2e-3f && fr <= 1.0f - 2e-3f)) { v = pm / vs[k]; fl = floorf(v); }  // exact near integers
+            if (!(v >= 0.f) || !(v < fres)) ok = false;
+            c[k] = (uint32_t)fl;
+            const float a = fl * vs[k];
+            const float g0 = a + g.mn[0];
+            const float ww = (p[k] - g0) * inv_vs[k];
+            w[k] = ww < 0.0f ? 0.0f : (ww > 1.0f ? 1.0f : ww);
+        }
+        if (!ok) continue;
+        float go[F];
+        bool have = false;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
+            const uint32_t row = hash_row(c[0] + ox, c[1] + oy, c[2] + oz, lp);
+            if (row >= row_lo && row < row_hi) {
+                if (!have) {
+#pragma unroll
+                    for (int f = 0; f < F; ++f) go[f] = dout[(s * g.L + l) * F + f];
+                    have = true;
+                }
+                const float wx = ox ? w[0] : 1.0f - w[0];
+                const float wy = oy ? w[1] : 1.0f - w[1];
+                const float wz = oz ? w[2] : 1.0f - w[2];
+                const float wt = (wx * wy) * wz;
+                float *dst = acc + (row - row_lo) * F;
+#pragma unroll
+                for (int f = 0; f < F; ++f) __hip_atomic_fetch_add(dst + f, go[f] * wt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+    float *dst = dtable + ((int64_t)lp.offset + row_lo) * F;
+    if (plan.n_splits[l] == 1) {
+        // exclusive owner: plain coalesced stores (+= so that callers accumulating over several launches stay correct)
+        for (int i = threadIdx.x; i < n_rows * F; i += kTiledThreads) dst[i] += acc[i];
+    } else {
+        for (int i = threadIdx.x; i < n_rows * F; i += kTiledThreads) {
+            const float v = acc[i];
+            if (v != 0.f) unsafeAtomicAdd(dst + i, v);
+        }
+    }
+}
+
 static int build_params(const arcn_hashgrid_desc *d, GridParams &g) {
     if (!d) return einval("hashgrid: desc is NULL");
     if (d->n_levels < 1 || d->n_levels > ARCN_MAX_LEVELS) return einval("hashgrid: n_levels out of range");
@@ -229,13 +331,50 @@ ARCN_EXPORT int arcn_hashgrid_fwd(const float *xyz, const float *table, const ar
 }
 
 ARCN_EXPORT int arcn_hashgrid_bwd(const float *xyz, const float *table, const float *dout,
-                                  const arcn_hashgrid_desc *desc_host, float *dtable, float *dxyz, int64_t n,
-                                  const int32_t *n_ptr, void *stream) {
+                                  const arcn_hashgrid_desc *desc_host, float *dtable, float *dxyz, int32_t *workspace,
+                                  int64_t n, const int32_t *n_ptr, void *stream) {
     if (n <= 0) return ARCN_OK;
     if (!xyz || !dout || (!dtable && !dxyz) || (dxyz && !table)) return einval("hashgrid_bwd: missing argument");
     GridParams g;
     int rc = build_params(desc_host, g);
     if (rc) return rc;
+    if (workspace && dtable && !dxyz) {
+        // owner-computes scatter through LDS (workspace only selects the path; nothing is stored in it)
+        TiledPlan plan;
+        int items = 0;
+        for (int l = 0; l < g.L; ++l) {
+            const int64_t size = g.lv[l].size;
+            const int rows_cap = kChunkRows * 2 / g.F;  // 128 KiB of floats
+            int nc = (int)((size + rows_cap - 1) / rows_cap);
+            int cr = (int)((size + nc - 1) / nc);
+            int ns = 32 / nc;  // about 32 workgroups per level
+            if (ns < 1) ns = 1;
+            // never split so finely that a split has fewer than 4096 samples
+            while (ns > 1 && n / ns < 4096) ns >>= 1;
+            plan.item_first[l] = items;
+            plan.n_chunks[l] = nc;
+            plan.n_splits[l] = ns;
+            plan.chunk_rows[l] = cr;
+            items += nc * ns;
+        }
+        plan.item_first[g.L] = items;
+        for (int l = g.L + 1; l <= ARCN_MAX_LEVELS; ++l) plan.item_first[l] = items;
+        const size_t lds = sizeof(float) * (size_t)kChunkRows * 2;
+        hipError_t e = hipSuccess;
+        switch (g.F) {
+        case 1: e = hipFuncSetAttribute(reinterpret_cast<const void *>(hashgrid_bwd_tiled_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
+        case 2: e = hipFuncSetAttribute(reinterpret_cast<const void *>(hashgrid_bwd_tiled_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
+        default: e = hipFuncSetAttribute(reinterpret_cast<const void *>(hashgrid_bwd_tiled_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
+        }
+        if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
+        dim3 pgrid((unsigned)items);
+        switch (g.F) {
+        case 1: hipLaunchKernelGGL(hashgrid_bwd_tiled_kernel<1>, pgrid, dim3(kTiledThreads), lds, as_stream(stream), xyz, dout, g, plan, dtable, n, n_ptr); break;
+        case 2: hipLaunchKernelGGL(hashgrid_bwd_tiled_kernel<2>, pgrid, dim3(kTiledThreads), lds, as_stream(stream), xyz, dout, g, plan, dtable, n, n_ptr); break;
+        default: hipLaunchKernelGGL(hashgrid_bwd_tiled_kernel<4>, pgrid, dim3(kTiledThreads), lds, as_stream(stream), xyz, dout, g, plan, dtable, n, n_ptr); break;
+        }
+        return check_launch("hashgrid_bwd_tiled");
+    }
     dim3 grid((unsigned)ceil_div<int64_t>(n * g.L, 256));
     switch (g.F) {
     case 1: hipLaunchKernelGGL(hashgrid_bwd_kernel<1>, grid, dim3(256), 0, as_stream(stream), xyz, table, dout, g, dtable, dxyz, n, n_ptr); break;

@@ -1,7 +1,8 @@
 // Fused Adam + EMA over one flat fp32 parameter buffer (gfx950, HBM-streaming: 28 B/param + 8 B/param for the EMA).
 // torch.optim.Adam semantics as configured by common/trainer/optimizer.py:6-54 (L2 weight decay folded into the
-// gradient, bias-corrected moments, eps added to sqrt(v_hat)); EMA.ema_step of arcnerf/trainer/ema.py:29-43:
-// shadow = decay*shadow + (1-decay)*param, applied after the parameter update.
+// gradient, bias-corrected moments, eps added to sqrt(v_hat)); EMA.ema_step of arcnerf/trainer/ema.py:29-43 (JNeRF
+// style): new = ((1-d)*p + d*old*(1-d^(n-1))) / (1-d^n), and the average is WRITTEN BACK into the parameter.
+// The gradient buffer can be cleared in the same pass (zero_grad), saving one 4 B/param sweep per step.
 #include "common.hpp"
 
 namespace arcn {
@@ -9,20 +10,26 @@ namespace arcn {
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, float *e, float lr, float b1, float b2, float eps,
-                                      float wd, float ema_decay, float gscale, float bc1, float bc2_sqrt) {
+                                      float wd, float ema_decay, float gscale, float bc1, float bc2_sqrt, float deb_old,
+                                      float deb_new) {
     g = g * gscale;
     if (wd != 0.f) g = g + wd * p;
     m = b1 * m + (1.0f - b1) * g;
     v = b2 * v + (1.0f - b2) * g * g;
     const float denom = sqrtf(v) / bc2_sqrt + eps;
     p = p - (lr / bc1) * (m / denom);
-    if (e) *e = ema_decay * (*e) + (1.0f - ema_decay) * p;
+    if (e) {
+        const float avg = ((1.0f - ema_decay) * p + ema_decay * (*e) * deb_old) * deb_new;
+        *e = avg;
+        p = avg;
+    }
 }
 
-__global__ void __launch_bounds__(256) adam_ema_kernel(float *__restrict__ param, const float *__restrict__ grad,
+__global__ void __launch_bounds__(256) adam_ema_kernel(float *__restrict__ param, float *__restrict__ grad,
                                                        float *__restrict__ m, float *__restrict__ v, float *__restrict__ ema,
                                                        int64_t n, float lr, float b1, float b2, float eps, float wd,
-                                                       float ema_decay, float gscale, float bc1, float bc2_sqrt) {
+                                                       float ema_decay, float gscale, float bc1, float bc2_sqrt, float deb_old,
+                                                       float deb_new, int zero_grad) {
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -36,24 +43,28 @@ __global__ void __launch_bounds__(256) adam_ema_kernel(float *__restrict__ param
         float vv[4] = {v4.x, v4.y, v4.z, v4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            adam1(p[k], g[k], mm[k], vv[k], ema ? &ee[k] : nullptr, lr, b1, b2, eps, wd, ema_decay, gscale, bc1, bc2_sqrt);
+            adam1(p[k], g[k], mm[k], vv[k], ema ? &ee[k] : nullptr, lr, b1, b2, eps, wd, ema_decay, gscale, bc1, bc2_sqrt, deb_old, deb_new);
         reinterpret_cast<f4 *>(param)[i] = f4{p[0], p[1], p[2], p[3]};
         reinterpret_cast<f4 *>(m)[i] = f4{mm[0], mm[1], mm[2], mm[3]};
         reinterpret_cast<f4 *>(v)[i] = f4{vv[0], vv[1], vv[2], vv[3]};
         if (ema) reinterpret_cast<f4 *>(ema)[i] = f4{ee[0], ee[1], ee[2], ee[3]};
+        if (zero_grad) reinterpret_cast<f4 *>(grad)[i] = f4{0.f, 0.f, 0.f, 0.f};
     }
     // tail
     const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) adam1(param[t], grad[t], m[t], v[t], ema ? &ema[t] : nullptr, lr, b1, b2, eps, wd, ema_decay, gscale, bc1, bc2_sqrt);
+    if (t < n) {
+        adam1(param[t], grad[t], m[t], v[t], ema ? &ema[t] : nullptr, lr, b1, b2, eps, wd, ema_decay, gscale, bc1, bc2_sqrt, deb_old, deb_new);
+        if (zero_grad) grad[t] = 0.f;
+    }
 }
 
 }  // namespace arcn
 
 using namespace arcn;
 
-ARCN_EXPORT int arcn_adam_ema_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *ema, int64_t n,
+ARCN_EXPORT int arcn_adam_ema_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, float *ema, int64_t n,
                                    float lr, float beta1, float beta2, float eps, float weight_decay, float ema_decay,
-                                   float grad_scale, int step, void *stream) {
+                                   float grad_scale, int step, int ema_step, int zero_grad, void *stream) {
     if (n <= 0) return ARCN_OK;
     if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return einval("adam_ema_step: missing/invalid argument");
     if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
@@ -62,9 +73,13 @@ ARCN_EXPORT int arcn_adam_ema_step(float *param, const float *grad, float *exp_a
     // bias corrections in double like torch (1 - beta**step), passed as fp32
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    if (ema && ema_step < 1) return einval("adam_ema_step: ema_step is 1-based");
+    const double d = (double)ema_decay;
+    const float deb_old = ema ? (float)(1.0 - pow(d, (double)(ema_step - 1))) : 0.f;
+    const float deb_new = ema ? (float)(1.0 / (1.0 - pow(d, (double)ema_step))) : 0.f;
     int64_t blocks = ceil_div<int64_t>((n >> 2) + 1, 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq,
-                       ema, n, lr, beta1, beta2, eps, weight_decay, ema_decay, grad_scale, bc1, bc2_sqrt);
+                       ema, n, lr, beta1, beta2, eps, weight_decay, ema_decay, grad_scale, bc1, bc2_sqrt, deb_old, deb_new, zero_grad);
     return check_launch("adam_ema_step");
 }

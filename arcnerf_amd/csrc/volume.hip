@@ -343,6 +343,30 @@ __global__ void __launch_bounds__(256) update_opafield_kernel(float *__restrict_
     opa[idx[i]] = (old >= 0) ? upd : old;
 }
 
+// Sort-free form of VolumeBound.optimize's update (volume_bound.py:199-211): the reference does
+// torch.unique(voxel_idx) + segmented max (K4) + update_opafield_by_voxel_idx.  Here: pass 1 scatters the per-sample
+// opacity with a uint atomicMax into a zeroed per-cell buffer and marks the cell; pass 2 walks the grid and applies
+// max(old*ema, new) to marked cells with old >= 0.  Identical result for non-negative opacities (sigma*dt >= 0).
+__global__ void __launch_bounds__(256) opa_scatter_max_kernel(const int64_t *__restrict__ cell, const float *__restrict__ opacity,
+                                                              int64_t n, float *__restrict__ cell_max,
+                                                              uint8_t *__restrict__ touched) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t c = cell[i];
+    atomicMax(reinterpret_cast<unsigned int *>(&cell_max[c]), __float_as_uint(opacity[i]));
+    touched[c] = 1;
+}
+
+__global__ void __launch_bounds__(256) opa_apply_kernel(float *__restrict__ opa, const float *__restrict__ cell_max,
+                                                        const uint8_t *__restrict__ touched, int64_t n_cells, float ema) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells || !touched[c]) return;
+    const float old = opa[c];
+    float upd = cell_max[c];
+    if (ema >= 0.0f) { float a = old * ema; upd = a > upd ? a : upd; }
+    if (old >= 0) opa[c] = upd;
+}
+
 // workspace[0] = sum of clamp(opa,0) (double-free fp32 tree: per-block sums accumulated atomically), then threshold
 __global__ void __launch_bounds__(256) opa_sum_kernel(const float *__restrict__ opa, int64_t n, double *__restrict__ acc) {
     double s = 0.0;
@@ -502,4 +526,19 @@ ARCN_EXPORT int arcn_update_bitfield_by_opafield(const float *opafield, uint8_t 
     hipLaunchKernelGGL(opa_threshold_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), opafield, bitfield, n,
                        threshold, acc);
     return check_launch("update_bitfield_by_opafield");
+}
+
+ARCN_EXPORT int arcn_opafield_scatter_update(float *opafield, const int64_t *cell_idx, const float *opacity, int64_t n,
+                                             int64_t n_cells, float ema, float *cell_max, uint8_t *touched, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!opafield || !cell_idx || !opacity || !cell_max || !touched || n_cells <= 0)
+        return einval("opafield_scatter_update: missing argument");
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(cell_max, 0, sizeof(float) * n_cells, st) != hipSuccess) return check_launch("memset");
+    if (hipMemsetAsync(touched, 0, n_cells, st) != hipSuccess) return check_launch("memset");
+    hipLaunchKernelGGL(opa_scatter_max_kernel, dim3((unsigned)ceil_div<int64_t>(n, 256)), dim3(256), 0, st, cell_idx, opacity, n,
+                       cell_max, touched);
+    hipLaunchKernelGGL(opa_apply_kernel, dim3((unsigned)ceil_div<int64_t>(n_cells, 256)), dim3(256), 0, st, opafield, cell_max,
+                       touched, n_cells, ema);
+    return check_launch("opafield_scatter_update");
 }

@@ -182,7 +182,7 @@ def hashgrid_fwd(xyz, table, desc, want_idx=False, n_dev=None, out=None):
     return (out, idx) if want_idx else out
 
 
-def hashgrid_bwd(xyz, table, dout, desc, want_dtable=True, want_dxyz=False, n_dev=None, dtable=None):
+def hashgrid_bwd(xyz, table, dout, desc, want_dtable=True, want_dxyz=False, n_dev=None, dtable=None, workspace=None):
     _req(xyz, table, dout)
     xyz, table, dout = _f32(xyz), _f32(table), _f32(dout)
     n = xyz.shape[0]
@@ -190,8 +190,8 @@ def hashgrid_bwd(xyz, table, dout, desc, want_dtable=True, want_dxyz=False, n_de
         dtable = torch.zeros_like(table)
     dxyz = torch.zeros((n, 3), dtype=torch.float32, device=xyz.device) if want_dxyz else None
     N.check(N.lib().arcn_hashgrid_bwd(N.ptr(xyz), N.ptr(table), N.ptr(dout), C.addressof(desc),
-                                     N.ptr(dtable) if want_dtable else None, N.ptr(dxyz), n, _nptr(n_dev), N.stream()),
-            'hashgrid_bwd')
+                                     N.ptr(dtable) if want_dtable else None, N.ptr(dxyz), N.ptr(workspace), n,
+                                     _nptr(n_dev), N.stream()), 'hashgrid_bwd')
     return dtable, dxyz
 
 
@@ -238,6 +238,33 @@ def act_bwd(x, y, dy, act, beta=1.0):
     N.check(N.lib().arcn_act_bwd(N.ptr(x), N.ptr(y), N.ptr(dy), N.ptr(dx), x.numel(), N.ACT[act], float(beta), N.stream()),
             'act_bwd')
     return dx
+
+
+def ngp_glue_fwd(geo_out, dirs, feat_off, Wf, sh_degree, feat_first=True, sigma_act='truncexp', n_dev=None,
+                 rad_in=None, sigma=None):
+    _req(geo_out, dirs)
+    n, Wg = geo_out.shape
+    W = Wf + sh_degree * sh_degree
+    if rad_in is None:
+        rad_in = torch.empty((n, W), dtype=torch.float32, device=geo_out.device)
+    if sigma is None:
+        sigma = torch.empty(n, dtype=torch.float32, device=geo_out.device)
+    N.check(N.lib().arcn_ngp_glue_fwd(N.ptr(geo_out), N.ptr(dirs), Wg, int(feat_off), int(Wf), int(sh_degree),
+                                     int(feat_first), N.ACT[sigma_act], N.ptr(rad_in), N.ptr(sigma), n, _nptr(n_dev),
+                                     N.stream()), 'ngp_glue_fwd')
+    return rad_in, sigma
+
+
+def ngp_glue_bwd(geo_out, d_rad_in, d_sigma, feat_off, Wf, sh_degree, feat_first=True, sigma_act='truncexp', n_dev=None,
+                 d_geo_out=None):
+    _req(geo_out, d_rad_in, d_sigma)
+    n, Wg = geo_out.shape
+    if d_geo_out is None:
+        d_geo_out = torch.empty_like(geo_out)
+    N.check(N.lib().arcn_ngp_glue_bwd(N.ptr(geo_out), N.ptr(d_rad_in), N.ptr(d_sigma), Wg, int(feat_off), int(Wf),
+                                     int(sh_degree), int(feat_first), N.ACT[sigma_act], N.ptr(d_geo_out), n, _nptr(n_dev),
+                                     N.stream()), 'ngp_glue_bwd')
+    return d_geo_out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -388,6 +415,23 @@ def update_opafield(opafield, flat_idx, opacity, ema=None):
     return opafield
 
 
+def opafield_scatter_update(opafield, cell_idx, opacity, ema=None, cell_max=None, touched=None):
+    """unique + segmented max + EMA update of the occupancy field for repeated flat cell indices, without a sort."""
+    _req(opafield, cell_idx, opacity)
+    assert opafield.is_contiguous() and opafield.dtype == torch.float32
+    idx = cell_idx.contiguous().long()
+    op = _f32(opacity)
+    nc = opafield.numel()
+    if cell_max is None:
+        cell_max = torch.empty(nc, dtype=torch.float32, device=opafield.device)
+    if touched is None:
+        touched = torch.empty(nc, dtype=torch.uint8, device=opafield.device)
+    N.check(N.lib().arcn_opafield_scatter_update(N.ptr(opafield), N.ptr(idx), N.ptr(op), idx.shape[0], nc,
+                                                -1.0 if ema is None else float(ema), N.ptr(cell_max), N.ptr(touched),
+                                                N.stream()), 'opafield_scatter_update')
+    return opafield
+
+
 def update_bitfield_by_opafield(opafield, bitfield, threshold):
     _req(opafield, bitfield)
     assert opafield.is_contiguous() and bitfield.is_contiguous()
@@ -398,9 +442,11 @@ def update_bitfield_by_opafield(opafield, bitfield, threshold):
 
 
 def adam_ema_step(param, grad, exp_avg, exp_avg_sq, ema, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                  ema_decay=0.95, grad_scale=1.0):
+                  ema_decay=0.95, grad_scale=1.0, ema_step=None, zero_grad=False):
+    """torch.optim.Adam step + the reference's EMA.ema_step (average written back into param), one pass."""
     _req(param, grad, exp_avg, exp_avg_sq, ema)
     N.check(N.lib().arcn_adam_ema_step(N.ptr(param), N.ptr(grad), N.ptr(exp_avg), N.ptr(exp_avg_sq), N.ptr(ema),
                                       param.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
-                                      float(weight_decay), float(ema_decay), float(grad_scale), int(step), N.stream()),
+                                      float(weight_decay), float(ema_decay), float(grad_scale), int(step),
+                                      int(step if ema_step is None else ema_step), int(zero_grad), N.stream()),
             'adam_ema_step')

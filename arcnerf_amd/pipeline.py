@@ -1,0 +1,438 @@
+"""Compacted-sample NGP pipeline: the MI355X fast path of the reference's instant-ngp configuration
+(configs/models/nerf_ngp.yaml + configs/expr/NeRF/lego/nerf_lego_nerf_ngp.yaml).
+
+One training step = the reference call stack of SURVEY.md §3.1 without its dense (R, 1024) tensors and host syncs:
+
+    rays --march_count/scan/write--> (offsets[R+1], t[S], ray_id[S])            FgModel.forward :178-186 (K2 + K3)
+         --packed_points-->           xyz[S,3], dirs[S,3]                        get_sigma_radiance_by_mask_pts :283-292
+         --hashgrid_fwd-->            feat[S,32]                                 HashGridEmbedder.forward
+         --mlp_fwd (geo)-->           geo_out[S,16]                              FusedMLPGeoNet.forward
+         --ngp_glue_fwd-->            sigma[S] = exp(geo_out[:,0]), rad_in[S,32] = [geo_out, SH(dir)]
+         --mlp_fwd (rad)-->           rgb[S,3] (sigmoid)                         FusedMLPRadianceNet.forward
+         --composite_packed_fwd-->    rgb/depth/mask per ray                     Base3dModel.ray_marching
+         <-- loss (Huber) / composite_packed_bwd / mlp_bwd / ngp_glue_bwd / mlp_bwd / hashgrid_bwd
+         [all-reduce of the flat gradient buffer when world_size > 1]
+         --adam_ema_step-->           params (Adam + the reference's write-back EMA), gradient cleared
+
+The sample count S lives on the device (offsets[R]); every buffer is pre-allocated at capacity and every kernel takes the
+device-side count, so the whole step issues no host synchronisation.  All parameters live in ONE flat fp32 buffer
+[hash table | geo W | radiance W] so the optimiser is one kernel and data-parallel training needs one collective.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .ops import functional as F
+
+
+class NgpConfig:
+    """Hyper-parameters of configs/models/nerf_ngp.yaml (defaults) — field names follow the yaml keys."""
+
+    def __init__(self, **kw):
+        # encoder (HashGridEmbedder)
+        self.n_levels = 16
+        self.n_feat_per_entry = 2
+        self.hashmap_size = 19
+        self.base_res = 16
+        self.max_res = 2048
+        self.side = 2.0
+        self.origin = (0.0, 0.0, 0.0)
+        # geometry net (FusedMLPGeoNet): W, D hidden layers, W_feat outputs, sigma = TruncExp(out[:,0])
+        self.geo_W = 64
+        self.geo_D = 1
+        self.W_feat = 16
+        self.geo_fused_semantics = True  # True: feat = whole output (tcnn module); False: out = [sigma | feat] (GeoNet)
+        self.sigma_act = 'truncexp'
+        # radiance net (FusedMLPRadianceNet, mode 'fv'): SH degree 4 view encoding
+        self.rad_W = 64
+        self.rad_D = 2
+        self.sh_degree = 4
+        self.rad_mode = 'fv'
+        self.has_bias = False
+        # obj_bound.volume + rays
+        self.n_grid = 128
+        self.n_sample = 1024
+        self.near_distance = 0.2
+        self.add_inf_z = False
+        self.white_bkg = False
+        self.noise_std = 1.0
+        self.opa_thres = 0.01
+        self.ema_optim_decay = 0.95
+        self.epoch_optim = 16
+        self.epoch_optim_warmup = 256
+        # optimiser block of nerf_lego_nerf_ngp.yaml
+        self.lr = 1e-1
+        self.eps = 1e-15
+        self.weight_decay = 1e-6
+        self.betas = (0.9, 0.999)
+        self.ema_decay = 0.95
+        self.huber_delta = 0.1
+        self.loss_weight = 3000.0
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise KeyError(k)
+            setattr(self, k, v)
+
+    @property
+    def dt(self):
+        """const_dt = volume.get_diag_len() / n_pts (volume_bound.py:112)"""
+        return float(np.float32(math.sqrt(3.0 * self.side * self.side)) / np.float32(self.n_sample))
+
+
+def hashgrid_level_table(n_levels, hashmap_size, base_res, max_res):
+    """HashGridEmbedder.init_embeddings (hashgrid_encoder.py:126-158): per_level_scale is a fp32 torch scalar."""
+    pls = torch.exp((torch.log(torch.tensor(max_res / base_res))) / (float(n_levels) - 1))
+    res, offs, total = [], [], 0
+    for i in range(n_levels):
+        offs.append(total)
+        r = math.ceil(2 ** (i * math.log2(pls)) * base_res - 1.0)
+        res.append(r)
+        total += min(2 ** hashmap_size, (r + 1) ** 3)
+    offs.append(total)
+    return res, offs
+
+
+class NgpField:
+    """Parameters of the NGP radiance field in one flat buffer + the kernel descriptors."""
+
+    def __init__(self, cfg, device='cuda', seed=0):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        res, offs = hashgrid_level_table(cfg.n_levels, cfg.hashmap_size, cfg.base_res, cfg.max_res)
+        self.resolutions, self.offsets = res, offs
+        half = cfg.side / 2.0
+        self.min_xyz = [cfg.origin[k] - half for k in range(3)]
+        self.max_xyz = [cfg.origin[k] + half for k in range(3)]
+        self.grid_desc = N.make_hashgrid_desc(res, offs, cfg.n_feat_per_entry, self.min_xyz, self.max_xyz)
+        enc_dim = cfg.n_levels * cfg.n_feat_per_entry
+        self.geo_out_dim = cfg.W_feat if cfg.geo_fused_semantics else 1 + cfg.W_feat
+        self.feat_off = 0 if cfg.geo_fused_semantics else 1
+        geo_dims = [enc_dim] + [cfg.geo_W] * cfg.geo_D + [self.geo_out_dim]
+        rad_in = cfg.W_feat + cfg.sh_degree ** 2
+        rad_dims = [rad_in] + [cfg.rad_W] * cfg.rad_D + [3]
+        self.geo_dims, self.rad_dims = geo_dims, rad_dims
+        self.geo_desc = N.make_mlp_desc(geo_dims, 'relu', None, has_bias=cfg.has_bias)
+        self.rad_desc = N.make_mlp_desc(rad_dims, 'relu', 'sigmoid', has_bias=cfg.has_bias)
+        # flat layout, every segment a multiple of 4 floats (16-byte aligned views for the fused optimiser)
+        def pad4(n):
+            return (n + 3) // 4 * 4
+        self.n_table = offs[-1] * cfg.n_feat_per_entry
+        self.n_geo_w = sum(geo_dims[i] * geo_dims[i + 1] for i in range(len(geo_dims) - 1))
+        self.n_rad_w = sum(rad_dims[i] * rad_dims[i + 1] for i in range(len(rad_dims) - 1))
+        self.n_geo_b = sum(geo_dims[1:]) if cfg.has_bias else 0
+        self.n_rad_b = sum(rad_dims[1:]) if cfg.has_bias else 0
+        self._seg = {}
+        off = 0
+        for name, n in (('table', self.n_table), ('geo_w', self.n_geo_w), ('rad_w', self.n_rad_w), ('geo_b', self.n_geo_b),
+                        ('rad_b', self.n_rad_b)):
+            self._seg[name] = (off, n)
+            off += pad4(n)
+        self.n_params = off
+        self.params = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.reset_parameters(seed)
+
+    def view(self, name, buf=None):
+        off, n = self._seg[name]
+        if n == 0:
+            return None
+        return (self.params if buf is None else buf)[off:off + n]
+
+    def reset_parameters(self, seed=0):
+        """table ~ U(-1e-4, 1e-4) (hashgrid_encoder.py:155-156); dense layers: torch.nn.Linear default init."""
+        g = torch.Generator(device='cpu').manual_seed(seed)
+        cfg = self.cfg
+        self.view('table').copy_((torch.rand(self.n_table, generator=g) * 2e-4 - 1e-4).to(self.device))
+        for name, dims in (('geo', self.geo_dims), ('rad', self.rad_dims)):
+            ws, bs = [], []
+            for i in range(len(dims) - 1):
+                bound = 1.0 / math.sqrt(dims[i])
+                ws.append((torch.rand(dims[i + 1] * dims[i], generator=g) * 2 - 1) * bound)
+                bs.append((torch.rand(dims[i + 1], generator=g) * 2 - 1) * bound)
+            self.view(name + '_w').copy_(torch.cat(ws).to(self.device))
+            if cfg.has_bias:
+                self.view(name + '_b').copy_(torch.cat(bs).to(self.device))
+
+    # ---- numpy export for the oracle-based checks ------------------------------------------------
+    def export_numpy(self):
+        out = {'table': self.view('table').detach().cpu().numpy().reshape(-1, self.cfg.n_feat_per_entry)}
+        for name, dims in (('geo', self.geo_dims), ('rad', self.rad_dims)):
+            w = self.view(name + '_w').detach().cpu().numpy()
+            b = self.view(name + '_b').detach().cpu().numpy() if self.cfg.has_bias else None
+            layers, o, ob = [], 0, 0
+            for i in range(len(dims) - 1):
+                n = dims[i] * dims[i + 1]
+                layers.append((w[o:o + n].reshape(dims[i + 1], dims[i]), None if b is None else b[ob:ob + dims[i + 1]]))
+                o += n
+                ob += dims[i + 1]
+            out[name] = layers
+        return out
+
+
+class NgpPipeline:
+    """Pre-allocated buffers + the kernel sequence of one render / train step for a fixed ray capacity."""
+
+    def __init__(self, field, max_rays=32768, max_samples=1 << 19, packed_bits=True, torch_aabb=False, xcd_scatter=True):
+        cfg = field.cfg
+        self.field, self.cfg = field, cfg
+        dev = field.device
+        self.max_rays, self.cap = int(max_rays), int(max_samples)
+        self.packed_bits = packed_bits
+        self.torch_aabb = torch_aabb
+        f32, i32 = torch.float32, torch.int32
+        S, R = self.cap, self.max_rays
+        self.aabb23 = torch.tensor([field.min_xyz, field.max_xyz], dtype=f32, device=dev)
+        self.rng = F.Pcg32Host(9121)
+        E = cfg.n_levels * cfg.n_feat_per_entry
+        b = self.buf = {}
+        b['scratch_t'] = torch.empty((R, cfg.n_sample), dtype=f32, device=dev)
+        b['counts'] = torch.zeros(R, dtype=i32, device=dev)
+        b['offsets'] = torch.zeros(R + 1, dtype=i32, device=dev)
+        b['near'] = torch.empty(R, dtype=f32, device=dev)
+        b['far'] = torch.empty(R, dtype=f32, device=dev)
+        b['t'] = torch.zeros(S, dtype=f32, device=dev)
+        b['ray_id'] = torch.zeros(S, dtype=i32, device=dev)
+        b['xyz'] = torch.zeros((S, 3), dtype=f32, device=dev)
+        b['dirs'] = torch.zeros((S, 3), dtype=f32, device=dev)
+        b['feat'] = torch.zeros((S, E), dtype=f32, device=dev)
+        b['geo_out'] = torch.zeros((S, field.geo_out_dim), dtype=f32, device=dev)
+        b['geo_acts'] = torch.zeros(max(1, F.mlp_acts_floats(field.geo_desc, S)), dtype=f32, device=dev)
+        b['rad_in'] = torch.zeros((S, field.rad_dims[0]), dtype=f32, device=dev)
+        b['sigma'] = torch.zeros(S, dtype=f32, device=dev)
+        b['rgb_s'] = torch.zeros((S, 3), dtype=f32, device=dev)
+        b['rad_acts'] = torch.zeros(max(1, F.mlp_acts_floats(field.rad_desc, S)), dtype=f32, device=dev)
+        b['noise'] = torch.zeros(S, dtype=f32, device=dev)
+        # backward
+        b['d_sigma'] = torch.zeros(S, dtype=f32, device=dev)
+        b['d_rgb_s'] = torch.zeros((S, 3), dtype=f32, device=dev)
+        b['d_rad_in'] = torch.zeros((S, field.rad_dims[0]), dtype=f32, device=dev)
+        b['d_geo_out'] = torch.zeros((S, field.geo_out_dim), dtype=f32, device=dev)
+        b['d_feat'] = torch.zeros((S, E), dtype=f32, device=dev)
+        b['mlp_scratch'] = torch.zeros(max(F.mlp_scratch_floats(field.geo_desc, S), F.mlp_scratch_floats(field.rad_desc, S)),
+                                       dtype=f32, device=dev)
+        # per-ray outputs
+        b['rgb'] = torch.zeros((R, 3), dtype=f32, device=dev)
+        b['depth'] = torch.zeros(R, dtype=f32, device=dev)
+        b['mask'] = torch.zeros(R, dtype=f32, device=dev)
+        b['p_dense'] = torch.full((1,), 2, dtype=i32, device=dev)
+        # XCD-owned-levels scatter workspace (owner + tile counters); None selects the plain agent-scope kernel
+        self.hash_ws = torch.zeros(2 * N.MAX_LEVELS, dtype=i32, device=dev) if xcd_scatter else None
+        # optimiser state
+        n = field.n_params
+        self.exp_avg = torch.zeros(n, dtype=f32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=f32, device=dev)
+        self.ema = field.params.clone()
+        self.step_count = 0
+        # occupancy (Volume bitfield/opafield, volume.py:741-760,959-969)
+        ng = cfg.n_grid
+        self.bitfield = torch.ones(ng ** 3, dtype=torch.bool, device=dev)
+        self.opafield = torch.zeros(ng ** 3, dtype=f32, device=dev)
+        self._bits = None
+        self._occ_scratch = None
+        self.set_bitfield(self.bitfield)
+
+    # ---- occupancy ------------------------------------------------------------------------------
+    def set_bitfield(self, bitfield_bool):
+        """bitfield (n_grid^3 | n_grid,n_grid,n_grid) bool, flat index x*n*n + y*n + z"""
+        self.bitfield = bitfield_bool.reshape(-1).to(self.field.device).contiguous()
+        if self.packed_bits:
+            ng3 = self.bitfield.numel()
+            assert ng3 % 8 == 0
+            w = (2 ** torch.arange(8, device=self.field.device, dtype=torch.int32))
+            self._bits = (self.bitfield.view(-1, 8).to(torch.int32) * w).sum(-1).to(torch.uint8).contiguous()
+
+    def _occ(self):
+        return self._bits if self.packed_bits else self.bitfield
+
+    # ---- forward --------------------------------------------------------------------------------
+    def sample(self, rays_o, rays_d):
+        """[A] bounds + occupancy marching in packed form (no host sync).  Advances the pcg32 like the reference."""
+        cfg, b = self.cfg, self.buf
+        R = rays_o.shape[0]
+        assert R <= self.max_rays
+        L = N.lib()
+        st = N.stream()
+        N.check(L.arcn_march_count(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
+                                   int(self.packed_bits), cfg.n_sample, cfg.dt, cfg.near_distance, int(self.torch_aabb),
+                                   self.rng.state, self.rng.inc, N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['near']),
+                                   N.ptr(b['far']), R, st), 'march_count')
+        self.rng.advance()
+        N.check(L.arcn_exclusive_scan_i32(N.ptr(b['counts']), N.ptr(b['offsets']), R, st), 'scan')
+        N.check(L.arcn_march_write(N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['offsets']), cfg.n_sample, N.ptr(b['t']),
+                                   N.ptr(b['ray_id']), R, self.cap, st), 'march_write')
+        self.n_dev = b['offsets'][R:R + 1]  # device-side sample count (view, no sync)
+        # dense width the reference would have used: max(2, max count) (fg_model.py:251-262)
+        torch.clamp(b['counts'][:R].max(), min=2, out=b['p_dense'][0])
+        return self.n_dev
+
+    def forward(self, rays_o, rays_d, bkg_color=None, train=False, noise=None):
+        """Render rays: returns rgb (R,3), depth (R), mask (R) views of the internal buffers."""
+        cfg, b, fld = self.cfg, self.buf, self.field
+        R = rays_o.shape[0]
+        rays_o, rays_d = rays_o.contiguous().float(), rays_d.contiguous().float()
+        n_dev = self.sample(rays_o, rays_d)
+        S = self.cap
+        L, st = N.lib(), N.stream()
+        N.check(L.arcn_packed_points(N.ptr(rays_o), N.ptr(rays_d), N.ptr(b['t']), N.ptr(b['ray_id']), N.ptr(b['xyz']),
+                                     N.ptr(b['dirs']), S, n_dev.data_ptr(), st), 'packed_points')
+        F.hashgrid_fwd(b['xyz'], fld.view('table'), fld.grid_desc, n_dev=n_dev, out=b['feat'])
+        F.mlp_fwd(b['feat'], fld.view('geo_w'), fld.view('geo_b'), fld.geo_desc, save_acts=train, n_dev=n_dev, out=b['geo_out'],
+                  acts=b['geo_acts'])
+        F.ngp_glue_fwd(b['geo_out'], b['dirs'], fld.feat_off, cfg.W_feat, cfg.sh_degree, feat_first=(cfg.rad_mode == 'fv'),
+                       sigma_act=cfg.sigma_act, n_dev=n_dev, rad_in=b['rad_in'], sigma=b['sigma'])
+        F.mlp_fwd(b['rad_in'], fld.view('rad_w'), fld.view('rad_b'), fld.rad_desc, save_acts=train, n_dev=n_dev, out=b['rgb_s'],
+                  acts=b['rad_acts'])
+        bk, bk_rows = (None, 0) if bkg_color is None else (bkg_color.contiguous().float().view(-1, 3), bkg_color.view(-1, 3).shape[0])
+        self._bkg = bk
+        self._noise = noise
+        N.check(L.arcn_composite_packed_fwd(N.ptr(b['sigma']), N.ptr(b['rgb_s']), N.ptr(b['t']), N.ptr(b['offsets']),
+                                            N.ptr(noise), N.ptr(bk), bk_rows, R, 2, b['p_dense'].data_ptr(),
+                                            int(cfg.add_inf_z), int(cfg.white_bkg), N.ptr(b['rgb']), N.ptr(b['depth']),
+                                            N.ptr(b['mask']), None, st), 'composite_packed_fwd')
+        return b['rgb'][:R], b['depth'][:R], b['mask'][:R]
+
+    # ---- backward + optimiser -----------------------------------------------------------------------
+    def backward(self, rays_o, rays_d, d_rgb, d_depth=None, d_mask=None):
+        """Accumulate d loss / d params into field.grads given the per-ray output gradients of the last forward(train=True)."""
+        cfg, b, fld = self.cfg, self.buf, self.field
+        R = rays_o.shape[0]
+        L, st = N.lib(), N.stream()
+        n_dev = self.n_dev
+        bk = self._bkg
+        bk_rows = 0 if bk is None else bk.shape[0]
+        N.check(L.arcn_composite_packed_bwd(N.ptr(b['sigma']), N.ptr(b['rgb_s']), N.ptr(b['t']), N.ptr(b['offsets']),
+                                            N.ptr(self._noise), N.ptr(bk), bk_rows, R, 2, b['p_dense'].data_ptr(),
+                                            int(cfg.add_inf_z), int(cfg.white_bkg), N.ptr(d_rgb), N.ptr(d_depth), N.ptr(d_mask),
+                                            N.ptr(b['d_sigma']), N.ptr(b['d_rgb_s']), st), 'composite_packed_bwd')
+        S = self.cap
+        g = fld.grads
+        N.check(L.arcn_mlp_bwd(N.ptr(b['rad_in']), N.ptr(fld.view('rad_w')), N.ptr(fld.view('rad_b')), N.C.addressof(fld.rad_desc),
+                               N.ptr(b['rgb_s']), N.ptr(b['rad_acts']), N.ptr(b['d_rgb_s']), N.ptr(b['d_rad_in']),
+                               N.ptr(fld.view('rad_w', g)), N.ptr(fld.view('rad_b', g)), N.ptr(b['mlp_scratch']), S, S,
+                               n_dev.data_ptr(), st), 'mlp_bwd(rad)')
+        F.ngp_glue_bwd(b['geo_out'], b['d_rad_in'], b['d_sigma'], fld.feat_off, cfg.W_feat, cfg.sh_degree,
+                       feat_first=(cfg.rad_mode == 'fv'), sigma_act=cfg.sigma_act, n_dev=n_dev, d_geo_out=b['d_geo_out'])
+        N.check(L.arcn_mlp_bwd(N.ptr(b['feat']), N.ptr(fld.view('geo_w')), N.ptr(fld.view('geo_b')), N.C.addressof(fld.geo_desc),
+                               N.ptr(b['geo_out']), N.ptr(b['geo_acts']), N.ptr(b['d_geo_out']), N.ptr(b['d_feat']),
+                               N.ptr(fld.view('geo_w', g)), N.ptr(fld.view('geo_b', g)), N.ptr(b['mlp_scratch']), S, S,
+                               n_dev.data_ptr(), st), 'mlp_bwd(geo)')
+        N.check(L.arcn_hashgrid_bwd(N.ptr(b['xyz']), N.ptr(fld.view('table')), N.ptr(b['d_feat']), N.C.addressof(fld.grid_desc),
+                                    N.ptr(fld.view('table', g)), None, N.ptr(self.hash_ws), S, n_dev.data_ptr(), st),
+                'hashgrid_bwd')
+
+    def huber_grad(self, rgb, target):
+        """ImgLoss(Huber, delta, weight) of arcnerf/loss/img_loss.py:60-100: loss value and d loss / d rgb (mean over R*3)."""
+        cfg = self.cfg
+        diff = rgb - target
+        ad = diff.abs()
+        loss = torch.where(ad < cfg.huber_delta, 0.5 / cfg.huber_delta * ad * ad, ad - 0.5 * cfg.huber_delta).mean() * cfg.loss_weight
+        scale = cfg.loss_weight / diff.numel()
+        d = torch.where(ad < cfg.huber_delta, diff / cfg.huber_delta, torch.sign(diff)) * scale
+        return loss, d.contiguous()
+
+    def optimizer_step(self, world_size=1):
+        cfg, fld = self.cfg, self.field
+        self.step_count += 1
+        F.adam_ema_step(fld.params, fld.grads, self.exp_avg, self.exp_avg_sq, self.ema, self.step_count, lr=cfg.lr,
+                        betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, ema_decay=cfg.ema_decay,
+                        grad_scale=1.0 / world_size, zero_grad=True)
+
+    def train_step(self, rays_o, rays_d, target_rgb, bkg_color=None, all_reduce=None, world_size=1):
+        """fwd + loss + bwd (+ one gradient all-reduce) + Adam/EMA.  Returns the loss tensor (device, no sync)."""
+        cfg, b = self.cfg, self.buf
+        noise = None
+        if cfg.noise_std > 0:
+            noise = b['noise'].normal_(0.0, cfg.noise_std)
+        rgb, _, _ = self.forward(rays_o, rays_d, bkg_color, train=True, noise=noise)
+        loss, d_rgb = self.huber_grad(rgb, target_rgb)
+        self.backward(rays_o, rays_d, d_rgb)
+        if all_reduce is not None:
+            all_reduce(self.field.grads)
+        self.optimizer_step(world_size)
+        return loss
+
+    # ---- occupancy update (VolumeBound.optimize, volume_bound.py:160-212) -----------------------------
+    def update_occupancy(self, cur_epoch, apply=True):
+        """Sample voxels, evaluate opacity = sigma * dt with the geo net, EMA-max into the opacity field and re-threshold
+        the bitfield.  apply=False runs all the work but leaves the marching bitfield untouched (fixed-workload benches)."""
+        cfg, fld = self.cfg, self.field
+        dev = fld.device
+        ng = cfg.n_grid
+        n_cells = ng ** 3
+        if cur_epoch <= 0 or cfg.epoch_optim is None or cur_epoch % cfg.epoch_optim != 0:
+            return
+        if cfg.epoch_optim_warmup is not None and cur_epoch < cfg.epoch_optim_warmup:
+            cell = torch.arange(n_cells, device=dev)
+        else:
+            n_s = n_cells // 4
+            uni = torch.randperm(n_cells, device=dev)[:n_s]
+            occ = torch.nonzero(self.bitfield)[:n_s, 0]
+            cell = torch.cat([uni, occ])
+        vs = cfg.side / ng
+        ix = torch.div(cell, ng * ng, rounding_mode='floor')
+        iy = torch.div(cell, ng, rounding_mode='floor') % ng
+        iz = cell % ng
+        idx3 = torch.stack([ix, iy, iz], -1).float()
+        mn = torch.tensor(fld.min_xyz, device=dev)
+        pts = idx3 * vs + 0.5 * vs + mn
+        pts = pts + (torch.rand_like(pts) - 0.5) * vs
+        n = pts.shape[0]
+        if self._occ_scratch is None or self._occ_scratch['feat'].shape[0] < n:
+            self._occ_scratch = {
+                'feat': torch.empty((n, cfg.n_levels * cfg.n_feat_per_entry), dtype=torch.float32, device=dev),
+                'geo_out': torch.empty((n, fld.geo_out_dim), dtype=torch.float32, device=dev),
+                'cell_max': torch.empty(n_cells, dtype=torch.float32, device=dev),
+                'touched': torch.empty(n_cells, dtype=torch.uint8, device=dev),
+            }
+        sc = self._occ_scratch
+        pts = pts.contiguous()
+        F.hashgrid_fwd(pts, fld.view('table'), fld.grid_desc, out=sc['feat'][:n])
+        F.mlp_fwd(sc['feat'][:n], fld.view('geo_w'), fld.view('geo_b'), fld.geo_desc, out=sc['geo_out'][:n])
+        sigma = F.act_fwd(sc['geo_out'][:n, 0].contiguous(), cfg.sigma_act)
+        opacity = sigma * cfg.dt  # get_est_opacity (base_3d_model.py:386-389)
+        F.opafield_scatter_update(self.opafield, cell, opacity, ema=cfg.ema_optim_decay, cell_max=sc['cell_max'],
+                                  touched=sc['touched'])
+        new_bits = torch.empty_like(self.bitfield)
+        F.update_bitfield_by_opafield(self.opafield, new_bits, cfg.opa_thres)
+        if apply:
+            self.set_bitfield(new_bits)
+
+
+# ----------------------------------------------------------------------------------------------------
+# synthetic workload: Blender-like cameras on a sphere, blob occupancy
+# ----------------------------------------------------------------------------------------------------
+def synthetic_rays(n_rays, seed=0, device='cuda', radius=3.0 / 1.05, hw=800, camera_angle_x=0.6911):
+    """Pinhole rays from cameras uniform on a sphere looking at the origin (center_pixel=True)."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    focal = 0.5 * hw / math.tan(0.5 * camera_angle_x)
+    c = torch.randn(n_rays, 3, generator=g)
+    c = c / c.norm(dim=-1, keepdim=True) * radius
+    fwd = -c / c.norm(dim=-1, keepdim=True)
+    up = torch.tensor([0.0, 0.0, 1.0]).expand_as(fwd)
+    right = torch.cross(fwd, up, dim=-1)
+    right = right / (right.norm(dim=-1, keepdim=True) + 1e-8)
+    up2 = torch.cross(right, fwd, dim=-1)
+    px = (torch.rand(n_rays, 2, generator=g) * hw).floor() + 0.5
+    x = (px[:, 0:1] - hw / 2) / focal
+    y = (px[:, 1:2] - hw / 2) / focal
+    d = fwd + x * right - y * up2
+    d = d / d.norm(dim=-1, keepdim=True)
+    return c.float().to(device).contiguous(), d.float().to(device).contiguous()
+
+
+def synthetic_bitfield(n_grid=128, frac=0.05, seed=0):
+    """Union of a few boxes / spheres filling about `frac` of the grid (numpy, flat index x*n*n+y*n+z)."""
+    rng = np.random.default_rng(seed)
+    ax = (np.arange(n_grid) + 0.5) / n_grid * 2 - 1
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing='ij')
+    bf = np.zeros((n_grid,) * 3, bool)
+    while bf.mean() < frac:
+        c = (rng.random(3) - 0.5) * 1.0
+        r = rng.random() * 0.2 + 0.08
+        if rng.random() < 0.5:
+            bf |= ((X - c[0]) ** 2 + (Y - c[1]) ** 2 + (Z - c[2]) ** 2) < r * r
+        else:
+            bf |= (np.abs(X - c[0]) < r) & (np.abs(Y - c[1]) < r * 0.7) & (np.abs(Z - c[2]) < r * 0.5)
+    return bf

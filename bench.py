@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""bench.py — ray-samples/sec (train) of the NGP-Lego hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full training pass of the hot path over one batch of synthetic rays: occupancy
+marching -> hash-grid encode -> fused geo/radiance MLPs -> compositing -> Huber loss -> backward -> (one RCCL
+all-reduce of the flat gradient buffer when N > 1) -> fused Adam + EMA, plus the occupancy-grid refresh every 16 steps
+at the reference cadence (its result is kept off the marching bitfield so the workload stays the named configuration).
+Inputs (rays, targets, occupancy, parameters) are resident in HBM before the timed region.
+value = valid samples evaluated by the nets over all ranks / max-over-ranks wall time of the K timed steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E (MI355X_MICROARCH.md)
+# algorithmic bytes per valid sample (NGP config fp32 table)
+BYTES_HASH_FWD = 16 * 8 * 2 * 4 + 12 + 32 * 4          # 1164
+BYTES_HASH_BWD = 32 * 4 + 12 + 2 * (16 * 8 * 2 * 4)     # 128 grad in + xyz + atomic payload counted as RMW = 2188
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=64)
+    ap.add_argument('--warmup', type=int, default=16)
+    ap.add_argument('--target-samples', type=int, default=1 << 18, help='valid samples per step (log_max_allowance 18)')
+    ap.add_argument('--occupancy', type=float, default=0.05)
+    ap.add_argument('--no-occ-update', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-rays', type=int, default=49152)
+    return ap.parse_args()
+
+
+class KernelTimers:
+    """HIP events (torch.cuda.Event on the launch stream == torch's current stream) around individual kernels."""
+
+    def __init__(self):
+        self.pairs = {}
+
+    def wrap(self, name, fn):
+        def inner(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            self.pairs.setdefault(name, []).append((e0, e1))
+            return r
+        return inner
+
+    def reset(self):
+        self.pairs = {}
+
+    def summary(self):
+        return {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in self.pairs.items()}
+
+
+def instrument(timers):
+    """Time the C-ABI entry points that dominate the step (the library handle is shared by the whole package)."""
+    from arcnerf_amd import _native as N
+    lib = N.lib()
+
+    class Proxy:
+        def __init__(self, real):
+            self._real = real
+            self._cache = {}
+
+        def __getattr__(self, name):
+            if name not in self._cache:
+                fn = getattr(self._real, name)
+                timed = {'arcn_hashgrid_fwd', 'arcn_hashgrid_bwd', 'arcn_mlp_fwd', 'arcn_mlp_bwd', 'arcn_march_count',
+                         'arcn_composite_packed_fwd', 'arcn_composite_packed_bwd', 'arcn_adam_ema_step'}
+                self._cache[name] = timers.wrap(name[5:], fn) if name in timed else fn
+            return self._cache[name]
+
+    proxy = Proxy(lib)
+    N._lib = proxy
+    return lib
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU fallback for the product path)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline, synthetic_bitfield, synthetic_rays
+
+    cfg = NgpConfig()  # configs/models/nerf_ngp.yaml + nerf_lego_nerf_ngp.yaml
+    field = NgpField(cfg, device=dev, seed=0)  # identical init on every rank (DDP broadcasts rank 0's, same effect)
+    pipe = NgpPipeline(field, max_rays=32768, max_samples=1 << 20, packed_bits=True)
+    bf = synthetic_bitfield(cfg.n_grid, args.occupancy, seed=0)
+    pipe.set_bitfield(torch.from_numpy(bf))
+
+    # dynamic batch size (pipeline.py:222-241): n_rays such that the valid samples hit the allowance
+    o, d = synthetic_rays(8192, seed=1000 + rank, device=dev)
+    pipe.sample(o, d)
+    per_ray = float(pipe.n_dev.item()) / 8192.0
+    n_rays = int(min(32768, max(128, (int(args.target_samples / max(per_ray, 1e-3)) + 127) // 128 * 128)))
+    n_pool = 8
+    pool = []
+    g = torch.Generator(device='cpu').manual_seed(77 + rank)
+    for i in range(n_pool):
+        o, d = synthetic_rays(n_rays, seed=10 * rank + i, device=dev)
+        pool.append((o, d, torch.rand(n_rays, 3, generator=g).to(dev), torch.rand(n_rays, 3, generator=g).to(dev)))
+
+    timers = KernelTimers()
+    instrument(timers)
+    all_reduce = (lambda t: dist.all_reduce(t)) if world > 1 else None
+    sample_log = torch.zeros(args.steps + args.warmup, dtype=torch.int64, device=dev)
+
+    def run(step_idx, epoch):
+        o, d, tgt, bkg = pool[step_idx % n_pool]
+        pipe.train_step(o, d, tgt, bkg_color=bkg, all_reduce=all_reduce, world_size=world)
+        sample_log[step_idx] = pipe.n_dev[0]
+        if not args.no_occ_update:
+            pipe.update_occupancy(epoch, apply=False)
+
+    epoch0 = 512  # steady-state regime of VolumeBound.optimize (after epoch_optim_warmup = 256)
+    for i in range(args.warmup):
+        run(i, epoch0 + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    timers.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        run(args.warmup + i, epoch0 + args.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    samples = sample_log[args.warmup:].sum()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(samples)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_samples = int(samples.item())
+    wall = float(tmax.item())
+    ksum = timers.summary()
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    s_per_launch = total_samples / world / args.steps
+    # roofline of the dominant kernel (by measured time): hash-grid gather / scatter are HBM-bound random 8-byte accesses
+    hash_kernels = {'hashgrid_fwd': BYTES_HASH_FWD, 'hashgrid_bwd': BYTES_HASH_BWD}
+    dom = max(hash_kernels, key=lambda k: ksum.get(k, 0.0))
+    # hashgrid_fwd is also launched by the occupancy refresh (different size): use the per-step average of its launches
+    n_launch = {k: len(v) for k, v in timers.pairs.items()}
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(dom)
+        except Exception:
+            traffic = None
+    dur_s = ksum[dom] * 1e-3
+    ach = hash_kernels[dom] * s_per_launch / dur_s if dom == 'hashgrid_bwd' else None
+    if dom == 'hashgrid_fwd':
+        # mean over launches mixes train (S) and occupancy-refresh (n_cells/2) sizes: weight the bytes accordingly
+        occ_launch = 0 if args.no_occ_update else sum(1 for e in range(epoch0 + args.warmup, epoch0 + args.warmup + args.steps) if e % cfg.epoch_optim == 0)
+        occ_pts = cfg.n_grid ** 3 // 4 + min(cfg.n_grid ** 3 // 4, int(bf.sum()))
+        tot_pts = s_per_launch * args.steps + occ_pts * occ_launch
+        ach = BYTES_HASH_FWD * tot_pts / (dur_s * n_launch[dom])
+    roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                'frac': ach / HBM_PEAK, 'traffic': traffic, 'avg_launch_ms': ksum[dom]}
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, field, bf, args.cpu_rays)
+
+    out = {
+        'metric': 'ray-samples/sec (train), NGP Lego 800x800', 'value': total_samples / wall, 'unit': 'samples/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'instant-ngp (hashgrid L16 F2 T2^19 + fused MLP 32-64-16 / 32-64-64-3 + volume prune 128^3), '
+                               'Blender-Lego-like 800x800 rays, {} rays/step/GPU, ~{:.0f} valid samples/step/GPU, '
+                               'occupancy {:.0%}, occupancy refresh every 16 steps{}'.format(
+                                   n_rays, s_per_launch, args.occupancy, ' (off)' if args.no_occ_update else ''),
+                   'rays_per_step_per_gpu': n_rays, 'samples_per_step_per_gpu': s_per_launch,
+                   'parallelism': 'ray-sharded dp{}'.format(world)},
+        'roofline': roofline,
+        'cpu_baseline': cpu,
+        'kernel_ms': ksum,
+    }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, field, bf, n_rays):
+    """The CPU oracle (C restatement of the reference path, OpenMP) timed on the host cores on a bounded sample of the
+    same workload: fwd + bwd of one training step for `n_rays` rays (about 10-30 s of CPU work)."""
+    from oracle import oracle as orc
+    from oracle.ngp_reference import oracle_train_step
+    from arcnerf_amd.pipeline import synthetic_rays
+    orc.build()
+    cores = orc.get_max_threads()
+    P = field.export_numpy()
+    o, d = synthetic_rays(n_rays, seed=4242, device='cpu')
+    o, d = o.numpy(), d.numpy()
+    rng = orc.Pcg32(9121)
+    t0 = time.perf_counter()
+    n = oracle_train_step(orc, field, cfg, P, o, d, bf, rng.state, rng.inc)
+    dt = time.perf_counter() - t0
+    return {'value': n / dt, 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+            'sample': 'fwd+bwd of one NGP training step for {} rays = {} valid samples ({:.1f} s), C oracle with OpenMP '
+                      '(hash-grid scatter serial)'.format(n_rays, n, dt)}
+
+
+if __name__ == '__main__':
+    main()

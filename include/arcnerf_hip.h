@@ -111,9 +111,12 @@ typedef struct {
  * hash_idx (n,L,8) int32 optional debug output (-1 for out-of-volume). */
 int arcn_hashgrid_fwd(const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out,
                       int32_t *hash_idx, int64_t n, const int32_t *n_ptr, void *stream);
-/* backward: dtable (n_total,F) accumulated with atomics (caller zeroes), dxyz (n,3) optional. */
+/* backward: dtable (n_total,F) accumulated with atomics (caller zeroes), dxyz (n,3) optional.
+ * workspace (any non-NULL device pointer, optional): selects the owner-computes scatter (each workgroup owns a slice
+ * of one level's dtable in LDS and writes it back with plain stores, no global atomics on large levels); without it, or
+ * when dxyz is requested, the plain one-atomic-per-corner kernel runs.  Both paths ADD into dtable. */
 int arcn_hashgrid_bwd(const float *xyz, const float *table, const float *dout, const arcn_hashgrid_desc *desc_host,
-                      float *dtable, float *dxyz, int64_t n, const int32_t *n_ptr, void *stream);
+                      float *dtable, float *dxyz, int32_t *workspace, int64_t n, const int32_t *n_ptr, void *stream);
 
 /* FreqEmbedder.forward (encoding/freq_encoder.py:65-88): out (n, D*(include_input + 2*n_freqs)). */
 int arcn_freq_fwd(const float *x, int D, int n_freqs, int include_input, float *out, int64_t n, void *stream);
@@ -121,6 +124,18 @@ int arcn_freq_bwd(const float *x, const float *dout, int D, int n_freqs, int inc
                   void *stream);
 /* SHEmbedder torch branch (encoding/sh_encoder.py:101-185): out (n, degree^2 + 3*include_input). */
 int arcn_sh_fwd(const float *dirs, int degree, int include_input, float *out, int64_t n, void *stream);
+
+/* geo -> radiance glue of Base3dModel._forward_pts_dir (arcnerf/models/base_3d_model.py:233-254):
+ * sigma (n) = sigma_act(geo_out[:,0]) (EncoderMLPGeoNet.handle_output, encoder_mlp_network.py:38-50);
+ * rad_in (n, Wf + deg^2) = fuse_radiance_inputs for modes 'fv' (feat_first=1) / 'vf' (encoder_mlp_network.py:93-118):
+ * geo_out[:, feat_off:feat_off+Wf] and SH(normalize(dirs)).  geo_out has row stride Wg. */
+int arcn_ngp_glue_fwd(const float *geo_out, const float *dirs, int Wg, int feat_off, int Wf, int sh_degree,
+                      int feat_first, int sigma_act, float *rad_in, float *sigma, int64_t n, const int32_t *n_ptr,
+                      void *stream);
+/* backward of the glue: d_geo_out (n,Wg) = scatter(d_rad_in feature slice) + d_sigma * sigma_act'(geo_out[:,0]). */
+int arcn_ngp_glue_bwd(const float *geo_out, const float *d_rad_in, const float *d_sigma, int Wg, int feat_off, int Wf,
+                      int sh_degree, int feat_first, int sigma_act, float *d_geo_out, int64_t n, const int32_t *n_ptr,
+                      void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fully fused small MLP (replaces tcnn.Network FullyFusedMLP, tcnn_fusedmlp_module.py:66-77,162-173, and
@@ -194,6 +209,11 @@ int arcn_sample_cdf(const float *bins, const float *cdf, const float *u, int64_t
 /* opafield[idx] = old>=0 ? max(old*ema, opacity) : old ; ema < 0 = no ema */
 int arcn_update_opafield(float *opafield, const int64_t *flat_idx, const float *opacity, int64_t n, float ema,
                          void *stream);
+/* Sort-free equivalent of  unique(voxel_idx) -> segmented max (K4) -> update_opafield_by_voxel_idx  for possibly
+ * repeated flat cell indices (volume_bound.py:199-211).  cell_max (n_cells floats) and touched (n_cells bytes) are
+ * scratch buffers (cleared inside).  opacity must be non-negative. */
+int arcn_opafield_scatter_update(float *opafield, const int64_t *cell_idx, const float *opacity, int64_t n,
+                                 int64_t n_cells, float ema, float *cell_max, uint8_t *touched, void *stream);
 /* thres = min(mean(clamp(opa,0)), threshold) computed on device; bitfield (bool bytes) = opa >= thres.
  * workspace: 2 floats (device). */
 int arcn_update_bitfield_by_opafield(const float *opafield, uint8_t *bitfield, int64_t n, float threshold,
@@ -202,11 +222,14 @@ int arcn_update_bitfield_by_opafield(const float *opafield, uint8_t *bitfield, i
 /* ------------------------------------------------------------------------------------------------
  * Optimiser over one flat fp32 buffer: torch.optim.Adam(lr, betas, eps, weight_decay) semantics
  * (common/trainer/optimizer.py:6-54) + EMA.ema_step (arcnerf/trainer/ema.py:29-43), fused.
- * step is 1-based. grad_scale multiplies the gradient first (1/world_size after all-reduce). ema may be NULL.
+ * step / ema_step are 1-based. grad_scale multiplies the gradient first (1/world_size after all-reduce).
+ * ema (the reference's `old_avg`) may be NULL; when given the debiased average
+ *   new = ((1-d)*p + d*old*(1-d^(ema_step-1))) / (1-d^ema_step)
+ * is stored to BOTH ema and param, as the reference does.  zero_grad != 0 clears grad in the same pass.
  * ---------------------------------------------------------------------------------------------- */
-int arcn_adam_ema_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *ema, int64_t n,
-                       float lr, float beta1, float beta2, float eps, float weight_decay, float ema_decay,
-                       float grad_scale, int step, void *stream);
+int arcn_adam_ema_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, float *ema, int64_t n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale,
+                       int step, int ema_step, int zero_grad, void *stream);
 
 #ifdef __cplusplus
 }

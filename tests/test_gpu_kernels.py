@@ -332,6 +332,20 @@ def test_hashgrid_ngp_large_vs_oracle(F, oracle):
     ref_dt = oracle.hashgrid_bwd(xyz, table, gout, res, offs, mn, mx)
     dt, _ = F.hashgrid_bwd(dev(xyz), tb, dev(gout), desc)
     close(host(dt), ref_dt, rtol=1e-4, atol=1e-5)
+    # owner-computes scatter through LDS (no global atomics on the large levels): same result, and it ADDS into dtable
+    ws = torch.zeros(64, dtype=torch.int32, device='cuda')
+    dt2, _ = F.hashgrid_bwd(dev(xyz), tb, dev(gout), desc, workspace=ws)
+    close(host(dt2), ref_dt, rtol=1e-4, atol=1e-5)
+    F.hashgrid_bwd(dev(xyz), tb, dev(gout), desc, workspace=ws, dtable=dt2)
+    close(host(dt2), 2 * ref_dt, rtol=1e-4, atol=2e-5)
+    # points exactly on / next to voxel faces exercise the exact-division fallback of the fast cell index
+    edge = np.round(xyz[:4000] * 64) / 64
+    edge[::3] += np.float32(1e-7)
+    edge = edge.astype(np.float32)
+    g2 = gout[:4000]
+    ref_e = oracle.hashgrid_bwd(edge, table, g2, res, offs, mn, mx)
+    dte, _ = F.hashgrid_bwd(dev(edge), tb, dev(g2), desc, workspace=ws)
+    close(host(dte), ref_e, rtol=1e-4, atol=1e-5)
     # device-side sample count: only the first n_dev samples are touched
     n_dev = torch.tensor([1234], dtype=torch.int32).cuda()
     out2 = torch.full((S, 32), 7.0, device='cuda')
@@ -427,12 +441,27 @@ def test_fused_mlp_shapes_vs_oracle(F, oracle, dims, act_out, bias, S):
     Ws = [(rng.normal(size=(dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
     bs = [(rng.normal(size=dims[i + 1]) * 0.1).astype(np.float32) for i in range(len(dims) - 1)] if bias else None
     x = rng.normal(size=(S, dims[0])).astype(np.float32)
-    hs, pres = [x], []
-    for i, W in enumerate(Ws):
-        last = i == len(Ws) - 1
-        y, pre = oracle.linear_fwd(hs[-1], W, bs[i] if bias else None, act_out if last else 'relu', want_pre=True)
-        hs.append(y)
-        pres.append(pre)
+
+    def fwd(x):
+        hs, pres = [x], []
+        for i, W in enumerate(Ws):
+            last = i == len(Ws) - 1
+            y, pre = oracle.linear_fwd(hs[-1], W, bs[i] if bias else None, act_out if last else 'relu', want_pre=True)
+            hs.append(y)
+            pres.append(pre)
+        return hs, pres
+
+    # a ReLU pre-activation within rounding noise of 0 may change sign with the summation order (MFMA k-order vs the
+    # oracle's): the derivative is discontinuous there, so such samples are removed from the comparison set
+    hs, pres = fwd(x)
+    relu_pres = pres if act_out == 'relu' else pres[:-1]
+    if relu_pres:
+        keep = np.ones(S, bool)
+        for p_ in relu_pres:
+            keep &= (np.abs(p_) > 1e-5).all(-1)
+        x = np.ascontiguousarray(x[keep])
+        S = x.shape[0]
+        hs, pres = fwd(x)
     desc = N.make_mlp_desc(dims, 'relu', act_out, has_bias=bias)
     w = dev(np.concatenate([W.reshape(-1) for W in Ws]))
     b = dev(np.concatenate(bs)) if bias else None
@@ -468,20 +497,36 @@ def test_occupancy_update_vs_reference_golden(F):
 
 
 def test_adam_ema_vs_torch(F):
+    """torch.optim.Adam + the reference's EMA.ema_step formula (arcnerf/trainer/ema.py:29-43) in plain torch fp32."""
     torch.manual_seed(0)
     n = 100003
+    decay = 0.95
     p0 = torch.randn(n)
     p_ref = p0.clone().requires_grad_(True)
     opt = torch.optim.Adam([p_ref], lr=1e-1, eps=1e-15, weight_decay=1e-6)
     p = p0.clone().cuda()
-    # 16-byte alignment is required: torch allocations are
     m, v, ema = torch.zeros(n).cuda(), torch.zeros(n).cuda(), p0.clone().cuda()
-    ema_ref = p0.clone()
+    old_avg = p0.clone()
     for step in range(1, 6):
         gr = torch.randn(n) * (10.0 ** torch.randint(-6, 1, (n,)).float())
         p_ref.grad = gr.clone()
         opt.step()
-        ema_ref = 0.95 * ema_ref + (1 - 0.95) * p_ref.detach()
-        F.adam_ema_step(p, gr.cuda(), m, v, ema, step, lr=1e-1, eps=1e-15, weight_decay=1e-6, ema_decay=0.95)
+        with torch.no_grad():
+            new_avg = ((1 - decay) * p_ref + decay * old_avg * (1 - decay ** (step - 1))) * (1.0 / (1 - decay ** step))
+            p_ref.copy_(new_avg)
+            old_avg = new_avg.clone()
+        gd = gr.cuda()
+        F.adam_ema_step(p, gd, m, v, ema, step, lr=1e-1, eps=1e-15, weight_decay=1e-6, ema_decay=decay, zero_grad=True)
+        assert float(gd.abs().max()) == 0.0
         close(host(p), p_ref.detach().numpy(), rtol=2e-5, atol=2e-6)
-        close(host(ema), ema_ref.numpy(), rtol=2e-5, atol=2e-6)
+        close(host(ema), old_avg.numpy(), rtol=2e-5, atol=2e-6)
+    # without EMA: plain Adam
+    q_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([q_ref], lr=1e-2)
+    q, m, v = p0.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    for step in range(1, 4):
+        gr = torch.randn(n)
+        q_ref.grad = gr.clone()
+        opt.step()
+        F.adam_ema_step(q, gr.cuda(), m, v, None, step, lr=1e-2)
+        close(host(q), q_ref.detach().numpy(), rtol=2e-5, atol=2e-6)
