@@ -1,0 +1,28 @@
+"""Ray helpers of the path: o + t*d point generation and the ray/AABB test.
+
+Mirrors arcnerf/geometry/ray.py:11-30 (get_ray_points_by_zvals) and :258-350 (aabb_ray_intersection).  The reference
+switches between a CUDA kernel (K2: rays starting inside the box are masked out) and a torch implementation (eps-shifted,
+inside rays hit) depending on availability; both semantics are kernels here, `force_torch` selects the torch one.
+"""
+import torch
+
+from ..ops import functional as F
+
+
+def get_ray_points_by_zvals(rays_o, rays_d, zvals):
+    """pts (N_rays, N_pts, 3) = rays_o + zvals * rays_d"""
+    return rays_o.unsqueeze(1) + zvals.unsqueeze(-1) * rays_d.unsqueeze(1)
+
+
+def normalize(vec):
+    """v / (|v| + 1e-8)  (arcnerf/geometry/transformation.py:11-25)"""
+    return vec / (torch.norm(vec, dim=-1).unsqueeze(-1) + 1e-8)
+
+
+@torch.no_grad()
+def aabb_ray_intersection(rays_o, rays_d, aabb_range, eps=1e-7, force_torch=False):
+    """aabb_range (N_v, 3, 2) -> near, far (N_rays, N_v), pts (N_rays, N_v, 2, 3), mask (N_rays, N_v) bool"""
+    assert aabb_range.shape[1] == 3 and aabb_range.shape[2] == 2, 'AABB range must be (N, 3, 2)'
+    if force_torch:
+        return F.aabb_intersection_torch(rays_o, rays_d, aabb_range, eps)
+    return F.aabb_intersection(rays_o, rays_d, aabb_range.permute(0, 2, 1).contiguous())

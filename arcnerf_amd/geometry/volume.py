@@ -1,0 +1,156 @@
+"""Volume: the axis-aligned occupancy grid bounding the object (the part of arcnerf/geometry/volume.py the hot path
+uses: range, voxel index maths, bool bitfield + fp32 opacity field and their update, ray/volume intersection).
+
+Differences by design (MI355X, 288 GB is not a reason to stream 50 MB of lattice points per step):
+  - `grid_pts` ((n+1)^3,3) and `volume_pts` (n^3,3) are computed on demand from indices instead of being resident
+    buffers that DDP re-broadcasts every forward;
+  - voxel flat index is x*n*n + y*n + z everywhere (volume_func.h:59-66), the bitfield is kept flat + bool like the
+    reference (checkpoint compatible) and a packed 1-bit copy is derived for the marcher.
+"""
+import torch
+import torch.nn as nn
+
+from ..ops import functional as F
+from .ray import aabb_ray_intersection
+
+
+class Volume(nn.Module):
+    def __init__(self, n_grid=None, origin=(0, 0, 0), side=None, xyz_len=None, dtype=torch.float32, requires_grad=False,
+                 **kwargs):
+        super().__init__()
+        self.n_grid = n_grid
+        self.dtype = dtype if isinstance(dtype, torch.dtype) else torch.float32
+        self.contains_bitfield = False
+        assert side is not None or xyz_len is not None, 'Specify at least side or xyz_len'
+        lens = [float(side)] * 3 if side is not None else [float(v) for v in xyz_len]
+        self.origin = nn.Parameter(torch.tensor([float(v) for v in origin], dtype=torch.float32), requires_grad=requires_grad)
+        self.xyz_len = nn.Parameter(torch.tensor(lens, dtype=torch.float32), requires_grad=requires_grad)
+        self.cal_range()
+
+    # ---- geometry -----------------------------------------------------------------------------------
+    def cal_range(self):
+        mn = self.origin.detach() - self.xyz_len.detach() / 2.0
+        mx = self.origin.detach() + self.xyz_len.detach() / 2.0
+        self.register_buffer('range', torch.stack([mn, mx], dim=-1))  # (3, 2)
+
+    def get_range(self):
+        return self.range
+
+    def get_device(self):
+        return self.origin.device
+
+    def get_n_grid(self):
+        return self.n_grid
+
+    def set_n_grid(self, n_grid, reset_pts=True):
+        self.n_grid = n_grid
+
+    def get_n_voxel(self):
+        return self.n_grid ** 3
+
+    def get_len(self):
+        return tuple(float(v) for v in self.xyz_len)
+
+    def get_origin(self):
+        return self.origin
+
+    def get_diag_len(self):
+        return float(torch.sqrt(((self.range[:, 1] - self.range[:, 0]) ** 2).sum()))
+
+    def get_voxel_size(self, to_list=True):
+        s = (self.range[:, 1] - self.range[:, 0]) / self.n_grid
+        return tuple(float(v) for v in s) if to_list else s
+
+    @staticmethod
+    def convert_flatten_index_to_xyz_index(flat, n):
+        z = flat % n
+        y = torch.div(flat, n, rounding_mode='trunc') % n
+        x = torch.div(flat, n * n, rounding_mode='trunc')
+        return torch.stack([x, y, z], dim=-1)
+
+    @staticmethod
+    def convert_xyz_index_to_flatten_index(xyz, n):
+        return xyz[:, 0] * (n * n) + xyz[:, 1] * n + xyz[:, 2]
+
+    def get_full_voxel_idx(self, flatten=False):
+        idx = self.convert_flatten_index_to_xyz_index(torch.arange(self.get_n_voxel(), device=self.get_device()), self.n_grid)
+        return idx if flatten else idx.view(self.n_grid, self.n_grid, self.n_grid, 3)
+
+    def get_voxel_pts_by_voxel_idx(self, voxel_idx):
+        vs = self.get_voxel_size(to_list=False)
+        return voxel_idx * vs + 0.5 * vs + self.range[:, 0]
+
+    def get_volume_pts(self, in_grid=False):
+        """voxel centres (n^3, 3): linspace(min + v/2, max - v/2, n) per axis like cal_volume_pts (volume.py:216-225)"""
+        vs = self.get_voxel_size()
+        ax = [torch.linspace(float(self.range[k, 0]) + 0.5 * vs[k], float(self.range[k, 1]) - 0.5 * vs[k], self.n_grid,
+                             device=self.get_device()) for k in range(3)]
+        pts = torch.stack(torch.meshgrid(*ax, indexing='ij'), -1)
+        return pts if in_grid else pts.view(-1, 3)
+
+    def ray_volume_intersection(self, rays_o, rays_d, in_occ_voxel=False, force=False):
+        """near, far (N_rays,1), pts (N_rays,2,3), mask (N_rays,1) against the outer box (volume.py:624-651)"""
+        assert not in_occ_voxel, 'per-voxel intersection is outside the hot path'
+        near, far, pts, mask = aabb_ray_intersection(rays_o, rays_d, self.range[None].to(rays_o.device))
+        return near, far, pts[:, 0], mask
+
+    # ---- occupancy ----------------------------------------------------------------------------------
+    def set_up_voxel_bitfield(self, init_occ=True):
+        self.contains_bitfield = True
+        fill = torch.ones if init_occ else torch.zeros
+        self.register_buffer('bitfield', fill((self.n_grid,) * 3, dtype=torch.bool))
+
+    def set_up_voxel_opafield(self):
+        self.register_buffer('opafield', torch.zeros((self.n_grid,) * 3, dtype=torch.float32))
+
+    def get_voxel_bitfield(self, flatten=False):
+        if not self.contains_bitfield:
+            return None
+        return self.bitfield.view(-1) if flatten else self.bitfield
+
+    def get_voxel_opafield(self, flatten=False):
+        return self.opafield.view(-1) if flatten else self.opafield
+
+    def reset_voxel_bitfield(self, occ=True):
+        self.bitfield.fill_(bool(occ))
+
+    def update_bitfield(self, occupancy, ops='and'):
+        occ = occupancy.view_as(self.bitfield)
+        if ops == 'and':
+            self.bitfield &= occ
+        elif ops == 'or':
+            self.bitfield |= occ
+        elif ops == 'overwrite':
+            self.bitfield.copy_(occ)
+        else:
+            raise NotImplementedError('Invalid ops {}'.format(ops))
+        return self.bitfield
+
+    def get_n_occupied_voxel(self):
+        return self.bitfield.sum()
+
+    def get_occupied_voxel_idx(self, flatten=False):
+        idx = torch.where(self.bitfield.view(-1))[0]
+        return idx if flatten else self.convert_flatten_index_to_xyz_index(idx, self.n_grid)
+
+    def check_pts_in_occ_voxel(self, pts):
+        """(B,) bool: pts inside an occupied voxel (K1)"""
+        return F.check_pts_in_occ_voxel(pts, self.bitfield, self.range.permute(1, 0).contiguous(), self.n_grid)
+
+    def update_opafield_by_voxel_idx(self, voxel_idx, opacity, ema=None):
+        """opafield[idx] = max(old*ema, new) where old >= 0; voxel_idx (B,3) without repetition (volume.py:983-1003)"""
+        flat = self.convert_xyz_index_to_flatten_index(voxel_idx, self.n_grid)
+        F.update_opafield(self.opafield.view(-1), flat, opacity, ema)
+
+    def update_opafield_by_flat_idx(self, flat_idx, opacity, ema=None):
+        """same as unique + segmented max + update_opafield_by_voxel_idx for possibly repeated cells, sort-free"""
+        F.opafield_scatter_update(self.opafield.view(-1), flat_idx, opacity, ema)
+
+    def get_mean_voxel_opacity(self):
+        return float(self.opafield.clamp(min=0).mean())
+
+    def update_bitfield_by_opafield(self, threshold=0.01, ops='and'):
+        """bitfield (ops) (opafield >= min(mean(clamp(opa,0)), threshold))  (volume.py:1013-1017), no host sync"""
+        new = torch.empty_like(self.bitfield)
+        F.update_bitfield_by_opafield(self.opafield.view(-1), new.view(-1), threshold)
+        self.update_bitfield(new, ops)

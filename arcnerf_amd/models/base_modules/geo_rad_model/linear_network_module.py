@@ -1,0 +1,109 @@
+"""GeoNet / RadianceNet: nn.Linear stacks with skip concatenation and geometric initialisation
+(arcnerf/models/base_modules/geo_rad_model/linear_network_module.py:16-335).  These are plain library GEMMs through
+torch; parameter names (`layers.{i}.weight/bias`, `embed_fn...`) match the reference's state_dict."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ....utils.cfgs_utils import dict_to_obj
+from ....utils.registry import MODULE_REGISTRY
+from ..activation import get_activation
+from ..linear import DenseLayer, SirenLayer
+from .encoder_mlp_network import EncoderMLPGeoNet, EncoderMLPRadainceNet
+
+
+@MODULE_REGISTRY.register()
+class GeoNet(EncoderMLPGeoNet):
+    def __init__(self, W=256, D=8, skips=[4], encoder=None, W_feat=256, use_bias=True, skip_reduce_output=False,
+                 norm_skip=False, act_cfg=None, geometric_init=True, radius_init=1.0, use_siren=False, weight_norm=False,
+                 out_act_cfg=None, *args, **kwargs):
+        super().__init__(W_feat=W_feat, out_act_cfg=out_act_cfg)
+        self.W, self.D, self.skips, self.norm_skip = W, D, list(skips), norm_skip
+        self.geometric_init, self.use_siren, self.radius_init = geometric_init, use_siren, radius_init
+        self.is_pretrained = False
+        input_ch, embed_freq = self.build_encoder(encoder)
+        if use_siren:
+            assert len(self.skips) == 0, 'do not use skips for siren'
+        layers = []
+        for i in range(D + 1):
+            after_skip = i > 0 and (i - 1) in self.skips
+            in_dim = self.embed_dim if i == 0 else (self.embed_dim + W if (after_skip and not skip_reduce_output) else W)
+            if i == D:
+                out_dim = 1 + W_feat if W_feat > 0 else 1
+            elif skip_reduce_output and i in self.skips:
+                out_dim = W - self.embed_dim
+            else:
+                out_dim = W
+            if i == D:
+                layer = nn.Linear(in_dim, out_dim, bias=use_bias)
+            elif use_siren:
+                layer = SirenLayer(in_dim, out_dim, is_first=(i == 0), bias=use_bias)
+            else:
+                layer = DenseLayer(in_dim, out_dim, activation=get_activation(act_cfg), bias=use_bias)
+            if geometric_init and not use_siren:
+                self._geometric_init(layer, i, in_dim, out_dim, input_ch, embed_freq, use_bias, after_skip)
+            if weight_norm:
+                layer = nn.utils.weight_norm(layer)
+            layers.append(layer)
+        self.layers = nn.ModuleList(layers)
+
+    def _geometric_init(self, layer, i, in_dim, out_dim, input_ch, embed_freq, use_bias, after_skip):
+        """sphere-like sdf initialisation (linear_network_module.py:139-163); layer inputs are [feature, x, embed_x]"""
+        if i == self.D:
+            nn.init.normal_(layer.weight, mean=np.sqrt(np.pi) / np.sqrt(in_dim), std=0.0001)
+            if use_bias:
+                nn.init.constant_(layer.bias[:1], -self.radius_init)
+            return
+        if use_bias:
+            nn.init.constant_(layer.bias, 0.0)
+        std = np.sqrt(2) / np.sqrt(out_dim)
+        if embed_freq > 0 and i == 0:
+            nn.init.constant_(layer.weight[:, input_ch:], 0.0)
+            nn.init.normal_(layer.weight[:, :input_ch], 0.0, std)
+        elif embed_freq > 0 and after_skip:
+            nn.init.normal_(layer.weight, 0.0, std)
+            nn.init.constant_(layer.weight[:, -(self.embed_dim - input_ch):], 0.0)
+        else:
+            nn.init.normal_(layer.weight, 0.0, std)
+
+    def forward(self, x):
+        x_embed = self.embed_fn(x)
+        out = x_embed
+        for i in range(self.D + 1):
+            out = self.layers[i](out)
+            if i in self.skips:
+                out = torch.cat([out, x_embed], dim=-1)
+                if self.norm_skip:
+                    out = out / math.sqrt(2)
+        return self.handle_output(out)
+
+
+@MODULE_REGISTRY.register()
+class RadianceNet(EncoderMLPRadainceNet):
+    def __init__(self, mode='vf', W=256, D=8, encoder=None, W_feat_in=256, use_bias=True, act_cfg=None, use_siren=False,
+                 weight_norm=False, out_act_cfg=None, *args, **kwargs):
+        super().__init__(mode=mode)
+        self.W, self.D, self.W_feat_in = W, D, W_feat_in
+        self.build_encoder(encoder, W_feat_in)
+        layers = []
+        for i in range(D + 1):
+            in_dim = self.init_input_dim if i == 0 else W
+            if i == D:
+                act = get_activation(out_act_cfg, dict_to_obj({'type': 'Sigmoid'}))
+                layer = DenseLayer(in_dim, 3, activation=act, bias=use_bias)
+            elif use_siren:
+                layer = SirenLayer(in_dim, W, is_first=(i == 0), bias=use_bias)
+            else:
+                layer = DenseLayer(in_dim, W, activation=get_activation(act_cfg), bias=use_bias)
+            if weight_norm:
+                layer = nn.utils.weight_norm(layer)
+            layers.append(layer)
+        self.layers = nn.ModuleList(layers)
+
+    def forward(self, x, view_dirs, normals, geo_feat):
+        out = self.fuse_radiance_inputs(x, view_dirs, normals, geo_feat)
+        for layer in self.layers:
+            out = layer(out)
+        return out

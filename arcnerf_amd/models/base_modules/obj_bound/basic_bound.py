@@ -1,0 +1,47 @@
+"""BasicBound (arcnerf/models/base_modules/obj_bound/basic_bound.py:12-106): no structure, near/far from config or data."""
+import torch
+import torch.nn as nn
+
+from ....render.ray_helper import get_near_far_from_rays, get_zvals_from_near_far
+from ....utils.cfgs_utils import get_value_from_cfgs_field
+from ....utils.registry import BOUND_REGISTRY
+
+
+@BOUND_REGISTRY.register()
+class BasicBound(nn.Module):
+    def __init__(self, cfgs):
+        super().__init__()
+        self.cfgs = cfgs
+        self.optim_cfgs = self.read_optim_cfgs()
+
+    def get_obj_bound(self):
+        return None
+
+    def get_optim_cfgs(self, key=None):
+        return self.optim_cfgs if key is None else self.optim_cfgs[key]
+
+    def set_optim_cfgs(self, key, value):
+        self.optim_cfgs[key] = value
+
+    def read_optim_cfgs(self):
+        return {
+            'epoch_optim': get_value_from_cfgs_field(self.cfgs, 'epoch_optim', None),
+            'epoch_optim_warmup': get_value_from_cfgs_field(self.cfgs, 'epoch_optim_warmup', None),
+            'ema_optim_decay': get_value_from_cfgs_field(self.cfgs, 'ema_optim_decay', 0.95),
+            'opa_thres': get_value_from_cfgs_field(self.cfgs, 'opa_thres', 0.01),
+        }
+
+    def get_near_far_from_rays(self, inputs, near_hardcode=None, far_hardcode=None, bounding_radius=None):
+        """-> near, far (B,1), mask_rays None"""
+        near, far = get_near_far_from_rays(inputs['rays_o'], inputs['rays_d'], inputs.get('bounds'), near_hardcode,
+                                           far_hardcode, bounding_radius)
+        return near, far, None
+
+    def get_zvals_from_near_far(self, near, far, n_pts, inference_only=False, inverse_linear=False, perturb=False, **kwargs):
+        """-> zvals (B,n_pts), mask_pts None"""
+        return get_zvals_from_near_far(near, far, n_pts, inverse_linear=inverse_linear,
+                                       perturb=perturb if not inference_only else False), None
+
+    @torch.no_grad()
+    def optimize(self, cur_epoch=0, n_pts=128, get_est_opacity=None):
+        return

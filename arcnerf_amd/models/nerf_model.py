@@ -1,0 +1,170 @@
+"""NeRF model (arcnerf/models/nerf_model.py:13-117): coarse (+ optional fine) geometry/radiance nets over the samples
+of FgModel, hierarchical up-sampling by inverse-CDF.
+
+MI355X fast path: when the configuration is the instant-ngp one (volume bound with occupancy marching, hash-grid encoder,
+fused geo/radiance MLPs, SH view encoding, no hierarchical stage) `forward` bypasses the dense (R, 1024) tensors and the
+host decisions of FgModel.forward and runs the packed, device-count-driven kernel sequence of arcnerf_amd.pipeline on the
+module's own parameters.  Outputs (keys, shapes, values) are the same; tests compare both paths.
+"""
+import torch
+
+from ..pipeline import NgpConfig, NgpField, NgpPipeline
+from ..render.ray_helper import sample_pdf
+from ..utils.cfgs_utils import get_value_from_cfgs_field
+from ..utils.registry import MODEL_REGISTRY
+from .base_modules import build_geo_model, build_radiance_model
+from .base_modules.encoding import HashGridEmbedder, SHEmbedder
+from .base_modules.geo_rad_model import FusedMLPGeoNet, FusedMLPRadianceNet
+from .base_modules.obj_bound import VolumeBound
+from .fg_model import FgModel
+
+
+class _PackedRenderFn(torch.autograd.Function):
+    """rgb, depth, mask = packed NGP render(rays; table, geo weights, radiance weights) with hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, bkg, table, geo_w, rad_w, pipe, train, noise_std):
+        pipe.bind_params({'table': table.detach().view(-1), 'geo_w': geo_w.detach(), 'rad_w': rad_w.detach()})
+        noise = pipe.buf['noise'].normal_(0.0, noise_std) if (train and noise_std > 0) else None
+        rgb, depth, mask = pipe.forward(rays_o, rays_d, bkg, train=train, noise=noise)
+        ctx.pipe, ctx.gen = pipe, pipe.generation
+        ctx.save_for_backward(rays_o, rays_d, table, geo_w, rad_w)
+        R = rays_o.shape[0]
+        counts = pipe.buf['counts'][:R].clone()
+        ctx.mark_non_differentiable(counts)
+        return rgb.clone(), depth.clone(), mask.clone(), counts
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth, d_mask, _):
+        pipe = ctx.pipe
+        if pipe.generation != ctx.gen:
+            raise RuntimeError('the packed NGP path keeps ONE forward per backward: raise model.chunk_rays above the number '
+                               'of rays of a training step (the reference default 32768 does) or call backward per chunk')
+        rays_o, rays_d, table, geo_w, rad_w = ctx.saved_tensors
+        g = {'table': torch.zeros_like(table).view(-1), 'geo_w': torch.zeros_like(geo_w), 'rad_w': torch.zeros_like(rad_w)}
+        pipe.bind_grads(g)
+        pipe.backward(rays_o, rays_d, d_rgb.contiguous(), d_depth.contiguous(), d_mask.contiguous())
+        pipe.bind_grads(None)
+        return None, None, None, g['table'].view_as(table), g['geo_w'], g['rad_w'], None, None, None
+
+
+@MODEL_REGISTRY.register()
+class NeRF(FgModel):
+    def __init__(self, cfgs):
+        super().__init__(cfgs)
+        self.coarse_geo_net = build_geo_model(self.cfgs.model.geometry)
+        self.coarse_radiance_net = build_radiance_model(self.cfgs.model.radiance)
+        self.ray_cfgs['n_importance'] = get_value_from_cfgs_field(self.cfgs.model.rays, 'n_importance', 0)
+        self.ray_cfgs['shared_network'] = get_value_from_cfgs_field(self.cfgs.model.rays, 'shared_network', False)
+        if self.get_ray_cfgs('n_importance') > 0:
+            if self.get_ray_cfgs('shared_network'):
+                self.fine_geo_net, self.fine_radiance_net = self.coarse_geo_net, self.coarse_radiance_net
+            else:
+                self.fine_geo_net = build_geo_model(self.cfgs.model.geometry)
+                self.fine_radiance_net = build_radiance_model(self.cfgs.model.radiance)
+        self.use_packed_path = True  # set False to force the dense reference-shaped path
+        self._pipe = None
+
+    def get_net(self):
+        if self.get_ray_cfgs('n_importance') > 0:
+            return self.fine_geo_net, self.fine_radiance_net
+        return self.coarse_geo_net, self.coarse_radiance_net
+
+    def init_setting(self):
+        self.coarse_geo_net.pretrain_siren()
+        if self.get_ray_cfgs('n_importance') > 0:
+            self.fine_geo_net.pretrain_siren()
+
+    # ---- packed instant-ngp path -------------------------------------------------------------------------
+    def packed_path_eligible(self):
+        g, r, b = self.coarse_geo_net, self.coarse_radiance_net, self.obj_bound
+        return (self.use_packed_path and self.get_ray_cfgs('n_importance') == 0 and isinstance(b, VolumeBound)
+                and b.uses_sparse_sampling() and isinstance(g, FusedMLPGeoNet) and isinstance(g.embed_fn, HashGridEmbedder)
+                and not g.embed_fn.include_input and g.W_feat > 0 and g.out_act is not None
+                and type(g.out_act).__name__ == 'TruncExp' and isinstance(r, FusedMLPRadianceNet) and r.mode in ('fv', 'vf')
+                and isinstance(r.embed_fn_view, SHEmbedder) and not r.embed_fn_view.include_input
+                and self.get_ray_cfgs('near') is None and self.get_ray_cfgs('far') is None)
+
+    def _packed_pipeline(self, device):
+        if self._pipe is None or self._pipe.field.device != device:
+            g, r, vol = self.coarse_geo_net, self.coarse_radiance_net, self.obj_bound.volume
+            e = g.embed_fn
+            side = float(e.max_xyz[0] - e.min_xyz[0])
+            cfg = NgpConfig(n_levels=e.n_levels, n_feat_per_entry=e.n_feat_per_entry, hashmap_size=int(round(torch.log2(torch.tensor(float(e.hashmap_size))).item())),
+                            base_res=e.base_res, max_res=e.max_res, side=side,
+                            origin=tuple(float(v) for v in (e.max_xyz + e.min_xyz) / 2.0), geo_W=g.W, geo_D=g.D, W_feat=g.W_feat,
+                            rad_W=r.W, rad_D=r.D, sh_degree=r.embed_fn_view.n_freqs, rad_mode=r.mode, n_grid=vol.get_n_grid(),
+                            n_sample=self.get_n_coarse_sample(), near_distance=self.obj_bound.get_optim_cfgs('near_distance'),
+                            add_inf_z=bool(self.add_inf_z), white_bkg=bool(self.get_ray_cfgs('white_bkg')),
+                            noise_std=float(self.get_ray_cfgs('noise_std') or 0.0))
+            assert abs(vol.get_diag_len() - (3.0 * side * side) ** 0.5) < 1e-5, 'encoder volume and bound volume differ'
+            fld = NgpField.__new__(NgpField)  # metadata only: the parameters stay in the nn.Modules
+            fld.cfg, fld.device = cfg, device
+            fld.resolutions, fld.offsets = e.resolutions, e.offsets
+            fld.min_xyz, fld.max_xyz = e.min_xyz.tolist(), e.max_xyz.tolist()
+            fld.grid_desc, fld.geo_desc, fld.rad_desc = e.desc, g.layers.desc, r.layers.desc
+            fld.geo_dims, fld.rad_dims = g.layers.dims, r.layers.dims
+            fld.geo_out_dim, fld.feat_off = g.layers.dims[-1], 0
+            fld.n_params = 0
+            fld.params = fld.grads = torch.zeros(4, device=device)
+            fld._seg = {}
+            max_rays = int(self.chunk_rays) if self.chunk_rays and self.chunk_rays > 0 else 32768
+            self._pipe = NgpPipeline(fld, max_rays=max_rays, max_samples=max(1 << 20, 2 * max_rays), packed_bits=True)
+            from ..ops.volume_func import sampler_rng
+            self._pipe.rng = sampler_rng()  # the process-wide sampler stream, like the reference's static generator
+        self._pipe.set_bitfield(self.obj_bound.volume.get_voxel_bitfield(flatten=True))
+        return self._pipe
+
+    def _forward_packed(self, inputs, inference_only):
+        rays_o, rays_d, bkg = inputs['rays_o'].contiguous().float(), inputs['rays_d'].contiguous().float(), inputs['bkg_color']
+        pipe = self._packed_pipeline(rays_o.device)
+        train = torch.is_grad_enabled() and not inference_only
+        noise_std = float(self.get_ray_cfgs('noise_std') or 0.0) if not inference_only else 0.0
+        g, r = self.coarse_geo_net, self.coarse_radiance_net
+        rgb, depth, mask, counts = _PackedRenderFn.apply(rays_o, rays_d, bkg, g.embed_fn.embeddings, g.layers.params,
+                                                        r.layers.params, pipe, train, noise_std)
+        hit = counts > 0
+        if not inference_only:
+            self.adjust_dynamicbs_factor(n_valid=pipe.n_dev[0])
+        # defaults of FgModel.update_values_for_invalid_rays for rays without samples
+        depth = torch.where(hit, depth, torch.full_like(depth, float(self.render_cfgs['depth_far'])))
+        if bkg is None:
+            dflt = torch.tensor(self.render_cfgs['bkg_color'], dtype=rgb.dtype, device=rgb.device)[None]
+            rgb = torch.where(hit[:, None], rgb, dflt.expand_as(rgb))
+        out = {'rgb': rgb, 'depth': depth, 'mask': mask}
+        if inference_only:
+            return out
+        return {k + '_coarse': v for k, v in out.items()}
+
+    def forward(self, inputs, inference_only=False, get_progress=False, cur_epoch=0, total_epoch=300000):
+        if not get_progress and self.packed_path_eligible() and inputs['rays_o'].is_cuda:
+            return self._forward_packed(inputs, inference_only)
+        return super().forward(inputs, inference_only, get_progress, cur_epoch, total_epoch)
+
+    # ---- dense reference-shaped path ----------------------------------------------------------------------
+    def _forward(self, inputs, inference_only=False, get_progress=False, cur_epoch=0, total_epoch=300000):
+        rays_o, rays_d, zvals = inputs['rays_o'], inputs['rays_d'], inputs['zvals']
+        mask_pts, bkg_color = inputs['mask_pts'], inputs['bkg_color']
+        output = {}
+        sigma, radiance = self.get_sigma_radiance_by_mask_pts(self.coarse_geo_net, self.coarse_radiance_net, rays_o, rays_d, zvals,
+                                                              mask_pts, inference_only)
+        out_c = self.ray_marching(sigma, radiance, zvals, inference_only=inference_only, bkg_color=bkg_color)
+        weights_c = out_c['weights']
+        output['coarse'] = self.output_get_progress(out_c, get_progress)
+        if self.get_ray_cfgs('n_importance') > 0:
+            zvals, mask_pts = self.upsample_zvals(zvals, weights_c, mask_pts, inference_only)
+            sigma, radiance = self.get_sigma_radiance_by_mask_pts(self.fine_geo_net, self.fine_radiance_net, rays_o, rays_d, zvals,
+                                                                  mask_pts, inference_only)
+            out_f = self.ray_marching(sigma, radiance, zvals, inference_only=inference_only, bkg_color=bkg_color)
+            output['fine'] = self.output_get_progress(out_f, get_progress)
+        return self.adjust_coarse_fine_output(output, inference_only)
+
+    def upsample_zvals(self, zvals, weights, mask_pts=None, inference_only=True):
+        """coarse weights[1:n-1] on the interval mid-points -> n_importance inverse-CDF samples, merged and sorted
+        (nerf_model.py:93-117)"""
+        w = weights[:, 1:self.get_ray_cfgs('n_sample') - 1]
+        mids = 0.5 * (zvals[..., 1:] + zvals[..., :-1])
+        det = True if inference_only else (not self.get_ray_cfgs('perturb'))
+        new = sample_pdf(mids.contiguous(), w.detach().contiguous(), self.get_ray_cfgs('n_importance'), det).detach()
+        zvals, _ = torch.sort(torch.cat([zvals, new], -1), -1)
+        return zvals, self.merge_full_mask(mask_pts, new)

@@ -1,0 +1,119 @@
+"""torch.autograd.Function wrappers around the HIP kernels (forward + hand-written backward each).
+
+The reference gets its backward from torch autograd over ~25 tiny kernels per encoder level; here
+every Function is one forward kernel and one backward kernel.
+"""
+import torch
+
+from . import functional as F
+
+
+class HashGridFn(torch.autograd.Function):
+    """out (n, L*F) = hash-grid encode(xyz; table).  Gradients: table (scatter), xyz (optional, for normals)."""
+
+    @staticmethod
+    def forward(ctx, xyz, table, desc, scatter_ws):
+        xyz = xyz.contiguous().float()
+        out = F.hashgrid_fwd(xyz, table, desc)
+        ctx.save_for_backward(xyz, table)
+        ctx.desc, ctx.ws = desc, scatter_ws
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xyz, table = ctx.saved_tensors
+        need_table, need_xyz = ctx.needs_input_grad[1], ctx.needs_input_grad[0]
+        dout = dout.contiguous()
+        dtable = dxyz = None
+        if need_table and not need_xyz:
+            dtable, _ = F.hashgrid_bwd(xyz, table, dout, ctx.desc, workspace=ctx.ws)
+            dtable = dtable.view_as(table)
+        elif need_table or need_xyz:
+            dtable, dxyz = F.hashgrid_bwd(xyz, table, dout, ctx.desc, want_dtable=need_table, want_dxyz=need_xyz)
+            if dtable is not None:
+                dtable = dtable.view_as(table)
+        return dxyz, dtable, None, None
+
+
+class FreqFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n_freqs, include_input):
+        x = x.contiguous().float()
+        ctx.save_for_backward(x)
+        ctx.cfg = (n_freqs, include_input)
+        return F.freq_fwd(x, n_freqs, include_input)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        return F.freq_bwd(x, dout.contiguous(), *ctx.cfg), None, None
+
+
+class TruncExpFn(torch.autograd.Function):
+    """arcnerf/ops/trunc_exp.py:7-37: fwd exp(x); bwd g * exp(clamp(x, -15, 15))"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous().float()
+        y = F.act_fwd(x, 'truncexp')
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        return F.act_bwd(x, y, g.contiguous(), 'truncexp')
+
+
+class FusedMlpFn(torch.autograd.Function):
+    """y = MLP(x; flat weights[, flat biases]) on the f32-MFMA fused kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weights, biases, desc):
+        x = x.contiguous().float()
+        need = any(ctx.needs_input_grad[:3])
+        if need:
+            out, acts = F.mlp_fwd(x, weights, biases, desc, save_acts=True)
+            ctx.save_for_backward(x, weights, biases if biases is not None else x.new_zeros(0), out, acts)
+        else:
+            out = F.mlp_fwd(x, weights, biases, desc)
+        ctx.desc = desc
+        ctx.has_bias = biases is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weights, biases, out, acts = ctx.saved_tensors
+        b = biases if ctx.has_bias else None
+        dx, dw, db = F.mlp_bwd(x, weights, b, ctx.desc, out, acts, dout.contiguous(), want_dx=ctx.needs_input_grad[0])
+        return dx, dw, (db if ctx.has_bias else None), None
+
+
+class RayMarchingFn(torch.autograd.Function):
+    """ray_marching of arcnerf/render/ray_helper.py:476-593 on dense (R,P) tensors; differentiable wrt sigma (or alpha)
+    and radiance.  Returns rgb, depth, mask, alpha, trans_shift, weights (per-sample outputs are detached views)."""
+
+    @staticmethod
+    def forward(ctx, sigma, radiance, zvals, alpha, bkg_color, noise, add_inf_z, white_bkg):
+        out = F.ray_marching_fwd(sigma, radiance, zvals, add_inf_z=add_inf_z, white_bkg=white_bkg, alpha=alpha,
+                                 bkg_color=bkg_color, noise=noise, want_samples=True, check_order=True)
+        ctx.flags = (add_inf_z, white_bkg)
+        ctx.has = (sigma is not None, radiance is not None, alpha is not None, bkg_color is not None, noise is not None)
+        dummy = zvals.new_zeros(0)
+        ctx.save_for_backward(*[t if t is not None else dummy for t in (sigma, radiance, zvals, alpha, bkg_color, noise)])
+        ctx.status = out['status']
+        rgb = out['rgb'] if out['rgb'] is not None else zvals.new_zeros(0)
+        ctx.mark_non_differentiable(out['alpha'], out['trans_shift'])
+        return rgb, out['depth'], out['mask'], out['alpha'], out['trans_shift'], out['weights'], out['status']
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth, d_mask, _da, _dt, d_w, _ds):
+        sigma, radiance, zvals, alpha, bkg, noise = [t if h else None for t, h in
+                                                     zip(ctx.saved_tensors, (ctx.has[0], ctx.has[1], True, ctx.has[2], ctx.has[3], ctx.has[4]))]
+        add_inf_z, white_bkg = ctx.flags
+        if d_w is not None and bool(d_w.abs().sum() != 0):
+            raise NotImplementedError('gradient through per-sample weights is not provided by the fused compositor')
+        d_geo, d_rad = F.ray_marching_bwd(sigma, radiance, zvals, d_rgb.contiguous() if radiance is not None else None,
+                                          d_depth.contiguous(), d_mask.contiguous(), add_inf_z=add_inf_z, white_bkg=white_bkg,
+                                          alpha=alpha, bkg_color=bkg, noise=noise)
+        return (d_geo if sigma is not None else None), d_rad, None, (d_geo if alpha is not None else None), None, None, None, None

@@ -231,7 +231,28 @@ class NgpPipeline:
         self.opafield = torch.zeros(ng ** 3, dtype=f32, device=dev)
         self._bits = None
         self._occ_scratch = None
+        self._pb = self._gb = None
+        self.generation = 0
         self.set_bitfield(self.bitfield)
+
+    # ---- parameter binding -------------------------------------------------------------------------
+    def bind_params(self, tensors):
+        """Run on externally owned flat fp32 tensors {'table','geo_w','rad_w'[,'geo_b','rad_b']} (e.g. nn.Parameters of the
+        model mirror) instead of the field's own flat buffer.  None restores the field."""
+        self._pb = tensors
+
+    def bind_grads(self, tensors):
+        self._gb = tensors
+
+    def _p(self, name):
+        if self._pb is not None:
+            return self._pb.get(name)
+        return self.field.view(name)
+
+    def _g(self, name):
+        if self._gb is not None:
+            return self._gb.get(name)
+        return self.field.view(name, self.field.grads)
 
     # ---- occupancy ------------------------------------------------------------------------------
     def set_bitfield(self, bitfield_bool):
@@ -277,12 +298,13 @@ class NgpPipeline:
         L, st = N.lib(), N.stream()
         N.check(L.arcn_packed_points(N.ptr(rays_o), N.ptr(rays_d), N.ptr(b['t']), N.ptr(b['ray_id']), N.ptr(b['xyz']),
                                      N.ptr(b['dirs']), S, n_dev.data_ptr(), st), 'packed_points')
-        F.hashgrid_fwd(b['xyz'], fld.view('table'), fld.grid_desc, n_dev=n_dev, out=b['feat'])
-        F.mlp_fwd(b['feat'], fld.view('geo_w'), fld.view('geo_b'), fld.geo_desc, save_acts=train, n_dev=n_dev, out=b['geo_out'],
+        self.generation += 1
+        F.hashgrid_fwd(b['xyz'], self._p('table'), fld.grid_desc, n_dev=n_dev, out=b['feat'])
+        F.mlp_fwd(b['feat'], self._p('geo_w'), self._p('geo_b'), fld.geo_desc, save_acts=train, n_dev=n_dev, out=b['geo_out'],
                   acts=b['geo_acts'])
         F.ngp_glue_fwd(b['geo_out'], b['dirs'], fld.feat_off, cfg.W_feat, cfg.sh_degree, feat_first=(cfg.rad_mode == 'fv'),
                        sigma_act=cfg.sigma_act, n_dev=n_dev, rad_in=b['rad_in'], sigma=b['sigma'])
-        F.mlp_fwd(b['rad_in'], fld.view('rad_w'), fld.view('rad_b'), fld.rad_desc, save_acts=train, n_dev=n_dev, out=b['rgb_s'],
+        F.mlp_fwd(b['rad_in'], self._p('rad_w'), self._p('rad_b'), fld.rad_desc, save_acts=train, n_dev=n_dev, out=b['rgb_s'],
                   acts=b['rad_acts'])
         bk, bk_rows = (None, 0) if bkg_color is None else (bkg_color.contiguous().float().view(-1, 3), bkg_color.view(-1, 3).shape[0])
         self._bkg = bk
@@ -307,19 +329,18 @@ class NgpPipeline:
                                             int(cfg.add_inf_z), int(cfg.white_bkg), N.ptr(d_rgb), N.ptr(d_depth), N.ptr(d_mask),
                                             N.ptr(b['d_sigma']), N.ptr(b['d_rgb_s']), st), 'composite_packed_bwd')
         S = self.cap
-        g = fld.grads
-        N.check(L.arcn_mlp_bwd(N.ptr(b['rad_in']), N.ptr(fld.view('rad_w')), N.ptr(fld.view('rad_b')), N.C.addressof(fld.rad_desc),
+        N.check(L.arcn_mlp_bwd(N.ptr(b['rad_in']), N.ptr(self._p('rad_w')), N.ptr(self._p('rad_b')), N.C.addressof(fld.rad_desc),
                                N.ptr(b['rgb_s']), N.ptr(b['rad_acts']), N.ptr(b['d_rgb_s']), N.ptr(b['d_rad_in']),
-                               N.ptr(fld.view('rad_w', g)), N.ptr(fld.view('rad_b', g)), N.ptr(b['mlp_scratch']), S, S,
+                               N.ptr(self._g('rad_w')), N.ptr(self._g('rad_b')), N.ptr(b['mlp_scratch']), S, S,
                                n_dev.data_ptr(), st), 'mlp_bwd(rad)')
         F.ngp_glue_bwd(b['geo_out'], b['d_rad_in'], b['d_sigma'], fld.feat_off, cfg.W_feat, cfg.sh_degree,
                        feat_first=(cfg.rad_mode == 'fv'), sigma_act=cfg.sigma_act, n_dev=n_dev, d_geo_out=b['d_geo_out'])
-        N.check(L.arcn_mlp_bwd(N.ptr(b['feat']), N.ptr(fld.view('geo_w')), N.ptr(fld.view('geo_b')), N.C.addressof(fld.geo_desc),
+        N.check(L.arcn_mlp_bwd(N.ptr(b['feat']), N.ptr(self._p('geo_w')), N.ptr(self._p('geo_b')), N.C.addressof(fld.geo_desc),
                                N.ptr(b['geo_out']), N.ptr(b['geo_acts']), N.ptr(b['d_geo_out']), N.ptr(b['d_feat']),
-                               N.ptr(fld.view('geo_w', g)), N.ptr(fld.view('geo_b', g)), N.ptr(b['mlp_scratch']), S, S,
+                               N.ptr(self._g('geo_w')), N.ptr(self._g('geo_b')), N.ptr(b['mlp_scratch']), S, S,
                                n_dev.data_ptr(), st), 'mlp_bwd(geo)')
-        N.check(L.arcn_hashgrid_bwd(N.ptr(b['xyz']), N.ptr(fld.view('table')), N.ptr(b['d_feat']), N.C.addressof(fld.grid_desc),
-                                    N.ptr(fld.view('table', g)), None, N.ptr(self.hash_ws), S, n_dev.data_ptr(), st),
+        N.check(L.arcn_hashgrid_bwd(N.ptr(b['xyz']), N.ptr(self._p('table')), N.ptr(b['d_feat']), N.C.addressof(fld.grid_desc),
+                                    N.ptr(self._g('table')), None, N.ptr(self.hash_ws), S, n_dev.data_ptr(), st),
                 'hashgrid_bwd')
 
     def huber_grad(self, rgb, target):
@@ -388,8 +409,8 @@ class NgpPipeline:
             }
         sc = self._occ_scratch
         pts = pts.contiguous()
-        F.hashgrid_fwd(pts, fld.view('table'), fld.grid_desc, out=sc['feat'][:n])
-        F.mlp_fwd(sc['feat'][:n], fld.view('geo_w'), fld.view('geo_b'), fld.geo_desc, out=sc['geo_out'][:n])
+        F.hashgrid_fwd(pts, self._p('table'), fld.grid_desc, out=sc['feat'][:n])
+        F.mlp_fwd(sc['feat'][:n], self._p('geo_w'), self._p('geo_b'), fld.geo_desc, out=sc['geo_out'][:n])
         sigma = F.act_fwd(sc['geo_out'][:n, 0].contiguous(), cfg.sigma_act)
         opacity = sigma * cfg.dt  # get_est_opacity (base_3d_model.py:386-389)
         F.opafield_scatter_update(self.opafield, cell, opacity, ema=cfg.ema_optim_decay, cell_max=sc['cell_max'],

@@ -1,0 +1,162 @@
+"""GPU tests of the model-level mirror: vanilla NeRF against the reference's own FullModel outputs (G9), the packed NGP
+fast path against the dense reference-shaped path, training through torch optimisers, and the compat shims."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+CFG = os.path.join(ROOT, 'configs')
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def close(a, b, rtol=1e-4, atol=1e-4):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def test_vanilla_nerf_matches_reference_fullmodel(gpu):
+    """configs/models/nerf.yaml (reduced widths): reference state_dict loaded into the mirror, same rays -> rgb/depth/mask
+    within 1e-4 in inference mode and in train mode (perturb/noise off), parameter gradients within 1e-3 of their max."""
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    g = load_golden('g9_nerf_model')
+    m = build_model(load_configs(os.path.join(CFG, 'nerf.yaml'), [str(v) for v in g['overrides']])).to(gpu)
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd.')})
+    inputs = {k[3:]: torch.from_numpy(g[k]).to(gpu) for k in g.files if k.startswith('in_')}
+    with torch.no_grad():
+        out = m({k: v.clone() for k, v in inputs.items()}, inference_only=True)
+    assert set(out.keys()) == {'rgb', 'depth', 'mask'}
+    for k in ('rgb', 'depth', 'mask'):
+        assert out[k].shape == g['infer_' + k].shape
+        close(out[k].cpu().numpy(), g['infer_' + k])
+    m.fg_model.set_ray_cfgs('perturb', False)
+    m.fg_model.set_ray_cfgs('noise_std', 0.0)
+    out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False)
+    assert set(out.keys()) == {'rgb_coarse', 'depth_coarse', 'mask_coarse', 'rgb_fine', 'depth_fine', 'mask_fine'}
+    for k in out:
+        close(out[k].detach().cpu().numpy(), g['train_' + k])
+    loss = ((out['rgb_fine'] - inputs['img']) ** 2).mean() + ((out['rgb_coarse'] - inputs['img']) ** 2).mean()
+    loss.backward()
+    for n, p in m.named_parameters():
+        ref = g['grad.' + n]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-7, n
+
+
+def _ngp_model(gpu, extra=()):
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    ov = ['--model.obj_bound.volume.n_grid', '32', '--model.rays.n_sample', '256', '--model.geometry.encoder.hashmap_size', '14',
+          '--model.geometry.encoder.n_levels', '8', '--model.geometry.encoder.max_res', '256'] + list(extra)
+    torch.manual_seed(3)
+    m = build_model(load_configs(os.path.join(CFG, 'nerf_ngp.yaml'), ov)).to(gpu)
+    with torch.no_grad():
+        m.fg_model.coarse_geo_net.embed_fn.embeddings.mul_(3000.0)
+    from arcnerf_amd.pipeline import synthetic_bitfield
+    bf = torch.from_numpy(synthetic_bitfield(32, 0.1, seed=4)).to(gpu)
+    m.fg_model.obj_bound.volume.update_bitfield(bf, ops='overwrite')
+    sampler_rng(reset=True)
+    return m
+
+
+def _rays(gpu, B=2, N=300):
+    from arcnerf_amd.pipeline import synthetic_rays
+    o, d = synthetic_rays(B * N, seed=21, device=gpu)
+    g = torch.Generator().manual_seed(5)
+    return {'rays_o': o.view(B, N, 3), 'rays_d': d.view(B, N, 3), 'rays_r': torch.zeros(B, N, 1, device=gpu),
+            'img': torch.rand(B, N, 3, generator=g).to(gpu), 'bkg_color': torch.rand(B, N, 3, generator=g).to(gpu)}
+
+
+def test_ngp_packed_path_equals_dense_reference_shaped_path(gpu):
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    m = _ngp_model(gpu, ['--model.rays.noise_std', '0.0'])
+    fg = m.fg_model
+    inputs = _rays(gpu)
+    outs, grads = {}, {}
+    for packed in (True, False):
+        fg.use_packed_path = packed
+        sampler_rng(reset=True)  # same jitter stream for both paths
+        m.zero_grad()
+        o_inf = m({k: v.clone() for k, v in inputs.items()}, inference_only=True)
+        o_tr = m({k: v.clone() for k, v in inputs.items()}, inference_only=False)
+        assert set(o_inf.keys()) == {'rgb', 'depth', 'mask'}
+        assert set(o_tr.keys()) == {'rgb_coarse', 'depth_coarse', 'mask_coarse'}
+        assert o_tr['rgb_coarse'].shape == (2, 300, 3) and o_tr['depth_coarse'].shape == (2, 300)
+        ((o_tr['rgb_coarse'] - inputs['img']) ** 2).mean().backward()
+        outs[packed] = {**{k: v.detach().cpu().numpy() for k, v in o_inf.items()}, **{k: v.detach().cpu().numpy() for k, v in o_tr.items()}}
+        grads[packed] = {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters() if p.grad is not None}
+    for k in outs[True]:
+        close(outs[True][k], outs[False][k], rtol=1e-5, atol=1e-5)
+    assert set(grads[True]) == set(grads[False]) and len(grads[True]) == 3
+    for n in grads[True]:
+        ref = grads[False][n]
+        assert np.abs(grads[True][n] - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-9, n
+    # rays that miss every occupied voxel take the defaults: rgb = bkg colour, depth = depth_far, mask = 0
+    d = outs[True]['depth']
+    miss = d == 10.0
+    assert miss.any() and (outs[True]['mask'][miss] == 0).all()
+    np.testing.assert_array_equal(outs[True]['rgb'][miss], inputs['bkg_color'].cpu().numpy()[miss])
+
+
+def test_ngp_model_trains_with_torch_adam_and_prunes(gpu):
+    m = _ngp_model(gpu)
+    fg = m.fg_model
+    inputs = _rays(gpu, 1, 2048)
+    with torch.no_grad():
+        fg.coarse_geo_net.embed_fn.embeddings.div_(3000.0)
+    inputs['bkg_color'] = torch.zeros_like(inputs['bkg_color'])
+    with torch.no_grad():
+        hit = m({k: v.clone() for k, v in inputs.items()}, inference_only=True)['depth'] < 10.0
+    tgt = hit[..., None].float() * torch.tensor([0.2, 0.7, 0.4], device=gpu)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2, eps=1e-15)
+    losses = []
+    for it in range(120):
+        out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=it)
+        loss = ((out['rgb_coarse'] - tgt) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.2 * losses[0], (losses[0], losses[-1])
+    f = fg.get_dynamicbs_factor()
+    assert f > 0
+    before = int(fg.obj_bound.volume.get_n_occupied_voxel())
+    m.optimize(cur_epoch=16)   # warm-up branch: every cell
+    m.optimize(cur_epoch=512)  # steady-state branch: 1/4 random + 1/4 occupied cells
+    after = int(fg.obj_bound.volume.get_n_occupied_voxel())
+    assert 0 < after <= 32 ** 3 and after != before
+
+
+def test_compat_shims_run_reference_shaped_calls(gpu):
+    import arcnerf_amd.compat as compat
+    compat.install()
+    import _volume_func
+    import tinycudann as tcnn
+    o, d = _rays(gpu, 1, 64)['rays_o'][0].contiguous(), _rays(gpu, 1, 64)['rays_d'][0].contiguous()
+    aabb = torch.tensor([[[-1.0, -1, -1], [1, 1, 1]]], device=gpu)
+    near, far = torch.zeros(64, 1, device=gpu), torch.zeros(64, 1, device=gpu)
+    pts, mask = torch.zeros(64, 1, 2, 3, device=gpu), torch.zeros(64, 1, dtype=torch.bool, device=gpu)
+    _volume_func.aabb_intersection(o, d, aabb, near, far, pts, mask)
+    assert mask.any() and (far[mask] > near[mask]).all()
+    with pytest.raises(RuntimeError):
+        _volume_func.aabb_intersection(o.cpu(), d, aabb, near, far, pts, mask)
+    enc = tcnn.Encoding(3, {'otype': 'HashGrid', 'n_levels': 4, 'n_features_per_level': 2, 'log2_hashmap_size': 10,
+                            'base_resolution': 4, 'per_level_scale': 2.0}).to(gpu)
+    net = tcnn.Network(8, 16, {'otype': 'FullyFusedMLP', 'activation': 'ReLU', 'output_activation': 'None', 'n_neurons': 64,
+                               'n_hidden_layers': 1}).to(gpu)
+    x = torch.rand(500, 3, device=gpu)
+    y = net(enc(x))
+    assert y.shape == (500, 16)
+    y.square().mean().backward()
+    assert enc.params.grad is not None and net.params.grad is not None and float(net.params.grad.abs().sum()) > 0
+    sh = tcnn.Encoding(3, {'otype': 'SphericalHarmonics', 'degree': 4}).to(gpu)
+    assert sh((d + 1) / 2).shape == (64, 16)
