@@ -1,0 +1,95 @@
+"""Data-parallel training of the hot path: one process per GPU, rays sharded across ranks, ONE all-reduce of the flat
+gradient buffer per step over RCCL/xGMI (torch.distributed backend "nccl" is RCCL on ROCm).
+
+What the reference does: DistributedDataParallel buckets + per-forward broadcast of ~100 MB of
+Volume buffers, an image-level DistributedSampler.  What this does instead:
+  - rays, not images, are sharded (`shard_range`), optionally balanced by last step's per-ray sample counts
+    (`balanced_shards`) because the dynamic-batch-size regime makes rays unequal;
+  - parameters live in one flat fp32 buffer (NgpField.params), so gradients are one contiguous tensor:
+    `allreduce_grads` is a single collective (48.8 MB for the NGP config; the 1/world factor is folded into the fused
+    Adam kernel's grad_scale, no extra pass);
+  - the occupancy grid is refreshed from the same seed on every rank or, when ranks may diverge, only the packed
+    256 KiB bitfield is broadcast (`broadcast_bitfield`) — never the lattice buffers.
+There is no data-path collective: rays are independent, a ray's samples never leave its rank.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_RANK', '0'))
+
+
+def init_from_env(backend=None, device=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun style).
+    Returns (rank, world).  No-op for world == 1."""
+    rank, world, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        kw = {}
+        if backend == 'nccl' and device is not None:
+            kw['device_id'] = device
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous [lo, hi) slice of n_total rays for `rank`; sizes differ by at most one, every ray exactly once."""
+    base, rem = divmod(int(n_total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def balanced_shards(counts, world):
+    """Split rays into `world` contiguous shards of (nearly) equal expected SAMPLE count.
+
+    counts: 1-D tensor of per-ray sample counts of the previous step (same rays or same distribution).
+    Returns a list of `world + 1` boundaries (python ints), boundaries[k]..boundaries[k+1] is rank k's slice."""
+    c = counts.to(torch.float64).cpu()
+    n = c.numel()
+    if n == 0:
+        return [0] * (world + 1)
+    csum = torch.cumsum(c + 1e-9, 0)  # strictly increasing so searchsorted is well defined
+    total = float(csum[-1])
+    targets = torch.tensor([total * k / world for k in range(1, world)], dtype=torch.float64)
+    cuts = torch.searchsorted(csum, targets, right=False) + 1
+    bounds = [0] + [int(min(max(v, 0), n)) for v in cuts.tolist()] + [n]
+    for k in range(1, len(bounds)):
+        bounds[k] = max(bounds[k], bounds[k - 1])
+    return bounds
+
+
+def allreduce_grads(flat_grads, world=None, group=None):
+    """SUM all-reduce of the flat gradient buffer in place (the average is applied by the optimiser's grad_scale)."""
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world > 1:
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+    return flat_grads
+
+
+def broadcast_bitfield(bits, src=0, group=None):
+    """Make every rank march the same occupancy: broadcast the packed bitfield (uint8, n_grid^3/8 bytes) from `src`."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(bits, src=src, group=group)
+    return bits
+
+
+def broadcast_params(flat_params, src=0, group=None):
+    """Initial parameter sync (what DDP does at construction)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat_params, src=src, group=group)
+    return flat_params
+
+
+def max_over_ranks(value, device=None, group=None):
+    """max of a python float over ranks (timing in bench.py)"""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())

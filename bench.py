@@ -98,8 +98,8 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        from arcnerf_amd import distributed as D
+        D.init_from_env(backend='nccl', device=dev)
 
     from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline, synthetic_bitfield, synthetic_rays
 
@@ -123,7 +123,7 @@ def main():
 
     timers = KernelTimers()
     instrument(timers)
-    all_reduce = (lambda t: dist.all_reduce(t)) if world > 1 else None
+    all_reduce = (lambda t: D.allreduce_grads(t, world)) if world > 1 else None
     sample_log = torch.zeros(args.steps + args.warmup, dtype=torch.int64, device=dev)
 
     def run(step_idx, epoch):

@@ -1,0 +1,101 @@
+"""world_size-2 `gloo` tests (CPU) of the data-parallel layer: ray sharding covers every ray exactly once, the single
+flat-gradient all-reduce reproduces the single-process full-batch gradient, the bitfield/parameter broadcasts make replicas
+identical, and replicas stay bit-identical after the optimiser step."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from arcnerf_amd import distributed as D
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_grad(rays, params):
+    """a deterministic stand-in for 'gradient of the mean loss over these rays' (linear in per-ray contributions)"""
+    w = torch.sin(rays.sum(-1, keepdim=True) * torch.arange(1, params.numel() + 1)[None] * 0.01)
+    return (w * (1.0 + params[None])).sum(0)
+
+
+def _worker(rank, world, port, n_rays, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    r, w = D.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    g = torch.Generator().manual_seed(0)
+    rays = torch.rand(n_rays, 6, generator=g)  # every rank sees the same global ray list and takes its shard
+    params = torch.linspace(-1, 1, 1000) if rank == 0 else torch.zeros(1000)
+    D.broadcast_params(params, src=0)
+    lo, hi = D.shard_range(n_rays, rank, world)
+    grads = _fake_grad(rays[lo:hi], params)
+    D.allreduce_grads(grads, world)
+    # the reference folds 1/world into DDP's averaging; here it is the optimiser's grad_scale
+    params = params - 0.1 * grads * (1.0 / n_rays)
+    bits = (torch.arange(4096) % 7 == 0).to(torch.uint8) if rank == 0 else torch.zeros(4096, dtype=torch.uint8)
+    D.broadcast_bitfield(bits, src=0)
+    t = D.max_over_ranks(1.0 + rank)
+    ret[rank] = (lo, hi, grads.numpy(), params.numpy(), bits.numpy(), t)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_allreduce_matches_single_process():
+    world, n_rays = 2, 1001
+    ctx = mp.get_context('spawn')
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_rays, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (lo0, hi0, g0, p0, b0, t0), (lo1, hi1, g1, p1, b1, t1) = ret[0], ret[1]
+    assert (lo0, hi0, lo1, hi1) == (0, 501, 501, 1001)
+    g = torch.Generator().manual_seed(0)
+    rays = torch.rand(n_rays, 6, generator=g)
+    ref = _fake_grad(rays, torch.linspace(-1, 1, 1000)).numpy()
+    np.testing.assert_allclose(g0, ref, rtol=1e-5, atol=1e-4)
+    assert np.array_equal(g0, g1) and np.array_equal(p0, p1)  # replicas stay bit-identical
+    assert np.array_equal(b0, b1) and b0.sum() == len(range(0, 4096, 7))
+    assert t0 == t1 == 2.0
+
+
+@pytest.mark.parametrize('n,world', [(10, 3), (7, 8), (32768, 8), (0, 2), (5, 1)])
+def test_shard_range_partitions_exactly(n, world):
+    seen = []
+    for r in range(world):
+        lo, hi = D.shard_range(n, r, world)
+        assert 0 <= lo <= hi <= n
+        seen += list(range(lo, hi))
+    assert seen == list(range(n))
+    sizes = [D.shard_range(n, r, world)[1] - D.shard_range(n, r, world)[0] for r in range(world)]
+    assert max(sizes) - min(sizes) <= 1
+
+
+def test_balanced_shards_equalise_sample_counts():
+    g = torch.Generator().manual_seed(1)
+    counts = (torch.rand(8192, generator=g) ** 4 * 300).long()  # a few long rays, many short ones
+    counts[::5] = 0
+    b = D.balanced_shards(counts, 8)
+    assert b[0] == 0 and b[-1] == 8192 and all(b[i] <= b[i + 1] for i in range(8))
+    per = [int(counts[b[i]:b[i + 1]].sum()) for i in range(8)]
+    assert max(per) - min(per) <= int(counts.max()) + 1
+    naive = [int(counts[D.shard_range(8192, r, 8)[0]:D.shard_range(8192, r, 8)[1]].sum()) for r in range(8)]
+    assert max(per) - min(per) <= max(naive) - min(naive)
+    assert D.balanced_shards(torch.zeros(0), 4) == [0, 0, 0, 0, 0]
+
+
+def test_single_process_helpers_are_noops():
+    t = torch.ones(4)
+    assert D.allreduce_grads(t, 1) is t and D.broadcast_bitfield(t) is t and D.broadcast_params(t) is t
+    assert D.max_over_ranks(3.5) == 3.5
