@@ -117,6 +117,60 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const float *__restrict__ 
 // sigma = out_act(geo_out[:,0]) (EncoderMLPGeoNet.handle_output / FusedMLPGeoNet.handle_output_combine);
 // rad_in = fuse_radiance_inputs(..) for modes 'fv' / 'vf' (encoder_mlp_network.py:93-118): geo feature slice and
 // SH(normalize(view_dir)) concatenated in mode order; normalize = v / (|v| + 1e-8) (geometry/transformation.py:21).
+// one lane per float4 of the output rows: loads and stores are fully coalesced (16 B per lane, consecutive lanes consecutive
+// addresses).  Requires Wf, Wg, feat_off and deg^2 to be multiples of 4 (NGP: 16/16/0/16); other shapes take the row kernel.
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256)
+ngp_glue_fwd_vec_kernel(const float *__restrict__ geo_out, const float *__restrict__ dirs, int Wg, int feat_off, int Wf,
+                        int degree, int feat_first, int sigma_act, float *__restrict__ rad_in, float *__restrict__ sigma,
+                        int64_t n, const int32_t *n_ptr) {
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int nsh = degree * degree, W = Wf + nsh, Q = W >> 2, Qf = Wf >> 2;
+    const int64_t total = cnt * Q;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / Q;
+        const int q = (int)(i - s * Q);
+        const int qf = feat_first ? q : q - (nsh >> 2);     // index inside the feature part
+        const int qs = feat_first ? q - Qf : q;              // index inside the SH part
+        f4v v;
+        if (qf >= 0 && qf < Qf) {
+            v = *reinterpret_cast<const f4v *>(geo_out + s * Wg + feat_off + 4 * qf);
+            if (qf == 0 && sigma && feat_off == 0) sigma[s] = act_fwd(v.x, sigma_act, 1.0f);
+        } else {
+            float dx = dirs[3 * s], dy = dirs[3 * s + 1], dz = dirs[3 * s + 2];
+            float nrm = sqrtf((dx * dx + dy * dy) + dz * dz) + 1e-8f;
+            float o[25];
+            sh_eval(dx / nrm, dy / nrm, dz / nrm, degree, o);
+            v = f4v{o[4 * qs], o[4 * qs + 1], o[4 * qs + 2], o[4 * qs + 3]};
+        }
+        *reinterpret_cast<f4v *>(rad_in + s * W + 4 * q) = v;
+        if (q == 0 && sigma && feat_off != 0) sigma[s] = act_fwd(geo_out[s * Wg], sigma_act, 1.0f);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+ngp_glue_bwd_vec_kernel(const float *__restrict__ geo_out, const float *__restrict__ d_rad_in, const float *__restrict__ d_sigma,
+                        int Wg, int feat_off, int Wf, int degree, int feat_first, int sigma_act,
+                        float *__restrict__ d_geo_out, int64_t n, const int32_t *n_ptr) {
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int nsh = degree * degree, W = Wf + nsh, Q = Wg >> 2;
+    const int64_t total = cnt * Q;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / Q;
+        const int q = (int)(i - s * Q);
+        const int c0 = 4 * q;
+        f4v v = {0.f, 0.f, 0.f, 0.f};
+        if (c0 >= feat_off && c0 + 3 < feat_off + Wf)
+            v = *reinterpret_cast<const f4v *>(d_rad_in + s * W + (feat_first ? 0 : nsh) + (c0 - feat_off));
+        if (q == 0 && d_sigma) {
+            const float x0 = geo_out[s * Wg];
+            v.x += d_sigma[s] * act_grad(x0, act_fwd(x0, sigma_act, 1.0f), sigma_act, 1.0f);
+        }
+        *reinterpret_cast<f4v *>(d_geo_out + s * Wg + c0) = v;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 ngp_glue_fwd_kernel(const float *__restrict__ geo_out, const float *__restrict__ dirs, int Wg, int feat_off, int Wf,
                     int degree, int feat_first, int sigma_act, float *__restrict__ rad_in, float *__restrict__ sigma,
@@ -216,8 +270,13 @@ ARCN_EXPORT int arcn_ngp_glue_fwd(const float *geo_out, const float *dirs, int W
     if (!geo_out || !rad_in || Wg < 1 || Wf < 0 || feat_off < 0 || feat_off + Wf > Wg || sh_degree < 0 || sh_degree > 5 ||
         (sh_degree > 0 && !dirs))
         return einval("ngp_glue_fwd: bad argument");
-    hipLaunchKernelGGL(ngp_glue_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), geo_out, dirs, Wg, feat_off,
-                       Wf, sh_degree, feat_first, sigma_act, rad_in, sigma, n, n_ptr);
+    const int nsh = sh_degree * sh_degree;
+    if ((Wg & 3) == 0 && (Wf & 3) == 0 && (nsh & 3) == 0 && feat_off == 0)
+        hipLaunchKernelGGL(ngp_glue_fwd_vec_kernel, dim3(grid_for(n * ((Wf + nsh) >> 2))), dim3(256), 0, as_stream(stream), geo_out,
+                           dirs, Wg, feat_off, Wf, sh_degree, feat_first, sigma_act, rad_in, sigma, n, n_ptr);
+    else
+        hipLaunchKernelGGL(ngp_glue_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), geo_out, dirs, Wg, feat_off,
+                           Wf, sh_degree, feat_first, sigma_act, rad_in, sigma, n, n_ptr);
     return check_launch("ngp_glue_fwd");
 }
 
@@ -226,7 +285,12 @@ ARCN_EXPORT int arcn_ngp_glue_bwd(const float *geo_out, const float *d_rad_in, c
                                   const int32_t *n_ptr, void *stream) {
     if (n <= 0) return ARCN_OK;
     if (!geo_out || !d_rad_in || !d_geo_out || Wg < 1 || feat_off + Wf > Wg) return einval("ngp_glue_bwd: bad argument");
-    hipLaunchKernelGGL(ngp_glue_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), geo_out, d_rad_in, d_sigma, Wg,
-                       feat_off, Wf, sh_degree, feat_first, sigma_act, d_geo_out, n, n_ptr);
+    const int nsh_b = sh_degree * sh_degree;
+    if ((Wg & 3) == 0 && (Wf & 3) == 0 && (nsh_b & 3) == 0 && feat_off == 0)
+        hipLaunchKernelGGL(ngp_glue_bwd_vec_kernel, dim3(grid_for(n * (Wg >> 2))), dim3(256), 0, as_stream(stream), geo_out, d_rad_in,
+                           d_sigma, Wg, feat_off, Wf, sh_degree, feat_first, sigma_act, d_geo_out, n, n_ptr);
+    else
+        hipLaunchKernelGGL(ngp_glue_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), geo_out, d_rad_in, d_sigma, Wg,
+                           feat_off, Wf, sh_degree, feat_first, sigma_act, d_geo_out, n, n_ptr);
     return check_launch("ngp_glue_bwd");
 }

@@ -337,9 +337,36 @@ sample_cdf_kernel(const float *__restrict__ bins, const float *__restrict__ cdf,
     for (int k = threadIdx.x; k < n_sample; k += blockDim.x) samples[r * n_sample + k] = s_val[k];
 }
 
+// ---- ImgLoss(Huber) value + gradient (arcnerf/loss/img_loss.py:60-100), mean over all R*3 elements, times weight ----
+__global__ void __launch_bounds__(256) huber_kernel(const float *__restrict__ x, const float *__restrict__ y, int64_t n, float delta,
+                                                    float weight, float *__restrict__ dx, float *__restrict__ loss) {
+    float acc = 0.f;
+    const float scale = weight / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = x[i] - y[i];
+        const float ad = fabsf(d);
+        const bool quad = ad < delta;
+        acc += quad ? (0.5f / delta) * ad * ad : ad - 0.5f * delta;
+        if (dx) dx[i] = (quad ? d / delta : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f))) * scale;
+    }
+    acc = wave_sum(acc);
+    if (loss && lane_id() == 0) atomicAdd(loss, acc * scale);
+}
+
 }  // namespace arcn
 
 using namespace arcn;
+
+ARCN_EXPORT int arcn_huber_loss_grad(const float *x, const float *y, int64_t n, float delta, float weight, float *dx,
+                                     float *loss, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!x || !y || !(delta > 0)) return einval("huber_loss_grad: bad argument");
+    if (loss && hipMemsetAsync(loss, 0, sizeof(float), as_stream(stream)) != hipSuccess) return check_launch("memset");
+    int64_t blocks = ceil_div<int64_t>(n, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(huber_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, y, n, delta, weight, dx, loss);
+    return check_launch("huber_loss_grad");
+}
 
 ARCN_EXPORT int arcn_ray_marching_fwd(const float *sigma, const float *alpha_in, const float *radiance,
                                       const float *zvals, const float *noise, const float *bkg, int64_t bkg_rows,

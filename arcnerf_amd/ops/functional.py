@@ -390,6 +390,19 @@ def composite_packed_bwd(sigma, radiance, t, offsets, d_rgb, d_depth=None, d_mas
     return d_sigma, d_rad
 
 
+def huber_loss_grad(x, y, delta, weight=1.0, dx=None, loss=None):
+    """weight * mean(Huber_delta(x - y)) and its gradient wrt x, one kernel, no host sync (loss stays on the device)"""
+    _req(x, y)
+    x, y = _f32(x), _f32(y)
+    if dx is None:
+        dx = torch.empty_like(x)
+    if loss is None:
+        loss = torch.zeros(1, dtype=torch.float32, device=x.device)
+    N.check(N.lib().arcn_huber_loss_grad(N.ptr(x), N.ptr(y), x.numel(), float(delta), float(weight), N.ptr(dx), N.ptr(loss),
+                                        N.stream()), 'huber_loss_grad')
+    return loss, dx
+
+
 def sample_cdf(bins, cdf, u, eps=1e-5, sort=True, want_inds=False):
     _req(bins, cdf, u)
     bins, cdf, u = _f32(bins), _f32(cdf), _f32(u)

@@ -217,6 +217,8 @@ class NgpPipeline:
         b['depth'] = torch.zeros(R, dtype=f32, device=dev)
         b['mask'] = torch.zeros(R, dtype=f32, device=dev)
         b['p_dense'] = torch.full((1,), 2, dtype=i32, device=dev)
+        b['d_rgb'] = torch.zeros((R, 3), dtype=f32, device=dev)
+        b['loss'] = torch.zeros(1, dtype=f32, device=dev)
         # XCD-owned-levels scatter workspace (owner + tile counters); None selects the plain agent-scope kernel
         self.hash_ws = torch.zeros(2 * N.MAX_LEVELS, dtype=i32, device=dev) if xcd_scatter else None
         # optimiser state
@@ -345,13 +347,10 @@ class NgpPipeline:
 
     def huber_grad(self, rgb, target):
         """ImgLoss(Huber, delta, weight) of arcnerf/loss/img_loss.py:60-100: loss value and d loss / d rgb (mean over R*3)."""
-        cfg = self.cfg
-        diff = rgb - target
-        ad = diff.abs()
-        loss = torch.where(ad < cfg.huber_delta, 0.5 / cfg.huber_delta * ad * ad, ad - 0.5 * cfg.huber_delta).mean() * cfg.loss_weight
-        scale = cfg.loss_weight / diff.numel()
-        d = torch.where(ad < cfg.huber_delta, diff / cfg.huber_delta, torch.sign(diff)) * scale
-        return loss, d.contiguous()
+        cfg, b = self.cfg, self.buf
+        R = rgb.shape[0]
+        loss, d = F.huber_loss_grad(rgb, target, cfg.huber_delta, cfg.loss_weight, dx=b['d_rgb'][:R], loss=b['loss'])
+        return loss[0], d
 
     def optimizer_step(self, world_size=1):
         cfg, fld = self.cfg, self.field

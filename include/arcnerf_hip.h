@@ -198,6 +198,11 @@ int arcn_composite_packed_bwd(const float *sigma, const float *radiance, const f
                               const int32_t *p_dense_ptr, int add_inf_z, int white_bkg, const float *d_rgb,
                               const float *d_depth, const float *d_mask, float *d_sigma, float *d_radiance, void *stream);
 
+/* ImgLoss with loss_type Huber (arcnerf/loss/img_loss.py:60-100): loss[0] = weight * mean(huber_delta(x - y)) over n
+ * elements, dx = d loss / d x.  dx and loss are optional. */
+int arcn_huber_loss_grad(const float *x, const float *y, int64_t n, float delta, float weight, float *dx, float *loss,
+                         void *stream);
+
 /* sample_cdf (ray_helper.py:432-473): bins/cdf (R,n_pts), u (R,n_sample) -> samples (R,n_sample) sorted,
  * inds (R,n_sample) int32 optional (searchsorted right=True). */
 int arcn_sample_cdf(const float *bins, const float *cdf, const float *u, int64_t R, int n_pts, int n_sample, float eps,
