@@ -47,9 +47,7 @@ class Encoding(nn.Module):
 
     def forward(self, x):
         if self.otype == 'HashGrid':
-            if self._ws is None or self._ws.device != x.device:
-                self._ws = torch.zeros(2 * N.MAX_LEVELS, dtype=torch.int32, device=x.device)
-            return HashGridFn.apply(x, self.params.view(-1, self.desc.n_feat), self.desc, self._ws)
+            return HashGridFn.apply(x, self.params.view(-1, self.desc.n_feat), self.desc, True)
         # tcnn maps [0,1] -> [-1,1] internally; the reference's torch branch evaluates the polynomials on the [0,1] value
         # (sh_encoder.py:116,140-185).  The parity target is the torch branch: undo the caller's (d+1)/2 and re-apply it
         # inside the kernel, i.e. evaluate on exactly the value the torch branch sees.

@@ -211,69 +211,104 @@ struct TiledPlan {
     int32_t chunk_rows[ARCN_MAX_LEVELS];
 };
 
+// Prep pass of the owner-computes scatter: one 32-byte record per (level, sample), level-major so the owners of level l
+// stream it contiguously.  Everything that is identical for the ~32 owner workgroups of a level is done ONCE here: the
+// exact cell (fp32 divide, bit-identical to the forward), the trilinear weights and the incoming gradient.
+//   word0 = cx | cy << 16, word1 = cz | valid << 16, w[3], g[2], pad
+struct __attribute__((aligned(16))) ScatterRec {
+    uint32_t cxy, czv;
+    float w0, w1, w2, g0, g1, pad;
+};
+
+template <int F>
+__global__ void __launch_bounds__(256)
+scatter_prep_kernel(const float *__restrict__ xyz, const float *__restrict__ dout, GridParams g, ScatterRec *__restrict__ recs,
+                    int64_t n_cap, int64_t n, const int32_t *n_ptr) {
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int l = blockIdx.y;
+    const LevelParams lp = g.lv[l];
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cnt; s += (int64_t)gridDim.x * blockDim.x) {
+        const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
+        const Cell cell = locate(p, g, lp.res);
+        ScatterRec r;
+        r.cxy = cell.valid ? (cell.c[0] | (cell.c[1] << 16)) : 0u;
+        r.czv = cell.valid ? (cell.c[2] | (1u << 16)) : 0u;
+        r.w0 = cell.valid ? cell.w[0] : 0.f;
+        r.w1 = cell.valid ? cell.w[1] : 0.f;
+        r.w2 = cell.valid ? cell.w[2] : 0.f;
+        r.g0 = dout[(s * g.L + l) * F];
+        r.g1 = F > 1 ? dout[(s * g.L + l) * F + (F > 1 ? 1 : 0)] : 0.f;
+        r.pad = 0.f;
+        recs[(int64_t)l * n_cap + s] = r;
+    }
+}
+
 template <int F>
 __global__ void __launch_bounds__(kTiledThreads)
-hashgrid_bwd_tiled_kernel(const float *__restrict__ xyz, const float *__restrict__ dout, GridParams g, TiledPlan plan,
+hashgrid_bwd_tiled_kernel(const ScatterRec *__restrict__ recs, int64_t n_cap, GridParams g, TiledPlan plan,
                           float *__restrict__ dtable, int64_t n, const int32_t *n_ptr) {
     extern __shared__ __attribute__((aligned(16))) float acc[];
     const int64_t cnt = dev_count(n, n_ptr);
-    int l = 0;
-    while (l + 1 < g.L && (int)blockIdx.x >= plan.item_first[l + 1]) ++l;
-    const int item = blockIdx.x - plan.item_first[l];
+    // work items are laid out finest level first: the unsplit fine-level owners (all the same length) fill the first
+    // round of CUs, the shorter split items of the coarse levels pack into the second one
+    int k = 0;
+    while (k + 1 < g.L && (int)blockIdx.x >= plan.item_first[k + 1]) ++k;
+    const int item = blockIdx.x - plan.item_first[k];
+    const int l = g.L - 1 - k;
     const int chunk = item / plan.n_splits[l], split = item % plan.n_splits[l];
     const LevelParams lp = g.lv[l];
     const uint32_t row_lo = (uint32_t)chunk * (uint32_t)plan.chunk_rows[l];
     const uint32_t row_hi_raw = row_lo + (uint32_t)plan.chunk_rows[l];
     const uint32_t row_hi = row_hi_raw < lp.size ? row_hi_raw : lp.size;
     const int n_rows = (int)(row_hi - row_lo);
+    const uint32_t n_rows_u = (uint32_t)n_rows;
     for (int i = threadIdx.x; i < n_rows * F; i += kTiledThreads) acc[i] = 0.f;
     __syncthreads();
     const int64_t per = (cnt + plan.n_splits[l] - 1) / plan.n_splits[l];
     const int64_t s_lo = per * split, s_hi = (s_lo + per < cnt) ? s_lo + per : cnt;
-    float vs[3], inv_vs[3];
+    // Inner loop: VALU-issue bound, so it only unpacks, hashes (two xors + mask per corner on power-of-two levels) and
+    // visits the few in-slice corners.  LDS float atomics cost ~3 cycles per ACTIVE lane on gfx950 (measured; integer ones
+    // are ~28x cheaper), hence the set-bit loop instead of 16 predicated full-wave ds_add_f32.
+    const ScatterRec *pr = recs + (int64_t)l * n_cap + s_lo + (int64_t)threadIdx.x;
+    int remaining = (s_lo + (int64_t)threadIdx.x < s_hi)
+                        ? (int)((s_hi - s_lo - (int64_t)threadIdx.x + kTiledThreads - 1) / kTiledThreads) : 0;
+    ScatterRec nxt = {};
+    if (remaining > 0) nxt = *pr;
+    for (; remaining > 0; --remaining) {
+        const ScatterRec r = nxt;
+        pr += kTiledThreads;
+        if (remaining > 1) nxt = *pr;  // register prefetch of the next record
+        const uint32_t cx = r.cxy & 0xffffu, cy = r.cxy >> 16, cz = r.czv & 0xffffu;
+        uint32_t hit = 0;
+        uint32_t hx0 = 0, hx1 = 0, hy0 = 0, hy1 = 0, hz0 = 0, hz1 = 0;
+        if (lp.mask) {
+            hx0 = cx; hx1 = cx + 1u;
+            hy0 = cy * 2654435761u; hy1 = hy0 + 2654435761u;
+            hz0 = cz * 805459861u; hz1 = hz0 + 805459861u;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { vs[k] = (g.mx[k] - g.mn[k]) / (float)lp.res; inv_vs[k] = 1.0f / vs[k]; }
-    const float fres = (float)lp.res;
-    for (int64_t s = s_lo + threadIdx.x; s < s_hi; s += kTiledThreads) {
-        const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
-        uint32_t c[3];
-        float w[3];
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float pm = p[k] - g.mn[k];
-            float v = pm * inv_vs[k];
-            float fl = floorf(v);
-            const float fr = v - fl;
-            if (!(fr >= 2e-3f && fr <= 1.0f - 2e-3f)) { v = pm / vs[k]; fl = floorf(v); }  // exact near integers
-            if (!(v >= 0.f) || !(v < fres)) ok = false;
-            c[k] = (uint32_t)fl;
-            const float a = fl * vs[k];
-            const float g0 = a + g.mn[0];
-            const float ww = (p[k] - g0) * inv_vs[k];
-            w[k] = ww < 0.0f ? 0.0f : (ww > 1.0f ? 1.0f : ww);
-        }
-        if (!ok) continue;
-        float go[F];
-        bool have = false;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
-            const uint32_t row = hash_row(c[0] + ox, c[1] + oy, c[2] + oz, lp);
-            if (row >= row_lo && row < row_hi) {
-                if (!have) {
-#pragma unroll
-                    for (int f = 0; f < F; ++f) go[f] = dout[(s * g.L + l) * F + f];
-                    have = true;
-                }
-                const float wx = ox ? w[0] : 1.0f - w[0];
-                const float wy = oy ? w[1] : 1.0f - w[1];
-                const float wz = oz ? w[2] : 1.0f - w[2];
-                const float wt = (wx * wy) * wz;
-                float *dst = acc + (row - row_lo) * F;
-#pragma unroll
-                for (int f = 0; f < F; ++f) __hip_atomic_fetch_add(dst + f, go[f] * wt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t rr = ((((q >> 1) & 1) ? hx1 : hx0) ^ ((q & 1) ? hy1 : hy0) ^ ((q >> 2) ? hz1 : hz0)) & lp.mask;
+                hit |= ((rr - row_lo) < n_rows_u ? 1u : 0u) << q;
             }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t rr = hash_row(cx + ((q >> 1) & 1), cy + (q & 1), cz + (q >> 2), lp);
+                hit |= ((rr - row_lo) < n_rows_u ? 1u : 0u) << q;
+            }
+        }
+        if (!(r.czv >> 16)) hit = 0;
+        while (hit) {
+            const int q = __builtin_ctz(hit);
+            hit &= hit - 1;
+            const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
+            uint32_t rr;
+            if (lp.mask) rr = ((ox ? hx1 : hx0) ^ (oy ? hy1 : hy0) ^ (oz ? hz1 : hz0)) & lp.mask;
+            else rr = hash_row(cx + ox, cy + oy, cz + oz, lp);
+            const float wt = ((ox ? r.w0 : 1.0f - r.w0) * (oy ? r.w1 : 1.0f - r.w1)) * (oz ? r.w2 : 1.0f - r.w2);
+            float *dsta = acc + (rr - row_lo) * F;
+            __hip_atomic_fetch_add(dsta, r.g0 * wt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (F > 1) __hip_atomic_fetch_add(dsta + (F > 1 ? 1 : 0), r.g1 * wt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     __syncthreads();
@@ -331,27 +366,29 @@ ARCN_EXPORT int arcn_hashgrid_fwd(const float *xyz, const float *table, const ar
 }
 
 ARCN_EXPORT int arcn_hashgrid_bwd(const float *xyz, const float *table, const float *dout,
-                                  const arcn_hashgrid_desc *desc_host, float *dtable, float *dxyz, int32_t *workspace,
+                                  const arcn_hashgrid_desc *desc_host, float *dtable, float *dxyz, float *workspace,
                                   int64_t n, const int32_t *n_ptr, void *stream) {
     if (n <= 0) return ARCN_OK;
     if (!xyz || !dout || (!dtable && !dxyz) || (dxyz && !table)) return einval("hashgrid_bwd: missing argument");
     GridParams g;
     int rc = build_params(desc_host, g);
     if (rc) return rc;
-    if (workspace && dtable && !dxyz) {
+    if (workspace && dtable && !dxyz && g.F <= 2) {
         // owner-computes scatter through LDS (workspace only selects the path; nothing is stored in it)
         TiledPlan plan;
         int items = 0;
-        for (int l = 0; l < g.L; ++l) {
+        for (int k = 0; k < g.L; ++k) {
+            const int l = g.L - 1 - k;  // item_first is indexed by dispatch position k, the per-level fields by level
             const int64_t size = g.lv[l].size;
             const int rows_cap = kChunkRows * 2 / g.F;  // 128 KiB of floats
             int nc = (int)((size + rows_cap - 1) / rows_cap);
             int cr = (int)((size + nc - 1) / nc);
             int ns = 32 / nc;  // about 32 workgroups per level
+            if (!g.lv[l].mask) ns *= 2;  // non-power-of-two levels pay an exact 64-bit modulo per corner: shorter items
             if (ns < 1) ns = 1;
             // never split so finely that a split has fewer than 4096 samples
             while (ns > 1 && n / ns < 4096) ns >>= 1;
-            plan.item_first[l] = items;
+            plan.item_first[k] = items;
             plan.n_chunks[l] = nc;
             plan.n_splits[l] = ns;
             plan.chunk_rows[l] = cr;
@@ -360,18 +397,21 @@ ARCN_EXPORT int arcn_hashgrid_bwd(const float *xyz, const float *table, const fl
         plan.item_first[g.L] = items;
         for (int l = g.L + 1; l <= ARCN_MAX_LEVELS; ++l) plan.item_first[l] = items;
         const size_t lds = sizeof(float) * (size_t)kChunkRows * 2;
-        hipError_t e = hipSuccess;
-        switch (g.F) {
-        case 1: e = hipFuncSetAttribute(reinterpret_cast<const void *>(hashgrid_bwd_tiled_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
-        case 2: e = hipFuncSetAttribute(reinterpret_cast<const void *>(hashgrid_bwd_tiled_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
-        default: e = hipFuncSetAttribute(reinterpret_cast<const void *>(hashgrid_bwd_tiled_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
-        }
+        hipError_t e = g.F == 1
+            ? hipFuncSetAttribute(reinterpret_cast<const void *>(hashgrid_bwd_tiled_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+            : hipFuncSetAttribute(reinterpret_cast<const void *>(hashgrid_bwd_tiled_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
         dim3 pgrid((unsigned)items);
-        switch (g.F) {
-        case 1: hipLaunchKernelGGL(hashgrid_bwd_tiled_kernel<1>, pgrid, dim3(kTiledThreads), lds, as_stream(stream), xyz, dout, g, plan, dtable, n, n_ptr); break;
-        case 2: hipLaunchKernelGGL(hashgrid_bwd_tiled_kernel<2>, pgrid, dim3(kTiledThreads), lds, as_stream(stream), xyz, dout, g, plan, dtable, n, n_ptr); break;
-        default: hipLaunchKernelGGL(hashgrid_bwd_tiled_kernel<4>, pgrid, dim3(kTiledThreads), lds, as_stream(stream), xyz, dout, g, plan, dtable, n, n_ptr); break;
+        ScatterRec *recs = reinterpret_cast<ScatterRec *>(workspace);
+        int64_t tb = ceil_div<int64_t>(n, 256);
+        if (tb > 1024) tb = 1024;
+        dim3 tgrid((unsigned)tb, (unsigned)g.L);
+        if (g.F == 1) {
+            hipLaunchKernelGGL(scatter_prep_kernel<1>, tgrid, dim3(256), 0, as_stream(stream), xyz, dout, g, recs, n, n, n_ptr);
+            hipLaunchKernelGGL(hashgrid_bwd_tiled_kernel<1>, pgrid, dim3(kTiledThreads), lds, as_stream(stream), recs, n, g, plan, dtable, n, n_ptr);
+        } else {
+            hipLaunchKernelGGL(scatter_prep_kernel<2>, tgrid, dim3(256), 0, as_stream(stream), xyz, dout, g, recs, n, n, n_ptr);
+            hipLaunchKernelGGL(hashgrid_bwd_tiled_kernel<2>, pgrid, dim3(kTiledThreads), lds, as_stream(stream), recs, n, g, plan, dtable, n, n_ptr);
         }
         return check_launch("hashgrid_bwd_tiled");
     }
@@ -382,4 +422,9 @@ ARCN_EXPORT int arcn_hashgrid_bwd(const float *xyz, const float *table, const fl
     default: hipLaunchKernelGGL(hashgrid_bwd_kernel<4>, grid, dim3(256), 0, as_stream(stream), xyz, table, dout, g, dtable, dxyz, n, n_ptr); break;
     }
     return check_launch("hashgrid_bwd");
+}
+
+ARCN_EXPORT int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc *desc_host, int64_t n) {
+    if (!desc_host || n <= 0) return 0;
+    return n * (int64_t)desc_host->n_levels * 8;  // one 32-byte record per (level, sample)
 }

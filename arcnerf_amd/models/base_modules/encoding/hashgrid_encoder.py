@@ -48,7 +48,5 @@ class HashGridEmbedder(nn.Module):
 
     def forward(self, xyz):
         assert xyz.dim() == 2 and xyz.shape[-1] == 3, 'Must be (B, 3) tensor'
-        if self._ws is None or self._ws.device != xyz.device:
-            self._ws = torch.zeros(2 * N.MAX_LEVELS, dtype=torch.int32, device=xyz.device)
-        emb = HashGridFn.apply(xyz, self.embeddings, self.desc, self._ws)
+        emb = HashGridFn.apply(xyz, self.embeddings, self.desc, True)
         return torch.cat([xyz, emb], dim=-1) if self.include_input else emb

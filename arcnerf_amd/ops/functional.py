@@ -182,10 +182,20 @@ def hashgrid_fwd(xyz, table, desc, want_idx=False, n_dev=None, out=None):
     return (out, idx) if want_idx else out
 
 
+def hashgrid_bwd_workspace(desc, n, device):
+    """scratch of the owner-computes scatter: one 32-byte record per (level, sample)"""
+    return torch.empty(max(1, int(n) * desc.n_levels * 8), dtype=torch.float32, device=device)
+
+
 def hashgrid_bwd(xyz, table, dout, desc, want_dtable=True, want_dxyz=False, n_dev=None, dtable=None, workspace=None):
+    """workspace: True (allocate) or a float tensor from hashgrid_bwd_workspace -> owner-computes scatter; None -> atomics"""
     _req(xyz, table, dout)
     xyz, table, dout = _f32(xyz), _f32(table), _f32(dout)
     n = xyz.shape[0]
+    if workspace is True:
+        workspace = hashgrid_bwd_workspace(desc, n, xyz.device)
+    if workspace is not None:
+        assert workspace.dtype == torch.float32 and workspace.numel() >= n * desc.n_levels * 8
     if want_dtable and dtable is None:
         dtable = torch.zeros_like(table)
     dxyz = torch.zeros((n, 3), dtype=torch.float32, device=xyz.device) if want_dxyz else None

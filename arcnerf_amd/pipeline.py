@@ -220,7 +220,7 @@ class NgpPipeline:
         b['d_rgb'] = torch.zeros((R, 3), dtype=f32, device=dev)
         b['loss'] = torch.zeros(1, dtype=f32, device=dev)
         # XCD-owned-levels scatter workspace (owner + tile counters); None selects the plain agent-scope kernel
-        self.hash_ws = torch.zeros(2 * N.MAX_LEVELS, dtype=i32, device=dev) if xcd_scatter else None
+        self.hash_ws = torch.empty(S * cfg.n_levels * 8, dtype=f32, device=dev) if xcd_scatter else None  # scatter records
         # optimiser state
         n = field.n_params
         self.exp_avg = torch.zeros(n, dtype=f32, device=dev)

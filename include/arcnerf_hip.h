@@ -112,11 +112,13 @@ typedef struct {
 int arcn_hashgrid_fwd(const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out,
                       int32_t *hash_idx, int64_t n, const int32_t *n_ptr, void *stream);
 /* backward: dtable (n_total,F) accumulated with atomics (caller zeroes), dxyz (n,3) optional.
- * workspace (any non-NULL device pointer, optional): selects the owner-computes scatter (each workgroup owns a slice
- * of one level's dtable in LDS and writes it back with plain stores, no global atomics on large levels); without it, or
- * when dxyz is requested, the plain one-atomic-per-corner kernel runs.  Both paths ADD into dtable. */
+ * workspace (device, arcn_hashgrid_bwd_workspace_floats(desc, n) floats, optional): selects the owner-computes scatter
+ * (a prep pass writes one 32-byte {cell, weights, gradient} record per (level, sample) into the workspace; each workgroup
+ * then owns a slice of one level's dtable in LDS and writes it back with plain stores, no global atomics on large levels);
+ * without it, when dxyz is requested, or for n_feat 4, the plain one-atomic-per-corner kernel runs.  Both ADD into dtable. */
 int arcn_hashgrid_bwd(const float *xyz, const float *table, const float *dout, const arcn_hashgrid_desc *desc_host,
-                      float *dtable, float *dxyz, int32_t *workspace, int64_t n, const int32_t *n_ptr, void *stream);
+                      float *dtable, float *dxyz, float *workspace, int64_t n, const int32_t *n_ptr, void *stream);
+int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc *desc_host, int64_t n);
 
 /* FreqEmbedder.forward (encoding/freq_encoder.py:65-88): out (n, D*(include_input + 2*n_freqs)). */
 int arcn_freq_fwd(const float *x, int D, int n_freqs, int include_input, float *out, int64_t n, void *stream);

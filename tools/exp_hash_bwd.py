@@ -29,13 +29,13 @@ table = fld.view('table')
 dt = torch.zeros_like(table)
 dout = torch.randn(n, 32, device=dev)
 print('full bwd plain  %.3f ms' % timeit(lambda: F.hashgrid_bwd(xyz, table, dout, fld.grid_desc, dtable=dt)))
-ws = torch.zeros(64, dtype=torch.int32, device=dev)
+ws = F.hashgrid_bwd_workspace(fld.grid_desc, n, dev)
 print('full bwd xcd    %.3f ms' % timeit(lambda: F.hashgrid_bwd(xyz, table, dout, fld.grid_desc, dtable=dt, workspace=ws)))
 print('full fwd        %.3f ms' % timeit(lambda: F.hashgrid_fwd(xyz, table, fld.grid_desc)))
 for l in range(16):
     desc = N.make_hashgrid_desc([fld.resolutions[l]], [fld.offsets[l], fld.offsets[l + 1]], 2, fld.min_xyz, fld.max_xyz)
     d1 = torch.randn(n, 2, device=dev)
-    tb = timeit(lambda: F.hashgrid_bwd(xyz, table, d1, desc, dtable=dt))
+    tb = timeit(lambda: F.hashgrid_bwd(xyz, table, d1, desc, dtable=dt, workspace=ws))
     tf = timeit(lambda: F.hashgrid_fwd(xyz, table, desc))
     print('level %2d res %4d: bwd %.3f ms  fwd %.3f ms' % (l, fld.resolutions[l], tb, tf))
 # uncontended atomic rate: random xyz in the volume
