@@ -16,6 +16,8 @@
 // summation-order noise (~1e-7 rel) — this is what lets the path meet the 1e-4 RGB parity bar without fp16.
 // Roofline: 18.8 kFLOP/sample fwd for the NGP nets; at the 1e8 samples/s target that is 1.9 TFLOP/s of the 157 TFLOP/s
 // f32 matrix peak — the MLP is bound by its operand traffic (128 B/sample features in, 16..64 B out), not by MFMA.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace arcn {
@@ -307,9 +309,8 @@ struct DwParams {
 
 __global__ void __launch_bounds__(256)
 mlp_bwd_dw_kernel(const float *__restrict__ x, const float *__restrict__ acts, const float *__restrict__ scratch, DwParams P,
-                  float *__restrict__ dweights, float *__restrict__ dbiases, int64_t n_cap, int64_t n,
+                  float *__restrict__ partials, float *__restrict__ bias_partials, int64_t n_cap, int64_t n,
                   const int32_t *n_ptr) {
-    __shared__ __attribute__((aligned(16))) float red[4][16][64][4];  // 64 KiB: per-wave accumulators
     const int64_t cnt = dev_count(n, n_ptr);
     // which (layer, quadrant)
     int l = 0;
@@ -338,52 +339,110 @@ mlp_bwd_dw_kernel(const float *__restrict__ x, const float *__restrict__ acts, c
     const int64_t steps = (cnt + 3) >> 2;
     const int64_t per = (steps + total_waves - 1) / total_waves;
     const int64_t st_lo = gw * per, st_hi = (st_lo + per < steps) ? st_lo + per : steps;
-    for (int64_t st = st_lo; st < st_hi; ++st) {
-        const int64_t s = st * 4 + g;
-        const bool ok = s < cnt;
-        float av[4], bv[4];
+    // 4 four-sample steps per iteration: all (up to 32) scalar operand loads are issued before the first MFMA so their
+    // L2 latency overlaps; tile rows/cols beyond this layer's size are skipped (wave-uniform).
+    constexpr int U = 4;
+    for (int64_t st = st_lo; st < st_hi; st += U) {
+        float av[U][4], bv[U][4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int row = 16 * (mt0 + a) + i;
-            av[a] = (ok && a < MT && row < N) ? dpre[s * N + row] : 0.f;
+        for (int u = 0; u < U; ++u) {
+            const int64_t s = (st + u) * 4 + g;
+            const bool ok = (st + u) < st_hi && s < cnt;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int row = 16 * (mt0 + a) + i;
+                av[u][a] = (ok && a < MT && row < N) ? dpre[s * N + row] : 0.f;
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int col = 16 * (nt0 + b) + i;
+                bv[u][b] = (ok && b < NTK && col < K) ? yprev[s * K + col] : 0.f;
+            }
         }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int col = 16 * (nt0 + b) + i;
-            bv[b] = (ok && b < NTK && col < K) ? yprev[s * K + col] : 0.f;
-        }
+        for (int u = 0; u < U; ++u) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            bsum[a] += av[a];
+            for (int a = 0; a < 4; ++a) {
+                if (a < MT) {
+                    bsum[a] += av[u][a];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < 4; ++b)
+                        if (b < NTK) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+                }
+            }
         }
     }
-    // cross-wave reduction in LDS, then one atomic per element per workgroup
+    // The 4 waves of the workgroup are summed through ONE 16 KiB LDS tile (wave 0 stores, waves 1..3 add in turn): small
+    // enough not to limit occupancy (the kernel is bound by load latency and wants many resident waves).  The workgroup's
+    // 64x64 partial then goes to its slot of `partials` with coalesced float4 stores; mlp_dw_reduce_kernel sums the slots.
+    // No global atomics here: they run at only ~20 G/s on MI355X.
+    __shared__ __attribute__((aligned(16))) float red[16][64][4];
+    __shared__ float bred[64];
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) *reinterpret_cast<f4 *>(&red[wave][a * 4 + b][lane][0]) = acc[a][b];
-    __syncthreads();
-    float *dW = dweights + P.w_off[l];
-    for (int e = threadIdx.x; e < 16 * 256; e += 256) {
-        const int tile = e >> 8, ln = (e >> 2) & 63, r = e & 3;
-        const int a = tile >> 2, b = tile & 3;
-        if (a >= MT || b >= NTK) continue;
-        float v = red[0][tile][ln][r] + red[1][tile][ln][r] + red[2][tile][ln][r] + red[3][tile][ln][r];
-        // accumulator layout: row = 4*(ln>>4) + r (output neuron), col = ln & 15 (input neuron)
-        const int row = 16 * (mt0 + a) + 4 * (ln >> 4) + r, col = 16 * (nt0 + b) + (ln & 15);
-        if (row < N && col < K && v != 0.f) unsafeAtomicAdd(&dW[(int64_t)row * K + col], v);
-    }
-    if (P.has_bias && dbiases && nt0 == 0) {
+                for (int b = 0; b < 4; ++b) {
+                    f4 *dst = reinterpret_cast<f4 *>(&red[a * 4 + b][lane][0]);
+                    *dst = (w == 0) ? acc[a][b] : (*dst + acc[a][b]);
+                }
+            if (P.has_bias && nt0 == 0) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            float v = bsum[a];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            const int row = 16 * (mt0 + a) + i;
-            if (g == 0 && a < MT && row < N && v != 0.f) unsafeAtomicAdd(&dbiases[P.b_off[l] + row], v);
+                for (int a = 0; a < 4; ++a) {
+                    float v = bsum[a];
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if (g == 0) bred[a * 16 + i] = (w == 0) ? v : bred[a * 16 + i] + v;
+                }
+            }
         }
+        __syncthreads();
+    }
+    const int64_t slot = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    f4 *part = reinterpret_cast<f4 *>(partials + slot * 4096);
+    const f4 *src4 = reinterpret_cast<const f4 *>(&red[0][0][0]);
+    for (int e = threadIdx.x; e < 1024; e += 256) part[e] = src4[e];
+    if (P.has_bias && bias_partials && nt0 == 0 && threadIdx.x < 64) bias_partials[slot * 64 + threadIdx.x] = bred[threadIdx.x];
+}
+
+// sum the per-workgroup partial tiles of one (layer, quadrant) and add them into dW / db.  grid = (16, quads, groups): each
+// z-slice sums its share of the slots (8 loads in flight per thread) and adds one value per element with a global atomic
+// (groups * 4096 * quads atomics in total, ~1e5).
+__global__ void __launch_bounds__(256)
+mlp_dw_reduce_kernel(const float *__restrict__ partials, const float *__restrict__ bias_partials, DwParams P, int n_slots,
+                     float *__restrict__ dweights, float *__restrict__ dbiases) {
+    int l = 0;
+    while (l + 1 < P.n_layers && (int)blockIdx.y >= P.quad_first[l + 1]) ++l;
+    const int q = blockIdx.y - P.quad_first[l];
+    const int N = P.dims[l + 1], K = P.dims[l];
+    const int qn = (tiles16(K) + 3) / 4;
+    const int mt0 = (q / qn) * 4, nt0 = (q % qn) * 4;
+    const int e = blockIdx.x * 256 + threadIdx.x;  // 0..4095 inside the 64x64 quadrant, fragment order
+    const int per = (n_slots + gridDim.z - 1) / gridDim.z;
+    const int lo = blockIdx.z * per, hi = min(n_slots, lo + per);
+    const float *src = partials + (int64_t)blockIdx.y * n_slots * 4096 + e;
+    float v = 0.f;
+    int sl = lo;
+    for (; sl + 8 <= hi; sl += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[(int64_t)(sl + u) * 4096];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; sl < hi; ++sl) v += src[(int64_t)sl * 4096];
+    const int tile = e >> 8, ln = (e >> 2) & 63, r = e & 3;
+    const int a = tile >> 2, b = tile & 3;
+    // accumulator layout: row = 4*(ln>>4) + r (output neuron), col = ln & 15 (input neuron)
+    const int row = 16 * (mt0 + a) + 4 * (ln >> 4) + r, col = 16 * (nt0 + b) + (ln & 15);
+    if (row < N && col < K && v != 0.f) unsafeAtomicAdd(&dweights[P.w_off[l] + (int64_t)row * K + col], v);
+    if (P.has_bias && dbiases && bias_partials && nt0 == 0 && blockIdx.x == 0 && threadIdx.x < 64) {
+        const float *bs = bias_partials + (int64_t)blockIdx.y * n_slots * 64 + threadIdx.x;
+        float bv = 0.f;
+        for (int k = lo; k < hi; ++k) bv += bs[(int64_t)k * 64];
+        const int brow = 16 * mt0 + threadIdx.x;  // threadIdx.x = a*16 + i
+        if (brow < N && bv != 0.f) unsafeAtomicAdd(&dbiases[P.b_off[l] + brow], bv);
     }
 }
 
@@ -426,7 +485,12 @@ static int set_lds(Kern k, size_t bytes) {
 
 inline unsigned tile_grid(int64_t n, int spb) {
     int64_t b = ceil_div<int64_t>(n, spb);
-    const int64_t cap = 256 * 4;  // 4 resident workgroups per CU re-use the staged weights across tiles
+    static int64_t cap = 0;  // resident workgroups re-use the staged weights across tiles
+    if (!cap) {
+        const char *e = getenv("ARCN_MLP_GRID");
+        cap = e ? atoll(e) : 512;
+        if (cap < 1) cap = 1024;
+    }
     return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
@@ -441,11 +505,27 @@ ARCN_EXPORT int64_t arcn_mlp_acts_floats(const arcn_mlp_desc *d, int64_t n_cap) 
     return s;
 }
 
-ARCN_EXPORT int64_t arcn_mlp_scratch_floats(const arcn_mlp_desc *d, int64_t n_cap) {
-    if (!d) return 0;
+// dpre of every layer, (n_cap, dims[l+1]) each
+static int64_t arcn_mlp_dpre_floats(const arcn_mlp_desc *d, int64_t n_cap) {
     int64_t s = 0;
     for (int l = 0; l < d->n_layers; ++l) s += n_cap * d->dims[l + 1];
     return s;
+}
+
+// sample slabs of the dW kernel: a function of the CAPACITY only, so the scratch layout is fixed per allocation
+static int64_t dw_slabs(int64_t n_cap) {
+    int64_t slabs = ceil_div<int64_t>(n_cap, 512);
+    if (slabs > 512) slabs = 512;
+    if (slabs < 1) slabs = 1;
+    return slabs;
+}
+
+ARCN_EXPORT int64_t arcn_mlp_scratch_floats(const arcn_mlp_desc *d, int64_t n_cap) {
+    if (!d) return 0;
+    int64_t quads = 0;
+    for (int l = 0; l < d->n_layers; ++l) quads += ((tiles16(d->dims[l + 1]) + 3) / 4) * ((tiles16(d->dims[l]) + 3) / 4);
+    // dpre of every layer + per-slab partial dW tiles (64x64 each) + per-slab partial bias sums
+    return arcn_mlp_dpre_floats(d, n_cap) + dw_slabs(n_cap) * quads * (4096 + 64);
 }
 
 ARCN_EXPORT int arcn_mlp_fwd(const float *x, const float *weights, const float *biases, const arcn_mlp_desc *desc_host,
@@ -459,7 +539,12 @@ ARCN_EXPORT int arcn_mlp_fwd(const float *x, const float *weights, const float *
     if (P.has_bias && !biases) return einval("mlp_fwd: biases required");
     const size_t lds_bytes = sizeof(float) * (size_t)lds_floats;
     if (lds_bytes > 144 * 1024) return einval("mlp_fwd: network too large for the LDS-resident fused kernel");
-    if (md <= 64) {
+    static const int fwd_nt = getenv("ARCN_MLP_NT") ? atoi(getenv("ARCN_MLP_NT")) : 2;  // 4 waves/SIMD beat 2 with wider tiles
+    if (md <= 64 && fwd_nt == 2) {
+        if ((rc = set_lds(mlp_fwd_kernel<4, 2>, lds_bytes))) return rc;
+        hipLaunchKernelGGL((mlp_fwd_kernel<4, 2>), dim3(tile_grid(n, 128)), dim3(256), lds_bytes, as_stream(stream), x, weights,
+                           biases, P, out, acts, n_cap, n, n_ptr);
+    } else if (md <= 64) {
         if ((rc = set_lds(mlp_fwd_kernel<4, 4>, lds_bytes))) return rc;
         hipLaunchKernelGGL((mlp_fwd_kernel<4, 4>), dim3(tile_grid(n, 256)), dim3(256), lds_bytes, as_stream(stream), x, weights,
                            biases, P, out, acts, n_cap, n, n_ptr);
@@ -484,7 +569,12 @@ ARCN_EXPORT int arcn_mlp_bwd(const float *x, const float *weights, const float *
     if (P.n_layers > 1 && !acts) return einval("mlp_bwd: saved activations required");
     const size_t lds_bytes = sizeof(float) * (size_t)lds_floats;
     if (lds_bytes > 144 * 1024) return einval("mlp_bwd: network too large for the LDS-resident fused kernel");
-    if (md <= 64) {
+    static const int bwd_nt = getenv("ARCN_MLP_BWD_NT") ? atoi(getenv("ARCN_MLP_BWD_NT")) : 2;
+    if (md <= 64 && bwd_nt == 2) {
+        if ((rc = set_lds(mlp_bwd_dx_kernel<4, 2>, lds_bytes))) return rc;
+        hipLaunchKernelGGL((mlp_bwd_dx_kernel<4, 2>), dim3(tile_grid(n, 128)), dim3(256), lds_bytes, as_stream(stream), weights, P,
+                           out, acts, dout, dx, scratch, n_cap, n, n_ptr);
+    } else if (md <= 64) {
         if ((rc = set_lds(mlp_bwd_dx_kernel<4, 4>, lds_bytes))) return rc;
         hipLaunchKernelGGL((mlp_bwd_dx_kernel<4, 4>), dim3(tile_grid(n, 256)), dim3(256), lds_bytes, as_stream(stream), weights, P,
                            out, acts, dout, dx, scratch, n_cap, n, n_ptr);
@@ -507,11 +597,13 @@ ARCN_EXPORT int arcn_mlp_bwd(const float *x, const float *weights, const float *
             quads += ((tiles16(P.dims[l + 1]) + 3) / 4) * ((tiles16(P.dims[l]) + 3) / 4);
         }
         D.quad_first[P.n_layers] = quads;
-        int64_t slabs = ceil_div<int64_t>(n, 2048);  // >= 512 four-sample steps per wave before the atomics
-        if (slabs > 256) slabs = 256;
-        if (slabs < 1) slabs = 1;
+        const int64_t slabs = dw_slabs(n_cap);
+        float *partials = scratch + arcn_mlp_dpre_floats(desc_host, n_cap);
+        float *bias_partials = partials + slabs * quads * 4096;
         hipLaunchKernelGGL(mlp_bwd_dw_kernel, dim3((unsigned)slabs, (unsigned)quads), dim3(256), 0, as_stream(stream), x, acts,
-                           scratch, D, dweights, dbiases, n_cap, n, n_ptr);
+                           scratch, D, partials, bias_partials, n_cap, n, n_ptr);
+        hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(16, (unsigned)quads, 8), dim3(256), 0, as_stream(stream), partials,
+                           bias_partials, D, (int)slabs, dweights, dbiases);
         if ((rc = check_launch("mlp_bwd_dw"))) return rc;
     }
     return ARCN_OK;

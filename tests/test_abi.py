@@ -56,7 +56,8 @@ def test_argument_validation_happens_before_any_launch(lib):
 def test_workspace_queries(lib):
     m = N.make_mlp_desc([32, 64, 64, 3])
     assert lib.arcn_mlp_acts_floats(C.addressof(m), 1000) == 1000 * 128
-    assert lib.arcn_mlp_scratch_floats(C.addressof(m), 1000) == 1000 * 131
+    # dpre of every layer + per-workgroup partial dW tiles (2 slabs) of the 3 (layer, 64x64 quadrant) pairs
+    assert lib.arcn_mlp_scratch_floats(C.addressof(m), 1000) == 1000 * 131 + 2 * 3 * (4096 + 64)
 
 
 def test_host_pcg32_matches_oracle(lib, oracle):
