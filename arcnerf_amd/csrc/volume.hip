@@ -417,10 +417,10 @@ __global__ void __launch_bounds__(256) update_opafield_kernel(float *__restrict_
 // opacity with a uint atomicMax into a zeroed per-cell buffer and marks the cell; pass 2 walks the grid and applies
 // max(old*ema, new) to marked cells with old >= 0.  Identical result for non-negative opacities (sigma*dt >= 0).
 __global__ void __launch_bounds__(256) opa_scatter_max_kernel(const int64_t *__restrict__ cell, const float *__restrict__ opacity,
-                                                              int64_t n, float *__restrict__ cell_max,
+                                                              int64_t n, const int32_t *n_ptr, float *__restrict__ cell_max,
                                                               uint8_t *__restrict__ touched) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= dev_count(n, n_ptr)) return;
     const int64_t c = cell[i];
     atomicMax(reinterpret_cast<unsigned int *>(&cell_max[c]), __float_as_uint(opacity[i]));
     touched[c] = 1;
@@ -445,7 +445,10 @@ __global__ void __launch_bounds__(256) opa_sum_kernel(const float *__restrict__ 
     }
 #pragma unroll
     for (int dlt = 32; dlt > 0; dlt >>= 1) s += __shfl_xor(s, dlt, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(acc, s);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, (part[0] + part[1]) + (part[2] + part[3]));
 }
 
 __global__ void __launch_bounds__(256) opa_threshold_kernel(const float *__restrict__ opa, uint8_t *__restrict__ bf,
@@ -589,8 +592,9 @@ ARCN_EXPORT int arcn_update_bitfield_by_opafield(const float *opafield, uint8_t 
     if (!opafield || !bitfield || !workspace) return einval("update_bitfield_by_opafield: missing argument");
     double *acc = reinterpret_cast<double *>(workspace);  // 2 floats = 1 double
     if (hipMemsetAsync(acc, 0, sizeof(double), as_stream(stream)) != hipSuccess) return check_launch("memset");
-    int64_t blocks = ceil_div<int64_t>(n, 256);
-    if (blocks > 1024) blocks = 1024;
+    int64_t blocks = ceil_div<int64_t>(n, 256 * 16);
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(opa_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), opafield, n, acc);
     hipLaunchKernelGGL(opa_threshold_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), opafield, bitfield, n,
                        threshold, acc);
@@ -598,7 +602,8 @@ ARCN_EXPORT int arcn_update_bitfield_by_opafield(const float *opafield, uint8_t 
 }
 
 ARCN_EXPORT int arcn_opafield_scatter_update(float *opafield, const int64_t *cell_idx, const float *opacity, int64_t n,
-                                             int64_t n_cells, float ema, float *cell_max, uint8_t *touched, void *stream) {
+                                             const int32_t *n_ptr, int64_t n_cells, float ema, float *cell_max,
+                                             uint8_t *touched, void *stream) {
     if (n <= 0) return ARCN_OK;
     if (!opafield || !cell_idx || !opacity || !cell_max || !touched || n_cells <= 0)
         return einval("opafield_scatter_update: missing argument");
@@ -606,7 +611,7 @@ ARCN_EXPORT int arcn_opafield_scatter_update(float *opafield, const int64_t *cel
     if (hipMemsetAsync(cell_max, 0, sizeof(float) * n_cells, st) != hipSuccess) return check_launch("memset");
     if (hipMemsetAsync(touched, 0, n_cells, st) != hipSuccess) return check_launch("memset");
     hipLaunchKernelGGL(opa_scatter_max_kernel, dim3((unsigned)ceil_div<int64_t>(n, 256)), dim3(256), 0, st, cell_idx, opacity, n,
-                       cell_max, touched);
+                       n_ptr, cell_max, touched);
     hipLaunchKernelGGL(opa_apply_kernel, dim3((unsigned)ceil_div<int64_t>(n_cells, 256)), dim3(256), 0, st, opafield, cell_max,
                        touched, n_cells, ema);
     return check_launch("opafield_scatter_update");

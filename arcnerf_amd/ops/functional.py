@@ -438,7 +438,7 @@ def update_opafield(opafield, flat_idx, opacity, ema=None):
     return opafield
 
 
-def opafield_scatter_update(opafield, cell_idx, opacity, ema=None, cell_max=None, touched=None):
+def opafield_scatter_update(opafield, cell_idx, opacity, ema=None, cell_max=None, touched=None, n_dev=None):
     """unique + segmented max + EMA update of the occupancy field for repeated flat cell indices, without a sort."""
     _req(opafield, cell_idx, opacity)
     assert opafield.is_contiguous() and opafield.dtype == torch.float32
@@ -449,7 +449,7 @@ def opafield_scatter_update(opafield, cell_idx, opacity, ema=None, cell_max=None
         cell_max = torch.empty(nc, dtype=torch.float32, device=opafield.device)
     if touched is None:
         touched = torch.empty(nc, dtype=torch.uint8, device=opafield.device)
-    N.check(N.lib().arcn_opafield_scatter_update(N.ptr(opafield), N.ptr(idx), N.ptr(op), idx.shape[0], nc,
+    N.check(N.lib().arcn_opafield_scatter_update(N.ptr(opafield), N.ptr(idx), N.ptr(op), idx.shape[0], _nptr(n_dev), nc,
                                                 -1.0 if ema is None else float(ema), N.ptr(cell_max), N.ptr(touched),
                                                 N.stream()), 'opafield_scatter_update')
     return opafield

@@ -269,6 +269,37 @@ class NgpPipeline:
     def _occ(self):
         return self._bits if self.packed_bits else self.bitfield
 
+    def _cached(self, key, make):
+        if not hasattr(self, '_cache'):
+            self._cache = {}
+        if key not in self._cache:
+            self._cache[key] = make()
+        return self._cache[key]
+
+    def _select_cells(self, n_cells):
+        """Cells refreshed after the warm-up (volume_bound.py:178-190): n/4 cells drawn uniformly without repetition plus the
+        first n/4 occupied cells (flat index order, like `get_occupied_voxel_idx()[:n]`).  Everything stays on the device:
+        the uniform part is a random full-period affine permutation of the (power-of-two) cell range instead of
+        torch.randperm (a 2M-key sort), the occupied part is an ordered compaction through cumsum + scatter, and the number
+        of valid entries is a device scalar (torch.nonzero would stall the launch queue every refresh)."""
+        dev = self.field.device
+        n_s = n_cells // 4
+        buf = self._cached('cell_buf', lambda: torch.zeros(2 * n_s + 1, dtype=torch.int64, device=dev))
+        ar = self._cached('arange_cells', lambda: torch.arange(n_cells, device=dev))
+        if n_cells & (n_cells - 1) == 0:
+            rs = self._cached('np_rng', lambda: np.random.default_rng(12345))
+            a = int(rs.integers(0, n_cells // 2)) * 2 + 1   # odd multiplier: i -> a*i + c is a bijection mod 2^k
+            c = int(rs.integers(0, n_cells))
+            buf[:n_s] = (ar[:n_s] * a + c) & (n_cells - 1)
+        else:
+            buf[:n_s] = torch.randperm(n_cells, device=dev)[:n_s]
+        occ = self.bitfield
+        csum = torch.cumsum(occ.to(torch.int32), 0)
+        dst = torch.where(occ & (csum <= n_s), csum.long() + (n_s - 1), torch.full_like(ar, 2 * n_s))
+        buf.scatter_(0, dst, ar)
+        n_dev = (torch.clamp(csum[-1:], max=n_s) + n_s).to(torch.int32)
+        return buf[:2 * n_s], n_dev
+
     # ---- forward --------------------------------------------------------------------------------
     def sample(self, rays_o, rays_d):
         """[A] bounds + occupancy marching in packed form (no host sync).  Advances the pcg32 like the reference."""
@@ -383,37 +414,35 @@ class NgpPipeline:
         n_cells = ng ** 3
         if cur_epoch <= 0 or cfg.epoch_optim is None or cur_epoch % cfg.epoch_optim != 0:
             return
+        n_dev = None
         if cfg.epoch_optim_warmup is not None and cur_epoch < cfg.epoch_optim_warmup:
-            cell = torch.arange(n_cells, device=dev)
+            cell = self._cached('arange_cells', lambda: torch.arange(n_cells, device=dev))
         else:
-            n_s = n_cells // 4
-            uni = torch.randperm(n_cells, device=dev)[:n_s]
-            occ = torch.nonzero(self.bitfield)[:n_s, 0]
-            cell = torch.cat([uni, occ])
+            cell, n_dev = self._select_cells(n_cells)
         vs = cfg.side / ng
         ix = torch.div(cell, ng * ng, rounding_mode='floor')
         iy = torch.div(cell, ng, rounding_mode='floor') % ng
         iz = cell % ng
         idx3 = torch.stack([ix, iy, iz], -1).float()
-        mn = torch.tensor(fld.min_xyz, device=dev)
+        mn = self._cached('mn', lambda: torch.tensor(fld.min_xyz, device=dev))
         pts = idx3 * vs + 0.5 * vs + mn
         pts = pts + (torch.rand_like(pts) - 0.5) * vs
         n = pts.shape[0]
         if self._occ_scratch is None or self._occ_scratch['feat'].shape[0] < n:
             self._occ_scratch = {
                 'feat': torch.empty((n, cfg.n_levels * cfg.n_feat_per_entry), dtype=torch.float32, device=dev),
-                'geo_out': torch.empty((n, fld.geo_out_dim), dtype=torch.float32, device=dev),
+                'geo_out': torch.zeros((n, fld.geo_out_dim), dtype=torch.float32, device=dev),
                 'cell_max': torch.empty(n_cells, dtype=torch.float32, device=dev),
                 'touched': torch.empty(n_cells, dtype=torch.uint8, device=dev),
             }
         sc = self._occ_scratch
         pts = pts.contiguous()
-        F.hashgrid_fwd(pts, self._p('table'), fld.grid_desc, out=sc['feat'][:n])
-        F.mlp_fwd(sc['feat'][:n], self._p('geo_w'), self._p('geo_b'), fld.geo_desc, out=sc['geo_out'][:n])
+        F.hashgrid_fwd(pts, self._p('table'), fld.grid_desc, out=sc['feat'][:n], n_dev=n_dev)
+        F.mlp_fwd(sc['feat'][:n], self._p('geo_w'), self._p('geo_b'), fld.geo_desc, out=sc['geo_out'][:n], n_dev=n_dev)
         sigma = F.act_fwd(sc['geo_out'][:n, 0].contiguous(), cfg.sigma_act)
         opacity = sigma * cfg.dt  # get_est_opacity (base_3d_model.py:386-389)
         F.opafield_scatter_update(self.opafield, cell, opacity, ema=cfg.ema_optim_decay, cell_max=sc['cell_max'],
-                                  touched=sc['touched'])
+                                  touched=sc['touched'], n_dev=n_dev)
         new_bits = torch.empty_like(self.bitfield)
         F.update_bitfield_by_opafield(self.opafield, new_bits, cfg.opa_thres)
         if apply:

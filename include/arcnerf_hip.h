@@ -218,9 +218,10 @@ int arcn_update_opafield(float *opafield, const int64_t *flat_idx, const float *
                          void *stream);
 /* Sort-free equivalent of  unique(voxel_idx) -> segmented max (K4) -> update_opafield_by_voxel_idx  for possibly
  * repeated flat cell indices (volume_bound.py:199-211).  cell_max (n_cells floats) and touched (n_cells bytes) are
- * scratch buffers (cleared inside).  opacity must be non-negative. */
+ * scratch buffers (cleared inside).  opacity must be non-negative.  n_ptr (device, optional): number of valid entries. */
 int arcn_opafield_scatter_update(float *opafield, const int64_t *cell_idx, const float *opacity, int64_t n,
-                                 int64_t n_cells, float ema, float *cell_max, uint8_t *touched, void *stream);
+                                 const int32_t *n_ptr, int64_t n_cells, float ema, float *cell_max, uint8_t *touched,
+                                 void *stream);
 /* thres = min(mean(clamp(opa,0)), threshold) computed on device; bitfield (bool bytes) = opa >= thres.
  * workspace: 2 floats (device). */
 int arcn_update_bitfield_by_opafield(const float *opafield, uint8_t *bitfield, int64_t n, float threshold,
