@@ -584,7 +584,19 @@ ARCN_EXPORT int arcn_mlp_bwd(const float *x, const float *weights, const float *
                            out, acts, dout, dx, scratch, n_cap, n, n_ptr);
     }
     if ((rc = check_launch("mlp_bwd_dx"))) return rc;
-    if (dweights) {
+    if (dweights) return arcn_mlp_bwd_dw(x, desc_host, acts, scratch, dweights, dbiases, n_cap, n, n_ptr, stream);
+    return ARCN_OK;
+}
+
+ARCN_EXPORT int arcn_mlp_bwd_dw(const float *x, const arcn_mlp_desc *desc_host, const float *acts, float *scratch,
+                                float *dweights, float *dbiases, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!x || !scratch || !dweights) return einval("mlp_bwd_dw: missing argument");
+    MlpParams P;
+    int lds_floats, md, rc;
+    if ((rc = build_mlp_params(desc_host, P, true, &lds_floats, &md))) return rc;
+    if (P.n_layers > 1 && !acts) return einval("mlp_bwd_dw: saved activations required");
+    {
         DwParams D;
         D.n_layers = P.n_layers;
         D.has_bias = P.has_bias;

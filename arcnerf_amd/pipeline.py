@@ -187,13 +187,21 @@ class NgpPipeline:
         self.rng = F.Pcg32Host(9121)
         E = cfg.n_levels * cfg.n_feat_per_entry
         b = self.buf = {}
-        b['scratch_t'] = torch.empty((R, cfg.n_sample), dtype=f32, device=dev)
-        b['counts'] = torch.zeros(R, dtype=i32, device=dev)
-        b['offsets'] = torch.zeros(R + 1, dtype=i32, device=dev)
-        b['near'] = torch.empty(R, dtype=f32, device=dev)
-        b['far'] = torch.empty(R, dtype=f32, device=dev)
-        b['t'] = torch.zeros(S, dtype=f32, device=dev)
-        b['ray_id'] = torch.zeros(S, dtype=i32, device=dev)
+        # sample buffers exist twice: the marcher of step i+1 (it depends only on rays + occupancy) can run on a second
+        # HIP stream while step i's backward is still scattering (prefetch_samples)
+        self._sets = []
+        for _ in range(2):
+            self._sets.append({
+                'scratch_t': torch.empty((R, cfg.n_sample), dtype=f32, device=dev),
+                'counts': torch.zeros(R, dtype=i32, device=dev), 'offsets': torch.zeros(R + 1, dtype=i32, device=dev),
+                'near': torch.empty(R, dtype=f32, device=dev), 'far': torch.empty(R, dtype=f32, device=dev),
+                't': torch.zeros(S, dtype=f32, device=dev), 'ray_id': torch.zeros(S, dtype=i32, device=dev),
+                'p_dense': torch.full((1,), 2, dtype=i32, device=dev)})
+        b.update(self._sets[0])
+        self._cur_set = 0
+        self._prefetched = None
+        self.aux_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+        self.use_streams = self.aux_stream is not None
         b['xyz'] = torch.zeros((S, 3), dtype=f32, device=dev)
         b['dirs'] = torch.zeros((S, 3), dtype=f32, device=dev)
         b['feat'] = torch.zeros((S, E), dtype=f32, device=dev)
@@ -210,13 +218,14 @@ class NgpPipeline:
         b['d_rad_in'] = torch.zeros((S, field.rad_dims[0]), dtype=f32, device=dev)
         b['d_geo_out'] = torch.zeros((S, field.geo_out_dim), dtype=f32, device=dev)
         b['d_feat'] = torch.zeros((S, E), dtype=f32, device=dev)
-        b['mlp_scratch'] = torch.zeros(max(F.mlp_scratch_floats(field.geo_desc, S), F.mlp_scratch_floats(field.rad_desc, S)),
-                                       dtype=f32, device=dev)
+        # separate backward scratch per network: the radiance dW kernel (aux stream) reads its dpre tensors while the
+        # geometry dX chain (main stream) is already writing its own
+        b['geo_scratch'] = torch.zeros(F.mlp_scratch_floats(field.geo_desc, S), dtype=f32, device=dev)
+        b['rad_scratch'] = torch.zeros(F.mlp_scratch_floats(field.rad_desc, S), dtype=f32, device=dev)
         # per-ray outputs
         b['rgb'] = torch.zeros((R, 3), dtype=f32, device=dev)
         b['depth'] = torch.zeros(R, dtype=f32, device=dev)
         b['mask'] = torch.zeros(R, dtype=f32, device=dev)
-        b['p_dense'] = torch.full((1,), 2, dtype=i32, device=dev)
         b['d_rgb'] = torch.zeros((R, 3), dtype=f32, device=dev)
         b['loss'] = torch.zeros(1, dtype=f32, device=dev)
         # XCD-owned-levels scatter workspace (owner + tile counters); None selects the plain agent-scope kernel
@@ -301,9 +310,38 @@ class NgpPipeline:
         return buf[:2 * n_s], n_dev
 
     # ---- forward --------------------------------------------------------------------------------
+    def prefetch_samples(self, rays_o, rays_d):
+        """March `rays` on the auxiliary stream into the spare sample-buffer set; the next forward() on the SAME tensors picks
+        the result up instead of marching again.  Safe to call right after the current step's forward was issued."""
+        if not self.use_streams:
+            return
+        main = torch.cuda.current_stream()
+        self.aux_stream.wait_stream(main)  # occupancy / previous consumers of the spare set are ordered before us
+        spare = 1 - self._cur_set
+        with torch.cuda.stream(self.aux_stream):
+            self._sample_into(self._sets[spare], rays_o, rays_d)
+            ev = torch.cuda.Event()
+            ev.record(self.aux_stream)
+        self._prefetched = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], spare, ev)
+
     def sample(self, rays_o, rays_d):
         """[A] bounds + occupancy marching in packed form (no host sync).  Advances the pcg32 like the reference."""
-        cfg, b = self.cfg, self.buf
+        pf = self._prefetched
+        if pf is not None and pf[:3] == (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0]):
+            torch.cuda.current_stream().wait_event(pf[4])
+            self._cur_set = pf[3]
+            self._prefetched = None
+            self.buf.update(self._sets[self._cur_set])
+        else:
+            self._prefetched = None
+            self._sample_into(self._sets[self._cur_set], rays_o, rays_d)
+            self.buf.update(self._sets[self._cur_set])
+        R = rays_o.shape[0]
+        self.n_dev = self.buf['offsets'][R:R + 1]  # device-side sample count (view, no sync)
+        return self.n_dev
+
+    def _sample_into(self, b, rays_o, rays_d):
+        cfg = self.cfg
         R = rays_o.shape[0]
         assert R <= self.max_rays
         L = N.lib()
@@ -316,10 +354,8 @@ class NgpPipeline:
         N.check(L.arcn_exclusive_scan_i32(N.ptr(b['counts']), N.ptr(b['offsets']), R, st), 'scan')
         N.check(L.arcn_march_write(N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['offsets']), cfg.n_sample, N.ptr(b['t']),
                                    N.ptr(b['ray_id']), R, self.cap, st), 'march_write')
-        self.n_dev = b['offsets'][R:R + 1]  # device-side sample count (view, no sync)
         # dense width the reference would have used: max(2, max count) (fg_model.py:251-262)
         torch.clamp(b['counts'][:R].max(), min=2, out=b['p_dense'][0])
-        return self.n_dev
 
     def forward(self, rays_o, rays_d, bkg_color=None, train=False, noise=None):
         """Render rays: returns rgb (R,3), depth (R), mask (R) views of the internal buffers."""
@@ -362,19 +398,36 @@ class NgpPipeline:
                                             int(cfg.add_inf_z), int(cfg.white_bkg), N.ptr(d_rgb), N.ptr(d_depth), N.ptr(d_mask),
                                             N.ptr(b['d_sigma']), N.ptr(b['d_rgb_s']), st), 'composite_packed_bwd')
         S = self.cap
+        aux = self.aux_stream if self.use_streams else None
+        main = torch.cuda.current_stream() if aux is not None else None
+
+        def dw_async(x, desc, acts, scratch, name):
+            """dW/db of one net on the auxiliary stream (latency-bound, few registers, 16 KiB LDS: co-resides with the
+            LDS-heavy scatter on the main stream)"""
+            if aux is None:
+                N.check(L.arcn_mlp_bwd_dw(N.ptr(x), N.C.addressof(desc), N.ptr(acts), N.ptr(scratch), N.ptr(self._g(name + '_w')),
+                                          N.ptr(self._g(name + '_b')), S, S, n_dev.data_ptr(), st), 'mlp_bwd_dw')
+                return
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                N.check(L.arcn_mlp_bwd_dw(N.ptr(x), N.C.addressof(desc), N.ptr(acts), N.ptr(scratch), N.ptr(self._g(name + '_w')),
+                                          N.ptr(self._g(name + '_b')), S, S, n_dev.data_ptr(), N.stream()), 'mlp_bwd_dw')
+
         N.check(L.arcn_mlp_bwd(N.ptr(b['rad_in']), N.ptr(self._p('rad_w')), N.ptr(self._p('rad_b')), N.C.addressof(fld.rad_desc),
                                N.ptr(b['rgb_s']), N.ptr(b['rad_acts']), N.ptr(b['d_rgb_s']), N.ptr(b['d_rad_in']),
-                               N.ptr(self._g('rad_w')), N.ptr(self._g('rad_b')), N.ptr(b['mlp_scratch']), S, S,
-                               n_dev.data_ptr(), st), 'mlp_bwd(rad)')
+                               None, None, N.ptr(b['rad_scratch']), S, S, n_dev.data_ptr(), st), 'mlp_bwd(rad)')
+        dw_async(b['rad_in'], fld.rad_desc, b['rad_acts'], b['rad_scratch'], 'rad')
         F.ngp_glue_bwd(b['geo_out'], b['d_rad_in'], b['d_sigma'], fld.feat_off, cfg.W_feat, cfg.sh_degree,
                        feat_first=(cfg.rad_mode == 'fv'), sigma_act=cfg.sigma_act, n_dev=n_dev, d_geo_out=b['d_geo_out'])
         N.check(L.arcn_mlp_bwd(N.ptr(b['feat']), N.ptr(self._p('geo_w')), N.ptr(self._p('geo_b')), N.C.addressof(fld.geo_desc),
                                N.ptr(b['geo_out']), N.ptr(b['geo_acts']), N.ptr(b['d_geo_out']), N.ptr(b['d_feat']),
-                               N.ptr(self._g('geo_w')), N.ptr(self._g('geo_b')), N.ptr(b['mlp_scratch']), S, S,
-                               n_dev.data_ptr(), st), 'mlp_bwd(geo)')
+                               None, None, N.ptr(b['geo_scratch']), S, S, n_dev.data_ptr(), st), 'mlp_bwd(geo)')
+        dw_async(b['feat'], fld.geo_desc, b['geo_acts'], b['geo_scratch'], 'geo')
         N.check(L.arcn_hashgrid_bwd(N.ptr(b['xyz']), N.ptr(self._p('table')), N.ptr(b['d_feat']), N.C.addressof(fld.grid_desc),
                                     N.ptr(self._g('table')), None, N.ptr(self.hash_ws), S, n_dev.data_ptr(), st),
                 'hashgrid_bwd')
+        if aux is not None:
+            main.wait_stream(aux)  # join: the optimiser (or the caller) needs every gradient
 
     def huber_grad(self, rgb, target):
         """ImgLoss(Huber, delta, weight) of arcnerf/loss/img_loss.py:60-100: loss value and d loss / d rgb (mean over R*3)."""
@@ -390,13 +443,16 @@ class NgpPipeline:
                         betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, ema_decay=cfg.ema_decay,
                         grad_scale=1.0 / world_size, zero_grad=True)
 
-    def train_step(self, rays_o, rays_d, target_rgb, bkg_color=None, all_reduce=None, world_size=1):
-        """fwd + loss + bwd (+ one gradient all-reduce) + Adam/EMA.  Returns the loss tensor (device, no sync)."""
+    def train_step(self, rays_o, rays_d, target_rgb, bkg_color=None, all_reduce=None, world_size=1, next_rays=None):
+        """fwd + loss + bwd (+ one gradient all-reduce) + Adam/EMA.  Returns the loss tensor (device, no sync).
+        next_rays = (rays_o, rays_d) of the FOLLOWING step: their marching is overlapped with this step's backward."""
         cfg, b = self.cfg, self.buf
         noise = None
         if cfg.noise_std > 0:
             noise = b['noise'].normal_(0.0, cfg.noise_std)
         rgb, _, _ = self.forward(rays_o, rays_d, bkg_color, train=True, noise=noise)
+        if next_rays is not None:
+            self.prefetch_samples(*next_rays)
         loss, d_rgb = self.huber_grad(rgb, target_rgb)
         self.backward(rays_o, rays_d, d_rgb)
         if all_reduce is not None:

@@ -128,7 +128,10 @@ def main():
 
     def run(step_idx, epoch):
         o, d, tgt, bkg = pool[step_idx % n_pool]
-        pipe.train_step(o, d, tgt, bkg_color=bkg, all_reduce=all_reduce, world_size=world)
+        nxt = pool[(step_idx + 1) % n_pool]
+        # the next batch's rays are known (the reference precaches and shuffles them on the GPU): its marching is issued on
+        # a second stream and overlaps this step's backward
+        pipe.train_step(o, d, tgt, bkg_color=bkg, all_reduce=all_reduce, world_size=world, next_rays=(nxt[0], nxt[1]))
         sample_log[step_idx] = pipe.n_dev[0]
         if not args.no_occ_update:
             pipe.update_occupancy(epoch, apply=False)

@@ -164,6 +164,10 @@ int arcn_mlp_fwd(const float *x, const float *weights, const float *biases, cons
 int arcn_mlp_bwd(const float *x, const float *weights, const float *biases, const arcn_mlp_desc *desc_host,
                  const float *out, const float *acts, const float *dout, float *dx, float *dweights, float *dbiases,
                  float *scratch, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream);
+/* second half of arcn_mlp_bwd on its own (dW, db from the dpre tensors arcn_mlp_bwd(..., dweights = NULL, ...) left in
+ * `scratch`), so a caller can run it on another stream while the dX chain of the next network proceeds. */
+int arcn_mlp_bwd_dw(const float *x, const arcn_mlp_desc *desc_host, const float *acts, float *scratch, float *dweights,
+                    float *dbiases, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream);
 /* float count the caller must provide in `acts` (hidden layers) and `scratch` (bwd) for capacity n_cap */
 int64_t arcn_mlp_acts_floats(const arcn_mlp_desc *desc_host, int64_t n_cap);
 int64_t arcn_mlp_scratch_floats(const arcn_mlp_desc *desc_host, int64_t n_cap);
