@@ -14,6 +14,34 @@ from ..ops import functional as F
 from .ray import aabb_ray_intersection
 
 
+def select_refresh_cells(bitfield_flat, n_cells, cache, rng):
+    """Cells refreshed by VolumeBound.optimize after its warm-up (volume_bound.py:178-190): n/4 cells drawn uniformly
+    without repetition + the first n/4 occupied cells in flat-index order (`get_occupied_voxel_idx()[:n]`).
+
+    Sync-free: the uniform part is a random full-period affine permutation of the (power-of-two) cell range instead of
+    torch.randperm (a 2M-key sort), the occupied part is an ordered compaction through cumsum + scatter, and the number
+    of valid entries is returned as a DEVICE int32 scalar — torch.nonzero/torch.where would stall the launch queue at every
+    refresh.  Returns (cells int64 (2*(n/4),), n_valid int32 (1,)).  `cache` is a dict for persistent buffers, `rng` a
+    numpy Generator (host side, only the two affine constants are drawn from it)."""
+    dev = bitfield_flat.device
+    n_s = n_cells // 4
+    if 'cell_buf' not in cache:
+        cache['cell_buf'] = torch.zeros(2 * n_s + 1, dtype=torch.int64, device=dev)
+        cache['arange'] = torch.arange(n_cells, device=dev)
+    buf, ar = cache['cell_buf'], cache['arange']
+    if n_cells & (n_cells - 1) == 0:
+        a = int(rng.integers(0, n_cells // 2)) * 2 + 1  # odd multiplier: i -> a*i + c is a bijection mod 2^k
+        c = int(rng.integers(0, n_cells))
+        buf[:n_s] = (ar[:n_s] * a + c) & (n_cells - 1)
+    else:
+        buf[:n_s] = torch.randperm(n_cells, device=dev)[:n_s]
+    csum = torch.cumsum(bitfield_flat.to(torch.int32), 0)
+    dst = torch.where(bitfield_flat & (csum <= n_s), csum.long() + (n_s - 1), torch.full_like(ar, 2 * n_s))
+    buf.scatter_(0, dst, ar)
+    n_valid = (torch.clamp(csum[-1:], max=n_s) + n_s).to(torch.int32)
+    return buf[:2 * n_s], n_valid
+
+
 class Volume(nn.Module):
     def __init__(self, n_grid=None, origin=(0, 0, 0), side=None, xyz_len=None, dtype=torch.float32, requires_grad=False,
                  **kwargs):
@@ -142,9 +170,10 @@ class Volume(nn.Module):
         flat = self.convert_xyz_index_to_flatten_index(voxel_idx, self.n_grid)
         F.update_opafield(self.opafield.view(-1), flat, opacity, ema)
 
-    def update_opafield_by_flat_idx(self, flat_idx, opacity, ema=None):
-        """same as unique + segmented max + update_opafield_by_voxel_idx for possibly repeated cells, sort-free"""
-        F.opafield_scatter_update(self.opafield.view(-1), flat_idx, opacity, ema)
+    def update_opafield_by_flat_idx(self, flat_idx, opacity, ema=None, n_dev=None):
+        """same as unique + segmented max + update_opafield_by_voxel_idx for possibly repeated cells, sort-free;
+        n_dev (device int32) = number of valid entries"""
+        F.opafield_scatter_update(self.opafield.view(-1), flat_idx, opacity, ema, n_dev=n_dev)
 
     def get_mean_voxel_opacity(self):
         return float(self.opafield.clamp(min=0).mean())

@@ -7,7 +7,9 @@ golden update).
 """
 import torch
 
-from ....geometry.volume import Volume
+import numpy as np
+
+from ....geometry.volume import Volume, select_refresh_cells
 from ....ops.volume_func import CUDA_BACKEND_AVAILABLE, sparse_volume_sampling
 from ....utils.cfgs_utils import get_value_from_cfgs_field, valid_key_in_cfgs
 from ....utils.registry import BOUND_REGISTRY
@@ -67,14 +69,19 @@ class VolumeBound(BasicBound):
         vol = self.volume
         n = vol.get_n_grid()
         dev = vol.get_device()
+        n_dev = None
         if warmup is not None and cur_epoch < warmup:
             cell = torch.arange(vol.get_n_voxel(), device=dev)
         else:
-            n_s = vol.get_n_voxel() // 4
-            cell = torch.cat([torch.randperm(vol.get_n_voxel(), device=dev)[:n_s], vol.get_occupied_voxel_idx(flatten=True)[:n_s]])
+            if not hasattr(self, '_refresh_cache'):
+                self._refresh_cache, self._refresh_rng = {}, np.random.default_rng(12345)
+            # entries past n_dev are stale cells from an earlier refresh: evaluated by the net (harmless) and skipped by the
+            # scatter, which honours the device-side count
+            cell, n_dev = select_refresh_cells(vol.get_voxel_bitfield(flatten=True), vol.get_n_voxel(), self._refresh_cache,
+                                               self._refresh_rng)
         pts = vol.get_voxel_pts_by_voxel_idx(vol.convert_flatten_index_to_xyz_index(cell, n).float())
         pts = pts + (torch.rand_like(pts) - 0.5) * vol.get_voxel_size(to_list=False)[None, :]
         dt = vol.get_diag_len() / float(n_pts)
         opacity = get_est_opacity(dt, pts.contiguous())
-        vol.update_opafield_by_flat_idx(cell, opacity, ema=self.get_optim_cfgs('ema_optim_decay'))
+        vol.update_opafield_by_flat_idx(cell, opacity, ema=self.get_optim_cfgs('ema_optim_decay'), n_dev=n_dev)
         vol.update_bitfield_by_opafield(threshold=self.get_optim_cfgs('opa_thres'), ops='overwrite')

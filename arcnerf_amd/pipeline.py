@@ -286,28 +286,10 @@ class NgpPipeline:
         return self._cache[key]
 
     def _select_cells(self, n_cells):
-        """Cells refreshed after the warm-up (volume_bound.py:178-190): n/4 cells drawn uniformly without repetition plus the
-        first n/4 occupied cells (flat index order, like `get_occupied_voxel_idx()[:n]`).  Everything stays on the device:
-        the uniform part is a random full-period affine permutation of the (power-of-two) cell range instead of
-        torch.randperm (a 2M-key sort), the occupied part is an ordered compaction through cumsum + scatter, and the number
-        of valid entries is a device scalar (torch.nonzero would stall the launch queue every refresh)."""
-        dev = self.field.device
-        n_s = n_cells // 4
-        buf = self._cached('cell_buf', lambda: torch.zeros(2 * n_s + 1, dtype=torch.int64, device=dev))
-        ar = self._cached('arange_cells', lambda: torch.arange(n_cells, device=dev))
-        if n_cells & (n_cells - 1) == 0:
-            rs = self._cached('np_rng', lambda: np.random.default_rng(12345))
-            a = int(rs.integers(0, n_cells // 2)) * 2 + 1   # odd multiplier: i -> a*i + c is a bijection mod 2^k
-            c = int(rs.integers(0, n_cells))
-            buf[:n_s] = (ar[:n_s] * a + c) & (n_cells - 1)
-        else:
-            buf[:n_s] = torch.randperm(n_cells, device=dev)[:n_s]
-        occ = self.bitfield
-        csum = torch.cumsum(occ.to(torch.int32), 0)
-        dst = torch.where(occ & (csum <= n_s), csum.long() + (n_s - 1), torch.full_like(ar, 2 * n_s))
-        buf.scatter_(0, dst, ar)
-        n_dev = (torch.clamp(csum[-1:], max=n_s) + n_s).to(torch.int32)
-        return buf[:2 * n_s], n_dev
+        from .geometry.volume import select_refresh_cells
+        cache = self._cached('refresh_cache', dict)
+        rng = self._cached('np_rng', lambda: np.random.default_rng(12345))
+        return select_refresh_cells(self.bitfield, n_cells, cache, rng)
 
     # ---- forward --------------------------------------------------------------------------------
     def prefetch_samples(self, rays_o, rays_d):

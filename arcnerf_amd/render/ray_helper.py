@@ -49,6 +49,63 @@ def get_zvals_from_near_far(near, far, n_pts, inclusive=True, inverse_linear=Fal
     return perturb_interval(zvals) if perturb else zvals
 
 
+def perturb_interval_with_mask(vals, mask=None):
+    """perturb only the valid prefix of each row; the masked tail keeps following the last valid value
+    (ray_helper.py:378-407)"""
+    pert = perturb_interval(vals)
+    if mask is None:
+        return pert
+    vals = torch.where(mask, pert, vals)
+    last = (mask.sum(dim=1) - 1).clamp(min=0)
+    last_val = vals.gather(1, last[:, None])
+    return torch.minimum(torch.maximum(vals, vals[:, 0:1]), last_val)
+
+
+def get_zvals_from_near_far_fix_step(near, far, fix_t, n_pts, inclusive=True, perturb=False):
+    """zvals = near + k*fix_t clamped to far, duplicate tail masked out (ray_helper.py:267-315).  This is the reference's
+    torch fallback when its CUDA sampler is missing; kept for API completeness — VolumeBound always uses the marcher here.
+    NB the reference perturbs unconditionally (`if perturb or True`, :312); `perturb=False` gives the deterministic grid."""
+    assert fix_t > 0, 'Only allow positive step...'
+    step = torch.arange(n_pts, device=near.device, dtype=near.dtype)[None]
+    zvals = (near if inclusive else near + fix_t) + step * fix_t
+    zvals = torch.minimum(torch.maximum(zvals, near), far)
+    same = torch.cat([torch.zeros_like(zvals[:, :1], dtype=torch.bool), (zvals[:, 1:] - zvals[:, :-1]) == 0.0], dim=1)
+    mask_pts = ~same
+    if perturb:
+        zvals = perturb_interval_with_mask(zvals, mask_pts)
+    return zvals, mask_pts
+
+
+def handle_valid_mask_zvals(zvals, mask):
+    """Move the valid samples of every ray to the front (stable), pad the tail with the last valid z, rows without any
+    valid sample become all-zero, constant fully-valid rows keep one sample (ray_helper.py:753-814).  Sort-free: the
+    destination column of a valid sample is the running count of valid samples before it."""
+    assert zvals.dim() == 2 and zvals.shape == mask.shape, 'Both tensor should be in (B, N)'
+    zvals, mask = zvals.clone(), mask.clone()
+    none = ~mask.any(dim=1)
+    zvals[none] = 0.0
+    const = (torch.abs(zvals[:, 1:] - zvals[:, :-1]) < 1e-7).all(dim=1) & mask.all(dim=1)
+    mask[const, 1:] = False
+    count = mask.sum(dim=1)
+    dest = torch.cumsum(mask.long(), dim=1) - 1
+    P = zvals.shape[1]
+    packed = torch.zeros_like(zvals)
+    packed.scatter_(1, torch.where(mask, dest, torch.full_like(dest, P - 1)), torch.where(mask, zvals, torch.zeros_like(zvals)))
+    # the scatter above may have dropped zeros on column P-1 of rows that are not full: rebuild from the last valid value
+    last_val = packed.gather(1, (count - 1).clamp(min=0)[:, None])
+    cols = torch.arange(P, device=zvals.device)[None]
+    out_mask = cols < count[:, None]
+    full_last = torch.where(count[:, None] == P, zvals.gather(1, torch.full_like(count, P - 1)[:, None]), last_val)
+    # column P-1 of a full row holds its own (last) sample; every other row pads with its last valid value
+    packed = torch.where(out_mask, packed, last_val.expand_as(packed))
+    packed[:, P - 1:] = torch.where(count[:, None] == P, full_last, packed[:, P - 1:])
+    packed[none] = 0.0
+    keep = ~(none | const)
+    zvals = torch.where(keep[:, None], packed, zvals)
+    mask = torch.where(keep[:, None], out_mask, mask)
+    return zvals, mask
+
+
 def sample_cdf(bins, cdf, n_sample, det=False, eps=1e-5):
     """inverse-CDF sampling + per-row sort, one kernel (searchsorted right=True semantics)"""
     if det:

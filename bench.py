@@ -91,7 +91,7 @@ def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count())
     assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU fallback for the product path)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -99,7 +99,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         from arcnerf_amd import distributed as D
-        D.init_from_env(backend='nccl', device=dev)
+        # ARCN_DIST_BACKEND=gloo lets several ranks share one GPU for functional testing; the real runs use RCCL
+        backend = os.environ.get('ARCN_DIST_BACKEND', 'nccl')
+        D.init_from_env(backend=backend, device=dev if backend == 'nccl' else None)
 
     from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline, synthetic_bitfield, synthetic_rays
 

@@ -122,3 +122,31 @@ def test_product_path_has_no_cpu_fallback():
     inputs = {'rays_o': torch.zeros(1, 8, 3), 'rays_d': torch.ones(1, 8, 3), 'rays_r': torch.zeros(1, 8, 1), 'bkg_color': torch.zeros(1, 8, 3)}
     with pytest.raises(RuntimeError):
         m(inputs, inference_only=True)
+
+
+def test_mask_compaction_and_fix_step_helpers_match_reference():
+    """the reference's torch fallback helpers (a4'): pure tensor code, pinned on the reference's own outputs (G3)"""
+    from arcnerf_amd.render.ray_helper import get_zvals_from_near_far_fix_step, handle_valid_mask_zvals
+    g = load_golden('g3_zvals')
+    z, m = handle_valid_mask_zvals(torch.from_numpy(g['hv_z']), torch.from_numpy(g['hv_m']))
+    assert np.array_equal(m.numpy(), g['hv_m_out']) and np.array_equal(z.numpy(), g['hv_z_out'])
+    zz, mm = get_zvals_from_near_far_fix_step(torch.tensor([[1.0], [2.0]]), torch.tensor([[1.35], [5.0]]), 0.1, 6)
+    assert mm.tolist() == [[True, True, True, True, True, False], [True] * 6]
+    np.testing.assert_allclose(zz[0].numpy(), [1.0, 1.1, 1.2, 1.3, 1.35, 1.35], rtol=1e-6)
+
+
+def test_refresh_cell_selection_is_sync_free_and_matches_reference_sets():
+    """uniform part: n/4 distinct cells; occupied part: the first n/4 occupied cells in flat order (volume_bound.py:178-190)"""
+    from arcnerf_amd.geometry.volume import select_refresh_cells
+    n = 16 ** 3
+    g = torch.Generator().manual_seed(0)
+    for frac in (0.05, 0.6):
+        bf = torch.rand(n, generator=g) < frac
+        cells, n_valid = select_refresh_cells(bf, n, {}, np.random.default_rng(1))
+        n_s = n // 4
+        occ = torch.nonzero(bf)[:, 0]
+        want = occ[:n_s]
+        assert int(n_valid) == n_s + want.numel()
+        uni = cells[:n_s]
+        assert uni.unique().numel() == n_s and int(uni.min()) >= 0 and int(uni.max()) < n
+        assert torch.equal(cells[n_s:int(n_valid)], want)
