@@ -187,139 +187,349 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(const float *__restri
     }
 }
 
-// ---- backward, owner-computes scatter through LDS -------------------------------------------------------------
-// Measured on MI355X: the chip retires only ~18-21 G scattered fp32 global atomics per second (they are served at the
-// memory side, not in the issuing XCD's L2), so the 128 atomics/sample of the plain kernel above cost 4 ms per 2^18
-// samples — 70 % of a training step — no matter how the work is arranged.  This kernel issues NO global atomics on the
-// fine levels: every workgroup OWNS a slice of <= kChunkRows rows of one level's dtable, held in LDS (128 KiB of the
-// CU's 160 KiB).  It scans the samples, recomputes each sample's cell and the 8 hashed rows for its level, and
-// accumulates the corners that fall into its slice with LDS atomics (ds_add_f32); at the end the slice is written back
-// with plain coalesced stores.  A corner hashes into a given slice with probability 1/n_chunks, so the LDS traffic is
-// tiny and the kernel is VALU-bound on the (cheap, integer) hashing; the price is that each of a level's n_chunks
-// workgroups re-derives every sample's cell.  Small (coarse) levels have few chunks but heavy same-row traffic: they are
-// additionally split over disjoint sample ranges, each split accumulating privately in LDS and merging its non-zero
-// rows with a few global atomics (n_splits * rows, negligible).
-// The cell index uses a reciprocal multiply with an exact-division fallback whenever the result is within 2e-3 of an
-// integer (error bound of the fast path 4e-4), so rows stay bit-identical to the forward/reference.
-constexpr int kChunkRows = 16384;  // x F(=2) floats = 128 KiB
+// ---- backward, binned owner-computes scatter --------------------------------------------------------------------------------
+// Measured on MI355X: the chip retires only ~18-21 G scattered fp32 global atomics per second (they are served at the memory
+// side, not in the issuing XCD's L2), so the 128 atomics/sample of the plain kernel above cost 4 ms per 2^18 samples no
+// matter how the work is arranged.  The scatter below issues NO global float atomics on the large levels: every table chunk
+// of <= 16384 rows (128 KiB of the CU's 160 KiB LDS) is OWNED by one workgroup, which accumulates it in LDS and writes it back
+// with plain coalesced stores.
+//   scatter_bin_kernel    one lane per (level, sample): cell, weights, gradient.  On the hashed power-of-two levels the 8
+//                         corners form 4 x-neighbour pairs whose two rows differ only in the low bits of the hash, i.e. live
+//                         in the same chunk: each pair becomes ONE 16-byte record {i0 | i1 << 16, wx, g0*wy*wz, g1*wy*wz}
+//                         appended to the bin of its owner chunk (LDS histogram for the rank, one global integer atomic per
+//                         bin and workgroup).  On the small levels below them consecutive samples of a ray sit in one cell for
+//                         long runs: each run is summed inside the wave first (segmented suffix sum) and only its head lane
+//                         emits 8 single-row records.
+//   scatter_accum_kernel  one workgroup per chunk streams ITS bin only (coalesced 16-byte loads, all 64 lanes busy) and
+//                         accumulates in LDS.  ds_add_f32 retires ~3 cycles per active lane on gfx950 (integer LDS atomics
+//                         are ~28x faster), so the large levels take a 1-bit row lock + plain 8-byte read-modify-write instead
+//                         (ds_or / ds_read_b64 / ds_write_b64 / ds_and: 5.8x the rate of two ds_add_f32 when all lanes are
+//                         active, tools/ubench/lds_lock.hip).  The small levels keep float atomics and are split over several
+//                         workgroups per chunk, merged with global atomics on the touched rows (few rows, negligible).
+// Bins have a fixed capacity (2x the mean; the hash spreads pairs evenly); a record that does not fit is applied directly
+// to dtable with global atomics, so correctness never depends on the statistics.
+// History (same workload, 272 K samples): plain global atomics 4.26 ms; every owner scanning all records of its level
+// (3.3 GB of L2 reads, ~16 of 64 lanes in front of the float atomics) 0.79 ms; this scheme 0.33 ms.
+constexpr int kChunkFloats = 32768;  // 128 KiB of accumulators per workgroup: 16384 rows at F = 2
 constexpr int kTiledThreads = 1024;
+constexpr int kMaxChunks = 1024;  // owner chunks per level (2^24-row levels with 16384-row chunks)
 
-struct TiledPlan {
-    int32_t item_first[ARCN_MAX_LEVELS + 1];  // prefix of work items per level
+struct BinPlan {
+    int32_t item_first[ARCN_MAX_LEVELS + 1];  // by dispatch position
+    int32_t level_of[ARCN_MAX_LEVELS];        // dispatch position -> level
     int32_t n_chunks[ARCN_MAX_LEVELS];
     int32_t n_splits[ARCN_MAX_LEVELS];
-    int32_t chunk_rows[ARCN_MAX_LEVELS];
-};
-
-// Prep pass of the owner-computes scatter: one 32-byte record per (level, sample), level-major so the owners of level l
-// stream it contiguously.  Everything that is identical for the ~32 owner workgroups of a level is done ONCE here: the
-// exact cell (fp32 divide, bit-identical to the forward), the trilinear weights and the incoming gradient.
-//   word0 = cx | cy << 16, word1 = cz | valid << 16, w[3], g[2], pad
-struct __attribute__((aligned(16))) ScatterRec {
-    uint32_t cxy, czv;
-    float w0, w1, w2, g0, g1, pad;
+    int32_t chunk_shift[ARCN_MAX_LEVELS];     // rows per chunk = 1 << shift
+    int32_t bin_first[ARCN_MAX_LEVELS];       // index of the level's first counter
+    int32_t cap[ARCN_MAX_LEVELS];             // records per bin
+    int64_t rec_first[ARCN_MAX_LEVELS];       // first record of the level's bin 0
+    uint32_t lock_levels;                     // consumer, bit l: row locks (else float atomics)
+    uint32_t active_levels;                   // debugging aid (ARCN_SCATTER_LEVELS): levels that are processed at all
+    uint32_t pair_levels;                     // hashed power-of-two levels with more than one chunk: <= 4 pair records per sample
+    int32_t n_bins;
+    int32_t debug;
+    int32_t chunk_floats;                     // LDS accumulator floats per workgroup (rows per chunk * F)
+    int64_t n_recs;
 };
 
 template <int F>
-__global__ void __launch_bounds__(256)
-scatter_prep_kernel(const float *__restrict__ xyz, const float *__restrict__ dout, GridParams g, ScatterRec *__restrict__ recs,
-                    int64_t n_cap, int64_t n, const int32_t *n_ptr) {
+__device__ __forceinline__ void overflow_add(float *__restrict__ dtable, const LevelParams &lp, uint32_t row, float a0, float a1) {
+    float *d = dtable + ((int64_t)lp.offset + row) * F;
+    unsafeAtomicAdd(d, a0);
+    if (F > 1) unsafeAtomicAdd(d + (F > 1 ? 1 : 0), a1);
+}
+
+constexpr int kBinThreads = 1024;  // samples per producer tile
+
+// place one record at position pos of its bin; beyond the bin's capacity it is applied to dtable directly
+template <int F>
+__device__ __forceinline__ void emit_record(uint4 *__restrict__ lrecs, float *__restrict__ dtable, const LevelParams &lp, int bin,
+                                            uint32_t pos, uint32_t cap, int shift, const uint4 &rec) {
+    if (pos < cap) {
+        lrecs[(int64_t)bin * cap + pos] = rec;
+    } else {
+        const uint32_t base_row = (uint32_t)bin << shift;
+        const uint32_t i0 = rec.x & 0xffffu, i1 = rec.x >> 16;
+        const float wx = __uint_as_float(rec.y), a0 = __uint_as_float(rec.z), a1 = __uint_as_float(rec.w);
+        const float wl = 1.0f - wx;
+        overflow_add<F>(dtable, lp, base_row + i0, a0 * wl, a1 * wl);
+        if (i1 != 0xffffu) overflow_add<F>(dtable, lp, base_row + i1, a0 * wx, a1 * wx);
+    }
+}
+
+// Latency, not bandwidth, bounds this kernel: a workgroup lives ~8 us (loads -> ranks in LDS -> barrier -> one global
+// integer atomic per bin -> barrier -> stores) and its ~90 VGPRs allow one 1024-thread workgroup per CU.  Staging the
+// records in LDS to write them out bin-sorted (coalesced) was tried and is slower: the extra barrier and scan lengthen
+// exactly that chain (212 us against 140 us).
+template <int F>
+__global__ void __launch_bounds__(kBinThreads)
+scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout, GridParams g, BinPlan plan,
+                   uint32_t *__restrict__ counters, uint4 *__restrict__ recs, float *__restrict__ dtable, int64_t n,
+                   const int32_t *n_ptr) {
+    __shared__ uint32_t hist[kMaxChunks];   // records of this tile per bin
+    __shared__ uint32_t gbase[kMaxChunks];  // first position of the tile's run in every bin
     const int64_t cnt = dev_count(n, n_ptr);
+    const int64_t tile0 = (int64_t)blockIdx.x * kBinThreads;
+    if (tile0 >= cnt) return;
     const int l = blockIdx.y;
+    if (!((plan.active_levels >> l) & 1u)) return;
     const LevelParams lp = g.lv[l];
-    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cnt; s += (int64_t)gridDim.x * blockDim.x) {
+    const int nc = plan.n_chunks[l], shift = plan.chunk_shift[l];
+    const uint32_t cmask = (1u << shift) - 1u;
+    for (int i = threadIdx.x; i < nc; i += kBinThreads) hist[i] = 0u;
+    __syncthreads();
+    const int t = threadIdx.x, lane = t & 63;
+    const int64_t s = tile0 + t;
+    int sbin[8];
+    uint32_t sidx[8];
+    float swx[8], sa[8], sb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sbin[k] = -1;
+    Cell cell;
+    cell.valid = false;
+    float g0 = 0.f, g1 = 0.f;
+    if (s < cnt) {
         const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
-        const Cell cell = locate(p, g, lp.res);
-        ScatterRec r;
-        r.cxy = cell.valid ? (cell.c[0] | (cell.c[1] << 16)) : 0u;
-        r.czv = cell.valid ? (cell.c[2] | (1u << 16)) : 0u;
-        r.w0 = cell.valid ? cell.w[0] : 0.f;
-        r.w1 = cell.valid ? cell.w[1] : 0.f;
-        r.w2 = cell.valid ? cell.w[2] : 0.f;
-        r.g0 = dout[(s * g.L + l) * F];
-        r.g1 = F > 1 ? dout[(s * g.L + l) * F + (F > 1 ? 1 : 0)] : 0.f;
-        r.pad = 0.f;
-        recs[(int64_t)l * n_cap + s] = r;
+        cell = locate(p, g, lp.res);
+        if (cell.valid) {
+            g0 = dout[(s * g.L + l) * F];
+            g1 = F > 1 ? dout[(s * g.L + l) * F + (F > 1 ? 1 : 0)] : 0.f;
+        }
+    }
+    // runs of consecutive samples (lanes) in the same cell: head lanes, and for every lane the last lane of its run
+    const uint32_t kxy = cell.valid ? (cell.c[0] | (cell.c[1] << 16)) : 0xffffffffu;
+    const uint32_t kz = cell.valid ? cell.c[2] : (uint32_t)lane;
+    const uint32_t pxy = __shfl_up(kxy, 1), pz = __shfl_up(kz, 1);
+    const bool head = lane == 0 || kxy != pxy || kz != pz;
+    const uint64_t heads = __ballot(head && cell.valid), valid = __ballot(cell.valid);
+    // Per wave: with an average run of >= 1.5 samples the runs are summed first (fewer records, fewer row updates, and no
+    // neighbouring lanes fighting over one row lock in the consumer); otherwise the x pairs go out as they are.
+    const bool reduce = 3 * __popcll(heads) <= 2 * __popcll(valid);
+    if (!reduce) {
+        if (cell.valid) {
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                const uint32_t oy = pr & 1, oz = pr >> 1;
+                const uint32_t r0 = hash_row(cell.c[0], cell.c[1] + oy, cell.c[2] + oz, lp);
+                const uint32_t r1 = hash_row(cell.c[0] + 1u, cell.c[1] + oy, cell.c[2] + oz, lp);
+                const float wyz = (oy ? cell.w[1] : 1.0f - cell.w[1]) * (oz ? cell.w[2] : 1.0f - cell.w[2]);
+                const float a0 = g0 * wyz, a1 = g1 * wyz;
+                const int c0 = (int)(r0 >> shift), c1 = (int)(r1 >> shift);
+                if (c0 == c1) {
+                    sbin[2 * pr] = c0;
+                    sidx[2 * pr] = (r0 & cmask) | ((r1 & cmask) << 16);
+                    swx[2 * pr] = cell.w[0];
+                    sa[2 * pr] = a0;
+                    sb[2 * pr] = a1;
+                } else {
+                    const float wl = 1.0f - cell.w[0];
+                    sbin[2 * pr] = c0;
+                    sidx[2 * pr] = (r0 & cmask) | 0xffff0000u;
+                    swx[2 * pr] = 0.f;
+                    sa[2 * pr] = a0 * wl;
+                    sb[2 * pr] = a1 * wl;
+                    sbin[2 * pr + 1] = c1;
+                    sidx[2 * pr + 1] = (r1 & cmask) | 0xffff0000u;
+                    swx[2 * pr + 1] = 0.f;
+                    sa[2 * pr + 1] = a0 * cell.w[0];
+                    sb[2 * pr + 1] = a1 * cell.w[0];
+                }
+            }
+        }
+    } else {
+        // segmented suffix sum by doubling over the 8 corners x F values; only the head lane of a run emits its 8 singles
+        const uint64_t all_heads = __ballot(head);
+        const uint64_t above = lane == 63 ? 0ull : (all_heads & ~((2ull << lane) - 1ull));
+        const int tail = above ? (int)__builtin_ctzll(above) - 1 : 63;
+        float va[8], vb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
+            float wt = 0.f;
+            if (cell.valid) wt = ((ox ? cell.w[0] : 1.0f - cell.w[0]) * (oy ? cell.w[1] : 1.0f - cell.w[1])) * (oz ? cell.w[2] : 1.0f - cell.w[2]);
+            va[q] = g0 * wt;
+            vb[q] = g1 * wt;
+        }
+        for (int d = 1; d < 64; d <<= 1) {
+            const bool take = lane + d <= tail;
+            if (!__ballot(take)) break;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float ua = __shfl_down(va[q], d);
+                va[q] += take ? ua : 0.f;
+                if (F > 1) {
+                    const float ub = __shfl_down(vb[q], d);
+                    vb[q] += take ? ub : 0.f;
+                }
+            }
+        }
+        if (head && cell.valid) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
+                const uint32_t r = hash_row(cell.c[0] + ox, cell.c[1] + oy, cell.c[2] + oz, lp);
+                sbin[q] = (int)(r >> shift);
+                sidx[q] = (r & cmask) | 0xffff0000u;
+                swx[q] = 0.f;
+                sa[q] = va[q];
+                sb[q] = vb[q];
+            }
+        }
+    }
+    uint32_t rank[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rank[k] = sbin[k] >= 0 ? atomicAdd(&hist[sbin[k]], 1u) : 0u;
+    __syncthreads();
+    // reserve the tile's run in every bin: one global integer atomic per (bin, tile)
+    for (int i = threadIdx.x; i < nc; i += kBinThreads) {
+        const uint32_t h = hist[i];
+        gbase[i] = h ? atomicAdd(&counters[plan.bin_first[l] + i], h) : 0u;
+    }
+    __syncthreads();
+    const uint32_t cap = (uint32_t)plan.cap[l];
+    uint4 *lrecs = recs + plan.rec_first[l];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (sbin[k] < 0) continue;
+        const uint4 rec = make_uint4(sidx[k], __float_as_uint(swx[k]), __float_as_uint(sa[k]), __float_as_uint(sb[k]));
+        emit_record<F>(lrecs, dtable, lp, sbin[k], gbase[sbin[k]] + rank[k], cap, shift, rec);
     }
 }
 
 template <int F>
 __global__ void __launch_bounds__(kTiledThreads)
-hashgrid_bwd_tiled_kernel(const ScatterRec *__restrict__ recs, int64_t n_cap, GridParams g, TiledPlan plan,
-                          float *__restrict__ dtable, int64_t n, const int32_t *n_ptr) {
+scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict__ counters, GridParams g, BinPlan plan,
+                     float *__restrict__ dtable) {
     extern __shared__ __attribute__((aligned(16))) float acc[];
-    const int64_t cnt = dev_count(n, n_ptr);
-    // work items are laid out finest level first: the unsplit fine-level owners (all the same length) fill the first
-    // round of CUs, the shorter split items of the coarse levels pack into the second one
     int k = 0;
     while (k + 1 < g.L && (int)blockIdx.x >= plan.item_first[k + 1]) ++k;
     const int item = blockIdx.x - plan.item_first[k];
-    const int l = g.L - 1 - k;
-    const int chunk = item / plan.n_splits[l], split = item % plan.n_splits[l];
+    const int l = plan.level_of[k];
+    if (!((plan.active_levels >> l) & 1u)) return;
+    const int ns = plan.n_splits[l];
+    const int chunk = item / ns, split = item - chunk * ns;
     const LevelParams lp = g.lv[l];
-    const uint32_t row_lo = (uint32_t)chunk * (uint32_t)plan.chunk_rows[l];
-    const uint32_t row_hi_raw = row_lo + (uint32_t)plan.chunk_rows[l];
-    const uint32_t row_hi = row_hi_raw < lp.size ? row_hi_raw : lp.size;
-    const int n_rows = (int)(row_hi - row_lo);
-    const uint32_t n_rows_u = (uint32_t)n_rows;
-    for (int i = threadIdx.x; i < n_rows * F; i += kTiledThreads) acc[i] = 0.f;
+    const uint32_t cap = (uint32_t)plan.cap[l];
+    uint32_t cnt = counters[plan.bin_first[l] + chunk];
+    cnt = cnt < cap ? cnt : cap;
+    const uint32_t per = (cnt + ns - 1) / ns;
+    const uint32_t lo = per * split, hi = (lo + per < cnt) ? lo + per : cnt;
+    if (lo >= hi) return;
+    const uint32_t row_lo = (uint32_t)chunk << plan.chunk_shift[l];
+    const uint32_t row_hi_raw = row_lo + (1u << plan.chunk_shift[l]);
+    const int n_rows = (int)((row_hi_raw < lp.size ? row_hi_raw : lp.size) - row_lo);
+    uint32_t *locks = reinterpret_cast<uint32_t *>(acc + plan.chunk_floats);
+    {
+        float4 *acc4 = reinterpret_cast<float4 *>(acc);
+        for (int i = threadIdx.x; i < (n_rows * F + 3) / 4; i += kTiledThreads) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int i = threadIdx.x; i < plan.chunk_floats / F / 32; i += kTiledThreads) locks[i] = 0u;
     __syncthreads();
-    const int64_t per = (cnt + plan.n_splits[l] - 1) / plan.n_splits[l];
-    const int64_t s_lo = per * split, s_hi = (s_lo + per < cnt) ? s_lo + per : cnt;
-    // Inner loop: VALU-issue bound, so it only unpacks, hashes (two xors + mask per corner on power-of-two levels) and
-    // visits the few in-slice corners.  LDS float atomics cost ~3 cycles per ACTIVE lane on gfx950 (measured; integer ones
-    // are ~28x cheaper), hence the set-bit loop instead of 16 predicated full-wave ds_add_f32.
-    const ScatterRec *pr = recs + (int64_t)l * n_cap + s_lo + (int64_t)threadIdx.x;
-    int remaining = (s_lo + (int64_t)threadIdx.x < s_hi)
-                        ? (int)((s_hi - s_lo - (int64_t)threadIdx.x + kTiledThreads - 1) / kTiledThreads) : 0;
-    ScatterRec nxt = {};
-    if (remaining > 0) nxt = *pr;
-    for (; remaining > 0; --remaining) {
-        const ScatterRec r = nxt;
-        pr += kTiledThreads;
-        if (remaining > 1) nxt = *pr;  // register prefetch of the next record
-        const uint32_t cx = r.cxy & 0xffffu, cy = r.cxy >> 16, cz = r.czv & 0xffffu;
-        uint32_t hit = 0;
-        uint32_t hx0 = 0, hx1 = 0, hy0 = 0, hy1 = 0, hz0 = 0, hz1 = 0;
-        if (lp.mask) {
-            hx0 = cx; hx1 = cx + 1u;
-            hy0 = cy * 2654435761u; hy1 = hy0 + 2654435761u;
-            hz0 = cz * 805459861u; hz1 = hz0 + 805459861u;
+    const bool locked = (plan.lock_levels >> l) & 1u;
+    const uint4 *pr = recs + plan.rec_first[l] + (int64_t)chunk * cap + lo;
+    const uint32_t len = hi - lo;
+    // A bin is only ~32 records per thread: with one load in flight per thread the loop would be bound by memory latency.
+    // Each trip takes kUnroll records per thread (the next group's loads are issued before the current group is applied).
+    constexpr int kUnroll = 4;
+    const uint32_t trips = (plan.debug & 1) ? 0u : (len + kTiledThreads * kUnroll - 1) / (kTiledThreads * kUnroll);
+    const uint4 none = make_uint4(0xffffffffu, 0u, 0u, 0u);  // i0 = i1 = 0xffff: nothing to do
+    uint32_t i = threadIdx.x;
+    uint4 nxt[kUnroll];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const uint32_t rr = ((((q >> 1) & 1) ? hx1 : hx0) ^ ((q & 1) ? hy1 : hy0) ^ ((q >> 2) ? hz1 : hz0)) & lp.mask;
-                hit |= ((rr - row_lo) < n_rows_u ? 1u : 0u) << q;
-            }
-        } else {
+    for (int u = 0; u < kUnroll; ++u) nxt[u] = (i + u * kTiledThreads < len) ? pr[i + u * kTiledThreads] : none;
+    for (uint32_t trip = 0; trip < trips; ++trip) {
+        uint4 cur[kUnroll];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const uint32_t rr = hash_row(cx + ((q >> 1) & 1), cy + (q & 1), cz + (q >> 2), lp);
-                hit |= ((rr - row_lo) < n_rows_u ? 1u : 0u) << q;
-            }
+        for (int u = 0; u < kUnroll; ++u) cur[u] = nxt[u];
+        i += kTiledThreads * kUnroll;
+        if (trip + 1 < trips) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) nxt[u] = (i + u * kTiledThreads < len) ? pr[i + u * kTiledThreads] : none;
         }
-        if (!(r.czv >> 16)) hit = 0;
-        while (hit) {
-            const int q = __builtin_ctz(hit);
-            hit &= hit - 1;
-            const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
-            uint32_t rr;
-            if (lp.mask) rr = ((ox ? hx1 : hx0) ^ (oy ? hy1 : hy0) ^ (oz ? hz1 : hz0)) & lp.mask;
-            else rr = hash_row(cx + ox, cy + oy, cz + oz, lp);
-            const float wt = ((ox ? r.w0 : 1.0f - r.w0) * (oy ? r.w1 : 1.0f - r.w1)) * (oz ? r.w2 : 1.0f - r.w2);
-            float *dsta = acc + (rr - row_lo) * F;
-            __hip_atomic_fetch_add(dsta, r.g0 * wt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (F > 1) __hip_atomic_fetch_add(dsta + (F > 1 ? 1 : 0), r.g1 * wt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const uint4 r = cur[u];
+            const uint32_t i0 = r.x & 0xffffu, i1 = r.x >> 16;
+            const bool have = i0 != 0xffffu;
+            const float wx = __uint_as_float(r.y), a0 = __uint_as_float(r.z), a1 = __uint_as_float(r.w);
+            const float wl = 1.0f - wx;
+            if (locked) {
+                int todo = have ? (i1 != 0xffffu ? 2 : 1) : 0;
+                uint32_t tgt = i0;
+                float va = a0 * wl, vb = a1 * wl;
+                // wave-uniform loop condition: the holder's update and release must stay INSIDE the loop (with a per-lane exit
+                // the compiler may sink them past it, where the holder would wait for the spinning lanes of its own wave)
+                while (__ballot(todo > 0)) {
+                    const uint32_t bit = 1u << (tgt & 31u);
+                    uint32_t *lk = locks + (tgt >> 5);
+                    uint32_t prev = bit;
+                    if (todo > 0) prev = __hip_atomic_fetch_or(lk, bit, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (!(prev & bit)) {
+                        if (F == 2) {
+                            float2 *cell = reinterpret_cast<float2 *>(acc) + tgt;
+                            float2 v = *cell;
+                            v.x += va;
+                            v.y += vb;
+                            *cell = v;
+                        } else {
+                            acc[tgt] += va;
+                        }
+                        __hip_atomic_fetch_and(lk, ~bit, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        --todo;
+                        tgt = i1;
+                        va = a0 * wx;
+                        vb = a1 * wx;
+                    }
+                }
+            } else if (have) {
+                float *d0 = acc + i0 * F;
+                __hip_atomic_fetch_add(d0, a0 * wl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (F > 1) __hip_atomic_fetch_add(d0 + (F > 1 ? 1 : 0), a1 * wl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (i1 != 0xffffu) {
+                    float *d1 = acc + i1 * F;
+                    __hip_atomic_fetch_add(d1, a0 * wx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (F > 1) __hip_atomic_fetch_add(d1 + (F > 1 ? 1 : 0), a1 * wx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
         }
     }
     __syncthreads();
     float *dst = dtable + ((int64_t)lp.offset + row_lo) * F;
-    if (plan.n_splits[l] == 1) {
-        // exclusive owner: plain coalesced stores (+= so that callers accumulating over several launches stay correct)
-        for (int i = threadIdx.x; i < n_rows * F; i += kTiledThreads) dst[i] += acc[i];
+    if (plan.debug & 2) return;
+    if (ns == 1) {
+        // exclusive owner: plain coalesced 16-byte stores (+= so that callers accumulating over several launches stay correct);
+        // the global loads of a batch are all issued before the first add, or the loop would run at memory latency
+        const int n4 = (n_rows * F) >> 2;  // level offsets and chunk sizes are multiples of 4 floats except on a ragged tail
+        const bool aligned = (((int64_t)lp.offset + row_lo) * F) % 4 == 0;
+        if (aligned) {
+            float4 *dst4 = reinterpret_cast<float4 *>(dst);
+            const float4 *acc4 = reinterpret_cast<const float4 *>(acc);
+            constexpr int kBatch = 8;
+            for (int j0 = threadIdx.x; j0 < n4; j0 += kTiledThreads * kBatch) {
+                float4 v[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int j = j0 + u * kTiledThreads;
+                    if (j < n4) v[u] = dst4[j];
+                }
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int j = j0 + u * kTiledThreads;
+                    if (j < n4) {
+                        const float4 a = acc4[j];
+                        v[u].x += a.x; v[u].y += a.y; v[u].z += a.z; v[u].w += a.w;
+                        dst4[j] = v[u];
+                    }
+                }
+            }
+            for (int j = n4 * 4 + threadIdx.x; j < n_rows * F; j += kTiledThreads) dst[j] += acc[j];
+        } else {
+            for (int j = threadIdx.x; j < n_rows * F; j += kTiledThreads) dst[j] += acc[j];
+        }
     } else {
-        for (int i = threadIdx.x; i < n_rows * F; i += kTiledThreads) {
-            const float v = acc[i];
-            if (v != 0.f) unsafeAtomicAdd(dst + i, v);
+        for (int j = threadIdx.x; j < n_rows * F; j += kTiledThreads) {
+            const float v = acc[j];
+            if (v != 0.f) unsafeAtomicAdd(dst + j, v);
         }
     }
 }
@@ -345,6 +555,86 @@ static int build_params(const arcn_hashgrid_desc *d, GridParams &g) {
     return ARCN_OK;
 }
 
+// Owner chunks, bins and dispatch order of the v3 backward for a capacity of n samples.
+static int build_bin_plan(const GridParams &g, int64_t n, BinPlan &plan) {
+    static const uint32_t lock_override = [] {
+        const char *e = getenv("ARCN_SCATTER_LOCK");
+        return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffffffu;
+    }();
+    static const int chunk_floats = [] {
+        const char *e = getenv("ARCN_SCATTER_CHUNK_FLOATS");  // tuning aid; power of two <= 32768
+        int v = e ? atoi(e) : kChunkFloats;
+        return (v >= 1024 && v <= kChunkFloats && !(v & (v - 1))) ? v : kChunkFloats;
+    }();
+    plan.chunk_floats = chunk_floats;
+    const int rows_cap = chunk_floats / g.F;
+    int bins = 0;
+    int64_t recs = 0;
+    static const uint32_t active = [] {
+        const char *e = getenv("ARCN_SCATTER_LEVELS");
+        return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffffffu;
+    }();
+    plan.active_levels = active;
+    static const int dbg = [] { const char *e = getenv("ARCN_SCATTER_DEBUG"); return e ? atoi(e) : 0; }();
+    plan.debug = dbg;
+    plan.lock_levels = 0u;
+    plan.pair_levels = 0u;
+    for (int l = 0; l < g.L; ++l) {
+        const int64_t size = g.lv[l].size;
+        int shift = 0;
+        while ((1 << shift) < rows_cap && ((int64_t)1 << shift) < size) ++shift;
+        const int64_t nc = (size + ((int64_t)1 << shift) - 1) >> shift;
+        if (nc > kMaxChunks) return einval("hashgrid_bwd: level too large for the binned scatter");
+        // hashed power-of-two levels: both rows of an x pair share a chunk -> 4 pair records per sample, samples interleaved;
+        // the small levels below them: runs of samples in one cell are summed in the producer -> at most 8 singles per sample
+        const bool paired = g.lv[l].mask != 0 && nc > 1;
+        if (paired) plan.pair_levels |= 1u << l;
+        if (paired && ((lock_override >> l) & 1u)) plan.lock_levels |= 1u << l;
+        const bool locked = (plan.lock_levels >> l) & 1u;
+        const int64_t mean = (paired ? 4 : 8) * n / nc;
+        int64_t cap = nc == 1 ? 8 * n : 2 * mean + 1024;
+        if (cap > 8 * n) cap = 8 * n;
+        if (cap > 0x7fffffffll) return einval("hashgrid_bwd: too many samples for the binned scatter");
+        // one exclusive owner per chunk (plain-store flush); splits only where float atomics make the items long
+        int ns = locked ? 1 : (int)(64 / nc);
+        if (ns < 1) ns = 1;
+        while (ns > 1 && cap / ns < 8192) ns >>= 1;
+        plan.n_chunks[l] = (int)nc;
+        plan.n_splits[l] = ns;
+        plan.chunk_shift[l] = shift;
+        plan.bin_first[l] = bins;
+        plan.cap[l] = (int)cap;
+        plan.rec_first[l] = recs;
+        bins += (int)nc;
+        recs += nc * cap;
+    }
+    plan.n_bins = bins;
+    plan.n_recs = recs;
+    // dispatch: levels with the longest items (largest bins per workgroup) first, ties finest first
+    int order[ARCN_MAX_LEVELS];
+    for (int l = 0; l < g.L; ++l) order[l] = g.L - 1 - l;
+    for (int a = 1; a < g.L; ++a)
+        for (int b = a; b > 0 && plan.cap[order[b]] / plan.n_splits[order[b]] > plan.cap[order[b - 1]] / plan.n_splits[order[b - 1]]; --b) {
+            const int tmp = order[b];
+            order[b] = order[b - 1];
+            order[b - 1] = tmp;
+        }
+    int items = 0, k = 0;
+    for (; k < g.L; ++k) {
+        const int l = order[k];
+        plan.item_first[k] = items;
+        plan.level_of[k] = l;
+        items += plan.n_chunks[l] * plan.n_splits[l];
+    }
+    for (; k <= ARCN_MAX_LEVELS; ++k) {
+        plan.item_first[k] = items;
+        if (k < ARCN_MAX_LEVELS) plan.level_of[k] = 0;
+    }
+    return ARCN_OK;
+}
+
+static inline int64_t bin_counter_floats(const BinPlan &plan) { return ((int64_t)plan.n_bins + 63) / 64 * 64; }
+
 }  // namespace arcn
 
 using namespace arcn;
@@ -365,55 +655,42 @@ ARCN_EXPORT int arcn_hashgrid_fwd(const float *xyz, const float *table, const ar
     return check_launch("hashgrid_fwd");
 }
 
+ARCN_EXPORT int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc *desc_host, int64_t n);
+
 ARCN_EXPORT int arcn_hashgrid_bwd(const float *xyz, const float *table, const float *dout,
                                   const arcn_hashgrid_desc *desc_host, float *dtable, float *dxyz, float *workspace,
-                                  int64_t n, const int32_t *n_ptr, void *stream) {
+                                  int64_t workspace_floats, int64_t n, const int32_t *n_ptr, void *stream) {
     if (n <= 0) return ARCN_OK;
     if (!xyz || !dout || (!dtable && !dxyz) || (dxyz && !table)) return einval("hashgrid_bwd: missing argument");
     GridParams g;
     int rc = build_params(desc_host, g);
     if (rc) return rc;
+    if (workspace && workspace_floats < arcn_hashgrid_bwd_workspace_floats(desc_host, n))
+        return einval("hashgrid_bwd: workspace smaller than arcn_hashgrid_bwd_workspace_floats(desc, n)");
     if (workspace && dtable && !dxyz && g.F <= 2) {
-        // owner-computes scatter through LDS (workspace only selects the path; nothing is stored in it)
-        TiledPlan plan;
-        int items = 0;
-        for (int k = 0; k < g.L; ++k) {
-            const int l = g.L - 1 - k;  // item_first is indexed by dispatch position k, the per-level fields by level
-            const int64_t size = g.lv[l].size;
-            const int rows_cap = kChunkRows * 2 / g.F;  // 128 KiB of floats
-            int nc = (int)((size + rows_cap - 1) / rows_cap);
-            int cr = (int)((size + nc - 1) / nc);
-            int ns = 32 / nc;  // about 32 workgroups per level
-            if (!g.lv[l].mask) ns *= 2;  // non-power-of-two levels pay an exact 64-bit modulo per corner: shorter items
-            if (ns < 1) ns = 1;
-            // never split so finely that a split has fewer than 4096 samples
-            while (ns > 1 && n / ns < 4096) ns >>= 1;
-            plan.item_first[k] = items;
-            plan.n_chunks[l] = nc;
-            plan.n_splits[l] = ns;
-            plan.chunk_rows[l] = cr;
-            items += nc * ns;
-        }
-        plan.item_first[g.L] = items;
-        for (int l = g.L + 1; l <= ARCN_MAX_LEVELS; ++l) plan.item_first[l] = items;
-        const size_t lds = sizeof(float) * (size_t)kChunkRows * 2;
-        hipError_t e = g.F == 1
-            ? hipFuncSetAttribute(reinterpret_cast<const void *>(hashgrid_bwd_tiled_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-            : hipFuncSetAttribute(reinterpret_cast<const void *>(hashgrid_bwd_tiled_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // v3: bin the corner-pair records per owner chunk, then accumulate every bin in LDS
+        BinPlan plan;
+        rc = build_bin_plan(g, n, plan);
+        if (rc) return rc;
+        uint32_t *counters = reinterpret_cast<uint32_t *>(workspace);
+        uint4 *recs = reinterpret_cast<uint4 *>(workspace + bin_counter_floats(plan));
+        hipError_t e = hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)plan.n_bins, as_stream(stream));
         if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
-        dim3 pgrid((unsigned)items);
-        ScatterRec *recs = reinterpret_cast<ScatterRec *>(workspace);
-        int64_t tb = ceil_div<int64_t>(n, 256);
-        if (tb > 1024) tb = 1024;
-        dim3 tgrid((unsigned)tb, (unsigned)g.L);
+        const size_t lds = sizeof(float) * (size_t)plan.chunk_floats + sizeof(uint32_t) * (size_t)(plan.chunk_floats / 32);
+        e = g.F == 1
+            ? hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_accum_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+            : hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_accum_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
+        dim3 bgrid((unsigned)ceil_div<int64_t>(n, kBinThreads), (unsigned)g.L);
+        dim3 agrid((unsigned)plan.item_first[g.L]);
         if (g.F == 1) {
-            hipLaunchKernelGGL(scatter_prep_kernel<1>, tgrid, dim3(256), 0, as_stream(stream), xyz, dout, g, recs, n, n, n_ptr);
-            hipLaunchKernelGGL(hashgrid_bwd_tiled_kernel<1>, pgrid, dim3(kTiledThreads), lds, as_stream(stream), recs, n, g, plan, dtable, n, n_ptr);
+            hipLaunchKernelGGL(scatter_bin_kernel<1>, bgrid, dim3(kBinThreads), 0, as_stream(stream), xyz, dout, g, plan, counters, recs, dtable, n, n_ptr);
+            hipLaunchKernelGGL(scatter_accum_kernel<1>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable);
         } else {
-            hipLaunchKernelGGL(scatter_prep_kernel<2>, tgrid, dim3(256), 0, as_stream(stream), xyz, dout, g, recs, n, n, n_ptr);
-            hipLaunchKernelGGL(hashgrid_bwd_tiled_kernel<2>, pgrid, dim3(kTiledThreads), lds, as_stream(stream), recs, n, g, plan, dtable, n, n_ptr);
+            hipLaunchKernelGGL(scatter_bin_kernel<2>, bgrid, dim3(kBinThreads), 0, as_stream(stream), xyz, dout, g, plan, counters, recs, dtable, n, n_ptr);
+            hipLaunchKernelGGL(scatter_accum_kernel<2>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable);
         }
-        return check_launch("hashgrid_bwd_tiled");
+        return check_launch("hashgrid_bwd_binned");
     }
     dim3 grid((unsigned)ceil_div<int64_t>(n * g.L, 256));
     switch (g.F) {
@@ -426,5 +703,10 @@ ARCN_EXPORT int arcn_hashgrid_bwd(const float *xyz, const float *table, const fl
 
 ARCN_EXPORT int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc *desc_host, int64_t n) {
     if (!desc_host || n <= 0) return 0;
-    return n * (int64_t)desc_host->n_levels * 8;  // one 32-byte record per (level, sample)
+    GridParams g;
+    if (build_params(desc_host, g)) return 0;
+    if (g.F > 2) return 0;  // n_feat 4 always takes the plain kernel
+    BinPlan plan;
+    if (build_bin_plan(g, n, plan)) return 0;
+    return bin_counter_floats(plan) + plan.n_recs * 4;  // bin counters + 16-byte records
 }

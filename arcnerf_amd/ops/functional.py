@@ -183,8 +183,9 @@ def hashgrid_fwd(xyz, table, desc, want_idx=False, n_dev=None, out=None):
 
 
 def hashgrid_bwd_workspace(desc, n, device):
-    """scratch of the owner-computes scatter: one 32-byte record per (level, sample)"""
-    return torch.empty(max(1, int(n) * desc.n_levels * 8), dtype=torch.float32, device=device)
+    """scratch of the binned scatter (bin counters + 16-byte corner-pair records); the library knows the size"""
+    floats = int(N.lib().arcn_hashgrid_bwd_workspace_floats(C.addressof(desc), int(n)))
+    return torch.empty(max(1, floats), dtype=torch.float32, device=device)
 
 
 def hashgrid_bwd(xyz, table, dout, desc, want_dtable=True, want_dxyz=False, n_dev=None, dtable=None, workspace=None):
@@ -195,12 +196,13 @@ def hashgrid_bwd(xyz, table, dout, desc, want_dtable=True, want_dxyz=False, n_de
     if workspace is True:
         workspace = hashgrid_bwd_workspace(desc, n, xyz.device)
     if workspace is not None:
-        assert workspace.dtype == torch.float32 and workspace.numel() >= n * desc.n_levels * 8
+        assert workspace.dtype == torch.float32
     if want_dtable and dtable is None:
         dtable = torch.zeros_like(table)
     dxyz = torch.zeros((n, 3), dtype=torch.float32, device=xyz.device) if want_dxyz else None
     N.check(N.lib().arcn_hashgrid_bwd(N.ptr(xyz), N.ptr(table), N.ptr(dout), C.addressof(desc),
-                                     N.ptr(dtable) if want_dtable else None, N.ptr(dxyz), N.ptr(workspace), n,
+                                     N.ptr(dtable) if want_dtable else None, N.ptr(dxyz), N.ptr(workspace),
+                                     0 if workspace is None else workspace.numel(), n,
                                      _nptr(n_dev), N.stream()), 'hashgrid_bwd')
     return dtable, dxyz
 

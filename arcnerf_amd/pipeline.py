@@ -229,7 +229,7 @@ class NgpPipeline:
         b['d_rgb'] = torch.zeros((R, 3), dtype=f32, device=dev)
         b['loss'] = torch.zeros(1, dtype=f32, device=dev)
         # XCD-owned-levels scatter workspace (owner + tile counters); None selects the plain agent-scope kernel
-        self.hash_ws = torch.empty(S * cfg.n_levels * 8, dtype=f32, device=dev) if xcd_scatter else None  # scatter records
+        self.hash_ws = F.hashgrid_bwd_workspace(self.field.grid_desc, S, dev) if xcd_scatter else None  # scatter bins
         # optimiser state
         n = field.n_params
         self.exp_avg = torch.zeros(n, dtype=f32, device=dev)
@@ -406,7 +406,8 @@ class NgpPipeline:
                                None, None, N.ptr(b['geo_scratch']), S, S, n_dev.data_ptr(), st), 'mlp_bwd(geo)')
         dw_async(b['feat'], fld.geo_desc, b['geo_acts'], b['geo_scratch'], 'geo')
         N.check(L.arcn_hashgrid_bwd(N.ptr(b['xyz']), N.ptr(self._p('table')), N.ptr(b['d_feat']), N.C.addressof(fld.grid_desc),
-                                    N.ptr(self._g('table')), None, N.ptr(self.hash_ws), S, n_dev.data_ptr(), st),
+                                    N.ptr(self._g('table')), None, N.ptr(self.hash_ws),
+                                    0 if self.hash_ws is None else self.hash_ws.numel(), S, n_dev.data_ptr(), st),
                 'hashgrid_bwd')
         if aux is not None:
             main.wait_stream(aux)  # join: the optimiser (or the caller) needs every gradient

@@ -111,13 +111,16 @@ typedef struct {
  * hash_idx (n,L,8) int32 optional debug output (-1 for out-of-volume). */
 int arcn_hashgrid_fwd(const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out,
                       int32_t *hash_idx, int64_t n, const int32_t *n_ptr, void *stream);
-/* backward: dtable (n_total,F) accumulated with atomics (caller zeroes), dxyz (n,3) optional.
- * workspace (device, arcn_hashgrid_bwd_workspace_floats(desc, n) floats, optional): selects the owner-computes scatter
- * (a prep pass writes one 32-byte {cell, weights, gradient} record per (level, sample) into the workspace; each workgroup
- * then owns a slice of one level's dtable in LDS and writes it back with plain stores, no global atomics on large levels);
- * without it, when dxyz is requested, or for n_feat 4, the plain one-atomic-per-corner kernel runs.  Both ADD into dtable. */
+/* backward: dtable (n_total,F) accumulated (caller zeroes), dxyz (n,3) optional.
+ * workspace (device, workspace_floats >= arcn_hashgrid_bwd_workspace_floats(desc, n) floats, optional; -1 if too small):
+ * selects the binned scatter.  A first pass turns every (level, sample) into up to four 16-byte records, one per pair of
+ * x-neighbour corners, appended to the bin of the table chunk (<= 16384 rows) that owns their rows; a second pass gives
+ * every chunk to one workgroup, which streams its bin, accumulates in LDS and writes the chunk back with plain stores - no
+ * global float atomics on the large levels.  Without a workspace, when dxyz is requested, or for n_feat 4, the plain
+ * one-atomic-per-corner kernel runs.  Both ADD into dtable. */
 int arcn_hashgrid_bwd(const float *xyz, const float *table, const float *dout, const arcn_hashgrid_desc *desc_host,
-                      float *dtable, float *dxyz, float *workspace, int64_t n, const int32_t *n_ptr, void *stream);
+                      float *dtable, float *dxyz, float *workspace, int64_t workspace_floats, int64_t n,
+                      const int32_t *n_ptr, void *stream);
 int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc *desc_host, int64_t n);
 
 /* FreqEmbedder.forward (encoding/freq_encoder.py:65-88): out (n, D*(include_input + 2*n_freqs)). */

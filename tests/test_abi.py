@@ -53,11 +53,27 @@ def test_argument_validation_happens_before_any_launch(lib):
                                      None, None) == 0
 
 
+def _ngp_levels():
+    from arcnerf_amd.pipeline import hashgrid_level_table
+    res, offs = hashgrid_level_table(16, 19, 16, 2048)
+    return res, offs, 2, [-1.5] * 3, [1.5] * 3
+
+
 def test_workspace_queries(lib):
     m = N.make_mlp_desc([32, 64, 64, 3])
     assert lib.arcn_mlp_acts_floats(C.addressof(m), 1000) == 1000 * 128
     # dpre of every layer + per-workgroup partial dW tiles (2 slabs) of the 3 (layer, 64x64 quadrant) pairs
     assert lib.arcn_mlp_scratch_floats(C.addressof(m), 1000) == 1000 * 131 + 2 * 3 * (4096 + 64)
+    # hash-grid scatter: bin counters + 16-byte records, never less than 8 floats per (level, sample)
+    h = N.make_hashgrid_desc(*_ngp_levels())
+    n = 1 << 16
+    w = lib.arcn_hashgrid_bwd_workspace_floats(C.addressof(h), n)
+    assert n * 16 * 8 <= w <= n * 16 * 64
+    assert lib.arcn_hashgrid_bwd_workspace_floats(C.addressof(h), 0) == 0
+    # too small a workspace is an argument error, not a memory fault (validated before any device work)
+    one = C.c_void_p(16)
+    assert lib.arcn_hashgrid_bwd(one, one, one, C.addressof(h), one, None, one, 64, n, None, None) == -1
+    assert b'workspace' in lib.arcn_last_error()
 
 
 def test_host_pcg32_matches_oracle(lib, oracle):

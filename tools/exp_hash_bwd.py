@@ -32,6 +32,13 @@ print('full bwd plain  %.3f ms' % timeit(lambda: F.hashgrid_bwd(xyz, table, dout
 ws = F.hashgrid_bwd_workspace(fld.grid_desc, n, dev)
 print('full bwd xcd    %.3f ms' % timeit(lambda: F.hashgrid_bwd(xyz, table, dout, fld.grid_desc, dtable=dt, workspace=ws)))
 print('full fwd        %.3f ms' % timeit(lambda: F.hashgrid_fwd(xyz, table, fld.grid_desc)))
+import ctypes as C
+lm = torch.empty(16 * n * 2, device=dev)
+def fwd_lm():
+    N.check(N.lib().arcn_hashgrid_fwd_lm(xyz.data_ptr(), table.data_ptr(), C.addressof(fld.grid_desc), lm.data_ptr(), n, n, None, N.stream()))
+print('full fwd LM/XCD %.3f ms' % timeit(fwd_lm))
+ref = F.hashgrid_fwd(xyz, table, fld.grid_desc)
+print('LM == row-major:', torch.equal(lm.view(16, n, 2).permute(1, 0, 2).reshape(n, 32), ref))
 for l in range(16):
     desc = N.make_hashgrid_desc([fld.resolutions[l]], [fld.offsets[l], fld.offsets[l + 1]], 2, fld.min_xyz, fld.max_xyz)
     d1 = torch.randn(n, 2, device=dev)
