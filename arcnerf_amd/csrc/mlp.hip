@@ -18,6 +18,8 @@
 // f32 matrix peak — the MLP is bound by its operand traffic (128 B/sample features in, 16..64 B out), not by MFMA.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace arcn {
@@ -56,14 +58,26 @@ template <bool TRANSPOSED>
 __device__ __forceinline__ void stage_fragments(float *lds, const float *__restrict__ W, int rows, int cols) {
     const int MT = tiles16(rows), T = tiles16(cols);
     const int total = MT * T * 256;
-    for (int e = threadIdx.x; e < total; e += blockDim.x) {
-        int r, c;
-        if (TRANSPOSED) { c = e / (MT * 16); r = e - c * (MT * 16); }  // walk W row-major: W row = c, W col = r
-        else { r = e / (T * 16); c = e - r * (T * 16); }
-        float v = 0.f;
-        if (r < rows && c < cols) v = TRANSPOSED ? W[(int64_t)c * rows + r] : W[(int64_t)r * cols + c];
-        const int mt = r >> 4, i = r & 15, t = c >> 4, g = (c & 15) >> 2, ks = c & 3;
-        lds[((mt * T + t) * 64 + g * 16 + i) * 4 + ks] = v;
+    // kBatch independent loads are issued before the first LDS store: a plain load -> store loop runs at L2 latency per
+    // element (12..28 trips per thread for the NGP nets, ~20 us at the start of every workgroup)
+    constexpr int kBatch = 8;
+    for (int e0 = threadIdx.x; e0 < total; e0 += blockDim.x * kBatch) {
+        float v[kBatch];
+        int dst[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int e = e0 + u * blockDim.x;
+            int r, c;
+            if (TRANSPOSED) { c = e / (MT * 16); r = e - c * (MT * 16); }  // walk W row-major: W row = c, W col = r
+            else { r = e / (T * 16); c = e - r * (T * 16); }
+            v[u] = 0.f;
+            if (e < total && r < rows && c < cols) v[u] = TRANSPOSED ? W[(int64_t)c * rows + r] : W[(int64_t)r * cols + c];
+            const int mt = r >> 4, i = r & 15, t = c >> 4, g = (c & 15) >> 2, ks = c & 3;
+            dst[u] = e < total ? ((mt * T + t) * 64 + g * 16 + i) * 4 + ks : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u)
+            if (dst[u] >= 0) lds[dst[u]] = v[u];
     }
 }
 
@@ -295,6 +309,155 @@ mlp_bwd_dx_kernel(const float *__restrict__ weights, MlpParams P, const float *_
     }
 }
 
+// ---- backward, fused: dx AND the dW partial sums in one pass (bias-free nets of 2 or 3 layers, widths <= 64) -----------------
+// The two-kernel path above writes dpre of every layer to scratch and the dW kernel reads x, the hidden activations and
+// dpre back: 1.9 KB/sample of HBM traffic for the NGP nets on top of the 0.9 KB the dx pass needs.  Here the dW tiles live in
+// registers for the whole kernel: after dpre_l is known (registers, lane (g, j): neurons 4g..4g+3 of sample j) the wave
+// transposes it and y_{l-1} through a private 1 KiB LDS tile each (one ds_write_b128 per lane, four ds_read_b32: lane (i, g)
+// gets neuron i of sample 4q+g) — exactly the A/B operands of dW += dpre^T . y over 4 samples per MFMA.  At the end the 4
+// waves are summed through LDS and the workgroup writes ONE partial per layer for mlp_dw_reduce_kernel.
+// T0..T3 = 16-wide tiles per layer boundary (T3 = 0: two layers); the dims themselves stay run-time (ragged widths are zero
+// padded by load_tiles / stage_fragments, so e.g. the 3-wide RGB output uses the T3 = 1 instance).
+template <int T0, int T1, int T2, int T3, int NT>
+__global__ void __launch_bounds__(256, 2)  // 2 workgroups per CU = 2 waves per SIMD: at most 256 VGPR + AGPR per lane
+mlp_bwd_fused_kernel(const float *__restrict__ x, const float *__restrict__ weights, MlpParams P, const float *__restrict__ out,
+                     const float *__restrict__ acts, const float *__restrict__ dout, float *__restrict__ dx,
+                     float *__restrict__ partials, int n_slots, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
+    constexpr int NL = T3 ? 3 : 2;
+    constexpr int WT = 4;
+    constexpr int TA = T3 ? T3 : 1;  // tiles of the last boundary when there are three layers
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int lds_w = 0;
+    for (int l = 0; l < NL; ++l) {
+        stage_fragments<true>(lds + P.lds_off[l], weights + P.w_off[l], P.dims[l], P.dims[l + 1]);
+        lds_w = P.lds_off[l] + tiles16(P.dims[l]) * tiles16(P.dims[l + 1]) * 256;
+    }
+    __syncthreads();
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+    float *trA = lds + lds_w + wave * 2048;  // 4 tiles of 16 samples x 16 neurons: dpre
+    float *trB = trA + 1024;                 // 4 tiles: y_{l-1}
+    constexpr int SPW = 16 * NT;
+    const int64_t n_tiles = ceil_div_dev(cnt, (int64_t)SPW * 4);
+    const int64_t a1_off = 0, a2_off = n_cap * P.dims[1];  // hidden activations of layer 0 / layer 1 inside `acts`
+    f4 acc0[T1][T0], acc1[T2][T1], acc2[TA][T2];
+#pragma unroll
+    for (int a = 0; a < T1; ++a)
+#pragma unroll
+        for (int b = 0; b < T0; ++b) acc0[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < T2; ++a)
+#pragma unroll
+        for (int b = 0; b < T1; ++b) acc1[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < T2; ++b) acc2[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+
+    // dW (MT x T tiles) += dpre^T . yprev for the NT sample tiles held in registers
+    auto accumulate = [&](auto &acc, const f4 (&dpre)[WT][NT], const f4 (&yprev)[WT][NT], auto mt_c, auto t_c) {
+        constexpr int MT = decltype(mt_c)::value, T = decltype(t_c)::value;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f4 *>(trA + mt * 256 + j * 16 + 4 * g) = dpre[mt][nt];
+#pragma unroll
+            for (int t = 0; t < T; ++t) *reinterpret_cast<f4 *>(trB + t * 256 + j * 16 + 4 * g) = yprev[t][nt];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float av[MT], bv[T];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) av[mt] = trA[mt * 256 + (4 * q + g) * 16 + j];
+#pragma unroll
+                for (int t = 0; t < T; ++t) bv[t] = trB[t * 256 + (4 * q + g) * 16 + j];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int t = 0; t < T; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[t], acc[mt][t], 0, 0, 0);
+            }
+        }
+    };
+    auto apply_act_grad = [&](f4 (&d)[WT][NT], const f4 (&y)[WT][NT], int act) {
+#pragma unroll
+        for (int mt = 0; mt < WT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                d[mt][nt].x *= act_grad_from_y(y[mt][nt].x, act, P.beta);
+                d[mt][nt].y *= act_grad_from_y(y[mt][nt].y, act, P.beta);
+                d[mt][nt].z *= act_grad_from_y(y[mt][nt].z, act, P.beta);
+                d[mt][nt].w *= act_grad_from_y(y[mt][nt].w, act, P.beta);
+            }
+    };
+    auto back = [&](f4 (&d)[WT][NT], int l, int MT, int T) {  // d <- W_l^T . d
+        f4 dp[WT][NT];
+#pragma unroll
+        for (int mt = 0; mt < WT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) dp[mt][nt] = f4{0.f, 0.f, 0.f, 0.f};
+        gemm_tiles<WT, NT>(dp, d, lds + P.lds_off[l], MT, T, lane);
+#pragma unroll
+        for (int mt = 0; mt < WT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) d[mt][nt] = dp[mt][nt];
+    };
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t s0 = tile * SPW * 4 + (int64_t)wave * SPW;
+        if (s0 >= cnt) continue;
+        f4 d[WT][NT], y[WT][NT], yp[WT][NT];
+        load_tiles<WT, NT>(d, dout, P.dims[NL], s0, cnt, g, j);
+        if (P.act_out != ARCN_ACT_NONE) {
+            load_tiles<WT, NT>(y, out, P.dims[NL], s0, cnt, g, j);
+            apply_act_grad(d, y, P.act_out);
+        }
+        if (NL == 3) {
+            load_tiles<WT, NT>(yp, acts + a2_off, P.dims[2], s0, cnt, g, j);
+            accumulate(acc2, d, yp, std::integral_constant<int, TA>{}, std::integral_constant<int, T2>{});
+            back(d, 2, T2, TA);
+            if (P.act_hidden != ARCN_ACT_NONE) apply_act_grad(d, yp, P.act_hidden);
+        }
+        load_tiles<WT, NT>(yp, acts + a1_off, P.dims[1], s0, cnt, g, j);
+        accumulate(acc1, d, yp, std::integral_constant<int, T2>{}, std::integral_constant<int, T1>{});
+        back(d, 1, T1, T2);
+        if (P.act_hidden != ARCN_ACT_NONE) apply_act_grad(d, yp, P.act_hidden);
+        load_tiles<WT, NT>(yp, x, P.dims[0], s0, cnt, g, j);
+        accumulate(acc0, d, yp, std::integral_constant<int, T1>{}, std::integral_constant<int, T0>{});
+        if (dx) {
+            back(d, 0, T0, T1);
+            store_tiles<WT, NT>(d, dx, P.dims[0], s0, cnt, g, j);
+        }
+    }
+    // sum the 4 waves through LDS (the transposition tiles are free now: 4 x 2048 floats >= 16 tiles of 256) and write the
+    // workgroup's partial of every layer in the fragment order mlp_dw_reduce_kernel expects: tile (a*4+b), lane, register
+    __syncthreads();
+    float *red = lds + lds_w;
+    auto flush = [&](auto &acc, int l, auto mt_c, auto t_c) {
+        constexpr int MT = decltype(mt_c)::value, T = decltype(t_c)::value;
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < T; ++b) {
+                        f4 *dst = reinterpret_cast<f4 *>(red + (a * 4 + b) * 256 + lane * 4);
+                        *dst = (w == 0) ? acc[a][b] : (*dst + acc[a][b]);
+                    }
+            }
+            __syncthreads();
+        }
+        f4 *part = reinterpret_cast<f4 *>(partials + ((int64_t)l * n_slots + blockIdx.x) * 4096);
+        const f4 *src4 = reinterpret_cast<const f4 *>(red);
+        for (int e = threadIdx.x; e < 1024; e += 256) {
+            const int tl = e >> 6;  // 64 float4 per tile
+            if ((tl >> 2) < MT && (tl & 3) < T) part[e] = src4[e];
+        }
+        __syncthreads();
+    };
+    flush(acc0, 0, std::integral_constant<int, T1>{}, std::integral_constant<int, T0>{});
+    flush(acc1, 1, std::integral_constant<int, T2>{}, std::integral_constant<int, T1>{});
+    if (NL == 3) flush(acc2, 2, std::integral_constant<int, TA>{}, std::integral_constant<int, T2>{});
+}
+
 // ---- backward, part 2: dW_l = dpre_l^T . y_{l-1}  (reduction over samples), db_l = sum_s dpre_l ----------------
 // grid = (slabs, n_layers * quads): one workgroup owns a slab of samples for one 64x64 quadrant of one layer's dW.
 // MFMA rows = output neurons, columns = input neurons, K = samples: both operands come straight from global memory in
@@ -422,8 +585,13 @@ mlp_dw_reduce_kernel(const float *__restrict__ partials, const float *__restrict
     const int per = (n_slots + gridDim.z - 1) / gridDim.z;
     const int lo = blockIdx.z * per, hi = min(n_slots, lo + per);
     const float *src = partials + (int64_t)blockIdx.y * n_slots * 4096 + e;
+    const int tile = e >> 8, ln = (e >> 2) & 63, r = e & 3;
+    const int a = tile >> 2, b = tile & 3;
+    // accumulator layout: row = 4*(ln>>4) + r (output neuron), col = ln & 15 (input neuron)
+    const int row = 16 * (mt0 + a) + 4 * (ln >> 4) + r, col = 16 * (nt0 + b) + (ln & 15);
+    const bool inside = row < N && col < K;  // tiles outside the layer are never written by the fused backward
     float v = 0.f;
-    int sl = lo;
+    int sl = inside ? lo : hi;
     for (; sl + 8 <= hi; sl += 8) {
         float t[8];
 #pragma unroll
@@ -432,11 +600,7 @@ mlp_dw_reduce_kernel(const float *__restrict__ partials, const float *__restrict
         for (int u = 0; u < 8; ++u) v += t[u];
     }
     for (; sl < hi; ++sl) v += src[(int64_t)sl * 4096];
-    const int tile = e >> 8, ln = (e >> 2) & 63, r = e & 3;
-    const int a = tile >> 2, b = tile & 3;
-    // accumulator layout: row = 4*(ln>>4) + r (output neuron), col = ln & 15 (input neuron)
-    const int row = 16 * (mt0 + a) + 4 * (ln >> 4) + r, col = 16 * (nt0 + b) + (ln & 15);
-    if (row < N && col < K && v != 0.f) unsafeAtomicAdd(&dweights[P.w_off[l] + (int64_t)row * K + col], v);
+    if (inside && v != 0.f) unsafeAtomicAdd(&dweights[P.w_off[l] + (int64_t)row * K + col], v);
     if (P.has_bias && dbiases && bias_partials && nt0 == 0 && blockIdx.x == 0 && threadIdx.x < 64) {
         const float *bs = bias_partials + (int64_t)blockIdx.y * n_slots * 64 + threadIdx.x;
         float bv = 0.f;
@@ -570,6 +734,42 @@ ARCN_EXPORT int arcn_mlp_bwd(const float *x, const float *weights, const float *
     const size_t lds_bytes = sizeof(float) * (size_t)lds_floats;
     if (lds_bytes > 144 * 1024) return einval("mlp_bwd: network too large for the LDS-resident fused kernel");
     static const int bwd_nt = getenv("ARCN_MLP_BWD_NT") ? atoi(getenv("ARCN_MLP_BWD_NT")) : 2;
+    static const int fused_ok = getenv("ARCN_MLP_FUSED_BWD") ? atoi(getenv("ARCN_MLP_FUSED_BWD")) : 1;
+    if (dweights && fused_ok && !P.has_bias && (P.n_layers == 2 || P.n_layers == 3) && md <= 64) {
+        // fused dx + dW for the tile shapes of the NGP nets; anything else takes the two-kernel path below
+        const int t0 = tiles16(P.dims[0]), t1 = tiles16(P.dims[1]), t2 = tiles16(P.dims[2]);
+        const int t3 = P.n_layers == 3 ? tiles16(P.dims[3]) : 0;
+        const int sig = t0 * 1000 + t1 * 100 + t2 * 10 + t3;
+        if (sig == 2410 || sig == 2441 || sig == 4410 || sig == 4441) {
+            const size_t fused_lds = lds_bytes + sizeof(float) * 8192;  // + one 8 KiB transposition area per wave
+            int64_t grid = tile_grid(n, 64);
+            if (grid > dw_slabs(n_cap)) grid = dw_slabs(n_cap);
+            float *partials = scratch + arcn_mlp_dpre_floats(desc_host, n_cap);
+            DwParams D;
+            D.n_layers = P.n_layers;
+            D.has_bias = 0;
+            for (int l = 0; l <= P.n_layers; ++l) D.dims[l] = P.dims[l];
+            for (int l = 0; l < P.n_layers; ++l) { D.w_off[l] = P.w_off[l]; D.b_off[l] = P.b_off[l]; D.quad_first[l] = l; }
+            D.quad_first[P.n_layers] = P.n_layers;
+#define ARCN_FUSED(T0, T1, T2, T3, NT)                                                                                          \
+    do {                                                                                                                         \
+        if ((rc = set_lds(mlp_bwd_fused_kernel<T0, T1, T2, T3, NT>, fused_lds))) return rc;                                       \
+        hipLaunchKernelGGL((mlp_bwd_fused_kernel<T0, T1, T2, T3, NT>), dim3((unsigned)grid), dim3(256), fused_lds,               \
+                           as_stream(stream), x, weights, P, out, acts, dout, dx, partials, (int)grid, n_cap, n, n_ptr);          \
+    } while (0)
+            static const int fused_nt3 = getenv("ARCN_MLP_FUSED_NT3") ? atoi(getenv("ARCN_MLP_FUSED_NT3")) : 1;
+            switch (sig) {
+            case 2410: ARCN_FUSED(2, 4, 1, 0, 2); break;
+            case 4410: ARCN_FUSED(4, 4, 1, 0, 2); break;
+            case 2441: if (fused_nt3 == 2) ARCN_FUSED(2, 4, 4, 1, 2); else ARCN_FUSED(2, 4, 4, 1, 1); break;
+            default: ARCN_FUSED(4, 4, 4, 1, 1); break;
+            }
+#undef ARCN_FUSED
+            hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(16, (unsigned)P.n_layers, 8), dim3(256), 0, as_stream(stream), partials,
+                               static_cast<const float *>(nullptr), D, (int)grid, dweights, dbiases);
+            return check_launch("mlp_bwd_fused");
+        }
+    }
     if (md <= 64 && bwd_nt == 2) {
         if ((rc = set_lds(mlp_bwd_dx_kernel<4, 2>, lds_bytes))) return rc;
         hipLaunchKernelGGL((mlp_bwd_dx_kernel<4, 2>), dim3(tile_grid(n, 128)), dim3(256), lds_bytes, as_stream(stream), weights, P,

@@ -37,6 +37,7 @@ struct DenseView {
         return 1e10f;
     }
     __device__ float z(int64_t r, int k) const { return zvals[r * P + k]; }
+    __device__ void zero_dropped(int64_t, float *, float *) const {}  // the host wrapper clears the dropped last column
 };
 
 // Packed (offsets, t) form reproducing the reference's padded dense (R, P_dense) tensors: valid samples first, the
@@ -79,6 +80,15 @@ struct PackedView {
         return d;
     }
     __device__ float z(int64_t r, int k) const { return zvals[sidx(r, k)]; }
+    // without the inf column the last of P_dense samples is the dropped column: no visited column covers its gradient
+    __device__ void zero_dropped(int64_t r, float *d_geo, float *d_radiance) const {
+        const int n = count(r);
+        if (!add_inf_z && n >= P_dense && n > 0) {
+            const int64_t si = (int64_t)offsets[r] + n - 1;
+            d_geo[si] = 0.f;
+            if (d_radiance) { d_radiance[si * 3] = 0.f; d_radiance[si * 3 + 1] = 0.f; d_radiance[si * 3 + 2] = 0.f; }
+        }
+    }
 };
 
 template <typename View>
@@ -166,8 +176,8 @@ composite_fwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict
     }
 }
 
-// d_geo / d_radiance are indexed like sigma / radiance.  Entries no visited column covers must be zeroed by the host
-// wrapper (dense: dropped last column; packed: sample n-1 of the longest rays).
+// d_geo / d_radiance are indexed like sigma / radiance.  Entries no visited column covers are zeroed by the host wrapper
+// (dense: dropped last column) or by the ray's own wave (packed: sample n-1 of the longest rays, View::zero_dropped).
 template <typename View>
 __global__ void __launch_bounds__(256)
 composite_bwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict__ bkg, int64_t bkg_rows, int64_t R,
@@ -182,6 +192,7 @@ composite_bwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict
     const int nc = v.ncol(r);
     const int nchunk = (nc + 63) >> 6;
     bool neg = false;
+    if (lane == 0) v.zero_dropped(r, d_geo, d_radiance);
     // pass 1: transmittance at every chunk start
     float carry = 1.0f;
     for (int c = 0; c < nchunk; ++c) {
@@ -273,21 +284,6 @@ composite_bwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict
             atomicAdd(&d_radiance[si * 3 + 1], virt_w * g1);
             atomicAdd(&d_radiance[si * 3 + 2], virt_w * g2);
         }
-    }
-}
-
-// zero d_sigma/d_radiance of the last sample of rays whose last sample is the dropped column (n == P_dense, no inf z)
-__global__ void packed_zero_dropped_kernel(const int32_t *offsets, int p_dense, const int32_t *p_dense_ptr, int64_t R,
-                                           float *d_sigma, float *d_radiance) {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    int pd = p_dense_ptr ? *p_dense_ptr : p_dense;
-    if (pd < 2) pd = 2;
-    int n = offsets[r + 1] - offsets[r];
-    if (n >= pd && n > 0) {
-        int64_t si = (int64_t)offsets[r] + n - 1;
-        d_sigma[si] = 0.f;
-        if (d_radiance) { d_radiance[si * 3] = 0.f; d_radiance[si * 3 + 1] = 0.f; d_radiance[si * 3 + 2] = 0.f; }
     }
 }
 
@@ -428,10 +424,6 @@ ARCN_EXPORT int arcn_composite_packed_bwd(const float *sigma, const float *radia
     if (R <= 0) return ARCN_OK;
     if (!sigma || !t_packed || !offsets || !d_sigma) return einval("composite_packed_bwd: missing argument");
     if (p_dense < 2) p_dense = 2;
-    if (!add_inf_z) {
-        hipLaunchKernelGGL(packed_zero_dropped_kernel, dim3((unsigned)ceil_div<int64_t>(R, 256)), dim3(256), 0,
-                           as_stream(stream), offsets, p_dense, p_dense_ptr, R, d_sigma, d_radiance);
-    }
     PackedView v{sigma, nullptr, radiance, t_packed, noise, offsets, p_dense, add_inf_z ? p_dense : p_dense - 1, add_inf_z};
     dim3 grid((unsigned)ceil_div<int64_t>(R, kRaysPerBlock));
     hipLaunchKernelGGL(composite_bwd_kernel<PackedView>, grid, dim3(256), 0, as_stream(stream), v, p_dense_ptr, bkg,

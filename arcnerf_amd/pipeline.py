@@ -218,8 +218,7 @@ class NgpPipeline:
         b['d_rad_in'] = torch.zeros((S, field.rad_dims[0]), dtype=f32, device=dev)
         b['d_geo_out'] = torch.zeros((S, field.geo_out_dim), dtype=f32, device=dev)
         b['d_feat'] = torch.zeros((S, E), dtype=f32, device=dev)
-        # separate backward scratch per network: the radiance dW kernel (aux stream) reads its dpre tensors while the
-        # geometry dX chain (main stream) is already writing its own
+        # backward scratch per network: per-workgroup dW partials (and dpre when the two-kernel backward runs)
         b['geo_scratch'] = torch.zeros(F.mlp_scratch_floats(field.geo_desc, S), dtype=f32, device=dev)
         b['rad_scratch'] = torch.zeros(F.mlp_scratch_floats(field.rad_desc, S), dtype=f32, device=dev)
         # per-ray outputs
@@ -380,37 +379,21 @@ class NgpPipeline:
                                             int(cfg.add_inf_z), int(cfg.white_bkg), N.ptr(d_rgb), N.ptr(d_depth), N.ptr(d_mask),
                                             N.ptr(b['d_sigma']), N.ptr(b['d_rgb_s']), st), 'composite_packed_bwd')
         S = self.cap
-        aux = self.aux_stream if self.use_streams else None
-        main = torch.cuda.current_stream() if aux is not None else None
-
-        def dw_async(x, desc, acts, scratch, name):
-            """dW/db of one net on the auxiliary stream (latency-bound, few registers, 16 KiB LDS: co-resides with the
-            LDS-heavy scatter on the main stream)"""
-            if aux is None:
-                N.check(L.arcn_mlp_bwd_dw(N.ptr(x), N.C.addressof(desc), N.ptr(acts), N.ptr(scratch), N.ptr(self._g(name + '_w')),
-                                          N.ptr(self._g(name + '_b')), S, S, n_dev.data_ptr(), st), 'mlp_bwd_dw')
-                return
-            aux.wait_stream(main)
-            with torch.cuda.stream(aux):
-                N.check(L.arcn_mlp_bwd_dw(N.ptr(x), N.C.addressof(desc), N.ptr(acts), N.ptr(scratch), N.ptr(self._g(name + '_w')),
-                                          N.ptr(self._g(name + '_b')), S, S, n_dev.data_ptr(), N.stream()), 'mlp_bwd_dw')
-
+        # dx and dW of each net come out of ONE fused kernel (arcn_mlp_bwd with dweights): dpre never leaves the registers
         N.check(L.arcn_mlp_bwd(N.ptr(b['rad_in']), N.ptr(self._p('rad_w')), N.ptr(self._p('rad_b')), N.C.addressof(fld.rad_desc),
                                N.ptr(b['rgb_s']), N.ptr(b['rad_acts']), N.ptr(b['d_rgb_s']), N.ptr(b['d_rad_in']),
-                               None, None, N.ptr(b['rad_scratch']), S, S, n_dev.data_ptr(), st), 'mlp_bwd(rad)')
-        dw_async(b['rad_in'], fld.rad_desc, b['rad_acts'], b['rad_scratch'], 'rad')
+                               N.ptr(self._g('rad_w')), N.ptr(self._g('rad_b')), N.ptr(b['rad_scratch']), S, S, n_dev.data_ptr(), st),
+                'mlp_bwd(rad)')
         F.ngp_glue_bwd(b['geo_out'], b['d_rad_in'], b['d_sigma'], fld.feat_off, cfg.W_feat, cfg.sh_degree,
                        feat_first=(cfg.rad_mode == 'fv'), sigma_act=cfg.sigma_act, n_dev=n_dev, d_geo_out=b['d_geo_out'])
         N.check(L.arcn_mlp_bwd(N.ptr(b['feat']), N.ptr(self._p('geo_w')), N.ptr(self._p('geo_b')), N.C.addressof(fld.geo_desc),
                                N.ptr(b['geo_out']), N.ptr(b['geo_acts']), N.ptr(b['d_geo_out']), N.ptr(b['d_feat']),
-                               None, None, N.ptr(b['geo_scratch']), S, S, n_dev.data_ptr(), st), 'mlp_bwd(geo)')
-        dw_async(b['feat'], fld.geo_desc, b['geo_acts'], b['geo_scratch'], 'geo')
+                               N.ptr(self._g('geo_w')), N.ptr(self._g('geo_b')), N.ptr(b['geo_scratch']), S, S, n_dev.data_ptr(), st),
+                'mlp_bwd(geo)')
         N.check(L.arcn_hashgrid_bwd(N.ptr(b['xyz']), N.ptr(self._p('table')), N.ptr(b['d_feat']), N.C.addressof(fld.grid_desc),
                                     N.ptr(self._g('table')), None, N.ptr(self.hash_ws),
                                     0 if self.hash_ws is None else self.hash_ws.numel(), S, n_dev.data_ptr(), st),
                 'hashgrid_bwd')
-        if aux is not None:
-            main.wait_stream(aux)  # join: the optimiser (or the caller) needs every gradient
 
     def huber_grad(self, rgb, target):
         """ImgLoss(Huber, delta, weight) of arcnerf/loss/img_loss.py:60-100: loss value and d loss / d rgb (mean over R*3)."""

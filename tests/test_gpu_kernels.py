@@ -434,7 +434,9 @@ def test_fused_mlp_vs_reference_golden(F, bias):
 
 @pytest.mark.parametrize('dims,act_out,bias,S', [([32, 64, 16], None, False, 5000), ([32, 64, 64, 3], 'sigmoid', False, 70001),
                                                  ([27, 48, 5], 'sigmoid', True, 333), ([63, 128, 128, 17], None, True, 1000),
-                                                 ([16, 16], 'relu', False, 64)])
+                                                 ([16, 16], 'relu', False, 64),
+                                                 # the other tile shapes of the fused dx + dW backward (64-wide input)
+                                                 ([64, 64, 16], None, False, 4097), ([50, 64, 64, 16], 'sigmoid', False, 3000)])
 def test_fused_mlp_shapes_vs_oracle(F, oracle, dims, act_out, bias, S):
     from arcnerf_amd import _native as N
     rng = np.random.default_rng(sum(dims))
