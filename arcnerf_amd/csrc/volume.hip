@@ -274,11 +274,19 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
         bool have_pending = false;      // a skip target carried over from the previous chunk
         float pending = 0.f;
         bool done = false;
+        const float dt_lane = lane == 0 ? 0.0f : dt;
         while (!done) {
             if (!(t_base <= fr)) break;  // every later lattice point fails `t <= far_end`
             // 1. lattice: lane l = t_base + dt (l times), sequentially rounded like the reference's t += dt
+            // Systolic: every step each lane takes its left neighbour's value (DPP wave_shr:1, free on the add) and adds dt;
+            // lane 0 has no neighbour, keeps its own value and adds 0.  After k steps lanes 0..k hold the exact sequential
+            // sums and keep reproducing them, so 63 single-instruction steps replace a 63-trip divergent loop.
             float t = t_base;
-            for (int k = 0; k < lane; ++k) t += dt;
+#pragma unroll
+            for (int k = 0; k < 63; ++k) {
+                const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0x138, 0xf, 0xf, false));
+                t = left + dt_lane;
+            }
             const float t_next_base = __shfl(t, 63, 64) + dt;
             // 2. per-point state
             float pos[3];
