@@ -243,6 +243,153 @@ mlp_fwd_kernel(const float *__restrict__ x, const float *__restrict__ weights, c
     }
 }
 
+// ---- forward, specialised on the tile shape ---------------------------------------------------------------------------------
+// PMC on the generic kernel above: ~10 VALU instructions per MFMA (run-time layer loop, per-tile width guards, a per-element
+// activation switch, 64-bit address arithmetic per 16-byte access).  With the number of 16-wide tiles of every layer boundary
+// as template parameters the layer loop and every guard resolve at compile time; the widths themselves stay run-time, a
+// ragged last tile (the 3-wide RGB output) takes the element-wise path.  Bias-free nets of 2 or 3 layers, widths <= 64.
+template <int TT, int NT>
+__device__ __forceinline__ void load_tiles_fast(f4 (&v)[4][NT], const float *__restrict__ src, int width, int64_t s0, int64_t cnt,
+                                                int g, int j) {
+    const bool full = width == 16 * TT;  // wave uniform
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int64_t s = s0 + 16 * nt + j;
+        const bool ok = s < cnt;
+        const float *p = src + s * width + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f4 r = {0.f, 0.f, 0.f, 0.f};
+            if (t < TT && ok) {
+                if (full) r = *reinterpret_cast<const f4 *>(p + 16 * t);
+                else {
+                    const int col = 16 * t + 4 * g;
+                    if (col < width) r.x = p[16 * t];
+                    if (col + 1 < width) r.y = p[16 * t + 1];
+                    if (col + 2 < width) r.z = p[16 * t + 2];
+                    if (col + 3 < width) r.w = p[16 * t + 3];
+                }
+            }
+            v[t][nt] = r;
+        }
+    }
+}
+
+template <int TT, int NT>
+__device__ __forceinline__ void store_tiles_fast(const f4 (&v)[4][NT], float *__restrict__ dst, int width, int64_t s0, int64_t cnt,
+                                                 int g, int j) {
+    const bool full = width == 16 * TT;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int64_t s = s0 + 16 * nt + j;
+        if (s >= cnt) continue;
+        float *p = dst + s * width + 4 * g;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const f4 r = v[t][nt];
+            if (full) *reinterpret_cast<f4 *>(p + 16 * t) = r;
+            else {
+                const int col = 16 * t + 4 * g;
+                if (col < width) p[16 * t] = r.x;
+                if (col + 1 < width) p[16 * t + 1] = r.y;
+                if (col + 2 < width) p[16 * t + 2] = r.z;
+                if (col + 3 < width) p[16 * t + 3] = r.w;
+            }
+        }
+    }
+}
+
+// activation of MT tiles, the switch hoisted out of the element loop
+template <int MT, int NT>
+__device__ __forceinline__ void act_tiles(f4 (&h)[4][NT], int act, float beta) {
+    if (act == ARCN_ACT_NONE) return;
+    if (act == ARCN_ACT_RELU) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                h[mt][nt].x = fmaxf(h[mt][nt].x, 0.f);
+                h[mt][nt].y = fmaxf(h[mt][nt].y, 0.f);
+                h[mt][nt].z = fmaxf(h[mt][nt].z, 0.f);
+                h[mt][nt].w = fmaxf(h[mt][nt].w, 0.f);
+            }
+        return;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            h[mt][nt].x = act_fwd(h[mt][nt].x, act, beta);
+            h[mt][nt].y = act_fwd(h[mt][nt].y, act, beta);
+            h[mt][nt].z = act_fwd(h[mt][nt].z, act, beta);
+            h[mt][nt].w = act_fwd(h[mt][nt].w, act, beta);
+        }
+}
+
+// padded rows of a ragged hidden layer must feed zeros to the next layer even when act(0) != 0
+template <int MT, int NT>
+__device__ __forceinline__ void zero_padded_rows(f4 (&h)[4][NT], int N, int g) {
+    if (N == 16 * MT) return;
+    const int row = 16 * (MT - 1) + 4 * g;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (row >= N) h[MT - 1][nt].x = 0.f;
+        if (row + 1 >= N) h[MT - 1][nt].y = 0.f;
+        if (row + 2 >= N) h[MT - 1][nt].z = 0.f;
+        if (row + 3 >= N) h[MT - 1][nt].w = 0.f;
+    }
+}
+
+template <int T0, int T1, int T2, int T3, int NT>
+__global__ void __launch_bounds__(256)
+mlp_fwd_fixed_kernel(const float *__restrict__ x, const float *__restrict__ weights, MlpParams P, float *__restrict__ out,
+                     float *__restrict__ acts, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
+    constexpr int NL = T3 ? 3 : 2;
+    constexpr int TA = T3 ? T3 : 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int l = 0; l < NL; ++l) stage_fragments<false>(lds + P.lds_off[l], weights + P.w_off[l], P.dims[l + 1], P.dims[l]);
+    __syncthreads();
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+    constexpr int SPW = 16 * NT;
+    const int64_t n_tiles = ceil_div_dev(cnt, (int64_t)SPW * 4);
+    const float *w0 = lds + P.lds_off[0], *w1 = lds + P.lds_off[1], *w2 = lds + P.lds_off[NL - 1];
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t s0 = tile * SPW * 4 + (int64_t)wave * SPW;
+        if (s0 >= cnt) continue;
+        f4 h[4][NT], o[4][NT];
+        load_tiles_fast<T0, NT>(h, x, P.dims[0], s0, cnt, g, j);
+        auto zero = [&](f4 (&a)[4][NT]) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) a[mt][nt] = f4{0.f, 0.f, 0.f, 0.f};
+        };
+        // layer 0: T0 -> T1 tiles
+        zero(o);
+        gemm_tiles<4, NT>(o, h, w0, T1, T0, lane);
+        act_tiles<T1, NT>(o, P.act_hidden, P.beta);
+        if (acts) store_tiles_fast<T1, NT>(o, acts, P.dims[1], s0, cnt, g, j);
+        zero_padded_rows<T1, NT>(o, P.dims[1], g);
+        // layer 1: T1 -> T2 tiles
+        zero(h);
+        gemm_tiles<4, NT>(h, o, w1, T2, T1, lane);
+        if (NL == 2) {
+            act_tiles<T2, NT>(h, P.act_out, P.beta);
+            store_tiles_fast<T2, NT>(h, out, P.dims[2], s0, cnt, g, j);
+        } else {
+            act_tiles<T2, NT>(h, P.act_hidden, P.beta);
+            if (acts) store_tiles_fast<T2, NT>(h, acts + n_cap * P.dims[1], P.dims[2], s0, cnt, g, j);
+            zero_padded_rows<T2, NT>(h, P.dims[2], g);
+            // layer 2: T2 -> T3 tiles
+            zero(o);
+            gemm_tiles<4, NT>(o, h, w2, TA, T2, lane);
+            act_tiles<TA, NT>(o, P.act_out, P.beta);
+            store_tiles_fast<TA, NT>(o, out, P.dims[3], s0, cnt, g, j);
+        }
+    }
+}
+
 // ---- backward, part 1: dpre_l for every layer (stored to scratch) and dx ----------------------------------
 template <int WT, int NT>
 __global__ void __launch_bounds__(256)
@@ -377,9 +524,23 @@ mlp_bwd_fused_kernel(const float *__restrict__ x, const float *__restrict__ weig
             }
         }
     };
-    auto apply_act_grad = [&](f4 (&d)[WT][NT], const f4 (&y)[WT][NT], int act) {
+    // d *= act'(y) on the first `mt_c` tiles; the activation switch is hoisted out of the element loop
+    auto apply_act_grad = [&](f4 (&d)[WT][NT], const f4 (&y)[WT][NT], int act, auto mt_c) {
+        constexpr int MT = decltype(mt_c)::value;
+        if (act == ARCN_ACT_RELU) {
 #pragma unroll
-        for (int mt = 0; mt < WT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    d[mt][nt].x = y[mt][nt].x > 0.f ? d[mt][nt].x : 0.f;
+                    d[mt][nt].y = y[mt][nt].y > 0.f ? d[mt][nt].y : 0.f;
+                    d[mt][nt].z = y[mt][nt].z > 0.f ? d[mt][nt].z : 0.f;
+                    d[mt][nt].w = y[mt][nt].w > 0.f ? d[mt][nt].w : 0.f;
+                }
+            return;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 d[mt][nt].x *= act_grad_from_y(y[mt][nt].x, act, P.beta);
@@ -405,26 +566,27 @@ mlp_bwd_fused_kernel(const float *__restrict__ x, const float *__restrict__ weig
         const int64_t s0 = tile * SPW * 4 + (int64_t)wave * SPW;
         if (s0 >= cnt) continue;
         f4 d[WT][NT], y[WT][NT], yp[WT][NT];
-        load_tiles<WT, NT>(d, dout, P.dims[NL], s0, cnt, g, j);
+        constexpr int TL = T3 ? T3 : T2;  // tiles of the network output
+        load_tiles_fast<TL, NT>(d, dout, P.dims[NL], s0, cnt, g, j);
         if (P.act_out != ARCN_ACT_NONE) {
-            load_tiles<WT, NT>(y, out, P.dims[NL], s0, cnt, g, j);
-            apply_act_grad(d, y, P.act_out);
+            load_tiles_fast<TL, NT>(y, out, P.dims[NL], s0, cnt, g, j);
+            apply_act_grad(d, y, P.act_out, std::integral_constant<int, TL>{});
         }
         if (NL == 3) {
-            load_tiles<WT, NT>(yp, acts + a2_off, P.dims[2], s0, cnt, g, j);
+            load_tiles_fast<T2, NT>(yp, acts + a2_off, P.dims[2], s0, cnt, g, j);
             accumulate(acc2, d, yp, std::integral_constant<int, TA>{}, std::integral_constant<int, T2>{});
             back(d, 2, T2, TA);
-            if (P.act_hidden != ARCN_ACT_NONE) apply_act_grad(d, yp, P.act_hidden);
+            if (P.act_hidden != ARCN_ACT_NONE) apply_act_grad(d, yp, P.act_hidden, std::integral_constant<int, T2>{});
         }
-        load_tiles<WT, NT>(yp, acts + a1_off, P.dims[1], s0, cnt, g, j);
+        load_tiles_fast<T1, NT>(yp, acts + a1_off, P.dims[1], s0, cnt, g, j);
         accumulate(acc1, d, yp, std::integral_constant<int, T2>{}, std::integral_constant<int, T1>{});
         back(d, 1, T1, T2);
-        if (P.act_hidden != ARCN_ACT_NONE) apply_act_grad(d, yp, P.act_hidden);
-        load_tiles<WT, NT>(yp, x, P.dims[0], s0, cnt, g, j);
+        if (P.act_hidden != ARCN_ACT_NONE) apply_act_grad(d, yp, P.act_hidden, std::integral_constant<int, T1>{});
+        load_tiles_fast<T0, NT>(yp, x, P.dims[0], s0, cnt, g, j);
         accumulate(acc0, d, yp, std::integral_constant<int, T1>{}, std::integral_constant<int, T0>{});
         if (dx) {
             back(d, 0, T0, T1);
-            store_tiles<WT, NT>(d, dx, P.dims[0], s0, cnt, g, j);
+            store_tiles_fast<T0, NT>(d, dx, P.dims[0], s0, cnt, g, j);
         }
     }
     // sum the 4 waves through LDS (the transposition tiles are free now: 4 x 2048 floats >= 16 tiles of 256) and write the
@@ -704,6 +866,26 @@ ARCN_EXPORT int arcn_mlp_fwd(const float *x, const float *weights, const float *
     const size_t lds_bytes = sizeof(float) * (size_t)lds_floats;
     if (lds_bytes > 144 * 1024) return einval("mlp_fwd: network too large for the LDS-resident fused kernel");
     static const int fwd_nt = getenv("ARCN_MLP_NT") ? atoi(getenv("ARCN_MLP_NT")) : 2;  // 4 waves/SIMD beat 2 with wider tiles
+    static const int fixed_ok = getenv("ARCN_MLP_FIXED_FWD") ? atoi(getenv("ARCN_MLP_FIXED_FWD")) : 1;
+    if (fixed_ok && !P.has_bias && (P.n_layers == 2 || P.n_layers == 3) && md <= 64) {
+        const int sig = tiles16(P.dims[0]) * 1000 + tiles16(P.dims[1]) * 100 + tiles16(P.dims[2]) * 10 +
+                        (P.n_layers == 3 ? tiles16(P.dims[3]) : 0);
+#define ARCN_FIXED(T0, T1, T2, T3)                                                                                               \
+    do {                                                                                                                         \
+        if ((rc = set_lds(mlp_fwd_fixed_kernel<T0, T1, T2, T3, 2>, lds_bytes))) return rc;                                        \
+        hipLaunchKernelGGL((mlp_fwd_fixed_kernel<T0, T1, T2, T3, 2>), dim3(tile_grid(n, 128)), dim3(256), lds_bytes,              \
+                           as_stream(stream), x, weights, P, out, acts, n_cap, n, n_ptr);                                         \
+        return check_launch("mlp_fwd_fixed");                                                                                    \
+    } while (0)
+        switch (sig) {
+        case 2410: ARCN_FIXED(2, 4, 1, 0);
+        case 4410: ARCN_FIXED(4, 4, 1, 0);
+        case 2441: ARCN_FIXED(2, 4, 4, 1);
+        case 4441: ARCN_FIXED(4, 4, 4, 1);
+        default: break;
+        }
+#undef ARCN_FIXED
+    }
     if (md <= 64 && fwd_nt == 2) {
         if ((rc = set_lds(mlp_fwd_kernel<4, 2>, lds_bytes))) return rc;
         hipLaunchKernelGGL((mlp_fwd_kernel<4, 2>), dim3(tile_grid(n, 128)), dim3(256), lds_bytes, as_stream(stream), x, weights,
