@@ -187,6 +187,69 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(const float *__restri
     }
 }
 
+// ---- forward, XCD-affine ---------------------------------------------------------------------------------------------------
+// MI355X: 8 XCDs, each with a private 4 MiB L2; one fine level of the table is exactly 4 MiB.  The kernel above lets every
+// XCD touch all 16 levels (48.8 MB), so fine-level gathers miss L2 and are served by the Infinity Cache.  Here a workgroup
+// handles ONE level for 256 consecutive samples and the level is chosen from the workgroup's position in the dispatch order
+// (workgroup b runs on XCD b % 8 - observed, used for speed only, any placement is correct): XCD x works through level x for
+// all its tiles, then level L-1-x, so at any time an XCD's L2 mostly holds a single level.
+// LM: level-major output out[(l * n_cap + s) * F + f] (coalesced stores); otherwise the usual row-major (n, L*F).
+struct LmPlan {
+    int32_t levels[8][4];   // up to 4 levels per XCD slot (-1 = none)
+    int32_t tiles;          // 256-sample tiles (from the capacity)
+};
+
+template <int F, bool LM>
+__global__ void __launch_bounds__(256)
+hashgrid_fwd_xcd_kernel(const float *__restrict__ xyz, const float *__restrict__ table, GridParams g, LmPlan plan,
+                        float *__restrict__ out, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int xcd = blockIdx.x & 7;
+    const int j = blockIdx.x >> 3;  // position inside this XCD's queue
+    const int li = j / plan.tiles, tile = j - li * plan.tiles;
+    const int l = plan.levels[xcd][li];
+    if (l < 0) return;
+    const int64_t s = (int64_t)tile * 256 + threadIdx.x;
+    if (s >= cnt) return;
+    const LevelParams lp = g.lv[l];
+    const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
+    const Cell cell = locate(p, g, lp.res);
+    float acc[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.f;
+    if (cell.valid) {
+        uint32_t rows[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rows[q] = hash_row(cell.c[0] + ((q >> 1) & 1), cell.c[1] + (q & 1), cell.c[2] + (q >> 2), lp);
+        float vals[8][F];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float *src = table + ((int64_t)rows[q] + lp.offset) * F;
+            if (F == 2) {
+                float2 t2 = *reinterpret_cast<const float2 *>(src);
+                vals[q][0] = t2.x;
+                vals[q][1 % F] = t2.y;
+            } else {
+#pragma unroll
+                for (int f = 0; f < F; ++f) vals[q][f] = src[f];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
+            const float wt = ((ox ? cell.w[0] : 1.0f - cell.w[0]) * (oy ? cell.w[1] : 1.0f - cell.w[1])) * (oz ? cell.w[2] : 1.0f - cell.w[2]);
+#pragma unroll
+            for (int f = 0; f < F; ++f) { float a = vals[q][f] * wt; acc[f] = acc[f] + a; }
+        }
+    }
+    float *o = LM ? out + ((int64_t)l * n_cap + s) * F : out + (s * g.L + l) * F;
+    if (F == 2) *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1 % F]);
+    else {
+#pragma unroll
+        for (int f = 0; f < F; ++f) o[f] = acc[f];
+    }
+}
+
 // ---- backward, binned owner-computes scatter --------------------------------------------------------------------------------
 // Measured on MI355X: the chip retires only ~18-21 G scattered fp32 global atomics per second (they are served at the memory
 // side, not in the issuing XCD's L2), so the 128 atomics/sample of the plain kernel above cost 4 ms per 2^18 samples no
@@ -263,8 +326,8 @@ __device__ __forceinline__ void emit_record(uint4 *__restrict__ lrecs, float *__
 // exactly that chain (212 us against 140 us).
 template <int F>
 __global__ void __launch_bounds__(kBinThreads)
-scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout, GridParams g, BinPlan plan,
-                   uint32_t *__restrict__ counters, uint4 *__restrict__ recs, float *__restrict__ dtable, int64_t n,
+scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout, int64_t dout_lm_stride, GridParams g,
+                   BinPlan plan, uint32_t *__restrict__ counters, uint4 *__restrict__ recs, float *__restrict__ dtable, int64_t n,
                    const int32_t *n_ptr) {
     __shared__ uint32_t hist[kMaxChunks];   // records of this tile per bin
     __shared__ uint32_t gbase[kMaxChunks];  // first position of the tile's run in every bin
@@ -292,8 +355,10 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
         const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
         cell = locate(p, g, lp.res);
         if (cell.valid) {
-            g0 = dout[(s * g.L + l) * F];
-            g1 = F > 1 ? dout[(s * g.L + l) * F + (F > 1 ? 1 : 0)] : 0.f;
+            // level-major gradients (dout_lm_stride > 0): the lanes of a wave read consecutive 8-byte words
+            const float *gp = dout_lm_stride ? dout + ((int64_t)l * dout_lm_stride + s) * F : dout + (s * g.L + l) * F;
+            g0 = gp[0];
+            g1 = F > 1 ? gp[F > 1 ? 1 : 0] : 0.f;
         }
     }
     // runs of consecutive samples (lanes) in the same cell: head lanes, and for every lane the last lane of its run
@@ -657,9 +722,9 @@ ARCN_EXPORT int arcn_hashgrid_fwd(const float *xyz, const float *table, const ar
 
 ARCN_EXPORT int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc *desc_host, int64_t n);
 
-ARCN_EXPORT int arcn_hashgrid_bwd(const float *xyz, const float *table, const float *dout,
-                                  const arcn_hashgrid_desc *desc_host, float *dtable, float *dxyz, float *workspace,
-                                  int64_t workspace_floats, int64_t n, const int32_t *n_ptr, void *stream) {
+static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *dout, int64_t dout_lm_stride,
+                             const arcn_hashgrid_desc *desc_host, float *dtable, float *dxyz, float *workspace,
+                             int64_t workspace_floats, int64_t n, const int32_t *n_ptr, void *stream) {
     if (n <= 0) return ARCN_OK;
     if (!xyz || !dout || (!dtable && !dxyz) || (dxyz && !table)) return einval("hashgrid_bwd: missing argument");
     GridParams g;
@@ -684,14 +749,15 @@ ARCN_EXPORT int arcn_hashgrid_bwd(const float *xyz, const float *table, const fl
         dim3 bgrid((unsigned)ceil_div<int64_t>(n, kBinThreads), (unsigned)g.L);
         dim3 agrid((unsigned)plan.item_first[g.L]);
         if (g.F == 1) {
-            hipLaunchKernelGGL(scatter_bin_kernel<1>, bgrid, dim3(kBinThreads), 0, as_stream(stream), xyz, dout, g, plan, counters, recs, dtable, n, n_ptr);
+            hipLaunchKernelGGL(scatter_bin_kernel<1>, bgrid, dim3(kBinThreads), 0, as_stream(stream), xyz, dout, dout_lm_stride, g, plan, counters, recs, dtable, n, n_ptr);
             hipLaunchKernelGGL(scatter_accum_kernel<1>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable);
         } else {
-            hipLaunchKernelGGL(scatter_bin_kernel<2>, bgrid, dim3(kBinThreads), 0, as_stream(stream), xyz, dout, g, plan, counters, recs, dtable, n, n_ptr);
+            hipLaunchKernelGGL(scatter_bin_kernel<2>, bgrid, dim3(kBinThreads), 0, as_stream(stream), xyz, dout, dout_lm_stride, g, plan, counters, recs, dtable, n, n_ptr);
             hipLaunchKernelGGL(scatter_accum_kernel<2>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable);
         }
         return check_launch("hashgrid_bwd_binned");
     }
+    if (dout_lm_stride) return einval("hashgrid_bwd_lm: needs a workspace, dtable only, n_feat 1 or 2");
     dim3 grid((unsigned)ceil_div<int64_t>(n * g.L, 256));
     switch (g.F) {
     case 1: hipLaunchKernelGGL(hashgrid_bwd_kernel<1>, grid, dim3(256), 0, as_stream(stream), xyz, table, dout, g, dtable, dxyz, n, n_ptr); break;
@@ -699,6 +765,20 @@ ARCN_EXPORT int arcn_hashgrid_bwd(const float *xyz, const float *table, const fl
     default: hipLaunchKernelGGL(hashgrid_bwd_kernel<4>, grid, dim3(256), 0, as_stream(stream), xyz, table, dout, g, dtable, dxyz, n, n_ptr); break;
     }
     return check_launch("hashgrid_bwd");
+}
+
+ARCN_EXPORT int arcn_hashgrid_bwd(const float *xyz, const float *table, const float *dout, const arcn_hashgrid_desc *desc_host,
+                                  float *dtable, float *dxyz, float *workspace, int64_t workspace_floats, int64_t n,
+                                  const int32_t *n_ptr, void *stream) {
+    return hashgrid_bwd_impl(xyz, table, dout, 0, desc_host, dtable, dxyz, workspace, workspace_floats, n, n_ptr, stream);
+}
+
+ARCN_EXPORT int arcn_hashgrid_bwd_lm(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host,
+                                     float *dtable, float *workspace, int64_t workspace_floats, int64_t n, const int32_t *n_ptr,
+                                     void *stream) {
+    if (dout_stride < n) return einval("hashgrid_bwd_lm: level stride smaller than n");
+    if (!workspace) return einval("hashgrid_bwd_lm: workspace required");
+    return hashgrid_bwd_impl(xyz, nullptr, dout_lm, dout_stride, desc_host, dtable, nullptr, workspace, workspace_floats, n, n_ptr, stream);
 }
 
 ARCN_EXPORT int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc *desc_host, int64_t n) {
@@ -709,4 +789,35 @@ ARCN_EXPORT int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc 
     BinPlan plan;
     if (build_bin_plan(g, n, plan)) return 0;
     return bin_counter_floats(plan) + plan.n_recs * 4;  // bin counters + 16-byte records
+}
+
+// XCD-affine forward (n_feat 1 or 2).  level_major = 0: out (n, L*F) row-major like arcn_hashgrid_fwd;
+// level_major = 1: out[(l * n_cap + s) * F + f].
+ARCN_EXPORT int arcn_hashgrid_fwd_xcd(const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out,
+                                      int level_major, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!xyz || !table || !out || n_cap < n) return einval("hashgrid_fwd_xcd: missing/invalid argument");
+    GridParams g;
+    int rc = build_params(desc_host, g);
+    if (rc) return rc;
+    if (g.F > 2) return einval("hashgrid_fwd_xcd: n_feat 1 or 2");
+    LmPlan plan;
+    for (int x = 0; x < 8; ++x) for (int k = 0; k < 4; ++k) plan.levels[x][k] = -1;
+    int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // pair a coarse (cache friendly) level with a fine one on every XCD: slot = min(l, L-1-l) mod 8
+    for (int l = 0; l < g.L; ++l) {
+        const int m = l < g.L - 1 - l ? l : g.L - 1 - l;
+        const int x = m & 7;
+        if (fill[x] >= 4) return einval("hashgrid_fwd_xcd: too many levels");
+        plan.levels[x][fill[x]++] = l;
+    }
+    int per = 0;
+    for (int x = 0; x < 8; ++x) per = fill[x] > per ? fill[x] : per;
+    plan.tiles = (int)ceil_div<int64_t>(n, 256);
+    dim3 grid((unsigned)(8 * per * plan.tiles));
+#define ARCN_XCD(F_, LM_) hipLaunchKernelGGL((hashgrid_fwd_xcd_kernel<F_, LM_>), grid, dim3(256), 0, as_stream(stream), xyz, table, g, plan, out, n_cap, n, n_ptr)
+    if (g.F == 1) { if (level_major) ARCN_XCD(1, true); else ARCN_XCD(1, false); }
+    else { if (level_major) ARCN_XCD(2, true); else ARCN_XCD(2, false); }
+#undef ARCN_XCD
+    return check_launch("hashgrid_fwd_xcd");
 }

@@ -299,6 +299,46 @@ __device__ __forceinline__ void store_tiles_fast(const f4 (&v)[4][NT], float *__
     }
 }
 
+// Level-major network input (what arcn_hashgrid_fwd_xcd writes, 2 features per level): column c = 2 l + f of sample s lives at
+// x[(l * stride + s) * 2 + f].  A lane's 4 columns 16t+4g.. are levels 8t+2g and 8t+2g+1: two 8-byte accesses, and the 16 lanes
+// of a level read 128 contiguous bytes.
+template <int TT, int NT>
+__device__ __forceinline__ void load_tiles_lm2(f4 (&v)[4][NT], const float *__restrict__ src, int64_t stride, int64_t s0, int64_t cnt,
+                                               int g, int j) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int64_t s = s0 + 16 * nt + j;
+        const bool ok = s < cnt;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f4 r = {0.f, 0.f, 0.f, 0.f};
+            if (t < TT && ok) {
+                const float *p = src + ((int64_t)(8 * t + 2 * g) * stride + s) * 2;
+                const float2 a = *reinterpret_cast<const float2 *>(p);
+                const float2 b = *reinterpret_cast<const float2 *>(p + stride * 2);
+                r = f4{a.x, a.y, b.x, b.y};
+            }
+            v[t][nt] = r;
+        }
+    }
+}
+
+template <int TT, int NT>
+__device__ __forceinline__ void store_tiles_lm2(const f4 (&v)[4][NT], float *__restrict__ dst, int64_t stride, int64_t s0, int64_t cnt,
+                                                int g, int j) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int64_t s = s0 + 16 * nt + j;
+        if (s >= cnt) continue;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            float *p = dst + ((int64_t)(8 * t + 2 * g) * stride + s) * 2;
+            *reinterpret_cast<float2 *>(p) = make_float2(v[t][nt].x, v[t][nt].y);
+            *reinterpret_cast<float2 *>(p + stride * 2) = make_float2(v[t][nt].z, v[t][nt].w);
+        }
+    }
+}
+
 // activation of MT tiles, the switch hoisted out of the element loop
 template <int MT, int NT>
 __device__ __forceinline__ void act_tiles(f4 (&h)[4][NT], int act, float beta) {
@@ -340,10 +380,10 @@ __device__ __forceinline__ void zero_padded_rows(f4 (&h)[4][NT], int N, int g) {
     }
 }
 
-template <int T0, int T1, int T2, int T3, int NT>
+template <int T0, int T1, int T2, int T3, int NT, bool XLM>
 __global__ void __launch_bounds__(256)
-mlp_fwd_fixed_kernel(const float *__restrict__ x, const float *__restrict__ weights, MlpParams P, float *__restrict__ out,
-                     float *__restrict__ acts, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
+mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, const float *__restrict__ weights, MlpParams P,
+                     float *__restrict__ out, float *__restrict__ acts, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
     constexpr int NL = T3 ? 3 : 2;
     constexpr int TA = T3 ? T3 : 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -358,7 +398,8 @@ mlp_fwd_fixed_kernel(const float *__restrict__ x, const float *__restrict__ weig
         const int64_t s0 = tile * SPW * 4 + (int64_t)wave * SPW;
         if (s0 >= cnt) continue;
         f4 h[4][NT], o[4][NT];
-        load_tiles_fast<T0, NT>(h, x, P.dims[0], s0, cnt, g, j);
+        if (XLM) load_tiles_lm2<T0, NT>(h, x, x_stride, s0, cnt, g, j);
+        else load_tiles_fast<T0, NT>(h, x, P.dims[0], s0, cnt, g, j);
         auto zero = [&](f4 (&a)[4][NT]) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
@@ -465,9 +506,9 @@ mlp_bwd_dx_kernel(const float *__restrict__ weights, MlpParams P, const float *_
 // waves are summed through LDS and the workgroup writes ONE partial per layer for mlp_dw_reduce_kernel.
 // T0..T3 = 16-wide tiles per layer boundary (T3 = 0: two layers); the dims themselves stay run-time (ragged widths are zero
 // padded by load_tiles / stage_fragments, so e.g. the 3-wide RGB output uses the T3 = 1 instance).
-template <int T0, int T1, int T2, int T3, int NT>
+template <int T0, int T1, int T2, int T3, int NT, bool XLM>
 __global__ void __launch_bounds__(256, 2)  // 2 workgroups per CU = 2 waves per SIMD: at most 256 VGPR + AGPR per lane
-mlp_bwd_fused_kernel(const float *__restrict__ x, const float *__restrict__ weights, MlpParams P, const float *__restrict__ out,
+mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, const float *__restrict__ weights, MlpParams P, const float *__restrict__ out,
                      const float *__restrict__ acts, const float *__restrict__ dout, float *__restrict__ dx,
                      float *__restrict__ partials, int n_slots, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
     constexpr int NL = T3 ? 3 : 2;
@@ -582,11 +623,13 @@ mlp_bwd_fused_kernel(const float *__restrict__ x, const float *__restrict__ weig
         accumulate(acc1, d, yp, std::integral_constant<int, T2>{}, std::integral_constant<int, T1>{});
         back(d, 1, T1, T2);
         if (P.act_hidden != ARCN_ACT_NONE) apply_act_grad(d, yp, P.act_hidden, std::integral_constant<int, T1>{});
-        load_tiles_fast<T0, NT>(yp, x, P.dims[0], s0, cnt, g, j);
+        if (XLM) load_tiles_lm2<T0, NT>(yp, x, x_stride, s0, cnt, g, j);
+        else load_tiles_fast<T0, NT>(yp, x, P.dims[0], s0, cnt, g, j);
         accumulate(acc0, d, yp, std::integral_constant<int, T1>{}, std::integral_constant<int, T0>{});
         if (dx) {
             back(d, 0, T0, T1);
-            store_tiles_fast<T0, NT>(d, dx, P.dims[0], s0, cnt, g, j);
+            if (XLM) store_tiles_lm2<T0, NT>(d, dx, x_stride, s0, cnt, g, j);  // dx in the layout of x
+            else store_tiles_fast<T0, NT>(d, dx, P.dims[0], s0, cnt, g, j);
         }
     }
     // sum the 4 waves through LDS (the transposition tiles are free now: 4 x 2048 floats >= 16 tiles of 256) and write the
@@ -854,8 +897,9 @@ ARCN_EXPORT int64_t arcn_mlp_scratch_floats(const arcn_mlp_desc *d, int64_t n_ca
     return arcn_mlp_dpre_floats(d, n_cap) + dw_slabs(n_cap) * quads * (4096 + 64);
 }
 
-ARCN_EXPORT int arcn_mlp_fwd(const float *x, const float *weights, const float *biases, const arcn_mlp_desc *desc_host,
-                             float *out, float *acts, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+// x_stride = 0: x is (n, dims[0]) row-major; > 0: level-major, 2 features per level, level stride x_stride samples
+static int mlp_fwd_impl(const float *x, int64_t x_stride, const float *weights, const float *biases, const arcn_mlp_desc *desc_host,
+                        float *out, float *acts, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
     if (n <= 0) return ARCN_OK;
     if (!x || !weights || !out) return einval("mlp_fwd: missing argument");
     MlpParams P;
@@ -867,25 +911,35 @@ ARCN_EXPORT int arcn_mlp_fwd(const float *x, const float *weights, const float *
     if (lds_bytes > 144 * 1024) return einval("mlp_fwd: network too large for the LDS-resident fused kernel");
     static const int fwd_nt = getenv("ARCN_MLP_NT") ? atoi(getenv("ARCN_MLP_NT")) : 2;  // 4 waves/SIMD beat 2 with wider tiles
     static const int fixed_ok = getenv("ARCN_MLP_FIXED_FWD") ? atoi(getenv("ARCN_MLP_FIXED_FWD")) : 1;
-    if (fixed_ok && !P.has_bias && (P.n_layers == 2 || P.n_layers == 3) && md <= 64) {
+    if ((fixed_ok || x_stride) && !P.has_bias && (P.n_layers == 2 || P.n_layers == 3) && md <= 64) {
         const int sig = tiles16(P.dims[0]) * 1000 + tiles16(P.dims[1]) * 100 + tiles16(P.dims[2]) * 10 +
                         (P.n_layers == 3 ? tiles16(P.dims[3]) : 0);
-#define ARCN_FIXED(T0, T1, T2, T3)                                                                                               \
+#define ARCN_FIXED(T0, T1, T2, T3, XLM)                                                                                          \
     do {                                                                                                                         \
-        if ((rc = set_lds(mlp_fwd_fixed_kernel<T0, T1, T2, T3, 2>, lds_bytes))) return rc;                                        \
-        hipLaunchKernelGGL((mlp_fwd_fixed_kernel<T0, T1, T2, T3, 2>), dim3(tile_grid(n, 128)), dim3(256), lds_bytes,              \
-                           as_stream(stream), x, weights, P, out, acts, n_cap, n, n_ptr);                                         \
+        if ((rc = set_lds(mlp_fwd_fixed_kernel<T0, T1, T2, T3, 2, XLM>, lds_bytes))) return rc;                                   \
+        hipLaunchKernelGGL((mlp_fwd_fixed_kernel<T0, T1, T2, T3, 2, XLM>), dim3(tile_grid(n, 128)), dim3(256), lds_bytes,         \
+                           as_stream(stream), x, x_stride, weights, P, out, acts, n_cap, n, n_ptr);                               \
         return check_launch("mlp_fwd_fixed");                                                                                    \
     } while (0)
-        switch (sig) {
-        case 2410: ARCN_FIXED(2, 4, 1, 0);
-        case 4410: ARCN_FIXED(4, 4, 1, 0);
-        case 2441: ARCN_FIXED(2, 4, 4, 1);
-        case 4441: ARCN_FIXED(4, 4, 4, 1);
-        default: break;
+        if (x_stride) {
+            if (P.dims[0] & 15) return einval("mlp_fwd_lm: input width must be a multiple of 16");
+            switch (sig) {
+            case 2410: ARCN_FIXED(2, 4, 1, 0, true);
+            case 4410: ARCN_FIXED(4, 4, 1, 0, true);
+            default: break;
+            }
+        } else {
+            switch (sig) {
+            case 2410: ARCN_FIXED(2, 4, 1, 0, false);
+            case 4410: ARCN_FIXED(4, 4, 1, 0, false);
+            case 2441: ARCN_FIXED(2, 4, 4, 1, false);
+            case 4441: ARCN_FIXED(4, 4, 4, 1, false);
+            default: break;
+            }
         }
 #undef ARCN_FIXED
     }
+    if (x_stride) return einval("mlp_fwd_lm: level-major input is only wired for bias-free 2-layer nets (32|64 -> 64 -> <=16)");
     if (md <= 64 && fwd_nt == 2) {
         if ((rc = set_lds(mlp_fwd_kernel<4, 2>, lds_bytes))) return rc;
         hipLaunchKernelGGL((mlp_fwd_kernel<4, 2>), dim3(tile_grid(n, 128)), dim3(256), lds_bytes, as_stream(stream), x, weights,
@@ -902,9 +956,20 @@ ARCN_EXPORT int arcn_mlp_fwd(const float *x, const float *weights, const float *
     return check_launch("mlp_fwd");
 }
 
-ARCN_EXPORT int arcn_mlp_bwd(const float *x, const float *weights, const float *biases, const arcn_mlp_desc *desc_host,
-                             const float *out, const float *acts, const float *dout, float *dx, float *dweights,
-                             float *dbiases, float *scratch, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+ARCN_EXPORT int arcn_mlp_fwd(const float *x, const float *weights, const float *biases, const arcn_mlp_desc *desc_host,
+                             float *out, float *acts, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+    return mlp_fwd_impl(x, 0, weights, biases, desc_host, out, acts, n_cap, n, n_ptr, stream);
+}
+
+ARCN_EXPORT int arcn_mlp_fwd_lm(const float *x_lm, int64_t x_stride, const float *weights, const arcn_mlp_desc *desc_host,
+                                float *out, float *acts, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+    if (x_stride < n) return einval("mlp_fwd_lm: level stride smaller than n");
+    return mlp_fwd_impl(x_lm, x_stride, weights, nullptr, desc_host, out, acts, n_cap, n, n_ptr, stream);
+}
+
+static int mlp_bwd_impl(const float *x, int64_t x_stride, const float *weights, const float *biases, const arcn_mlp_desc *desc_host,
+                        const float *out, const float *acts, const float *dout, float *dx, float *dweights,
+                        float *dbiases, float *scratch, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
     (void)biases;
     if (n <= 0) return ARCN_OK;
     if (!x || !weights || !out || !dout || !scratch) return einval("mlp_bwd: missing argument");
@@ -917,12 +982,12 @@ ARCN_EXPORT int arcn_mlp_bwd(const float *x, const float *weights, const float *
     if (lds_bytes > 144 * 1024) return einval("mlp_bwd: network too large for the LDS-resident fused kernel");
     static const int bwd_nt = getenv("ARCN_MLP_BWD_NT") ? atoi(getenv("ARCN_MLP_BWD_NT")) : 2;
     static const int fused_ok = getenv("ARCN_MLP_FUSED_BWD") ? atoi(getenv("ARCN_MLP_FUSED_BWD")) : 1;
-    if (dweights && fused_ok && !P.has_bias && (P.n_layers == 2 || P.n_layers == 3) && md <= 64) {
+    if (dweights && (fused_ok || x_stride) && !P.has_bias && (P.n_layers == 2 || P.n_layers == 3) && md <= 64) {
         // fused dx + dW for the tile shapes of the NGP nets; anything else takes the two-kernel path below
         const int t0 = tiles16(P.dims[0]), t1 = tiles16(P.dims[1]), t2 = tiles16(P.dims[2]);
         const int t3 = P.n_layers == 3 ? tiles16(P.dims[3]) : 0;
         const int sig = t0 * 1000 + t1 * 100 + t2 * 10 + t3;
-        if (sig == 2410 || sig == 2441 || sig == 4410 || sig == 4441) {
+        if (x_stride ? (sig == 2410 || sig == 4410) : (sig == 2410 || sig == 2441 || sig == 4410 || sig == 4441)) {
             const size_t fused_lds = lds_bytes + sizeof(float) * 8192;  // + one 8 KiB transposition area per wave
             int64_t grid = tile_grid(n, 64);
             if (grid > dw_slabs(n_cap)) grid = dw_slabs(n_cap);
@@ -933,18 +998,20 @@ ARCN_EXPORT int arcn_mlp_bwd(const float *x, const float *weights, const float *
             for (int l = 0; l <= P.n_layers; ++l) D.dims[l] = P.dims[l];
             for (int l = 0; l < P.n_layers; ++l) { D.w_off[l] = P.w_off[l]; D.b_off[l] = P.b_off[l]; D.quad_first[l] = l; }
             D.quad_first[P.n_layers] = P.n_layers;
-#define ARCN_FUSED(T0, T1, T2, T3, NT)                                                                                          \
+#define ARCN_FUSED(T0, T1, T2, T3, NT, XLM)                                                                                     \
     do {                                                                                                                         \
-        if ((rc = set_lds(mlp_bwd_fused_kernel<T0, T1, T2, T3, NT>, fused_lds))) return rc;                                       \
-        hipLaunchKernelGGL((mlp_bwd_fused_kernel<T0, T1, T2, T3, NT>), dim3((unsigned)grid), dim3(256), fused_lds,               \
-                           as_stream(stream), x, weights, P, out, acts, dout, dx, partials, (int)grid, n_cap, n, n_ptr);          \
+        if ((rc = set_lds(mlp_bwd_fused_kernel<T0, T1, T2, T3, NT, XLM>, fused_lds))) return rc;                                  \
+        hipLaunchKernelGGL((mlp_bwd_fused_kernel<T0, T1, T2, T3, NT, XLM>), dim3((unsigned)grid), dim3(256), fused_lds,          \
+                           as_stream(stream), x, x_stride, weights, P, out, acts, dout, dx, partials, (int)grid, n_cap, n, n_ptr); \
     } while (0)
             static const int fused_nt3 = getenv("ARCN_MLP_FUSED_NT3") ? atoi(getenv("ARCN_MLP_FUSED_NT3")) : 1;
-            switch (sig) {
-            case 2410: ARCN_FUSED(2, 4, 1, 0, 2); break;
-            case 4410: ARCN_FUSED(4, 4, 1, 0, 2); break;
-            case 2441: if (fused_nt3 == 2) ARCN_FUSED(2, 4, 4, 1, 2); else ARCN_FUSED(2, 4, 4, 1, 1); break;
-            default: ARCN_FUSED(4, 4, 4, 1, 1); break;
+            if (x_stride) {
+                if (sig == 2410) ARCN_FUSED(2, 4, 1, 0, 2, true); else ARCN_FUSED(4, 4, 1, 0, 2, true);
+            } else switch (sig) {
+            case 2410: ARCN_FUSED(2, 4, 1, 0, 2, false); break;
+            case 4410: ARCN_FUSED(4, 4, 1, 0, 2, false); break;
+            case 2441: if (fused_nt3 == 2) ARCN_FUSED(2, 4, 4, 1, 2, false); else ARCN_FUSED(2, 4, 4, 1, 1, false); break;
+            default: ARCN_FUSED(4, 4, 4, 1, 1, false); break;
             }
 #undef ARCN_FUSED
             hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(16, (unsigned)P.n_layers, 8), dim3(256), 0, as_stream(stream), partials,
@@ -952,6 +1019,7 @@ ARCN_EXPORT int arcn_mlp_bwd(const float *x, const float *weights, const float *
             return check_launch("mlp_bwd_fused");
         }
     }
+    if (x_stride) return einval("mlp_bwd_lm: level-major input needs dweights and a bias-free 2-layer net (32|64 -> 64 -> <=16)");
     if (md <= 64 && bwd_nt == 2) {
         if ((rc = set_lds(mlp_bwd_dx_kernel<4, 2>, lds_bytes))) return rc;
         hipLaunchKernelGGL((mlp_bwd_dx_kernel<4, 2>), dim3(tile_grid(n, 128)), dim3(256), lds_bytes, as_stream(stream), weights, P,
@@ -968,6 +1036,21 @@ ARCN_EXPORT int arcn_mlp_bwd(const float *x, const float *weights, const float *
     if ((rc = check_launch("mlp_bwd_dx"))) return rc;
     if (dweights) return arcn_mlp_bwd_dw(x, desc_host, acts, scratch, dweights, dbiases, n_cap, n, n_ptr, stream);
     return ARCN_OK;
+}
+
+ARCN_EXPORT int arcn_mlp_bwd(const float *x, const float *weights, const float *biases, const arcn_mlp_desc *desc_host,
+                             const float *out, const float *acts, const float *dout, float *dx, float *dweights,
+                             float *dbiases, float *scratch, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+    return mlp_bwd_impl(x, 0, weights, biases, desc_host, out, acts, dout, dx, dweights, dbiases, scratch, n_cap, n, n_ptr, stream);
+}
+
+ARCN_EXPORT int arcn_mlp_bwd_lm(const float *x_lm, int64_t x_stride, const float *weights, const arcn_mlp_desc *desc_host,
+                                const float *out, const float *acts, const float *dout, float *dx_lm, float *dweights,
+                                float *scratch, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+    if (x_stride < n) return einval("mlp_bwd_lm: level stride smaller than n");
+    if (!dweights) return einval("mlp_bwd_lm: dweights required");
+    return mlp_bwd_impl(x_lm, x_stride, weights, nullptr, desc_host, out, acts, dout, dx_lm, dweights, nullptr, scratch, n_cap, n,
+                        n_ptr, stream);
 }
 
 ARCN_EXPORT int arcn_mlp_bwd_dw(const float *x, const arcn_mlp_desc *desc_host, const float *acts, float *scratch,

@@ -174,7 +174,7 @@ class NgpField:
 class NgpPipeline:
     """Pre-allocated buffers + the kernel sequence of one render / train step for a fixed ray capacity."""
 
-    def __init__(self, field, max_rays=32768, max_samples=1 << 19, packed_bits=True, torch_aabb=False, xcd_scatter=True):
+    def __init__(self, field, max_rays=32768, max_samples=1 << 19, packed_bits=True, torch_aabb=False, xcd_scatter=True, level_major=True):
         cfg = field.cfg
         self.field, self.cfg = field, cfg
         dev = field.device
@@ -229,6 +229,11 @@ class NgpPipeline:
         b['loss'] = torch.zeros(1, dtype=f32, device=dev)
         # XCD-owned-levels scatter workspace (owner + tile counters); None selects the plain agent-scope kernel
         self.hash_ws = F.hashgrid_bwd_workspace(self.field.grid_desc, S, dev) if xcd_scatter else None  # scatter bins
+        # level-major features between the hash grid and the geometry net (XCD-affine gather, coalesced everywhere): the shapes
+        # the *_lm entry points are wired for; anything else keeps the row-major buffers
+        gd = [field.geo_desc.dims[i] for i in range(field.geo_desc.n_layers + 1)]
+        self.level_major = bool(level_major and xcd_scatter and cfg.n_feat_per_entry == 2 and field.geo_desc.n_layers == 2 and
+                                not field.geo_desc.has_bias and gd[0] in (32, 64) and 48 < gd[1] <= 64 and gd[2] <= 16)
         # optimiser state
         n = field.n_params
         self.exp_avg = torch.zeros(n, dtype=f32, device=dev)
@@ -349,9 +354,17 @@ class NgpPipeline:
         N.check(L.arcn_packed_points(N.ptr(rays_o), N.ptr(rays_d), N.ptr(b['t']), N.ptr(b['ray_id']), N.ptr(b['xyz']),
                                      N.ptr(b['dirs']), S, n_dev.data_ptr(), st), 'packed_points')
         self.generation += 1
-        F.hashgrid_fwd(b['xyz'], self._p('table'), fld.grid_desc, n_dev=n_dev, out=b['feat'])
-        F.mlp_fwd(b['feat'], self._p('geo_w'), self._p('geo_b'), fld.geo_desc, save_acts=train, n_dev=n_dev, out=b['geo_out'],
-                  acts=b['geo_acts'])
+        if self.level_major:
+            # encode -> geometry net through a LEVEL-MAJOR feature buffer (L, S, 2): the XCD-affine gather writes it coalesced and
+            # the net's tile loads read 128 contiguous bytes per level
+            N.check(L.arcn_hashgrid_fwd_xcd(N.ptr(b['xyz']), N.ptr(self._p('table')), N.C.addressof(fld.grid_desc), N.ptr(b['feat']),
+                                            1, S, S, n_dev.data_ptr(), st), 'hashgrid_fwd_xcd')
+            N.check(L.arcn_mlp_fwd_lm(N.ptr(b['feat']), S, N.ptr(self._p('geo_w')), N.C.addressof(fld.geo_desc), N.ptr(b['geo_out']),
+                                      N.ptr(b['geo_acts']) if train else None, S, S, n_dev.data_ptr(), st), 'mlp_fwd_lm(geo)')
+        else:
+            F.hashgrid_fwd(b['xyz'], self._p('table'), fld.grid_desc, n_dev=n_dev, out=b['feat'])
+            F.mlp_fwd(b['feat'], self._p('geo_w'), self._p('geo_b'), fld.geo_desc, save_acts=train, n_dev=n_dev, out=b['geo_out'],
+                      acts=b['geo_acts'])
         F.ngp_glue_fwd(b['geo_out'], b['dirs'], fld.feat_off, cfg.W_feat, cfg.sh_degree, feat_first=(cfg.rad_mode == 'fv'),
                        sigma_act=cfg.sigma_act, n_dev=n_dev, rad_in=b['rad_in'], sigma=b['sigma'])
         F.mlp_fwd(b['rad_in'], self._p('rad_w'), self._p('rad_b'), fld.rad_desc, save_acts=train, n_dev=n_dev, out=b['rgb_s'],
@@ -386,6 +399,13 @@ class NgpPipeline:
                 'mlp_bwd(rad)')
         F.ngp_glue_bwd(b['geo_out'], b['d_rad_in'], b['d_sigma'], fld.feat_off, cfg.W_feat, cfg.sh_degree,
                        feat_first=(cfg.rad_mode == 'fv'), sigma_act=cfg.sigma_act, n_dev=n_dev, d_geo_out=b['d_geo_out'])
+        if self.level_major:
+            N.check(L.arcn_mlp_bwd_lm(N.ptr(b['feat']), S, N.ptr(self._p('geo_w')), N.C.addressof(fld.geo_desc), N.ptr(b['geo_out']),
+                                      N.ptr(b['geo_acts']), N.ptr(b['d_geo_out']), N.ptr(b['d_feat']), N.ptr(self._g('geo_w')),
+                                      N.ptr(b['geo_scratch']), S, S, n_dev.data_ptr(), st), 'mlp_bwd_lm(geo)')
+            N.check(L.arcn_hashgrid_bwd_lm(N.ptr(b['xyz']), N.ptr(b['d_feat']), S, N.C.addressof(fld.grid_desc), N.ptr(self._g('table')),
+                                           N.ptr(self.hash_ws), self.hash_ws.numel(), S, n_dev.data_ptr(), st), 'hashgrid_bwd_lm')
+            return
         N.check(L.arcn_mlp_bwd(N.ptr(b['feat']), N.ptr(self._p('geo_w')), N.ptr(self._p('geo_b')), N.C.addressof(fld.geo_desc),
                                N.ptr(b['geo_out']), N.ptr(b['geo_acts']), N.ptr(b['d_geo_out']), N.ptr(b['d_feat']),
                                N.ptr(self._g('geo_w')), N.ptr(self._g('geo_b')), N.ptr(b['geo_scratch']), S, S, n_dev.data_ptr(), st),
@@ -459,8 +479,16 @@ class NgpPipeline:
             }
         sc = self._occ_scratch
         pts = pts.contiguous()
-        F.hashgrid_fwd(pts, self._p('table'), fld.grid_desc, out=sc['feat'][:n], n_dev=n_dev)
-        F.mlp_fwd(sc['feat'][:n], self._p('geo_w'), self._p('geo_b'), fld.geo_desc, out=sc['geo_out'][:n], n_dev=n_dev)
+        if self.level_major:
+            L, st, cap = N.lib(), N.stream(), sc['feat'].shape[0]
+            nd = None if n_dev is None else n_dev.data_ptr()
+            N.check(L.arcn_hashgrid_fwd_xcd(N.ptr(pts), N.ptr(self._p('table')), N.C.addressof(fld.grid_desc), N.ptr(sc['feat']), 1,
+                                            cap, n, nd, st), 'hashgrid_fwd_xcd(occ)')
+            N.check(L.arcn_mlp_fwd_lm(N.ptr(sc['feat']), cap, N.ptr(self._p('geo_w')), N.C.addressof(fld.geo_desc),
+                                      N.ptr(sc['geo_out']), None, cap, n, nd, st), 'mlp_fwd_lm(occ)')
+        else:
+            F.hashgrid_fwd(pts, self._p('table'), fld.grid_desc, out=sc['feat'][:n], n_dev=n_dev)
+            F.mlp_fwd(sc['feat'][:n], self._p('geo_w'), self._p('geo_b'), fld.geo_desc, out=sc['geo_out'][:n], n_dev=n_dev)
         sigma = F.act_fwd(sc['geo_out'][:n, 0].contiguous(), cfg.sigma_act)
         opacity = sigma * cfg.dt  # get_est_opacity (base_3d_model.py:386-389)
         F.opafield_scatter_update(self.opafield, cell, opacity, ema=cfg.ema_optim_decay, cell_max=sc['cell_max'],

@@ -46,6 +46,10 @@ TABLE_KERNELS = ROOFLINE_KERNELS + ('mlp_fwd', 'mlp_bwd', 'mlp_bwd_dw', 'march_c
                                     'composite_packed_bwd', 'adam_ema_step')
 
 
+# entry points of the level-major path are reported under the name of the op they implement
+ALIASES = {'hashgrid_fwd_xcd': 'hashgrid_fwd', 'hashgrid_bwd_lm': 'hashgrid_bwd', 'mlp_fwd_lm': 'mlp_fwd', 'mlp_bwd_lm': 'mlp_bwd'}
+
+
 class KernelTimers:
     """HIP events (torch.cuda.Event on the launch stream == torch's current stream) around individual C-ABI entry points.
     Only the names in `enabled` are bracketed: two event records per launch are not free on a 1 ms step, so the timed
@@ -88,7 +92,8 @@ def instrument(timers):
         def __getattr__(self, name):
             if name not in self._cache:
                 fn = getattr(self._real, name)
-                self._cache[name] = timers.wrap(name[5:], fn) if name[5:] in TABLE_KERNELS else fn
+                label = ALIASES.get(name[5:], name[5:])
+                self._cache[name] = timers.wrap(label, fn) if label in TABLE_KERNELS else fn
             return self._cache[name]
 
     proxy = Proxy(lib)
@@ -199,7 +204,7 @@ def main():
         except Exception:
             traffic = None
     dur_s = ksum[dom] * 1e-3
-    ach = hash_kernels[dom] * s_per_launch / dur_s if dom == 'hashgrid_bwd' else None
+    ach = hash_kernels[dom] * s_per_launch / dur_s
     if dom == 'hashgrid_fwd':
         # mean over launches mixes train (S) and occupancy-refresh (n_cells/2) sizes: weight the bytes accordingly
         occ_launch = 0 if args.no_occ_update else sum(1 for e in range(epoch0 + args.warmup, epoch0 + args.warmup + args.steps) if e % cfg.epoch_optim == 0)

@@ -111,6 +111,11 @@ typedef struct {
  * hash_idx (n,L,8) int32 optional debug output (-1 for out-of-volume). */
 int arcn_hashgrid_fwd(const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out,
                       int32_t *hash_idx, int64_t n, const int32_t *n_ptr, void *stream);
+/* Same result as arcn_hashgrid_fwd (bit-identical), scheduled so that each of the chip's 8 XCDs gathers only its own
+ * 2 of 16 levels (a level's table slice then stays in that XCD's L2); n_feat 1 or 2.
+ * level_major = 0: out (n, L*F) row-major; level_major = 1: out[(l * n_cap + s) * F + f]. */
+int arcn_hashgrid_fwd_xcd(const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out,
+                          int level_major, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream);
 /* backward: dtable (n_total,F) accumulated (caller zeroes), dxyz (n,3) optional.
  * workspace (device, workspace_floats >= arcn_hashgrid_bwd_workspace_floats(desc, n) floats, optional; -1 if too small):
  * selects the binned scatter.  A first pass turns every (level, sample) into up to four 16-byte records, one per pair of
@@ -122,6 +127,11 @@ int arcn_hashgrid_bwd(const float *xyz, const float *table, const float *dout, c
                       float *dtable, float *dxyz, float *workspace, int64_t workspace_floats, int64_t n,
                       const int32_t *n_ptr, void *stream);
 int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc *desc_host, int64_t n);
+/* binned scatter with LEVEL-MAJOR gradients dout_lm[(l * dout_stride + s) * F + f] (the layout arcn_hashgrid_fwd_xcd writes
+ * and arcn_mlp_bwd_lm produces); workspace required, dtable only. */
+int arcn_hashgrid_bwd_lm(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host,
+                         float *dtable, float *workspace, int64_t workspace_floats, int64_t n, const int32_t *n_ptr,
+                         void *stream);
 
 /* FreqEmbedder.forward (encoding/freq_encoder.py:65-88): out (n, D*(include_input + 2*n_freqs)). */
 int arcn_freq_fwd(const float *x, int D, int n_freqs, int include_input, float *out, int64_t n, void *stream);
@@ -171,6 +181,15 @@ int arcn_mlp_bwd(const float *x, const float *weights, const float *biases, cons
  * `scratch`), so a caller can run it on another stream while the dX chain of the next network proceeds. */
 int arcn_mlp_bwd_dw(const float *x, const arcn_mlp_desc *desc_host, const float *acts, float *scratch, float *dweights,
                     float *dbiases, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream);
+/* The same network with a LEVEL-MAJOR input / input gradient: x_lm[(l * x_stride + s) * 2 + f], 2 features per level (what
+ * arcn_hashgrid_fwd_xcd(level_major = 1) writes and arcn_hashgrid_bwd_lm consumes).  Wired for the bias-free 2-layer nets fed by
+ * the hash grid (input 32 or 64 wide, hidden <= 64, output <= 16); -1 otherwise.  bwd: dx_lm in the layout of x_lm, dweights
+ * required (fused dX + dW kernel). */
+int arcn_mlp_fwd_lm(const float *x_lm, int64_t x_stride, const float *weights, const arcn_mlp_desc *desc_host, float *out,
+                    float *acts, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream);
+int arcn_mlp_bwd_lm(const float *x_lm, int64_t x_stride, const float *weights, const arcn_mlp_desc *desc_host, const float *out,
+                    const float *acts, const float *dout, float *dx_lm, float *dweights, float *scratch, int64_t n_cap,
+                    int64_t n, const int32_t *n_ptr, void *stream);
 /* float count the caller must provide in `acts` (hidden layers) and `scratch` (bwd) for capacity n_cap */
 int64_t arcn_mlp_acts_floats(const arcn_mlp_desc *desc_host, int64_t n_cap);
 int64_t arcn_mlp_scratch_floats(const arcn_mlp_desc *desc_host, int64_t n_cap);

@@ -20,8 +20,8 @@ def test_smoke_small_config(gpu):
     assert errs['rgb'] < 1e-4
 
 
-@pytest.mark.parametrize('noise', [False, True])
-def test_full_ngp_config_step_matches_reference_stack(gpu, oracle, noise):
+@pytest.mark.parametrize('noise,level_major', [(False, True), (True, True), (False, False)])
+def test_full_ngp_config_step_matches_reference_stack(gpu, oracle, noise, level_major):
     """configs/models/nerf_ngp.yaml dimensions (L16 F2 T2^19, n_grid 128, 1024 samples/ray): RGB/depth/mask within 1e-4,
     identical sample count, gradients of table / geo / radiance weights within 1e-3 of their max."""
     from oracle.ngp_reference import oracle_step, compare
@@ -30,7 +30,8 @@ def test_full_ngp_config_step_matches_reference_stack(gpu, oracle, noise):
     fld = NgpField(cfg, device=gpu, seed=5)
     fld.view('table').mul_(3000.0)  # a trained-like table magnitude so features drive the nets
     R = 700
-    pipe = NgpPipeline(fld, max_rays=1024, max_samples=1 << 16, packed_bits=True)
+    pipe = NgpPipeline(fld, max_rays=1024, max_samples=1 << 16, packed_bits=True, level_major=level_major)
+    assert pipe.level_major == level_major
     bf = synthetic_bitfield(cfg.n_grid, 0.05, seed=1)
     pipe.set_bitfield(torch.from_numpy(bf))
     o, d = synthetic_rays(R, seed=9, device=gpu)

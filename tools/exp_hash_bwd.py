@@ -34,11 +34,13 @@ print('full bwd xcd    %.3f ms' % timeit(lambda: F.hashgrid_bwd(xyz, table, dout
 print('full fwd        %.3f ms' % timeit(lambda: F.hashgrid_fwd(xyz, table, fld.grid_desc)))
 import ctypes as C
 lm = torch.empty(16 * n * 2, device=dev)
-def fwd_lm():
-    N.check(N.lib().arcn_hashgrid_fwd_lm(xyz.data_ptr(), table.data_ptr(), C.addressof(fld.grid_desc), lm.data_ptr(), n, n, None, N.stream()))
-print('full fwd LM/XCD %.3f ms' % timeit(fwd_lm))
+rm = torch.empty(n * 32, device=dev)
+def fwd_x(buf, mode):
+    N.check(N.lib().arcn_hashgrid_fwd_xcd(xyz.data_ptr(), table.data_ptr(), C.addressof(fld.grid_desc), buf.data_ptr(), mode, n, n, None, N.stream()))
+print('fwd XCD level-major %.3f ms' % timeit(lambda: fwd_x(lm, 1)))
+print('fwd XCD row-major   %.3f ms' % timeit(lambda: fwd_x(rm, 0)))
 ref = F.hashgrid_fwd(xyz, table, fld.grid_desc)
-print('LM == row-major:', torch.equal(lm.view(16, n, 2).permute(1, 0, 2).reshape(n, 32), ref))
+print('LM == row-major:', torch.equal(lm.view(16, n, 2).permute(1, 0, 2).reshape(n, 32), ref), ' RM ==', torch.equal(rm.view(n, 32), ref))
 for l in range(16):
     desc = N.make_hashgrid_desc([fld.resolutions[l]], [fld.offsets[l], fld.offsets[l + 1]], 2, fld.min_xyz, fld.max_xyz)
     d1 = torch.randn(n, 2, device=dev)
