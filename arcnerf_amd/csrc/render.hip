@@ -38,6 +38,7 @@ struct DenseView {
     }
     __device__ float z(int64_t r, int k) const { return zvals[r * P + k]; }
     __device__ void zero_dropped(int64_t, float *, float *) const {}  // the host wrapper clears the dropped last column
+    __device__ void begin_ray(int64_t) {}
 };
 
 // Packed (offsets, t) form reproducing the reference's padded dense (R, P_dense) tensors: valid samples first, the
@@ -55,7 +56,14 @@ struct PackedView {
             Pe = add_inf_z ? P_dense : P_dense - 1;
         }
     }
-    __device__ int count(int64_t r) const { return offsets[r + 1] - offsets[r]; }
+    // per-ray segment, loaded ONCE by begin_ray (the accessors below are called per sample; re-reading offsets[] there costs a
+    // dependent global load each time because the compiler cannot prove the kernel's stores do not alias it)
+    int32_t seg_off = 0, seg_n = 0;
+    __device__ void begin_ray(int64_t r) {
+        seg_off = offsets[r];
+        seg_n = offsets[r + 1] - seg_off;
+    }
+    __device__ int count(int64_t) const { return seg_n; }
     __device__ int ncol(int64_t r) const {
         int n = count(r);
         if (n <= 0) return 0;
@@ -66,14 +74,14 @@ struct PackedView {
     __device__ bool real(int64_t r, int k) const { return k < count(r); }
     __device__ int64_t sidx(int64_t r, int k) const {
         int n = count(r);
-        return (int64_t)offsets[r] + (k < n ? k : n - 1);
+        return (int64_t)seg_off + (k < n ? k : n - 1);
     }
     __device__ int64_t nidx(int64_t r, int k) const { return sidx(r, k); }
     __device__ float delta(int64_t r, int k, bool &neg) const {
         int n = count(r);
         if (k >= n) return 1e10f;  // virtual final column
         if (k == n - 1) return (add_inf_z && n == P_dense) ? 1e10f : 0.0f;
-        int64_t b = (int64_t)offsets[r] + k;
+        int64_t b = (int64_t)seg_off + k;
         float d = zvals[b + 1] - zvals[b];
         if (fabsf(d) < 1e-5f) d = 0.0f;
         if (d < 0.f) neg = true;
@@ -84,7 +92,7 @@ struct PackedView {
     __device__ void zero_dropped(int64_t r, float *d_geo, float *d_radiance) const {
         const int n = count(r);
         if (!add_inf_z && n >= P_dense && n > 0) {
-            const int64_t si = (int64_t)offsets[r] + n - 1;
+            const int64_t si = (int64_t)seg_off + n - 1;
             d_geo[si] = 0.f;
             if (d_radiance) { d_radiance[si * 3] = 0.f; d_radiance[si * 3 + 1] = 0.f; d_radiance[si * 3 + 2] = 0.f; }
         }
@@ -114,6 +122,7 @@ composite_fwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict
     const int lane = lane_id();
     const int64_t r = (int64_t)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
     if (r >= R) return;
+    v.begin_ray(r);
     const int nc = v.ncol(r);
     float carry = 1.0f;
     float acc_d = 0.f, acc_m = 0.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, t_last = 0.f;
@@ -189,6 +198,7 @@ composite_bwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict
     const int wv = threadIdx.x >> 6;
     const int64_t r = (int64_t)blockIdx.x * kRaysPerBlock + wv;
     if (r >= R) return;
+    v.begin_ray(r);
     const int nc = v.ncol(r);
     const int nchunk = (nc + 63) >> 6;
     bool neg = false;

@@ -19,6 +19,7 @@ device-side count, so the whole step issues no host synchronisation.  All parame
 [hash table | geo W | radiance W] so the optimiser is one kernel and data-parallel training needs one collective.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -200,6 +201,8 @@ class NgpPipeline:
         b.update(self._sets[0])
         self._cur_set = 0
         self._prefetched = None
+        self._next_rays = None
+        self.prefetch_at = int(os.environ.get('ARCN_PREFETCH_AT', '1'))
         self.aux_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
         self.use_streams = self.aux_stream is not None
         b['xyz'] = torch.zeros((S, 3), dtype=f32, device=dev)
@@ -399,10 +402,12 @@ class NgpPipeline:
                 'mlp_bwd(rad)')
         F.ngp_glue_bwd(b['geo_out'], b['d_rad_in'], b['d_sigma'], fld.feat_off, cfg.W_feat, cfg.sh_degree,
                        feat_first=(cfg.rad_mode == 'fv'), sigma_act=cfg.sigma_act, n_dev=n_dev, d_geo_out=b['d_geo_out'])
+        self._prefetch_point(1)
         if self.level_major:
             N.check(L.arcn_mlp_bwd_lm(N.ptr(b['feat']), S, N.ptr(self._p('geo_w')), N.C.addressof(fld.geo_desc), N.ptr(b['geo_out']),
                                       N.ptr(b['geo_acts']), N.ptr(b['d_geo_out']), N.ptr(b['d_feat']), N.ptr(self._g('geo_w')),
                                       N.ptr(b['geo_scratch']), S, S, n_dev.data_ptr(), st), 'mlp_bwd_lm(geo)')
+            self._prefetch_point(2)
             N.check(L.arcn_hashgrid_bwd_lm(N.ptr(b['xyz']), N.ptr(b['d_feat']), S, N.C.addressof(fld.grid_desc), N.ptr(self._g('table')),
                                            N.ptr(self.hash_ws), self.hash_ws.numel(), S, n_dev.data_ptr(), st), 'hashgrid_bwd_lm')
             return
@@ -410,6 +415,7 @@ class NgpPipeline:
                                N.ptr(b['geo_out']), N.ptr(b['geo_acts']), N.ptr(b['d_geo_out']), N.ptr(b['d_feat']),
                                N.ptr(self._g('geo_w')), N.ptr(self._g('geo_b')), N.ptr(b['geo_scratch']), S, S, n_dev.data_ptr(), st),
                 'mlp_bwd(geo)')
+        self._prefetch_point(2)
         N.check(L.arcn_hashgrid_bwd(N.ptr(b['xyz']), N.ptr(self._p('table')), N.ptr(b['d_feat']), N.C.addressof(fld.grid_desc),
                                     N.ptr(self._g('table')), None, N.ptr(self.hash_ws),
                                     0 if self.hash_ws is None else self.hash_ws.numel(), S, n_dev.data_ptr(), st),
@@ -437,14 +443,23 @@ class NgpPipeline:
         if cfg.noise_std > 0:
             noise = b['noise'].normal_(0.0, cfg.noise_std)
         rgb, _, _ = self.forward(rays_o, rays_d, bkg_color, train=True, noise=noise)
-        if next_rays is not None:
-            self.prefetch_samples(*next_rays)
+        self._next_rays = next_rays
+        self._prefetch_point(0)
         loss, d_rgb = self.huber_grad(rgb, target_rgb)
         self.backward(rays_o, rays_d, d_rgb)
         if all_reduce is not None:
             all_reduce(self.field.grads)
+        self._prefetch_point(3)
         self.optimizer_step(world_size)
         return loss
+
+    def _prefetch_point(self, where):
+        """Issue the next batch's marching (second stream) at point `where` of the step: 0 after the forward, 1 before the
+        geometry-net backward, 2 before the hash-grid scatter, 3 before the optimiser.  The marcher is pure VALU work with a
+        256 KiB working set; it costs least next to the LDS / HBM-bound kernels."""
+        if getattr(self, '_next_rays', None) is not None and where == self.prefetch_at:
+            self.prefetch_samples(*self._next_rays)
+            self._next_rays = None
 
     # ---- occupancy update (VolumeBound.optimize, volume_bound.py:160-212) -----------------------------
     def update_occupancy(self, cur_epoch, apply=True):
