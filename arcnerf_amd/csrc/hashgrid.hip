@@ -21,6 +21,8 @@ struct LevelParams {
     int32_t res;
     uint32_t size;     // rows of this level
     uint32_t mask;     // size-1 if size is a power of two else 0
+    float vs[3];       // voxel size (max - min) / res per axis: the same fp32 division the reference does, done once on the host
+    float rvs[3];      // 1 / vs (only for the backward's interpolation weights, which carry a tolerance, never for the cell index)
     int32_t pad;
     double inv_size;   // 1.0/size
     int64_t offset;    // first row
@@ -52,15 +54,17 @@ struct Cell {
     bool valid;
 };
 
-__device__ __forceinline__ Cell locate(const float p[3], const GridParams &g, int res) {
+// FASTW: interpolation weights through the precomputed reciprocal (1 ulp off the divided value; the backward's tolerance
+// absorbs it).  The cell index always uses the exact division, so the rows stay bit-identical to the forward / the reference.
+template <bool FASTW = false>
+__device__ __forceinline__ Cell locate(const float p[3], const GridParams &g, const LevelParams &lp) {
     Cell cell;
-    float v[3], vs[3];
+    float v[3];
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        vs[k] = (g.mx[k] - g.mn[k]) / (float)res;
-        v[k] = (p[k] - g.mn[k]) / vs[k];
-        if (!(v[k] >= 0.f) || !(v[k] < (float)res)) ok = false;
+        v[k] = (p[k] - g.mn[k]) / lp.vs[k];
+        if (!(v[k] >= 0.f) || !(v[k] < (float)lp.res)) ok = false;
     }
     cell.valid = ok;
     if (!ok) return cell;
@@ -68,11 +72,11 @@ __device__ __forceinline__ Cell locate(const float p[3], const GridParams &g, in
     for (int k = 0; k < 3; ++k) {
         float cf = floorf(v[k]);
         cell.c[k] = (uint32_t)cf;
-        float a = cf * vs[k];
+        float a = cf * lp.vs[k];
         float g0 = a + g.mn[0];  // start_point[0] for every axis (volume.py:515)
-        float ww = (p[k] - g0) / vs[k];
+        float ww = FASTW ? (p[k] - g0) * lp.rvs[k] : (p[k] - g0) / lp.vs[k];
         cell.w[k] = ww < 0.0f ? 0.0f : (ww > 1.0f ? 1.0f : ww);
-        cell.dw[k] = (ww >= 0.0f && ww <= 1.0f) ? 1.0f / vs[k] : 0.0f;
+        cell.dw[k] = (ww >= 0.0f && ww <= 1.0f) ? 1.0f / lp.vs[k] : 0.0f;
     }
     return cell;
 }
@@ -89,7 +93,7 @@ __global__ void __launch_bounds__(256) hashgrid_fwd_kernel(const float *__restri
     const int l = (int)(gid - s * g.L);
     const LevelParams lp = g.lv[l];
     const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
-    const Cell cell = locate(p, g, lp.res);
+    const Cell cell = locate(p, g, lp);
     float acc[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) acc[f] = 0.f;
@@ -153,7 +157,7 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(const float *__restri
     const int l = (int)(gid - s * g.L);
     const LevelParams lp = g.lv[l];
     const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
-    const Cell cell = locate(p, g, lp.res);
+    const Cell cell = locate(p, g, lp);
     if (!cell.valid) return;
     float go[F];
 #pragma unroll
@@ -213,7 +217,7 @@ hashgrid_fwd_xcd_kernel(const float *__restrict__ xyz, const float *__restrict__
     if (s >= cnt) return;
     const LevelParams lp = g.lv[l];
     const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
-    const Cell cell = locate(p, g, lp.res);
+    const Cell cell = locate(p, g, lp);
     float acc[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) acc[f] = 0.f;
@@ -289,6 +293,7 @@ struct BinPlan {
     uint32_t lock_levels;                     // consumer, bit l: row locks (else float atomics)
     uint32_t active_levels;                   // debugging aid (ARCN_SCATTER_LEVELS): levels that are processed at all
     uint32_t pair_levels;                     // hashed power-of-two levels with more than one chunk: <= 4 pair records per sample
+    uint32_t nosplit_levels;                  // chunk rows > res on a hashed level: both rows of an x pair ALWAYS share the chunk
     int32_t n_bins;
     int32_t debug;
     int32_t chunk_floats;                     // LDS accumulator floats per workgroup (rows per chunk * F)
@@ -332,16 +337,17 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
     __shared__ uint32_t hist[kMaxChunks];   // records of this tile per bin
     __shared__ uint32_t gbase[kMaxChunks];  // first position of the tile's run in every bin
     const int64_t cnt = dev_count(n, n_ptr);
-    const int64_t tile0 = (int64_t)blockIdx.x * kBinThreads;
-    if (tile0 >= cnt) return;
     const int l = blockIdx.y;
     if (!((plan.active_levels >> l) & 1u)) return;
     const LevelParams lp = g.lv[l];
     const int nc = plan.n_chunks[l], shift = plan.chunk_shift[l];
     const uint32_t cmask = (1u << shift) - 1u;
+    const int t = threadIdx.x, lane = t & 63;
+    // Persistent over the level's tiles: a tile keeps a wave busy for ~3 us only, and one workgroup per tile left the chip at
+    // ~20 % wave occupancy waiting for the dispatcher (SQ_WAVE_CYCLES / duration); gridDim.x workgroups per level loop instead.
+    for (int64_t tile0 = (int64_t)blockIdx.x * kBinThreads; tile0 < cnt; tile0 += (int64_t)gridDim.x * kBinThreads) {
     for (int i = threadIdx.x; i < nc; i += kBinThreads) hist[i] = 0u;
     __syncthreads();
-    const int t = threadIdx.x, lane = t & 63;
     const int64_t s = tile0 + t;
     int sbin[8];
     uint32_t sidx[8];
@@ -353,13 +359,18 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
     float g0 = 0.f, g1 = 0.f;
     if (s < cnt) {
         const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
-        cell = locate(p, g, lp.res);
+        cell = locate<true>(p, g, lp);
         if (cell.valid) {
             // level-major gradients (dout_lm_stride > 0): the lanes of a wave read consecutive 8-byte words
             const float *gp = dout_lm_stride ? dout + ((int64_t)l * dout_lm_stride + s) * F : dout + (s * g.L + l) * F;
             g0 = gp[0];
             g1 = F > 1 ? gp[F > 1 ? 1 : 0] : 0.f;
         }
+    }
+    if (plan.debug & 16) {  // timing aid: loads + cell only
+        if (g0 == 12345.678f && cell.w[0] == 0.3f) counters[0] = 1u;
+        __syncthreads();
+        continue;
     }
     // runs of consecutive samples (lanes) in the same cell: head lanes, and for every lane the last lane of its run
     const uint32_t kxy = cell.valid ? (cell.c[0] | (cell.c[1] << 16)) : 0xffffffffu;
@@ -370,7 +381,27 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
     // Per wave: with an average run of >= 1.5 samples the runs are summed first (fewer records, fewer row updates, and no
     // neighbouring lanes fighting over one row lock in the consumer); otherwise the x pairs go out as they are.
     const bool reduce = 3 * __popcll(heads) <= 2 * __popcll(valid);
-    if (!reduce) {
+    const bool nosplit = (plan.nosplit_levels >> l) & 1u;  // wave uniform
+    const int n_slots = (!reduce && nosplit) ? 4 : 8;       // slots that can be occupied
+    if (!reduce && nosplit) {
+        // hashed level, chunk larger than the resolution: cx and cx+1 differ only below the chunk size, one record per pair
+        if (cell.valid) {
+            const uint32_t hy0 = cell.c[1] * 2654435761u, hy1 = hy0 + 2654435761u;
+            const uint32_t hz0 = cell.c[2] * 805459861u, hz1 = hz0 + 805459861u;
+            const float wy1 = cell.w[1], wy0 = 1.0f - wy1, wz1 = cell.w[2], wz0 = 1.0f - wz1;
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                const uint32_t hyz = ((pr & 1) ? hy1 : hy0) ^ ((pr >> 1) ? hz1 : hz0);
+                const uint32_t r0 = (cell.c[0] ^ hyz) & lp.mask, r1 = ((cell.c[0] + 1u) ^ hyz) & lp.mask;
+                const float wyz = ((pr & 1) ? wy1 : wy0) * ((pr >> 1) ? wz1 : wz0);
+                sbin[pr] = (int)(r0 >> shift);
+                sidx[pr] = (r0 & cmask) | ((r1 & cmask) << 16);
+                swx[pr] = cell.w[0];
+                sa[pr] = g0 * wyz;
+                sb[pr] = g1 * wyz;
+            }
+        }
+    } else if (!reduce) {
         if (cell.valid) {
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr) {
@@ -441,23 +472,34 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
             }
         }
     }
+    if (plan.debug & 32) {  // timing aid: records built, nothing ranked or stored
+        float acc_dbg = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc_dbg += (sbin[k] >= 0) ? sa[k] + sb[k] + swx[k] + (float)sidx[k] : 0.f;
+        if (acc_dbg == 12345.678f) counters[0] = 1u;
+        __syncthreads();
+        continue;
+    }
     uint32_t rank[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) rank[k] = sbin[k] >= 0 ? atomicAdd(&hist[sbin[k]], 1u) : 0u;
+    for (int k = 0; k < 8; ++k) rank[k] = (k < n_slots && sbin[k] >= 0) ? atomicAdd(&hist[sbin[k]], 1u) : 0u;
     __syncthreads();
     // reserve the tile's run in every bin: one global integer atomic per (bin, tile)
     for (int i = threadIdx.x; i < nc; i += kBinThreads) {
         const uint32_t h = hist[i];
-        gbase[i] = h ? atomicAdd(&counters[plan.bin_first[l] + i], h) : 0u;
+        gbase[i] = (h && !(plan.debug & 8)) ? atomicAdd(&counters[plan.bin_first[l] + i], h) : 0u;
     }
     __syncthreads();
     const uint32_t cap = (uint32_t)plan.cap[l];
     uint4 *lrecs = recs + plan.rec_first[l];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        if (sbin[k] < 0) continue;
+        if (k >= n_slots || sbin[k] < 0) continue;
         const uint4 rec = make_uint4(sidx[k], __float_as_uint(swx[k]), __float_as_uint(sa[k]), __float_as_uint(sb[k]));
+        if (plan.debug & 4) continue;
         emit_record<F>(lrecs, dtable, lp, sbin[k], gbase[sbin[k]] + rank[k], cap, shift, rec);
+    }
+    __syncthreads();  // hist / gbase are reused by the next tile
     }
 }
 
@@ -611,6 +653,11 @@ static int build_params(const arcn_hashgrid_desc *d, GridParams &g) {
         if (size <= 0 || size > 0xffffffffll || d->resolutions[l] <= 0) return einval("hashgrid: bad level table");
         LevelParams &lp = g.lv[l];
         lp.res = d->resolutions[l];
+        for (int k = 0; k < 3; ++k) {
+            const float ext = d->max_xyz[k] - d->min_xyz[k];
+            lp.vs[k] = ext / (float)lp.res;
+            lp.rvs[k] = 1.0f / lp.vs[k];
+        }
         lp.size = (uint32_t)size;
         lp.mask = ((size & (size - 1)) == 0) ? (uint32_t)(size - 1) : 0u;
         lp.pad = 0;
@@ -644,6 +691,7 @@ static int build_bin_plan(const GridParams &g, int64_t n, BinPlan &plan) {
     plan.debug = dbg;
     plan.lock_levels = 0u;
     plan.pair_levels = 0u;
+    plan.nosplit_levels = 0u;
     for (int l = 0; l < g.L; ++l) {
         const int64_t size = g.lv[l].size;
         int shift = 0;
@@ -654,6 +702,7 @@ static int build_bin_plan(const GridParams &g, int64_t n, BinPlan &plan) {
         // the small levels below them: runs of samples in one cell are summed in the producer -> at most 8 singles per sample
         const bool paired = g.lv[l].mask != 0 && nc > 1;
         if (paired) plan.pair_levels |= 1u << l;
+        if (g.lv[l].mask != 0 && ((int64_t)1 << shift) > g.lv[l].res) plan.nosplit_levels |= 1u << l;
         if (paired && ((lock_override >> l) & 1u)) plan.lock_levels |= 1u << l;
         const bool locked = (plan.lock_levels >> l) & 1u;
         const int64_t mean = (paired ? 4 : 8) * n / nc;
@@ -746,7 +795,10 @@ static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *
             ? hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_accum_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
             : hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_accum_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
-        dim3 bgrid((unsigned)ceil_div<int64_t>(n, kBinThreads), (unsigned)g.L);
+        static const int bin_wgs = [] { const char *e = getenv("ARCN_SCATTER_BIN_WGS"); return e ? atoi(e) : 32; }();
+        int64_t bx = ceil_div<int64_t>(n, kBinThreads);
+        if (bx > bin_wgs) bx = bin_wgs;  // persistent workgroups per level
+        dim3 bgrid((unsigned)bx, (unsigned)g.L);
         dim3 agrid((unsigned)plan.item_first[g.L]);
         if (g.F == 1) {
             hipLaunchKernelGGL(scatter_bin_kernel<1>, bgrid, dim3(kBinThreads), 0, as_stream(stream), xyz, dout, dout_lm_stride, g, plan, counters, recs, dtable, n, n_ptr);

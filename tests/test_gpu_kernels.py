@@ -364,6 +364,28 @@ def test_level_major_variants_match_row_major(F):
     assert lib.arcn_mlp_fwd_lm(N.ptr(lm), cap, N.ptr(w), C.addressof(bad), N.ptr(out), None, cap, S, None, st) == -1
 
 
+def test_hashgrid_scatter_bin_overflow_and_runs(F, oracle):
+    """Adversarial sample distributions for the binned scatter: (a) samples alternating between two far-apart cells (runs of
+    length 1, every record of a hashed level lands in the same <= 8 bins: their fixed capacity overflows and the direct-atomic
+    path must take the excess), (b) all samples inside one cell (one run per wave: the segmented reduction carries everything)."""
+    rng = np.random.default_rng(8)
+    res, offs = oracle.hashgrid_levels(16, 19, 16, 2048)
+    table = make_table(int(offs[-1]), 2, seed=2, scale=0.5)
+    desc = _desc(F, res, offs, 2)
+    mn, mx = np.full(3, -1, np.float32), np.full(3, 1, np.float32)
+    S = 40000
+    a = np.array([0.3137, -0.2711, 0.5519], np.float32)
+    b = np.array([-0.6123, 0.4401, -0.1907], np.float32)
+    jit = (rng.random((S, 3)).astype(np.float32) - 0.5) * np.float32(2e-4)   # stays inside one finest-level cell (1e-3 wide)
+    for name, xyz in (('alternating', np.where((np.arange(S) % 2 == 0)[:, None], a, b) + jit), ('one cell', a + jit)):
+        xyz = xyz.astype(np.float32)
+        gout = rng.normal(size=(S, 32)).astype(np.float32)
+        ref_dt = oracle.hashgrid_bwd(xyz, table, gout, res, offs, mn, mx)
+        dt, _ = F.hashgrid_bwd(dev(xyz), dev(table), dev(gout), desc, workspace=True)
+        scale = np.abs(ref_dt).max()
+        assert np.abs(host(dt) - ref_dt).max() < 2e-5 * scale, name   # sums of 2e4 terms per row: fp32 summation order noise
+
+
 def test_hashgrid_ngp_large_vs_oracle(F, oracle):
     rng = np.random.default_rng(6)
     res, offs = oracle.hashgrid_levels(16, 19, 16, 2048)
