@@ -121,8 +121,23 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const float *__restrict__ 
 // addresses).  Requires Wf, Wg, feat_off and deg^2 to be multiples of 4 (NGP: 16/16/0/16); other shapes take the row kernel.
 typedef float f4v __attribute__((ext_vector_type(4)));
 
+// SH(normalize(d)) once per RAY: every sample of a ray shares its direction, the glue below then gathers the row by ray id
+// instead of evaluating the polynomials per sample (4x over, one per output quad)
 __global__ void __launch_bounds__(256)
-ngp_glue_fwd_vec_kernel(const float *__restrict__ geo_out, const float *__restrict__ dirs, int Wg, int feat_off, int Wf,
+ngp_ray_sh_kernel(const float *__restrict__ rays_d, int degree, float *__restrict__ sh_ray, int64_t n_rays) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
+    const float nrm = sqrtf((dx * dx + dy * dy) + dz * dz) + 1e-8f;
+    float o[25];
+    sh_eval(dx / nrm, dy / nrm, dz / nrm, degree, o);
+    const int nsh = degree * degree;
+    for (int c = 0; c < nsh; ++c) sh_ray[r * nsh + c] = o[c];
+}
+
+__global__ void __launch_bounds__(256)
+ngp_glue_fwd_vec_kernel(const float *__restrict__ geo_out, const float *__restrict__ dirs, const float *__restrict__ sh_ray,
+                        const int32_t *__restrict__ ray_id, int Wg, int feat_off, int Wf,
                         int degree, int feat_first, int sigma_act, float *__restrict__ rad_in, float *__restrict__ sigma,
                         int64_t n, const int32_t *n_ptr) {
     const int64_t cnt = dev_count(n, n_ptr);
@@ -137,6 +152,8 @@ ngp_glue_fwd_vec_kernel(const float *__restrict__ geo_out, const float *__restri
         if (qf >= 0 && qf < Qf) {
             v = *reinterpret_cast<const f4v *>(geo_out + s * Wg + feat_off + 4 * qf);
             if (qf == 0 && sigma && feat_off == 0) sigma[s] = act_fwd(v.x, sigma_act, 1.0f);
+        } else if (sh_ray) {
+            v = *reinterpret_cast<const f4v *>(sh_ray + (int64_t)ray_id[s] * nsh + 4 * qs);
         } else {
             float dx = dirs[3 * s], dy = dirs[3 * s + 1], dz = dirs[3 * s + 2];
             float nrm = sqrtf((dx * dx + dy * dy) + dz * dz) + 1e-8f;
@@ -273,11 +290,34 @@ ARCN_EXPORT int arcn_ngp_glue_fwd(const float *geo_out, const float *dirs, int W
     const int nsh = sh_degree * sh_degree;
     if ((Wg & 3) == 0 && (Wf & 3) == 0 && (nsh & 3) == 0 && feat_off == 0)
         hipLaunchKernelGGL(ngp_glue_fwd_vec_kernel, dim3(grid_for(n * ((Wf + nsh) >> 2))), dim3(256), 0, as_stream(stream), geo_out,
-                           dirs, Wg, feat_off, Wf, sh_degree, feat_first, sigma_act, rad_in, sigma, n, n_ptr);
+                           dirs, static_cast<const float *>(nullptr), static_cast<const int32_t *>(nullptr), Wg, feat_off, Wf, sh_degree,
+                           feat_first, sigma_act, rad_in, sigma, n, n_ptr);
     else
         hipLaunchKernelGGL(ngp_glue_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), geo_out, dirs, Wg, feat_off,
                            Wf, sh_degree, feat_first, sigma_act, rad_in, sigma, n, n_ptr);
     return check_launch("ngp_glue_fwd");
+}
+
+ARCN_EXPORT int arcn_ngp_ray_sh(const float *rays_d, int sh_degree, float *sh_ray, int64_t n_rays, void *stream) {
+    if (n_rays <= 0) return ARCN_OK;
+    if (!rays_d || !sh_ray || sh_degree < 1 || sh_degree > 5) return einval("ngp_ray_sh: degree must be 1..5");
+    hipLaunchKernelGGL(ngp_ray_sh_kernel, dim3((unsigned)ceil_div<int64_t>(n_rays, 256)), dim3(256), 0, as_stream(stream), rays_d,
+                       sh_degree, sh_ray, n_rays);
+    return check_launch("ngp_ray_sh");
+}
+
+ARCN_EXPORT int arcn_ngp_glue_fwd_rays(const float *geo_out, const float *sh_ray, const int32_t *ray_id, int Wg, int feat_off,
+                                       int Wf, int sh_degree, int feat_first, int sigma_act, float *rad_in, float *sigma,
+                                       int64_t n, const int32_t *n_ptr, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    const int nsh = sh_degree * sh_degree;
+    if (!geo_out || !rad_in || !sh_ray || !ray_id || Wg < 1 || Wf < 0 || feat_off != 0 || Wf > Wg || sh_degree < 1 || sh_degree > 5 ||
+        (Wg & 3) || (Wf & 3) || (nsh & 3))
+        return einval("ngp_glue_fwd_rays: needs feat_off 0 and Wg, Wf, degree^2 multiples of 4");
+    hipLaunchKernelGGL(ngp_glue_fwd_vec_kernel, dim3(grid_for(n * ((Wf + nsh) >> 2))), dim3(256), 0, as_stream(stream), geo_out,
+                       static_cast<const float *>(nullptr), sh_ray, ray_id, Wg, feat_off, Wf, sh_degree, feat_first, sigma_act, rad_in,
+                       sigma, n, n_ptr);
+    return check_launch("ngp_glue_fwd_rays");
 }
 
 ARCN_EXPORT int arcn_ngp_glue_bwd(const float *geo_out, const float *d_rad_in, const float *d_sigma, int Wg, int feat_off,

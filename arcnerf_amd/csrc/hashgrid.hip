@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(const float *__restri
 // LM: level-major output out[(l * n_cap + s) * F + f] (coalesced stores); otherwise the usual row-major (n, L*F).
 struct LmPlan {
     int32_t levels[8][4];   // up to 4 levels per XCD slot (-1 = none)
-    int32_t tiles;          // 256-sample tiles (from the capacity)
+    int32_t tiles;          // workgroups per (XCD, level): each walks the 256-sample tiles with this stride
 };
 
 template <int F, bool LM>
@@ -210,12 +210,13 @@ hashgrid_fwd_xcd_kernel(const float *__restrict__ xyz, const float *__restrict__
     const int64_t cnt = dev_count(n, n_ptr);
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;  // position inside this XCD's queue
-    const int li = j / plan.tiles, tile = j - li * plan.tiles;
+    const int li = j / plan.tiles, slot = j - li * plan.tiles;
     const int l = plan.levels[xcd][li];
     if (l < 0) return;
-    const int64_t s = (int64_t)tile * 256 + threadIdx.x;
-    if (s >= cnt) return;
     const LevelParams lp = g.lv[l];
+    // plan.tiles workgroups per (XCD, level) walk the 256-sample tiles: the grid does not grow with the buffer capacity (a
+    // capacity-sized grid dispatched 3 empty workgroups for every busy one)
+    for (int64_t s = (int64_t)slot * 256 + threadIdx.x; s < cnt; s += (int64_t)plan.tiles * 256) {
     const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
     const Cell cell = locate(p, g, lp);
     float acc[F];
@@ -251,6 +252,7 @@ hashgrid_fwd_xcd_kernel(const float *__restrict__ xyz, const float *__restrict__
     else {
 #pragma unroll
         for (int f = 0; f < F; ++f) o[f] = acc[f];
+    }
     }
 }
 
@@ -865,7 +867,10 @@ ARCN_EXPORT int arcn_hashgrid_fwd_xcd(const float *xyz, const float *table, cons
     }
     int per = 0;
     for (int x = 0; x < 8; ++x) per = fill[x] > per ? fill[x] : per;
-    plan.tiles = (int)ceil_div<int64_t>(n, 256);
+    static const int xcd_tiles = [] { const char *e = getenv("ARCN_HASH_FWD_TILES"); return e ? atoi(e) : 512; }();
+    int64_t tiles = ceil_div<int64_t>(n, 256);
+    if (tiles > xcd_tiles) tiles = xcd_tiles;
+    plan.tiles = (int)tiles;
     dim3 grid((unsigned)(8 * per * plan.tiles));
 #define ARCN_XCD(F_, LM_) hipLaunchKernelGGL((hashgrid_fwd_xcd_kernel<F_, LM_>), grid, dim3(256), 0, as_stream(stream), xyz, table, g, plan, out, n_cap, n, n_ptr)
     if (g.F == 1) { if (level_major) ARCN_XCD(1, true); else ARCN_XCD(1, false); }

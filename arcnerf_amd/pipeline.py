@@ -225,6 +225,7 @@ class NgpPipeline:
         b['geo_scratch'] = torch.zeros(F.mlp_scratch_floats(field.geo_desc, S), dtype=f32, device=dev)
         b['rad_scratch'] = torch.zeros(F.mlp_scratch_floats(field.rad_desc, S), dtype=f32, device=dev)
         # per-ray outputs
+        b['sh_ray'] = torch.zeros((R, max(1, cfg.sh_degree ** 2)), dtype=f32, device=dev)
         b['rgb'] = torch.zeros((R, 3), dtype=f32, device=dev)
         b['depth'] = torch.zeros(R, dtype=f32, device=dev)
         b['mask'] = torch.zeros(R, dtype=f32, device=dev)
@@ -234,6 +235,8 @@ class NgpPipeline:
         self.hash_ws = F.hashgrid_bwd_workspace(self.field.grid_desc, S, dev) if xcd_scatter else None  # scatter bins
         # level-major features between the hash grid and the geometry net (XCD-affine gather, coalesced everywhere): the shapes
         # the *_lm entry points are wired for; anything else keeps the row-major buffers
+        self.ray_sh = (cfg.sh_degree >= 1 and field.feat_off == 0 and field.geo_out_dim % 4 == 0 and cfg.W_feat % 4 == 0 and
+                       (cfg.sh_degree ** 2) % 4 == 0)
         gd = [field.geo_desc.dims[i] for i in range(field.geo_desc.n_layers + 1)]
         self.level_major = bool(level_major and xcd_scatter and cfg.n_feat_per_entry == 2 and field.geo_desc.n_layers == 2 and
                                 not field.geo_desc.has_bias and gd[0] in (32, 64) and 48 < gd[1] <= 64 and gd[2] <= 16)
@@ -368,8 +371,15 @@ class NgpPipeline:
             F.hashgrid_fwd(b['xyz'], self._p('table'), fld.grid_desc, n_dev=n_dev, out=b['feat'])
             F.mlp_fwd(b['feat'], self._p('geo_w'), self._p('geo_b'), fld.geo_desc, save_acts=train, n_dev=n_dev, out=b['geo_out'],
                       acts=b['geo_acts'])
-        F.ngp_glue_fwd(b['geo_out'], b['dirs'], fld.feat_off, cfg.W_feat, cfg.sh_degree, feat_first=(cfg.rad_mode == 'fv'),
-                       sigma_act=cfg.sigma_act, n_dev=n_dev, rad_in=b['rad_in'], sigma=b['sigma'])
+        if self.ray_sh:
+            # view-direction harmonics once per ray, gathered per sample by ray id
+            N.check(L.arcn_ngp_ray_sh(N.ptr(rays_d), cfg.sh_degree, N.ptr(b['sh_ray']), R, st), 'ngp_ray_sh')
+            N.check(L.arcn_ngp_glue_fwd_rays(N.ptr(b['geo_out']), N.ptr(b['sh_ray']), N.ptr(b['ray_id']), fld.geo_out_dim, fld.feat_off,
+                                             cfg.W_feat, cfg.sh_degree, int(cfg.rad_mode == 'fv'), N.ACT[cfg.sigma_act],
+                                             N.ptr(b['rad_in']), N.ptr(b['sigma']), S, n_dev.data_ptr(), st), 'ngp_glue_fwd_rays')
+        else:
+            F.ngp_glue_fwd(b['geo_out'], b['dirs'], fld.feat_off, cfg.W_feat, cfg.sh_degree, feat_first=(cfg.rad_mode == 'fv'),
+                           sigma_act=cfg.sigma_act, n_dev=n_dev, rad_in=b['rad_in'], sigma=b['sigma'])
         F.mlp_fwd(b['rad_in'], self._p('rad_w'), self._p('rad_b'), fld.rad_desc, save_acts=train, n_dev=n_dev, out=b['rgb_s'],
                   acts=b['rad_acts'])
         bk, bk_rows = (None, 0) if bkg_color is None else (bkg_color.contiguous().float().view(-1, 3), bkg_color.view(-1, 3).shape[0])

@@ -147,6 +147,13 @@ int arcn_sh_fwd(const float *dirs, int degree, int include_input, float *out, in
 int arcn_ngp_glue_fwd(const float *geo_out, const float *dirs, int Wg, int feat_off, int Wf, int sh_degree,
                       int feat_first, int sigma_act, float *rad_in, float *sigma, int64_t n, const int32_t *n_ptr,
                       void *stream);
+/* the same with the view-direction part evaluated once per RAY: arcn_ngp_ray_sh fills sh_ray (n_rays, deg^2) =
+ * SH(normalize(rays_d)) and the glue gathers row ray_id[s] (bit-identical: every sample of a ray carries the ray's
+ * direction, fg_model.py:311-316).  Needs feat_off 0 and Wg, Wf, deg^2 multiples of 4. */
+int arcn_ngp_ray_sh(const float *rays_d, int sh_degree, float *sh_ray, int64_t n_rays, void *stream);
+int arcn_ngp_glue_fwd_rays(const float *geo_out, const float *sh_ray, const int32_t *ray_id, int Wg, int feat_off, int Wf,
+                           int sh_degree, int feat_first, int sigma_act, float *rad_in, float *sigma, int64_t n,
+                           const int32_t *n_ptr, void *stream);
 /* backward of the glue: d_geo_out (n,Wg) = scatter(d_rad_in feature slice) + d_sigma * sigma_act'(geo_out[:,0]). */
 int arcn_ngp_glue_bwd(const float *geo_out, const float *d_rad_in, const float *d_sigma, int Wg, int feat_off, int Wf,
                       int sh_degree, int feat_first, int sigma_act, float *d_geo_out, int64_t n, const int32_t *n_ptr,

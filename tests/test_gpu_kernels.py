@@ -364,6 +364,27 @@ def test_level_major_variants_match_row_major(F):
     assert lib.arcn_mlp_fwd_lm(N.ptr(lm), cap, N.ptr(w), C.addressof(bad), N.ptr(out), None, cap, S, None, st) == -1
 
 
+def test_glue_with_per_ray_harmonics_is_bit_identical(F):
+    import ctypes as C
+    from arcnerf_amd import _native as N
+    rng = np.random.default_rng(4)
+    R, S = 300, 7000
+    rays_d = dev((rng.normal(size=(R, 3)) * rng.uniform(0.5, 2.0, size=(R, 1))).astype(np.float32))
+    ray_id = torch.from_numpy(np.sort(rng.integers(0, R, size=S)).astype(np.int32)).cuda()
+    dirs = rays_d[ray_id.long()].contiguous()
+    geo = dev(rng.normal(size=(S, 16)).astype(np.float32))
+    for feat_first in (True, False):
+        ref_in, ref_sigma = F.ngp_glue_fwd(geo, dirs, 0, 16, 4, feat_first=feat_first, sigma_act='truncexp')
+        sh_ray = torch.zeros(R, 16, device='cuda')
+        rad_in = torch.zeros(S, 32, device='cuda')
+        sigma = torch.zeros(S, device='cuda')
+        lib, st = N.lib(), N.stream()
+        N.check(lib.arcn_ngp_ray_sh(N.ptr(rays_d), 4, N.ptr(sh_ray), R, st))
+        N.check(lib.arcn_ngp_glue_fwd_rays(N.ptr(geo), N.ptr(sh_ray), N.ptr(ray_id), 16, 0, 16, 4, int(feat_first), N.ACT['truncexp'],
+                                           N.ptr(rad_in), N.ptr(sigma), S, None, st))
+        assert torch.equal(rad_in, ref_in) and torch.equal(sigma, ref_sigma)
+
+
 def test_hashgrid_scatter_bin_overflow_and_runs(F, oracle):
     """Adversarial sample distributions for the binned scatter: (a) samples alternating between two far-apart cells (runs of
     length 1, every record of a hashed level lands in the same <= 8 bins: their fixed capacity overflows and the direct-atomic
