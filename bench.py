@@ -37,7 +37,7 @@ def parse():
     ap.add_argument('--occupancy', type=float, default=0.05)
     ap.add_argument('--no-occ-update', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-rays', type=int, default=49152)
+    ap.add_argument('--cpu-rays', type=int, default=131072)
     return ap.parse_args()
 
 
