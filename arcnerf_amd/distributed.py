@@ -73,6 +73,42 @@ def allreduce_grads(flat_grads, world=None, group=None):
     return flat_grads
 
 
+def grad_segments(n_total, k, align=4096):
+    """k contiguous [lo, hi) segments covering n_total elements, boundaries aligned to `align` elements (last one ragged)."""
+    k = max(1, int(k))
+    per = -(-int(n_total) // k)
+    per = -(-per // align) * align
+    segs, lo = [], 0
+    while lo < n_total:
+        hi = min(int(n_total), lo + per)
+        segs.append((lo, hi))
+        lo = hi
+    return segs
+
+
+class PipelinedGradSync:
+    """The per-step gradient all-reduce in K segments, each launched asynchronously (`async_op=True`: the collective waits for the
+    kernels already queued on the current stream and then runs on the communicator's own stream), so the optimiser can update
+    segment i while segments i+1.. are still on the wire: the fused Adam/EMA pass (HBM-bound, ~70 us for the NGP parameter
+    set) hides behind the ring instead of following it.  Same arithmetic as one flat all-reduce: a SUM per element."""
+
+    def __init__(self, n_total, n_segments=4, group=None):
+        self.group = group
+        self.segments = grad_segments(n_total, n_segments)
+        self.works = []
+
+    def launch(self, flat_grads):
+        self.works = []
+        if not (dist.is_initialized() and dist.get_world_size(self.group) > 1):
+            return
+        for lo, hi in self.segments:
+            self.works.append(dist.all_reduce(flat_grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self, i):
+        if self.works:
+            self.works[i].wait()
+
+
 def broadcast_bitfield(bits, src=0, group=None):
     """Make every rank march the same occupancy: broadcast the packed bitfield (uint8, n_grid^3/8 bytes) from `src`."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -203,6 +203,9 @@ class NgpPipeline:
         self._prefetched = None
         self._next_rays = None
         self.prefetch_at = int(os.environ.get('ARCN_PREFETCH_AT', '1'))
+        # multi-rank: the compute units idle while the gradient all-reduce is on the wire - march the next batch there
+        self.prefetch_at_dist = int(os.environ.get('ARCN_PREFETCH_AT_DIST', '3'))
+        self._prefetch_now = self.prefetch_at
         self.aux_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
         self.use_streams = self.aux_stream is not None
         b['xyz'] = torch.zeros((S, 3), dtype=f32, device=dev)
@@ -438,28 +441,42 @@ class NgpPipeline:
         loss, d = F.huber_loss_grad(rgb, target, cfg.huber_delta, cfg.loss_weight, dx=b['d_rgb'][:R], loss=b['loss'])
         return loss[0], d
 
-    def optimizer_step(self, world_size=1):
+    def optimizer_step(self, world_size=1, lo=None, hi=None, advance=True):
+        """fused Adam + EMA (+ gradient clear) on the whole flat buffer or on its slice [lo, hi) (pipelined gradient sync:
+        one call per segment, `advance` only on the first so every segment sees the same step count)."""
         cfg, fld = self.cfg, self.field
-        self.step_count += 1
-        F.adam_ema_step(fld.params, fld.grads, self.exp_avg, self.exp_avg_sq, self.ema, self.step_count, lr=cfg.lr,
+        if advance:
+            self.step_count += 1
+        sl = slice(lo, hi)
+        F.adam_ema_step(fld.params[sl], fld.grads[sl], self.exp_avg[sl], self.exp_avg_sq[sl], self.ema[sl], self.step_count, lr=cfg.lr,
                         betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, ema_decay=cfg.ema_decay,
                         grad_scale=1.0 / world_size, zero_grad=True)
 
-    def train_step(self, rays_o, rays_d, target_rgb, bkg_color=None, all_reduce=None, world_size=1, next_rays=None):
+    def train_step(self, rays_o, rays_d, target_rgb, bkg_color=None, all_reduce=None, world_size=1, next_rays=None, grad_sync=None):
         """fwd + loss + bwd (+ one gradient all-reduce) + Adam/EMA.  Returns the loss tensor (device, no sync).
-        next_rays = (rays_o, rays_d) of the FOLLOWING step: their marching is overlapped with this step's backward."""
+        next_rays = (rays_o, rays_d) of the FOLLOWING step: their marching is overlapped with this step's backward.
+        grad_sync: a distributed.PipelinedGradSync (takes precedence over the flat `all_reduce` callable)."""
         cfg, b = self.cfg, self.buf
         noise = None
         if cfg.noise_std > 0:
             noise = b['noise'].normal_(0.0, cfg.noise_std)
         rgb, _, _ = self.forward(rays_o, rays_d, bkg_color, train=True, noise=noise)
         self._next_rays = next_rays
+        self._prefetch_now = self.prefetch_at if (grad_sync is None and all_reduce is None) else self.prefetch_at_dist
         self._prefetch_point(0)
         loss, d_rgb = self.huber_grad(rgb, target_rgb)
         self.backward(rays_o, rays_d, d_rgb)
+        if grad_sync is not None:
+            # segmented all-reduce pipelined with the optimiser (distributed.PipelinedGradSync)
+            grad_sync.launch(self.field.grads)
+            self._prefetch_point(3)
+            for i, (lo, hi) in enumerate(grad_sync.segments):
+                grad_sync.wait(i)
+                self.optimizer_step(world_size, lo, hi, advance=(i == 0))
+            return loss
+        self._prefetch_point(3)  # before a blocking collective is queued: the second stream only waits for the backward
         if all_reduce is not None:
             all_reduce(self.field.grads)
-        self._prefetch_point(3)
         self.optimizer_step(world_size)
         return loss
 
@@ -467,7 +484,7 @@ class NgpPipeline:
         """Issue the next batch's marching (second stream) at point `where` of the step: 0 after the forward, 1 before the
         geometry-net backward, 2 before the hash-grid scatter, 3 before the optimiser.  The marcher is pure VALU work with a
         256 KiB working set; it costs least next to the LDS / HBM-bound kernels."""
-        if getattr(self, '_next_rays', None) is not None and where == self.prefetch_at:
+        if getattr(self, '_next_rays', None) is not None and where == self._prefetch_now:
             self.prefetch_samples(*self._next_rays)
             self._next_rays = None
 

@@ -140,6 +140,9 @@ def main():
     timers = KernelTimers()
     instrument(timers)
     all_reduce = (lambda t: D.allreduce_grads(t, world)) if world > 1 else None
+    # gradient sync: K async segments pipelined with the optimiser (default) or one flat all-reduce (ARCN_GRAD_SEGMENTS=0)
+    n_seg = int(os.environ.get('ARCN_GRAD_SEGMENTS', '4'))
+    grad_sync = D.PipelinedGradSync(field.n_params, n_seg) if (world > 1 and n_seg > 0) else None
     sample_log = torch.zeros(args.steps + args.warmup + 16, dtype=torch.int64, device=dev)
 
     def run(step_idx, epoch):
@@ -147,7 +150,8 @@ def main():
         nxt = pool[(step_idx + 1) % n_pool]
         # the next batch's rays are known (the reference precaches and shuffles them on the GPU): its marching is issued on
         # a second stream and overlaps this step's backward
-        pipe.train_step(o, d, tgt, bkg_color=bkg, all_reduce=all_reduce, world_size=world, next_rays=(nxt[0], nxt[1]))
+        pipe.train_step(o, d, tgt, bkg_color=bkg, all_reduce=all_reduce, world_size=world, next_rays=(nxt[0], nxt[1]),
+                        grad_sync=grad_sync)
         sample_log[step_idx] = pipe.n_dev[0]
         if not args.no_occ_update:
             pipe.update_occupancy(epoch, apply=False)

@@ -99,3 +99,46 @@ def test_single_process_helpers_are_noops():
     t = torch.ones(4)
     assert D.allreduce_grads(t, 1) is t and D.broadcast_bitfield(t) is t and D.broadcast_params(t) is t
     assert D.max_over_ranks(3.5) == 3.5
+
+
+def _sync_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    D.init_from_env(backend='gloo')
+    n = 100003
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = torch.randn(n, generator=g)
+    flat = grads.clone()
+    D.allreduce_grads(flat, world)
+    sync = D.PipelinedGradSync(n, n_segments=4)
+    seg = grads.clone()
+    sync.launch(seg)
+    updated = torch.zeros(n)
+    for i, (lo, hi) in enumerate(sync.segments):      # what train_step does: wait for segment i, update it, go on
+        sync.wait(i)
+        updated[lo:hi] = -0.1 * seg[lo:hi]
+    ret[rank] = (flat.numpy(), seg.numpy(), updated.numpy(), sync.segments)
+    dist.destroy_process_group()
+
+
+def test_pipelined_gradient_sync_equals_flat_allreduce():
+    """K asynchronous segment all-reduces (the multi-GPU step's gradient sync) give bit-identical sums to the single flat
+    collective, the segments tile the buffer exactly once, and every rank ends with the same update."""
+    segs = D.grad_segments(12215736, 4)
+    assert segs[0][0] == 0 and segs[-1][1] == 12215736 and all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
+    assert all(lo % 4096 == 0 for lo, _ in segs) and len(segs) == 4
+    assert D.grad_segments(10, 4) == [(0, 10)]
+    world = 2
+    ctx = mp.get_context('spawn')
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs)
+    f0, s0, u0, segs0 = ret[0]
+    f1, s1, u1, _ = ret[1]
+    assert np.array_equal(f0, s0) and np.array_equal(f1, s1) and np.array_equal(s0, s1)
+    assert np.array_equal(u0, u1) and np.array_equal(u0, -0.1 * s0)
+    assert len(segs0) == 4
