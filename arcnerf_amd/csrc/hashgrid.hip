@@ -297,7 +297,6 @@ struct BinPlan {
     uint32_t pair_levels;                     // hashed power-of-two levels with more than one chunk: <= 4 pair records per sample
     uint32_t nosplit_levels;                  // chunk rows > res on a hashed level: both rows of an x pair ALWAYS share the chunk
     int32_t n_bins;
-    int32_t debug;
     int32_t chunk_floats;                     // LDS accumulator floats per workgroup (rows per chunk * F)
     int64_t n_recs;
 };
@@ -368,11 +367,6 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
             g0 = gp[0];
             g1 = F > 1 ? gp[F > 1 ? 1 : 0] : 0.f;
         }
-    }
-    if (plan.debug & 16) {  // timing aid: loads + cell only
-        if (g0 == 12345.678f && cell.w[0] == 0.3f) counters[0] = 1u;
-        __syncthreads();
-        continue;
     }
     // runs of consecutive samples (lanes) in the same cell: head lanes, and for every lane the last lane of its run
     const uint32_t kxy = cell.valid ? (cell.c[0] | (cell.c[1] << 16)) : 0xffffffffu;
@@ -474,14 +468,6 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
             }
         }
     }
-    if (plan.debug & 32) {  // timing aid: records built, nothing ranked or stored
-        float acc_dbg = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc_dbg += (sbin[k] >= 0) ? sa[k] + sb[k] + swx[k] + (float)sidx[k] : 0.f;
-        if (acc_dbg == 12345.678f) counters[0] = 1u;
-        __syncthreads();
-        continue;
-    }
     uint32_t rank[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) rank[k] = (k < n_slots && sbin[k] >= 0) ? atomicAdd(&hist[sbin[k]], 1u) : 0u;
@@ -489,7 +475,7 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
     // reserve the tile's run in every bin: one global integer atomic per (bin, tile)
     for (int i = threadIdx.x; i < nc; i += kBinThreads) {
         const uint32_t h = hist[i];
-        gbase[i] = (h && !(plan.debug & 8)) ? atomicAdd(&counters[plan.bin_first[l] + i], h) : 0u;
+        gbase[i] = h ? atomicAdd(&counters[plan.bin_first[l] + i], h) : 0u;
     }
     __syncthreads();
     const uint32_t cap = (uint32_t)plan.cap[l];
@@ -498,7 +484,6 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
     for (int k = 0; k < 8; ++k) {
         if (k >= n_slots || sbin[k] < 0) continue;
         const uint4 rec = make_uint4(sidx[k], __float_as_uint(swx[k]), __float_as_uint(sa[k]), __float_as_uint(sb[k]));
-        if (plan.debug & 4) continue;
         emit_record<F>(lrecs, dtable, lp, sbin[k], gbase[sbin[k]] + rank[k], cap, shift, rec);
     }
     __syncthreads();  // hist / gbase are reused by the next tile
@@ -540,7 +525,7 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
     // A bin is only ~32 records per thread: with one load in flight per thread the loop would be bound by memory latency.
     // Each trip takes kUnroll records per thread (the next group's loads are issued before the current group is applied).
     constexpr int kUnroll = 4;
-    const uint32_t trips = (plan.debug & 1) ? 0u : (len + kTiledThreads * kUnroll - 1) / (kTiledThreads * kUnroll);
+    const uint32_t trips = (len + kTiledThreads * kUnroll - 1) / (kTiledThreads * kUnroll);
     const uint4 none = make_uint4(0xffffffffu, 0u, 0u, 0u);  // i0 = i1 = 0xffff: nothing to do
     uint32_t i = threadIdx.x;
     uint4 nxt[kUnroll];
@@ -604,7 +589,6 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
     }
     __syncthreads();
     float *dst = dtable + ((int64_t)lp.offset + row_lo) * F;
-    if (plan.debug & 2) return;
     if (ns == 1) {
         // exclusive owner: plain coalesced 16-byte stores (+= so that callers accumulating over several launches stay correct);
         // the global loads of a batch are all issued before the first add, or the loop would run at memory latency
@@ -689,8 +673,6 @@ static int build_bin_plan(const GridParams &g, int64_t n, BinPlan &plan) {
         return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffffffu;
     }();
     plan.active_levels = active;
-    static const int dbg = [] { const char *e = getenv("ARCN_SCATTER_DEBUG"); return e ? atoi(e) : 0; }();
-    plan.debug = dbg;
     plan.lock_levels = 0u;
     plan.pair_levels = 0u;
     plan.nosplit_levels = 0u;
