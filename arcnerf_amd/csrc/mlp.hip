@@ -339,6 +339,39 @@ __device__ __forceinline__ void store_tiles_lm2(const f4 (&v)[4][NT], float *__r
     }
 }
 
+// "Concat" network input, XMODE 2: x = [A | B] (a_first) or [B | A], 16 columns each.  A is row-major (n, 16) per sample;
+// B is a small table gathered by an index per sample (the per-ray spherical harmonics, by ray id).  This is the radiance net of
+// Base3dModel._forward_pts_dir (base_3d_model.py:233-254) with fuse_radiance_inputs (encoder_mlp_network.py:93-118) folded
+// into the first layer's operand load: no (n, 32) input buffer, no glue kernel.  Optional head: head_out[s] =
+// act(A[s][0]) (sigma, EncoderMLPGeoNet.handle_output) on the way in; its gradient d_head[s] * act'(A[s][0]) is added to
+// column 0 of dA on the way out.
+struct MlpCat {
+    const float *b_table;
+    const int32_t *b_index;
+    float *head_out;
+    const float *d_head;
+    int32_t a_first, head_act;
+};
+
+template <int NT>
+__device__ __forceinline__ void load_tiles_cat(f4 (&v)[4][NT], const float *__restrict__ a, const MlpCat &c, int64_t s0, int64_t cnt,
+                                               int g, int j, bool write_head) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int64_t s = s0 + 16 * nt + j;
+        f4 fa = {0.f, 0.f, 0.f, 0.f}, fb = {0.f, 0.f, 0.f, 0.f};
+        if (s < cnt) {
+            fa = *reinterpret_cast<const f4 *>(a + s * 16 + 4 * g);
+            fb = *reinterpret_cast<const f4 *>(c.b_table + (int64_t)c.b_index[s] * 16 + 4 * g);
+            if (write_head && c.head_out && g == 0) c.head_out[s] = act_fwd(fa.x, c.head_act, 1.0f);
+        }
+        v[0][nt] = c.a_first ? fa : fb;
+        v[1][nt] = c.a_first ? fb : fa;
+        v[2][nt] = f4{0.f, 0.f, 0.f, 0.f};
+        v[3][nt] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 // activation of MT tiles, the switch hoisted out of the element loop
 template <int MT, int NT>
 __device__ __forceinline__ void act_tiles(f4 (&h)[4][NT], int act, float beta) {
@@ -380,9 +413,9 @@ __device__ __forceinline__ void zero_padded_rows(f4 (&h)[4][NT], int N, int g) {
     }
 }
 
-template <int T0, int T1, int T2, int T3, int NT, bool XLM>
+template <int T0, int T1, int T2, int T3, int NT, int XMODE>  // XMODE: 0 row-major x, 1 level-major x, 2 concat (MlpCat)
 __global__ void __launch_bounds__(256)
-mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, const float *__restrict__ weights, MlpParams P,
+mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, const float *__restrict__ weights, MlpParams P,
                      float *__restrict__ out, float *__restrict__ acts, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
     constexpr int NL = T3 ? 3 : 2;
     constexpr int TA = T3 ? T3 : 1;
@@ -398,7 +431,8 @@ mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, const float 
         const int64_t s0 = tile * SPW * 4 + (int64_t)wave * SPW;
         if (s0 >= cnt) continue;
         f4 h[4][NT], o[4][NT];
-        if (XLM) load_tiles_lm2<T0, NT>(h, x, x_stride, s0, cnt, g, j);
+        if (XMODE == 2) load_tiles_cat<NT>(h, x, cat, s0, cnt, g, j, true);
+        else if (XMODE == 1) load_tiles_lm2<T0, NT>(h, x, x_stride, s0, cnt, g, j);
         else load_tiles_fast<T0, NT>(h, x, P.dims[0], s0, cnt, g, j);
         auto zero = [&](f4 (&a)[4][NT]) {
 #pragma unroll
@@ -506,9 +540,9 @@ mlp_bwd_dx_kernel(const float *__restrict__ weights, MlpParams P, const float *_
 // waves are summed through LDS and the workgroup writes ONE partial per layer for mlp_dw_reduce_kernel.
 // T0..T3 = 16-wide tiles per layer boundary (T3 = 0: two layers); the dims themselves stay run-time (ragged widths are zero
 // padded by load_tiles / stage_fragments, so e.g. the 3-wide RGB output uses the T3 = 1 instance).
-template <int T0, int T1, int T2, int T3, int NT, bool XLM>
+template <int T0, int T1, int T2, int T3, int NT, int XMODE>
 __global__ void __launch_bounds__(256, 2)  // 2 workgroups per CU = 2 waves per SIMD: at most 256 VGPR + AGPR per lane
-mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, const float *__restrict__ weights, MlpParams P, const float *__restrict__ out,
+mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, const float *__restrict__ weights, MlpParams P, const float *__restrict__ out,
                      const float *__restrict__ acts, const float *__restrict__ dout, float *__restrict__ dx,
                      float *__restrict__ partials, int n_slots, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
     constexpr int NL = T3 ? 3 : 2;
@@ -623,13 +657,31 @@ mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, const float 
         accumulate(acc1, d, yp, std::integral_constant<int, T2>{}, std::integral_constant<int, T1>{});
         back(d, 1, T1, T2);
         if (P.act_hidden != ARCN_ACT_NONE) apply_act_grad(d, yp, P.act_hidden, std::integral_constant<int, T1>{});
-        if (XLM) load_tiles_lm2<T0, NT>(yp, x, x_stride, s0, cnt, g, j);
+        if (XMODE == 2) load_tiles_cat<NT>(yp, x, cat, s0, cnt, g, j, false);
+        else if (XMODE == 1) load_tiles_lm2<T0, NT>(yp, x, x_stride, s0, cnt, g, j);
         else load_tiles_fast<T0, NT>(yp, x, P.dims[0], s0, cnt, g, j);
         accumulate(acc0, d, yp, std::integral_constant<int, T1>{}, std::integral_constant<int, T0>{});
         if (dx) {
-            back(d, 0, T0, T1);
-            if (XLM) store_tiles_lm2<T0, NT>(d, dx, x_stride, s0, cnt, g, j);  // dx in the layout of x
-            else store_tiles_fast<T0, NT>(d, dx, P.dims[0], s0, cnt, g, j);
+            if (XMODE == 2) {
+                // only the A half of x has a gradient (B is a function of the ray direction): dA (n, 16) = that tile of
+                // W_0^T dpre_0, plus the head's gradient in column 0
+                back(d, 0, cat.a_first ? 1 : T0, T1);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int64_t s = s0 + 16 * nt + j;
+                    if (s >= cnt) continue;
+                    f4 r = cat.a_first ? d[0][nt] : d[1][nt];
+                    if (cat.d_head && g == 0) {
+                        const float x0 = cat.a_first ? yp[0][nt].x : yp[1][nt].x;
+                        r.x += cat.d_head[s] * act_grad(x0, act_fwd(x0, cat.head_act, 1.0f), cat.head_act, 1.0f);
+                    }
+                    *reinterpret_cast<f4 *>(dx + s * 16 + 4 * g) = r;
+                }
+            } else {
+                back(d, 0, T0, T1);
+                if (XMODE == 1) store_tiles_lm2<T0, NT>(d, dx, x_stride, s0, cnt, g, j);  // dx in the layout of x
+                else store_tiles_fast<T0, NT>(d, dx, P.dims[0], s0, cnt, g, j);
+            }
         }
     }
     // sum the 4 waves through LDS (the transposition tiles are free now: 4 x 2048 floats >= 16 tiles of 256) and write the
@@ -898,8 +950,9 @@ ARCN_EXPORT int64_t arcn_mlp_scratch_floats(const arcn_mlp_desc *d, int64_t n_ca
 }
 
 // x_stride = 0: x is (n, dims[0]) row-major; > 0: level-major, 2 features per level, level stride x_stride samples
-static int mlp_fwd_impl(const float *x, int64_t x_stride, const float *weights, const float *biases, const arcn_mlp_desc *desc_host,
-                        float *out, float *acts, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+static int mlp_fwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, const float *weights, const float *biases,
+                        const arcn_mlp_desc *desc_host, float *out, float *acts, int64_t n_cap, int64_t n, const int32_t *n_ptr,
+                        void *stream) {
     if (n <= 0) return ARCN_OK;
     if (!x || !weights || !out) return einval("mlp_fwd: missing argument");
     MlpParams P;
@@ -911,34 +964,44 @@ static int mlp_fwd_impl(const float *x, int64_t x_stride, const float *weights, 
     if (lds_bytes > 144 * 1024) return einval("mlp_fwd: network too large for the LDS-resident fused kernel");
     static const int fwd_nt = getenv("ARCN_MLP_NT") ? atoi(getenv("ARCN_MLP_NT")) : 2;  // 4 waves/SIMD beat 2 with wider tiles
     static const int fixed_ok = getenv("ARCN_MLP_FIXED_FWD") ? atoi(getenv("ARCN_MLP_FIXED_FWD")) : 1;
-    if ((fixed_ok || x_stride) && !P.has_bias && (P.n_layers == 2 || P.n_layers == 3) && md <= 64) {
+    MlpCat cat = {};
+    if (cat_in) cat = *cat_in;
+    if ((fixed_ok || x_stride || cat_in) && !P.has_bias && (P.n_layers == 2 || P.n_layers == 3) && md <= 64) {
         const int sig = tiles16(P.dims[0]) * 1000 + tiles16(P.dims[1]) * 100 + tiles16(P.dims[2]) * 10 +
                         (P.n_layers == 3 ? tiles16(P.dims[3]) : 0);
-#define ARCN_FIXED(T0, T1, T2, T3, XLM)                                                                                          \
+#define ARCN_FIXED(T0, T1, T2, T3, XMODE)                                                                                        \
     do {                                                                                                                         \
-        if ((rc = set_lds(mlp_fwd_fixed_kernel<T0, T1, T2, T3, 2, XLM>, lds_bytes))) return rc;                                   \
-        hipLaunchKernelGGL((mlp_fwd_fixed_kernel<T0, T1, T2, T3, 2, XLM>), dim3(tile_grid(n, 128)), dim3(256), lds_bytes,         \
-                           as_stream(stream), x, x_stride, weights, P, out, acts, n_cap, n, n_ptr);                               \
+        if ((rc = set_lds(mlp_fwd_fixed_kernel<T0, T1, T2, T3, 2, XMODE>, lds_bytes))) return rc;                                 \
+        hipLaunchKernelGGL((mlp_fwd_fixed_kernel<T0, T1, T2, T3, 2, XMODE>), dim3(tile_grid(n, 128)), dim3(256), lds_bytes,       \
+                           as_stream(stream), x, x_stride, cat, weights, P, out, acts, n_cap, n, n_ptr);                          \
         return check_launch("mlp_fwd_fixed");                                                                                    \
     } while (0)
-        if (x_stride) {
+        if (cat_in) {
+            if (P.dims[0] != 32) return einval("mlp_fwd_cat: the input must be 16 + 16 columns");
+            switch (sig) {
+            case 2441: ARCN_FIXED(2, 4, 4, 1, 2);
+            case 2410: ARCN_FIXED(2, 4, 1, 0, 2);
+            default: break;
+            }
+        } else if (x_stride) {
             if (P.dims[0] & 15) return einval("mlp_fwd_lm: input width must be a multiple of 16");
             switch (sig) {
-            case 2410: ARCN_FIXED(2, 4, 1, 0, true);
-            case 4410: ARCN_FIXED(4, 4, 1, 0, true);
+            case 2410: ARCN_FIXED(2, 4, 1, 0, 1);
+            case 4410: ARCN_FIXED(4, 4, 1, 0, 1);
             default: break;
             }
         } else {
             switch (sig) {
-            case 2410: ARCN_FIXED(2, 4, 1, 0, false);
-            case 4410: ARCN_FIXED(4, 4, 1, 0, false);
-            case 2441: ARCN_FIXED(2, 4, 4, 1, false);
-            case 4441: ARCN_FIXED(4, 4, 4, 1, false);
+            case 2410: ARCN_FIXED(2, 4, 1, 0, 0);
+            case 4410: ARCN_FIXED(4, 4, 1, 0, 0);
+            case 2441: ARCN_FIXED(2, 4, 4, 1, 0);
+            case 4441: ARCN_FIXED(4, 4, 4, 1, 0);
             default: break;
             }
         }
 #undef ARCN_FIXED
     }
+    if (cat_in) return einval("mlp_fwd_cat: only wired for bias-free nets 32 -> 64 [-> 64] -> <=16");
     if (x_stride) return einval("mlp_fwd_lm: level-major input is only wired for bias-free 2-layer nets (32|64 -> 64 -> <=16)");
     if (md <= 64 && fwd_nt == 2) {
         if ((rc = set_lds(mlp_fwd_kernel<4, 2>, lds_bytes))) return rc;
@@ -958,16 +1021,26 @@ static int mlp_fwd_impl(const float *x, int64_t x_stride, const float *weights, 
 
 ARCN_EXPORT int arcn_mlp_fwd(const float *x, const float *weights, const float *biases, const arcn_mlp_desc *desc_host,
                              float *out, float *acts, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
-    return mlp_fwd_impl(x, 0, weights, biases, desc_host, out, acts, n_cap, n, n_ptr, stream);
+    return mlp_fwd_impl(x, 0, nullptr, weights, biases, desc_host, out, acts, n_cap, n, n_ptr, stream);
 }
 
 ARCN_EXPORT int arcn_mlp_fwd_lm(const float *x_lm, int64_t x_stride, const float *weights, const arcn_mlp_desc *desc_host,
                                 float *out, float *acts, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
     if (x_stride < n) return einval("mlp_fwd_lm: level stride smaller than n");
-    return mlp_fwd_impl(x_lm, x_stride, weights, nullptr, desc_host, out, acts, n_cap, n, n_ptr, stream);
+    return mlp_fwd_impl(x_lm, x_stride, nullptr, weights, nullptr, desc_host, out, acts, n_cap, n, n_ptr, stream);
 }
 
-static int mlp_bwd_impl(const float *x, int64_t x_stride, const float *weights, const float *biases, const arcn_mlp_desc *desc_host,
+ARCN_EXPORT int arcn_mlp_fwd_cat(const float *a, const float *b_table, const int32_t *b_index, int a_first, const float *weights,
+                                 const arcn_mlp_desc *desc_host, float *out, float *acts, float *head_out, int head_act,
+                                 int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!a || !b_table || !b_index) return einval("mlp_fwd_cat: missing argument");
+    MlpCat cat = {b_table, b_index, head_out, nullptr, a_first ? 1 : 0, head_act};
+    return mlp_fwd_impl(a, 0, &cat, weights, nullptr, desc_host, out, acts, n_cap, n, n_ptr, stream);
+}
+
+static int mlp_bwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, const float *weights, const float *biases,
+                        const arcn_mlp_desc *desc_host,
                         const float *out, const float *acts, const float *dout, float *dx, float *dweights,
                         float *dbiases, float *scratch, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
     (void)biases;
@@ -982,12 +1055,15 @@ static int mlp_bwd_impl(const float *x, int64_t x_stride, const float *weights, 
     if (lds_bytes > 144 * 1024) return einval("mlp_bwd: network too large for the LDS-resident fused kernel");
     static const int bwd_nt = getenv("ARCN_MLP_BWD_NT") ? atoi(getenv("ARCN_MLP_BWD_NT")) : 2;
     static const int fused_ok = getenv("ARCN_MLP_FUSED_BWD") ? atoi(getenv("ARCN_MLP_FUSED_BWD")) : 1;
-    if (dweights && (fused_ok || x_stride) && !P.has_bias && (P.n_layers == 2 || P.n_layers == 3) && md <= 64) {
+    MlpCat cat = {};
+    if (cat_in) cat = *cat_in;
+    if (dweights && (fused_ok || x_stride || cat_in) && !P.has_bias && (P.n_layers == 2 || P.n_layers == 3) && md <= 64) {
         // fused dx + dW for the tile shapes of the NGP nets; anything else takes the two-kernel path below
         const int t0 = tiles16(P.dims[0]), t1 = tiles16(P.dims[1]), t2 = tiles16(P.dims[2]);
         const int t3 = P.n_layers == 3 ? tiles16(P.dims[3]) : 0;
         const int sig = t0 * 1000 + t1 * 100 + t2 * 10 + t3;
-        if (x_stride ? (sig == 2410 || sig == 4410) : (sig == 2410 || sig == 2441 || sig == 4410 || sig == 4441)) {
+        if (cat_in ? ((sig == 2441 || sig == 2410) && P.dims[0] == 32)
+                   : x_stride ? (sig == 2410 || sig == 4410) : (sig == 2410 || sig == 2441 || sig == 4410 || sig == 4441)) {
             const size_t fused_lds = lds_bytes + sizeof(float) * 8192;  // + one 8 KiB transposition area per wave
             int64_t grid = tile_grid(n, 64);
             if (grid > dw_slabs(n_cap)) grid = dw_slabs(n_cap);
@@ -998,20 +1074,23 @@ static int mlp_bwd_impl(const float *x, int64_t x_stride, const float *weights, 
             for (int l = 0; l <= P.n_layers; ++l) D.dims[l] = P.dims[l];
             for (int l = 0; l < P.n_layers; ++l) { D.w_off[l] = P.w_off[l]; D.b_off[l] = P.b_off[l]; D.quad_first[l] = l; }
             D.quad_first[P.n_layers] = P.n_layers;
-#define ARCN_FUSED(T0, T1, T2, T3, NT, XLM)                                                                                     \
+#define ARCN_FUSED(T0, T1, T2, T3, NT, XMODE)                                                                                   \
     do {                                                                                                                         \
-        if ((rc = set_lds(mlp_bwd_fused_kernel<T0, T1, T2, T3, NT, XLM>, fused_lds))) return rc;                                  \
-        hipLaunchKernelGGL((mlp_bwd_fused_kernel<T0, T1, T2, T3, NT, XLM>), dim3((unsigned)grid), dim3(256), fused_lds,          \
-                           as_stream(stream), x, x_stride, weights, P, out, acts, dout, dx, partials, (int)grid, n_cap, n, n_ptr); \
+        if ((rc = set_lds(mlp_bwd_fused_kernel<T0, T1, T2, T3, NT, XMODE>, fused_lds))) return rc;                                \
+        hipLaunchKernelGGL((mlp_bwd_fused_kernel<T0, T1, T2, T3, NT, XMODE>), dim3((unsigned)grid), dim3(256), fused_lds,        \
+                           as_stream(stream), x, x_stride, cat, weights, P, out, acts, dout, dx, partials, (int)grid, n_cap, n,   \
+                           n_ptr);                                                                                               \
     } while (0)
             static const int fused_nt3 = getenv("ARCN_MLP_FUSED_NT3") ? atoi(getenv("ARCN_MLP_FUSED_NT3")) : 1;
-            if (x_stride) {
-                if (sig == 2410) ARCN_FUSED(2, 4, 1, 0, 2, true); else ARCN_FUSED(4, 4, 1, 0, 2, true);
+            if (cat_in) {
+                if (sig == 2441) ARCN_FUSED(2, 4, 4, 1, 1, 2); else ARCN_FUSED(2, 4, 1, 0, 2, 2);
+            } else if (x_stride) {
+                if (sig == 2410) ARCN_FUSED(2, 4, 1, 0, 2, 1); else ARCN_FUSED(4, 4, 1, 0, 2, 1);
             } else switch (sig) {
-            case 2410: ARCN_FUSED(2, 4, 1, 0, 2, false); break;
-            case 4410: ARCN_FUSED(4, 4, 1, 0, 2, false); break;
-            case 2441: if (fused_nt3 == 2) ARCN_FUSED(2, 4, 4, 1, 2, false); else ARCN_FUSED(2, 4, 4, 1, 1, false); break;
-            default: ARCN_FUSED(4, 4, 4, 1, 1, false); break;
+            case 2410: ARCN_FUSED(2, 4, 1, 0, 2, 0); break;
+            case 4410: ARCN_FUSED(4, 4, 1, 0, 2, 0); break;
+            case 2441: if (fused_nt3 == 2) ARCN_FUSED(2, 4, 4, 1, 2, 0); else ARCN_FUSED(2, 4, 4, 1, 1, 0); break;
+            default: ARCN_FUSED(4, 4, 4, 1, 1, 0); break;
             }
 #undef ARCN_FUSED
             hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(16, (unsigned)P.n_layers, 8), dim3(256), 0, as_stream(stream), partials,
@@ -1019,6 +1098,7 @@ static int mlp_bwd_impl(const float *x, int64_t x_stride, const float *weights, 
             return check_launch("mlp_bwd_fused");
         }
     }
+    if (cat_in) return einval("mlp_bwd_cat: needs dweights and a bias-free net 32 -> 64 [-> 64] -> <=16");
     if (x_stride) return einval("mlp_bwd_lm: level-major input needs dweights and a bias-free 2-layer net (32|64 -> 64 -> <=16)");
     if (md <= 64 && bwd_nt == 2) {
         if ((rc = set_lds(mlp_bwd_dx_kernel<4, 2>, lds_bytes))) return rc;
@@ -1041,7 +1121,8 @@ static int mlp_bwd_impl(const float *x, int64_t x_stride, const float *weights, 
 ARCN_EXPORT int arcn_mlp_bwd(const float *x, const float *weights, const float *biases, const arcn_mlp_desc *desc_host,
                              const float *out, const float *acts, const float *dout, float *dx, float *dweights,
                              float *dbiases, float *scratch, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
-    return mlp_bwd_impl(x, 0, weights, biases, desc_host, out, acts, dout, dx, dweights, dbiases, scratch, n_cap, n, n_ptr, stream);
+    return mlp_bwd_impl(x, 0, nullptr, weights, biases, desc_host, out, acts, dout, dx, dweights, dbiases, scratch, n_cap, n, n_ptr,
+                        stream);
 }
 
 ARCN_EXPORT int arcn_mlp_bwd_lm(const float *x_lm, int64_t x_stride, const float *weights, const arcn_mlp_desc *desc_host,
@@ -1049,8 +1130,19 @@ ARCN_EXPORT int arcn_mlp_bwd_lm(const float *x_lm, int64_t x_stride, const float
                                 float *scratch, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
     if (x_stride < n) return einval("mlp_bwd_lm: level stride smaller than n");
     if (!dweights) return einval("mlp_bwd_lm: dweights required");
-    return mlp_bwd_impl(x_lm, x_stride, weights, nullptr, desc_host, out, acts, dout, dx_lm, dweights, nullptr, scratch, n_cap, n,
-                        n_ptr, stream);
+    return mlp_bwd_impl(x_lm, x_stride, nullptr, weights, nullptr, desc_host, out, acts, dout, dx_lm, dweights, nullptr, scratch, n_cap,
+                        n, n_ptr, stream);
+}
+
+ARCN_EXPORT int arcn_mlp_bwd_cat(const float *a, const float *b_table, const int32_t *b_index, int a_first, const float *weights,
+                                 const arcn_mlp_desc *desc_host, const float *out, const float *acts, const float *dout, float *da,
+                                 const float *d_head, int head_act, float *dweights, float *scratch, int64_t n_cap, int64_t n,
+                                 const int32_t *n_ptr, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!a || !b_table || !b_index || !dweights) return einval("mlp_bwd_cat: missing argument");
+    MlpCat cat = {b_table, b_index, nullptr, d_head, a_first ? 1 : 0, head_act};
+    return mlp_bwd_impl(a, 0, &cat, weights, nullptr, desc_host, out, acts, dout, da, dweights, nullptr, scratch, n_cap, n, n_ptr,
+                        stream);
 }
 
 ARCN_EXPORT int arcn_mlp_bwd_dw(const float *x, const arcn_mlp_desc *desc_host, const float *acts, float *scratch,

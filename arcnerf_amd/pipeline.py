@@ -175,7 +175,7 @@ class NgpField:
 class NgpPipeline:
     """Pre-allocated buffers + the kernel sequence of one render / train step for a fixed ray capacity."""
 
-    def __init__(self, field, max_rays=32768, max_samples=1 << 19, packed_bits=True, torch_aabb=False, xcd_scatter=True, level_major=True):
+    def __init__(self, field, max_rays=32768, max_samples=1 << 19, packed_bits=True, torch_aabb=False, xcd_scatter=True, level_major=True, fused_glue=True):
         cfg = field.cfg
         self.field, self.cfg = field, cfg
         dev = field.device
@@ -240,6 +240,10 @@ class NgpPipeline:
         # the *_lm entry points are wired for; anything else keeps the row-major buffers
         self.ray_sh = (cfg.sh_degree >= 1 and field.feat_off == 0 and field.geo_out_dim % 4 == 0 and cfg.W_feat % 4 == 0 and
                        (cfg.sh_degree ** 2) % 4 == 0)
+        rd = [field.rad_desc.dims[i] for i in range(field.rad_desc.n_layers + 1)]
+        self.fused_glue = bool(fused_glue and self.ray_sh and field.geo_out_dim == 16 and cfg.W_feat == 16 and cfg.sh_degree == 4 and
+                               not field.rad_desc.has_bias and field.rad_desc.n_layers in (2, 3) and rd[0] == 32 and
+                               all(48 < w <= 64 for w in rd[1:-1]) and rd[-1] <= 16)
         gd = [field.geo_desc.dims[i] for i in range(field.geo_desc.n_layers + 1)]
         self.level_major = bool(level_major and xcd_scatter and cfg.n_feat_per_entry == 2 and field.geo_desc.n_layers == 2 and
                                 not field.geo_desc.has_bias and gd[0] in (32, 64) and 48 < gd[1] <= 64 and gd[2] <= 16)
@@ -374,17 +378,26 @@ class NgpPipeline:
             F.hashgrid_fwd(b['xyz'], self._p('table'), fld.grid_desc, n_dev=n_dev, out=b['feat'])
             F.mlp_fwd(b['feat'], self._p('geo_w'), self._p('geo_b'), fld.geo_desc, save_acts=train, n_dev=n_dev, out=b['geo_out'],
                       acts=b['geo_acts'])
-        if self.ray_sh:
-            # view-direction harmonics once per ray, gathered per sample by ray id
+        if self.fused_glue:
+            # view-direction harmonics once per ray; the radiance net assembles [geo features | SH(ray)] in its operand load and
+            # writes sigma = act(geo_out[:, 0]) on the way: no rad_in buffer, no glue kernel
             N.check(L.arcn_ngp_ray_sh(N.ptr(rays_d), cfg.sh_degree, N.ptr(b['sh_ray']), R, st), 'ngp_ray_sh')
-            N.check(L.arcn_ngp_glue_fwd_rays(N.ptr(b['geo_out']), N.ptr(b['sh_ray']), N.ptr(b['ray_id']), fld.geo_out_dim, fld.feat_off,
-                                             cfg.W_feat, cfg.sh_degree, int(cfg.rad_mode == 'fv'), N.ACT[cfg.sigma_act],
-                                             N.ptr(b['rad_in']), N.ptr(b['sigma']), S, n_dev.data_ptr(), st), 'ngp_glue_fwd_rays')
+            N.check(L.arcn_mlp_fwd_cat(N.ptr(b['geo_out']), N.ptr(b['sh_ray']), N.ptr(b['ray_id']), int(cfg.rad_mode == 'fv'),
+                                       N.ptr(self._p('rad_w')), N.C.addressof(fld.rad_desc), N.ptr(b['rgb_s']),
+                                       N.ptr(b['rad_acts']) if train else None, N.ptr(b['sigma']), N.ACT[cfg.sigma_act], S, S,
+                                       n_dev.data_ptr(), st), 'mlp_fwd_cat(rad)')
         else:
-            F.ngp_glue_fwd(b['geo_out'], b['dirs'], fld.feat_off, cfg.W_feat, cfg.sh_degree, feat_first=(cfg.rad_mode == 'fv'),
-                           sigma_act=cfg.sigma_act, n_dev=n_dev, rad_in=b['rad_in'], sigma=b['sigma'])
-        F.mlp_fwd(b['rad_in'], self._p('rad_w'), self._p('rad_b'), fld.rad_desc, save_acts=train, n_dev=n_dev, out=b['rgb_s'],
-                  acts=b['rad_acts'])
+            if self.ray_sh:
+                N.check(L.arcn_ngp_ray_sh(N.ptr(rays_d), cfg.sh_degree, N.ptr(b['sh_ray']), R, st), 'ngp_ray_sh')
+                N.check(L.arcn_ngp_glue_fwd_rays(N.ptr(b['geo_out']), N.ptr(b['sh_ray']), N.ptr(b['ray_id']), fld.geo_out_dim,
+                                                 fld.feat_off, cfg.W_feat, cfg.sh_degree, int(cfg.rad_mode == 'fv'),
+                                                 N.ACT[cfg.sigma_act], N.ptr(b['rad_in']), N.ptr(b['sigma']), S, n_dev.data_ptr(), st),
+                        'ngp_glue_fwd_rays')
+            else:
+                F.ngp_glue_fwd(b['geo_out'], b['dirs'], fld.feat_off, cfg.W_feat, cfg.sh_degree, feat_first=(cfg.rad_mode == 'fv'),
+                               sigma_act=cfg.sigma_act, n_dev=n_dev, rad_in=b['rad_in'], sigma=b['sigma'])
+            F.mlp_fwd(b['rad_in'], self._p('rad_w'), self._p('rad_b'), fld.rad_desc, save_acts=train, n_dev=n_dev, out=b['rgb_s'],
+                      acts=b['rad_acts'])
         bk, bk_rows = (None, 0) if bkg_color is None else (bkg_color.contiguous().float().view(-1, 3), bkg_color.view(-1, 3).shape[0])
         self._bkg = bk
         self._noise = noise
@@ -409,12 +422,19 @@ class NgpPipeline:
                                             N.ptr(b['d_sigma']), N.ptr(b['d_rgb_s']), st), 'composite_packed_bwd')
         S = self.cap
         # dx and dW of each net come out of ONE fused kernel (arcn_mlp_bwd with dweights): dpre never leaves the registers
-        N.check(L.arcn_mlp_bwd(N.ptr(b['rad_in']), N.ptr(self._p('rad_w')), N.ptr(self._p('rad_b')), N.C.addressof(fld.rad_desc),
-                               N.ptr(b['rgb_s']), N.ptr(b['rad_acts']), N.ptr(b['d_rgb_s']), N.ptr(b['d_rad_in']),
-                               N.ptr(self._g('rad_w')), N.ptr(self._g('rad_b')), N.ptr(b['rad_scratch']), S, S, n_dev.data_ptr(), st),
-                'mlp_bwd(rad)')
-        F.ngp_glue_bwd(b['geo_out'], b['d_rad_in'], b['d_sigma'], fld.feat_off, cfg.W_feat, cfg.sh_degree,
-                       feat_first=(cfg.rad_mode == 'fv'), sigma_act=cfg.sigma_act, n_dev=n_dev, d_geo_out=b['d_geo_out'])
+        if self.fused_glue:
+            # ... and the radiance net writes d geo_out directly (feature half of its input gradient + sigma's gradient in col 0)
+            N.check(L.arcn_mlp_bwd_cat(N.ptr(b['geo_out']), N.ptr(b['sh_ray']), N.ptr(b['ray_id']), int(cfg.rad_mode == 'fv'),
+                                       N.ptr(self._p('rad_w')), N.C.addressof(fld.rad_desc), N.ptr(b['rgb_s']), N.ptr(b['rad_acts']),
+                                       N.ptr(b['d_rgb_s']), N.ptr(b['d_geo_out']), N.ptr(b['d_sigma']), N.ACT[cfg.sigma_act],
+                                       N.ptr(self._g('rad_w')), N.ptr(b['rad_scratch']), S, S, n_dev.data_ptr(), st), 'mlp_bwd_cat(rad)')
+        else:
+            N.check(L.arcn_mlp_bwd(N.ptr(b['rad_in']), N.ptr(self._p('rad_w')), N.ptr(self._p('rad_b')), N.C.addressof(fld.rad_desc),
+                                   N.ptr(b['rgb_s']), N.ptr(b['rad_acts']), N.ptr(b['d_rgb_s']), N.ptr(b['d_rad_in']),
+                                   N.ptr(self._g('rad_w')), N.ptr(self._g('rad_b')), N.ptr(b['rad_scratch']), S, S, n_dev.data_ptr(), st),
+                    'mlp_bwd(rad)')
+            F.ngp_glue_bwd(b['geo_out'], b['d_rad_in'], b['d_sigma'], fld.feat_off, cfg.W_feat, cfg.sh_degree,
+                           feat_first=(cfg.rad_mode == 'fv'), sigma_act=cfg.sigma_act, n_dev=n_dev, d_geo_out=b['d_geo_out'])
         self._prefetch_point(1)
         if self.level_major:
             N.check(L.arcn_mlp_bwd_lm(N.ptr(b['feat']), S, N.ptr(self._p('geo_w')), N.C.addressof(fld.geo_desc), N.ptr(b['geo_out']),

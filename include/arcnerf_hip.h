@@ -197,6 +197,18 @@ int arcn_mlp_fwd_lm(const float *x_lm, int64_t x_stride, const float *weights, c
 int arcn_mlp_bwd_lm(const float *x_lm, int64_t x_stride, const float *weights, const arcn_mlp_desc *desc_host, const float *out,
                     const float *acts, const float *dout, float *dx_lm, float *dweights, float *scratch, int64_t n_cap,
                     int64_t n, const int32_t *n_ptr, void *stream);
+/* The radiance net of Base3dModel._forward_pts_dir (base_3d_model.py:233-254) with fuse_radiance_inputs
+ * (encoder_mlp_network.py:93-118) folded into the first layer's operand load: x = [a | b] (a_first) or [b | a], 16 columns each,
+ * a (n,16) row-major per sample (the geometry net's output), b = b_table[b_index[s]] (arcn_ngp_ray_sh rows by ray id).
+ * head_out (optional) = head_act(a[:,0]) (sigma, EncoderMLPGeoNet.handle_output).  bwd: da (n,16) = gradient of a incl.
+ * d_head * head_act'(a[:,0]) in column 0 (b has no gradient); dweights required.  Bias-free nets 32 -> 64 [-> 64] -> <=16. */
+int arcn_mlp_fwd_cat(const float *a, const float *b_table, const int32_t *b_index, int a_first, const float *weights,
+                     const arcn_mlp_desc *desc_host, float *out, float *acts, float *head_out, int head_act, int64_t n_cap,
+                     int64_t n, const int32_t *n_ptr, void *stream);
+int arcn_mlp_bwd_cat(const float *a, const float *b_table, const int32_t *b_index, int a_first, const float *weights,
+                     const arcn_mlp_desc *desc_host, const float *out, const float *acts, const float *dout, float *da,
+                     const float *d_head, int head_act, float *dweights, float *scratch, int64_t n_cap, int64_t n,
+                     const int32_t *n_ptr, void *stream);
 /* float count the caller must provide in `acts` (hidden layers) and `scratch` (bwd) for capacity n_cap */
 int64_t arcn_mlp_acts_floats(const arcn_mlp_desc *desc_host, int64_t n_cap);
 int64_t arcn_mlp_scratch_floats(const arcn_mlp_desc *desc_host, int64_t n_cap);

@@ -383,6 +383,29 @@ def test_glue_with_per_ray_harmonics_is_bit_identical(F):
         N.check(lib.arcn_ngp_glue_fwd_rays(N.ptr(geo), N.ptr(sh_ray), N.ptr(ray_id), 16, 0, 16, 4, int(feat_first), N.ACT['truncexp'],
                                            N.ptr(rad_in), N.ptr(sigma), S, None, st))
         assert torch.equal(rad_in, ref_in) and torch.equal(sigma, ref_sigma)
+        # the radiance net with the glue folded into its operand load (fwd + fused bwd) against glue kernel + plain net
+        for dims, act_out in (([32, 64, 64, 3], 'sigmoid'), ([32, 64, 16], None)):
+            mdesc = N.make_mlp_desc(dims, 'relu', act_out)
+            w = dev((rng.normal(size=sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))) * 0.2).astype(np.float32))
+            out_ref, acts_ref = F.mlp_fwd(ref_in, w, None, mdesc, save_acts=True)
+            out = torch.zeros(S, dims[-1], device='cuda')
+            acts = torch.zeros(F.mlp_acts_floats(mdesc, S), device='cuda')
+            sig2 = torch.zeros(S, device='cuda')
+            N.check(lib.arcn_mlp_fwd_cat(N.ptr(geo), N.ptr(sh_ray), N.ptr(ray_id), int(feat_first), N.ptr(w), C.addressof(mdesc),
+                                         N.ptr(out), N.ptr(acts), N.ptr(sig2), N.ACT['truncexp'], S, S, None, st))
+            assert torch.equal(out, out_ref) and torch.equal(sig2, ref_sigma)
+            dout = dev(rng.normal(size=(S, dims[-1])).astype(np.float32))
+            d_sigma = dev(rng.normal(size=S).astype(np.float32))
+            dx_ref, dw_ref, _ = F.mlp_bwd(ref_in, w, None, mdesc, out_ref, acts_ref, dout)
+            dgeo_ref = F.ngp_glue_bwd(geo, dx_ref, d_sigma, 0, 16, 4, feat_first=feat_first, sigma_act='truncexp')
+            dgeo = torch.zeros(S, 16, device='cuda')
+            dw = torch.zeros_like(w)
+            scr = torch.zeros(F.mlp_scratch_floats(mdesc, S), device='cuda')
+            N.check(lib.arcn_mlp_bwd_cat(N.ptr(geo), N.ptr(sh_ray), N.ptr(ray_id), int(feat_first), N.ptr(w), C.addressof(mdesc),
+                                         N.ptr(out), N.ptr(acts), N.ptr(dout), N.ptr(dgeo), N.ptr(d_sigma), N.ACT['truncexp'],
+                                         N.ptr(dw), N.ptr(scr), S, S, None, st))
+            close(host(dgeo), host(dgeo_ref), rtol=1e-5, atol=1e-6)
+            close(host(dw), host(dw_ref), rtol=1e-5, atol=1e-5)
 
 
 def test_hashgrid_scatter_bin_overflow_and_runs(F, oracle):

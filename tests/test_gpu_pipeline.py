@@ -20,8 +20,9 @@ def test_smoke_small_config(gpu):
     assert errs['rgb'] < 1e-4
 
 
-@pytest.mark.parametrize('noise,level_major', [(False, True), (True, True), (False, False)])
-def test_full_ngp_config_step_matches_reference_stack(gpu, oracle, noise, level_major):
+@pytest.mark.parametrize('noise,level_major,fused_glue', [(False, True, True), (True, True, True), (False, False, False),
+                                                          (False, True, False)])
+def test_full_ngp_config_step_matches_reference_stack(gpu, oracle, noise, level_major, fused_glue):
     """configs/models/nerf_ngp.yaml dimensions (L16 F2 T2^19, n_grid 128, 1024 samples/ray): RGB/depth/mask within 1e-4,
     identical sample count, gradients of table / geo / radiance weights within 1e-3 of their max."""
     from oracle.ngp_reference import oracle_step, compare
@@ -30,8 +31,8 @@ def test_full_ngp_config_step_matches_reference_stack(gpu, oracle, noise, level_
     fld = NgpField(cfg, device=gpu, seed=5)
     fld.view('table').mul_(3000.0)  # a trained-like table magnitude so features drive the nets
     R = 700
-    pipe = NgpPipeline(fld, max_rays=1024, max_samples=1 << 16, packed_bits=True, level_major=level_major)
-    assert pipe.level_major == level_major
+    pipe = NgpPipeline(fld, max_rays=1024, max_samples=1 << 16, packed_bits=True, level_major=level_major, fused_glue=fused_glue)
+    assert pipe.level_major == level_major and pipe.fused_glue == fused_glue
     bf = synthetic_bitfield(cfg.n_grid, 0.05, seed=1)
     pipe.set_bitfield(torch.from_numpy(bf))
     o, d = synthetic_rays(R, seed=9, device=gpu)
