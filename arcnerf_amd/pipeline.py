@@ -202,6 +202,11 @@ class NgpPipeline:
         self._cur_set = 0
         self._prefetched = None
         self._next_rays = None
+        self.occ_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+        self.occ_async = bool(int(os.environ.get('ARCN_OCC_ASYNC', '1'))) and self.occ_stream is not None
+        self._occ_params_event = None   # the refresh still reads the parameters: the optimiser waits for it
+        self._occ_bits_event = None     # the refreshed bitfield is ready: the marcher waits for it
+        self._occ_state_event = None    # last refresh finished: readers of .bitfield / .opafield wait for it
         self.prefetch_at = int(os.environ.get('ARCN_PREFETCH_AT', '1'))
         # multi-rank: the compute units idle while the gradient all-reduce is on the wire - march the next batch there
         self.prefetch_at_dist = int(os.environ.get('ARCN_PREFETCH_AT_DIST', '3'))
@@ -255,8 +260,8 @@ class NgpPipeline:
         self.step_count = 0
         # occupancy (Volume bitfield/opafield, volume.py:741-760,959-969)
         ng = cfg.n_grid
-        self.bitfield = torch.ones(ng ** 3, dtype=torch.bool, device=dev)
-        self.opafield = torch.zeros(ng ** 3, dtype=f32, device=dev)
+        self._bitfield = torch.ones(ng ** 3, dtype=torch.bool, device=dev)
+        self._opafield = torch.zeros(ng ** 3, dtype=f32, device=dev)
         self._bits = None
         self._occ_scratch = None
         self._pb = self._gb = None
@@ -283,6 +288,21 @@ class NgpPipeline:
         return self.field.view(name, self.field.grads)
 
     # ---- occupancy ------------------------------------------------------------------------------
+    # the occupancy state is produced on the refresh stream: reading it makes the CURRENT stream wait for the last refresh
+    @property
+    def bitfield(self):
+        self._wait_occupancy_state()
+        return self._bitfield
+
+    @bitfield.setter
+    def bitfield(self, value):
+        self._bitfield = value
+
+    @property
+    def opafield(self):
+        self._wait_occupancy_state()
+        return self._opafield
+
     def set_bitfield(self, bitfield_bool):
         """bitfield (n_grid^3 | n_grid,n_grid,n_grid) bool, flat index x*n*n + y*n + z"""
         self.bitfield = bitfield_bool.reshape(-1).to(self.field.device).contiguous()
@@ -293,7 +313,7 @@ class NgpPipeline:
             self._bits = (self.bitfield.view(-1, 8).to(torch.int32) * w).sum(-1).to(torch.uint8).contiguous()
 
     def _occ(self):
-        return self._bits if self.packed_bits else self.bitfield
+        return self._bits if self.packed_bits else self._bitfield
 
     def _cached(self, key, make):
         if not hasattr(self, '_cache'):
@@ -341,6 +361,7 @@ class NgpPipeline:
 
     def _sample_into(self, b, rays_o, rays_d):
         cfg = self.cfg
+        self._wait_occupancy_bits()
         R = rays_o.shape[0]
         assert R <= self.max_rays
         L = N.lib()
@@ -465,6 +486,9 @@ class NgpPipeline:
         """fused Adam + EMA (+ gradient clear) on the whole flat buffer or on its slice [lo, hi) (pipelined gradient sync:
         one call per segment, `advance` only on the first so every segment sees the same step count)."""
         cfg, fld = self.cfg, self.field
+        if self._occ_params_event is not None:
+            torch.cuda.current_stream().wait_event(self._occ_params_event)
+            self._occ_params_event = None
         if advance:
             self.step_count += 1
         sl = slice(lo, hi)
@@ -511,13 +535,46 @@ class NgpPipeline:
     # ---- occupancy update (VolumeBound.optimize, volume_bound.py:160-212) -----------------------------
     def update_occupancy(self, cur_epoch, apply=True):
         """Sample voxels, evaluate opacity = sigma * dt with the geo net, EMA-max into the opacity field and re-threshold
-        the bitfield.  apply=False runs all the work but leaves the marching bitfield untouched (fixed-workload benches)."""
+        the bitfield.  apply=False runs all the work but leaves the marching bitfield untouched (fixed-workload benches).
+        The refresh is queued on its own stream (ARCN_OCC_ASYNC=0: on the caller's): it only needs the parameters as they are
+        now, so it runs next to the following step; the next optimiser step waits for it before overwriting them, and - when
+        the new bitfield is applied - so does the next marching pass."""
+        cfg = self.cfg
+        if cur_epoch <= 0 or cfg.epoch_optim is None or cur_epoch % cfg.epoch_optim != 0:
+            return
+        if not self.occ_async:
+            self._refresh_occupancy(cur_epoch, apply)
+            return
+        main = torch.cuda.current_stream()
+        side = self.occ_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._refresh_occupancy(cur_epoch, apply)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._occ_params_event = ev
+        self._occ_state_event = ev  # readers of .bitfield / .opafield wait for this refresh
+        if apply:
+            self._occ_bits_event = ev  # ... and so does the marcher when the bitfield it reads was replaced
+            for t in (self._bitfield, getattr(self, '_bits', None)):   # allocated on the side stream, read on the others
+                if t is not None:
+                    t.record_stream(main)
+                    if self.aux_stream is not None:
+                        t.record_stream(self.aux_stream)
+
+    def _wait_occupancy_bits(self):
+        if self._occ_bits_event is not None:
+            torch.cuda.current_stream().wait_event(self._occ_bits_event)
+
+    def _wait_occupancy_state(self):
+        if self._occ_state_event is not None:
+            torch.cuda.current_stream().wait_event(self._occ_state_event)
+
+    def _refresh_occupancy(self, cur_epoch, apply):
         cfg, fld = self.cfg, self.field
         dev = fld.device
         ng = cfg.n_grid
         n_cells = ng ** 3
-        if cur_epoch <= 0 or cfg.epoch_optim is None or cur_epoch % cfg.epoch_optim != 0:
-            return
         n_dev = None
         if cfg.epoch_optim_warmup is not None and cur_epoch < cfg.epoch_optim_warmup:
             cell = self._cached('arange_cells', lambda: torch.arange(n_cells, device=dev))
