@@ -339,8 +339,10 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
 
 // pass 2: exclusive scan of int32 counts, single workgroup (n_rays is a few 10^4..10^6): 1024 threads, each owning a
 // contiguous slice, wave scans + LDS for the 16 wave totals.  offsets[n] = total.
+// max_total > 0 clamps every offset to it: when the rays ask for more samples than the packed buffers hold, the rays past the
+// capacity keep a (possibly empty) truncated segment and every consumer of `offsets` stays inside the buffers.
 __global__ void __launch_bounds__(1024) exclusive_scan_kernel(const int32_t *__restrict__ counts,
-                                                              int32_t *__restrict__ offsets, int64_t n) {
+                                                              int32_t *__restrict__ offsets, int64_t n, int64_t max_total) {
     __shared__ int32_t s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t per = (n + 1023) / 1024;
@@ -358,11 +360,12 @@ __global__ void __launch_bounds__(1024) exclusive_scan_kernel(const int32_t *__r
     int32_t base = 0;
     for (int w = 0; w < wv; ++w) base += s_wave[w];
     int32_t run = base + incl - sum;
-    for (int64_t k = lo; k < hi; ++k) { offsets[k] = run; run += counts[k]; }
+    const int32_t lim = max_total > 0 ? (int32_t)(max_total < 0x7fffffff ? max_total : 0x7fffffff) : 0x7fffffff;
+    for (int64_t k = lo; k < hi; ++k) { offsets[k] = run < lim ? run : lim; run += counts[k]; }
     if (tid == 1023) {
         int32_t total = 0;
         for (int w = 0; w < 16; ++w) total += s_wave[w];
-        offsets[n] = total;
+        offsets[n] = total < lim ? total : lim;
     }
 }
 
@@ -558,9 +561,9 @@ ARCN_EXPORT int arcn_march_count(const float *rays_o, const float *rays_d, const
     return check_launch("march_count");
 }
 
-ARCN_EXPORT int arcn_exclusive_scan_i32(const int32_t *counts, int32_t *offsets, int64_t n, void *stream) {
+ARCN_EXPORT int arcn_exclusive_scan_i32(const int32_t *counts, int32_t *offsets, int64_t n, int64_t max_total, void *stream) {
     if (n < 0 || !counts || !offsets) return einval("exclusive_scan_i32: missing argument");
-    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), counts, offsets, n);
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), counts, offsets, n, max_total);
     return check_launch("exclusive_scan_i32");
 }
 

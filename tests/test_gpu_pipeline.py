@@ -186,3 +186,41 @@ def test_optimizer_by_segments_is_bit_identical(gpu):
         outs.append((fld.params.clone(), pipe.ema.clone(), pipe.exp_avg.clone(), pipe.exp_avg_sq.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_edge_batches_no_samples_and_capacity_overflow(gpu):
+    """(a) every ray misses the volume: the device-side sample count is 0, the step must run (no host-visible sample count
+    anywhere), return the background and leave the parameters' gradients at zero; (b) more samples than the packed buffers
+    hold: the step must stay inside its buffers (the excess samples are dropped from the tail) and stay finite."""
+    from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline, synthetic_bitfield, synthetic_rays
+    cfg = NgpConfig(n_levels=8, hashmap_size=15, max_res=512, n_grid=64, n_sample=512, noise_std=0.0)
+    fld = NgpField(cfg, device=gpu, seed=0)
+    pipe = NgpPipeline(fld, max_rays=1024, max_samples=1 << 15)
+    pipe.set_bitfield(torch.from_numpy(synthetic_bitfield(cfg.n_grid, 0.2, seed=3)))
+    R = 1024
+    o, d = synthetic_rays(R, seed=1, device=gpu)
+    tgt = torch.rand(R, 3, device=gpu)
+    bkg = torch.rand(R, 3, device=gpu)
+    p0 = fld.params.clone()
+    # (a) look away from the volume
+    rgb, depth, mask = pipe.forward(o, (-d).contiguous(), bkg, train=True)
+    assert int(pipe.n_dev.item()) == 0
+    assert torch.equal(rgb, bkg) and float(mask.abs().max()) == 0.0
+    loss, d_rgb = pipe.huber_grad(rgb, tgt)
+    pipe.backward(o, (-d).contiguous(), d_rgb)
+    assert float(fld.grads.abs().max()) == 0.0
+    pipe.train_step(o, (-d).contiguous(), tgt, bkg_color=bkg)
+    torch.cuda.synchronize()
+    assert torch.isfinite(fld.params).all()
+    # (b) a capacity far below the demand
+    fld2 = NgpField(cfg, device=gpu, seed=0)
+    small = NgpPipeline(fld2, max_rays=1024, max_samples=1 << 12)
+    small.set_bitfield(torch.ones(cfg.n_grid ** 3, dtype=torch.bool))
+    guard = small.buf['sigma'].shape[0]
+    for _ in range(3):
+        loss = small.train_step(o, d, tgt, bkg_color=bkg)
+    torch.cuda.synchronize()
+    assert int(small.buf['counts'][:R].sum().item()) > (1 << 12)    # the marcher asked for more than the buffers hold
+    assert int(small.buf['offsets'][R].item()) == (1 << 12)         # ... and the packed segments were clamped to them
+    assert small.buf['sigma'].shape[0] == guard and torch.isfinite(fld2.params).all() and bool(torch.isfinite(loss))
+    assert torch.isfinite(small.buf['rgb'][:R]).all()
