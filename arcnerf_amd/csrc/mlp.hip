@@ -1042,7 +1042,8 @@ ARCN_EXPORT int arcn_mlp_fwd_cat(const float *a, const float *b_table, const int
 static int mlp_bwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, const float *weights, const float *biases,
                         const arcn_mlp_desc *desc_host,
                         const float *out, const float *acts, const float *dout, float *dx, float *dweights,
-                        float *dbiases, float *scratch, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+                        float *dbiases, float *scratch, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream,
+                        int defer_reduce = 0) {
     (void)biases;
     if (n <= 0) return ARCN_OK;
     if (!x || !weights || !out || !dout || !scratch) return einval("mlp_bwd: missing argument");
@@ -1093,8 +1094,10 @@ static int mlp_bwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
             default: ARCN_FUSED(4, 4, 4, 1, 1, 0); break;
             }
 #undef ARCN_FUSED
-            hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(16, (unsigned)P.n_layers, 8), dim3(256), 0, as_stream(stream), partials,
-                               static_cast<const float *>(nullptr), D, (int)grid, dweights, dbiases);
+            // defer_reduce: the per-workgroup partials stay in `scratch`; arcn_mlp_bwd_reduce adds them into dweights later
+            if (!defer_reduce)
+                hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(16, (unsigned)P.n_layers, 8), dim3(256), 0, as_stream(stream), partials,
+                                   static_cast<const float *>(nullptr), D, (int)grid, dweights, dbiases);
             return check_launch("mlp_bwd_fused");
         }
     }
@@ -1127,22 +1130,46 @@ ARCN_EXPORT int arcn_mlp_bwd(const float *x, const float *weights, const float *
 
 ARCN_EXPORT int arcn_mlp_bwd_lm(const float *x_lm, int64_t x_stride, const float *weights, const arcn_mlp_desc *desc_host,
                                 const float *out, const float *acts, const float *dout, float *dx_lm, float *dweights,
-                                float *scratch, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+                                float *scratch, int defer_reduce, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
     if (x_stride < n) return einval("mlp_bwd_lm: level stride smaller than n");
     if (!dweights) return einval("mlp_bwd_lm: dweights required");
     return mlp_bwd_impl(x_lm, x_stride, nullptr, weights, nullptr, desc_host, out, acts, dout, dx_lm, dweights, nullptr, scratch, n_cap,
-                        n, n_ptr, stream);
+                        n, n_ptr, stream, defer_reduce);
 }
 
 ARCN_EXPORT int arcn_mlp_bwd_cat(const float *a, const float *b_table, const int32_t *b_index, int a_first, const float *weights,
                                  const arcn_mlp_desc *desc_host, const float *out, const float *acts, const float *dout, float *da,
-                                 const float *d_head, int head_act, float *dweights, float *scratch, int64_t n_cap, int64_t n,
-                                 const int32_t *n_ptr, void *stream) {
+                                 const float *d_head, int head_act, float *dweights, float *scratch, int defer_reduce,
+                                 int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
     if (n <= 0) return ARCN_OK;
     if (!a || !b_table || !b_index || !dweights) return einval("mlp_bwd_cat: missing argument");
     MlpCat cat = {b_table, b_index, nullptr, d_head, a_first ? 1 : 0, head_act};
     return mlp_bwd_impl(a, 0, &cat, weights, nullptr, desc_host, out, acts, dout, da, dweights, nullptr, scratch, n_cap, n, n_ptr,
-                        stream);
+                        stream, defer_reduce);
+}
+
+// second half of arcn_mlp_bwd_lm / arcn_mlp_bwd_cat called with defer_reduce = 1: sum the per-workgroup dW partials left in
+// `scratch` into dweights (same n_cap and n as the backward call: they fix the number of partials).
+ARCN_EXPORT int arcn_mlp_bwd_reduce(const arcn_mlp_desc *desc_host, float *scratch, float *dweights, int64_t n_cap, int64_t n,
+                                    void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!scratch || !dweights) return einval("mlp_bwd_reduce: missing argument");
+    MlpParams P;
+    int lds_floats, md, rc;
+    if ((rc = build_mlp_params(desc_host, P, true, &lds_floats, &md))) return rc;
+    if (P.has_bias || P.n_layers < 2 || P.n_layers > 3 || md > 64) return einval("mlp_bwd_reduce: not a fused-backward shape");
+    int64_t grid = tile_grid(n, 64);
+    if (grid > dw_slabs(n_cap)) grid = dw_slabs(n_cap);
+    DwParams D;
+    D.n_layers = P.n_layers;
+    D.has_bias = 0;
+    for (int l = 0; l <= P.n_layers; ++l) D.dims[l] = P.dims[l];
+    for (int l = 0; l < P.n_layers; ++l) { D.w_off[l] = P.w_off[l]; D.b_off[l] = P.b_off[l]; D.quad_first[l] = l; }
+    D.quad_first[P.n_layers] = P.n_layers;
+    float *partials = scratch + arcn_mlp_dpre_floats(desc_host, n_cap);
+    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(16, (unsigned)P.n_layers, 8), dim3(256), 0, as_stream(stream), partials,
+                       static_cast<const float *>(nullptr), D, (int)grid, dweights, static_cast<float *>(nullptr));
+    return check_launch("mlp_bwd_reduce");
 }
 
 ARCN_EXPORT int arcn_mlp_bwd_dw(const float *x, const arcn_mlp_desc *desc_host, const float *acts, float *scratch,

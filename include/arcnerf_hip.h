@@ -197,8 +197,8 @@ int arcn_mlp_bwd_dw(const float *x, const arcn_mlp_desc *desc_host, const float 
 int arcn_mlp_fwd_lm(const float *x_lm, int64_t x_stride, const float *weights, const arcn_mlp_desc *desc_host, float *out,
                     float *acts, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream);
 int arcn_mlp_bwd_lm(const float *x_lm, int64_t x_stride, const float *weights, const arcn_mlp_desc *desc_host, const float *out,
-                    const float *acts, const float *dout, float *dx_lm, float *dweights, float *scratch, int64_t n_cap,
-                    int64_t n, const int32_t *n_ptr, void *stream);
+                    const float *acts, const float *dout, float *dx_lm, float *dweights, float *scratch, int defer_reduce,
+                    int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream);
 /* The radiance net of Base3dModel._forward_pts_dir (base_3d_model.py:233-254) with fuse_radiance_inputs
  * (encoder_mlp_network.py:93-118) folded into the first layer's operand load: x = [a | b] (a_first) or [b | a], 16 columns each,
  * a (n,16) row-major per sample (the geometry net's output), b = b_table[b_index[s]] (arcn_ngp_ray_sh rows by ray id).
@@ -209,8 +209,12 @@ int arcn_mlp_fwd_cat(const float *a, const float *b_table, const int32_t *b_inde
                      int64_t n, const int32_t *n_ptr, void *stream);
 int arcn_mlp_bwd_cat(const float *a, const float *b_table, const int32_t *b_index, int a_first, const float *weights,
                      const arcn_mlp_desc *desc_host, const float *out, const float *acts, const float *dout, float *da,
-                     const float *d_head, int head_act, float *dweights, float *scratch, int64_t n_cap, int64_t n,
-                     const int32_t *n_ptr, void *stream);
+                     const float *d_head, int head_act, float *dweights, float *scratch, int defer_reduce, int64_t n_cap,
+                     int64_t n, const int32_t *n_ptr, void *stream);
+/* defer_reduce = 1 in the two calls above leaves the per-workgroup dW partials in `scratch`; this adds them into dweights
+ * (same n_cap and n).  Lets a caller take the two tiny reductions off the backward's critical path. */
+int arcn_mlp_bwd_reduce(const arcn_mlp_desc *desc_host, float *scratch, float *dweights, int64_t n_cap, int64_t n,
+                        void *stream);
 /* float count the caller must provide in `acts` (hidden layers) and `scratch` (bwd) for capacity n_cap */
 int64_t arcn_mlp_acts_floats(const arcn_mlp_desc *desc_host, int64_t n_cap);
 int64_t arcn_mlp_scratch_floats(const arcn_mlp_desc *desc_host, int64_t n_cap);
