@@ -342,13 +342,18 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
 // max_total > 0 clamps every offset to it: when the rays ask for more samples than the packed buffers hold, the rays past the
 // capacity keep a (possibly empty) truncated segment and every consumer of `offsets` stays inside the buffers.
 __global__ void __launch_bounds__(1024) exclusive_scan_kernel(const int32_t *__restrict__ counts,
-                                                              int32_t *__restrict__ offsets, int64_t n, int64_t max_total) {
+                                                              int32_t *__restrict__ offsets, int64_t n, int64_t max_total,
+                                                              int32_t *__restrict__ max_out) {
     __shared__ int32_t s_wave[16];
+    __shared__ int32_t s_max;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_max = 0;
+    __syncthreads();
     const int64_t per = (n + 1023) / 1024;
     const int64_t lo = (int64_t)tid * per, hi = (lo + per < n) ? lo + per : n;
-    int32_t sum = 0;
-    for (int64_t k = lo; k < hi; ++k) sum += counts[k];
+    int32_t sum = 0, mx = 0;
+    for (int64_t k = lo; k < hi; ++k) { const int32_t c = counts[k]; sum += c; mx = c > mx ? c : mx; }
+    if (max_out && mx > 0) atomicMax(&s_max, mx);  // the dense width the reference would have used (fg_model.py:251-262)
     int32_t incl = sum;
 #pragma unroll
     for (int dlt = 1; dlt < 64; dlt <<= 1) {
@@ -366,6 +371,7 @@ __global__ void __launch_bounds__(1024) exclusive_scan_kernel(const int32_t *__r
         int32_t total = 0;
         for (int w = 0; w < 16; ++w) total += s_wave[w];
         offsets[n] = total < lim ? total : lim;
+        if (max_out) *max_out = s_max;
     }
 }
 
@@ -561,9 +567,10 @@ ARCN_EXPORT int arcn_march_count(const float *rays_o, const float *rays_d, const
     return check_launch("march_count");
 }
 
-ARCN_EXPORT int arcn_exclusive_scan_i32(const int32_t *counts, int32_t *offsets, int64_t n, int64_t max_total, void *stream) {
+ARCN_EXPORT int arcn_exclusive_scan_i32(const int32_t *counts, int32_t *offsets, int64_t n, int64_t max_total, int32_t *max_out,
+                                        void *stream) {
     if (n < 0 || !counts || !offsets) return einval("exclusive_scan_i32: missing argument");
-    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), counts, offsets, n, max_total);
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), counts, offsets, n, max_total, max_out);
     return check_launch("exclusive_scan_i32");
 }
 

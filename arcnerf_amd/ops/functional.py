@@ -147,7 +147,7 @@ def march_packed(rays_o, rays_d, aabb23, n_grid, bitfield, n_pts, dt, near_dista
                                N.ptr(scratch), N.ptr(counts), N.ptr(near), N.ptr(far), R, N.stream()), 'march_count')
     if capacity is None:
         capacity = R * n_pts
-    N.check(L.arcn_exclusive_scan_i32(N.ptr(counts), N.ptr(offsets), R, int(capacity), N.stream()), 'exclusive_scan_i32')
+    N.check(L.arcn_exclusive_scan_i32(N.ptr(counts), N.ptr(offsets), R, int(capacity), None, N.stream()), 'exclusive_scan_i32')
     t = torch.empty(capacity, dtype=torch.float32, device=dev)
     ray_id = torch.empty(capacity, dtype=torch.int32, device=dev)
     N.check(L.arcn_march_write(N.ptr(scratch), N.ptr(counts), N.ptr(offsets), int(n_pts), N.ptr(t), N.ptr(ray_id), R,

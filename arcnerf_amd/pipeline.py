@@ -373,11 +373,10 @@ class NgpPipeline:
                                    self.rng.state, self.rng.inc, N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['near']),
                                    N.ptr(b['far']), R, st), 'march_count')
         self.rng.advance()
-        N.check(L.arcn_exclusive_scan_i32(N.ptr(b['counts']), N.ptr(b['offsets']), R, self.cap, st), 'scan')
+        # offsets (clamped to the capacity) and the dense width the reference would have used, max(2, max count)
+        N.check(L.arcn_exclusive_scan_i32(N.ptr(b['counts']), N.ptr(b['offsets']), R, self.cap, N.ptr(b['p_dense']), st), 'scan')
         N.check(L.arcn_march_write(N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['offsets']), cfg.n_sample, N.ptr(b['t']),
                                    N.ptr(b['ray_id']), R, self.cap, st), 'march_write')
-        # dense width the reference would have used: max(2, max count) (fg_model.py:251-262)
-        torch.clamp(b['counts'][:R].max(), min=2, out=b['p_dense'][0])
 
     def forward(self, rays_o, rays_d, bkg_color=None, train=False, noise=None):
         """Render rays: returns rgb (R,3), depth (R), mask (R) views of the internal buffers."""

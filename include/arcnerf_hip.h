@@ -79,7 +79,8 @@ void arcn_pcg32_advance(uint64_t *state_inc_host, int64_t delta);
  *   pass 1  arcn_march_count : near/far (K2 or torch semantics) + march, counts (n_rays) int32, optional dense scratch
  *   pass 2  arcn_exclusive_scan_i32 : offsets (n_rays+1) int32 (offsets[n_rays] = total); max_total > 0 clamps every offset to
  *           the capacity of the packed buffers: rays past it keep a truncated (possibly empty) segment, nothing downstream
- *           indexes beyond the buffers when the rays ask for more samples than they hold
+ *           indexes beyond the buffers when the rays ask for more samples than they hold; max_out (optional, device) receives
+ *           max(counts), the dense width P the reference would have used (fg_model.py:251-262)
  *   pass 3  arcn_march_write : t (S) float, ray_id (S) int32 in ray-major order; dense t scratch reused.
  * scratch_t (n_rays,n_pts) float holds the emitted t of pass 1 (no init needed).
  * ---------------------------------------------------------------------------------------------- */
@@ -87,7 +88,8 @@ int arcn_march_count(const float *rays_o, const float *rays_d, const float *aabb
                      int bitfield_is_packed, int n_pts, float dt, float near_distance, int aabb_torch_semantics,
                      uint64_t rng_state, uint64_t rng_inc, float *scratch_t, int32_t *counts, float *near_out,
                      float *far_out, int64_t n_rays, void *stream);
-int arcn_exclusive_scan_i32(const int32_t *counts, int32_t *offsets, int64_t n, int64_t max_total, void *stream);
+int arcn_exclusive_scan_i32(const int32_t *counts, int32_t *offsets, int64_t n, int64_t max_total, int32_t *max_out,
+                            void *stream);
 int arcn_march_write(const float *scratch_t, const int32_t *counts, const int32_t *offsets, int n_pts, float *t_packed,
                      int32_t *ray_id, int64_t n_rays, int64_t capacity, void *stream);
 
