@@ -185,6 +185,53 @@ __global__ void __launch_bounds__(256) aabb_kernel(const float *__restrict__ ray
     }
 }
 
+// ---- ray / sphere shell test (arcnerf/geometry/ray.py:180-255) -------------------------------------------------------
+// one lane per (ray, radius).  set_tensor_to_zeros = |x| < 1e-5 -> 0 (common/utils/torch_utils.py:50-54); near/far clamped
+// at 0, both 0 where the ray misses; rays starting inside always hit (near 0).
+__device__ __forceinline__ float zero_small(float v) { return fabsf(v) < 1e-5f ? 0.0f : v; }
+
+__global__ void __launch_bounds__(256) sphere_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                     const float *__restrict__ radius, float ox, float oy, float oz,
+                                                     float *__restrict__ near, float *__restrict__ far,
+                                                     float *__restrict__ pts, uint8_t *__restrict__ mask, int64_t n_rays,
+                                                     int64_t n_r) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays * n_r) return;
+    const int64_t ray = i / n_r, k = i - ray * n_r;
+    const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
+    const float d[3] = {rays_d[3 * ray], rays_d[3 * ray + 1], rays_d[3 * ray + 2]};
+    const float r = radius[k];
+    const float oc[3] = {ox - o[0], oy - o[1], oz - o[2]};
+    float z_half = oc[0] * d[0];
+    z_half = z_half + oc[1] * d[1];
+    z_half = z_half + oc[2] * d[2];
+    z_half = zero_small(z_half);
+    float oc2 = oc[0] * oc[0];
+    oc2 = oc2 + oc[1] * oc[1];
+    oc2 = oc2 + oc[2] * oc[2];
+    const bool inside = sqrtf(oc2) <= r;
+    bool m = (z_half > 0.0f) || inside;
+    const float d2 = zero_small(oc2 - z_half * z_half);
+    m = m && (d2 >= 0.0f);
+    float z_off = zero_small(r * r - d2);
+    m = m && (z_off >= 0.0f);
+    z_off = sqrtf(z_off);
+    float nr = fmaxf(z_half - z_off, 0.0f), fr = fmaxf(z_half + z_off, 0.0f);
+    if (!m) { nr = 0.0f; fr = 0.0f; }
+    near[i] = nr;
+    far[i] = fr;
+    mask[i] = m ? 1 : 0;
+    if (pts) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float p0 = nr * d[a];
+            pts[i * 6 + a] = o[a] + p0;
+            float p1 = fr * d[a];
+            pts[i * 6 + 3 + a] = o[a] + p1;
+        }
+    }
+}
+
 // ---- K3 (dense boundary form) -------------------------------------------------------------------------
 __global__ void __launch_bounds__(128)
 sparse_sampling_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
@@ -506,6 +553,16 @@ ARCN_EXPORT int arcn_aabb_intersection_torch(const float *rays_o, const float *r
     hipLaunchKernelGGL(aabb_kernel<true>, dim3((unsigned)ceil_div<int64_t>(n_rays * n_v, 256)), dim3(256), 0,
                        as_stream(stream), rays_o, rays_d, aabb32, eps, near, far, pts, mask, n_rays, n_v);
     return check_launch("aabb_intersection_torch");
+}
+
+ARCN_EXPORT int arcn_sphere_intersection(const float *rays_o, const float *rays_d, const float *radius, const float *origin_host,
+                                         float *near, float *far, float *pts, uint8_t *mask, int64_t n_rays, int64_t n_r,
+                                         void *stream) {
+    if (n_rays * n_r <= 0) return ARCN_OK;
+    if (!rays_o || !rays_d || !radius || !origin_host || !near || !far || !mask) return einval("sphere_intersection: missing argument");
+    hipLaunchKernelGGL(sphere_kernel, dim3((unsigned)ceil_div<int64_t>(n_rays * n_r, 256)), dim3(256), 0, as_stream(stream), rays_o,
+                       rays_d, radius, origin_host[0], origin_host[1], origin_host[2], near, far, pts, mask, n_rays, n_r);
+    return check_launch("sphere_intersection");
 }
 
 ARCN_EXPORT int arcn_sparse_volume_sampling(const float *rays_o, const float *rays_d, const float *near,

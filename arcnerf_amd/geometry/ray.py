@@ -1,6 +1,7 @@
-"""Ray helpers of the path: o + t*d point generation and the ray/AABB test.
+"""Ray helpers of the path: o + t*d point generation, the ray/AABB test and the ray/sphere test.
 
-Mirrors arcnerf/geometry/ray.py:11-30 (get_ray_points_by_zvals) and :258-350 (aabb_ray_intersection).  The reference
+Mirrors arcnerf/geometry/ray.py:11-30 (get_ray_points_by_zvals), :180-255 (sphere_ray_intersection) and :258-350
+(aabb_ray_intersection).  The reference
 switches between a CUDA kernel (K2: rays starting inside the box are masked out) and a torch implementation (eps-shifted,
 inside rays hit) depending on availability; both semantics are kernels here, `force_torch` selects the torch one.
 """
@@ -26,3 +27,10 @@ def aabb_ray_intersection(rays_o, rays_d, aabb_range, eps=1e-7, force_torch=Fals
     if force_torch:
         return F.aabb_intersection_torch(rays_o, rays_d, aabb_range, eps)
     return F.aabb_intersection(rays_o, rays_d, aabb_range.permute(0, 2, 1).contiguous())
+
+
+@torch.no_grad()
+def sphere_ray_intersection(rays_o, rays_d, radius, origin=(0, 0, 0)):
+    """radius float or (N_r,) -> near, far (N_rays, N_r), pts (N_rays, N_r, 2, 3), mask (N_rays, N_r) bool
+    (outside/no hit: 0, 0, mask 0; inside: near 0; rays_d assumed normalised, like the reference)"""
+    return F.sphere_intersection(rays_o, rays_d, radius, origin)

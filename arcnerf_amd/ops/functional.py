@@ -71,6 +71,24 @@ def aabb_intersection_torch(rays_o, rays_d, aabb_v32, eps=1e-7, want_pts=True):
     return near, far, pts, mask
 
 
+def sphere_intersection(rays_o, rays_d, radius, origin=(0.0, 0.0, 0.0), want_pts=True):
+    """sphere_ray_intersection of geometry/ray.py:180-255; radius float or (N_r,) tensor."""
+    _req(rays_o, rays_d)
+    o, d = _f32(rays_o), _f32(rays_d)
+    if not torch.is_tensor(radius):
+        radius = torch.tensor([float(radius)], dtype=torch.float32, device=o.device)
+    rad = _f32(radius.to(o.device)).view(-1)
+    R, K = o.shape[0], rad.shape[0]
+    near = torch.zeros((R, K), dtype=torch.float32, device=o.device)
+    far = torch.zeros((R, K), dtype=torch.float32, device=o.device)
+    pts = torch.zeros((R, K, 2, 3), dtype=torch.float32, device=o.device) if want_pts else None
+    mask = torch.zeros((R, K), dtype=torch.bool, device=o.device)
+    org = (C.c_float * 3)(*[float(v) for v in origin])
+    N.check(N.lib().arcn_sphere_intersection(N.ptr(o), N.ptr(d), N.ptr(rad), C.addressof(org), N.ptr(near), N.ptr(far), N.ptr(pts),
+                                            mask.data_ptr(), R, K, N.stream()), 'sphere_intersection')
+    return near, far, pts, mask
+
+
 def sparse_volume_sampling(rays_o, rays_d, near, far, n_pts, dt, aabb23, n_grid, bitfield, near_distance, rng_state,
                            rng_inc, want_counts=False):
     _req(rays_o, rays_d, near, far, aabb23, bitfield)

@@ -56,6 +56,11 @@ int arcn_aabb_intersection(const float *rays_o, const float *rays_d, const float
  * starting inside the box are hits with near = eps. */
 int arcn_aabb_intersection_torch(const float *rays_o, const float *rays_d, const float *aabb32, float eps, float *near,
                                  float *far, float *pts, uint8_t *mask, int64_t n_rays, int64_t n_v, void *stream);
+/* sphere_ray_intersection (arcnerf/geometry/ray.py:180-255; SphereBound, sphere_bound.py:10-37): radius (n_r) device,
+ * origin_host[3] HOST; near/far (n_rays,n_r), pts (n_rays,n_r,2,3) optional, mask (n_rays,n_r) bytes.  Misses give 0/0,
+ * rays starting inside hit with near 0, |x| < 1e-5 intermediates are flushed to 0 like set_tensor_to_zeros. */
+int arcn_sphere_intersection(const float *rays_o, const float *rays_d, const float *radius, const float *origin_host,
+                             float *near, float *far, float *pts, uint8_t *mask, int64_t n_rays, int64_t n_r, void *stream);
 
 /* K3 sparse_volume_sampling (volume_func_kernel.cu:174-291). zvals/mask (n_rays,n_pts) zero-initialised by the
  * caller.  (rng_state, rng_inc) is the host pcg32 BEFORE the call (reference: file-static `pcg32 rng{9121}`,

@@ -132,6 +132,20 @@ def aabb_intersection_torch(rays_o, rays_d, aabb_v32, eps=1e-7):
     return near, far, pts, mask.astype(bool)
 
 
+def sphere_intersection(rays_o, rays_d, radius, origin=(0.0, 0.0, 0.0)):
+    """sphere_ray_intersection (geometry/ray.py:180-255); radius scalar or (n_r,)."""
+    o, d = _f32(rays_o), _f32(rays_d)
+    rad = _f32(np.atleast_1d(radius))
+    org = _f32(np.asarray(origin, np.float32).reshape(3))
+    R, K = o.shape[0], rad.shape[0]
+    near = np.zeros((R, K), np.float32)
+    far = np.zeros((R, K), np.float32)
+    pts = np.zeros((R, K, 2, 3), np.float32)
+    mask = np.zeros((R, K), np.uint8)
+    lib().orc_sphere_intersection(_p(o), _p(d), _p(rad), _p(org), _p(near), _p(far), _p(pts), _p(mask), C.c_int64(R), C.c_int64(K))
+    return near, far, pts, mask.astype(bool)
+
+
 def sparse_volume_sampling(rays_o, rays_d, near, far, n_pts, dt, aabb23, n_grid, bitfield, near_distance,
                            rng_state, rng_inc, with_trace=False):
     """K3.  Returns zvals (R,n_pts), mask (R,n_pts) bool, counts (R) [, voxel trace (R,n_pts) int32]."""

@@ -184,6 +184,49 @@ ORC_API void orc_aabb_intersection_torch(const float *rays_o, const float *rays_
 }
 
 /* ---------------------------------------------------------------------------------------
+ * sphere_ray_intersection (arcnerf/geometry/ray.py:180-255) with set_tensor_to_zeros (|x| < 1e-5 -> 0,
+ * common/utils/torch_utils.py:50-54) and batch_dot_product (sum over the last dim).  radius (n_r), one origin.
+ * near/far (n_rays, n_r), pts (n_rays, n_r, 2, 3), mask (n_rays, n_r).
+ * ------------------------------------------------------------------------------------- */
+static inline float orc_zero_small(float v) { return fabsf(v) < 1e-5f ? 0.0f : v; }
+
+ORC_API void orc_sphere_intersection(const float *rays_o, const float *rays_d, const float *radius, const float *origin,
+                                     float *near_out, float *far_out, float *pts, uint8_t *mask_out, int64_t n_rays,
+                                     int64_t n_r) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n_rays * n_r; ++i) {
+        int64_t ray = i / n_r, k = i % n_r;
+        const float *o = rays_o + 3 * ray, *d = rays_d + 3 * ray;
+        const float r = radius[k];
+        float oc[3];
+        for (int a = 0; a < 3; ++a) oc[a] = origin[a] - o[a];
+        float z_half = oc[0] * d[0];
+        z_half = z_half + oc[1] * d[1];
+        z_half = z_half + oc[2] * d[2];
+        z_half = orc_zero_small(z_half);
+        float oc2 = oc[0] * oc[0];
+        oc2 = oc2 + oc[1] * oc[1];
+        oc2 = oc2 + oc[2] * oc[2];
+        const int inside = sqrtf(oc2) <= r;
+        int mask = (z_half > 0.0f) || inside;
+        float d2 = orc_zero_small(oc2 - z_half * z_half);
+        mask = mask && (d2 >= 0.0f);
+        float z_off = orc_zero_small(r * r - d2);
+        mask = mask && (z_off >= 0.0f);
+        z_off = sqrtf(z_off); /* NaN where masked out, overwritten below */
+        float near = z_half - z_off, far = z_half + z_off;
+        if (!(near >= 0.0f)) near = isnan(near) ? near : 0.0f; /* clamp_min keeps NaN */
+        if (!(far >= 0.0f)) far = isnan(far) ? far : 0.0f;
+        if (!mask) { near = 0.0f; far = 0.0f; }
+        near_out[i] = near; far_out[i] = far; mask_out[i] = (uint8_t)mask;
+        for (int a = 0; a < 3; ++a) {
+            pts[i * 6 + a] = o[a] + near * d[a];
+            pts[i * 6 + 3 + a] = o[a] + far * d[a];
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------
  * K3  sparse_volume_sampling (volume_func_kernel.cu:174-236).  zvals/mask must be
  * zero-initialised by the caller (ops/volume_func.py:100-105).  rng (state,inc) is the
  * host generator BEFORE the launch; the kernel copy advances i*8 per ray.

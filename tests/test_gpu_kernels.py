@@ -190,6 +190,35 @@ def test_aabb_torch_semantics_vs_reference_golden(F):
     close(host(pts), g['pts'], rtol=1e-5, atol=1e-5)
 
 
+def test_sphere_intersection_vs_reference_golden_and_oracle(F, oracle):
+    g = load_golden('g4_intersections')
+    near, far, pts, mask = F.sphere_intersection(dev(g['rays_o']), dev(g['rays_d']), dev(g['radius']))
+    assert (host(mask) == g['s_mask']).all()
+    close(host(near), g['s_near'], rtol=1e-6, atol=1e-6)
+    close(host(far), g['s_far'], rtol=1e-6, atol=1e-6)
+    close(host(pts), g['s_pts'], rtol=1e-6, atol=2e-6)
+    # bit-exact against the C restatement (same operation order), shifted origin and a scalar radius included
+    rng = np.random.default_rng(12)
+    o = (rng.normal(size=(5000, 3)) * 1.5).astype(np.float32)
+    d = rng.normal(size=(5000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    org = (0.25, -0.5, 0.125)
+    ref = oracle.sphere_intersection(o, d, 1.3, org)
+    got = F.sphere_intersection(dev(o), dev(d), 1.3, org)
+    for a, b in zip(got, ref):
+        assert np.array_equal(host(a), b)
+    # the module mirror: Sphere / SphereBound
+    from arcnerf_amd.models.base_modules.obj_bound import build_obj_bound
+    from arcnerf_amd.utils.cfgs_utils import dict_to_obj
+    bound, kind = build_obj_bound(dict_to_obj({'obj_bound': {'sphere': {'origin': list(org), 'radius': 1.3}}}))
+    bound = bound.cuda()
+    nr, fr, mask_rays = bound.get_near_far_from_rays({'rays_o': dev(o), 'rays_d': dev(d)})
+    assert kind == 'sphere' and nr.shape == (5000, 1) and mask_rays.shape == (5000,)
+    assert np.array_equal(host(nr), ref[0]) and np.array_equal(host(mask_rays), ref[3][:, 0])
+    zvals, mask_pts = bound.get_zvals_from_near_far(nr, fr, 16, inference_only=True)
+    assert zvals.shape == (5000, 16) and mask_pts is None
+
+
 def test_k2_bit_exact_vs_oracle(F, oracle):
     g = load_golden('g4_intersections')
     aabb23 = np.ascontiguousarray(np.transpose(g['aabb'], (0, 2, 1)))

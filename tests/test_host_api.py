@@ -150,3 +150,19 @@ def test_refresh_cell_selection_is_sync_free_and_matches_reference_sets():
         uni = cells[:n_s]
         assert uni.unique().numel() == n_s and int(uni.min()) >= 0 and int(uni.max()) < n
         assert torch.equal(cells[n_s:int(n_valid)], want)
+
+
+def test_sphere_bound_is_registered_and_built_from_cfgs():
+    """build_obj_bound picks SphereBound for an `obj_bound.sphere` block (obj_bound/__init__.py:25-62) with the reference's
+    Sphere accessors; the ray test itself needs the GPU (tests/test_gpu_kernels.py)."""
+    from arcnerf_amd.models.base_modules.obj_bound import build_obj_bound
+    from arcnerf_amd.utils.cfgs_utils import dict_to_obj
+    from arcnerf_amd.utils.registry import BOUND_REGISTRY
+    assert 'SphereBound' in BOUND_REGISTRY
+    bound, kind = build_obj_bound(dict_to_obj({'obj_bound': {'sphere': {'origin': [0.0, 0.5, 0.0], 'radius': 2.0}, 'epoch_optim': 16}}))
+    assert kind == 'sphere' and type(bound).__name__ == 'SphereBound'
+    assert bound.get_obj_bound().get_radius(in_float=True) == 2.0
+    assert bound.get_obj_bound().get_origin(in_tuple=True) == (0.0, 0.5, 0.0)
+    assert bound.get_optim_cfgs('epoch_optim') == 16
+    with pytest.raises(RuntimeError):   # no CPU fallback on the product path
+        bound.get_near_far_from_rays({'rays_o': torch.zeros(4, 3), 'rays_d': torch.ones(4, 3)})

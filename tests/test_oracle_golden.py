@@ -115,6 +115,20 @@ def test_g4_aabb_torch_semantics(oracle):
     close(pts, g['pts'], atol=1e-5)
 
 
+def test_g4_sphere_intersection(oracle):
+    """sphere_ray_intersection (geometry/ray.py:180-255) incl. the hand cases of tests_ray.py (outside / tangent / inside /
+    on-surface rays): masks identical, near / far / points to 1 ulp (torch's dot-product summation order)."""
+    g = load_golden('g4_intersections')
+    near, far, pts, mask = oracle.sphere_intersection(g['rays_o'], g['rays_d'], g['radius'])
+    assert (mask == g['s_mask']).all()
+    close(near, g['s_near'], rtol=1e-6, atol=1e-6)
+    close(far, g['s_far'], rtol=1e-6, atol=1e-6)
+    close(pts, g['s_pts'], rtol=1e-6, atol=2e-6)
+    assert (near[~mask] == 0).all() and (far[~mask] == 0).all() and (near >= 0).all() and (far >= near).all()
+    inside = np.linalg.norm(g['rays_o'], axis=-1) < g['radius'][0] - 1e-3
+    assert mask[inside, 0].all() and (near[inside, 0] == 0).all()
+
+
 def test_k2_consistent_with_torch_path(oracle):
     """K2 (CUDA semantics) has no runnable reference: where it reports a hit with tmin>0 it must agree with
     the torch path up to the torch path's +-eps shift."""
