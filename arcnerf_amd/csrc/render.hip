@@ -359,6 +359,60 @@ __global__ void __launch_bounds__(256) huber_kernel(const float *__restrict__ x,
     if (loss && lane_id() == 0) atomicAdd(loss, acc * scale);
 }
 
+// ---- NeuS interval opacity --------------------------------------------------------------------------------------------
+// sdf_to_alpha (arcnerf/models/neus_model.py:242-265), cdf = sigmoid(sdf * s) (:221-228).  One lane per interval; s is read
+// from device memory (it is exp(10 * inv_s) of a learnable parameter: no host round trip).  Backward also reduces d s.
+__device__ __forceinline__ float sigmoidf_dev(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void __launch_bounds__(256)
+sdf_to_alpha_fwd_kernel(const float *__restrict__ mid_sdf, const float *__restrict__ zvals, const float *__restrict__ mid_slope,
+                        const float *__restrict__ s_ptr, int clip, float *__restrict__ alpha, int64_t R, int P) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * (P - 1)) return;
+    const int64_t r = i / (P - 1);
+    const int k = (int)(i - r * (P - 1));
+    const float s = *s_ptr;
+    const float dist = zvals[r * P + k + 1] - zvals[r * P + k];
+    const float h = mid_slope[i] * dist * 0.5f;
+    const float pc = sigmoidf_dev((mid_sdf[i] - h) * s), nc = sigmoidf_dev((mid_sdf[i] + h) * s);
+    float a = (pc - nc + 1e-5f) / (pc + 1e-5f);
+    if (clip) a = a < 0.0f ? 0.0f : (a > 1.0f ? 1.0f : a);
+    alpha[i] = a;
+}
+
+__global__ void __launch_bounds__(256)
+sdf_to_alpha_bwd_kernel(const float *__restrict__ mid_sdf, const float *__restrict__ zvals, const float *__restrict__ mid_slope,
+                        const float *__restrict__ s_ptr, int clip, const float *__restrict__ d_alpha, float *__restrict__ d_sdf,
+                        float *__restrict__ d_slope, float *__restrict__ d_s, int64_t R, int P) {
+    __shared__ float s_part[4];
+    const float s = *s_ptr;
+    float acc = 0.f;
+    const int64_t total = R * (P - 1);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / (P - 1);
+        const int k = (int)(i - r * (P - 1));
+        const float dist = zvals[r * P + k + 1] - zvals[r * P + k];
+        const float h = mid_slope[i] * dist * 0.5f;
+        const float prev = mid_sdf[i] - h, next = mid_sdf[i] + h;
+        const float pc = sigmoidf_dev(prev * s), nc = sigmoidf_dev(next * s);
+        const float B = pc + 1e-5f;
+        const float a = (pc - nc + 1e-5f) / B;
+        float g = d_alpha[i];
+        if (clip && (a < 0.0f || a > 1.0f)) g = 0.0f;  // torch.clip passes the gradient on [0, 1] inclusive
+        const float gp = g * (nc / (B * B)) * (pc * (1.0f - pc));
+        const float gn = -g * (1.0f / B) * (nc * (1.0f - nc));
+        d_sdf[i] = (gp + gn) * s;
+        d_slope[i] = (gn - gp) * s * (dist * 0.5f);
+        acc += gp * prev + gn * next;
+    }
+    if (!d_s) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(d_s, (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+}
+
 }  // namespace arcn
 
 using namespace arcn;
@@ -451,4 +505,25 @@ ARCN_EXPORT int arcn_sample_cdf(const float *bins, const float *cdf, const float
     hipLaunchKernelGGL(sample_cdf_kernel, dim3((unsigned)R), dim3(256), sizeof(float) * n_pad, as_stream(stream), bins, cdf,
                        u, n_pts, n_sample, n_pad, eps, do_sort, samples, inds);
     return check_launch("sample_cdf");
+}
+
+ARCN_EXPORT int arcn_sdf_to_alpha_fwd(const float *mid_sdf, const float *zvals, const float *mid_slope, const float *s_dev, int clip,
+                                      float *alpha, int64_t R, int P, void *stream) {
+    if (R <= 0 || P < 2) return ARCN_OK;
+    if (!mid_sdf || !zvals || !mid_slope || !s_dev || !alpha) return einval("sdf_to_alpha_fwd: missing argument");
+    hipLaunchKernelGGL(sdf_to_alpha_fwd_kernel, dim3((unsigned)ceil_div<int64_t>(R * (P - 1), 256)), dim3(256), 0, as_stream(stream),
+                       mid_sdf, zvals, mid_slope, s_dev, clip, alpha, R, P);
+    return check_launch("sdf_to_alpha_fwd");
+}
+
+ARCN_EXPORT int arcn_sdf_to_alpha_bwd(const float *mid_sdf, const float *zvals, const float *mid_slope, const float *s_dev, int clip,
+                                      const float *d_alpha, float *d_sdf, float *d_slope, float *d_s, int64_t R, int P,
+                                      void *stream) {
+    if (R <= 0 || P < 2) return ARCN_OK;
+    if (!mid_sdf || !zvals || !mid_slope || !s_dev || !d_alpha || !d_sdf || !d_slope) return einval("sdf_to_alpha_bwd: missing argument");
+    int64_t blocks = ceil_div<int64_t>(R * (P - 1), 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sdf_to_alpha_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), mid_sdf, zvals, mid_slope,
+                       s_dev, clip, d_alpha, d_sdf, d_slope, d_s, R, P);
+    return check_launch("sdf_to_alpha_bwd");
 }

@@ -117,3 +117,24 @@ class RayMarchingFn(torch.autograd.Function):
                                           d_depth.contiguous(), d_mask.contiguous(), add_inf_z=add_inf_z, white_bkg=white_bkg,
                                           alpha=alpha, bkg_color=bkg, noise=noise)
         return (d_geo if sigma is not None else None), d_rad, None, (d_geo if alpha is not None else None), None, None, None, None
+
+
+class SdfToAlphaFn(torch.autograd.Function):
+    """NeuS sdf_to_alpha (arcnerf/models/neus_model.py:242-265) with gradients w.r.t. the mid-point sdf, the slope and the
+    scale s (a tensor: exp(10 * inv_s) of the learnable parameter; a float scale gets no gradient).  zvals carry no gradient,
+    as in the reference's use (they are detached samples)."""
+
+    @staticmethod
+    def forward(ctx, mid_sdf, zvals, mid_slope, s, clip):
+        ctx.clip = bool(clip)
+        ctx.s_is_tensor = torch.is_tensor(s)
+        s_t = s if ctx.s_is_tensor else torch.tensor([float(s)], dtype=torch.float32, device=zvals.device)
+        ctx.save_for_backward(mid_sdf, zvals, mid_slope, s_t)
+        return F.sdf_to_alpha_fwd(mid_sdf, zvals, mid_slope, s_t, clip=ctx.clip)
+
+    @staticmethod
+    def backward(ctx, d_alpha):
+        mid_sdf, zvals, mid_slope, s_t = ctx.saved_tensors
+        d_sdf, d_slope, d_s = F.sdf_to_alpha_bwd(mid_sdf, zvals, mid_slope, s_t, d_alpha.contiguous(), clip=ctx.clip)
+        d_s = d_s.reshape(s_t.shape) if (ctx.s_is_tensor and ctx.needs_input_grad[3]) else None
+        return d_sdf, None, d_slope, d_s, None

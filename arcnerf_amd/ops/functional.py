@@ -433,6 +433,40 @@ def huber_loss_grad(x, y, delta, weight=1.0, dx=None, loss=None):
     return loss, dx
 
 
+def _scale_tensor(s, device):
+    """the NeuS scale as a device scalar (a python float is uploaded once; a tensor - exp(10 * inv_s) - is used in place)"""
+    if torch.is_tensor(s):
+        _req(s)
+        return _f32(s).reshape(1)
+    return torch.tensor([float(s)], dtype=torch.float32, device=device)
+
+
+def sdf_to_alpha_fwd(mid_sdf, zvals, mid_slope, s, clip=True):
+    """NeuS sdf_to_alpha (models/neus_model.py:242-265): mid_sdf, mid_slope (R,P-1), zvals (R,P) -> alpha (R,P-1)"""
+    _req(mid_sdf, zvals, mid_slope)
+    sd, z, sl = _f32(mid_sdf), _f32(zvals), _f32(mid_slope)
+    R, P = z.shape
+    assert sd.shape == (R, P - 1) and sl.shape == (R, P - 1)
+    alpha = torch.empty((R, P - 1), dtype=torch.float32, device=z.device)
+    sv = _scale_tensor(s, z.device)
+    N.check(N.lib().arcn_sdf_to_alpha_fwd(N.ptr(sd), N.ptr(z), N.ptr(sl), N.ptr(sv), int(bool(clip)), N.ptr(alpha), R, P, N.stream()),
+            'sdf_to_alpha_fwd')
+    return alpha
+
+
+def sdf_to_alpha_bwd(mid_sdf, zvals, mid_slope, s, d_alpha, clip=True):
+    """-> d mid_sdf, d mid_slope (R,P-1), d s (1,) device tensor"""
+    _req(mid_sdf, zvals, mid_slope, d_alpha)
+    sd, z, sl, da = _f32(mid_sdf), _f32(zvals), _f32(mid_slope), _f32(d_alpha)
+    R, P = z.shape
+    d_sdf, d_slope = torch.empty_like(sd), torch.empty_like(sl)
+    d_s = torch.zeros(1, dtype=torch.float32, device=z.device)
+    sv = _scale_tensor(s, z.device)
+    N.check(N.lib().arcn_sdf_to_alpha_bwd(N.ptr(sd), N.ptr(z), N.ptr(sl), N.ptr(sv), int(bool(clip)), N.ptr(da), N.ptr(d_sdf),
+                                         N.ptr(d_slope), N.ptr(d_s), R, P, N.stream()), 'sdf_to_alpha_bwd')
+    return d_sdf, d_slope, d_s
+
+
 def sample_cdf(bins, cdf, u, eps=1e-5, sort=True, want_inds=False):
     _req(bins, cdf, u)
     bins, cdf, u = _f32(bins), _f32(cdf), _f32(u)

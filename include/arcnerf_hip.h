@@ -263,6 +263,14 @@ int arcn_composite_packed_bwd(const float *sigma, const float *radiance, const f
 int arcn_huber_loss_grad(const float *x, const float *y, int64_t n, float delta, float weight, float *dx, float *loss,
                          void *stream);
 
+/* NeuS sdf_to_alpha (arcnerf/models/neus_model.py:242-265, cdf = sigmoid(sdf * s), :221-228): mid_sdf, mid_slope, alpha
+ * (R, P-1); zvals (R, P); s_dev = the scale as a DEVICE scalar (exp(10 * inv_s) of a learnable parameter).  bwd writes
+ * d_sdf, d_slope and ADDS the scalar d s into d_s (optional; caller zeroes). */
+int arcn_sdf_to_alpha_fwd(const float *mid_sdf, const float *zvals, const float *mid_slope, const float *s_dev, int clip,
+                          float *alpha, int64_t R, int P, void *stream);
+int arcn_sdf_to_alpha_bwd(const float *mid_sdf, const float *zvals, const float *mid_slope, const float *s_dev, int clip,
+                          const float *d_alpha, float *d_sdf, float *d_slope, float *d_s, int64_t R, int P, void *stream);
+
 /* sample_cdf (ray_helper.py:432-473): bins/cdf (R,n_pts), u (R,n_sample) -> samples (R,n_sample) sorted,
  * inds (R,n_sample) int32 optional (searchsorted right=True). */
 int arcn_sample_cdf(const float *bins, const float *cdf, const float *u, int64_t R, int n_pts, int n_sample, float eps,

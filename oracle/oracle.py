@@ -322,6 +322,26 @@ def linear_bwd(x, W, pre, y, dy, act=None, beta=1.0, has_bias=False):
 # ------------------------------------------------------------------------------------------------
 # compositing / resampling
 # ------------------------------------------------------------------------------------------------
+def sdf_to_alpha_fwd(mid_sdf, zvals, mid_slope, s, clip=True):
+    """NeuS sdf_to_alpha (models/neus_model.py:242-265): alpha (R, P-1)."""
+    sd, z, sl = _f32(mid_sdf), _f32(zvals), _f32(mid_slope)
+    R, P = z.shape
+    alpha = np.zeros((R, P - 1), np.float32)
+    lib().orc_sdf_to_alpha_fwd(_p(sd), _p(z), _p(sl), C.c_float(s), C.c_int(int(clip)), _p(alpha), C.c_int64(R), C.c_int(P))
+    return alpha
+
+
+def sdf_to_alpha_bwd(mid_sdf, zvals, mid_slope, s, d_alpha, clip=True):
+    """-> d mid_sdf, d mid_slope (R, P-1), d s (float)"""
+    sd, z, sl, da = _f32(mid_sdf), _f32(zvals), _f32(mid_slope), _f32(d_alpha)
+    R, P = z.shape
+    d_sdf, d_slope = np.zeros_like(sd), np.zeros_like(sl)
+    d_s = C.c_double(0.0)
+    lib().orc_sdf_to_alpha_bwd(_p(sd), _p(z), _p(sl), C.c_float(s), C.c_int(int(clip)), _p(da), _p(d_sdf), _p(d_slope),
+                               C.byref(d_s), C.c_int64(R), C.c_int(P))
+    return d_sdf, d_slope, float(d_s.value)
+
+
 def ray_marching_fwd(sigma, radiance, zvals, add_inf_z=False, white_bkg=False, alpha=None, bkg_color=None, noise=None):
     """Returns dict(rgb, depth, mask, alpha, trans_shift, weights) like ray_helper.ray_marching."""
     z = _f32(zvals)

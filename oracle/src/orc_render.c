@@ -209,3 +209,50 @@ ORC_API void orc_zvals_from_near_far(const float *near, const float *far, int64_
         }
     }
 }
+
+
+/* ---------------------------------------------------------------------------------------
+ * NeuS interval opacity: sdf_to_alpha (arcnerf/models/neus_model.py:242-265) with sdf_to_cdf = sigmoid(sdf * s)
+ * (:221-228).  mid_sdf, mid_slope, alpha (R, P-1); zvals (R, P).  Backward: d alpha -> d mid_sdf, d mid_slope and the
+ * scalar d s (sum over all intervals); torch.clip passes the gradient on [0, 1] inclusive.
+ * ------------------------------------------------------------------------------------- */
+static inline float orc_sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+ORC_API void orc_sdf_to_alpha_fwd(const float *mid_sdf, const float *zvals, const float *mid_slope, float s, int clip,
+                                  float *alpha, int64_t R, int P) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < R; ++r)
+        for (int k = 0; k < P - 1; ++k) {
+            const int64_t i = r * (P - 1) + k;
+            const float dist = zvals[r * P + k + 1] - zvals[r * P + k];
+            const float h = mid_slope[i] * dist * 0.5f;
+            const float pc = orc_sigmoidf((mid_sdf[i] - h) * s), nc = orc_sigmoidf((mid_sdf[i] + h) * s);
+            float a = (pc - nc + 1e-5f) / (pc + 1e-5f);
+            if (clip) a = a < 0.0f ? 0.0f : (a > 1.0f ? 1.0f : a);
+            alpha[i] = a;
+        }
+}
+
+ORC_API void orc_sdf_to_alpha_bwd(const float *mid_sdf, const float *zvals, const float *mid_slope, float s, int clip,
+                                  const float *d_alpha, float *d_sdf, float *d_slope, double *d_s, int64_t R, int P) {
+    double acc = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : acc)
+    for (int64_t r = 0; r < R; ++r)
+        for (int k = 0; k < P - 1; ++k) {
+            const int64_t i = r * (P - 1) + k;
+            const float dist = zvals[r * P + k + 1] - zvals[r * P + k];
+            const float h = mid_slope[i] * dist * 0.5f;
+            const float prev = mid_sdf[i] - h, next = mid_sdf[i] + h;
+            const float pc = orc_sigmoidf(prev * s), nc = orc_sigmoidf(next * s);
+            const float B = pc + 1e-5f;
+            const float a = (pc - nc + 1e-5f) / B;
+            float g = d_alpha[i];
+            if (clip && (a < 0.0f || a > 1.0f)) g = 0.0f;
+            const float gp = g * (nc / (B * B)) * (pc * (1.0f - pc)); /* d / d (prev * s) */
+            const float gn = -g * (1.0f / B) * (nc * (1.0f - nc));    /* d / d (next * s) */
+            d_sdf[i] = (gp + gn) * s;
+            d_slope[i] = (gn - gp) * s * (dist * 0.5f);
+            acc += (double)(gp * prev + gn * next);
+        }
+    *d_s = acc;
+}

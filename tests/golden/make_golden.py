@@ -7,7 +7,7 @@ Run only in the build container (needs /root/reference):
 The .npz files hold inputs and the reference's outputs (data only).  Nothing here travels as
 code to the GPU box; tests read the .npz files and never import the reference.
 Vector ids follow SURVEY.md §8(c): G1 compositing, G2 resampling, G3 zvals, G4 intersections,
-G5 voxel math, G6 hash grid, G7 freq/SH, G8 MLPs + TruncExp, G10 occupancy update.
+G5 voxel math, G6 hash grid, G7 freq/SH, G8 MLPs + TruncExp, G10 occupancy update, G12 NeuS interval opacity.
 (G9 end-to-end model vectors are made by make_golden_models.py; G11 pcg32 is a published
 known-answer vector checked in tests/test_oracle_golden.py.)
 """
@@ -377,7 +377,40 @@ def g10_occupancy():
          mean_opa=np.float32(vol.get_mean_voxel_opacity()))
 
 
+def g12_neus():
+    """NeuS per-interval math (arcnerf/models/neus_model.py:221-265): sdf_to_cdf / sdf_to_pdf / sdf_to_alpha with the
+    gradients w.r.t. the mid sdf, the slope and the (learnable) scale s, both clip settings, duplicated-z tails included."""
+    from arcnerf.models.neus_model import sdf_to_alpha, sdf_to_cdf, sdf_to_pdf
+    g = torch.Generator().manual_seed(1212)
+    R, P = 48, 33
+    zvals, _ = torch.sort(torch.rand(R, P, generator=g) * 4.0 + 0.5, dim=-1)
+    zvals[::5, -6:] = zvals[::5, -7:-6]                       # padded tails: zero-length intervals
+    sdf = (torch.rand(R, P - 1, generator=g) - 0.4) * 0.6
+    slope = -torch.rand(R, P - 1, generator=g) * 1.2
+    slope[:, ::7] = 0.0
+    out = dict(zvals=npy(zvals), mid_sdf=npy(sdf), mid_slope=npy(slope))
+    for tag, s_val in (('s64', 64.0), ('s4', 4.0), ('s800', 800.0)):
+        out[tag + '_cdf'] = npy(sdf_to_cdf(sdf, s_val))
+        out[tag + '_pdf'] = npy(sdf_to_pdf(sdf, s_val))
+        for clip in (True, False):
+            a = sdf.clone().requires_grad_(True)
+            b = slope.clone().requires_grad_(True)
+            sv = torch.tensor(s_val, requires_grad=True)
+            alpha = sdf_to_alpha(a, zvals, b, sv, clip=clip)
+            gout = torch.rand(alpha.shape, generator=torch.Generator().manual_seed(7))
+            (alpha * gout).sum().backward()
+            key = '{}_clip{}'.format(tag, int(clip))
+            out[key + '_alpha'] = npy(alpha)
+            out[key + '_d_sdf'], out[key + '_d_slope'], out[key + '_d_s'] = npy(a.grad), npy(b.grad), npy(sv.grad)
+            out[key + '_gout'] = npy(gout)
+    save('g12_neus', **out)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1:     # regenerate selected vectors only, e.g. `make_golden.py g12_neus`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     g1_compositing()
     g2_resampling()
     g3_zvals()

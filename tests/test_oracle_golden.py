@@ -338,3 +338,20 @@ def test_k3_sampler_invariants(oracle):
     if cnt[7] > 0:
         k = np.round((z[7, 0] - start7) / dt)
         assert abs(z[7, 0] - (start7 + k * dt)) < 1e-4
+
+
+# ---- G12 NeuS interval opacity -----------------------------------------------------------------------
+@pytest.mark.parametrize('tag,s', [('s64', 64.0), ('s4', 4.0), ('s800', 800.0)])
+@pytest.mark.parametrize('clip', [True, False])
+def test_g12_sdf_to_alpha(oracle, tag, s, clip):
+    """sdf_to_alpha fwd + gradients w.r.t. mid sdf / slope / the scale against the reference's autograd (neus_model.py:242-265)."""
+    g = load_golden('g12_neus')
+    key = '{}_clip{}'.format(tag, int(clip))
+    alpha = oracle.sdf_to_alpha_fwd(g['mid_sdf'], g['zvals'], g['mid_slope'], s, clip)
+    close(alpha, g[key + '_alpha'], rtol=1e-6, atol=5e-7)
+    d_sdf, d_slope, d_s = oracle.sdf_to_alpha_bwd(g['mid_sdf'], g['zvals'], g['mid_slope'], s, g[key + '_gout'], clip)
+    close(d_sdf, g[key + '_d_sdf'], rtol=1e-4, atol=1e-5 * np.abs(g[key + '_d_sdf']).max())
+    close(d_slope, g[key + '_d_slope'], rtol=1e-4, atol=1e-5 * max(np.abs(g[key + '_d_slope']).max(), 1e-30))
+    assert abs(d_s - float(g[key + '_d_s'])) <= 1e-4 * abs(float(g[key + '_d_s'])) + 1e-7
+    dup = g['zvals'][:, 1:] == g['zvals'][:, :-1]          # padded tails: zero-length intervals carry alpha = 1e-5 / (cdf + 1e-5)
+    assert dup.any() and (d_slope[dup] == 0).all()
