@@ -5,8 +5,9 @@ from ..utils.cfgs_utils import valid_key_in_cfgs
 from ..utils.registry import MODEL_REGISTRY
 from .full_model import FullModel
 from .nerf_model import NeRF
+from .neus_model import Neus
 
-__all__ = ['build_model', 'FullModel', 'NeRF']
+__all__ = ['build_model', 'FullModel', 'NeRF', 'Neus']
 
 
 def build_model(cfgs, logger=None):

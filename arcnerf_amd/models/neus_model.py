@@ -1,12 +1,126 @@
-"""NeuS per-interval math (arcnerf/models/neus_model.py:221-265): sdf_to_cdf, sdf_to_pdf, sdf_to_alpha.
+"""NeuS (arcnerf/models/neus_model.py): the model class (:21-218) and its per-interval math sdf_to_cdf / sdf_to_pdf /
+sdf_to_alpha (:221-265).  SURVEY.md section 8f, rank 1.
 
-Second piece of the NeuS row (the first is the sphere bound).  sdf_to_alpha runs as one HIP
-kernel forward and one backward (gradients to the mid sdf, the slope and the learnable scale).  The `Neus` model class
-itself needs the geometry net's input gradient (normals) with a second-order backward for the Eikonal term and is not built
-yet: `build_model` raises NotImplementedError for `type: NeuS`."""
+What runs where: the sphere bound, sdf_to_alpha (fwd + bwd), the inverse-CDF up-sampling and the compositing (alpha= branch)
+are HIP kernels; the geometry / radiance nets of configs/models/neus.yaml are 256-wide nn.Linear stacks (library GEMMs through
+torch, as in the reference) whose input gradient - the normal - is taken by autograd with create_graph=True, so the Eikonal term
+and everything downstream of the normals differentiate a second time through torch.  The hash-grid + fused-MLP variant
+(NeuS-NGP) needs a second-order backward of those kernels and is not built yet."""
+import math
+
+import numpy as np
 import torch
+import torch.nn as nn
+import torch.nn.functional as F
 
+from ..geometry.ray import get_ray_points_by_zvals, normalize
 from ..ops.autograd import SdfToAlphaFn
+from ..render.ray_helper import alpha_to_weights, sample_pdf
+from ..utils.cfgs_utils import get_value_from_cfgs_field
+from ..utils.registry import MODEL_REGISTRY
+from ..utils.torch_utils import chunk_processing
+from .base_modules import build_geo_model, build_radiance_model
+from .sdf_model import SdfModel
+
+
+@MODEL_REGISTRY.register()
+class Neus(SdfModel):
+    def __init__(self, cfgs):
+        super().__init__(cfgs)
+        self.geo_net = build_geo_model(self.cfgs.model.geometry)
+        self.radiance_net = build_radiance_model(self.cfgs.model.radiance)
+        self.ray_cfgs['n_importance'] = get_value_from_cfgs_field(self.cfgs.model.rays, 'n_importance', 0)
+        self.ray_cfgs['n_iter'] = get_value_from_cfgs_field(self.cfgs.model.rays, 'n_iter', 4)
+        self.radius_init = get_value_from_cfgs_field(self.cfgs.model.geometry, 'radius_init', 1.0)
+        self.inv_s, self.speed_factor = self.get_params()
+        self.anneal_end = get_value_from_cfgs_field(self.cfgs.model.params, 'anneal_end', 0)
+        self.radius_bound = get_value_from_cfgs_field(self.cfgs.model.rays, 'radius_bound', 1.5)
+
+    def get_net(self):
+        return self.geo_net, self.radiance_net
+
+    def get_params(self):
+        """inv_s = -log(init_var) / speed_factor, learnable (neus_model.py:45-53)"""
+        dtype = next(self.parameters()).dtype
+        init_var = get_value_from_cfgs_field(self.cfgs.model.params, 'init_var', 0.05)
+        speed_factor = get_value_from_cfgs_field(self.cfgs.model.params, 'speed_factor', 10)
+        return nn.Parameter(torch.tensor([-np.log(init_var) / speed_factor], dtype=dtype), requires_grad=True), speed_factor
+
+    def forward_scale(self):
+        """scale = exp(inv_s * speed)"""
+        return torch.exp(self.inv_s * self.speed_factor)
+
+    def get_cos_anneal(self, cur_epoch):
+        return 1.0 if self.anneal_end == 0 else min(1.0, cur_epoch / self.anneal_end)
+
+    def _forward(self, inputs, inference_only=False, get_progress=False, cur_epoch=0, total_epoch=300000):
+        rays_o, rays_d, zvals = inputs['rays_o'], inputs['rays_d'], inputs['zvals']
+        mask_pts, bkg_color = inputs['mask_pts'], inputs['bkg_color']
+        zvals, mask_pts = self.upsample_zvals(rays_o, rays_d, zvals, mask_pts, inference_only)
+        mid_zvals, zvals, mask_mid_pts = self.handle_mid_pts(zvals, mask_pts)
+        sdf, radiance, normal_pts = self.get_sdf_radiance_normal_by_mask_pts(self.geo_net, self.radiance_net, rays_o, rays_d,
+                                                                             mid_zvals, mask_mid_pts, inference_only)
+        rays_d_repeat = torch.repeat_interleave(rays_d.unsqueeze(1), mid_zvals.shape[1], dim=1)
+        cos_anneal_ratio = 1.0 if inference_only else self.get_cos_anneal(cur_epoch)
+        # rays and normals are opposite: the slope (their dot product) is negative
+        slope = torch.sum(rays_d_repeat * normal_pts, dim=-1, keepdim=True)[..., 0]
+        iter_slope = -(F.relu(-slope * 0.5 + 0.5) * (1 - cos_anneal_ratio) + F.relu(-slope) * cos_anneal_ratio)
+        alpha = sdf_to_alpha(sdf, zvals, iter_slope, self.forward_scale())
+        output = self.ray_marching(sdf, radiance, mid_zvals, alpha=alpha, inference_only=inference_only, bkg_color=bkg_color)
+        output['normal'] = torch.sum(output['weights'].unsqueeze(-1) * normalize(normal_pts), -2)
+        if not inference_only:
+            output['params'] = {'scale': float(self.forward_scale().clone())}
+            output['normal_pts'] = normal_pts
+        return self.output_get_progress(output, get_progress)
+
+    def upsample_zvals(self, rays_o, rays_d, zvals, mask_pts=None, inference_only=False, s=32):
+        """n_iter rounds of importance sampling around the sdf zero crossing (neus_model.py:106-172)"""
+        if self.get_ray_cfgs('n_importance') <= 0:
+            return zvals, mask_pts
+        n_per_iter = self.get_ray_cfgs('n_importance') // self.get_ray_cfgs('n_iter')
+        for i in range(self.get_ray_cfgs('n_iter')):
+            n_rays, n_pts = zvals.shape[:2]
+            pts = get_ray_points_by_zvals(rays_o, rays_d, zvals).view(-1, 3)
+            sdf = self.forward_pts(pts).view(n_rays, n_pts)
+            prev_sdf, next_sdf = sdf[:, :-1], sdf[:, 1:]
+            mid_sdf = (prev_sdf + next_sdf) * 0.5
+            slope = (next_sdf - prev_sdf) / (zvals[:, 1:] - zvals[:, :-1] + 1e-5)
+            prev_slope = torch.cat([torch.zeros_like(slope[:, :1]), slope[:, :-1]], dim=-1)
+            slope = torch.minimum(prev_slope, slope).clamp(-10.0, 0.0)
+            radius = torch.norm(pts.view(n_rays, n_pts, 3), dim=-1)
+            inside_sphere = (radius[:, :-1] < self.radius_bound) | (radius[:, 1:] < self.radius_bound)
+            slope = slope * inside_sphere
+            alpha = sdf_to_alpha(mid_sdf, zvals, slope, s * (2 ** (i + 1)), clip=False)
+            _, weights = alpha_to_weights(alpha)
+            det = True if inference_only else (not self.get_ray_cfgs('perturb'))
+            new = sample_pdf(zvals.contiguous(), weights.detach().contiguous(), n_per_iter, det).detach()
+            zvals, _ = torch.sort(torch.cat([zvals, new], dim=-1), dim=-1)
+            mask_pts = self.merge_full_mask(mask_pts, new)
+        return zvals, mask_pts
+
+    def handle_mid_pts(self, zvals, mask_pts):
+        """section mid points + one extra section at the far end (neus_model.py:174-202)"""
+        sample_dist = (zvals[:, -1] - zvals[:, 0]) / self.get_ray_cfgs('n_sample') * 0.5
+        if mask_pts is None:
+            mid = 0.5 * (zvals[..., 1:] + zvals[..., :-1])
+            mid = torch.cat([mid, (mid[:, -1] + sample_dist).unsqueeze(-1)], dim=-1)
+            return mid, torch.cat([zvals, (zvals[:, -1] + sample_dist).unsqueeze(-1)], dim=-1), None
+        zeros_mask = torch.zeros((mask_pts.shape[0], 1), dtype=torch.bool, device=zvals.device)
+        ones_mask = torch.ones((mask_pts.shape[0], 1), dtype=torch.bool, device=zvals.device)
+        final_zvals = zvals[:, -1] + sample_dist * 2.0
+        _zvals = torch.ones((zvals.shape[0], zvals.shape[1] + 1), dtype=zvals.dtype, device=zvals.device) * final_zvals.unsqueeze(1)
+        _zvals[torch.cat([mask_pts, zeros_mask], dim=1)] = zvals[mask_pts]
+        mid = 0.5 * (_zvals[..., 1:] + _zvals[..., :-1])
+        return mid, _zvals, torch.cat([ones_mask, mask_pts[:, :-1]], dim=1)
+
+    def get_est_opacity(self, dt, pts):
+        """opacity of a voxel-sized step towards the origin (neus_model.py:204-218)"""
+        rays_d = -normalize(pts)
+        sdf, _, normal = chunk_processing(self.geo_net.forward_with_grad, self.chunk_pts, False, pts)
+        slope = torch.sum(rays_d * normal, dim=-1, keepdim=True)
+        zvals = torch.zeros((pts.shape[0], 2), dtype=pts.dtype, device=pts.device)
+        zvals[:, 1] += dt * 1.0 / math.sqrt(3)
+        return sdf_to_alpha(sdf, zvals, -F.relu(-slope), self.forward_scale())[:, 0]
 
 
 def sdf_to_cdf(sdf, s):

@@ -1,0 +1,51 @@
+"""SdfModel (arcnerf/models/sdf_model.py:11-101): foreground models whose geometry value is a signed distance (NeuS, VolSDF).
+Points are evaluated with the geometry net's input gradient (the normal), which also feeds the radiance net.  surface_render
+(sphere tracing, :103-168) is a consumer of the path, not part of it, and is not provided."""
+import torch
+
+from ..geometry.ray import get_ray_points_by_zvals, normalize
+from ..utils.torch_utils import chunk_processing
+from .fg_model import FgModel
+
+
+class SdfModel(FgModel):
+    @staticmethod
+    def sigma_reverse():
+        """sdf: smaller inside the object"""
+        return True
+
+    def get_est_opacity(self, dt, pts):
+        raise NotImplementedError('You must implement the function in sdf-like models')
+
+    def forward_pts_dir(self, pts, view_dir=None):
+        geo_net, radiance_net = self.get_net()
+        rays_d = torch.zeros_like(pts) if view_dir is None else normalize(view_dir)
+        sigma, rgb, _ = chunk_processing(self._forward_pts_dir, self.chunk_pts, False, geo_net, radiance_net, pts, rays_d)
+        return sigma, rgb
+
+    def get_sdf_radiance_normal_by_mask_pts(self, geo_net, radiance_net, rays_o, rays_d, zvals, mask_pts=None, inference_only=False):
+        """-> sdf (B,N), radiance (B,N,3), normal (B,N,3); only the valid points are evaluated, the padded tail repeats the last
+        valid point's values (sdf_model.py:42-101)"""
+        n_rays, n_pts = zvals.shape
+        pts = get_ray_points_by_zvals(rays_o, rays_d, zvals)
+        dirs = torch.repeat_interleave(rays_d.unsqueeze(1), n_pts, dim=1)
+        if mask_pts is None:
+            pts, dirs = pts.view(-1, 3), dirs.view(-1, 3)
+        else:
+            pts, dirs = pts[mask_pts].view(-1, 3), dirs[mask_pts].view(-1, 3)
+            if not inference_only:
+                self.adjust_dynamicbs_factor(mask_pts)
+        _sdf, _radiance, _normal = chunk_processing(self._forward_pts_dir, self.chunk_pts, False, geo_net, radiance_net, pts, dirs)
+        if mask_pts is None:
+            return _sdf.view(n_rays, -1), _radiance.view(n_rays, -1, 3), _normal.view(n_rays, -1, 3)
+        last = torch.cumsum(mask_pts.sum(dim=1), dim=0) - 1
+        sdf = torch.ones((n_rays, n_pts), dtype=zvals.dtype, device=zvals.device) * _sdf[last].unsqueeze(1)
+        radiance = torch.ones((n_rays, n_pts, 3), dtype=zvals.dtype, device=zvals.device) * _radiance[last].unsqueeze(1)
+        normal = torch.ones((n_rays, n_pts, 3), dtype=zvals.dtype, device=zvals.device) * _normal[last].unsqueeze(1)
+        sdf[mask_pts], radiance[mask_pts], normal[mask_pts] = _sdf, _radiance, _normal
+        return sdf, radiance, normal
+
+    @staticmethod
+    def _forward_pts_dir(geo_net, radiance_net, pts, rays_d=None):
+        sdf, feature, normal = geo_net.forward_with_grad(pts)
+        return sdf[..., 0], radiance_net(pts, rays_d, normal, feature), normal

@@ -116,7 +116,9 @@ class RayMarchingFn(torch.autograd.Function):
         d_geo, d_rad = F.ray_marching_bwd(sigma, radiance, zvals, d_rgb.contiguous() if radiance is not None else None,
                                           d_depth.contiguous(), d_mask.contiguous(), add_inf_z=add_inf_z, white_bkg=white_bkg,
                                           alpha=alpha, bkg_color=bkg, noise=noise)
-        return (d_geo if sigma is not None else None), d_rad, None, (d_geo if alpha is not None else None), None, None, None, None
+        # with alpha= given, sigma is only recorded (NeuS passes the sdf there, ray_helper.py:550-556): it gets no gradient
+        d_sigma = d_geo if (sigma is not None and alpha is None) else None
+        return d_sigma, d_rad, None, (d_geo if alpha is not None else None), None, None, None, None
 
 
 class SdfToAlphaFn(torch.autograd.Function):

@@ -166,3 +166,21 @@ def test_sphere_bound_is_registered_and_built_from_cfgs():
     assert bound.get_optim_cfgs('epoch_optim') == 16
     with pytest.raises(RuntimeError):   # no CPU fallback on the product path
         bound.get_near_far_from_rays({'rays_o': torch.zeros(4, 3), 'rays_d': torch.ones(4, 3)})
+
+
+def test_neus_yaml_builds_and_loads_reference_state_dict():
+    """configs/models/neus.yaml (the reference's file) builds the Neus mirror with SphereBound, geometric init, weight norm and
+    softplus(100); a state_dict exported by the reference loads with strict=True (same parameter names and shapes)."""
+    import numpy as np
+    from conftest import ROOT, load_golden
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    g = load_golden('g13_neus_model')
+    m = build_model(load_configs(os.path.join(ROOT, 'configs', 'neus.yaml'), [str(v) for v in g['overrides']]))
+    fg = m.fg_model
+    assert type(fg).__name__ == 'Neus' and type(fg.obj_bound).__name__ == 'SphereBound' and fg.sigma_reverse()
+    assert fg.get_ray_cfgs('n_importance') == 32 and fg.get_ray_cfgs('n_iter') == 4 and fg.radius_bound == 1.5
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd.')}
+    m.load_state_dict(sd, strict=True)
+    assert abs(float(fg.forward_scale()) - float(g['train_scale'])) < 1e-4
+    assert fg.get_cos_anneal(25000) == 0.5 and fg.get_cos_anneal(10 ** 6) == 1.0
