@@ -4,10 +4,11 @@ from copy import deepcopy
 from ..utils.cfgs_utils import valid_key_in_cfgs
 from ..utils.registry import MODEL_REGISTRY
 from .full_model import FullModel
+from .hdrnerf_model import HDRNeRF
 from .nerf_model import NeRF
 from .neus_model import Neus
 
-__all__ = ['build_model', 'FullModel', 'NeRF', 'Neus']
+__all__ = ['build_model', 'FullModel', 'HDRNeRF', 'NeRF', 'Neus']
 
 
 def build_model(cfgs, logger=None):

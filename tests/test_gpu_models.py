@@ -119,6 +119,42 @@ def test_neus_matches_reference_fullmodel(gpu):
     assert checked > 20 and 'grad.fg_model.inv_s' in g.files
 
 
+def test_hdrnerf_matches_reference_fullmodel(gpu):
+    """configs/models/hdrnerf.yaml (reduced widths): per-ray exposure times through FullModel, tone-mapping
+    MLPs, LDR + HDR compositing passes, unit-exposure output; reference state_dict loaded with strict=True."""
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    g = load_golden('g14_hdrnerf_model')
+    m = build_model(load_configs(os.path.join(CFG, 'hdrnerf.yaml'), [str(v) for v in g['overrides']])).to(gpu)
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd.')})
+    inputs = {k[3:]: torch.from_numpy(g[k]).to(gpu) for k in g.files if k.startswith('in_')}
+    with torch.no_grad():
+        out = m({k: v.clone() for k, v in inputs.items()}, inference_only=True)
+    assert set(out.keys()) == {'rgb', 'hdr', 'depth', 'mask'}
+    for k in out:
+        assert out[k].shape == g['infer_' + k].shape
+        close(out[k].cpu().numpy(), g['infer_' + k], rtol=2e-4, atol=2e-4)
+    m.fg_model.set_ray_cfgs('perturb', False)
+    m.fg_model.set_ray_cfgs('noise_std', 0.0)
+    out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False)
+    keys = {a + '_' + b for a in ('rgb', 'hdr', 'depth', 'mask', 'unit_exp') for b in ('coarse', 'fine')}
+    assert set(out.keys()) == keys
+    for k in keys:
+        assert out[k].shape == g['train_' + k].shape, k
+        close(out[k].detach().cpu().numpy(), g['train_' + k], rtol=2e-4, atol=2e-4)
+    unit = sum(((out['unit_exp_' + s] - 0.5) ** 2).mean() for s in ('coarse', 'fine'))
+    loss = ((out['rgb_fine'] - inputs['img']) ** 2).mean() + ((out['rgb_coarse'] - inputs['img']) ** 2).mean() + 0.5 * unit
+    assert abs(float(loss) - float(g['train_loss'])) < 1e-5
+    loss.backward()
+    checked = 0
+    for n, p in m.named_parameters():
+        if 'grad.' + n in g.files:
+            ref = g['grad.' + n]
+            assert np.abs(p.grad.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-7, n
+            checked += 1
+    assert checked > 30
+
+
 def test_ngp_packed_path_equals_dense_reference_shaped_path(gpu):
     from arcnerf_amd.ops.volume_func import sampler_rng
     m = _ngp_model(gpu, ['--model.rays.noise_std', '0.0'])
