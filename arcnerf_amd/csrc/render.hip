@@ -191,7 +191,8 @@ template <typename View>
 __global__ void __launch_bounds__(256)
 composite_bwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict__ bkg, int64_t bkg_rows, int64_t R,
                      int white_bkg, const float *__restrict__ d_rgb, const float *__restrict__ d_depth,
-                     const float *__restrict__ d_mask, float *__restrict__ d_geo, float *__restrict__ d_radiance) {
+                     const float *__restrict__ d_mask, const float *__restrict__ d_tlast, float *__restrict__ d_geo,
+                     float *__restrict__ d_radiance) {
     __shared__ float s_carry[kRaysPerBlock][kMaxChunks];
     v.patch(p_dense_ptr);
     const int lane = lane_id();
@@ -228,6 +229,8 @@ composite_bwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict
         const float *bk = bkg + (bkg_rows == 1 ? 0 : r) * 3;
         B = g0 * bk[0] + g1 * bk[1] + g2 * bk[2];
     }
+    // upstream gradient of T_last itself (trans_shift[:, -1]): FullModel blends a background model's colour and depth with it
+    if (d_tlast) B += d_tlast[r];
     const bool final_visited = nc > 0 && v.final_visited(r);
     // pass 2: reverse walk.  suffix_i = sum_{j>i} w_j g_j + (T_last*B if T_last depends on alpha_i)
     float suffix_carry = 0.f;
@@ -446,8 +449,8 @@ ARCN_EXPORT int arcn_ray_marching_fwd(const float *sigma, const float *alpha_in,
 ARCN_EXPORT int arcn_ray_marching_bwd(const float *sigma, const float *alpha_in, const float *radiance,
                                       const float *zvals, const float *noise, const float *bkg, int64_t bkg_rows,
                                       int64_t R, int P, int add_inf_z, int white_bkg, const float *d_rgb,
-                                      const float *d_depth, const float *d_mask, float *d_geo, float *d_radiance,
-                                      void *stream) {
+                                      const float *d_depth, const float *d_mask, const float *d_tlast, float *d_geo,
+                                      float *d_radiance, void *stream) {
     if (R <= 0) return ARCN_OK;
     if ((!sigma && !alpha_in) || !zvals || !d_geo || P < 1) return einval("ray_marching_bwd: missing argument");
     const int Pe = (add_inf_z || alpha_in) ? P : P - 1;
@@ -460,7 +463,7 @@ ARCN_EXPORT int arcn_ray_marching_bwd(const float *sigma, const float *alpha_in,
     DenseView v{sigma, alpha_in, radiance, zvals, noise, P, Pe};
     dim3 grid((unsigned)ceil_div<int64_t>(R, kRaysPerBlock));
     hipLaunchKernelGGL(composite_bwd_kernel<DenseView>, grid, dim3(256), 0, as_stream(stream), v, nullptr, bkg, bkg_rows,
-                       R, white_bkg, d_rgb, d_depth, d_mask, d_geo, d_radiance);
+                       R, white_bkg, d_rgb, d_depth, d_mask, d_tlast, d_geo, d_radiance);
     return check_launch("ray_marching_bwd");
 }
 
@@ -491,7 +494,7 @@ ARCN_EXPORT int arcn_composite_packed_bwd(const float *sigma, const float *radia
     PackedView v{sigma, nullptr, radiance, t_packed, noise, offsets, p_dense, add_inf_z ? p_dense : p_dense - 1, add_inf_z};
     dim3 grid((unsigned)ceil_div<int64_t>(R, kRaysPerBlock));
     hipLaunchKernelGGL(composite_bwd_kernel<PackedView>, grid, dim3(256), 0, as_stream(stream), v, p_dense_ptr, bkg,
-                       bkg_rows, R, white_bkg, d_rgb, d_depth, d_mask, d_sigma, d_radiance);
+                       bkg_rows, R, white_bkg, d_rgb, d_depth, d_mask, static_cast<const float *>(nullptr), d_sigma, d_radiance);
     return check_launch("composite_packed_bwd");
 }
 

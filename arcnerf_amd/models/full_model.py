@@ -1,25 +1,49 @@
-"""FullModel (arcnerf/models/full_model.py:10-560): flattens (B, N, ...) ray batches, runs the foreground model in
-`chunk_rays` chunks and reshapes back.  Background models (NeRF++ / MultiVol) are the next row of the scope table; a
-config with `model.background` raises until that row is built."""
+"""FullModel (arcnerf/models/full_model.py:10-560): flattens (B, N, ...) ray batches, runs the foreground model (and the
+background model, when `model.background` is configured) in `chunk_rays` chunks, blends the two and reshapes back.
+
+Blending (full_model.py:141-349): `rgb` mode adds the background colour / depth scaled by the transmittance left after the
+foreground's last sample; `sigma` mode concatenates the per-sample densities and colours of both models along the ray and
+composites them again in one pass.  The foreground mask stays the foreground's."""
 import torch
 import torch.nn as nn
 
+from ..utils.cfgs_utils import get_value_from_cfgs_field
 from ..utils.torch_utils import chunk_processing
+
+
+def _stage_keys(output):
+    """suffixes under which a model reported its results: [''] (one stage) or ['_coarse'(, '_fine')]"""
+    if any(k.endswith('_coarse') or k.endswith('_fine') for k in output):
+        return ['_coarse'] + (['_fine'] if any(k.endswith('_fine') for k in output) else [])
+    return ['']
 
 
 class FullModel(nn.Module):
     def __init__(self, cfgs, fg_model, bkg_cfgs=None, bkg_model=None):
         super().__init__()
-        if bkg_model is not None:
-            raise NotImplementedError('background models are not on this path yet (SURVEY.md §8f row 2)')
-        self.cfgs, self.fg_model, self.bkg_cfgs, self.bkg_model = cfgs, fg_model, None, None
+        self.cfgs, self.fg_model, self.bkg_cfgs, self.bkg_model = cfgs, fg_model, bkg_cfgs, bkg_model
         self.fg_only = False
+        if self.bkg_cfgs is not None:
+            self.bkg_blend = get_value_from_cfgs_field(self.bkg_cfgs.model, 'bkg_blend', 'rgb')
+            self.check_bkg_cfgs()
+            if self.bkg_blend == 'sigma':
+                self.fg_model.set_add_inf_z(True)  # keep every foreground sigma for the joint compositing
+            self.fg_only = get_value_from_cfgs_field(self.bkg_cfgs.model, 'fg_only', False)
+
+    def check_bkg_cfgs(self):
+        if self.bkg_blend == 'rgb':
+            assert self.fg_model.get_ray_cfgs('add_inf_z') is False, 'Do not add_inf_z for foreground'
+            assert self.bkg_model.get_ray_cfgs('add_inf_z') is True, 'Must use add_inf_z for background in rgb blending mode'
+        elif self.bkg_blend == 'sigma':
+            assert self.bkg_model.get_ray_cfgs('add_inf_z') is False, 'Do not add_inf_z for background in sigma blending mode'
+        else:
+            raise NotImplementedError('Invalid bkg_blend type {}'.format(self.bkg_blend))
 
     def get_fg_model(self):
         return self.fg_model
 
     def get_bkg_model(self):
-        return None
+        return self.bkg_model
 
     def get_chunk_rays(self):
         return self.fg_model.get_chunk_rays()
@@ -29,12 +53,18 @@ class FullModel(nn.Module):
 
     def set_chunk_rays(self, v):
         self.fg_model.set_chunk_rays(v)
+        if self.bkg_model is not None:
+            self.bkg_model.set_chunk_rays(v)
 
     def set_chunk_pts(self, v):
         self.fg_model.set_chunk_pts(v)
+        if self.bkg_model is not None:
+            self.bkg_model.set_chunk_pts(v)
 
     def init_setting(self):
         self.fg_model.init_setting()
+        if self.bkg_model is not None:
+            self.bkg_model.init_setting()
 
     def is_cuda(self):
         return next(self.parameters()).is_cuda
@@ -80,21 +110,94 @@ class FullModel(nn.Module):
                 output[k] = v.view(batch_size, n_rays_per_batch, *v.shape[1:])
         return output
 
+    @staticmethod
+    def clean_two_stage_progress(output):
+        """keep ONE set of progress_ entries: the one-stage set if present, else the fine one, else the coarse one, un-suffixed"""
+        prog = [k for k in output if k.startswith('progress_')]
+        if not prog:
+            return output
+        staged = [k for k in prog if k.endswith('_coarse') or k.endswith('_fine')]
+        if len(staged) < len(prog):
+            for k in staged:
+                output.pop(k)
+            return output
+        keep = '_fine' if any(k.endswith('_fine') for k in prog) else '_coarse'
+        for k in staged:
+            v = output.pop(k)
+            if k.endswith(keep):
+                output[k[:-len(keep)]] = v
+        return output
+
+    def blend_bkg_rgb(self, fg_output, bkg_output):
+        """rgb, depth += T_fg(after the last sample) * background (full_model.py:278-330).  A two-stage foreground takes the
+        background stage of the same name when there is one, else the background's coarse / only stage."""
+        fg_stages, bkg_stages = _stage_keys(fg_output), _stage_keys(bkg_output)
+        for st in fg_stages:
+            assert 'progress_trans_shift' + st in fg_output, 'You must get_progress for fg_model'
+            if st in bkg_stages:
+                bst = st
+            elif st == '':
+                bst = bkg_stages[-1]       # one-stage foreground: the finest background available
+            else:
+                bst = bkg_stages[0]        # '_coarse' or '' of the background
+            lam = fg_output['progress_trans_shift' + st][:, -1]
+            fg_output['rgb' + st] = fg_output['rgb' + st] + lam[:, None] * bkg_output['rgb' + bst]
+            fg_output['depth' + st] = fg_output['depth' + st] + lam * bkg_output['depth' + bst]
+        return self.clean_two_stage_progress(fg_output) if fg_stages != [''] else fg_output
+
+    def blend_bkg_sigma(self, fg_output, bkg_output, inference_only=False, get_progress=False):
+        """joint compositing of the foreground's and the background's samples (full_model.py:141-276)"""
+        fg_stages, bkg_stages = _stage_keys(fg_output), _stage_keys(bkg_output)
+        out = {}
+        for st in fg_stages:
+            assert 'progress_sigma' + st in fg_output, 'You must get_progress for fg_model'
+            bst = st if st in bkg_stages else (bkg_stages[-1] if st == '' else bkg_stages[0])
+            z_fg, z_bkg = fg_output['progress_zvals' + st], bkg_output['progress_zvals' + bst]
+            s_fg, r_fg = fg_output['progress_sigma' + st], fg_output['progress_radiance' + st]
+            # rays whose foreground samples run past the first background shell contribute nothing from the foreground
+            invalid = z_fg[:, -1] > z_bkg[:, 0]
+            s_fg[invalid], r_fg[invalid], z_fg[invalid] = 0, 0, 0
+            joint = self.fg_model.ray_marching(torch.cat([s_fg, bkg_output['progress_sigma' + bst]], 1),
+                                               torch.cat([r_fg, bkg_output['progress_radiance' + bst]], 1),
+                                               torch.cat([z_fg, z_bkg], 1), inference_only=inference_only)
+            joint = self.fg_model.output_get_progress(joint, get_progress, s_fg.shape[1])
+            for k, v in joint.items():
+                out[k + st] = fg_output[k + st] if (k == 'mask' and fg_stages != [''] and k + st in fg_output) else v
+        return self.clean_two_stage_progress(out) if fg_stages != [''] else out
+
+    def blend_output(self, fg_output, bkg_output=None, inference_only=False, get_progress=False):
+        if bkg_output is None:
+            final = self.clean_two_stage_progress(fg_output)
+        elif self.bkg_blend == 'rgb':
+            final = self.blend_bkg_rgb(fg_output, bkg_output)
+        elif self.bkg_blend == 'sigma':
+            final = self.blend_bkg_sigma(fg_output, bkg_output, inference_only, get_progress)
+        else:
+            raise NotImplementedError('Invalid bkg_blend type {}...'.format(self.bkg_blend))
+        return final if get_progress else self.clean_progress(final)
+
     def forward(self, inputs, inference_only=False, get_progress=False, cur_epoch=0, total_epoch=300000):
         flat, b, n = self.prepare_flatten_inputs(inputs)
-        out = chunk_processing(self.process_fg_bkg_model, self.fg_model.get_chunk_rays(), False, self.fg_model, None, flat,
+        chunk_rays = self.fg_model.get_chunk_rays()
+        if self.bkg_model is not None:
+            chunk_rays = min(chunk_rays, self.bkg_model.get_chunk_rays())
+        out = chunk_processing(self.process_fg_bkg_model, chunk_rays, False, self.fg_model, self.bkg_model, flat,
                                inference_only, get_progress, cur_epoch, total_epoch)
         return self.reshape_output(out, b, n)
 
     def process_fg_bkg_model(self, fg_model, bkg_model, flat_inputs, inference_only, get_progress, cur_epoch, total_epoch):
-        out = fg_model.forward(flat_inputs, inference_only, get_progress, cur_epoch, total_epoch)
-        if not get_progress:
-            out = self.clean_progress(out)
-        return self.detach_progress(out)
+        get_progress_fg = True if bkg_model is not None else get_progress   # blending needs the foreground's progress
+        fg_output = fg_model.forward(flat_inputs, inference_only, get_progress_fg, cur_epoch, total_epoch)
+        bkg_output = None
+        if bkg_model is not None and not self.fg_only:
+            bkg_output = bkg_model.forward(flat_inputs, inference_only, True, cur_epoch, total_epoch)
+        return self.detach_progress(self.blend_output(fg_output, bkg_output, inference_only, get_progress))
 
     @torch.no_grad()
     def optimize(self, cur_epoch=0):
         self.fg_model.optimize(cur_epoch)
+        if self.bkg_model is not None:
+            self.bkg_model.optimize(cur_epoch)
 
     def forward_pts_dir(self, pts, view_dir=None):
         return self.fg_model.forward_pts_dir(pts, view_dir)

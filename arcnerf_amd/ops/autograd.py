@@ -91,7 +91,9 @@ class FusedMlpFn(torch.autograd.Function):
 
 class RayMarchingFn(torch.autograd.Function):
     """ray_marching of arcnerf/render/ray_helper.py:476-593 on dense (R,P) tensors; differentiable wrt sigma (or alpha)
-    and radiance.  Returns rgb, depth, mask, alpha, trans_shift, weights (per-sample outputs are detached views)."""
+    and radiance.  Returns rgb, depth, mask, alpha, trans_shift, weights, status and t_last = trans_shift[:, -1] as a
+    DIFFERENTIABLE output (FullModel scales the background model's colour and depth with it); the other per-sample outputs
+    are detached views."""
 
     @staticmethod
     def forward(ctx, sigma, radiance, zvals, alpha, bkg_color, noise, add_inf_z, white_bkg):
@@ -104,10 +106,11 @@ class RayMarchingFn(torch.autograd.Function):
         ctx.status = out['status']
         rgb = out['rgb'] if out['rgb'] is not None else zvals.new_zeros(0)
         ctx.mark_non_differentiable(out['alpha'], out['trans_shift'])
-        return rgb, out['depth'], out['mask'], out['alpha'], out['trans_shift'], out['weights'], out['status']
+        t_last = out['trans_shift'][:, -1].clone()
+        return rgb, out['depth'], out['mask'], out['alpha'], out['trans_shift'], out['weights'], out['status'], t_last
 
     @staticmethod
-    def backward(ctx, d_rgb, d_depth, d_mask, _da, _dt, d_w, _ds):
+    def backward(ctx, d_rgb, d_depth, d_mask, _da, _dt, d_w, _ds, d_tlast):
         sigma, radiance, zvals, alpha, bkg, noise = [t if h else None for t, h in
                                                      zip(ctx.saved_tensors, (ctx.has[0], ctx.has[1], True, ctx.has[2], ctx.has[3], ctx.has[4]))]
         add_inf_z, white_bkg = ctx.flags
@@ -115,7 +118,8 @@ class RayMarchingFn(torch.autograd.Function):
             raise NotImplementedError('gradient through per-sample weights is not provided by the fused compositor')
         d_geo, d_rad = F.ray_marching_bwd(sigma, radiance, zvals, d_rgb.contiguous() if radiance is not None else None,
                                           d_depth.contiguous(), d_mask.contiguous(), add_inf_z=add_inf_z, white_bkg=white_bkg,
-                                          alpha=alpha, bkg_color=bkg, noise=noise)
+                                          alpha=alpha, bkg_color=bkg, noise=noise,
+                                          d_tlast=None if d_tlast is None else d_tlast.contiguous())
         # with alpha= given, sigma is only recorded (NeuS passes the sdf there, ray_helper.py:550-556): it gets no gradient
         d_sigma = d_geo if (sigma is not None and alpha is None) else None
         return d_sigma, d_rad, None, (d_geo if alpha is not None else None), None, None, None, None

@@ -374,8 +374,8 @@ def ray_marching_fwd(sigma, radiance, zvals, add_inf_z=False, white_bkg=False, a
 
 
 def ray_marching_bwd(sigma, radiance, zvals, d_rgb, d_depth=None, d_mask=None, add_inf_z=False, white_bkg=False,
-                     alpha=None, bkg_color=None, noise=None):
-    _req(sigma, radiance, zvals, alpha, bkg_color, noise, d_rgb, d_depth, d_mask)
+                     alpha=None, bkg_color=None, noise=None, d_tlast=None):
+    _req(sigma, radiance, zvals, alpha, bkg_color, noise, d_rgb, d_depth, d_mask, d_tlast)
     z = _f32(zvals)
     R, P = z.shape
     sg, al, rad, ns = _f32(sigma), _f32(alpha), _f32(radiance), _f32(noise)
@@ -384,7 +384,8 @@ def ray_marching_bwd(sigma, radiance, zvals, d_rgb, d_depth=None, d_mask=None, a
     d_rad = torch.empty((R, P, 3), dtype=torch.float32, device=z.device) if rad is not None else None
     N.check(N.lib().arcn_ray_marching_bwd(N.ptr(sg), N.ptr(al), N.ptr(rad), N.ptr(z), N.ptr(ns), N.ptr(bk), bk_rows, R, P,
                                          int(add_inf_z), int(white_bkg), N.ptr(_f32(d_rgb)), N.ptr(_f32(d_depth)),
-                                         N.ptr(_f32(d_mask)), N.ptr(d_geo), N.ptr(d_rad), N.stream()), 'ray_marching_bwd')
+                                         N.ptr(_f32(d_mask)), N.ptr(_f32(d_tlast)), N.ptr(d_geo), N.ptr(d_rad), N.stream()),
+            'ray_marching_bwd')
     return d_geo, d_rad
 
 

@@ -11,14 +11,21 @@ from ..ops.autograd import RayMarchingFn
 
 
 def get_near_far_from_rays(rays_o, rays_d, bounds=None, near_hardcode=None, far_hardcode=None, bounding_radius=None):
-    """near, far (N_rays, 1).  Sphere bounding (bounding_radius) belongs to the NeuS row and is not provided yet."""
+    """near, far (N_rays, 1) from data bounds and / or the ray-sphere test of a bounding radius, overridden by the hard-coded
+    values (ray_helper.py:175-228)"""
     n_rays = rays_o.shape[0]
     if near_hardcode is None or far_hardcode is None:
         if bounds is None and bounding_radius is None:
             raise NotImplementedError('You must specify near/far in some place...')
-        if bounds is None or bounding_radius is not None:
-            raise NotImplementedError('ray-sphere bounds are part of the NeuS row (next), not of this path yet')
-        near, far = bounds[:, 0:1], bounds[:, 1:2]
+        if bounds is None:
+            from ..geometry.ray import sphere_ray_intersection
+            near, far, _, _ = sphere_ray_intersection(rays_o, rays_d, float(bounding_radius))
+        else:
+            near, far = bounds[:, 0:1], bounds[:, 1:2]
+            if bounding_radius is not None:  # the sphere restricts the far end
+                from ..geometry.ray import sphere_ray_intersection
+                far_bound = sphere_ray_intersection(rays_o, rays_d, float(bounding_radius))[1]
+                far = torch.where(far > far_bound, far_bound, far)
         if near_hardcode is not None:
             near = near * 0 + near_hardcode
         if far_hardcode is not None:
@@ -47,6 +54,22 @@ def get_zvals_from_near_far(near, far, n_pts, inclusive=True, inverse_linear=Fal
     else:
         zvals = near + (far - near) * t
     return perturb_interval(zvals) if perturb else zvals
+
+
+def get_zvals_from_sphere_radius(rays_o, rays_d, sphere_radius):
+    """far intersection of every ray with every sphere shell (ray_helper.py:343-358); 0 where a ray misses a shell"""
+    from ..geometry.ray import sphere_ray_intersection
+    return sphere_ray_intersection(rays_o, rays_d, sphere_radius)[1]
+
+
+def get_zvals_outside_sphere(rays_o, rays_d, n_pts, radius, perturb=False):
+    """multi-sphere sampling outside a bounding radius, shells at radius / t for t in (0,1) (ray_helper.py:318-340):
+    -> zvals (N_rays, N_pts), sphere_radius (N_pts,)"""
+    t_vals = torch.linspace(0.0, 1.0, n_pts + 2, dtype=rays_o.dtype, device=rays_o.device)[1:-1]
+    sphere_radius = radius / torch.flip(t_vals, dims=[-1])
+    if perturb:
+        sphere_radius = perturb_interval(sphere_radius[None])[0]
+    return get_zvals_from_sphere_radius(rays_o, rays_d, sphere_radius), sphere_radius
 
 
 def perturb_interval_with_mask(vals, mask=None):
@@ -142,8 +165,11 @@ def ray_marching(sigma, radiance, zvals, add_inf_z=False, noise_std=0.0, weights
         noise = torch.randn((R, Pe), dtype=zvals.dtype, device=zvals.device) * noise_std
     if bkg_color is not None:
         assert bkg_color.shape[0] == R or bkg_color.shape[0] == 1, 'Only bkg with N_rays/1 allowed..'
-    rgb, depth, mask, a, trans, w, status = RayMarchingFn.apply(sigma, radiance, zvals.contiguous(), alpha, bkg_color, noise,
-                                                               bool(add_inf_z), bool(white_bkg))
+    rgb, depth, mask, a, trans, w, status, t_last = RayMarchingFn.apply(sigma, radiance, zvals.contiguous(), alpha, bkg_color,
+                                                                       noise, bool(add_inf_z), bool(white_bkg))
+    if torch.is_grad_enabled() and t_last.requires_grad:
+        # the last column carries gradient: FullModel.blend_bkg_rgb scales the background model with trans_shift[:, -1]
+        trans = torch.cat([trans[:, :-1], t_last[:, None]], dim=1)
     _LAST_STATUS['t'] = status
     if weights_only:
         return {'weights': w}

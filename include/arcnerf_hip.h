@@ -236,6 +236,8 @@ int arcn_act_bwd(const float *x, const float *y, const float *dy, float *dx, int
  * dense form: sigma/alpha_in (R,P), radiance (R,P,3), zvals (R,P); Pe = P if (add_inf_z || alpha_in) else P-1.
  * per-sample outputs alpha/trans/weights (R,Pe) optional.  bkg (bkg_rows,3), bkg_rows in {0,1,R}.
  * status (device int32, optional) is set to 1 if some delta < 0 (the reference asserts, :534).
+ * bwd: d_tlast (R, optional) = upstream gradient of trans_shift[:, -1], the transmittance FullModel.blend_bkg_rgb scales a
+ * background model with (full_model.py:278-330); the bkg_color term of rgb uses the same quantity (:569-571).
  * ---------------------------------------------------------------------------------------------- */
 int arcn_ray_marching_fwd(const float *sigma, const float *alpha_in, const float *radiance, const float *zvals,
                           const float *noise, const float *bkg, int64_t bkg_rows, int64_t R, int P, int add_inf_z,
@@ -243,8 +245,8 @@ int arcn_ray_marching_fwd(const float *sigma, const float *alpha_in, const float
                           float *weights_out, int32_t *status, void *stream);
 int arcn_ray_marching_bwd(const float *sigma, const float *alpha_in, const float *radiance, const float *zvals,
                           const float *noise, const float *bkg, int64_t bkg_rows, int64_t R, int P, int add_inf_z,
-                          int white_bkg, const float *d_rgb, const float *d_depth, const float *d_mask, float *d_geo,
-                          float *d_radiance, void *stream);
+                          int white_bkg, const float *d_rgb, const float *d_depth, const float *d_mask, const float *d_tlast,
+                          float *d_geo, float *d_radiance, void *stream);
 
 /* packed form over (offsets, t): identical numbers to the dense form applied to the reference's padded (R,P') view
  * (mask rows [T..T F..F], padded z = last z): P_dense = the dense column count the reference would have used

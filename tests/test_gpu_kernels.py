@@ -714,3 +714,43 @@ def test_sdf_to_alpha_vs_reference_golden_and_oracle(F, oracle, tag, s, clip):
     close(host(d_sdf), r_sdf, rtol=1e-4, atol=1e-5 * np.abs(r_sdf).max())
     close(host(d_slope), r_slope, rtol=1e-4, atol=1e-5 * np.abs(r_slope).max())
     assert abs(float(d_s) - r_s) <= 1e-3 * abs(r_s) + 1e-5    # fp32 tree sum of 3.8e5 terms vs the oracle's double
+
+
+def test_compositor_last_transmittance_is_differentiable(F):
+    """trans_shift[:, -1] (what a background model is blended with, full_model.py:278-330) carries gradient to sigma / alpha:
+    against plain torch autograd on alpha_to_weights (ray_helper.py:596-620), sigma and alpha= inputs, both add_inf_z."""
+    from arcnerf_amd.render.ray_helper import ray_marching
+    rng = np.random.default_rng(31)
+    R, P = 257, 70
+    z = dev(np.sort(rng.random((R, P)).astype(np.float32) * 4 + 0.5, axis=-1))
+    rad = dev(rng.random((R, P, 3)).astype(np.float32))
+    gt, gc = dev(rng.normal(size=R).astype(np.float32)), dev(rng.normal(size=(R, 3)).astype(np.float32))
+
+    def torch_ref(sigma, alpha, add_inf_z):
+        if alpha is None:
+            deltas = z[:, 1:] - z[:, :-1]
+            deltas = torch.where(deltas.abs() < 1e-5, torch.zeros_like(deltas), deltas)   # ray_helper.py:531
+            if add_inf_z:
+                deltas = torch.cat([deltas, torch.full((R, 1), 1e10, device=z.device)], -1)
+                sg, rd = sigma, rad
+            else:
+                sg, rd = sigma[:, :-1], rad[:, :-1]
+            alpha, rd_ = 1 - torch.exp(-torch.relu(sg) * deltas), rd
+        else:
+            rd_ = rad
+        ts = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha + 1e-10], -1), -1)[:, :-1]
+        rgb = ((alpha * ts).unsqueeze(-1) * rd_).sum(-2)
+        return (rgb * gc).sum() + (ts[:, -1] * gt).sum()
+
+    for mode in ('sigma', 'sigma_inf', 'alpha'):
+        leaf = dev((rng.random((R, P)) * (3.0 if mode != 'alpha' else 0.6)).astype(np.float32)).requires_grad_(True)
+        ref_leaf = leaf.detach().clone().requires_grad_(True)
+        if mode == 'alpha':
+            out = ray_marching(None, rad, z, alpha=leaf)
+            torch_ref(None, ref_leaf, False).backward()
+        else:
+            out = ray_marching(leaf, rad, z, add_inf_z=(mode == 'sigma_inf'))
+            torch_ref(ref_leaf, None, mode == 'sigma_inf').backward()
+        assert out['trans_shift'].requires_grad
+        ((out['rgb'] * gc).sum() + (out['trans_shift'][:, -1] * gt).sum()).backward()
+        close(host(leaf.grad), host(ref_leaf.grad), rtol=2e-4, atol=2e-5 * float(ref_leaf.grad.abs().max()))

@@ -155,6 +155,45 @@ def test_hdrnerf_matches_reference_fullmodel(gpu):
     assert checked > 30
 
 
+@pytest.mark.parametrize('blend', ['rgb', 'sigma'])
+def test_nerfpp_background_matches_reference_fullmodel(gpu, blend):
+    """configs/models/nerfpp.yaml (reduced widths, SURVEY.md 8f rank 2, NeRF++ half): NeRF foreground + inverted-sphere
+    background on multi-sphere shells, blended in `rgb` mode (T_fg,last * background) and in `sigma` mode (joint compositing of
+    both models' samples); reference state_dict with strict=True; outputs within 2e-4, rgb-mode gradients within 1e-3 of max."""
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    g = load_golden('g15_nerfpp_model')
+    ov = [str(v) for v in g['overrides']] + ([str(v) for v in g['sigma_overrides']] if blend == 'sigma' else [])
+    m = build_model(load_configs(os.path.join(CFG, 'nerfpp.yaml'), ov)).to(gpu)
+    assert type(m.bkg_model).__name__ == 'NeRFPP' and m.bkg_blend == blend
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd.')})
+    inputs = {k[3:]: torch.from_numpy(g[k]).to(gpu) for k in g.files if k.startswith('in_')}
+    tag = blend + '_'
+    with torch.no_grad():
+        out = m({k: v.clone() for k, v in inputs.items()}, inference_only=True)
+    assert set(out.keys()) == {'rgb', 'depth', 'mask'}
+    for k in out:
+        close(out[k].cpu().numpy(), g[tag + 'infer_' + k], rtol=2e-4, atol=2e-4)
+    for mdl in (m.fg_model, m.bkg_model):
+        mdl.set_ray_cfgs('perturb', False)
+        mdl.set_ray_cfgs('noise_std', 0.0)
+    out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False)
+    assert set(out.keys()) == {'rgb_coarse', 'depth_coarse', 'mask_coarse', 'rgb_fine', 'depth_fine', 'mask_fine'}
+    for k in out:
+        close(out[k].detach().cpu().numpy(), g[tag + 'train_' + k], rtol=2e-4, atol=2e-4)
+    if blend == 'rgb':
+        loss = ((out['rgb_fine'] - inputs['img']) ** 2).mean() + ((out['rgb_coarse'] - inputs['img']) ** 2).mean()
+        assert abs(float(loss) - float(g['rgb_train_loss'])) < 1e-5
+        loss.backward()
+        checked = 0
+        for n, p in m.named_parameters():
+            if 'rgb_grad.' + n in g.files:
+                ref = g['rgb_grad.' + n]
+                assert np.abs(p.grad.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-7, n
+                checked += 1
+        assert checked > 60
+
+
 def test_ngp_packed_path_equals_dense_reference_shaped_path(gpu):
     from arcnerf_amd.ops.volume_func import sampler_rng
     m = _ngp_model(gpu, ['--model.rays.noise_std', '0.0'])
