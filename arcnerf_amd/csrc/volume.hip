@@ -6,6 +6,7 @@
 // stepping) and this file is compiled with -ffp-contract=off so every t and every voxel index is bit-identical to the
 // CPU oracle.  Every kernel runs on the caller's stream; nothing synchronises.
 #include "common.hpp"
+#include "morton.hpp"
 
 namespace arcn {
 
@@ -69,16 +70,21 @@ __device__ __forceinline__ void aabb_torch(const float o[3], const float d[3], c
     near_o = near; far_o = far; mask_o = mask;
 }
 
-// Occupancy storage: the reference's bool-per-voxel tensor (volume.py:741-760) or a packed 1-bit-per-voxel field in the
-// same x*n*n+y*n+z order (256 KiB at 128^3: L2/LDS resident).
-template <bool PACKED>
+// Occupancy storage MODE:
+//   0  the reference's bool-per-voxel tensor (volume.py:741-760), x*n*n+y*n+z order
+//   1  packed 1 bit per voxel in the same order (256 KiB at 128^3: L2/LDS resident)
+//   2  packed 1 bit per voxel in MORTON order, voxel coordinates truncated and clamped into the grid: the
+//      `_bitfield_func` layout (volume_func.h:141-194)
+enum { OCC_BOOL = 0, OCC_PACKED = 1, OCC_MORTON = 2 };
+
+template <int MODE>
 __device__ __forceinline__ bool bit_at(const uint8_t *bf, uint32_t flat) {
-    if (PACKED) return (bf[flat >> 3] >> (flat & 7)) & 1;
+    if (MODE != OCC_BOOL) return (bf[flat >> 3] >> (flat & 7)) & 1;
     return bf[flat] != 0;
 }
 
-// volume_func.h:59-88
-template <bool PACKED>
+// volume_func.h:59-88 (modes 0/1), volume_func.h:170-194 (mode 2)
+template <int MODE>
 __device__ __forceinline__ bool occupied_at(const float p[3], const uint8_t *bf, const Aabb &b, uint32_t n) {
     float vi[3];
 #pragma unroll
@@ -86,11 +92,16 @@ __device__ __forceinline__ bool occupied_at(const float p[3], const uint8_t *bf,
         float vs = (b.mx[k] - b.mn[k]) / (float)n;
         vi[k] = (p[k] - b.mn[k]) / vs;
     }
+    if (MODE == OCC_MORTON) {
+        const int hi = (int)n - 1;
+        const int x = min(max((int)vi[0], 0), hi), y = min(max((int)vi[1], 0), hi), z = min(max((int)vi[2], 0), hi);
+        return bit_at<MODE>(bf, morton3d((uint32_t)x, (uint32_t)y, (uint32_t)z));
+    }
     float lo = vi[0] < vi[1] ? vi[0] : vi[1]; lo = lo < vi[2] ? lo : vi[2];
     float hi = vi[0] > vi[1] ? vi[0] : vi[1]; hi = hi > vi[2] ? hi : vi[2];
     if (lo < 0 || hi >= (float)n) return false;
     uint32_t x = (uint32_t)floorf(vi[0]), y = (uint32_t)floorf(vi[1]), z = (uint32_t)floorf(vi[2]);
-    return bit_at<PACKED>(bf, x * (n * n) + y * n + z);
+    return bit_at<MODE>(bf, x * (n * n) + y * n + z);
 }
 
 __device__ __forceinline__ bool in_aabb(const float p[3], const Aabb &b) {
@@ -116,7 +127,7 @@ __device__ __forceinline__ float dist_to_next_voxel(const float pos[3], const fl
 }
 
 // The marching loop of K3 (volume_func_kernel.cu:203-222).  EMIT(j, t) is called for every accepted sample.
-template <bool PACKED, typename Emit>
+template <int MODE, typename Emit>
 __device__ __forceinline__ uint32_t march_ray(const float o[3], const float d[3], float startt, float far_end, float dt,
                                               const Aabb &b, const uint8_t *bf, uint32_t n_grid, uint32_t n_pts,
                                               Emit emit) {
@@ -127,7 +138,7 @@ __device__ __forceinline__ uint32_t march_ray(const float o[3], const float d[3]
 #pragma unroll
         for (int k = 0; k < 3; ++k) { float a = d[k] * t; pos[k] = o[k] + a; }
         if (!in_aabb(pos, b)) break;
-        if (occupied_at<PACKED>(pos, bf, b, n_grid)) {
+        if (occupied_at<MODE>(pos, bf, b, n_grid)) {
             emit(j, t);
             ++j;
             t += dt;
@@ -147,7 +158,7 @@ __global__ void __launch_bounds__(256) check_occ_kernel(const float *__restrict_
     if (i >= n) return;
     Aabb b = load_aabb(aabb);
     float p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
-    out[i] = occupied_at<false>(p, bf, b, n_grid) ? 1 : 0;
+    out[i] = occupied_at<OCC_BOOL>(p, bf, b, n_grid) ? 1 : 0;
 }
 
 // ---- K2 / torch-path intersection ------------------------------------------------------------------
@@ -232,7 +243,10 @@ __global__ void __launch_bounds__(256) sphere_kernel(const float *__restrict__ r
     }
 }
 
-// ---- K3 (dense boundary form) -------------------------------------------------------------------------
+// ---- K3 / K5 (dense boundary form) ---------------------------------------------------------------------
+// MODE OCC_BOOL = K3 sparse_volume_sampling (volume_func_kernel.cu:174-236); MODE OCC_MORTON = K5 sparse_volume_sampling_bit
+// (bitfield_func_kernel.cu:20-82): the same loop over a Morton-ordered packed bitfield.
+template <int MODE>
 __global__ void __launch_bounds__(128)
 sparse_sampling_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                        const float *__restrict__ near, const float *__restrict__ far, const float *__restrict__ aabb,
@@ -251,7 +265,7 @@ sparse_sampling_kernel(const float *__restrict__ rays_o, const float *__restrict
     float *zr = zvals + i * (int64_t)n_pts;
     uint8_t *mr = mask + i * (int64_t)n_pts;
     float last = 0.f;
-    uint32_t j = march_ray<false>(o, d, startt, far[i], dt, b, bf, n_grid, n_pts, [&](uint32_t jj, float t) {
+    uint32_t j = march_ray<MODE>(o, d, startt, far[i], dt, b, bf, n_grid, n_pts, [&](uint32_t jj, float t) {
         zr[jj] = t;
         mr[jj] = 1;
         last = t;
@@ -282,7 +296,7 @@ __global__ void __launch_bounds__(256) reduce_max_kernel(const float *__restrict
 //      carried into the next chunk,
 //   4. writes the emitted t's compacted by popcount.
 // Same arithmetic, same decisions => bit-identical zvals / counts (tests compare against the serial CPU oracle).
-template <bool PACKED>
+template <int MODE>
 __global__ void __launch_bounds__(256)
 march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ aabb,
                    const uint8_t *__restrict__ bf, uint32_t n_grid, uint32_t n_pts, float dt, float near_distance,
@@ -340,7 +354,7 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
 #pragma unroll
             for (int k = 0; k < 3; ++k) { float a = d[k] * t; pos[k] = o[k] + a; }
             const bool alive = (t <= fr) && in_aabb(pos, b);
-            const bool occ = alive && occupied_at<PACKED>(pos, bf, b, n_grid);
+            const bool occ = alive && occupied_at<MODE>(pos, bf, b, n_grid);
             const float target = (alive && !occ) ? t + dist_to_next_voxel(pos, d, b, n_grid) : 0.f;
             const uint64_t alive_m = __ballot(alive), occ_m = __ballot(occ);
             // 3. replay on wave-uniform state
@@ -574,10 +588,26 @@ ARCN_EXPORT int arcn_sparse_volume_sampling(const float *rays_o, const float *ra
     if (!rays_o || !rays_d || !near || !far || !aabb || !bitfield || !zvals || !mask || n_pts <= 0 || n_grid <= 0 || !(dt > 0))
         return einval("sparse_volume_sampling: missing/invalid argument");
     Pcg32 rng{rng_state, rng_inc};
-    hipLaunchKernelGGL(sparse_sampling_kernel, dim3((unsigned)ceil_div<int64_t>(n_rays, 128)), dim3(128), 0,
+    hipLaunchKernelGGL(sparse_sampling_kernel<OCC_BOOL>, dim3((unsigned)ceil_div<int64_t>(n_rays, 128)), dim3(128), 0,
                        as_stream(stream), rays_o, rays_d, near, far, aabb, bitfield, (uint32_t)n_grid, (uint32_t)n_pts, dt,
                        near_distance, rng, zvals, mask, counts, n_rays);
     return check_launch("sparse_volume_sampling");
+}
+
+ARCN_EXPORT int arcn_sparse_volume_sampling_bit(const float *rays_o, const float *rays_d, const float *near,
+                                                const float *far, int n_pts, float dt, const float *aabb, int n_grid,
+                                                const uint8_t *bitfield, float near_distance, uint64_t rng_state,
+                                                uint64_t rng_inc, float *zvals, uint8_t *mask, int32_t *counts,
+                                                int64_t n_rays, void *stream) {
+    if (n_rays <= 0) return ARCN_OK;
+    if (!rays_o || !rays_d || !near || !far || !aabb || !bitfield || !zvals || !mask || n_pts <= 0 || n_grid <= 0 || !(dt > 0))
+        return einval("sparse_volume_sampling_bit: missing/invalid argument");
+    if (n_grid > 1024 || (n_grid & (n_grid - 1))) return einval("sparse_volume_sampling_bit: n_grid must be a power of two <= 1024");
+    Pcg32 rng{rng_state, rng_inc};
+    hipLaunchKernelGGL(sparse_sampling_kernel<OCC_MORTON>, dim3((unsigned)ceil_div<int64_t>(n_rays, 128)), dim3(128), 0,
+                       as_stream(stream), rays_o, rays_d, near, far, aabb, bitfield, (uint32_t)n_grid, (uint32_t)n_pts, dt,
+                       near_distance, rng, zvals, mask, counts, n_rays);
+    return check_launch("sparse_volume_sampling_bit");
 }
 
 ARCN_EXPORT int arcn_tensor_reduce_max(const float *full, const int64_t *idx, int n_group, float *uni, int64_t n,
@@ -613,12 +643,18 @@ ARCN_EXPORT int arcn_march_count(const float *rays_o, const float *rays_d, const
         return einval("march_count: missing/invalid argument");
     Pcg32 rng{rng_state, rng_inc};
     dim3 grid((unsigned)ceil_div<int64_t>(n_rays, 4));
-    if (bitfield_is_packed)
-        hipLaunchKernelGGL(march_count_kernel<true>, grid, dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, bitfield,
+    if (bitfield_is_packed == 2 && (n_grid > 1024 || (n_grid & (n_grid - 1))))
+        return einval("march_count: a Morton bitfield needs a power-of-two n_grid <= 1024");
+    if (bitfield_is_packed == 2)
+        hipLaunchKernelGGL(march_count_kernel<OCC_MORTON>, grid, dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, bitfield,
+                           (uint32_t)n_grid, (uint32_t)n_pts, dt, near_distance, aabb_torch_semantics, rng, scratch_t,
+                           counts, near_out, far_out, n_rays);
+    else if (bitfield_is_packed)
+        hipLaunchKernelGGL(march_count_kernel<OCC_PACKED>, grid, dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, bitfield,
                            (uint32_t)n_grid, (uint32_t)n_pts, dt, near_distance, aabb_torch_semantics, rng, scratch_t,
                            counts, near_out, far_out, n_rays);
     else
-        hipLaunchKernelGGL(march_count_kernel<false>, grid, dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, bitfield,
+        hipLaunchKernelGGL(march_count_kernel<OCC_BOOL>, grid, dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, bitfield,
                            (uint32_t)n_grid, (uint32_t)n_pts, dt, near_distance, aabb_torch_semantics, rng, scratch_t,
                            counts, near_out, far_out, n_rays);
     return check_launch("march_count");

@@ -1,14 +1,14 @@
-"""build_obj_bound (arcnerf/models/base_modules/obj_bound/__init__.py:25-62).  `volume`, `sphere` and no-bound are built;
-the `bitfield` bound belongs to the multivol row and raises until that row is built."""
+"""build_obj_bound (arcnerf/models/base_modules/obj_bound/__init__.py:25-62): volume > sphere > bitfield > none."""
 from copy import deepcopy
 
 from ....utils.cfgs_utils import get_value_from_cfgs_field, valid_key_in_cfgs
 from ....utils.registry import BOUND_REGISTRY
 from .basic_bound import BasicBound
+from .bitfield_bound import BitfieldBound
 from .sphere_bound import SphereBound
 from .volume_bound import VolumeBound
 
-__all__ = ['BasicBound', 'SphereBound', 'VolumeBound', 'build_obj_bound']
+__all__ = ['BasicBound', 'BitfieldBound', 'SphereBound', 'VolumeBound', 'build_obj_bound']
 
 
 def build_obj_bound(cfgs):
@@ -19,4 +19,6 @@ def build_obj_bound(cfgs):
         return BOUND_REGISTRY.get('VolumeBound')(deepcopy(cfgs.obj_bound)), 'volume'
     if 'sphere' in keys:
         return BOUND_REGISTRY.get('SphereBound')(deepcopy(cfgs.obj_bound)), 'sphere'
-    raise NotImplementedError('Not such bounding class {} on this path yet...'.format(list(keys)))
+    if 'bitfield' in keys:
+        return BOUND_REGISTRY.get('BitfieldBound')(deepcopy(cfgs.obj_bound)), 'bitfield'
+    raise NotImplementedError('Not such bounding class {}...'.format(list(keys)))

@@ -15,7 +15,7 @@ from ..utils.registry import MODEL_REGISTRY
 from .base_modules import build_geo_model, build_radiance_model
 from .base_modules.encoding import HashGridEmbedder, SHEmbedder
 from .base_modules.geo_rad_model import FusedMLPGeoNet, FusedMLPRadianceNet
-from .base_modules.obj_bound import VolumeBound
+from .base_modules.obj_bound import BitfieldBound, VolumeBound
 from .fg_model import FgModel
 
 
@@ -78,8 +78,9 @@ class NeRF(FgModel):
     # ---- packed instant-ngp path -------------------------------------------------------------------------
     def packed_path_eligible(self):
         g, r, b = self.coarse_geo_net, self.coarse_radiance_net, self.obj_bound
-        return (self.use_packed_path and self.get_ray_cfgs('n_importance') == 0 and isinstance(b, VolumeBound)
-                and b.uses_sparse_sampling() and isinstance(g, FusedMLPGeoNet) and isinstance(g.embed_fn, HashGridEmbedder)
+        pruned = (isinstance(b, VolumeBound) and b.uses_sparse_sampling()) or \
+                 (isinstance(b, BitfieldBound) and b.get_obj_bound() is not None)
+        return (self.use_packed_path and self.get_ray_cfgs('n_importance') == 0 and pruned and isinstance(g, FusedMLPGeoNet) and isinstance(g.embed_fn, HashGridEmbedder)
                 and not g.embed_fn.include_input and g.W_feat > 0 and g.out_act is not None
                 and type(g.out_act).__name__ == 'TruncExp' and isinstance(r, FusedMLPRadianceNet) and r.mode in ('fv', 'vf')
                 and isinstance(r.embed_fn_view, SHEmbedder) and not r.embed_fn_view.include_input
@@ -110,9 +111,17 @@ class NeRF(FgModel):
             fld._seg = {}
             max_rays = int(self.chunk_rays) if self.chunk_rays and self.chunk_rays > 0 else 32768
             self._pipe = NgpPipeline(fld, max_rays=max_rays, max_samples=max(1 << 20, 2 * max_rays), packed_bits=True)
-            from ..ops.volume_func import sampler_rng
-            self._pipe.rng = sampler_rng()  # the process-wide sampler stream, like the reference's static generator
-        self._pipe.set_bitfield(self.obj_bound.volume.get_voxel_bitfield(flatten=True))
+            # the process-wide sampler stream of the native module the bound samples with, like the reference's static generators
+            if isinstance(self.obj_bound, BitfieldBound):
+                from ..ops.bitfield_func import bitfield_rng
+                self._pipe.rng = bitfield_rng()
+            else:
+                from ..ops.volume_func import sampler_rng
+                self._pipe.rng = sampler_rng()
+        if isinstance(self.obj_bound, BitfieldBound):
+            self._pipe.set_occupancy_bits(self.obj_bound.density_bitfield, 2)  # Morton bits, marched in place
+        else:
+            self._pipe.set_bitfield(self.obj_bound.volume.get_voxel_bitfield(flatten=True))
         return self._pipe
 
     def _forward_packed(self, inputs, inference_only):

@@ -117,6 +117,94 @@ def tensor_reduce_max(full, idx, n_group):
     return out
 
 
+# ------------------------------------------------------------------------------------------------
+# `_bitfield_func` family (K5-K10): Morton-order density grid + packed bitfield
+# ------------------------------------------------------------------------------------------------
+def sparse_volume_sampling_bit(rays_o, rays_d, near, far, n_pts, dt, aabb23, n_grid, bitfield, near_distance, rng_state,
+                               rng_inc, want_counts=False):
+    _req(rays_o, rays_d, near, far, aabb23, bitfield)
+    o, d = _f32(rays_o), _f32(rays_d)
+    nr, fr = _f32(near).view(-1), _f32(far).view(-1)
+    aabb = _f32(aabb23)
+    if bitfield.dtype != torch.uint8 or bitfield.numel() != int(n_grid) ** 3 // 8:
+        raise RuntimeError('bitfield should be uint8 in (n_grid**3/8,)')
+    bf = bitfield.contiguous()
+    R = o.shape[0]
+    zvals = torch.zeros((R, n_pts), dtype=torch.float32, device=o.device)
+    mask = torch.zeros((R, n_pts), dtype=torch.bool, device=o.device)
+    counts = torch.zeros(R, dtype=torch.int32, device=o.device) if want_counts else None
+    N.check(N.lib().arcn_sparse_volume_sampling_bit(N.ptr(o), N.ptr(d), N.ptr(nr), N.ptr(fr), int(n_pts), float(dt),
+                                                   N.ptr(aabb), int(n_grid), N.ptr(bf), float(near_distance),
+                                                   int(rng_state), int(rng_inc), N.ptr(zvals), mask.data_ptr(),
+                                                   N.ptr(counts), R, N.stream()), 'sparse_volume_sampling_bit')
+    return (zvals, mask, counts) if want_counts else (zvals, mask)
+
+
+def generate_grid_samples(density_grid, n_elements, ema_step, n_grid, thresh, rng_state, rng_inc):
+    _req(density_grid)
+    g = _f32(density_grid)
+    pos = torch.empty((n_elements, 3), dtype=torch.float32, device=g.device)
+    idx = torch.empty((n_elements,), dtype=torch.int32, device=g.device)
+    N.check(N.lib().arcn_generate_grid_samples(N.ptr(g), int(ema_step), int(n_elements), int(n_grid), float(thresh),
+                                              int(rng_state), int(rng_inc), N.ptr(pos), N.ptr(idx), N.stream()),
+            'generate_grid_samples')
+    return pos, idx
+
+
+def splat_grid_samples(density, indices, n_samples, density_grid_tmp):
+    """In place on density_grid_tmp (float32, contiguous)."""
+    _req(density, indices, density_grid_tmp)
+    if density_grid_tmp.dtype != torch.float32 or not density_grid_tmp.is_contiguous():
+        raise RuntimeError('density_grid_tmp must be a contiguous float32 tensor')
+    if indices.dtype != torch.int32:
+        raise RuntimeError('density_grid_indices must be int32')
+    den = _f32(density).view(-1)
+    if n_samples > den.shape[0] or n_samples > indices.shape[0]:
+        raise RuntimeError('n_samples exceeds the inputs')
+    N.check(N.lib().arcn_splat_grid_samples(N.ptr(den), N.ptr(indices.contiguous()), int(n_samples), N.ptr(density_grid_tmp),
+                                           N.stream()), 'splat_grid_samples')
+    return density_grid_tmp
+
+
+def ema_grid_samples_nerf(density_grid_tmp, density_grid, n_elements, decay):
+    """In place on density_grid."""
+    _req(density_grid_tmp, density_grid)
+    for t in (density_grid_tmp, density_grid):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() < n_elements:
+            raise RuntimeError('grids must be contiguous float32 tensors of at least n_elements')
+    N.check(N.lib().arcn_ema_grid_samples_nerf(N.ptr(density_grid_tmp), int(n_elements), float(decay), N.ptr(density_grid),
+                                              N.stream()), 'ema_grid_samples_nerf')
+    return density_grid
+
+
+def update_bitfield(density_grid, density_grid_mean, density_grid_bitfield, thres, n_grid):
+    """In place on density_grid_bitfield.  density_grid_mean: python float, or a 1-element device tensor (read on the device:
+    no host round trip)."""
+    _req(density_grid, density_grid_bitfield)
+    if density_grid.dtype != torch.float32 or not density_grid.is_contiguous() or density_grid.numel() < int(n_grid) ** 3:
+        raise RuntimeError('density_grid must be a contiguous float32 tensor of n_grid**3')
+    if density_grid_bitfield.dtype != torch.uint8 or density_grid_bitfield.numel() < int(n_grid) ** 3 // 8:
+        raise RuntimeError('bitfield should be uint8 in (n_grid**3/8,)')
+    mean_dev, mean_host = None, 0.0
+    if torch.is_tensor(density_grid_mean) and density_grid_mean.is_cuda:
+        mean_dev = _f32(density_grid_mean).view(-1)
+    else:
+        mean_host = float(density_grid_mean)
+    N.check(N.lib().arcn_update_bitfield(N.ptr(density_grid), mean_host, N.ptr(mean_dev), N.ptr(density_grid_bitfield),
+                                        float(thres), int(n_grid), N.stream()), 'update_bitfield')
+    return density_grid_bitfield
+
+
+def count_bitfield(density_grid_bitfield, n_grid, counter=None):
+    """Returns the device counter (1,) float32 (reference semantics: 8 per non-zero byte)."""
+    _req(density_grid_bitfield)
+    if counter is None:
+        counter = torch.zeros((1,), dtype=torch.float32, device=density_grid_bitfield.device)
+    N.check(N.lib().arcn_count_bitfield(N.ptr(density_grid_bitfield.contiguous()), N.ptr(counter), int(n_grid), N.stream()),
+            'count_bitfield')
+    return counter
+
+
 class Pcg32Host:
     """The explicit (seed, call counter) replacement of the reference's file-static `pcg32 rng{9121}`
     (arcnerf/ops/include/common.h:22-23): state before launch k is seed-state advanced k * 2^32."""

@@ -314,6 +314,13 @@ class NgpPipeline:
             w = (2 ** torch.arange(8, device=self.field.device, dtype=torch.int32))
             self._bits = (self.bitfield.view(-1, 8).to(torch.int32) * w).sum(-1).to(torch.uint8).contiguous()
 
+    def set_occupancy_bits(self, bits, mode):
+        """Hand over an already packed occupancy (uint8, 1 bit per voxel) without conversion: mode 1 = x-major order, mode 2 =
+        Morton order with clamped coordinates (BitfieldBound.density_bitfield, the `_bitfield_func` layout)."""
+        assert bits.dtype == torch.uint8 and bits.is_contiguous() and mode in (1, 2)
+        assert bits.numel() * 8 == self.cfg.n_grid ** 3
+        self._bits, self.packed_bits = bits, mode
+
     def _occ(self):
         return self._bits if self.packed_bits else self._bitfield
 

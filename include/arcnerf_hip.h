@@ -75,6 +75,35 @@ int arcn_sparse_volume_sampling(const float *rays_o, const float *rays_d, const 
  * pattern (valid for non-negative floats). uni (n_group) zero-initialised by the caller. */
 int arcn_tensor_reduce_max(const float *full, const int64_t *idx, int n_group, float *uni, int64_t n, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * `_bitfield_func` (arcnerf/ops/src/bitfield_func/bitfield_func.cpp:279-286; BitfieldBound, obj_bound/bitfield_bound.py):
+ * a float density grid of n_grid^3 cells in MORTON order (volume_func.h:141-168) and its packed bitfield of n_grid^3 / 8
+ * bytes.  n_grid must be a power of two <= 1024 (10 Morton bits per axis).  The module keeps its own file-static
+ * `pcg32 rng{9121}` shared by K5 and K6 and advanced 2^32 after each of them; here the caller passes (state, inc).
+ * ---------------------------------------------------------------------------------------------- */
+/* K5 sparse_volume_sampling_bit (bitfield_func_kernel.cu:20-136): K3's loop with the occupancy test
+ * density_grid_occupied_at_bit (voxel coordinates truncated, clamped into the grid, Morton bit).  Same outputs as K3. */
+int arcn_sparse_volume_sampling_bit(const float *rays_o, const float *rays_d, const float *near, const float *far, int n_pts,
+                                    float dt, const float *aabb, int n_grid, const uint8_t *bitfield, float near_distance,
+                                    uint64_t rng_state, uint64_t rng_inc, float *zvals, uint8_t *mask, int32_t *counts,
+                                    int64_t n_rays, void *stream);
+/* K6 generate_grid_samples (bitfield_func_kernel.cu:141-212): n_elements cells picked by the (i, ema_step) uint32 LCG, up to
+ * 10 probes for one with density > thresh; positions (n,3) jittered in [0,1)^3, indices (n) int32 Morton cell. */
+int arcn_generate_grid_samples(const float *density_grid, int ema_step, int n_elements, int n_grid, float thresh,
+                               uint64_t rng_state, uint64_t rng_inc, float *positions, int32_t *indices, void *stream);
+/* K7 splat_grid_samples (bitfield_func_kernel.cu:215-252): grid_tmp[idx[i]] = max(grid_tmp[idx[i]], density[i]) on the bit
+ * pattern (non-negative values). */
+int arcn_splat_grid_samples(const float *density, const int32_t *indices, int n_samples, float *density_grid_tmp, void *stream);
+/* K8 ema_grid_samples_nerf (bitfield_func_kernel.cu:257-296): grid = grid < 0 ? grid : max(grid * decay, grid_tmp). */
+int arcn_ema_grid_samples_nerf(const float *density_grid_tmp, int n_elements, float decay, float *density_grid, void *stream);
+/* K9 update_bitfield / grid_to_bitfield (bitfield_func_kernel.cu:301-345): bit = grid > min(opa_thres, mean).  The mean is
+ * the host float of the reference signature, or, when density_grid_mean_dev != NULL, read from that device scalar. */
+int arcn_update_bitfield(const float *density_grid, float density_grid_mean, const float *density_grid_mean_dev,
+                         uint8_t *bitfield, float opa_thres, int n_grid, void *stream);
+/* K10 count_bitfield (bitfield_func_kernel.cu:350-389): counter[0] += 8 for every NON-ZERO byte (the reference tests
+ * `byte && (1 << j)`, a logical and); counter is a device float the caller zeroes. */
+int arcn_count_bitfield(const uint8_t *bitfield, float *counter, int n_grid, void *stream);
+
 /* host pcg32 helpers (include/pcg32.h:50-165), HOST pointers: state_inc_host[2] = {state, inc}. */
 void arcn_pcg32_seed(uint64_t initstate, uint64_t initseq, uint64_t *state_inc_host);
 void arcn_pcg32_advance(uint64_t *state_inc_host, int64_t delta);
@@ -88,6 +117,8 @@ void arcn_pcg32_advance(uint64_t *state_inc_host, int64_t delta);
  *           max(counts), the dense width P the reference would have used (fg_model.py:251-262)
  *   pass 3  arcn_march_write : t (S) float, ray_id (S) int32 in ray-major order; dense t scratch reused.
  * scratch_t (n_rays,n_pts) float holds the emitted t of pass 1 (no init needed).
+ * bitfield_is_packed: 0 = bool per voxel (K3 layout), 1 = 1 bit per voxel in the same x-major order, 2 = 1 bit per voxel
+ * in Morton order with clamped coordinates (the K5 / BitfieldBound layout).
  * ---------------------------------------------------------------------------------------------- */
 int arcn_march_count(const float *rays_o, const float *rays_d, const float *aabb, int n_grid, const uint8_t *bitfield,
                      int bitfield_is_packed, int n_pts, float dt, float near_distance, int aabb_torch_semantics,

@@ -174,6 +174,85 @@ def tensor_reduce_max(full, idx, n_group):
     return out
 
 
+# ---- `_bitfield_func` family (K5-K10): Morton-order packed bitfield -------------------------------------------------
+def morton3d(xyz):
+    xyz = np.ascontiguousarray(xyz, dtype=np.uint32)
+    out = np.zeros(xyz.shape[0], np.uint32)
+    lib().orc_morton3d(_p(xyz), _p(out), C.c_int64(xyz.shape[0]))
+    return out
+
+
+def morton3d_invert(idx):
+    idx = np.ascontiguousarray(idx, dtype=np.uint32)
+    out = np.zeros((idx.shape[0], 3), np.uint32)
+    lib().orc_morton3d_invert(_p(idx), _p(out), C.c_int64(idx.shape[0]))
+    return out
+
+
+def sparse_volume_sampling_bit(rays_o, rays_d, near, far, n_pts, dt, aabb23, n_grid, bitfield, near_distance,
+                               rng_state, rng_inc, with_trace=False):
+    """K5.  bitfield: packed (n_grid**3 / 8) uint8 in Morton order.  Returns like sparse_volume_sampling."""
+    o, d = _f32(rays_o), _f32(rays_d)
+    nr, fr = _f32(near).reshape(-1), _f32(far).reshape(-1)
+    bf = np.ascontiguousarray(bitfield, dtype=np.uint8).reshape(-1)
+    assert bf.shape[0] == n_grid ** 3 // 8
+    aabb = _f32(aabb23)
+    R = o.shape[0]
+    zvals = np.zeros((R, n_pts), np.float32)
+    mask = np.zeros((R, n_pts), np.uint8)
+    counts = np.zeros(R, np.int32)
+    trace = np.full((R, n_pts), -1, np.int32) if with_trace else None
+    lib().orc_sparse_volume_sampling_bit(_p(o), _p(d), _p(nr), _p(fr), C.c_int(n_pts), C.c_float(dt), _p(aabb),
+                                         C.c_int(n_grid), _p(bf), C.c_float(near_distance), C.c_uint64(rng_state),
+                                         C.c_uint64(rng_inc), _p(zvals), _p(mask), _p(trace), _p(counts), C.c_int64(R))
+    if with_trace:
+        return zvals, mask.astype(bool), counts, trace
+    return zvals, mask.astype(bool), counts
+
+
+def generate_grid_samples(density_grid, n_elements, ema_step, n_grid, thresh, rng_state, rng_inc):
+    """K6.  positions (n,3) in [0,1), indices (n) int32 (Morton cell)."""
+    g = _f32(density_grid).reshape(-1)
+    pos = np.zeros((n_elements, 3), np.float32)
+    idx = np.zeros(n_elements, np.int32)
+    lib().orc_generate_grid_samples(_p(g), C.c_int(ema_step), C.c_int(n_elements), C.c_int(n_grid), C.c_float(thresh),
+                                    C.c_uint64(rng_state), C.c_uint64(rng_inc), _p(pos), _p(idx))
+    return pos, idx
+
+
+def splat_grid_samples(density, indices, grid_tmp):
+    """K7, in place on grid_tmp (contiguous float32)."""
+    assert grid_tmp.dtype == np.float32 and grid_tmp.flags.c_contiguous
+    den = _f32(density).reshape(-1)
+    idx = np.ascontiguousarray(indices, dtype=np.int32)
+    lib().orc_splat_grid_samples(_p(den), _p(idx), C.c_int(idx.shape[0]), _p(grid_tmp))
+    return grid_tmp
+
+
+def ema_grid_samples_nerf(grid_tmp, grid, decay):
+    """K8, in place on grid."""
+    assert grid.dtype == np.float32 and grid.flags.c_contiguous
+    tmp = _f32(grid_tmp).reshape(-1)
+    lib().orc_ema_grid_samples_nerf(_p(tmp), C.c_int(grid.shape[0]), C.c_float(decay), _p(grid))
+    return grid
+
+
+def update_bitfield(grid, mean, opa_thres, n_grid):
+    """K9 -> packed bitfield (n_grid**3/8) uint8."""
+    g = _f32(grid).reshape(-1)
+    bf = np.zeros(n_grid ** 3 // 8, np.uint8)
+    lib().orc_update_bitfield(_p(g), C.c_float(mean), _p(bf), C.c_float(opa_thres), C.c_int(n_grid))
+    return bf
+
+
+def count_bitfield(bitfield, n_grid):
+    """K10 (reference semantics: 8 per non-zero byte)."""
+    bf = np.ascontiguousarray(bitfield, dtype=np.uint8).reshape(-1)
+    cnt = np.zeros(1, np.float32)
+    lib().orc_count_bitfield(_p(bf), _p(cnt), C.c_int(n_grid))
+    return float(cnt[0])
+
+
 def update_opafield(opafield, flat_idx, opacity, ema=None):
     """In place on a contiguous float32 array."""
     assert opafield.dtype == np.float32 and opafield.flags.c_contiguous

@@ -278,3 +278,91 @@ def test_compat_shims_run_reference_shaped_calls(gpu):
     assert enc.params.grad is not None and net.params.grad is not None and float(net.params.grad.abs().sum()) > 0
     sh = tcnn.Encoding(3, {'otype': 'SphericalHarmonics', 'degree': 4}).to(gpu)
     assert sh((d + 1) / 2).shape == (64, 16)
+
+
+def _ngp_bitfield_model(gpu, bf_bool, extra=()):
+    """same nets as _ngp_model, bounded by a BitfieldBound whose Morton bitfield holds the same occupancy"""
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    from arcnerf_amd.ops.bitfield_func import bitfield_rng
+    from oracle import oracle as orc
+    from test_oracle_bitfield import to_morton_bits
+    ov = ['--model.obj_bound.bitfield.n_grid', '32', '--model.rays.n_sample', '256', '--model.geometry.encoder.hashmap_size', '14',
+          '--model.geometry.encoder.n_levels', '8', '--model.geometry.encoder.max_res', '256'] + list(extra)
+    torch.manual_seed(3)
+    m = build_model(load_configs(os.path.join(CFG, 'nerf_ngp_bitfield.yaml'), ov)).to(gpu)
+    with torch.no_grad():
+        m.fg_model.coarse_geo_net.embed_fn.embeddings.mul_(3000.0)
+        m.fg_model.obj_bound.density_bitfield.copy_(torch.from_numpy(to_morton_bits(bf_bool, orc)))
+    bitfield_rng(reset=True)
+    return m
+
+
+def test_ngp_bitfield_bound_equals_volume_bound_and_packed_equals_dense(gpu):
+    """BitfieldBound (Morton bits, K5) renders what VolumeBound (bool volume, K3) renders for the same occupancy and weights,
+    on the packed fast path and on the dense reference-shaped path, forward and parameter gradients."""
+    from arcnerf_amd.ops.bitfield_func import bitfield_rng
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    from arcnerf_amd.models.base_modules.obj_bound import BitfieldBound
+    mv = _ngp_model(gpu, ['--model.rays.noise_std', '0.0'])
+    bf = mv.fg_model.obj_bound.volume.get_voxel_bitfield().cpu().numpy()
+    mb = _ngp_bitfield_model(gpu, bf, ['--model.rays.noise_std', '0.0'])
+    assert isinstance(mb.fg_model.obj_bound, BitfieldBound) and mb.fg_model.packed_path_eligible()
+    mb.load_state_dict({k: v for k, v in mv.state_dict().items() if 'obj_bound' not in k}, strict=False)
+    inputs = _rays(gpu)
+    res = {}
+    for name, m in (('volume', mv), ('bitfield', mb)):
+        for packed in (True, False):
+            m.fg_model.use_packed_path = packed
+            sampler_rng(reset=True)
+            bitfield_rng(reset=True)
+            m.zero_grad()
+            o_inf = m({k: v.clone() for k, v in inputs.items()}, inference_only=True)
+            o_tr = m({k: v.clone() for k, v in inputs.items()}, inference_only=False)
+            ((o_tr['rgb_coarse'] - inputs['img']) ** 2).mean().backward()
+            res[name, packed] = ({**{k: v.detach().cpu().numpy() for k, v in o_inf.items()},
+                                  **{k: v.detach().cpu().numpy() for k, v in o_tr.items()}},
+                                 {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters() if p.grad is not None})
+    ref_out, ref_grad = res['volume', False]
+    assert (ref_out['depth'] < 10.0).any()
+    for key in (('volume', True), ('bitfield', True), ('bitfield', False)):
+        out, grad = res[key]
+        for k in ref_out:
+            close(out[k], ref_out[k], rtol=1e-5, atol=1e-5)
+        assert set(grad) == set(ref_grad)
+        for n in grad:
+            assert np.abs(grad[n] - ref_grad[n]).max() <= 1e-3 * np.abs(ref_grad[n]).max() + 1e-9, (key, n)
+    # same dense width on both dense paths and bit-identical samples: the two samplers walk the same t lattice
+    assert np.array_equal(res['bitfield', False][0]['depth'], res['volume', False][0]['depth'])
+
+
+def test_ngp_bitfield_model_trains_and_prunes(gpu):
+    bf = np.ones((32, 32, 32), bool)
+    m = _ngp_bitfield_model(gpu, bf)
+    fg = m.fg_model
+    inputs = _rays(gpu, 1, 2048)
+    with torch.no_grad():
+        fg.coarse_geo_net.embed_fn.embeddings.div_(3000.0)
+    inputs['bkg_color'] = torch.zeros_like(inputs['bkg_color'])
+    o, d = inputs['rays_o'][0], inputs['rays_d'][0]
+    t_mid = -(o * d).sum(-1, keepdim=True)
+    hit = ((o + t_mid * d).norm(dim=-1) < 0.5)[None]
+    tgt = hit[..., None].float() * torch.tensor([0.2, 0.7, 0.4], device=gpu)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2, eps=1e-15)
+    losses = []
+    for it in range(1, 161):
+        out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=it)
+        loss = ((out['rgb_coarse'] - tgt) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        if it % 16 == 0:
+            m.optimize(cur_epoch=it)   # warm-up refreshes: every cell
+    assert losses[-1] < 0.3 * losses[0], (losses[0], losses[-1])
+    cnt, ratio = fg.obj_bound.get_bitfield_count()
+    assert 0 < ratio < 0.9 and fg.obj_bound.ema_step == 10
+    m.optimize(cur_epoch=512)   # steady state: n/4 uniform + n/4 from occupied cells
+    assert fg.obj_bound.ema_step == 11
+    sd = m.state_dict()
+    assert any(k.endswith('obj_bound.density_bitfield') for k in sd) and any(k.endswith('obj_bound.density_grid') for k in sd)
