@@ -33,6 +33,50 @@ grid_samples_kernel(uint32_t n_elements, Pcg32 rng, uint32_t step, const float *
     indices[i] = (int32_t)idx;
 }
 
+// ---- K12 generate_grid_samples_multivol (multivol_func_kernel.cu:148-206) ---------------------------------------------
+// K6 over the cascade: a level is drawn first (redrawn while it is the inner one when that is excluded), the cell probe adds the
+// level's slot, and the jittered point is mapped to that level's volume (inner box scaled 2^level about its centre).
+__global__ void __launch_bounds__(256)
+grid_samples_multivol_kernel(uint32_t n_elements, const float *__restrict__ aabb, Pcg32 rng, uint32_t step,
+                             const float *__restrict__ grid_in, float *__restrict__ positions, int32_t *__restrict__ indices,
+                             uint32_t n_cascades, uint32_t n_grid, float thresh, int inclusive) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_elements) return;
+    rng.advance((int64_t)(uint32_t)(i * 4u));
+    uint32_t level = 0;
+    if (inclusive) {
+        level = (uint32_t)(rng.next_float() * (float)n_cascades) % n_cascades;
+    } else {
+        while (level == 0) level = (uint32_t)(rng.next_float() * (float)n_cascades) % n_cascades;
+    }
+    const uint32_t n_cells = n_grid * n_grid * n_grid;
+    const uint32_t base = (i + step * n_elements) * 56924617u + 96925573u;
+    const uint32_t slot = (inclusive ? level : level - 1) * n_cells;
+    uint32_t idx = 0;
+    for (uint32_t j = 0; j < 10; ++j) {
+        idx = (base + j * 19349663u) % n_cells + slot;
+        if (grid_in[idx] > thresh) break;
+    }
+    const uint32_t cell = idx % n_cells;
+    const float c[3] = {(float)morton_compact(cell), (float)morton_compact(cell >> 1), (float)morton_compact(cell >> 2)};
+    float r[3];
+    r[0] = rng.next_float();
+    r[1] = rng.next_float();
+    r[2] = rng.next_float();
+    const float scale = scalbnf(1.0f, (int)level), ng = (float)n_grid;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float center = (aabb[k] + aabb[3 + k]) / 2.0f;
+        const float len = aabb[3 + k] - aabb[k];
+        float p = (c[k] + r[k]) / ng;
+        p = p - 0.5f;
+        p = p * len;
+        p = p * scale;
+        positions[3 * (int64_t)i + k] = p + center;
+    }
+    indices[i] = (int32_t)idx;
+}
+
 // ---- K7 splat_grid_samples (bitfield_func_kernel.cu:215-229) ----------------------------------------------------------
 // max over the samples of each cell; non-negative floats order like their bit patterns, so an integer atomic max is exact
 __global__ void __launch_bounds__(256)
@@ -155,6 +199,35 @@ ARCN_EXPORT int arcn_update_bitfield(const float *density_grid, float density_gr
     hipLaunchKernelGGL(grid_to_bitfield_kernel, dim3(ceil_div<uint32_t>(n_bytes, 256)), dim3(256), 0, as_stream(stream), n_bytes,
                        density_grid, bitfield, density_grid_mean, density_grid_mean_dev, opa_thres);
     return check_launch("update_bitfield");
+}
+
+ARCN_EXPORT int arcn_generate_grid_samples_multivol(const float *density_grid, int ema_step, int n_elements, const float *aabb,
+                                                    int n_cascade, int n_grid, float thresh, int inclusive, uint64_t rng_state,
+                                                    uint64_t rng_inc, float *positions, int32_t *indices, void *stream) {
+    if (n_elements <= 0) return ARCN_OK;
+    if (!density_grid || !aabb || !positions || !indices) return einval("generate_grid_samples_multivol: missing argument");
+    if (!pow2_grid(n_grid)) return einval("generate_grid_samples_multivol: n_grid must be a power of two <= 1024");
+    if (n_cascade < 1 || (!inclusive && n_cascade < 2) || (int64_t)n_grid * n_grid * n_grid * n_cascade > 0xffffffffLL)
+        return einval("generate_grid_samples_multivol: bad n_cascade");
+    Pcg32 rng{rng_state, rng_inc};
+    hipLaunchKernelGGL(grid_samples_multivol_kernel, dim3(ceil_div<uint32_t>((uint32_t)n_elements, 256)), dim3(256), 0,
+                       as_stream(stream), (uint32_t)n_elements, aabb, rng, (uint32_t)ema_step, density_grid, positions, indices,
+                       (uint32_t)n_cascade, (uint32_t)n_grid, thresh, inclusive);
+    return check_launch("generate_grid_samples_multivol");
+}
+
+ARCN_EXPORT int arcn_update_bitfield_multivol(const float *density_grid, float density_grid_mean, const float *density_grid_mean_dev,
+                                              uint8_t *bitfield, float opa_thres, int n_grid, int n_cascade, int inclusive,
+                                              void *stream) {
+    if (!density_grid || !bitfield) return einval("update_bitfield_multivol: missing argument");
+    if (!pow2_grid(n_grid) || n_grid < 2) return einval("update_bitfield_multivol: n_grid must be a power of two in [2, 1024]");
+    const int levels = inclusive ? n_cascade : n_cascade - 1;
+    if (levels < 1 || (int64_t)n_grid * n_grid * n_grid * levels > 0xffffffffLL) return einval("update_bitfield_multivol: bad n_cascade");
+    if ((uintptr_t)density_grid & 15) return einval("update_bitfield_multivol: the grid must be 16-byte aligned");
+    const uint32_t n_bytes = (uint32_t)n_grid * (uint32_t)n_grid * (uint32_t)n_grid / 8u * (uint32_t)levels;
+    hipLaunchKernelGGL(grid_to_bitfield_kernel, dim3(ceil_div<uint32_t>(n_bytes, 256)), dim3(256), 0, as_stream(stream), n_bytes,
+                       density_grid, bitfield, density_grid_mean, density_grid_mean_dev, opa_thres);
+    return check_launch("update_bitfield_multivol");
 }
 
 ARCN_EXPORT int arcn_count_bitfield(const uint8_t *bitfield, float *counter, int n_grid, void *stream) {

@@ -274,6 +274,100 @@ sparse_sampling_kernel(const float *__restrict__ rays_o, const float *__restrict
     if (j > 0) for (; j < n_pts; ++j) zr[j] = last;
 }
 
+// ---- K11 sparse_sampling_in_multivol_bitfield (multivol_func_kernel.cu:14-96, volume_func.h:196-298) ---------------------
+// n_cascade nested volumes (volume m = the inner one scaled 2^m about its centre), each an n_grid^3 Morton bitfield; the step
+// grows with the distance (dt = clamp(t * cone_angle, min_step, max_step)).  With inclusive = 0 the inner volume has no grid
+// (level m lives in slot m-1) and a ray that re-enters it drops everything sampled so far.
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (hi < v ? hi : v); }
+__device__ __forceinline__ float cone_dt(float t, float cone_angle, float min_step, float max_step) {
+    return clampf(t * cone_angle, min_step, max_step);
+}
+
+__device__ __forceinline__ uint32_t mip_from_pos(const float pos[3], const Aabb &in, uint32_t n_cascades) {
+    int e_max = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float center = (in.mn[k] + in.mx[k]) / 2.0f;
+        const float half = (in.mx[k] - in.mn[k]) / 2.0f;
+        const float inv = 1.0f / half;
+        const float a = fabsf(pos[k] - center) * inv;
+        int e;
+        frexpf(a, &e);
+        if (k == 0 || e > e_max) e_max = e;
+    }
+    const int m = e_max > 0 ? e_max : 0;
+    return (uint32_t)(m < (int)n_cascades - 1 ? m : (int)n_cascades - 1);
+}
+
+__device__ __forceinline__ uint32_t morton_at_multivol(const float pos[3], uint32_t mip, const Aabb &in, uint32_t n) {
+    const float scale = scalbnf(1.0f, -(int)mip);
+    int c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float center = (in.mn[k] + in.mx[k]) / 2.0f;
+        float p = pos[k] - center;
+        p = p * scale;
+        p = p + center;
+        const float vs = (in.mx[k] - in.mn[k]) / (float)n;
+        const float vi = (p - in.mn[k]) / vs;
+        c[k] = min(max((int)vi, 0), (int)n - 1);
+    }
+    return morton3d((uint32_t)c[0], (uint32_t)c[1], (uint32_t)c[2]);
+}
+
+__global__ void __launch_bounds__(128)
+multivol_sampling_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ near,
+                         const float *__restrict__ far, const float *__restrict__ min_aabb, const float *__restrict__ aabb,
+                         const uint8_t *__restrict__ bf, uint32_t n_grid, uint32_t n_cascade, uint32_t n_pts, float cone_angle,
+                         float min_step, float max_step, float near_distance, int inclusive, Pcg32 rng,
+                         float *__restrict__ zvals, uint8_t *__restrict__ mask, int32_t *__restrict__ counts, int64_t n_rays) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays) return;
+    rng.advance((int64_t)(uint32_t)((uint32_t)i * 8u));
+    const Aabb outer = load_aabb(aabb), in = load_aabb(min_aabb);
+    const float o[3] = {rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2]};
+    const float d[3] = {rays_d[3 * i], rays_d[3 * i + 1], rays_d[3 * i + 2]};
+    float startt = fmaxf(near[i], near_distance);
+    const float far_end = far[i];
+    const float jit = cone_dt(startt, cone_angle, min_step, max_step) * rng.next_float();
+    startt += jit;
+    const uint32_t level_cells = n_grid * n_grid * n_grid;
+    float *zr = zvals + i * (int64_t)n_pts;
+    uint8_t *mr = mask + i * (int64_t)n_pts;
+    uint32_t j = 0;
+    float t = startt, last = 0.f;
+    float pos[3];
+    while (t <= far_end && j < n_pts) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { float a = d[k] * t; pos[k] = o[k] + a; }
+        if (!in_aabb(pos, outer)) break;
+        const float dt = cone_dt(t, cone_angle, min_step, max_step);
+        const uint32_t mip = mip_from_pos(pos, in, n_cascade);
+        if (mip == 0 && !inclusive) {
+            while (j > 0) { zr[j] = 0.0f; mr[j] = 0; j--; }
+            zr[j] = 0.0f;
+            mr[j] = 0;
+            const float t_target = t + dist_to_next_voxel(pos, d, in, n_grid);
+            do { t += dt; } while (t < t_target);
+        } else {
+            const uint32_t idx = morton_at_multivol(pos, mip, in, n_grid);
+            const uint32_t slot = inclusive ? mip : mip - 1;
+            if ((bf[(idx >> 3) + ((level_cells * slot) >> 3)] >> (idx & 7)) & 1) {
+                zr[j] = t;
+                mr[j] = 1;
+                last = t;
+                ++j;
+                t += dt;
+            } else {
+                const float t_target = t + dist_to_next_voxel(pos, d, in, n_grid);
+                do { t += cone_dt(t, cone_angle, min_step, max_step); } while (t < t_target);
+            }
+        }
+    }
+    if (counts) counts[i] = (int32_t)j;
+    if (j > 0) for (; j < n_pts; ++j) zr[j] = last;
+}
+
 // ---- K4 ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) reduce_max_kernel(const float *__restrict__ full, const int64_t *__restrict__ idx,
                                                          float *__restrict__ uni, int64_t n) {
@@ -608,6 +702,27 @@ ARCN_EXPORT int arcn_sparse_volume_sampling_bit(const float *rays_o, const float
                        as_stream(stream), rays_o, rays_d, near, far, aabb, bitfield, (uint32_t)n_grid, (uint32_t)n_pts, dt,
                        near_distance, rng, zvals, mask, counts, n_rays);
     return check_launch("sparse_volume_sampling_bit");
+}
+
+ARCN_EXPORT int arcn_sparse_sampling_in_multivol_bitfield(const float *rays_o, const float *rays_d, const float *near,
+                                                          const float *far, int n_pts, float cone_angle, float min_step,
+                                                          float max_step, const float *min_aabb, const float *aabb, int n_grid,
+                                                          int n_cascade, const uint8_t *bitfield, float near_distance,
+                                                          int inclusive, uint64_t rng_state, uint64_t rng_inc, float *zvals,
+                                                          uint8_t *mask, int32_t *counts, int64_t n_rays, void *stream) {
+    if (n_rays <= 0) return ARCN_OK;
+    if (!rays_o || !rays_d || !near || !far || !min_aabb || !aabb || !bitfield || !zvals || !mask || n_pts <= 0)
+        return einval("sparse_sampling_in_multivol_bitfield: missing/invalid argument");
+    if (n_grid <= 0 || n_grid > 1024 || (n_grid & (n_grid - 1)))
+        return einval("sparse_sampling_in_multivol_bitfield: n_grid must be a power of two <= 1024");
+    if (n_cascade < 1 || (!inclusive && n_cascade < 2) || (int64_t)n_grid * n_grid * n_grid * n_cascade > 0xffffffffLL)
+        return einval("sparse_sampling_in_multivol_bitfield: bad n_cascade");
+    if (!(min_step > 0) || !(max_step >= min_step)) return einval("sparse_sampling_in_multivol_bitfield: need 0 < min_step <= max_step");
+    Pcg32 rng{rng_state, rng_inc};
+    hipLaunchKernelGGL(multivol_sampling_kernel, dim3((unsigned)ceil_div<int64_t>(n_rays, 128)), dim3(128), 0, as_stream(stream),
+                       rays_o, rays_d, near, far, min_aabb, aabb, bitfield, (uint32_t)n_grid, (uint32_t)n_cascade, (uint32_t)n_pts,
+                       cone_angle, min_step, max_step, near_distance, inclusive, rng, zvals, mask, counts, n_rays);
+    return check_launch("sparse_sampling_in_multivol_bitfield");
 }
 
 ARCN_EXPORT int arcn_tensor_reduce_max(const float *full, const int64_t *idx, int n_group, float *uni, int64_t n,

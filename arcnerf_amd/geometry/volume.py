@@ -55,6 +55,16 @@ class Volume(nn.Module):
         self.xyz_len = nn.Parameter(torch.tensor(lens, dtype=torch.float32), requires_grad=requires_grad)
         self.cal_range()
 
+    # The reference keeps three derived point sets as buffers (corner (8,3), grid_pts ((n+1)^3,3), volume_pts (n^3,3):
+    # geometry/volume.py:200-232 there), 50 MB at n_grid 128 that nothing on this path reads; they are recomputed on demand
+    # here (get_volume_pts ...).  A reference checkpoint carries them: accept and drop them so it loads with strict=True.
+    DERIVED_REFERENCE_BUFFERS = ('corner', 'grid_pts', 'volume_pts')
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for name in self.DERIVED_REFERENCE_BUFFERS:
+            state_dict.pop(prefix + name, None)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     # ---- geometry -----------------------------------------------------------------------------------
     def cal_range(self):
         mn = self.origin.detach() - self.xyz_len.detach() / 2.0

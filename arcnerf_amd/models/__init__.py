@@ -5,11 +5,12 @@ from ..utils.cfgs_utils import dict_to_obj, obj_to_dict, valid_key_in_cfgs
 from ..utils.registry import MODEL_REGISTRY
 from .full_model import FullModel
 from .hdrnerf_model import HDRNeRF
+from .multivol_bkg_model import MultiVol
 from .nerf_model import NeRF
 from .nerfpp_bkg_model import NeRFPP
 from .neus_model import Neus
 
-__all__ = ['build_model', 'FullModel', 'HDRNeRF', 'NeRF', 'NeRFPP', 'Neus']
+__all__ = ['build_model', 'FullModel', 'HDRNeRF', 'MultiVol', 'NeRF', 'NeRFPP', 'Neus']
 
 
 def build_model(cfgs, logger=None):

@@ -1,0 +1,30 @@
+"""Evaluate the nets on the VALID samples of a padded (rays, slots) layout only.
+
+The pruned samplers return zvals (B, P) with a [T..T F..F] mask per ray, padded slots repeating the last valid z.  The
+reference gathers the valid points, runs the nets once, and fills every padded slot with its ray's last valid value so that the
+compositor sees zero-length intervals there (fg_model.py:331-386, multivol_bkg_model.py:150-196); rays without any sample are
+split off beforehand and get sigma = 0.  Here that is one function, and the empty rays are handled in place (no second gather)."""
+import torch
+
+from ..geometry.ray import get_ray_points_by_zvals
+from ..utils.torch_utils import chunk_processing
+
+
+def nets_on_valid_samples(forward_pts_dir, chunk_pts, geo_net, radiance_net, rays_o, rays_d, zvals, mask_pts):
+    """-> sigma (B, P), radiance (B, P, 3).  Rows of `mask_pts` without a True get zeros."""
+    n_rays, n_pts = zvals.shape
+    counts = mask_pts.sum(dim=1)
+    sigma = zvals.new_zeros((n_rays, n_pts))
+    radiance = zvals.new_zeros((n_rays, n_pts, 3))
+    pts = get_ray_points_by_zvals(rays_o, rays_d, zvals)[mask_pts].view(-1, 3)
+    if pts.shape[0] == 0:
+        return sigma, radiance
+    dirs = rays_d.unsqueeze(1).expand(n_rays, n_pts, 3)[mask_pts].view(-1, 3)
+    s_valid, r_valid = chunk_processing(forward_pts_dir, chunk_pts, False, geo_net, radiance_net, pts.contiguous(), dirs.contiguous())
+    has = counts > 0
+    last = (torch.cumsum(counts, dim=0) - 1).clamp_min(0)   # flat index of each ray's last valid sample
+    sigma = torch.where(has[:, None], s_valid[last][:, None].expand(n_rays, n_pts), sigma).contiguous()
+    radiance = torch.where(has[:, None, None], r_valid[last][:, None, :].expand(n_rays, n_pts, 3), radiance).contiguous()
+    sigma[mask_pts] = s_valid
+    radiance[mask_pts] = r_valid
+    return sigma, radiance

@@ -1,0 +1,89 @@
+"""MultiVol (arcnerf/models/multivol_bkg_model.py:18-261): instant-ngp's cascade of nested volumes, as a background model
+(inner volume excluded) or as a whole-scene model (`inclusive`).  Volume m is the basic volume scaled 2^m about its origin; each
+level is an n_grid^3 Morton density grid + bitfield, stored level after level.  Sampling = the cone-stepping cascade marcher
+(K11); pruning = the shared Morton-grid refresh with the cascade's cell draw (K12) and bit packing.  SURVEY.md section 8f, rank 2."""
+import torch
+
+from ..geometry.density_grid import MortonDensityGrid
+from ..geometry.ray import aabb_ray_intersection
+from ..geometry.volume import Volume
+from ..ops.multivol_func import (CUDA_BACKEND_AVAILABLE, generate_grid_samples_multivol, sparse_sampling_in_multivol_bitfield,
+                                 update_bitfield_multivol)
+from ..utils.cfgs_utils import get_value_from_cfgs_field
+from ..utils.registry import MODEL_REGISTRY
+from .base_modules import build_geo_model, build_radiance_model
+from .bkg_model import BkgModel
+from .masked_samples import nets_on_valid_samples
+
+
+@MODEL_REGISTRY.register()
+class MultiVol(BkgModel, MortonDensityGrid):
+    def __init__(self, cfgs):
+        super().__init__(cfgs)
+        assert CUDA_BACKEND_AVAILABLE, 'multivol requires libarcnerf_hip.so (there is no torch fallback)'
+        self.geo_net = build_geo_model(self.cfgs.model.geometry)
+        self.radiance_net = build_radiance_model(self.cfgs.model.radiance)
+        vc = self.cfgs.model.basic_volume
+        self.n_grid = get_value_from_cfgs_field(vc, 'n_grid', 128)
+        self.n_cascade = int(vc.n_cascade)
+        assert self.n_cascade > 1, 'You should have at least 2 cascades...'
+        self.inclusive = bool(get_value_from_cfgs_field(vc, 'inclusive', False))
+        box = {k: v for k, v in vc.__dict__.items() if k in ('origin', 'side', 'xyz_len')}
+        self.basic_volume = Volume(n_grid=self.n_grid, **box)
+        grow = 2 ** (self.n_cascade - 1)
+        self.max_volume = Volume(origin=self.basic_volume.get_origin(), xyz_len=[s * grow for s in self.basic_volume.get_len()])
+        # step length: from one coarse-sample interval of the inner volume up to one cell of the outermost one
+        self.cone_angle = get_value_from_cfgs_field(self.cfgs.model.rays, 'cone_angle', 0.0)
+        self.min_step = self.basic_volume.get_diag_len() / self.get_ray_cfgs('n_sample')
+        self.max_step = self.max_volume.get_diag_len() / self.n_grid
+        self.n_elements = self.n_grid ** 3
+        self.n_levels = self.n_cascade if self.inclusive else self.n_cascade - 1
+        self.total_n_elements = self.n_elements * self.n_levels
+        self._alloc_density_grid(self.total_n_elements)
+
+    def get_near_far_from_rays(self, rays_o, rays_d):
+        """near, far (B,1) against the outermost volume, torch semantics: the cameras sit inside it"""
+        box = self.max_volume.get_range()[None].to(rays_o.device)
+        near, far, _, _ = aabb_ray_intersection(rays_o, rays_d, box, force_torch=True)
+        return near, far
+
+    def get_zvals_from_near_far(self, near, far, n_pts, rays_o, rays_d, **kwargs):
+        """zvals (B, n_pts), mask_pts (B, n_pts) from the cascade marcher"""
+        return sparse_sampling_in_multivol_bitfield(rays_o, rays_d, near, far, n_pts, self.cone_angle, self.min_step, self.max_step,
+                                                    self.basic_volume.get_range(), self.max_volume.get_range(), self.n_grid,
+                                                    self.n_cascade, self.density_bitfield,
+                                                    near_distance=self.get_optim_cfgs('near_distance'), inclusive=self.inclusive)
+
+    def get_sigma_radiance_by_mask_pts(self, geo_net, radiance_net, rays_o, rays_d, zvals, mask_pts):
+        return nets_on_valid_samples(self._forward_pts_dir, self.chunk_pts, geo_net, radiance_net, rays_o, rays_d, zvals, mask_pts)
+
+    def forward(self, inputs, inference_only=False, get_progress=False, cur_epoch=0, total_epoch=300000):
+        rays_o, rays_d = inputs['rays_o'], inputs['rays_d']
+        with torch.no_grad():
+            near, far = self.get_near_far_from_rays(rays_o, rays_d)
+            zvals, mask_pts = self.get_zvals_from_near_far(near, far, self.get_ray_cfgs('n_sample'), rays_o, rays_d)
+            width = max(1, int(mask_pts.sum(dim=1).max()))   # the longest ray decides the padded width
+            zvals, mask_pts = zvals[:, :width].contiguous(), mask_pts[:, :width].contiguous()
+        sigma, radiance = self.get_sigma_radiance_by_mask_pts(self.geo_net, self.radiance_net, rays_o, rays_d, zvals, mask_pts)
+        return self.output_get_progress(self.ray_marching(sigma, radiance, zvals, inference_only=inference_only), get_progress)
+
+    @torch.no_grad()
+    def optimize(self, cur_epoch=0):
+        plan = self.refresh_plan(cur_epoch, self.get_optim_cfgs('epoch_optim'), self.get_optim_cfgs('epoch_optim_warmup'),
+                                 self.total_n_elements)
+        if plan is not None:
+            self._update_density_grid(*plan, self.get_ray_cfgs('n_sample'))
+
+    def _update_density_grid(self, n_uniform, n_nonuniform, n_pts):
+        inner = self.basic_volume.get_range()
+        dt = self.basic_volume.get_diag_len() / float(n_pts)   # opacity over one inner-volume step, whatever the level
+
+        def draw(n, thresh):
+            return generate_grid_samples_multivol(self.density_grid, n, inner, self.ema_step, self.n_cascade, self.n_grid, thresh,
+                                                  self.inclusive)
+
+        def repack(grid, mean, bits):
+            update_bitfield_multivol(grid, mean, bits, self.get_optim_cfgs('opa_thres'), self.n_grid, self.n_cascade, self.inclusive)
+
+        self._refresh_density_grid((n_uniform, n_nonuniform), draw, lambda pos: self.get_est_opacity(dt, pos),
+                                   self.get_optim_cfgs('ema_optim_decay'), self.get_optim_cfgs('opa_thres'), repack)

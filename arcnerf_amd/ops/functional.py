@@ -205,6 +205,67 @@ def count_bitfield(density_grid_bitfield, n_grid, counter=None):
     return counter
 
 
+# ------------------------------------------------------------------------------------------------
+# `_multivol_func` family (K11, K12, cascaded K9)
+# ------------------------------------------------------------------------------------------------
+def _multivol_levels(n_cascade, inclusive):
+    return int(n_cascade) if inclusive else int(n_cascade) - 1
+
+
+def sparse_sampling_in_multivol_bitfield(rays_o, rays_d, near, far, n_pts, cone_angle, min_step, max_step, min_aabb23, aabb23,
+                                         n_grid, n_cascade, bitfield, near_distance, inclusive, rng_state, rng_inc,
+                                         want_counts=False):
+    _req(rays_o, rays_d, near, far, min_aabb23, aabb23, bitfield)
+    o, d = _f32(rays_o), _f32(rays_d)
+    nr, fr = _f32(near).view(-1), _f32(far).view(-1)
+    if bitfield.dtype != torch.uint8 or bitfield.numel() != int(n_grid) ** 3 // 8 * _multivol_levels(n_cascade, inclusive):
+        raise RuntimeError('bitfield should be uint8 in (n_grid**3/8 * levels,)')
+    R = o.shape[0]
+    zvals = torch.zeros((R, n_pts), dtype=torch.float32, device=o.device)
+    mask = torch.zeros((R, n_pts), dtype=torch.bool, device=o.device)
+    counts = torch.zeros(R, dtype=torch.int32, device=o.device) if want_counts else None
+    N.check(N.lib().arcn_sparse_sampling_in_multivol_bitfield(
+        N.ptr(o), N.ptr(d), N.ptr(nr), N.ptr(fr), int(n_pts), float(cone_angle), float(min_step), float(max_step),
+        N.ptr(_f32(min_aabb23)), N.ptr(_f32(aabb23)), int(n_grid), int(n_cascade), N.ptr(bitfield.contiguous()),
+        float(near_distance), int(bool(inclusive)), int(rng_state), int(rng_inc), N.ptr(zvals), mask.data_ptr(), N.ptr(counts), R,
+        N.stream()), 'sparse_sampling_in_multivol_bitfield')
+    return (zvals, mask, counts) if want_counts else (zvals, mask)
+
+
+def generate_grid_samples_multivol(density_grid, n_elements, aabb23, ema_step, n_cascade, n_grid, thresh, inclusive, rng_state,
+                                   rng_inc):
+    _req(density_grid, aabb23)
+    g = _f32(density_grid)
+    if g.numel() < int(n_grid) ** 3 * _multivol_levels(n_cascade, inclusive):
+        raise RuntimeError('density_grid should hold n_grid**3 * levels cells')
+    pos = torch.empty((n_elements, 3), dtype=torch.float32, device=g.device)
+    idx = torch.empty((n_elements,), dtype=torch.int32, device=g.device)
+    N.check(N.lib().arcn_generate_grid_samples_multivol(N.ptr(g), int(ema_step), int(n_elements), N.ptr(_f32(aabb23)),
+                                                       int(n_cascade), int(n_grid), float(thresh), int(bool(inclusive)),
+                                                       int(rng_state), int(rng_inc), N.ptr(pos), N.ptr(idx), N.stream()),
+            'generate_grid_samples_multivol')
+    return pos, idx
+
+
+def update_bitfield_multivol(density_grid, density_grid_mean, density_grid_bitfield, thres, n_grid, n_cascade, inclusive):
+    """In place on density_grid_bitfield; density_grid_mean a python float or a 1-element device tensor."""
+    _req(density_grid, density_grid_bitfield)
+    cells = int(n_grid) ** 3 * _multivol_levels(n_cascade, inclusive)
+    if density_grid.dtype != torch.float32 or not density_grid.is_contiguous() or density_grid.numel() < cells:
+        raise RuntimeError('density_grid must be a contiguous float32 tensor of n_grid**3 * levels')
+    if density_grid_bitfield.dtype != torch.uint8 or density_grid_bitfield.numel() < cells // 8:
+        raise RuntimeError('bitfield should be uint8 in (n_grid**3/8 * levels,)')
+    mean_dev, mean_host = None, 0.0
+    if torch.is_tensor(density_grid_mean) and density_grid_mean.is_cuda:
+        mean_dev = _f32(density_grid_mean).view(-1)
+    else:
+        mean_host = float(density_grid_mean)
+    N.check(N.lib().arcn_update_bitfield_multivol(N.ptr(density_grid), mean_host, N.ptr(mean_dev), N.ptr(density_grid_bitfield),
+                                                 float(thres), int(n_grid), int(n_cascade), int(bool(inclusive)), N.stream()),
+            'update_bitfield_multivol')
+    return density_grid_bitfield
+
+
 class Pcg32Host:
     """The explicit (seed, call counter) replacement of the reference's file-static `pcg32 rng{9121}`
     (arcnerf/ops/include/common.h:22-23): state before launch k is seed-state advanced k * 2^32."""

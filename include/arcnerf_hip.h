@@ -104,6 +104,31 @@ int arcn_update_bitfield(const float *density_grid, float density_grid_mean, con
  * `byte && (1 << j)`, a logical and); counter is a device float the caller zeroes. */
 int arcn_count_bitfield(const uint8_t *bitfield, float *counter, int n_grid, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * `_multivol_func` (arcnerf/ops/src/multivol_func/multivol_func.cpp; MultiVol background, models/multivol_bkg_model.py):
+ * n_cascade nested volumes — volume m = the inner box scaled 2^m about its centre — each an n_grid^3 Morton grid, stored level
+ * after level; with inclusive = 0 the inner volume has no grid and level m lives in slot m-1.  Own pcg32 stream like
+ * `_bitfield_func` (K11 and K12 advance it 2^32 per launch).
+ * ---------------------------------------------------------------------------------------------- */
+/* K11 sparse_sampling_in_multivol_bitfield (multivol_func_kernel.cu:14-146): marching with dt = clamp(t * cone_angle,
+ * min_step, max_step) through the cascade (level from the point's largest normalised coordinate, volume_func.h:201-226);
+ * min_aabb (2,3) = inner volume, aabb (2,3) = outermost.  inclusive = 0: a ray that re-enters the inner volume drops the
+ * samples taken so far.  Outputs as K3. */
+int arcn_sparse_sampling_in_multivol_bitfield(const float *rays_o, const float *rays_d, const float *near, const float *far,
+                                              int n_pts, float cone_angle, float min_step, float max_step,
+                                              const float *min_aabb, const float *aabb, int n_grid, int n_cascade,
+                                              const uint8_t *bitfield, float near_distance, int inclusive, uint64_t rng_state,
+                                              uint64_t rng_inc, float *zvals, uint8_t *mask, int32_t *counts, int64_t n_rays,
+                                              void *stream);
+/* K12 generate_grid_samples_multivol (multivol_func_kernel.cu:148-240): K6 over the cascade; aabb (2,3) = inner volume;
+ * positions in world space of the drawn level, indices = slot * n_grid^3 + Morton cell. */
+int arcn_generate_grid_samples_multivol(const float *density_grid, int ema_step, int n_elements, const float *aabb,
+                                        int n_cascade, int n_grid, float thresh, int inclusive, uint64_t rng_state,
+                                        uint64_t rng_inc, float *positions, int32_t *indices, void *stream);
+/* update_bitfield_multivol (multivol_func_kernel.cu:242-300): K9 over all stored levels. */
+int arcn_update_bitfield_multivol(const float *density_grid, float density_grid_mean, const float *density_grid_mean_dev,
+                                  uint8_t *bitfield, float opa_thres, int n_grid, int n_cascade, int inclusive, void *stream);
+
 /* host pcg32 helpers (include/pcg32.h:50-165), HOST pointers: state_inc_host[2] = {state, inc}. */
 void arcn_pcg32_seed(uint64_t initstate, uint64_t initseq, uint64_t *state_inc_host);
 void arcn_pcg32_advance(uint64_t *state_inc_host, int64_t delta);

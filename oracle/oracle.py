@@ -253,6 +253,45 @@ def count_bitfield(bitfield, n_grid):
     return float(cnt[0])
 
 
+# ---- `_multivol_func` family (K11, K12, cascaded K9) -------------------------------------------------------------------
+def sparse_sampling_in_multivol_bitfield(rays_o, rays_d, near, far, n_pts, cone_angle, min_step, max_step, min_aabb23, aabb23,
+                                         n_grid, n_cascade, bitfield, near_distance, inclusive, rng_state, rng_inc):
+    """K11 -> zvals (R,n_pts), mask (R,n_pts) bool, counts (R)"""
+    o, d = _f32(rays_o), _f32(rays_d)
+    nr, fr = _f32(near).reshape(-1), _f32(far).reshape(-1)
+    bf = np.ascontiguousarray(bitfield, dtype=np.uint8).reshape(-1)
+    assert bf.shape[0] == n_grid ** 3 // 8 * (n_cascade if inclusive else n_cascade - 1)
+    R = o.shape[0]
+    zvals = np.zeros((R, n_pts), np.float32)
+    mask = np.zeros((R, n_pts), np.uint8)
+    counts = np.zeros(R, np.int32)
+    lib().orc_sparse_sampling_in_multivol_bitfield(
+        _p(o), _p(d), _p(nr), _p(fr), C.c_int(n_pts), C.c_float(cone_angle), C.c_float(min_step), C.c_float(max_step),
+        _p(_f32(min_aabb23)), _p(_f32(aabb23)), C.c_int(n_grid), C.c_int(n_cascade), _p(bf), C.c_float(near_distance),
+        C.c_int(int(bool(inclusive))), C.c_uint64(rng_state), C.c_uint64(rng_inc), _p(zvals), _p(mask), _p(counts), C.c_int64(R))
+    return zvals, mask.astype(bool), counts
+
+
+def generate_grid_samples_multivol(density_grid, n_elements, aabb23, ema_step, n_cascade, n_grid, thresh, inclusive, rng_state,
+                                   rng_inc):
+    """K12 -> positions (n,3) world space, indices (n) int32 = slot * n_grid^3 + Morton cell"""
+    g = _f32(density_grid).reshape(-1)
+    pos = np.zeros((n_elements, 3), np.float32)
+    idx = np.zeros(n_elements, np.int32)
+    lib().orc_generate_grid_samples_multivol(_p(g), C.c_int(ema_step), C.c_int(n_elements), _p(_f32(aabb23)), C.c_int(n_cascade),
+                                             C.c_int(n_grid), C.c_float(thresh), C.c_int(int(bool(inclusive))),
+                                             C.c_uint64(rng_state), C.c_uint64(rng_inc), _p(pos), _p(idx))
+    return pos, idx
+
+
+def update_bitfield_multivol(grid, mean, opa_thres, n_grid, n_cascade, inclusive):
+    g = _f32(grid).reshape(-1)
+    bf = np.zeros(n_grid ** 3 // 8 * (n_cascade if inclusive else n_cascade - 1), np.uint8)
+    lib().orc_update_bitfield_multivol(_p(g), C.c_float(mean), _p(bf), C.c_float(opa_thres), C.c_int(n_grid), C.c_int(n_cascade),
+                                       C.c_int(int(bool(inclusive))))
+    return bf
+
+
 def update_opafield(opafield, flat_idx, opacity, ema=None):
     """In place on a contiguous float32 array."""
     assert opafield.dtype == np.float32 and opafield.flags.c_contiguous

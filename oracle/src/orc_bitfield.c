@@ -188,3 +188,159 @@ ORC_API void orc_count_bitfield(const uint8_t *bitfield, float *counter, int n_g
         for (int j = 0; j < 8; ++j)
             if ((bitfield[i] && (uint8_t)(1u << j)) > 0) counter[0] += 1.0f;
 }
+
+/* =======================================================================================
+ * `_multivol_func` (arcnerf/ops/src/multivol_func/multivol_func_kernel.cu, volume_func.h:196-298): n_cascade nested
+ * volumes, volume m = the inner ("basic") one scaled by 2^m about its centre, each an n_grid^3 Morton bitfield; with
+ * inclusive = 0 the inner volume itself has no grid and level m lives in slot m-1.  CUDA only: PARITY UNPINNED.
+ * ===================================================================================== */
+
+/* include/common.h:64-67 */
+static inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (hi < v ? hi : v); }
+
+/* volume_func.h:277-279 */
+static inline float calc_dt(float t, float cone_angle, float min_step, float max_step) {
+    return clampf(t * cone_angle, min_step, max_step);
+}
+
+/* volume_func.h:201-226: level = exponent of the largest |coordinate| in units of the inner half side */
+static inline int mip_from_pos(const float pos[3], const float mn[3], const float mx[3], uint32_t n_cascades) {
+    int e_max = 0;
+    for (int k = 0; k < 3; ++k) {
+        float center = (mn[k] + mx[k]) / 2.0f;
+        float half = (mx[k] - mn[k]) / 2.0f;
+        float inv = 1.0f / half;
+        float a = fabsf(pos[k] - center) * inv;
+        int e;
+        frexpf(a, &e);
+        if (k == 0 || e > e_max) e_max = e;
+    }
+    int m = e_max > 0 ? e_max : 0;
+    return m < (int)n_cascades - 1 ? m : (int)n_cascades - 1;
+}
+
+/* volume_func.h:229-254: shrink the point by 2^-mip about the centre, then the Morton cell of the inner grid */
+static inline uint32_t morton_idx_at_multivol(const float pos_in[3], uint32_t mip, const float mn[3], const float mx[3],
+                                              uint32_t n) {
+    float scale = scalbnf(1.0f, -(int)mip);
+    int c[3];
+    for (int k = 0; k < 3; ++k) {
+        float center = (mn[k] + mx[k]) / 2.0f;
+        float p = pos_in[k] - center;
+        p = p * scale;
+        p = p + center;
+        float vs = (mx[k] - mn[k]) / (float)n;
+        float vi = (p - mn[k]) / vs;
+        c[k] = clampi((int)vi, 0, (int)n - 1);
+    }
+    return morton3d((uint32_t)c[0], (uint32_t)c[1], (uint32_t)c[2]);
+}
+
+/* K11 sparse_sampling_in_multivol_bitfield (multivol_func_kernel.cu:14-96).  min_aabb = inner volume, aabb = outermost. */
+ORC_API void orc_sparse_sampling_in_multivol_bitfield(const float *rays_o, const float *rays_d, const float *near,
+                                                      const float *far, int n_pts, float cone_angle, float min_step,
+                                                      float max_step, const float *min_aabb, const float *aabb, int n_grid,
+                                                      int n_cascade, const uint8_t *bitfield, float near_distance,
+                                                      int inclusive, uint64_t rng_state, uint64_t rng_inc, float *zvals,
+                                                      uint8_t *mask, int32_t *counts, int64_t n_rays) {
+    const float *mn = aabb, *mx = aabb + 3, *imn = min_aabb, *imx = min_aabb + 3;
+    const uint32_t n = (uint32_t)n_grid, level_cells = n * n * n;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < n_rays; ++i) {
+        orc_pcg32 rng = {rng_state, rng_inc};
+        orc_pcg32_advance(&rng, (int64_t)(uint32_t)((uint32_t)i * 8u));
+        const float *o = rays_o + 3 * i, *d = rays_d + 3 * i;
+        float startt = fmaxf(near[i], near_distance);
+        float far_end = far[i];
+        float jit = calc_dt(startt, cone_angle, min_step, max_step) * orc_pcg32_next_float(&rng);
+        startt += jit;
+        uint32_t j = 0;
+        float t = startt;
+        float pos[3];
+        float *zr = zvals + i * (int64_t)n_pts;
+        uint8_t *mr = mask + i * (int64_t)n_pts;
+        while (t <= far_end && j < (uint32_t)n_pts) {
+            for (int k = 0; k < 3; ++k) { float a = d[k] * t; pos[k] = o[k] + a; }
+            if (!in_aabb(pos, mn, mx)) break;
+            float dt = calc_dt(t, cone_angle, min_step, max_step);
+            uint32_t mip = (uint32_t)mip_from_pos(pos, imn, imx, (uint32_t)n_cascade);
+            if (mip == 0 && !inclusive) {
+                /* the ray re-entered the inner volume: drop everything sampled so far (no bkg -> fg -> bkg sequences) */
+                while (j > 0) { zr[j] = 0.0f; mr[j] = 0; j--; }
+                zr[j] = 0.0f;
+                mr[j] = 0;
+                float t_target = t + dist_to_next_voxel(pos, d, imn, imx, n);
+                do { t += dt; } while (t < t_target);
+            } else {
+                uint32_t idx = morton_idx_at_multivol(pos, mip, imn, imx, n);
+                uint32_t slot = inclusive ? mip : mip - 1;
+                if (bitfield[idx / 8 + (level_cells * slot) / 8] & (1u << (idx % 8))) {
+                    zr[j] = t;
+                    mr[j] = 1;
+                    ++j;
+                    t += dt;
+                } else {
+                    float t_target = t + dist_to_next_voxel(pos, d, imn, imx, n);
+                    do { t += calc_dt(t, cone_angle, min_step, max_step); } while (t < t_target);
+                }
+            }
+        }
+        if (counts) counts[i] = (int32_t)j;
+        if (j > 0 && j < (uint32_t)n_pts) {
+            float last = zr[j - 1];
+            while (j < (uint32_t)n_pts) { zr[j] = last; ++j; }
+        }
+    }
+}
+
+/* K12 generate_grid_samples_multivol (multivol_func_kernel.cu:148-206).  aabb = inner volume (2,3). */
+ORC_API void orc_generate_grid_samples_multivol(const float *grid_in, int ema_step, int n_elements_i, const float *aabb,
+                                                int n_cascade, int n_grid_i, float thresh, int inclusive, uint64_t rng_state,
+                                                uint64_t rng_inc, float *positions, int32_t *indices) {
+    const uint32_t n_elements = (uint32_t)n_elements_i, n_grid = (uint32_t)n_grid_i, step = (uint32_t)ema_step;
+    const uint32_t n_cascades = (uint32_t)n_cascade, n_per_level = n_grid * n_grid * n_grid;
+    for (uint32_t i = 0; i < n_elements; ++i) {
+        orc_pcg32 rng = {rng_state, rng_inc};
+        orc_pcg32_advance(&rng, (int64_t)(uint32_t)(i * 4u));
+        uint32_t level = 0;
+        if (inclusive) {
+            level = (uint32_t)(orc_pcg32_next_float(&rng) * (float)n_cascades) % n_cascades;
+        } else {
+            while (level == 0) level = (uint32_t)(orc_pcg32_next_float(&rng) * (float)n_cascades) % n_cascades;
+        }
+        uint32_t idx = 0;
+        for (uint32_t j = 0; j < 10; ++j) {
+            idx = ((i + step * n_elements) * 56924617u + j * 19349663u + 96925573u) % n_per_level;
+            idx += (inclusive ? level : level - 1) * n_per_level;
+            if (grid_in[idx] > thresh) break;
+        }
+        uint32_t pos_idx = idx % n_per_level;
+        uint32_t c[3] = {morton3d_invert(pos_idx >> 0), morton3d_invert(pos_idx >> 1), morton3d_invert(pos_idx >> 2)};
+        float r[3];
+        for (int k = 0; k < 3; ++k) r[k] = orc_pcg32_next_float(&rng);
+        float scale = scalbnf(1.0f, (int)level);
+        for (int k = 0; k < 3; ++k) {
+            float center = (aabb[k] + aabb[3 + k]) / 2.0f;
+            float len = aabb[3 + k] - aabb[k];
+            float p = ((float)c[k] + r[k]) / (float)n_grid;
+            p = p - 0.5f;
+            p = p * len;
+            p = p * scale;
+            positions[3 * (int64_t)i + k] = p + center;
+        }
+        indices[i] = (int32_t)idx;
+    }
+}
+
+/* update_bitfield_multivol (multivol_func_kernel.cu:242-300): K9's rule over every stored level */
+ORC_API void orc_update_bitfield_multivol(const float *grid, float mean, uint8_t *bitfield, float opa_thres, int n_grid,
+                                          int n_cascade, int inclusive) {
+    const uint32_t n = (uint32_t)n_grid * (uint32_t)n_grid * (uint32_t)n_grid / 8u *
+                       (uint32_t)(inclusive ? n_cascade : n_cascade - 1);
+    const float thresh = opa_thres < mean ? opa_thres : mean;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint8_t bits = 0;
+        for (int j = 0; j < 8; ++j) bits |= grid[(int64_t)i * 8 + j] > thresh ? (uint8_t)(1u << j) : 0;
+        bitfield[i] = bits;
+    }
+}

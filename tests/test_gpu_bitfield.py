@@ -223,3 +223,93 @@ def test_bitfield_bound_refresh_matches_oracle_flow(oracle):
     assert c_ref.sum() > 0
     assert 'density_bitfield' in bound.state_dict() and 'density_grid' in bound.state_dict()
     bitfield_rng(reset=True)
+
+
+# ---- `_multivol_func` (K11, K12, cascaded K9) ---------------------------------------------------------------------------
+def _cascade_case(rng, n_grid, n_cascade, inclusive, R, frac=0.3):
+    levels = n_cascade if inclusive else n_cascade - 1
+    bits = np.packbits(rng.random(levels * n_grid ** 3) < frac, bitorder='little')
+    o = ((rng.random((R, 3)) - 0.5) * 3.0).astype(np.float32)
+    o[: R // 2] *= 0.2
+    d = rng.normal(size=(R, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    inner = np.array([[-0.5, -0.5, -0.5], [0.5, 0.5, 0.5]], np.float32)
+    outer = inner * 2 ** (n_cascade - 1)
+    return bits, o, d, inner, outer
+
+
+@pytest.mark.parametrize('inclusive', [True, False])
+@pytest.mark.parametrize('n_grid,n_cascade,n_pts,R,cone', [(16, 4, 192, 600, 1.0 / 16), (128, 5, 1024, 4096, 1.0 / 256), (32, 3, 256, 1000, 0.0)])
+def test_k11_cascade_sampler_bit_exact_vs_oracle(F, oracle, inclusive, n_grid, n_cascade, n_pts, R, cone):
+    rng = np.random.default_rng(n_grid + int(inclusive))
+    bits, o, d, inner, outer = _cascade_case(rng, n_grid, n_cascade, inclusive, R, 0.3 if n_grid < 128 else 0.05)
+    near, far, _, _ = oracle.aabb_intersection_torch(o, d, np.stack([outer[0], outer[1]], -1)[None])
+    min_step = np.float32(np.sqrt(3.0) / n_pts)
+    max_step = np.float32(np.sqrt(3.0) * 2 ** (n_cascade - 1) / n_grid)
+    h = oracle.Pcg32(9121)
+    h.advance()
+    z_ref, m_ref, c_ref = oracle.sparse_sampling_in_multivol_bitfield(o, d, near, far, n_pts, cone, min_step, max_step, inner, outer,
+                                                                      n_grid, n_cascade, bits, 0.05, inclusive, h.state, h.inc)
+    z, m, c = F.sparse_sampling_in_multivol_bitfield(dev(o), dev(d), dev(near), dev(far), n_pts, cone, float(min_step), float(max_step),
+                                                     dev(inner), dev(outer), n_grid, n_cascade, dev(bits), 0.05, inclusive, h.state,
+                                                     h.inc, want_counts=True)
+    assert np.array_equal(host(c), c_ref) and np.array_equal(host(m), m_ref)
+    assert np.array_equal(host(z).view(np.uint32), z_ref.view(np.uint32))
+    assert c_ref.sum() > 5 * R
+
+
+@pytest.mark.parametrize('inclusive', [True, False])
+def test_k12_and_cascaded_k9_bit_exact(F, oracle, inclusive):
+    n_grid, n_cascade = 32, 5
+    levels = n_cascade if inclusive else n_cascade - 1
+    n = levels * n_grid ** 3 // 4
+    rng = np.random.default_rng(12)
+    grid = (rng.random(levels * n_grid ** 3).astype(np.float32) - 0.5)
+    inner = np.array([[-0.5, -1.0, 0.0], [0.5, 1.0, 3.0]], np.float32)
+    h = oracle.Pcg32(9121)
+    for step, thresh in ((0, -0.01), (9, 0.3)):
+        pos_ref, idx_ref = oracle.generate_grid_samples_multivol(grid, n, inner, step, n_cascade, n_grid, thresh, inclusive, h.state, h.inc)
+        pos, idx = F.generate_grid_samples_multivol(dev(grid), n, dev(inner), step, n_cascade, n_grid, thresh, inclusive, h.state, h.inc)
+        assert np.array_equal(host(idx), idx_ref)
+        assert np.array_equal(host(pos).view(np.uint32), pos_ref.view(np.uint32))
+        h.advance()
+    mean = float(np.clip(grid, 0, None).mean())
+    bf = torch.zeros(levels * n_grid ** 3 // 8, dtype=torch.uint8, device='cuda')
+    F.update_bitfield_multivol(dev(grid), torch.tensor([mean], device='cuda'), bf, 0.01, n_grid, n_cascade, inclusive)
+    assert np.array_equal(host(bf), oracle.update_bitfield_multivol(grid, mean, 0.01, n_grid, n_cascade, inclusive))
+    with pytest.raises(RuntimeError):   # a grid that cannot hold every level
+        F.generate_grid_samples_multivol(dev(grid[:100]), 10, dev(inner), 0, n_cascade, n_grid, 0.0, inclusive, h.state, h.inc)
+
+
+def test_compat_multivol_func_module(oracle):
+    import arcnerf_amd.compat as compat
+    compat.install()
+    import _multivol_func as M
+    from arcnerf_amd.ops.multivol_func import multivol_rng
+    rng = np.random.default_rng(13)
+    n_grid, n_cascade, n_pts, R = 16, 3, 64, 128
+    bits, o, d, inner, outer = _cascade_case(rng, n_grid, n_cascade, False, R)
+    near, far, _, _ = oracle.aabb_intersection_torch(o, d, np.stack([outer[0], outer[1]], -1)[None])
+    multivol_rng(reset=True)
+    h = oracle.Pcg32(9121)
+    z = torch.zeros((R, n_pts), device='cuda')
+    m = torch.zeros((R, n_pts), dtype=torch.bool, device='cuda')
+    M.sparse_sampling_in_multivol_bitfield(dev(o), dev(d), dev(near), dev(far), n_pts, 0.05, 0.03, 0.4, dev(inner), dev(outer), n_grid,
+                                           n_cascade, dev(bits), 0.05, False, z, m)
+    z_ref, m_ref, _ = oracle.sparse_sampling_in_multivol_bitfield(o, d, near, far, n_pts, 0.05, 0.03, 0.4, inner, outer, n_grid,
+                                                                  n_cascade, bits, 0.05, False, h.state, h.inc)
+    assert np.array_equal(host(z).view(np.uint32), z_ref.view(np.uint32)) and np.array_equal(host(m), m_ref)
+    h.advance()
+    grid = (rng.random(2 * n_grid ** 3).astype(np.float32) - 0.5)
+    pos = torch.empty((500, 3), device='cuda')
+    idx = torch.empty((500,), dtype=torch.int32, device='cuda')
+    M.generate_grid_samples_multivol(dev(grid), 2, 500, dev(inner), n_cascade, n_grid, 0.1, False, pos, idx)
+    pos_ref, idx_ref = oracle.generate_grid_samples_multivol(grid, 500, inner, 2, n_cascade, n_grid, 0.1, False, h.state, h.inc)
+    assert np.array_equal(host(idx), idx_ref) and np.array_equal(host(pos).view(np.uint32), pos_ref.view(np.uint32))
+    bf = torch.zeros(2 * n_grid ** 3 // 8, dtype=torch.uint8, device='cuda')
+    M.update_bitfield_multivol(dev(grid), 0.2, bf, 0.01, n_grid, n_cascade, False)
+    assert np.array_equal(host(bf), oracle.update_bitfield_multivol(grid, 0.2, 0.01, n_grid, n_cascade, False))
+    with pytest.raises(RuntimeError):
+        M.sparse_sampling_in_multivol_bitfield(dev(o), dev(d), dev(near), dev(far), n_pts, 0.05, 0.03, 0.4, dev(inner), dev(outer), n_grid,
+                                               n_cascade, dev(bits[:-1]), 0.05, False, z, m)
+    multivol_rng(reset=True)

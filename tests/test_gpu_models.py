@@ -366,3 +366,127 @@ def test_ngp_bitfield_model_trains_and_prunes(gpu):
     assert fg.obj_bound.ema_step == 11
     sd = m.state_dict()
     assert any(k.endswith('obj_bound.density_bitfield') for k in sd) and any(k.endswith('obj_bound.density_grid') for k in sd)
+
+
+@pytest.mark.parametrize('tag', ['incl_', 'excl_'])
+def test_multivol_matches_reference_model_on_oracle_samples(gpu, tag):
+    """G16: the reference's MultiVol (configs/models/multivol.yaml, small grids, torch-Linear nets) run on CPU with its CUDA-only
+    sampler call replaced by the oracle of that kernel.  Here: the HIP sampler reproduces the stored zvals / masks bit for bit,
+    and the mirror model with the reference state_dict (strict) reproduces outputs within 2e-4 and gradients within 1e-3 of max,
+    for both `inclusive` settings (rays without samples included)."""
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.ops.multivol_func import multivol_rng
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    g = load_golden('g16_multivol_model')
+    ov = [str(v) for v in g['overrides']] + ['--model.basic_volume.inclusive', str(tag == 'incl_')]
+    m = build_model(load_configs(os.path.join(CFG, 'multivol.yaml'), ov)).to(gpu)
+    mv = m.fg_model
+    assert type(mv).__name__ == 'MultiVol' and mv.inclusive == (tag == 'incl_')
+    m.load_state_dict({k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + 'sd.')})
+    inputs = {k[3:]: torch.from_numpy(g[k]).to(gpu) for k in g.files if k.startswith('in_')}
+    multivol_rng(reset=True)
+    # the sampler alone, on the two launches the golden run made (inference, then train)
+    o, d = inputs['rays_o'][0], inputs['rays_d'][0]
+    for call in range(2):
+        near, far = mv.get_near_far_from_rays(o, d)
+        close(near.cpu().numpy(), g[tag + 'call{}_near'.format(call)], rtol=0, atol=1e-6)
+        z, msk = mv.get_zvals_from_near_far(torch.from_numpy(g[tag + 'call{}_near'.format(call)]).to(gpu),
+                                            torch.from_numpy(g[tag + 'call{}_far'.format(call)]).to(gpu), mv.get_ray_cfgs('n_sample'), o, d)
+        assert np.array_equal(msk.cpu().numpy(), g[tag + 'call{}_mask'.format(call)])
+        assert np.array_equal(z.cpu().numpy().view(np.uint32), g[tag + 'call{}_zvals'.format(call)].view(np.uint32))
+    assert (g[tag + 'call0_mask'].sum(1) == 0).any()
+    multivol_rng(reset=True)
+    with torch.no_grad():
+        out = m({k: v.clone() for k, v in inputs.items()}, inference_only=True)
+    assert set(out.keys()) == {'rgb', 'depth', 'mask'}
+    for k in out:
+        close(out[k].cpu().numpy(), g[tag + 'infer_' + k], rtol=2e-4, atol=2e-4)
+    out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False)
+    for k in out:
+        close(out[k].detach().cpu().numpy(), g[tag + 'train_' + k], rtol=2e-4, atol=2e-4)
+    rgb_key = [k for k in out if k.startswith('rgb')][0]
+    loss = ((out[rgb_key] - inputs['img']) ** 2).mean()
+    assert abs(float(loss) - float(g[tag + 'train_loss'])) < 1e-5
+    loss.backward()
+    checked = 0
+    for n, p in m.named_parameters():
+        if tag + 'grad.' + n in g.files:
+            ref = g[tag + 'grad.' + n]
+            assert np.abs(p.grad.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-7, n
+            checked += 1
+    assert checked >= 8
+    multivol_rng(reset=True)
+
+
+def test_nerf_with_multivol_background_trains_and_prunes(gpu):
+    """configs/nerf_multivol.yaml reduced: packed NGP foreground + MultiVol background (hash grid + fused MLPs over the cascade),
+    rgb blending; the loss drops, both occupancy structures refresh, and the cascade's refresh equals the oracle's replay."""
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.ops.multivol_func import multivol_rng
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    from oracle import oracle as orc
+    enc = ['hashmap_size', '14', 'n_levels', '8', 'max_res', '256']
+    ov = ['--model.obj_bound.volume.n_grid', '32', '--model.rays.n_sample', '128', '--model.background.rays.n_sample', '128',
+          '--model.background.basic_volume.n_grid', '16', '--model.background.basic_volume.n_cascade', '3',
+          '--model.background.basic_volume.side', '2.0', '--model.background.geometry.encoder.side', '8.0',
+          '--model.background.rays.cone_angle', '0.03125', '--model.rays.noise_std', '0.0', '--model.background.rays.noise_std', '0.0']
+    for pre in ('--model.geometry.encoder.', '--model.background.geometry.encoder.'):
+        for k, v in zip(enc[::2], enc[1::2]):
+            ov += [pre + k, v]
+    torch.manual_seed(7)
+    m = build_model(load_configs(os.path.join(CFG, 'nerf_multivol.yaml'), ov)).to(gpu)
+    bkg = m.bkg_model
+    assert type(bkg).__name__ == 'MultiVol' and not bkg.inclusive and bkg.total_n_elements == 2 * 16 ** 3
+    sampler_rng(reset=True)
+    multivol_rng(reset=True)
+    inputs = _rays(gpu, 1, 1024)
+    inputs['bkg_color'] = torch.zeros_like(inputs['bkg_color'])
+    tgt = (inputs['rays_d'] * 0.5 + 0.5).clamp(0, 1)   # a sky that depends on the viewing direction: the background has to learn it
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2, eps=1e-15)
+    losses = []
+    for it in range(1, 81):
+        out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=it)
+        loss = ((out['rgb_coarse'] - tgt) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        if it % 16 == 0:
+            m.optimize(cur_epoch=it)
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+    assert bkg.ema_step == 5 and int(bkg.density_bitfield.min()) < 255
+    trained = [p for p in bkg.parameters() if p.requires_grad]
+    assert len(trained) == 3   # hash table + two fused weight blocks (the volumes' origin / side are frozen parameters)
+    for p in trained:
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    # one more refresh, replayed through the oracle from the current grid (steady state: n/4 uniform + n/4 from occupied cells)
+    grid = bkg.density_grid.cpu().numpy().copy()
+    h, state = orc.Pcg32(9121), multivol_rng()
+    while (h.state, h.inc) != (state.state, state.inc):   # bring a host generator to the module's current position
+        h.advance()
+    seen = {}
+    orig = bkg.get_est_opacity
+
+    def spy(dt, pts):
+        seen['pts'] = pts.detach().cpu().numpy()
+        seen['opa'] = orig(dt, pts)
+        return seen['opa']
+
+    bkg.get_est_opacity = spy
+    m.optimize(cur_epoch=512)
+    bkg.get_est_opacity = orig
+    n_q = bkg.total_n_elements // 4
+    inner = bkg.basic_volume.get_range().permute(1, 0).contiguous().cpu().numpy()
+    pos_u, idx_u = orc.generate_grid_samples_multivol(grid, n_q, inner, 5, 3, 16, -0.01, False, h.state, h.inc)
+    h.advance()
+    pos_n, idx_n = orc.generate_grid_samples_multivol(grid, n_q, inner, 5, 3, 16, 0.01, False, h.state, h.inc)
+    assert np.array_equal(seen['pts'].view(np.uint32), np.concatenate([pos_u, pos_n]).view(np.uint32))
+    tmp = np.zeros_like(grid)
+    orc.splat_grid_samples(seen['opa'].cpu().numpy(), np.concatenate([idx_u, idx_n]), tmp)
+    orc.ema_grid_samples_nerf(tmp, grid, 0.95)
+    assert np.array_equal(bkg.density_grid.cpu().numpy().view(np.uint32), grid.view(np.uint32))
+    mean = float(bkg.get_density_grid_mean().cpu().numpy()[0])
+    assert np.array_equal(bkg.density_bitfield.cpu().numpy(), orc.update_bitfield_multivol(grid, mean, 0.01, 16, 3, False))
+    sampler_rng(reset=True)
+    multivol_rng(reset=True)

@@ -141,3 +141,112 @@ def test_k7_k8_k9_k10_rules(oracle):
     bf[[1, 5, 9]] = [1, 255, 16]
     assert oracle.count_bitfield(bf, n_grid) == 24.0
     assert oracle.count_bitfield(np.zeros(n // 8, np.uint8), n_grid) == 0.0
+
+
+# ---- `_multivol_func` (K11, K12, cascaded K9): CUDA only in the reference, parity unpinned ----------------------------
+def _level_of(pts, half):
+    """volume_func.h:201-226 restated with numpy: exponent of the largest |coordinate| / half side (frexp), floored at 0"""
+    a = np.abs(pts.astype(np.float32)) * np.float32(1.0 / half)
+    return np.maximum(np.frexp(a)[1].max(-1), 0)
+
+
+def test_k11_degenerates_to_k5(oracle):
+    """one inclusive level, zero cone angle, min_step = max_step: the cascade marcher is the single-volume marcher"""
+    rng = np.random.default_rng(6)
+    n_grid, n_pts, R = 16, 128, 300
+    bits = to_morton_bits(rng.random((n_grid,) * 3) < 0.2, oracle)
+    o, d = _rays(rng, R)
+    aabb23 = np.array([[-1, -1, -1], [1, 1, 1]], np.float32)
+    near, far, _, _ = oracle.aabb_intersection(o, d, aabb23[None])
+    dt = np.float32(2 * np.sqrt(3.0) / n_pts)
+    h = oracle.Pcg32(9121)
+    z5, m5, c5 = oracle.sparse_volume_sampling_bit(o, d, near, far, n_pts, dt, aabb23, n_grid, bits, 0.1, h.state, h.inc)
+    z11, m11, c11 = oracle.sparse_sampling_in_multivol_bitfield(o, d, near, far, n_pts, 0.0, dt, dt, aabb23, aabb23, n_grid, 1, bits,
+                                                               0.1, True, h.state, h.inc)
+    assert c5.sum() > 1000 and np.array_equal(c5, c11) and np.array_equal(m5, m11)
+    assert np.array_equal(z5.view(np.uint32), z11.view(np.uint32))
+
+
+@pytest.mark.parametrize('inclusive', [True, False])
+def test_k11_invariants(oracle, inclusive):
+    rng = np.random.default_rng(8)
+    n_grid, n_cascade, n_pts, R = 16, 4, 192, 400
+    levels = n_cascade if inclusive else n_cascade - 1
+    cells = rng.random(levels * n_grid ** 3) < 0.3
+    bits = np.packbits(cells, bitorder='little')
+    o = ((rng.random((R, 3)) - 0.5) * 3.0).astype(np.float32)
+    o[: R // 2] *= 0.2   # half of the cameras inside the inner volume
+    d = rng.normal(size=(R, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    inner = np.array([[-0.5, -0.5, -0.5], [0.5, 0.5, 0.5]], np.float32)
+    outer = inner * 2 ** (n_cascade - 1)
+    near, far, _, hit = oracle.aabb_intersection_torch(o, d, np.stack([outer[0], outer[1]], -1)[None])
+    cone, min_step, max_step = 1.0 / 16, np.float32(np.sqrt(3.0) / n_pts), np.float32(np.sqrt(3.0) * 8 / n_grid)
+    h = oracle.Pcg32(9121)
+    z, m, c = oracle.sparse_sampling_in_multivol_bitfield(o, d, near, far, n_pts, cone, min_step, max_step, inner, outer, n_grid,
+                                                          n_cascade, bits, 0.05, inclusive, h.state, h.inc)
+    assert (m.sum(1) == c).all() and c.sum() > 2000
+    perm_cache = {}
+    for r in range(R):
+        k = c[r]
+        assert m[r, :k].all() and not m[r, k:].any()
+        if k == 0:
+            assert (z[r] == 0).all()
+            continue
+        zz = z[r, :k]
+        assert (z[r, k:] == zz[-1]).all() and (np.diff(zz) > 0).all()
+        assert zz[0] >= max(near[r, 0], 0.05) and zz[-1] <= far[r, 0]
+        # consecutive samples are at least one cone step apart: dt = clamp(t * cone, min_step, max_step)
+        dts = np.clip(zz[:-1] * np.float32(cone), min_step, max_step)
+        assert (np.diff(zz) >= dts * (1 - 1e-6)).all()
+        pts = o[r] + d[r] * zz[:, None]
+        lvl = np.minimum(_level_of(pts, 0.5), n_cascade - 1)
+        if not inclusive:
+            assert (lvl >= 1).all()   # nothing is sampled inside the excluded inner volume ...
+            # ... and nothing is kept from before the ray's last visit to it
+            t_all = np.arange(0, far[r, 0], float(min_step) / 2, dtype=np.float32)
+            inside = (np.abs(o[r] + d[r] * t_all[:, None]).max(-1) < 0.5) & (t_all > max(near[r, 0], 0.05) + max_step)
+            if inside.any():
+                assert zz[0] > t_all[inside].max() - max_step
+        # every sample sits in an occupied cell of its level's grid
+        q = pts / (2.0 ** lvl)[:, None]
+        ijk = np.clip(((q + 0.5) * n_grid).astype(np.int64), 0, n_grid - 1).astype(np.uint32)
+        mort = oracle.morton3d(ijk)
+        slot = lvl if inclusive else lvl - 1
+        assert cells[slot * n_grid ** 3 + mort].all()
+
+
+@pytest.mark.parametrize('inclusive', [True, False])
+def test_k12_and_cascaded_k9(oracle, inclusive):
+    n_grid, n_cascade, n = 8, 4, 5000
+    levels = n_cascade if inclusive else n_cascade - 1
+    rng = np.random.default_rng(9)
+    grid = (rng.random(levels * n_grid ** 3).astype(np.float32) - 0.5)
+    inner = np.array([[-0.5, -1.0, 0.0], [0.5, 1.0, 3.0]], np.float32)   # anisotropic, off-centre box
+    h = oracle.Pcg32(9121)
+    pos, idx = oracle.generate_grid_samples_multivol(grid, n, inner, 3, n_cascade, n_grid, 0.2, inclusive, h.state, h.inc)
+    slot = idx // n_grid ** 3
+    assert slot.min() >= 0 and slot.max() == levels - 1 and len(np.unique(slot)) == levels
+    level = slot if inclusive else slot + 1
+    # the point lies in its Morton cell of the level's volume (inner box scaled 2^level about its centre)
+    center, length = (inner[0] + inner[1]) / 2, inner[1] - inner[0]
+    u = (pos - center) / (length * (2.0 ** level)[:, None]) + 0.5
+    cell = oracle.morton3d_invert((idx % n_grid ** 3).astype(np.uint32))
+    f = u * n_grid - cell
+    assert (f > -1e-4).all() and (f < 1 + 1e-4).all()
+    # level draw of sample i = first draws of stream position 4i (redrawn while 0 when the inner volume is excluded)
+    for i in (0, 5, 77):
+        h2 = oracle.Pcg32(9121)
+        h2.advance(4 * i)
+        lv = 0
+        while True:
+            lv = int(np.float32(h2.next_float(1)[0]) * np.float32(n_cascade)) % n_cascade
+            if inclusive or lv != 0:
+                break
+        assert lv == level[i]
+    p = (grid > 0.2).mean()
+    assert abs((grid[idx] > 0.2).mean() - (1 - (1 - p) ** 10)) < 0.03
+    mean = float(np.clip(grid, 0, None).mean())
+    bf = oracle.update_bitfield_multivol(grid, mean, 0.01, n_grid, n_cascade, inclusive)
+    assert bf.shape[0] == levels * n_grid ** 3 // 8
+    assert np.array_equal(np.unpackbits(bf, bitorder='little').astype(bool), grid > min(0.01, mean))
