@@ -1,12 +1,14 @@
-"""get_activation (arcnerf/models/base_modules/activation.py:24-50): config `type` -> activation module."""
+"""get_activation (arcnerf/models/base_modules/activation.py:24-50): config `type` -> activation module, table driven."""
 import torch
 import torch.nn as nn
 
 from ...ops.trunc_exp import TruncExp
-from ...utils.cfgs_utils import dict_to_obj, get_value_from_cfgs_field
+from ...utils.cfgs_utils import get_value_from_cfgs_field as _opt
 
 
 class Sine(nn.Module):
+    """sin(w0 x), the SIREN activation"""
+
     def __init__(self, w0=30.0):
         super().__init__()
         self.w0 = w0
@@ -15,22 +17,24 @@ class Sine(nn.Module):
         return torch.sin(self.w0 * x)
 
 
+# type (lower case) -> constructor taking the config node; defaults are the reference's
+_ACTIVATIONS = {
+    'relu': lambda c: nn.ReLU(inplace=True),
+    'leakyrelu': lambda c: nn.LeakyReLU(negative_slope=_opt(c, 'slope', 0.01), inplace=True),
+    'softplus': lambda c: nn.Softplus(beta=_opt(c, 'beta', 100)),
+    'sigmoid': lambda c: nn.Sigmoid(),
+    'sine': lambda c: Sine(w0=_opt(c, 'w', 30)),
+    'truncexp': lambda c: TruncExp(_opt(c, 'clip', 15.0)),
+    'identity': lambda c: nn.Identity(),
+}
+
+
 def get_activation(cfg, default=None):
+    """cfg.type selects the module; cfg None -> `default` (ReLU when that is None too)"""
+    cfg = cfg if cfg is not None else default
     if cfg is None:
-        cfg = default if default is not None else dict_to_obj({'type': 'relu'})
-    kind = cfg.type.lower()
-    if kind == 'relu':
-        return nn.ReLU(inplace=True)
-    if kind == 'softplus':
-        return nn.Softplus(beta=get_value_from_cfgs_field(cfg, 'beta', 100))
-    if kind == 'leakyrelu':
-        return nn.LeakyReLU(negative_slope=get_value_from_cfgs_field(cfg, 'slope', 0.01), inplace=True)
-    if kind == 'sine':
-        return Sine(w0=get_value_from_cfgs_field(cfg, 'w', 30))
-    if kind == 'sigmoid':
-        return nn.Sigmoid()
-    if kind == 'truncexp':
-        return TruncExp(get_value_from_cfgs_field(cfg, 'clip', 15.0))
-    if kind == 'identity':
-        return nn.Identity()
-    raise NotImplementedError('No activation class {}'.format(cfg.type))
+        return _ACTIVATIONS['relu'](None)
+    make = _ACTIVATIONS.get(cfg.type.lower())
+    if make is None:
+        raise NotImplementedError('No activation class {}'.format(cfg.type))
+    return make(cfg)

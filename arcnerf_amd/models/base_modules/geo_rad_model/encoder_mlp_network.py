@@ -32,36 +32,31 @@ class EncoderMLPGeoNet(BaseGeoNet):
 
 
 class EncoderMLPRadainceNet(BaseRadianceNet):
+    """`mode` is a string over {p: encoded position, v: encoded unit view direction, n: normal, f: geometry feature}; the net's
+    input is those blocks concatenated in the order the characters appear (encoder_mlp_network.py:62-118).  (The class name keeps
+    the reference's spelling: it is part of the interface.)"""
+
     def __init__(self, mode='vf'):
         super().__init__()
-        assert len(mode) > 0 and all(m in 'pvnf' for m in mode), 'Invalid mode only pvnf allowed...'
+        assert len(mode) > 0 and set(mode) <= set('pvnf'), 'Invalid mode only pvnf allowed...'
         self.mode = mode
         self.init_input_dim = 0
         self.embed_fn_pts = self.embed_fn_view = None
 
     def build_encoder(self, encoder, W_feat_in):
+        """encoders for the p / v blocks and the total input width"""
+        width = {'n': 3, 'f': max(int(W_feat_in), 0)}
         if 'p' in self.mode:
-            self.embed_fn_pts, _, _ = build_encoder(encoder.pts if encoder is not None else None)
-            self.init_input_dim += self.embed_fn_pts.get_output_dim()
+            self.embed_fn_pts = build_encoder(getattr(encoder, 'pts', None) if encoder is not None else None)[0]
+            width['p'] = self.embed_fn_pts.get_output_dim()
         if 'v' in self.mode:
-            self.embed_fn_view, _, _ = build_encoder(encoder.view if encoder is not None else None)
-            self.init_input_dim += self.embed_fn_view.get_output_dim()
-        if 'n' in self.mode:
-            self.init_input_dim += 3
-        if 'f' in self.mode and W_feat_in > 0:
-            self.init_input_dim += W_feat_in
+            self.embed_fn_view = build_encoder(getattr(encoder, 'view', None) if encoder is not None else None)[0]
+            width['v'] = self.embed_fn_view.get_output_dim()
+        self.init_input_dim = sum(width[m] for m in self.mode)
 
     def fuse_radiance_inputs(self, x, view_dirs, normals, geo_feat):
-        """inputs concatenated in the order of the characters of `mode` (encoder_mlp_network.py:93-118)"""
-        parts = {}
-        if 'p' in self.mode:
-            parts['p'] = self.embed_fn_pts(x)
-        if 'v' in self.mode:
-            parts['v'] = self.embed_fn_view(normalize(view_dirs))
-        if 'n' in self.mode:
-            parts['n'] = normals
-        if 'f' in self.mode:
-            parts['f'] = geo_feat
-        out = torch.cat([parts[m] for m in self.mode], dim=-1)
-        assert out.shape[-1] == self.init_input_dim, 'Shape not match'
-        return out
+        block = {'p': lambda: self.embed_fn_pts(x), 'v': lambda: self.embed_fn_view(normalize(view_dirs)),
+                 'n': lambda: normals, 'f': lambda: geo_feat}
+        fused = torch.cat([block[m]() for m in self.mode], dim=-1)
+        assert fused.shape[-1] == self.init_input_dim, 'Shape not match'
+        return fused

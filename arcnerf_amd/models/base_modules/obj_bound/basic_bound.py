@@ -3,12 +3,15 @@ import torch
 import torch.nn as nn
 
 from ....render.ray_helper import get_near_far_from_rays, get_zvals_from_near_far
-from ....utils.cfgs_utils import get_value_from_cfgs_field
+from ....utils.optim_cfgs import OptimCfgAccess, read_prune_settings
 from ....utils.registry import BOUND_REGISTRY
+
+# defaults of the refresh settings under model.obj_bound (no `epoch_optim` = the structure is never pruned)
+BOUND_OPTIM_DEFAULTS = {'epoch_optim': None, 'epoch_optim_warmup': None, 'ema_optim_decay': 0.95, 'opa_thres': 0.01}
 
 
 @BOUND_REGISTRY.register()
-class BasicBound(nn.Module):
+class BasicBound(nn.Module, OptimCfgAccess):
     def __init__(self, cfgs):
         super().__init__()
         self.cfgs = cfgs
@@ -17,19 +20,8 @@ class BasicBound(nn.Module):
     def get_obj_bound(self):
         return None
 
-    def get_optim_cfgs(self, key=None):
-        return self.optim_cfgs if key is None else self.optim_cfgs[key]
-
-    def set_optim_cfgs(self, key, value):
-        self.optim_cfgs[key] = value
-
     def read_optim_cfgs(self):
-        return {
-            'epoch_optim': get_value_from_cfgs_field(self.cfgs, 'epoch_optim', None),
-            'epoch_optim_warmup': get_value_from_cfgs_field(self.cfgs, 'epoch_optim_warmup', None),
-            'ema_optim_decay': get_value_from_cfgs_field(self.cfgs, 'ema_optim_decay', 0.95),
-            'opa_thres': get_value_from_cfgs_field(self.cfgs, 'opa_thres', 0.01),
-        }
+        return read_prune_settings(self.cfgs, BOUND_OPTIM_DEFAULTS)
 
     def get_near_far_from_rays(self, inputs, near_hardcode=None, far_hardcode=None, bounding_radius=None):
         """-> near, far (B,1), mask_rays None"""

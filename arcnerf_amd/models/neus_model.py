@@ -73,45 +73,47 @@ class Neus(SdfModel):
             output['normal_pts'] = normal_pts
         return self.output_get_progress(output, get_progress)
 
+    def _crossing_weights(self, zvals, sdf, dist_to_origin, sharpness):
+        """compositing weights of the sections under a fixed sigmoid sharpness: large where the sdf crosses zero.  The section
+        slope is the finite difference, replaced by the previous section's when that is steeper-downwards-limited (the min of
+        the two, in [-10, 0]) and zeroed for sections entirely outside the radius bound (neus_model.py:126-160)"""
+        step = zvals[:, 1:] - zvals[:, :-1]
+        slope = (sdf[:, 1:] - sdf[:, :-1]) / (step + 1e-5)
+        slope = torch.minimum(F.pad(slope[:, :-1], (1, 0)), slope).clamp(-10.0, 0.0)
+        touches_bound = torch.minimum(dist_to_origin[:, :-1], dist_to_origin[:, 1:]) < self.radius_bound
+        alpha = sdf_to_alpha((sdf[:, :-1] + sdf[:, 1:]) * 0.5, zvals, slope * touches_bound, sharpness, clip=False)
+        return alpha_to_weights(alpha)[1]
+
     def upsample_zvals(self, rays_o, rays_d, zvals, mask_pts=None, inference_only=False, s=32):
-        """n_iter rounds of importance sampling around the sdf zero crossing (neus_model.py:106-172)"""
-        if self.get_ray_cfgs('n_importance') <= 0:
+        """n_iter rounds of importance sampling around the sdf zero crossing, the sharpness doubling every round
+        (neus_model.py:106-172)"""
+        n_new, rounds = self.get_ray_cfgs('n_importance'), self.get_ray_cfgs('n_iter')
+        if n_new <= 0:
             return zvals, mask_pts
-        n_per_iter = self.get_ray_cfgs('n_importance') // self.get_ray_cfgs('n_iter')
-        for i in range(self.get_ray_cfgs('n_iter')):
-            n_rays, n_pts = zvals.shape[:2]
-            pts = get_ray_points_by_zvals(rays_o, rays_d, zvals).view(-1, 3)
-            sdf = self.forward_pts(pts).view(n_rays, n_pts)
-            prev_sdf, next_sdf = sdf[:, :-1], sdf[:, 1:]
-            mid_sdf = (prev_sdf + next_sdf) * 0.5
-            slope = (next_sdf - prev_sdf) / (zvals[:, 1:] - zvals[:, :-1] + 1e-5)
-            prev_slope = torch.cat([torch.zeros_like(slope[:, :1]), slope[:, :-1]], dim=-1)
-            slope = torch.minimum(prev_slope, slope).clamp(-10.0, 0.0)
-            radius = torch.norm(pts.view(n_rays, n_pts, 3), dim=-1)
-            inside_sphere = (radius[:, :-1] < self.radius_bound) | (radius[:, 1:] < self.radius_bound)
-            slope = slope * inside_sphere
-            alpha = sdf_to_alpha(mid_sdf, zvals, slope, s * (2 ** (i + 1)), clip=False)
-            _, weights = alpha_to_weights(alpha)
-            det = True if inference_only else (not self.get_ray_cfgs('perturb'))
-            new = sample_pdf(zvals.contiguous(), weights.detach().contiguous(), n_per_iter, det).detach()
-            zvals, _ = torch.sort(torch.cat([zvals, new], dim=-1), dim=-1)
-            mask_pts = self.merge_full_mask(mask_pts, new)
+        deterministic = inference_only or not self.get_ray_cfgs('perturb')
+        for rnd in range(rounds):
+            pts = get_ray_points_by_zvals(rays_o, rays_d, zvals)
+            sdf = self.forward_pts(pts.view(-1, 3)).view(zvals.shape)
+            weights = self._crossing_weights(zvals, sdf, torch.norm(pts, dim=-1), s * 2 ** (rnd + 1))
+            fresh = sample_pdf(zvals.contiguous(), weights.detach().contiguous(), n_new // rounds, deterministic).detach()
+            zvals = torch.sort(torch.cat([zvals, fresh], dim=-1), dim=-1)[0]
+            mask_pts = self.merge_full_mask(mask_pts, fresh)
         return zvals, mask_pts
 
     def handle_mid_pts(self, zvals, mask_pts):
-        """section mid points + one extra section at the far end (neus_model.py:174-202)"""
-        sample_dist = (zvals[:, -1] - zvals[:, 0]) / self.get_ray_cfgs('n_sample') * 0.5
+        """-> section mid points (B, P), section ends (B, P+1), mask of the mid points: the P samples bound P-1 sections and one
+        more is appended behind the last sample (half a coarse step long, a full one in the masked layout) so that every sample
+        owns a section (neus_model.py:174-202)"""
+        half_step = (zvals[:, -1] - zvals[:, 0]) / self.get_ray_cfgs('n_sample') * 0.5
         if mask_pts is None:
-            mid = 0.5 * (zvals[..., 1:] + zvals[..., :-1])
-            mid = torch.cat([mid, (mid[:, -1] + sample_dist).unsqueeze(-1)], dim=-1)
-            return mid, torch.cat([zvals, (zvals[:, -1] + sample_dist).unsqueeze(-1)], dim=-1), None
-        zeros_mask = torch.zeros((mask_pts.shape[0], 1), dtype=torch.bool, device=zvals.device)
-        ones_mask = torch.ones((mask_pts.shape[0], 1), dtype=torch.bool, device=zvals.device)
-        final_zvals = zvals[:, -1] + sample_dist * 2.0
-        _zvals = torch.ones((zvals.shape[0], zvals.shape[1] + 1), dtype=zvals.dtype, device=zvals.device) * final_zvals.unsqueeze(1)
-        _zvals[torch.cat([mask_pts, zeros_mask], dim=1)] = zvals[mask_pts]
-        mid = 0.5 * (_zvals[..., 1:] + _zvals[..., :-1])
-        return mid, _zvals, torch.cat([ones_mask, mask_pts[:, :-1]], dim=1)
+            inner = 0.5 * (zvals[..., 1:] + zvals[..., :-1])
+            mid = torch.cat([inner, (inner[:, -1] + half_step)[:, None]], dim=-1)
+            return mid, torch.cat([zvals, (zvals[:, -1] + half_step)[:, None]], dim=-1), None
+        n_rays, n_pts = zvals.shape
+        col = torch.zeros((n_rays, 1), dtype=torch.bool, device=zvals.device)
+        ends = ((zvals[:, -1] + half_step * 2.0)[:, None]).repeat(1, n_pts + 1)   # padded slots and the extra end: beyond the ray
+        ends[torch.cat([mask_pts, col], dim=1)] = zvals[mask_pts]
+        return 0.5 * (ends[..., 1:] + ends[..., :-1]), ends, torch.cat([~col, mask_pts[:, :-1]], dim=1)
 
     def get_est_opacity(self, dt, pts):
         """opacity of a voxel-sized step towards the origin (neus_model.py:204-218)"""
