@@ -1,0 +1,1 @@
+"""Ray / sphere / volume geometry of the hot path, kernel-backed."""

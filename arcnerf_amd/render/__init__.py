@@ -1,0 +1,1 @@
+"""Sampling along rays and alpha compositing (render/ray_helper mirror)."""

@@ -1,0 +1,1 @@
+"""Config, registry and tensor helpers the host-side mirror needs."""
