@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from arcnerf_amd import _native as N
-from arcnerf_amd.ops.autograd import FusedMlpFn, HashGridFn
+from arcnerf_amd.ops.autograd import FusedMlpFn, hashgrid_encode
 from arcnerf_amd.ops import functional as F
 from arcnerf_amd.pipeline import hashgrid_level_table
 
@@ -47,7 +47,7 @@ class Encoding(nn.Module):
 
     def forward(self, x):
         if self.otype == 'HashGrid':
-            return HashGridFn.apply(x, self.params.view(-1, self.desc.n_feat), self.desc, True)
+            return hashgrid_encode(x, self.params.view(-1, self.desc.n_feat), self.desc, True)
         # tcnn maps [0,1] -> [-1,1] internally; the reference's torch branch evaluates the polynomials on the [0,1] value
         # (sh_encoder.py:116,140-185).  The parity target is the torch branch: undo the caller's (d+1)/2 and re-apply it
         # inside the kernel, i.e. evaluate on exactly the value the torch branch sees.

@@ -191,6 +191,72 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(const float *__restri
     }
 }
 
+// ---- second order: the input gradient dx = J(x; table)^T dout differentiated once more ---------------------------------
+// NeuS on a hash grid takes normals = d sdf / d x with create_graph=True and puts a loss on them (BaseGeoNet.forward_with_grad,
+// base_network.py; the reference's torch backend differentiates hashgrid_encode_torch twice by autograd).  With the upstream
+// gradient gdx (n,3) on dx and D_q = sum_k gdx_k dW_q/dp_k:
+//   ddout[s,l,f]    = sum_q T[r_q,f] D_q                      gather with weights D
+//   dtable[r_q,f]  += dout_f D_q                              scatter with weights D
+//   d2xyz[s,j]     += sum_q <dout, T[r_q]> dD_q/dp_j          cross terms only (every a_k is piecewise linear in p_k)
+// One lane per (sample, level); any output may be null.  d2xyz accumulates over the levels with atomics (caller zeroes it).
+template <int F>
+__global__ void __launch_bounds__(256)
+hashgrid_bwd_bwd_kernel(const float *__restrict__ xyz, const float *__restrict__ gdx, const float *__restrict__ table,
+                        const float *__restrict__ dout, GridParams g, float *__restrict__ ddout, float *__restrict__ dtable,
+                        float *__restrict__ d2xyz, int64_t n, const int32_t *n_ptr) {
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= cnt * g.L) return;
+    const int64_t s = gid / g.L;
+    const int l = (int)(gid - s * g.L);
+    const LevelParams lp = g.lv[l];
+    const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
+    const Cell cell = locate(p, g, lp);
+    float acc[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.f;
+    if (cell.valid) {
+        const float gd[3] = {gdx[3 * s], gdx[3 * s + 1], gdx[3 * s + 2]};
+        float go[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) go[f] = dout[gid * F + f];
+        float hx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t o[3] = {(uint32_t)((q >> 1) & 1), (uint32_t)(q & 1), (uint32_t)(q >> 2)};
+            const int64_t row = (int64_t)hash_row(cell.c[0] + o[0], cell.c[1] + o[1], cell.c[2] + o[2], lp) + lp.offset;
+            float a[3], sd[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                a[k] = o[k] ? cell.w[k] : 1.0f - cell.w[k];
+                sd[k] = o[k] ? cell.dw[k] : -cell.dw[k];
+            }
+            float D = gd[0] * sd[0] * a[1] * a[2];
+            D = D + gd[1] * a[0] * sd[1] * a[2];
+            D = D + gd[2] * a[0] * a[1] * sd[2];
+            float dot = 0.f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const float t = table[row * F + f];
+                acc[f] = acc[f] + t * D;
+                dot += go[f] * t;
+                if (dtable) unsafeAtomicAdd(&dtable[row * F + f], go[f] * D);
+            }
+            hx[0] += dot * sd[0] * (gd[1] * sd[1] * a[2] + gd[2] * a[1] * sd[2]);
+            hx[1] += dot * sd[1] * (gd[0] * sd[0] * a[2] + gd[2] * a[0] * sd[2]);
+            hx[2] += dot * sd[2] * (gd[0] * sd[0] * a[1] + gd[1] * a[0] * sd[1]);
+        }
+        if (d2xyz) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) unsafeAtomicAdd(&d2xyz[3 * s + k], hx[k]);
+        }
+    }
+    if (ddout) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) ddout[gid * F + f] = acc[f];
+    }
+}
+
 // ---- forward, XCD-affine ---------------------------------------------------------------------------------------------------
 // MI355X: 8 XCDs, each with a private 4 MiB L2; one fine level of the table is exactly 4 MiB.  The kernel above lets every
 // XCD touch all 16 levels (48.8 MB), so fine-level gathers miss L2 and are served by the Infinity Cache.  Here a workgroup
@@ -807,6 +873,23 @@ ARCN_EXPORT int arcn_hashgrid_bwd(const float *xyz, const float *table, const fl
                                   float *dtable, float *dxyz, float *workspace, int64_t workspace_floats, int64_t n,
                                   const int32_t *n_ptr, void *stream) {
     return hashgrid_bwd_impl(xyz, table, dout, 0, desc_host, dtable, dxyz, workspace, workspace_floats, n, n_ptr, stream);
+}
+
+ARCN_EXPORT int arcn_hashgrid_bwd_bwd(const float *xyz, const float *gdx, const float *table, const float *dout,
+                                      const arcn_hashgrid_desc *desc_host, float *ddout, float *dtable, float *d2xyz, int64_t n,
+                                      const int32_t *n_ptr, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!xyz || !gdx || !table || !dout || (!ddout && !dtable && !d2xyz)) return einval("hashgrid_bwd_bwd: missing argument");
+    GridParams g;
+    int rc = build_params(desc_host, g);
+    if (rc) return rc;
+    dim3 grid((unsigned)ceil_div<int64_t>(n * g.L, 256));
+    switch (g.F) {
+    case 1: hipLaunchKernelGGL(hashgrid_bwd_bwd_kernel<1>, grid, dim3(256), 0, as_stream(stream), xyz, gdx, table, dout, g, ddout, dtable, d2xyz, n, n_ptr); break;
+    case 2: hipLaunchKernelGGL(hashgrid_bwd_bwd_kernel<2>, grid, dim3(256), 0, as_stream(stream), xyz, gdx, table, dout, g, ddout, dtable, d2xyz, n, n_ptr); break;
+    default: hipLaunchKernelGGL(hashgrid_bwd_bwd_kernel<4>, grid, dim3(256), 0, as_stream(stream), xyz, gdx, table, dout, g, ddout, dtable, d2xyz, n, n_ptr); break;
+    }
+    return check_launch("hashgrid_bwd_bwd");
 }
 
 ARCN_EXPORT int arcn_hashgrid_bwd_lm(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host,

@@ -6,7 +6,8 @@ import torch
 import torch.nn as nn
 
 from .... import _native as N
-from ....ops.autograd import HashGridFn
+from ....geometry.volume import Volume
+from ....ops.autograd import hashgrid_encode
 from ....pipeline import hashgrid_level_table
 from ....utils.registry import ENCODER_REGISTRY
 
@@ -33,6 +34,8 @@ class HashGridEmbedder(nn.Module):
         mx = torch.tensor([float(origin[k]) + lens[k] / 2.0 for k in range(3)])
         self.register_buffer('min_xyz', mn)
         self.register_buffer('max_xyz', mx)
+        # the reference's torch backend keeps its box as a Volume submodule (hashgrid_encoder.py:90): same keys in the state_dict
+        self.volume = Volume(n_grid=base_res, origin=origin, side=side, xyz_len=xyz_len)
         self.desc = N.make_hashgrid_desc(self.resolutions, self.offsets, n_feat_per_entry, mn.tolist(), mx.tolist())
         self.out_dim = n_levels * n_feat_per_entry + include_input * input_dim
         self._ws = None
@@ -48,5 +51,5 @@ class HashGridEmbedder(nn.Module):
 
     def forward(self, xyz):
         assert xyz.dim() == 2 and xyz.shape[-1] == 3, 'Must be (B, 3) tensor'
-        emb = HashGridFn.apply(xyz, self.embeddings, self.desc, True)
+        emb = hashgrid_encode(xyz, self.embeddings, self.desc, True)
         return torch.cat([xyz, emb], dim=-1) if self.include_input else emb

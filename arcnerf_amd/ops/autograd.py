@@ -9,7 +9,11 @@ from . import functional as F
 
 
 class HashGridFn(torch.autograd.Function):
-    """out (n, L*F) = hash-grid encode(xyz; table).  Gradients: table (scatter), xyz (optional, for normals)."""
+    """out (n, L*F) = hash-grid encode(xyz; table): the node that carries the TABLE gradient (binned scatter).
+
+    The xyz gradient lives on a second node (HashGridXyzFn, value 0) added by `hashgrid_encode` when xyz requires grad.  Two
+    nodes because autograd then prunes by itself: torch.autograd.grad(sdf, xyz) - the normals of an sdf model - never reaches
+    this node, so no table scatter runs for it, and a plain backward() of a density model never touches the xyz node."""
 
     @staticmethod
     def forward(ctx, xyz, table, desc, scatter_ws):
@@ -22,17 +26,61 @@ class HashGridFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         xyz, table = ctx.saved_tensors
-        need_table, need_xyz = ctx.needs_input_grad[1], ctx.needs_input_grad[0]
-        dout = dout.contiguous()
         dtable = dxyz = None
-        if need_table and not need_xyz:
-            dtable, _ = F.hashgrid_bwd(xyz, table, dout, ctx.desc, workspace=ctx.ws)
+        if ctx.needs_input_grad[1]:
+            if ctx.needs_input_grad[0]:   # direct use with a differentiable xyz (first order only): both in one kernel
+                dtable, dxyz = F.hashgrid_bwd(xyz, table, dout.contiguous(), ctx.desc, want_dtable=True, want_dxyz=True)
+            else:
+                dtable, _ = F.hashgrid_bwd(xyz, table, dout.contiguous(), ctx.desc, workspace=ctx.ws)
             dtable = dtable.view_as(table)
-        elif need_table or need_xyz:
-            dtable, dxyz = F.hashgrid_bwd(xyz, table, dout, ctx.desc, want_dtable=need_table, want_dxyz=need_xyz)
-            if dtable is not None:
-                dtable = dtable.view_as(table)
+        elif ctx.needs_input_grad[0]:
+            _, dxyz = F.hashgrid_bwd(xyz, table, dout.contiguous(), ctx.desc, want_dtable=False, want_dxyz=True)
         return dxyz, dtable, None, None
+
+
+class HashGridDxFn(torch.autograd.Function):
+    """dxyz (n,3) = J(xyz; table)^T dout, itself differentiable in dout, table and xyz (arcn_hashgrid_bwd_bwd)."""
+
+    @staticmethod
+    def forward(ctx, xyz, table, dout, desc):
+        dout = dout.contiguous().float()
+        _, dxyz = F.hashgrid_bwd(xyz, table, dout, desc, want_dtable=False, want_dxyz=True)
+        ctx.save_for_backward(xyz, table, dout)
+        ctx.desc = desc
+        return dxyz
+
+    @staticmethod
+    def backward(ctx, gdx):
+        xyz, table, dout = ctx.saved_tensors
+        need_x, need_t, need_d = ctx.needs_input_grad[:3]
+        ddout, dtable, d2x = F.hashgrid_bwd_bwd(xyz, gdx.contiguous(), table, dout, ctx.desc, want_ddout=need_d, want_dtable=need_t,
+                                                want_d2xyz=need_x)
+        return d2x, (dtable.view_as(table) if dtable is not None else None), ddout, None
+
+
+class HashGridXyzFn(torch.autograd.Function):
+    """Value 0, gradient d encode / d xyz: the xyz-side node of the encoding (see HashGridFn).  Its backward is built from a
+    differentiable function, so create_graph=True gives a graph through which a loss on the input gradient reaches the table."""
+
+    @staticmethod
+    def forward(ctx, xyz, table, desc, n_out):
+        ctx.save_for_backward(xyz, table)
+        ctx.desc = desc
+        return xyz.new_zeros((xyz.shape[0], n_out))
+
+    @staticmethod
+    def backward(ctx, dout):
+        xyz, table = ctx.saved_tensors
+        return HashGridDxFn.apply(xyz, table, dout, ctx.desc), None, None, None
+
+
+def hashgrid_encode(xyz, table, desc, scatter_ws=True):
+    """(n, L*F) hash-grid features, differentiable in table and - to second order - in xyz"""
+    xyz = xyz.contiguous().float()
+    out = HashGridFn.apply(xyz.detach(), table, desc, scatter_ws)
+    if xyz.requires_grad and torch.is_grad_enabled():
+        out = out + HashGridXyzFn.apply(xyz, table, desc, out.shape[1])
+    return out
 
 
 class FreqFn(torch.autograd.Function):

@@ -374,6 +374,19 @@ def hashgrid_bwd(xyz, table, dout, desc, want_dtable=True, want_dxyz=False, n_de
     return dtable, dxyz
 
 
+def hashgrid_bwd_bwd(xyz, gdx, table, dout, desc, want_ddout=True, want_dtable=True, want_d2xyz=False):
+    """second-order pieces of the encoding's input gradient (see arcn_hashgrid_bwd_bwd) -> ddout, dtable, d2xyz (None if unwanted)"""
+    _req(xyz, gdx, table, dout)
+    xyz, gdx, table, dout = _f32(xyz), _f32(gdx), _f32(table), _f32(dout)
+    n = xyz.shape[0]
+    ddout = torch.empty_like(dout) if want_ddout else None
+    dtable = torch.zeros_like(table) if want_dtable else None
+    d2xyz = torch.zeros((n, 3), dtype=torch.float32, device=xyz.device) if want_d2xyz else None
+    N.check(N.lib().arcn_hashgrid_bwd_bwd(N.ptr(xyz), N.ptr(gdx), N.ptr(table), N.ptr(dout), C.addressof(desc), N.ptr(ddout),
+                                         N.ptr(dtable), N.ptr(d2xyz), n, None, N.stream()), 'hashgrid_bwd_bwd')
+    return ddout, dtable, d2xyz
+
+
 def freq_fwd(x, n_freqs, include_input=True):
     _req(x)
     x = _f32(x)

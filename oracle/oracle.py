@@ -371,6 +371,20 @@ def hashgrid_bwd(xyz, table, dout, resolutions, offsets, min_xyz, max_xyz, want_
     return (dtable, dxyz) if want_dxyz else dtable
 
 
+def hashgrid_bwd_bwd(xyz, gdx, table, dout, resolutions, offsets, min_xyz, max_xyz):
+    """second-order pieces of the encoding's input gradient -> ddout (S, L*F), dtable (n_total, F), d2xyz (S, 3)"""
+    xyz, gdx, table, dout = _f32(xyz), _f32(gdx), _f32(table), _f32(dout)
+    res = np.ascontiguousarray(resolutions, dtype=np.int32)
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    S, L, F = xyz.shape[0], len(res), table.shape[1]
+    ddout = np.zeros((S, L * F), np.float32)
+    dtable = np.zeros_like(table)
+    d2x = np.zeros((S, 3), np.float32)
+    lib().orc_hashgrid_bwd_bwd(_p(xyz), C.c_int64(S), _p(gdx), _p(table), _p(dout), C.c_int(L), C.c_int(F), _p(res), _p(off),
+                               _p(_f32(min_xyz)), _p(_f32(max_xyz)), _p(ddout), _p(dtable), _p(d2x))
+    return ddout, dtable, d2x
+
+
 def freq_fwd(x, n_freqs, include_input=True):
     x = _f32(x)
     S, D = x.shape

@@ -112,6 +112,58 @@ ORC_API void orc_hashgrid_bwd(const float *xyz, int64_t S, const float *table, c
 }
 
 /* ---------------------------------------------------------------------------------------
+ * Hash-grid backward differentiated once more (autograd of hashgrid_encode_torch, hashgrid_encoder.py:191-230, taken twice:
+ * BaseGeoNet.forward_with_grad builds normals with create_graph=True and the loss reaches them).
+ * With y_f = sum_q T[r_q,f] W_q and W_q = a_x a_y a_z (a_k = w_k or 1 - w_k), the first backward gives
+ *   dx_k = sum_q (sum_f dout_f T[r_q,f]) dW_q/dp_k.
+ * For an upstream gradient gdx (S,3) on dx, with D_q = sum_k gdx_k dW_q/dp_k:
+ *   ddout_f        = sum_q T[r_q,f] D_q                      (a gather with weights D)
+ *   dtable[r_q,f] += dout_f D_q                              (a scatter with weights D)
+ *   d2x_j          = sum_q (sum_f dout_f T[r_q,f]) dD_q/dp_j (cross terms only: each a_k is piecewise linear)
+ * Any output pointer may be NULL.  Serial, sample-major summation order.
+ * ------------------------------------------------------------------------------------- */
+ORC_API void orc_hashgrid_bwd_bwd(const float *xyz, int64_t S, const float *gdx, const float *table, const float *dout, int L,
+                                  int F, const int32_t *resolutions, const int64_t *offsets, const float *min_xyz,
+                                  const float *max_xyz, float *ddout, float *dtable, float *d2xyz) {
+    for (int64_t s = 0; s < S; ++s) {
+        const float *p = xyz + 3 * s, *gd = gdx + 3 * s;
+        float hx[3] = {0.f, 0.f, 0.f};
+        for (int l = 0; l < L; ++l) {
+            int64_t c[3];
+            float w[3], vs[3], dw[3];
+            float *dd = ddout ? ddout + s * (int64_t)(L * F) + l * F : NULL;
+            if (dd) for (int f = 0; f < F; ++f) dd[f] = 0.0f;
+            if (!level_setup(p, min_xyz, max_xyz, resolutions[l], c, w, vs, dw)) continue;
+            const float *g = dout + s * (int64_t)(L * F) + l * F;
+            int64_t size = offsets[l + 1] - offsets[l];
+            for (int q = 0; q < 8; ++q) {
+                int64_t h = fast_hash3(c[0] + PERM[q][0], c[1] + PERM[q][1], c[2] + PERM[q][2], size) + offsets[l];
+                float a[3], sd[3]; /* a_k and d a_k / d p_k */
+                for (int k = 0; k < 3; ++k) {
+                    a[k] = PERM[q][k] ? w[k] : 1.0f - w[k];
+                    sd[k] = (PERM[q][k] ? 1.0f : -1.0f) * dw[k];
+                }
+                float D = gd[0] * sd[0] * a[1] * a[2];
+                D = D + gd[1] * a[0] * sd[1] * a[2];
+                D = D + gd[2] * a[0] * a[1] * sd[2];
+                float dot = 0.f;
+                for (int f = 0; f < F; ++f) {
+                    if (dd) dd[f] = dd[f] + table[h * F + f] * D;
+                    if (dtable) dtable[h * F + f] += g[f] * D;
+                    dot += g[f] * table[h * F + f];
+                }
+                if (d2xyz) {
+                    hx[0] += dot * sd[0] * (gd[1] * sd[1] * a[2] + gd[2] * a[1] * sd[2]);
+                    hx[1] += dot * sd[1] * (gd[0] * sd[0] * a[2] + gd[2] * a[0] * sd[2]);
+                    hx[2] += dot * sd[2] * (gd[0] * sd[0] * a[1] + gd[1] * a[0] * sd[1]);
+                }
+            }
+        }
+        if (d2xyz) for (int k = 0; k < 3; ++k) d2xyz[3 * s + k] = hx[k];
+    }
+}
+
+/* ---------------------------------------------------------------------------------------
  * FreqEmbedder.forward (encoding/freq_encoder.py:65-88), log_sampling, (sin, cos).
  * out (S, D*(include_input + 2*n_freqs)); order: x, then per freq: sin(all dims), cos(all dims).
  * ------------------------------------------------------------------------------------- */

@@ -264,6 +264,40 @@ def g6_hashgrid():
 
 
 # ------------------------------------------------------------------------------------------------
+def g17_hashgrid_second_order():
+    """The input gradient of the encoding differentiated once more (what NeuS on a hash grid needs: normal = d sdf / d x taken
+    with create_graph=True, then a loss on the normal).  dx = d<y, gy>/dx ; L2 = <dx, gdx> ; vectors: dL2/d table, dL2/d gy,
+    dL2/d x, all from the reference's torch backend by autograd."""
+    g = torch.Generator().manual_seed(1717)
+    out = {}
+    for tag, kw, S in (('ngp', dict(n_levels=16, n_feat_per_entry=2, hashmap_size=19, base_res=16, max_res=2048), 160),
+                       ('tiny', dict(n_levels=4, n_feat_per_entry=2, hashmap_size=8, base_res=2, max_res=16), 256),
+                       ('f4', dict(n_levels=6, n_feat_per_entry=4, hashmap_size=10, base_res=4, max_res=64), 128)):
+        emb = HashGridEmbedder(side=2.0, dtype='torch.float32', include_input=False, backend=None, **kw)
+        table = make_table(emb.n_total_embed, emb.n_feat_per_entry, seed=17, scale=0.5)
+        emb.embeddings.data = torch.from_numpy(table.copy())
+        xyz = (torch.rand(S, 3, generator=g) - 0.5) * 2.2
+        xyz[:3] = torch.tensor([[-1.0, -1.0, -1.0], [0.0, 0.0, 0.0], [0.99999, -0.99999, 0.5]])
+        x = xyz.clone().requires_grad_(True)
+        gy = torch.randn(S, emb.get_output_dim(), generator=g).requires_grad_(True)
+        gdx = torch.randn(S, 3, generator=g)
+        y = emb(x)
+        dx, = torch.autograd.grad((y * gy).sum(), x, create_graph=True)
+        l2 = (dx * gdx).sum()
+        d_table, d_gy, d_x = torch.autograd.grad(l2, [emb.embeddings, gy, x], allow_unused=True)
+        rows = torch.nonzero(d_table.abs().sum(-1) > 0)[:, 0]
+        out.update({
+            tag + '_cfg': np.array([kw['n_levels'], kw['n_feat_per_entry'], kw['hashmap_size'], kw['base_res'], kw['max_res']]),
+            tag + '_xyz': npy(xyz), tag + '_gy': npy(gy), tag + '_gdx': npy(gdx), tag + '_dx': npy(dx),
+            tag + '_d_gy': npy(d_gy), tag + '_d_x': npy(d_x if d_x is not None else torch.zeros_like(xyz)),
+            tag + '_d_table_rows': npy(rows).astype(np.int32), tag + '_d_table_vals': npy(d_table[rows]),
+        })
+        print(tag, 'dx', float(dx.abs().max()), 'd_gy', float(d_gy.abs().max()), 'd_x', None if d_x is None else float(d_x.abs().max()),
+              'rows', len(rows))
+    save('g17_hashgrid_second_order', **out)
+
+
+# ------------------------------------------------------------------------------------------------
 def g7_freq_sh():
     g = torch.Generator().manual_seed(707)
     S = 128

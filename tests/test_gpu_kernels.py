@@ -754,3 +754,48 @@ def test_compositor_last_transmittance_is_differentiable(F):
         assert out['trans_shift'].requires_grad
         ((out['rgb'] * gc).sum() + (out['trans_shift'][:, -1] * gt).sum()).backward()
         close(host(leaf.grad), host(ref_leaf.grad), rtol=2e-4, atol=2e-5 * float(ref_leaf.grad.abs().max()))
+
+
+# ---- hash grid, second order (NeuS on a hash grid: a loss on d encode / d xyz) -------------------------------------------
+@pytest.mark.parametrize('tag', ['ngp', 'tiny', 'f4'])
+def test_hashgrid_second_order_vs_reference_golden_and_oracle(F, oracle, tag):
+    """G17 (reference torch backend under double autograd): the kernel behind arcn_hashgrid_bwd_bwd, and the autograd graph of
+    HashGridEmbedder (table node + xyz node) differentiated twice."""
+    from arcnerf_amd import _native as N
+    from arcnerf_amd.ops.autograd import hashgrid_encode
+    g = load_golden('g17_hashgrid_second_order')
+    L, Fe, T, base, mx_res = [int(v) for v in g[tag + '_cfg']]
+    res, offs = oracle.hashgrid_levels(L, T, base, mx_res)
+    table = make_table(int(offs[-1]), Fe, seed=17, scale=0.5)
+    desc = N.make_hashgrid_desc([int(r) for r in res], [int(o) for o in offs], Fe, [-1.0] * 3, [1.0] * 3)
+    xyz, gy, gdx = g[tag + '_xyz'], g[tag + '_gy'], g[tag + '_gdx']
+    ddout, dtable, d2x = F.hashgrid_bwd_bwd(dev(xyz), dev(gdx), dev(table), dev(gy), desc, want_d2xyz=True)
+    o_ddout, o_dtable, o_d2x = oracle.hashgrid_bwd_bwd(xyz, gdx, table, gy, res, offs, np.full(3, -1.0, np.float32), np.full(3, 1.0, np.float32))
+    for got, orc_v, key in ((ddout, o_ddout, '_d_gy'), (d2x, o_d2x, '_d_x')):
+        scale = np.abs(g[tag + key]).max()
+        close(host(got), orc_v, rtol=1e-4, atol=1e-5 * scale)
+        close(host(got), g[tag + key], rtol=1e-4, atol=2e-4 * scale)
+    rows = g[tag + '_d_table_rows']
+    scale = np.abs(g[tag + '_d_table_vals']).max()
+    close(host(dtable), o_dtable, rtol=1e-4, atol=1e-5 * scale)
+    close(host(dtable)[rows], g[tag + '_d_table_vals'], rtol=1e-4, atol=1e-4 * scale)
+    # the same numbers through autograd: dx with create_graph, then a second differentiation
+    x = dev(xyz).requires_grad_(True)
+    tab = dev(table).requires_grad_(True)
+    gy_t = dev(gy).requires_grad_(True)
+    y = hashgrid_encode(x, tab, desc)
+    dx, = torch.autograd.grad((y * gy_t).sum(), x, create_graph=True)
+    close(host(dx), g[tag + '_dx'], rtol=1e-4, atol=1e-4 * np.abs(g[tag + '_dx']).max())
+    a_tab, a_gy, a_x = torch.autograd.grad((dx * dev(gdx)).sum(), [tab, gy_t, x])
+    close(host(a_gy), g[tag + '_d_gy'], rtol=1e-4, atol=2e-4 * np.abs(g[tag + '_d_gy']).max())
+    close(host(a_x), g[tag + '_d_x'], rtol=1e-4, atol=2e-4 * np.abs(g[tag + '_d_x']).max())
+    close(host(a_tab)[rows], g[tag + '_d_table_vals'], rtol=1e-4, atol=1e-4 * scale)
+    # first order is unchanged by the node split: table gradient on one node, xyz gradient on the other
+    y2 = hashgrid_encode(x, tab, desc)
+    b_tab, b_x = torch.autograd.grad((y2 * dev(gy)).sum(), [tab, x])
+    ref_tab, ref_dx = oracle.hashgrid_bwd(xyz, table, gy, res, offs, np.full(3, -1.0, np.float32), np.full(3, 1.0, np.float32), want_dxyz=True)
+    close(host(b_x), ref_dx, rtol=1e-4, atol=1e-5 * np.abs(ref_dx).max())
+    close(host(b_tab), ref_tab, rtol=1e-4, atol=1e-5 * np.abs(ref_tab).max())
+    # a density model never builds the xyz node
+    y3 = hashgrid_encode(dev(xyz), tab, desc)
+    assert type(y3.grad_fn).__name__ == 'HashGridFnBackward'

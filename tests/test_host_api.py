@@ -69,7 +69,7 @@ def test_builders_and_output_dims():
     c = load_configs(os.path.join(CFG, 'nerf_ngp.yaml'))
     geo, rad = build_geo_model(c.model.geometry), build_radiance_model(c.model.radiance)
     assert geo.layers.dims == [32, 64, 16] and rad.layers.dims == [32, 64, 64, 3] and rad.init_input_dim == 32
-    assert [n for n, _ in geo.named_parameters()] == ['embed_fn.embeddings', 'layers.params']
+    assert [n for n, p in geo.named_parameters() if p.requires_grad] == ['embed_fn.embeddings', 'layers.params']
     assert geo.embed_fn.resolutions == [15, 22, 30, 42, 58, 80, 111, 153, 212, 294, 406, 561, 776, 1072, 1482, 2047]
     assert geo.embed_fn.n_total_embed == 6098108
 

@@ -188,6 +188,25 @@ def test_g6_hashgrid(oracle, tag):
     close(dxyz, g[tag + '_d_xyz'], rtol=1e-4, atol=1e-4 * scale)
 
 
+@pytest.mark.parametrize('tag', ['ngp', 'tiny', 'f4'])
+def test_g17_hashgrid_second_order(oracle, tag):
+    """the encoding's input gradient differentiated again, against the reference's torch backend under double autograd"""
+    g = load_golden('g17_hashgrid_second_order')
+    L, F, T, base, mx_res = [int(v) for v in g[tag + '_cfg']]
+    res, offs = oracle.hashgrid_levels(L, T, base, mx_res)
+    table = make_table(int(offs[-1]), F, seed=17, scale=0.5)
+    mn, mx = np.full(3, -1.0, np.float32), np.full(3, 1.0, np.float32)
+    _, dx = oracle.hashgrid_bwd(g[tag + '_xyz'], table, g[tag + '_gy'], res, offs, mn, mx, want_dxyz=True)
+    close(dx, g[tag + '_dx'], rtol=1e-4, atol=1e-4 * np.abs(g[tag + '_dx']).max())
+    ddout, dtable, d2x = oracle.hashgrid_bwd_bwd(g[tag + '_xyz'], g[tag + '_gdx'], table, g[tag + '_gy'], res, offs, mn, mx)
+    close(ddout, g[tag + '_d_gy'], rtol=1e-4, atol=1e-4 * np.abs(g[tag + '_d_gy']).max())
+    rows = g[tag + '_d_table_rows']
+    nz = np.nonzero(np.abs(dtable).sum(-1) > 0)[0]
+    assert set(nz.tolist()) <= set(rows.tolist())
+    close(dtable[rows], g[tag + '_d_table_vals'], rtol=1e-4, atol=1e-4 * np.abs(g[tag + '_d_table_vals']).max())
+    close(d2x, g[tag + '_d_x'], rtol=1e-4, atol=2e-4 * np.abs(g[tag + '_d_x']).max())
+
+
 # ---- G7 freq / SH --------------------------------------------------------------------------------
 def test_g7_freq(oracle):
     g = load_golden('g7_freq_sh')
