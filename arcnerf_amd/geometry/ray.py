@@ -34,3 +34,12 @@ def sphere_ray_intersection(rays_o, rays_d, radius, origin=(0, 0, 0)):
     """radius float or (N_r,) -> near, far (N_rays, N_r), pts (N_rays, N_r, 2, 3), mask (N_rays, N_r) bool
     (outside/no hit: 0, 0, mask 0; inside: near 0; rays_d assumed normalised, like the reference)"""
     return F.sphere_intersection(rays_o, rays_d, radius, origin)
+
+
+def __getattr__(name):
+    """surface_ray_intersection / sphere_tracing / secant_root_finding live in geometry/surface.py (which imports this module);
+    they stay reachable under the reference's path arcnerf.geometry.ray"""
+    if name in ('surface_ray_intersection', 'sphere_tracing', 'secant_root_finding'):
+        from . import surface
+        return getattr(surface, name)
+    raise AttributeError(name)

@@ -11,6 +11,7 @@ from ..geometry.ray import get_ray_points_by_zvals, normalize
 from ..utils.cfgs_utils import get_value_from_cfgs_field
 from ..utils.torch_utils import chunk_processing
 from .base_3d_model import Base3dModel
+from .surface_render import render_surface
 from .base_modules.obj_bound import build_obj_bound
 
 
@@ -205,3 +206,8 @@ class FgModel(Base3dModel):
 
     def optimize(self, cur_epoch=0):
         self.obj_bound.optimize(cur_epoch, self.get_n_coarse_sample(), self.get_est_opacity)
+
+    def surface_render(self, inputs, method='sphere_tracing', n_step=128, n_iter=100, threshold=0.01, level=50.0, grad_dir='descent'):
+        """inference only: colour of the first surface point of every ray; rays that miss the object bound are skipped
+        (fg_model.py:412-470, base_3d_model.py:307-366)"""
+        return render_surface(self, inputs, method, n_step, n_iter, threshold, level, grad_dir)

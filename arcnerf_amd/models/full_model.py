@@ -199,6 +199,14 @@ class FullModel(nn.Module):
         if self.bkg_model is not None:
             self.bkg_model.optimize(cur_epoch)
 
+    def surface_render(self, inputs, method='sphere_tracing', n_step=128, n_iter=100, threshold=0.01, level=0.0, grad_dir='ascent',
+                       **kwargs):
+        """inference only, foreground model only: inputs (B, N, ...) -> rgb (B, N, 3), depth, mask[, normal] (full_model.py:477-524)"""
+        flat, batch_size, n_rays_per_batch = self.prepare_flatten_inputs(inputs)
+        out = chunk_processing(self.fg_model.surface_render, self.fg_model.get_chunk_rays(), False, flat, method, n_step, n_iter,
+                               threshold, level, grad_dir)
+        return self.reshape_output(out, batch_size, n_rays_per_batch)
+
     def forward_pts_dir(self, pts, view_dir=None):
         return self.fg_model.forward_pts_dir(pts, view_dir)
 

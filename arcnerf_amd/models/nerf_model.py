@@ -150,6 +150,12 @@ class NeRF(FgModel):
             return self._forward_packed(inputs, inference_only)
         return super().forward(inputs, inference_only, get_progress, cur_epoch, total_epoch)
 
+    def surface_render(self, inputs, method='secant_root_finding', n_step=128, n_iter=20, threshold=0.01, level=50.0, grad_dir='descent'):
+        """a density has no exact surface: the `level` crossing found by the secant search only (nerf_model.py:119-135)"""
+        assert grad_dir == 'descent', 'Invalid for density model in nerf...'
+        assert method != 'sphere_tracing', 'Do not support for density model in nerf...'
+        return super().surface_render(inputs, method, n_step, n_iter, threshold, level, grad_dir)
+
     # ---- dense reference-shaped path ----------------------------------------------------------------------
     def _forward(self, inputs, inference_only=False, get_progress=False, cur_epoch=0, total_epoch=300000):
         rays_o, rays_d, zvals = inputs['rays_o'], inputs['rays_d'], inputs['zvals']

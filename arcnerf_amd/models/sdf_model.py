@@ -1,11 +1,12 @@
 """SdfModel (arcnerf/models/sdf_model.py:11-101): foreground models whose geometry value is a signed distance (NeuS, VolSDF).
-Points are evaluated with the geometry net's input gradient (the normal), which also feeds the radiance net.  surface_render
-(sphere tracing, :103-168) is a consumer of the path, not part of it, and is not provided."""
+Points are evaluated with the geometry net's input gradient (the normal), which also feeds the radiance net; surface_render
+(:116-185) finds the zero level by sphere tracing or the secant search and also returns the normal."""
 import torch
 
 from ..geometry.ray import get_ray_points_by_zvals, normalize
 from ..utils.torch_utils import chunk_processing
 from .fg_model import FgModel
+from .surface_render import render_surface
 
 
 class SdfModel(FgModel):
@@ -16,6 +17,11 @@ class SdfModel(FgModel):
 
     def get_est_opacity(self, dt, pts):
         raise NotImplementedError('You must implement the function in sdf-like models')
+
+    def surface_render(self, inputs, method='sphere_tracing', n_step=128, n_iter=20, threshold=0.01, level=0.0, grad_dir='ascent'):
+        assert level == 0.0, 'Invalid level for sdf model...'
+        assert grad_dir == 'ascent', 'Invalid grad_dir for sdf model...'
+        return render_surface(self, inputs, method, n_step, n_iter, threshold, level, grad_dir, with_normal=True)
 
     def forward_pts_dir(self, pts, view_dir=None):
         geo_net, radiance_net = self.get_net()

@@ -593,3 +593,43 @@ def test_neus_ngp_with_multivol_background_trains(gpu):
     assert set(res.keys()) >= {'rgb', 'depth', 'mask', 'normal'} and torch.isfinite(res['rgb']).all()
     sampler_rng(reset=True)
     multivol_rng(reset=True)
+
+
+def test_surface_render_matches_reference(gpu):
+    """G19: FullModel.surface_render of the reference on the G13 NeuS model (sphere tracing; secant search on the zero level,
+    normals included) and on the G9 NeRF model (secant search on a density level).  The hit masks are identical, depth / rgb /
+    normal within 2e-4 (the device-resident loops evaluate frozen rays again instead of gathering the active ones: same results)."""
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    g = load_golden('g19_surface_render')
+
+    def load(fixture, cfg):
+        f = load_golden(fixture)
+        m = build_model(load_configs(os.path.join(CFG, cfg), [str(v) for v in f['overrides']])).to(gpu)
+        m.load_state_dict({k[3:]: torch.from_numpy(f[k]) for k in f.files if k.startswith('sd.')})
+        return m.eval(), {k[3:]: torch.from_numpy(f[k]).to(gpu) for k in f.files if k.startswith('in_')}
+
+    def check(res, tag, keys):
+        assert set(res.keys()) == set(keys)
+        assert np.array_equal(res['mask'].cpu().numpy(), g[tag + 'mask'])
+        for k in keys:
+            assert res[k].shape == g[tag + k].shape, k
+            close(res[k].detach().cpu().numpy(), g[tag + k], rtol=2e-4, atol=2e-4)
+
+    neus, inputs = load('g13_neus_model', 'neus.yaml')
+    res = neus.surface_render({k: v.clone() for k, v in inputs.items()}, method='sphere_tracing', n_iter=60, threshold=0.002)
+    check(res, 'neus_st_', ('rgb', 'depth', 'mask', 'normal'))
+    assert 0 < float(res['mask'].sum()) < res['mask'].numel()   # some rays miss the sphere bound: the skipped-ray branch ran
+    res = neus.surface_render({k: v.clone() for k, v in inputs.items()}, method='secant_root_finding', n_step=48, n_iter=12, threshold=0.002)
+    check(res, 'neus_sec_', ('rgb', 'depth', 'mask', 'normal'))
+    with pytest.raises(AssertionError):
+        neus.surface_render(inputs, level=1.0)
+    nerf, inputs = load('g9_nerf_model', 'nerf.yaml')
+    res = nerf.surface_render({k: v.clone() for k, v in inputs.items()}, method='secant_root_finding', n_step=48, n_iter=12,
+                              threshold=0.002, level=float(g['nerf_level']), grad_dir='descent')
+    check(res, 'nerf_sec_', ('rgb', 'depth', 'mask'))
+    with pytest.raises(AssertionError):
+        nerf.surface_render(inputs, method='sphere_tracing')
+    with pytest.raises(NotImplementedError):
+        from arcnerf_amd.geometry.ray import surface_ray_intersection
+        surface_ray_intersection(inputs['rays_o'][0], inputs['rays_d'][0], None, method='bisection')
