@@ -368,6 +368,86 @@ multivol_sampling_kernel(const float *__restrict__ rays_o, const float *__restri
     if (j > 0) for (; j < n_pts; ++j) zr[j] = last;
 }
 
+// ---- ray generation (arcnerf/render/ray_helper.py:12-153, geometry/projection.py:8-66) ------------------------------------
+// One lane per ray: pixel -> camera (z = 1, skew included) -> world -> direction, normalised or warped to NDC, plus the mip-nerf
+// radius in full-image mode (the lane recomputes its right neighbour's direction instead of a second pass over a (W,H,3) tensor).
+struct CamParams {
+    float fx, skew, cx, fy, cy;
+    float r[3][4];  // c2w rows
+};
+
+__device__ __forceinline__ void ray_dir(const CamParams &c, float pi, float pj, bool normalise, float out[3]) {
+    float cam[3];
+    cam[0] = (pi - (c.skew * (pj - c.cy) / c.fy) - c.cx) / c.fx * 1.0f;
+    cam[1] = (pj - c.cy) / c.fy * 1.0f;
+    cam[2] = 1.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float w = c.r[k][0] * cam[0];
+        w = w + c.r[k][1] * cam[1];
+        w = w + c.r[k][2] * cam[2];
+        w = w + c.r[k][3];
+        out[k] = w - c.r[k][3];
+    }
+    if (normalise) {
+        const float nrm = sqrtf(out[0] * out[0] + out[1] * out[1] + out[2] * out[2]) + 1e-8f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[k] = out[k] / nrm;
+    }
+}
+
+// origin and direction of pixel (pi, pj) as the reference returns them: normalised, or warped to NDC (get_ndc_rays)
+__device__ __forceinline__ void pixel_ray(const CamParams &c, int W, int H, float pi, float pj, bool normalise, bool ndc,
+                                          float ndc_near, float o[3], float d[3]) {
+    o[0] = c.r[0][3]; o[1] = c.r[1][3]; o[2] = c.r[2][3];
+    ray_dir(c, pi, pj, normalise && !ndc, d);
+    if (ndc) {
+        const float t = -(ndc_near + o[2]) / d[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[k] = o[k] + t * d[k];
+        const float ax = -1.0f / ((float)W / (2.0f * c.fx)), ay = -1.0f / ((float)H / (2.0f * c.fy));
+        const float no[3] = {ax * o[0] / o[2], ay * o[1] / o[2], 1.0f + 2.0f * ndc_near / o[2]};
+        const float nd[3] = {ax * (d[0] / d[2] - o[0] / o[2]), ay * (d[1] / d[2] - o[1] / o[2]), -2.0f * ndc_near / o[2]};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { o[k] = no[k]; d[k] = nd[k]; }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+get_rays_kernel(int W, int H, const float *__restrict__ K, const float *__restrict__ c2w, int wh_order,
+                const int64_t *__restrict__ index, int64_t n, int center_pixel, int normalise, int ndc, float ndc_near,
+                float *__restrict__ rays_o, float *__restrict__ rays_d, float *__restrict__ rays_r) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    CamParams c;
+    c.fx = K[0]; c.skew = K[1]; c.cx = K[2]; c.fy = K[4]; c.cy = K[5];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) c.r[k][m] = c2w[4 * k + m];
+    int64_t i, j;
+    if (index) { i = index[p] / H; j = index[p] % H; }
+    else if (wh_order) { i = p / H; j = p % H; }
+    else { j = p / W; i = p % W; }
+    const float off = center_pixel ? 0.5f : 0.0f;
+    float o[3], d[3];
+    pixel_ray(c, W, H, (float)i + off, (float)j + off, normalise, ndc, ndc_near, o, d);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { rays_o[3 * p + k] = o[k]; rays_d[3 * p + k] = d[k]; }
+    if (rays_r && !index) {
+        // radius from the directions as returned (after the NDC warp when it is on); the reference appends dx[-2:-1], so the
+        // last column takes column W-3's value
+        const int64_t ia = i < W - 1 ? i : W - 3;
+        float ao[3], a[3], bo[3], b[3];
+        pixel_ray(c, W, H, (float)ia + off, (float)j + off, normalise, ndc, ndc_near, ao, a);
+        pixel_ray(c, W, H, (float)(ia + 1) + off, (float)j + off, normalise, ndc, ndc_near, bo, b);
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const float df = a[k] - b[k]; acc += df * df; }
+        rays_r[p] = sqrtf(acc) * 2.0f / sqrtf(12.0f);
+    }
+}
+
 // ---- K4 ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) reduce_max_kernel(const float *__restrict__ full, const int64_t *__restrict__ idx,
                                                          float *__restrict__ uni, int64_t n) {
@@ -723,6 +803,19 @@ ARCN_EXPORT int arcn_sparse_sampling_in_multivol_bitfield(const float *rays_o, c
                        rays_o, rays_d, near, far, min_aabb, aabb, bitfield, (uint32_t)n_grid, (uint32_t)n_cascade, (uint32_t)n_pts,
                        cone_angle, min_step, max_step, near_distance, inclusive, rng, zvals, mask, counts, n_rays);
     return check_launch("sparse_sampling_in_multivol_bitfield");
+}
+
+ARCN_EXPORT int arcn_get_rays(int W, int H, const float *intrinsic, const float *c2w, int wh_order, const int64_t *index, int64_t n,
+                              int center_pixel, int normalize_rays_d, int ndc, float ndc_near, float *rays_o, float *rays_d,
+                              float *rays_r, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!intrinsic || !c2w || !rays_o || !rays_d || W <= 0 || H <= 0) return einval("get_rays: missing/invalid argument");
+    if (!index && n != (int64_t)W * H) return einval("get_rays: without an index the output holds W*H rays");
+    if (rays_r && index) return einval("get_rays: the ray radius exists in full-image mode only");
+    if (rays_r && W < 3) return einval("get_rays: the ray radius needs W >= 3");
+    hipLaunchKernelGGL(get_rays_kernel, dim3((unsigned)ceil_div<int64_t>(n, 256)), dim3(256), 0, as_stream(stream), W, H, intrinsic,
+                       c2w, wh_order, index, n, center_pixel, normalize_rays_d, ndc, ndc_near, rays_o, rays_d, rays_r);
+    return check_launch("get_rays");
 }
 
 ARCN_EXPORT int arcn_tensor_reduce_max(const float *full, const int64_t *idx, int n_group, float *uni, int64_t n,

@@ -89,6 +89,24 @@ def sphere_intersection(rays_o, rays_d, radius, origin=(0.0, 0.0, 0.0), want_pts
     return near, far, pts, mask
 
 
+def get_rays(W, H, intrinsic, c2w, wh_order=True, flat_index=None, center_pixel=False, normalize_rays_d=True, ndc=False,
+             ndc_near=1.0):
+    """-> rays_o (n,3), rays_d (n,3), rays_r (n,1) or None (when flat_index, (n,) int64 column-major pixel ids, is given)"""
+    _req(intrinsic, c2w, flat_index)
+    K, M = _f32(intrinsic), _f32(c2w)
+    if tuple(K.shape) != (3, 3) or tuple(M.shape) != (4, 4):
+        raise RuntimeError('intrinsic must be (3,3) and c2w (4,4)')
+    n = int(W) * int(H) if flat_index is None else flat_index.shape[0]
+    idx = None if flat_index is None else flat_index.contiguous().long()
+    o = torch.empty((n, 3), dtype=torch.float32, device=K.device)
+    d = torch.empty((n, 3), dtype=torch.float32, device=K.device)
+    r = torch.empty((n, 1), dtype=torch.float32, device=K.device) if idx is None else None
+    N.check(N.lib().arcn_get_rays(int(W), int(H), N.ptr(K), N.ptr(M), int(bool(wh_order)), N.ptr(idx), n, int(bool(center_pixel)),
+                                 int(bool(normalize_rays_d)), int(bool(ndc)), float(ndc_near), N.ptr(o), N.ptr(d), N.ptr(r),
+                                 N.stream()), 'get_rays')
+    return o, d, r
+
+
 def sparse_volume_sampling(rays_o, rays_d, near, far, n_pts, dt, aabb23, n_grid, bitfield, near_distance, rng_state,
                            rng_inc, want_counts=False):
     _req(rays_o, rays_d, near, far, aabb23, bitfield)

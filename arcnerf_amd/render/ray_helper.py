@@ -10,6 +10,29 @@ from ..ops import functional as F
 from ..ops.autograd import RayMarchingFn
 
 
+def get_rays(W, H, intrinsic, c2w, wh_order=True, index=None, n_rays=-1, to_np=False, ndc=False, ndc_near=1.0, center_pixel=False,
+             normalize_rays_d=True):
+    """Rays of one camera in world coordinates, one kernel (render/ray_helper.py:12-119).
+    intrinsic (3,3), c2w (4,4) device tensors.  index: (N,2) (i, j) pixel pairs; n_rays > 0: that many distinct random pixels
+    (numpy's global generator, like the reference); neither: the full image, flattened column-major (wh_order) or row-major.
+    -> rays_o (N,3), rays_d (N,3), index (list of column-major pixel ids, or None), rays_r (N,1) mip-nerf radius (full image only)"""
+    assert (index is None) or n_rays <= 0, 'You are not allowed to sampled both by index and N_ray'
+    device = intrinsic.device
+    flat = None
+    if index is not None:
+        assert len(index.shape) == 2 and index.shape[-1] == 2, 'invalid shape, should be (N_rays, 2)'
+        index = torch.as_tensor(index, dtype=torch.long, device=device)
+        flat = index[:, 0] * H + index[:, 1]
+    if n_rays > 0:
+        import numpy as np
+        flat = torch.tensor(np.random.choice(range(0, W * H), n_rays, replace=False), dtype=torch.long, device=device)
+    rays_o, rays_d, rays_r = F.get_rays(W, H, intrinsic, c2w, wh_order=wh_order, flat_index=flat, center_pixel=center_pixel,
+                                        normalize_rays_d=normalize_rays_d, ndc=ndc, ndc_near=ndc_near)
+    if to_np:
+        rays_o, rays_d = rays_o.cpu().numpy(), rays_d.cpu().numpy()
+    return rays_o, rays_d, (flat.cpu().numpy().tolist() if flat is not None else None), rays_r
+
+
 def get_near_far_from_rays(rays_o, rays_d, bounds=None, near_hardcode=None, far_hardcode=None, bounding_radius=None):
     """near, far (N_rays, 1) from data bounds and / or the ray-sphere test of a bounding radius, overridden by the hard-coded
     values (ray_helper.py:175-228)"""

@@ -62,6 +62,15 @@ int arcn_aabb_intersection_torch(const float *rays_o, const float *rays_d, const
 int arcn_sphere_intersection(const float *rays_o, const float *rays_d, const float *radius, const float *origin_host,
                              float *near, float *far, float *pts, uint8_t *mask, int64_t n_rays, int64_t n_r, void *stream);
 
+/* get_rays (arcnerf/render/ray_helper.py:12-119) with pixel_to_world (geometry/projection.py:8-66) and get_ndc_rays
+ * (ray_helper.py:122-153): intrinsic (3,3) and c2w (4,4) row-major DEVICE floats.  index == NULL: all W*H pixels, column-major
+ * (wh_order = 1: p = i * H + j) or row-major (p = j * W + i); else index (n) int64 holds column-major pixel ids i * H + j.
+ * rays_o, rays_d (n,3); rays_r (n) optional, full-image mode only: the mip-nerf radius |d(i,j) - d(i+1,j)| * 2 / sqrt(12) (the
+ * last column takes column W-3's value, as the reference's `dx[-2:-1]` does). */
+int arcn_get_rays(int W, int H, const float *intrinsic, const float *c2w, int wh_order, const int64_t *index, int64_t n,
+                  int center_pixel, int normalize_rays_d, int ndc, float ndc_near, float *rays_o, float *rays_d, float *rays_r,
+                  void *stream);
+
 /* K3 sparse_volume_sampling (volume_func_kernel.cu:174-291). zvals/mask (n_rays,n_pts) zero-initialised by the
  * caller.  (rng_state, rng_inc) is the host pcg32 BEFORE the call (reference: file-static `pcg32 rng{9121}`,
  * include/common.h:22-23, advanced 2^32 after every launch); the caller owns that bookkeeping (arcn_pcg32_*).

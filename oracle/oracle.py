@@ -146,6 +146,21 @@ def sphere_intersection(rays_o, rays_d, radius, origin=(0.0, 0.0, 0.0)):
     return near, far, pts, mask.astype(bool)
 
 
+def get_rays(W, H, intrinsic, c2w, wh_order=True, index=None, center_pixel=False, normalize_rays_d=True, ndc=False, ndc_near=1.0):
+    """-> rays_o (n,3), rays_d (n,3), rays_r (n,1) or None (index given).  index: (n,2) (i, j) pairs or None (full image)."""
+    K, M = _f32(intrinsic).reshape(9), _f32(c2w).reshape(16)
+    flat = None
+    if index is not None:
+        index = np.asarray(index, dtype=np.int64)
+        flat = np.ascontiguousarray(index[:, 0] * H + index[:, 1])
+    n = W * H if flat is None else flat.shape[0]
+    o, d = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    r = np.zeros((n, 1), np.float32) if flat is None else None
+    lib().orc_get_rays(C.c_int(W), C.c_int(H), _p(K), _p(M), C.c_int(int(wh_order)), _p(flat), C.c_int64(n), C.c_int(int(center_pixel)),
+                       C.c_int(int(normalize_rays_d)), C.c_int(int(ndc)), C.c_float(ndc_near), _p(o), _p(d), _p(r))
+    return o, d, r
+
+
 def sparse_volume_sampling(rays_o, rays_d, near, far, n_pts, dt, aabb23, n_grid, bitfield, near_distance,
                            rng_state, rng_inc, with_trace=False):
     """K3.  Returns zvals (R,n_pts), mask (R,n_pts) bool, counts (R) [, voxel trace (R,n_pts) int32]."""

@@ -366,3 +366,64 @@ ORC_API int orc_get_max_threads(void) {
     return 1;
 #endif
 }
+
+/* ---------------------------------------------------------------------------------------
+ * get_rays (arcnerf/render/ray_helper.py:12-119) = pixel_to_cam (geometry/projection.py:8-34: x_cam = (i - s (j - cy) / fy - cx)
+ * / fx * z, y_cam = (j - cy) / fy * z, z = 1) + cam_to_world (einsum R x + t, transformation.py:44-59) - cam_loc, then normalize
+ * (v / (|v| + 1e-8)) or the NDC warp (get_ndc_rays, ray_helper.py:122-153).
+ * Pixel p of the flat list: index == NULL -> p = i * H + j (wh_order, column-major) or p = j * W + i (row-major); else index[p] is
+ * the column-major id i * H + j.  rays_r (optional, full image only, W >= 3): |d(i,j) - d(i+1,j)| * 2 / sqrt(12) (mip-nerf radius);
+ * the last column takes the value of column W-3 (the reference appends `dx[-2:-1]`).
+ * ------------------------------------------------------------------------------------- */
+static void orc_ray_dir(const float *K, const float *c2w, float pi, float pj, int normalize_d, float out[3]) {
+    const float fx = K[0], s = K[1], cx = K[2], fy = K[4], cy = K[5];
+    float cam[3];
+    cam[0] = (pi - (s * (pj - cy) / fy) - cx) / fx * 1.0f;
+    cam[1] = (pj - cy) / fy * 1.0f;
+    cam[2] = 1.0f;
+    for (int k = 0; k < 3; ++k) {
+        float w = c2w[4 * k + 0] * cam[0];
+        w = w + c2w[4 * k + 1] * cam[1];
+        w = w + c2w[4 * k + 2] * cam[2];
+        w = w + c2w[4 * k + 3];
+        out[k] = w - c2w[4 * k + 3];
+    }
+    if (normalize_d) {
+        float nrm = sqrtf(out[0] * out[0] + out[1] * out[1] + out[2] * out[2]) + 1e-8f;
+        for (int k = 0; k < 3; ++k) out[k] = out[k] / nrm;
+    }
+}
+
+ORC_API void orc_get_rays(int W, int H, const float *K, const float *c2w, int wh_order, const int64_t *index, int64_t n,
+                          int center_pixel, int normalize_d, int ndc, float ndc_near, float *rays_o, float *rays_d, float *rays_r) {
+    const float off = center_pixel ? 0.5f : 0.0f;
+    for (int64_t p = 0; p < n; ++p) {
+        int64_t i, j;
+        if (index) { i = index[p] / H; j = index[p] % H; }
+        else if (wh_order) { i = p / H; j = p % H; }
+        else { j = p / W; i = p % W; }
+        float d[3], o[3] = {c2w[3], c2w[7], c2w[11]};
+        orc_ray_dir(K, c2w, (float)i + off, (float)j + off, normalize_d && !ndc, d);
+        if (ndc) {
+            const float fx = K[0], fy = K[4];
+            float t = -(ndc_near + o[2]) / d[2];
+            for (int k = 0; k < 3; ++k) o[k] = o[k] + t * d[k];
+            const float ax = -1.0f / ((float)W / (2.0f * fx)), ay = -1.0f / ((float)H / (2.0f * fy));
+            float no[3] = {ax * o[0] / o[2], ay * o[1] / o[2], 1.0f + 2.0f * ndc_near / o[2]};
+            float nd[3] = {ax * (d[0] / d[2] - o[0] / o[2]), ay * (d[1] / d[2] - o[1] / o[2]), -2.0f * ndc_near / o[2]};
+            for (int k = 0; k < 3; ++k) { o[k] = no[k]; d[k] = nd[k]; }
+        }
+        for (int k = 0; k < 3; ++k) { rays_o[3 * p + k] = o[k]; rays_d[3 * p + k] = d[k]; }
+    }
+    if (rays_r && !index) {
+        for (int64_t p = 0; p < n; ++p) {
+            int64_t i, j;
+            if (wh_order) { i = p / H; j = p % H; } else { j = p / W; i = p % W; }
+            int64_t ia = i < W - 1 ? i : W - 3;   /* `dx[-2:-1]` (ray_helper.py:108,112): the last column takes the SECOND-to-last difference */
+            int64_t pa = wh_order ? ia * H + j : j * W + ia, pb = wh_order ? (ia + 1) * H + j : j * W + ia + 1;
+            float acc = 0.f;
+            for (int k = 0; k < 3; ++k) { float df = rays_d[3 * pa + k] - rays_d[3 * pb + k]; acc += df * df; }
+            rays_r[p] = sqrtf(acc) * 2.0f / sqrtf(12.0f);
+        }
+    }
+}

@@ -298,6 +298,35 @@ def g17_hashgrid_second_order():
 
 
 # ------------------------------------------------------------------------------------------------
+def g20_get_rays():
+    """ray generation (render/ray_helper.py:12-119): full image in both flattening orders (with the mip-nerf radius), a pixel
+    subset, centre-pixel offset, un-normalised directions, NDC; an intrinsic with skew, a generic pose."""
+    from arcnerf.render.ray_helper import get_rays
+    g = torch.Generator().manual_seed(2020)
+    W, H = 13, 9
+    K = torch.tensor([[11.5, 0.3, 6.2], [0.0, 12.25, 4.4], [0.0, 0.0, 1.0]])
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    c2w = torch.eye(4)
+    c2w[:3, :3] = q
+    c2w[:3, 3] = torch.tensor([0.7, -1.3, 2.9])
+    idx = torch.stack([torch.randint(0, W, (17,), generator=g), torch.randint(0, H, (17,), generator=g)], -1)
+    out = {'W': np.int32(W), 'H': np.int32(H), 'K': npy(K), 'c2w': npy(c2w), 'index': npy(idx)}
+    cases = {'wh': dict(wh_order=True), 'hw': dict(wh_order=False), 'center': dict(wh_order=True, center_pixel=True),
+             'raw': dict(wh_order=False, normalize_rays_d=False), 'ndc': dict(wh_order=True, ndc=True, ndc_near=1.0),
+             'idx': dict(index=idx), 'idx_center_ndc': dict(index=idx, center_pixel=True, ndc=True, ndc_near=0.5)}
+    for tag, kw in cases.items():
+        o, d, flat, r = get_rays(W, H, K, c2w, **kw)
+        out[tag + '_o'], out[tag + '_d'] = npy(o), npy(d)
+        if r is not None:
+            out[tag + '_r'] = npy(r)
+        if flat is not None:
+            out[tag + '_flat'] = np.array(flat, np.int64)
+    save('g20_get_rays', **out)
+
+
+# ------------------------------------------------------------------------------------------------
 def g7_freq_sh():
     g = torch.Generator().manual_seed(707)
     S = 128

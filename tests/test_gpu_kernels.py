@@ -799,3 +799,37 @@ def test_hashgrid_second_order_vs_reference_golden_and_oracle(F, oracle, tag):
     # a density model never builds the xyz node
     y3 = hashgrid_encode(dev(xyz), tab, desc)
     assert type(y3.grad_fn).__name__ == 'HashGridFnBackward'
+
+
+# ---- ray generation -----------------------------------------------------------------------------------------------------
+def test_get_rays_vs_reference_golden_and_oracle(F, oracle):
+    """G20 (reference get_rays): both flattening orders with the mip-nerf radius, pixel subsets, centre pixel, raw directions, NDC"""
+    from arcnerf_amd.render.ray_helper import get_rays
+    g = load_golden('g20_get_rays')
+    W, H, K, c2w, idx = int(g['W']), int(g['H']), g['K'], g['c2w'], g['index']
+    cases = {'wh': dict(wh_order=True), 'hw': dict(wh_order=False), 'center': dict(wh_order=True, center_pixel=True),
+             'raw': dict(wh_order=False, normalize_rays_d=False), 'ndc': dict(wh_order=True, ndc=True, ndc_near=1.0),
+             'idx': dict(index=idx), 'idx_center_ndc': dict(index=idx, center_pixel=True, ndc=True, ndc_near=0.5)}
+    for tag, kw in cases.items():
+        kw_t = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+        o, d, flat, r = get_rays(W, H, dev(K), dev(c2w), **kw_t)
+        ro, rd, rr = oracle.get_rays(W, H, K, c2w, **kw)
+        close(host(o), g[tag + '_o'], rtol=1e-5, atol=1e-5)
+        close(host(d), g[tag + '_d'], rtol=1e-5, atol=1e-5)
+        close(host(o), ro, rtol=1e-6, atol=1e-6)
+        close(host(d), rd, rtol=1e-6, atol=1e-6)
+        if tag + '_r' in g.files:
+            assert flat is None
+            close(host(r), g[tag + '_r'], rtol=1e-4, atol=1e-6)
+            close(host(r), rr, rtol=1e-5, atol=1e-7)
+        else:
+            assert r is None and flat == g[tag + '_flat'].tolist()
+    # Lego-sized image: the full 800x800 grid in one launch, unit directions, origin = camera centre
+    o, d, _, r = get_rays(800, 800, dev(K) * 60, dev(c2w))
+    assert o.shape == (640000, 3) and torch.allclose(d.norm(dim=-1), torch.ones(640000, device='cuda'), atol=1e-5)
+    assert torch.equal(o, dev(c2w)[:3, 3].expand_as(o)) and r.shape == (640000, 1) and float(r.min()) > 0
+    np.random.seed(0)
+    o, d, flat, r = get_rays(W, H, dev(K), dev(c2w), n_rays=20)
+    assert o.shape == (20, 3) and len(set(flat)) == 20 and r is None
+    with pytest.raises(AssertionError):
+        get_rays(W, H, dev(K), dev(c2w), index=dev(idx), n_rays=5)

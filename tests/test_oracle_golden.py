@@ -207,6 +207,22 @@ def test_g17_hashgrid_second_order(oracle, tag):
     close(d2x, g[tag + '_d_x'], rtol=1e-4, atol=2e-4 * np.abs(g[tag + '_d_x']).max())
 
 
+def test_g20_get_rays(oracle):
+    g = load_golden('g20_get_rays')
+    W, H, K, c2w, idx = int(g['W']), int(g['H']), g['K'], g['c2w'], g['index']
+    cases = {'wh': dict(wh_order=True), 'hw': dict(wh_order=False), 'center': dict(wh_order=True, center_pixel=True),
+             'raw': dict(wh_order=False, normalize_rays_d=False), 'ndc': dict(wh_order=True, ndc=True, ndc_near=1.0),
+             'idx': dict(index=idx), 'idx_center_ndc': dict(index=idx, center_pixel=True, ndc=True, ndc_near=0.5)}
+    for tag, kw in cases.items():
+        o, d, r = oracle.get_rays(W, H, K, c2w, **kw)
+        close(o, g[tag + '_o'], rtol=1e-5, atol=1e-5)
+        close(d, g[tag + '_d'], rtol=1e-5, atol=1e-5)
+        if tag + '_r' in g.files:
+            close(r, g[tag + '_r'], rtol=1e-4, atol=1e-6)
+        else:
+            assert r is None and (g[tag + '_flat'] == idx[:, 0] * H + idx[:, 1]).all()
+
+
 # ---- G7 freq / SH --------------------------------------------------------------------------------
 def test_g7_freq(oracle):
     g = load_golden('g7_freq_sh')
