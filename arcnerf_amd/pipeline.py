@@ -197,7 +197,13 @@ class NgpPipeline:
                 'counts': torch.zeros(R, dtype=i32, device=dev), 'offsets': torch.zeros(R + 1, dtype=i32, device=dev),
                 'near': torch.empty(R, dtype=f32, device=dev), 'far': torch.empty(R, dtype=f32, device=dev),
                 't': torch.zeros(S, dtype=f32, device=dev), 'ray_id': torch.zeros(S, dtype=i32, device=dev),
-                'p_dense': torch.full((1,), 2, dtype=i32, device=dev)})
+                'p_dense': torch.full((1,), 2, dtype=i32, device=dev),
+                # everything else that depends on the rays and the occupancy only is produced with the samples (second stream
+                # when prefetched): sample positions / directions, per-ray harmonics, the density noise of a training step
+                'xyz': torch.zeros((S, 3), dtype=f32, device=dev), 'dirs': torch.zeros((S, 3), dtype=f32, device=dev),
+                'sh_ray': torch.zeros((R, max(1, cfg.sh_degree ** 2)), dtype=f32, device=dev),
+                'noise': torch.zeros(S, dtype=f32, device=dev)})
+        self._noise_ready = [False, False]
         b.update(self._sets[0])
         self._cur_set = 0
         self._prefetched = None
@@ -213,8 +219,6 @@ class NgpPipeline:
         self._prefetch_now = self.prefetch_at
         self.aux_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
         self.use_streams = self.aux_stream is not None
-        b['xyz'] = torch.zeros((S, 3), dtype=f32, device=dev)
-        b['dirs'] = torch.zeros((S, 3), dtype=f32, device=dev)
         b['feat'] = torch.zeros((S, E), dtype=f32, device=dev)
         b['geo_out'] = torch.zeros((S, field.geo_out_dim), dtype=f32, device=dev)
         b['geo_acts'] = torch.zeros(max(1, F.mlp_acts_floats(field.geo_desc, S)), dtype=f32, device=dev)
@@ -222,7 +226,6 @@ class NgpPipeline:
         b['sigma'] = torch.zeros(S, dtype=f32, device=dev)
         b['rgb_s'] = torch.zeros((S, 3), dtype=f32, device=dev)
         b['rad_acts'] = torch.zeros(max(1, F.mlp_acts_floats(field.rad_desc, S)), dtype=f32, device=dev)
-        b['noise'] = torch.zeros(S, dtype=f32, device=dev)
         # backward
         b['d_sigma'] = torch.zeros(S, dtype=f32, device=dev)
         b['d_rgb_s'] = torch.zeros((S, 3), dtype=f32, device=dev)
@@ -233,7 +236,6 @@ class NgpPipeline:
         b['geo_scratch'] = torch.zeros(F.mlp_scratch_floats(field.geo_desc, S), dtype=f32, device=dev)
         b['rad_scratch'] = torch.zeros(F.mlp_scratch_floats(field.rad_desc, S), dtype=f32, device=dev)
         # per-ray outputs
-        b['sh_ray'] = torch.zeros((R, max(1, cfg.sh_degree ** 2)), dtype=f32, device=dev)
         b['rgb'] = torch.zeros((R, 3), dtype=f32, device=dev)
         b['depth'] = torch.zeros(R, dtype=f32, device=dev)
         b['mask'] = torch.zeros(R, dtype=f32, device=dev)
@@ -338,9 +340,10 @@ class NgpPipeline:
         return select_refresh_cells(self.bitfield, n_cells, cache, rng)
 
     # ---- forward --------------------------------------------------------------------------------
-    def prefetch_samples(self, rays_o, rays_d):
-        """March `rays` on the auxiliary stream into the spare sample-buffer set; the next forward() on the SAME tensors picks
-        the result up instead of marching again.  Safe to call right after the current step's forward was issued."""
+    def prefetch_samples(self, rays_o, rays_d, noise=False):
+        """March `rays` on the auxiliary stream into the spare sample-buffer set (with the sample positions, the per-ray harmonics
+        and - noise=True - the density noise of a training step); the next forward() on the SAME tensors picks the result up
+        instead of marching again.  Safe to call right after the current step's forward was issued."""
         if not self.use_streams:
             return
         main = torch.cuda.current_stream()
@@ -348,6 +351,9 @@ class NgpPipeline:
         spare = 1 - self._cur_set
         with torch.cuda.stream(self.aux_stream):
             self._sample_into(self._sets[spare], rays_o, rays_d)
+            self._noise_ready[spare] = bool(noise and self.cfg.noise_std > 0)
+            if self._noise_ready[spare]:
+                self._sets[spare]['noise'].normal_(0.0, self.cfg.noise_std)
             ev = torch.cuda.Event()
             ev.record(self.aux_stream)
         self._prefetched = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], spare, ev)
@@ -362,6 +368,7 @@ class NgpPipeline:
             self.buf.update(self._sets[self._cur_set])
         else:
             self._prefetched = None
+            self._noise_ready[self._cur_set] = False
             self._sample_into(self._sets[self._cur_set], rays_o, rays_d)
             self.buf.update(self._sets[self._cur_set])
         R = rays_o.shape[0]
@@ -384,17 +391,24 @@ class NgpPipeline:
         N.check(L.arcn_exclusive_scan_i32(N.ptr(b['counts']), N.ptr(b['offsets']), R, self.cap, N.ptr(b['p_dense']), st), 'scan')
         N.check(L.arcn_march_write(N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['offsets']), cfg.n_sample, N.ptr(b['t']),
                                    N.ptr(b['ray_id']), R, self.cap, st), 'march_write')
+        N.check(L.arcn_packed_points(N.ptr(rays_o), N.ptr(rays_d), N.ptr(b['t']), N.ptr(b['ray_id']), N.ptr(b['xyz']),
+                                     N.ptr(b['dirs']), self.cap, b['offsets'][R:R + 1].data_ptr(), st), 'packed_points')
+        if self.ray_sh:
+            N.check(L.arcn_ngp_ray_sh(N.ptr(rays_d), cfg.sh_degree, N.ptr(b['sh_ray']), R, st), 'ngp_ray_sh')
 
     def forward(self, rays_o, rays_d, bkg_color=None, train=False, noise=None):
         """Render rays: returns rgb (R,3), depth (R), mask (R) views of the internal buffers."""
         cfg, b, fld = self.cfg, self.buf, self.field
         R = rays_o.shape[0]
         rays_o, rays_d = rays_o.contiguous().float(), rays_d.contiguous().float()
-        n_dev = self.sample(rays_o, rays_d)
+        n_dev = self.sample(rays_o, rays_d)   # + sample positions / directions, per-ray harmonics
         S = self.cap
         L, st = N.lib(), N.stream()
-        N.check(L.arcn_packed_points(N.ptr(rays_o), N.ptr(rays_d), N.ptr(b['t']), N.ptr(b['ray_id']), N.ptr(b['xyz']),
-                                     N.ptr(b['dirs']), S, n_dev.data_ptr(), st), 'packed_points')
+        if noise == 'auto':   # training noise: the prefetched set brings it along, otherwise draw it now
+            noise = None
+            if cfg.noise_std > 0:
+                noise = b['noise'] if self._noise_ready[self._cur_set] else b['noise'].normal_(0.0, cfg.noise_std)
+                self._noise_ready[self._cur_set] = False
         self.generation += 1
         if self.level_major:
             # encode -> geometry net through a LEVEL-MAJOR feature buffer (L, S, 2): the XCD-affine gather writes it coalesced and
@@ -410,14 +424,12 @@ class NgpPipeline:
         if self.fused_glue:
             # view-direction harmonics once per ray; the radiance net assembles [geo features | SH(ray)] in its operand load and
             # writes sigma = act(geo_out[:, 0]) on the way: no rad_in buffer, no glue kernel
-            N.check(L.arcn_ngp_ray_sh(N.ptr(rays_d), cfg.sh_degree, N.ptr(b['sh_ray']), R, st), 'ngp_ray_sh')
             N.check(L.arcn_mlp_fwd_cat(N.ptr(b['geo_out']), N.ptr(b['sh_ray']), N.ptr(b['ray_id']), int(cfg.rad_mode == 'fv'),
                                        N.ptr(self._p('rad_w')), N.C.addressof(fld.rad_desc), N.ptr(b['rgb_s']),
                                        N.ptr(b['rad_acts']) if train else None, N.ptr(b['sigma']), N.ACT[cfg.sigma_act], S, S,
                                        n_dev.data_ptr(), st), 'mlp_fwd_cat(rad)')
         else:
             if self.ray_sh:
-                N.check(L.arcn_ngp_ray_sh(N.ptr(rays_d), cfg.sh_degree, N.ptr(b['sh_ray']), R, st), 'ngp_ray_sh')
                 N.check(L.arcn_ngp_glue_fwd_rays(N.ptr(b['geo_out']), N.ptr(b['sh_ray']), N.ptr(b['ray_id']), fld.geo_out_dim,
                                                  fld.feat_off, cfg.W_feat, cfg.sh_degree, int(cfg.rad_mode == 'fv'),
                                                  N.ACT[cfg.sigma_act], N.ptr(b['rad_in']), N.ptr(b['sigma']), S, n_dev.data_ptr(), st),
@@ -518,10 +530,7 @@ class NgpPipeline:
         next_rays = (rays_o, rays_d) of the FOLLOWING step: their marching is overlapped with this step's backward.
         grad_sync: a distributed.PipelinedGradSync (takes precedence over the flat `all_reduce` callable)."""
         cfg, b = self.cfg, self.buf
-        noise = None
-        if cfg.noise_std > 0:
-            noise = b['noise'].normal_(0.0, cfg.noise_std)
-        rgb, _, _ = self.forward(rays_o, rays_d, bkg_color, train=True, noise=noise)
+        rgb, _, _ = self.forward(rays_o, rays_d, bkg_color, train=True, noise='auto')
         self._next_rays = next_rays
         self._prefetch_now = self.prefetch_at if (grad_sync is None and all_reduce is None) else self.prefetch_at_dist
         self._prefetch_point(0)
@@ -546,7 +555,7 @@ class NgpPipeline:
         geometry-net backward, 2 before the hash-grid scatter, 3 before the optimiser.  The marcher is pure VALU work with a
         256 KiB working set; it costs least next to the LDS / HBM-bound kernels."""
         if getattr(self, '_next_rays', None) is not None and where == self._prefetch_now:
-            self.prefetch_samples(*self._next_rays)
+            self.prefetch_samples(*self._next_rays, noise=True)
             self._next_rays = None
 
     # ---- occupancy update (VolumeBound.optimize, volume_bound.py:160-212) -----------------------------

@@ -219,6 +219,21 @@ def main():
     roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                 'frac': ach / HBM_PEAK, 'traffic': traffic, 'avg_launch_ms': ksum[dom]}
 
+    # The hash LOOKUP on its own (north_star names it): besides the algorithmic HBM accounting, the bound this gather actually
+    # sits on.  Every 8-byte corner read of a hashed level drags one 128-byte line from the XCD's L2 into the CU's L1
+    # (MI355X_MICROARCH.md: L2 ~34.5 TB/s aggregate): 16 levels x 8 corners x 128 B per sample is the line traffic if no
+    # gather hit L1; the coarse levels do hit, which is why the kernel can finish faster than that bound.
+    lookup = None
+    if ksum.get('hashgrid_fwd'):
+        occ_launch = 0 if args.no_occ_update else sum(1 for e in range(epoch0 + args.warmup, epoch0 + args.warmup + args.steps) if e % cfg.epoch_optim == 0)
+        occ_pts = cfg.n_grid ** 3 // 4 + min(cfg.n_grid ** 3 // 4, int(bf.sum()))
+        pts = (s_per_launch * args.steps + occ_pts * occ_launch) / max(1, n_launch['hashgrid_fwd'])
+        sec = ksum['hashgrid_fwd'] * 1e-3
+        l2_lines = 16 * 8 * 128.0 * pts
+        lookup = {'kernel': 'hashgrid_fwd', 'bound': 'hbm', 'achieved': BYTES_HASH_FWD * pts / sec / 1e9, 'peak': HBM_PEAK / 1e9,
+                  'unit': 'GB/s', 'frac': BYTES_HASH_FWD * pts / sec / HBM_PEAK, 'avg_launch_ms': ksum['hashgrid_fwd'],
+                  'l2_line_bytes_upper': l2_lines, 'l2_peak_GBps': 34500.0, 'l2_line_frac_upper': l2_lines / sec / 34.5e12}
+
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, field, bf, args.cpu_rays)
@@ -234,6 +249,7 @@ def main():
                    'rays_per_step_per_gpu': n_rays, 'samples_per_step_per_gpu': s_per_launch,
                    'parallelism': 'ray-sharded dp{}'.format(world)},
         'roofline': roofline,
+        'roofline_lookup': lookup,
         'cpu_baseline': cpu,
         'kernel_ms': ktable,
     }
