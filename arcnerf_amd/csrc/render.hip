@@ -112,22 +112,22 @@ __device__ __forceinline__ float alpha_at(const View &v, int64_t r, int k, float
     return 1.0f - expf(-sr * delta);
 }
 
+// ---- per-ray bodies (one wave = one ray), shared by the forward, backward and fused training kernels --------------------------
+struct RayOut {
+    float rgb[3], depth, mask, carry, t_last;
+};
+
+// forward walk of ray r: transmittance scan, weighted sums.  chunk_carry (optional, LDS row of this wave) receives the
+// transmittance at every chunk start - exactly what the backward walk needs, so the fused kernel skips its first pass.
 template <typename View>
-__global__ void __launch_bounds__(256)
-composite_fwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict__ bkg, int64_t bkg_rows, int64_t R,
-                     int white_bkg, float *__restrict__ rgb, float *__restrict__ depth, float *__restrict__ mask,
-                     float *__restrict__ alpha_out, float *__restrict__ trans_out, float *__restrict__ weights_out,
-                     int32_t *status) {
-    v.patch(p_dense_ptr);
-    const int lane = lane_id();
-    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
-    if (r >= R) return;
-    v.begin_ray(r);
-    const int nc = v.ncol(r);
+__device__ __forceinline__ RayOut composite_fwd_ray(View &v, int64_t r, int lane, int nc, const float *__restrict__ bkg,
+                                                    int64_t bkg_rows, int white_bkg, float *__restrict__ alpha_out,
+                                                    float *__restrict__ trans_out, float *__restrict__ weights_out,
+                                                    float *chunk_carry, bool &neg) {
     float carry = 1.0f;
     float acc_d = 0.f, acc_m = 0.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, t_last = 0.f;
-    bool neg = false;
     for (int base = 0; base < nc; base += 64) {
+        if (chunk_carry && lane == 0) chunk_carry[base >> 6] = carry;
         const int k = base + lane;
         const bool on = k < nc;
         float a = 0.f, q = 1.f, zz = 0.f, se;
@@ -160,8 +160,9 @@ composite_fwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict
         }
         carry = carry * __shfl(incl, 63, 64);
     }
-    acc_d = wave_sum(acc_d);
-    acc_m = wave_sum(acc_m);
+    RayOut o;
+    o.depth = wave_sum(acc_d);
+    o.mask = wave_sum(acc_m);
     acc_r = wave_sum(acc_r);
     acc_g = wave_sum(acc_g);
     acc_b = wave_sum(acc_b);
@@ -169,59 +170,56 @@ composite_fwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict
     // trans_shift[:, -1]: T at column Pe-1.  If that column is not among the visited ones every column after the
     // visited ones has q == 1 (in fp32), so it equals the running product.
     if (!(nc > 0 && v.final_visited(r))) t_last = carry;
+    o.carry = carry;
+    o.t_last = t_last;
+    const float sums[3] = {acc_r, acc_g, acc_b};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float x = sums[c];
+        if (bkg && bkg_rows > 0) x = x + t_last * bkg[(bkg_rows == 1 ? 0 : r) * 3 + c];
+        else if (white_bkg) x = x + (1.0f - o.mask);
+        o.rgb[c] = x;
+    }
+    return o;
+}
+
+template <typename View>
+__global__ void __launch_bounds__(256)
+composite_fwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict__ bkg, int64_t bkg_rows, int64_t R,
+                     int white_bkg, float *__restrict__ rgb, float *__restrict__ depth, float *__restrict__ mask,
+                     float *__restrict__ alpha_out, float *__restrict__ trans_out, float *__restrict__ weights_out,
+                     int32_t *status) {
+    v.patch(p_dense_ptr);
+    const int lane = lane_id();
+    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
+    if (r >= R) return;
+    v.begin_ray(r);
+    bool neg = false;
+    const RayOut o = composite_fwd_ray(v, r, lane, v.ncol(r), bkg, bkg_rows, white_bkg, alpha_out, trans_out, weights_out,
+                                       (float *)nullptr, neg);
     if (neg && status && lane == 0) atomicOr(status, 1);
     if (lane == 0) {
-        if (depth) depth[r] = acc_d;
-        if (mask) mask[r] = acc_m;
+        if (depth) depth[r] = o.depth;
+        if (mask) mask[r] = o.mask;
         if (rgb && v.radiance) {
-            float o[3] = {acc_r, acc_g, acc_b};
-            for (int c = 0; c < 3; ++c) {
-                float x = o[c];
-                if (bkg && bkg_rows > 0) x = x + t_last * bkg[(bkg_rows == 1 ? 0 : r) * 3 + c];
-                else if (white_bkg) x = x + (1.0f - acc_m);
-                rgb[r * 3 + c] = x;
-            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rgb[r * 3 + c] = o.rgb[c];
         }
     }
 }
 
+// reverse walk of ray r given the upstream gradients (g0,g1,g2) on rgb, gd on depth, gm on mask, gt on T_last, the
+// transmittance at every chunk start (chunk_carry) and the product over all visited columns (carry).
+// suffix_i = sum_{j>i} w_j g_j + (T_last*B if T_last depends on alpha_i); TRUE suffix sums (see the file header).
 // d_geo / d_radiance are indexed like sigma / radiance.  Entries no visited column covers are zeroed by the host wrapper
 // (dense: dropped last column) or by the ray's own wave (packed: sample n-1 of the longest rays, View::zero_dropped).
 template <typename View>
-__global__ void __launch_bounds__(256)
-composite_bwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict__ bkg, int64_t bkg_rows, int64_t R,
-                     int white_bkg, const float *__restrict__ d_rgb, const float *__restrict__ d_depth,
-                     const float *__restrict__ d_mask, const float *__restrict__ d_tlast, float *__restrict__ d_geo,
-                     float *__restrict__ d_radiance) {
-    __shared__ float s_carry[kRaysPerBlock][kMaxChunks];
-    v.patch(p_dense_ptr);
-    const int lane = lane_id();
-    const int wv = threadIdx.x >> 6;
-    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlock + wv;
-    if (r >= R) return;
-    v.begin_ray(r);
-    const int nc = v.ncol(r);
+__device__ __forceinline__ void composite_bwd_ray(View &v, int64_t r, int lane, int nc, float carry, const float *chunk_carry,
+                                                  float g0, float g1, float g2, float gd, float gm, float gt,
+                                                  const float *__restrict__ bkg, int64_t bkg_rows, int white_bkg,
+                                                  float *__restrict__ d_geo, float *__restrict__ d_radiance) {
     const int nchunk = (nc + 63) >> 6;
     bool neg = false;
-    if (lane == 0) v.zero_dropped(r, d_geo, d_radiance);
-    // pass 1: transmittance at every chunk start
-    float carry = 1.0f;
-    for (int c = 0; c < nchunk; ++c) {
-        if (lane == 0) s_carry[wv][c] = carry;
-        const int k = c * 64 + lane;
-        float q = 1.f, se;
-        if (k < nc) {
-            float dl = v.delta(r, k, neg);
-            float a = alpha_at(v, r, k, dl, &se);
-            q = (1.0f - a) + 1e-10f;
-        }
-        float incl = wave_incl_prod(q);
-        carry = carry * __shfl(incl, 63, 64);
-    }
-    __builtin_amdgcn_wave_barrier();
-    const float g0 = d_rgb ? d_rgb[3 * r] : 0.f, g1 = d_rgb ? d_rgb[3 * r + 1] : 0.f, g2 = d_rgb ? d_rgb[3 * r + 2] : 0.f;
-    const float gd = d_depth ? d_depth[r] : 0.f;
-    float gm = d_mask ? d_mask[r] : 0.f;
     const bool use_bkg = bkg && bkg_rows > 0 && v.radiance;
     if (!use_bkg && white_bkg && v.radiance) gm = gm - (g0 + g1 + g2);
     float B = 0.f;  // dL/dT_last
@@ -230,9 +228,8 @@ composite_bwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict
         B = g0 * bk[0] + g1 * bk[1] + g2 * bk[2];
     }
     // upstream gradient of T_last itself (trans_shift[:, -1]): FullModel blends a background model's colour and depth with it
-    if (d_tlast) B += d_tlast[r];
+    B += gt;
     const bool final_visited = nc > 0 && v.final_visited(r);
-    // pass 2: reverse walk.  suffix_i = sum_{j>i} w_j g_j + (T_last*B if T_last depends on alpha_i)
     float suffix_carry = 0.f;
     float virt_dgeo = 0.f, virt_w = 0.f;
     bool has_virt = false;
@@ -253,7 +250,7 @@ composite_bwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict
         float incl = wave_incl_prod(q);
         float excl = __shfl_up(incl, 1, 64);
         if (lane == 0) excl = 1.0f;
-        float T = s_carry[wv][c] * excl;
+        float T = chunk_carry[c] * excl;
         float w = a * T;
         float term = on ? w * gi : 0.f;
         // when column Pe-1 is visited, T_last = T at that column: it depends on every earlier alpha only
@@ -296,6 +293,107 @@ composite_bwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict
             atomicAdd(&d_radiance[si * 3 + 0], virt_w * g0);
             atomicAdd(&d_radiance[si * 3 + 1], virt_w * g1);
             atomicAdd(&d_radiance[si * 3 + 2], virt_w * g2);
+        }
+    }
+}
+
+template <typename View>
+__global__ void __launch_bounds__(256)
+composite_bwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict__ bkg, int64_t bkg_rows, int64_t R,
+                     int white_bkg, const float *__restrict__ d_rgb, const float *__restrict__ d_depth,
+                     const float *__restrict__ d_mask, const float *__restrict__ d_tlast, float *__restrict__ d_geo,
+                     float *__restrict__ d_radiance) {
+    __shared__ float s_carry[kRaysPerBlock][kMaxChunks];
+    v.patch(p_dense_ptr);
+    const int lane = lane_id();
+    const int wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+    if (r >= R) return;
+    v.begin_ray(r);
+    const int nc = v.ncol(r);
+    const int nchunk = (nc + 63) >> 6;
+    bool neg = false;
+    if (lane == 0) v.zero_dropped(r, d_geo, d_radiance);
+    // pass 1: transmittance at every chunk start
+    float carry = 1.0f;
+    for (int c = 0; c < nchunk; ++c) {
+        if (lane == 0) s_carry[wv][c] = carry;
+        const int k = c * 64 + lane;
+        float q = 1.f, se;
+        if (k < nc) {
+            float dl = v.delta(r, k, neg);
+            float a = alpha_at(v, r, k, dl, &se);
+            q = (1.0f - a) + 1e-10f;
+        }
+        float incl = wave_incl_prod(q);
+        carry = carry * __shfl(incl, 63, 64);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float g0 = d_rgb ? d_rgb[3 * r] : 0.f, g1 = d_rgb ? d_rgb[3 * r + 1] : 0.f, g2 = d_rgb ? d_rgb[3 * r + 2] : 0.f;
+    // pass 2: reverse walk
+    composite_bwd_ray(v, r, lane, nc, carry, s_carry[wv], g0, g1, g2, d_depth ? d_depth[r] : 0.f, d_mask ? d_mask[r] : 0.f,
+                      d_tlast ? d_tlast[r] : 0.f, bkg, bkg_rows, white_bkg, d_geo, d_radiance);
+}
+
+// ---- fused training step of the compositor: forward + ImgLoss(Huber) + backward in ONE pass per ray ------------------------
+// The Huber gradient of a ray depends on that ray's colour only (d loss / d rgb = huber'(rgb - target) * weight / (3R)), so the
+// wave that composited ray r can walk it backwards right away: one launch instead of compositing, loss and backward kernels
+// plus a memset, the per-chunk transmittances are kept from the forward walk, and the inputs are read while still in cache.
+// loss_acc += this launch's loss (one atomic per workgroup); loss_clear (optional) is zeroed for the NEXT launch to use.
+template <typename View>
+__global__ void __launch_bounds__(256)
+composite_train_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict__ bkg, int64_t bkg_rows, int64_t R,
+                       int white_bkg, const float *__restrict__ target, float delta, float weight, float *__restrict__ rgb,
+                       float *__restrict__ depth, float *__restrict__ mask, float *__restrict__ d_rgb,
+                       float *__restrict__ loss_acc, float *__restrict__ loss_clear, float *__restrict__ d_geo,
+                       float *__restrict__ d_radiance) {
+    __shared__ float s_carry[kRaysPerBlock][kMaxChunks];
+    __shared__ float s_loss[kRaysPerBlock];
+    v.patch(p_dense_ptr);
+    const int lane = lane_id();
+    const int wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss_clear) *loss_clear = 0.f;
+    float my_loss = 0.f;
+    if (r < R) {
+        v.begin_ray(r);
+        const int nc = v.ncol(r);
+        bool neg = false;
+        if (lane == 0) v.zero_dropped(r, d_geo, d_radiance);
+        const RayOut o = composite_fwd_ray(v, r, lane, nc, bkg, bkg_rows, white_bkg, (float *)nullptr, (float *)nullptr,
+                                           (float *)nullptr, s_carry[wv], neg);
+        __builtin_amdgcn_wave_barrier();
+        // arcnerf/loss/img_loss.py:60-100, mean over all R*3 elements, times weight (same arithmetic as huber_kernel)
+        const float scale = weight / (float)(R * 3);
+        float g[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float d = o.rgb[c] - target[3 * r + c];
+            const float ad = fabsf(d);
+            const bool quad = ad < delta;
+            my_loss += (quad ? (0.5f / delta) * ad * ad : ad - 0.5f * delta) * scale;
+            g[c] = (quad ? d / delta : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f))) * scale;
+        }
+        if (lane == 0) {
+            if (depth) depth[r] = o.depth;
+            if (mask) mask[r] = o.mask;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (rgb) rgb[r * 3 + c] = o.rgb[c];
+                if (d_rgb) d_rgb[r * 3 + c] = g[c];
+            }
+        }
+        composite_bwd_ray(v, r, lane, nc, o.carry, s_carry[wv], g[0], g[1], g[2], 0.f, 0.f, 0.f, bkg, bkg_rows, white_bkg, d_geo,
+                          d_radiance);
+    }
+    if (loss_acc) {
+        if (lane == 0) s_loss[wv] = my_loss;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < kRaysPerBlock; ++k) t += s_loss[k];
+            if (t != 0.f) atomicAdd(loss_acc, t);
         }
     }
 }
@@ -481,6 +579,27 @@ ARCN_EXPORT int arcn_composite_packed_fwd(const float *sigma, const float *radia
     hipLaunchKernelGGL(composite_fwd_kernel<PackedView>, grid, dim3(256), 0, as_stream(stream), v, p_dense_ptr, bkg,
                        bkg_rows, R, white_bkg, rgb, depth, mask, nullptr, nullptr, weights_out, nullptr);
     return check_launch("composite_packed_fwd");
+}
+
+ARCN_EXPORT int arcn_composite_packed_train(const float *sigma, const float *radiance, const float *t_packed, const int32_t *offsets,
+                                            const float *noise, const float *bkg, int64_t bkg_rows, int64_t R, int p_dense,
+                                            const int32_t *p_dense_ptr, int add_inf_z, int white_bkg, const float *target,
+                                            float huber_delta, float loss_weight, float *rgb, float *depth, float *mask,
+                                            float *d_rgb, float *loss_acc, float *loss_clear, float *d_sigma, float *d_radiance,
+                                            void *stream) {
+    if (R <= 0) return ARCN_OK;
+    if (!sigma || !radiance || !t_packed || !offsets || !target || !d_sigma || !d_radiance)
+        return einval("composite_packed_train: missing argument");
+    if (!(bkg_rows == 0 || bkg_rows == 1 || bkg_rows == R)) return einval("composite_packed_train: bkg rows must be 0/1/R");
+    if (!(huber_delta > 0.f)) return einval("composite_packed_train: huber delta must be positive");
+    if (p_dense < 2) p_dense = 2;
+    if ((add_inf_z ? p_dense : p_dense - 1) > 64 * kMaxChunks) return einval("composite_packed_train: at most 4096 samples per ray");
+    PackedView v{sigma, nullptr, radiance, t_packed, noise, offsets, p_dense, add_inf_z ? p_dense : p_dense - 1, add_inf_z};
+    dim3 grid((unsigned)ceil_div<int64_t>(R, kRaysPerBlock));
+    hipLaunchKernelGGL(composite_train_kernel<PackedView>, grid, dim3(256), 0, as_stream(stream), v, p_dense_ptr, bkg, bkg_rows, R,
+                       white_bkg, target, huber_delta, loss_weight, rgb, depth, mask, d_rgb, loss_acc, loss_clear, d_sigma,
+                       d_radiance);
+    return check_launch("composite_packed_train");
 }
 
 ARCN_EXPORT int arcn_composite_packed_bwd(const float *sigma, const float *radiance, const float *t_packed,

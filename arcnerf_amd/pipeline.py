@@ -241,6 +241,11 @@ class NgpPipeline:
         b['mask'] = torch.zeros(R, dtype=f32, device=dev)
         b['d_rgb'] = torch.zeros((R, 3), dtype=f32, device=dev)
         b['loss'] = torch.zeros(1, dtype=f32, device=dev)
+        # fused compositor: loss of step k accumulates in slot k % 1024 (the kernel clears the next slot), so the tensor returned
+        # by train_step stays valid for the following 1000 steps without a copy
+        b['loss_ring'] = torch.zeros(1024, dtype=f32, device=dev)
+        self._loss_slot = 0
+        self.fused_composite = bool(int(os.environ.get('ARCN_FUSED_COMPOSITE', '1')))
         # XCD-owned-levels scatter workspace (owner + tile counters); None selects the plain agent-scope kernel
         self.hash_ws = F.hashgrid_bwd_workspace(self.field.grid_desc, S, dev) if xcd_scatter else None  # scatter bins
         # level-major features between the hash grid and the geometry net (XCD-affine gather, coalesced everywhere): the shapes
@@ -396,8 +401,10 @@ class NgpPipeline:
         if self.ray_sh:
             N.check(L.arcn_ngp_ray_sh(N.ptr(rays_d), cfg.sh_degree, N.ptr(b['sh_ray']), R, st), 'ngp_ray_sh')
 
-    def forward(self, rays_o, rays_d, bkg_color=None, train=False, noise=None):
-        """Render rays: returns rgb (R,3), depth (R), mask (R) views of the internal buffers."""
+    def forward(self, rays_o, rays_d, bkg_color=None, train=False, noise=None, huber_target=None):
+        """Render rays: returns rgb (R,3), depth (R), mask (R) views of the internal buffers.
+        huber_target (R,3), training only: compositing, the Huber image loss and the compositor's backward run as ONE kernel; the
+        loss lands in self.last_loss and backward() starts at the radiance net."""
         cfg, b, fld = self.cfg, self.buf, self.field
         R = rays_o.shape[0]
         rays_o, rays_d = rays_o.contiguous().float(), rays_d.contiguous().float()
@@ -442,6 +449,19 @@ class NgpPipeline:
         bk, bk_rows = (None, 0) if bkg_color is None else (bkg_color.contiguous().float().view(-1, 3), bkg_color.view(-1, 3).shape[0])
         self._bkg = bk
         self._noise = noise
+        self._composite_bwd_done = False
+        if huber_target is not None and train:
+            ring, k = b['loss_ring'], self._loss_slot
+            self._loss_slot = (k + 1) % ring.numel()
+            N.check(L.arcn_composite_packed_train(N.ptr(b['sigma']), N.ptr(b['rgb_s']), N.ptr(b['t']), N.ptr(b['offsets']), N.ptr(noise),
+                                                  N.ptr(bk), bk_rows, R, 2, b['p_dense'].data_ptr(), int(cfg.add_inf_z),
+                                                  int(cfg.white_bkg), N.ptr(huber_target.contiguous().float()), cfg.huber_delta,
+                                                  cfg.loss_weight, N.ptr(b['rgb']), N.ptr(b['depth']), N.ptr(b['mask']), N.ptr(b['d_rgb']),
+                                                  ring[k:k + 1].data_ptr(), ring[self._loss_slot:self._loss_slot + 1].data_ptr(),
+                                                  N.ptr(b['d_sigma']), N.ptr(b['d_rgb_s']), st), 'composite_packed_train')
+            self.last_loss = ring[k]
+            self._composite_bwd_done = True
+            return b['rgb'][:R], b['depth'][:R], b['mask'][:R]
         N.check(L.arcn_composite_packed_fwd(N.ptr(b['sigma']), N.ptr(b['rgb_s']), N.ptr(b['t']), N.ptr(b['offsets']),
                                             N.ptr(noise), N.ptr(bk), bk_rows, R, 2, b['p_dense'].data_ptr(),
                                             int(cfg.add_inf_z), int(cfg.white_bkg), N.ptr(b['rgb']), N.ptr(b['depth']),
@@ -457,10 +477,12 @@ class NgpPipeline:
         n_dev = self.n_dev
         bk = self._bkg
         bk_rows = 0 if bk is None else bk.shape[0]
-        N.check(L.arcn_composite_packed_bwd(N.ptr(b['sigma']), N.ptr(b['rgb_s']), N.ptr(b['t']), N.ptr(b['offsets']),
-                                            N.ptr(self._noise), N.ptr(bk), bk_rows, R, 2, b['p_dense'].data_ptr(),
-                                            int(cfg.add_inf_z), int(cfg.white_bkg), N.ptr(d_rgb), N.ptr(d_depth), N.ptr(d_mask),
-                                            N.ptr(b['d_sigma']), N.ptr(b['d_rgb_s']), st), 'composite_packed_bwd')
+        if not getattr(self, '_composite_bwd_done', False):   # the fused compositor already produced d_sigma / d_rgb_s
+            N.check(L.arcn_composite_packed_bwd(N.ptr(b['sigma']), N.ptr(b['rgb_s']), N.ptr(b['t']), N.ptr(b['offsets']),
+                                                N.ptr(self._noise), N.ptr(bk), bk_rows, R, 2, b['p_dense'].data_ptr(),
+                                                int(cfg.add_inf_z), int(cfg.white_bkg), N.ptr(d_rgb), N.ptr(d_depth), N.ptr(d_mask),
+                                                N.ptr(b['d_sigma']), N.ptr(b['d_rgb_s']), st), 'composite_packed_bwd')
+        self._composite_bwd_done = False
         S = self.cap
         # dx and dW of each net come out of ONE fused kernel (arcn_mlp_bwd with dweights): dpre never leaves the registers
         if self.fused_glue:
@@ -530,11 +552,15 @@ class NgpPipeline:
         next_rays = (rays_o, rays_d) of the FOLLOWING step: their marching is overlapped with this step's backward.
         grad_sync: a distributed.PipelinedGradSync (takes precedence over the flat `all_reduce` callable)."""
         cfg, b = self.cfg, self.buf
-        rgb, _, _ = self.forward(rays_o, rays_d, bkg_color, train=True, noise='auto')
+        fused = self.fused_composite
+        rgb, _, _ = self.forward(rays_o, rays_d, bkg_color, train=True, noise='auto', huber_target=target_rgb if fused else None)
         self._next_rays = next_rays
         self._prefetch_now = self.prefetch_at if (grad_sync is None and all_reduce is None) else self.prefetch_at_dist
         self._prefetch_point(0)
-        loss, d_rgb = self.huber_grad(rgb, target_rgb)
+        if fused:
+            loss, d_rgb = self.last_loss, b['d_rgb'][:rays_o.shape[0]]
+        else:
+            loss, d_rgb = self.huber_grad(rgb, target_rgb)
         self.backward(rays_o, rays_d, d_rgb)
         if grad_sync is not None:
             # segmented all-reduce pipelined with the optimiser (distributed.PipelinedGradSync)

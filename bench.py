@@ -42,7 +42,7 @@ def parse():
 
 
 ROOFLINE_KERNELS = ('hashgrid_fwd', 'hashgrid_bwd')
-TABLE_KERNELS = ROOFLINE_KERNELS + ('mlp_fwd', 'mlp_bwd', 'mlp_bwd_dw', 'march_count', 'composite_packed_fwd',
+TABLE_KERNELS = ROOFLINE_KERNELS + ('mlp_fwd', 'mlp_bwd', 'mlp_bwd_dw', 'march_count', 'composite_packed_train', 'composite_packed_fwd',
                                     'composite_packed_bwd', 'adam_ema_step')
 
 
