@@ -374,7 +374,6 @@ __device__ __forceinline__ void overflow_add(float *__restrict__ dtable, const L
     if (F > 1) unsafeAtomicAdd(d + (F > 1 ? 1 : 0), a1);
 }
 
-constexpr int kBinThreads = 1024;  // samples per producer tile
 
 // place one record at position pos of its bin; beyond the bin's capacity it is applied to dtable directly
 template <int F>
@@ -396,7 +395,7 @@ __device__ __forceinline__ void emit_record(uint4 *__restrict__ lrecs, float *__
 // integer atomic per bin -> barrier -> stores) and its ~90 VGPRs allow one 1024-thread workgroup per CU.  Staging the
 // records in LDS to write them out bin-sorted (coalesced) was tried and is slower: the extra barrier and scan lengthen
 // exactly that chain (212 us against 140 us).
-template <int F>
+template <int F, int kBinThreads>
 __global__ void __launch_bounds__(kBinThreads)
 scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout, int64_t dout_lm_stride, GridParams g,
                    BinPlan plan, uint32_t *__restrict__ counters, uint4 *__restrict__ recs, float *__restrict__ dtable, int64_t n,
@@ -846,17 +845,24 @@ static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *
             : hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_accum_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
         static const int bin_wgs = [] { const char *e = getenv("ARCN_SCATTER_BIN_WGS"); return e ? atoi(e) : 32; }();
-        int64_t bx = ceil_div<int64_t>(n, kBinThreads);
-        if (bx > bin_wgs) bx = bin_wgs;  // persistent workgroups per level
+        // producer workgroup size = samples per tile.  The kernel needs ~124 VGPRs, so a 1024-thread workgroup owns a whole CU;
+        // two 512-thread workgroups per CU (covering each other's barrier phases) measured SLOWER, 0.262 vs 0.249 ms for the
+        // whole scatter (twice the per-bin global atomics, half the run length per bin): ARCN_SCATTER_BIN_THREADS=512 keeps it
+        static const int bin_threads = [] { const char *e = getenv("ARCN_SCATTER_BIN_THREADS"); int v = e ? atoi(e) : 1024; return v == 512 ? 512 : 1024; }();
+        int64_t bx = ceil_div<int64_t>(n, bin_threads);
+        const int64_t wgs = (int64_t)bin_wgs * (1024 / bin_threads);
+        if (bx > wgs) bx = wgs;  // persistent workgroups per level
         dim3 bgrid((unsigned)bx, (unsigned)g.L);
         dim3 agrid((unsigned)plan.item_first[g.L]);
+#define ARCN_BIN(F_, T_) hipLaunchKernelGGL((scatter_bin_kernel<F_, T_>), bgrid, dim3(T_), 0, as_stream(stream), xyz, dout, dout_lm_stride, g, plan, counters, recs, dtable, n, n_ptr)
         if (g.F == 1) {
-            hipLaunchKernelGGL(scatter_bin_kernel<1>, bgrid, dim3(kBinThreads), 0, as_stream(stream), xyz, dout, dout_lm_stride, g, plan, counters, recs, dtable, n, n_ptr);
+            if (bin_threads == 1024) ARCN_BIN(1, 1024); else ARCN_BIN(1, 512);
             hipLaunchKernelGGL(scatter_accum_kernel<1>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable);
         } else {
-            hipLaunchKernelGGL(scatter_bin_kernel<2>, bgrid, dim3(kBinThreads), 0, as_stream(stream), xyz, dout, dout_lm_stride, g, plan, counters, recs, dtable, n, n_ptr);
+            if (bin_threads == 1024) ARCN_BIN(2, 1024); else ARCN_BIN(2, 512);
             hipLaunchKernelGGL(scatter_accum_kernel<2>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable);
         }
+#undef ARCN_BIN
         return check_launch("hashgrid_bwd_binned");
     }
     if (dout_lm_stride) return einval("hashgrid_bwd_lm: needs a workspace, dtable only, n_feat 1 or 2");
