@@ -364,6 +364,7 @@ struct BinPlan {
     uint32_t nosplit_levels;                  // chunk rows > res on a hashed level: both rows of an x pair ALWAYS share the chunk
     int32_t n_bins;
     int32_t chunk_floats;                     // LDS accumulator floats per workgroup (rows per chunk * F)
+    int32_t use_cas;                          // consumer, F = 2: 64-bit compare-and-swap on the row instead of the bit lock
     int64_t n_recs;
 };
 
@@ -400,8 +401,10 @@ __global__ void __launch_bounds__(kBinThreads)
 scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout, int64_t dout_lm_stride, GridParams g,
                    BinPlan plan, uint32_t *__restrict__ counters, uint4 *__restrict__ recs, float *__restrict__ dtable, int64_t n,
                    const int32_t *n_ptr) {
-    __shared__ uint32_t hist[kMaxChunks];   // records of this tile per bin
-    __shared__ uint32_t gbase[kMaxChunks];  // first position of the tile's run in every bin
+    // hist: records of this tile per bin; gbase: first position of the tile's run in every bin.  Both double-buffered over the
+    // tiles: the other buffer's histogram is cleared while this tile reserves its runs, so a tile costs two barriers, not four.
+    __shared__ uint32_t hist2[2][kMaxChunks];
+    __shared__ uint32_t gbase2[2][kMaxChunks];
     const int64_t cnt = dev_count(n, n_ptr);
     const int l = blockIdx.y;
     if (!((plan.active_levels >> l) & 1u)) return;
@@ -409,11 +412,13 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
     const int nc = plan.n_chunks[l], shift = plan.chunk_shift[l];
     const uint32_t cmask = (1u << shift) - 1u;
     const int t = threadIdx.x, lane = t & 63;
+    for (int i = threadIdx.x; i < nc; i += kBinThreads) hist2[0][i] = 0u;
+    __syncthreads();
+    int buf = 0;
     // Persistent over the level's tiles: a tile keeps a wave busy for ~3 us only, and one workgroup per tile left the chip at
     // ~20 % wave occupancy waiting for the dispatcher (SQ_WAVE_CYCLES / duration); gridDim.x workgroups per level loop instead.
-    for (int64_t tile0 = (int64_t)blockIdx.x * kBinThreads; tile0 < cnt; tile0 += (int64_t)gridDim.x * kBinThreads) {
-    for (int i = threadIdx.x; i < nc; i += kBinThreads) hist[i] = 0u;
-    __syncthreads();
+    for (int64_t tile0 = (int64_t)blockIdx.x * kBinThreads; tile0 < cnt; tile0 += (int64_t)gridDim.x * kBinThreads, buf ^= 1) {
+    uint32_t *hist = hist2[buf], *gbase = gbase2[buf];
     const int64_t s = tile0 + t;
     int sbin[8];
     uint32_t sidx[8];
@@ -537,10 +542,11 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
 #pragma unroll
     for (int k = 0; k < 8; ++k) rank[k] = (k < n_slots && sbin[k] >= 0) ? atomicAdd(&hist[sbin[k]], 1u) : 0u;
     __syncthreads();
-    // reserve the tile's run in every bin: one global integer atomic per (bin, tile)
+    // reserve the tile's run in every bin: one global integer atomic per (bin, tile); clear the NEXT tile's histogram
     for (int i = threadIdx.x; i < nc; i += kBinThreads) {
         const uint32_t h = hist[i];
         gbase[i] = h ? atomicAdd(&counters[plan.bin_first[l] + i], h) : 0u;
+        hist2[buf ^ 1][i] = 0u;
     }
     __syncthreads();
     const uint32_t cap = (uint32_t)plan.cap[l];
@@ -551,7 +557,8 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
         const uint4 rec = make_uint4(sidx[k], __float_as_uint(swx[k]), __float_as_uint(sa[k]), __float_as_uint(sb[k]));
         emit_record<F>(lrecs, dtable, lp, sbin[k], gbase[sbin[k]] + rank[k], cap, shift, rec);
     }
-    __syncthreads();  // hist / gbase are reused by the next tile
+    // no barrier here: the next tile counts into the other histogram and reserves into the other gbase; this tile's gbase is
+    // overwritten two tiles later, behind two more barriers
     }
 }
 
@@ -612,7 +619,34 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
             const bool have = i0 != 0xffffu;
             const float wx = __uint_as_float(r.y), a0 = __uint_as_float(r.z), a1 = __uint_as_float(r.w);
             const float wl = 1.0f - wx;
-            if (locked) {
+            if (locked && F == 2 && plan.use_cas) {
+                // lock-free: read the 8-byte row, add, 64-bit compare-and-swap; two LDS operations per row update when nobody
+                // interferes (the bit lock needs four: or, read, write, and).  The comparison is bitwise, so NaNs and signed
+                // zeros are handled; a lost race just retries with the value the swap returned.
+                unsigned long long *rows = reinterpret_cast<unsigned long long *>(acc);
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const uint32_t tgt = side ? i1 : i0;
+                    const float wt = side ? wx : wl;
+                    if (have && tgt != 0xffffu) {
+                        const float va = a0 * wt, vb = a1 * wt;
+                        unsigned long long *cell = rows + tgt;
+                        // first guess: the row is still zero (true for its first update, and then ONE operation does it); a wrong
+                        // guess costs what the explicit read would have cost, the failed swap returns the current value
+                        unsigned long long seen = plan.use_cas == 2 ? *cell : 0ull;
+                        while (true) {
+                            float2 v = __builtin_bit_cast(float2, seen);
+                            v.x += va;
+                            v.y += vb;
+                            unsigned long long expect = seen;
+                            if (__hip_atomic_compare_exchange_strong(cell, &expect, __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                                break;
+                            seen = expect;
+                        }
+                    }
+                }
+            } else if (locked) {
                 int todo = have ? (i1 != 0xffffu ? 2 : 1) : 0;
                 uint32_t tgt = i0;
                 float va = a0 * wl, vb = a1 * wl;
@@ -730,6 +764,7 @@ static int build_bin_plan(const GridParams &g, int64_t n, BinPlan &plan) {
         return (v >= 1024 && v <= kChunkFloats && !(v & (v - 1))) ? v : kChunkFloats;
     }();
     plan.chunk_floats = chunk_floats;
+    { static const int cas = [] { const char *e = getenv("ARCN_SCATTER_CAS"); return e ? atoi(e) : 1; }(); plan.use_cas = cas; }
     const int rows_cap = chunk_floats / g.F;
     int bins = 0;
     int64_t recs = 0;
