@@ -184,3 +184,32 @@ def test_neus_yaml_builds_and_loads_reference_state_dict():
     m.load_state_dict(sd, strict=True)
     assert abs(float(fg.forward_scale()) - float(g['train_scale'])) < 1e-4
     assert fg.get_cos_anneal(25000) == 0.5 and fg.get_cos_anneal(10 ** 6) == 1.0
+
+
+def test_checkpoint_round_trip_in_the_reference_format(tmp_path):
+    """model_io: the `*.pt.tar` dict of common/utils/model_io.py - save, partial load with a size mismatch, resume of epoch/optimizer"""
+    import torch
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.utils.cfgs_utils import dict_to_obj, load_configs
+    from arcnerf_amd.utils.model_io import load_model, save_model
+    ov = ['--model.geometry.W', '32', '--model.geometry.W_feat', '32', '--model.radiance.W', '16', '--model.radiance.W_feat_in', '32']
+    m = build_model(load_configs(os.path.join(CFG, 'nerf.yaml'), ov))
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    run = dict_to_obj({'dist': {'world_size': 1}, 'progress': {'start_epoch': -1}})
+    path = save_model(None, m, opt, 7, 0.5, str(tmp_path), run)
+    assert path.endswith('model_epoch007.pt.tar')
+    ck = torch.load(path, map_location='cpu')
+    assert set(ck) == {'epoch', 'state_dict', 'optimizer', 'loss'} and not any(k.startswith('module.') for k in ck['state_dict'])
+    m2 = build_model(load_configs(os.path.join(CFG, 'nerf.yaml'), ov))
+    opt2 = torch.optim.Adam(m2.parameters(), lr=1e-3)
+    load_model(None, m2, opt2, path, run, strict=True)
+    assert run.progress.start_epoch == 7
+    for (k, a), (_, b_) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b_), k
+    # a model with another width takes what fits and reports the rest
+    m3 = build_model(load_configs(os.path.join(CFG, 'nerf.yaml'), ov[:-1] + ['32', '--model.radiance.W', '24']))
+    log = []
+    logger = type('L', (), {'add_log': lambda self, msg, level='info': log.append((level, msg))})()
+    load_model(logger, m3, None, save_model(None, m, opt, 1, 0.0, str(tmp_path), run, spec_name='final'), dict_to_obj({'dist': {'world_size': 1}}))
+    assert any(lv == 'warning' and 'size mismatch' in msg for lv, msg in log)
+    assert torch.equal(m3.state_dict()['fg_model.coarse_geo_net.layers.0.weight'], m.state_dict()['fg_model.coarse_geo_net.layers.0.weight'])
