@@ -918,15 +918,20 @@ static int set_lds(Kern k, size_t bytes) {
     return ARCN_OK;
 }
 
-inline unsigned tile_grid(int64_t n, int spb) {
+inline unsigned tile_grid(int64_t n, int spb, bool forward = false) {
     int64_t b = ceil_div<int64_t>(n, spb);
-    static int64_t cap = 0;  // resident workgroups re-use the staged weights across tiles
+    static int64_t cap = 0, cap_fwd = 0;  // resident workgroups re-use the staged weights across tiles
     if (!cap) {
         const char *e = getenv("ARCN_MLP_GRID");
         cap = e ? atoll(e) : 512;
         if (cap < 1) cap = 1024;
+        // the specialised forward kernels need 164 VGPRs: three waves per SIMD fit, i.e. three workgroups per CU
+        const char *f = getenv("ARCN_MLP_GRID_FWD");
+        cap_fwd = f ? atoll(f) : cap;
+        if (cap_fwd < 1) cap_fwd = cap;
     }
-    return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
+    const int64_t c = forward ? cap_fwd : cap;
+    return (unsigned)(b > c ? c : (b < 1 ? 1 : b));
 }
 
 }  // namespace arcn
@@ -986,7 +991,7 @@ static int mlp_fwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
 #define ARCN_FIXED(T0, T1, T2, T3, XMODE)                                                                                        \
     do {                                                                                                                         \
         if ((rc = set_lds(mlp_fwd_fixed_kernel<T0, T1, T2, T3, 2, XMODE>, lds_bytes))) return rc;                                 \
-        hipLaunchKernelGGL((mlp_fwd_fixed_kernel<T0, T1, T2, T3, 2, XMODE>), dim3(tile_grid(n, 128)), dim3(256), lds_bytes,       \
+        hipLaunchKernelGGL((mlp_fwd_fixed_kernel<T0, T1, T2, T3, 2, XMODE>), dim3(tile_grid(n, 128, true)), dim3(256), lds_bytes,       \
                            as_stream(stream), x, x_stride, cat, weights, P, out, acts, n_cap, n, n_ptr);                          \
         return check_launch("mlp_fwd_fixed");                                                                                    \
     } while (0)

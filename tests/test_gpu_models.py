@@ -633,3 +633,56 @@ def test_surface_render_matches_reference(gpu):
     with pytest.raises(NotImplementedError):
         from arcnerf_amd.geometry.ray import surface_ray_intersection
         surface_ray_intersection(inputs['rays_o'][0], inputs['rays_d'][0], None, method='bisection')
+
+
+def test_neus_ngp_with_fused_radiance_net_second_order(gpu):
+    """the reference's dtu_65_neus_ngp.yaml shape: sdf net = hash encoder + nn.Linear (second order through the encoder), radiance
+    = FusedMLPRadianceNet in mode 'pvnf' fed with the NORMALS - the rgb loss reaches the table through the fused net's input
+    gradient and the encoder's double backward.  Checked against finite differences of the loss along a random table direction."""
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    ov = ['--model.obj_bound.volume.n_grid', '16', '--model.rays.n_sample', '48', '--model.rays.n_importance', '0',
+          '--model.geometry.encoder.n_levels', '4', '--model.geometry.encoder.hashmap_size', '10', '--model.geometry.encoder.max_res', '32',
+          '--model.geometry.encoder.base_res', '4', '--model.radiance.type', 'FusedMLPRadianceNet', '--model.background.type', 'NeRFPP']
+    import copy
+    cfgs = load_configs(os.path.join(CFG, 'neus_ngp_multivol.yaml'), ov)
+    del cfgs.model.__dict__['background']   # foreground only
+    torch.manual_seed(5)
+    m = build_model(cfgs).to(gpu)
+    assert type(m.fg_model.radiance_net).__name__ == 'FusedMLPRadianceNet' and m.fg_model.radiance_net.mode == 'pvnf'
+    table = m.fg_model.geo_net.embed_fn.embeddings
+    with torch.no_grad():
+        table.copy_((torch.rand_like(table) - 0.5) * 0.2)
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    from arcnerf_amd.pipeline import synthetic_rays
+    o, d = synthetic_rays(256, seed=2, device=gpu)
+    inputs = {'rays_o': (o * 0.4).view(1, -1, 3).contiguous(), 'rays_d': d.view(1, -1, 3), 'rays_r': torch.zeros(1, 256, 1, device=gpu),
+              'bkg_color': torch.zeros(1, 256, 3, device=gpu)}
+    tgt = (inputs['rays_d'] * 0.5 + 0.5).clamp(0, 1)
+    m.fg_model.set_ray_cfgs('perturb', False)
+
+    def loss_fn():
+        sampler_rng(reset=True)   # same samples every evaluation
+        out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=20000)
+        return ((out['rgb'] - tgt) ** 2).mean() + 0.1 * ((out['normal_pts'].norm(dim=-1) - 1.0) ** 2).mean()
+
+    loss = loss_fn()
+    m.zero_grad()
+    loss.backward()
+    g = table.grad.clone()
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+    for p in m.parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all()
+    # directional derivative along the (normalised) gradient itself, central differences in float32
+    direction = g / g.norm()
+    eps = 2e-3
+    with torch.no_grad():
+        table.add_(eps * direction)
+        lp = float(loss_fn())
+        table.sub_(2 * eps * direction)
+        lm = float(loss_fn())
+        table.add_(eps * direction)
+    fd, an = (lp - lm) / (2 * eps), float((g * direction).sum())
+    assert abs(fd - an) <= 0.05 * abs(an) + 1e-4, (fd, an)
+    sampler_rng(reset=True)
