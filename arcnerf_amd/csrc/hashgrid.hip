@@ -145,6 +145,26 @@ __global__ void __launch_bounds__(256) hashgrid_fwd_kernel(const float *__restri
     }
 }
 
+// Sum the per-level contributions to a sample's 3-vector and add it to out[3*s..]: one lane per (sample, level) with the L levels
+// of a sample in consecutive lanes.  When L is a power of two (<= 64) the L lanes sit in one wavefront: butterfly reduce, the
+// level-0 lane adds with a plain read-modify-write (single owner) - otherwise one float atomic per lane and component.
+// Every lane of the group must call this (contribute zeros instead of returning early).
+__device__ __forceinline__ void add_over_levels(float *__restrict__ out, int64_t s, int l, int L, float v[3]) {
+    if ((L & (L - 1)) == 0 && L <= 64) {
+        for (int off = 1; off < L; off <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] += __shfl_xor(v[k], off, 64);
+        }
+        if (l == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) out[3 * s + k] += v[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) unsafeAtomicAdd(&out[3 * s + k], v[k]);
+    }
+}
+
 template <int F>
 __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(const float *__restrict__ xyz, const float *__restrict__ table,
                                                            const float *__restrict__ dout, GridParams g,
@@ -158,13 +178,13 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(const float *__restri
     const LevelParams lp = g.lv[l];
     const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
     const Cell cell = locate(p, g, lp);
-    if (!cell.valid) return;
     float go[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) go[f] = dout[gid * F + f];
     float gx[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
+        if (!cell.valid) break;
         const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
         const int64_t row = (int64_t)hash_row(cell.c[0] + ox, cell.c[1] + oy, cell.c[2] + oz, lp) + lp.offset;
         float wx = ox ? cell.w[0] : 1.0f - cell.w[0];
@@ -185,10 +205,7 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(const float *__restri
             gx[2] += dot * wx * wy * sz * cell.dw[2];
         }
     }
-    if (dxyz) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) unsafeAtomicAdd(&dxyz[3 * s + k], gx[k]);
-    }
+    if (dxyz) add_over_levels(dxyz, s, l, g.L, gx);
 }
 
 // ---- second order: the input gradient dx = J(x; table)^T dout differentiated once more ---------------------------------
@@ -215,6 +232,7 @@ hashgrid_bwd_bwd_kernel(const float *__restrict__ xyz, const float *__restrict__
     float acc[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) acc[f] = 0.f;
+    float hsum[3] = {0.f, 0.f, 0.f};
     if (cell.valid) {
         const float gd[3] = {gdx[3 * s], gdx[3 * s + 1], gdx[3 * s + 2]};
         float go[F];
@@ -246,11 +264,9 @@ hashgrid_bwd_bwd_kernel(const float *__restrict__ xyz, const float *__restrict__
             hx[1] += dot * sd[1] * (gd[0] * sd[0] * a[2] + gd[2] * a[0] * sd[2]);
             hx[2] += dot * sd[2] * (gd[0] * sd[0] * a[1] + gd[1] * a[0] * sd[1]);
         }
-        if (d2xyz) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) unsafeAtomicAdd(&d2xyz[3 * s + k], hx[k]);
-        }
+        hsum[0] = hx[0]; hsum[1] = hx[1]; hsum[2] = hx[2];
     }
+    if (d2xyz) add_over_levels(d2xyz, s, l, g.L, hsum);
     if (ddout) {
 #pragma unroll
         for (int f = 0; f < F; ++f) ddout[gid * F + f] = acc[f];
@@ -559,6 +575,81 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
     }
     // no barrier here: the next tile counts into the other histogram and reserves into the other gbase; this tile's gbase is
     // overwritten two tiles later, behind two more barriers
+    }
+}
+
+// Producer of the SECOND-ORDER table scatter (arcn_hashgrid_bwd_bwd): dtable[r_q] += dout * D_q with the derivative weights
+// D_q = sum_k gdx_k dW_q/dp_k.  D has no (x pair) x (yz) product structure, so every corner goes out as a single-row record
+// {row, wx = 0, dout0 * D, dout1 * D}: 8 records per (sample, level), the bins of a plan built for twice the samples.  Same
+// ranking scheme as scatter_bin_kernel (LDS histogram, one global integer atomic per bin and tile), same consumer.
+template <int F>
+__global__ void __launch_bounds__(1024)
+scatter_bin_dir_kernel(const float *__restrict__ xyz, const float *__restrict__ gdx, const float *__restrict__ dout, GridParams g,
+                       BinPlan plan, uint32_t *__restrict__ counters, uint4 *__restrict__ recs, float *__restrict__ dtable, int64_t n,
+                       const int32_t *n_ptr) {
+    __shared__ uint32_t hist2[2][kMaxChunks];
+    __shared__ uint32_t gbase2[2][kMaxChunks];
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int l = blockIdx.y;
+    if (!((plan.active_levels >> l) & 1u)) return;
+    const LevelParams lp = g.lv[l];
+    const int nc = plan.n_chunks[l], shift = plan.chunk_shift[l];
+    const uint32_t cmask = (1u << shift) - 1u;
+    for (int i = threadIdx.x; i < nc; i += 1024) hist2[0][i] = 0u;
+    __syncthreads();
+    int buf = 0;
+    for (int64_t tile0 = (int64_t)blockIdx.x * 1024; tile0 < cnt; tile0 += (int64_t)gridDim.x * 1024, buf ^= 1) {
+        uint32_t *hist = hist2[buf], *gbase = gbase2[buf];
+        const int64_t s = tile0 + threadIdx.x;
+        int sbin[8];
+        uint32_t sidx[8], rank[8];
+        float sa[8], sb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sbin[q] = -1;
+        if (s < cnt) {
+            const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
+            const Cell cell = locate(p, g, lp);
+            if (cell.valid) {
+                const float gd[3] = {gdx[3 * s], gdx[3 * s + 1], gdx[3 * s + 2]};
+                const float *gp = dout + (s * g.L + l) * F;
+                const float g0 = gp[0], g1 = F > 1 ? gp[F > 1 ? 1 : 0] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint32_t o[3] = {(uint32_t)((q >> 1) & 1), (uint32_t)(q & 1), (uint32_t)(q >> 2)};
+                    const uint32_t r = hash_row(cell.c[0] + o[0], cell.c[1] + o[1], cell.c[2] + o[2], lp);
+                    float a[3], sd[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        a[k] = o[k] ? cell.w[k] : 1.0f - cell.w[k];
+                        sd[k] = o[k] ? cell.dw[k] : -cell.dw[k];
+                    }
+                    float D = gd[0] * sd[0] * a[1] * a[2];
+                    D = D + gd[1] * a[0] * sd[1] * a[2];
+                    D = D + gd[2] * a[0] * a[1] * sd[2];
+                    sbin[q] = (int)(r >> shift);
+                    sidx[q] = (r & cmask) | 0xffff0000u;
+                    sa[q] = g0 * D;
+                    sb[q] = g1 * D;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rank[q] = sbin[q] >= 0 ? atomicAdd(&hist[sbin[q]], 1u) : 0u;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nc; i += 1024) {
+            const uint32_t h = hist[i];
+            gbase[i] = h ? atomicAdd(&counters[plan.bin_first[l] + i], h) : 0u;
+            hist2[buf ^ 1][i] = 0u;
+        }
+        __syncthreads();
+        const uint32_t cap = (uint32_t)plan.cap[l];
+        uint4 *lrecs = recs + plan.rec_first[l];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (sbin[q] < 0) continue;
+            const uint4 rec = make_uint4(sidx[q], 0u, __float_as_uint(sa[q]), __float_as_uint(sb[q]));
+            emit_record<F>(lrecs, dtable, lp, sbin[q], gbase[sbin[q]] + rank[q], cap, shift, rec);
+        }
     }
 }
 
@@ -917,18 +1008,49 @@ ARCN_EXPORT int arcn_hashgrid_bwd(const float *xyz, const float *table, const fl
 }
 
 ARCN_EXPORT int arcn_hashgrid_bwd_bwd(const float *xyz, const float *gdx, const float *table, const float *dout,
-                                      const arcn_hashgrid_desc *desc_host, float *ddout, float *dtable, float *d2xyz, int64_t n,
-                                      const int32_t *n_ptr, void *stream) {
+                                      const arcn_hashgrid_desc *desc_host, float *ddout, float *dtable, float *d2xyz,
+                                      float *workspace, int64_t workspace_floats, int64_t n, const int32_t *n_ptr, void *stream) {
     if (n <= 0) return ARCN_OK;
     if (!xyz || !gdx || !table || !dout || (!ddout && !dtable && !d2xyz)) return einval("hashgrid_bwd_bwd: missing argument");
     GridParams g;
     int rc = build_params(desc_host, g);
     if (rc) return rc;
+    // binned table scatter: 8 single-row records per (sample, level), bins sized by a plan for 2n samples
+    const bool binned = workspace && dtable && g.F <= 2;
+    if (binned) {
+        if (workspace_floats < arcn_hashgrid_bwd_workspace_floats(desc_host, 2 * n))
+            return einval("hashgrid_bwd_bwd: workspace smaller than arcn_hashgrid_bwd_workspace_floats(desc, 2 * n)");
+        BinPlan plan;
+        rc = build_bin_plan(g, 2 * n, plan);
+        if (rc) return rc;
+        uint32_t *counters = reinterpret_cast<uint32_t *>(workspace);
+        uint4 *recs = reinterpret_cast<uint4 *>(workspace + bin_counter_floats(plan));
+        hipError_t e = hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)plan.n_bins, as_stream(stream));
+        if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
+        const size_t lds = sizeof(float) * (size_t)plan.chunk_floats + sizeof(uint32_t) * (size_t)(plan.chunk_floats / 32);
+        e = g.F == 1
+            ? hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_accum_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+            : hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_accum_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
+        int64_t bx = ceil_div<int64_t>(n, 1024);
+        if (bx > 32) bx = 32;
+        dim3 bgrid((unsigned)bx, (unsigned)g.L), agrid((unsigned)plan.item_first[g.L]);
+        if (g.F == 1) {
+            hipLaunchKernelGGL(scatter_bin_dir_kernel<1>, bgrid, dim3(1024), 0, as_stream(stream), xyz, gdx, dout, g, plan, counters, recs, dtable, n, n_ptr);
+            hipLaunchKernelGGL(scatter_accum_kernel<1>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable);
+        } else {
+            hipLaunchKernelGGL(scatter_bin_dir_kernel<2>, bgrid, dim3(1024), 0, as_stream(stream), xyz, gdx, dout, g, plan, counters, recs, dtable, n, n_ptr);
+            hipLaunchKernelGGL(scatter_accum_kernel<2>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable);
+        }
+        if ((rc = check_launch("hashgrid_bwd_bwd_binned"))) return rc;
+        if (!ddout && !d2xyz) return ARCN_OK;
+    }
+    float *dt_plain = binned ? nullptr : dtable;
     dim3 grid((unsigned)ceil_div<int64_t>(n * g.L, 256));
     switch (g.F) {
-    case 1: hipLaunchKernelGGL(hashgrid_bwd_bwd_kernel<1>, grid, dim3(256), 0, as_stream(stream), xyz, gdx, table, dout, g, ddout, dtable, d2xyz, n, n_ptr); break;
-    case 2: hipLaunchKernelGGL(hashgrid_bwd_bwd_kernel<2>, grid, dim3(256), 0, as_stream(stream), xyz, gdx, table, dout, g, ddout, dtable, d2xyz, n, n_ptr); break;
-    default: hipLaunchKernelGGL(hashgrid_bwd_bwd_kernel<4>, grid, dim3(256), 0, as_stream(stream), xyz, gdx, table, dout, g, ddout, dtable, d2xyz, n, n_ptr); break;
+    case 1: hipLaunchKernelGGL(hashgrid_bwd_bwd_kernel<1>, grid, dim3(256), 0, as_stream(stream), xyz, gdx, table, dout, g, ddout, dt_plain, d2xyz, n, n_ptr); break;
+    case 2: hipLaunchKernelGGL(hashgrid_bwd_bwd_kernel<2>, grid, dim3(256), 0, as_stream(stream), xyz, gdx, table, dout, g, ddout, dt_plain, d2xyz, n, n_ptr); break;
+    default: hipLaunchKernelGGL(hashgrid_bwd_bwd_kernel<4>, grid, dim3(256), 0, as_stream(stream), xyz, gdx, table, dout, g, ddout, dt_plain, d2xyz, n, n_ptr); break;
     }
     return check_launch("hashgrid_bwd_bwd");
 }

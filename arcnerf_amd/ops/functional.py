@@ -392,16 +392,21 @@ def hashgrid_bwd(xyz, table, dout, desc, want_dtable=True, want_dxyz=False, n_de
     return dtable, dxyz
 
 
-def hashgrid_bwd_bwd(xyz, gdx, table, dout, desc, want_ddout=True, want_dtable=True, want_d2xyz=False):
-    """second-order pieces of the encoding's input gradient (see arcn_hashgrid_bwd_bwd) -> ddout, dtable, d2xyz (None if unwanted)"""
+def hashgrid_bwd_bwd(xyz, gdx, table, dout, desc, want_ddout=True, want_dtable=True, want_d2xyz=False, workspace=True):
+    """second-order pieces of the encoding's input gradient (see arcn_hashgrid_bwd_bwd) -> ddout, dtable, d2xyz (None if unwanted).
+    workspace True: binned table scatter (allocates its scratch); None: one float atomic per corner."""
     _req(xyz, gdx, table, dout)
     xyz, gdx, table, dout = _f32(xyz), _f32(gdx), _f32(table), _f32(dout)
     n = xyz.shape[0]
     ddout = torch.empty_like(dout) if want_ddout else None
     dtable = torch.zeros_like(table) if want_dtable else None
     d2xyz = torch.zeros((n, 3), dtype=torch.float32, device=xyz.device) if want_d2xyz else None
+    ws = None
+    if want_dtable and workspace is not None and table.shape[-1] <= 2 and n > 0:
+        ws = hashgrid_bwd_workspace(desc, 2 * n, xyz.device) if workspace is True else workspace
     N.check(N.lib().arcn_hashgrid_bwd_bwd(N.ptr(xyz), N.ptr(gdx), N.ptr(table), N.ptr(dout), C.addressof(desc), N.ptr(ddout),
-                                         N.ptr(dtable), N.ptr(d2xyz), n, None, N.stream()), 'hashgrid_bwd_bwd')
+                                         N.ptr(dtable), N.ptr(d2xyz), N.ptr(ws), 0 if ws is None else ws.numel(), n, None,
+                                         N.stream()), 'hashgrid_bwd_bwd')
     return ddout, dtable, d2xyz
 
 

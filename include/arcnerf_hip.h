@@ -189,10 +189,12 @@ int arcn_hashgrid_fwd(const float *xyz, const float *table, const arcn_hashgrid_
  * d(output)/d(xyz) (NeuS normals on a hash grid: BaseGeoNet.forward_with_grad, base_network.py, with the torch backend of
  * hashgrid_encoder.py:191-230 under double autograd; tcnn's grid encoding has the same second-order terms).  gdx (n,3) = gradient
  * arriving on dxyz.  Outputs, each optional: ddout (n, L*F) = d/d dout; dtable (n_total,F) += d/d table (caller zeroes);
- * d2xyz (n,3) += d/d xyz (caller zeroes; cross terms of the trilinear weights). */
+ * d2xyz (n,3) += d/d xyz (caller zeroes; cross terms of the trilinear weights).  workspace (optional, at least
+ * arcn_hashgrid_bwd_workspace_floats(desc, 2 * n) floats): the table part runs as a binned scatter (8 single-row records per
+ * sample and level, same consumer as arcn_hashgrid_bwd) instead of one float atomic per corner and feature. */
 int arcn_hashgrid_bwd_bwd(const float *xyz, const float *gdx, const float *table, const float *dout,
-                          const arcn_hashgrid_desc *desc_host, float *ddout, float *dtable, float *d2xyz, int64_t n,
-                          const int32_t *n_ptr, void *stream);
+                          const arcn_hashgrid_desc *desc_host, float *ddout, float *dtable, float *d2xyz, float *workspace,
+                          int64_t workspace_floats, int64_t n, const int32_t *n_ptr, void *stream);
 /* Same result as arcn_hashgrid_fwd (bit-identical), scheduled so that each of the chip's 8 XCDs gathers only its own
  * 2 of 16 levels (a level's table slice then stays in that XCD's L2); n_feat 1 or 2.
  * level_major = 0: out (n, L*F) row-major; level_major = 1: out[(l * n_cap + s) * F + f]. */

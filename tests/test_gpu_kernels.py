@@ -769,7 +769,9 @@ def test_hashgrid_second_order_vs_reference_golden_and_oracle(F, oracle, tag):
     table = make_table(int(offs[-1]), Fe, seed=17, scale=0.5)
     desc = N.make_hashgrid_desc([int(r) for r in res], [int(o) for o in offs], Fe, [-1.0] * 3, [1.0] * 3)
     xyz, gy, gdx = g[tag + '_xyz'], g[tag + '_gy'], g[tag + '_gdx']
-    ddout, dtable, d2x = F.hashgrid_bwd_bwd(dev(xyz), dev(gdx), dev(table), dev(gy), desc, want_d2xyz=True)
+    ddout, dtable, d2x = F.hashgrid_bwd_bwd(dev(xyz), dev(gdx), dev(table), dev(gy), desc, want_d2xyz=True)   # binned table scatter (F <= 2)
+    _, dtable_atomic, _ = F.hashgrid_bwd_bwd(dev(xyz), dev(gdx), dev(table), dev(gy), desc, want_ddout=False, workspace=None)
+    close(host(dtable), host(dtable_atomic), rtol=1e-4, atol=1e-6 * float(dtable_atomic.abs().max()))
     o_ddout, o_dtable, o_d2x = oracle.hashgrid_bwd_bwd(xyz, gdx, table, gy, res, offs, np.full(3, -1.0, np.float32), np.full(3, 1.0, np.float32))
     for got, orc_v, key in ((ddout, o_ddout, '_d_gy'), (d2x, o_d2x, '_d_x')):
         scale = np.abs(g[tag + key]).max()
