@@ -126,30 +126,6 @@ __device__ __forceinline__ float dist_to_next_voxel(const float pos[3], const fl
     return fmaxf(t_min / (float)n, 0.0f);
 }
 
-// The marching loop of K3 (volume_func_kernel.cu:203-222).  EMIT(j, t) is called for every accepted sample.
-template <int MODE, typename Emit>
-__device__ __forceinline__ uint32_t march_ray(const float o[3], const float d[3], float startt, float far_end, float dt,
-                                              const Aabb &b, const uint8_t *bf, uint32_t n_grid, uint32_t n_pts,
-                                              Emit emit) {
-    uint32_t j = 0;
-    float t = startt;
-    float pos[3];
-    while (t <= far_end && j < n_pts) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { float a = d[k] * t; pos[k] = o[k] + a; }
-        if (!in_aabb(pos, b)) break;
-        if (occupied_at<MODE>(pos, bf, b, n_grid)) {
-            emit(j, t);
-            ++j;
-            t += dt;
-        } else {
-            float t_target = t + dist_to_next_voxel(pos, d, b, n_grid);
-            do { t += dt; } while (t < t_target);
-        }
-    }
-    return j;
-}
-
 // ---- K1 ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) check_occ_kernel(const float *__restrict__ xyz, const uint8_t *__restrict__ bf,
                                                         const float *__restrict__ aabb, uint32_t n_grid,
@@ -244,35 +220,10 @@ __global__ void __launch_bounds__(256) sphere_kernel(const float *__restrict__ r
 }
 
 // ---- K3 / K5 (dense boundary form) ---------------------------------------------------------------------
-// MODE OCC_BOOL = K3 sparse_volume_sampling (volume_func_kernel.cu:174-236); MODE OCC_MORTON = K5 sparse_volume_sampling_bit
-// (bitfield_func_kernel.cu:20-82): the same loop over a Morton-ordered packed bitfield.
-template <int MODE>
-__global__ void __launch_bounds__(128)
-sparse_sampling_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                       const float *__restrict__ near, const float *__restrict__ far, const float *__restrict__ aabb,
-                       const uint8_t *__restrict__ bf, uint32_t n_grid, uint32_t n_pts, float dt, float near_distance,
-                       Pcg32 rng, float *__restrict__ zvals, uint8_t *__restrict__ mask, int32_t *__restrict__ counts,
-                       int64_t n_rays) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rays) return;
-    rng.advance((int64_t)(uint32_t)((uint32_t)i * 8u));
-    const Aabb b = load_aabb(aabb);
-    float o[3] = {rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2]};
-    float d[3] = {rays_d[3 * i], rays_d[3 * i + 1], rays_d[3 * i + 2]};
-    float startt = fmaxf(near[i], near_distance);
-    float jit = dt * rng.next_float();
-    startt += jit;
-    float *zr = zvals + i * (int64_t)n_pts;
-    uint8_t *mr = mask + i * (int64_t)n_pts;
-    float last = 0.f;
-    uint32_t j = march_ray<MODE>(o, d, startt, far[i], dt, b, bf, n_grid, n_pts, [&](uint32_t jj, float t) {
-        zr[jj] = t;
-        mr[jj] = 1;
-        last = t;
-    });
-    if (counts) counts[i] = (int32_t)j;
-    if (j > 0) for (; j < n_pts; ++j) zr[j] = last;
-}
+// K3 sparse_volume_sampling (volume_func_kernel.cu:174-236) and K5 sparse_volume_sampling_bit (bitfield_func_kernel.cu:20-82) are
+// the reference's one-thread-per-ray marching loop over a bool / Morton-bit occupancy.  Both entry points run the wave-per-ray
+// marcher below (march_count_kernel) with the caller's near / far: same lattice, same decisions, bit-identical zvals and masks
+// (the tests compare against the serial loop of the CPU oracle).
 
 // ---- K11 sparse_sampling_in_multivol_bitfield (multivol_func_kernel.cu:14-96, volume_func.h:196-298) ---------------------
 // n_cascade nested volumes (volume m = the inner one scaled 2^m about its centre), each an n_grid^3 Morton bitfield; the step
@@ -475,7 +426,8 @@ __global__ void __launch_bounds__(256)
 march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ aabb,
                    const uint8_t *__restrict__ bf, uint32_t n_grid, uint32_t n_pts, float dt, float near_distance,
                    int torch_sem, Pcg32 rng, float *__restrict__ scratch_t, int32_t *__restrict__ counts,
-                   float *__restrict__ near_out, float *__restrict__ far_out, int64_t n_rays) {
+                   float *__restrict__ near_out, float *__restrict__ far_out, const float *__restrict__ near_in,
+                   const float *__restrict__ far_in, uint8_t *__restrict__ mask_out, int64_t n_rays) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n_rays) return;
@@ -485,7 +437,11 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
     float d[3] = {rays_d[3 * i], rays_d[3 * i + 1], rays_d[3 * i + 2]};
     float nr, fr;
     bool hit;
-    if (torch_sem) {
+    if (near_in) {   // dense boundary form (K3 / K5): the caller's bounds, every ray is marched
+        nr = near_in[i];
+        fr = far_in[i];
+        hit = true;
+    } else if (torch_sem) {
         float bb[6] = {b.mn[0], b.mx[0], b.mn[1], b.mx[1], b.mn[2], b.mx[2]};
         aabb_torch(o, d, bb, 1e-7f, nr, fr, hit);
     } else {
@@ -569,7 +525,20 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
             t_base = t_next_base;
         }
     }
-    if (lane == 0) counts[i] = (int32_t)j;
+    if (lane == 0 && counts) counts[i] = (int32_t)j;
+    if (mask_out && j > 0) {
+        // dense boundary form: scratch_t IS the (n_rays, n_pts) zvals tensor - the first j slots hold the samples; flag them and
+        // repeat the last one over the tail (volume_func_kernel.cu:225-233)
+        float *zr = scratch_t + i * (int64_t)n_pts;
+        uint8_t *mr = mask_out + i * (int64_t)n_pts;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        const float last = zr[j - 1];
+        for (uint32_t k = lane; k < n_pts; k += 64) {
+            if (k < j) mr[k] = 1;
+            else zr[k] = last;
+        }
+    }
 }
 
 // pass 2: exclusive scan of int32 counts, single workgroup (n_rays is a few 10^4..10^6): 1024 threads, each owning a
@@ -762,9 +731,11 @@ ARCN_EXPORT int arcn_sparse_volume_sampling(const float *rays_o, const float *ra
     if (!rays_o || !rays_d || !near || !far || !aabb || !bitfield || !zvals || !mask || n_pts <= 0 || n_grid <= 0 || !(dt > 0))
         return einval("sparse_volume_sampling: missing/invalid argument");
     Pcg32 rng{rng_state, rng_inc};
-    hipLaunchKernelGGL(sparse_sampling_kernel<OCC_BOOL>, dim3((unsigned)ceil_div<int64_t>(n_rays, 128)), dim3(128), 0,
-                       as_stream(stream), rays_o, rays_d, near, far, aabb, bitfield, (uint32_t)n_grid, (uint32_t)n_pts, dt,
-                       near_distance, rng, zvals, mask, counts, n_rays);
+    // one wavefront per ray (the marcher of the compacted sampler) with the caller's bounds: bit-identical to the
+    // reference's serial one-thread-per-ray loop and ~3x faster
+    hipLaunchKernelGGL(march_count_kernel<OCC_BOOL>, dim3((unsigned)ceil_div<int64_t>(n_rays, 4)), dim3(256), 0, as_stream(stream), rays_o,
+                       rays_d, aabb, bitfield, (uint32_t)n_grid, (uint32_t)n_pts, dt, near_distance, 0, rng, zvals, counts,
+                       (float *)nullptr, (float *)nullptr, near, far, mask, n_rays);
     return check_launch("sparse_volume_sampling");
 }
 
@@ -778,9 +749,11 @@ ARCN_EXPORT int arcn_sparse_volume_sampling_bit(const float *rays_o, const float
         return einval("sparse_volume_sampling_bit: missing/invalid argument");
     if (n_grid > 1024 || (n_grid & (n_grid - 1))) return einval("sparse_volume_sampling_bit: n_grid must be a power of two <= 1024");
     Pcg32 rng{rng_state, rng_inc};
-    hipLaunchKernelGGL(sparse_sampling_kernel<OCC_MORTON>, dim3((unsigned)ceil_div<int64_t>(n_rays, 128)), dim3(128), 0,
-                       as_stream(stream), rays_o, rays_d, near, far, aabb, bitfield, (uint32_t)n_grid, (uint32_t)n_pts, dt,
-                       near_distance, rng, zvals, mask, counts, n_rays);
+    // one wavefront per ray (the marcher of the compacted sampler) with the caller's bounds: bit-identical to the
+    // reference's serial one-thread-per-ray loop and ~3x faster
+    hipLaunchKernelGGL(march_count_kernel<OCC_MORTON>, dim3((unsigned)ceil_div<int64_t>(n_rays, 4)), dim3(256), 0, as_stream(stream), rays_o,
+                       rays_d, aabb, bitfield, (uint32_t)n_grid, (uint32_t)n_pts, dt, near_distance, 0, rng, zvals, counts,
+                       (float *)nullptr, (float *)nullptr, near, far, mask, n_rays);
     return check_launch("sparse_volume_sampling_bit");
 }
 
@@ -856,15 +829,15 @@ ARCN_EXPORT int arcn_march_count(const float *rays_o, const float *rays_d, const
     if (bitfield_is_packed == 2)
         hipLaunchKernelGGL(march_count_kernel<OCC_MORTON>, grid, dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, bitfield,
                            (uint32_t)n_grid, (uint32_t)n_pts, dt, near_distance, aabb_torch_semantics, rng, scratch_t,
-                           counts, near_out, far_out, n_rays);
+                           counts, near_out, far_out, (const float *)nullptr, (const float *)nullptr, (uint8_t *)nullptr, n_rays);
     else if (bitfield_is_packed)
         hipLaunchKernelGGL(march_count_kernel<OCC_PACKED>, grid, dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, bitfield,
                            (uint32_t)n_grid, (uint32_t)n_pts, dt, near_distance, aabb_torch_semantics, rng, scratch_t,
-                           counts, near_out, far_out, n_rays);
+                           counts, near_out, far_out, (const float *)nullptr, (const float *)nullptr, (uint8_t *)nullptr, n_rays);
     else
         hipLaunchKernelGGL(march_count_kernel<OCC_BOOL>, grid, dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, bitfield,
                            (uint32_t)n_grid, (uint32_t)n_pts, dt, near_distance, aabb_torch_semantics, rng, scratch_t,
-                           counts, near_out, far_out, n_rays);
+                           counts, near_out, far_out, (const float *)nullptr, (const float *)nullptr, (uint8_t *)nullptr, n_rays);
     return check_launch("march_count");
 }
 
