@@ -835,3 +835,33 @@ def test_get_rays_vs_reference_golden_and_oracle(F, oracle):
     assert o.shape == (20, 3) and len(set(flat)) == 20 and r is None
     with pytest.raises(AssertionError):
         get_rays(W, H, dev(K), dev(c2w), index=dev(idx), n_rays=5)
+
+
+def test_fused_adam_optimizer_matches_torch_adam(F):
+    """arcnerf_amd.optim.FusedAdam (torch.optim front end of arcn_adam_ema_step) against torch.optim.Adam: several steps, weight
+    decay, ragged sizes, changing gradients; state_dict layout; fused gradient clear"""
+    from arcnerf_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(1000, 2), (33, 64), (7,)]
+    pa = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = FusedAdam(pa, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-3, zero_grad_on_step=True)
+    ob = torch.optim.Adam(pb, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-3)
+    for it in range(12):
+        for a, b_ in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).cuda() * (0.1 if it % 3 else 10.0)
+            a.grad = gr.clone()
+            b_.grad = gr.clone()
+        oa.step()
+        ob.step()
+        for a in pa:
+            assert float(a.grad.abs().max()) == 0.0   # cleared in the same pass
+    for a, b_ in zip(pa, pb):
+        close(host(a), host(b_), rtol=2e-6, atol=2e-7)
+    sd = oa.state_dict()
+    assert set(sd['state'][0].keys()) == {'step', 'exp_avg', 'exp_avg_sq'} and sd['state'][0]['step'] == 12
+    close(host(sd['state'][1]['exp_avg_sq']), host(ob.state_dict()['state'][1]['exp_avg_sq']), rtol=2e-6, atol=1e-12)
+    with pytest.raises(RuntimeError):
+        cpu_p = torch.zeros(4, requires_grad=True)
+        cpu_p.grad = torch.ones(4)
+        FusedAdam([cpu_p]).step()

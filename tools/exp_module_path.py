@@ -16,11 +16,16 @@ o, d = synthetic_rays(R, seed=0, device=dev)
 inputs = {'rays_o': o.view(1, R, 3), 'rays_d': d.view(1, R, 3), 'rays_r': torch.zeros(1, R, 1, device=dev),
           'img': torch.rand(1, R, 3, device=dev), 'bkg_color': torch.ones(1, R, 3, device=dev)}
 tgt = torch.rand(1, R, 3, device=dev)
-opt = torch.optim.Adam(m.parameters(), lr=1e-2, eps=1e-15)
+if os.environ.get('FUSED_ADAM', '0') == '1':
+    from arcnerf_amd.optim import FusedAdam
+    opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=1e-2, eps=1e-15, zero_grad_on_step=True)
+else:
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2, eps=1e-15)
 def step(it):
     out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=it)
     loss = torch.nn.functional.huber_loss(out['rgb_coarse'], tgt, delta=0.1)
-    opt.zero_grad(set_to_none=False)
+    if os.environ.get('FUSED_ADAM', '0') != '1':
+        opt.zero_grad(set_to_none=False)
     loss.backward()
     opt.step()
     return loss
