@@ -826,24 +826,23 @@ mlp_bwd_dw_kernel(const float *__restrict__ x, const float *__restrict__ acts, c
     if (P.has_bias && bias_partials && nt0 == 0 && threadIdx.x < 64) bias_partials[slot * 64 + threadIdx.x] = bred[threadIdx.x];
 }
 
-// sum the per-workgroup partial tiles of one (layer, quadrant) and add them into dW / db.  grid = (16, quads), 1024 threads:
-// thread (element e of the 64x64 quadrant, slice z of 4) sums every 4th slot with 32 loads in flight (the kernel is pure load
-// latency: the previous version walked 64 slots 8 at a time in 384 small workgroups and took 27 us for 25 MB), the 4 slices meet
-// in LDS and slice 0 adds the total into dW with a plain read-modify-write: one owner per element, no atomics, and a fixed
-// summation order (bit-reproducible gradients).
-constexpr int kReduceSlices = 4;
-__global__ void __launch_bounds__(256 * kReduceSlices)
+// sum the per-workgroup partial tiles of one (layer, quadrant) and add them into dW / db.  grid = (4096 / kReduceElems, quads),
+// 1024 threads: thread (element e, slice z of kReduceSlices) sums every kReduceSlices-th slot with ALL its loads in flight at once
+// (the kernel is pure load latency: 512 slots x 16 KiB per layer), the slices meet in LDS and slice 0 adds the total into dW with
+// a plain read-modify-write: one owner per element, no atomics, and a fixed summation order (bit-reproducible gradients).
+constexpr int kReduceElems = 64, kReduceSlices = 16;
+__global__ void __launch_bounds__(kReduceElems * kReduceSlices)
 mlp_dw_reduce_kernel(const float *__restrict__ partials, const float *__restrict__ bias_partials, DwParams P, int n_slots,
                      float *__restrict__ dweights, float *__restrict__ dbiases) {
-    __shared__ float part[kReduceSlices][256];
+    __shared__ float part[kReduceSlices][kReduceElems];
     int l = 0;
     while (l + 1 < P.n_layers && (int)blockIdx.y >= P.quad_first[l + 1]) ++l;
     const int q = blockIdx.y - P.quad_first[l];
     const int N = P.dims[l + 1], K = P.dims[l];
     const int qn = (tiles16(K) + 3) / 4;
     const int mt0 = (q / qn) * 4, nt0 = (q % qn) * 4;
-    const int el = threadIdx.x & 255, z = threadIdx.x >> 8;
-    const int e = blockIdx.x * 256 + el;  // 0..4095 inside the 64x64 quadrant, fragment order
+    const int el = threadIdx.x % kReduceElems, z = threadIdx.x / kReduceElems;
+    const int e = blockIdx.x * kReduceElems + el;  // 0..4095 inside the 64x64 quadrant, fragment order
     const float *src = partials + (int64_t)blockIdx.y * n_slots * 4096 + e;
     const int tile = e >> 8, ln = (e >> 2) & 63, r = e & 3;
     const int a = tile >> 2, b = tile & 3;
@@ -1115,7 +1114,7 @@ static int mlp_bwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
 #undef ARCN_FUSED
             // defer_reduce: the per-workgroup partials stay in `scratch`; arcn_mlp_bwd_reduce adds them into dweights later
             if (!defer_reduce)
-                hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(16, (unsigned)P.n_layers), dim3(256 * kReduceSlices), 0, as_stream(stream), partials,
+                hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(4096 / kReduceElems, (unsigned)P.n_layers), dim3(kReduceElems * kReduceSlices), 0, as_stream(stream), partials,
                                    static_cast<const float *>(nullptr), D, (int)grid, dweights, dbiases);
             return check_launch("mlp_bwd_fused");
         }
@@ -1186,7 +1185,7 @@ ARCN_EXPORT int arcn_mlp_bwd_reduce(const arcn_mlp_desc *desc_host, float *scrat
     for (int l = 0; l < P.n_layers; ++l) { D.w_off[l] = P.w_off[l]; D.b_off[l] = P.b_off[l]; D.quad_first[l] = l; }
     D.quad_first[P.n_layers] = P.n_layers;
     float *partials = scratch + arcn_mlp_dpre_floats(desc_host, n_cap);
-    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(16, (unsigned)P.n_layers), dim3(256 * kReduceSlices), 0, as_stream(stream), partials,
+    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(4096 / kReduceElems, (unsigned)P.n_layers), dim3(kReduceElems * kReduceSlices), 0, as_stream(stream), partials,
                        static_cast<const float *>(nullptr), D, (int)grid, dweights, static_cast<float *>(nullptr));
     return check_launch("mlp_bwd_reduce");
 }
@@ -1217,7 +1216,7 @@ ARCN_EXPORT int arcn_mlp_bwd_dw(const float *x, const arcn_mlp_desc *desc_host, 
         float *bias_partials = partials + slabs * quads * 4096;
         hipLaunchKernelGGL(mlp_bwd_dw_kernel, dim3((unsigned)slabs, (unsigned)quads), dim3(256), 0, as_stream(stream), x, acts,
                            scratch, D, partials, bias_partials, n_cap, n, n_ptr);
-        hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(16, (unsigned)quads), dim3(256 * kReduceSlices), 0, as_stream(stream), partials,
+        hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(4096 / kReduceElems, (unsigned)quads), dim3(kReduceElems * kReduceSlices), 0, as_stream(stream), partials,
                            bias_partials, D, (int)slabs, dweights, dbiases);
         if ((rc = check_launch("mlp_bwd_dw"))) return rc;
     }
