@@ -172,6 +172,29 @@ class NgpField:
         return out
 
 
+class StepLoss:
+    """Loss of one training step, reduced on first use from the per-workgroup partial sums the fused compositor stored (nothing is
+    launched for it during the step).  float(loss) / loss.item() / loss.tensor(); valid while its ring slot is (64 steps)."""
+
+    def __init__(self, pipe, slot, generation, n_wgs):
+        self._pipe, self._slot, self._generation, self._n, self._value = pipe, slot, generation, n_wgs, None
+
+    def tensor(self):
+        if self._value is None:
+            if self._pipe._loss_step[self._slot] != self._generation:
+                raise RuntimeError('this step\'s loss partials have been overwritten (read a loss within 64 steps of its step)')
+            self._value = self._pipe.buf['loss_ring'][self._slot, :self._n].sum()
+        return self._value
+
+    def item(self):
+        return float(self.tensor().item())
+
+    __float__ = item
+
+    def __repr__(self):
+        return 'StepLoss({})'.format(self.item())
+
+
 class NgpPipeline:
     """Pre-allocated buffers + the kernel sequence of one render / train step for a fixed ray capacity."""
 
@@ -241,10 +264,12 @@ class NgpPipeline:
         b['mask'] = torch.zeros(R, dtype=f32, device=dev)
         b['d_rgb'] = torch.zeros((R, 3), dtype=f32, device=dev)
         b['loss'] = torch.zeros(1, dtype=f32, device=dev)
-        # fused compositor: loss of step k accumulates in slot k % 1024 (the kernel clears the next slot), so the tensor returned
-        # by train_step stays valid for the following 1000 steps without a copy
-        b['loss_ring'] = torch.zeros(1024, dtype=f32, device=dev)
+        # fused compositor: every workgroup (4 rays) stores its share of the step's loss; the scalar is summed only when somebody
+        # reads it (StepLoss).  A ring of slots keeps the last 64 steps' partials readable.
+        self._loss_wgs = (R + 3) // 4
+        b['loss_ring'] = torch.zeros((64, self._loss_wgs), dtype=f32, device=dev)
         self._loss_slot = 0
+        self._loss_step = [-1] * 64
         self.fused_composite = bool(int(os.environ.get('ARCN_FUSED_COMPOSITE', '1')))
         # XCD-owned-levels scatter workspace (owner + tile counters); None selects the plain agent-scope kernel
         self.hash_ws = F.hashgrid_bwd_workspace(self.field.grid_desc, S, dev) if xcd_scatter else None  # scatter bins
@@ -452,14 +477,15 @@ class NgpPipeline:
         self._composite_bwd_done = False
         if huber_target is not None and train:
             ring, k = b['loss_ring'], self._loss_slot
-            self._loss_slot = (k + 1) % ring.numel()
+            self._loss_slot = (k + 1) % ring.shape[0]
+            self._loss_step[k] = self.generation
             N.check(L.arcn_composite_packed_train(N.ptr(b['sigma']), N.ptr(b['rgb_s']), N.ptr(b['t']), N.ptr(b['offsets']), N.ptr(noise),
                                                   N.ptr(bk), bk_rows, R, 2, b['p_dense'].data_ptr(), int(cfg.add_inf_z),
                                                   int(cfg.white_bkg), N.ptr(huber_target.contiguous().float()), cfg.huber_delta,
                                                   cfg.loss_weight, N.ptr(b['rgb']), N.ptr(b['depth']), N.ptr(b['mask']), N.ptr(b['d_rgb']),
-                                                  ring[k:k + 1].data_ptr(), ring[self._loss_slot:self._loss_slot + 1].data_ptr(),
+                                                  ring[k].data_ptr(),
                                                   N.ptr(b['d_sigma']), N.ptr(b['d_rgb_s']), st), 'composite_packed_train')
-            self.last_loss = ring[k]
+            self.last_loss = StepLoss(self, k, self.generation, (R + 3) // 4)
             self._composite_bwd_done = True
             return b['rgb'][:R], b['depth'][:R], b['mask'][:R]
         N.check(L.arcn_composite_packed_fwd(N.ptr(b['sigma']), N.ptr(b['rgb_s']), N.ptr(b['t']), N.ptr(b['offsets']),

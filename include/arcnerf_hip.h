@@ -326,13 +326,13 @@ int arcn_ray_marching_bwd(const float *sigma, const float *alpha_in, const float
 /* Fused training step of the packed compositor: arcn_composite_packed_fwd + arcn_huber_loss_grad (ImgLoss Huber,
  * arcnerf/loss/img_loss.py:60-100, mean over R*3, times loss_weight) + arcn_composite_packed_bwd in one pass per ray - the Huber
  * gradient of a ray depends on that ray's colour only.  target (R,3); rgb/depth/mask/d_rgb (R,..) optional outputs; d_sigma (S),
- * d_radiance (S,3) as the backward; *loss_acc += the loss of this launch (caller provides it zeroed), *loss_clear (optional) is
- * set to 0 for a following launch to accumulate into. */
+ * d_radiance (S,3) as the backward; loss_partials (optional, ceil(R / 4) floats): entry w receives the summed loss terms of rays
+ * 4w .. 4w+3, the loss of the launch is the sum of the entries (a single scalar accumulator would cost 2080 serialised atomics). */
 int arcn_composite_packed_train(const float *sigma, const float *radiance, const float *t_packed, const int32_t *offsets,
                                 const float *noise, const float *bkg, int64_t bkg_rows, int64_t R, int p_dense,
                                 const int32_t *p_dense_ptr, int add_inf_z, int white_bkg, const float *target, float huber_delta,
-                                float loss_weight, float *rgb, float *depth, float *mask, float *d_rgb, float *loss_acc,
-                                float *loss_clear, float *d_sigma, float *d_radiance, void *stream);
+                                float loss_weight, float *rgb, float *depth, float *mask, float *d_rgb, float *loss_partials,
+                                float *d_sigma, float *d_radiance, void *stream);
 /* packed form over (offsets, t): identical numbers to the dense form applied to the reference's padded (R,P') view
  * (mask rows [T..T F..F], padded z = last z): P_dense = the dense column count the reference would have used
  * (max(2, max count), fg_model.py:251-262) read from *p_dense_ptr (device) or p_dense if the pointer is NULL. */
