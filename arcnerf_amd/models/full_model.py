@@ -190,7 +190,9 @@ class FullModel(nn.Module):
         fg_output = fg_model.forward(flat_inputs, inference_only, get_progress_fg, cur_epoch, total_epoch)
         bkg_output = None
         if bkg_model is not None and not self.fg_only:
-            bkg_output = bkg_model.forward(flat_inputs, inference_only, True, cur_epoch, total_epoch)
+            # the background's per-sample progress is only consumed by the joint compositing of the `sigma` blend (the reference asks
+            # for it unconditionally, full_model.py:437): in `rgb` mode a background may take its packed path
+            bkg_output = bkg_model.forward(flat_inputs, inference_only, self.bkg_blend == 'sigma', cur_epoch, total_epoch)
         return self.detach_progress(self.blend_output(fg_output, bkg_output, inference_only, get_progress))
 
     @torch.no_grad()

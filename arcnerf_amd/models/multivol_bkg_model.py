@@ -7,10 +7,13 @@ import torch
 from ..geometry.density_grid import MortonDensityGrid
 from ..geometry.ray import aabb_ray_intersection
 from ..geometry.volume import Volume
-from ..ops.multivol_func import (CUDA_BACKEND_AVAILABLE, generate_grid_samples_multivol, sparse_sampling_in_multivol_bitfield,
-                                 update_bitfield_multivol)
+from ..ops import functional as Fn
+from ..ops.autograd import PackedCompositeFn
+from ..ops.multivol_func import (CUDA_BACKEND_AVAILABLE, generate_grid_samples_multivol, multivol_rng,
+                                 sparse_sampling_in_multivol_bitfield, update_bitfield_multivol)
 from ..utils.cfgs_utils import get_value_from_cfgs_field
 from ..utils.registry import MODEL_REGISTRY
+from ..utils.torch_utils import chunk_processing
 from .base_modules import build_geo_model, build_radiance_model
 from .bkg_model import BkgModel
 from .masked_samples import nets_on_valid_samples
@@ -40,6 +43,7 @@ class MultiVol(BkgModel, MortonDensityGrid):
         self.n_levels = self.n_cascade if self.inclusive else self.n_cascade - 1
         self.total_n_elements = self.n_elements * self.n_levels
         self._alloc_density_grid(self.total_n_elements)
+        self.use_packed_path = True   # set False to force the dense reference-shaped path (always taken when progress is requested)
 
     def get_near_far_from_rays(self, rays_o, rays_d):
         """near, far (B,1) against the outermost volume, torch semantics: the cameras sit inside it"""
@@ -57,8 +61,38 @@ class MultiVol(BkgModel, MortonDensityGrid):
     def get_sigma_radiance_by_mask_pts(self, geo_net, radiance_net, rays_o, rays_d, zvals, mask_pts):
         return nets_on_valid_samples(self._forward_pts_dir, self.chunk_pts, geo_net, radiance_net, rays_o, rays_d, zvals, mask_pts)
 
+    def _forward_packed(self, rays_o, rays_d, inference_only):
+        """Same result as the dense path below when only rgb / depth / mask are wanted, without the padded (rays, slots) tensors:
+        the sampler's per-ray counts are scanned into offsets, the valid samples compacted (kernels, one host read for the total),
+        the nets see the packed points and the packed compositor does the rest - no boolean-mask gathers or scatters."""
+        n_rays, n_pts = rays_o.shape[0], self.get_ray_cfgs('n_sample')
+        with torch.no_grad():
+            near, far = self.get_near_far_from_rays(rays_o, rays_d)
+            rng = multivol_rng()
+            zvals, _, counts = Fn.sparse_sampling_in_multivol_bitfield(
+                rays_o, rays_d, near, far, n_pts, self.cone_angle, self.min_step, self.max_step,
+                self.basic_volume.get_range().permute(1, 0).contiguous(), self.max_volume.get_range().permute(1, 0).contiguous(),
+                self.n_grid, self.n_cascade, self.density_bitfield, self.get_optim_cfgs('near_distance'), self.inclusive, rng.state,
+                rng.inc, want_counts=True)
+            rng.advance()
+            t, ray_id, offsets, p_dense, total = Fn.pack_dense_samples(zvals, counts)
+            if total > 0:
+                xyz, dirs = Fn.packed_points(rays_o, rays_d, t, ray_id)
+        if total == 0:   # nothing sampled anywhere: empty rays composite to 0 (+ white background)
+            zero = rays_o.new_zeros((n_rays,))
+            rgb = rays_o.new_ones((n_rays, 3)) if self.get_ray_cfgs('white_bkg') else rays_o.new_zeros((n_rays, 3))
+            return {'rgb': rgb, 'depth': zero, 'mask': zero.clone()}
+        sigma, radiance = chunk_processing(self._forward_pts_dir, self.chunk_pts, False, self.geo_net, self.radiance_net, xyz, dirs)
+        noise_std = float(self.get_ray_cfgs('noise_std') or 0.0) if not inference_only else 0.0
+        noise = torch.randn_like(sigma) * noise_std if noise_std > 0 else None
+        rgb, depth, mask = PackedCompositeFn.apply(sigma.contiguous(), radiance.contiguous(), t, offsets, p_dense, bool(self.add_inf_z),
+                                                   bool(self.get_ray_cfgs('white_bkg')), noise)
+        return {'rgb': rgb, 'depth': depth, 'mask': mask}
+
     def forward(self, inputs, inference_only=False, get_progress=False, cur_epoch=0, total_epoch=300000):
         rays_o, rays_d = inputs['rays_o'], inputs['rays_d']
+        if self.use_packed_path and not get_progress and rays_o.is_cuda:
+            return self._forward_packed(rays_o.contiguous().float(), rays_d.contiguous().float(), inference_only)
         with torch.no_grad():
             near, far = self.get_near_far_from_rays(rays_o, rays_d)
             zvals, mask_pts = self.get_zvals_from_near_far(near, far, self.get_ray_cfgs('n_sample'), rays_o, rays_d)

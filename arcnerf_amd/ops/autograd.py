@@ -173,6 +173,27 @@ class RayMarchingFn(torch.autograd.Function):
         return d_sigma, d_rad, None, (d_geo if alpha is not None else None), None, None, None, None
 
 
+class PackedCompositeFn(torch.autograd.Function):
+    """rgb (R,3), depth (R), mask (R) = alpha compositing of PACKED samples (sigma (S), radiance (S,3), t (S), offsets (R+1)):
+    the result the reference's padded dense tensors would give (width p_dense = the longest ray, tails repeating the last sample),
+    without materialising them.  Gradients for sigma and radiance."""
+
+    @staticmethod
+    def forward(ctx, sigma, radiance, t, offsets, p_dense_dev, add_inf_z, white_bkg, noise):
+        out = F.composite_packed_fwd(sigma, radiance, t, offsets, p_dense_dev=p_dense_dev, add_inf_z=add_inf_z, white_bkg=white_bkg,
+                                     noise=noise)
+        ctx.save_for_backward(sigma, radiance, t, offsets, p_dense_dev, noise)
+        ctx.flags = (bool(add_inf_z), bool(white_bkg))
+        return out['rgb'], out['depth'], out['mask']
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth, d_mask):
+        sigma, radiance, t, offsets, p_dense_dev, noise = ctx.saved_tensors
+        d_sigma, d_rad = F.composite_packed_bwd(sigma, radiance, t, offsets, d_rgb.contiguous(), d_depth.contiguous(), d_mask.contiguous(),
+                                                p_dense_dev=p_dense_dev, add_inf_z=ctx.flags[0], white_bkg=ctx.flags[1], noise=noise)
+        return d_sigma, d_rad, None, None, None, None, None, None
+
+
 class SdfToAlphaFn(torch.autograd.Function):
     """NeuS sdf_to_alpha (arcnerf/models/neus_model.py:242-265) with gradients w.r.t. the mid-point sdf, the slope and the
     scale s (a tensor: exp(10 * inv_s) of the learnable parameter; a float scale gets no gradient).  zvals carry no gradient,

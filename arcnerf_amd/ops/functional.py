@@ -340,6 +340,27 @@ def march_packed(rays_o, rays_d, aabb23, n_grid, bitfield, n_pts, dt, near_dista
     return {'t': t, 'ray_id': ray_id, 'offsets': offsets, 'counts': counts, 'near': near, 'far': far}
 
 
+def pack_dense_samples(zvals, counts):
+    """Dense sampler output (R, n_pts) with per-ray counts (valid samples first) -> the packed form the compositor and
+    packed_points consume: t (total,), ray_id (total,) int32, offsets (R+1,) int32, p_dense (1,) int32 = max(counts), total.
+    ONE host read (the total, to size the packed tensors); exclusive scan + compaction are kernels."""
+    _req(zvals, counts)
+    z = _f32(zvals)
+    R, n_pts = z.shape
+    cnt = counts.contiguous().to(torch.int32)
+    offsets = torch.empty(R + 1, dtype=torch.int32, device=z.device)
+    p_dense = torch.zeros(1, dtype=torch.int32, device=z.device)
+    L = N.lib()
+    N.check(L.arcn_exclusive_scan_i32(N.ptr(cnt), N.ptr(offsets), R, int(R * n_pts), N.ptr(p_dense), N.stream()), 'exclusive_scan_i32')
+    total = int(offsets[R].item())
+    t = torch.empty(max(total, 1), dtype=torch.float32, device=z.device)
+    ray_id = torch.empty(max(total, 1), dtype=torch.int32, device=z.device)
+    if total > 0:
+        N.check(L.arcn_march_write(N.ptr(z), N.ptr(cnt), N.ptr(offsets), int(n_pts), N.ptr(t), N.ptr(ray_id), R, total, N.stream()),
+                'march_write')
+    return t[:total], ray_id[:total], offsets, p_dense, total
+
+
 def packed_points(rays_o, rays_d, t, ray_id, n=None, n_dev=None, want_dirs=True):
     _req(rays_o, rays_d, t, ray_id)
     o, d = _f32(rays_o), _f32(rays_d)
