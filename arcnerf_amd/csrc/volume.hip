@@ -266,27 +266,14 @@ __device__ __forceinline__ uint32_t morton_at_multivol(const float pos[3], uint3
     return morton3d((uint32_t)c[0], (uint32_t)c[1], (uint32_t)c[2]);
 }
 
-__global__ void __launch_bounds__(128)
-multivol_sampling_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ near,
-                         const float *__restrict__ far, const float *__restrict__ min_aabb, const float *__restrict__ aabb,
-                         const uint8_t *__restrict__ bf, uint32_t n_grid, uint32_t n_cascade, uint32_t n_pts, float cone_angle,
-                         float min_step, float max_step, float near_distance, int inclusive, Pcg32 rng,
-                         float *__restrict__ zvals, uint8_t *__restrict__ mask, int32_t *__restrict__ counts, int64_t n_rays) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rays) return;
-    rng.advance((int64_t)(uint32_t)((uint32_t)i * 8u));
-    const Aabb outer = load_aabb(aabb), in = load_aabb(min_aabb);
-    const float o[3] = {rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2]};
-    const float d[3] = {rays_d[3 * i], rays_d[3 * i + 1], rays_d[3 * i + 2]};
-    float startt = fmaxf(near[i], near_distance);
-    const float far_end = far[i];
-    const float jit = cone_dt(startt, cone_angle, min_step, max_step) * rng.next_float();
-    startt += jit;
+// The reference loop for one ray, start to end (multivol_func_kernel.cu:33-96).  Every lane of the calling wave runs it with the
+// same values; `writer` (one lane) stores.  zr / mr are the ray's zero-initialised rows; returns the number of samples.
+__device__ __forceinline__ uint32_t multivol_serial_ray(const float o[3], const float d[3], float t, float far_end, const Aabb &outer,
+                                                        const Aabb &in, const uint8_t *__restrict__ bf, uint32_t n_grid,
+                                                        uint32_t n_cascade, uint32_t n_pts, float cone_angle, float min_step,
+                                                        float max_step, int inclusive, bool writer, float *__restrict__ zr) {
     const uint32_t level_cells = n_grid * n_grid * n_grid;
-    float *zr = zvals + i * (int64_t)n_pts;
-    uint8_t *mr = mask + i * (int64_t)n_pts;
     uint32_t j = 0;
-    float t = startt, last = 0.f;
     float pos[3];
     while (t <= far_end && j < n_pts) {
 #pragma unroll
@@ -295,18 +282,16 @@ multivol_sampling_kernel(const float *__restrict__ rays_o, const float *__restri
         const float dt = cone_dt(t, cone_angle, min_step, max_step);
         const uint32_t mip = mip_from_pos(pos, in, n_cascade);
         if (mip == 0 && !inclusive) {
-            while (j > 0) { zr[j] = 0.0f; mr[j] = 0; j--; }
-            zr[j] = 0.0f;
-            mr[j] = 0;
+            // back inside the excluded inner volume: everything sampled so far is dropped
+            if (writer) for (uint32_t q = 0; q <= j; ++q) zr[q] = 0.0f;
+            j = 0;
             const float t_target = t + dist_to_next_voxel(pos, d, in, n_grid);
             do { t += dt; } while (t < t_target);
         } else {
             const uint32_t idx = morton_at_multivol(pos, mip, in, n_grid);
             const uint32_t slot = inclusive ? mip : mip - 1;
             if ((bf[(idx >> 3) + ((level_cells * slot) >> 3)] >> (idx & 7)) & 1) {
-                zr[j] = t;
-                mr[j] = 1;
-                last = t;
+                if (writer) zr[j] = t;
                 ++j;
                 t += dt;
             } else {
@@ -315,8 +300,134 @@ multivol_sampling_kernel(const float *__restrict__ rays_o, const float *__restri
             }
         }
     }
-    if (counts) counts[i] = (int32_t)j;
-    if (j > 0) for (; j < n_pts; ++j) zr[j] = last;
+    return j;
+}
+
+// One wavefront per ray.  Outside the excluded inner volume every t the reference loop visits lies on ONE lattice
+// t_{k+1} = t_k + clamp(t_k * cone_angle, min_step, max_step) (the occupied branch and the skip loop both step that way), so the
+// wave-parallel scheme of march_count_kernel applies: 64 consecutive lattice points by a systolic DPP chain, level / occupancy /
+// skip target of all 64 in parallel, the control flow replayed on ballot masks, emitted t compacted by popcount.  What is serial:
+// the stretch INSIDE the inner volume when it is excluded (fixed-dt voxel hops, no samples: typical for cameras in the scene
+// centre), and the rare ray that re-enters it later (restart with the plain loop).  Bit-identical to the serial loop.
+__global__ void __launch_bounds__(256)
+multivol_sampling_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ near,
+                         const float *__restrict__ far, const float *__restrict__ min_aabb, const float *__restrict__ aabb,
+                         const uint8_t *__restrict__ bf, uint32_t n_grid, uint32_t n_cascade, uint32_t n_pts, float cone_angle,
+                         float min_step, float max_step, float near_distance, int inclusive, Pcg32 rng,
+                         float *__restrict__ zvals, uint8_t *__restrict__ mask, int32_t *__restrict__ counts, int64_t n_rays) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_rays) return;
+    rng.advance((int64_t)(uint32_t)((uint32_t)i * 8u));
+    const Aabb outer = load_aabb(aabb), in = load_aabb(min_aabb);
+    const float o[3] = {rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2]};
+    const float d[3] = {rays_d[3 * i], rays_d[3 * i + 1], rays_d[3 * i + 2]};
+    float startt = fmaxf(near[i], near_distance);
+    const float fr = far[i];
+    const float jit = cone_dt(startt, cone_angle, min_step, max_step) * rng.next_float();
+    startt += jit;
+    const uint32_t level_cells = n_grid * n_grid * n_grid;
+    float *zr = zvals + i * (int64_t)n_pts;
+    uint8_t *mr = mask + i * (int64_t)n_pts;
+    uint32_t j = 0;
+    bool ended = false, restart = false;
+    float t_base = startt;
+    float pos[3];
+    // phase 1 (inner volume excluded): hop through it voxel by voxel, nothing is sampled there
+    if (!inclusive) {
+        while (t_base <= fr) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { float a = d[k] * t_base; pos[k] = o[k] + a; }
+            if (!in_aabb(pos, outer)) { ended = true; break; }
+            if (mip_from_pos(pos, in, n_cascade) != 0) break;
+            const float dt = cone_dt(t_base, cone_angle, min_step, max_step);
+            const float t_target = t_base + dist_to_next_voxel(pos, d, in, n_grid);
+            do { t_base += dt; } while (t_base < t_target);
+        }
+    }
+    // phase 2: the cone lattice, 64 points per trip
+    bool have_pending = false;
+    float pending = 0.f;
+    const float lane_on = lane == 0 ? 0.0f : 1.0f;
+    while (!ended) {
+        if (!(t_base <= fr)) break;
+        float t = t_base;
+#pragma unroll
+        for (int k = 0; k < 63; ++k) {
+            const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0x138, 0xf, 0xf, false));
+            const float step = cone_dt(left, cone_angle, min_step, max_step) * lane_on;   // lane 0 keeps the chunk's first point
+            t = left + step;
+        }
+        const float t63 = __shfl(t, 63, 64);
+        const float t_next_base = t63 + cone_dt(t63, cone_angle, min_step, max_step);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { float a = d[k] * t; pos[k] = o[k] + a; }
+        const bool alive = (t <= fr) && in_aabb(pos, outer);
+        uint32_t mip = 0;
+        if (alive) mip = mip_from_pos(pos, in, n_cascade);
+        const bool inner = alive && mip == 0 && !inclusive;
+        bool occ = false;
+        if (alive && !inner) {
+            const uint32_t idx = morton_at_multivol(pos, mip, in, n_grid);
+            const uint32_t slot = inclusive ? mip : mip - 1;
+            occ = (bf[(idx >> 3) + ((level_cells * slot) >> 3)] >> (idx & 7)) & 1;
+        }
+        const float target = (alive && !occ) ? t + dist_to_next_voxel(pos, d, in, n_grid) : 0.f;
+        const uint64_t alive_m = __ballot(alive), occ_m = __ballot(occ), inner_m = __ballot(inner);
+        uint64_t emit_m = 0;
+        int k = 0;
+        if (have_pending) {
+            const uint64_t ge = __ballot(t >= pending);
+            if (ge == 0) { t_base = t_next_base; continue; }
+            k = __builtin_ctzll(ge);
+            have_pending = false;
+        }
+        while (k < 64) {
+            if (!((alive_m >> k) & 1)) { ended = true; break; }
+            if ((inner_m >> k) & 1) { restart = true; ended = true; break; }   // re-entered the excluded volume: rare, redo serially
+            if ((occ_m >> k) & 1) {
+                const uint64_t stop = ~(occ_m & alive_m) >> k;
+                int run = stop ? __builtin_ctzll(stop) : 64 - k;
+                const int room = (int)(n_pts - j);
+                if (run >= room) { run = room; ended = true; }
+                emit_m |= (run >= 64 ? ~0ull : ((1ull << run) - 1ull)) << k;
+                j += (uint32_t)run;
+                k += run;
+                if (ended) break;
+            } else {
+                const float tgt = __shfl(target, k, 64);
+                const uint64_t after = (k >= 63) ? 0ull : (~0ull << (k + 1));
+                const uint64_t ge = __ballot(t >= tgt) & after;
+                if (ge == 0) { have_pending = true; pending = tgt; k = 64; }
+                else k = __builtin_ctzll(ge);
+            }
+        }
+        if ((emit_m >> lane) & 1) {
+            const uint32_t before = (uint32_t)__builtin_popcountll(emit_m & ((1ull << lane) - 1ull));
+            const uint32_t cnt_chunk = (uint32_t)__builtin_popcountll(emit_m);
+            zr[j - cnt_chunk + before] = t;
+        }
+        t_base = t_next_base;
+    }
+    if (restart) {
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        for (uint32_t q = lane; q < j; q += 64) zr[q] = 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        j = multivol_serial_ray(o, d, startt, fr, outer, in, bf, n_grid, n_cascade, n_pts, cone_angle, min_step, max_step, inclusive,
+                                lane == 0, zr);
+    }
+    if (lane == 0 && counts) counts[i] = (int32_t)j;
+    if (j > 0) {
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        const float last = zr[j - 1];
+        for (uint32_t q = lane; q < n_pts; q += 64) {
+            if (q < j) mr[q] = 1;
+            else zr[q] = last;
+        }
+    }
 }
 
 // ---- ray generation (arcnerf/render/ray_helper.py:12-153, geometry/projection.py:8-66) ------------------------------------
@@ -772,7 +883,7 @@ ARCN_EXPORT int arcn_sparse_sampling_in_multivol_bitfield(const float *rays_o, c
         return einval("sparse_sampling_in_multivol_bitfield: bad n_cascade");
     if (!(min_step > 0) || !(max_step >= min_step)) return einval("sparse_sampling_in_multivol_bitfield: need 0 < min_step <= max_step");
     Pcg32 rng{rng_state, rng_inc};
-    hipLaunchKernelGGL(multivol_sampling_kernel, dim3((unsigned)ceil_div<int64_t>(n_rays, 128)), dim3(128), 0, as_stream(stream),
+    hipLaunchKernelGGL(multivol_sampling_kernel, dim3((unsigned)ceil_div<int64_t>(n_rays, 4)), dim3(256), 0, as_stream(stream),
                        rays_o, rays_d, near, far, min_aabb, aabb, bitfield, (uint32_t)n_grid, (uint32_t)n_cascade, (uint32_t)n_pts,
                        cone_angle, min_step, max_step, near_distance, inclusive, rng, zvals, mask, counts, n_rays);
     return check_launch("sparse_sampling_in_multivol_bitfield");
