@@ -266,49 +266,13 @@ __device__ __forceinline__ uint32_t morton_at_multivol(const float pos[3], uint3
     return morton3d((uint32_t)c[0], (uint32_t)c[1], (uint32_t)c[2]);
 }
 
-// The reference loop for one ray, start to end (multivol_func_kernel.cu:33-96).  Every lane of the calling wave runs it with the
-// same values; `writer` (one lane) stores.  zr / mr are the ray's zero-initialised rows; returns the number of samples.
-__device__ __forceinline__ uint32_t multivol_serial_ray(const float o[3], const float d[3], float t, float far_end, const Aabb &outer,
-                                                        const Aabb &in, const uint8_t *__restrict__ bf, uint32_t n_grid,
-                                                        uint32_t n_cascade, uint32_t n_pts, float cone_angle, float min_step,
-                                                        float max_step, int inclusive, bool writer, float *__restrict__ zr) {
-    const uint32_t level_cells = n_grid * n_grid * n_grid;
-    uint32_t j = 0;
-    float pos[3];
-    while (t <= far_end && j < n_pts) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { float a = d[k] * t; pos[k] = o[k] + a; }
-        if (!in_aabb(pos, outer)) break;
-        const float dt = cone_dt(t, cone_angle, min_step, max_step);
-        const uint32_t mip = mip_from_pos(pos, in, n_cascade);
-        if (mip == 0 && !inclusive) {
-            // back inside the excluded inner volume: everything sampled so far is dropped
-            if (writer) for (uint32_t q = 0; q <= j; ++q) zr[q] = 0.0f;
-            j = 0;
-            const float t_target = t + dist_to_next_voxel(pos, d, in, n_grid);
-            do { t += dt; } while (t < t_target);
-        } else {
-            const uint32_t idx = morton_at_multivol(pos, mip, in, n_grid);
-            const uint32_t slot = inclusive ? mip : mip - 1;
-            if ((bf[(idx >> 3) + ((level_cells * slot) >> 3)] >> (idx & 7)) & 1) {
-                if (writer) zr[j] = t;
-                ++j;
-                t += dt;
-            } else {
-                const float t_target = t + dist_to_next_voxel(pos, d, in, n_grid);
-                do { t += cone_dt(t, cone_angle, min_step, max_step); } while (t < t_target);
-            }
-        }
-    }
-    return j;
-}
-
-// One wavefront per ray.  Outside the excluded inner volume every t the reference loop visits lies on ONE lattice
-// t_{k+1} = t_k + clamp(t_k * cone_angle, min_step, max_step) (the occupied branch and the skip loop both step that way), so the
-// wave-parallel scheme of march_count_kernel applies: 64 consecutive lattice points by a systolic DPP chain, level / occupancy /
-// skip target of all 64 in parallel, the control flow replayed on ballot masks, emitted t compacted by popcount.  What is serial:
-// the stretch INSIDE the inner volume when it is excluded (fixed-dt voxel hops, no samples: typical for cameras in the scene
-// centre), and the rare ray that re-enters it later (restart with the plain loop).  Bit-identical to the serial loop.
+// One wavefront per ray.  Outside the excluded inner volume every t the reference loop (multivol_func_kernel.cu:33-96) visits lies
+// on ONE lattice t_{k+1} = t_k + clamp(t_k * cone_angle, min_step, max_step) (the occupied branch and the skip loop both step that
+// way), so the wave-parallel scheme of march_count_kernel applies: 64 consecutive lattice points by a systolic DPP chain, level /
+// occupancy / skip target of all 64 in parallel, the control flow replayed on ballot masks, emitted t compacted by popcount.
+// INSIDE an excluded inner volume the loop hops voxel by voxel with a fixed dt and samples nothing; that stretch is walked
+// serially (by every lane alike), and reaching it drops the samples taken so far, as the reference does.  A ray is therefore a
+// sequence [inner hops] [lattice trips] [inner hops] ...  Bit-identical to the serial loop (tests against the CPU oracle).
 __global__ void __launch_bounds__(256)
 multivol_sampling_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ near,
                          const float *__restrict__ far, const float *__restrict__ min_aabb, const float *__restrict__ aabb,
@@ -322,111 +286,171 @@ multivol_sampling_kernel(const float *__restrict__ rays_o, const float *__restri
     const Aabb outer = load_aabb(aabb), in = load_aabb(min_aabb);
     const float o[3] = {rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2]};
     const float d[3] = {rays_d[3 * i], rays_d[3 * i + 1], rays_d[3 * i + 2]};
-    float startt = fmaxf(near[i], near_distance);
+    float t_base = fmaxf(near[i], near_distance);
     const float fr = far[i];
-    const float jit = cone_dt(startt, cone_angle, min_step, max_step) * rng.next_float();
-    startt += jit;
+    const float jit = cone_dt(t_base, cone_angle, min_step, max_step) * rng.next_float();
+    t_base += jit;
+    // per-ray / per-launch invariants of the level, cell and skip-distance formulas, hoisted by hand out of the marching loops (the
+    // same IEEE operations as mip_from_pos / morton_at_multivol / dist_to_next_voxel, evaluated once)
+    float center[3], inv_half[3], vsz[3], inv_d[3], hs[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        center[k] = (in.mn[k] + in.mx[k]) / 2.0f;
+        const float half = (in.mx[k] - in.mn[k]) / 2.0f;
+        inv_half[k] = 1.0f / half;
+        vsz[k] = (in.mx[k] - in.mn[k]) / (float)n_grid;
+        inv_d[k] = 1.0f / d[k];
+        hs[k] = half * copysignf(1.0f, d[k]);
+    }
+    auto level_of = [&](const float p[3]) -> uint32_t {
+        int e_max = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int e;
+            frexpf(fabsf(p[k] - center[k]) * inv_half[k], &e);
+            if (k == 0 || e > e_max) e_max = e;
+        }
+        const int m = e_max > 0 ? e_max : 0;
+        return (uint32_t)(m < (int)n_cascade - 1 ? m : (int)n_cascade - 1);
+    };
+    auto cell_of = [&](const float p[3], uint32_t mip) -> uint32_t {
+        const float scale = scalbnf(1.0f, -(int)mip);
+        int c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float q = p[k] - center[k];
+            q = q * scale;
+            q = q + center[k];
+            const float vi = (q - in.mn[k]) / vsz[k];
+            c[k] = min(max((int)vi, 0), (int)n_grid - 1);
+        }
+        return morton3d((uint32_t)c[0], (uint32_t)c[1], (uint32_t)c[2]);
+    };
+    auto skip_of = [&](const float p[3]) -> float {
+        float t_min = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float pn = (float)n_grid * p[k];
+            float a = pn + center[k];
+            a = a + hs[k];
+            const float tt = (floorf(a) - pn) * inv_d[k];
+            if (k == 0 || tt < t_min) t_min = tt;
+        }
+        return fmaxf(t_min / (float)n_grid, 0.0f);
+    };
     const uint32_t level_cells = n_grid * n_grid * n_grid;
     float *zr = zvals + i * (int64_t)n_pts;
     uint8_t *mr = mask + i * (int64_t)n_pts;
-    uint32_t j = 0;
-    bool ended = false, restart = false;
-    float t_base = startt;
-    float pos[3];
-    // phase 1 (inner volume excluded): hop through it voxel by voxel, nothing is sampled there
-    if (!inclusive) {
-        while (t_base <= fr) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { float a = d[k] * t_base; pos[k] = o[k] + a; }
-            if (!in_aabb(pos, outer)) { ended = true; break; }
-            if (mip_from_pos(pos, in, n_cascade) != 0) break;
-            const float dt = cone_dt(t_base, cone_angle, min_step, max_step);
-            const float t_target = t_base + dist_to_next_voxel(pos, d, in, n_grid);
-            do { t_base += dt; } while (t_base < t_target);
-        }
-    }
-    // phase 2: the cone lattice, 64 points per trip
-    bool have_pending = false;
-    float pending = 0.f;
+    uint32_t j = 0, dirty = 0;   // dirty: slots written by samples that were dropped later
+    bool ended = false;
     const float lane_on = lane == 0 ? 0.0f : 1.0f;
+    float pos[3];
     while (!ended) {
-        if (!(t_base <= fr)) break;
-        float t = t_base;
+        // inner hops (inner volume excluded): from a point inside it to the first visited point outside, nothing is sampled
+        if (!inclusive) {
+            while (t_base <= fr) {
 #pragma unroll
-        for (int k = 0; k < 63; ++k) {
-            const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0x138, 0xf, 0xf, false));
-            const float step = cone_dt(left, cone_angle, min_step, max_step) * lane_on;   // lane 0 keeps the chunk's first point
-            t = left + step;
-        }
-        const float t63 = __shfl(t, 63, 64);
-        const float t_next_base = t63 + cone_dt(t63, cone_angle, min_step, max_step);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { float a = d[k] * t; pos[k] = o[k] + a; }
-        const bool alive = (t <= fr) && in_aabb(pos, outer);
-        uint32_t mip = 0;
-        if (alive) mip = mip_from_pos(pos, in, n_cascade);
-        const bool inner = alive && mip == 0 && !inclusive;
-        bool occ = false;
-        if (alive && !inner) {
-            const uint32_t idx = morton_at_multivol(pos, mip, in, n_grid);
-            const uint32_t slot = inclusive ? mip : mip - 1;
-            occ = (bf[(idx >> 3) + ((level_cells * slot) >> 3)] >> (idx & 7)) & 1;
-        }
-        const float target = (alive && !occ) ? t + dist_to_next_voxel(pos, d, in, n_grid) : 0.f;
-        const uint64_t alive_m = __ballot(alive), occ_m = __ballot(occ), inner_m = __ballot(inner);
-        uint64_t emit_m = 0;
-        int k = 0;
-        if (have_pending) {
-            const uint64_t ge = __ballot(t >= pending);
-            if (ge == 0) { t_base = t_next_base; continue; }
-            k = __builtin_ctzll(ge);
-            have_pending = false;
-        }
-        while (k < 64) {
-            if (!((alive_m >> k) & 1)) { ended = true; break; }
-            if ((inner_m >> k) & 1) { restart = true; ended = true; break; }   // re-entered the excluded volume: rare, redo serially
-            if ((occ_m >> k) & 1) {
-                const uint64_t stop = ~(occ_m & alive_m) >> k;
-                int run = stop ? __builtin_ctzll(stop) : 64 - k;
-                const int room = (int)(n_pts - j);
-                if (run >= room) { run = room; ended = true; }
-                emit_m |= (run >= 64 ? ~0ull : ((1ull << run) - 1ull)) << k;
-                j += (uint32_t)run;
-                k += run;
-                if (ended) break;
-            } else {
-                const float tgt = __shfl(target, k, 64);
-                const uint64_t after = (k >= 63) ? 0ull : (~0ull << (k + 1));
-                const uint64_t ge = __ballot(t >= tgt) & after;
-                if (ge == 0) { have_pending = true; pending = tgt; k = 64; }
-                else k = __builtin_ctzll(ge);
+                for (int k = 0; k < 3; ++k) { float a = d[k] * t_base; pos[k] = o[k] + a; }
+                if (!in_aabb(pos, outer)) { ended = true; break; }
+                if (level_of(pos) != 0) break;
+                const float dt = cone_dt(t_base, cone_angle, min_step, max_step);
+                const float t_target = t_base + skip_of(pos);
+                do { t_base += dt; } while (t_base < t_target);
             }
+            if (ended) break;
         }
-        if ((emit_m >> lane) & 1) {
-            const uint32_t before = (uint32_t)__builtin_popcountll(emit_m & ((1ull << lane) - 1ull));
-            const uint32_t cnt_chunk = (uint32_t)__builtin_popcountll(emit_m);
-            zr[j - cnt_chunk + before] = t;
+        // lattice trips from t_base until the ray ends or a visited point lies in the excluded inner volume again
+        bool have_pending = false, reenter = false;
+        float pending = 0.f;
+        while (!ended && !reenter) {
+            if (!(t_base <= fr)) { ended = true; break; }
+            float t = t_base;
+#pragma unroll
+            for (int k = 0; k < 63; ++k) {
+                const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0x138, 0xf, 0xf, false));
+                const float step = cone_dt(left, cone_angle, min_step, max_step) * lane_on;   // lane 0 keeps the trip's first point
+                t = left + step;
+            }
+            const float t63 = __shfl(t, 63, 64);
+            const float t_next_base = t63 + cone_dt(t63, cone_angle, min_step, max_step);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { float a = d[k] * t; pos[k] = o[k] + a; }
+            const bool alive = (t <= fr) && in_aabb(pos, outer);
+            uint32_t mip = 0;
+            if (alive) mip = level_of(pos);
+            const bool inner = alive && mip == 0 && !inclusive;
+            bool occ = false;
+            if (alive && !inner) {
+                const uint32_t idx = cell_of(pos, mip);
+                const uint32_t slot = inclusive ? mip : mip - 1;
+                occ = (bf[(idx >> 3) + ((level_cells * slot) >> 3)] >> (idx & 7)) & 1;
+            }
+            const float target = (alive && !occ) ? t + skip_of(pos) : 0.f;
+            const uint64_t alive_m = __ballot(alive), occ_m = __ballot(occ), inner_m = __ballot(inner);
+            // In the far levels the step outgrows the (inner-grid sized) skip distance: an empty point's target is reached by the
+            // very next lattice point.  Runs of such points are walked in one go, like runs of occupied ones.
+            const float t_right = __shfl_down(t, 1, 64);
+            const uint64_t step1_m = __ballot(alive && !occ && !inner && lane < 63 && target <= t_right);
+            uint64_t emit_m = 0;
+            uint32_t j_trip = j;
+            int k = 0;
+            if (have_pending) {
+                const uint64_t ge = __ballot(t >= pending);
+                if (ge == 0) { t_base = t_next_base; continue; }
+                k = __builtin_ctzll(ge);
+                have_pending = false;
+            }
+            while (k < 64) {
+                if (!((alive_m >> k) & 1)) { ended = true; break; }
+                if ((inner_m >> k) & 1) {
+                    // the visited point k is back inside the excluded volume: drop every sample so far and hop from there
+                    dirty = j_trip > dirty ? j_trip : dirty;
+                    j_trip = 0;
+                    emit_m = 0;
+                    t_base = __shfl(t, k, 64);
+                    reenter = true;
+                    break;
+                }
+                if ((occ_m >> k) & 1) {
+                    const uint64_t stop = ~(occ_m & alive_m) >> k;
+                    int run = stop ? __builtin_ctzll(stop) : 64 - k;
+                    const int room = (int)(n_pts - j_trip);
+                    if (run >= room) { run = room; ended = true; }
+                    emit_m |= (run >= 64 ? ~0ull : ((1ull << run) - 1ull)) << k;
+                    j_trip += (uint32_t)run;
+                    k += run;
+                    if (ended) break;
+                } else if ((step1_m >> k) & 1) {
+                    const uint64_t stop = ~step1_m >> k;          // first lane that is not a one-step empty point
+                    k += stop ? __builtin_ctzll(stop) : 64 - k;   // (it is visited: its left neighbour stepped onto it)
+                } else {
+                    const float tgt = __shfl(target, k, 64);
+                    const uint64_t after = (k >= 63) ? 0ull : (~0ull << (k + 1));
+                    const uint64_t ge = __ballot(t >= tgt) & after;
+                    if (ge == 0) { have_pending = true; pending = tgt; k = 64; }
+                    else k = __builtin_ctzll(ge);
+                }
+            }
+            j = j_trip;
+            if ((emit_m >> lane) & 1) {
+                const uint32_t before = (uint32_t)__builtin_popcountll(emit_m & ((1ull << lane) - 1ull));
+                const uint32_t cnt_chunk = (uint32_t)__builtin_popcountll(emit_m);
+                zr[j - cnt_chunk + before] = t;
+            }
+            if (!reenter) t_base = t_next_base;
         }
-        t_base = t_next_base;
-    }
-    if (restart) {
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        for (uint32_t q = lane; q < j; q += 64) zr[q] = 0.0f;
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        j = multivol_serial_ray(o, d, startt, fr, outer, in, bf, n_grid, n_cascade, n_pts, cone_angle, min_step, max_step, inclusive,
-                                lane == 0, zr);
     }
     if (lane == 0 && counts) counts[i] = (int32_t)j;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
     if (j > 0) {
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
         const float last = zr[j - 1];
         for (uint32_t q = lane; q < n_pts; q += 64) {
             if (q < j) mr[q] = 1;
             else zr[q] = last;
         }
+    } else {
+        for (uint32_t q = lane; q < dirty; q += 64) zr[q] = 0.0f;   // dropped samples leave the row as the caller initialised it
     }
 }
 
