@@ -7,6 +7,7 @@ host decisions of FgModel.forward and runs the packed, device-count-driven kerne
 module's own parameters.  Outputs (keys, shapes, values) are the same; tests compare both paths.
 """
 import torch
+from torch.autograd.function import once_differentiable
 
 from ..pipeline import NgpConfig, NgpField, NgpPipeline
 from ..render.ray_helper import sample_pdf
@@ -35,6 +36,7 @@ class _PackedRenderFn(torch.autograd.Function):
         return rgb.clone(), depth.clone(), mask.clone(), counts
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, d_rgb, d_depth, d_mask, _):
         pipe = ctx.pipe
         if pipe.generation != ctx.gen:

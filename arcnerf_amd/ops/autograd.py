@@ -4,6 +4,7 @@ The reference gets its backward from torch autograd over ~25 tiny kernels per en
 every Function is one forward kernel and one backward kernel.
 """
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import functional as F
 
@@ -24,6 +25,7 @@ class HashGridFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable   # first order only: a second differentiation through this node raises instead of being silently wrong
     def backward(ctx, dout):
         xyz, table = ctx.saved_tensors
         dtable = dxyz = None
@@ -50,6 +52,7 @@ class HashGridDxFn(torch.autograd.Function):
         return dxyz
 
     @staticmethod
+    @once_differentiable   # first order only: a second differentiation through this node raises instead of being silently wrong
     def backward(ctx, gdx):
         xyz, table, dout = ctx.saved_tensors
         need_x, need_t, need_d = ctx.needs_input_grad[:3]
@@ -92,6 +95,7 @@ class FreqFn(torch.autograd.Function):
         return F.freq_fwd(x, n_freqs, include_input)
 
     @staticmethod
+    @once_differentiable   # first order only: a second differentiation through this node raises instead of being silently wrong
     def backward(ctx, dout):
         (x,) = ctx.saved_tensors
         return F.freq_bwd(x, dout.contiguous(), *ctx.cfg), None, None
@@ -108,6 +112,7 @@ class TruncExpFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable   # first order only: a second differentiation through this node raises instead of being silently wrong
     def backward(ctx, g):
         x, y = ctx.saved_tensors
         return F.act_bwd(x, y, g.contiguous(), 'truncexp')
@@ -130,6 +135,7 @@ class FusedMlpFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable   # first order only: a second differentiation through this node raises instead of being silently wrong
     def backward(ctx, dout):
         x, weights, biases, out, acts = ctx.saved_tensors
         b = biases if ctx.has_bias else None
@@ -158,6 +164,7 @@ class RayMarchingFn(torch.autograd.Function):
         return rgb, out['depth'], out['mask'], out['alpha'], out['trans_shift'], out['weights'], out['status'], t_last
 
     @staticmethod
+    @once_differentiable   # first order only: a second differentiation through this node raises instead of being silently wrong
     def backward(ctx, d_rgb, d_depth, d_mask, _da, _dt, d_w, _ds, d_tlast):
         sigma, radiance, zvals, alpha, bkg, noise = [t if h else None for t, h in
                                                      zip(ctx.saved_tensors, (ctx.has[0], ctx.has[1], True, ctx.has[2], ctx.has[3], ctx.has[4]))]
@@ -187,6 +194,7 @@ class PackedCompositeFn(torch.autograd.Function):
         return out['rgb'], out['depth'], out['mask']
 
     @staticmethod
+    @once_differentiable   # first order only: a second differentiation through this node raises instead of being silently wrong
     def backward(ctx, d_rgb, d_depth, d_mask):
         sigma, radiance, t, offsets, p_dense_dev, noise = ctx.saved_tensors
         d_sigma, d_rad = F.composite_packed_bwd(sigma, radiance, t, offsets, d_rgb.contiguous(), d_depth.contiguous(), d_mask.contiguous(),
@@ -208,6 +216,7 @@ class SdfToAlphaFn(torch.autograd.Function):
         return F.sdf_to_alpha_fwd(mid_sdf, zvals, mid_slope, s_t, clip=ctx.clip)
 
     @staticmethod
+    @once_differentiable   # first order only: a second differentiation through this node raises instead of being silently wrong
     def backward(ctx, d_alpha):
         mid_sdf, zvals, mid_slope, s_t = ctx.saved_tensors
         d_sdf, d_slope, d_s = F.sdf_to_alpha_bwd(mid_sdf, zvals, mid_slope, s_t, d_alpha.contiguous(), clip=ctx.clip)

@@ -865,3 +865,17 @@ def test_fused_adam_optimizer_matches_torch_adam(F):
         cpu_p = torch.zeros(4, requires_grad=True)
         cpu_p.grad = torch.ones(4)
         FusedAdam([cpu_p]).step()
+
+
+def test_first_order_only_nodes_refuse_a_second_differentiation(F):
+    """the fused MLP has a hand-written first-order backward: asking autograd to differentiate THROUGH that backward (an sdf net on
+    the fused kernels with normals by create_graph) must raise, not return gradients that silently ignore the path"""
+    from arcnerf_amd import _native as N
+    from arcnerf_amd.ops.autograd import FusedMlpFn
+    desc = N.make_mlp_desc([8, 16, 4], 'relu', None, False)
+    w = torch.randn(8 * 16 + 16 * 4, device='cuda', requires_grad=True)
+    x = torch.randn(64, 8, device='cuda', requires_grad=True)
+    y = FusedMlpFn.apply(x, w, None, desc)
+    dx, = torch.autograd.grad(y.sum(), x, create_graph=True)
+    with pytest.raises(RuntimeError):
+        dx.pow(2).sum().backward()
