@@ -141,4 +141,5 @@ for it in range(1, MAX_IT + 1):
                               'rays_per_step': n_rays, 'samples_per_s_incl_host': samples_total / max(t_train, 1e-9)})
         print(json.dumps(out['points'][-1]), file=sys.stderr, flush=True)
         t_last = time.perf_counter()
-print(json.dumps(out))
+if MAX_IT > 0:
+    print(json.dumps(out))
