@@ -556,6 +556,9 @@ __global__ void __launch_bounds__(256) reduce_max_kernel(const float *__restrict
 //      carried into the next chunk,
 //   4. writes the emitted t's compacted by popcount.
 // Same arithmetic, same decisions => bit-identical zvals / counts (tests compare against the serial CPU oracle).
+#ifndef ARCN_MARCH_JUMP_TABLE
+#define ARCN_MARCH_JUMP_TABLE 1
+#endif
 template <int MODE>
 __global__ void __launch_bounds__(256)
 march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ aabb,
@@ -622,6 +625,23 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
             const bool occ = alive && occupied_at<MODE>(pos, bf, b, n_grid);
             const float target = (alive && !occ) ? t + dist_to_next_voxel(pos, d, b, n_grid) : 0.f;
             const uint64_t alive_m = __ballot(alive), occ_m = __ballot(occ);
+            // jump table: for an empty point the reference's `do t += dt while (t < t_target)` lands on the first later lattice
+            // point with t >= target.  t grows with the lane, so every lane finds its landing lane by bisection over the wave
+            // (6 cross-lane reads, all lanes at once) and the replay below only follows pointers.  64 = beyond this trip.
+            int next_lane = 64;
+            if (ARCN_MARCH_JUMP_TABLE) {
+                int lo = lane + 1, hi = 64;
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const int mid = (lo + hi) >> 1;
+                    const float tm = __shfl(t, mid & 63, 64);
+                    const bool ge = mid < 64 && tm >= target;
+                    const bool open = lo < hi;
+                    hi = (open && ge) ? mid : hi;
+                    lo = (open && !ge) ? mid + 1 : lo;
+                }
+                next_lane = lo;
+            }
             // 3. replay on wave-uniform state
             uint64_t emit_m = 0;
             int k = 0;
@@ -643,6 +663,10 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
                     j += (uint32_t)run;
                     k += run;
                     if (done) break;
+                } else if (ARCN_MARCH_JUMP_TABLE) {
+                    const int nx = __builtin_amdgcn_readlane(next_lane, k);
+                    if (nx >= 64) { have_pending = true; pending = __shfl(target, k, 64); }
+                    k = nx;
                 } else {
                     const float tgt = __shfl(target, k, 64);
                     const uint64_t after = (k >= 63) ? 0ull : (~0ull << (k + 1));
