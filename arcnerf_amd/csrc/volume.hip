@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(256) reduce_max_kernel(const float *__restrict
 //   4. writes the emitted t's compacted by popcount.
 // Same arithmetic, same decisions => bit-identical zvals / counts (tests compare against the serial CPU oracle).
 #ifndef ARCN_MARCH_JUMP_TABLE
-#define ARCN_MARCH_JUMP_TABLE 1
+#define ARCN_MARCH_JUMP_TABLE 2   // 0: ballot search per jump, 1: per-lane jump table + scalar pointer chase, 2: no scalar loop (orbit by binary lifting)
 #endif
 template <int MODE>
 __global__ void __launch_bounds__(256)
@@ -650,6 +650,45 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
                 if (ge == 0) { t_base = t_next_base; continue; }  // the whole chunk is skipped
                 k = __builtin_ctzll(ge);
                 have_pending = false;
+            }
+            if (ARCN_MARCH_JUMP_TABLE == 2) {
+                // The visited points are the orbit of k under J: occupied -> the next lane, empty -> its landing lane, not alive ->
+                // itself (the walk ends there), 64 = beyond this trip.  No scalar loop: J^(2^r) by pointer doubling (5 cross-lane
+                // reads), then every lane y finds the last orbit element <= y by binary lifting from k (6 reads): y is visited iff
+                // that element is y.
+                int J[6];
+                J[0] = !alive ? lane : (occ ? lane + 1 : next_lane);
+#pragma unroll
+                for (int r = 1; r < 6; ++r) {
+                    const int hop = __shfl(J[r - 1], J[r - 1] & 63, 64);
+                    J[r] = J[r - 1] >= 64 ? 64 : hop;
+                }
+                int pos = k;
+#pragma unroll
+                for (int r = 5; r >= 0; --r) {
+                    const int hop = __shfl(J[r], pos & 63, 64);
+                    const int cand = pos >= 64 ? 64 : hop;
+                    pos = cand <= lane ? cand : pos;
+                }
+                const uint64_t visited_m = __ballot(lane >= k && pos == lane);
+                uint64_t e_m = visited_m & occ_m;
+                const int room = (int)(n_pts - j);
+                if (__builtin_popcountll(e_m) >= room) {          // the ray is full after `room` more samples
+                    uint64_t keep = e_m;
+                    for (int drop = __builtin_popcountll(e_m) - room; drop > 0; --drop) keep &= ~(1ull << (63 - __builtin_clzll(keep)));
+                    e_m = keep;
+                    done = true;
+                }
+                emit_m = e_m;
+                j += (uint32_t)__builtin_popcountll(e_m);
+                if (!done) {
+                    if (visited_m & ~alive_m) done = true;         // the walk reached a point past far / outside the box
+                    else {
+                        const int last = 63 - __builtin_clzll(visited_m);   // leaves the trip from here
+                        if (!((occ_m >> last) & 1)) { have_pending = true; pending = __shfl(target, last, 64); }
+                    }
+                }
+                k = 64;
             }
             while (k < 64) {
                 if (!((alive_m >> k) & 1)) { done = true; break; }
