@@ -550,10 +550,12 @@ __global__ void __launch_bounds__(256) reduce_max_kernel(const float *__restrict
 // visits lies on ONE lattice t_0 = start, t_{k+1} = fl(t_k + dt) (both branches only ever add dt).  So a wave
 //   1. generates 64 consecutive lattice values with the same sequential fp32 adds (lane l performs l adds),
 //   2. evaluates in parallel, for its 64 points, `alive` (t <= far && inside the box), `occupied` and the skip distance,
-//   3. REPLAYS the reference's control flow on wave-uniform 64-bit masks: runs of occupied points are emitted with bit
-//      tricks, an unoccupied visited point k jumps to the first lattice point m > k with t_m >= t_k + dist_k (exactly the
-//      reference's `do t += dt while (t < t_target)`), found with one vector compare + ballot; a target beyond the chunk is
-//      carried into the next chunk,
+//   3. REPLAYS the reference's control flow: an unoccupied visited point k jumps to the first lattice point m > k with
+//      t_m >= t_k + dist_k (exactly the reference's `do t += dt while (t < t_target)`), an occupied one is emitted and steps
+//      to k + 1; a target beyond the chunk is carried into the next chunk.  Three implementations (ARCN_MARCH_JUMP_TABLE):
+//      0 = a scalar loop over the visited points with one vector compare + ballot per jump; 1 = landing lanes of all 64 points
+//      by bisection first, the scalar loop only chases pointers; 2 (default) = no scalar loop at all, the visited set is the
+//      orbit of the entry lane under the jump table, by pointer doubling and a binary-lifting walk (172 / 150 / 108 us),
 //   4. writes the emitted t's compacted by popcount.
 // Same arithmetic, same decisions => bit-identical zvals / counts (tests compare against the serial CPU oracle).
 #ifndef ARCN_MARCH_JUMP_TABLE
