@@ -111,51 +111,86 @@ __device__ __forceinline__ float act_grad(float v, float y, int act, float beta)
 }
 
 // ---- wave-level scans (64 lanes) ---------------------------------------------------------------
+// All of these run on the VALU's DPP cross-lane path: a shift inside a 16-lane row is a modifier on the consuming instruction,
+// and the three row totals cross rows through v_readlane (SGPRs).  The ds_bpermute forms (__shfl*) they replace go through the
+// LDS pipeline at ~6 issue cycles per wave each: the fused compositor issued 59 of them per ray and, with 8320 rays in flight,
+// spent a quarter of its run time queued on that pipeline.  Every lane of the wave must be active at the call.
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// DPP controls (gfx9 encoding): row_shl:n 0x100+n (lane i reads lane i+n of its row), row_shr:n 0x110+n (lane i reads lane i-n),
+// wave_shl:1 0x130, wave_shr:1 0x138, row_mirror 0x140, row_half_mirror 0x141.  A lane whose source falls outside the row (or the
+// wave) keeps `fill`.
+template <int CTRL>
+__device__ __forceinline__ float dpp_take(float fill, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_take_i(int fill, int v) {
+    return __builtin_amdgcn_update_dpp(fill, v, CTRL, 0xf, 0xf, false);
+}
+template <int LANE>
+__device__ __forceinline__ float lane_value(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), LANE));
+}
+
+// lane i <- lane i-1 (lane 0 <- fill) and lane i <- lane i+1 (lane 63 <- fill)
+__device__ __forceinline__ float wave_from_below(float v, float fill) { return dpp_take<0x138>(fill, v); }
+__device__ __forceinline__ float wave_from_above(float v, float fill) { return dpp_take<0x130>(fill, v); }
 
 // inclusive prefix product across the wave
 __device__ __forceinline__ float wave_incl_prod(float v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float o = __shfl_up(v, d, 64);
-        if (lane >= d) v = v * o;
-    }
-    return v;
+    v = v * dpp_take<0x111>(1.f, v);
+    v = v * dpp_take<0x112>(1.f, v);
+    v = v * dpp_take<0x114>(1.f, v);
+    v = v * dpp_take<0x118>(1.f, v);
+    const float r0 = lane_value<15>(v), r1 = lane_value<31>(v), r2 = lane_value<47>(v);
+    const int row = lane_id() >> 4;
+    const float r01 = r0 * r1;
+    const float below = row == 0 ? 1.f : (row == 1 ? r0 : (row == 2 ? r01 : r01 * r2));
+    return below * v;
 }
 
 // inclusive prefix sum
 __device__ __forceinline__ float wave_incl_sum(float v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float o = __shfl_up(v, d, 64);
-        if (lane >= d) v = v + o;
-    }
-    return v;
+    v = v + dpp_take<0x111>(0.f, v);
+    v = v + dpp_take<0x112>(0.f, v);
+    v = v + dpp_take<0x114>(0.f, v);
+    v = v + dpp_take<0x118>(0.f, v);
+    const float r0 = lane_value<15>(v), r1 = lane_value<31>(v), r2 = lane_value<47>(v);
+    const int row = lane_id() >> 4;
+    const float r01 = r0 + r1;
+    const float below = row == 0 ? 0.f : (row == 1 ? r0 : (row == 2 ? r01 : r01 + r2));
+    return below + v;
 }
 
 // inclusive suffix sum (lane i gets sum of lanes >= i)
 __device__ __forceinline__ float wave_incl_suffix_sum(float v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float o = __shfl_down(v, d, 64);
-        if (lane + d < 64) v = v + o;
-    }
-    return v;
+    v = v + dpp_take<0x101>(0.f, v);
+    v = v + dpp_take<0x102>(0.f, v);
+    v = v + dpp_take<0x104>(0.f, v);
+    v = v + dpp_take<0x108>(0.f, v);
+    const float r1 = lane_value<16>(v), r2 = lane_value<32>(v), r3 = lane_value<48>(v);
+    const int row = lane_id() >> 4;
+    const float r23 = r2 + r3;
+    const float above = row == 3 ? 0.f : (row == 2 ? r3 : (row == 1 ? r23 : r23 + r1));
+    return above + v;
 }
 
+// sum over the wave, the same value in every lane
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    v = v + dpp_take<0xB1>(0.f, v);   // quad_perm [1,0,3,2]
+    v = v + dpp_take<0x4E>(0.f, v);   // quad_perm [2,3,0,1]
+    v = v + dpp_take<0x141>(0.f, v);  // the other quad of the half row
+    v = v + dpp_take<0x140>(0.f, v);  // the other half of the row
+    return (lane_value<0>(v) + lane_value<16>(v)) + (lane_value<32>(v) + lane_value<48>(v));
 }
 
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    v = v + dpp_take_i<0xB1>(0, v);
+    v = v + dpp_take_i<0x4E>(0, v);
+    v = v + dpp_take_i<0x141>(0, v);
+    v = v + dpp_take_i<0x140>(0, v);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 
 }  // namespace arcn

@@ -457,8 +457,10 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
     // runs of consecutive samples (lanes) in the same cell: head lanes, and for every lane the last lane of its run
     const uint32_t kxy = cell.valid ? (cell.c[0] | (cell.c[1] << 16)) : 0xffffffffu;
     const uint32_t kz = cell.valid ? cell.c[2] : (uint32_t)lane;
-    const uint32_t pxy = __shfl_up(kxy, 1), pz = __shfl_up(kz, 1);
-    const bool head = lane == 0 || kxy != pxy || kz != pz;
+    // a run never crosses a 16-lane row: the run sums below then stay on the DPP row shifts (VALU) instead of ds_bpermute, which
+    // queued on the LDS pipeline next to the histogram atomics; at most three runs per wave are cut in two by this
+    const uint32_t pxy = (uint32_t)dpp_take_i<0x111>(-1, (int)kxy), pz = (uint32_t)dpp_take_i<0x111>(-1, (int)kz);
+    const bool head = (lane & 15) == 0 || kxy != pxy || kz != pz;
     const uint64_t heads = __ballot(head && cell.valid), valid = __ballot(cell.valid);
     // Per wave: with an average run of >= 1.5 samples the runs are summed first (fewer records, fewer row updates, and no
     // neighbouring lanes fighting over one row lock in the consumer); otherwise the x pairs go out as they are.
@@ -518,7 +520,7 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
         // segmented suffix sum by doubling over the 8 corners x F values; only the head lane of a run emits its 8 singles
         const uint64_t all_heads = __ballot(head);
         const uint64_t above = lane == 63 ? 0ull : (all_heads & ~((2ull << lane) - 1ull));
-        const int tail = above ? (int)__builtin_ctzll(above) - 1 : 63;
+        const int tail = above ? (int)__builtin_ctzll(above) - 1 : 63;  // <= the last lane of this lane's row
         float va[8], vb[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -528,19 +530,28 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
             va[q] = g0 * wt;
             vb[q] = g1 * wt;
         }
-        for (int d = 1; d < 64; d <<= 1) {
-            const bool take = lane + d <= tail;
-            if (!__ballot(take)) break;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float ua = __shfl_down(va[q], d);
-                va[q] += take ? ua : 0.f;
-                if (F > 1) {
-                    const float ub = __shfl_down(vb[q], d);
-                    vb[q] += take ? ub : 0.f;
-                }
-            }
+        // one doubling step with the row shift as a template constant; false once no lane has anything left to take
+#define ARCN_RUN_STEP(D)                                                              \
+        {                                                                             \
+            const bool take = lane + (D) <= tail;                                     \
+            more = __ballot(take) != 0ull;                                            \
+            if (more) {                                                               \
+                _Pragma("unroll") for (int q = 0; q < 8; ++q) {                       \
+                    const float ua = dpp_take<0x100 + (D)>(0.f, va[q]);               \
+                    va[q] += take ? ua : 0.f;                                         \
+                    if (F > 1) {                                                      \
+                        const float ub = dpp_take<0x100 + (D)>(0.f, vb[q]);           \
+                        vb[q] += take ? ub : 0.f;                                     \
+                    }                                                                 \
+                }                                                                     \
+            }                                                                         \
         }
+        bool more = true;
+        ARCN_RUN_STEP(1)
+        if (more) ARCN_RUN_STEP(2)
+        if (more) ARCN_RUN_STEP(4)
+        if (more) ARCN_RUN_STEP(8)
+#undef ARCN_RUN_STEP
         if (head && cell.valid) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {

@@ -138,8 +138,7 @@ __device__ __forceinline__ RayOut composite_fwd_ray(View &v, int64_t r, int lane
             zz = v.z(r, k);
         }
         float incl = wave_incl_prod(q);
-        float excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.0f;
+        float excl = wave_from_below(incl, 1.0f);
         float T = carry * excl;
         float w = a * T;
         if (on) {
@@ -158,7 +157,7 @@ __device__ __forceinline__ RayOut composite_fwd_ray(View &v, int64_t r, int lane
             }
             if (k == nc - 1) t_last = T;
         }
-        carry = carry * __shfl(incl, 63, 64);
+        carry = carry * lane_value<63>(incl);
     }
     RayOut o;
     o.depth = wave_sum(acc_d);
@@ -248,16 +247,14 @@ __device__ __forceinline__ void composite_bwd_ray(View &v, int64_t r, int lane, 
             }
         }
         float incl = wave_incl_prod(q);
-        float excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.0f;
+        float excl = wave_from_below(incl, 1.0f);
         float T = chunk_carry[c] * excl;
         float w = a * T;
         float term = on ? w * gi : 0.f;
         // when column Pe-1 is visited, T_last = T at that column: it depends on every earlier alpha only
         if (on && k == nc - 1 && final_visited) term += T * B;
         float sfx_incl = wave_incl_suffix_sum(term);
-        float sfx_excl = __shfl_down(sfx_incl, 1, 64);
-        if (lane == 63) sfx_excl = 0.f;
+        float sfx_excl = wave_from_above(sfx_incl, 0.f);
         float suffix = sfx_excl + suffix_carry;
         // otherwise T_last is the product over ALL visited q (== carry) and depends on every visited alpha
         if (!final_visited) suffix += carry * B;
@@ -280,7 +277,7 @@ __device__ __forceinline__ void composite_bwd_ray(View &v, int64_t r, int lane, 
                 virt_w = w;
             }
         }
-        suffix_carry += __shfl(sfx_incl, 0, 64);
+        suffix_carry += lane_value<0>(sfx_incl);
     }
     // the virtual final column aliases sample n-1, whose own column (delta 0) was stored by another lane of this
     // wave: accumulate after those stores have been issued and completed.
@@ -326,7 +323,7 @@ composite_bwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict
             q = (1.0f - a) + 1e-10f;
         }
         float incl = wave_incl_prod(q);
-        carry = carry * __shfl(incl, 63, 64);
+        carry = carry * lane_value<63>(incl);
     }
     __builtin_amdgcn_wave_barrier();
     const float g0 = d_rgb ? d_rgb[3 * r] : 0.f, g1 = d_rgb ? d_rgb[3 * r + 1] : 0.f, g2 = d_rgb ? d_rgb[3 * r + 2] : 0.f;
