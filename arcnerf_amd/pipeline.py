@@ -285,7 +285,11 @@ class NgpPipeline:
         self.level_major = bool(level_major and xcd_scatter and cfg.n_feat_per_entry == 2 and field.geo_desc.n_layers == 2 and
                                 not field.geo_desc.has_bias and gd[0] in (32, 64) and 48 < gd[1] <= 64 and gd[2] <= 16)
         # optional: issue the two dW reductions after the scatter instead of right behind their nets (measured: slower, 0.833 vs 0.822 ms)
-        self.defer_dw = bool(int(os.environ.get('ARCN_DEFER_DW', '0'))) and self.level_major
+        # dW partial reductions of the fused MLP backward: 0 = inside the backward entry points, 1 = after the scatter, 2 = on their own
+        # stream next to the following backward kernels (they are latency-bound: 128 / 192 workgroups, ~16 us each)
+        self.defer_dw = int(os.environ.get('ARCN_DEFER_DW', '0')) if self.level_major else 0
+        self.red_stream = torch.cuda.Stream(device=dev) if (dev.type == 'cuda' and self.defer_dw == 2) else None
+        self._red_event = None
         # optimiser state
         n = field.n_params
         self.exp_avg = torch.zeros(n, dtype=f32, device=dev)
@@ -516,8 +520,10 @@ class NgpPipeline:
             N.check(L.arcn_mlp_bwd_cat(N.ptr(b['geo_out']), N.ptr(b['sh_ray']), N.ptr(b['ray_id']), int(cfg.rad_mode == 'fv'),
                                        N.ptr(self._p('rad_w')), N.C.addressof(fld.rad_desc), N.ptr(b['rgb_s']), N.ptr(b['rad_acts']),
                                        N.ptr(b['d_rgb_s']), N.ptr(b['d_geo_out']), N.ptr(b['d_sigma']), N.ACT[cfg.sigma_act],
-                                       N.ptr(self._g('rad_w')), N.ptr(b['rad_scratch']), int(self.defer_dw), S, S, n_dev.data_ptr(), st),
+                                       N.ptr(self._g('rad_w')), N.ptr(b['rad_scratch']), int(self.defer_dw > 0), S, S, n_dev.data_ptr(), st),
                     'mlp_bwd_cat(rad)')
+            if self.red_stream is not None:
+                self._reduce_on_side(fld.rad_desc, b['rad_scratch'], self._g('rad_w'), S)
         else:
             N.check(L.arcn_mlp_bwd(N.ptr(b['rad_in']), N.ptr(self._p('rad_w')), N.ptr(self._p('rad_b')), N.C.addressof(fld.rad_desc),
                                    N.ptr(b['rgb_s']), N.ptr(b['rad_acts']), N.ptr(b['d_rgb_s']), N.ptr(b['d_rad_in']),
@@ -529,11 +535,13 @@ class NgpPipeline:
         if self.level_major:
             N.check(L.arcn_mlp_bwd_lm(N.ptr(b['feat']), S, N.ptr(self._p('geo_w')), N.C.addressof(fld.geo_desc), N.ptr(b['geo_out']),
                                       N.ptr(b['geo_acts']), N.ptr(b['d_geo_out']), N.ptr(b['d_feat']), N.ptr(self._g('geo_w')),
-                                      N.ptr(b['geo_scratch']), int(self.defer_dw), S, S, n_dev.data_ptr(), st), 'mlp_bwd_lm(geo)')
+                                      N.ptr(b['geo_scratch']), int(self.defer_dw > 0), S, S, n_dev.data_ptr(), st), 'mlp_bwd_lm(geo)')
+            if self.red_stream is not None:
+                self._reduce_on_side(fld.geo_desc, b['geo_scratch'], self._g('geo_w'), S)
             self._prefetch_point(2)
             N.check(L.arcn_hashgrid_bwd_lm(N.ptr(b['xyz']), N.ptr(b['d_feat']), S, N.C.addressof(fld.grid_desc), N.ptr(self._g('table')),
                                            N.ptr(self.hash_ws), self.hash_ws.numel(), S, n_dev.data_ptr(), st), 'hashgrid_bwd_lm')
-            if self.defer_dw:
+            if self.defer_dw == 1:
                 # the two tiny dW reductions run here, after the scatter, instead of between the big backward kernels where
                 # they queue behind the overlapped marching (27 us each there, 6 us here)
                 N.check(L.arcn_mlp_bwd_reduce(N.C.addressof(fld.geo_desc), N.ptr(b['geo_scratch']), N.ptr(self._g('geo_w')), S, S, st),
@@ -541,6 +549,7 @@ class NgpPipeline:
                 if self.fused_glue:
                     N.check(L.arcn_mlp_bwd_reduce(N.C.addressof(fld.rad_desc), N.ptr(b['rad_scratch']), N.ptr(self._g('rad_w')), S, S,
                                                   st), 'mlp_bwd_reduce(rad)')
+            self._join_reductions()
             return
         N.check(L.arcn_mlp_bwd(N.ptr(b['feat']), N.ptr(self._p('geo_w')), N.ptr(self._p('geo_b')), N.C.addressof(fld.geo_desc),
                                N.ptr(b['geo_out']), N.ptr(b['geo_acts']), N.ptr(b['d_geo_out']), N.ptr(b['d_feat']),
@@ -551,6 +560,21 @@ class NgpPipeline:
                                     N.ptr(self._g('table')), None, N.ptr(self.hash_ws),
                                     0 if self.hash_ws is None else self.hash_ws.numel(), S, n_dev.data_ptr(), st),
                 'hashgrid_bwd')
+
+    def _reduce_on_side(self, desc, scratch, dweights, S):
+        """queue one net's dW partial reduction on the reduction stream, behind the backward kernel just launched"""
+        main = torch.cuda.current_stream()
+        self.red_stream.wait_stream(main)
+        with torch.cuda.stream(self.red_stream):
+            N.check(N.lib().arcn_mlp_bwd_reduce(N.C.addressof(desc), N.ptr(scratch), N.ptr(dweights), S, S, N.stream()),
+                    'mlp_bwd_reduce')
+            self._red_event = torch.cuda.Event()
+            self._red_event.record(self.red_stream)
+
+    def _join_reductions(self):
+        if self._red_event is not None:
+            torch.cuda.current_stream().wait_event(self._red_event)
+            self._red_event = None
 
     def huber_grad(self, rgb, target):
         """ImgLoss(Huber, delta, weight) of arcnerf/loss/img_loss.py:60-100: loss value and d loss / d rgb (mean over R*3)."""

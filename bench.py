@@ -153,7 +153,10 @@ def main():
         # a second stream and overlaps this step's backward
         pipe.train_step(o, d, tgt, bkg_color=bkg, all_reduce=all_reduce, world_size=world, next_rays=(nxt[0], nxt[1]),
                         grad_sync=grad_sync)
-        sample_log[step_idx] = pipe.n_dev[0]
+        # bookkeeping copy of this step's device-side sample count: on the sampling stream (which produced it), not in the
+        # serial chain of the step's kernels
+        with torch.cuda.stream(pipe.aux_stream):
+            sample_log[step_idx] = pipe.n_dev[0]
         if not args.no_occ_update:
             pipe.update_occupancy(epoch, apply=False)
 
