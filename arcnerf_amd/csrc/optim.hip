@@ -3,6 +3,9 @@
 // gradient, bias-corrected moments, eps added to sqrt(v_hat)); EMA.ema_step of arcnerf/trainer/ema.py:29-43 (JNeRF
 // style): new = ((1-d)*p + d*old*(1-d^(n-1))) / (1-d^n), and the average is WRITTEN BACK into the parameter.
 // The gradient buffer can be cleared in the same pass (zero_grad), saving one 4 B/param sweep per step.
+// Since the average is written back, the shadow copy equals the parameter after every step (ema.py:41-42 stores the same tensor
+// in both): a caller that is the only writer of `param` passes ema == param, the kernel then takes the parameter it has just read
+// as the old average and writes no second copy (28 B/param in all, bit-identical to keeping the shadow).
 #include "common.hpp"
 
 namespace arcn {
@@ -29,7 +32,7 @@ __global__ void __launch_bounds__(256) adam_ema_kernel(float *__restrict__ param
                                                        float *__restrict__ m, float *__restrict__ v, float *__restrict__ ema,
                                                        int64_t n, float lr, float b1, float b2, float eps, float wd,
                                                        float ema_decay, float gscale, float bc1, float bc2_sqrt, float deb_old,
-                                                       float deb_new, int zero_grad) {
+                                                       float deb_new, int zero_grad, int ema_in_param) {
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -38,12 +41,14 @@ __global__ void __launch_bounds__(256) adam_ema_kernel(float *__restrict__ param
         f4 m4 = reinterpret_cast<f4 *>(m)[i];
         f4 v4 = reinterpret_cast<f4 *>(v)[i];
         f4 e4 = {0.f, 0.f, 0.f, 0.f};
-        if (ema) e4 = reinterpret_cast<f4 *>(ema)[i];
+        if (ema_in_param) e4 = p4;
+        else if (ema) e4 = reinterpret_cast<f4 *>(ema)[i];
+        const bool avg = ema || ema_in_param;
         float p[4] = {p4.x, p4.y, p4.z, p4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
         float vv[4] = {v4.x, v4.y, v4.z, v4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            adam1(p[k], g[k], mm[k], vv[k], ema ? &ee[k] : nullptr, lr, b1, b2, eps, wd, ema_decay, gscale, bc1, bc2_sqrt, deb_old, deb_new);
+            adam1(p[k], g[k], mm[k], vv[k], avg ? &ee[k] : nullptr, lr, b1, b2, eps, wd, ema_decay, gscale, bc1, bc2_sqrt, deb_old, deb_new);
         reinterpret_cast<f4 *>(param)[i] = f4{p[0], p[1], p[2], p[3]};
         reinterpret_cast<f4 *>(m)[i] = f4{mm[0], mm[1], mm[2], mm[3]};
         reinterpret_cast<f4 *>(v)[i] = f4{vv[0], vv[1], vv[2], vv[3]};
@@ -53,7 +58,9 @@ __global__ void __launch_bounds__(256) adam_ema_kernel(float *__restrict__ param
     // tail
     const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) {
-        adam1(param[t], grad[t], m[t], v[t], ema ? &ema[t] : nullptr, lr, b1, b2, eps, wd, ema_decay, gscale, bc1, bc2_sqrt, deb_old, deb_new);
+        float old = param[t];
+        adam1(param[t], grad[t], m[t], v[t], ema_in_param ? &old : (ema ? &ema[t] : nullptr), lr, b1, b2, eps, wd, ema_decay, gscale, bc1,
+              bc2_sqrt, deb_old, deb_new);
         if (zero_grad) grad[t] = 0.f;
     }
 }
@@ -79,7 +86,9 @@ ARCN_EXPORT int arcn_adam_ema_step(float *param, float *grad, float *exp_avg, fl
     const float deb_new = ema ? (float)(1.0 / (1.0 - pow(d, (double)ema_step))) : 0.f;
     int64_t blocks = ceil_div<int64_t>((n >> 2) + 1, 256);
     if (blocks > 2048) blocks = 2048;
+    const int ema_in_param = ema == param;  // the running average lives in the parameter itself (see the file header)
     hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq,
-                       ema, n, lr, beta1, beta2, eps, weight_decay, ema_decay, grad_scale, bc1, bc2_sqrt, deb_old, deb_new, zero_grad);
+                       ema_in_param ? static_cast<float *>(nullptr) : ema, n, lr, beta1, beta2, eps, weight_decay, ema_decay, grad_scale, bc1,
+                       bc2_sqrt, deb_old, deb_new, zero_grad, ema_in_param);
     return check_launch("adam_ema_step");
 }

@@ -294,7 +294,10 @@ class NgpPipeline:
         n = field.n_params
         self.exp_avg = torch.zeros(n, dtype=f32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=f32, device=dev)
-        self.ema = field.params.clone()
+        # EMA shadow (ema.py's old_avg): equal to the parameters after every step because the average is written back, and this
+        # pipeline is the only writer of the flat buffer -> the shadow IS the buffer (arcn_adam_ema_step with ema == param);
+        # ARCN_EMA_ALIAS=0 keeps the separate copy
+        self.ema = field.params if bool(int(os.environ.get('ARCN_EMA_ALIAS', '1'))) else field.params.clone()
         self.step_count = 0
         # occupancy (Volume bitfield/opafield, volume.py:741-760,959-969)
         ng = cfg.n_grid

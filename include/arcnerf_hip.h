@@ -387,6 +387,9 @@ int arcn_update_bitfield_by_opafield(const float *opafield, uint8_t *bitfield, i
  * ema (the reference's `old_avg`) may be NULL; when given the debiased average
  *   new = ((1-d)*p + d*old*(1-d^(ema_step-1))) / (1-d^ema_step)
  * is stored to BOTH ema and param, as the reference does.  zero_grad != 0 clears grad in the same pass.
+ * ema == param: the two copies are equal after every step, so a caller that is the only writer of `param` between steps
+ *   may pass the parameter buffer itself; the value read from it is the old average and no second copy is written
+ *   (same bits, 8 B/param less traffic).
  * ---------------------------------------------------------------------------------------------- */
 int arcn_adam_ema_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, float *ema, int64_t n, float lr,
                        float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale,

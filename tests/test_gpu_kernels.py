@@ -879,3 +879,28 @@ def test_first_order_only_nodes_refuse_a_second_differentiation(F):
     dx, = torch.autograd.grad(y.sum(), x, create_graph=True)
     with pytest.raises(RuntimeError):
         dx.pow(2).sum().backward()
+
+
+def test_adam_ema_shadow_in_parameter_is_bit_identical(F):
+    """ema.py:41-42 stores the new average in the parameter AND the shadow, so the two are equal after every step: passing the
+    parameter buffer as `ema` (no second copy) must give the same bits as keeping the shadow - from the first step on, whatever the
+    shadow held before it (the step-1 debias factor of the old average is 0)."""
+    gpu = torch.device('cuda:0')
+    n = 100003
+    g = torch.Generator(device='cuda').manual_seed(11)
+    p0 = torch.randn(n, device=gpu, generator=g)
+    state = []
+    for alias in (False, True):
+        p, m, v = p0.clone(), torch.zeros(n, device=gpu), torch.zeros(n, device=gpu)
+        shadow = p if alias else torch.full((n,), 7.0, device=gpu)
+        gg = torch.Generator(device='cuda').manual_seed(5)
+        for step in range(1, 6):
+            grad = torch.randn(n, device=gpu, generator=gg)
+            F.adam_ema_step(p, grad, m, v, shadow, step, lr=1e-1, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6, ema_decay=0.95,
+                            zero_grad=True)
+            assert float(grad.abs().max()) == 0.0
+            if not alias:
+                assert torch.equal(shadow, p)
+        state.append((p, m, v))
+    for a, b in zip(*state):
+        assert torch.equal(a, b)
