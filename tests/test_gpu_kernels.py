@@ -865,6 +865,20 @@ def test_fused_adam_optimizer_matches_torch_adam(F):
         cpu_p = torch.zeros(4, requires_grad=True)
         cpu_p.grad = torch.ones(4)
         FusedAdam([cpu_p]).step()
+    # the EMA variants: shadow in state['ema'] vs in the parameter itself, same bits
+    qa = [p.detach().clone().requires_grad_(True) for p in pb]
+    qb = [p.detach().clone().requires_grad_(True) for p in pb]
+    ea = FusedAdam(qa, lr=1e-1, eps=1e-15, ema_decay=0.95)
+    eb = FusedAdam(qb, lr=1e-1, eps=1e-15, ema_decay=0.95, ema_in_param=True)
+    for it in range(4):
+        for a, b_ in zip(qa, qb):
+            a.grad = torch.randn(a.shape, generator=g).cuda()
+            b_.grad = a.grad.clone()
+        ea.step()
+        eb.step()
+    for a, b_ in zip(qa, qb):
+        assert torch.equal(a, b_) and torch.equal(ea.state[a]['ema'], a)
+    assert 'ema' not in eb.state[qb[0]]
 
 
 def test_first_order_only_nodes_refuse_a_second_differentiation(F):

@@ -27,7 +27,7 @@ from arcnerf_amd.utils.cfgs_utils import load_configs
 m = build_model(load_configs(os.path.join(ROOT, 'configs', 'nerf_ngp.yaml'), ['--model.rays.white_bkg', 'True'])).to(dev)
 fg = m.fg_model
 opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=1e-1, eps=1e-15, weight_decay=1e-6, ema_decay=0.95,
-                zero_grad_on_step=True)   # optim block of nerf_lego_nerf_ngp.yaml: Adam 1e-1 WITH the EMA write-back (ema.decay 0.95)
+                zero_grad_on_step=True, ema_in_param=True)   # optim block of nerf_lego_nerf_ngp.yaml: Adam 1e-1 WITH the EMA write-back (ema.decay 0.95)
 
 
 @torch.no_grad()
