@@ -457,11 +457,13 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
     // runs of consecutive samples (lanes) in the same cell: head lanes, and for every lane the last lane of its run
     const uint32_t kxy = cell.valid ? (cell.c[0] | (cell.c[1] << 16)) : 0xffffffffu;
     const uint32_t kz = cell.valid ? cell.c[2] : (uint32_t)lane;
-    // a run never crosses a 16-lane row: the run sums below then stay on the DPP row shifts (VALU) instead of ds_bpermute, which
-    // queued on the LDS pipeline next to the histogram atomics; at most three runs per wave are cut in two by this
-    const uint32_t pxy = (uint32_t)dpp_take_i<0x111>(-1, (int)kxy), pz = (uint32_t)dpp_take_i<0x111>(-1, (int)kz);
-    const bool head = (lane & 15) == 0 || kxy != pxy || kz != pz;
-    const uint64_t heads = __ballot(head && cell.valid), valid = __ballot(cell.valid);
+    // The run sums below work inside 16-lane rows first (DPP row shifts on the VALU instead of ds_bpermute, which queued on the LDS
+    // pipeline next to the histogram atomics): `head` also cuts a run at every row start; the pieces of a run that crosses rows are
+    // joined afterwards through v_readlane, and only the true heads emit records.
+    const uint32_t pxy = (uint32_t)dpp_take_i<0x138>(-1, (int)kxy), pz = (uint32_t)dpp_take_i<0x138>(-1, (int)kz);
+    const bool true_head = lane == 0 || kxy != pxy || kz != pz;
+    const bool head = true_head || (lane & 15) == 0;
+    const uint64_t heads = __ballot(true_head && cell.valid), valid = __ballot(cell.valid);
     // Per wave: with an average run of >= 1.5 samples the runs are summed first (fewer records, fewer row updates, and no
     // neighbouring lanes fighting over one row lock in the consumer); otherwise the x pairs go out as they are.
     const bool reduce = 3 * __popcll(heads) <= 2 * __popcll(valid);
@@ -552,7 +554,26 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
         if (more) ARCN_RUN_STEP(4)
         if (more) ARCN_RUN_STEP(8)
 #undef ARCN_RUN_STEP
-        if (head && cell.valid) {
+        // join the pieces of runs that cross a row start, top row first so that a run spanning several rows chains up: lane b holds
+        // the sum of its piece, the lanes of the last piece of the row below take it
+        const uint64_t true_heads = __ballot(true_head);
+#pragma unroll
+        for (int b = 48; b >= 16; b -= 16) {
+            if ((true_heads >> b) & 1ull) continue;
+            const uint64_t below = all_heads & ((1ull << b) - 1ull);  // never empty: lane b-16 is a head
+            const int piece = 63 - (int)__builtin_clzll(below);
+            const bool joins = lane >= piece && lane < b;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float ua = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, va[q]), b));
+                va[q] += joins ? ua : 0.f;
+                if (F > 1) {
+                    const float ub = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vb[q]), b));
+                    vb[q] += joins ? ub : 0.f;
+                }
+            }
+        }
+        if (true_head && cell.valid) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
