@@ -4,7 +4,7 @@ usage: python tools/pmc_traffic.py gpurun_out/<tag>   (expects pmc_FETCH_SIZE/ a
 
 Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both counters are in KiB; on gfx950 FETCH_SIZE
 tallies 128-byte read requests at 64 bytes, so streaming reads are doubled (calibrated on adam_ema_kernel, whose traffic is
-known exactly: 4 floats read + 5 written per parameter)."""
+known exactly: 4 floats read + 4 written per parameter with the EMA shadow in the parameter buffer, 5 + 5 with a separate one)."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
@@ -61,8 +61,8 @@ def main(root):
     out['_note'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 8 --warmup 4), median over the '
                     'training launches, KiB*1024, summed over the kernels of an entry point (mlp_* = the two nets of a step are '
                     'different launches of one kernel: value is their median). FETCH_SIZE doubled per MI355X_MICROARCH.md '
-                    '(gfx950 tallies 128-B read requests at 64 B); calibration: adam_ema_kernel reads 4 and writes 5 floats per '
-                    'parameter.')
+                    '(gfx950 tallies 128-B read requests at 64 B); calibration: adam_ema_kernel reads 4 and writes 4 floats per '
+                    'parameter (EMA shadow in the parameter buffer; 5 + 5 with a separate shadow).')
     print(json.dumps(out, indent=1))
 
 
