@@ -198,7 +198,8 @@ class StepLoss:
 class NgpPipeline:
     """Pre-allocated buffers + the kernel sequence of one render / train step for a fixed ray capacity."""
 
-    def __init__(self, field, max_rays=32768, max_samples=1 << 19, packed_bits=True, torch_aabb=False, xcd_scatter=True, level_major=True, fused_glue=True):
+    def __init__(self, field, max_rays=32768, max_samples=1 << 19, packed_bits=True, torch_aabb=False, xcd_scatter=True, level_major=True, fused_glue=True,
+                 prefetch_depth=None):
         cfg = field.cfg
         self.field, self.cfg = field, cfg
         dev = field.device
@@ -213,8 +214,13 @@ class NgpPipeline:
         b = self.buf = {}
         # sample buffers exist twice: the marcher of step i+1 (it depends only on rays + occupancy) can run on a second
         # HIP stream while step i's backward is still scattering (prefetch_samples)
+        # prefetch_depth 2 (ARCN_PREFETCH_DEPTH overrides): three sets, two batches in flight - train_step(next_rays=) is then
+        # given the rays of step i+2 and marches them next to step i's optimiser pass (pure HBM streaming, idle VALUs) instead of next
+        # to the backward kernels; a refreshed occupancy takes effect two steps later instead of one
+        env_depth = os.environ.get('ARCN_PREFETCH_DEPTH')
+        self.prefetch_depth = max(1, int(env_depth if env_depth is not None else (prefetch_depth or 1)))
         self._sets = []
-        for _ in range(2):
+        for _ in range(1 + self.prefetch_depth):
             self._sets.append({
                 'scratch_t': torch.empty((R, cfg.n_sample), dtype=f32, device=dev),
                 'counts': torch.zeros(R, dtype=i32, device=dev), 'offsets': torch.zeros(R + 1, dtype=i32, device=dev),
@@ -226,17 +232,17 @@ class NgpPipeline:
                 'xyz': torch.zeros((S, 3), dtype=f32, device=dev), 'dirs': torch.zeros((S, 3), dtype=f32, device=dev),
                 'sh_ray': torch.zeros((R, max(1, cfg.sh_degree ** 2)), dtype=f32, device=dev),
                 'noise': torch.zeros(S, dtype=f32, device=dev)})
-        self._noise_ready = [False, False]
+        self._noise_ready = [False] * len(self._sets)
         b.update(self._sets[0])
         self._cur_set = 0
-        self._prefetched = None
+        self._prefetched = []   # FIFO of (rays_o ptr, rays_d ptr, R, set index, event), oldest first
         self._next_rays = None
         self.occ_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
         self.occ_async = bool(int(os.environ.get('ARCN_OCC_ASYNC', '1'))) and self.occ_stream is not None
         self._occ_params_event = None   # the refresh still reads the parameters: the optimiser waits for it
         self._occ_bits_event = None     # the refreshed bitfield is ready: the marcher waits for it
         self._occ_state_event = None    # last refresh finished: readers of .bitfield / .opafield wait for it
-        self.prefetch_at = int(os.environ.get('ARCN_PREFETCH_AT', '1'))
+        self.prefetch_at = int(os.environ.get('ARCN_PREFETCH_AT', '1' if self.prefetch_depth == 1 else '3'))
         # multi-rank: the compute units idle while the gradient all-reduce is on the wire - march the next batch there
         self.prefetch_at_dist = int(os.environ.get('ARCN_PREFETCH_AT_DIST', '3'))
         self._prefetch_now = self.prefetch_at
@@ -385,7 +391,10 @@ class NgpPipeline:
             return
         main = torch.cuda.current_stream()
         self.aux_stream.wait_stream(main)  # occupancy / previous consumers of the spare set are ordered before us
-        spare = 1 - self._cur_set
+        if len(self._prefetched) >= self.prefetch_depth:
+            self._prefetched.pop(0)   # never picked up: its set is free again
+        busy = {self._cur_set} | {pf[3] for pf in self._prefetched}
+        spare = next(i for i in range(len(self._sets)) if i not in busy)
         with torch.cuda.stream(self.aux_stream):
             self._sample_into(self._sets[spare], rays_o, rays_d)
             self._noise_ready[spare] = bool(noise and self.cfg.noise_std > 0)
@@ -393,18 +402,23 @@ class NgpPipeline:
                 self._sets[spare]['noise'].normal_(0.0, self.cfg.noise_std)
             ev = torch.cuda.Event()
             ev.record(self.aux_stream)
-        self._prefetched = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], spare, ev)
+        self._prefetched.append((rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], spare, ev))
 
     def sample(self, rays_o, rays_d):
         """[A] bounds + occupancy marching in packed form (no host sync).  Advances the pcg32 like the reference."""
-        pf = self._prefetched
-        if pf is not None and pf[:3] == (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0]):
+        key = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0])
+        hit = next((k for k, pf in enumerate(self._prefetched) if pf[:3] == key), None)
+        if hit is not None:
+            pf = self._prefetched.pop(hit)
+            del self._prefetched[:hit]   # older entries were skipped by the caller: drop them
             torch.cuda.current_stream().wait_event(pf[4])
             self._cur_set = pf[3]
-            self._prefetched = None
             self.buf.update(self._sets[self._cur_set])
         else:
-            self._prefetched = None
+            if self.prefetch_depth == 1:
+                self._prefetched = []
+            elif any(pf[3] == self._cur_set for pf in self._prefetched):   # cannot happen: the current set is never handed out
+                raise RuntimeError('sample buffer set in use by a prefetch')
             self._noise_ready[self._cur_set] = False
             self._sample_into(self._sets[self._cur_set], rays_o, rays_d)
             self.buf.update(self._sets[self._cur_set])
@@ -627,12 +641,15 @@ class NgpPipeline:
         if all_reduce is not None:
             all_reduce(self.field.grads)
         self.optimizer_step(world_size)
+        self._prefetch_point(4)
         return loss
 
     def _prefetch_point(self, where):
         """Issue the next batch's marching (second stream) at point `where` of the step: 0 after the forward, 1 before the
-        geometry-net backward, 2 before the hash-grid scatter, 3 before the optimiser.  The marcher is pure VALU work with a
-        256 KiB working set; it costs least next to the LDS / HBM-bound kernels."""
+        geometry-net backward, 2 before the hash-grid scatter, 3 before the optimiser, 4 after it.  The marcher is pure VALU work with
+        a 256 KiB working set; it costs least next to the LDS / HBM-bound kernels.  One batch ahead (prefetch_depth 1) its chain has
+        to be done when the next forward starts, so it goes next to the backward (1); two batches ahead it goes next to the
+        optimiser pass (3): 0.711 vs 0.722 ms/step, A/B in one session (`tools/ab_prefetch.sh`)."""
         if getattr(self, '_next_rays', None) is not None and where == self._prefetch_now:
             self.prefetch_samples(*self._next_rays, noise=True)
             self._next_rays = None

@@ -122,7 +122,8 @@ def main():
 
     cfg = NgpConfig()  # configs/models/nerf_ngp.yaml + nerf_lego_nerf_ngp.yaml
     field = NgpField(cfg, device=dev, seed=0)  # identical init on every rank (DDP broadcasts rank 0's, same effect)
-    pipe = NgpPipeline(field, max_rays=32768, max_samples=1 << 20, packed_bits=True)
+    # the ray batches of a run are known in advance (the reference precaches and shuffles them on the GPU): march two steps ahead
+    pipe = NgpPipeline(field, max_rays=32768, max_samples=1 << 20, packed_bits=True, prefetch_depth=2)
     bf = synthetic_bitfield(cfg.n_grid, args.occupancy, seed=0)
     pipe.set_bitfield(torch.from_numpy(bf))
 
@@ -148,9 +149,9 @@ def main():
 
     def run(step_idx, epoch):
         o, d, tgt, bkg = pool[step_idx % n_pool]
-        nxt = pool[(step_idx + 1) % n_pool]
-        # the next batch's rays are known (the reference precaches and shuffles them on the GPU): its marching is issued on
-        # a second stream and overlaps this step's backward
+        nxt = pool[(step_idx + pipe.prefetch_depth) % n_pool]
+        # the marching of the batch `prefetch_depth` steps ahead is issued on a second stream during this step (next to the
+        # optimiser pass at depth 2, next to the backward at depth 1); every step still marches exactly one batch
         pipe.train_step(o, d, tgt, bkg_color=bkg, all_reduce=all_reduce, world_size=world, next_rays=(nxt[0], nxt[1]),
                         grad_sync=grad_sync)
         # bookkeeping copy of this step's device-side sample count: on the sampling stream (which produced it), not in the

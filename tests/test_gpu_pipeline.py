@@ -273,3 +273,66 @@ def test_fused_compositor_step_equals_three_kernel_step(gpu, add_inf_z, white_bk
         pipe.train_step(o, d, tgt, bkg_color=bkg)
     with pytest.raises(RuntimeError):
         float(stale)
+
+
+@pytest.mark.parametrize('depth', [1, 2])
+def test_prefetched_marching_equals_inline_marching(gpu, depth):
+    """The marcher of a later batch runs on the second stream into a spare buffer set (one or two batches ahead).  (1) Given the
+    same jitter stream per batch, a prefetched forward is bit-identical to an inline one - sample distances, offsets, positions,
+    per-ray harmonics, colours; a prefetched batch the caller skips is dropped.  (2) In a training loop fed `prefetch_depth` batches
+    ahead every batch is marched exactly once and every forward after the lead-in picks its samples up from the queue."""
+    from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline, synthetic_bitfield, synthetic_rays
+    cfg = NgpConfig(n_levels=8, hashmap_size=15, max_res=512, n_grid=64, n_sample=512, noise_std=0.0, lr=1e-2)
+    bits = torch.from_numpy(synthetic_bitfield(cfg.n_grid, 0.1, seed=3))
+    R = 1024
+    batches = [synthetic_rays(R, seed=40 + i, device=gpu) for i in range(6)]
+
+    def make(d):
+        p = NgpPipeline(NgpField(cfg, device=gpu, seed=0), max_rays=R, max_samples=1 << 16, prefetch_depth=d)
+        p.set_bitfield(bits)
+        return p
+    inline, ahead = make(1), make(depth)
+    assert ahead.prefetch_depth == depth and len(ahead._sets) == depth + 1
+    # (1) same marching order on both sides: b0 .. b(depth), the last `depth` of them prefetched
+    want = []
+    for o, d in batches[:depth + 1]:
+        rgb, dep, msk = inline.forward(o, d)
+        n = int(inline.n_dev.item())
+        want.append((rgb.clone(), dep.clone(), inline.buf['t'][:n].clone(), inline.buf['offsets'][:R + 1].clone(),
+                     inline.buf['xyz'][:n].clone(), inline.buf['sh_ray'][:R].clone()))
+    ahead.forward(*batches[0])
+    for o, d in batches[1:depth + 1]:
+        ahead.prefetch_samples(o, d)
+    assert len(ahead._prefetched) == depth
+    for k in range(1, depth + 1):
+        rgb, dep, msk = ahead.forward(*batches[k])
+        n = int(ahead.n_dev.item())
+        got = (rgb, dep, ahead.buf['t'][:n], ahead.buf['offsets'][:R + 1], ahead.buf['xyz'][:n], ahead.buf['sh_ray'][:R])
+        assert n > 1000
+        for a, b in zip(got, want[k]):
+            assert torch.equal(a, b)
+    assert ahead._prefetched == []
+    # a skipped batch: its entry goes away with the hit on a younger one (depth 2) or with the inline march (depth 1)
+    ahead.prefetch_samples(*batches[0])
+    if depth == 2:
+        ahead.prefetch_samples(*batches[1])
+        ahead.forward(*batches[1])
+    else:
+        ahead.forward(*batches[2])
+    assert ahead._prefetched == []
+    # (2) training loop, `depth` batches ahead
+    marched = []
+    real = ahead._sample_into
+    ahead._sample_into = lambda b, o, d: (marched.append(o.data_ptr()), real(b, o, d))[1]
+    tgt = torch.rand(R, 3, device=gpu)
+    steps = 12
+    losses = []
+    for i in range(steps):
+        o, d = batches[i % len(batches)]
+        losses.append(float(ahead.train_step(o, d, tgt, next_rays=batches[(i + depth) % len(batches)])))
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses))
+    # lead-in: the first `depth` batches are marched inline; after that one prefetch per step and no inline march
+    assert len(marched) == steps + depth
+    assert marched[:2 * depth:2] == [batches[i][0].data_ptr() for i in range(depth)]
+    assert len(ahead._prefetched) == depth
