@@ -109,6 +109,10 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count())
     assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU fallback for the product path)'
     torch.cuda.set_device(local_rank)
+    # the step's kernels go to a high-priority stream: the dispatcher then prefers their workgroups over those of the sampling
+    # stream (marching of a later batch), which only fills what is left; -1 % on the step (ARCN_MAIN_PRIORITY=0: default stream)
+    if int(os.environ.get('ARCN_MAIN_PRIORITY', '-1')) != 0:
+        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ.get('ARCN_MAIN_PRIORITY', '-1'))))
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
