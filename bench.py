@@ -199,6 +199,23 @@ def main():
             run(args.warmup + args.steps + i, epoch0 + args.warmup + args.steps + i)
         torch.cuda.synchronize()
         ktable = timers.summary()
+    # the training gather on its own (nothing else on the device): in the step it runs next to the sampling stream's marcher
+    alone_ms = alone_pts = None
+    if world == 1:
+        from arcnerf_amd import _native as NV
+        import ctypes
+        torch.cuda.synchronize()
+        b, st, S = pipe.buf, NV.stream(), pipe.cap
+        alone_pts = int(pipe.n_dev.item())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(24):
+            if it == 4:
+                e0.record()
+            NV.check(NV.lib().arcn_hashgrid_fwd_xcd(NV.ptr(b['xyz']), NV.ptr(field.view('table')), ctypes.addressof(field.grid_desc),
+                                                    NV.ptr(b['feat']), 1, S, S, pipe.n_dev.data_ptr(), st), 'hashgrid_fwd_xcd')
+        e1.record()
+        torch.cuda.synchronize()
+        alone_ms = e0.elapsed_time(e1) / 20.0
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -241,6 +258,12 @@ def main():
         lookup = {'kernel': 'hashgrid_fwd', 'bound': 'hbm', 'achieved': BYTES_HASH_FWD * pts / sec / 1e9, 'peak': HBM_PEAK / 1e9,
                   'unit': 'GB/s', 'frac': BYTES_HASH_FWD * pts / sec / HBM_PEAK, 'avg_launch_ms': ksum['hashgrid_fwd'],
                   'l2_line_bytes_upper': l2_lines, 'l2_peak_GBps': 34500.0, 'l2_line_frac_upper': l2_lines / sec / 34.5e12}
+        if alone_ms:
+            # same kernel, same batch, back to back with nothing beside it (in the step it shares the chip with the marcher of a
+            # later batch on the sampling stream)
+            lookup['alone_launch_ms'] = alone_ms
+            lookup['alone_frac'] = BYTES_HASH_FWD * alone_pts / (alone_ms * 1e-3) / HBM_PEAK
+            lookup['alone_l2_line_frac_upper'] = 16 * 8 * 128.0 * alone_pts / (alone_ms * 1e-3) / 34.5e12
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
