@@ -299,6 +299,38 @@ __device__ __forceinline__ void store_tiles_fast(const f4 (&v)[4][NT], float *__
     }
 }
 
+// Saved hidden activations in TILE ORDER (level-major / concat entry points, whose activations only ever go to the matching fused
+// backward): the f4 of lane (g, j) - neurons 16t+4g.. of sample 16q+j - sits at ((q * TT + t) * 64 + lane) * 4, so one wave-wide
+// store or load is 1 KiB contiguous.  Row-major rows (256 B for 64 neurons) make the same instruction touch 16 separate 64-byte
+// pieces: 40 % more HBM write traffic by PMC and a 2 % slower step.  Needs a width of exactly 16 * TT and room for pad16(n_cap) rows.
+__host__ __device__ __forceinline__ int64_t pad16(int64_t n) { return (n + 15) & ~(int64_t)15; }
+
+template <int TT, int NT>
+__device__ __forceinline__ void store_tiles_frag(const f4 (&v)[4][NT], float *__restrict__ dst, int64_t s0, int64_t cnt, int lane) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (s0 + 16 * nt + (lane & 15) >= cnt) continue;
+        float *p = dst + (((s0 >> 4) + nt) * TT * 64 + lane) * 4;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) *reinterpret_cast<f4 *>(p + t * 256) = v[t][nt];
+    }
+}
+
+template <int TT, int NT>
+__device__ __forceinline__ void load_tiles_frag(f4 (&v)[4][NT], const float *__restrict__ src, int64_t s0, int64_t cnt, int lane) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const bool ok = s0 + 16 * nt + (lane & 15) < cnt;
+        const float *p = src + (((s0 >> 4) + nt) * TT * 64 + lane) * 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f4 r = {0.f, 0.f, 0.f, 0.f};
+            if (t < TT && ok) r = *reinterpret_cast<const f4 *>(p + t * 256);
+            v[t][nt] = r;
+        }
+    }
+}
+
 // Level-major network input (what arcn_hashgrid_fwd_xcd writes, 2 features per level): column c = 2 l + f of sample s lives at
 // x[(l * stride + s) * 2 + f].  A lane's 4 columns 16t+4g.. are levels 8t+2g and 8t+2g+1: two 8-byte accesses, and the 16 lanes
 // of a level read 128 contiguous bytes.
@@ -419,6 +451,7 @@ mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
                      float *__restrict__ out, float *__restrict__ acts, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
     constexpr int NL = T3 ? 3 : 2;
     constexpr int TA = T3 ? T3 : 1;
+    constexpr bool FRAG = XMODE != 0;  // saved activations in tile order (store_tiles_frag): the level-major / concat entry points
     extern __shared__ __attribute__((aligned(16))) float lds[];
     for (int l = 0; l < NL; ++l) stage_fragments<false>(lds + P.lds_off[l], weights + P.w_off[l], P.dims[l + 1], P.dims[l]);
     __syncthreads();
@@ -444,7 +477,10 @@ mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
         zero(o);
         gemm_tiles<4, NT>(o, h, w0, T1, T0, lane);
         act_tiles<T1, NT>(o, P.act_hidden, P.beta);
-        if (acts) store_tiles_fast<T1, NT>(o, acts, P.dims[1], s0, cnt, g, j);
+        if (acts) {
+            if (FRAG) store_tiles_frag<T1, NT>(o, acts, s0, cnt, lane);
+            else store_tiles_fast<T1, NT>(o, acts, P.dims[1], s0, cnt, g, j);
+        }
         zero_padded_rows<T1, NT>(o, P.dims[1], g);
         // layer 1: T1 -> T2 tiles
         zero(h);
@@ -454,7 +490,10 @@ mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
             store_tiles_fast<T2, NT>(h, out, P.dims[2], s0, cnt, g, j);
         } else {
             act_tiles<T2, NT>(h, P.act_hidden, P.beta);
-            if (acts) store_tiles_fast<T2, NT>(h, acts + n_cap * P.dims[1], P.dims[2], s0, cnt, g, j);
+            if (acts) {
+                if (FRAG) store_tiles_frag<T2, NT>(h, acts + pad16(n_cap) * P.dims[1], s0, cnt, lane);
+                else store_tiles_fast<T2, NT>(h, acts + n_cap * P.dims[1], P.dims[2], s0, cnt, g, j);
+            }
             zero_padded_rows<T2, NT>(h, P.dims[2], g);
             // layer 2: T2 -> T3 tiles
             zero(o);
@@ -561,7 +600,8 @@ mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
     float *trB = trA + 1024;                 // 4 tiles: y_{l-1}
     constexpr int SPW = 16 * NT;
     const int64_t n_tiles = ceil_div_dev(cnt, (int64_t)SPW * 4);
-    const int64_t a1_off = 0, a2_off = n_cap * P.dims[1];  // hidden activations of layer 0 / layer 1 inside `acts`
+    constexpr bool FRAG = XMODE != 0;  // tile-order activations from the matching forward (store_tiles_frag)
+    const int64_t a1_off = 0, a2_off = (FRAG ? pad16(n_cap) : n_cap) * P.dims[1];  // hidden activations of layer 0 / layer 1 inside `acts`
     f4 acc0[T1][T0], acc1[T2][T1], acc2[TA][T2];
 #pragma unroll
     for (int a = 0; a < T1; ++a)
@@ -648,12 +688,14 @@ mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
             apply_act_grad(d, y, P.act_out, std::integral_constant<int, TL>{});
         }
         if (NL == 3) {
-            load_tiles_fast<T2, NT>(yp, acts + a2_off, P.dims[2], s0, cnt, g, j);
+            if (FRAG) load_tiles_frag<T2, NT>(yp, acts + a2_off, s0, cnt, lane);
+            else load_tiles_fast<T2, NT>(yp, acts + a2_off, P.dims[2], s0, cnt, g, j);
             accumulate(acc2, d, yp, std::integral_constant<int, TA>{}, std::integral_constant<int, T2>{});
             back(d, 2, T2, TA);
             if (P.act_hidden != ARCN_ACT_NONE) apply_act_grad(d, yp, P.act_hidden, std::integral_constant<int, T2>{});
         }
-        load_tiles_fast<T1, NT>(yp, acts + a1_off, P.dims[1], s0, cnt, g, j);
+        if (FRAG) load_tiles_frag<T1, NT>(yp, acts + a1_off, s0, cnt, lane);
+        else load_tiles_fast<T1, NT>(yp, acts + a1_off, P.dims[1], s0, cnt, g, j);
         accumulate(acc1, d, yp, std::integral_constant<int, T2>{}, std::integral_constant<int, T1>{});
         back(d, 1, T1, T2);
         if (P.act_hidden != ARCN_ACT_NONE) apply_act_grad(d, yp, P.act_hidden, std::integral_constant<int, T1>{});
@@ -940,7 +982,8 @@ using namespace arcn;
 ARCN_EXPORT int64_t arcn_mlp_acts_floats(const arcn_mlp_desc *d, int64_t n_cap) {
     if (!d) return 0;
     int64_t s = 0;
-    for (int l = 0; l < d->n_layers - 1; ++l) s += n_cap * d->dims[l + 1];
+    // rows padded to a multiple of 16: the level-major / concat entry points keep the activations in tile order (store_tiles_frag)
+    for (int l = 0; l < d->n_layers - 1; ++l) s += pad16(n_cap) * d->dims[l + 1];
     return s;
 }
 
@@ -984,6 +1027,10 @@ static int mlp_fwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
     static const int fixed_ok = getenv("ARCN_MLP_FIXED_FWD") ? atoi(getenv("ARCN_MLP_FIXED_FWD")) : 1;
     MlpCat cat = {};
     if (cat_in) cat = *cat_in;
+    if (x_stride || cat_in) {   // these entry points save the hidden activations in tile order: full 16-wide tiles only
+        for (int l = 1; l < P.n_layers; ++l)
+            if (P.dims[l] & 15) return einval("mlp_fwd_lm / mlp_fwd_cat: hidden widths must be multiples of 16");
+    }
     if ((fixed_ok || x_stride || cat_in) && !P.has_bias && (P.n_layers == 2 || P.n_layers == 3) && md <= 64) {
         const int sig = tiles16(P.dims[0]) * 1000 + tiles16(P.dims[1]) * 100 + tiles16(P.dims[2]) * 10 +
                         (P.n_layers == 3 ? tiles16(P.dims[3]) : 0);
@@ -1076,6 +1123,10 @@ static int mlp_bwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
     static const int fused_ok = getenv("ARCN_MLP_FUSED_BWD") ? atoi(getenv("ARCN_MLP_FUSED_BWD")) : 1;
     MlpCat cat = {};
     if (cat_in) cat = *cat_in;
+    if (x_stride || cat_in) {   // tile-order activations from arcn_mlp_fwd_lm / arcn_mlp_fwd_cat
+        for (int l = 1; l < P.n_layers; ++l)
+            if (P.dims[l] & 15) return einval("mlp_bwd_lm / mlp_bwd_cat: hidden widths must be multiples of 16");
+    }
     if (dweights && (fused_ok || x_stride || cat_in) && !P.has_bias && (P.n_layers == 2 || P.n_layers == 3) && md <= 64) {
         // fused dx + dW for the tile shapes of the NGP nets; anything else takes the two-kernel path below
         const int t0 = tiles16(P.dims[0]), t1 = tiles16(P.dims[1]), t2 = tiles16(P.dims[2]);

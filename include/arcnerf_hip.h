@@ -275,7 +275,11 @@ int arcn_mlp_bwd_dw(const float *x, const arcn_mlp_desc *desc_host, const float 
 /* The same network with a LEVEL-MAJOR input / input gradient: x_lm[(l * x_stride + s) * 2 + f], 2 features per level (what
  * arcn_hashgrid_fwd_xcd(level_major = 1) writes and arcn_hashgrid_bwd_lm consumes).  Wired for the bias-free 2-layer nets fed by
  * the hash grid (input 32 or 64 wide, hidden <= 64, output <= 16); -1 otherwise.  bwd: dx_lm in the layout of x_lm, dweights
- * required (fused dX + dW kernel). */
+ * required (fused dX + dW kernel).
+ * `acts` of arcn_mlp_fwd_lm / arcn_mlp_fwd_cat is OPAQUE: the hidden activations are kept in the tile order of the kernels
+ * (1 KiB contiguous per wave-wide access instead of sixteen 64-byte pieces of row-major rows), hidden widths must be multiples of
+ * 16, and the buffer (arcn_mlp_acts_floats) only makes sense to the matching arcn_mlp_bwd_lm / arcn_mlp_bwd_cat call with the
+ * same n_cap.  arcn_mlp_fwd / arcn_mlp_bwd keep the row-major layout documented above. */
 int arcn_mlp_fwd_lm(const float *x_lm, int64_t x_stride, const float *weights, const arcn_mlp_desc *desc_host, float *out,
                     float *acts, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream);
 int arcn_mlp_bwd_lm(const float *x_lm, int64_t x_stride, const float *weights, const arcn_mlp_desc *desc_host, const float *out,
@@ -297,7 +301,7 @@ int arcn_mlp_bwd_cat(const float *a, const float *b_table, const int32_t *b_inde
  * (same n_cap and n).  Lets a caller take the two tiny reductions off the backward's critical path. */
 int arcn_mlp_bwd_reduce(const arcn_mlp_desc *desc_host, float *scratch, float *dweights, int64_t n_cap, int64_t n,
                         void *stream);
-/* float count the caller must provide in `acts` (hidden layers) and `scratch` (bwd) for capacity n_cap */
+/* float count the caller must provide in `acts` (hidden layers, rows padded to a multiple of 16) and `scratch` (bwd) for capacity n_cap */
 int64_t arcn_mlp_acts_floats(const arcn_mlp_desc *desc_host, int64_t n_cap);
 int64_t arcn_mlp_scratch_floats(const arcn_mlp_desc *desc_host, int64_t n_cap);
 
