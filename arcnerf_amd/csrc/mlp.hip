@@ -616,22 +616,30 @@ mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
 #pragma unroll
         for (int b = 0; b < T2; ++b) acc2[a][b] = f4{0.f, 0.f, 0.f, 0.f};
 
-    // dW (MT x T tiles) += dpre^T . yprev for the NT sample tiles held in registers
+    // dW (MT x T tiles) += dpre^T . yprev for the NT sample tiles held in registers.  The 16 x 16 transposition tile is row = sample,
+    // 16 floats per row, with the four 16-byte chunks of row s XOR-swizzled by (s >> 1) & 3: ds_write_b128 is serviced in contiguous
+    // 8-lane groups on 32 banks, and with plain rows the 8 lanes of a group (samples j .. j+7, same chunk) fall on two bank quads -
+    // a 4-way conflict, 32 LDS cycles per store instead of 8 (SQ_LDS_BANK_CONFLICT was 52 % of the kernel's LDS cycles).  The
+    // ds_read_b32 side (32-lane groups: two consecutive rows, one swizzle value) stays conflict-free.
+    const int tr_wr = j * 16 + ((g ^ ((j >> 1) & 3)) << 2);
+    int tr_rd[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tr_rd[q] = (4 * q + g) * 16 + (((j >> 2) ^ ((2 * q + (g >> 1)) & 3)) << 2) + (j & 3);
     auto accumulate = [&](auto &acc, const f4 (&dpre)[WT][NT], const f4 (&yprev)[WT][NT], auto mt_c, auto t_c) {
         constexpr int MT = decltype(mt_c)::value, T = decltype(t_c)::value;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f4 *>(trA + mt * 256 + j * 16 + 4 * g) = dpre[mt][nt];
+            for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f4 *>(trA + mt * 256 + tr_wr) = dpre[mt][nt];
 #pragma unroll
-            for (int t = 0; t < T; ++t) *reinterpret_cast<f4 *>(trB + t * 256 + j * 16 + 4 * g) = yprev[t][nt];
+            for (int t = 0; t < T; ++t) *reinterpret_cast<f4 *>(trB + t * 256 + tr_wr) = yprev[t][nt];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float av[MT], bv[T];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) av[mt] = trA[mt * 256 + (4 * q + g) * 16 + j];
+                for (int mt = 0; mt < MT; ++mt) av[mt] = trA[mt * 256 + tr_rd[q]];
 #pragma unroll
-                for (int t = 0; t < T; ++t) bv[t] = trB[t * 256 + (4 * q + g) * 16 + j];
+                for (int t = 0; t < T; ++t) bv[t] = trB[t * 256 + tr_rd[q]];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
