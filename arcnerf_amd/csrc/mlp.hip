@@ -477,7 +477,10 @@ mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
         zero(o);
         gemm_tiles<4, NT>(o, h, w0, T1, T0, lane);
         act_tiles<T1, NT>(o, P.act_hidden, P.beta);
-        if (acts) {
+        // the two-layer tile-order nets get no activations at all: their backward recomputes layer 0 from x (32 x 64 MACs per sample
+        // against 256 B written here and read there: geometry net forward 40 -> 32 us, backward +1 us; for the three-layer net the
+        // backward is MFMA-bound and the same trade loses, 58 -> 55 forward but 86 -> 96 us backward)
+        if (acts && !(FRAG && NL == 2)) {
             if (FRAG) store_tiles_frag<T1, NT>(o, acts, s0, cnt, lane);
             else store_tiles_fast<T1, NT>(o, acts, P.dims[1], s0, cnt, g, j);
         }
@@ -593,6 +596,11 @@ mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
         stage_fragments<true>(lds + P.lds_off[l], weights + P.w_off[l], P.dims[l], P.dims[l + 1]);
         lds_w = P.lds_off[l] + tiles16(P.dims[l]) * tiles16(P.dims[l + 1]) * 256;
     }
+    constexpr bool FRAG = XMODE != 0;        // tile-order activations from the matching forward (store_tiles_frag)
+    constexpr bool RECOMP = FRAG && NL == 2;  // ... which saved none for a two-layer net: layer 0 is recomputed from x
+    // forward fragments of W_0 behind the transposition tiles
+    const float *w0_fwd = lds + lds_w + 8192;
+    if (RECOMP) stage_fragments<false>(lds + lds_w + 8192, weights + P.w_off[0], P.dims[1], P.dims[0]);
     __syncthreads();
     const int64_t cnt = dev_count(n, n_ptr);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
@@ -600,7 +608,6 @@ mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
     float *trB = trA + 1024;                 // 4 tiles: y_{l-1}
     constexpr int SPW = 16 * NT;
     const int64_t n_tiles = ceil_div_dev(cnt, (int64_t)SPW * 4);
-    constexpr bool FRAG = XMODE != 0;  // tile-order activations from the matching forward (store_tiles_frag)
     const int64_t a1_off = 0, a2_off = (FRAG ? pad16(n_cap) : n_cap) * P.dims[1];  // hidden activations of layer 0 / layer 1 inside `acts`
     f4 acc0[T1][T0], acc1[T2][T1], acc2[TA][T2];
 #pragma unroll
@@ -702,12 +709,31 @@ mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
             back(d, 2, T2, TA);
             if (P.act_hidden != ARCN_ACT_NONE) apply_act_grad(d, yp, P.act_hidden, std::integral_constant<int, T2>{});
         }
-        if (FRAG) load_tiles_frag<T1, NT>(yp, acts + a1_off, s0, cnt, lane);
-        else load_tiles_fast<T1, NT>(yp, acts + a1_off, P.dims[1], s0, cnt, g, j);
+        f4 xt[WT][NT];
+        if (RECOMP) {
+            // h_1 = act(W_0 x), the same fragments and MFMA order as the forward: bit-identical to what it would have saved
+            if (XMODE == 2) load_tiles_cat<NT>(xt, x, cat, s0, cnt, g, j, false);
+            else load_tiles_lm2<T0, NT>(xt, x, x_stride, s0, cnt, g, j);
+#pragma unroll
+            for (int mt = 0; mt < WT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) yp[mt][nt] = f4{0.f, 0.f, 0.f, 0.f};
+            gemm_tiles<WT, NT>(yp, xt, w0_fwd, T1, T0, lane);
+            act_tiles<T1, NT>(yp, P.act_hidden, P.beta);
+        } else if (FRAG) {
+            load_tiles_frag<T1, NT>(yp, acts + a1_off, s0, cnt, lane);
+        } else {
+            load_tiles_fast<T1, NT>(yp, acts + a1_off, P.dims[1], s0, cnt, g, j);
+        }
         accumulate(acc1, d, yp, std::integral_constant<int, T2>{}, std::integral_constant<int, T1>{});
         back(d, 1, T1, T2);
         if (P.act_hidden != ARCN_ACT_NONE) apply_act_grad(d, yp, P.act_hidden, std::integral_constant<int, T1>{});
-        if (XMODE == 2) load_tiles_cat<NT>(yp, x, cat, s0, cnt, g, j, false);
+        if (RECOMP) {
+#pragma unroll
+            for (int mt = 0; mt < WT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) yp[mt][nt] = xt[mt][nt];
+        } else if (XMODE == 2) load_tiles_cat<NT>(yp, x, cat, s0, cnt, g, j, false);
         else if (XMODE == 1) load_tiles_lm2<T0, NT>(yp, x, x_stride, s0, cnt, g, j);
         else load_tiles_fast<T0, NT>(yp, x, P.dims[0], s0, cnt, g, j);
         accumulate(acc0, d, yp, std::integral_constant<int, T1>{}, std::integral_constant<int, T0>{});
@@ -1142,7 +1168,8 @@ static int mlp_bwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
         const int sig = t0 * 1000 + t1 * 100 + t2 * 10 + t3;
         if (cat_in ? ((sig == 2441 || sig == 2410) && P.dims[0] == 32)
                    : x_stride ? (sig == 2410 || sig == 4410) : (sig == 2410 || sig == 2441 || sig == 4410 || sig == 4441)) {
-            const size_t fused_lds = lds_bytes + sizeof(float) * 8192;  // + one 8 KiB transposition area per wave
+            // + one 8 KiB transposition area per wave + the forward fragments of W_0 (<= 16 tiles) for the recomputed layer-0 activations
+            const size_t fused_lds = lds_bytes + sizeof(float) * (8192 + 4096);
             int64_t grid = tile_grid(n, 64);
             if (grid > dw_slabs(n_cap)) grid = dw_slabs(n_cap);
             float *partials = scratch + arcn_mlp_dpre_floats(desc_host, n_cap);
