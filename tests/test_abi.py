@@ -61,7 +61,9 @@ def _ngp_levels():
 
 def test_workspace_queries(lib):
     m = N.make_mlp_desc([32, 64, 64, 3])
-    assert lib.arcn_mlp_acts_floats(C.addressof(m), 1000) == 1000 * 128
+    # hidden activations, rows padded to a multiple of 16 (the level-major / concat entry points keep them in 16-sample tiles)
+    assert lib.arcn_mlp_acts_floats(C.addressof(m), 1000) == 1008 * 128
+    assert lib.arcn_mlp_acts_floats(C.addressof(m), 1024) == 1024 * 128
     # dpre of every layer + per-workgroup partial dW tiles (2 slabs) of the 3 (layer, 64x64 quadrant) pairs
     assert lib.arcn_mlp_scratch_floats(C.addressof(m), 1000) == 1000 * 131 + 2 * 3 * (4096 + 64)
     # hash-grid scatter: bin counters + 16-byte records, never less than 8 floats per (level, sample)
