@@ -111,8 +111,11 @@ def main():
     torch.cuda.set_device(local_rank)
     # the step's kernels go to a high-priority stream: the dispatcher then prefers their workgroups over those of the sampling
     # stream (marching of a later batch), which only fills what is left; -1 % on the step (ARCN_MAIN_PRIORITY=0: default stream)
-    if int(os.environ.get('ARCN_MAIN_PRIORITY', '-1')) != 0:
-        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ.get('ARCN_MAIN_PRIORITY', '-1'))))
+    # Single GPU only by default: with several ranks the collectives' own kernels run at normal priority beside the step's, and
+    # that combination could not be measured here (no multi-GPU box for this session)
+    main_priority = int(os.environ.get('ARCN_MAIN_PRIORITY', '-1' if world == 1 else '0'))
+    if main_priority != 0:
+        torch.cuda.set_stream(torch.cuda.Stream(priority=main_priority))
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
