@@ -2,6 +2,7 @@
 (arcnerf/models/base_modules/geo_rad_model/linear_network_module.py:16-335).  These are plain library GEMMs through
 torch; parameter names (`layers.{i}.weight/bias`, `embed_fn...`) match the reference's state_dict."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -101,9 +102,33 @@ class RadianceNet(EncoderMLPRadainceNet):
                 layer = nn.utils.weight_norm(layer)
             layers.append(layer)
         self.layers = nn.ModuleList(layers)
+        self._fused_desc = self._fused_shape()
+
+    def _fused_shape(self):
+        """MLP descriptor of the fused HIP kernel when this stack is one it computes exactly like the nn.Linear chain: two or three
+        bias-free DenseLayers (no weight norm, no SIREN), ReLU inside, sigmoid out, every width <= 64 (the reference's hash-grid
+        configurations, e.g. the radiance net of NeuS-NGP).  The parameters stay the layers' own `weight`s (same state_dict); only
+        the arithmetic moves from three library GEMMs + activations per direction to one kernel.  ARCN_LINEAR_FUSED=0 disables."""
+        if not int(os.environ.get('ARCN_LINEAR_FUSED', '1')) or len(self.layers) not in (2, 3):
+            return None
+        for i, layer in enumerate(self.layers):
+            last = i == len(self.layers) - 1
+            if type(layer) is not DenseLayer or layer.bias is not None or hasattr(layer, 'weight_g'):
+                return None
+            if not isinstance(layer.activation, nn.Sigmoid if last else nn.ReLU):
+                return None
+        dims = [self.layers[0].in_features] + [layer.out_features for layer in self.layers]
+        if max(dims) > 64:
+            return None
+        from .... import _native as N
+        return N.make_mlp_desc(dims, 'relu', 'sigmoid', has_bias=False)
 
     def forward(self, x, view_dirs, normals, geo_feat):
         out = self.fuse_radiance_inputs(x, view_dirs, normals, geo_feat)
+        if self._fused_desc is not None and out.is_cuda and out.dtype == torch.float32:
+            from ....ops.autograd import FusedMlpFn
+            weights = torch.cat([layer.weight.reshape(-1) for layer in self.layers])
+            return FusedMlpFn.apply(out.contiguous(), weights, None, self._fused_desc)
         for layer in self.layers:
             out = layer(out)
         return out
