@@ -115,25 +115,29 @@ class FgModel(Base3dModel):
             mask_rays = torch.logical_and(mask_rays, torch.any(mask_pts, dim=1))
         if bool(torch.all(mask_rays)):
             return self._forward(inputs, inference_only, get_progress, cur_epoch, total_epoch)
-        z_valid = zvals[mask_rays]
-        m_valid = mask_pts[mask_rays] if mask_pts is not None else None
-        empty = int(mask_rays.sum()) == 0
+        # ONE nonzero (one host sync) for the whole split: every `v[mask]` / `full[mask] = v` on the same mask would repeat it
+        idx_rays = mask_rays.nonzero(as_tuple=True)[0]
+        z_valid = zvals.index_select(0, idx_rays)
+        m_valid = mask_pts.index_select(0, idx_rays) if mask_pts is not None else None
+        empty = idx_rays.numel() == 0
         if empty:  # all-background batch: one synthetic ray gives the output keys, then everything takes the defaults
             mask_rays = mask_rays.clone()
             mask_rays[0] = True
+            idx_rays = torch.zeros(1, dtype=torch.long, device=zvals.device)
             z_valid = torch.zeros((1, zvals.shape[1]), dtype=zvals.dtype, device=zvals.device)
             z_valid[0, 1:] = 1.0
             if mask_pts is not None:
                 m_valid = torch.zeros((1, mask_pts.shape[1]), dtype=torch.bool, device=zvals.device)
                 m_valid[0, :2] = True
-        sub = {k: (v[mask_rays] if isinstance(v, torch.Tensor) else v) for k, v in inputs.items()}
+        sub = {k: (v.index_select(0, idx_rays) if isinstance(v, torch.Tensor) else v) for k, v in inputs.items()}
         sub['zvals'], sub['mask_pts'] = z_valid, m_valid
-        sub['bkg_color'] = bkg_color[mask_rays] if bkg_color is not None else None
+        sub['bkg_color'] = bkg_color.index_select(0, idx_rays) if bkg_color is not None else None
         out_valid = self._forward(sub, inference_only, get_progress, cur_epoch, total_epoch)
         if empty:
             mask_rays[0] = False
+            idx_rays = idx_rays[:0]
             out_valid = {k: (v[:0] if isinstance(v, torch.Tensor) else v) for k, v in out_valid.items()}
-        return self.update_values_for_invalid_rays(out_valid, mask_rays, bkg_color)
+        return self.update_values_for_invalid_rays(out_valid, mask_rays, bkg_color, idx_rays)
 
     def _forward(self, inputs, inference_only=False, get_progress=False, cur_epoch=0, total_epoch=300000):
         raise NotImplementedError('implement _forward (rays with coarse zvals) in the child class')
@@ -146,7 +150,9 @@ class FgModel(Base3dModel):
         if mask_pts is None:
             pts, dirs = pts.reshape(-1, 3), dirs.reshape(-1, 3)
         else:
-            pts, dirs = pts[mask_pts].view(-1, 3), dirs[mask_pts].view(-1, 3)
+            flat = mask_pts.reshape(-1).nonzero(as_tuple=True)[0]   # one nonzero for the two gathers and the two scatters
+            pts = pts.reshape(-1, 3).index_select(0, flat)
+            dirs = rays_d.index_select(0, torch.div(flat, n_pts, rounding_mode='floor'))   # the expanded view is never materialised
             if not inference_only:
                 self.adjust_dynamicbs_factor(mask_pts)
         _sigma, _radiance = chunk_processing(self._forward_pts_dir, self.chunk_pts, False, geo_net, radiance_net, pts.contiguous(),
@@ -156,11 +162,11 @@ class FgModel(Base3dModel):
         last = torch.cumsum(mask_pts.sum(dim=1), dim=0) - 1
         sigma = _sigma[last].unsqueeze(1).repeat(1, n_pts)
         radiance = _radiance[last].unsqueeze(1).repeat(1, n_pts, 1)
-        sigma[mask_pts] = _sigma
-        radiance[mask_pts] = _radiance
+        sigma = sigma.view(-1).index_copy(0, flat, _sigma.reshape(-1)).view(n_rays, n_pts)
+        radiance = radiance.view(-1, 3).index_copy(0, flat, _radiance.reshape(-1, 3)).view(n_rays, n_pts, 3)
         return sigma, radiance
 
-    def update_values_for_invalid_rays(self, output_valid, mask, rand_bkg_color=None):
+    def update_values_for_invalid_rays(self, output_valid, mask, rand_bkg_color=None, idx=None):
         """defaults for rays that never entered _forward: rgb* = bkg colour, depth* = depth_far, mask* = 0, normal* = cfg
         normal, progress_trans_shift* = 1, progress_sigma* = -1 for sdf models, other progress_* = 0 (fg_model.py:320-387)"""
         n_rays = mask.shape[0]
@@ -193,8 +199,9 @@ class FgModel(Base3dModel):
             else:
                 out[k] = v
                 continue
-            full[mask] = v
-            out[k] = full
+            if idx is None:
+                idx = mask.nonzero(as_tuple=True)[0]
+            out[k] = full.index_copy(0, idx, v)
         return out
 
     @staticmethod

@@ -16,15 +16,16 @@ def nets_on_valid_samples(forward_pts_dir, chunk_pts, geo_net, radiance_net, ray
     counts = mask_pts.sum(dim=1)
     sigma = zvals.new_zeros((n_rays, n_pts))
     radiance = zvals.new_zeros((n_rays, n_pts, 3))
-    pts = get_ray_points_by_zvals(rays_o, rays_d, zvals)[mask_pts].view(-1, 3)
-    if pts.shape[0] == 0:
+    flat = mask_pts.reshape(-1).nonzero(as_tuple=True)[0]   # one nonzero (one host sync) for both gathers and both scatters
+    if flat.numel() == 0:
         return sigma, radiance
-    dirs = rays_d.unsqueeze(1).expand(n_rays, n_pts, 3)[mask_pts].view(-1, 3)
+    pts = get_ray_points_by_zvals(rays_o, rays_d, zvals).reshape(-1, 3).index_select(0, flat)
+    dirs = rays_d.index_select(0, torch.div(flat, n_pts, rounding_mode='floor'))
     s_valid, r_valid = chunk_processing(forward_pts_dir, chunk_pts, False, geo_net, radiance_net, pts.contiguous(), dirs.contiguous())
     has = counts > 0
     last = (torch.cumsum(counts, dim=0) - 1).clamp_min(0)   # flat index of each ray's last valid sample
     sigma = torch.where(has[:, None], s_valid[last][:, None].expand(n_rays, n_pts), sigma).contiguous()
     radiance = torch.where(has[:, None, None], r_valid[last][:, None, :].expand(n_rays, n_pts, 3), radiance).contiguous()
-    sigma[mask_pts] = s_valid
-    radiance[mask_pts] = r_valid
+    sigma = sigma.view(-1).index_copy(0, flat, s_valid.reshape(-1)).view(n_rays, n_pts)
+    radiance = radiance.view(-1, 3).index_copy(0, flat, r_valid.reshape(-1, 3)).view(n_rays, n_pts, 3)
     return sigma, radiance
