@@ -111,8 +111,8 @@ class Neus(SdfModel):
             return mid, torch.cat([zvals, (zvals[:, -1] + half_step)[:, None]], dim=-1), None
         n_rays, n_pts = zvals.shape
         col = torch.zeros((n_rays, 1), dtype=torch.bool, device=zvals.device)
-        ends = ((zvals[:, -1] + half_step * 2.0)[:, None]).repeat(1, n_pts + 1)   # padded slots and the extra end: beyond the ray
-        ends[torch.cat([mask_pts, col], dim=1)] = zvals[mask_pts]
+        beyond = (zvals[:, -1] + half_step * 2.0)[:, None]                         # padded slots and the extra end: beyond the ray
+        ends = torch.cat([torch.where(mask_pts, zvals, beyond.expand(n_rays, n_pts)), beyond], dim=1)
         return 0.5 * (ends[..., 1:] + ends[..., :-1]), ends, torch.cat([~col, mask_pts[:, :-1]], dim=1)
 
     def get_est_opacity(self, dt, pts):

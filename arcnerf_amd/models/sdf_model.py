@@ -34,11 +34,13 @@ class SdfModel(FgModel):
         valid point's values (sdf_model.py:42-101)"""
         n_rays, n_pts = zvals.shape
         pts = get_ray_points_by_zvals(rays_o, rays_d, zvals)
-        dirs = torch.repeat_interleave(rays_d.unsqueeze(1), n_pts, dim=1)
         if mask_pts is None:
-            pts, dirs = pts.view(-1, 3), dirs.view(-1, 3)
+            pts, dirs = pts.view(-1, 3), torch.repeat_interleave(rays_d.unsqueeze(1), n_pts, dim=1).view(-1, 3)
         else:
-            pts, dirs = pts[mask_pts].view(-1, 3), dirs[mask_pts].view(-1, 3)
+            # one nonzero (one host sync) serves the two gathers here and the three scatters below
+            flat = mask_pts.reshape(-1).nonzero(as_tuple=True)[0]
+            pts = pts.reshape(-1, 3).index_select(0, flat)
+            dirs = rays_d.index_select(0, torch.div(flat, n_pts, rounding_mode='floor'))
             if not inference_only:
                 self.adjust_dynamicbs_factor(mask_pts)
         _sdf, _radiance, _normal = chunk_processing(self._forward_pts_dir, self.chunk_pts, False, geo_net, radiance_net, pts, dirs)
@@ -48,7 +50,9 @@ class SdfModel(FgModel):
         sdf = torch.ones((n_rays, n_pts), dtype=zvals.dtype, device=zvals.device) * _sdf[last].unsqueeze(1)
         radiance = torch.ones((n_rays, n_pts, 3), dtype=zvals.dtype, device=zvals.device) * _radiance[last].unsqueeze(1)
         normal = torch.ones((n_rays, n_pts, 3), dtype=zvals.dtype, device=zvals.device) * _normal[last].unsqueeze(1)
-        sdf[mask_pts], radiance[mask_pts], normal[mask_pts] = _sdf, _radiance, _normal
+        sdf = sdf.view(-1).index_copy(0, flat, _sdf.reshape(-1)).view(n_rays, n_pts)
+        radiance = radiance.view(-1, 3).index_copy(0, flat, _radiance.reshape(-1, 3)).view(n_rays, n_pts, 3)
+        normal = normal.view(-1, 3).index_copy(0, flat, _normal.reshape(-1, 3)).view(n_rays, n_pts, 3)
         return sdf, radiance, normal
 
     @staticmethod
