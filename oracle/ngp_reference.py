@@ -8,14 +8,18 @@ product package.  Follows the reference call stack of SURVEY.md §3.1: K2 bounds
 import numpy as np
 
 
-def oracle_step(orc, fld, cfg, P, o, d, bkg, bf, rng_state, rng_inc, g_rgb=None, huber_target=None, noise=None):
+def oracle_step(orc, fld, cfg, P, o, d, bkg, bf, rng_state, rng_inc, g_rgb=None, huber_target=None, noise=None, torch_bounds=False):
     """Forward (and backward when g_rgb or huber_target is given) of one NGP step on the CPU.
 
     fld: an arcnerf_amd.pipeline.NgpField (only its metadata: level table, bounds, segment layout); P = fld.export_numpy().
-    Returns dict(rgb, depth, mask (R,), valid (R,), n_samples, counts [, grads (flat), loss]).
+    Returns dict(rgb, depth, mask (R,), valid (R,), n_samples, counts, zvals, mask_pts [, grads (flat), loss]).
+    Pinned to a run of the reference itself by tests/test_oracle_ngp_golden.py (golden G21).
     """
     aabb23 = np.array([fld.min_xyz, fld.max_xyz], np.float32)
-    near, far, _, _ = orc.aabb_intersection(o, d, aabb23[None])
+    if torch_bounds:  # the reference's own torch AABB code (geometry/ray.py:295-339) instead of K2
+        near, far, _, _ = orc.aabb_intersection_torch(o, d, np.ascontiguousarray(aabb23.T)[None])
+    else:
+        near, far, _, _ = orc.aabb_intersection(o, d, aabb23[None])
     z, m, cnt = orc.sparse_volume_sampling(o, d, near, far, cfg.n_sample, np.float32(cfg.dt), aabb23, cfg.n_grid, bf,
                                            cfg.near_distance, rng_state, rng_inc)
     R = o.shape[0]
@@ -24,6 +28,7 @@ def oracle_step(orc, fld, cfg, P, o, d, bkg, bf, rng_state, rng_inc, g_rgb=None,
     z, m = np.ascontiguousarray(z[:, :Pd]), np.ascontiguousarray(m[:, :Pd])
     valid = cnt > 0
     out['valid'] = valid
+    out['zvals'], out['mask_pts'] = z, m
     rr, jj = np.nonzero(m)
     pts = (o[rr] + z[rr, jj][:, None] * d[rr]).astype(np.float32)
     res = np.array(fld.resolutions, np.int32)
@@ -89,10 +94,12 @@ def oracle_step(orc, fld, cfg, P, o, d, bkg, bf, rng_state, rng_inc, g_rgb=None,
     d_sigma[last[vi]] += pad_s[vi]
     d_rgb_s[last[vi]] += pad_r[vi]
     dy = d_rgb_s
-    g_rad = []
+    g_rad, b_rad, b_geo = [], [], []
     for i in reversed(range(len(P['rad']))):
-        dy, dW, _ = orc.linear_bwd(rs[i], P['rad'][i][0], rpres[i], rs[i + 1], dy, 'relu' if i < len(P['rad']) - 1 else 'sigmoid')
+        dy, dW, db = orc.linear_bwd(rs[i], P['rad'][i][0], rpres[i], rs[i + 1], dy, 'relu' if i < len(P['rad']) - 1 else 'sigmoid',
+                                    has_bias=P['rad'][i][1] is not None)
         g_rad.insert(0, dW)
+        b_rad.insert(0, db)
     d_rin = dy
     d_geo_out = np.zeros_like(geo_out)
     sl = slice(0, cfg.W_feat) if cfg.rad_mode == 'fv' else slice(cfg.sh_degree ** 2, None)
@@ -101,14 +108,20 @@ def oracle_step(orc, fld, cfg, P, o, d, bkg, bf, rng_state, rng_inc, g_rgb=None,
     dy = d_geo_out
     g_geo = []
     for i in reversed(range(len(P['geo']))):
-        dy, dW, _ = orc.linear_bwd(hs[i], P['geo'][i][0], pres[i], hs[i + 1], dy, 'relu' if i < len(P['geo']) - 1 else None)
+        dy, dW, db = orc.linear_bwd(hs[i], P['geo'][i][0], pres[i], hs[i + 1], dy, 'relu' if i < len(P['geo']) - 1 else None,
+                                    has_bias=P['geo'][i][1] is not None)
         g_geo.insert(0, dW)
+        b_geo.insert(0, db)
     d_table = orc.hashgrid_bwd(pts, P['table'], dy, res, offs, mn, mx)
     grads = np.zeros(fld.n_params, np.float32)
     for name, arr in (('table', d_table.reshape(-1)), ('geo_w', np.concatenate([g.reshape(-1) for g in g_geo])),
                       ('rad_w', np.concatenate([g.reshape(-1) for g in g_rad]))):
         off, n = fld._seg[name]
         grads[off:off + n] = arr
+    for name, bs in (('geo_b', b_geo), ('rad_b', b_rad)):
+        off, n = fld._seg.get(name, (0, 0))
+        if n and all(b is not None for b in bs):
+            grads[off:off + n] = np.concatenate(bs)
     out['grads'] = grads
     return out
 

@@ -1,0 +1,65 @@
+"""Pins oracle/ngp_reference.py:oracle_step (the numpy/C restatement of the reference's NGP call stack that the GPU pipeline tests and
+the smoke check compare against) to golden G21: the reference's OWN FullModel / FgModel / NeRF / HashGridEmbedder / GeoNet / RadianceNet /
+ray_marching run end to end at the dimensions of configs/models/nerf_ngp.yaml (tests/golden/make_golden_ngp.py)."""
+import numpy as np
+import pytest
+
+import g21_utils as G
+
+
+@pytest.fixture(scope='module')
+def g21():
+    g = G.golden()
+    return g, G.table(g), G.bitfield(g)
+
+
+def _field(net):
+    from arcnerf_amd.pipeline import NgpConfig, NgpField
+    cfg = NgpConfig(noise_std=0.0, **G.NETS[net])
+    return cfg, NgpField(cfg, device='cpu', seed=0)
+
+
+@pytest.mark.parametrize('variant,net', [('k2', 'lin'), ('k2', 'nb'), ('k2', 'nb_fused'), ('tb', 'lin')])
+def test_oracle_step_matches_reference_run(oracle, g21, variant, net):
+    from oracle.ngp_reference import oracle_step
+    g, tbl, bf = g21
+    cfg, fld = _field(net)
+    assert fld.offsets == [int(v) for v in g['offsets']] and fld.resolutions == [int(v) for v in g['resolutions']]
+    P = dict(G.net_weights(g, variant, net), table=tbl)
+    o, d = g['in_rays_o'][0], g['in_rays_d'][0]
+    bkg, img = g['in_bkg_color'][0], g['in_img'][0]
+    src = 'nb' if net == 'nb_fused' else net
+    pre = '{}_{}_'.format(variant, src)
+    rng = oracle.Pcg32(9121)
+    tb = variant == 'tb'
+    # launch 0: inference
+    ref = oracle_step(oracle, fld, cfg, P, o, d, bkg, bf, rng.state, rng.inc, torch_bounds=tb)
+    Pd = ref['zvals'].shape[1]
+    assert np.array_equal(ref['zvals'], g[pre + 'infer_zvals']) and np.array_equal(ref['mask_pts'], G.mask_pts(g, pre + 'infer_mask_pts', Pd))
+    depth = np.where(ref['valid'], ref['depth'], 10.0).astype(np.float32)
+    G.check_outputs(g, pre + 'infer_', ref['rgb'], depth, ref['mask'], train=False)
+    assert (~ref['valid']).sum() > 20 and np.array_equal(ref['rgb'][~ref['valid']], bkg[~ref['valid']])
+    # launch 1: train, noise off, gradients of 100 * mse
+    rng.advance()
+    ref = oracle_step(oracle, fld, cfg, P, o, d, bkg, bf, rng.state, rng.inc, torch_bounds=tb)
+    g_rgb = (2.0 * (ref['rgb'] - img) / img.size * 100.0).astype(np.float32)
+    ref = oracle_step(oracle, fld, cfg, P, o, d, bkg, bf, rng.state, rng.inc, g_rgb=g_rgb, torch_bounds=tb)
+    Pd = ref['zvals'].shape[1]
+    assert np.array_equal(ref['zvals'], g[pre + 'train0_zvals']) and np.array_equal(ref['mask_pts'], G.mask_pts(g, pre + 'train0_mask_pts', Pd))
+    depth = np.where(ref['valid'], ref['depth'], 10.0).astype(np.float32)
+    G.check_outputs(g, pre + 'train0_', ref['rgb'], depth, ref['mask'])
+    tg, nets = G.split_flat_grads(fld, ref['grads'])
+    G.check_table_grad(g, pre + 'train0_tgrad_', tg)
+    G.check_net_grads(g, variant, net, 'train0', nets)
+    # launch 2: train with the reference's own noise draw
+    rng.advance()
+    noise = G.packed_noise(g, variant, net, ref['counts'] * 0 + oracle_step(oracle, fld, cfg, P, o, d, bkg, bf, rng.state, rng.inc, torch_bounds=tb)['counts'])
+    cfg.noise_std = 1.0
+    ref = oracle_step(oracle, fld, cfg, P, o, d, bkg, bf, rng.state, rng.inc, noise=noise, torch_bounds=tb)
+    g_rgb = (2.0 * (ref['rgb'] - img) / img.size * 100.0).astype(np.float32)
+    ref = oracle_step(oracle, fld, cfg, P, o, d, bkg, bf, rng.state, rng.inc, g_rgb=g_rgb, noise=noise, torch_bounds=tb)
+    depth = np.where(ref['valid'], ref['depth'], 10.0).astype(np.float32)
+    G.check_outputs(g, pre + 'train1_', ref['rgb'], depth, ref['mask'])
+    tg, nets = G.split_flat_grads(fld, ref['grads'])
+    G.check_table_grad(g, pre + 'train1_tgrad_', tg)
+    G.check_net_grads(g, variant, net, 'train1', nets)
