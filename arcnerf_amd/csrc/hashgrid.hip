@@ -338,6 +338,192 @@ hashgrid_fwd_xcd_kernel(const float *__restrict__ xyz, const float *__restrict__
     }
 }
 
+// ---- forward, XCD-affine, cost-balanced (v2) ----------------------------------------------------------------------------------
+// Measured per-level cost of the kernel above on ONE XCD (2.6e5 samples, tools/exp_gather.py --levels): 18 us for the coarse
+// power-of-two levels (an instruction floor: six correctly rounded fp32 divisions and eight hashes per lane), 28 us for the
+// non-power-of-two levels 1-4 (eight 64-bit modulos through f64), rising to 70 us at level 15 (every corner a new 128-byte line out
+// of the XCD's L2).  Pairing level x with level 15-x therefore leaves XCD 1 with 96 us of work and XCD 7 with 42.  This kernel
+//   * takes a PLAN of (level, sample-range fraction, workgroups) segments per XCD built from a per-level cost model so that
+//     all XCDs finish together (a fine level may spill a sliver onto the neighbouring XCD);
+//   * divides by the voxel size with the precomputed correctly rounded reciprocal + one fused residual step (Markstein:
+//     q0 = n*r, e = fma(-q0, vs, n), q = fma(e, r, q0) - equal to the IEEE quotient in 1.4e9 randomised cases per level constant,
+//     tools/ubench/markstein.c); the CELL INDEX, which must be bit-exact, additionally takes the true division whenever a lane's
+//     quotient lies within 4e-7 relative of an integer (a wave-uniform branch, taken by ~10 % of the waves on the finest level);
+//   * on the non-power-of-two levels computes the modulo once per (y, z) corner pair: with kb = bits of res + 1,
+//     h = B ^ cx = (B & ~lowmask) + ((B & lowmask) ^ cx), so row = ((B & ~lowmask) mod size + ((B & lowmask) ^ cx)) mod size and
+//     the second mod is one conditional subtract - 4 f64 modulos per lane instead of 8.
+// Accumulation order and arithmetic are those of the kernels above: results are bit-identical.
+struct FwdSeg {
+    int32_t level;
+    uint32_t f0, f1;      // sample-tile range of the segment as fractions (x / 65536) of the launch's tile count
+    int32_t wg0, wg1;     // positions in the XCD's workgroup queue that work on it
+};
+constexpr int kFwdSegs = 8;
+struct FwdPlan {
+    FwdSeg seg[8][kFwdSegs];
+    int32_t n_seg[8];
+    int32_t lowbits[ARCN_MAX_LEVELS];   // non-power-of-two levels: kb (0 = use the direct 8-modulo path)
+};
+
+__device__ __forceinline__ float div_by_const(float n, float vs, float rvs) {
+    const float q0 = n * rvs;
+    const float e = __builtin_fmaf(-q0, vs, n);
+    return __builtin_fmaf(e, rvs, q0);
+}
+
+__device__ __forceinline__ uint32_t mod_size(uint64_t h, const LevelParams &lp) {
+    double q = floor((double)h * lp.inv_size);
+    int64_t r = (int64_t)h - (int64_t)q * (int64_t)lp.size;
+    if (r < 0) r += lp.size;
+    else if (r >= (int64_t)lp.size) r -= lp.size;
+    return (uint32_t)r;
+}
+
+template <int F, bool LM, bool PAIR, int NT = 0>
+__global__ void __launch_bounds__(256)
+hashgrid_fwd_bal_kernel(const float *__restrict__ xyz, const float *__restrict__ table, GridParams g, FwdPlan plan,
+                        float *__restrict__ out, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int xcd = blockIdx.x & 7;
+    const int j = blockIdx.x >> 3;
+    int k = -1;
+#pragma unroll
+    for (int i = 0; i < kFwdSegs; ++i)
+        if (i < plan.n_seg[xcd] && j >= plan.seg[xcd][i].wg0 && j < plan.seg[xcd][i].wg1) k = i;
+    if (k < 0) return;
+    const FwdSeg sg = plan.seg[xcd][k];
+    const int l = sg.level;
+    const LevelParams lp = g.lv[l];
+    const int64_t tiles = (cnt + 255) >> 8;
+    const int64_t t0 = (tiles * sg.f0) >> 16, t1 = (tiles * sg.f1) >> 16;
+    const int nslot = sg.wg1 - sg.wg0, slot = j - sg.wg0;
+    const int kb = plan.lowbits[l];
+    const float fres = (float)lp.res;
+    for (int64_t t = t0 + slot; t < t1; t += nslot) {
+        const int64_t s = (t << 8) + threadIdx.x;
+        if (s >= cnt) break;
+        // NT: positions and features stream through once per level; marked non-temporal they do not displace the level's table
+        // lines from the XCD's L2 (the table of a fine level is exactly the size of that L2)
+        const float p[3] = {(NT & 1) ? __builtin_nontemporal_load(xyz + 3 * s) : xyz[3 * s],
+                            (NT & 1) ? __builtin_nontemporal_load(xyz + 3 * s + 1) : xyz[3 * s + 1],
+                            (NT & 1) ? __builtin_nontemporal_load(xyz + 3 * s + 2) : xyz[3 * s + 2]};
+        float nn[3], v[3];
+        bool amb = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            nn[a] = p[a] - g.mn[a];
+            const float q0 = nn[a] * lp.rvs[a];
+            v[a] = q0;
+            const float d = fabsf(q0 - rintf(q0));
+            amb = amb || !(d > 4e-7f * fmaxf(fabsf(q0), 1.0f));   // also true for NaN
+        }
+        if (__any(amb)) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) v[a] = nn[a] / lp.vs[a];
+        }
+        bool ok = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            if (!(v[a] >= 0.f) || !(v[a] < fres)) ok = false;
+        float acc[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f] = 0.f;
+        if (ok) {
+            uint32_t c[3];
+            float w[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float cf = floorf(v[a]);
+                c[a] = (uint32_t)cf;
+                const float st = cf * lp.vs[a];
+                const float g0 = st + g.mn[0];
+                const float ww = div_by_const(p[a] - g0, lp.vs[a], lp.rvs[a]);
+                w[a] = ww < 0.0f ? 0.0f : (ww > 1.0f ? 1.0f : ww);
+            }
+            uint32_t rows[8];   // corner q: x = (q>>1)&1, y = q&1, z = q>>2
+            if (lp.mask) {
+                const uint32_t hy0 = c[1] * 2654435761u, hy1 = hy0 + 2654435761u;
+                const uint32_t hz0 = c[2] * 805459861u, hz1 = hz0 + 805459861u;
+                const uint32_t A[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};   // index y + 2 z
+#pragma unroll
+                for (int q = 0; q < 8; ++q) rows[q] = ((c[0] + ((q >> 1) & 1)) ^ A[(q & 1) + 2 * (q >> 2)]) & lp.mask;
+            } else if (kb > 0) {
+                const uint64_t hy0 = (uint64_t)c[1] * 2654435761ull, hy1 = hy0 + 2654435761ull;
+                const uint64_t hz0 = (uint64_t)c[2] * 805459861ull, hz1 = hz0 + 805459861ull;
+                const uint64_t B[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+                const uint64_t lowmask = (1ull << kb) - 1ull;
+#pragma unroll
+                for (int yz = 0; yz < 4; ++yz) {
+                    const uint32_t mh = mod_size(B[yz] & ~lowmask, lp);
+                    const uint32_t bl = (uint32_t)(B[yz] & lowmask);
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) {
+                        uint32_t r = mh + (bl ^ (c[0] + x));
+                        if (r >= lp.size) r -= lp.size;
+                        rows[(x << 1) + (yz & 1) + ((yz >> 1) << 2)] = r;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) rows[q] = hash_row(c[0] + ((q >> 1) & 1), c[1] + (q & 1), c[2] + (q >> 2), lp);
+            }
+            float vals[8][F];
+            const float *lt = table + lp.offset * F;
+            if (PAIR && F == 2 && lp.mask) {
+                // the two x-neighbours of a (y, z) corner pair: rows r and r' = ((cx+1) ^ A) & mask.  cx even -> r' = r ^ 1: both in
+                // one aligned 16-byte word (one dwordx4); cx odd -> a second 8-byte load under the lane mask
+                const bool even = (c[0] & 1u) == 0u;
+#pragma unroll
+                for (int yz = 0; yz < 4; ++yz) {
+                    const int q0 = (yz & 1) + ((yz >> 1) << 2), q1 = q0 + 2;
+                    const uint32_t r0 = rows[q0];
+                    const float4 t4 = *reinterpret_cast<const float4 *>(lt + (size_t)(r0 & ~1u) * 2);
+                    const bool hi = (r0 & 1u) != 0u;
+                    vals[q0][0] = hi ? t4.z : t4.x;
+                    vals[q0][1] = hi ? t4.w : t4.y;
+                    float2 o2 = make_float2(hi ? t4.x : t4.z, hi ? t4.y : t4.w);
+                    if (!even) o2 = *reinterpret_cast<const float2 *>(lt + (size_t)rows[q1] * 2);
+                    vals[q1][0] = o2.x;
+                    vals[q1][1] = o2.y;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float *src = lt + (size_t)rows[q] * F;
+                    if (F == 2) {
+                        const float2 t2 = *reinterpret_cast<const float2 *>(src);
+                        vals[q][0] = t2.x;
+                        vals[q][1 % F] = t2.y;
+                    } else {
+#pragma unroll
+                        for (int f = 0; f < F; ++f) vals[q][f] = src[f];
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
+                const float wt = ((ox ? w[0] : 1.0f - w[0]) * (oy ? w[1] : 1.0f - w[1])) * (oz ? w[2] : 1.0f - w[2]);
+#pragma unroll
+                for (int f = 0; f < F; ++f) { float a = vals[q][f] * wt; acc[f] = acc[f] + a; }
+            }
+        }
+        float *o = LM ? out + ((int64_t)l * n_cap + s) * F : out + (s * g.L + l) * F;
+        if (F == 2) {
+            if (NT & 2) {
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                v2f val = {acc[0], acc[1 % F]};
+                __builtin_nontemporal_store(val, reinterpret_cast<v2f *>(o));
+            } else {
+                *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1 % F]);
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < F; ++f) o[f] = acc[f];
+        }
+    }
+}
+
 // ---- backward, binned owner-computes scatter --------------------------------------------------------------------------------
 // Measured on MI355X: the chip retires only ~18-21 G scattered fp32 global atomics per second (they are served at the memory
 // side, not in the issuing XCD's L2), so the 128 atomics/sample of the plain kernel above cost 4 ms per 2^18 samples no
@@ -1105,6 +1291,118 @@ ARCN_EXPORT int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc 
     return bin_counter_floats(plan) + plan.n_recs * 4;  // bin counters + 16-byte records
 }
 
+// Cost model of one level of the forward gather on one XCD, in arbitrary units (us per 2.6e5 samples measured on MI355X with the
+// bench's ray batch, tools/exp_gather.py --levels): an instruction floor, the extra modulo work of the non-power-of-two levels, and
+// a memory term that grows with the resolution (fewer samples per cell -> fewer lanes of a wave share a line).
+static float fwd_level_cost(const LevelParams &lp) {
+    // one-XCD time of the level minus the launch overhead, pair loads on (tools/exp_gather.py --levels with ARCN_GATHER_ONE_XCD=1)
+    static const float res_pts[] = {64.f, 80.f, 111.f, 153.f, 212.f, 294.f, 406.f, 561.f, 776.f, 1072.f, 1482.f, 2047.f, 8192.f};
+    static const float mem_pts[] = {0.0f, 1.0f, 2.9f, 6.4f, 10.5f, 16.9f, 24.4f, 32.6f, 38.0f, 40.9f, 42.6f, 42.5f, 43.0f};
+    static const float floor_cost = [] { const char *e = getenv("ARCN_GATHER_FLOOR"); return e ? (float)atof(e) : 10.0f; }();
+    static const float mod_cost = [] { const char *e = getenv("ARCN_GATHER_MODCOST"); return e ? (float)atof(e) : 3.0f; }();
+    const float r = (float)lp.res;
+    float mem = 0.f;
+    const int np = (int)(sizeof(res_pts) / sizeof(res_pts[0]));
+    if (r >= res_pts[np - 1]) mem = mem_pts[np - 1];
+    else
+        for (int i = 0; i + 1 < np; ++i)
+            if (r >= res_pts[i] && r < res_pts[i + 1]) {
+                mem = mem_pts[i] + (mem_pts[i + 1] - mem_pts[i]) * (r - res_pts[i]) / (res_pts[i + 1] - res_pts[i]);
+                break;
+            }
+    return floor_cost + (lp.mask ? 0.f : mod_cost) + mem;
+}
+
+// Levels in descending cost are poured into the 8 XCD queues, each filled to 1/8 of the total; a level that does not fit is cut
+// (by sample range) and continues on the next XCD.  Workgroups per segment follow its share of the XCD's cost.
+static int build_fwd_plan(const GridParams &g, int64_t n, FwdPlan &plan, int &wg_per_xcd) {
+    int order[ARCN_MAX_LEVELS];
+    float cost[ARCN_MAX_LEVELS];
+    float total = 0.f;
+    for (int l = 0; l < g.L; ++l) {
+        order[l] = l;
+        cost[l] = fwd_level_cost(g.lv[l]);
+        total += cost[l];
+        // modulo sharing needs (res + 1) < 2^kb <= size
+        int kb = 0;
+        if (!g.lv[l].mask) {
+            while ((1u << kb) <= (uint32_t)(g.lv[l].res + 1)) ++kb;
+            if ((1ull << kb) > (uint64_t)g.lv[l].size) kb = 0;
+        }
+        plan.lowbits[l] = kb;
+    }
+    for (int l = g.L; l < ARCN_MAX_LEVELS; ++l) plan.lowbits[l] = 0;
+    for (int i = 0; i < g.L; ++i)
+        for (int k = i + 1; k < g.L; ++k)
+            if (cost[order[k]] > cost[order[i]]) { int t = order[i]; order[i] = order[k]; order[k] = t; }
+    const int64_t tiles = ceil_div<int64_t>(n, 256);
+    static const int max_wg = [] { const char *e = getenv("ARCN_GATHER_WGS"); return e ? atoi(e) : 1024; }();
+    int64_t want = ceil_div<int64_t>(tiles * g.L, 8);    // one tile per workgroup when there is little work
+    wg_per_xcd = (int)(want < max_wg ? want : max_wg);
+    if (wg_per_xcd < 1) wg_per_xcd = 1;
+    static const int one_xcd = [] { const char *e = getenv("ARCN_GATHER_ONE_XCD"); return e ? atoi(e) : 0; }();  // calibration aid
+    const float share = one_xcd ? total * 1.01f : total / 8.f;
+    for (int x = 0; x < 8; ++x) plan.n_seg[x] = 0;
+    // the 8 most expensive levels (the fine ones: every one of them fills a 4 MiB L2 by itself) get an XCD each and are never cut -
+    // two fine levels in one L2 evict each other (measured: +6 us on the XCDs that held a cut level); the cheaper levels, whose
+    // touched rows are a small part of their table, are the filler that evens the queues out
+    float load[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto add_seg = [&](int x, int l, float f0, float f1, float c) -> int {
+        if (plan.n_seg[x] >= kFwdSegs) return -1;
+        FwdSeg &sg = plan.seg[x][plan.n_seg[x]++];
+        sg.level = l;
+        sg.f0 = (uint32_t)(f0 * 65536.f + 0.5f);
+        sg.f1 = f1 >= 1.f ? 65536u : (uint32_t)(f1 * 65536.f + 0.5f);
+        sg.wg0 = 0;
+        sg.wg1 = (int32_t)(c * 1024.f);   // the cost, until the queues are complete
+        load[x] += c;
+        return 0;
+    };
+    const int whole = one_xcd ? 0 : (g.L < 8 ? g.L : 8);
+    for (int i = 0; i < whole; ++i)
+        if (add_seg(i, order[i], 0.f, 1.f, cost[order[i]])) return einval("hashgrid_fwd_xcd: plan overflow");
+    for (int i = whole; i < g.L; ++i) {
+        const int l = order[i];
+        float left = cost[l], f0 = 0.f;
+        int guard = 0;
+        while (left > 1e-6f * total && guard++ < 64) {
+            int x = 0;   // the least loaded queue that can still take a segment
+            float best = 1e30f;
+            for (int q = 0; q < (one_xcd ? 1 : 8); ++q) {
+                static const float odd_bias = [] { const char *e = getenv("ARCN_GATHER_ODD_SCALE"); return e ? (float)atof(e) : 1.0f; }();
+                const float eff = load[q] / ((q & 1) ? odd_bias : 2.0f - odd_bias);
+                if (plan.n_seg[q] < kFwdSegs && eff < best) { best = eff; x = q; }
+            }
+            if (best > 1e29f) return einval("hashgrid_fwd_xcd: plan overflow");
+            static const float odd_scale = [] { const char *e = getenv("ARCN_GATHER_ODD_SCALE"); return e ? (float)atof(e) : 1.0f; }();
+            const float room = share * ((x & 1) ? odd_scale : 2.0f - odd_scale) - load[x];
+            const float take = (room <= 1e-4f * total || left <= room) ? left : room;
+            const float f1 = (take >= left) ? 1.f : f0 + (1.f - f0) * (take / left);
+            if (add_seg(x, l, f0, f1, take)) return einval("hashgrid_fwd_xcd: plan overflow");
+            f0 = f1;
+            left -= take;
+        }
+    }
+    for (int q = 0; q < 8; ++q) {
+        float sum = 0.f;
+        for (int i = 0; i < plan.n_seg[q]; ++i) sum += (float)plan.seg[q][i].wg1;
+        int pos = 0;
+        float acc = 0.f;
+        for (int i = 0; i < plan.n_seg[q]; ++i) {
+            acc += (float)plan.seg[q][i].wg1;
+            int end = (i == plan.n_seg[q] - 1) ? wg_per_xcd : (int)(acc / (sum > 0.f ? sum : 1.f) * (float)wg_per_xcd + 0.5f);
+            if (end <= pos) end = pos + 1;              // every segment gets a workgroup
+            if (end > wg_per_xcd) end = wg_per_xcd;
+            plan.seg[q][i].wg0 = pos;
+            plan.seg[q][i].wg1 = end;
+            pos = end;
+        }
+        if (plan.n_seg[q] > 0 && plan.seg[q][plan.n_seg[q] - 1].wg1 <= plan.seg[q][plan.n_seg[q] - 1].wg0)
+            return einval("hashgrid_fwd_xcd: more segments than workgroups");
+    }
+    return ARCN_OK;
+}
+
 // XCD-affine forward (n_feat 1 or 2).  level_major = 0: out (n, L*F) row-major like arcn_hashgrid_fwd;
 // level_major = 1: out[(l * n_cap + s) * F + f].
 ARCN_EXPORT int arcn_hashgrid_fwd_xcd(const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out,
@@ -1115,6 +1413,8 @@ ARCN_EXPORT int arcn_hashgrid_fwd_xcd(const float *xyz, const float *table, cons
     int rc = build_params(desc_host, g);
     if (rc) return rc;
     if (g.F > 2) return einval("hashgrid_fwd_xcd: n_feat 1 or 2");
+    static const int variant = [] { const char *e = getenv("ARCN_GATHER_VARIANT"); return e ? atoi(e) : 3; }();
+    if (variant == 0) {
     LmPlan plan;
     for (int x = 0; x < 8; ++x) for (int k = 0; k < 4; ++k) plan.levels[x][k] = -1;
     int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1136,5 +1436,27 @@ ARCN_EXPORT int arcn_hashgrid_fwd_xcd(const float *xyz, const float *table, cons
     if (g.F == 1) { if (level_major) ARCN_XCD(1, true); else ARCN_XCD(1, false); }
     else { if (level_major) ARCN_XCD(2, true); else ARCN_XCD(2, false); }
 #undef ARCN_XCD
+    } else {
+    FwdPlan plan;
+    int wg_per_xcd = 0;
+    rc = build_fwd_plan(g, n, plan, wg_per_xcd);
+    if (rc) return rc;
+    {   // calibration aid: only one XCD's queue runs
+        static const int only = [] { const char *e = getenv("ARCN_GATHER_ONLY_XCD"); return e ? atoi(e) : -1; }();
+        if (only >= 0) for (int x = 0; x < 8; ++x) if (x != only) plan.n_seg[x] = 0;
+    }
+    dim3 grid((unsigned)(8 * wg_per_xcd));
+#define ARCN_BAL(F_, LM_, P_) hipLaunchKernelGGL((hashgrid_fwd_bal_kernel<F_, LM_, P_>), grid, dim3(256), 0, as_stream(stream), xyz, table, g, plan, out, n_cap, n, n_ptr)
+    const bool pair = (variant & 1) != 0;
+    if (g.F == 1) { if (level_major) ARCN_BAL(1, true, false); else ARCN_BAL(1, false, false); }
+    else if (pair && (variant & 12) && level_major) {   // experiments: non-temporal position loads (4) / feature stores (8)
+        if ((variant & 12) == 4) hipLaunchKernelGGL((hashgrid_fwd_bal_kernel<2, true, true, 1>), grid, dim3(256), 0, as_stream(stream), xyz, table, g, plan, out, n_cap, n, n_ptr);
+        else if ((variant & 12) == 8) hipLaunchKernelGGL((hashgrid_fwd_bal_kernel<2, true, true, 2>), grid, dim3(256), 0, as_stream(stream), xyz, table, g, plan, out, n_cap, n, n_ptr);
+        else hipLaunchKernelGGL((hashgrid_fwd_bal_kernel<2, true, true, 3>), grid, dim3(256), 0, as_stream(stream), xyz, table, g, plan, out, n_cap, n, n_ptr);
+    }
+    else if (pair) { if (level_major) ARCN_BAL(2, true, true); else ARCN_BAL(2, false, true); }
+    else { if (level_major) ARCN_BAL(2, true, false); else ARCN_BAL(2, false, false); }
+#undef ARCN_BAL
+    }
     return check_launch("hashgrid_fwd_xcd");
 }

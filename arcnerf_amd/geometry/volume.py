@@ -14,12 +14,32 @@ from ..ops import functional as F
 from .ray import aabb_ray_intersection
 
 
+def mix_permutation(idx, n, rng):
+    """idx (int64 tensor of values in [0, n), n a power of two) -> pi(idx) for a bijection pi of [0, n) drawn from `rng`:
+    x -> a*x + c (a odd), x -> x ^ (x >> s): both invertible modulo 2^k; two rounds with independent constants."""
+    k = n.bit_length() - 1
+    m = n - 1
+    x = idx
+    for _ in range(2):
+        a = int(rng.integers(0, n // 2)) * 2 + 1
+        a |= 1 << max(1, k // 2)           # keep the multiplier from being tiny
+        c = int(rng.integers(0, n))
+        x = (x * (a & m) + c) & m
+        x = x ^ (x >> max(1, (k + 1) // 2))
+        x = (x * 0x9E3779B1) & m           # odd constant: a second multiply after the shift spreads the high bits
+        x = x ^ (x >> max(1, k // 3))
+    return x
+
+
 def select_refresh_cells(bitfield_flat, n_cells, cache, rng):
     """Cells refreshed by VolumeBound.optimize after its warm-up (volume_bound.py:178-190): n/4 cells drawn uniformly
     without repetition + the first n/4 occupied cells in flat-index order (`get_occupied_voxel_idx()[:n]`).
 
-    Sync-free: the uniform part is a random full-period affine permutation of the (power-of-two) cell range instead of
-    torch.randperm (a 2M-key sort), the occupied part is an ordered compaction through cumsum + scatter, and the number
+    Sync-free: the uniform part is the first n/4 images of a seeded BIJECTION of the (power-of-two) cell range - two rounds of
+    odd-multiply / add / xor-shift, each a permutation of [0, 2^k) - instead of torch.randperm (a 2M-key sort); a plain affine map
+    a*i + c would be an arithmetic progression (one contiguous quarter of the grid for a = 1), the mixing rounds make the subset
+    look uniform in (x, y, z) (tests/test_host_api.py checks the per-octant / per-slab counts).  The occupied part is an ordered
+    compaction through cumsum + scatter, and the number
     of valid entries is returned as a DEVICE int32 scalar — torch.nonzero/torch.where would stall the launch queue at every
     refresh.  Returns (cells int64 (2*(n/4),), n_valid int32 (1,)).  `cache` is a dict for persistent buffers, `rng` a
     numpy Generator (host side, only the two affine constants are drawn from it)."""
@@ -30,9 +50,7 @@ def select_refresh_cells(bitfield_flat, n_cells, cache, rng):
         cache['arange'] = torch.arange(n_cells, device=dev)
     buf, ar = cache['cell_buf'], cache['arange']
     if n_cells & (n_cells - 1) == 0:
-        a = int(rng.integers(0, n_cells // 2)) * 2 + 1  # odd multiplier: i -> a*i + c is a bijection mod 2^k
-        c = int(rng.integers(0, n_cells))
-        buf[:n_s] = (ar[:n_s] * a + c) & (n_cells - 1)
+        buf[:n_s] = mix_permutation(ar[:n_s], n_cells, rng)
     else:
         buf[:n_s] = torch.randperm(n_cells, device=dev)[:n_s]
     csum = torch.cumsum(bitfield_flat.to(torch.int32), 0)

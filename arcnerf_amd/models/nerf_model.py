@@ -27,7 +27,7 @@ class _PackedRenderFn(torch.autograd.Function):
     def forward(ctx, rays_o, rays_d, bkg, table, geo_w, rad_w, pipe, train, noise_std):
         pipe.bind_params({'table': table.detach().view(-1), 'geo_w': geo_w.detach(), 'rad_w': rad_w.detach()})
         noise = pipe.buf['noise'].normal_(0.0, noise_std) if (train and noise_std > 0) else None
-        rgb, depth, mask = pipe.forward(rays_o, rays_d, bkg, train=train, noise=noise)
+        rgb, depth, mask = pipe.forward(rays_o, rays_d, bkg, train=train, noise=noise, presampled=True)
         ctx.pipe, ctx.gen = pipe, pipe.generation
         ctx.save_for_backward(rays_o, rays_d, table, geo_w, rad_w)
         R = rays_o.shape[0]
@@ -88,7 +88,9 @@ class NeRF(FgModel):
                 and isinstance(r.embed_fn_view, SHEmbedder) and not r.embed_fn_view.include_input
                 and self.get_ray_cfgs('near') is None and self.get_ray_cfgs('far') is None)
 
-    def _packed_pipeline(self, device):
+    def _packed_pipeline(self, device, min_samples=0):
+        if self._pipe is not None and self._pipe.cap < min_samples:
+            self._pipe = None   # grow: the buffers are rebuilt at the new capacity
         if self._pipe is None or self._pipe.field.device != device:
             g, r, vol = self.coarse_geo_net, self.coarse_radiance_net, self.obj_bound.volume
             e = g.embed_fn
@@ -112,7 +114,7 @@ class NeRF(FgModel):
             fld.params = fld.grads = torch.zeros(4, device=device)
             fld._seg = {}
             max_rays = int(self.chunk_rays) if self.chunk_rays and self.chunk_rays > 0 else 32768
-            self._pipe = NgpPipeline(fld, max_rays=max_rays, max_samples=max(1 << 20, 2 * max_rays), packed_bits=True)
+            self._pipe = NgpPipeline(fld, max_rays=max_rays, max_samples=max(1 << 20, 2 * max_rays, int(min_samples)), packed_bits=True)
             # the process-wide sampler stream of the native module the bound samples with, like the reference's static generators
             if isinstance(self.obj_bound, BitfieldBound):
                 from ..ops.bitfield_func import bitfield_rng
@@ -126,9 +128,28 @@ class NeRF(FgModel):
             self._pipe.set_bitfield(self.obj_bound.volume.get_voxel_bitfield(flatten=True))
         return self._pipe
 
+    def _sample_packed(self, rays_o, rays_d):
+        """March the rays into the packed buffers and make sure NO sample was dropped: the packed buffers have a fixed capacity and the
+        scan clamps the segments to it, while the reference's dense (R, n_sample) tensors hold every sample (first steps with an
+        all-ones bitfield, 32768-ray inference chunks).  When R * n_sample can exceed the capacity the marcher's own total is read
+        back (one host read, where the reference's FgModel.forward has three) and, if it does not fit, the buffers are rebuilt 1.25x
+        larger than needed and the SAME launch of the sampler's pcg32 stream is repeated."""
+        pipe = self._packed_pipeline(rays_o.device)
+        R = rays_o.shape[0]
+        state = pipe.rng.state
+        pipe.sample(rays_o, rays_d)
+        if R * pipe.cfg.n_sample > pipe.cap:
+            need = int(pipe.buf['counts'][:R].sum())
+            if need > pipe.cap:
+                pipe = self._packed_pipeline(rays_o.device, min_samples=(need * 5 // 4 + 1023) // 1024 * 1024)
+                pipe.rng.set_state(state)
+                pipe.sample(rays_o, rays_d)
+                assert int(pipe.n_dev.item()) == need
+        return pipe
+
     def _forward_packed(self, inputs, inference_only):
         rays_o, rays_d, bkg = inputs['rays_o'].contiguous().float(), inputs['rays_d'].contiguous().float(), inputs['bkg_color']
-        pipe = self._packed_pipeline(rays_o.device)
+        pipe = self._sample_packed(rays_o, rays_d)
         train = torch.is_grad_enabled() and not inference_only
         noise_std = float(self.get_ray_cfgs('noise_std') or 0.0) if not inference_only else 0.0
         g, r = self.coarse_geo_net, self.coarse_radiance_net

@@ -154,6 +154,7 @@ class RayMarchingFn(torch.autograd.Function):
         out = F.ray_marching_fwd(sigma, radiance, zvals, add_inf_z=add_inf_z, white_bkg=white_bkg, alpha=alpha,
                                  bkg_color=bkg_color, noise=noise, want_samples=True, check_order=True)
         ctx.flags = (add_inf_z, white_bkg)
+        ctx.set_materialize_grads(False)
         ctx.has = (sigma is not None, radiance is not None, alpha is not None, bkg_color is not None, noise is not None)
         dummy = zvals.new_zeros(0)
         ctx.save_for_backward(*[t if t is not None else dummy for t in (sigma, radiance, zvals, alpha, bkg_color, noise)])
@@ -169,12 +170,30 @@ class RayMarchingFn(torch.autograd.Function):
         sigma, radiance, zvals, alpha, bkg, noise = [t if h else None for t, h in
                                                      zip(ctx.saved_tensors, (ctx.has[0], ctx.has[1], True, ctx.has[2], ctx.has[3], ctx.has[4]))]
         add_inf_z, white_bkg = ctx.flags
-        if d_w is not None and bool(d_w.abs().sum() != 0):
-            raise NotImplementedError('gradient through per-sample weights is not provided by the fused compositor')
-        d_geo, d_rad = F.ray_marching_bwd(sigma, radiance, zvals, d_rgb.contiguous() if radiance is not None else None,
-                                          d_depth.contiguous(), d_mask.contiguous(), add_inf_z=add_inf_z, white_bkg=white_bkg,
+        R, P = zvals.shape
+        # gradients are NOT materialised (forward sets set_materialize_grads(False)): an output nobody differentiated arrives as None,
+        # so "is there a gradient on the per-sample weights" is a host-side test, no reduction, no device read
+        zr = zvals.new_zeros(R)
+        d_depth = zr if d_depth is None else d_depth.contiguous()
+        d_mask = zr if d_mask is None else d_mask.contiguous()
+        if radiance is not None:
+            d_rgb = zvals.new_zeros((R, 3)) if d_rgb is None else d_rgb.contiguous()
+        else:
+            d_rgb = None
+        d_geo, d_rad = F.ray_marching_bwd(sigma, radiance, zvals, d_rgb, d_depth, d_mask, add_inf_z=add_inf_z, white_bkg=white_bkg,
                                           alpha=alpha, bkg_color=bkg, noise=noise,
                                           d_tlast=None if d_tlast is None else d_tlast.contiguous())
+        if d_w is not None:
+            # weights_i = alpha_i T_i: their gradient is the gradient of sum_i w_i * d_w_i, i.e. of a compositing pass whose "colour" is
+            # d_w (first channel) with d_rgb = (1, 0, 0) and no background term (ray_helper.py:596-620; e.g. the NeuS normal map)
+            Pe = d_w.shape[1]
+            col = zvals.new_zeros((R, P, 3))
+            col[:, :Pe, 0] = d_w
+            e0 = zvals.new_zeros((R, 3))
+            e0[:, 0] = 1.0
+            d_geo_w, _ = F.ray_marching_bwd(sigma, col, zvals, e0, zr, zr, add_inf_z=add_inf_z, white_bkg=False, alpha=alpha,
+                                            bkg_color=None, noise=noise)
+            d_geo = d_geo + d_geo_w
         # with alpha= given, sigma is only recorded (NeuS passes the sdf there, ray_helper.py:550-556): it gets no gradient
         d_sigma = d_geo if (sigma is not None and alpha is None) else None
         return d_sigma, d_rad, None, (d_geo if alpha is not None else None), None, None, None, None

@@ -303,6 +303,10 @@ class Pcg32Host:
     def advance(self, delta=1 << 32):
         N.lib().arcn_pcg32_advance(C.addressof(self._si), delta)
 
+    def set_state(self, state):
+        """rewind / restore (e.g. to repeat a launch with larger buffers)"""
+        self._si[0] = state
+
 
 # ------------------------------------------------------------------------------------------------
 # compacted sampler

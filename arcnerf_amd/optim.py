@@ -45,8 +45,9 @@ class FusedAdam(torch.optim.Optimizer):
                     st['step'] = 0
                     st['exp_avg'] = torch.zeros_like(p)
                     st['exp_avg_sq'] = torch.zeros_like(p)
-                    if self.ema_decay is not None and not self.ema_in_param:
-                        st['ema'] = p.detach().clone()
+                if self.ema_decay is not None and not self.ema_in_param and st.get('ema') is None:
+                    # also after load_state_dict of a checkpoint written by torch.optim.Adam (step / exp_avg / exp_avg_sq only)
+                    st['ema'] = p.detach().clone()
                 st['step'] = int(st['step']) + 1
                 F.adam_ema_step(p, p.grad, st['exp_avg'], st['exp_avg_sq'], p if self.ema_in_param else st.get('ema'), st['step'], lr=group['lr'],
                                 betas=group['betas'], eps=group['eps'], weight_decay=group['weight_decay'],

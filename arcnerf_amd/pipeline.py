@@ -358,6 +358,7 @@ class NgpPipeline:
             assert ng3 % 8 == 0
             w = (2 ** torch.arange(8, device=self.field.device, dtype=torch.int32))
             self._bits = (self.bitfield.view(-1, 8).to(torch.int32) * w).sum(-1).to(torch.uint8).contiguous()
+            self._share_bits_with_aux()
 
     def set_occupancy_bits(self, bits, mode):
         """Hand over an already packed occupancy (uint8, 1 bit per voxel) without conversion: mode 1 = x-major order, mode 2 =
@@ -365,6 +366,15 @@ class NgpPipeline:
         assert bits.dtype == torch.uint8 and bits.is_contiguous() and mode in (1, 2)
         assert bits.numel() * 8 == self.cfg.n_grid ** 3
         self._bits, self.packed_bits = bits, mode
+        self._share_bits_with_aux()
+
+    def _share_bits_with_aux(self):
+        """occupancy bits produced / handed over on the current stream are read by marchers on the sampling stream: order the
+        sampling stream behind their producer and tell the allocator about the second consumer"""
+        aux = getattr(self, 'aux_stream', None)
+        if aux is not None and self._bits is not None and self._bits.is_cuda:
+            aux.wait_stream(torch.cuda.current_stream())
+            self._bits.record_stream(aux)
 
     def _occ(self):
         return self._bits if self.packed_bits else self._bitfield
@@ -402,12 +412,16 @@ class NgpPipeline:
                 self._sets[spare]['noise'].normal_(0.0, self.cfg.noise_std)
             ev = torch.cuda.Event()
             ev.record(self.aux_stream)
-        self._prefetched.append((rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], spare, ev))
+        # the entry keeps the ray tensors alive (their addresses cannot be handed to another batch by the caching allocator) and
+        # remembers their versions (an in-place refill of a staging buffer invalidates the prefetch)
+        self._prefetched.append((rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], spare, ev, rays_o, rays_d,
+                                 rays_o._version, rays_d._version))
 
     def sample(self, rays_o, rays_d):
         """[A] bounds + occupancy marching in packed form (no host sync).  Advances the pcg32 like the reference."""
         key = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0])
-        hit = next((k for k, pf in enumerate(self._prefetched) if pf[:3] == key), None)
+        hit = next((k for k, pf in enumerate(self._prefetched)
+                    if pf[:3] == key and pf[5]._version == pf[7] and pf[6]._version == pf[8]), None)
         if hit is not None:
             pf = self._prefetched.pop(hit)
             del self._prefetched[:hit]   # older entries were skipped by the caller: drop them
@@ -447,14 +461,15 @@ class NgpPipeline:
         if self.ray_sh:
             N.check(L.arcn_ngp_ray_sh(N.ptr(rays_d), cfg.sh_degree, N.ptr(b['sh_ray']), R, st), 'ngp_ray_sh')
 
-    def forward(self, rays_o, rays_d, bkg_color=None, train=False, noise=None, huber_target=None):
+    def forward(self, rays_o, rays_d, bkg_color=None, train=False, noise=None, huber_target=None, presampled=False):
         """Render rays: returns rgb (R,3), depth (R), mask (R) views of the internal buffers.
+        presampled: sample(rays_o, rays_d) has just been called by the caller (e.g. to check the capacity): do not march again.
         huber_target (R,3), training only: compositing, the Huber image loss and the compositor's backward run as ONE kernel; the
         loss lands in self.last_loss and backward() starts at the radiance net."""
         cfg, b, fld = self.cfg, self.buf, self.field
         R = rays_o.shape[0]
         rays_o, rays_d = rays_o.contiguous().float(), rays_d.contiguous().float()
-        n_dev = self.sample(rays_o, rays_d)   # + sample positions / directions, per-ray harmonics
+        n_dev = self.n_dev if presampled else self.sample(rays_o, rays_d)   # + sample positions / directions, per-ray harmonics
         S = self.cap
         L, st = N.lib(), N.stream()
         if noise == 'auto':   # training noise: the prefetched set brings it along, otherwise draw it now

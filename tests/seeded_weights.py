@@ -36,11 +36,11 @@ def check_grad(summary, g, rtol=1e-3, name=''):
     assert np.abs(g2[:4] - summary['head']).max() <= tol, name
     assert np.abs(g2[5::16] - summary['mod16']).max() <= tol, name
     assert abs(float(np.abs(g2).max()) - float(summary['max'])) <= tol, name
-    assert abs(g2.astype(np.float64).sum() - float(summary['sum'])) <= 1e-4 * float(summary['abs']) + 1e-7, name
-    assert abs(np.abs(g2).astype(np.float64).sum() - float(summary['abs'])) <= 1e-4 * float(summary['abs']) + 1e-7, name
+    assert abs(g2.astype(np.float64).sum() - float(summary['sum'])) <= rtol * float(summary['abs']) + 1e-7, name
+    assert abs(np.abs(g2).astype(np.float64).sum() - float(summary['abs'])) <= rtol * float(summary['abs']) + 1e-7, name
     sgn = np.random.default_rng(99).integers(0, 2, size=(3,) + g2.shape, dtype=np.int8).astype(np.float64) * 2 - 1
     proj = np.array([(sgn[i] * g2).sum() for i in range(3)])
-    assert np.abs(proj - summary['proj']).max() <= 1e-4 * float(summary['abs']) + 1e-7, name
+    assert np.abs(proj - summary['proj']).max() <= rtol * float(summary['abs']) + 1e-7, name
 
 
 def state_dict_from_fixture(g, prefix='sd.'):

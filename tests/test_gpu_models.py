@@ -225,6 +225,31 @@ def test_ngp_packed_path_equals_dense_reference_shaped_path(gpu):
     np.testing.assert_array_equal(outs[True]['rgb'][miss], inputs['bkg_color'].cpu().numpy()[miss])
 
 
+def test_packed_path_grows_instead_of_dropping_samples(gpu):
+    """An all-occupied grid and a large chunk ask for more samples than the packed buffers hold (1.6 M > 2^20): the path must notice,
+    grow and repeat the launch - the reference's dense tensors never drop a sample.  Same outputs as the dense path on every ray."""
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    m = _ngp_model(gpu, ['--model.rays.noise_std', '0.0'])
+    fg = m.fg_model
+    fg.obj_bound.volume.update_bitfield(torch.ones(32, 32, 32, dtype=torch.bool, device=gpu), ops='overwrite')
+    inputs = _rays(gpu, 1, 12000)
+    outs = {}
+    for packed in (True, False):
+        fg.use_packed_path = packed
+        sampler_rng(reset=True)
+        with torch.no_grad():
+            o = m({k: v.clone() for k, v in inputs.items()}, inference_only=True)
+        outs[packed] = {k: v.cpu().numpy() for k, v in o.items()}
+    assert fg._pipe.cap > (1 << 20) and int(fg._pipe.n_dev.item()) > (1 << 20)
+    for k in outs[True]:
+        close(outs[True][k], outs[False][k], rtol=1e-5, atol=1e-5)
+    # ... and a training step through the grown buffers still differentiates
+    fg.use_packed_path = True
+    out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False)
+    ((out['rgb_coarse'] - inputs['img']) ** 2).mean().backward()
+    assert float(fg.coarse_geo_net.embed_fn.embeddings.grad.abs().max()) > 0
+
+
 def test_ngp_model_trains_with_torch_adam_and_prunes(gpu):
     m = _ngp_model(gpu)
     fg = m.fg_model

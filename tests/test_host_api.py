@@ -213,3 +213,31 @@ def test_checkpoint_round_trip_in_the_reference_format(tmp_path):
     load_model(logger, m3, None, save_model(None, m, opt, 1, 0.0, str(tmp_path), run, spec_name='final'), dict_to_obj({'dist': {'world_size': 1}}))
     assert any(lv == 'warning' and 'size mismatch' in msg for lv, msg in log)
     assert torch.equal(m3.state_dict()['fg_model.coarse_geo_net.layers.0.weight'], m.state_dict()['fg_model.coarse_geo_net.layers.0.weight'])
+
+
+def test_refresh_cell_subset_is_a_bijection_and_spatially_uniform():
+    """select_refresh_cells draws its n/4 'uniform' cells as the image of range(n/4) under a seeded bijection of the cell range
+    (the reference uses torch.randperm): every cell exactly once over the full range, and the quarter subset spreads over the grid
+    like a uniform draw (octants and x / y / z slabs within 5 sigma of the binomial expectation) for many seeds."""
+    import numpy as np
+    import torch
+    from arcnerf_amd.geometry.volume import mix_permutation
+    n_grid = 32
+    n = n_grid ** 3
+    ar = torch.arange(n)
+    for seed in range(20):
+        rng = np.random.default_rng(seed)
+        full = mix_permutation(ar, n, rng).numpy()
+        assert np.array_equal(np.sort(full), np.arange(n))
+        rng = np.random.default_rng(seed)
+        sub = mix_permutation(ar[:n // 4], n, rng).numpy()
+        assert np.array_equal(sub, full[:n // 4])
+        x, y, z = sub // (n_grid * n_grid), (sub // n_grid) % n_grid, sub % n_grid
+        octant = (x >= n_grid // 2) * 4 + (y >= n_grid // 2) * 2 + (z >= n_grid // 2)
+        cnt = np.bincount(octant, minlength=8)
+        exp, sd = n / 32, np.sqrt(n / 4 * (1 / 8) * (7 / 8))
+        assert np.abs(cnt - exp).max() < 5 * sd, (seed, cnt)
+        for axis in (x, y, z):
+            c = np.bincount(axis, minlength=n_grid)
+            e, s_ = n / 4 / n_grid, np.sqrt(n / 4 / n_grid)
+            assert np.abs(c - e).max() < 5 * s_, (seed, c)

@@ -63,3 +63,26 @@ def test_oracle_step_matches_reference_run(oracle, g21, variant, net):
     tg, nets = G.split_flat_grads(fld, ref['grads'])
     G.check_table_grad(g, pre + 'train1_tgrad_', tg)
     G.check_net_grads(g, variant, net, 'train1', nets)
+
+
+def test_torch_cpu_nerf_matches_reference_full_width():
+    """oracle/torch_cpu_nerf.py (the PyTorch-CPU-eager stand-in for scripts/cpu.sh that bench.py times) against golden G22: the
+    reference's FullModel on configs/models/nerf.yaml at full width - outputs within 1e-4, the loss within 1e-5."""
+    import torch
+    import seeded_weights as SW
+    from conftest import load_golden
+    from oracle.torch_cpu_nerf import TorchCpuNerf
+    g = load_golden('g22_nerf_fullwidth')
+    m = TorchCpuNerf()
+    m.load_reference_state({k: torch.from_numpy(v) for k, v in SW.state_dict_from_fixture(g).items()})
+    o, d = torch.from_numpy(g['in_rays_o'][0]), torch.from_numpy(g['in_rays_d'][0])
+    bkg, img = torch.from_numpy(g['in_bkg_color'][0]), torch.from_numpy(g['in_img'][0])
+    out = m(o, d, bkg, perturb=False, noise_std=0.0)
+    for k, v in out.items():
+        assert np.abs(v.detach().numpy() - g['train_' + k][0]).max() < 1e-4, k
+    loss = ((out['rgb_fine'] - img) ** 2).mean() + ((out['rgb_coarse'] - img) ** 2).mean()
+    assert abs(float(loss) - float(g['train_loss'])) < 1e-5
+    loss.backward()
+    gw = m.coarse.rad[1].weight.grad.numpy()
+    ref = g['grad.fg_model.coarse_radiance_net.layers.1.weight']
+    assert np.abs(gw - ref).max() <= 1e-3 * np.abs(ref).max()
