@@ -598,6 +598,43 @@ __device__ __forceinline__ void emit_record(uint4 *__restrict__ lrecs, float *__
 // integer atomic per bin -> barrier -> stores) and its ~90 VGPRs allow one 1024-thread workgroup per CU.  Staging the
 // records in LDS to write them out bin-sorted (coalesced) was tried and is slower: the extra barrier and scan lengthen
 // exactly that chain (212 us against 140 us).
+// Cell + weights for the scatter producer: the cell index from the reciprocal quotient, re-done with the true division in any wave
+// where a lane's quotient lies within 4e-7 (relative) of an integer (see hashgrid_fwd_bal_kernel: bit-identical cells), the weights
+// through the reciprocal (1 ulp, inside the backward's tolerance, as before).
+__device__ __forceinline__ Cell locate_fastcell(const float p[3], const GridParams &g, const LevelParams &lp, bool in_range) {
+    Cell cell;
+    float nn[3], v[3];
+    bool amb = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        nn[a] = p[a] - g.mn[a];
+        const float q0 = nn[a] * lp.rvs[a];
+        v[a] = q0;
+        const float d = fabsf(q0 - rintf(q0));
+        amb = amb || !(d > 4e-7f * fmaxf(fabsf(q0), 1.0f));
+    }
+    if (__any(amb && in_range)) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) v[a] = nn[a] / lp.vs[a];
+    }
+    bool ok = in_range;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        if (!(v[a] >= 0.f) || !(v[a] < (float)lp.res)) ok = false;
+    cell.valid = ok;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float cf = floorf(v[a]);
+        cell.c[a] = ok ? (uint32_t)cf : 0u;
+        const float st = cf * lp.vs[a];
+        const float g0 = st + g.mn[0];
+        const float ww = (p[a] - g0) * lp.rvs[a];
+        cell.w[a] = ww < 0.0f ? 0.0f : (ww > 1.0f ? 1.0f : ww);
+        cell.dw[a] = 0.f;
+    }
+    return cell;
+}
+
 template <int F, int kBinThreads>
 __global__ void __launch_bounds__(kBinThreads)
 scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout, int64_t dout_lm_stride, GridParams g,
@@ -619,6 +656,19 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
     int buf = 0;
     // Persistent over the level's tiles: a tile keeps a wave busy for ~3 us only, and one workgroup per tile left the chip at
     // ~20 % wave occupancy waiting for the dispatcher (SQ_WAVE_CYCLES / duration); gridDim.x workgroups per level loop instead.
+    // inputs of the NEXT tile are requested before this tile waits for its bin reservations (software pipeline: the loads travel
+    // while the reservation atomics do)
+    float np_[3] = {0.f, 0.f, 0.f}, ng0 = 0.f, ng1 = 0.f;
+    auto fetch = [&](int64_t s) {
+        if (s < cnt) {
+            np_[0] = xyz[3 * s]; np_[1] = xyz[3 * s + 1]; np_[2] = xyz[3 * s + 2];
+            // level-major gradients (dout_lm_stride > 0): the lanes of a wave read consecutive 8-byte words
+            const float *gp = dout_lm_stride ? dout + ((int64_t)l * dout_lm_stride + s) * F : dout + (s * g.L + l) * F;
+            ng0 = gp[0];
+            ng1 = F > 1 ? gp[F > 1 ? 1 : 0] : 0.f;
+        }
+    };
+    fetch((int64_t)blockIdx.x * kBinThreads + t);
     for (int64_t tile0 = (int64_t)blockIdx.x * kBinThreads; tile0 < cnt; tile0 += (int64_t)gridDim.x * kBinThreads, buf ^= 1) {
     uint32_t *hist = hist2[buf], *gbase = gbase2[buf];
     const int64_t s = tile0 + t;
@@ -627,19 +677,9 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
     float swx[8], sa[8], sb[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) sbin[k] = -1;
-    Cell cell;
-    cell.valid = false;
-    float g0 = 0.f, g1 = 0.f;
-    if (s < cnt) {
-        const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
-        cell = locate<true>(p, g, lp);
-        if (cell.valid) {
-            // level-major gradients (dout_lm_stride > 0): the lanes of a wave read consecutive 8-byte words
-            const float *gp = dout_lm_stride ? dout + ((int64_t)l * dout_lm_stride + s) * F : dout + (s * g.L + l) * F;
-            g0 = gp[0];
-            g1 = F > 1 ? gp[F > 1 ? 1 : 0] : 0.f;
-        }
-    }
+    const float p[3] = {np_[0], np_[1], np_[2]};
+    const Cell cell = locate_fastcell(p, g, lp, s < cnt);
+    const float g0 = cell.valid ? ng0 : 0.f, g1 = cell.valid ? ng1 : 0.f;
     // runs of consecutive samples (lanes) in the same cell: head lanes, and for every lane the last lane of its run
     const uint32_t kxy = cell.valid ? (cell.c[0] | (cell.c[1] << 16)) : 0xffffffffu;
     const uint32_t kz = cell.valid ? cell.c[2] : (uint32_t)lane;
@@ -777,6 +817,7 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
     for (int k = 0; k < 8; ++k) rank[k] = (k < n_slots && sbin[k] >= 0) ? atomicAdd(&hist[sbin[k]], 1u) : 0u;
     __syncthreads();
     // reserve the tile's run in every bin: one global integer atomic per (bin, tile); clear the NEXT tile's histogram
+    fetch(tile0 + (int64_t)gridDim.x * kBinThreads + t);
     for (int i = threadIdx.x; i < nc; i += kBinThreads) {
         const uint32_t h = hist[i];
         gbase[i] = h ? atomicAdd(&counters[plan.bin_first[l] + i], h) : 0u;
@@ -1069,8 +1110,10 @@ static int build_bin_plan(const GridParams &g, int64_t n, BinPlan &plan) {
     }();
     static const int chunk_floats = [] {
         const char *e = getenv("ARCN_SCATTER_CHUNK_FLOATS");  // tuning aid; power of two <= 32768
-        int v = e ? atoi(e) : kChunkFloats;
-        return (v >= 1024 && v <= kChunkFloats && !(v & (v - 1))) ? v : kChunkFloats;
+        // 8192-row owner chunks (64 KiB of LDS, two consumer workgroups per CU): 704 owners on 512 slots instead of 352 on 256 -
+        // step 0.680 -> 0.664 ms against the 16384-row chunks, scatter 0.213 -> 0.196 ms per launch (A/B in one session)
+        int v = e ? atoi(e) : 16384;
+        return (v >= 1024 && v <= kChunkFloats && !(v & (v - 1))) ? v : 16384;
     }();
     plan.chunk_floats = chunk_floats;
     { static const int cas = [] { const char *e = getenv("ARCN_SCATTER_CAS"); return e ? atoi(e) : 1; }(); plan.use_cas = cas; }

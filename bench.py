@@ -38,6 +38,9 @@ def parse():
     ap.add_argument('--no-occ-update', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-rays', type=int, default=131072)
+    ap.add_argument('--config', default='ngp', choices=['ngp', 'nerf', 'neus', 'neus_ngp_multivol', 'hdrnerf'],
+                    help='BASELINE.json configs: ngp = config 2 (default, the headline), nerf = 1, neus = 3, neus_ngp_multivol = 4, hdrnerf = 5')
+    ap.add_argument('--rays', type=int, default=0, help='rays per step per GPU for the module-path configs (0 = the config default)')
     return ap.parse_args()
 
 
@@ -102,8 +105,155 @@ def instrument(timers):
     return lib
 
 
+# ---- configs 1 / 3 / 4 / 5: the reference-shaped module path (build_model -> FullModel.forward -> loss -> backward -> Adam) --------
+F32_MFMA_PEAK = 157.3e12   # FLOP/s, v_mfma_f32_* (MI355X_MICROARCH.md): the nets of these configs compute in exact f32
+MODULE_CONFIGS = {
+    # name: yaml, default rays, fg net evaluations per ray and step, fwd FLOP per fg net evaluation (2 x MACs of the linear stacks)
+    'nerf': dict(yaml='nerf.yaml', rays=4096, evals=64 + 64 + 128, flop=2 * (63 * 256 + 3 * 256 * 256 + 319 * 256 + 3 * 256 * 256 + 256 * 257 + 283 * 128 + 128 * 3),
+                 desc='vanilla NeRF, freq encoder, 64+128 samples/ray (coarse 64 + fine 192 net evaluations), 8x256 + 128 nets, Adam'),
+    'hdrnerf': dict(yaml='hdrnerf.yaml', rays=4096, evals=64 + 64 + 128, flop=2 * (63 * 256 + 3 * 256 * 256 + 319 * 256 + 3 * 256 * 256 + 256 * 257 + 283 * 128 + 128 * 3 + 3 * 2 * 128),
+                    desc='HDR-NeRF: nerf nets + three 1->128->1 tone mappers, per-ray exposure, LDR + HDR compositing, Adam'),
+    'neus': dict(yaml='neus.yaml', rays=2048, evals=64 + 64, flop=2 * (39 * 256 + 3 * 256 * 256 + 256 * 217 + 3 * 256 * 256 + 256 * 257 + (3 + 27 + 3 + 256) * 256 + 3 * 256 * 256 + 256 * 3),
+                 desc='NeuS sdf net 8x256 softplus-100 + radiance 4x256, 64+64 samples/ray, 4 up-sampling rounds, normals + Eikonal (double backward), Adam'),
+    'neus_ngp_multivol': dict(yaml='neus_ngp_multivol.yaml', rays=4096, evals=None, flop=None,
+                              desc='NeuS on the hash grid in the pruned volume + MultiVol background (hash grid + fused MLPs), Adam'),
+}
+
+
+def bench_module(args, name):
+    """One training step of the module path per `step`; samples = foreground net evaluations (rays x samples per ray of the final
+    differentiated pass; the hierarchical up-sampling passes of NeuS are extra work inside the step, not counted)."""
+    spec = MODULE_CONFIGS[name]
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count())
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU fallback for the product path)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        from arcnerf_amd import distributed as D
+        D.init_from_env(backend=os.environ.get('ARCN_DIST_BACKEND', 'nccl'), device=dev)
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.optim import FusedAdam
+    from arcnerf_amd.pipeline import synthetic_bitfield, synthetic_rays
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    n_rays = args.rays or spec['rays']
+    torch.manual_seed(0)   # identical initial parameters on every rank
+    m = build_model(load_configs(os.path.join(ROOT, 'configs', spec['yaml']), [])).to(dev)
+    fg = m.fg_model
+    if name == 'neus_ngp_multivol':
+        fg.obj_bound.volume.update_bitfield(torch.from_numpy(synthetic_bitfield(128, args.occupancy, seed=0)).to(dev), ops='overwrite')
+    radius = 2.2 if name == 'neus_ngp_multivol' else (3.0 if name == 'neus' else 4.0)
+    pool = []
+    g = torch.Generator(device='cpu').manual_seed(77 + rank)
+    for i in range(4):
+        o, d = synthetic_rays(n_rays, seed=10 * rank + i, device=dev, radius=radius)
+        inp = {'rays_o': o.view(1, -1, 3), 'rays_d': d.view(1, -1, 3), 'rays_r': torch.zeros(1, n_rays, 1, device=dev),
+               'bkg_color': torch.rand(1, n_rays, 3, generator=g).to(dev), 'img': torch.rand(1, n_rays, 3, generator=g).to(dev)}
+        if name == 'hdrnerf':
+            inp['exp_time'] = (torch.rand(1, n_rays, 1, generator=g) * 4.0 + 0.1).to(dev)
+        pool.append(inp)
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = FusedAdam(params, lr=5e-4, eps=1e-15)
+    flat_numel = sum(p.numel() for p in params)
+
+    def loss_of(out, inp):
+        if name in ('nerf', 'hdrnerf'):
+            l = ((out['rgb_fine'] - inp['img']) ** 2).mean() + ((out['rgb_coarse'] - inp['img']) ** 2).mean()
+            if name == 'hdrnerf':
+                l = l + 0.5 * sum(((out['unit_exp_' + s] - 0.5) ** 2).mean() for s in ('coarse', 'fine'))
+            return l
+        return ((out['rgb'] - inp['img']) ** 2).mean() + 0.1 * ((out['normal_pts'].norm(dim=-1) - 1.0) ** 2).mean()
+
+    n_eval = [0]
+
+    def step(i):
+        inp = pool[i % len(pool)]
+        out = m({k: v for k, v in inp.items()}, inference_only=False, cur_epoch=20000 + i)
+        loss = loss_of(out, inp)
+        opt.zero_grad(set_to_none=False)
+        loss.backward()
+        if world > 1:   # DDP semantics: average of the ranks' gradients, one bucketed all-reduce over the flat list
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            dist.all_reduce(flat)
+            flat.div_(world)
+            off = 0
+            for p in params:
+                p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        opt.step()
+        if spec['evals'] is None and 'normal_pts' in out:
+            n_eval[0] = int(out['normal_pts'].shape[0] * out['normal_pts'].shape[1])
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall = float(tmax.item())
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    evals_per_step = n_rays * spec['evals'] if spec['evals'] else n_eval[0]
+    total = evals_per_step * args.steps * world
+    roofline = None
+    if spec['flop']:
+        # fwd + bwd (dX and dW) = 3x the forward FLOP of the linear stacks; NeuS additionally differentiates the sdf net twice
+        ach = 3.0 * spec['flop'] * evals_per_step / (wall / args.steps)
+        roofline = {'kernel': 'linear stacks of the geometry / radiance nets (hipBLASLt f32 GEMMs + fused MFMA kernels)', 'bound': 'mfma', 'achieved': ach / 1e12,
+                    'peak': F32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s', 'frac': ach / F32_MFMA_PEAK, 'traffic': None,
+                    'note': 'algorithmic FLOP = 3 x forward MACs x 2 per net evaluation; f32 MFMA peak (the nets compute in f32)'}
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline and name == 'nerf':
+        cpu = cpu_baseline_nerf()
+    out = {'metric': 'ray-samples/sec (train)', 'value': total / wall, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
+           'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': '{} ({}), {} rays/step/GPU, {} net evaluations/step/GPU, module path build_model({}) + FusedAdam'.format(
+               name, spec['desc'], n_rays, evals_per_step, spec['yaml']), 'rays_per_step_per_gpu': n_rays,
+               'samples_per_step_per_gpu': evals_per_step, 'n_params': flat_numel, 'parallelism': 'ray-sharded dp{}'.format(world)},
+           'roofline': roofline, 'cpu_baseline': cpu}
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_nerf():
+    """BASELINE.md section 3 for config 1: (a) the PyTorch-CPU-eager restatement of the reference modules (oracle/torch_cpu_nerf.py, the
+    stand-in for scripts/cpu.sh) on all host cores and on one; bounded samples."""
+    from oracle.torch_cpu_nerf import time_train_steps
+    import multiprocessing
+    cores = multiprocessing.cpu_count()
+    legs = []
+    for threads, rays in ((cores, 1024), (1, 32)):
+        n, dt = time_train_steps(rays, steps=1, threads=threads)
+        legs.append({'value': n / dt, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
+                     'sample': 'fwd+bwd+Adam of one config-1 step, {} rays = {} net evaluations, {:.1f} s, PyTorch CPU eager'.format(rays, n, dt)})
+    best = dict(legs[0])
+    best['threads_1'] = legs[1]
+    return best
+
+
 def main():
     args = parse()
+    if args.config != 'ngp':
+        return bench_module(args, args.config)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count())

@@ -1,0 +1,108 @@
+"""Pipeline-level data parallelism on the GPU: two ranks (gloo over 127.0.0.1, both on cuda:0 - the RCCL path needs
+several GPUs and is the driver's to run) each run `NgpPipeline.train_step` on their shard of the rays, with the flat gradient
+all-reduce and with the 4-segment pipelined sync, and must end with the parameters a single process gets when it accumulates the two
+shards' gradients itself and applies the optimiser with grad_scale 1/world - the averaging semantics of the reference's DDP
+(common/trainer/basic_trainer.py:197-198)."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+N_RAYS, STEPS = 1536, 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup(dev):
+    from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline, synthetic_bitfield, synthetic_rays
+    cfg = NgpConfig(n_levels=8, hashmap_size=15, max_res=512, n_grid=64, n_sample=512, noise_std=0.0, lr=1e-2)
+    fld = NgpField(cfg, device=dev, seed=3)
+    fld.view('table').mul_(1000.0)
+    pipe = NgpPipeline(fld, max_rays=2048, max_samples=1 << 17)
+    pipe.set_bitfield(torch.from_numpy(synthetic_bitfield(cfg.n_grid, 0.1, seed=5)))
+    batches = []
+    g = torch.Generator().manual_seed(11)
+    for i in range(STEPS):
+        o, d = synthetic_rays(N_RAYS, seed=40 + i, device=dev)
+        batches.append((o, d, torch.rand(N_RAYS, 3, generator=g).to(dev), torch.rand(N_RAYS, 3, generator=g).to(dev)))
+    return cfg, fld, pipe, batches
+
+
+def _worker(rank, world, port, mode, path):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from arcnerf_amd import distributed as D
+    D.init_from_env(backend='gloo')
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    cfg, fld, pipe, batches = _setup(dev)
+    D.broadcast_params(fld.params, src=0)
+    sync = D.PipelinedGradSync(fld.n_params, 4) if mode == 'pipelined' else None
+    for o, d, tgt, bkg in batches:
+        lo, hi = D.shard_range(N_RAYS, rank, world)
+        pipe.rng.set_state(_rank_rng_state(pipe, rank))
+        if sync is not None:
+            pipe.train_step(o[lo:hi].contiguous(), d[lo:hi].contiguous(), tgt[lo:hi].contiguous(), bkg_color=bkg[lo:hi].contiguous(),
+                            world_size=world, grad_sync=sync)
+        else:
+            pipe.train_step(o[lo:hi].contiguous(), d[lo:hi].contiguous(), tgt[lo:hi].contiguous(), bkg_color=bkg[lo:hi].contiguous(),
+                            all_reduce=lambda t: D.allreduce_grads(t, world), world_size=world)
+    torch.cuda.synchronize()
+    np.save(path + '.rank{}.npy'.format(rank), fld.params.cpu().numpy())
+    torch.distributed.destroy_process_group()
+
+
+def _rank_rng_state(pipe, rank):
+    """every rank marches with its own pcg32 stream (rank-local RNG like the reference): seed 9121 + rank, restarted per step so that
+    the single-process replay below can reproduce it"""
+    from arcnerf_amd.ops import functional as F
+    return F.Pcg32Host(9121 + rank).state
+
+
+@pytest.mark.parametrize('mode', ['flat', 'pipelined'])
+def test_two_ranks_train_like_one_process_accumulating_both_shards(mode):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    world = 2
+    ctx = mp.get_context('spawn')
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'params')
+        procs = [ctx.Process(target=_worker, args=(r, world, port, mode, path)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        got = [np.load(path + '.rank{}.npy'.format(r)) for r in range(world)]
+    assert np.array_equal(got[0], got[1])           # replicas stay identical
+    # single-process replay: both shards' gradients accumulated into the flat buffer, one optimiser pass with grad_scale 1/world
+    from arcnerf_amd import distributed as D
+    dev = torch.device('cuda:0')
+    cfg, fld, pipe, batches = _setup(dev)
+    p0 = fld.params.cpu().numpy().copy()
+    for o, d, tgt, bkg in batches:
+        fld.grads.zero_()
+        for rank in range(world):
+            lo, hi = D.shard_range(N_RAYS, rank, world)
+            pipe.rng.set_state(_rank_rng_state(pipe, rank))
+            oo, dd = o[lo:hi].contiguous(), d[lo:hi].contiguous()
+            rgb, _, _ = pipe.forward(oo, dd, bkg[lo:hi].contiguous(), train=True)
+            _, d_rgb = pipe.huber_grad(rgb, tgt[lo:hi].contiguous())
+            pipe.backward(oo, dd, d_rgb)
+        pipe.optimizer_step(world)
+    torch.cuda.synchronize()
+    ref = fld.params.cpu().numpy()
+    moved = np.abs(ref - p0).max()
+    assert moved > 1e-3                              # the steps did something
+    assert np.abs(got[0] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()) + 1e-4 * moved, np.abs(got[0] - ref).max()

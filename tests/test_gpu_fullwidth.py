@@ -98,7 +98,10 @@ def test_neus_full_width(gpu):
     loss = ((out['rgb'] - inputs['img']) ** 2).mean() + 0.1 * eik
     assert abs(float(eik) - float(g['train_eikonal'])) < 1e-5 and abs(float(loss) - float(g['train_loss'])) < 1e-5
     loss.backward()
-    checked, seeded = _check_grads(m, g, 1e-3, loose=('geo_net.layers.0.weight_v', 'geo_net.layers.5.weight_v'))
+    # one of the 40 rays has an up-sampled position on the other side of a near-tie of the inverse CDF (tools/diag_neus_fullwidth.py:
+    # every gradient agrees to <= 1.3e-4 of its max except the two matrices that multiply the 2^9-frequency position embedding, which
+    # feel that single sample: 0.9e-2 and 1.2e-2)
+    checked, seeded = _check_grads(m, g, 1e-3, loose=('geo_net.layers.0.weight_v', 'geo_net.layers.5.weight_v'), loose_rtol=2e-2)
     assert checked >= 20 and seeded >= 12 and 'grad.fg_model.inv_s' in g.files
 
 
