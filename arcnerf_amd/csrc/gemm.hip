@@ -1,0 +1,450 @@
+// Dense layers of the wide nets on gfx950 matrix cores: the three products a torch.nn.Linear needs in forward, backward and
+// double backward, hand-written with the exact f32 MFMA (v_mfma_f32_16x16x4_f32), for a HUGE row count S (samples, 10^5..10^6) and
+// small feature dimensions (3..320).
+//
+// Replaces the library GEMMs under GeoNet / RadianceNet (arcnerf/models/base_modules/geo_rad_model/linear_network_module.py:174-197,
+// 318-335: nn.Linear / DenseLayer stacks, 8 x 256 with a skip concat for NeRF / NeuS / HDR-NeRF, 32 -> 64 -> 17 for NeuS on the hash
+// grid) and their autograd:
+//   arcn_gemm_nt   Y (S,N)  = X (S,K) . W(N,K)^T (+ bias)          forward of a layer
+//   arcn_gemm_nn   dX (S,K) = dY (S,N) . W (N,K)                   input gradient
+//   arcn_gemm_tn   dW (N,K) = dY (S,N)^T . X (S,K)                 weight gradient: a reduction over ALL samples
+// The three are closed under differentiation (each one's gradients are the other two), which is what NeuS needs: its normals are
+// d sdf / d x taken with create_graph=True and the Eikonal loss differentiates them again (base_network.py:30-44).
+//
+// Why not the library: the weight gradient of a 64 x 32 or 17 x 64 layer over 3e5 samples is a (tiny x tiny) output with an enormous
+// reduction; hipBLASLt runs it without splitting the reduction (MT64x32x128 / MT32x32x256 tiles: 0.94 / 1.46 ms per call, 6.7 ms of a
+// 17 ms NeuS-NGP step).  arcn_gemm_tn cuts the samples into slabs, one workgroup per (slab, output tile), partial sums to a scratch
+// buffer, and a second kernel adds the slabs in a fixed order (deterministic, no float atomics).
+//
+// Orientation (as in mlp.hip): MFMA rows = output features, MFMA columns = samples (nt / nn) or input features (tn); with the K order
+// k = 16 t + 4 g + ks a lane's four consecutive reduction elements are one 16-byte LDS read that feeds four MFMAs.  Operand tiles are
+// staged through LDS in that fragment order, double buffered, 32 reduction elements per stage (128 B per row: whole cache lines).
+#include "common.hpp"
+
+namespace arcn {
+
+typedef float gf4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float gemm_act(float v, int act, float beta) {
+    switch (act) {
+    case ARCN_ACT_RELU: return v > 0.f ? v : 0.f;
+    case ARCN_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    case ARCN_ACT_SOFTPLUS: { const float bv = beta * v; return bv > 20.f ? v : log1pf(expf(bv)) / beta; }
+    default: return v;
+    }
+}
+
+// four consecutive elements of row `row` starting at column `col` of a row-major matrix (ld floats per row), zero outside
+// [0, rows) x [0, cols); one 16-byte load when the matrix allows it
+template <bool ALIGNED>
+__device__ __forceinline__ gf4 load_row4(const float *__restrict__ p, int64_t row, int col, int64_t ld, int64_t rows, int cols, bool aligned) {
+    gf4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ALIGNED) {
+        // every row 16-byte aligned, cols a multiple of 4.  Branch-free and select-free: an out-of-range lane reads element (0, 0); the
+        // caller zeroes it when the value is USED (stash), so nothing waits for the load before the MFMA block of the current stage
+        const bool ok = row < rows && col < cols;
+        return *reinterpret_cast<const gf4 *>(p + (ok ? row * ld + col : 0));
+    }
+    if (row >= rows || col >= cols) return v;
+    const float *src = p + row * ld + col;
+    if (aligned && col + 3 < cols) return *reinterpret_cast<const gf4 *>(src);
+    v.x = src[0];
+    if (col + 1 < cols) v.y = src[1];
+    if (col + 2 < cols) v.z = src[2];
+    if (col + 3 < cols) v.w = src[3];
+    return v;
+}
+
+// ---- out (S, No) = in (S, Ki) . M,  M[ki][no] = TRANS_W ? W[ki][no] (W row-major (Ki, No)) : W[no][ki] (W row-major (No, Ki)) --------
+// 256 threads = 4 waves laid out WAVES_N (outputs) x 4 / WAVES_N (samples); a wave owns MT output tiles x NT sample tiles of 16 x 16.
+template <int MT, int NT, int WAVES_N, bool TRANS_W, bool ALIGNED>
+__global__ void __launch_bounds__(256)
+gemm_rows_kernel(const float *__restrict__ in, int64_t ld_in, const float *__restrict__ W, int ld_w, const float *__restrict__ bias,
+                 float *__restrict__ out, int64_t ld_out, int64_t S, const int32_t *n_ptr, int Ki, int No, int act, float beta,
+                 int in_aligned, int w_aligned, int out_aligned) {
+    constexpr int WAVES_M = 4 / WAVES_N;
+    constexpr int BN = 16 * MT * WAVES_N, BM = 16 * NT * WAVES_M, BK = 32;
+    __shared__ __attribute__((aligned(16))) float Ws[2][BN * BK];
+    __shared__ __attribute__((aligned(16))) float Xs[2][BM * BK];
+    const int64_t cnt = dev_count(S, n_ptr);
+    const int64_t s_base = (int64_t)blockIdx.x * BM;
+    if (s_base >= cnt) return;
+    const int n_base = blockIdx.y * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_n = wave % WAVES_N, wave_m = wave / WAVES_N;
+    constexpr int XQ = BM * 8 / 256;           // float4 per thread of the sample tile
+    constexpr int WQ = (BN * 8 + 255) / 256;   // ... of the weight tile (a 16-output tile has only 128 of them)
+    constexpr int WF = BN * 8;
+    gf4 xr[XQ], wr[WQ];
+    uint32_t okx = 0u, okw = 0u;   // ALIGNED: which of the staged loads were in range (applied in stash)
+    const int n_chunks = (Ki + BK - 1) / BK;
+
+    auto fetch = [&](int c) {
+        const int k0 = c * BK;
+        okx = 0u;
+        okw = 0u;
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int f = tid + 256 * q, sl = f >> 3, kq = f & 7;
+            xr[q] = load_row4<ALIGNED>(in, s_base + sl, k0 + 4 * kq, ld_in, cnt, Ki, in_aligned);
+            okx |= (uint32_t)((s_base + sl < cnt) && (k0 + 4 * kq < Ki)) << q;
+        }
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int f = tid + 256 * q;
+            if (f >= WF) continue;
+            if (!TRANS_W) {
+                const int nl = f >> 3, kq = f & 7;
+                wr[q] = load_row4<ALIGNED>(W, n_base + nl, k0 + 4 * kq, ld_w, No, Ki, w_aligned);
+                okw |= (uint32_t)((n_base + nl < No) && (k0 + 4 * kq < Ki)) << q;
+            } else {
+                const int kk = f / (BN / 4), nq = f % (BN / 4);   // four consecutive OUTPUTS of reduction row k0 + kk
+                wr[q] = load_row4<ALIGNED>(W, k0 + kk, n_base + 4 * nq, ld_w, Ki, No, w_aligned);
+                okw |= (uint32_t)((k0 + kk < Ki) && (n_base + 4 * nq < No)) << q;
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+        if (ALIGNED) {
+            const gf4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < XQ; ++q) xr[q] = ((okx >> q) & 1u) ? xr[q] : zero;
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) wr[q] = ((okw >> q) & 1u) ? wr[q] : zero;
+        }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int f = tid + 256 * q, sl = f >> 3, kq = f & 7;
+            const int t = kq >> 2, g = kq & 3;
+            // slot of row j XOR-swizzled with (4 t + g): the 8 lanes that hold one row's 128 bytes land in 8 different bank groups,
+            // and the fragment reads below (16 consecutive rows of one (t, g)) stay conflict-free
+            *reinterpret_cast<gf4 *>(&Xs[buf][(((sl >> 4) * 2 + t) * 64 + g * 16 + ((sl & 15) ^ (4 * t + g))) * 4]) = xr[q];
+        }
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int f = tid + 256 * q;
+            if (f >= WF) continue;
+            if (!TRANS_W) {
+                const int nl = f >> 3, kq = f & 7;
+                const int t = kq >> 2, g = kq & 3;
+                *reinterpret_cast<gf4 *>(&Ws[buf][(((nl >> 4) * 2 + t) * 64 + g * 16 + ((nl & 15) ^ (4 * t + g))) * 4]) = wr[q];
+            } else {
+                const int kk = f / (BN / 4), nq = f % (BN / 4);
+                const int t = kk >> 4, g = (kk & 15) >> 2, ks = kk & 3;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nl = 4 * nq + r;
+                    Ws[buf][(((nl >> 4) * 2 + t) * 64 + g * 16 + ((nl & 15) ^ (4 * t + g))) * 4 + ks] = wr[q][r];
+                }
+            }
+        }
+    };
+
+    gf4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = gf4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) fetch(c + 1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            gf4 a[MT], b[NT];
+            const int sw = (lane & 48) + ((lane & 15) ^ (4 * t + (lane >> 4)));   // swizzled slot of lane (g, i)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const gf4 *>(&Ws[buf][(((wave_n * MT + m) * 2 + t) * 64 + sw) * 4]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const gf4 *>(&Xs[buf][(((wave_m * NT + n) * 2 + t) * 64 + sw) * 4]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][ks], b[n][ks], acc[m][n], 0, 0, 0);
+        }
+        if (c + 1 < n_chunks) {
+            stash(buf ^ 1);     // the other buffer was last read two iterations ago (behind the barrier below)
+            __syncthreads();
+        }
+    }
+    // lane (g, j): outputs 16 mt + 4 g + 0..3 of sample 16 nt + j
+    const int g = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int no = n_base + (wave_n * MT + m) * 16 + 4 * g;
+        if (no >= No) continue;
+        gf4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            bv.x = bias[no];
+            if (no + 1 < No) bv.y = bias[no + 1];
+            if (no + 2 < No) bv.z = bias[no + 2];
+            if (no + 3 < No) bv.w = bias[no + 3];
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int64_t s = s_base + (wave_m * NT + n) * 16 + j;
+            if (s >= cnt) continue;
+            gf4 v = acc[m][n] + bv;
+            if (act != ARCN_ACT_NONE) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gemm_act(v[r], act, beta);
+            }
+            float *dst = out + s * ld_out + no;
+            if (out_aligned && no + 3 < No) *reinterpret_cast<gf4 *>(dst) = v;
+            else {
+                dst[0] = v.x;
+                if (no + 1 < No) dst[1] = v.y;
+                if (no + 2 < No) dst[2] = v.z;
+                if (no + 3 < No) dst[3] = v.w;
+            }
+        }
+    }
+}
+
+// ---- partial (slab, N, K) = sum over the slab's samples of A (S,N)^T . B (S,K) ------------------------------------------------------
+// waves 2 x 2; a wave owns MT row tiles (features of A) x NT column tiles (features of B)
+template <int MT, int NT, bool ALIGNED>
+__global__ void __launch_bounds__(256)
+gemm_tn_kernel(const float *__restrict__ A, int64_t ld_a, const float *__restrict__ B, int64_t ld_b, float *__restrict__ scratch,
+               int64_t S, const int32_t *n_ptr, int N, int K, int n_slabs, int a_aligned, int b_aligned) {
+    constexpr int BN = 32 * MT, BKo = 32 * NT, BS = 32;
+    __shared__ __attribute__((aligned(16))) float As[2][BN * BS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BKo * BS];
+    const int64_t cnt = dev_count(S, n_ptr);
+    const int slab = blockIdx.x;
+    const int tiles_k = (K + BKo - 1) / BKo;
+    const int tn = blockIdx.y / tiles_k, tk = blockIdx.y % tiles_k;
+    const int n_base = tn * BN, k_base = tk * BKo;
+    // slabs are multiples of 32 samples
+    const int64_t per = ((cnt + n_slabs - 1) / n_slabs + BS - 1) / BS * BS;
+    const int64_t s_lo = (int64_t)slab * per, s_hi = (s_lo + per < cnt) ? s_lo + per : cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_n = wave & 1, wave_k = wave >> 1;
+    constexpr int AQ = BN * 8 / 256, BQ = BKo * 8 / 256;   // float4 per thread per stage (32 samples x BN / 4)
+    gf4 ar[AQ], br[BQ];
+    uint32_t oka = 0u, okb = 0u;
+    gf4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = gf4{0.f, 0.f, 0.f, 0.f};
+    const int64_t n_chunks = s_lo < s_hi ? (s_hi - s_lo + BS - 1) / BS : 0;
+
+    auto fetch = [&](int64_t c) {
+        const int64_t s0 = s_lo + c * BS;
+        oka = 0u;
+        okb = 0u;
+#pragma unroll
+        for (int q = 0; q < AQ; ++q) {
+            const int f = tid + 256 * q, sl = f / (BN / 4), nq = f % (BN / 4);
+            ar[q] = load_row4<ALIGNED>(A, s0 + sl, n_base + 4 * nq, ld_a, s_hi, N, a_aligned);
+            oka |= (uint32_t)((s0 + sl < s_hi) && (n_base + 4 * nq < N)) << q;
+        }
+#pragma unroll
+        for (int q = 0; q < BQ; ++q) {
+            const int f = tid + 256 * q, sl = f / (BKo / 4), kq = f % (BKo / 4);
+            br[q] = load_row4<ALIGNED>(B, s0 + sl, k_base + 4 * kq, ld_b, s_hi, K, b_aligned);
+            okb |= (uint32_t)((s0 + sl < s_hi) && (k_base + 4 * kq < K)) << q;
+        }
+    };
+    // fragment order [feature tile][t][g][feature in tile][ks] with sample = 16 t + 4 g + ks: a lane's 16-byte read = 4 samples
+    auto stash = [&](int buf) {
+        if (ALIGNED) {
+            const gf4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < AQ; ++q) ar[q] = ((oka >> q) & 1u) ? ar[q] : zero;
+#pragma unroll
+            for (int q = 0; q < BQ; ++q) br[q] = ((okb >> q) & 1u) ? br[q] : zero;
+        }
+#pragma unroll
+        for (int q = 0; q < AQ; ++q) {
+            const int f = tid + 256 * q, sl = f / (BN / 4), nq = f % (BN / 4);
+            const int t = sl >> 4, g = (sl & 15) >> 2, ks = sl & 3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nl = 4 * nq + r;
+                As[buf][(((nl >> 4) * 2 + t) * 64 + g * 16 + (nl & 15)) * 4 + ks] = ar[q][r];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < BQ; ++q) {
+            const int f = tid + 256 * q, sl = f / (BKo / 4), kq = f % (BKo / 4);
+            const int t = sl >> 4, g = (sl & 15) >> 2, ks = sl & 3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kl = 4 * kq + r;
+                Bs[buf][(((kl >> 4) * 2 + t) * 64 + g * 16 + (kl & 15)) * 4 + ks] = br[q][r];
+            }
+        }
+    };
+    if (n_chunks > 0) {
+        fetch(0);
+        stash(0);
+    }
+    __syncthreads();
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        const int buf = (int)(c & 1);
+        if (c + 1 < n_chunks) fetch(c + 1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            gf4 a[MT], b[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const gf4 *>(&As[buf][(((wave_n * MT + m) * 2 + t) * 64 + lane) * 4]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const gf4 *>(&Bs[buf][(((wave_k * NT + n) * 2 + t) * 64 + lane) * 4]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][ks], b[n][ks], acc[m][n], 0, 0, 0);
+        }
+        if (c + 1 < n_chunks) {
+            stash(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // lane (g, j): rows n = 16 mt + 4 g + r, column k = 16 nt + j
+    const int g = lane >> 4, j = lane & 15;
+    float *dst = scratch + (int64_t)slab * N * K;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int k = k_base + (wave_k * NT + n) * 16 + j;
+            if (k >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = n_base + (wave_n * MT + m) * 16 + 4 * g + r;
+                if (row < N) dst[(int64_t)row * K + k] = acc[m][n][r];
+            }
+        }
+}
+
+// out[i] (+)= sum over slabs in a fixed order: 4 lanes per element take the slabs k = lane, lane + 4, ... with 4 independent
+// accumulators each (16 loads in flight per element instead of one dependent chain), combined in a fixed tree
+__global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(const float *__restrict__ scratch, float *__restrict__ out, int64_t n_elem,
+                                                             int n_slabs, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;   // 0..3
+    __shared__ float red[4][64];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < n_elem) {
+        int k = part;
+        for (; k + 12 < n_slabs; k += 16) {
+            a0 += scratch[(int64_t)k * n_elem + i];
+            a1 += scratch[(int64_t)(k + 4) * n_elem + i];
+            a2 += scratch[(int64_t)(k + 8) * n_elem + i];
+            a3 += scratch[(int64_t)(k + 12) * n_elem + i];
+        }
+        for (; k < n_slabs; k += 4) a0 += scratch[(int64_t)k * n_elem + i];
+    }
+    red[part][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (part == 0 && i < n_elem) {
+        const int j = threadIdx.x & 63;
+        const float s = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+        out[i] = accumulate ? out[i] + s : s;
+    }
+}
+
+static inline int is_aligned(const void *p, int64_t ld) { return ((reinterpret_cast<uintptr_t>(p) & 15u) == 0 && (ld & 3) == 0) ? 1 : 0; }
+
+static int tn_slabs(int64_t S, int N, int K, int bn, int bk) {
+    const int64_t tiles = (int64_t)((N + bn - 1) / bn) * ((K + bk - 1) / bk);
+    int64_t slabs = 1024 / (tiles > 0 ? tiles : 1);
+    if (slabs > 256) slabs = 256;                // the slab partials are summed by a second kernel: keep that sum short
+    const int64_t max_slabs = (S + 255) / 256;   // at least 256 samples per slab
+    if (slabs > max_slabs) slabs = max_slabs;
+    if (slabs < 1) slabs = 1;
+    if (slabs > 1024) slabs = 1024;
+    return (int)slabs;
+}
+
+}  // namespace arcn
+
+using namespace arcn;
+
+static int gemm_rows(bool trans_w, const float *in, int64_t ld_in, const float *W, int ld_w, const float *bias, float *out, int64_t ld_out,
+                     int64_t S, const int32_t *n_ptr, int Ki, int No, int act, float beta, void *stream) {
+    if (S <= 0) return ARCN_OK;
+    if (!in || !W || !out || Ki < 1 || No < 1) return einval("gemm: missing / invalid argument");
+    const int ia = is_aligned(in, ld_in), wa = is_aligned(W, ld_w), oa = is_aligned(out, ld_out);
+    // the branch-free 16-byte loads need both operands aligned and both of THEIR column counts multiples of 4
+    const bool all_al = ia && wa && (Ki & 3) == 0 && (!trans_w || (No & 3) == 0);
+#define ARCN_ROWS(MT_, NT_, WN_)                                                                                                      \
+    do {                                                                                                                              \
+        constexpr int BN_ = 16 * MT_ * WN_, BM_ = 16 * NT_ * (4 / WN_);                                                               \
+        dim3 grid((unsigned)ceil_div<int64_t>(S, BM_), (unsigned)ceil_div<int>(No, BN_));                                            \
+        if (trans_w && all_al)                                                                                                        \
+            hipLaunchKernelGGL((gemm_rows_kernel<MT_, NT_, WN_, true, true>), grid, dim3(256), 0, as_stream(stream), in, ld_in, W,    \
+                               ld_w, bias, out, ld_out, S, n_ptr, Ki, No, act, beta, ia, wa, oa);                                     \
+        else if (trans_w)                                                                                                             \
+            hipLaunchKernelGGL((gemm_rows_kernel<MT_, NT_, WN_, true, false>), grid, dim3(256), 0, as_stream(stream), in, ld_in, W,   \
+                               ld_w, bias, out, ld_out, S, n_ptr, Ki, No, act, beta, ia, wa, oa);                                     \
+        else if (all_al)                                                                                                              \
+            hipLaunchKernelGGL((gemm_rows_kernel<MT_, NT_, WN_, false, true>), grid, dim3(256), 0, as_stream(stream), in, ld_in, W,   \
+                               ld_w, bias, out, ld_out, S, n_ptr, Ki, No, act, beta, ia, wa, oa);                                     \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((gemm_rows_kernel<MT_, NT_, WN_, false, false>), grid, dim3(256), 0, as_stream(stream), in, ld_in, W,  \
+                               ld_w, bias, out, ld_out, S, n_ptr, Ki, No, act, beta, ia, wa, oa);                                     \
+    } while (0)
+    if (No > 64) ARCN_ROWS(4, 4, 2);        // 128 outputs x 128 samples per workgroup
+    else if (No > 32) ARCN_ROWS(4, 2, 1);   // 64 outputs x 128 samples
+    else if (No > 16) ARCN_ROWS(2, 2, 1);   // 32 outputs x 128 samples
+    else ARCN_ROWS(1, 2, 1);                // 16 outputs x 128 samples
+#undef ARCN_ROWS
+    return check_launch("gemm_rows");
+}
+
+/* Y (S,N) = act(X (S,K) . W (N,K)^T + bias): nn.Linear / DenseLayer forward (linear_network_module.py:174-197, linear.py). */
+ARCN_EXPORT int arcn_gemm_nt(const float *x, int64_t ld_x, const float *w, const float *bias, float *y, int64_t ld_y, int64_t n_rows,
+                             const int32_t *n_ptr, int K, int N, int act, float beta, void *stream) {
+    return gemm_rows(false, x, ld_x, w, K, bias, y, ld_y, n_rows, n_ptr, K, N, act, beta, stream);
+}
+
+/* dX (S,K) = dY (S,N) . W (N,K): input gradient of the layer. */
+ARCN_EXPORT int arcn_gemm_nn(const float *dy, int64_t ld_dy, const float *w, float *dx, int64_t ld_dx, int64_t n_rows, const int32_t *n_ptr,
+                             int N, int K, void *stream) {
+    return gemm_rows(true, dy, ld_dy, w, K, nullptr, dx, ld_dx, n_rows, n_ptr, N, K, ARCN_ACT_NONE, 1.0f, stream);
+}
+
+ARCN_EXPORT int64_t arcn_gemm_tn_scratch_floats(int64_t n_rows, int N, int K) {
+    const bool small = (N <= 64 && K <= 64);
+    const int slabs = small ? tn_slabs(n_rows, N, K, 64, 64) : tn_slabs(n_rows, N, K, 128, 128);
+    return (int64_t)slabs * N * K;
+}
+
+/* dW (N,K) (+)= dY (S,N)^T . X (S,K): weight gradient, reduced over all rows in a fixed order (slab partials in `scratch`, at least
+ * arcn_gemm_tn_scratch_floats(n_rows, N, K) floats). */
+ARCN_EXPORT int arcn_gemm_tn(const float *dy, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *scratch, int64_t scratch_floats,
+                             int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate, void *stream) {
+    if (!dy || !x || !dw || !scratch || N < 1 || K < 1) return einval("gemm_tn: missing / invalid argument");
+    if (scratch_floats < arcn_gemm_tn_scratch_floats(n_rows, N, K)) return einval("gemm_tn: scratch smaller than arcn_gemm_tn_scratch_floats");
+    const int aa = is_aligned(dy, ld_dy), ba = is_aligned(x, ld_x);
+    const bool al = aa && ba && (N & 3) == 0 && (K & 3) == 0;
+    const bool small = (N <= 64 && K <= 64);
+    int slabs;
+    if (n_rows <= 0) {
+        slabs = 0;
+    } else if (small) {
+        slabs = tn_slabs(n_rows, N, K, 64, 64);
+        dim3 grid((unsigned)slabs, (unsigned)(ceil_div<int>(N, 64) * ceil_div<int>(K, 64)));
+        if (al) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, true>), grid, dim3(256), 0, as_stream(stream), dy, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, aa, ba);
+        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, false>), grid, dim3(256), 0, as_stream(stream), dy, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, aa, ba);
+    } else {
+        slabs = tn_slabs(n_rows, N, K, 128, 128);
+        dim3 grid((unsigned)slabs, (unsigned)(ceil_div<int>(N, 128) * ceil_div<int>(K, 128)));
+        if (al) hipLaunchKernelGGL((gemm_tn_kernel<4, 4, true>), grid, dim3(256), 0, as_stream(stream), dy, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, aa, ba);
+        else hipLaunchKernelGGL((gemm_tn_kernel<4, 4, false>), grid, dim3(256), 0, as_stream(stream), dy, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, aa, ba);
+    }
+    const int64_t n_elem = (int64_t)N * K;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ceil_div<int64_t>(n_elem, 64)), dim3(256), 0, as_stream(stream), scratch, dw,
+                       n_elem, slabs, accumulate);
+    return check_launch("gemm_tn");
+}

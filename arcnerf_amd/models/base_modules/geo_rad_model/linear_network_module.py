@@ -1,6 +1,7 @@
 """GeoNet / RadianceNet: nn.Linear stacks with skip concatenation and geometric initialisation
-(arcnerf/models/base_modules/geo_rad_model/linear_network_module.py:16-335).  These are plain library GEMMs through
-torch; parameter names (`layers.{i}.weight/bias`, `embed_fn...`) match the reference's state_dict."""
+(arcnerf/models/base_modules/geo_rad_model/linear_network_module.py:16-335).  Every layer's product, its gradients and (NeuS) their
+gradients run on the hand-written f32-MFMA kernels of csrc/gemm.hip (base_modules/linear.py); parameter names
+(`layers.{i}.weight/bias`, `embed_fn...`) match the reference's state_dict."""
 import math
 import os
 
@@ -11,7 +12,7 @@ import torch.nn as nn
 from ....utils.cfgs_utils import dict_to_obj
 from ....utils.registry import MODULE_REGISTRY
 from ..activation import get_activation
-from ..linear import DenseLayer, SirenLayer
+from ..linear import DenseLayer, Linear, SirenLayer
 from .encoder_mlp_network import EncoderMLPGeoNet, EncoderMLPRadainceNet
 
 
@@ -38,7 +39,7 @@ class GeoNet(EncoderMLPGeoNet):
             else:
                 out_dim = W
             if i == D:
-                layer = nn.Linear(in_dim, out_dim, bias=use_bias)
+                layer = Linear(in_dim, out_dim, bias=use_bias)
             elif use_siren:
                 layer = SirenLayer(in_dim, out_dim, is_first=(i == 0), bias=use_bias)
             else:

@@ -1,5 +1,6 @@
-"""DenseLayer / SirenLayer (arcnerf/models/base_modules/linear.py:11-71): nn.Linear + activation.  Plain library GEMMs
-(rocBLAS/hipBLASLt through torch) — used by the wide vanilla-NeRF stacks; the small NGP nets run on the fused kernel."""
+"""DenseLayer / SirenLayer (arcnerf/models/base_modules/linear.py:11-71): nn.Linear + activation.  Same parameters and state_dict
+keys as torch.nn.Linear; on fp32 CUDA tensors the product, its gradients and their gradients run on the hand-written f32-MFMA kernels
+of csrc/gemm.hip (ops.autograd.linear), the activation stays a torch module (differentiable to any order)."""
 import math
 
 import torch
@@ -8,7 +9,15 @@ import torch.nn as nn
 from .activation import Sine
 
 
-class DenseLayer(nn.Linear):
+class Linear(nn.Linear):
+    """torch.nn.Linear whose forward runs ops.autograd.linear (the last layer of GeoNet, the tone mappers of HDR-NeRF)"""
+
+    def forward(self, x):
+        from ...ops.autograd import linear
+        return linear(x, self.weight, self.bias)
+
+
+class DenseLayer(Linear):
     def __init__(self, input_dim, out_dim, activation=None, bias=True):
         super().__init__(input_dim, out_dim, bias=bias)
         self.activation = activation if activation is not None else nn.ReLU(inplace=True)
@@ -17,7 +26,7 @@ class DenseLayer(nn.Linear):
         return self.activation(super().forward(x))
 
 
-class SirenLayer(nn.Linear):
+class SirenLayer(Linear):
     def __init__(self, input_dim, out_dim, is_first=False, bias=True):
         self.is_first, self.input_dim, self.w0, self.c = is_first, input_dim, 30, 6
         super().__init__(input_dim, out_dim, bias=bias)

@@ -241,3 +241,86 @@ class SdfToAlphaFn(torch.autograd.Function):
         d_sdf, d_slope, d_s = F.sdf_to_alpha_bwd(mid_sdf, zvals, mid_slope, s_t, d_alpha.contiguous(), clip=ctx.clip)
         d_s = d_s.reshape(s_t.shape) if (ctx.s_is_tensor and ctx.needs_input_grad[3]) else None
         return d_sdf, None, d_slope, d_s, None
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# nn.Linear on the hand-written f32-MFMA products (csrc/gemm.hip).  The three products are each other's gradients, so the graph is
+# differentiable to any order: NeuS takes d sdf / d x with create_graph=True and differentiates the Eikonal loss through it again
+# (base_network.py:30-44), which needs the double backward of every layer of the sdf net.
+# ------------------------------------------------------------------------------------------------------------------------------------
+class GemmNT(torch.autograd.Function):
+    """y (S,N) = x (S,K) @ w (N,K).T [+ bias]"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return F.gemm_nt(x, w, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        dx = GemmNN.apply(g, w) if ctx.needs_input_grad[0] else None
+        dw = GemmTN.apply(g, x) if ctx.needs_input_grad[1] else None
+        db = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+class GemmNN(torch.autograd.Function):
+    """dx (S,K) = dy (S,N) @ w (N,K)"""
+
+    @staticmethod
+    def forward(ctx, dy, w):
+        ctx.save_for_backward(dy, w)
+        return F.gemm_nn(dy, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        dy, w = ctx.saved_tensors
+        g = g.contiguous()
+        d_dy = GemmNT.apply(g, w, None) if ctx.needs_input_grad[0] else None
+        d_w = GemmTN.apply(dy, g) if ctx.needs_input_grad[1] else None
+        return d_dy, d_w
+
+
+class GemmTN(torch.autograd.Function):
+    """dw (N,K) = a (S,N).T @ b (S,K)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return F.gemm_tn(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        d_a = GemmNT.apply(b, g, None) if ctx.needs_input_grad[0] else None
+        d_b = GemmNN.apply(a, g) if ctx.needs_input_grad[1] else None
+        return d_a, d_b
+
+
+def linear(x, weight, bias=None):
+    """torch.nn.functional.linear for fp32 CUDA tensors on the MFMA products; anything else (CPU tensors of the host-side tests, other
+    dtypes) goes to torch.  ARCN_LINEAR_GEMM=0 routes everything to torch (A/B against the library GEMMs)."""
+    import os
+    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32) or os.environ.get('ARCN_LINEAR_GEMM', '1') == '0':
+        return torch.nn.functional.linear(x, weight, bias)
+    shp = x.shape
+    x2 = x.reshape(-1, shp[-1])
+    if x2.shape[0] == 0:
+        return torch.nn.functional.linear(x, weight, bias)
+    # the kernels move 16 bytes per lane when every row starts 16-byte aligned: feature dimensions that are not multiples of 4
+    # (63, 319, 283 inputs; 257, 17, 3 outputs) are zero-padded - the weight / bias pads are tiny, the input pad is one copy, and the
+    # padded OUTPUT is sliced outside the autograd node so that its gradient arrives padded (aligned) as well
+    n_out, k_in = weight.shape
+    kp, npad = (-k_in) % 4, (-n_out) % 4
+    pad = torch.nn.functional.pad
+    w = pad(weight, (0, kp, 0, npad)) if (kp or npad) else weight
+    b = pad(bias, (0, npad)) if (bias is not None and npad) else bias
+    x2 = pad(x2, (0, kp)) if kp else x2.contiguous()
+    y = GemmNT.apply(x2, w.contiguous(), b)
+    if npad:
+        y = y[:, :n_out]
+    return y.reshape(*shp[:-1], n_out)

@@ -532,6 +532,47 @@ def mlp_fwd(x, weights, biases, desc, save_acts=False, n_dev=None, out=None, act
     return (out, acts) if save_acts else out
 
 
+# ------------------------------------------------------------------------------------------------
+# dense layers of the wide nets: the three f32-MFMA products of csrc/gemm.hip
+# ------------------------------------------------------------------------------------------------
+def gemm_nt(x, w, bias=None, act=None, beta=1.0):
+    """y (S,N) = act(x (S,K) @ w (N,K).T + bias)"""
+    _req(x, w, bias)
+    x, w, bias = _f32(x), _f32(w), _f32(bias)
+    S, K = x.shape
+    Nn = w.shape[0]
+    assert w.shape[1] == K
+    y = torch.empty((S, Nn), dtype=torch.float32, device=x.device)
+    N.check(N.lib().arcn_gemm_nt(N.ptr(x), K, N.ptr(w), N.ptr(bias), N.ptr(y), Nn, S, None, K, Nn, N.ACT[act], float(beta), N.stream()), 'gemm_nt')
+    return y
+
+
+def gemm_nn(dy, w):
+    """dx (S,K) = dy (S,N) @ w (N,K)"""
+    _req(dy, w)
+    dy, w = _f32(dy), _f32(w)
+    S, Nn = dy.shape
+    K = w.shape[1]
+    assert w.shape[0] == Nn
+    dx = torch.empty((S, K), dtype=torch.float32, device=dy.device)
+    N.check(N.lib().arcn_gemm_nn(N.ptr(dy), Nn, N.ptr(w), N.ptr(dx), K, S, None, Nn, K, N.stream()), 'gemm_nn')
+    return dx
+
+
+def gemm_tn(dy, x):
+    """dw (N,K) = dy (S,N).T @ x (S,K), reduced over the rows in a fixed order"""
+    _req(dy, x)
+    dy, x = _f32(dy), _f32(x)
+    S, Nn = dy.shape
+    K = x.shape[1]
+    assert x.shape[0] == S
+    dw = torch.empty((Nn, K), dtype=torch.float32, device=dy.device)
+    nf = max(1, int(N.lib().arcn_gemm_tn_scratch_floats(S, Nn, K)))
+    scratch = torch.empty(nf, dtype=torch.float32, device=dy.device)
+    N.check(N.lib().arcn_gemm_tn(N.ptr(dy), Nn, N.ptr(x), K, N.ptr(dw), N.ptr(scratch), nf, S, None, Nn, K, 0, N.stream()), 'gemm_tn')
+    return dw
+
+
 def mlp_bwd(x, weights, biases, desc, out, acts, dout, want_dx=True, n_dev=None, dweights=None, dbiases=None, scratch=None):
     _req(x, weights, out, dout)
     x, dout = _f32(x), _f32(dout)

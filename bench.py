@@ -168,6 +168,18 @@ def bench_module(args, name):
         return ((out['rgb'] - inp['img']) ** 2).mean() + 0.1 * ((out['normal_pts'].norm(dim=-1) - 1.0) ** 2).mean()
 
     n_eval = [0]
+    valid_acc, valid_calls = torch.zeros(1, device=dev), [0]
+    if spec['evals'] is None:
+        # pruned volume: count the valid foreground samples where the model itself measures them (FgModel.adjust_dynamicbs_factor is
+        # called with the sample mask of every net evaluation pass, fg_model.py:100-115); accumulated on the device, read once
+        orig_adjust = fg.adjust_dynamicbs_factor
+
+        def counting_adjust(mask_pts=None, n_valid=None):
+            if mask_pts is not None or n_valid is not None:
+                valid_acc.add_((mask_pts.sum() if n_valid is None else n_valid).float())
+                valid_calls[0] += 1
+            return orig_adjust(mask_pts, n_valid)
+        fg.adjust_dynamicbs_factor = counting_adjust
 
     def step(i):
         inp = pool[i % len(pool)]
@@ -184,13 +196,13 @@ def bench_module(args, name):
                 p.grad.copy_(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
         opt.step()
-        if spec['evals'] is None and 'normal_pts' in out:
-            n_eval[0] = int(out['normal_pts'].shape[0] * out['normal_pts'].shape[1])
         return loss
 
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    valid_acc.zero_()
+    valid_calls[0] = 0
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -202,6 +214,8 @@ def bench_module(args, name):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if spec['evals'] is None:
+        n_eval[0] = int(float(valid_acc.item()) / max(1, args.steps)) if valid_calls[0] else n_rays
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -241,7 +255,16 @@ def cpu_baseline_nerf():
     import multiprocessing
     cores = multiprocessing.cpu_count()
     legs = []
-    for threads, rays in ((cores, 1024), (1, 32)):
+    # eager PyTorch on this many-core host is fastest well below the hardware thread count (small GEMMs): the 'all cores' leg is the
+    # best of a few thread counts on a bounded sample
+    best_t, best_v = None, 0.0
+    for threads in sorted({cores, max(1, cores // 2), 64, 32}):
+        if threads > cores:
+            continue
+        n, dt = time_train_steps(128, steps=1, threads=threads)
+        if n / dt > best_v:
+            best_t, best_v = threads, n / dt
+    for threads, rays in ((best_t, 1024), (1, 32)):
         n, dt = time_train_steps(rays, steps=1, threads=threads)
         legs.append({'value': n / dt, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
                      'sample': 'fwd+bwd+Adam of one config-1 step, {} rays = {} net evaluations, {:.1f} s, PyTorch CPU eager'.format(rays, n, dt)})
@@ -326,14 +349,18 @@ def main():
         dist.barrier()
     timers.reset(ROOFLINE_KERNELS)
     torch.cuda.synchronize()
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    step_events[0].record()
     for i in range(args.steps):
         run(args.warmup + i, epoch0 + args.warmup + i)
+        step_events[i + 1].record()   # per-step spread (the driver's default K makes a 40 ms timed region)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_step = sorted(step_events[i].elapsed_time(step_events[i + 1]) for i in range(args.steps))
 
     samples = sample_log[args.warmup:args.warmup + args.steps].sum()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -395,7 +422,10 @@ def main():
         tot_pts = s_per_launch * args.steps + occ_pts * occ_launch
         ach = BYTES_HASH_FWD * tot_pts / (dur_s * n_launch[dom])
     roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                'frac': ach / HBM_PEAK, 'traffic': traffic, 'avg_launch_ms': ksum[dom]}
+                'frac': ach / HBM_PEAK, 'traffic': traffic, 'avg_launch_ms': ksum[dom],
+                # PMC counters cannot be collected inside a timed run: the figure is the per-launch HBM bytes of the committed
+                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/profile_round.sh)
+                'traffic_source': 'profiles/pmc_traffic.json' if traffic is not None else None}
 
     # The hash LOOKUP on its own (north_star names it): besides the algorithmic HBM accounting, the bound this gather actually
     # sits on.  Every 8-byte corner read of a hashed level drags one 128-byte line from the XCD's L2 into the CU's L1
@@ -432,6 +462,9 @@ def main():
                                    n_rays, s_per_launch, args.occupancy, ' (off)' if args.no_occ_update else ''),
                    'rays_per_step_per_gpu': n_rays, 'samples_per_step_per_gpu': s_per_launch,
                    'parallelism': 'ray-sharded dp{}'.format(world)},
+        'timed_region_ms': wall * 1e3,
+        'step_ms_spread': {'min': per_step[0], 'p50': per_step[len(per_step) // 2], 'p90': per_step[min(len(per_step) - 1, int(0.9 * len(per_step)))],
+                           'max': per_step[-1]},
         'roofline': roofline,
         'roofline_lookup': lookup,
         'cpu_baseline': cpu,
@@ -444,22 +477,30 @@ def main():
 
 def cpu_baseline(cfg, field, bf, n_rays):
     """The CPU oracle (C restatement of the reference path, OpenMP) timed on the host cores on a bounded sample of the
-    same workload: fwd + bwd of one training step for `n_rays` rays (about 10-30 s of CPU work)."""
+    same workload: fwd + bwd of one NGP training step, on all host cores (about 10-20 s of CPU work) and on ONE thread (a smaller
+    sample); BASELINE.md section 3."""
     from oracle import oracle as orc
     from oracle.ngp_reference import oracle_train_step
     from arcnerf_amd.pipeline import synthetic_rays
     orc.build()
     cores = orc.get_max_threads()
     P = field.export_numpy()
-    o, d = synthetic_rays(n_rays, seed=4242, device='cpu')
-    o, d = o.numpy(), d.numpy()
-    rng = orc.Pcg32(9121)
-    t0 = time.perf_counter()
-    n = oracle_train_step(orc, field, cfg, P, o, d, bf, rng.state, rng.inc)
-    dt = time.perf_counter() - t0
-    return {'value': n / dt, 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
-            'sample': 'fwd+bwd of one NGP training step for {} rays = {} valid samples ({:.1f} s), C oracle with OpenMP '
-                      '(hash-grid scatter serial)'.format(n_rays, n, dt)}
+    legs = []
+    for threads, rays in ((cores, n_rays), (1, max(256, n_rays // 64))):
+        orc.set_num_threads(threads)
+        o, d = synthetic_rays(rays, seed=4242, device='cpu')
+        o, d = o.numpy(), d.numpy()
+        rng = orc.Pcg32(9121)
+        t0 = time.perf_counter()
+        n = oracle_train_step(orc, field, cfg, P, o, d, bf, rng.state, rng.inc)
+        dt = time.perf_counter() - t0
+        legs.append({'value': n / dt, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
+                     'sample': 'fwd+bwd of one NGP training step for {} rays = {} valid samples ({:.1f} s), C oracle with OpenMP '
+                               '(numpy glue between the kernels; hash-grid scatter parallel over levels x row slices)'.format(rays, n, dt)})
+    orc.set_num_threads(cores)
+    out = dict(legs[0])
+    out['threads_1'] = legs[1]
+    return out
 
 
 if __name__ == '__main__':

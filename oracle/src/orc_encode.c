@@ -1,5 +1,8 @@
 /* ORACLE (test infrastructure only) — encoders of the path.  See orc_common.h. */
 #include "orc_common.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 static const int PERM[8][3] = {{0,0,0},{0,1,0},{1,0,0},{1,1,0},{0,0,1},{0,1,1},{1,0,1},{1,1,1}};
 
@@ -74,11 +77,49 @@ ORC_API void orc_hashgrid_fwd(const float *xyz, int64_t S, const float *table, i
  * Hash-grid backward: dtable (n_total,F) += scatter(dout * w); dxyz (S,3) optional.
  * dxyz follows autograd through w = clip((p-g0)/vs,0,1): d w/d p = 1/vs inside (0,1), else 0.
  * (torch.clip passes gradient where min <= x <= max, boundaries included.)
- * Serial scatter => deterministic summation order (sample-major).
+ * Deterministic summation order (sample-major per table row) for any thread count.
  * ------------------------------------------------------------------------------------- */
 ORC_API void orc_hashgrid_bwd(const float *xyz, int64_t S, const float *table, const float *dout, int L, int F,
                               const int32_t *resolutions, const int64_t *offsets, const float *min_xyz,
                               const float *max_xyz, float *dtable, float *dxyz) {
+    /* The table scatter runs as L x n_slices independent tasks: task (l, k) walks ALL samples of level l in order and applies the
+     * updates whose row falls into its k-th slice of the level's rows.  Rows of different tasks are disjoint and every row still
+     * receives its contributions in sample-major order, so the result is bit-identical to the serial loop for any thread count
+     * (the price: the cell / hash arithmetic of a level is repeated n_slices times). */
+    if (dtable) {
+        int nthreads = 1;
+#ifdef _OPENMP
+        nthreads = omp_get_max_threads();
+#endif
+        int n_slices = nthreads / (L > 0 ? L : 1);
+        if (n_slices < 1) n_slices = 1;
+        if (n_slices > 16) n_slices = 16;
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int task = 0; task < L * n_slices; ++task) {
+            const int l = task / n_slices, k = task % n_slices;
+            const int64_t size = offsets[l + 1] - offsets[l];
+            const int64_t lo = size * k / n_slices, hi = size * (k + 1) / n_slices;
+            for (int64_t s = 0; s < S; ++s) {
+                const float *p = xyz + 3 * s;
+                int64_t c[3];
+                float w[3], vs[3], dw[3];
+                if (!level_setup(p, min_xyz, max_xyz, resolutions[l], c, w, vs, dw)) continue;
+                const float *g = dout + s * (int64_t)(L * F) + l * F;
+                for (int q = 0; q < 8; ++q) {
+                    const int64_t r = fast_hash3(c[0] + PERM[q][0], c[1] + PERM[q][1], c[2] + PERM[q][2], size);
+                    if (r < lo || r >= hi) continue;
+                    const int64_t h = r + offsets[l];
+                    float wx = PERM[q][0] ? w[0] : 1.0f - w[0];
+                    float wy = PERM[q][1] ? w[1] : 1.0f - w[1];
+                    float wz = PERM[q][2] ? w[2] : 1.0f - w[2];
+                    float wt = (wx * wy) * wz;
+                    for (int f = 0; f < F; ++f) dtable[h * F + f] += g[f] * wt;
+                }
+            }
+        }
+    }
+    if (!dxyz) return;
+#pragma omp parallel for schedule(static)
     for (int64_t s = 0; s < S; ++s) {
         const float *p = xyz + 3 * s;
         float gx[3] = {0.f, 0.f, 0.f};
@@ -93,21 +134,15 @@ ORC_API void orc_hashgrid_bwd(const float *xyz, int64_t S, const float *table, c
                 float wx = PERM[q][0] ? w[0] : 1.0f - w[0];
                 float wy = PERM[q][1] ? w[1] : 1.0f - w[1];
                 float wz = PERM[q][2] ? w[2] : 1.0f - w[2];
-                float wt = (wx * wy) * wz;
                 float dot = 0.f;
-                for (int f = 0; f < F; ++f) {
-                    if (dtable) dtable[h * F + f] += g[f] * wt;
-                    dot += g[f] * table[h * F + f];
-                }
-                if (dxyz) {
-                    float sx = PERM[q][0] ? 1.0f : -1.0f, sy = PERM[q][1] ? 1.0f : -1.0f, sz = PERM[q][2] ? 1.0f : -1.0f;
-                    gx[0] += dot * sx * wy * wz * dw[0];
-                    gx[1] += dot * wx * sy * wz * dw[1];
-                    gx[2] += dot * wx * wy * sz * dw[2];
-                }
+                for (int f = 0; f < F; ++f) dot += g[f] * table[h * F + f];
+                float sx = PERM[q][0] ? 1.0f : -1.0f, sy = PERM[q][1] ? 1.0f : -1.0f, sz = PERM[q][2] ? 1.0f : -1.0f;
+                gx[0] += dot * sx * wy * wz * dw[0];
+                gx[1] += dot * wx * sy * wz * dw[1];
+                gx[2] += dot * wx * wy * sz * dw[2];
             }
         }
-        if (dxyz) for (int k = 0; k < 3; ++k) dxyz[3 * s + k] = gx[k];
+        for (int k = 0; k < 3; ++k) dxyz[3 * s + k] = gx[k];
     }
 }
 

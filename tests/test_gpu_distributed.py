@@ -48,6 +48,13 @@ def _worker(rank, world, port, mode, path):
     cfg, fld, pipe, batches = _setup(dev)
     D.broadcast_params(fld.params, src=0)
     sync = D.PipelinedGradSync(fld.n_params, 4) if mode == 'pipelined' else None
+    reduced = []
+
+    def flat_all_reduce(t):
+        D.allreduce_grads(t, world)
+        if not reduced:
+            reduced.append(t.clone())     # the summed gradient of the first step, as the optimiser sees it
+
     for o, d, tgt, bkg in batches:
         lo, hi = D.shard_range(N_RAYS, rank, world)
         pipe.rng.set_state(_rank_rng_state(pipe, rank))
@@ -56,9 +63,11 @@ def _worker(rank, world, port, mode, path):
                             world_size=world, grad_sync=sync)
         else:
             pipe.train_step(o[lo:hi].contiguous(), d[lo:hi].contiguous(), tgt[lo:hi].contiguous(), bkg_color=bkg[lo:hi].contiguous(),
-                            all_reduce=lambda t: D.allreduce_grads(t, world), world_size=world)
+                            all_reduce=flat_all_reduce, world_size=world)
     torch.cuda.synchronize()
     np.save(path + '.rank{}.npy'.format(rank), fld.params.cpu().numpy())
+    if reduced and rank == 0:
+        np.save(path + '.grad0.npy', reduced[0].cpu().numpy())
     torch.distributed.destroy_process_group()
 
 
@@ -85,13 +94,14 @@ def test_two_ranks_train_like_one_process_accumulating_both_shards(mode):
             p.join(300)
         assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
         got = [np.load(path + '.rank{}.npy'.format(r)) for r in range(world)]
+        grad0 = np.load(path + '.grad0.npy') if mode == 'flat' else None
     assert np.array_equal(got[0], got[1])           # replicas stay identical
     # single-process replay: both shards' gradients accumulated into the flat buffer, one optimiser pass with grad_scale 1/world
     from arcnerf_amd import distributed as D
     dev = torch.device('cuda:0')
     cfg, fld, pipe, batches = _setup(dev)
     p0 = fld.params.cpu().numpy().copy()
-    for o, d, tgt, bkg in batches:
+    for step, (o, d, tgt, bkg) in enumerate(batches):
         fld.grads.zero_()
         for rank in range(world):
             lo, hi = D.shard_range(N_RAYS, rank, world)
@@ -100,9 +110,16 @@ def test_two_ranks_train_like_one_process_accumulating_both_shards(mode):
             rgb, _, _ = pipe.forward(oo, dd, bkg[lo:hi].contiguous(), train=True)
             _, d_rgb = pipe.huber_grad(rgb, tgt[lo:hi].contiguous())
             pipe.backward(oo, dd, d_rgb)
+        if step == 0 and grad0 is not None:
+            # the collective is a SUM of the ranks' gradients (the 1/world of DDP's average is the optimiser's grad_scale): checked on
+            # the gradient itself, because Adam's update is nearly invariant to a wrong scale
+            ref_g = fld.grads.cpu().numpy()
+            assert np.abs(grad0 - ref_g).max() <= 1e-5 * np.abs(ref_g).max()
         pipe.optimizer_step(world)
     torch.cuda.synchronize()
     ref = fld.params.cpu().numpy()
     moved = np.abs(ref - p0).max()
     assert moved > 1e-3                              # the steps did something
-    assert np.abs(got[0] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()) + 1e-4 * moved, np.abs(got[0] - ref).max()
+    # Adam (eps 1e-15) turns the summation-order noise of near-zero gradient entries into full-size steps of either sign: parameters
+    # agree to a fraction of a percent of the distance they travelled, not bit for bit
+    assert np.abs(got[0] - ref).max() <= 1e-2 * moved, (np.abs(got[0] - ref).max(), moved)

@@ -967,3 +967,62 @@ def test_ray_marching_weights_gradient_vs_torch(add_inf_z):
     sigma.grad = None
     (torch_ref(sigma, rad)[3] ** 2).sum().backward()
     assert (g1 - sigma.grad).abs().max() <= 1e-4 * sigma.grad.abs().max() + 1e-6
+
+
+GEMM_SHAPES = [(5000, 63, 256), (1001, 319, 256), (777, 256, 257), (4096, 283, 128), (3000, 128, 3), (2500, 32, 64), (2500, 64, 17),
+               (130, 1, 128), (64, 128, 1), (9, 39, 217)]
+
+
+@pytest.mark.parametrize('S,K,Nn', GEMM_SHAPES)
+def test_gemm_products_vs_float64(S, K, Nn):
+    """arcn_gemm_nt / nn / tn (csrc/gemm.hip: the dense layers of GeoNet / RadianceNet, linear_network_module.py:174-197,318-335) against
+    float64 matmuls: exact f32 MFMA accumulation, so only summation-order noise."""
+    from arcnerf_amd.ops import functional as Fn
+    g = torch.Generator().manual_seed(S + K + Nn)
+    x = torch.randn(S, K, generator=g).cuda()
+    w = (torch.randn(Nn, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(Nn, generator=g).cuda()
+    dy = torch.randn(S, Nn, generator=g).cuda()
+    y = Fn.gemm_nt(x, w, b)
+    ref = (x.double() @ w.double().t() + b.double())
+    assert (y.double() - ref).abs().max() <= 2e-6 * max(1.0, ref.abs().max().item())
+    yr = Fn.gemm_nt(x, w, None, act='relu')
+    assert (yr.double() - torch.relu(x.double() @ w.double().t())).abs().max() <= 2e-6 * max(1.0, ref.abs().max().item())
+    dx = Fn.gemm_nn(dy, w)
+    refx = dy.double() @ w.double()
+    assert (dx.double() - refx).abs().max() <= 2e-6 * max(1.0, refx.abs().max().item())
+    dw = Fn.gemm_tn(dy, x)
+    refw = dy.double().t() @ x.double()
+    assert (dw.double() - refw).abs().max() <= 2e-6 * max(1.0, refw.abs().max().item()) * max(1.0, (S / 1000.0) ** 0.5)
+    assert torch.equal(dw, Fn.gemm_tn(dy, x))      # fixed reduction order: bit-reproducible
+
+
+def test_linear_layers_double_backward_vs_torch():
+    """a 3-layer softplus(100) net with a skip concat on ops.autograd.linear: outputs, d out / d x (create_graph), and the gradients of a
+    loss on BOTH (the NeuS pattern: rgb loss + Eikonal on the normals) against the same net on torch.nn.functional.linear."""
+    from arcnerf_amd.ops.autograd import linear
+    g = torch.Generator().manual_seed(5)
+    S = 3000
+    x0 = torch.randn(S, 39, generator=g).cuda()
+    Ws = [(torch.randn(o, i, generator=g) / i ** 0.5).cuda().requires_grad_(True) for o, i in ((256, 39), (217, 256), (65, 256))]
+    bs = [(torch.randn(o, generator=g) * 0.1).cuda().requires_grad_(True) for o in (256, 217, 65)]
+
+    def net(x, lin):
+        h = torch.nn.functional.softplus(lin(x, Ws[0], bs[0]), beta=100)
+        h = torch.nn.functional.softplus(lin(h, Ws[1], bs[1]), beta=100)
+        h = torch.cat([h, x], -1) / 2 ** 0.5
+        return lin(h, Ws[2], bs[2])
+
+    res = {}
+    for name, lin in (('hip', linear), ('torch', torch.nn.functional.linear)):
+        x = x0.clone().requires_grad_(True)
+        out = net(x, lin)
+        sdf = out[:, :1]
+        nrm = torch.autograd.grad(sdf, x, torch.ones_like(sdf), create_graph=True)[0]
+        loss = (out[:, 1:] ** 2).mean() + 0.1 * ((nrm[:, :3].norm(dim=-1) - 1.0) ** 2).mean()
+        for p in Ws + bs:
+            p.grad = None
+        loss.backward()
+        res[name] = [out.detach(), nrm.detach(), x.grad.clone()] + [p.grad.clone() for p in Ws + bs]
+    for a, b_ in zip(res['hip'], res['torch']):
+        assert (a - b_).abs().max() <= 2e-4 * b_.abs().max() + 1e-7
