@@ -57,9 +57,9 @@ __device__ __forceinline__ gf4 load_row4(const float *__restrict__ p, int64_t ro
 
 // ---- out (S, No) = in (S, Ki) . M,  M[ki][no] = TRANS_W ? W[ki][no] (W row-major (Ki, No)) : W[no][ki] (W row-major (No, Ki)) --------
 // 256 threads = 4 waves laid out WAVES_N (outputs) x 4 / WAVES_N (samples); a wave owns MT output tiles x NT sample tiles of 16 x 16.
-template <int MT, int NT, int WAVES_N, bool TRANS_W, bool ALIGNED>
+template <int MT, int NT, int WAVES_N, bool TRANS_W, bool ALIGNED, bool MASK>
 __global__ void __launch_bounds__(256)
-gemm_rows_kernel(const float *__restrict__ in, int64_t ld_in, const float *__restrict__ W, int ld_w, const float *__restrict__ bias,
+gemm_rows_kernel(const float *__restrict__ in, const float *__restrict__ mask, int64_t ld_in, const float *__restrict__ W, int ld_w, const float *__restrict__ bias,
                  float *__restrict__ out, int64_t ld_out, int64_t S, const int32_t *n_ptr, int Ki, int No, int act, float beta,
                  int in_aligned, int w_aligned, int out_aligned) {
     constexpr int WAVES_M = 4 / WAVES_N;
@@ -76,6 +76,7 @@ gemm_rows_kernel(const float *__restrict__ in, int64_t ld_in, const float *__res
     constexpr int WQ = (BN * 8 + 255) / 256;   // ... of the weight tile (a 16-output tile has only 128 of them)
     constexpr int WF = BN * 8;
     gf4 xr[XQ], wr[WQ];
+    gf4 mr[MASK ? XQ : 1];         // MASK: `in` is multiplied by (mask > 0) on the way in (ReLU backward: dpre = dy * (y > 0))
     uint32_t okx = 0u, okw = 0u;   // ALIGNED: which of the staged loads were in range (applied in stash)
     const int n_chunks = (Ki + BK - 1) / BK;
 
@@ -87,6 +88,7 @@ gemm_rows_kernel(const float *__restrict__ in, int64_t ld_in, const float *__res
         for (int q = 0; q < XQ; ++q) {
             const int f = tid + 256 * q, sl = f >> 3, kq = f & 7;
             xr[q] = load_row4<ALIGNED>(in, s_base + sl, k0 + 4 * kq, ld_in, cnt, Ki, in_aligned);
+            if (MASK) mr[q] = load_row4<ALIGNED>(mask, s_base + sl, k0 + 4 * kq, ld_in, cnt, Ki, in_aligned);
             okx |= (uint32_t)((s_base + sl < cnt) && (k0 + 4 * kq < Ki)) << q;
         }
 #pragma unroll
@@ -111,6 +113,12 @@ gemm_rows_kernel(const float *__restrict__ in, int64_t ld_in, const float *__res
             for (int q = 0; q < XQ; ++q) xr[q] = ((okx >> q) & 1u) ? xr[q] : zero;
 #pragma unroll
             for (int q = 0; q < WQ; ++q) wr[q] = ((okw >> q) & 1u) ? wr[q] : zero;
+        }
+        if (MASK) {
+#pragma unroll
+            for (int q = 0; q < XQ; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xr[q][r] = mr[q][r] > 0.f ? xr[q][r] : 0.f;
         }
 #pragma unroll
         for (int q = 0; q < XQ; ++q) {
@@ -208,9 +216,9 @@ gemm_rows_kernel(const float *__restrict__ in, int64_t ld_in, const float *__res
 
 // ---- partial (slab, N, K) = sum over the slab's samples of A (S,N)^T . B (S,K) ------------------------------------------------------
 // waves 2 x 2; a wave owns MT row tiles (features of A) x NT column tiles (features of B)
-template <int MT, int NT, bool ALIGNED>
+template <int MT, int NT, bool ALIGNED, bool MASK>
 __global__ void __launch_bounds__(256)
-gemm_tn_kernel(const float *__restrict__ A, int64_t ld_a, const float *__restrict__ B, int64_t ld_b, float *__restrict__ scratch,
+gemm_tn_kernel(const float *__restrict__ A, const float *__restrict__ mask, int64_t ld_a, const float *__restrict__ B, int64_t ld_b, float *__restrict__ scratch,
                int64_t S, const int32_t *n_ptr, int N, int K, int n_slabs, int a_aligned, int b_aligned) {
     constexpr int BN = 32 * MT, BKo = 32 * NT, BS = 32;
     __shared__ __attribute__((aligned(16))) float As[2][BN * BS];
@@ -227,6 +235,7 @@ gemm_tn_kernel(const float *__restrict__ A, int64_t ld_a, const float *__restric
     const int wave_n = wave & 1, wave_k = wave >> 1;
     constexpr int AQ = BN * 8 / 256, BQ = BKo * 8 / 256;   // float4 per thread per stage (32 samples x BN / 4)
     gf4 ar[AQ], br[BQ];
+    gf4 mr[MASK ? AQ : 1];
     uint32_t oka = 0u, okb = 0u;
     gf4 acc[MT][NT];
 #pragma unroll
@@ -243,6 +252,7 @@ gemm_tn_kernel(const float *__restrict__ A, int64_t ld_a, const float *__restric
         for (int q = 0; q < AQ; ++q) {
             const int f = tid + 256 * q, sl = f / (BN / 4), nq = f % (BN / 4);
             ar[q] = load_row4<ALIGNED>(A, s0 + sl, n_base + 4 * nq, ld_a, s_hi, N, a_aligned);
+            if (MASK) mr[q] = load_row4<ALIGNED>(mask, s0 + sl, n_base + 4 * nq, ld_a, s_hi, N, a_aligned);
             oka |= (uint32_t)((s0 + sl < s_hi) && (n_base + 4 * nq < N)) << q;
         }
 #pragma unroll
@@ -260,6 +270,12 @@ gemm_tn_kernel(const float *__restrict__ A, int64_t ld_a, const float *__restric
             for (int q = 0; q < AQ; ++q) ar[q] = ((oka >> q) & 1u) ? ar[q] : zero;
 #pragma unroll
             for (int q = 0; q < BQ; ++q) br[q] = ((okb >> q) & 1u) ? br[q] : zero;
+        }
+        if (MASK) {
+#pragma unroll
+            for (int q = 0; q < AQ; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ar[q][r] = mr[q][r] > 0.f ? ar[q][r] : 0.f;
         }
 #pragma unroll
         for (int q = 0; q < AQ; ++q) {
@@ -370,48 +386,49 @@ static int tn_slabs(int64_t S, int N, int K, int bn, int bk) {
 
 using namespace arcn;
 
-static int gemm_rows(bool trans_w, const float *in, int64_t ld_in, const float *W, int ld_w, const float *bias, float *out, int64_t ld_out,
+static int gemm_rows(bool trans_w, const float *in, const float *mask, int64_t ld_in, const float *W, int ld_w, const float *bias, float *out, int64_t ld_out,
                      int64_t S, const int32_t *n_ptr, int Ki, int No, int act, float beta, void *stream) {
     if (S <= 0) return ARCN_OK;
     if (!in || !W || !out || Ki < 1 || No < 1) return einval("gemm: missing / invalid argument");
     const int ia = is_aligned(in, ld_in), wa = is_aligned(W, ld_w), oa = is_aligned(out, ld_out);
     // the branch-free 16-byte loads need both operands aligned and both of THEIR column counts multiples of 4
     const bool all_al = ia && wa && (Ki & 3) == 0 && (!trans_w || (No & 3) == 0);
+#define ARCN_ROWS_L(MT_, NT_, WN_, TW_, AL_, MK_)                                                                                      \
+    hipLaunchKernelGGL((gemm_rows_kernel<MT_, NT_, WN_, TW_, AL_, MK_>), grid, dim3(256), 0, as_stream(stream), in, mask, ld_in, W, ld_w,   \
+                       bias, out, ld_out, S, n_ptr, Ki, No, act, beta, ia, wa, oa)
 #define ARCN_ROWS(MT_, NT_, WN_)                                                                                                      \
     do {                                                                                                                              \
         constexpr int BN_ = 16 * MT_ * WN_, BM_ = 16 * NT_ * (4 / WN_);                                                               \
         dim3 grid((unsigned)ceil_div<int64_t>(S, BM_), (unsigned)ceil_div<int>(No, BN_));                                            \
-        if (trans_w && all_al)                                                                                                        \
-            hipLaunchKernelGGL((gemm_rows_kernel<MT_, NT_, WN_, true, true>), grid, dim3(256), 0, as_stream(stream), in, ld_in, W,    \
-                               ld_w, bias, out, ld_out, S, n_ptr, Ki, No, act, beta, ia, wa, oa);                                     \
-        else if (trans_w)                                                                                                             \
-            hipLaunchKernelGGL((gemm_rows_kernel<MT_, NT_, WN_, true, false>), grid, dim3(256), 0, as_stream(stream), in, ld_in, W,   \
-                               ld_w, bias, out, ld_out, S, n_ptr, Ki, No, act, beta, ia, wa, oa);                                     \
-        else if (all_al)                                                                                                              \
-            hipLaunchKernelGGL((gemm_rows_kernel<MT_, NT_, WN_, false, true>), grid, dim3(256), 0, as_stream(stream), in, ld_in, W,   \
-                               ld_w, bias, out, ld_out, S, n_ptr, Ki, No, act, beta, ia, wa, oa);                                     \
-        else                                                                                                                          \
-            hipLaunchKernelGGL((gemm_rows_kernel<MT_, NT_, WN_, false, false>), grid, dim3(256), 0, as_stream(stream), in, ld_in, W,  \
-                               ld_w, bias, out, ld_out, S, n_ptr, Ki, No, act, beta, ia, wa, oa);                                     \
+        if (mask) {   /* masked operand: the aligned instantiations only (the callers pad) */                                         \
+            if (!all_al) return einval("gemm: a masked operand needs 16-byte aligned rows and feature counts that are multiples of 4"); \
+            if (trans_w) ARCN_ROWS_L(MT_, NT_, WN_, true, true, true);                                                                 \
+            else ARCN_ROWS_L(MT_, NT_, WN_, false, true, true);                                                                        \
+        } else if (trans_w && all_al) ARCN_ROWS_L(MT_, NT_, WN_, true, true, false);                                                   \
+        else if (trans_w) ARCN_ROWS_L(MT_, NT_, WN_, true, false, false);                                                              \
+        else if (all_al) ARCN_ROWS_L(MT_, NT_, WN_, false, true, false);                                                               \
+        else ARCN_ROWS_L(MT_, NT_, WN_, false, false, false);                                                                          \
     } while (0)
     if (No > 64) ARCN_ROWS(4, 4, 2);        // 128 outputs x 128 samples per workgroup
     else if (No > 32) ARCN_ROWS(4, 2, 1);   // 64 outputs x 128 samples
     else if (No > 16) ARCN_ROWS(2, 2, 1);   // 32 outputs x 128 samples
     else ARCN_ROWS(1, 2, 1);                // 16 outputs x 128 samples
 #undef ARCN_ROWS
+#undef ARCN_ROWS_L
     return check_launch("gemm_rows");
 }
 
 /* Y (S,N) = act(X (S,K) . W (N,K)^T + bias): nn.Linear / DenseLayer forward (linear_network_module.py:174-197, linear.py). */
 ARCN_EXPORT int arcn_gemm_nt(const float *x, int64_t ld_x, const float *w, const float *bias, float *y, int64_t ld_y, int64_t n_rows,
                              const int32_t *n_ptr, int K, int N, int act, float beta, void *stream) {
-    return gemm_rows(false, x, ld_x, w, K, bias, y, ld_y, n_rows, n_ptr, K, N, act, beta, stream);
+    return gemm_rows(false, x, nullptr, ld_x, w, K, bias, y, ld_y, n_rows, n_ptr, K, N, act, beta, stream);
 }
 
-/* dX (S,K) = dY (S,N) . W (N,K): input gradient of the layer. */
-ARCN_EXPORT int arcn_gemm_nn(const float *dy, int64_t ld_dy, const float *w, float *dx, int64_t ld_dx, int64_t n_rows, const int32_t *n_ptr,
-                             int N, int K, void *stream) {
-    return gemm_rows(true, dy, ld_dy, w, K, nullptr, dx, ld_dx, n_rows, n_ptr, N, K, ARCN_ACT_NONE, 1.0f, stream);
+/* dX (S,K) = (dY (S,N) * (mask > 0)) . W (N,K): input gradient of the layer; mask (same layout as dy, may be NULL) = the layer's
+ * ReLU output, which folds the activation's backward into the operand load. */
+ARCN_EXPORT int arcn_gemm_nn(const float *dy, const float *mask, int64_t ld_dy, const float *w, float *dx, int64_t ld_dx, int64_t n_rows,
+                             const int32_t *n_ptr, int N, int K, void *stream) {
+    return gemm_rows(true, dy, mask, ld_dy, w, K, nullptr, dx, ld_dx, n_rows, n_ptr, N, K, ARCN_ACT_NONE, 1.0f, stream);
 }
 
 ARCN_EXPORT int64_t arcn_gemm_tn_scratch_floats(int64_t n_rows, int N, int K) {
@@ -422,12 +439,13 @@ ARCN_EXPORT int64_t arcn_gemm_tn_scratch_floats(int64_t n_rows, int N, int K) {
 
 /* dW (N,K) (+)= dY (S,N)^T . X (S,K): weight gradient, reduced over all rows in a fixed order (slab partials in `scratch`, at least
  * arcn_gemm_tn_scratch_floats(n_rows, N, K) floats). */
-ARCN_EXPORT int arcn_gemm_tn(const float *dy, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *scratch, int64_t scratch_floats,
-                             int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate, void *stream) {
+ARCN_EXPORT int arcn_gemm_tn(const float *dy, const float *mask, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *scratch,
+                             int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate, void *stream) {
     if (!dy || !x || !dw || !scratch || N < 1 || K < 1) return einval("gemm_tn: missing / invalid argument");
     if (scratch_floats < arcn_gemm_tn_scratch_floats(n_rows, N, K)) return einval("gemm_tn: scratch smaller than arcn_gemm_tn_scratch_floats");
     const int aa = is_aligned(dy, ld_dy), ba = is_aligned(x, ld_x);
     const bool al = aa && ba && (N & 3) == 0 && (K & 3) == 0;
+    if (mask && !al) return einval("gemm_tn: a masked operand needs 16-byte aligned rows and feature counts that are multiples of 4");
     const bool small = (N <= 64 && K <= 64);
     int slabs;
     if (n_rows <= 0) {
@@ -435,13 +453,15 @@ ARCN_EXPORT int arcn_gemm_tn(const float *dy, int64_t ld_dy, const float *x, int
     } else if (small) {
         slabs = tn_slabs(n_rows, N, K, 64, 64);
         dim3 grid((unsigned)slabs, (unsigned)(ceil_div<int>(N, 64) * ceil_div<int>(K, 64)));
-        if (al) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, true>), grid, dim3(256), 0, as_stream(stream), dy, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, aa, ba);
-        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, false>), grid, dim3(256), 0, as_stream(stream), dy, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, aa, ba);
+        if (mask) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, true, true>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, aa, ba);
+        else if (al) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, true, false>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, aa, ba);
+        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, false, false>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, aa, ba);
     } else {
         slabs = tn_slabs(n_rows, N, K, 128, 128);
         dim3 grid((unsigned)slabs, (unsigned)(ceil_div<int>(N, 128) * ceil_div<int>(K, 128)));
-        if (al) hipLaunchKernelGGL((gemm_tn_kernel<4, 4, true>), grid, dim3(256), 0, as_stream(stream), dy, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, aa, ba);
-        else hipLaunchKernelGGL((gemm_tn_kernel<4, 4, false>), grid, dim3(256), 0, as_stream(stream), dy, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, aa, ba);
+        if (mask) hipLaunchKernelGGL((gemm_tn_kernel<4, 4, true, true>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, aa, ba);
+        else if (al) hipLaunchKernelGGL((gemm_tn_kernel<4, 4, true, false>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, aa, ba);
+        else hipLaunchKernelGGL((gemm_tn_kernel<4, 4, false, false>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, aa, ba);
     }
     const int64_t n_elem = (int64_t)N * K;
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ceil_div<int64_t>(n_elem, 64)), dim3(256), 0, as_stream(stream), scratch, dw,

@@ -23,6 +23,9 @@ class DenseLayer(Linear):
         self.activation = activation if activation is not None else nn.ReLU(inplace=True)
 
     def forward(self, x):
+        if type(self.activation) is nn.ReLU:
+            from ...ops.autograd import linear_relu
+            return linear_relu(x, self.weight, self.bias)      # bias + ReLU in the product's epilogue, mask folded into its backward
         return self.activation(super().forward(x))
 
 

@@ -301,26 +301,86 @@ class GemmTN(torch.autograd.Function):
         return d_a, d_b
 
 
-def linear(x, weight, bias=None):
-    """torch.nn.functional.linear for fp32 CUDA tensors on the MFMA products; anything else (CPU tensors of the host-side tests, other
-    dtypes) goes to torch.  ARCN_LINEAR_GEMM=0 routes everything to torch (A/B against the library GEMMs)."""
-    import os
-    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32) or os.environ.get('ARCN_LINEAR_GEMM', '1') == '0':
-        return torch.nn.functional.linear(x, weight, bias)
-    shp = x.shape
-    x2 = x.reshape(-1, shp[-1])
-    if x2.shape[0] == 0:
-        return torch.nn.functional.linear(x, weight, bias)
-    # the kernels move 16 bytes per lane when every row starts 16-byte aligned: feature dimensions that are not multiples of 4
-    # (63, 319, 283 inputs; 257, 17, 3 outputs) are zero-padded - the weight / bias pads are tiny, the input pad is one copy, and the
-    # padded OUTPUT is sliced outside the autograd node so that its gradient arrives padded (aligned) as well
+class LinearReluFn(torch.autograd.Function):
+    """y = relu(x @ w.T + bias) in ONE kernel (bias + activation in the product's epilogue); backward with the activation's mask
+    folded into the operand loads of the two gradient products (dpre = dy * (y > 0) is never written): per layer and direction one
+    launch instead of the library's GEMM + elementwise passes.  First order only (the ReLU stacks of NeRF / HDR-NeRF / the radiance
+    nets; a second differentiation raises instead of being silently wrong - softplus sdf nets take the generic `linear`)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        y = F.gemm_nt(x, w, bias, act='relu')
+        ctx.save_for_backward(x, w, y)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        g = g.contiguous()
+        dx = F.gemm_nn(g, w, mask=y) if ctx.needs_input_grad[0] else None
+        dw = F.gemm_tn(g, x, mask=y) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            ones = _ones_cols(g.shape[0], g.device)
+            db = F.gemm_tn(g, ones, mask=y)[:, 0].contiguous()    # column sums of dy * (y > 0) on the same reduction kernel
+        return dx, dw, db
+
+
+_ONES = {}
+
+
+def _ones_cols(n_rows, device):
+    key = (str(device), )
+    t = _ONES.get(key)
+    if t is None or t.shape[0] < n_rows:
+        t = torch.ones((max(n_rows, 1 << 16), 4), dtype=torch.float32, device=device)
+        _ONES[key] = t
+    return t[:n_rows]
+
+
+def _padded_operands(x, weight, bias):
+    """the kernels move 16 bytes per lane when every row starts 16-byte aligned: feature dimensions that are not multiples of 4 (63,
+    319, 283 inputs; 257, 17, 3 outputs) are zero-padded - the weight / bias pads are tiny, the input pad is one copy, and the padded
+    OUTPUT is sliced outside the autograd node so that its gradient arrives padded (aligned) as well"""
     n_out, k_in = weight.shape
     kp, npad = (-k_in) % 4, (-n_out) % 4
     pad = torch.nn.functional.pad
     w = pad(weight, (0, kp, 0, npad)) if (kp or npad) else weight
     b = pad(bias, (0, npad)) if (bias is not None and npad) else bias
+    x2 = x.reshape(-1, x.shape[-1])
     x2 = pad(x2, (0, kp)) if kp else x2.contiguous()
-    y = GemmNT.apply(x2, w.contiguous(), b)
+    return x2, w.contiguous(), b, n_out, npad
+
+
+def _use_hip_linear(x, weight):
+    import os
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.numel() > 0 and
+            os.environ.get('ARCN_LINEAR_GEMM', '1') != '0')
+
+
+def linear_relu(x, weight, bias=None):
+    """relu(torch.nn.functional.linear(x, weight, bias)) as one fused layer (LinearReluFn); torch for anything but fp32 CUDA tensors"""
+    import os
+    if not _use_hip_linear(x, weight) or os.environ.get('ARCN_LINEAR_FUSED_RELU', '1') == '0':
+        return torch.relu(linear(x, weight, bias))
+    shp = x.shape
+    x2, w, b, n_out, npad = _padded_operands(x, weight, bias)
+    y = LinearReluFn.apply(x2, w, b)
+    if npad:
+        y = y[:, :n_out]
+    return y.reshape(*shp[:-1], n_out)
+
+
+def linear(x, weight, bias=None):
+    """torch.nn.functional.linear for fp32 CUDA tensors on the MFMA products; anything else (CPU tensors of the host-side tests, other
+    dtypes) goes to torch.  ARCN_LINEAR_GEMM=0 routes everything to torch (A/B against the library GEMMs)."""
+    if not _use_hip_linear(x, weight):
+        return torch.nn.functional.linear(x, weight, bias)
+    shp = x.shape
+    x2, w, b, n_out, npad = _padded_operands(x, weight, bias)
+    y = GemmNT.apply(x2, w, b)
     if npad:
         y = y[:, :n_out]
     return y.reshape(*shp[:-1], n_out)

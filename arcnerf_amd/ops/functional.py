@@ -547,29 +547,29 @@ def gemm_nt(x, w, bias=None, act=None, beta=1.0):
     return y
 
 
-def gemm_nn(dy, w):
-    """dx (S,K) = dy (S,N) @ w (N,K)"""
-    _req(dy, w)
-    dy, w = _f32(dy), _f32(w)
+def gemm_nn(dy, w, mask=None):
+    """dx (S,K) = (dy * (mask > 0)) (S,N) @ w (N,K)"""
+    _req(dy, w, mask)
+    dy, w, mask = _f32(dy), _f32(w), _f32(mask)
     S, Nn = dy.shape
     K = w.shape[1]
     assert w.shape[0] == Nn
     dx = torch.empty((S, K), dtype=torch.float32, device=dy.device)
-    N.check(N.lib().arcn_gemm_nn(N.ptr(dy), Nn, N.ptr(w), N.ptr(dx), K, S, None, Nn, K, N.stream()), 'gemm_nn')
+    N.check(N.lib().arcn_gemm_nn(N.ptr(dy), N.ptr(mask), Nn, N.ptr(w), N.ptr(dx), K, S, None, Nn, K, N.stream()), 'gemm_nn')
     return dx
 
 
-def gemm_tn(dy, x):
-    """dw (N,K) = dy (S,N).T @ x (S,K), reduced over the rows in a fixed order"""
-    _req(dy, x)
-    dy, x = _f32(dy), _f32(x)
+def gemm_tn(dy, x, mask=None):
+    """dw (N,K) = (dy * (mask > 0)) (S,N).T @ x (S,K), reduced over the rows in a fixed order"""
+    _req(dy, x, mask)
+    dy, x, mask = _f32(dy), _f32(x), _f32(mask)
     S, Nn = dy.shape
     K = x.shape[1]
     assert x.shape[0] == S
     dw = torch.empty((Nn, K), dtype=torch.float32, device=dy.device)
     nf = max(1, int(N.lib().arcn_gemm_tn_scratch_floats(S, Nn, K)))
     scratch = torch.empty(nf, dtype=torch.float32, device=dy.device)
-    N.check(N.lib().arcn_gemm_tn(N.ptr(dy), Nn, N.ptr(x), K, N.ptr(dw), N.ptr(scratch), nf, S, None, Nn, K, 0, N.stream()), 'gemm_tn')
+    N.check(N.lib().arcn_gemm_tn(N.ptr(dy), N.ptr(mask), Nn, N.ptr(x), K, N.ptr(dw), N.ptr(scratch), nf, S, None, Nn, K, 0, N.stream()), 'gemm_tn')
     return dw
 
 

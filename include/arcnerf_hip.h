@@ -277,16 +277,18 @@ int arcn_mlp_bwd_dw(const float *x, const arcn_mlp_desc *desc_host, const float 
  * each other's gradients, so forward, backward and the double backward of NeuS normals (base_network.py:30-44) all run on them.
  * Row-major operands with explicit leading dimensions (ld_* in floats): a column slice of a wider buffer can be passed directly.
  *   arcn_gemm_nt: y (n_rows, N) = act(x (n_rows, K) . w (N, K)^T + bias)   act = ARCN_ACT_*, bias may be NULL
- *   arcn_gemm_nn: dx (n_rows, K) = dy (n_rows, N) . w (N, K)
- *   arcn_gemm_tn: dw (N, K) (+)= dy (n_rows, N)^T . x (n_rows, K), reduced over the rows in a fixed order through `scratch`
+ *   arcn_gemm_nn: dx (n_rows, K) = dy' (n_rows, N) . w (N, K)
+ *   arcn_gemm_tn: dw (N, K) (+)= dy' (n_rows, N)^T . x (n_rows, K), reduced over the rows in a fixed order through `scratch`
+ *                 dy' = dy, or dy * (mask > 0) when `mask` (layout of dy; the layer's ReLU output) is given: the activation's
+ *                 backward (torch threshold_backward after a DenseLayer, linear.py) folded into the operand load
  *                 (>= arcn_gemm_tn_scratch_floats(n_rows, N, K) floats); accumulate = 1 adds to dw, 0 overwrites */
 int arcn_gemm_nt(const float *x, int64_t ld_x, const float *w, const float *bias, float *y, int64_t ld_y, int64_t n_rows,
                  const int32_t *n_ptr, int K, int N, int act, float beta, void *stream);
-int arcn_gemm_nn(const float *dy, int64_t ld_dy, const float *w, float *dx, int64_t ld_dx, int64_t n_rows, const int32_t *n_ptr,
-                 int N, int K, void *stream);
+int arcn_gemm_nn(const float *dy, const float *mask, int64_t ld_dy, const float *w, float *dx, int64_t ld_dx, int64_t n_rows,
+                 const int32_t *n_ptr, int N, int K, void *stream);
 int64_t arcn_gemm_tn_scratch_floats(int64_t n_rows, int N, int K);
-int arcn_gemm_tn(const float *dy, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *scratch, int64_t scratch_floats,
-                 int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate, void *stream);
+int arcn_gemm_tn(const float *dy, const float *mask, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *scratch,
+                 int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate, void *stream);
 /* The same network with a LEVEL-MAJOR input / input gradient: x_lm[(l * x_stride + s) * 2 + f], 2 features per level (what
  * arcn_hashgrid_fwd_xcd(level_major = 1) writes and arcn_hashgrid_bwd_lm consumes).  Wired for the bias-free 2-layer nets fed by
  * the hash grid (input 32 or 64 wide, hidden <= 64, output <= 16); -1 otherwise.  bwd: dx_lm in the layout of x_lm, dweights

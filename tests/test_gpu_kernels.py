@@ -1026,3 +1026,26 @@ def test_linear_layers_double_backward_vs_torch():
         res[name] = [out.detach(), nrm.detach(), x.grad.clone()] + [p.grad.clone() for p in Ws + bs]
     for a, b_ in zip(res['hip'], res['torch']):
         assert (a - b_).abs().max() <= 2e-4 * b_.abs().max() + 1e-7
+
+
+@pytest.mark.parametrize('S,K,Nn,bias', [(3000, 63, 256, True), (2049, 319, 256, True), (1500, 283, 128, True), (1000, 32, 64, False), (777, 256, 257, True)])
+def test_fused_linear_relu_layer_vs_torch(S, K, Nn, bias):
+    """LinearReluFn (bias + ReLU in the epilogue of arcn_gemm_nt, the ReLU mask folded into arcn_gemm_nn / arcn_gemm_tn, bias gradient on
+    the reduction kernel) against relu(F.linear) under torch autograd: DenseLayer of linear.py:11-35."""
+    from arcnerf_amd.ops.autograd import linear_relu
+    g = torch.Generator().manual_seed(K * 7 + Nn)
+    x0 = torch.randn(S, K, generator=g).cuda()
+    w = (torch.randn(Nn, K, generator=g) / K ** 0.5).cuda().requires_grad_(True)
+    b = (torch.randn(Nn, generator=g) * 0.3).cuda().requires_grad_(True) if bias else None
+    up = torch.randn(S, Nn, generator=g).cuda()
+    x = x0.clone().requires_grad_(True)
+    y = linear_relu(x, w, b)
+    (y * up).sum().backward()
+    ref_y = torch.relu(torch.nn.functional.linear(x0.double(), w.detach().double(), None if b is None else b.detach().double()))
+    assert (y.double() - ref_y).abs().max() <= 2e-6 * ref_y.abs().max()
+    # the gradients against float64 products with the layer's OWN activation mask (an entry whose pre-activation is within rounding
+    # of zero may fall on either side of the ReLU in two different summation orders; its gradient then legitimately differs)
+    dpre = (up * (y.detach() > 0)).double()
+    for got, ref in ((x.grad, dpre @ w.detach().double()), (w.grad, dpre.t() @ x0.double())) + (((b.grad, dpre.sum(0)),) if bias else ()):
+        assert got.shape == ref.shape
+        assert (got.double() - ref).abs().max() <= 3e-6 * ref.abs().max() * max(1.0, (S / 1000.0) ** 0.5)
