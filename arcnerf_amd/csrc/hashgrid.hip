@@ -1426,22 +1426,33 @@ static int build_fwd_plan(const GridParams &g, int64_t n, FwdPlan &plan, int &wg
             left -= take;
         }
     }
+    // workgroups of an XCD's queue: one per segment, the rest in proportion to the segments' cost (small launches: a queue is never
+    // shorter than its segment list)
+    int max_seg = 1;
+    for (int q = 0; q < 8; ++q) max_seg = plan.n_seg[q] > max_seg ? plan.n_seg[q] : max_seg;
+    if (wg_per_xcd < max_seg) wg_per_xcd = max_seg;
     for (int q = 0; q < 8; ++q) {
+        const int ns = plan.n_seg[q];
+        if (ns == 0) continue;
         float sum = 0.f;
-        for (int i = 0; i < plan.n_seg[q]; ++i) sum += (float)plan.seg[q][i].wg1;
-        int pos = 0;
-        float acc = 0.f;
-        for (int i = 0; i < plan.n_seg[q]; ++i) {
-            acc += (float)plan.seg[q][i].wg1;
-            int end = (i == plan.n_seg[q] - 1) ? wg_per_xcd : (int)(acc / (sum > 0.f ? sum : 1.f) * (float)wg_per_xcd + 0.5f);
-            if (end <= pos) end = pos + 1;              // every segment gets a workgroup
-            if (end > wg_per_xcd) end = wg_per_xcd;
-            plan.seg[q][i].wg0 = pos;
-            plan.seg[q][i].wg1 = end;
-            pos = end;
+        int big = 0;
+        for (int i = 0; i < ns; ++i) {
+            sum += (float)plan.seg[q][i].wg1;
+            if (plan.seg[q][i].wg1 > plan.seg[q][big].wg1) big = i;
         }
-        if (plan.n_seg[q] > 0 && plan.seg[q][plan.n_seg[q] - 1].wg1 <= plan.seg[q][plan.n_seg[q] - 1].wg0)
-            return einval("hashgrid_fwd_xcd: more segments than workgroups");
+        const int extra = wg_per_xcd - ns;
+        int cnt[kFwdSegs], used = 0;
+        for (int i = 0; i < ns; ++i) {
+            cnt[i] = 1 + (int)((float)extra * ((float)plan.seg[q][i].wg1 / (sum > 0.f ? sum : 1.f)));
+            used += cnt[i];
+        }
+        cnt[big] += wg_per_xcd - used;   // rounding remainder (>= 0) to the most expensive segment
+        int pos = 0;
+        for (int i = 0; i < ns; ++i) {
+            plan.seg[q][i].wg0 = pos;
+            plan.seg[q][i].wg1 = pos + cnt[i];
+            pos += cnt[i];
+        }
     }
     return ARCN_OK;
 }

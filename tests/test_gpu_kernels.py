@@ -1049,3 +1049,31 @@ def test_fused_linear_relu_layer_vs_torch(S, K, Nn, bias):
     for got, ref in ((x.grad, dpre @ w.detach().double()), (w.grad, dpre.t() @ x0.double())) + (((b.grad, dpre.sum(0)),) if bias else ()):
         assert got.shape == ref.shape
         assert (got.double() - ref).abs().max() <= 3e-6 * ref.abs().max() * max(1.0, (S / 1000.0) ** 0.5)
+
+
+@pytest.mark.parametrize('side', [2.0, 1.5, 24.0])
+def test_balanced_gather_is_bit_identical_for_any_launch_size(side):
+    """arcn_hashgrid_fwd_xcd (cost-balanced XCD plan, reciprocal division with exact fallback, shared modulo, 16-byte pair loads) against
+    the plain gather for 1 ... 2.6e5 points incl. the volume's corners and faces: every feature bit for bit, row- and level-major.
+    (A launch with fewer workgroups than plan segments used to be rejected.)"""
+    import ctypes as C
+    from arcnerf_amd import _native as N
+    from arcnerf_amd.ops import functional as Fn
+    from arcnerf_amd.pipeline import hashgrid_level_table
+    res, offs = hashgrid_level_table(16, 19, 16, 2048)
+    lib, st = N.lib(), N.stream()
+    h = side / 2
+    desc = N.make_hashgrid_desc(res, offs, 2, [-h] * 3, [h] * 3)
+    table = (torch.rand(offs[-1] * 2, device='cuda') - 0.5)
+    for n in (1, 63, 300, 2048, 7257, 20000, 262144 + 77):
+        g = torch.Generator().manual_seed(n)
+        xyz = ((torch.rand(n, 3, generator=g) - 0.5) * side * 1.05).cuda()
+        if n >= 5:
+            xyz[:5] = torch.tensor([[-h, -h, -h], [h, h, h], [0, 0, 0], [h - 1e-7, 0, 0], [-h + 1e-7, 0.1, 0.2]], device='cuda')
+        ref = Fn.hashgrid_fwd(xyz, table, desc)
+        rm = torch.zeros(n, 32, device='cuda')
+        lm = torch.zeros(16, n, 2, device='cuda')
+        N.check(lib.arcn_hashgrid_fwd_xcd(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(rm), 0, n, n, None, st))
+        N.check(lib.arcn_hashgrid_fwd_xcd(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(lm), 1, n, n, None, st))
+        assert torch.equal(rm, ref), n
+        assert torch.equal(lm.permute(1, 0, 2).reshape(n, 32), ref), n
