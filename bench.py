@@ -264,7 +264,7 @@ def cpu_baseline_nerf():
         n, dt = time_train_steps(128, steps=1, threads=threads)
         if n / dt > best_v:
             best_t, best_v = threads, n / dt
-    for threads, rays in ((best_t, 1024), (1, 32)):
+    for threads, rays in ((best_t, 4096), (1, 32)):   # 4096 rays = the n_rays of scripts/cpu.sh's configs/default.yaml
         n, dt = time_train_steps(rays, steps=1, threads=threads)
         legs.append({'value': n / dt, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
                      'sample': 'fwd+bwd+Adam of one config-1 step, {} rays = {} net evaluations, {:.1f} s, PyTorch CPU eager'.format(rays, n, dt)})
