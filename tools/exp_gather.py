@@ -68,6 +68,9 @@ def main():
     print('samples %d  variant %s  whole launch: median %.1f us  best %.1f us  -> %.2f TB/s algorithmic, %.3f of 8 TB/s' % (
         n, os.environ.get('ARCN_GATHER_VARIANT', '-'), med, best, alg / med / 1e6, alg / med / 1e6 / 8.0))
     if args.check:
+        ref0 = torch.zeros((S, 32), device=dev)
+        mp, bp = timeit(lambda: F.hashgrid_fwd(b['xyz'], table, fld.grid_desc, n_dev=pipe.n_dev, out=ref0), args.iters)
+        print('plain kernel (one lane per (sample, level), every XCD touches all 16 levels, row-major output): median %.1f us best %.1f' % (mp, bp))
         ref = torch.zeros((S, 32), device=dev)
         F.hashgrid_fwd(b['xyz'], table, fld.grid_desc, n_dev=pipe.n_dev, out=ref)
         launch(fld.grid_desc)
