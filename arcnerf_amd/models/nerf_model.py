@@ -6,6 +6,8 @@ fused geo/radiance MLPs, SH view encoding, no hierarchical stage) `forward` bypa
 host decisions of FgModel.forward and runs the packed, device-count-driven kernel sequence of arcnerf_amd.pipeline on the
 module's own parameters.  Outputs (keys, shapes, values) are the same; tests compare both paths.
 """
+import os
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -128,29 +130,60 @@ class NeRF(FgModel):
             self._pipe.set_bitfield(self.obj_bound.volume.get_voxel_bitfield(flatten=True))
         return self._pipe
 
-    def _sample_packed(self, rays_o, rays_d):
-        """March the rays into the packed buffers and make sure NO sample was dropped: the packed buffers have a fixed capacity and the
-        scan clamps the segments to it, while the reference's dense (R, n_sample) tensors hold every sample (first steps with an
-        all-ones bitfield, 32768-ray inference chunks).  When R * n_sample can exceed the capacity the marcher's own total is read
-        back (one host read, where the reference's FgModel.forward has three) and, if it does not fit, the buffers are rebuilt 1.25x
-        larger than needed and the SAME launch of the sampler's pcg32 stream is repeated."""
+    def _sample_packed(self, rays_o, rays_d, exact):
+        """March the rays into the packed buffers and make sure no sample is dropped SILENTLY: the packed buffers have a fixed
+        capacity and the scan clamps the segments to it, while the reference's dense (R, n_sample) tensors hold every sample (first
+        steps with an all-ones bitfield, 32768-ray inference chunks).  Only when R * n_sample can exceed the capacity:
+          exact (inference): the marcher's total is read back (one host read, where the reference's FgModel.forward has three) and,
+            if it does not fit, the buffers are rebuilt 1.25x larger than needed and the SAME launch of the sampler's pcg32 stream is
+            repeated - nothing is ever truncated;
+          training: a host read per step would serialise the host with the device (measured: 1.04 -> 3.75 ms/step with
+            torch.optim.Adam), so the total travels to pinned memory asynchronously and is checked at the NEXT call - an overflowed
+            step is reported with a warning and the buffers grow before the following step (the reference-sized first steps of a
+            training run are the only place this happens: the dynamic batch size keeps later steps near 2^18 samples)."""
+        self._check_deferred_overflow(rays_o.device)
         pipe = self._packed_pipeline(rays_o.device)
         R = rays_o.shape[0]
         state = pipe.rng.state
         pipe.sample(rays_o, rays_d)
-        if R * pipe.cfg.n_sample > pipe.cap:
-            need = int(pipe.buf['counts'][:R].sum())
-            if need > pipe.cap:
-                pipe = self._packed_pipeline(rays_o.device, min_samples=(need * 5 // 4 + 1023) // 1024 * 1024)
-                pipe.rng.set_state(state)
-                pipe.sample(rays_o, rays_d)
-                assert int(pipe.n_dev.item()) == need
+        if R * pipe.cfg.n_sample > pipe.cap and os.environ.get('ARCN_PACKED_OVERFLOW_CHECK', '1') != '0':
+            total = pipe.buf['counts'][:R].sum(dtype=torch.int64)
+            if exact:
+                need = int(total)
+                if need > pipe.cap:
+                    pipe = self._packed_pipeline(rays_o.device, min_samples=(need * 5 // 4 + 1023) // 1024 * 1024)
+                    pipe.rng.set_state(state)
+                    pipe.sample(rays_o, rays_d)
+                    assert int(pipe.n_dev.item()) == need
+            else:
+                if getattr(self, '_ovf_host', None) is None:
+                    self._ovf_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+                self._ovf_host.copy_(total.view(1), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pending_ovf = (ev, pipe.cap, R)
         return pipe
+
+    def _check_deferred_overflow(self, device):
+        pend = getattr(self, '_pending_ovf', None)
+        if pend is None:
+            return
+        self._pending_ovf = None
+        ev, cap, R = pend
+        ev.synchronize()    # recorded a whole step ago: no wait in practice
+        need = int(self._ovf_host[0])
+        if need > cap:
+            import warnings
+            warnings.warn('packed NGP path: the previous training step asked for {} samples for {} rays but the buffers hold {}; the '
+                          'rays past the capacity were rendered with truncated sample sets in that step.  Growing the buffers to '
+                          '{} samples now (set model.chunk_rays lower, or render with inference_only=True for the exact '
+                          'path).'.format(need, R, cap, (need * 5 // 4 + 1023) // 1024 * 1024))
+            self._packed_pipeline(device, min_samples=(need * 5 // 4 + 1023) // 1024 * 1024)
 
     def _forward_packed(self, inputs, inference_only):
         rays_o, rays_d, bkg = inputs['rays_o'].contiguous().float(), inputs['rays_d'].contiguous().float(), inputs['bkg_color']
-        pipe = self._sample_packed(rays_o, rays_d)
         train = torch.is_grad_enabled() and not inference_only
+        pipe = self._sample_packed(rays_o, rays_d, exact=not train)
         noise_std = float(self.get_ray_cfgs('noise_std') or 0.0) if not inference_only else 0.0
         g, r = self.coarse_geo_net, self.coarse_radiance_net
         rgb, depth, mask, counts = _PackedRenderFn.apply(rays_o, rays_d, bkg, g.embed_fn.embeddings, g.layers.params,

@@ -248,6 +248,24 @@ def test_packed_path_grows_instead_of_dropping_samples(gpu):
     out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False)
     ((out['rgb_coarse'] - inputs['img']) ** 2).mean().backward()
     assert float(fg.coarse_geo_net.embed_fn.embeddings.grad.abs().max()) > 0
+    # TRAINING on a fresh model: no host read per step - the overflow of step 1 is reported (warning) and repaired at step 2, whose
+    # outputs then equal the dense path's on every ray
+    import warnings
+    m2 = _ngp_model(gpu, ['--model.rays.noise_std', '0.0'])
+    fg2 = m2.fg_model
+    fg2.obj_bound.volume.update_bitfield(torch.ones(32, 32, 32, dtype=torch.bool, device=gpu), ops='overwrite')
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        m2({k: v.clone() for k, v in inputs.items()}, inference_only=False)
+        assert fg2._pipe.cap == (1 << 20) and not [w for w in caught if 'packed NGP path' in str(w.message)]
+        sampler_rng(reset=True)
+        o2 = m2({k: v.clone() for k, v in inputs.items()}, inference_only=False)
+        assert [w for w in caught if 'packed NGP path' in str(w.message)] and fg2._pipe.cap > (1 << 20)
+    fg2.use_packed_path = False
+    sampler_rng(reset=True)
+    o2d = m2({k: v.clone() for k, v in inputs.items()}, inference_only=False)
+    for k in o2:
+        close(o2[k].detach().cpu().numpy(), o2d[k].detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
 def test_ngp_model_trains_with_torch_adam_and_prunes(gpu):
