@@ -10,7 +10,9 @@ import torch
 import numpy as np
 
 from ....geometry.volume import Volume, select_refresh_cells
-from ....ops.volume_func import CUDA_BACKEND_AVAILABLE, sparse_volume_sampling
+from ....ops import volume_func as _vf
+from ....ops.volume_func import sparse_volume_sampling
+from ....render.ray_helper import get_zvals_from_near_far_fix_step, handle_valid_mask_zvals
 from ....utils.cfgs_utils import get_value_from_cfgs_field, valid_key_in_cfgs
 from ....utils.registry import BOUND_REGISTRY
 from .basic_bound import BasicBound
@@ -54,11 +56,34 @@ class VolumeBound(BasicBound):
 
     @torch.no_grad()
     def get_zvals_from_sparse_volume(self, rays_o, rays_d, near, far, n_pts, inference_only, inverse_linear, perturb):
-        """zvals (B,n_pts), mask_pts (B,n_pts) [T..T F..F], tails repeat the last valid z (volume_bound.py:95-143)"""
-        assert CUDA_BACKEND_AVAILABLE, 'libarcnerf_hip.so is required (no torch fallback for the sparse sampler)'
-        dt = self.volume.get_diag_len() / n_pts
-        return sparse_volume_sampling(rays_o, rays_d, near, far, n_pts, dt, self.volume.get_range(), self.volume.get_n_grid(),
-                                      self.volume.get_voxel_bitfield(), near_distance=self.get_optim_cfgs('near_distance'))
+        """zvals (B,n_pts), mask_pts (B,n_pts) [T..T F..F], tails repeat the last valid z (volume_bound.py:95-143).
+
+        The occupancy marcher (K3) whenever the native module is there - which on this platform is always, the product path has no
+        CPU branch.  `ops.volume_func.CUDA_BACKEND_AVAILABLE = False` selects what the reference does WITHOUT its extension
+        (volume_bound.py:126-141, SURVEY a4'): fixed-step (or uniform) zvals, the occupancy test of every sample (`check_pts_in_occ_voxel`
+        - here still the HIP kernel, on GPU tensors), stable compaction of the survivors.  A different algorithm from K3 (no voxel
+        skipping, no start jitter; it cannot even run at n_grid 128 on the reference's CPU path: 293 GB), kept so that a caller who
+        compares against an extension-less reference has the same semantics."""
+        if _vf.CUDA_BACKEND_AVAILABLE:
+            dt = self.volume.get_diag_len() / n_pts
+            return sparse_volume_sampling(rays_o, rays_d, near, far, n_pts, dt, self.volume.get_range(), self.volume.get_n_grid(),
+                                          self.volume.get_voxel_bitfield(), near_distance=self.get_optim_cfgs('near_distance'))
+        if self.get_optim_cfgs('ray_sample_fix_step'):
+            zvals, mask_pts = self.get_zvals_from_near_far_fix_step(near, far, n_pts, inference_only, perturb)
+            pts = rays_o[:, None, :] + zvals[..., None] * rays_d[:, None, :]
+            valid = self.volume.check_pts_in_occ_voxel(pts[mask_pts].view(-1, 3))
+            mask_pts = mask_pts.clone()
+            mask_pts[mask_pts.clone()] = valid
+        else:
+            zvals, _ = super().get_zvals_from_near_far(near, far, n_pts, inference_only, inverse_linear, perturb)
+            pts = rays_o[:, None, :] + zvals[..., None] * rays_d[:, None, :]
+            mask_pts = self.volume.check_pts_in_occ_voxel(pts.view(-1, 3)).view(-1, n_pts)
+        return handle_valid_mask_zvals(zvals, mask_pts)
+
+    def get_zvals_from_near_far_fix_step(self, near, far, n_pts, inference_only=False, perturb=False, **kwargs):
+        """fixed step = diagonal / n_pts (volume_bound.py:145-158)"""
+        fix_t = self.volume.get_diag_len() / n_pts
+        return get_zvals_from_near_far_fix_step(near, far, fix_t, n_pts, perturb=perturb if not inference_only else False)
 
     @torch.no_grad()
     def optimize(self, cur_epoch=0, n_pts=128, get_est_opacity=None):

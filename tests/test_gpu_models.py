@@ -801,3 +801,49 @@ def test_linear_radiance_net_fused_route_matches_linear_chain(gpu):
     assert (res[0][0] - res[1][0]).abs().max() < 1e-5
     for a, b in zip(res[0][1], res[1][1]):
         assert (a - b).abs().max() < 1e-4 * max(1.0, float(b.abs().max()))
+
+
+def test_extensionless_sampler_semantics_on_gpu(gpu, oracle, monkeypatch):
+    """SURVEY a4': what the reference samples WITHOUT its CUDA extension (volume_bound.py:126-141: fixed-step zvals -> occupancy test of
+    every sample -> stable compaction), selected by `ops.volume_func.CUDA_BACKEND_AVAILABLE = False`, on GPU tensors with the HIP
+    occupancy kernel.  The two helpers reproduce the reference's own outputs (golden G3) on the GPU; the whole chain equals a numpy
+    restatement built from the pinned pieces (oracle check_pts_in_occ_voxel = G5)."""
+    from conftest import load_golden
+    from arcnerf_amd.render.ray_helper import get_zvals_from_near_far_fix_step, handle_valid_mask_zvals
+    import arcnerf_amd.ops.volume_func as vf
+    g = load_golden('g3_zvals')
+    z, m = handle_valid_mask_zvals(torch.from_numpy(g['hv_z']).to(gpu), torch.from_numpy(g['hv_m']).to(gpu))
+    assert np.array_equal(m.cpu().numpy(), g['hv_m_out']) and np.array_equal(z.cpu().numpy(), g['hv_z_out'])
+    zz, mm = get_zvals_from_near_far_fix_step(torch.tensor([[1.0], [2.0]], device=gpu), torch.tensor([[1.35], [5.0]], device=gpu), 0.1, 6)
+    assert mm.cpu().tolist() == [[True, True, True, True, True, False], [True] * 6]
+    np.testing.assert_allclose(zz[0].cpu().numpy(), [1.0, 1.1, 1.2, 1.3, 1.35, 1.35], rtol=1e-6)
+    # the chain through VolumeBound
+    m_ = _ngp_model(gpu)
+    bound = m_.fg_model.obj_bound
+    from arcnerf_amd.pipeline import synthetic_rays
+    o, d = synthetic_rays(500, seed=77, device=gpu)
+    near, far, mask_rays = bound.get_near_far_from_rays({'rays_o': o, 'rays_d': d})
+    n_pts = 256
+    monkeypatch.setattr(vf, 'CUDA_BACKEND_AVAILABLE', False)
+    zv, mp = bound.get_zvals_from_near_far(near, far, n_pts, inference_only=True, rays_o=o, rays_d=d)
+    monkeypatch.setattr(vf, 'CUDA_BACKEND_AVAILABLE', True)
+    # numpy restatement
+    vol = bound.volume
+    dt = np.float32(vol.get_diag_len() / n_pts)
+    nr, fr = near.cpu().numpy(), far.cpu().numpy()
+    zs = np.minimum(np.maximum(nr + np.arange(n_pts, dtype=np.float32)[None] * dt, nr), fr).astype(np.float32)
+    mk = np.concatenate([np.ones((zs.shape[0], 1), bool), (zs[:, 1:] - zs[:, :-1]) != 0.0], 1)
+    on, dn = o.cpu().numpy(), d.cpu().numpy()
+    pts = (on[:, None, :] + zs[..., None] * dn[:, None, :]).astype(np.float32)
+    aabb23 = vol.get_range().permute(1, 0).contiguous().cpu().numpy()
+    occ = oracle.check_pts_in_occ_voxel(pts.reshape(-1, 3), vol.get_voxel_bitfield(flatten=True).cpu().numpy(), aabb23, vol.get_n_grid()).reshape(zs.shape)
+    mk &= occ
+    ref_z, ref_m = handle_valid_mask_zvals(torch.from_numpy(zs), torch.from_numpy(mk))
+    assert np.array_equal(mp.cpu().numpy(), ref_m.numpy())
+    assert int(ref_m.sum()) > 1000 and (~ref_m.any(1)).sum() > 10      # rays with and without samples
+    # positions computed on the GPU may differ from numpy's by an ulp at voxel faces: compare where the masks agree (everywhere)
+    np.testing.assert_allclose(zv.cpu().numpy(), ref_z.numpy(), rtol=1e-6, atol=1e-6)
+    # every kept sample lies in an occupied voxel and rows are [T..T F..F] with the tail repeating the last z
+    cnt = mp.sum(1)
+    cols = torch.arange(n_pts, device=gpu)[None]
+    assert torch.equal(mp, cols < cnt[:, None])
