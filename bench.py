@@ -248,7 +248,7 @@ def bench_module(args, name):
         dist.destroy_process_group()
 
 
-def cpu_baseline_nerf():
+def cpu_baseline_nerf(rays_all=4096):
     """BASELINE.md section 3 for config 1: (a) the PyTorch-CPU-eager restatement of the reference modules (oracle/torch_cpu_nerf.py, the
     stand-in for scripts/cpu.sh) on all host cores and on one; bounded samples."""
     from oracle.torch_cpu_nerf import time_train_steps
@@ -264,7 +264,7 @@ def cpu_baseline_nerf():
         n, dt = time_train_steps(128, steps=1, threads=threads)
         if n / dt > best_v:
             best_t, best_v = threads, n / dt
-    for threads, rays in ((best_t, 4096), (1, 32)):   # 4096 rays = the n_rays of scripts/cpu.sh's configs/default.yaml
+    for threads, rays in ((best_t, rays_all), (1, 32)):   # 4096 rays = the n_rays of scripts/cpu.sh's configs/default.yaml
         n, dt = time_train_steps(rays, steps=1, threads=threads)
         legs.append({'value': n / dt, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
                      'sample': 'fwd+bwd+Adam of one config-1 step, {} rays = {} net evaluations, {:.1f} s, PyTorch CPU eager'.format(rays, n, dt)})
@@ -451,6 +451,13 @@ def main():
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, field, bf, args.cpu_rays)
+        # north_star: "the reference CPU path (scripts/cpu.sh) timed on the host cores of the same box in the same run" - that script
+        # trains the vanilla-NeRF config (config 1) on the CPU; its PyTorch-eager stand-in (oracle/torch_cpu_nerf.py, pinned to G22)
+        # rides along as a bounded leg (the full config-1 numbers come from `bench.py --config nerf`)
+        try:
+            cpu['scripts_cpu_sh'] = cpu_baseline_nerf(rays_all=1024)
+        except Exception as e:   # never lose the headline line to the side leg
+            cpu['scripts_cpu_sh'] = {'error': repr(e)}
 
     out = {
         'metric': 'ray-samples/sec (train), NGP Lego 800x800', 'value': total_samples / wall, 'unit': 'samples/s',
