@@ -54,6 +54,31 @@ __device__ __forceinline__ float act_grad_from_y(float y, int act, float beta) {
 // Stage W (rows x cols, row-major, leading dimension ld) — or its transpose — into LDS in MFMA A-fragment order:
 //   element A[r][c] -> lds[((mt*T + t)*64 + g*16 + i)*4 + ks],  r = 16mt+i, c = 16t+4g+ks, zero padded to 16 multiples.
 // TRANSPOSED: A = W^T, i.e. A[r][c] = W[c][r] with W (cols x rows).
+// ARCN_MLP_SPLIT_BF16 (experiment, off): every f32 operand as hi + lo bf16 halves and the product as three bf16 MFMAs
+// (hi*hi + hi*lo + lo*hi; v_mfma_f32_16x16x16_bf16 takes exactly the 16 reduction elements 16t + 4g + ks that four 16x16x4 f32 MFMAs
+// take, with the same lane <-> element map, so fragments, permutation and accumulators are unchanged).  The weight fragments are split
+// when they are staged: the 16-byte slot of lane (g, i) holds [hi(ks 0..3) | lo(ks 0..3)].
+#ifndef ARCN_MLP_SPLIT_BF16
+#define ARCN_MLP_SPLIT_BF16 0
+#endif
+typedef short bf4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    uint32_t r;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// v = hi + lo (+ 2^-17 relative): hi = bf16(v) round to nearest even, lo = bf16(v - hi)
+__device__ __forceinline__ void split_bf16(const f4 &v, bf4 &hi, bf4 &lo) {
+    const uint32_t h01 = cvt_pk_bf16(v.x, v.y), h23 = cvt_pk_bf16(v.z, v.w);
+    const float r0 = v.x - __uint_as_float(h01 << 16), r1 = v.y - __uint_as_float(h01 & 0xffff0000u);
+    const float r2 = v.z - __uint_as_float(h23 << 16), r3 = v.w - __uint_as_float(h23 & 0xffff0000u);
+    const uint32_t l01 = cvt_pk_bf16(r0, r1), l23 = cvt_pk_bf16(r2, r3);
+    hi = __builtin_bit_cast(bf4, make_uint2(h01, h23));
+    lo = __builtin_bit_cast(bf4, make_uint2(l01, l23));
+}
+
 template <bool TRANSPOSED>
 __device__ __forceinline__ void stage_fragments(float *lds, const float *__restrict__ W, int rows, int cols) {
     const int MT = tiles16(rows), T = tiles16(cols);
@@ -77,7 +102,17 @@ __device__ __forceinline__ void stage_fragments(float *lds, const float *__restr
         }
 #pragma unroll
         for (int u = 0; u < kBatch; ++u)
-            if (dst[u] >= 0) lds[dst[u]] = v[u];
+            if (dst[u] >= 0) {
+#if ARCN_MLP_SPLIT_BF16
+                const uint32_t h = cvt_pk_bf16(v[u], 0.f) & 0xffffu;
+                const uint32_t lw = cvt_pk_bf16(v[u] - __uint_as_float(h << 16), 0.f) & 0xffffu;
+                unsigned short *slot = reinterpret_cast<unsigned short *>(lds) + (dst[u] >> 2) * 8 + (dst[u] & 3);
+                slot[0] = (unsigned short)h;
+                slot[4] = (unsigned short)lw;
+#else
+                lds[dst[u]] = v[u];
+#endif
+            }
     }
 }
 
@@ -143,6 +178,33 @@ __device__ __forceinline__ void store_tiles(const f4 (&v)[WT][NT], float *__rest
 template <int WT, int NT>
 __device__ __forceinline__ void gemm_tiles(f4 (&out)[WT][NT], const f4 (&in)[WT][NT], const float *lds_frag, int MT, int T,
                                            int lane) {
+#if ARCN_MLP_SPLIT_BF16
+    bf4 bh[WT][NT], bl[WT][NT];
+#pragma unroll
+    for (int t = 0; t < WT; ++t)
+        if (t < T) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) split_bf16(in[t][nt], bh[t][nt], bl[t][nt]);
+        }
+#pragma unroll
+    for (int mt = 0; mt < WT; ++mt) {
+        if (mt < MT) {
+#pragma unroll
+            for (int t = 0; t < WT; ++t) {
+                if (t < T) {
+                    const uint4 a = *reinterpret_cast<const uint4 *>(lds_frag + ((mt * T + t) * 64 + lane) * 4);
+                    const bf4 ah = __builtin_bit_cast(bf4, make_uint2(a.x, a.y)), al = __builtin_bit_cast(bf4, make_uint2(a.z, a.w));
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) out[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh[t][nt], out[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) out[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl[t][nt], out[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) out[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh[t][nt], out[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+#else
 #pragma unroll
     for (int mt = 0; mt < WT; ++mt) {
         if (mt < MT) {
@@ -162,6 +224,7 @@ __device__ __forceinline__ void gemm_tiles(f4 (&out)[WT][NT], const f4 (&in)[WT]
             }
         }
     }
+#endif
 }
 
 // ---- forward ------------------------------------------------------------------------------------------
