@@ -7,6 +7,8 @@ Differences by design (MI355X, 288 GB is not a reason to stream 50 MB of lattice
   - voxel flat index is x*n*n + y*n + z everywhere (volume_func.h:59-66), the bitfield is kept flat + bool like the
     reference (checkpoint compatible) and a packed 1-bit copy is derived for the marcher.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -50,7 +52,12 @@ def select_refresh_cells(bitfield_flat, n_cells, cache, rng):
         cache['arange'] = torch.arange(n_cells, device=dev)
     buf, ar = cache['cell_buf'], cache['arange']
     if n_cells & (n_cells - 1) == 0:
-        buf[:n_s] = mix_permutation(ar[:n_s], n_cells, rng)
+        if os.environ.get('ARCN_REFRESH_AFFINE', '0') == '1':   # round-1 selection (an arithmetic progression), for A/B only
+            a = int(rng.integers(0, n_cells // 2)) * 2 + 1
+            c = int(rng.integers(0, n_cells))
+            buf[:n_s] = (ar[:n_s] * a + c) & (n_cells - 1)
+        else:
+            buf[:n_s] = mix_permutation(ar[:n_s], n_cells, rng)
     else:
         buf[:n_s] = torch.randperm(n_cells, device=dev)[:n_s]
     csum = torch.cumsum(bitfield_flat.to(torch.int32), 0)
