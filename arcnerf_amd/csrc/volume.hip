@@ -561,16 +561,45 @@ __global__ void __launch_bounds__(256) reduce_max_kernel(const float *__restrict
 #ifndef ARCN_MARCH_JUMP_TABLE
 #define ARCN_MARCH_JUMP_TABLE 2   // 0: ballot search per jump, 1: per-lane jump table + scalar pointer chase, 2: no scalar loop (orbit by binary lifting)
 #endif
-template <int MODE>
+// FUSED (round 2, `arcn_march_packed`): the packed outputs come straight out of this kernel.  A wave keeps its ray's emitted t in LDS
+// (n_pts <= 1024: 4 KiB per wave) instead of a dense (n_rays, n_pts) scratch in HBM; the workgroup's 4 counts enter a chained scan
+// over the workgroups ("decoupled look-back": publish the local sum, walk back over the predecessors' status words until one carries
+// an inclusive prefix, publish the own inclusive prefix); then the waves copy their samples to t_packed / ray_id at their final
+// offsets.  Ray blocks are handed out by a ticket (atomic counter) so that a workgroup only ever waits for workgroups that have
+// already started.  Replaces march_count + exclusive_scan (ONE 1024-thread workgroup) + march_write and 2 x 34 MB of scratch traffic.
+struct MarchPacked {
+    int32_t *offsets;        // (n_rays + 1), clamped to capacity
+    float *t_packed;
+    int32_t *ray_id;
+    int64_t capacity;
+    int32_t *p_dense;        // max count over the rays (atomic max; zeroed by the launcher)
+    unsigned long long *lookback;   // [0] ticket counter, [1 + b] status word of ray block b: flag << 62 | value (zeroed by the launcher)
+};
+
+template <int MODE, bool FUSED>
 __global__ void __launch_bounds__(256)
 march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ aabb,
                    const uint8_t *__restrict__ bf, uint32_t n_grid, uint32_t n_pts, float dt, float near_distance,
                    int torch_sem, Pcg32 rng, float *__restrict__ scratch_t, int32_t *__restrict__ counts,
                    float *__restrict__ near_out, float *__restrict__ far_out, const float *__restrict__ near_in,
-                   const float *__restrict__ far_in, uint8_t *__restrict__ mask_out, int64_t n_rays) {
+                   const float *__restrict__ far_in, uint8_t *__restrict__ mask_out, int64_t n_rays, MarchPacked pk) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n_rays) return;
+    __shared__ float lds_t[FUSED ? 4 : 1][FUSED ? 1024 : 1];
+    __shared__ int32_t s_cnt[4];
+    __shared__ int32_t s_base;
+    __shared__ uint32_t s_ticket;
+    uint32_t blk = blockIdx.x;
+    if (FUSED) {
+        if (threadIdx.x == 0) s_ticket = (uint32_t)atomicAdd(pk.lookback, 1ull);
+        __syncthreads();
+        blk = s_ticket;
+    }
+    const int wave_id = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blk * 4 + wave_id;
+    const bool in_range = i < n_rays;
+    if (!FUSED && !in_range) return;
+    uint32_t j = 0;
+    if (in_range) {
     rng.advance((int64_t)(uint32_t)((uint32_t)i * 8u));
     const Aabb b = load_aabb(aabb);
     float o[3] = {rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2]};
@@ -598,9 +627,8 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
     float startt = fmaxf(nr, near_distance);
     const float jit = dt * rng.next_float();
     startt += jit;
-    uint32_t j = 0;
     if (hit) {
-        float *zr = scratch_t + i * (int64_t)n_pts;
+        float *zr = FUSED ? nullptr : scratch_t + i * (int64_t)n_pts;
         float t_base = startt;          // lattice value of lane 0 of the current chunk (wave uniform)
         bool have_pending = false;      // a skip target carried over from the previous chunk
         float pending = 0.f;
@@ -720,12 +748,80 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
             if ((emit_m >> lane) & 1) {
                 const uint32_t before = (uint32_t)__builtin_popcountll(emit_m & ((1ull << lane) - 1ull));
                 const uint32_t cnt_chunk = (uint32_t)__builtin_popcountll(emit_m);
-                zr[j - cnt_chunk + before] = t;
+                if (FUSED) lds_t[wave_id][j - cnt_chunk + before] = t;
+                else zr[j - cnt_chunk + before] = t;
             }
             t_base = t_next_base;
         }
     }
     if (lane == 0 && counts) counts[i] = (int32_t)j;
+    }   // in_range
+    if (FUSED) {
+        if (lane == 0) s_cnt[wave_id] = (int32_t)j;
+        __syncthreads();
+        if (wave_id == 0) {
+            // wave 0 runs the look-back, 64 predecessors per step (a single thread walking back one status word at a time is a chain of
+            // up to n_blocks dependent L2 round trips: measured 1 ms for 2080 blocks)
+            const int32_t agg = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            int32_t mx = s_cnt[0] > s_cnt[1] ? s_cnt[0] : s_cnt[1];
+            mx = mx > s_cnt[2] ? mx : s_cnt[2];
+            mx = mx > s_cnt[3] ? mx : s_cnt[3];
+            if (lane == 0 && pk.p_dense && mx > 0) atomicMax(pk.p_dense, mx);
+            // one 64-bit word carries flag AND value, and no other data passes between the workgroups: relaxed atomics (an acquire
+            // here would invalidate the CU's vector L1 on every poll, under the marching waves' occupancy lookups)
+            unsigned long long *status = pk.lookback + 1;
+            if (lane == 0)
+                __hip_atomic_store(status + blk, ((blk == 0 ? 2ull : 1ull) << 62) | (unsigned long long)(uint32_t)agg, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            long long excl = 0;
+            long long base = (long long)blk - 1;   // lane l looks at block base - l
+            uint32_t spins = 0;
+            while (base >= 0) {
+                const long long idx = base - lane;
+                unsigned long long v = 2ull << 62;             // before block 0: an inclusive prefix of 0
+                if (idx >= 0) v = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned flag = (unsigned)(v >> 62);
+                const uint64_t incl_m = __ballot(flag == 2), none_m = __ballot(flag == 0);
+                const int first_incl = incl_m ? __builtin_ctzll(incl_m) : 64;          // closest predecessor with an inclusive prefix
+                const uint64_t needed = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1ull);   // lanes 0 .. first_incl
+                if (none_m & needed) {   // somebody in the needed range has not published yet: it holds a lower ticket, it is running
+                    if (++spins > (1u << 24)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                long long part = ((needed >> lane) & 1ull) ? (long long)(uint32_t)v : 0;
+#pragma unroll
+                for (int dlt = 32; dlt >= 1; dlt >>= 1) part += __shfl_xor(part, dlt, 64);
+                excl += part;
+                if (incl_m) break;
+                base -= 64;
+            }
+            if (lane == 0) {
+                if (blk != 0)
+                    __hip_atomic_store(status + blk, (2ull << 62) | (unsigned long long)(uint32_t)(excl + agg), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                s_base = (int32_t)excl;
+                const int64_t n_blk = (n_rays + 3) / 4;
+                if ((int64_t)blk == n_blk - 1) {
+                    const long long tot = excl + agg;
+                    pk.offsets[n_rays] = (int32_t)(tot < pk.capacity ? tot : pk.capacity);
+                }
+            }
+        }
+        __syncthreads();
+        if (in_range) {
+            int64_t off = s_base;
+            for (int w = 0; w < wave_id; ++w) off += s_cnt[w];
+            if (lane == 0) pk.offsets[i] = (int32_t)(off < pk.capacity ? off : pk.capacity);
+            for (uint32_t k = lane; k < j; k += 64) {
+                if (off + k < pk.capacity) {
+                    pk.t_packed[off + k] = lds_t[wave_id][k];
+                    pk.ray_id[off + k] = (int32_t)i;
+                }
+            }
+        }
+        return;
+    }
     if (mask_out && j > 0) {
         // dense boundary form: scratch_t IS the (n_rays, n_pts) zvals tensor - the first j slots hold the samples; flag them and
         // repeat the last one over the tail (volume_func_kernel.cu:225-233)
@@ -933,9 +1029,9 @@ ARCN_EXPORT int arcn_sparse_volume_sampling(const float *rays_o, const float *ra
     Pcg32 rng{rng_state, rng_inc};
     // one wavefront per ray (the marcher of the compacted sampler) with the caller's bounds: bit-identical to the
     // reference's serial one-thread-per-ray loop and ~3x faster
-    hipLaunchKernelGGL(march_count_kernel<OCC_BOOL>, dim3((unsigned)ceil_div<int64_t>(n_rays, 4)), dim3(256), 0, as_stream(stream), rays_o,
+    hipLaunchKernelGGL((march_count_kernel<OCC_BOOL, false>), dim3((unsigned)ceil_div<int64_t>(n_rays, 4)), dim3(256), 0, as_stream(stream), rays_o,
                        rays_d, aabb, bitfield, (uint32_t)n_grid, (uint32_t)n_pts, dt, near_distance, 0, rng, zvals, counts,
-                       (float *)nullptr, (float *)nullptr, near, far, mask, n_rays);
+                       (float *)nullptr, (float *)nullptr, near, far, mask, n_rays, MarchPacked{});
     return check_launch("sparse_volume_sampling");
 }
 
@@ -951,9 +1047,9 @@ ARCN_EXPORT int arcn_sparse_volume_sampling_bit(const float *rays_o, const float
     Pcg32 rng{rng_state, rng_inc};
     // one wavefront per ray (the marcher of the compacted sampler) with the caller's bounds: bit-identical to the
     // reference's serial one-thread-per-ray loop and ~3x faster
-    hipLaunchKernelGGL(march_count_kernel<OCC_MORTON>, dim3((unsigned)ceil_div<int64_t>(n_rays, 4)), dim3(256), 0, as_stream(stream), rays_o,
+    hipLaunchKernelGGL((march_count_kernel<OCC_MORTON, false>), dim3((unsigned)ceil_div<int64_t>(n_rays, 4)), dim3(256), 0, as_stream(stream), rays_o,
                        rays_d, aabb, bitfield, (uint32_t)n_grid, (uint32_t)n_pts, dt, near_distance, 0, rng, zvals, counts,
-                       (float *)nullptr, (float *)nullptr, near, far, mask, n_rays);
+                       (float *)nullptr, (float *)nullptr, near, far, mask, n_rays, MarchPacked{});
     return check_launch("sparse_volume_sampling_bit");
 }
 
@@ -1027,18 +1123,51 @@ ARCN_EXPORT int arcn_march_count(const float *rays_o, const float *rays_d, const
     if (bitfield_is_packed == 2 && (n_grid > 1024 || (n_grid & (n_grid - 1))))
         return einval("march_count: a Morton bitfield needs a power-of-two n_grid <= 1024");
     if (bitfield_is_packed == 2)
-        hipLaunchKernelGGL(march_count_kernel<OCC_MORTON>, grid, dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, bitfield,
+        hipLaunchKernelGGL((march_count_kernel<OCC_MORTON, false>), grid, dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, bitfield,
                            (uint32_t)n_grid, (uint32_t)n_pts, dt, near_distance, aabb_torch_semantics, rng, scratch_t,
-                           counts, near_out, far_out, (const float *)nullptr, (const float *)nullptr, (uint8_t *)nullptr, n_rays);
+                           counts, near_out, far_out, (const float *)nullptr, (const float *)nullptr, (uint8_t *)nullptr, n_rays, MarchPacked{});
     else if (bitfield_is_packed)
-        hipLaunchKernelGGL(march_count_kernel<OCC_PACKED>, grid, dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, bitfield,
+        hipLaunchKernelGGL((march_count_kernel<OCC_PACKED, false>), grid, dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, bitfield,
                            (uint32_t)n_grid, (uint32_t)n_pts, dt, near_distance, aabb_torch_semantics, rng, scratch_t,
-                           counts, near_out, far_out, (const float *)nullptr, (const float *)nullptr, (uint8_t *)nullptr, n_rays);
+                           counts, near_out, far_out, (const float *)nullptr, (const float *)nullptr, (uint8_t *)nullptr, n_rays, MarchPacked{});
     else
-        hipLaunchKernelGGL(march_count_kernel<OCC_BOOL>, grid, dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, bitfield,
+        hipLaunchKernelGGL((march_count_kernel<OCC_BOOL, false>), grid, dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, bitfield,
                            (uint32_t)n_grid, (uint32_t)n_pts, dt, near_distance, aabb_torch_semantics, rng, scratch_t,
-                           counts, near_out, far_out, (const float *)nullptr, (const float *)nullptr, (uint8_t *)nullptr, n_rays);
+                           counts, near_out, far_out, (const float *)nullptr, (const float *)nullptr, (uint8_t *)nullptr, n_rays, MarchPacked{});
     return check_launch("march_count");
+}
+
+/* bounds + occupancy marching + compaction in ONE launch (round 2): what arcn_march_count + arcn_exclusive_scan_i32 + arcn_march_write
+ * produce, without the dense (n_rays, n_pts) scratch.  workspace: (n_rays / 4 + 2) 8-byte words (ticket + status words of the chained
+ * scan), zeroed here; p_dense (optional) receives the largest per-ray count. */
+ARCN_EXPORT int64_t arcn_march_packed_workspace_bytes(int64_t n_rays) { return (ceil_div<int64_t>(n_rays > 0 ? n_rays : 0, 4) + 2) * 8; }
+
+ARCN_EXPORT int arcn_march_packed(const float *rays_o, const float *rays_d, const float *aabb, int n_grid, const uint8_t *bitfield,
+                                  int bitfield_is_packed, int n_pts, float dt, float near_distance, int aabb_torch_semantics,
+                                  uint64_t rng_state, uint64_t rng_inc, int32_t *counts, float *near_out, float *far_out, int32_t *offsets,
+                                  float *t_packed, int32_t *ray_id, int64_t capacity, int32_t *p_dense, void *workspace, int64_t n_rays,
+                                  void *stream) {
+    if (n_rays <= 0) return ARCN_OK;
+    if (!rays_o || !rays_d || !aabb || !bitfield || !counts || !offsets || !t_packed || !ray_id || !workspace || n_pts <= 0 ||
+        n_pts > 1024 || n_grid <= 0 || !(dt > 0) || capacity <= 0)
+        return einval("march_packed: missing/invalid argument (n_pts <= 1024)");
+    if (bitfield_is_packed == 2 && (n_grid > 1024 || (n_grid & (n_grid - 1))))
+        return einval("march_packed: a Morton bitfield needs a power-of-two n_grid <= 1024");
+    hipError_t e = hipMemsetAsync(workspace, 0, (size_t)arcn_march_packed_workspace_bytes(n_rays), as_stream(stream));
+    if (e == hipSuccess && p_dense) e = hipMemsetAsync(p_dense, 0, sizeof(int32_t), as_stream(stream));
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
+    Pcg32 rng{rng_state, rng_inc};
+    MarchPacked pk{offsets, t_packed, ray_id, capacity, p_dense, reinterpret_cast<unsigned long long *>(workspace)};
+    dim3 grid((unsigned)ceil_div<int64_t>(n_rays, 4));
+#define ARCN_MP(MODE_) hipLaunchKernelGGL((march_count_kernel<MODE_, true>), grid, dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb,    \
+                                          bitfield, (uint32_t)n_grid, (uint32_t)n_pts, dt, near_distance, aabb_torch_semantics, rng,        \
+                                          (float *)nullptr, counts, near_out, far_out, (const float *)nullptr, (const float *)nullptr,       \
+                                          (uint8_t *)nullptr, n_rays, pk)
+    if (bitfield_is_packed == 2) ARCN_MP(OCC_MORTON);
+    else if (bitfield_is_packed) ARCN_MP(OCC_PACKED);
+    else ARCN_MP(OCC_BOOL);
+#undef ARCN_MP
+    return check_launch("march_packed");
 }
 
 ARCN_EXPORT int arcn_exclusive_scan_i32(const int32_t *counts, int32_t *offsets, int64_t n, int64_t max_total, int32_t *max_out,

@@ -219,6 +219,9 @@ class NgpPipeline:
         # to the backward kernels; a refreshed occupancy takes effect two steps later instead of one
         env_depth = os.environ.get('ARCN_PREFETCH_DEPTH')
         self.prefetch_depth = max(1, int(env_depth if env_depth is not None else (prefetch_depth or 1)))
+        # arcn_march_packed (one launch: marching + chained look-back scan + compaction, no dense scratch) is bit-identical but measured
+        # slower - 107 vs 87 us alone, step 0.725 vs 0.669 ms (workgroups hold their slots while they wait for their predecessors): opt-in
+        self.march_fused = bool(int(os.environ.get('ARCN_MARCH_FUSED', '0'))) and cfg.n_sample <= 1024
         self._sets = []
         for _ in range(1 + self.prefetch_depth):
             self._sets.append({
@@ -231,7 +234,9 @@ class NgpPipeline:
                 # when prefetched): sample positions / directions, per-ray harmonics, the density noise of a training step
                 'xyz': torch.zeros((S, 3), dtype=f32, device=dev), 'dirs': torch.zeros((S, 3), dtype=f32, device=dev),
                 'sh_ray': torch.zeros((R, max(1, cfg.sh_degree ** 2)), dtype=f32, device=dev),
-                'noise': torch.zeros(S, dtype=f32, device=dev)})
+                'noise': torch.zeros(S, dtype=f32, device=dev),
+                # ticket + status words of the fused marcher's chained scan (arcn_march_packed)
+                'march_ws': torch.zeros(max(16, int(N.lib().arcn_march_packed_workspace_bytes(R))), dtype=torch.uint8, device=dev)})
         self._noise_ready = [False] * len(self._sets)
         b.update(self._sets[0])
         self._cur_set = 0
@@ -447,15 +452,24 @@ class NgpPipeline:
         assert R <= self.max_rays
         L = N.lib()
         st = N.stream()
-        N.check(L.arcn_march_count(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
-                                   int(self.packed_bits), cfg.n_sample, cfg.dt, cfg.near_distance, int(self.torch_aabb),
-                                   self.rng.state, self.rng.inc, N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['near']),
-                                   N.ptr(b['far']), R, st), 'march_count')
-        self.rng.advance()
-        # offsets (clamped to the capacity) and the dense width the reference would have used, max(2, max count)
-        N.check(L.arcn_exclusive_scan_i32(N.ptr(b['counts']), N.ptr(b['offsets']), R, self.cap, N.ptr(b['p_dense']), st), 'scan')
-        N.check(L.arcn_march_write(N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['offsets']), cfg.n_sample, N.ptr(b['t']),
-                                   N.ptr(b['ray_id']), R, self.cap, st), 'march_write')
+        if self.march_fused:
+            # bounds + marching + chained scan + compaction in one launch, no dense (R, n_sample) scratch
+            N.check(L.arcn_march_packed(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
+                                        int(self.packed_bits), cfg.n_sample, cfg.dt, cfg.near_distance, int(self.torch_aabb),
+                                        self.rng.state, self.rng.inc, N.ptr(b['counts']), N.ptr(b['near']), N.ptr(b['far']),
+                                        N.ptr(b['offsets']), N.ptr(b['t']), N.ptr(b['ray_id']), self.cap, N.ptr(b['p_dense']),
+                                        N.ptr(b['march_ws']), R, st), 'march_packed')
+            self.rng.advance()
+        else:
+            N.check(L.arcn_march_count(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
+                                       int(self.packed_bits), cfg.n_sample, cfg.dt, cfg.near_distance, int(self.torch_aabb),
+                                       self.rng.state, self.rng.inc, N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['near']),
+                                       N.ptr(b['far']), R, st), 'march_count')
+            self.rng.advance()
+            # offsets (clamped to the capacity) and the dense width the reference would have used, max(2, max count)
+            N.check(L.arcn_exclusive_scan_i32(N.ptr(b['counts']), N.ptr(b['offsets']), R, self.cap, N.ptr(b['p_dense']), st), 'scan')
+            N.check(L.arcn_march_write(N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['offsets']), cfg.n_sample, N.ptr(b['t']),
+                                       N.ptr(b['ray_id']), R, self.cap, st), 'march_write')
         N.check(L.arcn_packed_points(N.ptr(rays_o), N.ptr(rays_d), N.ptr(b['t']), N.ptr(b['ray_id']), N.ptr(b['xyz']),
                                      N.ptr(b['dirs']), self.cap, b['offsets'][R:R + 1].data_ptr(), st), 'packed_points')
         if self.ray_sh:

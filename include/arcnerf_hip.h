@@ -158,6 +158,15 @@ int arcn_march_count(const float *rays_o, const float *rays_d, const float *aabb
                      int bitfield_is_packed, int n_pts, float dt, float near_distance, int aabb_torch_semantics,
                      uint64_t rng_state, uint64_t rng_inc, float *scratch_t, int32_t *counts, float *near_out,
                      float *far_out, int64_t n_rays, void *stream);
+/* The three passes above in ONE launch (no dense scratch): a wave keeps its ray's samples in LDS, the workgroups' counts go through a
+ * chained scan (decoupled look-back, ray blocks handed out by ticket), the waves copy their samples to their final offsets.
+ * Same outputs as the three-pass form, bit for bit (offsets clamped to `capacity`, p_dense = largest per-ray count).
+ * workspace: arcn_march_packed_workspace_bytes(n_rays) bytes of device memory (zeroed by the call). */
+int64_t arcn_march_packed_workspace_bytes(int64_t n_rays);
+int arcn_march_packed(const float *rays_o, const float *rays_d, const float *aabb, int n_grid, const uint8_t *bitfield,
+                      int bitfield_is_packed, int n_pts, float dt, float near_distance, int aabb_torch_semantics, uint64_t rng_state,
+                      uint64_t rng_inc, int32_t *counts, float *near_out, float *far_out, int32_t *offsets, float *t_packed,
+                      int32_t *ray_id, int64_t capacity, int32_t *p_dense, void *workspace, int64_t n_rays, void *stream);
 int arcn_exclusive_scan_i32(const int32_t *counts, int32_t *offsets, int64_t n, int64_t max_total, int32_t *max_out,
                             void *stream);
 int arcn_march_write(const float *scratch_t, const int32_t *counts, const int32_t *offsets, int n_pts, float *t_packed,

@@ -336,3 +336,33 @@ def test_prefetched_marching_equals_inline_marching(gpu, depth):
     assert len(marched) == steps + depth
     assert marched[:2 * depth:2] == [batches[i][0].data_ptr() for i in range(depth)]
     assert len(ahead._prefetched) == depth
+
+
+@pytest.mark.parametrize('R,cap', [(1, 1 << 12), (7, 1 << 12), (1001, 1 << 16), (4096, 1 << 18), (4096, 9000)])
+def test_fused_marcher_equals_three_pass_form(gpu, R, cap):
+    """arcn_march_packed (marching + chained look-back scan + compaction in one launch, samples staged in LDS) against
+    arcn_march_count + arcn_exclusive_scan_i32 + arcn_march_write: counts, offsets (incl. the clamp to the capacity), t, ray_id, near /
+    far and the dense width bit for bit - for a single ray, ragged ray counts and an overflowing capacity."""
+    from arcnerf_amd import _native as N
+    from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline, synthetic_bitfield, synthetic_rays
+    cfg = NgpConfig(n_levels=4, hashmap_size=12, max_res=64, n_grid=64, n_sample=512, noise_std=0.0)
+    fld = NgpField(cfg, device=gpu, seed=0)
+    bf = torch.from_numpy(synthetic_bitfield(cfg.n_grid, 0.15, seed=8))
+    o, d = synthetic_rays(R, seed=R, device=gpu)
+    outs = []
+    for fused in (True, False):
+        pipe = NgpPipeline(fld, max_rays=4096, max_samples=cap)
+        pipe.march_fused = fused
+        pipe.set_bitfield(bf)
+        pipe.sample(o, d)
+        torch.cuda.synchronize()
+        n = int(pipe.n_dev.item())
+        b = pipe.buf
+        outs.append((n, b['counts'][:R].clone(), b['offsets'][:R + 1].clone(), b['t'][:n].clone(), b['ray_id'][:n].clone(),
+                     b['near'][:R].clone(), b['far'][:R].clone(), int(b['p_dense'].item())))
+    a, c = outs
+    assert a[0] == c[0] and a[0] > 0 and a[7] == c[7]
+    for x, y in zip(a[1:7], c[1:7]):
+        assert torch.equal(x, y)
+    if cap == 9000:
+        assert a[0] == 9000      # clamped
