@@ -135,14 +135,15 @@ gemm_rows_kernel(const float *__restrict__ in, const float *__restrict__ mask, i
             if (!TRANS_W) {
                 const int nl = f >> 3, kq = f & 7;
                 const int t = kq >> 2, g = kq & 3;
-                *reinterpret_cast<gf4 *>(&Ws[buf][(((nl >> 4) * 2 + t) * 64 + g * 16 + ((nl & 15) ^ (4 * t + g))) * 4]) = wr[q];
+                *reinterpret_cast<gf4 *>(&Ws[buf][(((nl >> 4) * 2 + t) * 64 + g * 16 + ((nl & 15) ^ (4 * t + g) ^ ((nl >> 4) & 3))) * 4]) = wr[q];
             } else {
                 const int kk = f / (BN / 4), nq = f % (BN / 4);
                 const int t = kk >> 4, g = (kk & 15) >> 2, ks = kk & 3;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int nl = 4 * nq + r;
-                    Ws[buf][(((nl >> 4) * 2 + t) * 64 + g * 16 + ((nl & 15) ^ (4 * t + g))) * 4 + ks] = wr[q][r];
+                    // (+ the tile index in the swizzle: the transposed staging writes 4-byte words, 32 lanes of one (t, g, ks))
+                    Ws[buf][(((nl >> 4) * 2 + t) * 64 + g * 16 + ((nl & 15) ^ (4 * t + g) ^ ((nl >> 4) & 3))) * 4 + ks] = wr[q][r];
                 }
             }
         }
@@ -165,7 +166,8 @@ gemm_rows_kernel(const float *__restrict__ in, const float *__restrict__ mask, i
             gf4 a[MT], b[NT];
             const int sw = (lane & 48) + ((lane & 15) ^ (4 * t + (lane >> 4)));   // swizzled slot of lane (g, i)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const gf4 *>(&Ws[buf][(((wave_n * MT + m) * 2 + t) * 64 + sw) * 4]);
+            for (int m = 0; m < MT; ++m)
+                a[m] = *reinterpret_cast<const gf4 *>(&Ws[buf][(((wave_n * MT + m) * 2 + t) * 64 + (sw ^ ((wave_n * MT + m) & 3))) * 4]);
 #pragma unroll
             for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const gf4 *>(&Xs[buf][(((wave_m * NT + n) * 2 + t) * 64 + sw) * 4]);
 #pragma unroll
@@ -284,7 +286,8 @@ gemm_tn_kernel(const float *__restrict__ A, const float *__restrict__ mask, int6
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int nl = 4 * nq + r;
-                As[buf][(((nl >> 4) * 2 + t) * 64 + g * 16 + (nl & 15)) * 4 + ks] = ar[q][r];
+                // feature slot XOR-swizzled with the tile index: the 32 lanes of a store spread over 16 bank groups instead of 4
+                As[buf][(((nl >> 4) * 2 + t) * 64 + g * 16 + ((nl & 15) ^ ((nl >> 4) & 3))) * 4 + ks] = ar[q][r];
             }
         }
 #pragma unroll
@@ -294,7 +297,7 @@ gemm_tn_kernel(const float *__restrict__ A, const float *__restrict__ mask, int6
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int kl = 4 * kq + r;
-                Bs[buf][(((kl >> 4) * 2 + t) * 64 + g * 16 + (kl & 15)) * 4 + ks] = br[q][r];
+                Bs[buf][(((kl >> 4) * 2 + t) * 64 + g * 16 + ((kl & 15) ^ ((kl >> 4) & 3))) * 4 + ks] = br[q][r];
             }
         }
     };
@@ -310,9 +313,11 @@ gemm_tn_kernel(const float *__restrict__ A, const float *__restrict__ mask, int6
         for (int t = 0; t < 2; ++t) {
             gf4 a[MT], b[NT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const gf4 *>(&As[buf][(((wave_n * MT + m) * 2 + t) * 64 + lane) * 4]);
+            for (int m = 0; m < MT; ++m)
+                a[m] = *reinterpret_cast<const gf4 *>(&As[buf][(((wave_n * MT + m) * 2 + t) * 64 + (lane & 48) + ((lane & 15) ^ ((wave_n * MT + m) & 3))) * 4]);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const gf4 *>(&Bs[buf][(((wave_k * NT + n) * 2 + t) * 64 + lane) * 4]);
+            for (int n = 0; n < NT; ++n)
+                b[n] = *reinterpret_cast<const gf4 *>(&Bs[buf][(((wave_k * NT + n) * 2 + t) * 64 + (lane & 48) + ((lane & 15) ^ ((wave_k * NT + n) & 3))) * 4]);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
