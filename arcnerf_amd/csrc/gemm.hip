@@ -374,6 +374,214 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(const float *__rest
     }
 }
 
+// ---- split-bf16 forms: f32 operands as three bf16 planes, six bf16 MFMAs per product ------------------------------------------------
+// The f32 MFMA runs at 1/16 of the bf16 rate (157 vs 2500 TFLOP/s).  An f32 value is EXACTLY hi + mid + lo with three bf16 numbers
+// (8 + 8 + 8 significand bits, the exponent range of f32): hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), every subtraction
+// exact.  A product a.b then needs the six partial products down to 2^-16 of it -- hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid -- each
+// exact in the matrix core's f32 accumulation; what is dropped (mid.lo, lo.mid, lo.lo) is < 2^-24 |a b|, i.e. below the rounding of
+// an f32 multiply.  Six v_mfma_f32_16x16x32_bf16 (16 cycles each) replace eight v_mfma_f32_16x16x4_f32 (32 cycles each) per 32
+// reduction elements: 2.67 x the matrix rate at f32 accuracy (tests/test_gpu_kernels.py::test_gemm_products_vs_float64).  The cost is
+// the split itself (5.5 VALU operations per element, once per staged element) and 6 instead of 4 LDS bytes per element.
+// Inf / NaN inputs give NaN (inf - inf in the split) where an f32 product might give inf.
+typedef uint32_t gu4 __attribute__((ext_vector_type(4)));
+typedef __bf16 gbf8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// eight consecutive reduction elements -> their three bf16 planes (16 bytes each)
+__device__ __forceinline__ void split3(const float (&x)[8], gu4 &hi, gu4 &mid, gu4 &lo) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float x0 = x[2 * p], x1 = x[2 * p + 1];
+        const uint32_t h = pk_bf16(x0, x1);
+        const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+        const uint32_t m = pk_bf16(r0, r1);
+        const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+        hi[p] = h;
+        mid[p] = m;
+        lo[p] = pk_bf16(s0, s1);
+    }
+}
+
+__device__ __forceinline__ gf4 mfma_bf16(const gu4 &a, const gu4 &b, const gf4 &c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gbf8, a), __builtin_bit_cast(gbf8, b), c, 0, 0, 0);
+}
+
+// the six partial products, smallest first, of MT x 1 tiles: planes 0 / 1 / 2 = hi / mid / lo
+#define ARCN_SPLIT_TERMS(OP)  OP(0, 2) OP(2, 0) OP(1, 1) OP(0, 1) OP(1, 0) OP(0, 0)
+
+// weight operand, split once per call into MFMA fragment order: Wf[((c * tiles + m) * 3 + plane) * 64 + lane], lane (g, i) = the
+// reduction elements 32 c + 4 g + 0..3 and 32 c + 16 + 4 g + 0..3 of output feature 16 m + i (zero outside the matrix).  (Which eight
+// elements a lane group holds is free as long as both operands agree; this choice lets four neighbouring lanes of the sample operand's
+// loads cover 64 contiguous bytes of a row.)
+__global__ void __launch_bounds__(256) gemm_split_w_kernel(const float *__restrict__ W, int ld_w, int trans, int No, int Ki, gu4 *__restrict__ out) {
+    const int tiles = (No + 15) / 16, chunks = (Ki + 31) / 32;
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= chunks * tiles) return;
+    const int c = idx / tiles, m = idx % tiles;
+    const int no = 16 * m + (lane & 15), k0 = 32 * c + 4 * (lane >> 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = k0 + (e < 4 ? e : 12 + e);
+        v[e] = (no < No && k < Ki) ? (trans ? W[(int64_t)k * ld_w + no] : W[(int64_t)no * ld_w + k]) : 0.f;
+    }
+    gu4 h, md, l;
+    split3(v, h, md, l);
+    out[((int64_t)idx * 3 + 0) * 64 + lane] = h;
+    out[((int64_t)idx * 3 + 1) * 64 + lane] = md;
+    out[((int64_t)idx * 3 + 2) * 64 + lane] = l;
+}
+
+// out (S, No) = act(in (S, Ki) . M + bias) with M given as Wf; 128 samples x 128 outputs per workgroup, waves 2 (outputs) x 2 (samples),
+// a wave owns 4 x 4 tiles.  The sample operand goes global -> registers -> split -> LDS (double buffered, 24 KB per stage), the weight
+// fragments go global (L2) -> registers, one stage ahead.  `in` rows must be 16-byte aligned, Ki a multiple of 4.
+template <bool MASK>
+__global__ void __launch_bounds__(256, 3)
+gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ mask, int64_t ld_in, const gu4 *__restrict__ Wf, const float *__restrict__ bias,
+                       float *__restrict__ out, int64_t ld_out, int64_t S, const int32_t *n_ptr, int Ki, int No, int act, float beta, int out_aligned) {
+    constexpr int MT = 4, NT = 4, BN = 128, BM = 128;
+    __shared__ __attribute__((aligned(16))) gu4 Xs[2][(BM / 16) * 3 * 64];
+    const int64_t cnt = dev_count(S, n_ptr);
+    const int64_t s_base = (int64_t)blockIdx.x * BM;
+    if (s_base >= cnt) return;
+    const int n_base = blockIdx.y * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_n = wave & 1, wave_m = wave >> 1;
+    const int tiles = (No + 15) / 16;
+    const int tile0 = blockIdx.y * (BN / 16) + wave_n * MT;
+    const int n_chunks = (Ki + 31) / 32;
+    // two register sets: the loads of stage c + 2 are issued before the MFMA block of stage c (two MFMA blocks to land in)
+    struct Staged {
+        gf4 x[2][2];
+        gf4 m[MASK ? 2 : 1][2];
+        uint32_t ok;
+    };
+    Staged ra;
+
+    auto fetch = [&](int c, Staged &st) {
+        st.ok = 0u;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f = tid + 256 * q, sl = f >> 2, g = f & 3;
+            const int col = 32 * c + 4 * g;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                st.x[q][h] = load_row4<true>(in, s_base + sl, col + 16 * h, ld_in, cnt, Ki, 1);
+                if (MASK) st.m[q][h] = load_row4<true>(mask, s_base + sl, col + 16 * h, ld_in, cnt, Ki, 1);
+                st.ok |= (uint32_t)((s_base + sl < cnt) && (col + 16 * h < Ki)) << (2 * q + h);
+            }
+        }
+    };
+    auto stash = [&](int buf, const Staged &st) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f = tid + 256 * q, sl = f >> 2, g = f & 3;
+            float x[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = ((st.ok >> (2 * q + h)) & 1u) ? st.x[q][h][r] : 0.f;
+                    if (MASK) v = st.m[q][h][r] > 0.f ? v : 0.f;
+                    x[4 * h + r] = v;
+                }
+            gu4 hi, md, lo;
+            split3(x, hi, md, lo);
+            // slot of row i rotated by 4 g: the 16 lanes of one write phase (4 rows x 4 groups) land in 16 different 16-byte bank groups
+            gu4 *dst = &Xs[buf][(sl >> 4) * 192 + g * 16 + ((sl + 4 * g) & 15)];
+            dst[0] = hi;
+            dst[64] = md;
+            dst[128] = lo;
+        }
+    };
+    // (a tile past the last one re-reads the last: its products are never stored)
+    auto loadw = [&](int c, gu4 (&w)[MT][3]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int tile = tile0 + m < tiles ? tile0 + m : tiles - 1;
+            const gu4 *src = Wf + ((int64_t)(c * tiles + tile) * 3) * 64 + lane;
+            w[m][0] = src[0];
+            w[m][1] = src[64];
+            w[m][2] = src[128];
+        }
+    };
+
+    gf4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = gf4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf, const gu4 (&w)[MT][3]) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const gu4 *xb = &Xs[buf][(wave_m * NT + n) * 192 + (lane & 48) + ((lane + ((lane >> 4) << 2)) & 15)];
+            gu4 b[3];
+            b[0] = xb[0];
+            b[1] = xb[64];
+            b[2] = xb[128];
+#define ARCN_OP(PW, PX) _Pragma("unroll") for (int m = 0; m < MT; ++m) acc[m][n] = mfma_bf16(w[m][PW], b[PX], acc[m][n]);
+            ARCN_SPLIT_TERMS(ARCN_OP)
+#undef ARCN_OP
+        }
+    };
+
+    gu4 wa[MT][3];
+    fetch(0, ra);
+    stash(0, ra);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+        loadw(c, wa);
+        // unconditional (the last stage re-reads itself): with one path through the loads the compiler's vmcnt for the weight fragments
+        // leaves these four in flight over the MFMA block
+        __builtin_amdgcn_sched_barrier(0);   // (weights first: vmcnt retires in order, and the MFMAs wait for the weights only)
+        fetch(c + 1 < n_chunks ? c + 1 : c, ra);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(c & 1, wa);
+        // (unconditional as well: a conditional consumer lets the compiler sink the loads above down to it, behind the MFMA block)
+        stash((c + 1) & 1, ra);
+        __syncthreads();
+    }
+    // lane (g, j): outputs 16 mt + 4 g + 0..3 of sample 16 nt + j
+    const int g = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int no = n_base + (wave_n * MT + m) * 16 + 4 * g;
+        if (no >= No) continue;
+        gf4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            bv.x = bias[no];
+            if (no + 1 < No) bv.y = bias[no + 1];
+            if (no + 2 < No) bv.z = bias[no + 2];
+            if (no + 3 < No) bv.w = bias[no + 3];
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int64_t s = s_base + (wave_m * NT + n) * 16 + j;
+            if (s >= cnt) continue;
+            gf4 v = acc[m][n] + bv;
+            if (act != ARCN_ACT_NONE) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gemm_act(v[r], act, beta);
+            }
+            float *dst = out + s * ld_out + no;
+            if (out_aligned && no + 3 < No) *reinterpret_cast<gf4 *>(dst) = v;
+            else {
+                dst[0] = v.x;
+                if (no + 1 < No) dst[1] = v.y;
+                if (no + 2 < No) dst[2] = v.z;
+                if (no + 3 < No) dst[3] = v.w;
+            }
+        }
+    }
+}
+
 static inline int is_aligned(const void *p, int64_t ld) { return ((reinterpret_cast<uintptr_t>(p) & 15u) == 0 && (ld & 3) == 0) ? 1 : 0; }
 
 static int tn_slabs(int64_t S, int N, int K, int bn, int bk) {
@@ -434,6 +642,56 @@ ARCN_EXPORT int arcn_gemm_nt(const float *x, int64_t ld_x, const float *w, const
 ARCN_EXPORT int arcn_gemm_nn(const float *dy, const float *mask, int64_t ld_dy, const float *w, float *dx, int64_t ld_dx, int64_t n_rows,
                              const int32_t *n_ptr, int N, int K, void *stream) {
     return gemm_rows(true, dy, mask, ld_dy, w, K, nullptr, dx, ld_dx, n_rows, n_ptr, N, K, ARCN_ACT_NONE, 1.0f, stream);
+}
+
+/* bytes of the split-weight workspace of arcn_gemm_nt_split / arcn_gemm_nn_split for n_out output features and k_red reduction
+ * elements (three bf16 planes in MFMA fragment order, padded to 16 x 32 tiles) */
+ARCN_EXPORT int64_t arcn_gemm_split_bytes(int n_out, int k_red) {
+    if (n_out < 1 || k_red < 1) return 0;
+    return (int64_t)ceil_div<int>(k_red, 32) * ceil_div<int>(n_out, 16) * 3 * 64 * 16;
+}
+
+static int gemm_rows_split(bool trans_w, const float *in, const float *mask, int64_t ld_in, const float *W, int ld_w, const float *bias, float *out,
+                           int64_t ld_out, int64_t S, const int32_t *n_ptr, int Ki, int No, int act, float beta, void *ws, int64_t ws_bytes, void *stream) {
+    if (S <= 0) return ARCN_OK;
+    if (!in || !W || !out || !ws || Ki < 1 || No < 1) return einval("gemm_split: missing / invalid argument");
+    if (!is_aligned(in, ld_in) || (Ki & 3) != 0 || (reinterpret_cast<uintptr_t>(ws) & 15u) != 0 || (mask && !is_aligned(mask, ld_in)))
+        return einval("gemm_split: the row operand needs 16-byte aligned rows and a reduction length that is a multiple of 4");
+    if (ws_bytes < arcn_gemm_split_bytes(No, Ki)) return einval("gemm_split: workspace smaller than arcn_gemm_split_bytes");
+    // a ragged last block of <= 64 outputs (257 = 2 x 128 + 1) goes to the exact-f32 kernel's narrow tiles instead of a mostly empty
+    // 128-output block
+    const int rem = No % 128, No_main = (rem > 0 && rem <= 64 && No > 128) ? No - rem : No;
+    if (No_main < No) {
+        const float *Wr = trans_w ? W + No_main : W + (int64_t)No_main * ld_w;
+        const int rc = gemm_rows(trans_w, in, mask, ld_in, Wr, ld_w, bias ? bias + No_main : nullptr, out + No_main, ld_out, S, n_ptr, Ki, No - No_main, act, beta, stream);
+        if (rc != ARCN_OK) return rc;
+    }
+    dim3 grid((unsigned)ceil_div<int64_t>(S, 128), (unsigned)ceil_div<int>(No_main, 128));
+    const int oa = is_aligned(out, ld_out);
+    No = No_main;
+    const int frag_tiles = ceil_div<int>(Ki, 32) * ceil_div<int>(No, 16);
+    hipLaunchKernelGGL(gemm_split_w_kernel, dim3((unsigned)ceil_div<int>(frag_tiles, 4)), dim3(256), 0, as_stream(stream), W, ld_w, trans_w ? 1 : 0, No, Ki,
+                       reinterpret_cast<gu4 *>(ws));
+    if (mask)
+        hipLaunchKernelGGL((gemm_rows_split_kernel<true>), grid, dim3(256), 0, as_stream(stream), in, mask, ld_in, reinterpret_cast<const gu4 *>(ws), bias, out, ld_out,
+                           S, n_ptr, Ki, No, act, beta, oa);
+    else
+        hipLaunchKernelGGL((gemm_rows_split_kernel<false>), grid, dim3(256), 0, as_stream(stream), in, mask, ld_in, reinterpret_cast<const gu4 *>(ws), bias, out, ld_out,
+                           S, n_ptr, Ki, No, act, beta, oa);
+    return check_launch("gemm_rows_split");
+}
+
+/* arcn_gemm_nt on the bf16 matrix rate: x and w as three bf16 planes each, six MFMAs per product, f32 accuracy (see the kernel).  x rows
+ * 16-byte aligned, K a multiple of 4; `ws` = arcn_gemm_split_bytes(N, K) bytes of device scratch (the split weights). */
+ARCN_EXPORT int arcn_gemm_nt_split(const float *x, int64_t ld_x, const float *w, const float *bias, float *y, int64_t ld_y, int64_t n_rows,
+                                   const int32_t *n_ptr, int K, int N, int act, float beta, void *ws, int64_t ws_bytes, void *stream) {
+    return gemm_rows_split(false, x, nullptr, ld_x, w, K, bias, y, ld_y, n_rows, n_ptr, K, N, act, beta, ws, ws_bytes, stream);
+}
+
+/* arcn_gemm_nn likewise: dy rows 16-byte aligned, N a multiple of 4; `ws` = arcn_gemm_split_bytes(K, N) bytes. */
+ARCN_EXPORT int arcn_gemm_nn_split(const float *dy, const float *mask, int64_t ld_dy, const float *w, float *dx, int64_t ld_dx, int64_t n_rows,
+                                   const int32_t *n_ptr, int N, int K, void *ws, int64_t ws_bytes, void *stream) {
+    return gemm_rows_split(true, dy, mask, ld_dy, w, K, nullptr, dx, ld_dx, n_rows, n_ptr, N, K, ARCN_ACT_NONE, 1.0f, ws, ws_bytes, stream);
 }
 
 ARCN_EXPORT int64_t arcn_gemm_tn_scratch_floats(int64_t n_rows, int N, int K) {

@@ -4,6 +4,7 @@ torch is used for device memory and the current HIP stream only; every numerical
 gfx950 kernel in libarcnerf_hip.so.  All functions require CUDA(HIP) tensors and raise RuntimeError otherwise —
 there is deliberately no CPU fallback.
 """
+import os
 import ctypes as C
 
 import torch
@@ -535,6 +536,20 @@ def mlp_fwd(x, weights, biases, desc, save_acts=False, n_dev=None, out=None, act
 # ------------------------------------------------------------------------------------------------
 # dense layers of the wide nets: the three f32-MFMA products of csrc/gemm.hip
 # ------------------------------------------------------------------------------------------------
+# ARCN_GEMM_SPLIT=0: the exact-f32 MFMA kernels everywhere; 1 (default): layers with more than 64 outputs run on the bf16 matrix rate
+# with every operand split into three bf16 planes (six products, f32 accuracy; csrc/gemm.hip)
+_GEMM_SPLIT = os.environ.get('ARCN_GEMM_SPLIT', '1') != '0'
+_GEMM_SPLIT_MIN_OUT = int(os.environ.get('ARCN_GEMM_SPLIT_MIN_OUT', '65'))
+
+
+def _use_split(rows, k_red, n_out):
+    return _GEMM_SPLIT and n_out >= _GEMM_SPLIT_MIN_OUT and k_red % 4 == 0 and k_red >= 32 and rows.data_ptr() % 16 == 0
+
+
+def _split_ws(n_out, k_red, device):
+    return torch.empty(int(N.lib().arcn_gemm_split_bytes(n_out, k_red)), dtype=torch.uint8, device=device)
+
+
 def gemm_nt(x, w, bias=None, act=None, beta=1.0):
     """y (S,N) = act(x (S,K) @ w (N,K).T + bias)"""
     _req(x, w, bias)
@@ -543,6 +558,11 @@ def gemm_nt(x, w, bias=None, act=None, beta=1.0):
     Nn = w.shape[0]
     assert w.shape[1] == K
     y = torch.empty((S, Nn), dtype=torch.float32, device=x.device)
+    if _use_split(x, K, Nn):
+        ws = _split_ws(Nn, K, x.device)
+        N.check(N.lib().arcn_gemm_nt_split(N.ptr(x), K, N.ptr(w), N.ptr(bias), N.ptr(y), Nn, S, None, K, Nn, N.ACT[act], float(beta),
+                                         N.ptr(ws), ws.numel(), N.stream()), 'gemm_nt_split')
+        return y
     N.check(N.lib().arcn_gemm_nt(N.ptr(x), K, N.ptr(w), N.ptr(bias), N.ptr(y), Nn, S, None, K, Nn, N.ACT[act], float(beta), N.stream()), 'gemm_nt')
     return y
 
@@ -555,6 +575,11 @@ def gemm_nn(dy, w, mask=None):
     K = w.shape[1]
     assert w.shape[0] == Nn
     dx = torch.empty((S, K), dtype=torch.float32, device=dy.device)
+    if _use_split(dy, Nn, K):
+        ws = _split_ws(K, Nn, dy.device)
+        N.check(N.lib().arcn_gemm_nn_split(N.ptr(dy), N.ptr(mask), Nn, N.ptr(w), N.ptr(dx), K, S, None, Nn, K, N.ptr(ws), ws.numel(),
+                                         N.stream()), 'gemm_nn_split')
+        return dx
     N.check(N.lib().arcn_gemm_nn(N.ptr(dy), N.ptr(mask), Nn, N.ptr(w), N.ptr(dx), K, S, None, Nn, K, N.stream()), 'gemm_nn')
     return dx
 

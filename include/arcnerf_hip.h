@@ -298,6 +298,17 @@ int arcn_gemm_nn(const float *dy, const float *mask, int64_t ld_dy, const float 
 int64_t arcn_gemm_tn_scratch_floats(int64_t n_rows, int N, int K);
 int arcn_gemm_tn(const float *dy, const float *mask, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *scratch,
                  int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate, void *stream);
+/* The same three products on the bf16 matrix rate at f32 accuracy ("split" forms): every f32 operand is EXACTLY hi + mid + lo in three
+ * bf16 numbers, and the six partial products down to 2^-16 are accumulated in f32 (what is dropped is < 2^-24 of the product, below an
+ * f32 multiply's own rounding); 6 v_mfma_f32_16x16x32_bf16 replace 8 v_mfma_f32_16x16x4_f32 per 32 reduction elements (2.67 x the
+ * matrix rate).  Same meaning and layouts as above.  Requirements: row operands (x, dy, mask) with 16-byte aligned rows, reduction
+ * length (K for nt, N for nn) and, for tn, N and K multiples of 4; `ws` = device scratch of arcn_gemm_split_bytes(outputs, reduction
+ * length) bytes that receives the split weights (nt: (N, K), nn: (K, N)).  Inf / NaN operands give NaN. */
+int64_t arcn_gemm_split_bytes(int n_out, int k_red);
+int arcn_gemm_nt_split(const float *x, int64_t ld_x, const float *w, const float *bias, float *y, int64_t ld_y, int64_t n_rows,
+                       const int32_t *n_ptr, int K, int N, int act, float beta, void *ws, int64_t ws_bytes, void *stream);
+int arcn_gemm_nn_split(const float *dy, const float *mask, int64_t ld_dy, const float *w, float *dx, int64_t ld_dx, int64_t n_rows,
+                       const int32_t *n_ptr, int N, int K, void *ws, int64_t ws_bytes, void *stream);
 /* The same network with a LEVEL-MAJOR input / input gradient: x_lm[(l * x_stride + s) * 2 + f], 2 features per level (what
  * arcn_hashgrid_fwd_xcd(level_major = 1) writes and arcn_hashgrid_bwd_lm consumes).  Wired for the bias-free 2-layer nets fed by
  * the hash grid (input 32 or 64 wide, hidden <= 64, output <= 16); -1 otherwise.  bwd: dx_lm in the layout of x_lm, dweights
