@@ -582,6 +582,140 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
     }
 }
 
+// partial (slab, N, K) = sum over the slab's samples of A (S,N)^T . B (S,K), split form.  128 x 128 outputs per workgroup (waves 2 x 2,
+// 4 x 4 tiles each), 32 samples per stage.  The reduction runs over SAMPLES, so a lane group's eight reduction elements are eight
+// rows of the operands: a thread loads the same four features of eight consecutive samples (eight 16-byte loads; 32 lanes cover 512
+// contiguous bytes of a row), which is four fragments' worth of eight-sample columns in its own registers -- the transposition costs
+// nothing -- splits them and writes 16-byte fragment slots.  One LDS stage (48 KB: three workgroups per CU) with the next stage's loads
+// in flight over the MFMA block.  Rows 16-byte aligned, N and K multiples of 4.
+template <bool MASK>
+__global__ void __launch_bounds__(256, MASK ? 2 : 3)
+gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask, int64_t ld_a, const float *__restrict__ B, int64_t ld_b, float *__restrict__ scratch,
+                     int64_t S, const int32_t *n_ptr, int N, int K, int n_slabs) {
+    constexpr int MT = 4, NT = 4, BN = 128, BKo = 128, BS = 32;
+    __shared__ __attribute__((aligned(16))) gu4 Ls[2 * 8 * 192];   // [operand][feature tile][plane][g][feature slot]
+    const int64_t cnt = dev_count(S, n_ptr);
+    const int slab = blockIdx.x;
+    const int tiles_k = (K + BKo - 1) / BKo;
+    const int tn = blockIdx.y / tiles_k, tk = blockIdx.y % tiles_k;
+    const int n_base = tn * BN, k_base = tk * BKo;
+    const int64_t per = ((cnt + n_slabs - 1) / n_slabs + BS - 1) / BS * BS;
+    const int64_t s_lo = (int64_t)slab * per, s_hi = (s_lo + per < cnt) ? s_lo + per : cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_n = wave & 1, wave_k = wave >> 1;
+    // staging role: waves 0, 1 the A operand, waves 2, 3 the B operand; unit = (feature quad, sample octet)
+    const bool is_b = wave >= 2;
+    const float *__restrict__ src = is_b ? B : A;
+    const int64_t ld_s = is_b ? ld_b : ld_a;
+    const int f_base = is_b ? k_base : n_base, f_cnt = is_b ? K : N;
+    const int unit = tid & 127, nq = unit & 31, sg = unit >> 5;
+    const int fcol = (f_base + 4 * nq < f_cnt) ? f_base + 4 * nq : 0;   // features past the matrix: any valid column (never stored)
+    gf4 xr[8];
+    gf4 mr[MASK ? 8 : 1];
+    uint32_t ok = 0u;
+    const int64_t n_chunks = s_lo < s_hi ? (s_hi - s_lo + BS - 1) / BS : 0;
+
+    // (uniform stage base + one 32-bit byte offset per row: half the address registers of eight 64-bit pointers)
+    auto fetch = [&](int64_t c) {
+        ok = 0u;
+        const int64_t row0 = s_lo + c * BS;
+        const char *base = reinterpret_cast<const char *>(src + row0 * ld_s);
+        const char *mbase = reinterpret_cast<const char *>(mask + row0 * ld_s);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool in = row0 + 8 * sg + e < s_hi;
+            const uint32_t off = (uint32_t)(((in ? 8 * sg + e : 0) * ld_s + fcol) * 4);
+            xr[e] = *reinterpret_cast<const gf4 *>(base + off);
+            if (MASK) mr[e] = *reinterpret_cast<const gf4 *>((is_b ? base : mbase) + off);
+            ok |= (uint32_t)in << e;
+        }
+    };
+    auto stash = [&]() {
+        gu4 *blk = &Ls[(is_b ? 8 * 192 : 0) + (nq >> 2) * 192 + sg * 16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = ((ok >> e) & 1u) ? xr[e][r] : 0.f;
+                if (MASK) v = (is_b || mr[e][r] > 0.f) ? v : 0.f;
+                x[e] = v;
+            }
+            gu4 hi, md, lo;
+            split3(x, hi, md, lo);
+            // feature slot rotated by the tile index: the 16 lanes of a write phase (4 tiles x 4 quads) hit 16 different bank groups
+            gu4 *dst = blk + ((4 * (nq & 3) + r + (nq >> 2)) & 15);
+            dst[0] = hi;
+            dst[64] = md;
+            dst[128] = lo;
+            __builtin_amdgcn_sched_barrier(0);   // one feature at a time: interleaving the four splits costs 36 more live registers
+        }
+    };
+
+    gf4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = gf4{0.f, 0.f, 0.f, 0.f};
+
+    // output tiles in two halves of 2 x 4: 24 registers of A fragments instead of 48 (the B fragments are read twice)
+    auto compute = [&]() {
+#pragma unroll
+        for (int mh = 0; mh < MT; mh += 2) {
+            gu4 a[2][3];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int tile = wave_n * MT + mh + m;
+                const gu4 *ab = &Ls[tile * 192 + (lane & 48) + ((lane + tile) & 15)];
+                a[m][0] = ab[0];
+                a[m][1] = ab[64];
+                a[m][2] = ab[128];
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int tile = wave_k * NT + n;
+                const gu4 *bb = &Ls[8 * 192 + tile * 192 + (lane & 48) + ((lane + tile) & 15)];
+                gu4 b[3];
+                b[0] = bb[0];
+                b[1] = bb[64];
+                b[2] = bb[128];
+#define ARCN_OP(PW, PX) _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[mh + m][n] = mfma_bf16(a[m][PW], b[PX], acc[mh + m][n]);
+                ARCN_SPLIT_TERMS(ARCN_OP)
+#undef ARCN_OP
+            }
+        }
+    };
+
+    if (n_chunks > 0) {
+        fetch(0);
+        stash();
+        __syncthreads();
+        for (int64_t c = 0; c < n_chunks; ++c) {
+            fetch(c + 1 < n_chunks ? c + 1 : c);   // (unconditional, like the consumers below: see gemm_rows_split_kernel)
+            __builtin_amdgcn_sched_barrier(0);
+            compute();
+            __syncthreads();
+            stash();
+            __syncthreads();
+        }
+    }
+    // lane (g, j): rows n = 16 mt + 4 g + r, column k = 16 nt + j
+    const int g = lane >> 4, j = lane & 15;
+    float *dst = scratch + (int64_t)slab * N * K;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int k = k_base + (wave_k * NT + n) * 16 + j;
+            if (k >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = n_base + (wave_n * MT + m) * 16 + 4 * g + r;
+                if (row < N) dst[(int64_t)row * K + k] = acc[m][n][r];
+            }
+        }
+}
+
 static inline int is_aligned(const void *p, int64_t ld) { return ((reinterpret_cast<uintptr_t>(p) & 15u) == 0 && (ld & 3) == 0) ? 1 : 0; }
 
 static int tn_slabs(int64_t S, int N, int K, int bn, int bk) {
@@ -658,9 +792,9 @@ static int gemm_rows_split(bool trans_w, const float *in, const float *mask, int
     if (!is_aligned(in, ld_in) || (Ki & 3) != 0 || (reinterpret_cast<uintptr_t>(ws) & 15u) != 0 || (mask && !is_aligned(mask, ld_in)))
         return einval("gemm_split: the row operand needs 16-byte aligned rows and a reduction length that is a multiple of 4");
     if (ws_bytes < arcn_gemm_split_bytes(No, Ki)) return einval("gemm_split: workspace smaller than arcn_gemm_split_bytes");
-    // a ragged last block of <= 64 outputs (257 = 2 x 128 + 1) goes to the exact-f32 kernel's narrow tiles instead of a mostly empty
-    // 128-output block
-    const int rem = No % 128, No_main = (rem > 0 && rem <= 64 && No > 128) ? No - rem : No;
+    // a ragged last block of <= 16 outputs (257 = 2 x 128 + 1) goes to the exact-f32 kernel's 16-output tiles (one more pass over the
+    // rows, memory bound) instead of a nearly empty 128-output block; a wider remainder is cheaper as a partly empty block
+    const int rem = No % 128, No_main = (rem > 0 && rem <= 16 && No > 128) ? No - rem : No;
     if (No_main < No) {
         const float *Wr = trans_w ? W + No_main : W + (int64_t)No_main * ld_w;
         const int rc = gemm_rows(trans_w, in, mask, ld_in, Wr, ld_w, bias ? bias + No_main : nullptr, out + No_main, ld_out, S, n_ptr, Ki, No - No_main, act, beta, stream);
@@ -731,3 +865,26 @@ ARCN_EXPORT int arcn_gemm_tn(const float *dy, const float *mask, int64_t ld_dy, 
                        n_elem, slabs, accumulate);
     return check_launch("gemm_tn");
 }
+
+/* arcn_gemm_tn on the bf16 matrix rate (split form, see arcn_gemm_nt_split): same arguments and scratch; dy, mask and x rows 16-byte
+ * aligned, N and K multiples of 4. */
+ARCN_EXPORT int arcn_gemm_tn_split(const float *dy, const float *mask, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *scratch,
+                                   int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate, void *stream) {
+    if (!dy || !x || !dw || !scratch || N < 1 || K < 1) return einval("gemm_tn_split: missing / invalid argument");
+    if (scratch_floats < arcn_gemm_tn_scratch_floats(n_rows, N, K)) return einval("gemm_tn_split: scratch smaller than arcn_gemm_tn_scratch_floats");
+    if (!is_aligned(dy, ld_dy) || !is_aligned(x, ld_x) || (N & 3) != 0 || (K & 3) != 0 || (mask && !is_aligned(mask, ld_dy)))
+        return einval("gemm_tn_split: operands need 16-byte aligned rows and feature counts that are multiples of 4");
+    if (N <= 64 && K <= 64) return arcn_gemm_tn(dy, mask, ld_dy, x, ld_x, dw, scratch, scratch_floats, n_rows, n_ptr, N, K, accumulate, stream);
+    int slabs = 0;
+    if (n_rows > 0) {
+        slabs = tn_slabs(n_rows, N, K, 128, 128);
+        dim3 grid((unsigned)slabs, (unsigned)(ceil_div<int>(N, 128) * ceil_div<int>(K, 128)));
+        if (mask) hipLaunchKernelGGL((gemm_tn_split_kernel<true>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs);
+        else hipLaunchKernelGGL((gemm_tn_split_kernel<false>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs);
+    }
+    const int64_t n_elem = (int64_t)N * K;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ceil_div<int64_t>(n_elem, 64)), dim3(256), 0, as_stream(stream), scratch, dw,
+                       n_elem, slabs, accumulate);
+    return check_launch("gemm_tn_split");
+}
+

@@ -594,7 +594,9 @@ def gemm_tn(dy, x, mask=None):
     dw = torch.empty((Nn, K), dtype=torch.float32, device=dy.device)
     nf = max(1, int(N.lib().arcn_gemm_tn_scratch_floats(S, Nn, K)))
     scratch = torch.empty(nf, dtype=torch.float32, device=dy.device)
-    N.check(N.lib().arcn_gemm_tn(N.ptr(dy), N.ptr(mask), Nn, N.ptr(x), K, N.ptr(dw), N.ptr(scratch), nf, S, None, Nn, K, 0, N.stream()), 'gemm_tn')
+    split = _GEMM_SPLIT and (Nn > 64 or K > 64) and Nn % 4 == 0 and K % 4 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+    fn = N.lib().arcn_gemm_tn_split if split else N.lib().arcn_gemm_tn
+    N.check(fn(N.ptr(dy), N.ptr(mask), Nn, N.ptr(x), K, N.ptr(dw), N.ptr(scratch), nf, S, None, Nn, K, 0, N.stream()), 'gemm_tn')
     return dw
 
 
