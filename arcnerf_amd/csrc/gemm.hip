@@ -419,7 +419,7 @@ __device__ __forceinline__ gf4 mfma_bf16(const gu4 &a, const gu4 &b, const gf4 &
 // elements a lane group holds is free as long as both operands agree; this choice lets four neighbouring lanes of the sample operand's
 // loads cover 64 contiguous bytes of a row.)
 __global__ void __launch_bounds__(256) gemm_split_w_kernel(const float *__restrict__ W, int ld_w, int trans, int No, int Ki, gu4 *__restrict__ out) {
-    const int tiles = (No + 15) / 16, chunks = (Ki + 31) / 32;
+    const int tiles = (No + 15) / 16, chunks = (Ki + 31) / 32 + 1;   // + one all-zero stage (k >= Ki)
     const int lane = threadIdx.x & 63;
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx >= chunks * tiles) return;
@@ -441,20 +441,24 @@ __global__ void __launch_bounds__(256) gemm_split_w_kernel(const float *__restri
 // out (S, No) = act(in (S, Ki) . M + bias) with M given as Wf; 128 samples x 128 outputs per workgroup, waves 2 (outputs) x 2 (samples),
 // a wave owns 4 x 4 tiles.  The sample operand goes global -> registers -> split -> LDS (double buffered, 24 KB per stage), the weight
 // fragments go global (L2) -> registers, one stage ahead.  `in` rows must be 16-byte aligned, Ki a multiple of 4.
-template <bool MASK>
-__global__ void __launch_bounds__(256, 3)
+// (MT, NT, WAVES_N) = (2, 8, 4): 128 outputs per workgroup, three workgroups per CU; (4, 8, 4): 256 outputs -- the sample operand is
+// read, split and staged once for twice the MFMAs (128 accumulator registers, two workgroups per CU).  The kernel covers the outputs
+// [n_off, min(n_off + gridDim.y * BN, No)).
+template <bool MASK, int MT, int NT, int WAVES_N>
+__global__ void __launch_bounds__(256, (MASK || MT * NT > 16) ? 2 : 3)
 gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ mask, int64_t ld_in, const gu4 *__restrict__ Wf, const float *__restrict__ bias,
-                       float *__restrict__ out, int64_t ld_out, int64_t S, const int32_t *n_ptr, int Ki, int No, int act, float beta, int out_aligned) {
-    constexpr int MT = 4, NT = 4, BN = 128, BM = 128;
+                       float *__restrict__ out, int64_t ld_out, int64_t S, const int32_t *n_ptr, int Ki, int No, int n_off, int act, float beta, int out_aligned) {
+    constexpr int BN = 16 * MT * WAVES_N, BM = 128;
+    static_assert(16 * NT * (4 / WAVES_N) == BM, "the staging below is written for 128 samples per workgroup");
     __shared__ __attribute__((aligned(16))) gu4 Xs[2][(BM / 16) * 3 * 64];
     const int64_t cnt = dev_count(S, n_ptr);
     const int64_t s_base = (int64_t)blockIdx.x * BM;
     if (s_base >= cnt) return;
-    const int n_base = blockIdx.y * BN;
+    const int n_base = n_off + blockIdx.y * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_n = wave & 1, wave_m = wave >> 1;
+    const int wave_n = wave % WAVES_N, wave_m = wave / WAVES_N;
     const int tiles = (No + 15) / 16;
-    const int tile0 = blockIdx.y * (BN / 16) + wave_n * MT;
+    const int tile0 = n_base / 16 + wave_n * MT;
     const int n_chunks = (Ki + 31) / 32;
     // two register sets: the loads of stage c + 2 are issued before the MFMA block of stage c (two MFMA blocks to land in)
     struct Staged {
@@ -462,7 +466,7 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
         gf4 m[MASK ? 2 : 1][2];
         uint32_t ok;
     };
-    Staged ra;
+    Staged ra, rb;
 
     auto fetch = [&](int c, Staged &st) {
         st.ok = 0u;
@@ -498,6 +502,7 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
             dst[0] = hi;
             dst[64] = md;
             dst[128] = lo;
+            if (MT * NT > 16) __builtin_amdgcn_sched_barrier(0);   // (one unit at a time where registers are short)
         }
     };
     // (a tile past the last one re-reads the last: its products are never stored)
@@ -532,20 +537,34 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
         }
     };
 
+    // Two stages per trip with two register sets: the loads of stage c + 2 are issued before the MFMA block of stage c and consumed after
+    // the MFMA block of stage c + 1.  Everything in the loop is unconditional -- a conditional consumer lets the compiler sink the loads
+    // down to it, behind the MFMA block -- so a stage past the end re-reads the last stage (clamped) against the all-zero weight stage
+    // that the split kernel appends (Wf stage n_chunks), and an odd stage count costs one idle MFMA block.
+    // (the masked 256-output form has no registers for the second set: one set, loads one MFMA block ahead)
+    constexpr bool TWO = !(MASK && MT * NT > 16);
+    constexpr int D = TWO ? 2 : 1;
+    Staged &r_odd = TWO ? rb : ra;
+    const int last = n_chunks - 1;
     gu4 wa[MT][3];
     fetch(0, ra);
+    if (TWO) fetch(last < 1 ? last : 1, rb);
     stash(0, ra);
     __syncthreads();
-    for (int c = 0; c < n_chunks; ++c) {
+    for (int c = 0; c < n_chunks; c += 2) {
         loadw(c, wa);
-        // unconditional (the last stage re-reads itself): with one path through the loads the compiler's vmcnt for the weight fragments
-        // leaves these four in flight over the MFMA block
         __builtin_amdgcn_sched_barrier(0);   // (weights first: vmcnt retires in order, and the MFMAs wait for the weights only)
-        fetch(c + 1 < n_chunks ? c + 1 : c, ra);
+        fetch(c + D < last ? c + D : last, ra);
         __builtin_amdgcn_sched_barrier(0);
-        compute(c & 1, wa);
-        // (unconditional as well: a conditional consumer lets the compiler sink the loads above down to it, behind the MFMA block)
-        stash((c + 1) & 1, ra);
+        compute(0, wa);
+        stash(1, r_odd);
+        __syncthreads();
+        loadw(c + 1, wa);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(c + 1 + D < last ? c + 1 + D : last, r_odd);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1, wa);
+        stash(0, ra);
         __syncthreads();
     }
     // lane (g, j): outputs 16 mt + 4 g + 0..3 of sample 16 nt + j
@@ -782,7 +801,7 @@ ARCN_EXPORT int arcn_gemm_nn(const float *dy, const float *mask, int64_t ld_dy, 
  * elements (three bf16 planes in MFMA fragment order, padded to 16 x 32 tiles) */
 ARCN_EXPORT int64_t arcn_gemm_split_bytes(int n_out, int k_red) {
     if (n_out < 1 || k_red < 1) return 0;
-    return (int64_t)ceil_div<int>(k_red, 32) * ceil_div<int>(n_out, 16) * 3 * 64 * 16;
+    return (int64_t)(ceil_div<int>(k_red, 32) + 1) * ceil_div<int>(n_out, 16) * 3 * 64 * 16;
 }
 
 static int gemm_rows_split(bool trans_w, const float *in, const float *mask, int64_t ld_in, const float *W, int ld_w, const float *bias, float *out,
@@ -792,26 +811,40 @@ static int gemm_rows_split(bool trans_w, const float *in, const float *mask, int
     if (!is_aligned(in, ld_in) || (Ki & 3) != 0 || (reinterpret_cast<uintptr_t>(ws) & 15u) != 0 || (mask && !is_aligned(mask, ld_in)))
         return einval("gemm_split: the row operand needs 16-byte aligned rows and a reduction length that is a multiple of 4");
     if (ws_bytes < arcn_gemm_split_bytes(No, Ki)) return einval("gemm_split: workspace smaller than arcn_gemm_split_bytes");
-    // a ragged last block of <= 16 outputs (257 = 2 x 128 + 1) goes to the exact-f32 kernel's 16-output tiles (one more pass over the
-    // rows, memory bound) instead of a nearly empty 128-output block; a wider remainder is cheaper as a partly empty block
-    const int rem = No % 128, No_main = (rem > 0 && rem <= 16 && No > 128) ? No - rem : No;
-    if (No_main < No) {
-        const float *Wr = trans_w ? W + No_main : W + (int64_t)No_main * ld_w;
-        const int rc = gemm_rows(trans_w, in, mask, ld_in, Wr, ld_w, bias ? bias + No_main : nullptr, out + No_main, ld_out, S, n_ptr, Ki, No - No_main, act, beta, stream);
-        if (rc != ARCN_OK) return rc;
-    }
-    dim3 grid((unsigned)ceil_div<int64_t>(S, 128), (unsigned)ceil_div<int>(No_main, 128));
-    const int oa = is_aligned(out, ld_out);
-    No = No_main;
-    const int frag_tiles = ceil_div<int>(Ki, 32) * ceil_div<int>(No, 16);
+    const int frag_tiles = (ceil_div<int>(Ki, 32) + 1) * ceil_div<int>(No, 16);
     hipLaunchKernelGGL(gemm_split_w_kernel, dim3((unsigned)ceil_div<int>(frag_tiles, 4)), dim3(256), 0, as_stream(stream), W, ld_w, trans_w ? 1 : 0, No, Ki,
                        reinterpret_cast<gu4 *>(ws));
-    if (mask)
-        hipLaunchKernelGGL((gemm_rows_split_kernel<true>), grid, dim3(256), 0, as_stream(stream), in, mask, ld_in, reinterpret_cast<const gu4 *>(ws), bias, out, ld_out,
-                           S, n_ptr, Ki, No, act, beta, oa);
-    else
-        hipLaunchKernelGGL((gemm_rows_split_kernel<false>), grid, dim3(256), 0, as_stream(stream), in, mask, ld_in, reinterpret_cast<const gu4 *>(ws), bias, out, ld_out,
-                           S, n_ptr, Ki, No, act, beta, oa);
+    const int oa = is_aligned(out, ld_out);
+    const unsigned gx = (unsigned)ceil_div<int64_t>(S, 128);
+    static const int big = [] { const char *e = getenv("ARCN_SPLIT_BN256"); return e ? atoi(e) : 1; }();
+#define ARCN_RS(MT_, NBLK_, OFF_)                                                                                                          \
+    do {                                                                                                                                   \
+        dim3 grid(gx, (unsigned)(NBLK_));                                                                                                  \
+        if (mask)                                                                                                                          \
+            hipLaunchKernelGGL((gemm_rows_split_kernel<true, MT_, 8, 4>), grid, dim3(256), 0, as_stream(stream), in, mask, ld_in,         \
+                               reinterpret_cast<const gu4 *>(ws), bias, out, ld_out, S, n_ptr, Ki, No, OFF_, act, beta, oa);               \
+        else                                                                                                                               \
+            hipLaunchKernelGGL((gemm_rows_split_kernel<false, MT_, 8, 4>), grid, dim3(256), 0, as_stream(stream), in, mask, ld_in,        \
+                               reinterpret_cast<const gu4 *>(ws), bias, out, ld_out, S, n_ptr, Ki, No, OFF_, act, beta, oa);               \
+    } while (0)
+    // the outputs in blocks: 256 wide while they last, then what remains -- <= 16 outputs (257 = 256 + 1) on the exact-f32 kernel's
+    // 16-output tiles (one more pass over the rows, memory bound), <= 128 as one 128-wide block, more as a partly empty 256-wide one
+    int done = 0;
+    if (big && No >= 256) {
+        ARCN_RS(4, No / 256, 0);
+        done = No / 256 * 256;
+    }
+    const int rem = No - done;
+    if (rem > 0 && rem <= 16 && done > 0) {
+        const float *Wr = trans_w ? W + done : W + (int64_t)done * ld_w;
+        const int rc = gemm_rows(trans_w, in, mask, ld_in, Wr, ld_w, bias ? bias + done : nullptr, out + done, ld_out, S, n_ptr, Ki, rem, act, beta, stream);
+        if (rc != ARCN_OK) return rc;
+    } else if (rem > 128 && big) {
+        ARCN_RS(4, 1, done);
+    } else if (rem > 0) {
+        ARCN_RS(2, ceil_div<int>(rem, 128), done);
+    }
+#undef ARCN_RS
     return check_launch("gemm_rows_split");
 }
 

@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--config', default='ngp', choices=['ngp', 'nerf', 'neus', 'neus_ngp_multivol', 'hdrnerf'],
                     help='BASELINE.json configs: ngp = config 2 (default, the headline), nerf = 1, neus = 3, neus_ngp_multivol = 4, hdrnerf = 5')
     ap.add_argument('--rays', type=int, default=0, help='rays per step per GPU for the module-path configs (0 = the config default)')
+    ap.add_argument('--chunk-pts', type=int, default=0, help='points per net evaluation chunk of the module-path configs (0 = the yaml value, the reference\'s 4096*32: a memory knob sized for an 11 GB card; the chunks are independent, so it changes launch sizes only)')
     return ap.parse_args()
 
 
@@ -142,6 +143,8 @@ def bench_module(args, name):
     n_rays = args.rays or spec['rays']
     torch.manual_seed(0)   # identical initial parameters on every rank
     m = build_model(load_configs(os.path.join(ROOT, 'configs', spec['yaml']), [])).to(dev)
+    if args.chunk_pts:
+        m.set_chunk_pts(args.chunk_pts)
     fg = m.fg_model
     if name == 'neus_ngp_multivol':
         fg.obj_bound.volume.update_bitfield(torch.from_numpy(synthetic_bitfield(128, args.occupancy, seed=0)).to(dev), ops='overwrite')
@@ -230,9 +233,10 @@ def bench_module(args, name):
     if spec['flop']:
         # fwd + bwd (dX and dW) = 3x the forward FLOP of the linear stacks; NeuS additionally differentiates the sdf net twice
         ach = 3.0 * spec['flop'] * evals_per_step / (wall / args.steps)
-        roofline = {'kernel': 'linear stacks of the geometry / radiance nets (hipBLASLt f32 GEMMs + fused MFMA kernels)', 'bound': 'mfma', 'achieved': ach / 1e12,
-                    'peak': F32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s', 'frac': ach / F32_MFMA_PEAK, 'traffic': None,
-                    'note': 'algorithmic FLOP = 3 x forward MACs x 2 per net evaluation; f32 MFMA peak (the nets compute in f32)'}
+        roofline = {'kernel': 'linear stacks of the geometry / radiance nets (csrc/gemm.hip: split-bf16 MFMA products at f32 accuracy + fused MFMA kernels)', 'bound': 'mfma',
+                    'achieved': ach / 1e12, 'peak': F32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s', 'frac': ach / F32_MFMA_PEAK, 'traffic': None,
+                    'note': 'algorithmic f32 FLOP = 3 x forward MACs x 2 per net evaluation, over the WHOLE step time; priced against the exact-f32 MFMA peak '
+                            '(the products are f32-accurate; each is six bf16 MFMAs, so the matrix pipe itself does 6/8 of the f32 MFMA cycles)'}
     cpu = None
     if world == 1 and not args.no_cpu_baseline and name == 'nerf':
         cpu = cpu_baseline_nerf()
@@ -241,7 +245,8 @@ def bench_module(args, name):
            'dtype': 'f32', 'data': 'synthetic',
            'config': {'workload': '{} ({}), {} rays/step/GPU, {} net evaluations/step/GPU, module path build_model({}) + FusedAdam'.format(
                name, spec['desc'], n_rays, evals_per_step, spec['yaml']), 'rays_per_step_per_gpu': n_rays,
-               'samples_per_step_per_gpu': evals_per_step, 'n_params': flat_numel, 'parallelism': 'ray-sharded dp{}'.format(world)},
+               'samples_per_step_per_gpu': evals_per_step, 'n_params': flat_numel, 'parallelism': 'ray-sharded dp{}'.format(world),
+               'chunk_pts': int(m.get_chunk_pts())},
            'roofline': roofline, 'cpu_baseline': cpu}
     print(json.dumps(out))
     if dist is not None:

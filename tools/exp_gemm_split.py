@@ -22,7 +22,8 @@ for S, K, N in [(4096 + 37, 64, 128), (4096 + 37, 256, 256), (4096 + 37, 284, 26
     ref = (dy.double() * (m > 0)).t() @ x.double()
     e_tn = ((F.gemm_tn(dy, x, m).double() - ref).abs().max() / ref.abs().max()).item()
     print('S %d K %d N %d: max err / max |ref|: nt %.2e (library %.2e) nn %.2e tn %.2e' % (S, K, N, e_nt, e_lib, e_nn, e_tn))
-for S, K, N in [(1 << 20, 256, 256), (1 << 20, 320, 256), (1 << 20, 64, 256), (1 << 20, 284, 128), (786432, 256, 260)]:
+SB = int(os.environ.get('EXP_S', 1 << 20))
+for S, K, N in [(SB, 256, 256), (SB, 320, 256), (SB, 64, 256), (SB, 284, 128), (SB * 3 // 4, 256, 260)]:
     x = torch.randn(S, K, device='cuda'); w = torch.randn(N, K, device='cuda'); dy = torch.randn(S, N, device='cuda'); b = torch.randn(N, device='cuda')
     fl = 2.0 * S * K * N
     r = []
