@@ -349,8 +349,9 @@ gemm_tn_kernel(const float *__restrict__ A, const float *__restrict__ mask, int6
 
 // out[i] (+)= sum over slabs in a fixed order: 4 lanes per element take the slabs k = lane, lane + 4, ... with 4 independent
 // accumulators each (16 loads in flight per element instead of one dependent chain), combined in a fixed tree
-__global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(const float *__restrict__ scratch, float *__restrict__ out, int64_t n_elem,
-                                                             int n_slabs, int accumulate) {
+// (elements [n_first, n_elem) of a slab go to out2: the column sums that gemm_tn_split_kernel appends)
+__global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(const float *__restrict__ scratch, float *__restrict__ out, int64_t n_elem, int64_t stride,
+                                                             int n_slabs, int accumulate, int64_t n_first, float *__restrict__ out2) {
     const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;   // 0..3
     __shared__ float red[4][64];
@@ -358,19 +359,20 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(const float *__rest
     if (i < n_elem) {
         int k = part;
         for (; k + 12 < n_slabs; k += 16) {
-            a0 += scratch[(int64_t)k * n_elem + i];
-            a1 += scratch[(int64_t)(k + 4) * n_elem + i];
-            a2 += scratch[(int64_t)(k + 8) * n_elem + i];
-            a3 += scratch[(int64_t)(k + 12) * n_elem + i];
+            a0 += scratch[(int64_t)k * stride + i];
+            a1 += scratch[(int64_t)(k + 4) * stride + i];
+            a2 += scratch[(int64_t)(k + 8) * stride + i];
+            a3 += scratch[(int64_t)(k + 12) * stride + i];
         }
-        for (; k < n_slabs; k += 4) a0 += scratch[(int64_t)k * n_elem + i];
+        for (; k < n_slabs; k += 4) a0 += scratch[(int64_t)k * stride + i];
     }
     red[part][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (part == 0 && i < n_elem) {
         const int j = threadIdx.x & 63;
         const float s = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
-        out[i] = accumulate ? out[i] + s : s;
+        float *o = i < n_first ? out + i : out2 + (i - n_first);
+        *o = accumulate ? *o + s : s;
     }
 }
 
@@ -610,7 +612,7 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
 template <bool MASK>
 __global__ void __launch_bounds__(256, MASK ? 2 : 3)
 gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask, int64_t ld_a, const float *__restrict__ B, int64_t ld_b, float *__restrict__ scratch,
-                     int64_t S, const int32_t *n_ptr, int N, int K, int n_slabs) {
+                     int64_t S, const int32_t *n_ptr, int N, int K, int n_slabs, int want_colsum) {
     constexpr int MT = 4, NT = 4, BN = 128, BKo = 128, BS = 32;
     __shared__ __attribute__((aligned(16))) gu4 Ls[2 * 8 * 192];   // [operand][feature tile][plane][g][feature slot]
     const int64_t cnt = dev_count(S, n_ptr);
@@ -632,6 +634,7 @@ gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask
     gf4 xr[8];
     gf4 mr[MASK ? 8 : 1];
     uint32_t ok = 0u;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};   // want_colsum: column sums of the (masked) A operand = the layer's bias gradient, for free
     const int64_t n_chunks = s_lo < s_hi ? (s_hi - s_lo + BS - 1) / BS : 0;
 
     // (uniform stage base + one 32-bit byte offset per row: half the address registers of eight 64-bit pointers)
@@ -660,6 +663,7 @@ gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask
                 if (MASK) v = (is_b || mr[e][r] > 0.f) ? v : 0.f;
                 x[e] = v;
             }
+            csum[r] += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
             gu4 hi, md, lo;
             split3(x, hi, md, lo);
             // feature slot rotated by the tile index: the 16 lanes of a write phase (4 tiles x 4 quads) hit 16 different bank groups
@@ -714,13 +718,34 @@ gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask
             __builtin_amdgcn_sched_barrier(0);
             compute();
             __syncthreads();
+            float keep[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) keep[r] = csum[r];
             stash();
+            if (c + 1 >= n_chunks) {   // the stage re-read past the end is never multiplied, and must not be summed either
+#pragma unroll
+                for (int r = 0; r < 4; ++r) csum[r] = keep[r];
+            }
             __syncthreads();
+        }
+    }
+    // column sums: the four sample octets of a feature quad live in four threads (unit = quad + 32 octet) of waves 0 and 1
+    float *slab_out = scratch + (int64_t)slab * ((int64_t)N * K + N);
+    if (want_colsum && tk == 0) {
+        float *red = reinterpret_cast<float *>(Ls);
+        if (!is_b) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[unit * 4 + r] = csum[r];
+        }
+        __syncthreads();
+        if (tid < BN && n_base + tid < N) {
+            const int q = tid >> 2, r = tid & 3;
+            slab_out[(int64_t)N * K + n_base + tid] = (red[q * 4 + r] + red[(q + 32) * 4 + r]) + (red[(q + 64) * 4 + r] + red[(q + 96) * 4 + r]);
         }
     }
     // lane (g, j): rows n = 16 mt + 4 g + r, column k = 16 nt + j
     const int g = lane >> 4, j = lane & 15;
-    float *dst = scratch + (int64_t)slab * N * K;
+    float *dst = slab_out;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -864,7 +889,7 @@ ARCN_EXPORT int arcn_gemm_nn_split(const float *dy, const float *mask, int64_t l
 ARCN_EXPORT int64_t arcn_gemm_tn_scratch_floats(int64_t n_rows, int N, int K) {
     const bool small = (N <= 64 && K <= 64);
     const int slabs = small ? tn_slabs(n_rows, N, K, 64, 64) : tn_slabs(n_rows, N, K, 128, 128);
-    return (int64_t)slabs * N * K;
+    return (int64_t)slabs * ((int64_t)N * K + N);   // (+ N per slab: the column sums of arcn_gemm_tn_split)
 }
 
 /* dW (N,K) (+)= dY (S,N)^T . X (S,K): weight gradient, reduced over all rows in a fixed order (slab partials in `scratch`, at least
@@ -895,29 +920,29 @@ ARCN_EXPORT int arcn_gemm_tn(const float *dy, const float *mask, int64_t ld_dy, 
     }
     const int64_t n_elem = (int64_t)N * K;
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ceil_div<int64_t>(n_elem, 64)), dim3(256), 0, as_stream(stream), scratch, dw,
-                       n_elem, slabs, accumulate);
+                       n_elem, n_elem, slabs, accumulate, n_elem, (float *)nullptr);
     return check_launch("gemm_tn");
 }
 
 /* arcn_gemm_tn on the bf16 matrix rate (split form, see arcn_gemm_nt_split): same arguments and scratch; dy, mask and x rows 16-byte
- * aligned, N and K multiples of 4. */
-ARCN_EXPORT int arcn_gemm_tn_split(const float *dy, const float *mask, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *scratch,
+ * aligned, N and K multiples of 4.  db (N floats, may be NULL) (+)= the column sums of dy' -- the layer's bias gradient, summed from the
+ * operand as it is staged (no second pass over dy). */
+ARCN_EXPORT int arcn_gemm_tn_split(const float *dy, const float *mask, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *db, float *scratch,
                                    int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate, void *stream) {
     if (!dy || !x || !dw || !scratch || N < 1 || K < 1) return einval("gemm_tn_split: missing / invalid argument");
     if (scratch_floats < arcn_gemm_tn_scratch_floats(n_rows, N, K)) return einval("gemm_tn_split: scratch smaller than arcn_gemm_tn_scratch_floats");
     if (!is_aligned(dy, ld_dy) || !is_aligned(x, ld_x) || (N & 3) != 0 || (K & 3) != 0 || (mask && !is_aligned(mask, ld_dy)))
         return einval("gemm_tn_split: operands need 16-byte aligned rows and feature counts that are multiples of 4");
-    if (N <= 64 && K <= 64) return arcn_gemm_tn(dy, mask, ld_dy, x, ld_x, dw, scratch, scratch_floats, n_rows, n_ptr, N, K, accumulate, stream);
     int slabs = 0;
     if (n_rows > 0) {
         slabs = tn_slabs(n_rows, N, K, 128, 128);
         dim3 grid((unsigned)slabs, (unsigned)(ceil_div<int>(N, 128) * ceil_div<int>(K, 128)));
-        if (mask) hipLaunchKernelGGL((gemm_tn_split_kernel<true>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs);
-        else hipLaunchKernelGGL((gemm_tn_split_kernel<false>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs);
+        if (mask) hipLaunchKernelGGL((gemm_tn_split_kernel<true>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, db ? 1 : 0);
+        else hipLaunchKernelGGL((gemm_tn_split_kernel<false>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, db ? 1 : 0);
     }
-    const int64_t n_elem = (int64_t)N * K;
+    const int64_t n_first = (int64_t)N * K, n_elem = n_first + (db ? N : 0);
+    // (the slab stride is N K + N whether or not db is wanted; without db the last N of each slab are not read)
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ceil_div<int64_t>(n_elem, 64)), dim3(256), 0, as_stream(stream), scratch, dw,
-                       n_elem, slabs, accumulate);
+                       n_elem, n_first + N, slabs, accumulate, n_first, db);
     return check_launch("gemm_tn_split");
 }
-

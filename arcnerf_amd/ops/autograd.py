@@ -320,24 +320,15 @@ class LinearReluFn(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         g = g.contiguous()
         dx = F.gemm_nn(g, w, mask=y) if ctx.needs_input_grad[0] else None
-        dw = F.gemm_tn(g, x, mask=y) if ctx.needs_input_grad[1] else None
-        db = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            ones = _ones_cols(g.shape[0], g.device)
-            db = F.gemm_tn(g, ones, mask=y)[:, 0].contiguous()    # column sums of dy * (y > 0) on the same reduction kernel
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dw = db = None
+        if ctx.needs_input_grad[1] and want_db:
+            dw, db = F.gemm_tn(g, x, mask=y, want_colsum=True)   # bias gradient = column sums of dy * (y > 0), from the same pass
+        elif ctx.needs_input_grad[1]:
+            dw = F.gemm_tn(g, x, mask=y)
+        elif want_db:
+            db = F.gemm_tn(g, F._ones_cols(g.shape[0], g.device), mask=y)[:, 0].contiguous()
         return dx, dw, db
-
-
-_ONES = {}
-
-
-def _ones_cols(n_rows, device):
-    key = (str(device), )
-    t = _ONES.get(key)
-    if t is None or t.shape[0] < n_rows:
-        t = torch.ones((max(n_rows, 1 << 16), 4), dtype=torch.float32, device=device)
-        _ONES[key] = t
-    return t[:n_rows]
 
 
 def _padded_operands(x, weight, bias):

@@ -584,8 +584,9 @@ def gemm_nn(dy, w, mask=None):
     return dx
 
 
-def gemm_tn(dy, x, mask=None):
-    """dw (N,K) = (dy * (mask > 0)) (S,N).T @ x (S,K), reduced over the rows in a fixed order"""
+def gemm_tn(dy, x, mask=None, want_colsum=False):
+    """dw (N,K) = (dy * (mask > 0)) (S,N).T @ x (S,K), reduced over the rows in a fixed order; want_colsum: also the column sums (N) of
+    dy * (mask > 0) - a layer's bias gradient - from the same pass where the split kernel runs, else from a second product with ones"""
     _req(dy, x, mask)
     dy, x, mask = _f32(dy), _f32(x), _f32(mask)
     S, Nn = dy.shape
@@ -595,9 +596,28 @@ def gemm_tn(dy, x, mask=None):
     nf = max(1, int(N.lib().arcn_gemm_tn_scratch_floats(S, Nn, K)))
     scratch = torch.empty(nf, dtype=torch.float32, device=dy.device)
     split = _GEMM_SPLIT and (Nn > 64 or K > 64) and Nn % 4 == 0 and K % 4 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
-    fn = N.lib().arcn_gemm_tn_split if split else N.lib().arcn_gemm_tn
-    N.check(fn(N.ptr(dy), N.ptr(mask), Nn, N.ptr(x), K, N.ptr(dw), N.ptr(scratch), nf, S, None, Nn, K, 0, N.stream()), 'gemm_tn')
-    return dw
+    if split:
+        db = torch.empty(Nn, dtype=torch.float32, device=dy.device) if want_colsum else None
+        N.check(N.lib().arcn_gemm_tn_split(N.ptr(dy), N.ptr(mask), Nn, N.ptr(x), K, N.ptr(dw), N.ptr(db), N.ptr(scratch), nf, S, None, Nn, K, 0,
+                                         N.stream()), 'gemm_tn_split')
+        return (dw, db) if want_colsum else dw
+    N.check(N.lib().arcn_gemm_tn(N.ptr(dy), N.ptr(mask), Nn, N.ptr(x), K, N.ptr(dw), N.ptr(scratch), nf, S, None, Nn, K, 0, N.stream()), 'gemm_tn')
+    if not want_colsum:
+        return dw
+    ones = _ones_cols(S, dy.device)
+    return dw, gemm_tn(dy, ones, mask)[:, 0].contiguous()
+
+
+_ONES = {}
+
+
+def _ones_cols(n_rows, device):
+    key = str(device)
+    t = _ONES.get(key)
+    if t is None or t.shape[0] < n_rows:
+        t = torch.ones((max(n_rows, 1 << 16), 4), dtype=torch.float32, device=device)
+        _ONES[key] = t
+    return t[:n_rows]
 
 
 def mlp_bwd(x, weights, biases, desc, out, acts, dout, want_dx=True, n_dev=None, dweights=None, dbiases=None, scratch=None):

@@ -309,7 +309,8 @@ int arcn_gemm_nt_split(const float *x, int64_t ld_x, const float *w, const float
                        const int32_t *n_ptr, int K, int N, int act, float beta, void *ws, int64_t ws_bytes, void *stream);
 int arcn_gemm_nn_split(const float *dy, const float *mask, int64_t ld_dy, const float *w, float *dx, int64_t ld_dx, int64_t n_rows,
                        const int32_t *n_ptr, int N, int K, void *ws, int64_t ws_bytes, void *stream);
-int arcn_gemm_tn_split(const float *dy, const float *mask, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *scratch,
+/* tn: db (N floats, may be NULL) (+)= the column sums of dy' = the layer's bias gradient, summed from the operand as it is staged */
+int arcn_gemm_tn_split(const float *dy, const float *mask, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *db, float *scratch,
                        int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate, void *stream);
 /* The same network with a LEVEL-MAJOR input / input gradient: x_lm[(l * x_stride + s) * 2 + f], 2 features per level (what
  * arcn_hashgrid_fwd_xcd(level_major = 1) writes and arcn_hashgrid_bwd_lm consumes).  Wired for the bias-free 2-layer nets fed by

@@ -995,6 +995,19 @@ def test_gemm_products_vs_float64(S, K, Nn):
     refw = dy.double().t() @ x.double()
     assert (dw.double() - refw).abs().max() <= 2e-6 * max(1.0, refw.abs().max().item()) * max(1.0, (S / 1000.0) ** 0.5)
     assert torch.equal(dw, Fn.gemm_tn(dy, x))      # fixed reduction order: bit-reproducible
+    # masked operand (a ReLU layer's backward) + the bias gradient from the same pass
+    m = torch.randn(S, Nn, generator=g).cuda()
+    dyd = dy.double() * (m > 0)
+    if K % 4 == 0 and Nn % 4 == 0:
+        dwm, db = Fn.gemm_tn(dy, x, mask=m, want_colsum=True)
+        refw = dyd.t() @ x.double()
+        assert (dwm.double() - refw).abs().max() <= 2e-6 * max(1.0, refw.abs().max().item()) * max(1.0, (S / 1000.0) ** 0.5)
+        refb = dyd.sum(0)
+        assert (db.double() - refb).abs().max() <= 2e-6 * max(1.0, refb.abs().max().item()) * max(1.0, (S / 1000.0) ** 0.5)
+        assert torch.equal(dwm, Fn.gemm_tn(dy, x, mask=m))
+        dxm = Fn.gemm_nn(dy, w, mask=m)
+        refx = dyd @ w.double()
+        assert (dxm.double() - refx).abs().max() <= 2e-6 * max(1.0, refx.abs().max().item())
 
 
 def test_linear_layers_double_backward_vs_torch():
