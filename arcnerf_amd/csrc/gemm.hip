@@ -609,8 +609,8 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
 // contiguous bytes of a row), which is four fragments' worth of eight-sample columns in its own registers -- the transposition costs
 // nothing -- splits them and writes 16-byte fragment slots.  One LDS stage (48 KB: three workgroups per CU) with the next stage's loads
 // in flight over the MFMA block.  Rows 16-byte aligned, N and K multiples of 4.
-template <bool MASK>
-__global__ void __launch_bounds__(256, MASK ? 2 : 3)
+template <bool MASK, bool COLSUM>
+__global__ void __launch_bounds__(256, (MASK || COLSUM) ? 2 : 3)
 gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask, int64_t ld_a, const float *__restrict__ B, int64_t ld_b, float *__restrict__ scratch,
                      int64_t S, const int32_t *n_ptr, int N, int K, int n_slabs, int want_colsum) {
     constexpr int MT = 4, NT = 4, BN = 128, BKo = 128, BS = 32;
@@ -663,7 +663,7 @@ gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask
                 if (MASK) v = (is_b || mr[e][r] > 0.f) ? v : 0.f;
                 x[e] = v;
             }
-            csum[r] += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+            if (COLSUM) csum[r] += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
             gu4 hi, md, lo;
             split3(x, hi, md, lo);
             // feature slot rotated by the tile index: the 16 lanes of a write phase (4 tiles x 4 quads) hit 16 different bank groups
@@ -719,10 +719,12 @@ gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask
             compute();
             __syncthreads();
             float keep[4];
+            if (COLSUM) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) keep[r] = csum[r];
+                for (int r = 0; r < 4; ++r) keep[r] = csum[r];
+            }
             stash();
-            if (c + 1 >= n_chunks) {   // the stage re-read past the end is never multiplied, and must not be summed either
+            if (COLSUM && c + 1 >= n_chunks) {   // the stage re-read past the end is never multiplied, and must not be summed either
 #pragma unroll
                 for (int r = 0; r < 4; ++r) csum[r] = keep[r];
             }
@@ -731,7 +733,7 @@ gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask
     }
     // column sums: the four sample octets of a feature quad live in four threads (unit = quad + 32 octet) of waves 0 and 1
     float *slab_out = scratch + (int64_t)slab * ((int64_t)N * K + N);
-    if (want_colsum && tk == 0) {
+    if (COLSUM && want_colsum && tk == 0) {
         float *red = reinterpret_cast<float *>(Ls);
         if (!is_b) {
 #pragma unroll
@@ -935,10 +937,22 @@ ARCN_EXPORT int arcn_gemm_tn_split(const float *dy, const float *mask, int64_t l
         return einval("gemm_tn_split: operands need 16-byte aligned rows and feature counts that are multiples of 4");
     int slabs = 0;
     if (n_rows > 0) {
+        // one full round of workgroups: 256 CUs x 3 (unmasked: 168 registers) or x 2 (masked) resident workgroups; the generic choice
+        // (1024 / tiles) is 1.33 rounds of the unmasked kernel - a third of the chip idle for the second round - and twice the partials
+        const int tiles = ceil_div<int>(N, 128) * ceil_div<int>(K, 128);
+        static const int slots_u = [] { const char *e = getenv("ARCN_TN_SLOTS"); return e ? atoi(e) : 768; }();
+        const int slots = (mask || db) ? 512 : slots_u;
         slabs = tn_slabs(n_rows, N, K, 128, 128);
-        dim3 grid((unsigned)slabs, (unsigned)(ceil_div<int>(N, 128) * ceil_div<int>(K, 128)));
-        if (mask) hipLaunchKernelGGL((gemm_tn_split_kernel<true>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, db ? 1 : 0);
-        else hipLaunchKernelGGL((gemm_tn_split_kernel<false>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, db ? 1 : 0);
+        if (slabs > slots / tiles) slabs = slots / tiles > 0 ? slots / tiles : 1;
+        dim3 grid((unsigned)slabs, (unsigned)tiles);
+#define ARCN_TNS(MK_, CS_)                                                                                                             \
+    hipLaunchKernelGGL((gemm_tn_split_kernel<MK_, CS_>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, \
+                       n_ptr, N, K, slabs, db ? 1 : 0)
+        if (mask && db) ARCN_TNS(true, true);
+        else if (mask) ARCN_TNS(true, false);
+        else if (db) ARCN_TNS(false, true);
+        else ARCN_TNS(false, false);
+#undef ARCN_TNS
     }
     const int64_t n_first = (int64_t)N * K, n_elem = n_first + (db ? N : 0);
     // (the slab stride is N K + N whether or not db is wanted; without db the last N of each slab are not read)

@@ -17,7 +17,7 @@ img = torch.rand(1, R, 3, device=dev)
 opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=5e-4, eps=1e-15)
 def step(i):
     out = m(dict(inp), inference_only=False, cur_epoch=20000 + i)
-    if name == 'neus':
+    if name.startswith('neus'):
         loss = ((out['rgb'] - img) ** 2).mean() + 0.1 * ((out['normal_pts'].norm(dim=-1) - 1.0) ** 2).mean()
     else:
         loss = ((out['rgb_fine'] - img) ** 2).mean() + ((out['rgb_coarse'] - img) ** 2).mean()
@@ -28,4 +28,4 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     for i in range(2): step(10 + i)
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=28, max_name_column_width=60))
+print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=40, max_name_column_width=60))
