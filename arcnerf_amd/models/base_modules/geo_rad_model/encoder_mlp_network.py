@@ -54,9 +54,14 @@ class EncoderMLPRadainceNet(BaseRadianceNet):
             width['v'] = self.embed_fn_view.get_output_dim()
         self.init_input_dim = sum(width[m] for m in self.mode)
 
-    def fuse_radiance_inputs(self, x, view_dirs, normals, geo_feat):
+    def fuse_radiance_inputs(self, x, view_dirs, normals, geo_feat, pad4=False):
         block = {'p': lambda: self.embed_fn_pts(x), 'v': lambda: self.embed_fn_view(normalize(view_dirs)),
                  'n': lambda: normals, 'f': lambda: geo_feat}
-        fused = torch.cat([block[m]() for m in self.mode], dim=-1)
-        assert fused.shape[-1] == self.init_input_dim, 'Shape not match'
-        return fused
+        parts = [block[m]() for m in self.mode]
+        assert sum(p.shape[-1] for p in parts) == self.init_input_dim, 'Shape not match'
+        kp = (-self.init_input_dim) % 4
+        if pad4 and kp and parts[0].is_cuda and parts[0].dtype == torch.float32:
+            from ....ops.autograd import _hip_linear_enabled
+            if _hip_linear_enabled():     # the first layer's padded input width (283 -> 284) from the concat itself, not a second copy
+                parts.append(parts[0].new_zeros(parts[0].shape[:-1] + (kp,)))
+        return torch.cat(parts, dim=-1)

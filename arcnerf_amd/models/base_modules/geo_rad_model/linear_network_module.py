@@ -72,6 +72,11 @@ class GeoNet(EncoderMLPGeoNet):
 
     def forward(self, x):
         x_embed = self.embed_fn(x)
+        if all(self.layers[i].out_features % 4 == 0 for i in self.skips if i <= self.D):
+            # (63 -> 64 columns ONCE where the layers run on the HIP products: layer 0 and the skip concat both take the padded
+            # block, 256 + 64 = the padded 319, instead of a pad copy of each)
+            from ....ops.autograd import pad_cols4
+            x_embed = pad_cols4(x_embed)
         out = x_embed
         for i in range(self.D + 1):
             out = self.layers[i](out)
@@ -125,7 +130,7 @@ class RadianceNet(EncoderMLPRadainceNet):
         return N.make_mlp_desc(dims, 'relu', 'sigmoid', has_bias=False)
 
     def forward(self, x, view_dirs, normals, geo_feat):
-        out = self.fuse_radiance_inputs(x, view_dirs, normals, geo_feat)
+        out = self.fuse_radiance_inputs(x, view_dirs, normals, geo_feat, pad4=self._fused_desc is None)
         if self._fused_desc is not None and out.is_cuda and out.dtype == torch.float32:
             from ....ops.autograd import FusedMlpFn
             weights = torch.cat([layer.weight.reshape(-1) for layer in self.layers])

@@ -262,8 +262,12 @@ class GemmNT(torch.autograd.Function):
         x, w = ctx.saved_tensors
         g = g.contiguous()
         dx = GemmNN.apply(g, w) if ctx.needs_input_grad[0] else None
-        dw = GemmTN.apply(g, x) if ctx.needs_input_grad[1] else None
-        db = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] and want_db:
+            dw, db = GemmTNB.apply(g, x)      # the bias gradient (column sums of g) from the weight-gradient pass
+        else:
+            dw = GemmTN.apply(g, x) if ctx.needs_input_grad[1] else None
+            db = g.sum(0) if want_db else None
         return dx, dw, db
 
 
@@ -298,6 +302,27 @@ class GemmTN(torch.autograd.Function):
         g = g.contiguous()
         d_a = GemmNT.apply(b, g, None) if ctx.needs_input_grad[0] else None
         d_b = GemmNN.apply(a, g) if ctx.needs_input_grad[1] else None
+        return d_a, d_b
+
+
+class GemmTNB(torch.autograd.Function):
+    """(dw (N,K), db (N)) = (a (S,N).T @ b (S,K), column sums of a): a layer's weight and bias gradients in one pass over a"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return F.gemm_tn(a, b, want_colsum=True)
+
+    @staticmethod
+    def backward(ctx, g_w, g_b):
+        a, b = ctx.saved_tensors
+        d_a = d_b = None
+        if ctx.needs_input_grad[0]:
+            d_a = GemmNT.apply(b, g_w.contiguous(), None) if g_w is not None else None
+            if g_b is not None:
+                d_a = g_b.unsqueeze(0).expand_as(a) if d_a is None else d_a + g_b.unsqueeze(0)
+        if ctx.needs_input_grad[1] and g_w is not None:
+            d_b = GemmNN.apply(a, g_w.contiguous())
         return d_a, d_b
 
 
@@ -341,8 +366,25 @@ def _padded_operands(x, weight, bias):
     w = pad(weight, (0, kp, 0, npad)) if (kp or npad) else weight
     b = pad(bias, (0, npad)) if (bias is not None and npad) else bias
     x2 = x.reshape(-1, x.shape[-1])
-    x2 = pad(x2, (0, kp)) if kp else x2.contiguous()
+    if x2.shape[-1] == k_in + kp:      # already padded by the caller (pad_cols4: one pad shared by a layer input and a skip concat)
+        x2 = x2.contiguous()
+    else:
+        x2 = pad(x2, (0, kp)) if kp else x2.contiguous()
     return x2, w.contiguous(), b, n_out, npad
+
+
+def pad_cols4(x):
+    """x with zero columns appended up to a multiple of 4 where the dense layers run on the HIP products (their padded input width),
+    x itself otherwise: lets a module pad ONCE what it feeds to several layers / concatenations instead of one pad copy per layer"""
+    kp = (-x.shape[-1]) % 4
+    if not kp or not (x.is_cuda and x.dtype == torch.float32) or not _hip_linear_enabled():
+        return x
+    return torch.nn.functional.pad(x, (0, kp))
+
+
+def _hip_linear_enabled():
+    import os
+    return os.environ.get('ARCN_LINEAR_GEMM', '1') != '0'
 
 
 def _use_hip_linear(x, weight):
@@ -368,7 +410,7 @@ def linear(x, weight, bias=None):
     """torch.nn.functional.linear for fp32 CUDA tensors on the MFMA products; anything else (CPU tensors of the host-side tests, other
     dtypes) goes to torch.  ARCN_LINEAR_GEMM=0 routes everything to torch (A/B against the library GEMMs)."""
     if not _use_hip_linear(x, weight):
-        return torch.nn.functional.linear(x, weight, bias)
+        return torch.nn.functional.linear(x[..., :weight.shape[1]], weight, bias)    # (a pad_cols4 input on an empty batch)
     shp = x.shape
     x2, w, b, n_out, npad = _padded_operands(x, weight, bias)
     y = GemmNT.apply(x2, w, b)
