@@ -26,6 +26,11 @@ class DenseLayer(Linear):
         if type(self.activation) is nn.ReLU:
             from ...ops.autograd import linear_relu
             return linear_relu(x, self.weight, self.bias)      # bias + ReLU in the product's epilogue, mask folded into its backward
+        if type(self.activation) is nn.Softplus and self.activation.threshold == 20:
+            from ...ops.autograd import linear_act_nograd
+            y = linear_act_nograd(x, self.weight, self.bias, 'softplus', float(self.activation.beta))   # graph-free passes only
+            if y is not None:
+                return y
         return self.activation(super().forward(x))
 
 

@@ -2,11 +2,12 @@
 sdf_to_alpha (:221-265).  SURVEY.md section 8f, rank 1.
 
 What runs where: the sphere bound, sdf_to_alpha (fwd + bwd), the inverse-CDF up-sampling and the compositing (alpha= branch)
-are HIP kernels; the geometry / radiance nets of configs/models/neus.yaml are 256-wide nn.Linear stacks (library GEMMs through
-torch, as in the reference) whose input gradient - the normal - is taken by autograd with create_graph=True, so the Eikonal term
-and everything downstream of the normals differentiate a second time through torch.  The hash-grid + fused-MLP variant
+are HIP kernels; the geometry / radiance nets of configs/models/neus.yaml are 256-wide linear stacks on the MFMA products of
+csrc/gemm.hip (ops.autograd.linear: closed under differentiation), whose input gradient - the normal - is taken by autograd with
+create_graph=True, so the Eikonal term and everything downstream of the normals differentiate a second time.  The hash-grid + fused-MLP variant
 (NeuS-NGP) needs a second-order backward of those kernels and is not built yet."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -21,6 +22,10 @@ from ..utils.registry import MODEL_REGISTRY
 from ..utils.torch_utils import chunk_processing
 from .base_modules import build_geo_model, build_radiance_model
 from .sdf_model import SdfModel
+
+
+# ARCN_NEUS_UPSAMPLE_GRAPH=1: build the (unused) autograd graph of the importance-sampling rounds as the reference does (A/B)
+_UPSAMPLE_WITH_GRAPH = os.environ.get('ARCN_NEUS_UPSAMPLE_GRAPH', '0') == '1'
 
 
 @MODEL_REGISTRY.register()
@@ -92,9 +97,12 @@ class Neus(SdfModel):
             return zvals, mask_pts
         deterministic = inference_only or not self.get_ray_cfgs('perturb')
         for rnd in range(rounds):
-            pts = get_ray_points_by_zvals(rays_o, rays_d, zvals)
-            sdf = self.forward_pts(pts.view(-1, 3)).view(zvals.shape)
-            weights = self._crossing_weights(zvals, sdf, torch.norm(pts, dim=-1), s * 2 ** (rnd + 1))
+            # (the new depths are detached from the net - the reference detaches `weights` - so the sdf evaluations of these rounds need
+            # no graph: no saved activations, and the dense layers take their activation-in-the-epilogue form)
+            with torch.set_grad_enabled(_UPSAMPLE_WITH_GRAPH and torch.is_grad_enabled()):
+                pts = get_ray_points_by_zvals(rays_o, rays_d, zvals)
+                sdf = self.forward_pts(pts.view(-1, 3)).view(zvals.shape)
+                weights = self._crossing_weights(zvals, sdf, torch.norm(pts, dim=-1), s * 2 ** (rnd + 1))
             fresh = sample_pdf(zvals.contiguous(), weights.detach().contiguous(), n_new // rounds, deterministic).detach()
             zvals = torch.sort(torch.cat([zvals, fresh], dim=-1), dim=-1)[0]
             mask_pts = self.merge_full_mask(mask_pts, fresh)

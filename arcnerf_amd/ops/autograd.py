@@ -406,6 +406,21 @@ def linear_relu(x, weight, bias=None):
     return y.reshape(*shp[:-1], n_out)
 
 
+def linear_act_nograd(x, weight, bias, act, beta=1.0):
+    """act(F.linear(x, weight, bias)) with the activation in the product's epilogue, for passes that build no graph (the importance
+    sampling rounds of NeuS evaluate the softplus sdf net four times per step under no_grad); None when the fast path does not apply"""
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        return None
+    if not _use_hip_linear(x, weight):
+        return None
+    shp = x.shape
+    x2, w, b, n_out, npad = _padded_operands(x.detach(), weight.detach(), None if bias is None else bias.detach())
+    y = F.gemm_nt(x2, w, b, act=act, beta=beta)
+    if npad:
+        y = y[:, :n_out]
+    return y.reshape(*shp[:-1], n_out)
+
+
 def linear(x, weight, bias=None):
     """torch.nn.functional.linear for fp32 CUDA tensors on the MFMA products; anything else (CPU tensors of the host-side tests, other
     dtypes) goes to torch.  ARCN_LINEAR_GEMM=0 routes everything to torch (A/B against the library GEMMs)."""
