@@ -988,6 +988,12 @@ def test_gemm_products_vs_float64(S, K, Nn):
     assert (y.double() - ref).abs().max() <= 2e-6 * max(1.0, ref.abs().max().item())
     yr = Fn.gemm_nt(x, w, None, act='relu')
     assert (yr.double() - torch.relu(x.double() @ w.double().t())).abs().max() <= 2e-6 * max(1.0, ref.abs().max().item())
+    # softplus(beta = 100) epilogue (the graph-free sdf evaluations of NeuS): hardware exp2 / log2 with a compensated log1p
+    ysp = Fn.gemm_nt(x * 0.05, w, b * 0.05, act='softplus', beta=100.0)
+    refsp = torch.nn.functional.softplus((x.double() * 0.05) @ w.double().t() + b.double() * 0.05, beta=100.0)
+    assert (ysp.double() - refsp).abs().max() <= 2e-6 * max(1.0, refsp.abs().max().item())
+    # relative too (tiny values far below zero): beta x the product's own rounding (2e-6 of its scale) is the floor, e^(beta z) amplifies it
+    assert ((ysp.double() - refsp).abs() <= 3e-4 * refsp.abs() + 1e-9).all()
     dx = Fn.gemm_nn(dy, w)
     refx = dy.double() @ w.double()
     assert (dx.double() - refx).abs().max() <= 2e-6 * max(1.0, refx.abs().max().item())
