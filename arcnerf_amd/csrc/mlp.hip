@@ -58,14 +58,18 @@ __device__ __forceinline__ float act_grad_from_y(float y, int act, float beta) {
 // (hi*hi + hi*lo + lo*hi; v_mfma_f32_16x16x16_bf16 takes exactly the 16 reduction elements 16t + 4g + ks that four 16x16x4 f32 MFMAs
 // take, with the same lane <-> element map, so fragments, permutation and accumulators are unchanged).  The weight fragments are split
 // when they are staged: the 16-byte slot of lane (g, i) holds [hi(ks 0..3) | lo(ks 0..3)].
+// ARCN_MLP_SPLIT_BF16 == 3: THREE planes (hi + mid + lo, exact) and the six partial products down to 2^-16 - f32 accuracy, as in
+// gemm.hip; the slot of lane (g, i) grows to 24 bytes [hi | mid | lo] (kFragLane floats per lane).
 #ifndef ARCN_MLP_SPLIT_BF16
 #define ARCN_MLP_SPLIT_BF16 0
 #endif
+constexpr int kFragLane = ARCN_MLP_SPLIT_BF16 == 3 ? 6 : 4;   // floats per lane of a weight fragment
+constexpr int kFragTile = 64 * kFragLane;                      // floats per 16 x 16 fragment
 typedef short bf4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
     uint32_t r;
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 
@@ -77,6 +81,19 @@ __device__ __forceinline__ void split_bf16(const f4 &v, bf4 &hi, bf4 &lo) {
     const uint32_t l01 = cvt_pk_bf16(r0, r1), l23 = cvt_pk_bf16(r2, r3);
     hi = __builtin_bit_cast(bf4, make_uint2(h01, h23));
     lo = __builtin_bit_cast(bf4, make_uint2(l01, l23));
+}
+
+// v = hi + mid + lo exactly (three bf16, 24 significand bits)
+__device__ __forceinline__ void split_bf16_3(const f4 &v, bf4 &hi, bf4 &mid, bf4 &lo) {
+    const uint32_t h01 = cvt_pk_bf16(v.x, v.y), h23 = cvt_pk_bf16(v.z, v.w);
+    const float r0 = v.x - __uint_as_float(h01 << 16), r1 = v.y - __uint_as_float(h01 & 0xffff0000u);
+    const float r2 = v.z - __uint_as_float(h23 << 16), r3 = v.w - __uint_as_float(h23 & 0xffff0000u);
+    const uint32_t m01 = cvt_pk_bf16(r0, r1), m23 = cvt_pk_bf16(r2, r3);
+    const float s0 = r0 - __uint_as_float(m01 << 16), s1 = r1 - __uint_as_float(m01 & 0xffff0000u);
+    const float s2 = r2 - __uint_as_float(m23 << 16), s3 = r3 - __uint_as_float(m23 & 0xffff0000u);
+    hi = __builtin_bit_cast(bf4, make_uint2(h01, h23));
+    mid = __builtin_bit_cast(bf4, make_uint2(m01, m23));
+    lo = __builtin_bit_cast(bf4, make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3)));
 }
 
 template <bool TRANSPOSED>
@@ -103,7 +120,16 @@ __device__ __forceinline__ void stage_fragments(float *lds, const float *__restr
 #pragma unroll
         for (int u = 0; u < kBatch; ++u)
             if (dst[u] >= 0) {
-#if ARCN_MLP_SPLIT_BF16
+#if ARCN_MLP_SPLIT_BF16 == 3
+                const uint32_t h = cvt_pk_bf16(v[u], 0.f) & 0xffffu;
+                const float r = v[u] - __uint_as_float(h << 16);
+                const uint32_t md = cvt_pk_bf16(r, 0.f) & 0xffffu;
+                const uint32_t lw = cvt_pk_bf16(r - __uint_as_float(md << 16), 0.f) & 0xffffu;
+                unsigned short *slot = reinterpret_cast<unsigned short *>(lds) + (dst[u] >> 2) * 12 + (dst[u] & 3);
+                slot[0] = (unsigned short)h;
+                slot[4] = (unsigned short)md;
+                slot[8] = (unsigned short)lw;
+#elif ARCN_MLP_SPLIT_BF16
                 const uint32_t h = cvt_pk_bf16(v[u], 0.f) & 0xffffu;
                 const uint32_t lw = cvt_pk_bf16(v[u] - __uint_as_float(h << 16), 0.f) & 0xffffu;
                 unsigned short *slot = reinterpret_cast<unsigned short *>(lds) + (dst[u] >> 2) * 8 + (dst[u] & 3);
@@ -178,7 +204,30 @@ __device__ __forceinline__ void store_tiles(const f4 (&v)[WT][NT], float *__rest
 template <int WT, int NT>
 __device__ __forceinline__ void gemm_tiles(f4 (&out)[WT][NT], const f4 (&in)[WT][NT], const float *lds_frag, int MT, int T,
                                            int lane) {
-#if ARCN_MLP_SPLIT_BF16
+#if ARCN_MLP_SPLIT_BF16 == 3
+    bf4 bh[WT][NT], bm[WT][NT], bl[WT][NT];
+#pragma unroll
+    for (int t = 0; t < WT; ++t)
+        if (t < T) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) split_bf16_3(in[t][nt], bh[t][nt], bm[t][nt], bl[t][nt]);
+        }
+#pragma unroll
+    for (int mt = 0; mt < WT; ++mt) {
+        if (mt < MT) {
+#pragma unroll
+            for (int t = 0; t < WT; ++t) {
+                if (t < T) {
+                    const uint2 *ap = reinterpret_cast<const uint2 *>(lds_frag + ((mt * T + t) * 64 + lane) * kFragLane);
+                    const bf4 ah = __builtin_bit_cast(bf4, ap[0]), am = __builtin_bit_cast(bf4, ap[1]), al = __builtin_bit_cast(bf4, ap[2]);
+#define ARCN_T(A_, B_) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) out[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A_, B_[t][nt], out[mt][nt], 0, 0, 0);
+                    ARCN_T(ah, bl) ARCN_T(al, bh) ARCN_T(am, bm) ARCN_T(ah, bm) ARCN_T(am, bh) ARCN_T(ah, bh)
+#undef ARCN_T
+                }
+            }
+        }
+    }
+#elif ARCN_MLP_SPLIT_BF16
     bf4 bh[WT][NT], bl[WT][NT];
 #pragma unroll
     for (int t = 0; t < WT; ++t)
@@ -211,7 +260,7 @@ __device__ __forceinline__ void gemm_tiles(f4 (&out)[WT][NT], const f4 (&in)[WT]
 #pragma unroll
             for (int t = 0; t < WT; ++t) {
                 if (t < T) {
-                    const f4 a = *reinterpret_cast<const f4 *>(lds_frag + ((mt * T + t) * 64 + lane) * 4);
+                    const f4 a = *reinterpret_cast<const f4 *>(lds_frag + ((mt * T + t) * 64 + lane) * 4);   // (kFragLane == 4 here)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) out[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, in[t][nt].x, out[mt][nt], 0, 0, 0);
 #pragma unroll
@@ -657,7 +706,7 @@ mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
     int lds_w = 0;
     for (int l = 0; l < NL; ++l) {
         stage_fragments<true>(lds + P.lds_off[l], weights + P.w_off[l], P.dims[l], P.dims[l + 1]);
-        lds_w = P.lds_off[l] + tiles16(P.dims[l]) * tiles16(P.dims[l + 1]) * 256;
+        lds_w = P.lds_off[l] + tiles16(P.dims[l]) * tiles16(P.dims[l + 1]) * kFragTile;
     }
     constexpr bool FRAG = XMODE != 0;        // tile-order activations from the matching forward (store_tiles_frag)
     constexpr bool RECOMP = FRAG && NL == 2;  // ... which saved none for a two-layer net: layer 0 is recomputed from x
@@ -1035,7 +1084,7 @@ static int build_mlp_params(const arcn_mlp_desc *d, MlpParams &P, bool transpose
         P.lds_off[l] = loff;
         woff += d->dims[l] * d->dims[l + 1];
         boff += d->dims[l + 1];
-        loff += tiles16(d->dims[l]) * tiles16(d->dims[l + 1]) * 256;
+        loff += tiles16(d->dims[l]) * tiles16(d->dims[l + 1]) * kFragTile;
     }
     (void)transposed;
     P.act_hidden = d->act_hidden;
@@ -1232,7 +1281,7 @@ static int mlp_bwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
         if (cat_in ? ((sig == 2441 || sig == 2410) && P.dims[0] == 32)
                    : x_stride ? (sig == 2410 || sig == 4410) : (sig == 2410 || sig == 2441 || sig == 4410 || sig == 4441)) {
             // + one 8 KiB transposition area per wave + the forward fragments of W_0 (<= 16 tiles) for the recomputed layer-0 activations
-            const size_t fused_lds = lds_bytes + sizeof(float) * (8192 + 4096);
+            const size_t fused_lds = lds_bytes + sizeof(float) * (8192 + 16 * kFragTile);
             int64_t grid = tile_grid(n, 64);
             if (grid > dw_slabs(n_cap)) grid = dw_slabs(n_cap);
             float *partials = scratch + arcn_mlp_dpre_floats(desc_host, n_cap);
