@@ -347,7 +347,20 @@ def main():
             pipe.update_occupancy(epoch, apply=False)
 
     epoch0 = 512  # steady-state regime of VolumeBound.optimize (after epoch_optim_warmup = 256)
+    # a fresh box hands over an idle GPU: ~0.3 s of untimed device work before the W warmup steps (which are 3-10 ms in total) so that
+    # clock / power-state ramps are not inside the timed region
+    _spin = torch.empty(1 << 26, dtype=torch.float32, device=dev)
+    _t = time.perf_counter()
+    while time.perf_counter() - _t < 0.3:
+        _spin.mul_(1.0001)
+        torch.cuda.synchronize()
+    del _spin
     for i in range(args.warmup):
+        if i == max(0, args.warmup - 2):
+            # the event brackets of the timed region are exercised in the last two warmup steps already: their first use in a process
+            # (event pool, lazily loaded runtime pages on a fresh box) showed up as ONE 24 ms step inside the timed region
+            timers.reset(ROOFLINE_KERNELS)
+            torch.cuda.Event(enable_timing=True).record()
         run(i, epoch0 + i)
     torch.cuda.synchronize()
     if dist is not None:
