@@ -454,10 +454,14 @@ __global__ void __launch_bounds__(256) gemm_split_w_kernel(const float *__restri
 // (MT, NT, WAVES_N) = (2, 8, 4): 128 outputs per workgroup, three workgroups per CU; (4, 8, 4): 256 outputs -- the sample operand is
 // read, split and staged once for twice the MFMAs (128 accumulator registers, two workgroups per CU).  The kernel covers the outputs
 // [n_off, min(n_off + gridDim.y * BN, No)).
-template <bool MASK, int MT, int NT, int WAVES_N>
-__global__ void __launch_bounds__(256, (MASK || MT * NT > 16) ? 2 : 3)
+// MASK: 0 none, 1 the float tensor `mask` (layout of `in`; in * (mask > 0)), 2 a BIT mask: `mask` points at uint32 words, Ki / 32 per
+// row, bit b of word w = (y[32 w + b] > 0) - what the forward product of a ReLU layer writes through `relu_bits` (No / 32 words per row,
+// No % 32 == 0): the backward then reads 1 bit instead of 32 per masked element (a third less HBM traffic for the masked products).
+template <int MASK, int MT, int NT, int WAVES_N, bool BITS_OUT>
+__global__ void __launch_bounds__(256, (MASK == 1 || MT * NT > 16) ? 2 : 3)
 gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ mask, int64_t ld_in, const gu4 *__restrict__ Wf, const float *__restrict__ bias,
-                       float *__restrict__ out, int64_t ld_out, int64_t S, const int32_t *n_ptr, int Ki, int No, int n_off, int act, float beta, int out_aligned) {
+                       float *__restrict__ out, uint32_t *__restrict__ relu_bits, int64_t ld_out, int64_t S, const int32_t *n_ptr, int Ki, int No, int n_off,
+                       int act, float beta, int out_aligned) {
     constexpr int BN = 16 * MT * WAVES_N, BM = 128;
     static_assert(16 * NT * (4 / WAVES_N) == BM, "the staging below is written for 128 samples per workgroup");
     __shared__ __attribute__((aligned(16))) gu4 Xs[2][(BM / 16) * 3 * 64];
@@ -473,10 +477,13 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
     // two register sets: the loads of stage c + 2 are issued before the MFMA block of stage c (two MFMA blocks to land in)
     struct Staged {
         gf4 x[2][2];
-        gf4 m[MASK ? 2 : 1][2];
+        gf4 m[MASK == 1 ? 2 : 1][2];
+        uint32_t mb[2];
         uint32_t ok;
     };
     Staged ra, rb;
+    const uint32_t *__restrict__ mbits = reinterpret_cast<const uint32_t *>(mask);
+    const int mwords = Ki >> 5;
 
     auto fetch = [&](int c, Staged &st) {
         st.ok = 0u;
@@ -487,8 +494,12 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 st.x[q][h] = load_row4<true>(in, s_base + sl, col + 16 * h, ld_in, cnt, Ki, 1);
-                if (MASK) st.m[q][h] = load_row4<true>(mask, s_base + sl, col + 16 * h, ld_in, cnt, Ki, 1);
+                if (MASK == 1) st.m[q][h] = load_row4<true>(mask, s_base + sl, col + 16 * h, ld_in, cnt, Ki, 1);
                 st.ok |= (uint32_t)((s_base + sl < cnt) && (col + 16 * h < Ki)) << (2 * q + h);
+            }
+            if (MASK == 2) {   // stage c = word c of the row (32 reduction elements): this thread's bits are 4 g + 16 h + 0..3
+                const int64_t row = s_base + sl < cnt ? s_base + sl : 0;
+                st.mb[q] = mbits[row * mwords + (c < mwords ? c : 0)];
             }
         }
     };
@@ -502,7 +513,8 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = ((st.ok >> (2 * q + h)) & 1u) ? st.x[q][h][r] : 0.f;
-                    if (MASK) v = st.m[q][h][r] > 0.f ? v : 0.f;
+                    if (MASK == 1) v = st.m[q][h][r] > 0.f ? v : 0.f;
+                    if (MASK == 2) v = ((st.mb[q] >> (4 * g + 16 * h + r)) & 1u) ? v : 0.f;
                     x[4 * h + r] = v;
                 }
             gu4 hi, md, lo;
@@ -552,7 +564,7 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
     // down to it, behind the MFMA block -- so a stage past the end re-reads the last stage (clamped) against the all-zero weight stage
     // that the split kernel appends (Wf stage n_chunks), and an odd stage count costs one idle MFMA block.
     // (the masked 256-output form has no registers for the second set: one set, loads one MFMA block ahead)
-    constexpr bool TWO = !(MASK && MT * NT > 16);
+    constexpr bool TWO = !(MASK != 0 && MT * NT > 16);
     constexpr int D = TWO ? 2 : 1;
     Staged &r_odd = TWO ? rb : ra;
     const int last = n_chunks - 1;
@@ -579,22 +591,27 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
     }
     // lane (g, j): outputs 16 mt + 4 g + 0..3 of sample 16 nt + j
     const int g = lane >> 4, j = lane & 15;
+    gf4 bvm[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int no = n_base + (wave_n * MT + m) * 16 + 4 * g;
+        bvm[m] = gf4{0.f, 0.f, 0.f, 0.f};
+        if (bias && no < No) {
+            bvm[m].x = bias[no];
+            if (no + 1 < No) bvm[m].y = bias[no + 1];
+            if (no + 2 < No) bvm[m].z = bias[no + 2];
+            if (no + 3 < No) bvm[m].w = bias[no + 3];
+        }
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int no = n_base + (wave_n * MT + m) * 16 + 4 * g;
         if (no >= No) continue;
-        gf4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-            bv.x = bias[no];
-            if (no + 1 < No) bv.y = bias[no + 1];
-            if (no + 2 < No) bv.z = bias[no + 2];
-            if (no + 3 < No) bv.w = bias[no + 3];
-        }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int64_t s = s_base + (wave_m * NT + n) * 16 + j;
             if (s >= cnt) continue;
-            gf4 v = acc[m][n] + bv;
+            gf4 v = acc[m][n] + bvm[m];
             if (act != ARCN_ACT_NONE) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = gemm_act(v[r], act, beta);
@@ -609,6 +626,31 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
             }
         }
     }
+    // ReLU bit mask of the outputs (No % 32 == 0, host-checked): a lane's four outputs are a nibble, the four lane groups of a sample
+    // and two adjacent tiles make a 32-bit word; every lane runs the exchange, lane group 0 stores
+    if (BITS_OUT && relu_bits) {
+        const int words = No >> 5, w0 = (n_base + wave_n * MT * 16) >> 5;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int64_t s = s_base + (wave_m * NT + n) * 16 + j;
+#pragma unroll
+            for (int k = 0; k < (MT + 1) / 2; ++k) {
+                uint32_t wd = 0u;
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) {
+                    const int m = 2 * k + mm;
+                    if (m < MT) {
+                        const gf4 v = acc[m][n] + bvm[m];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) wd |= (uint32_t)(v[r] > 0.f) << (16 * mm + 4 * g + r);
+                    }
+                }
+                wd |= (uint32_t)__shfl_xor((int)wd, 16);
+                wd |= (uint32_t)__shfl_xor((int)wd, 32);
+                if (g == 0 && s < cnt && w0 + k < words) relu_bits[s * words + w0 + k] = wd;
+            }
+        }
+    }
 }
 
 // partial (slab, N, K) = sum over the slab's samples of A (S,N)^T . B (S,K), split form.  128 x 128 outputs per workgroup (waves 2 x 2,
@@ -617,8 +659,9 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
 // contiguous bytes of a row), which is four fragments' worth of eight-sample columns in its own registers -- the transposition costs
 // nothing -- splits them and writes 16-byte fragment slots.  One LDS stage (48 KB: three workgroups per CU) with the next stage's loads
 // in flight over the MFMA block.  Rows 16-byte aligned, N and K multiples of 4.
-template <bool MASK, bool COLSUM>
-__global__ void __launch_bounds__(256, (MASK || COLSUM) ? 2 : 3)
+// MASK: 0 none, 1 float mask tensor, 2 ReLU bit mask (N / 32 uint32 words per row; see gemm_rows_split_kernel)
+template <int MASK, bool COLSUM>
+__global__ void __launch_bounds__(256, (MASK != 0 || COLSUM) ? 2 : 3)
 gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask, int64_t ld_a, const float *__restrict__ B, int64_t ld_b, float *__restrict__ scratch,
                      int64_t S, const int32_t *n_ptr, int N, int K, int n_slabs, int want_colsum) {
     constexpr int MT = 4, NT = 4, BN = 128, BKo = 128, BS = 32;
@@ -640,7 +683,10 @@ gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask
     const int unit = tid & 127, nq = unit & 31, sg = unit >> 5;
     const int fcol = (f_base + 4 * nq < f_cnt) ? f_base + 4 * nq : 0;   // features past the matrix: any valid column (never stored)
     gf4 xr[8];
-    gf4 mr[MASK ? 8 : 1];
+    gf4 mr[MASK == 1 ? 8 : 1];
+    uint32_t mb[MASK == 2 ? 8 : 1];
+    const uint32_t *__restrict__ mbits = reinterpret_cast<const uint32_t *>(mask);
+    const int mwords = N >> 5, mword = fcol >> 5, mshift = fcol & 31;   // (A-role threads: fcol is a column of dy)
     uint32_t ok = 0u;
     float csum[4] = {0.f, 0.f, 0.f, 0.f};   // want_colsum: column sums of the (masked) A operand = the layer's bias gradient, for free
     const int64_t n_chunks = s_lo < s_hi ? (s_hi - s_lo + BS - 1) / BS : 0;
@@ -656,7 +702,8 @@ gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask
             const bool in = row0 + 8 * sg + e < s_hi;
             const uint32_t off = (uint32_t)(((in ? 8 * sg + e : 0) * ld_s + fcol) * 4);
             xr[e] = *reinterpret_cast<const gf4 *>(base + off);
-            if (MASK) mr[e] = *reinterpret_cast<const gf4 *>((is_b ? base : mbase) + off);
+            if (MASK == 1) mr[e] = *reinterpret_cast<const gf4 *>((is_b ? base : mbase) + off);
+            if (MASK == 2) mb[e] = is_b ? 0xffffffffu : mbits[(row0 + (in ? 8 * sg + e : 0)) * mwords + mword];
             ok |= (uint32_t)in << e;
         }
     };
@@ -668,7 +715,8 @@ gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float v = ((ok >> e) & 1u) ? xr[e][r] : 0.f;
-                if (MASK) v = (is_b || mr[e][r] > 0.f) ? v : 0.f;
+                if (MASK == 1) v = (is_b || mr[e][r] > 0.f) ? v : 0.f;
+                if (MASK == 2) v = ((mb[e] >> (mshift + r)) & 1u) ? v : 0.f;
                 x[e] = v;
             }
             if (COLSUM) csum[r] += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
@@ -839,12 +887,18 @@ ARCN_EXPORT int64_t arcn_gemm_split_bytes(int n_out, int k_red) {
     return (int64_t)(ceil_div<int>(k_red, 32) + 1) * ceil_div<int>(n_out, 16) * 3 * 64 * 16;
 }
 
-static int gemm_rows_split(bool trans_w, const float *in, const float *mask, int64_t ld_in, const float *W, int ld_w, const float *bias, float *out,
-                           int64_t ld_out, int64_t S, const int32_t *n_ptr, int Ki, int No, int act, float beta, void *ws, int64_t ws_bytes, void *stream) {
+static int gemm_rows_split(bool trans_w, const float *in, const float *mask, const uint32_t *mask_bits, int64_t ld_in, const float *W, int ld_w,
+                           const float *bias, float *out, uint32_t *relu_bits, int64_t ld_out, int64_t S, const int32_t *n_ptr, int Ki, int No, int act,
+                           float beta, void *ws, int64_t ws_bytes, void *stream) {
     if (S <= 0) return ARCN_OK;
     if (!in || !W || !out || !ws || Ki < 1 || No < 1) return einval("gemm_split: missing / invalid argument");
     if (!is_aligned(in, ld_in) || (Ki & 3) != 0 || (reinterpret_cast<uintptr_t>(ws) & 15u) != 0 || (mask && !is_aligned(mask, ld_in)))
         return einval("gemm_split: the row operand needs 16-byte aligned rows and a reduction length that is a multiple of 4");
+    if (mask_bits && (Ki & 31) != 0) return einval("gemm_split: a bit mask needs a reduction length that is a multiple of 32");
+    if (relu_bits && ((No & 31) != 0 || act != ARCN_ACT_RELU)) return einval("gemm_split: relu_bits needs a ReLU epilogue and outputs in multiples of 32");
+    if ((mask || mask_bits) && relu_bits) return einval("gemm_split: relu_bits is an output of the unmasked forward product");
+    const int mk = mask_bits ? 2 : (mask ? 1 : 0);
+    if (mask_bits) mask = reinterpret_cast<const float *>(mask_bits);
     if (ws_bytes < arcn_gemm_split_bytes(No, Ki)) return einval("gemm_split: workspace smaller than arcn_gemm_split_bytes");
     const int frag_tiles = (ceil_div<int>(Ki, 32) + 1) * ceil_div<int>(No, 16);
     hipLaunchKernelGGL(gemm_split_w_kernel, dim3((unsigned)ceil_div<int>(frag_tiles, 4)), dim3(256), 0, as_stream(stream), W, ld_w, trans_w ? 1 : 0, No, Ki,
@@ -855,12 +909,18 @@ static int gemm_rows_split(bool trans_w, const float *in, const float *mask, int
 #define ARCN_RS(MT_, NBLK_, OFF_)                                                                                                          \
     do {                                                                                                                                   \
         dim3 grid(gx, (unsigned)(NBLK_));                                                                                                  \
-        if (mask)                                                                                                                          \
-            hipLaunchKernelGGL((gemm_rows_split_kernel<true, MT_, 8, 4>), grid, dim3(256), 0, as_stream(stream), in, mask, ld_in,         \
-                               reinterpret_cast<const gu4 *>(ws), bias, out, ld_out, S, n_ptr, Ki, No, OFF_, act, beta, oa);               \
+        if (mk == 2)                                                                                                                       \
+            hipLaunchKernelGGL((gemm_rows_split_kernel<2, MT_, 8, 4, false>), grid, dim3(256), 0, as_stream(stream), in, mask, ld_in,     \
+                               reinterpret_cast<const gu4 *>(ws), bias, out, relu_bits, ld_out, S, n_ptr, Ki, No, OFF_, act, beta, oa);    \
+        else if (mk == 1)                                                                                                                  \
+            hipLaunchKernelGGL((gemm_rows_split_kernel<1, MT_, 8, 4, false>), grid, dim3(256), 0, as_stream(stream), in, mask, ld_in,     \
+                               reinterpret_cast<const gu4 *>(ws), bias, out, relu_bits, ld_out, S, n_ptr, Ki, No, OFF_, act, beta, oa);    \
+        else if (relu_bits)                                                                                                                \
+            hipLaunchKernelGGL((gemm_rows_split_kernel<0, MT_, 8, 4, true>), grid, dim3(256), 0, as_stream(stream), in, mask, ld_in,      \
+                               reinterpret_cast<const gu4 *>(ws), bias, out, relu_bits, ld_out, S, n_ptr, Ki, No, OFF_, act, beta, oa);    \
         else                                                                                                                               \
-            hipLaunchKernelGGL((gemm_rows_split_kernel<false, MT_, 8, 4>), grid, dim3(256), 0, as_stream(stream), in, mask, ld_in,        \
-                               reinterpret_cast<const gu4 *>(ws), bias, out, ld_out, S, n_ptr, Ki, No, OFF_, act, beta, oa);               \
+            hipLaunchKernelGGL((gemm_rows_split_kernel<0, MT_, 8, 4, false>), grid, dim3(256), 0, as_stream(stream), in, mask, ld_in,     \
+                               reinterpret_cast<const gu4 *>(ws), bias, out, relu_bits, ld_out, S, n_ptr, Ki, No, OFF_, act, beta, oa);    \
     } while (0)
     // the outputs in blocks: 256 wide while they last, then what remains -- <= 16 outputs (257 = 256 + 1) on the exact-f32 kernel's
     // 16-output tiles (one more pass over the rows, memory bound), <= 128 as one 128-wide block, more as a partly empty 256-wide one
@@ -870,7 +930,7 @@ static int gemm_rows_split(bool trans_w, const float *in, const float *mask, int
         done = No / 256 * 256;
     }
     const int rem = No - done;
-    if (rem > 0 && rem <= 16 && done > 0) {
+    if (rem > 0 && rem <= 16 && done > 0 && mk != 2) {
         const float *Wr = trans_w ? W + done : W + (int64_t)done * ld_w;
         const int rc = gemm_rows(trans_w, in, mask, ld_in, Wr, ld_w, bias ? bias + done : nullptr, out + done, ld_out, S, n_ptr, Ki, rem, act, beta, stream);
         if (rc != ARCN_OK) return rc;
@@ -884,16 +944,20 @@ static int gemm_rows_split(bool trans_w, const float *in, const float *mask, int
 }
 
 /* arcn_gemm_nt on the bf16 matrix rate: x and w as three bf16 planes each, six MFMAs per product, f32 accuracy (see the kernel).  x rows
- * 16-byte aligned, K a multiple of 4; `ws` = arcn_gemm_split_bytes(N, K) bytes of device scratch (the split weights). */
-ARCN_EXPORT int arcn_gemm_nt_split(const float *x, int64_t ld_x, const float *w, const float *bias, float *y, int64_t ld_y, int64_t n_rows,
-                                   const int32_t *n_ptr, int K, int N, int act, float beta, void *ws, int64_t ws_bytes, void *stream) {
-    return gemm_rows_split(false, x, nullptr, ld_x, w, K, bias, y, ld_y, n_rows, n_ptr, K, N, act, beta, ws, ws_bytes, stream);
+ * 16-byte aligned, K a multiple of 4; `ws` = arcn_gemm_split_bytes(N, K) bytes of device scratch (the split weights).  relu_bits (may be
+ * NULL; act = ReLU, N % 32 == 0): n_rows x N / 32 words, bit b of word w of a row = (y[32 w + b] > 0) - the mask the layer's backward
+ * needs, 1/32 of the bytes of y. */
+ARCN_EXPORT int arcn_gemm_nt_split(const float *x, int64_t ld_x, const float *w, const float *bias, float *y, uint32_t *relu_bits, int64_t ld_y,
+                                   int64_t n_rows, const int32_t *n_ptr, int K, int N, int act, float beta, void *ws, int64_t ws_bytes, void *stream) {
+    return gemm_rows_split(false, x, nullptr, nullptr, ld_x, w, K, bias, y, relu_bits, ld_y, n_rows, n_ptr, K, N, act, beta, ws, ws_bytes, stream);
 }
 
-/* arcn_gemm_nn likewise: dy rows 16-byte aligned, N a multiple of 4; `ws` = arcn_gemm_split_bytes(K, N) bytes. */
-ARCN_EXPORT int arcn_gemm_nn_split(const float *dy, const float *mask, int64_t ld_dy, const float *w, float *dx, int64_t ld_dx, int64_t n_rows,
-                                   const int32_t *n_ptr, int N, int K, void *ws, int64_t ws_bytes, void *stream) {
-    return gemm_rows_split(true, dy, mask, ld_dy, w, K, nullptr, dx, ld_dx, n_rows, n_ptr, N, K, ARCN_ACT_NONE, 1.0f, ws, ws_bytes, stream);
+/* arcn_gemm_nn likewise: dy rows 16-byte aligned, N a multiple of 4; `ws` = arcn_gemm_split_bytes(K, N) bytes.  mask_bits (may be NULL,
+ * then `mask` applies; N % 32 == 0): the relu_bits of the layer's forward instead of its float output as the mask. */
+ARCN_EXPORT int arcn_gemm_nn_split(const float *dy, const float *mask, const uint32_t *mask_bits, int64_t ld_dy, const float *w, float *dx, int64_t ld_dx,
+                                   int64_t n_rows, const int32_t *n_ptr, int N, int K, void *ws, int64_t ws_bytes, void *stream) {
+    return gemm_rows_split(true, dy, mask, mask_bits, ld_dy, w, K, nullptr, dx, nullptr, ld_dx, n_rows, n_ptr, N, K, ARCN_ACT_NONE, 1.0f, ws, ws_bytes,
+                           stream);
 }
 
 ARCN_EXPORT int64_t arcn_gemm_tn_scratch_floats(int64_t n_rows, int N, int K) {
@@ -936,10 +1000,13 @@ ARCN_EXPORT int arcn_gemm_tn(const float *dy, const float *mask, int64_t ld_dy, 
 
 /* arcn_gemm_tn on the bf16 matrix rate (split form, see arcn_gemm_nt_split): same arguments and scratch; dy, mask and x rows 16-byte
  * aligned, N and K multiples of 4.  db (N floats, may be NULL) (+)= the column sums of dy' -- the layer's bias gradient, summed from the
- * operand as it is staged (no second pass over dy). */
-ARCN_EXPORT int arcn_gemm_tn_split(const float *dy, const float *mask, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *db, float *scratch,
-                                   int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate, void *stream) {
+ * operand as it is staged (no second pass over dy).  mask_bits (may be NULL; N % 32 == 0): the forward's relu_bits as the mask. */
+ARCN_EXPORT int arcn_gemm_tn_split(const float *dy, const float *mask, const uint32_t *mask_bits, int64_t ld_dy, const float *x, int64_t ld_x, float *dw,
+                                   float *db, float *scratch, int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate,
+                                   void *stream) {
     if (!dy || !x || !dw || !scratch || N < 1 || K < 1) return einval("gemm_tn_split: missing / invalid argument");
+    if (mask_bits && (N & 31) != 0) return einval("gemm_tn_split: a bit mask needs N to be a multiple of 32");
+    const int mk = mask_bits ? 2 : (mask ? 1 : 0);
     if (scratch_floats < arcn_gemm_tn_scratch_floats(n_rows, N, K)) return einval("gemm_tn_split: scratch smaller than arcn_gemm_tn_scratch_floats");
     if (!is_aligned(dy, ld_dy) || !is_aligned(x, ld_x) || (N & 3) != 0 || (K & 3) != 0 || (mask && !is_aligned(mask, ld_dy)))
         return einval("gemm_tn_split: operands need 16-byte aligned rows and feature counts that are multiples of 4");
@@ -949,17 +1016,20 @@ ARCN_EXPORT int arcn_gemm_tn_split(const float *dy, const float *mask, int64_t l
         // (1024 / tiles) is 1.33 rounds of the unmasked kernel - a third of the chip idle for the second round - and twice the partials
         const int tiles = ceil_div<int>(N, 128) * ceil_div<int>(K, 128);
         static const int slots_u = [] { const char *e = getenv("ARCN_TN_SLOTS"); return e ? atoi(e) : 768; }();
-        const int slots = (mask || db) ? 512 : slots_u;
+        const int slots = (mk != 0 || db) ? 512 : slots_u;
         slabs = tn_slabs(n_rows, N, K, 128, 128);
         if (slabs > slots / tiles) slabs = slots / tiles > 0 ? slots / tiles : 1;
         dim3 grid((unsigned)slabs, (unsigned)tiles);
 #define ARCN_TNS(MK_, CS_)                                                                                                             \
-    hipLaunchKernelGGL((gemm_tn_split_kernel<MK_, CS_>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, \
+    hipLaunchKernelGGL((gemm_tn_split_kernel<MK_, CS_>), grid, dim3(256), 0, as_stream(stream), dy, mptr, ld_dy, x, ld_x, scratch, n_rows, \
                        n_ptr, N, K, slabs, db ? 1 : 0)
-        if (mask && db) ARCN_TNS(true, true);
-        else if (mask) ARCN_TNS(true, false);
-        else if (db) ARCN_TNS(false, true);
-        else ARCN_TNS(false, false);
+        const float *mptr = mask_bits ? reinterpret_cast<const float *>(mask_bits) : mask;
+        if (mk == 2 && db) ARCN_TNS(2, true);
+        else if (mk == 2) ARCN_TNS(2, false);
+        else if (mk == 1 && db) ARCN_TNS(1, true);
+        else if (mk == 1) ARCN_TNS(1, false);
+        else if (db) ARCN_TNS(0, true);
+        else ARCN_TNS(0, false);
 #undef ARCN_TNS
     }
     const int64_t n_first = (int64_t)N * K, n_elem = n_first + (db ? N : 0);

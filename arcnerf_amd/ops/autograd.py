@@ -334,25 +334,35 @@ class LinearReluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias):
-        y = F.gemm_nt(x, w, bias, act='relu')
-        ctx.save_for_backward(x, w, y)
+        # where the split kernels run and the width allows, the mask of the backward is kept as BITS (1/32 of y's bytes): the two
+        # masked gradient products read dy + bits instead of dy + y
+        n_out, k_in = w.shape
         ctx.has_bias = bias is not None
+        if F.relu_bits_supported(x, k_in, n_out) and F._use_split(x, n_out, k_in) and n_out > 64:
+            y, bits = F.gemm_nt(x, w, bias, act='relu', want_bits=True)
+            ctx.use_bits = True
+            ctx.save_for_backward(x, w, bits)
+        else:
+            y = F.gemm_nt(x, w, bias, act='relu')
+            ctx.use_bits = False
+            ctx.save_for_backward(x, w, y)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        x, w, y = ctx.saved_tensors
+        x, w, m = ctx.saved_tensors
         g = g.contiguous()
-        dx = F.gemm_nn(g, w, mask=y) if ctx.needs_input_grad[0] else None
+        kw = {'mask_bits': m} if ctx.use_bits else {'mask': m}
+        dx = F.gemm_nn(g, w, **kw) if ctx.needs_input_grad[0] else None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         dw = db = None
         if ctx.needs_input_grad[1] and want_db:
-            dw, db = F.gemm_tn(g, x, mask=y, want_colsum=True)   # bias gradient = column sums of dy * (y > 0), from the same pass
+            dw, db = F.gemm_tn(g, x, want_colsum=True, **kw)   # bias gradient = column sums of dy * (y > 0), from the same pass
         elif ctx.needs_input_grad[1]:
-            dw = F.gemm_tn(g, x, mask=y)
+            dw = F.gemm_tn(g, x, **kw)
         elif want_db:
-            db = F.gemm_tn(g, F._ones_cols(g.shape[0], g.device), mask=y)[:, 0].contiguous()
+            db = F.gemm_tn(g, F._ones_cols(g.shape[0], g.device), **kw)[:, 0].contiguous()
         return dx, dw, db
 
 

@@ -550,8 +550,14 @@ def _split_ws(n_out, k_red, device):
     return torch.empty(int(N.lib().arcn_gemm_split_bytes(n_out, k_red)), dtype=torch.uint8, device=device)
 
 
-def gemm_nt(x, w, bias=None, act=None, beta=1.0):
-    """y (S,N) = act(x (S,K) @ w (N,K).T + bias)"""
+def relu_bits_supported(rows, k_red, n_out):
+    """whether gemm_nt(..., want_bits=True) can write the ReLU mask of its output as bits (split kernels, outputs in multiples of 32)"""
+    return _use_split(rows, k_red, n_out) and n_out % 32 == 0 and os.environ.get('ARCN_RELU_BITS', '1') != '0'
+
+
+def gemm_nt(x, w, bias=None, act=None, beta=1.0, want_bits=False):
+    """y (S,N) = act(x (S,K) @ w (N,K).T + bias); want_bits (act = relu, relu_bits_supported): also the (S, N / 32) int32 words whose
+    bit b of word w is (y[:, 32 w + b] > 0) - the mask gemm_nn / gemm_tn take as `mask_bits` (1/32 of the bytes of y)"""
     _req(x, w, bias)
     x, w, bias = _f32(x), _f32(w), _f32(bias)
     S, K = x.shape
@@ -560,16 +566,21 @@ def gemm_nt(x, w, bias=None, act=None, beta=1.0):
     y = torch.empty((S, Nn), dtype=torch.float32, device=x.device)
     if _use_split(x, K, Nn):
         ws = _split_ws(Nn, K, x.device)
-        N.check(N.lib().arcn_gemm_nt_split(N.ptr(x), K, N.ptr(w), N.ptr(bias), N.ptr(y), Nn, S, None, K, Nn, N.ACT[act], float(beta),
+        bits = None
+        if want_bits:
+            assert act == 'relu' and Nn % 32 == 0
+            bits = torch.empty((S, Nn // 32), dtype=torch.int32, device=x.device)
+        N.check(N.lib().arcn_gemm_nt_split(N.ptr(x), K, N.ptr(w), N.ptr(bias), N.ptr(y), N.ptr(bits), Nn, S, None, K, Nn, N.ACT[act], float(beta),
                                          N.ptr(ws), ws.numel(), N.stream()), 'gemm_nt_split')
-        return y
+        return (y, bits) if want_bits else y
+    assert not want_bits
     N.check(N.lib().arcn_gemm_nt(N.ptr(x), K, N.ptr(w), N.ptr(bias), N.ptr(y), Nn, S, None, K, Nn, N.ACT[act], float(beta), N.stream()), 'gemm_nt')
     return y
 
 
-def gemm_nn(dy, w, mask=None):
-    """dx (S,K) = (dy * (mask > 0)) (S,N) @ w (N,K)"""
-    _req(dy, w, mask)
+def gemm_nn(dy, w, mask=None, mask_bits=None):
+    """dx (S,K) = (dy * (mask > 0)) (S,N) @ w (N,K); mask_bits: the forward's ReLU bit words instead of the float mask"""
+    _req(dy, w, mask, mask_bits)
     dy, w, mask = _f32(dy), _f32(w), _f32(mask)
     S, Nn = dy.shape
     K = w.shape[1]
@@ -577,17 +588,19 @@ def gemm_nn(dy, w, mask=None):
     dx = torch.empty((S, K), dtype=torch.float32, device=dy.device)
     if _use_split(dy, Nn, K):
         ws = _split_ws(K, Nn, dy.device)
-        N.check(N.lib().arcn_gemm_nn_split(N.ptr(dy), N.ptr(mask), Nn, N.ptr(w), N.ptr(dx), K, S, None, Nn, K, N.ptr(ws), ws.numel(),
+        N.check(N.lib().arcn_gemm_nn_split(N.ptr(dy), N.ptr(mask), N.ptr(mask_bits), Nn, N.ptr(w), N.ptr(dx), K, S, None, Nn, K, N.ptr(ws), ws.numel(),
                                          N.stream()), 'gemm_nn_split')
         return dx
+    assert mask_bits is None, 'bit masks are read by the split products only'
     N.check(N.lib().arcn_gemm_nn(N.ptr(dy), N.ptr(mask), Nn, N.ptr(w), N.ptr(dx), K, S, None, Nn, K, N.stream()), 'gemm_nn')
     return dx
 
 
-def gemm_tn(dy, x, mask=None, want_colsum=False):
+def gemm_tn(dy, x, mask=None, want_colsum=False, mask_bits=None):
     """dw (N,K) = (dy * (mask > 0)) (S,N).T @ x (S,K), reduced over the rows in a fixed order; want_colsum: also the column sums (N) of
-    dy * (mask > 0) - a layer's bias gradient - from the same pass where the split kernel runs, else from a second product with ones"""
-    _req(dy, x, mask)
+    dy * (mask > 0) - a layer's bias gradient - from the same pass where the split kernel runs, else from a second product with ones;
+    mask_bits: the forward's ReLU bit words instead of the float mask"""
+    _req(dy, x, mask, mask_bits)
     dy, x, mask = _f32(dy), _f32(x), _f32(mask)
     S, Nn = dy.shape
     K = x.shape[1]
@@ -598,9 +611,10 @@ def gemm_tn(dy, x, mask=None, want_colsum=False):
     split = _GEMM_SPLIT and (Nn > 64 or K > 64) and Nn % 4 == 0 and K % 4 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
     if split:
         db = torch.empty(Nn, dtype=torch.float32, device=dy.device) if want_colsum else None
-        N.check(N.lib().arcn_gemm_tn_split(N.ptr(dy), N.ptr(mask), Nn, N.ptr(x), K, N.ptr(dw), N.ptr(db), N.ptr(scratch), nf, S, None, Nn, K, 0,
-                                         N.stream()), 'gemm_tn_split')
+        N.check(N.lib().arcn_gemm_tn_split(N.ptr(dy), N.ptr(mask), N.ptr(mask_bits), Nn, N.ptr(x), K, N.ptr(dw), N.ptr(db), N.ptr(scratch), nf, S, None,
+                                         Nn, K, 0, N.stream()), 'gemm_tn_split')
         return (dw, db) if want_colsum else dw
+    assert mask_bits is None, 'bit masks are read by the split products only'
     N.check(N.lib().arcn_gemm_tn(N.ptr(dy), N.ptr(mask), Nn, N.ptr(x), K, N.ptr(dw), N.ptr(scratch), nf, S, None, Nn, K, 0, N.stream()), 'gemm_tn')
     if not want_colsum:
         return dw

@@ -305,13 +305,16 @@ int arcn_gemm_tn(const float *dy, const float *mask, int64_t ld_dy, const float 
  * length (K for nt, N for nn) and, for tn, N and K multiples of 4; `ws` = device scratch of arcn_gemm_split_bytes(outputs, reduction
  * length) bytes that receives the split weights (nt: (N, K), nn: (K, N)).  Inf / NaN operands give NaN. */
 int64_t arcn_gemm_split_bytes(int n_out, int k_red);
-int arcn_gemm_nt_split(const float *x, int64_t ld_x, const float *w, const float *bias, float *y, int64_t ld_y, int64_t n_rows,
+int arcn_gemm_nt_split(const float *x, int64_t ld_x, const float *w, const float *bias, float *y, uint32_t *relu_bits, int64_t ld_y, int64_t n_rows,
                        const int32_t *n_ptr, int K, int N, int act, float beta, void *ws, int64_t ws_bytes, void *stream);
-int arcn_gemm_nn_split(const float *dy, const float *mask, int64_t ld_dy, const float *w, float *dx, int64_t ld_dx, int64_t n_rows,
-                       const int32_t *n_ptr, int N, int K, void *ws, int64_t ws_bytes, void *stream);
-/* tn: db (N floats, may be NULL) (+)= the column sums of dy' = the layer's bias gradient, summed from the operand as it is staged */
-int arcn_gemm_tn_split(const float *dy, const float *mask, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *db, float *scratch,
-                       int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate, void *stream);
+int arcn_gemm_nn_split(const float *dy, const float *mask, const uint32_t *mask_bits, int64_t ld_dy, const float *w, float *dx, int64_t ld_dx,
+                       int64_t n_rows, const int32_t *n_ptr, int N, int K, void *ws, int64_t ws_bytes, void *stream);
+/* tn: db (N floats, may be NULL) (+)= the column sums of dy' = the layer's bias gradient, summed from the operand as it is staged.
+ * ReLU masks as BITS: arcn_gemm_nt_split(act = ReLU, N % 32 == 0) writes relu_bits (n_rows x N / 32 uint32, bit b of word w of a row =
+ * (y[32 w + b] > 0)); nn / tn take them as mask_bits instead of the float `mask` (which then is ignored): the masked backward products
+ * read 1 bit instead of 32 per element. */
+int arcn_gemm_tn_split(const float *dy, const float *mask, const uint32_t *mask_bits, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *db,
+                       float *scratch, int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate, void *stream);
 /* The same network with a LEVEL-MAJOR input / input gradient: x_lm[(l * x_stride + s) * 2 + f], 2 features per level (what
  * arcn_hashgrid_fwd_xcd(level_major = 1) writes and arcn_hashgrid_bwd_lm consumes).  Wired for the bias-free 2-layer nets fed by
  * the hash grid (input 32 or 64 wide, hidden <= 64, output <= 16); -1 otherwise.  bwd: dx_lm in the layout of x_lm, dweights

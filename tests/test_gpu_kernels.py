@@ -1016,6 +1016,29 @@ def test_gemm_products_vs_float64(S, K, Nn):
         assert (dxm.double() - refx).abs().max() <= 2e-6 * max(1.0, refx.abs().max().item())
 
 
+@pytest.mark.parametrize('S,K,Nn', [(3001, 256, 256), (1111, 320, 256), (2000, 284, 128), (777, 128, 384)])
+def test_relu_bit_masks_equal_float_masks(S, K, Nn):
+    """arcn_gemm_nt_split(relu_bits): bit b of word w of a row is (y[32 w + b] > 0); the masked gradient products give bit-identical
+    results whether they read those words (mask_bits) or y itself as the mask (linear.py:11-35's ReLU backward)."""
+    from arcnerf_amd.ops import functional as Fn
+    g = torch.Generator().manual_seed(S + K)
+    x = torch.randn(S, K, generator=g).cuda()
+    w = (torch.randn(Nn, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(Nn, generator=g).cuda()
+    dy = torch.randn(S, Nn, generator=g).cuda()
+    assert Fn.relu_bits_supported(x, K, Nn)
+    y, bits = Fn.gemm_nt(x, w, b, act='relu', want_bits=True)
+    assert torch.equal(y, Fn.gemm_nt(x, w, b, act='relu'))
+    ref = (y > 0).view(S, Nn // 32, 32).to(torch.int64)
+    words = (ref << torch.arange(32, device='cuda')).sum(-1)
+    assert torch.equal(bits.to(torch.int64) & 0xffffffff, words)
+    assert torch.equal(Fn.gemm_nn(dy, w, mask_bits=bits), Fn.gemm_nn(dy, w, mask=y))
+    dw_b, db_b = Fn.gemm_tn(dy, x, mask_bits=bits, want_colsum=True)
+    dw_f, db_f = Fn.gemm_tn(dy, x, mask=y, want_colsum=True)
+    assert torch.equal(dw_b, dw_f) and torch.equal(db_b, db_f)
+    assert torch.equal(Fn.gemm_tn(dy, x, mask_bits=bits), Fn.gemm_tn(dy, x, mask=y))
+
+
 def test_linear_layers_double_backward_vs_torch():
     """a 3-layer softplus(100) net with a skip concat on ops.autograd.linear: outputs, d out / d x (create_graph), and the gradients of a
     loss on BOTH (the NeuS pattern: rgb loss + Eikonal on the normals) against the same net on torch.nn.functional.linear."""
