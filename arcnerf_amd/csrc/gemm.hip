@@ -454,9 +454,11 @@ __global__ void __launch_bounds__(256) gemm_split_w_kernel(const float *__restri
 // (MT, NT, WAVES_N) = (2, 8, 4): 128 outputs per workgroup, three workgroups per CU; (4, 8, 4): 256 outputs -- the sample operand is
 // read, split and staged once for twice the MFMAs (128 accumulator registers, two workgroups per CU).  The kernel covers the outputs
 // [n_off, min(n_off + gridDim.y * BN, No)).
-// MASK: 0 none, 1 the float tensor `mask` (layout of `in`; in * (mask > 0)), 2 a BIT mask: `mask` points at uint32 words, Ki / 32 per
-// row, bit b of word w = (y[32 w + b] > 0) - what the forward product of a ReLU layer writes through `relu_bits` (No / 32 words per row,
-// No % 32 == 0): the backward then reads 1 bit instead of 32 per masked element (a third less HBM traffic for the masked products).
+// MASK: 0 none, 1 the float tensor `mask` (layout of `in`; in * (mask > 0)), 2 a BIT mask: `mask` points at uint32 words in the layout
+// the forward product of a ReLU layer writes through `relu_bits`: word [s / 8][f / 4] holds the 8 rows 8 (s / 8) + i x 4 features
+// 4 (f / 4) + r of y as bit 4 i + r = (y > 0) (ceil(S / 8) x N / 4 words).  The backward then reads 1 bit instead of 32 per masked
+// element (a third less HBM traffic for the masked products), and the 8-row x 4-feature block is exactly what ONE staging thread of
+// the weight-gradient kernel masks: one 4-byte load instead of eight 16-byte ones.
 template <int MASK, int MT, int NT, int WAVES_N, bool BITS_OUT>
 __global__ void __launch_bounds__(256, (MASK == 1 || MT * NT > 16) ? 2 : 3)
 gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ mask, int64_t ld_in, const gu4 *__restrict__ Wf, const float *__restrict__ bias,
@@ -478,12 +480,12 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
     struct Staged {
         gf4 x[2][2];
         gf4 m[MASK == 1 ? 2 : 1][2];
-        uint32_t mb[2];
+        uint32_t mb[2][2];
         uint32_t ok;
     };
     Staged ra, rb;
     const uint32_t *__restrict__ mbits = reinterpret_cast<const uint32_t *>(mask);
-    const int mwords = Ki >> 5;
+    const int mquads = Ki >> 2;
 
     auto fetch = [&](int c, Staged &st) {
         st.ok = 0u;
@@ -497,9 +499,11 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
                 if (MASK == 1) st.m[q][h] = load_row4<true>(mask, s_base + sl, col + 16 * h, ld_in, cnt, Ki, 1);
                 st.ok |= (uint32_t)((s_base + sl < cnt) && (col + 16 * h < Ki)) << (2 * q + h);
             }
-            if (MASK == 2) {   // stage c = word c of the row (32 reduction elements): this thread's bits are 4 g + 16 h + 0..3
-                const int64_t row = s_base + sl < cnt ? s_base + sl : 0;
-                st.mb[q] = mbits[row * mwords + (c < mwords ? c : 0)];
+            if (MASK == 2) {   // the words of this row's octet and of the feature quads 8 c + g (+ 4): bits 4 (row & 7) + r
+                const int64_t oct = (s_base + sl < cnt ? s_base + sl : 0) >> 3;
+                const int quad = 8 * c + g;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) st.mb[q][h] = mbits[oct * mquads + (quad + 4 * h < mquads ? quad + 4 * h : 0)];
             }
         }
     };
@@ -514,7 +518,7 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
                 for (int r = 0; r < 4; ++r) {
                     float v = ((st.ok >> (2 * q + h)) & 1u) ? st.x[q][h][r] : 0.f;
                     if (MASK == 1) v = st.m[q][h][r] > 0.f ? v : 0.f;
-                    if (MASK == 2) v = ((st.mb[q] >> (4 * g + 16 * h + r)) & 1u) ? v : 0.f;
+                    if (MASK == 2) v = ((st.mb[q][h] >> (4 * (sl & 7) + r)) & 1u) ? v : 0.f;
                     x[4 * h + r] = v;
                 }
             gu4 hi, md, lo;
@@ -626,28 +630,25 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
             }
         }
     }
-    // ReLU bit mask of the outputs (No % 32 == 0, host-checked): a lane's four outputs are a nibble, the four lane groups of a sample
-    // and two adjacent tiles make a 32-bit word; every lane runs the exchange, lane group 0 stores
+    // ReLU bit mask of the outputs: a lane's four outputs of a sample are a nibble; the eight lanes j = 8 o .. 8 o + 7 of a lane group
+    // hold the eight rows of one word (every lane runs the exchange, the first lane of an octet stores)
     if (BITS_OUT && relu_bits) {
-        const int words = No >> 5, w0 = (n_base + wave_n * MT * 16) >> 5;
+        const int quads = No >> 2;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int64_t s = s_base + (wave_m * NT + n) * 16 + j;
+        for (int m = 0; m < MT; ++m) {
+            const int no = n_base + (wave_n * MT + m) * 16 + 4 * g;
 #pragma unroll
-            for (int k = 0; k < (MT + 1) / 2; ++k) {
+            for (int n = 0; n < NT; ++n) {
+                const int64_t s = s_base + (wave_m * NT + n) * 16 + j;
+                const gf4 v = acc[m][n] + bvm[m];
                 uint32_t wd = 0u;
 #pragma unroll
-                for (int mm = 0; mm < 2; ++mm) {
-                    const int m = 2 * k + mm;
-                    if (m < MT) {
-                        const gf4 v = acc[m][n] + bvm[m];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) wd |= (uint32_t)(v[r] > 0.f) << (16 * mm + 4 * g + r);
-                    }
-                }
-                wd |= (uint32_t)__shfl_xor((int)wd, 16);
-                wd |= (uint32_t)__shfl_xor((int)wd, 32);
-                if (g == 0 && s < cnt && w0 + k < words) relu_bits[s * words + w0 + k] = wd;
+                for (int r = 0; r < 4; ++r) wd |= (uint32_t)(v[r] > 0.f) << (4 * (j & 7) + r);
+                wd = s < cnt ? wd : 0u;
+                wd |= (uint32_t)__shfl_xor((int)wd, 1);
+                wd |= (uint32_t)__shfl_xor((int)wd, 2);
+                wd |= (uint32_t)__shfl_xor((int)wd, 4);
+                if ((j & 7) == 0 && s < cnt && no < No) relu_bits[(s >> 3) * quads + (no >> 2)] = wd;
             }
         }
     }
@@ -659,7 +660,7 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
 // contiguous bytes of a row), which is four fragments' worth of eight-sample columns in its own registers -- the transposition costs
 // nothing -- splits them and writes 16-byte fragment slots.  One LDS stage (48 KB: three workgroups per CU) with the next stage's loads
 // in flight over the MFMA block.  Rows 16-byte aligned, N and K multiples of 4.
-// MASK: 0 none, 1 float mask tensor, 2 ReLU bit mask (N / 32 uint32 words per row; see gemm_rows_split_kernel)
+// MASK: 0 none, 1 float mask tensor, 2 ReLU bit mask (8-row x 4-feature words; see gemm_rows_split_kernel)
 template <int MASK, bool COLSUM>
 __global__ void __launch_bounds__(256, (MASK != 0 || COLSUM) ? 2 : 3)
 gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask, int64_t ld_a, const float *__restrict__ B, int64_t ld_b, float *__restrict__ scratch,
@@ -684,26 +685,26 @@ gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask
     const int fcol = (f_base + 4 * nq < f_cnt) ? f_base + 4 * nq : 0;   // features past the matrix: any valid column (never stored)
     gf4 xr[8];
     gf4 mr[MASK == 1 ? 8 : 1];
-    uint32_t mb[MASK == 2 ? 8 : 1];
+    uint32_t mb = 0xffffffffu;   // MASK == 2: ONE word = this thread's 8 rows x 4 features of the stage
     const uint32_t *__restrict__ mbits = reinterpret_cast<const uint32_t *>(mask);
-    const int mwords = N >> 5, mword = fcol >> 5, mshift = fcol & 31;   // (A-role threads: fcol is a column of dy)
+    const int mquads = N >> 2, mquad = fcol >> 2;   // (A-role threads: fcol is a column of dy)
     uint32_t ok = 0u;
     float csum[4] = {0.f, 0.f, 0.f, 0.f};   // want_colsum: column sums of the (masked) A operand = the layer's bias gradient, for free
     const int64_t n_chunks = s_lo < s_hi ? (s_hi - s_lo + BS - 1) / BS : 0;
 
     // (uniform stage base + one 32-bit byte offset per row: half the address registers of eight 64-bit pointers)
-    auto fetch = [&](int64_t c) {
+    auto fetch = [&](int64_t c, bool live) {
         ok = 0u;
         const int64_t row0 = s_lo + c * BS;
+        if (MASK == 2 && !is_b) mb = mbits[((row0 >> 3) + sg) * mquads + mquad];   // (s_lo and the stages are multiples of 32 rows)
         const char *base = reinterpret_cast<const char *>(src + row0 * ld_s);
         const char *mbase = reinterpret_cast<const char *>(mask + row0 * ld_s);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const bool in = row0 + 8 * sg + e < s_hi;
+            const bool in = live && row0 + 8 * sg + e < s_hi;   // (!live: the stage re-read past the end counts as all-invalid rows)
             const uint32_t off = (uint32_t)(((in ? 8 * sg + e : 0) * ld_s + fcol) * 4);
             xr[e] = *reinterpret_cast<const gf4 *>(base + off);
             if (MASK == 1) mr[e] = *reinterpret_cast<const gf4 *>((is_b ? base : mbase) + off);
-            if (MASK == 2) mb[e] = is_b ? 0xffffffffu : mbits[(row0 + (in ? 8 * sg + e : 0)) * mwords + mword];
             ok |= (uint32_t)in << e;
         }
     };
@@ -716,7 +717,7 @@ gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask
             for (int e = 0; e < 8; ++e) {
                 float v = ((ok >> e) & 1u) ? xr[e][r] : 0.f;
                 if (MASK == 1) v = (is_b || mr[e][r] > 0.f) ? v : 0.f;
-                if (MASK == 2) v = ((mb[e] >> (mshift + r)) & 1u) ? v : 0.f;
+                if (MASK == 2) v = __uint_as_float(__float_as_uint(v) & (uint32_t)__builtin_amdgcn_sbfe((int)mb, 4 * e + r, 1));   // bit -> 0 / ~0
                 x[e] = v;
             }
             if (COLSUM) csum[r] += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
@@ -766,24 +767,16 @@ gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask
     };
 
     if (n_chunks > 0) {
-        fetch(0);
+        fetch(0, true);
         stash();
         __syncthreads();
         for (int64_t c = 0; c < n_chunks; ++c) {
-            fetch(c + 1 < n_chunks ? c + 1 : c);   // (unconditional, like the consumers below: see gemm_rows_split_kernel)
+            // (unconditional, like the consumers below: see gemm_rows_split_kernel; past the end: the last stage again, as zeros)
+            fetch(c + 1 < n_chunks ? c + 1 : c, c + 1 < n_chunks);
             __builtin_amdgcn_sched_barrier(0);
             compute();
             __syncthreads();
-            float keep[4];
-            if (COLSUM) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) keep[r] = csum[r];
-            }
             stash();
-            if (COLSUM && c + 1 >= n_chunks) {   // the stage re-read past the end is never multiplied, and must not be summed either
-#pragma unroll
-                for (int r = 0; r < 4; ++r) csum[r] = keep[r];
-            }
             __syncthreads();
         }
     }
@@ -894,8 +887,7 @@ static int gemm_rows_split(bool trans_w, const float *in, const float *mask, con
     if (!in || !W || !out || !ws || Ki < 1 || No < 1) return einval("gemm_split: missing / invalid argument");
     if (!is_aligned(in, ld_in) || (Ki & 3) != 0 || (reinterpret_cast<uintptr_t>(ws) & 15u) != 0 || (mask && !is_aligned(mask, ld_in)))
         return einval("gemm_split: the row operand needs 16-byte aligned rows and a reduction length that is a multiple of 4");
-    if (mask_bits && (Ki & 31) != 0) return einval("gemm_split: a bit mask needs a reduction length that is a multiple of 32");
-    if (relu_bits && ((No & 31) != 0 || act != ARCN_ACT_RELU)) return einval("gemm_split: relu_bits needs a ReLU epilogue and outputs in multiples of 32");
+    if (relu_bits && ((No & 3) != 0 || act != ARCN_ACT_RELU)) return einval("gemm_split: relu_bits needs a ReLU epilogue and outputs in multiples of 4");
     if ((mask || mask_bits) && relu_bits) return einval("gemm_split: relu_bits is an output of the unmasked forward product");
     const int mk = mask_bits ? 2 : (mask ? 1 : 0);
     if (mask_bits) mask = reinterpret_cast<const float *>(mask_bits);
@@ -930,7 +922,7 @@ static int gemm_rows_split(bool trans_w, const float *in, const float *mask, con
         done = No / 256 * 256;
     }
     const int rem = No - done;
-    if (rem > 0 && rem <= 16 && done > 0 && mk != 2) {
+    if (rem > 0 && rem <= 16 && done > 0 && mk != 2 && !relu_bits) {   // (the exact kernel neither reads nor writes bit masks)
         const float *Wr = trans_w ? W + done : W + (int64_t)done * ld_w;
         const int rc = gemm_rows(trans_w, in, mask, ld_in, Wr, ld_w, bias ? bias + done : nullptr, out + done, ld_out, S, n_ptr, Ki, rem, act, beta, stream);
         if (rc != ARCN_OK) return rc;
@@ -945,15 +937,15 @@ static int gemm_rows_split(bool trans_w, const float *in, const float *mask, con
 
 /* arcn_gemm_nt on the bf16 matrix rate: x and w as three bf16 planes each, six MFMAs per product, f32 accuracy (see the kernel).  x rows
  * 16-byte aligned, K a multiple of 4; `ws` = arcn_gemm_split_bytes(N, K) bytes of device scratch (the split weights).  relu_bits (may be
- * NULL; act = ReLU, N % 32 == 0): n_rows x N / 32 words, bit b of word w of a row = (y[32 w + b] > 0) - the mask the layer's backward
- * needs, 1/32 of the bytes of y. */
+ * NULL; act = ReLU, N % 4 == 0): ceil(n_rows / 8) x N / 4 words, word [s / 8][f / 4] bit 4 (s % 8) + (f % 4) = (y[s][f] > 0) - the mask
+ * the layer's backward needs, 1/32 of the bytes of y. */
 ARCN_EXPORT int arcn_gemm_nt_split(const float *x, int64_t ld_x, const float *w, const float *bias, float *y, uint32_t *relu_bits, int64_t ld_y,
                                    int64_t n_rows, const int32_t *n_ptr, int K, int N, int act, float beta, void *ws, int64_t ws_bytes, void *stream) {
     return gemm_rows_split(false, x, nullptr, nullptr, ld_x, w, K, bias, y, relu_bits, ld_y, n_rows, n_ptr, K, N, act, beta, ws, ws_bytes, stream);
 }
 
 /* arcn_gemm_nn likewise: dy rows 16-byte aligned, N a multiple of 4; `ws` = arcn_gemm_split_bytes(K, N) bytes.  mask_bits (may be NULL,
- * then `mask` applies; N % 32 == 0): the relu_bits of the layer's forward instead of its float output as the mask. */
+ * then `mask` applies): the relu_bits of the layer's forward instead of its float output as the mask. */
 ARCN_EXPORT int arcn_gemm_nn_split(const float *dy, const float *mask, const uint32_t *mask_bits, int64_t ld_dy, const float *w, float *dx, int64_t ld_dx,
                                    int64_t n_rows, const int32_t *n_ptr, int N, int K, void *ws, int64_t ws_bytes, void *stream) {
     return gemm_rows_split(true, dy, mask, mask_bits, ld_dy, w, K, nullptr, dx, nullptr, ld_dx, n_rows, n_ptr, N, K, ARCN_ACT_NONE, 1.0f, ws, ws_bytes,
@@ -1000,12 +992,11 @@ ARCN_EXPORT int arcn_gemm_tn(const float *dy, const float *mask, int64_t ld_dy, 
 
 /* arcn_gemm_tn on the bf16 matrix rate (split form, see arcn_gemm_nt_split): same arguments and scratch; dy, mask and x rows 16-byte
  * aligned, N and K multiples of 4.  db (N floats, may be NULL) (+)= the column sums of dy' -- the layer's bias gradient, summed from the
- * operand as it is staged (no second pass over dy).  mask_bits (may be NULL; N % 32 == 0): the forward's relu_bits as the mask. */
+ * operand as it is staged (no second pass over dy).  mask_bits (may be NULL): the forward's relu_bits as the mask. */
 ARCN_EXPORT int arcn_gemm_tn_split(const float *dy, const float *mask, const uint32_t *mask_bits, int64_t ld_dy, const float *x, int64_t ld_x, float *dw,
                                    float *db, float *scratch, int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate,
                                    void *stream) {
     if (!dy || !x || !dw || !scratch || N < 1 || K < 1) return einval("gemm_tn_split: missing / invalid argument");
-    if (mask_bits && (N & 31) != 0) return einval("gemm_tn_split: a bit mask needs N to be a multiple of 32");
     const int mk = mask_bits ? 2 : (mask ? 1 : 0);
     if (scratch_floats < arcn_gemm_tn_scratch_floats(n_rows, N, K)) return einval("gemm_tn_split: scratch smaller than arcn_gemm_tn_scratch_floats");
     if (!is_aligned(dy, ld_dy) || !is_aligned(x, ld_x) || (N & 3) != 0 || (K & 3) != 0 || (mask && !is_aligned(mask, ld_dy)))

@@ -552,12 +552,12 @@ def _split_ws(n_out, k_red, device):
 
 def relu_bits_supported(rows, k_red, n_out):
     """whether gemm_nt(..., want_bits=True) can write the ReLU mask of its output as bits (split kernels, outputs in multiples of 32)"""
-    return _use_split(rows, k_red, n_out) and n_out % 32 == 0 and os.environ.get('ARCN_RELU_BITS', '1') != '0'
+    return _use_split(rows, k_red, n_out) and n_out % 4 == 0 and os.environ.get('ARCN_RELU_BITS', '1') != '0'
 
 
 def gemm_nt(x, w, bias=None, act=None, beta=1.0, want_bits=False):
-    """y (S,N) = act(x (S,K) @ w (N,K).T + bias); want_bits (act = relu, relu_bits_supported): also the (S, N / 32) int32 words whose
-    bit b of word w is (y[:, 32 w + b] > 0) - the mask gemm_nn / gemm_tn take as `mask_bits` (1/32 of the bytes of y)"""
+    """y (S,N) = act(x (S,K) @ w (N,K).T + bias); want_bits (act = relu, relu_bits_supported): also the (ceil(S / 8), N / 4) int32 words
+    [s // 8, f // 4] whose bit 4 (s % 8) + (f % 4) is (y[s, f] > 0) - the mask gemm_nn / gemm_tn take as `mask_bits` (1/32 of y's bytes)"""
     _req(x, w, bias)
     x, w, bias = _f32(x), _f32(w), _f32(bias)
     S, K = x.shape
@@ -568,8 +568,8 @@ def gemm_nt(x, w, bias=None, act=None, beta=1.0, want_bits=False):
         ws = _split_ws(Nn, K, x.device)
         bits = None
         if want_bits:
-            assert act == 'relu' and Nn % 32 == 0
-            bits = torch.empty((S, Nn // 32), dtype=torch.int32, device=x.device)
+            assert act == 'relu' and Nn % 4 == 0
+            bits = torch.empty(((S + 7) // 8, Nn // 4), dtype=torch.int32, device=x.device)
         N.check(N.lib().arcn_gemm_nt_split(N.ptr(x), K, N.ptr(w), N.ptr(bias), N.ptr(y), N.ptr(bits), Nn, S, None, K, Nn, N.ACT[act], float(beta),
                                          N.ptr(ws), ws.numel(), N.stream()), 'gemm_nt_split')
         return (y, bits) if want_bits else y

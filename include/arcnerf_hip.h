@@ -310,9 +310,9 @@ int arcn_gemm_nt_split(const float *x, int64_t ld_x, const float *w, const float
 int arcn_gemm_nn_split(const float *dy, const float *mask, const uint32_t *mask_bits, int64_t ld_dy, const float *w, float *dx, int64_t ld_dx,
                        int64_t n_rows, const int32_t *n_ptr, int N, int K, void *ws, int64_t ws_bytes, void *stream);
 /* tn: db (N floats, may be NULL) (+)= the column sums of dy' = the layer's bias gradient, summed from the operand as it is staged.
- * ReLU masks as BITS: arcn_gemm_nt_split(act = ReLU, N % 32 == 0) writes relu_bits (n_rows x N / 32 uint32, bit b of word w of a row =
- * (y[32 w + b] > 0)); nn / tn take them as mask_bits instead of the float `mask` (which then is ignored): the masked backward products
- * read 1 bit instead of 32 per element. */
+ * ReLU masks as BITS: arcn_gemm_nt_split(act = ReLU, N % 4 == 0) writes relu_bits (ceil(n_rows / 8) x N / 4 uint32: word [s / 8][f / 4],
+ * bit 4 (s % 8) + (f % 4) = (y[s][f] > 0)); nn / tn take them as mask_bits instead of the float `mask` (which then is ignored): the
+ * masked backward products read 1 bit instead of 32 per element. */
 int arcn_gemm_tn_split(const float *dy, const float *mask, const uint32_t *mask_bits, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *db,
                        float *scratch, int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate, void *stream);
 /* The same network with a LEVEL-MAJOR input / input gradient: x_lm[(l * x_stride + s) * 2 + f], 2 features per level (what

@@ -1016,10 +1016,10 @@ def test_gemm_products_vs_float64(S, K, Nn):
         assert (dxm.double() - refx).abs().max() <= 2e-6 * max(1.0, refx.abs().max().item())
 
 
-@pytest.mark.parametrize('S,K,Nn', [(3001, 256, 256), (1111, 320, 256), (2000, 284, 128), (777, 128, 384)])
+@pytest.mark.parametrize('S,K,Nn', [(3001, 256, 256), (1111, 320, 256), (2000, 284, 128), (777, 128, 384), (130, 68, 132)])
 def test_relu_bit_masks_equal_float_masks(S, K, Nn):
-    """arcn_gemm_nt_split(relu_bits): bit b of word w of a row is (y[32 w + b] > 0); the masked gradient products give bit-identical
-    results whether they read those words (mask_bits) or y itself as the mask (linear.py:11-35's ReLU backward)."""
+    """arcn_gemm_nt_split(relu_bits): word [s / 8][f / 4] bit 4 (s % 8) + f % 4 is (y[s][f] > 0); the masked gradient products give
+    bit-identical results whether they read those words (mask_bits) or y itself as the mask (linear.py:11-35's ReLU backward)."""
     from arcnerf_amd.ops import functional as Fn
     g = torch.Generator().manual_seed(S + K)
     x = torch.randn(S, K, generator=g).cuda()
@@ -1029,8 +1029,11 @@ def test_relu_bit_masks_equal_float_masks(S, K, Nn):
     assert Fn.relu_bits_supported(x, K, Nn)
     y, bits = Fn.gemm_nt(x, w, b, act='relu', want_bits=True)
     assert torch.equal(y, Fn.gemm_nt(x, w, b, act='relu'))
-    ref = (y > 0).view(S, Nn // 32, 32).to(torch.int64)
-    words = (ref << torch.arange(32, device='cuda')).sum(-1)
+    So = (S + 7) // 8
+    pos = torch.zeros(So * 8, Nn, dtype=torch.int64, device='cuda')
+    pos[:S] = (y > 0)
+    blocks = pos.view(So, 8, Nn // 4, 4).permute(0, 2, 1, 3).reshape(So, Nn // 4, 32)      # word [s / 8][f / 4], bit 4 (s % 8) + f % 4
+    words = (blocks << torch.arange(32, device='cuda')).sum(-1)
     assert torch.equal(bits.to(torch.int64) & 0xffffffff, words)
     assert torch.equal(Fn.gemm_nn(dy, w, mask_bits=bits), Fn.gemm_nn(dy, w, mask=y))
     dw_b, db_b = Fn.gemm_tn(dy, x, mask_bits=bits, want_colsum=True)
