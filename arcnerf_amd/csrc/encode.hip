@@ -113,13 +113,75 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const float *__restrict__ 
         dx[i] = dy[i] * act_grad(x[i], y ? y[i] : 0.f, act, beta);
 }
 
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// ---- softplus closed under differentiation (the sdf nets of NeuS: normals with create_graph, Eikonal loss through them again) -------
+// y = softplus_beta(z) (torch threshold 20);  s = dy/dz = sigmoid(beta z);  ds/dz = beta s (1 - s).
+//   softplus_grad : out = g * s                                   (first backward; ALSO the gradient of out with respect to g)
+//   softplus_grad2: dg = h * s,  dz = h * g * beta s (1 - s)       (backward of softplus_grad for an incoming h: one pass over z, g, h
+//                                                                   instead of torch's sigmoid / mul / sigmoid_backward chain)
+// one float4 per lane (n a multiple of 4 and 16-byte aligned pointers on the vector path)
+__device__ __forceinline__ void softplus_s(float z, float beta, float &s, float &ds) {
+    const float bv = beta * z;
+    if (bv > 20.f) { s = 1.f; ds = 0.f; return; }
+    const float e = expf(bv), r = 1.f / (e + 1.f);
+    s = e * r;
+    ds = beta * s * r;
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) softplus_grad_kernel(const float *__restrict__ z, const float *__restrict__ g, float *__restrict__ out, int64_t n,
+                                                            float beta) {
+    constexpr int W = VEC ? 4 : 1;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * W; i < n; i += (int64_t)gridDim.x * blockDim.x * W) {
+        float zv[W], gv[W], ov[W];
+        if (VEC) { *reinterpret_cast<f4v *>(zv) = *reinterpret_cast<const f4v *>(z + i); *reinterpret_cast<f4v *>(gv) = *reinterpret_cast<const f4v *>(g + i); }
+        else { zv[0] = z[i]; gv[0] = g[i]; }
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            float s, ds;
+            softplus_s(zv[k], beta, s, ds);
+            ov[k] = gv[k] * s;
+        }
+        if (VEC) *reinterpret_cast<f4v *>(out + i) = *reinterpret_cast<const f4v *>(ov);
+        else out[i] = ov[0];
+    }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) softplus_grad2_kernel(const float *__restrict__ z, const float *__restrict__ g, const float *__restrict__ h,
+                                                             float *__restrict__ dg, float *__restrict__ dz, int64_t n, float beta) {
+    constexpr int W = VEC ? 4 : 1;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * W; i < n; i += (int64_t)gridDim.x * blockDim.x * W) {
+        float zv[W], gv[W], hv[W], a[W], b[W];
+        if (VEC) {
+            *reinterpret_cast<f4v *>(zv) = *reinterpret_cast<const f4v *>(z + i);
+            *reinterpret_cast<f4v *>(gv) = *reinterpret_cast<const f4v *>(g + i);
+            *reinterpret_cast<f4v *>(hv) = *reinterpret_cast<const f4v *>(h + i);
+        } else { zv[0] = z[i]; gv[0] = g[i]; hv[0] = h[i]; }
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            float s, ds;
+            softplus_s(zv[k], beta, s, ds);
+            a[k] = hv[k] * s;
+            b[k] = hv[k] * gv[k] * ds;
+        }
+        if (VEC) {
+            if (dg) *reinterpret_cast<f4v *>(dg + i) = *reinterpret_cast<const f4v *>(a);
+            if (dz) *reinterpret_cast<f4v *>(dz + i) = *reinterpret_cast<const f4v *>(b);
+        } else {
+            if (dg) dg[i] = a[0];
+            if (dz) dz[i] = b[0];
+        }
+    }
+}
+
 // ---- geo -> radiance glue of Base3dModel._forward_pts_dir (arcnerf/models/base_3d_model.py:233-254) ---------------
 // sigma = out_act(geo_out[:,0]) (EncoderMLPGeoNet.handle_output / FusedMLPGeoNet.handle_output_combine);
 // rad_in = fuse_radiance_inputs(..) for modes 'fv' / 'vf' (encoder_mlp_network.py:93-118): geo feature slice and
 // SH(normalize(view_dir)) concatenated in mode order; normalize = v / (|v| + 1e-8) (geometry/transformation.py:21).
 // one lane per float4 of the output rows: loads and stores are fully coalesced (16 B per lane, consecutive lanes consecutive
 // addresses).  Requires Wf, Wg, feat_off and deg^2 to be multiples of 4 (NGP: 16/16/0/16); other shapes take the row kernel.
-typedef float f4v __attribute__((ext_vector_type(4)));
 
 // SH(normalize(d)) once per RAY: every sample of a ray shares its direction, the glue below then gathers the row by ray id
 // instead of evaluating the polynomials per sample (4x over, one per output quad)
@@ -278,6 +340,31 @@ ARCN_EXPORT int arcn_act_bwd(const float *x, const float *y, const float *dy, fl
     if (!x || !dy || !dx) return einval("act_bwd: missing argument");
     hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, y, dy, dx, n, act, beta);
     return check_launch("act_bwd");
+}
+
+static inline bool vec4_ok(int64_t n, const void *a, const void *b, const void *c, const void *d, const void *e) {
+    uintptr_t m = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e;
+    return (n & 3) == 0 && (m & 15u) == 0;
+}
+
+ARCN_EXPORT int arcn_softplus_grad(const float *z, const float *g, float *out, int64_t n, float beta, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!z || !g || !out) return einval("softplus_grad: missing argument");
+    if (vec4_ok(n, z, g, out, nullptr, nullptr))
+        hipLaunchKernelGGL(softplus_grad_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), z, g, out, n, beta);
+    else
+        hipLaunchKernelGGL(softplus_grad_kernel<false>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), z, g, out, n, beta);
+    return check_launch("softplus_grad");
+}
+
+ARCN_EXPORT int arcn_softplus_grad2(const float *z, const float *g, const float *h, float *dg, float *dz, int64_t n, float beta, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!z || !g || !h || (!dg && !dz)) return einval("softplus_grad2: missing argument");
+    if (vec4_ok(n, z, g, h, dg, dz))
+        hipLaunchKernelGGL(softplus_grad2_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), z, g, h, dg, dz, n, beta);
+    else
+        hipLaunchKernelGGL(softplus_grad2_kernel<false>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), z, g, h, dg, dz, n, beta);
+    return check_launch("softplus_grad2");
 }
 
 ARCN_EXPORT int arcn_ngp_glue_fwd(const float *geo_out, const float *dirs, int Wg, int feat_off, int Wf, int sh_degree,

@@ -31,6 +31,8 @@ class DenseLayer(Linear):
             y = linear_act_nograd(x, self.weight, self.bias, 'softplus', float(self.activation.beta))   # graph-free passes only
             if y is not None:
                 return y
+            from ...ops.autograd import softplus
+            return softplus(super().forward(x), float(self.activation.beta))    # closed under differentiation on fused kernels
         return self.activation(super().forward(x))
 
 

@@ -326,6 +326,48 @@ class GemmTNB(torch.autograd.Function):
         return d_a, d_b
 
 
+class SoftplusFn(torch.autograd.Function):
+    """torch.nn.functional.softplus(z, beta, threshold=20) differentiable twice on fused kernels: the sdf nets of NeuS evaluate it,
+    take d sdf / d x through it with create_graph=True (SoftplusGradFn) and differentiate the Eikonal loss through that again."""
+
+    @staticmethod
+    def forward(ctx, z, beta):
+        ctx.save_for_backward(z)
+        ctx.beta = beta
+        return F.act_fwd(z, 'softplus', beta)
+
+    @staticmethod
+    def backward(ctx, g):
+        z, = ctx.saved_tensors
+        return SoftplusGradFn.apply(g.contiguous(), z, ctx.beta), None
+
+
+class SoftplusGradFn(torch.autograd.Function):
+    """out = g * sigmoid(beta z); backward (first order from here: a third differentiation raises): dg = h s, dz = h g beta s (1 - s)
+    from ONE pass over z, g, h"""
+
+    @staticmethod
+    def forward(ctx, g, z, beta):
+        ctx.save_for_backward(g, z)
+        ctx.beta = beta
+        return F.softplus_grad(z, g, beta)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, h):
+        g, z = ctx.saved_tensors
+        dg, dz = F.softplus_grad2(z, g, h.contiguous(), ctx.beta, want_dg=ctx.needs_input_grad[0], want_dz=ctx.needs_input_grad[1])
+        return dg, dz, None
+
+
+def softplus(z, beta):
+    """softplus on the fused twice-differentiable kernels for fp32 CUDA tensors (ARCN_SOFTPLUS_FUSED=0: torch), torch otherwise"""
+    import os
+    if not (z.is_cuda and z.dtype == torch.float32 and z.numel() > 0) or os.environ.get('ARCN_SOFTPLUS_FUSED', '1') == '0':
+        return torch.nn.functional.softplus(z, beta=beta)
+    return SoftplusFn.apply(z.contiguous(), float(beta))
+
+
 class LinearReluFn(torch.autograd.Function):
     """y = relu(x @ w.T + bias) in ONE kernel (bias + activation in the product's epilogue); backward with the activation's mask
     folded into the operand loads of the two gradient products (dpre = dy * (y > 0) is never written): per layer and direction one

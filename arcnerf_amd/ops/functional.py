@@ -472,6 +472,25 @@ def act_fwd(x, act, beta=1.0):
     return y
 
 
+def softplus_grad(z, g, beta):
+    """g * sigmoid(beta z) (torch softplus threshold 20)"""
+    _req(z, g)
+    z, g = _f32(z), _f32(g)
+    out = torch.empty_like(z)
+    N.check(N.lib().arcn_softplus_grad(N.ptr(z), N.ptr(g), N.ptr(out), z.numel(), float(beta), N.stream()), 'softplus_grad')
+    return out
+
+
+def softplus_grad2(z, g, h, beta, want_dg=True, want_dz=True):
+    """backward of softplus_grad for an incoming h: (h * s, h * g * beta s (1 - s)), s = sigmoid(beta z), in one pass"""
+    _req(z, g, h)
+    z, g, h = _f32(z), _f32(g), _f32(h)
+    dg = torch.empty_like(z) if want_dg else None
+    dz = torch.empty_like(z) if want_dz else None
+    N.check(N.lib().arcn_softplus_grad2(N.ptr(z), N.ptr(g), N.ptr(h), N.ptr(dg), N.ptr(dz), z.numel(), float(beta), N.stream()), 'softplus_grad2')
+    return dg, dz
+
+
 def act_bwd(x, y, dy, act, beta=1.0):
     _req(x, dy)
     x, y, dy = _f32(x), _f32(y), _f32(dy)

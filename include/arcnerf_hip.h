@@ -350,6 +350,12 @@ int64_t arcn_mlp_scratch_floats(const arcn_mlp_desc *desc_host, int64_t n_cap);
 
 /* elementwise activation (TruncExp F1 etc.) */
 int arcn_act_fwd(const float *x, float *y, int64_t n, int act, float beta, void *stream);
+/* softplus closed under differentiation (nn.Softplus(beta = 100) of the NeuS sdf net, base_modules/activation.py; the normals are
+ * d sdf / d x with create_graph = True and the Eikonal loss differentiates them again, base_network.py:30-44), s = sigmoid(beta z):
+ *   arcn_softplus_grad : out = g * s                                  first backward (and d out / d g applied to g)
+ *   arcn_softplus_grad2: dg = h * s, dz = h * g * beta s (1 - s)       backward of arcn_softplus_grad for an incoming h (dg / dz may be NULL) */
+int arcn_softplus_grad(const float *z, const float *g, float *out, int64_t n, float beta, void *stream);
+int arcn_softplus_grad2(const float *z, const float *g, const float *h, float *dg, float *dz, int64_t n, float beta, void *stream);
 int arcn_act_bwd(const float *x, const float *y, const float *dy, float *dx, int64_t n, int act, float beta,
                  void *stream);
 

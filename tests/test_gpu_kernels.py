@@ -1042,6 +1042,29 @@ def test_relu_bit_masks_equal_float_masks(S, K, Nn):
     assert torch.equal(Fn.gemm_tn(dy, x, mask_bits=bits), Fn.gemm_tn(dy, x, mask=y))
 
 
+@pytest.mark.parametrize('n', [(4096, 256), (1001, 217), (7,)])
+def test_softplus_twice_differentiable_vs_torch(n):
+    """ops.autograd.softplus (SoftplusFn / SoftplusGradFn on arcn_softplus_grad / arcn_softplus_grad2) against
+    torch.nn.functional.softplus(beta=100) under the NeuS pattern: value, d / d input with create_graph, then the gradients of a loss on
+    both through the first derivative (base_network.py:30-44 over nn.Softplus(beta=100), activation.py)."""
+    from arcnerf_amd.ops.autograd import softplus
+    g = torch.Generator().manual_seed(len(n))
+    z0 = (torch.randn(*n, generator=g) * 0.08).cuda()
+    z0.view(-1)[:3] = torch.tensor([0.5, -0.5, 0.2])           # beyond / far below / at the threshold beta z = 20
+    w0 = torch.randn(*n, generator=g).cuda()
+    res = {}
+    for name, fn in (('hip', lambda t: softplus(t, 100.0)), ('torch', lambda t: torch.nn.functional.softplus(t, beta=100.0))):
+        z = z0.clone().requires_grad_(True)
+        w = w0.clone().requires_grad_(True)
+        y = fn(z * w)
+        dz, = torch.autograd.grad(y, z, torch.ones_like(y) * 0.7, create_graph=True)
+        loss = (y ** 2).sum() + (dz ** 2).sum() * 0.3 + (dz * w).sum()
+        gz, gw = torch.autograd.grad(loss, (z, w))
+        res[name] = (y.detach(), dz.detach(), gz, gw)
+    for a, b, tol in zip(res['hip'], res['torch'], (1e-6, 1e-5, 1e-4, 1e-4)):
+        assert (a - b).abs().max() <= tol * max(1.0, b.abs().max().item()), (a - b).abs().max()
+
+
 def test_linear_layers_double_backward_vs_torch():
     """a 3-layer softplus(100) net with a skip concat on ops.autograd.linear: outputs, d out / d x (create_graph), and the gradients of a
     loss on BOTH (the NeuS pattern: rgb loss + Eikonal on the normals) against the same net on torch.nn.functional.linear."""
