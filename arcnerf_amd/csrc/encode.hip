@@ -121,9 +121,17 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 //   softplus_grad2: dg = h * s,  dz = h * g * beta s (1 - s)       (backward of softplus_grad for an incoming h: one pass over z, g, h
 //                                                                   instead of torch's sigmoid / mul / sigmoid_backward chain)
 // one float4 per lane (n a multiple of 4 and 16-byte aligned pointers on the vector path)
-__device__ __forceinline__ void softplus_s(float z, float beta, float &s, float &ds) {
+// from_y: the argument is y = softplus(z) itself (a layer that applies the activation in its product's epilogue keeps no z):
+// s = 1 - e^(-beta y) exactly, and ds is then d s / d y = beta (1 - s) (the chain through y supplies the second factor s).
+__device__ __forceinline__ void softplus_s(float z, float beta, int from_y, float &s, float &ds) {
     const float bv = beta * z;
     if (bv > 20.f) { s = 1.f; ds = 0.f; return; }
+    if (from_y) {
+        const float q = expf(-bv);       // 1 - s
+        s = -expm1f(-bv);
+        ds = beta * q;
+        return;
+    }
     const float e = expf(bv), r = 1.f / (e + 1.f);
     s = e * r;
     ds = beta * s * r;
@@ -131,7 +139,7 @@ __device__ __forceinline__ void softplus_s(float z, float beta, float &s, float 
 
 template <bool VEC>
 __global__ void __launch_bounds__(256) softplus_grad_kernel(const float *__restrict__ z, const float *__restrict__ g, float *__restrict__ out, int64_t n,
-                                                            float beta) {
+                                                            float beta, int from_y) {
     constexpr int W = VEC ? 4 : 1;
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * W; i < n; i += (int64_t)gridDim.x * blockDim.x * W) {
         float zv[W], gv[W], ov[W];
@@ -140,7 +148,7 @@ __global__ void __launch_bounds__(256) softplus_grad_kernel(const float *__restr
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             float s, ds;
-            softplus_s(zv[k], beta, s, ds);
+            softplus_s(zv[k], beta, from_y, s, ds);
             ov[k] = gv[k] * s;
         }
         if (VEC) *reinterpret_cast<f4v *>(out + i) = *reinterpret_cast<const f4v *>(ov);
@@ -150,7 +158,7 @@ __global__ void __launch_bounds__(256) softplus_grad_kernel(const float *__restr
 
 template <bool VEC>
 __global__ void __launch_bounds__(256) softplus_grad2_kernel(const float *__restrict__ z, const float *__restrict__ g, const float *__restrict__ h,
-                                                             float *__restrict__ dg, float *__restrict__ dz, int64_t n, float beta) {
+                                                             float *__restrict__ dg, float *__restrict__ dz, int64_t n, float beta, int from_y) {
     constexpr int W = VEC ? 4 : 1;
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * W; i < n; i += (int64_t)gridDim.x * blockDim.x * W) {
         float zv[W], gv[W], hv[W], a[W], b[W];
@@ -162,7 +170,7 @@ __global__ void __launch_bounds__(256) softplus_grad2_kernel(const float *__rest
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             float s, ds;
-            softplus_s(zv[k], beta, s, ds);
+            softplus_s(zv[k], beta, from_y, s, ds);
             a[k] = hv[k] * s;
             b[k] = hv[k] * gv[k] * ds;
         }
@@ -347,23 +355,24 @@ static inline bool vec4_ok(int64_t n, const void *a, const void *b, const void *
     return (n & 3) == 0 && (m & 15u) == 0;
 }
 
-ARCN_EXPORT int arcn_softplus_grad(const float *z, const float *g, float *out, int64_t n, float beta, void *stream) {
+ARCN_EXPORT int arcn_softplus_grad(const float *z, const float *g, float *out, int64_t n, float beta, int from_y, void *stream) {
     if (n <= 0) return ARCN_OK;
     if (!z || !g || !out) return einval("softplus_grad: missing argument");
     if (vec4_ok(n, z, g, out, nullptr, nullptr))
-        hipLaunchKernelGGL(softplus_grad_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), z, g, out, n, beta);
+        hipLaunchKernelGGL(softplus_grad_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), z, g, out, n, beta, from_y);
     else
-        hipLaunchKernelGGL(softplus_grad_kernel<false>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), z, g, out, n, beta);
+        hipLaunchKernelGGL(softplus_grad_kernel<false>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), z, g, out, n, beta, from_y);
     return check_launch("softplus_grad");
 }
 
-ARCN_EXPORT int arcn_softplus_grad2(const float *z, const float *g, const float *h, float *dg, float *dz, int64_t n, float beta, void *stream) {
+ARCN_EXPORT int arcn_softplus_grad2(const float *z, const float *g, const float *h, float *dg, float *dz, int64_t n, float beta, int from_y,
+                                    void *stream) {
     if (n <= 0) return ARCN_OK;
     if (!z || !g || !h || (!dg && !dz)) return einval("softplus_grad2: missing argument");
     if (vec4_ok(n, z, g, h, dg, dz))
-        hipLaunchKernelGGL(softplus_grad2_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), z, g, h, dg, dz, n, beta);
+        hipLaunchKernelGGL(softplus_grad2_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), z, g, h, dg, dz, n, beta, from_y);
     else
-        hipLaunchKernelGGL(softplus_grad2_kernel<false>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), z, g, h, dg, dz, n, beta);
+        hipLaunchKernelGGL(softplus_grad2_kernel<false>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), z, g, h, dg, dz, n, beta, from_y);
     return check_launch("softplus_grad2");
 }
 

@@ -31,8 +31,11 @@ class DenseLayer(Linear):
             y = linear_act_nograd(x, self.weight, self.bias, 'softplus', float(self.activation.beta))   # graph-free passes only
             if y is not None:
                 return y
-            from ...ops.autograd import softplus
-            return softplus(super().forward(x), float(self.activation.beta))    # closed under differentiation on fused kernels
+            from ...ops.autograd import linear_softplus, softplus
+            y = linear_softplus(x, self.weight, self.bias, float(self.activation.beta))   # activation in the epilogue, twice differentiable
+            if y is not None:
+                return y
+            return softplus(super().forward(x), float(self.activation.beta))
         return self.activation(super().forward(x))
 
 

@@ -339,25 +339,66 @@ class SoftplusFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         z, = ctx.saved_tensors
-        return SoftplusGradFn.apply(g.contiguous(), z, ctx.beta), None
+        return SoftplusGradFn.apply(g.contiguous(), z, ctx.beta, False), None
 
 
 class SoftplusGradFn(torch.autograd.Function):
     """out = g * sigmoid(beta z); backward (first order from here: a third differentiation raises): dg = h s, dz = h g beta s (1 - s)
-    from ONE pass over z, g, h"""
+    from ONE pass over z, g, h.  from_y: the second argument is y = softplus(z) (sigmoid(beta z) = 1 - exp(-beta y)) and the second
+    gradient is the one with respect to y."""
 
     @staticmethod
-    def forward(ctx, g, z, beta):
+    def forward(ctx, g, z, beta, from_y=False):
         ctx.save_for_backward(g, z)
-        ctx.beta = beta
-        return F.softplus_grad(z, g, beta)
+        ctx.beta, ctx.from_y = beta, from_y
+        return F.softplus_grad(z, g, beta, from_y)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, h):
         g, z = ctx.saved_tensors
-        dg, dz = F.softplus_grad2(z, g, h.contiguous(), ctx.beta, want_dg=ctx.needs_input_grad[0], want_dz=ctx.needs_input_grad[1])
-        return dg, dz, None
+        dg, dz = F.softplus_grad2(z, g, h.contiguous(), ctx.beta, want_dg=ctx.needs_input_grad[0], want_dz=ctx.needs_input_grad[1],
+                                  from_y=ctx.from_y)
+        return dg, dz, None, None
+
+
+class LinearSoftplusFn(torch.autograd.Function):
+    """y = softplus_beta(x @ w.T + bias) with the activation in the product's epilogue: the pre-activation is never written.  The
+    backward is a composition of twice-differentiable nodes (SoftplusGradFn from y, GemmNN, GemmTNB), so the normals of NeuS
+    (create_graph=True) and the Eikonal loss through them differentiate it again."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, beta):
+        y = F.gemm_nt(x, w, bias, act='softplus', beta=beta)
+        ctx.save_for_backward(x, w, y)
+        ctx.beta, ctx.has_bias = beta, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        gs = SoftplusGradFn.apply(g.contiguous(), y, ctx.beta, True)
+        dx = GemmNN.apply(gs, w) if ctx.needs_input_grad[0] else None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] and want_db:
+            dw, db = GemmTNB.apply(gs, x)
+        else:
+            dw = GemmTN.apply(gs, x) if ctx.needs_input_grad[1] else None
+            db = gs.sum(0) if want_db else None
+        return dx, dw, db, None
+
+
+def linear_softplus(x, weight, bias, beta):
+    """softplus(F.linear(x, weight, bias), beta) as one fused, twice-differentiable layer; None where the HIP products do not apply"""
+    import os
+    if not _use_hip_linear(x, weight) or os.environ.get('ARCN_SOFTPLUS_FUSED', '1') == '0' or os.environ.get('ARCN_LINEAR_SOFTPLUS', '1') == '0':
+        return None
+    shp = x.shape
+    x2, w, b, n_out, npad = _padded_operands(x, weight, bias)
+    y = LinearSoftplusFn.apply(x2, w, b, float(beta))
+    if npad:
+        y = y[:, :n_out]
+    return y.reshape(*shp[:-1], n_out)
 
 
 def softplus(z, beta):

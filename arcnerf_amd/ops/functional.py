@@ -472,22 +472,24 @@ def act_fwd(x, act, beta=1.0):
     return y
 
 
-def softplus_grad(z, g, beta):
-    """g * sigmoid(beta z) (torch softplus threshold 20)"""
+def softplus_grad(z, g, beta, from_y=False):
+    """g * sigmoid(beta z) (torch softplus threshold 20); from_y: `z` is y = softplus(z) (sigmoid(beta z) = 1 - exp(-beta y))"""
     _req(z, g)
     z, g = _f32(z), _f32(g)
     out = torch.empty_like(z)
-    N.check(N.lib().arcn_softplus_grad(N.ptr(z), N.ptr(g), N.ptr(out), z.numel(), float(beta), N.stream()), 'softplus_grad')
+    N.check(N.lib().arcn_softplus_grad(N.ptr(z), N.ptr(g), N.ptr(out), z.numel(), float(beta), int(from_y), N.stream()), 'softplus_grad')
     return out
 
 
-def softplus_grad2(z, g, h, beta, want_dg=True, want_dz=True):
-    """backward of softplus_grad for an incoming h: (h * s, h * g * beta s (1 - s)), s = sigmoid(beta z), in one pass"""
+def softplus_grad2(z, g, h, beta, want_dg=True, want_dz=True, from_y=False):
+    """backward of softplus_grad for an incoming h: (h * s, h * g * beta s (1 - s)), s = sigmoid(beta z), in one pass; from_y: the second
+    is the gradient with respect to y, h * g * beta (1 - s)"""
     _req(z, g, h)
     z, g, h = _f32(z), _f32(g), _f32(h)
     dg = torch.empty_like(z) if want_dg else None
     dz = torch.empty_like(z) if want_dz else None
-    N.check(N.lib().arcn_softplus_grad2(N.ptr(z), N.ptr(g), N.ptr(h), N.ptr(dg), N.ptr(dz), z.numel(), float(beta), N.stream()), 'softplus_grad2')
+    N.check(N.lib().arcn_softplus_grad2(N.ptr(z), N.ptr(g), N.ptr(h), N.ptr(dg), N.ptr(dz), z.numel(), float(beta), int(from_y), N.stream()),
+            'softplus_grad2')
     return dg, dz
 
 

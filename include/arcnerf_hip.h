@@ -353,9 +353,11 @@ int arcn_act_fwd(const float *x, float *y, int64_t n, int act, float beta, void 
 /* softplus closed under differentiation (nn.Softplus(beta = 100) of the NeuS sdf net, base_modules/activation.py; the normals are
  * d sdf / d x with create_graph = True and the Eikonal loss differentiates them again, base_network.py:30-44), s = sigmoid(beta z):
  *   arcn_softplus_grad : out = g * s                                  first backward (and d out / d g applied to g)
- *   arcn_softplus_grad2: dg = h * s, dz = h * g * beta s (1 - s)       backward of arcn_softplus_grad for an incoming h (dg / dz may be NULL) */
-int arcn_softplus_grad(const float *z, const float *g, float *out, int64_t n, float beta, void *stream);
-int arcn_softplus_grad2(const float *z, const float *g, const float *h, float *dg, float *dz, int64_t n, float beta, void *stream);
+ *   arcn_softplus_grad2: dg = h * s, dz = h * g * beta s (1 - s)       backward of arcn_softplus_grad for an incoming h (dg / dz may be NULL)
+ * from_y = 1: `z` holds y = softplus(z) instead (a layer with the activation in its product's epilogue keeps no z): s = 1 - e^(-beta y), and
+ * dz becomes the gradient with respect to y, h * g * beta (1 - s) (the chain through y multiplies by s again). */
+int arcn_softplus_grad(const float *z, const float *g, float *out, int64_t n, float beta, int from_y, void *stream);
+int arcn_softplus_grad2(const float *z, const float *g, const float *h, float *dg, float *dz, int64_t n, float beta, int from_y, void *stream);
 int arcn_act_bwd(const float *x, const float *y, const float *dy, float *dx, int64_t n, int act, float beta,
                  void *stream);
 
