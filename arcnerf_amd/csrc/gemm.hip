@@ -696,7 +696,10 @@ gemm_tn_split_kernel(const float *__restrict__ A, const float *__restrict__ mask
     auto fetch = [&](int64_t c, bool live) {
         ok = 0u;
         const int64_t row0 = s_lo + c * BS;
-        if (MASK == 2 && !is_b) mb = mbits[((row0 >> 3) + sg) * mquads + mquad];   // (s_lo and the stages are multiples of 32 rows)
+        if (MASK == 2 && !is_b) {   // (s_lo and the stages are multiples of 32 rows; octets past the last row: any valid word)
+            const int64_t oct = (row0 >> 3) + sg, oct_last = (cnt - 1) >> 3;
+            mb = mbits[(oct < oct_last ? oct : oct_last) * mquads + mquad];
+        }
         const char *base = reinterpret_cast<const char *>(src + row0 * ld_s);
         const char *mbase = reinterpret_cast<const char *>(mask + row0 * ld_s);
 #pragma unroll

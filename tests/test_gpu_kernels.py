@@ -1016,7 +1016,8 @@ def test_gemm_products_vs_float64(S, K, Nn):
         assert (dxm.double() - refx).abs().max() <= 2e-6 * max(1.0, refx.abs().max().item())
 
 
-@pytest.mark.parametrize('S,K,Nn', [(3001, 256, 256), (1111, 320, 256), (2000, 284, 128), (777, 128, 384), (130, 68, 132)])
+@pytest.mark.parametrize('S,K,Nn', [(3001, 256, 256), (1111, 320, 256), (2000, 284, 128), (777, 128, 384), (130, 68, 132), (7, 108, 192), (1, 204, 224),
+                                    (131077, 336, 272)])
 def test_relu_bit_masks_equal_float_masks(S, K, Nn):
     """arcn_gemm_nt_split(relu_bits): word [s / 8][f / 4] bit 4 (s % 8) + f % 4 is (y[s][f] > 0); the masked gradient products give
     bit-identical results whether they read those words (mask_bits) or y itself as the mask (linear.py:11-35's ReLU backward)."""
