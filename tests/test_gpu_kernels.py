@@ -1029,7 +1029,8 @@ def test_relu_bit_masks_equal_float_masks(S, K, Nn):
     dy = torch.randn(S, Nn, generator=g).cuda()
     assert Fn.relu_bits_supported(x, K, Nn)
     y, bits = Fn.gemm_nt(x, w, b, act='relu', want_bits=True)
-    assert torch.equal(y, Fn.gemm_nt(x, w, b, act='relu'))
+    # (same product; a <= 16-wide remainder of the outputs runs on the exact-f32 kernel only when no bits are asked for)
+    assert (y - Fn.gemm_nt(x, w, b, act='relu')).abs().max() <= 2e-6 * y.abs().max()
     So = (S + 7) // 8
     pos = torch.zeros(So * 8, Nn, dtype=torch.int64, device='cuda')
     pos[:S] = (y > 0)
