@@ -421,7 +421,7 @@ class LinearReluFn(torch.autograd.Function):
         # masked gradient products read dy + bits instead of dy + y
         n_out, k_in = w.shape
         ctx.has_bias = bias is not None
-        if F.relu_bits_supported(x, k_in, n_out) and F._use_split(x, n_out, k_in) and n_out > 64:
+        if any(ctx.needs_input_grad) and F.relu_bits_supported(x, k_in, n_out) and F._use_split(x, n_out, k_in) and n_out > 64:
             y, bits = F.gemm_nt(x, w, bias, act='relu', want_bits=True)
             ctx.use_bits = True
             ctx.save_for_backward(x, w, bits)
