@@ -242,7 +242,7 @@ def bench_module(args, name):
         cpu = cpu_baseline_nerf()
     out = {'metric': 'ray-samples/sec (train)', 'value': total / wall, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
            'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-           'dtype': 'f32', 'data': 'synthetic',
+           'dtype': 'f32 (dense layers wider than 64: f32 operands as three bf16 planes, six MFMA terms, f32 accumulate - f32 accuracy)', 'data': 'synthetic',
            'config': {'workload': '{} ({}), {} rays/step/GPU, {} net evaluations/step/GPU, module path build_model({}) + FusedAdam'.format(
                name, spec['desc'], n_rays, evals_per_step, spec['yaml']), 'rays_per_step_per_gpu': n_rays,
                'samples_per_step_per_gpu': evals_per_step, 'n_params': flat_numel, 'parallelism': 'ray-sharded dp{}'.format(world),
