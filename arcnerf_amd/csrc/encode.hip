@@ -184,6 +184,98 @@ __global__ void __launch_bounds__(256) softplus_grad2_kernel(const float *__rest
     }
 }
 
+// ---- the tone mappers of HDR-NeRF (arcnerf/models/hdrnerf_model.py:44-75): per colour channel a 1 -> W -> 1 net, ReLU inside, sigmoid
+// out, on ln(exposure) + log radiance of every sample.  As dense layers each channel moves a (samples, W) activation tensor through HBM
+// four times per step for 2 W MACs per sample; here the hidden layer lives in registers.  params per channel: [w1 (W) | b1 (W) | w2 (W)
+// | b2], x / y / dy / dx are (n, C) row-major, one channel per blockIdx.y.
+constexpr int kToneW = 128;
+
+__global__ void __launch_bounds__(256) tonemap_fwd_kernel(const float *__restrict__ x, const float *__restrict__ params, float *__restrict__ y, int64_t n, int C,
+                                                          int W) {
+    __shared__ float sw[3 * kToneW + 1];
+    const int c = blockIdx.y;
+    for (int i = threadIdx.x; i < 3 * W + 1; i += 256) sw[i] = params[(int64_t)c * (3 * W + 1) + i];
+    __syncthreads();
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < n; s += (int64_t)gridDim.x * 256) {
+        const float xv = x[s * C + c];
+        float acc = sw[3 * W];
+        for (int j = 0; j < W; ++j) acc += sw[2 * W + j] * fmaxf(sw[j] * xv + sw[W + j], 0.f);
+        y[s * C + c] = 1.0f / (1.0f + expf(-acc));
+    }
+}
+
+// one workgroup keeps its parameter-gradient partials in registers over all its 256-sample tiles: per tile, phase 1 with a thread per
+// SAMPLE (dz, dx), phase 2 with a thread per HIDDEN UNIT over the tile's samples staged in LDS (the three sums of that unit: no
+// cross-lane reduction), then one partial row per workgroup, added in workgroup order by tonemap_reduce_kernel (deterministic)
+__global__ void __launch_bounds__(256) tonemap_bwd_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ dy,
+                                                          const float *__restrict__ params, float *__restrict__ dx, float *__restrict__ partials, int64_t n,
+                                                          int C, int W) {
+    __shared__ float sw[3 * kToneW + 1], sx[256], sdz[256], red[3 * kToneW], red2[256];
+    const int c = blockIdx.y, tid = threadIdx.x, j = tid & 127, half = tid >> 7;
+    for (int i = tid; i < 3 * W + 1; i += 256) sw[i] = params[(int64_t)c * (3 * W + 1) + i];
+    __syncthreads();
+    const float w1 = j < W ? sw[j] : 0.f, b1 = j < W ? sw[W + j] : 0.f, w2 = j < W ? sw[2 * W + j] : 0.f;
+    float a_w1 = 0.f, a_b1 = 0.f, a_w2 = 0.f, a_b2 = 0.f;
+    const int64_t tiles = (n + 255) / 256;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t s = t * 256 + tid;
+        const bool ok = s < n;
+        const float xv = ok ? x[s * C + c] : 0.f, yv = ok ? y[s * C + c] : 0.f, dyv = ok ? dy[s * C + c] : 0.f;
+        const float dz = dyv * yv * (1.0f - yv);
+        a_b2 += dz;
+        if (dx) {
+            float dxv = 0.f;
+            for (int k = 0; k < W; ++k) dxv += (sw[k] * xv + sw[W + k] > 0.f) ? dz * sw[2 * W + k] * sw[k] : 0.f;
+            if (ok) dx[s * C + c] = dxv;
+        }
+        sx[tid] = xv;
+        sdz[tid] = dz;
+        __syncthreads();
+        if (j < W) {
+            for (int i = half; i < 256; i += 2) {
+                const float xs = sx[i], dzs = sdz[i];
+                const float pre = w1 * xs + b1;
+                const float dpre = pre > 0.f ? dzs * w2 : 0.f;
+                a_w1 += dpre * xs;
+                a_b1 += dpre;
+                a_w2 += dzs * fmaxf(pre, 0.f);
+            }
+        }
+        __syncthreads();
+    }
+    // combine the two sample halves of a hidden unit, and the workgroup's db2
+    if (half == 1 && j < W) { red[j] = a_w1; red[kToneW + j] = a_b1; red[2 * kToneW + j] = a_w2; }
+    red2[tid] = a_b2;
+    __syncthreads();
+    float *out = partials + ((int64_t)c * gridDim.x + blockIdx.x) * (3 * W + 1);
+    if (half == 0 && j < W) {
+        out[j] = a_w1 + red[j];
+        out[W + j] = a_b1 + red[kToneW + j];
+        out[2 * W + j] = a_w2 + red[2 * kToneW + j];
+    }
+    if (tid == 0) {
+        float sum = 0.f;
+        for (int i = 0; i < 256; ++i) sum += red2[i];
+        out[3 * W] = sum;
+    }
+}
+
+__global__ void __launch_bounds__(256) tonemap_reduce_kernel(const float *__restrict__ partials, float *__restrict__ dparams, int n_wg, int C, int W) {
+    const int P = 3 * W + 1, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= C * P) return;
+    const int c = i / P, k = i % P;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = 0;
+    for (; b + 3 < n_wg; b += 4) {
+        a0 += partials[((int64_t)c * n_wg + b) * P + k];
+        a1 += partials[((int64_t)c * n_wg + b + 1) * P + k];
+        a2 += partials[((int64_t)c * n_wg + b + 2) * P + k];
+        a3 += partials[((int64_t)c * n_wg + b + 3) * P + k];
+    }
+    for (; b < n_wg; ++b) a0 += partials[((int64_t)c * n_wg + b) * P + k];
+    dparams[i] = (a0 + a1) + (a2 + a3);
+}
+
 // ---- geo -> radiance glue of Base3dModel._forward_pts_dir (arcnerf/models/base_3d_model.py:233-254) ---------------
 // sigma = out_act(geo_out[:,0]) (EncoderMLPGeoNet.handle_output / FusedMLPGeoNet.handle_output_combine);
 // rad_in = fuse_radiance_inputs(..) for modes 'fv' / 'vf' (encoder_mlp_network.py:93-118): geo feature slice and
@@ -374,6 +466,34 @@ ARCN_EXPORT int arcn_softplus_grad2(const float *z, const float *g, const float 
     else
         hipLaunchKernelGGL(softplus_grad2_kernel<false>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), z, g, h, dg, dz, n, beta, from_y);
     return check_launch("softplus_grad2");
+}
+
+static int tonemap_wgs(int64_t n) {
+    int64_t t = (n + 255) / 256;
+    return (int)(t < 1 ? 1 : (t > 512 ? 512 : t));
+}
+
+ARCN_EXPORT int arcn_tonemap_fwd(const float *x, const float *params, float *y, int64_t n, int C, int W, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!x || !params || !y || C < 1 || W < 1 || W > kToneW) return einval("tonemap_fwd: missing argument or hidden width outside 1..128");
+    int64_t gx = (n + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(tonemap_fwd_kernel, dim3((unsigned)gx, (unsigned)C), dim3(256), 0, as_stream(stream), x, params, y, n, C, W);
+    return check_launch("tonemap_fwd");
+}
+
+ARCN_EXPORT int64_t arcn_tonemap_scratch_floats(int64_t n, int C, int W) { return (int64_t)tonemap_wgs(n) * C * (3 * W + 1); }
+
+ARCN_EXPORT int arcn_tonemap_bwd(const float *x, const float *y, const float *dy, const float *params, float *dx, float *dparams, float *scratch,
+                                 int64_t scratch_floats, int64_t n, int C, int W, void *stream) {
+    if (!x || !y || !dy || !params || !dparams || !scratch || C < 1 || W < 1 || W > kToneW)
+        return einval("tonemap_bwd: missing argument or hidden width outside 1..128");
+    if (scratch_floats < arcn_tonemap_scratch_floats(n, C, W)) return einval("tonemap_bwd: scratch smaller than arcn_tonemap_scratch_floats");
+    const int wgs = n > 0 ? tonemap_wgs(n) : 0;
+    if (n > 0)
+        hipLaunchKernelGGL(tonemap_bwd_kernel, dim3((unsigned)wgs, (unsigned)C), dim3(256), 0, as_stream(stream), x, y, dy, params, dx, scratch, n, C, W);
+    hipLaunchKernelGGL(tonemap_reduce_kernel, dim3((unsigned)((C * (3 * W + 1) + 255) / 256)), dim3(256), 0, as_stream(stream), scratch, dparams, wgs, C, W);
+    return check_launch("tonemap_bwd");
 }
 
 ARCN_EXPORT int arcn_ngp_glue_fwd(const float *geo_out, const float *dirs, int Wg, int feat_off, int Wf, int sh_degree,

@@ -13,6 +13,28 @@ from .base_modules.linear import DenseLayer
 from .nerf_model import NeRF
 
 
+
+def _fused_tone_mappers(mlps, x):
+    """the three 1 -> W -> 1 tone mappers (ReLU inside, sigmoid out, biases, W <= 128) in ONE kernel per direction with the hidden layer
+    in registers (ops.autograd.ToneMapFn): as dense layers each channel moved a (samples, W) tensor through HBM four times per step.
+    Same parameters (the layers' own weight / bias, packed per call: 3 x 385 floats).  None where that shape does not apply."""
+    import os
+    if os.environ.get('ARCN_TONEMAP_FUSED', '1') == '0' or not (x.is_cuda and x.dtype == torch.float32 and x.numel() > 0):
+        return None
+    rows = []
+    for layers in mlps:
+        if len(layers) != 2 or any(type(la) is not DenseLayer or hasattr(la, 'weight_g') or la.bias is None for la in layers):
+            return None
+        if type(layers[0].activation) is not nn.ReLU or type(layers[1].activation) is not nn.Sigmoid:
+            return None
+        if layers[0].in_features != 1 or layers[1].out_features != 1 or layers[0].out_features > 128:
+            return None
+        rows.append(torch.cat([layers[0].weight.reshape(-1), layers[0].bias.reshape(-1), layers[1].weight.reshape(-1), layers[1].bias.reshape(-1)]))
+    if len({r.numel() for r in rows}) != 1:
+        return None
+    from ..ops.autograd import ToneMapFn
+    return ToneMapFn.apply(x.contiguous(), torch.stack(rows))
+
 @MODEL_REGISTRY.register()
 class HDRNeRF(NeRF):
     def __init__(self, cfgs):
@@ -49,6 +71,9 @@ class HDRNeRF(NeRF):
     def forward_exp_mlps(l_r, l_g, l_b, rgb_h, exp_time):
         """rgb_h (B,3) log-HDR, exp_time (B,) -> LDR rgb (B,3)"""
         log_t = torch.log(exp_time)
+        fused = _fused_tone_mappers((l_r, l_g, l_b), rgb_h + log_t[:, None])
+        if fused is not None:
+            return fused
         chans = []
         for c, layers in enumerate((l_r, l_g, l_b)):
             h = (rgb_h[:, c] + log_t)[:, None]

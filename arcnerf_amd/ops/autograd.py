@@ -326,6 +326,24 @@ class GemmTNB(torch.autograd.Function):
         return d_a, d_b
 
 
+class ToneMapFn(torch.autograd.Function):
+    """HDR-NeRF's per-channel 1 -> W -> 1 tone mappers (hdrnerf_model.py:44-75) as one kernel per direction: x (n, C), params
+    (C, 3 W + 1) = [w1 | b1 | w2 | b2] per channel.  First order only."""
+
+    @staticmethod
+    def forward(ctx, x, params):
+        y = F.tonemap_fwd(x, params)
+        ctx.save_for_backward(x, params, y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, params, y = ctx.saved_tensors
+        dx, dparams = F.tonemap_bwd(x, y, g.contiguous(), params, want_dx=ctx.needs_input_grad[0])
+        return dx, (dparams if ctx.needs_input_grad[1] else None)
+
+
 class SoftplusFn(torch.autograd.Function):
     """torch.nn.functional.softplus(z, beta, threshold=20) differentiable twice on fused kernels: the sdf nets of NeuS evaluate it,
     take d sdf / d x through it with create_graph=True (SoftplusGradFn) and differentiate the Eikonal loss through that again."""

@@ -472,6 +472,31 @@ def act_fwd(x, act, beta=1.0):
     return y
 
 
+def tonemap_fwd(x, params):
+    """x (n, C), params (C, 3 W + 1) = [w1 | b1 | w2 | b2] per channel -> sigmoid(b2 + w2 . relu(w1 x + b1)) (n, C)"""
+    _req(x, params)
+    x, params = _f32(x), _f32(params)
+    n, Cc = x.shape
+    W = (params.shape[1] - 1) // 3
+    y = torch.empty_like(x)
+    N.check(N.lib().arcn_tonemap_fwd(N.ptr(x), N.ptr(params), N.ptr(y), n, Cc, W, N.stream()), 'tonemap_fwd')
+    return y
+
+
+def tonemap_bwd(x, y, dy, params, want_dx=True):
+    _req(x, y, dy, params)
+    x, y, dy, params = _f32(x), _f32(y), _f32(dy), _f32(params)
+    n, Cc = x.shape
+    W = (params.shape[1] - 1) // 3
+    dx = torch.empty_like(x) if want_dx else None
+    dparams = torch.empty_like(params)
+    nf = max(1, int(N.lib().arcn_tonemap_scratch_floats(n, Cc, W)))
+    scratch = torch.empty(nf, dtype=torch.float32, device=x.device)
+    N.check(N.lib().arcn_tonemap_bwd(N.ptr(x), N.ptr(y), N.ptr(dy), N.ptr(params), N.ptr(dx), N.ptr(dparams), N.ptr(scratch), nf, n, Cc, W,
+                                   N.stream()), 'tonemap_bwd')
+    return dx, dparams
+
+
 def softplus_grad(z, g, beta, from_y=False):
     """g * sigmoid(beta z) (torch softplus threshold 20); from_y: `z` is y = softplus(z) (sigmoid(beta z) = 1 - exp(-beta y))"""
     _req(z, g)

@@ -350,6 +350,14 @@ int64_t arcn_mlp_scratch_floats(const arcn_mlp_desc *desc_host, int64_t n_cap);
 
 /* elementwise activation (TruncExp F1 etc.) */
 int arcn_act_fwd(const float *x, float *y, int64_t n, int act, float beta, void *stream);
+/* The tone mappers of HDR-NeRF (arcnerf/models/hdrnerf_model.py:44-75: per colour channel DenseLayer(1, W) + ReLU, DenseLayer(W, 1) +
+ * sigmoid on ln(exposure) + log radiance) with the hidden layer in registers.  x / y / dy / dx (n, C) row-major, params / dparams
+ * (C, 3 W + 1) = per channel [w1 (W) | b1 (W) | w2 (W) | b2], W <= 128.  bwd: dx may be NULL; dparams is overwritten (workgroup partials
+ * in `scratch`, >= arcn_tonemap_scratch_floats floats, added in a fixed order). */
+int arcn_tonemap_fwd(const float *x, const float *params, float *y, int64_t n, int C, int W, void *stream);
+int64_t arcn_tonemap_scratch_floats(int64_t n, int C, int W);
+int arcn_tonemap_bwd(const float *x, const float *y, const float *dy, const float *params, float *dx, float *dparams, float *scratch,
+                     int64_t scratch_floats, int64_t n, int C, int W, void *stream);
 /* softplus closed under differentiation (nn.Softplus(beta = 100) of the NeuS sdf net, base_modules/activation.py; the normals are
  * d sdf / d x with create_graph = True and the Eikonal loss differentiates them again, base_network.py:30-44), s = sigmoid(beta z):
  *   arcn_softplus_grad : out = g * s                                  first backward (and d out / d g applied to g)

@@ -1067,6 +1067,34 @@ def test_softplus_twice_differentiable_vs_torch(n):
         assert (a - b).abs().max() <= tol * max(1.0, b.abs().max().item()), (a - b).abs().max()
 
 
+@pytest.mark.parametrize('n,C,W', [(5000, 3, 128), (257, 3, 128), (1, 1, 7), (70001, 2, 64)])
+def test_tone_mappers_vs_torch(n, C, W):
+    """arcn_tonemap_fwd / bwd (ops.autograd.ToneMapFn) against the reference's per-channel DenseLayer(1, W) + ReLU, DenseLayer(W, 1) +
+    sigmoid stacks (hdrnerf_model.py:44-75) under torch autograd: values, input gradient, parameter gradients."""
+    from arcnerf_amd.ops.autograd import ToneMapFn
+    g = torch.Generator().manual_seed(n + W)
+    x0 = (torch.randn(n, C, generator=g) * 2.0).cuda()
+    p0 = torch.randn(C, 3 * W + 1, generator=g).cuda() * 0.5
+    gy = torch.randn(n, C, generator=g).cuda()
+    x, p = x0.clone().requires_grad_(True), p0.clone().requires_grad_(True)
+    y = ToneMapFn.apply(x, p)
+    y.backward(gy)
+    xr, pr = x0.clone().requires_grad_(True), p0.clone().requires_grad_(True)
+    cols = []
+    for c in range(C):
+        w1, b1, w2, b2 = pr[c, :W], pr[c, W:2 * W], pr[c, 2 * W:3 * W], pr[c, 3 * W]
+        h = torch.relu(xr[:, c:c + 1] * w1[None] + b1[None])
+        cols.append(torch.sigmoid(h @ w2 + b2))
+    yr = torch.stack(cols, -1)
+    yr.backward(gy)
+    assert (y - yr).abs().max() <= 2e-6
+    assert (x.grad - xr.grad).abs().max() <= 2e-5 * max(1.0, xr.grad.abs().max().item())
+    assert (p.grad - pr.grad).abs().max() <= 1e-4 * max(1.0, pr.grad.abs().max().item()), (p.grad - pr.grad).abs().max()
+    x2, p2 = x0.clone().requires_grad_(True), p0.clone().requires_grad_(True)
+    ToneMapFn.apply(x2, p2).backward(gy)
+    assert torch.equal(p2.grad, p.grad)        # fixed summation order
+
+
 def test_linear_layers_double_backward_vs_torch():
     """a 3-layer softplus(100) net with a skip concat on ops.autograd.linear: outputs, d out / d x (create_graph), and the gradients of a
     loss on BOTH (the NeuS pattern: rgb loss + Eikonal on the normals) against the same net on torch.nn.functional.linear."""

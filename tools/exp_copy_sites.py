@@ -14,6 +14,8 @@ m = build_model(load_configs(os.path.join(os.path.dirname(os.path.dirname(os.pat
 o, d = synthetic_rays(R, seed=0, device=dev, radius=3.0 if name == 'neus' else 4.0)
 inp = {'rays_o': o.view(1, -1, 3), 'rays_d': d.view(1, -1, 3), 'rays_r': torch.zeros(1, R, 1, device=dev), 'bkg_color': torch.rand(1, R, 3, device=dev)}
 img = torch.rand(1, R, 3, device=dev)
+if name == 'hdrnerf':
+    inp['exp_time'] = torch.rand(1, R, 1, device=dev) * 4.0 + 0.1
 opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=5e-4, eps=1e-15)
 def step(i):
     out = m(dict(inp), inference_only=False, cur_epoch=20000 + i)
