@@ -24,6 +24,10 @@ class EncoderMLPGeoNet(BaseGeoNet):
         """linear nets: out = [geo | feat]"""
         if self.W_feat <= 0:
             geo, feat = out, None
+        elif out.shape[-1] > 1 + self.W_feat:
+            # the final product's own padded tensor (linear(keep_pad=True)): ONE split node, whose backward is one concatenation of the
+            # two gradients and the zero pad instead of two slice nodes (zero fill + copy each) and an add
+            geo, feat, _ = torch.split(out, [1, self.W_feat, out.shape[-1] - 1 - self.W_feat], dim=-1)
         else:
             geo, feat = out[:, 0].unsqueeze(-1), out[:, 1:]
         if self.out_act is not None:

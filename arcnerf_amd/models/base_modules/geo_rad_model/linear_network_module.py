@@ -16,6 +16,9 @@ from ..linear import DenseLayer, Linear, SirenLayer
 from .encoder_mlp_network import EncoderMLPGeoNet, EncoderMLPRadainceNet
 
 
+_KEEP_PAD = os.environ.get('ARCN_GEO_SPLIT_NODE', '1') != '0'   # A/B: the final product's padded tensor split once (handle_output)
+
+
 @MODULE_REGISTRY.register()
 class GeoNet(EncoderMLPGeoNet):
     def __init__(self, W=256, D=8, skips=[4], encoder=None, W_feat=256, use_bias=True, skip_reduce_output=False,
@@ -79,7 +82,11 @@ class GeoNet(EncoderMLPGeoNet):
             x_embed = pad_cols4(x_embed)
         out = x_embed
         for i in range(self.D + 1):
-            out = self.layers[i](out)
+            if i == self.D and self.W_feat > 0 and type(self.layers[i]) is Linear and not hasattr(self.layers[i], 'weight_g') and _KEEP_PAD:
+                from ....ops.autograd import linear
+                out = linear(out, self.layers[i].weight, self.layers[i].bias, keep_pad=True)    # handle_output splits the padded tensor
+            else:
+                out = self.layers[i](out)
             if i in self.skips:
                 out = torch.cat([out, x_embed], dim=-1)
                 if self.norm_skip:

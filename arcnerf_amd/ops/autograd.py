@@ -532,14 +532,17 @@ def linear_act_nograd(x, weight, bias, act, beta=1.0):
     return y.reshape(*shp[:-1], n_out)
 
 
-def linear(x, weight, bias=None):
+def linear(x, weight, bias=None, keep_pad=False):
     """torch.nn.functional.linear for fp32 CUDA tensors on the MFMA products; anything else (CPU tensors of the host-side tests, other
-    dtypes) goes to torch.  ARCN_LINEAR_GEMM=0 routes everything to torch (A/B against the library GEMMs)."""
+    dtypes) goes to torch.  ARCN_LINEAR_GEMM=0 routes everything to torch (A/B against the library GEMMs).  keep_pad: return the
+    product's own (rows, out + pad) tensor (zero columns up to a multiple of 4) for a caller that splits it itself."""
     if not _use_hip_linear(x, weight):
         return torch.nn.functional.linear(x[..., :weight.shape[1]], weight, bias)    # (a pad_cols4 input on an empty batch)
     shp = x.shape
     x2, w, b, n_out, npad = _padded_operands(x, weight, bias)
     y = GemmNT.apply(x2, w, b)
+    if keep_pad:
+        return y.reshape(*shp[:-1], n_out + npad)
     if npad:
         y = y[:, :n_out]
     return y.reshape(*shp[:-1], n_out)
