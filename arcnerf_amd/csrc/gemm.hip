@@ -1,6 +1,8 @@
 // Dense layers of the wide nets on gfx950 matrix cores: the three products a torch.nn.Linear needs in forward, backward and
-// double backward, hand-written with the exact f32 MFMA (v_mfma_f32_16x16x4_f32), for a HUGE row count S (samples, 10^5..10^6) and
-// small feature dimensions (3..320).
+// double backward, hand-written for a HUGE row count S (samples, 10^5..10^6) and small feature dimensions (3..320), in two forms:
+//   exact   v_mfma_f32_16x16x4_f32 (157 TFLOP/s peak): narrow layers (<= 64 outputs), unaligned operands         (first half of the file)
+//   split   every f32 operand as three bf16 planes, six v_mfma_f32_16x16x32_bf16 per product, f32 accuracy: the default for layers
+//           wider than 64 - 1.4-1.7x the exact form; ReLU masks as bits, bias gradient and softplus fused in     (second half)
 //
 // Replaces the library GEMMs under GeoNet / RadianceNet (arcnerf/models/base_modules/geo_rad_model/linear_network_module.py:174-197,
 // 318-335: nn.Linear / DenseLayer stacks, 8 x 256 with a skip concat for NeRF / NeuS / HDR-NeRF, 32 -> 64 -> 17 for NeuS on the hash
