@@ -73,6 +73,38 @@ class GeoNet(EncoderMLPGeoNet):
         else:
             nn.init.normal_(layer.weight, 0.0, std)
 
+    def forward_with_grad(self, x):
+        """(geo, feat, d geo / d x).  For the sdf net of NeuS on the hash grid - one hidden softplus layer, no biases, nothing but the hash
+        features as input - the input gradient is an explicit output of one first-order node (ops.autograd.SdfMlpJacFn) pushed through
+        the encoding's d enc / d x kernel, instead of a create_graph differentiation of the layer stack; everything else takes
+        base_network.py:30-44."""
+        fast = self._jacobian_path(x)
+        return fast if fast is not None else super().forward_with_grad(x)
+
+    def _jacobian_path(self, x):
+        from ..encoding.hashgrid_encoder import HashGridEmbedder
+        if os.environ.get('ARCN_SDF_JACOBIAN', '1') == '0' or not (x.is_cuda and x.dtype == torch.float32 and x.numel() > 0):
+            return None
+        if x.requires_grad or self.D != 1 or self.skips or self.W_feat <= 0 or self.out_act is not None:
+            return None
+        emb, l0, l1 = self.embed_fn, self.layers[0], self.layers[1]
+        if type(emb) is not HashGridEmbedder or emb.include_input:
+            return None
+        if type(l0) is not DenseLayer or type(l0.activation) is not nn.Softplus or l0.activation.threshold != 20 or type(l1) is not Linear:
+            return None
+        if l0.bias is not None or l1.bias is not None or hasattr(l0, 'weight_g') or hasattr(l1, 'weight_g'):
+            return None
+        from ....ops.autograd import HashGridDxFn, HashGridFn, SdfMlpJacFn
+        pts = x.detach().contiguous()
+        with torch.enable_grad():
+            enc = HashGridFn.apply(pts, emb.embeddings, emb.desc, True)
+            n_out = l1.weight.shape[0]
+            w2 = torch.nn.functional.pad(l1.weight, (0, 0, 0, (-n_out) % 4))     # rows to a multiple of 4: aligned products both ways
+            out, jac = SdfMlpJacFn.apply(enc, l0.weight, w2, float(l0.activation.beta))
+            geo, feat = self.handle_output(out[:, :n_out])
+            grad = HashGridDxFn.apply(pts, emb.embeddings, jac, emb.desc)
+        return geo, feat, grad
+
     def forward(self, x):
         x_embed = self.embed_fn(x)
         if all(self.layers[i].out_features % 4 == 0 for i in self.skips if i <= self.D):

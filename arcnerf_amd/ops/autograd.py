@@ -427,6 +427,49 @@ def softplus(z, beta):
     return SoftplusFn.apply(z.contiguous(), float(beta))
 
 
+class SdfMlpJacFn(torch.autograd.Function):
+    """The two-layer softplus sdf net of NeuS on the hash grid (GeoNet D = 1, no bias: out = W2 softplus_beta(W1 f)) together with the
+    Jacobian row of its first output, J = d out[:, 0] / d f = W1^T (s * W2[0]) with s = sigmoid(beta W1 f) - as EXPLICIT outputs of a
+    first-order node.  The normals are then d enc / d x applied to J (HashGridDxFn), and the Eikonal / radiance losses reach the
+    weights through the gradient of J - no create_graph, no second differentiation of every layer (base_network.py:30-44 builds the
+    same quantity by differentiating the layer stack twice).  Products on the exact-f32 kernels of csrc/gemm.hip.
+        backward, for incoming g_out (S, O) and g_J (S, K):   dh = g_out W2,  u = g_J W1^T,
+        dz = dh s + W2[0] u beta s (1 - s),   df = dz W1,   dW1 = dz^T f + diag(W2[0]) s^T g_J,   dW2 = g_out^T h,  dW2[0] += sum_s s u"""
+
+    @staticmethod
+    def forward(ctx, f, w1, w2, beta):
+        f = f.contiguous()
+        h = F.gemm_nt(f, w1, None, act='softplus', beta=beta)             # (S, H)
+        out = F.gemm_nt(h, w2, None)                                      # (S, O)
+        s = -torch.expm1(h * (-beta))                                     # sigmoid(beta z) from y = softplus(z)
+        jac = F.gemm_nn(s, (w1 * w2[0][:, None]).contiguous())             # (S, K) = s (diag(W2[0]) W1)
+        ctx.save_for_backward(f, w1, w2, h)
+        ctx.beta = beta
+        return out, jac
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out, g_jac):
+        f, w1, w2, h = ctx.saved_tensors
+        beta = ctx.beta
+        s = -torch.expm1(h * (-beta))
+        w20 = w2[0]
+        dz = F.gemm_nn(g_out.contiguous(), w2) * s                        # dh s
+        dw2 = F.gemm_tn(g_out.contiguous(), h)
+        dw1 = None
+        if g_jac is not None:
+            g_jac = g_jac.contiguous()
+            u = F.gemm_nt(g_jac, w1, None)                                # (S, H) = g_J W1^T
+            su = s * u
+            dz = dz + su * (1.0 - s) * (beta * w20)[None]
+            dw2[0] += su.sum(0)
+            dw1 = F.gemm_tn(s, g_jac) * w20[:, None]
+        df = F.gemm_nn(dz, w1) if ctx.needs_input_grad[0] else None
+        dw1_a = F.gemm_tn(dz, f)
+        dw1 = dw1_a if dw1 is None else dw1 + dw1_a
+        return df, dw1, dw2, None
+
+
 class LinearReluFn(torch.autograd.Function):
     """y = relu(x @ w.T + bias) in ONE kernel (bias + activation in the product's epilogue); backward with the activation's mask
     folded into the operand loads of the two gradient products (dpre = dy * (y > 0) is never written): per layer and direction one

@@ -1095,6 +1095,31 @@ def test_tone_mappers_vs_torch(n, C, W):
     assert torch.equal(p2.grad, p.grad)        # fixed summation order
 
 
+def test_sdf_net_with_explicit_jacobian_vs_torch_double_backward():
+    """ops.autograd.SdfMlpJacFn (out = W2 softplus(W1 f) and J = d out[:, 0] / d f as explicit outputs of a first-order node) against the
+    reference's construction - torch.autograd.grad(..., create_graph=True) through the layer stack (base_network.py:30-44) - for a loss on
+    both: values and the gradients with respect to the features and both weight matrices."""
+    from arcnerf_amd.ops.autograd import SdfMlpJacFn
+    g = torch.Generator().manual_seed(3)
+    S, K, H, O, beta = 5001, 32, 64, 20, 100.0
+    f0 = (torch.randn(S, K, generator=g) * 0.3).cuda()
+    w10 = (torch.randn(H, K, generator=g) / K ** 0.5 * 0.3).cuda()
+    w20 = (torch.randn(O, H, generator=g) / H ** 0.5).cuda()
+    go, gj = torch.randn(S, O, generator=g).cuda(), torch.randn(S, K, generator=g).cuda()
+    res = {}
+    for name in ('hip', 'torch'):
+        f, w1, w2 = (t.clone().requires_grad_(True) for t in (f0, w10, w20))
+        if name == 'hip':
+            out, jac = SdfMlpJacFn.apply(f, w1, w2, beta)
+        else:
+            out = torch.nn.functional.softplus(f @ w1.t(), beta=beta) @ w2.t()
+            jac, = torch.autograd.grad(out[:, 0].sum(), f, create_graph=True)
+        loss = (out * go).sum() + (jac * gj).sum()
+        res[name] = (out.detach(), jac.detach()) + torch.autograd.grad(loss, (f, w1, w2))
+    for a, b in zip(res['hip'], res['torch']):
+        assert (a - b).abs().max() <= 2e-5 * b.abs().max(), ((a - b).abs().max() / b.abs().max()).item()
+
+
 def test_linear_layers_double_backward_vs_torch():
     """a 3-layer softplus(100) net with a skip concat on ops.autograd.linear: outputs, d out / d x (create_graph), and the gradients of a
     loss on BOTH (the NeuS pattern: rgb loss + Eikonal on the normals) against the same net on torch.nn.functional.linear."""
