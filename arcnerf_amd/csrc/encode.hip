@@ -143,8 +143,11 @@ __global__ void __launch_bounds__(256) softplus_grad_kernel(const float *__restr
     constexpr int W = VEC ? 4 : 1;
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * W; i < n; i += (int64_t)gridDim.x * blockDim.x * W) {
         float zv[W], gv[W], ov[W];
-        if (VEC) { *reinterpret_cast<f4v *>(zv) = *reinterpret_cast<const f4v *>(z + i); *reinterpret_cast<f4v *>(gv) = *reinterpret_cast<const f4v *>(g + i); }
-        else { zv[0] = z[i]; gv[0] = g[i]; }
+        if (VEC) {
+            *reinterpret_cast<f4v *>(zv) = *reinterpret_cast<const f4v *>(z + i);
+            if (g) *reinterpret_cast<f4v *>(gv) = *reinterpret_cast<const f4v *>(g + i);
+            else gv[0] = gv[1] = gv[2] = gv[3] = 1.f;      // g == NULL: the derivative s itself
+        } else { zv[0] = z[i]; gv[0] = g ? g[i] : 1.f; }
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             float s, ds;
@@ -449,7 +452,7 @@ static inline bool vec4_ok(int64_t n, const void *a, const void *b, const void *
 
 ARCN_EXPORT int arcn_softplus_grad(const float *z, const float *g, float *out, int64_t n, float beta, int from_y, void *stream) {
     if (n <= 0) return ARCN_OK;
-    if (!z || !g || !out) return einval("softplus_grad: missing argument");
+    if (!z || !out) return einval("softplus_grad: missing argument");
     if (vec4_ok(n, z, g, out, nullptr, nullptr))
         hipLaunchKernelGGL(softplus_grad_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), z, g, out, n, beta, from_y);
     else

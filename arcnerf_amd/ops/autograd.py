@@ -441,7 +441,7 @@ class SdfMlpJacFn(torch.autograd.Function):
         f = f.contiguous()
         h = F.gemm_nt(f, w1, None, act='softplus', beta=beta)             # (S, H)
         out = F.gemm_nt(h, w2, None)                                      # (S, O)
-        s = -torch.expm1(h * (-beta))                                     # sigmoid(beta z) from y = softplus(z)
+        s = F.softplus_grad(h, None, beta, from_y=True)                   # sigmoid(beta z) from y = softplus(z), one pass
         jac = F.gemm_nn(s, (w1 * w2[0][:, None]).contiguous())             # (S, K) = s (diag(W2[0]) W1)
         ctx.save_for_backward(f, w1, w2, h)
         ctx.beta = beta
@@ -452,7 +452,7 @@ class SdfMlpJacFn(torch.autograd.Function):
     def backward(ctx, g_out, g_jac):
         f, w1, w2, h = ctx.saved_tensors
         beta = ctx.beta
-        s = -torch.expm1(h * (-beta))
+        s = F.softplus_grad(h, None, beta, from_y=True)
         w20 = w2[0]
         dz = F.gemm_nn(g_out.contiguous(), w2) * s                        # dh s
         dw2 = F.gemm_tn(g_out.contiguous(), h)

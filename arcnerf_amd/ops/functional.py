@@ -498,7 +498,8 @@ def tonemap_bwd(x, y, dy, params, want_dx=True):
 
 
 def softplus_grad(z, g, beta, from_y=False):
-    """g * sigmoid(beta z) (torch softplus threshold 20); from_y: `z` is y = softplus(z) (sigmoid(beta z) = 1 - exp(-beta y))"""
+    """g * sigmoid(beta z) (torch softplus threshold 20; g None: the sigmoid itself); from_y: `z` is y = softplus(z)
+    (sigmoid(beta z) = 1 - exp(-beta y))"""
     _req(z, g)
     z, g = _f32(z), _f32(g)
     out = torch.empty_like(z)

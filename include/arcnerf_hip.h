@@ -360,7 +360,7 @@ int arcn_tonemap_bwd(const float *x, const float *y, const float *dy, const floa
                      int64_t scratch_floats, int64_t n, int C, int W, void *stream);
 /* softplus closed under differentiation (nn.Softplus(beta = 100) of the NeuS sdf net, base_modules/activation.py; the normals are
  * d sdf / d x with create_graph = True and the Eikonal loss differentiates them again, base_network.py:30-44), s = sigmoid(beta z):
- *   arcn_softplus_grad : out = g * s                                  first backward (and d out / d g applied to g)
+ *   arcn_softplus_grad : out = g * s                                  first backward (and d out / d g applied to g); g may be NULL: out = s
  *   arcn_softplus_grad2: dg = h * s, dz = h * g * beta s (1 - s)       backward of arcn_softplus_grad for an incoming h (dg / dz may be NULL)
  * from_y = 1: `z` holds y = softplus(z) instead (a layer with the activation in its product's epilogue keeps no z): s = 1 - e^(-beta y), and
  * dz becomes the gradient with respect to y, h * g * beta (1 - s) (the chain through y multiplies by s again). */
