@@ -187,6 +187,26 @@ __global__ void __launch_bounds__(256) softplus_grad2_kernel(const float *__rest
     }
 }
 
+// backward of the sdf net with an explicit Jacobian output (ops.autograd.SdfMlpJacFn): per element of the (n, H) hidden layer
+//   dz = dh s + c_j u s (1 - s),  su = s u      (c = beta W2[0]; dz and su may alias dh and u)
+__global__ void __launch_bounds__(256) sdf_jac_dz_kernel(const float *__restrict__ dh, const float *__restrict__ u, const float *__restrict__ s,
+                                                         const float *__restrict__ c, float *__restrict__ dz, float *__restrict__ su, int64_t n, int H) {
+    const int64_t total = n * H;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        const f4v a = *reinterpret_cast<const f4v *>(dh + i), b = *reinterpret_cast<const f4v *>(u + i), sv = *reinterpret_cast<const f4v *>(s + i);
+        const f4v cv = *reinterpret_cast<const f4v *>(c + (int)(i % H));
+        f4v o1, o2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = sv[k] * b[k];
+            o2[k] = t;
+            o1[k] = a[k] * sv[k] + cv[k] * t * (1.0f - sv[k]);
+        }
+        *reinterpret_cast<f4v *>(dz + i) = o1;
+        *reinterpret_cast<f4v *>(su + i) = o2;
+    }
+}
+
 // ---- the tone mappers of HDR-NeRF (arcnerf/models/hdrnerf_model.py:44-75): per colour channel a 1 -> W -> 1 net, ReLU inside, sigmoid
 // out, on ln(exposure) + log radiance of every sample.  As dense layers each channel moves a (samples, W) activation tensor through HBM
 // four times per step for 2 W MACs per sample; here the hidden layer lives in registers.  params per channel: [w1 (W) | b1 (W) | w2 (W)
@@ -469,6 +489,14 @@ ARCN_EXPORT int arcn_softplus_grad2(const float *z, const float *g, const float 
     else
         hipLaunchKernelGGL(softplus_grad2_kernel<false>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), z, g, h, dg, dz, n, beta, from_y);
     return check_launch("softplus_grad2");
+}
+
+ARCN_EXPORT int arcn_sdf_jac_dz(const float *dh, const float *u, const float *s, const float *c, float *dz, float *su, int64_t n, int H, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!dh || !u || !s || !c || !dz || !su || H < 4 || (H & 3) != 0) return einval("sdf_jac_dz: missing argument or hidden width not a multiple of 4");
+    if (((uintptr_t)dh | (uintptr_t)u | (uintptr_t)s | (uintptr_t)c | (uintptr_t)dz | (uintptr_t)su) & 15u) return einval("sdf_jac_dz: 16-byte aligned tensors");
+    hipLaunchKernelGGL(sdf_jac_dz_kernel, dim3(grid_for(n * H / 4)), dim3(256), 0, as_stream(stream), dh, u, s, c, dz, su, n, H);
+    return check_launch("sdf_jac_dz");
 }
 
 static int tonemap_wgs(int64_t n) {

@@ -454,16 +454,17 @@ class SdfMlpJacFn(torch.autograd.Function):
         beta = ctx.beta
         s = F.softplus_grad(h, None, beta, from_y=True)
         w20 = w2[0]
-        dz = F.gemm_nn(g_out.contiguous(), w2) * s                        # dh s
+        dz = F.gemm_nn(g_out.contiguous(), w2)                            # dh
         dw2 = F.gemm_tn(g_out.contiguous(), h)
         dw1 = None
         if g_jac is not None:
             g_jac = g_jac.contiguous()
             u = F.gemm_nt(g_jac, w1, None)                                # (S, H) = g_J W1^T
-            su = s * u
-            dz = dz + su * (1.0 - s) * (beta * w20)[None]
+            dz, su = F.sdf_jac_dz(dz, u, s, (beta * w20).contiguous())    # dz = dh s + W2[0] u beta s (1 - s), su = s u: one pass, in place
             dw2[0] += su.sum(0)
             dw1 = F.gemm_tn(s, g_jac) * w20[:, None]
+        else:
+            dz = dz * s
         df = F.gemm_nn(dz, w1) if ctx.needs_input_grad[0] else None
         dw1_a = F.gemm_tn(dz, f)
         dw1 = dw1_a if dw1 is None else dw1 + dw1_a

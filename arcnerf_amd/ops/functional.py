@@ -472,6 +472,14 @@ def act_fwd(x, act, beta=1.0):
     return y
 
 
+def sdf_jac_dz(dh, u, s, c):
+    """(dh s + c u s (1 - s), s u) over an (n, H) hidden layer, c (H): written over dh and u"""
+    _req(dh, u, s, c)
+    n, H = dh.shape
+    N.check(N.lib().arcn_sdf_jac_dz(N.ptr(dh), N.ptr(u), N.ptr(s), N.ptr(c), N.ptr(dh), N.ptr(u), n, H, N.stream()), 'sdf_jac_dz')
+    return dh, u
+
+
 def tonemap_fwd(x, params):
     """x (n, C), params (C, 3 W + 1) = [w1 | b1 | w2 | b2] per channel -> sigmoid(b2 + w2 . relu(w1 x + b1)) (n, C)"""
     _req(x, params)

@@ -350,6 +350,9 @@ int64_t arcn_mlp_scratch_floats(const arcn_mlp_desc *desc_host, int64_t n_cap);
 
 /* elementwise activation (TruncExp F1 etc.) */
 int arcn_act_fwd(const float *x, float *y, int64_t n, int act, float beta, void *stream);
+/* One elementwise pass of ops.autograd.SdfMlpJacFn's backward (the NeuS-on-hash-grid sdf net with its Jacobian as an explicit output):
+ * dz = dh s + c_j u s (1 - s), su = s u over an (n, H) hidden layer, c (H) = beta W2[0]; dz / su may alias dh / u. */
+int arcn_sdf_jac_dz(const float *dh, const float *u, const float *s, const float *c, float *dz, float *su, int64_t n, int H, void *stream);
 /* The tone mappers of HDR-NeRF (arcnerf/models/hdrnerf_model.py:44-75: per colour channel DenseLayer(1, W) + ReLU, DenseLayer(W, 1) +
  * sigmoid on ln(exposure) + log radiance) with the hidden layer in registers.  x / y / dy / dx (n, C) row-major, params / dparams
  * (C, 3 W + 1) = per channel [w1 (W) | b1 (W) | w2 (W) | b2], W <= 128.  bwd: dx may be NULL; dparams is overwritten (workgroup partials
