@@ -236,8 +236,11 @@ def bench_module(args, name):
         ach = 3.0 * spec['flop'] * evals_per_step / (wall / args.steps)
         roofline = {'kernel': 'linear stacks of the geometry / radiance nets (csrc/gemm.hip: split-bf16 MFMA products at f32 accuracy + fused MFMA kernels)', 'bound': 'mfma',
                     'achieved': ach / 1e12, 'peak': F32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s', 'frac': ach / F32_MFMA_PEAK, 'traffic': None,
+                    'peak_split': 2500.0 / 6.0, 'frac_of_split_peak': ach / (2.5e15 / 6.0),
                     'note': 'algorithmic f32 FLOP = 3 x forward MACs x 2 per net evaluation, over the WHOLE step time; priced against the exact-f32 MFMA peak '
-                            '(the products are f32-accurate; each is six bf16 MFMAs, so the matrix pipe itself does 6/8 of the f32 MFMA cycles)'}
+                            '(the products are f32-accurate; each is six bf16 MFMAs, so the matrix pipe itself does 6/8 of the f32 MFMA cycles); '
+                            'peak_split = the dense bf16 MFMA peak / 6 terms = what the split form could do at full clock (the kernels sit on the '
+                            '1400 W package limit at 1.93-1.97 GHz, DESIGN.md 5b)'}
     cpu = None
     if world == 1 and not args.no_cpu_baseline and name == 'nerf':
         cpu = cpu_baseline_nerf()
