@@ -45,7 +45,7 @@ def parse():
     return ap.parse_args()
 
 
-COLD_STEPS = 96   # untimed steps of the workload before the W warmup steps (see main)
+COLD_STEPS = 96   # untimed steps of the workload before the W warmup steps (see main); a multiple of the ray pool size (8)
 ROOFLINE_KERNELS = ('hashgrid_fwd', 'hashgrid_bwd')
 TABLE_KERNELS = ROOFLINE_KERNELS + ('mlp_fwd', 'mlp_bwd', 'mlp_bwd_dw', 'march_count', 'composite_packed_train', 'composite_packed_fwd',
                                     'composite_packed_bwd', 'adam_ema_step')
@@ -359,13 +359,14 @@ def main():
         _spin.mul_(1.0001)
         torch.cuda.synchronize()
     del _spin
-    # ... and COLD_STEPS untimed steps of the workload itself before the W warmup steps: the FIRST process on a fresh box shows one
-    # 24-37 ms step some 30 steps in (timed step 13 of a default run; never in a second process on the same box), which a W = 5 run
-    # would otherwise have inside its 13 ms timed region.  Reported as config.cold_start_steps.
+    # ... and COLD_STEPS untimed steps of the workload itself before the W warmup steps (a multiple of the ray pool, so the prefetched
+    # batches line up with warmup step 0): with W = 5 the warmup alone is 3 ms of device work on a box that has run nothing yet.
+    # Reported as config.cold_start_steps.
     for i in range(COLD_STEPS):
         run(i % n_pool, epoch0 + 1 + (i % 15))     # (no occupancy refresh among them: that cadence belongs to the counted steps)
     torch.cuda.synchronize()
-    # the stall is on the HOST (ARCN_BENCH_TRACE=1: 38 ms inside one step's enqueue calls) and always at timed step 12-13, i.e. after
+    # The FIRST process on a fresh box showed ONE 24-38 ms step inside the timed region (never in a second process on the same box).
+    # The stall is on the HOST (ARCN_BENCH_TRACE=1: 38 ms inside one step's enqueue calls) and always at timed step 12-13, i.e. after
     # ~50 of the per-launch timing events of the timed region: the runtime's event pool growing for the first time on that box.  Grow
     # it here: as many events as the timed region will create, recorded once and released.
     _ev = [torch.cuda.Event(enable_timing=True) for _ in range(6 * args.steps + 512)]
