@@ -351,15 +351,7 @@ def main():
             pipe.update_occupancy(epoch, apply=False)
 
     epoch0 = 512  # steady-state regime of VolumeBound.optimize (after epoch_optim_warmup = 256)
-    # a fresh box hands over an idle GPU: ~0.3 s of untimed device work before the W warmup steps (which are 3-10 ms in total) so that
-    # clock / power-state ramps are not inside the timed region
-    _spin = torch.empty(1 << 26, dtype=torch.float32, device=dev)
-    _t = time.perf_counter()
-    while time.perf_counter() - _t < 0.3:
-        _spin.mul_(1.0001)
-        torch.cuda.synchronize()
-    del _spin
-    # ... and COLD_STEPS untimed steps of the workload itself before the W warmup steps (a multiple of the ray pool, so the prefetched
+    # a fresh box hands over an idle GPU: COLD_STEPS untimed steps of the workload before the W warmup steps (a multiple of the ray pool, so the prefetched
     # batches line up with warmup step 0): with W = 5 the warmup alone is 3 ms of device work on a box that has run nothing yet.
     # Reported as config.cold_start_steps.
     for i in range(COLD_STEPS):
