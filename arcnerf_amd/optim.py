@@ -26,6 +26,90 @@ class FusedAdam(torch.optim.Optimizer):
         self.ema_decay = ema_decay
         self.zero_grad_on_step = zero_grad_on_step
         self.ema_in_param = bool(ema_in_param and ema_decay is not None)
+        self.grad_scale = 1.0     # multiplies every gradient as it is read: 1 / world after a SUM all-reduce (DDP's average, no extra pass)
+        self._flat = None         # per param group: dict(params, grads, exp_avg, exp_avg_sq, ema, slots) once flatten() ran
+
+    # ---- one flat buffer per parameter group --------------------------------------------------------------------------------------
+    def flatten(self):
+        """Re-home the parameters of every group into ONE contiguous fp32 buffer per group, their gradients into one flat gradient
+        buffer (`p.grad` becomes a view; autograd accumulates into it in place) and the Adam state into flat buffers too: `step()` is
+        then one kernel launch per group, `flat_grads()` is what a data-parallel step all-reduces with ONE collective and no
+        gather / scatter copies (the reference wraps the model in DistributedDataParallel, common/trainer/basic_trainer.py:197-198,
+        whose buckets are the same idea), and `zero_grad()` is one memset.  Segments are padded to 16 bytes; the pad elements have zero
+        parameter, gradient and state, which Adam leaves at zero.  state_dict() keeps torch.optim.Adam's per-parameter layout (the
+        entries are views).  Returns self."""
+        self._flat = []
+        for group in self.param_groups:
+            ps = [p for p in group['params'] if p.requires_grad]
+            for p in ps:
+                if not (p.is_cuda and p.dtype == torch.float32):
+                    raise RuntimeError('FusedAdam handles float32 CUDA parameters (there is no CPU fallback)')
+            slots, off = [], 0
+            for p in ps:
+                slots.append((off, p.numel()))
+                off += (p.numel() + 3) // 4 * 4
+            dev = ps[0].device if ps else None
+            mk = lambda: torch.zeros(max(off, 4), dtype=torch.float32, device=dev)   # noqa: E731
+            fb = dict(list=ps, slots=slots, params=mk(), grads=mk(), exp_avg=mk(), exp_avg_sq=mk(),
+                      ema=mk() if (self.ema_decay is not None and not self.ema_in_param) else None, step=0)
+            with torch.no_grad():
+                for p, (o, n) in zip(ps, slots):
+                    fb['params'][o:o + n].copy_(p.detach().reshape(-1))
+                    st = self.state[p]
+                    if 'exp_avg' in st:
+                        fb['exp_avg'][o:o + n].copy_(st['exp_avg'].reshape(-1))
+                        fb['exp_avg_sq'][o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+                        fb['step'] = max(fb['step'], int(st['step']))
+                    if p.grad is not None:
+                        fb['grads'][o:o + n].copy_(p.grad.reshape(-1))
+                    if fb['ema'] is not None:
+                        src = st['ema'] if st.get('ema') is not None else p.detach()
+                        fb['ema'][o:o + n].copy_(src.reshape(-1))
+                    p.data = fb['params'][o:o + n].view(p.shape)
+                    p.grad = fb['grads'][o:o + n].view(p.shape)
+                    st['step'] = fb['step']
+                    st['exp_avg'] = fb['exp_avg'][o:o + n].view(p.shape)
+                    st['exp_avg_sq'] = fb['exp_avg_sq'][o:o + n].view(p.shape)
+                    if fb['ema'] is not None:
+                        st['ema'] = fb['ema'][o:o + n].view(p.shape)
+            self._flat.append(fb)
+        return self
+
+    def flat_grads(self, group=0):
+        """The flat gradient buffer of a parameter group (after flatten()): the tensor to all-reduce."""
+        if self._flat is None:
+            raise RuntimeError('FusedAdam.flat_grads() needs flatten() first')
+        return self._flat[group]['grads']
+
+    def flat_params(self, group=0):
+        if self._flat is None:
+            raise RuntimeError('FusedAdam.flat_params() needs flatten() first')
+        return self._flat[group]['params']
+
+    def zero_grad(self, set_to_none=False):
+        if self._flat is None:
+            return super().zero_grad(set_to_none=set_to_none)
+        for fb in self._flat:      # the views stay in place (set_to_none would detach them from the flat buffer)
+            fb['grads'].zero_()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        if self._flat is not None:   # the loaded per-parameter tensors replaced the views: fold them back into the flat buffers
+            self.flatten()
+
+    def _step_flat(self):
+        for group, fb in zip(self.param_groups, self._flat):
+            for p, (o, n) in zip(fb['list'], fb['slots']):
+                if p.grad is None or p.grad.data_ptr() != fb['grads'].data_ptr() + 4 * o or p.data_ptr() != fb['params'].data_ptr() + 4 * o:
+                    raise RuntimeError('FusedAdam (flat): a parameter or its .grad was re-assigned after flatten(); '
+                                       'use zero_grad(set_to_none=False) and in-place updates, or call flatten() again')
+            fb['step'] += 1
+            for p in fb['list']:
+                self.state[p]['step'] = fb['step']
+            F.adam_ema_step(fb['params'], fb['grads'], fb['exp_avg'], fb['exp_avg_sq'], fb['params'] if self.ema_in_param else fb['ema'],
+                            fb['step'], lr=group['lr'], betas=group['betas'], eps=group['eps'], weight_decay=group['weight_decay'],
+                            ema_decay=self.ema_decay if self.ema_decay is not None else 0.0, grad_scale=self.grad_scale,
+                            zero_grad=self.zero_grad_on_step)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -33,6 +117,9 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self._flat is not None:
+            self._step_flat()
+            return loss
         for group in self.param_groups:
             for p in group['params']:
                 if p.grad is None:
@@ -51,5 +138,6 @@ class FusedAdam(torch.optim.Optimizer):
                 st['step'] = int(st['step']) + 1
                 F.adam_ema_step(p, p.grad, st['exp_avg'], st['exp_avg_sq'], p if self.ema_in_param else st.get('ema'), st['step'], lr=group['lr'],
                                 betas=group['betas'], eps=group['eps'], weight_decay=group['weight_decay'],
-                                ema_decay=self.ema_decay if self.ema_decay is not None else 0.0, zero_grad=self.zero_grad_on_step)
+                                ema_decay=self.ema_decay if self.ema_decay is not None else 0.0, grad_scale=self.grad_scale,
+                                zero_grad=self.zero_grad_on_step)
         return loss

@@ -45,6 +45,67 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks_if_needed(args):
+    """`python bench.py --gpus N` without a launcher (RANK / WORLD_SIZE unset) starts the N ranks itself, one process per GPU, the way the
+    reference's launcher does (scripts/gpu.sh:9-21 -> common/trainer/basic_trainer.py:73-111: mp.spawn of one worker per gpu id with a
+    tcp://127.0.0.1 rendezvous): this process re-executes the same command line under `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1`, rank 0 of the children prints the ONE JSON line, and the exit code is passed on.
+    Under torchrun (the driver's N > 1 form) RANK / WORLD_SIZE are set and this is a no-op."""
+    if args.gpus <= 1 or ('RANK' in os.environ and 'WORLD_SIZE' in os.environ):
+        return
+    import socket
+    import subprocess
+    backend = os.environ.get('ARCN_DIST_BACKEND', 'nccl')
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        sys.exit('bench.py needs a GPU (there is no CPU fallback for the product path)')
+    if backend == 'nccl' and args.gpus > n_dev:
+        sys.exit('bench.py --gpus {}: only {} GPU(s) visible and RCCL wants one GPU per rank '
+                 '(ARCN_DIST_BACKEND=gloo lets several ranks share a GPU for functional tests)'.format(args.gpus, n_dev))
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL's intra-node transport on this host driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    env['ARCN_BENCH_SELF_SPAWNED'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node={}'.format(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def dist_report(dist, world, launch, payload_bytes, n_collectives, per_rank, extra=None):
+    """The `rccl` object of the JSON line: which backend carried the gradient exchange, how many ranks it saw, bytes per step."""
+    if dist is None:
+        return None
+    r = {'backend': dist.get_backend(), 'world_size_seen': dist.get_world_size(), 'launcher': launch,
+         'allreduce_bytes_per_step': int(payload_bytes), 'collectives_per_step': int(n_collectives),
+         'ring_bytes_on_the_wire_per_gpu': int(2 * (world - 1) / world * payload_bytes), 'per_rank_samples_per_step': per_rank}
+    if extra:
+        r.update(extra)
+    return r
+
+
+def time_allreduce_alone(dist, buf, iters=10):
+    """The gradient all-reduce with nothing beside it, HIP events on the current stream (a synchronous collective makes the current
+    stream wait for the communicator's): ms per call and the ring's bus bandwidth.  After the timed region, on a scratch buffer."""
+    scratch = torch.zeros_like(buf)
+    for _ in range(3):
+        dist.all_reduce(scratch)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        dist.all_reduce(scratch)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    w = dist.get_world_size()
+    return {'allreduce_alone_ms': ms, 'allreduce_busbw_GBps': 2 * (w - 1) / w * scratch.numel() * 4 / (ms * 1e-3) / 1e9}
+
+
 COLD_STEPS = 96   # untimed steps of the workload before the W warmup steps (see main); a multiple of the ray pool size (8)
 ROOFLINE_KERNELS = ('hashgrid_fwd', 'hashgrid_bwd')
 TABLE_KERNELS = ROOFLINE_KERNELS + ('mlp_fwd', 'mlp_bwd', 'mlp_bwd_dw', 'march_count', 'composite_packed_train', 'composite_packed_fwd',
@@ -160,8 +221,15 @@ def bench_module(args, name):
             inp['exp_time'] = (torch.rand(1, n_rays, 1, generator=g) * 4.0 + 0.1).to(dev)
         pool.append(inp)
     params = [p for p in m.parameters() if p.requires_grad]
-    opt = FusedAdam(params, lr=5e-4, eps=1e-15)
+    # parameters, gradients and Adam state in ONE flat buffer: p.grad are views autograd accumulates into, so the data-parallel exchange
+    # is one collective on that buffer with no gather / scatter copies, DDP's 1 / world is the optimiser's grad_scale, and the
+    # optimiser and the gradient clear are one launch each
+    opt = FusedAdam(params, lr=5e-4, eps=1e-15).flatten()
+    opt.grad_scale = 1.0 / world
+    flat_grads = opt.flat_grads()
     flat_numel = sum(p.numel() for p in params)
+    if world > 1:
+        D.broadcast_params(opt.flat_params(), src=0)   # what DDP does at construction
 
     def loss_of(out, inp):
         if name in ('nerf', 'hdrnerf'):
@@ -189,16 +257,10 @@ def bench_module(args, name):
         inp = pool[i % len(pool)]
         out = m({k: v for k, v in inp.items()}, inference_only=False, cur_epoch=20000 + i)
         loss = loss_of(out, inp)
-        opt.zero_grad(set_to_none=False)
+        opt.zero_grad()
         loss.backward()
-        if world > 1:   # DDP semantics: average of the ranks' gradients, one bucketed all-reduce over the flat list
-            flat = torch.cat([p.grad.reshape(-1) for p in params])
-            dist.all_reduce(flat)
-            flat.div_(world)
-            off = 0
-            for p in params:
-                p.grad.copy_(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
+        if world > 1:   # DDP semantics (average of the ranks' gradients): SUM all-reduce of the flat buffer, 1 / world in the optimiser
+            dist.all_reduce(flat_grads)
         opt.step()
         return loss
 
@@ -224,12 +286,21 @@ def bench_module(args, name):
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
+    evals_per_step = n_rays * spec['evals'] if spec['evals'] else n_eval[0]
+    per_rank = [evals_per_step]
+    rccl_extra = None
+    if dist is not None:
+        mine = torch.tensor([evals_per_step], dtype=torch.int64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [int(t.item()) for t in allr]
+        rccl_extra = time_allreduce_alone(dist, flat_grads)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
-    evals_per_step = n_rays * spec['evals'] if spec['evals'] else n_eval[0]
-    total = evals_per_step * args.steps * world
+    total = sum(per_rank) * args.steps
+    evals_per_step = sum(per_rank) / world
     roofline = None
     if spec['flop']:
         # fwd + bwd (dX and dW) = 3x the forward FLOP of the linear stacks; NeuS additionally differentiates the sdf net twice
@@ -251,6 +322,7 @@ def bench_module(args, name):
                name, spec['desc'], n_rays, evals_per_step, spec['yaml']), 'rays_per_step_per_gpu': n_rays,
                'samples_per_step_per_gpu': evals_per_step, 'n_params': flat_numel, 'parallelism': 'ray-sharded dp{}'.format(world),
                'chunk_pts': int(m.get_chunk_pts())},
+           'rccl': dist_report(dist, world, LAUNCH, flat_grads.numel() * 4, 1, per_rank, rccl_extra),
            'roofline': roofline, 'cpu_baseline': cpu}
     print(json.dumps(out))
     if dist is not None:
@@ -282,8 +354,15 @@ def cpu_baseline_nerf(rays_all=4096):
     return best
 
 
+LAUNCH = 'single process'
+
+
 def main():
+    global LAUNCH
     args = parse()
+    spawn_ranks_if_needed(args)
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        LAUNCH = 'bench.py --gpus N re-executed itself under torch.distributed.run' if os.environ.get('ARCN_BENCH_SELF_SPAWNED') else 'external torchrun'
     if args.config != 'ngp':
         return bench_module(args, args.config)
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -293,9 +372,9 @@ def main():
     torch.cuda.set_device(local_rank)
     # the step's kernels go to a high-priority stream: the dispatcher then prefers their workgroups over those of the sampling
     # stream (marching of a later batch), which only fills what is left; -1 % on the step (ARCN_MAIN_PRIORITY=0: default stream)
-    # Single GPU only by default: with several ranks the collectives' own kernels run at normal priority beside the step's, and
-    # that combination could not be measured here (no multi-GPU box for this session)
-    main_priority = int(os.environ.get('ARCN_MAIN_PRIORITY', '-1' if world == 1 else '0'))
+    # Same for every world size (the collectives run on the communicator's own stream, between the backward and the optimiser pass that
+    # waits for them: the only thing they share the chip with is the sampling stream's marcher).
+    main_priority = int(os.environ.get('ARCN_MAIN_PRIORITY', '-1'))
     if main_priority != 0:
         torch.cuda.set_stream(torch.cuda.Stream(priority=main_priority))
     dev = torch.device('cuda', local_rank)
@@ -397,11 +476,19 @@ def main():
     if os.environ.get('ARCN_BENCH_TRACE'):   # where a slow step lost its time: GPU span vs host enqueue span per step
         print(json.dumps({'gpu_ms': [round(v, 3) for v in per_step_raw], 'host_ms': [round((b - a) * 1e3, 3) for a, b in zip(cpu_marks[:-1], cpu_marks[1:])]}), file=sys.stderr)
 
-    samples = sample_log[args.warmup:args.warmup + args.steps].sum()
+    samples = sample_log[args.warmup:args.warmup + args.steps].sum().reshape(1)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    per_rank = [int(samples.item()) / args.steps]
+    rccl_extra = None
     if dist is not None:
+        allr = [torch.zeros_like(samples) for _ in range(world)]
+        dist.all_gather(allr, samples)
+        per_rank = [int(t.item()) / args.steps for t in allr]
         dist.all_reduce(samples)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        rccl_extra = time_allreduce_alone(dist, field.grads)
+        rccl_extra['grad_sync'] = ('{} async segments pipelined with the optimiser pass'.format(len(grad_sync.segments)) if grad_sync is not None
+                                   else 'one flat all-reduce')
     total_samples = int(samples.item())
     wall = float(tmax.item())
     ksum = timers.summary()
@@ -507,6 +594,7 @@ def main():
         'timed_region_ms': wall * 1e3,
         'step_ms_spread': {'slowest_step': slowest, 'min': per_step[0], 'p50': per_step[len(per_step) // 2], 'p90': per_step[min(len(per_step) - 1, int(0.9 * len(per_step)))],
                            'max': per_step[-1]},
+        'rccl': dist_report(dist, world, LAUNCH, field.n_params * 4, len(grad_sync.segments) if grad_sync is not None else 1, per_rank, rccl_extra),
         'roofline': roofline,
         'roofline_lookup': lookup,
         'cpu_baseline': cpu,

@@ -123,3 +123,55 @@ def test_two_ranks_train_like_one_process_accumulating_both_shards(mode):
     # Adam (eps 1e-15) turns the summation-order noise of near-zero gradient entries into full-size steps of either sign: parameters
     # agree to a fraction of a percent of the distance they travelled, not bit for bit
     assert np.abs(got[0] - ref).max() <= 1e-2 * moved, (np.abs(got[0] - ref).max(), moved)
+
+
+def _run_bench(extra, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env['ARCN_DIST_BACKEND'] = 'gloo'      # two ranks on ONE GPU: RCCL wants a GPU per rank, the launch path is the same
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + extra, env=env, cwd=root, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]      # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize('config', ['ngp', 'neus_ngp_multivol'])
+def test_bench_gpus_flag_spawns_the_ranks_itself(config):
+    """`python bench.py --gpus 2` with no launcher around it (the driver's command form) must start two ranks itself (the reference:
+    scripts/gpu.sh:9-21 -> basic_trainer.py:73-111 mp.spawn), report n_gpus = 2, the collective backend / world size it saw, the bytes
+    per step of the gradient all-reduce, per-rank sample counts, and a whole-job value = all ranks' samples / max-over-ranks time."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    extra = ['--gpus', '2', '--steps', '4', '--warmup', '2', '--no-cpu-baseline']
+    if config != 'ngp':
+        extra += ['--config', config, '--rays', '1024']
+    out = _run_bench(extra)
+    assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'ray-sharded dp2' and out['scaling'] == 'weak'
+    rc = out['rccl']
+    assert rc['backend'] == 'gloo' and rc['world_size_seen'] == 2 and 'bench.py --gpus N' in rc['launcher']
+    assert rc['allreduce_bytes_per_step'] >= 4 * out['config'].get('n_params', 12_000_000)
+    assert len(rc['per_rank_samples_per_step']) == 2 and min(rc['per_rank_samples_per_step']) > 0
+    total = sum(rc['per_rank_samples_per_step']) * out['steps']
+    assert abs(out['value'] - total / (out['ms_per_step'] * 1e-3 * out['steps'])) <= 1e-3 * out['value']
+    # weak scaling: both ranks carry a full batch (rank-local rays), so the job's samples are about twice one rank's
+    assert 1.6 <= sum(rc['per_rank_samples_per_step']) / max(rc['per_rank_samples_per_step']) <= 2.0
+
+
+def test_bench_refuses_more_rccl_ranks_than_gpus():
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'ARCN_DIST_BACKEND')}
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n), '--steps', '1', '--warmup', '0'], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'one GPU per rank' in r.stderr

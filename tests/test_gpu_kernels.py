@@ -881,6 +881,54 @@ def test_fused_adam_optimizer_matches_torch_adam(F):
     assert 'ema' not in eb.state[qb[0]]
 
 
+def test_fused_adam_flat_buffer_equals_per_parameter_steps(F):
+    """FusedAdam.flatten(): parameters, gradients (views that autograd accumulates into) and state in ONE buffer per group, one launch
+    per step, `grad_scale` = DDP's 1 / world on a SUM all-reduced buffer; same bits as the per-parameter launches, torch.optim.Adam's
+    state_dict layout, load_state_dict re-flattens, a re-assigned .grad is refused"""
+    from arcnerf_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(5)
+    shapes = [(257, 63), (33, 64), (7,), (1,), (64, 3)]
+    pa = [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    xs = [torch.randn(16, s[-1] if len(s) > 1 else s[0], generator=g).cuda() for s in shapes]
+
+    def loss(ps, k):
+        return sum(((x @ p.t() if p.dim() > 1 else x * p) * (k + 1.0)).pow(2).mean() for x, p in zip(xs, ps))
+    oa = FusedAdam(pa, lr=1e-2, eps=1e-15, weight_decay=1e-3, ema_decay=0.95).flatten()
+    ob = FusedAdam(pb, lr=1e-2, eps=1e-15, weight_decay=1e-3, ema_decay=0.95)
+    oa.grad_scale = ob.grad_scale = 0.5
+    fg = oa.flat_grads()
+    assert fg.numel() % 4 == 0 and all(p.grad.data_ptr() % 16 == 0 for p in pa)
+    for it in range(5):
+        oa.zero_grad()
+        ob.zero_grad(set_to_none=False)
+        loss(pa, it).backward()
+        loss(pb, it).backward()
+        assert fg.data_ptr() == oa.flat_grads().data_ptr() and float(fg.abs().sum()) > 0     # autograd wrote into the flat buffer
+        for a, b_ in zip(pa, pb):
+            assert torch.equal(a.grad, b_.grad)
+        oa.step()
+        ob.step()
+        for a, b_ in zip(pa, pb):
+            assert torch.equal(a, b_)
+    sd = oa.state_dict()
+    assert set(sd['state'][0].keys()) == {'step', 'exp_avg', 'exp_avg_sq', 'ema'} and sd['state'][0]['step'] == 5
+    assert torch.equal(sd['state'][2]['exp_avg_sq'], ob.state_dict()['state'][2]['exp_avg_sq'])
+    # a checkpoint goes back in: the loaded tensors are folded into the flat buffers again
+    oa.load_state_dict(ob.state_dict())
+    oa.zero_grad()
+    ob.zero_grad(set_to_none=False)
+    loss(pa, 9).backward()
+    loss(pb, 9).backward()
+    oa.step()
+    ob.step()
+    for a, b_ in zip(pa, pb):
+        assert torch.equal(a, b_)
+    pa[1].grad = torch.zeros_like(pa[1])
+    with pytest.raises(RuntimeError):
+        oa.step()
+
+
 def test_first_order_only_nodes_refuse_a_second_differentiation(F):
     """the fused MLP has a hand-written first-order backward: asking autograd to differentiate THROUGH that backward (an sdf net on
     the fused kernels with normals by create_graph) must raise, not return gradients that silently ignore the path"""
