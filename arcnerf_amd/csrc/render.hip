@@ -395,23 +395,20 @@ composite_train_kernel(View v, const int32_t *p_dense_ptr, const float *__restri
 }
 
 // ---- inverse CDF resampling ---------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-sample_cdf_kernel(const float *__restrict__ bins, const float *__restrict__ cdf, const float *__restrict__ u, int n_pts,
-                  int n_sample, int n_pad, float eps, int do_sort, float *__restrict__ samples,
-                  int32_t *__restrict__ inds) {
-    extern __shared__ __attribute__((aligned(16))) float s_val[];
-    const int64_t r = blockIdx.x;
-    const float *b = bins + r * n_pts, *c = cdf + r * n_pts;
+// one row's searchsorted(right=True) + lerp for the uniforms k = tid, tid + blockDim, ... into s_val, then the row sort and the store
+__device__ __forceinline__ void inverse_cdf_row(const float *__restrict__ b, const float *c, const float *__restrict__ u_row, int n_pts,
+                                                int n_sample, int n_pad, float eps, int do_sort, float *s_val, float *__restrict__ samples_row,
+                                                int32_t *__restrict__ inds_row) {
     for (int k = threadIdx.x; k < n_pad; k += blockDim.x) {
         float out = INFINITY;
         if (k < n_sample) {
-            float uu = u[r * n_sample + k];
+            float uu = u_row[k];
             int lo = 0, hi = n_pts;  // searchsorted(right=True): first index with cdf > u
             while (lo < hi) {
                 int mid = (lo + hi) >> 1;
                 if (c[mid] <= uu) lo = mid + 1; else hi = mid;
             }
-            if (inds) inds[r * n_sample + k] = lo;
+            if (inds_row) inds_row[k] = lo;
             int below = lo - 1 < 0 ? 0 : (lo - 1 > n_pts - 1 ? n_pts - 1 : lo - 1);
             int above = lo > n_pts - 1 ? n_pts - 1 : lo;
             float denom = c[above] - c[below];
@@ -437,7 +434,67 @@ sample_cdf_kernel(const float *__restrict__ bins, const float *__restrict__ cdf,
             }
         }
     }
-    for (int k = threadIdx.x; k < n_sample; k += blockDim.x) samples[r * n_sample + k] = s_val[k];
+    for (int k = threadIdx.x; k < n_sample; k += blockDim.x) samples_row[k] = s_val[k];
+}
+
+__global__ void __launch_bounds__(256)
+sample_cdf_kernel(const float *__restrict__ bins, const float *__restrict__ cdf, const float *__restrict__ u, int n_pts,
+                  int n_sample, int n_pad, float eps, int do_sort, float *__restrict__ samples,
+                  int32_t *__restrict__ inds) {
+    extern __shared__ __attribute__((aligned(16))) float s_val[];
+    const int64_t r = blockIdx.x;
+    inverse_cdf_row(bins + r * n_pts, cdf + r * n_pts, u + r * n_sample, n_pts, n_sample, n_pad, eps, do_sort, s_val, samples + r * n_sample,
+                    inds ? inds + r * n_sample : nullptr);
+}
+
+// sample_pdf (ray_helper.py:410-429) in one launch per call: weights + eps -> / sum -> cumsum -> inverse CDF -> sort.  The cdf is built
+// the way torch builds it on the host the reference's CPU path runs on: the running sum is kept in DOUBLE and every prefix is rounded
+// to float (at::native cumsum accumulates float tensors in acc_type<float, false> = double), sequentially - a float tree scan differs
+// from it by up to ~1e-6 near cdf = 1, and the inverse CDF divides by bin masses down to 1e-5.  The normaliser is the double sum of
+// the (weight + eps) floats rounded to float (torch.sum is a vectorised float sum whose order depends on the host's ISA; it is within
+// an ulp or two of this).  One workgroup per ray; u has u_rows = 1 (one lattice for all rays) or R rows.
+__global__ void __launch_bounds__(256)
+sample_pdf_kernel(const float *__restrict__ bins, const float *__restrict__ weights, const float *__restrict__ u, int u_rows, int n_pts,
+                  int n_sample, int n_pad, float eps, int do_sort, float *__restrict__ samples, float *__restrict__ cdf_out) {
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    float *s_cdf = s_mem;                  // n_pts
+    float *s_val = s_mem + n_pts;          // n_pad
+    __shared__ double s_part[4];
+    __shared__ float s_norm;
+    const int64_t r = blockIdx.x;
+    const int n_w = n_pts - 1;
+    const float *w = weights + r * n_w;
+    double part = 0.0;
+    for (int k = threadIdx.x; k < n_w; k += blockDim.x) {
+        const float v = w[k] + eps;
+        s_cdf[k + 1] = v;
+        part += (double)v;
+    }
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < (int)((blockDim.x + 63) >> 6); ++i) tot += s_part[i];
+        s_norm = (float)tot;
+    }
+    __syncthreads();
+    const float norm = s_norm;
+    for (int k = threadIdx.x; k < n_w; k += blockDim.x) s_cdf[k + 1] = s_cdf[k + 1] / norm;     // pdf, in place
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double acc = 0.0;
+        s_cdf[0] = 0.0f;
+        for (int k = 1; k < n_pts; ++k) {
+            acc += (double)s_cdf[k];
+            s_cdf[k] = (float)acc;
+        }
+    }
+    __syncthreads();
+    if (cdf_out)
+        for (int k = threadIdx.x; k < n_pts; k += blockDim.x) cdf_out[r * n_pts + k] = s_cdf[k];
+    inverse_cdf_row(bins + r * n_pts, s_cdf, u + (u_rows > 1 ? r * n_sample : 0), n_pts, n_sample, n_pad, eps, do_sort, s_val,
+                    samples + r * n_sample, nullptr);
 }
 
 // ---- ImgLoss(Huber) value + gradient (arcnerf/loss/img_loss.py:60-100), mean over all R*3 elements, times weight ----
@@ -621,6 +678,19 @@ ARCN_EXPORT int arcn_sample_cdf(const float *bins, const float *cdf, const float
     hipLaunchKernelGGL(sample_cdf_kernel, dim3((unsigned)R), dim3(256), sizeof(float) * n_pad, as_stream(stream), bins, cdf,
                        u, n_pts, n_sample, n_pad, eps, do_sort, samples, inds);
     return check_launch("sample_cdf");
+}
+
+ARCN_EXPORT int arcn_sample_pdf(const float *bins, const float *weights, const float *u, int64_t R, int n_pts, int n_sample, int u_rows,
+                                float eps, int do_sort, float *samples, float *cdf_out, void *stream) {
+    if (R <= 0 || n_sample <= 0) return ARCN_OK;
+    if (!bins || !weights || !u || !samples || n_pts < 2) return einval("sample_pdf: missing argument");
+    if (u_rows != 1 && u_rows != R) return einval("sample_pdf: u must have 1 or R rows");
+    int n_pad = 1;
+    while (n_pad < n_sample) n_pad <<= 1;
+    if (n_pad + n_pts > 15360) return einval("sample_pdf: n_sample + n_pts too large for one workgroup's LDS");
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)R), dim3(256), sizeof(float) * (size_t)(n_pad + n_pts), as_stream(stream), bins, weights,
+                       u, u_rows, n_pts, n_sample, n_pad, eps, do_sort, samples, cdf_out);
+    return check_launch("sample_pdf");
 }
 
 ARCN_EXPORT int arcn_sdf_to_alpha_fwd(const float *mid_sdf, const float *zvals, const float *mid_slope, const float *s_dev, int clip,

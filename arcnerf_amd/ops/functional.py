@@ -850,6 +850,19 @@ def sample_cdf(bins, cdf, u, eps=1e-5, sort=True, want_inds=False):
 # ------------------------------------------------------------------------------------------------
 # occupancy update, optimiser
 # ------------------------------------------------------------------------------------------------
+def sample_pdf(bins, weights, u, eps=1e-5, sort=True, want_cdf=False):
+    """bins (R, n_pts), weights (R, n_pts-1), u (1 | R, n_sample) -> samples (R, n_sample) sorted [, cdf (R, n_pts)]"""
+    _req(bins, weights, u)
+    R, n_pts = bins.shape
+    assert weights.shape == (R, n_pts - 1) and u.dim() == 2 and u.shape[0] in (1, R)
+    n_sample = u.shape[1]
+    samples = torch.empty((R, n_sample), dtype=torch.float32, device=bins.device)
+    cdf = torch.empty((R, n_pts), dtype=torch.float32, device=bins.device) if want_cdf else None
+    N.check(N.lib().arcn_sample_pdf(N.ptr(bins), N.ptr(weights), N.ptr(u), R, n_pts, n_sample, int(u.shape[0]), float(eps), int(sort),
+                                   N.ptr(samples), N.ptr(cdf), N.stream()), 'sample_pdf')
+    return (samples, cdf) if want_cdf else samples
+
+
 def update_opafield(opafield, flat_idx, opacity, ema=None):
     _req(opafield, flat_idx, opacity)
     assert opafield.is_contiguous() and opafield.dtype == torch.float32

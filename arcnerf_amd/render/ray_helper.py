@@ -1,8 +1,9 @@
 """z sampling helpers and alpha compositing with the reference's function names and return conventions
 (arcnerf/render/ray_helper.py:175-620,753-814), backed by the HIP kernels.
 
-Randomness: perturbation uses torch.rand like the reference (cannot be matched bit-for-bit, parity runs use
-perturb=False / inference_only=True).
+Randomness: perturbation draws uniforms through `uniform()` below, one call per reference `torch.rand` call and in the same
+order (ray_helper.py:375 perturb_interval, :453 sample_cdf), so a parity run with perturb=True can feed it the reference's recorded
+draws (tests/rand_feed.py; golden G23 / G18 / G25); the generator itself cannot be matched bit for bit across devices.
 """
 import torch
 
@@ -60,11 +61,16 @@ def get_near_far_from_rays(rays_o, rays_d, bounds=None, near_hardcode=None, far_
     return near, far
 
 
+def uniform(shape, dtype, device):
+    """U[0, 1) draws of the sampling helpers: the ONE place they come from (see the module docstring)"""
+    return torch.rand(tuple(shape), dtype=dtype, device=device)
+
+
 def perturb_interval(vals):
     mids = 0.5 * (vals[..., 1:] + vals[..., :-1])
     upper = torch.cat([mids, vals[..., -1:]], -1)
     lower = torch.cat([vals[..., :1], mids], -1)
-    return lower + (upper - lower) * torch.rand_like(upper)
+    return lower + (upper - lower) * uniform(upper.shape, upper.dtype, upper.device)
 
 
 def get_zvals_from_near_far(near, far, n_pts, inclusive=True, inverse_linear=False, perturb=False):
@@ -157,16 +163,24 @@ def sample_cdf(bins, cdf, n_sample, det=False, eps=1e-5):
     if det:
         u = torch.linspace(0.0, 1.0, steps=n_sample, device=bins.device).expand(cdf.shape[0], n_sample)
     else:
-        u = torch.rand(cdf.shape[0], n_sample, device=bins.device)
+        u = uniform((cdf.shape[0], n_sample), torch.float32, bins.device)
     return F.sample_cdf(bins, cdf.detach(), u.contiguous(), eps=eps, sort=True)
 
 
+_LATTICE = {}
+
+
 def sample_pdf(bins, weights, n_sample, det=False, eps=1e-5):
-    weights = weights + eps
-    pdf = weights / torch.sum(weights, -1, keepdim=True)
-    cdf = torch.cumsum(pdf, -1)
-    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
-    return sample_cdf(bins, cdf, n_sample, det, eps)
+    """(ray_helper.py:410-429) weights -> pdf -> cdf -> inverse CDF -> sorted samples: ONE kernel (arcn_sample_pdf; the cdf accumulated
+    in double and rounded per prefix like torch's CPU cumsum) instead of add / sum / div / cumsum / cat / searchsorted / gathers / sort"""
+    if det:
+        key = (int(n_sample), bins.device)
+        if key not in _LATTICE:
+            _LATTICE[key] = torch.linspace(0.0, 1.0, steps=n_sample, device=bins.device)[None].contiguous()
+        u = _LATTICE[key]
+    else:
+        u = uniform((bins.shape[0], n_sample), torch.float32, bins.device).contiguous()
+    return F.sample_pdf(bins.detach().contiguous().float(), weights.detach().contiguous().float(), u, eps=eps, sort=True)
 
 
 def alpha_to_weights(alpha):

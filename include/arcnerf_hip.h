@@ -429,6 +429,13 @@ int arcn_sdf_to_alpha_bwd(const float *mid_sdf, const float *zvals, const float 
 int arcn_sample_cdf(const float *bins, const float *cdf, const float *u, int64_t R, int n_pts, int n_sample, float eps,
                     int do_sort, float *samples, int32_t *inds, void *stream);
 
+/* sample_pdf (ray_helper.py:410-429) in one launch: weights (R, n_pts-1) -> (+eps) / sum -> cdf (R, n_pts) with a leading 0 -> inverse
+ * CDF at u -> sorted samples (R, n_sample).  u has u_rows = 1 (one lattice for every ray: det) or R rows.  The cdf is accumulated in
+ * double and rounded to float prefix by prefix, which is what torch.cumsum does on the reference's CPU path; cdf_out (R, n_pts)
+ * optional. */
+int arcn_sample_pdf(const float *bins, const float *weights, const float *u, int64_t R, int n_pts, int n_sample, int u_rows, float eps,
+                    int do_sort, float *samples, float *cdf_out, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Occupancy update (volume_bound.py:160-212, geometry/volume.py:983-1017)
  * ---------------------------------------------------------------------------------------------- */

@@ -169,16 +169,24 @@ ORC_API void orc_sample_cdf(const float *bins, const float *cdf, const float *u,
     }
 }
 
-/* sample_pdf (ray_helper.py:410-429): weights (R,n_pts-1) -> cdf (R,n_pts) */
+/* sample_pdf (ray_helper.py:410-429): weights (R,n_pts-1) -> cdf (R,n_pts).
+ * torch.cumsum on the CPU keeps the running sum of a float tensor in double (at::acc_type<float, false>) and rounds every prefix to
+ * float: restated exactly (given torch's normaliser this reproduces golden G2's cdf bit for bit).  torch.sum is a vectorised float
+ * sum whose order depends on the host ISA; restated as the double sum rounded to float (within an ulp or two of it). */
 ORC_API void orc_weights_to_cdf(const float *weights, int64_t R, int n_w, float eps, float *cdf) {
 #pragma omp parallel for schedule(static)
     for (int64_t r = 0; r < R; ++r) {
         const float *w = weights + r * n_w;
-        float sum = 0.f;
-        for (int i = 0; i < n_w; ++i) sum += w[i] + eps;
-        float acc = 0.f;
+        double tot = 0.0;
+        for (int i = 0; i < n_w; ++i) tot += (double)(w[i] + eps);
+        const float sum = (float)tot;
+        double acc = 0.0;
         cdf[r * (n_w + 1)] = 0.f;
-        for (int i = 0; i < n_w; ++i) { acc += (w[i] + eps) / sum; cdf[r * (n_w + 1) + i + 1] = acc; }
+        for (int i = 0; i < n_w; ++i) {
+            const float pdf = (w[i] + eps) / sum;
+            acc += (double)pdf;
+            cdf[r * (n_w + 1) + i + 1] = (float)acc;
+        }
     }
 }
 

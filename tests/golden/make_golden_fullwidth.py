@@ -16,6 +16,7 @@ sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, '/root/reference')
 sys.path.insert(1, os.path.dirname(HERE))
+sys.path.insert(2, HERE)
 _r = types.ModuleType('pytorch3d.transforms.rotation_conversions')
 for _n in ['axis_angle_to_matrix', 'matrix_to_axis_angle', 'matrix_to_rotation_6d', 'rotation_6d_to_matrix']:
     setattr(_r, _n, lambda *a, **k: None)
@@ -118,18 +119,75 @@ def nerf_like(cfg_name, fixture, seed, hdr=False):
     save(fixture, out)
 
 
-def neus(fixture, seed):
+def neus(fixture, seed, pool=400, keep=40, margin=2e-6, pos_noise=5e-6):
+    """G23.  Inference pass (deterministic lattice) + TRAINING pass with `perturb: True` as configs/models/neus.yaml has it, the
+    reference's torch.rand draws on tape (tie_probe.RandTape) so the mirror can be fed the same uniforms.  Why not perturb off as in the
+    first version of this fixture: the deterministic lattice contains u = 1.0, compared with a float cumsum that is 1.0 to an ulp - a
+    coin flip on the last sample of the first up-sampling round of every ray that hits (tie_probe.py) - and the Eikonal gradient of the
+    matrices fed by the 2^9-frequency embedding feels one moved sample at the 1e-2 level.  With recorded uniforms every inverse-CDF
+    decision of the stored rays has a margin >= `margin` in cdf units (they are picked from a pool by that criterion; indices and
+    margins are stored), so the gradients can be held at 1e-3 without exceptions."""
+    import arcnerf.models.neus_model as NM
+    import arcnerf.render.ray_helper as RH
+    from tie_probe import ProbeU, RandTape, float64_gradients, inference_flip_sensitivity, inference_lattice_margin, store_fp32_error
     torch.manual_seed(seed)
     model = build_model(load_configs('/root/reference/configs/models/neus.yaml', list(OVERRIDES)), None)
     out = {'overrides': np.array(OVERRIDES)}
     reseed_big_weights(model, out, seed)
-    g, inputs = rays(seed + 1, 1, 40, 3.0, 1.6)     # some rays miss the radius-1.5 sphere
+    g, pool_in = rays(seed + 1, 1, pool, 3.0, 1.6)
+    n_miss = 4                                         # the last rays of the pool pass the radius-1.5 sphere by: invalid-ray defaults
+    tang = torch.cross(pool_in['rays_o'][0, -n_miss:], torch.tensor([0.0, 0.0, 1.0]).expand(n_miss, 3), dim=-1)
+    pool_in['rays_d'][0, -n_miss:] = tang / tang.norm(dim=-1, keepdim=True)
+    model.fg_model.set_ray_cfgs('noise_std', 0.0)
+    assert model.fg_model.get_ray_cfgs('perturb') is True
+    flat = {k: v.view(-1, v.shape[-1]) for k, v in pool_in.items()}
+    hit = model.fg_model.obj_bound.get_near_far_from_rays(flat)[2]
+    hit = torch.ones(pool, dtype=torch.bool) if hit is None else hit.view(-1)
+    tape = RandTape(seed + 2)
+    with tape.record(), ProbeU(tape, RH, NM) as probe:
+        model({k: v.clone() for k, v in pool_in.items()}, inference_only=False, cur_epoch=20000)
+    pool_draws = [d.clone() for d in tape.draws]
+    m_hit = probe.per_ray()[1]
+    n_hit = int(hit.sum())
+    assert m_hit.shape[0] == n_hit and all(d.shape[0] in (n_hit, pool) for d in pool_draws)   # coarse depths: all rays; up-sampling: the hits
+    m_pool = np.full(pool, 1.0)
+    m_pool[hit.numpy()] = m_hit
+    assert int((~hit[-n_miss:]).sum()) == n_miss
+    # inference runs on the deterministic lattice, whose u = 1.0 is a coin flip against cdf[-1] (tie_probe.py): keep only rays whose
+    # inference outputs are the same either way
+    flip = inference_flip_sensitivity(model, pool_in, RH)
+    lat = np.full(pool, 1.0)
+    noise = np.zeros(pool)
+    lat[hit.numpy()], noise[hit.numpy()] = inference_lattice_margin(model, pool_in, RH, NM)
+    m_pool = np.minimum(m_pool, lat)      # one margin for both passes: taped uniforms (training) and lattice points (inference)
+    noise[hit.numpy()] = np.maximum(noise[hit.numpy()], probe.per_ray_noise())   # worst-conditioned sample of either pass (tie_probe.position_noise)
+    ok = np.nonzero((m_pool >= margin) & hit.numpy() & (flip < 1e-5) & (noise <= pos_noise))[0]
+    print('rays with a sample in an ill-conditioned bin (position noise >', pos_noise, '):', int((noise > pos_noise).sum()), 'of', pool)
+    sel = np.sort(np.concatenate([ok[:keep - n_miss], np.arange(pool - n_miss, pool)]))
+    assert len(sel) == keep, (len(ok), keep)
+    out['flip_sensitivity'], out['position_noise'] = flip[sel], noise[sel]
+    print('neus: rays whose inference outputs depend on the u = 1 decision:', int((flip >= 1e-5).sum()), 'of', pool)
+    rank = np.cumsum(hit.numpy()) - 1                  # pool ray -> row of the draws
+    rows = rank[sel][hit.numpy()[sel]]
+    inputs = {k: v[:, sel].contiguous() for k, v in pool_in.items()}
+    out['pool_size'], out['pool_sel'], out['tie_margin'] = np.array(pool), sel, m_pool[sel]
+    print('neus: pool', pool, 'hit', int(hit.sum()), 'rays with margin <', margin, ':', int((m_pool < margin).sum()), 'kept', keep,
+          'of which hit', int(hit.numpy()[sel].sum()), 'min margin kept', m_pool[sel].min())
+    # inference (deterministic lattice): outputs only
     res = model({k: v.clone() for k, v in inputs.items()}, inference_only=True)
     for k, v in res.items():
         out['infer_' + k] = v.detach().numpy()
-    model.fg_model.set_ray_cfgs('perturb', False)
-    model.fg_model.set_ray_cfgs('noise_std', 0.0)
-    res = model({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=20000)
+    # training pass on the kept rays with their rows of the taped draws
+    draws = [d[sel] if d.shape[0] == pool else d[rows] for d in pool_draws]
+    seen_z, real_mid = [], model.fg_model.handle_mid_pts
+    model.fg_model.handle_mid_pts = lambda z, mk: (seen_z.append(z.detach().clone()), real_mid(z, mk))[1]
+    with tape.replay(draws), ProbeU(tape, RH, NM) as probe:
+        res = model({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=20000)
+    model.fg_model.handle_mid_pts = real_mid
+    out['train_zvals_upsampled'] = seen_z[0].numpy()      # (hit rays, 128): the depths after the four up-sampling rounds
+    assert probe.per_ray()[1].min() >= margin, probe.per_ray()[1].min()
+    for i, d in enumerate(draws):
+        out['draw_{:02d}'.format(i)] = d.numpy()
     eik = ((res['normal_pts'].norm(dim=-1) - 1.0) ** 2).mean()
     loss = ((res['rgb'] - inputs['img']) ** 2).mean() + 0.1 * eik
     loss.backward()
@@ -142,12 +200,21 @@ def neus(fixture, seed):
     for k, v in inputs.items():
         out['in_' + k] = v.numpy()
     store_grads(model, out)
-    print('neus: hit rays', int((res['mask'] > 0).sum()), 'of 40, scale', out['train_scale'], 'loss', float(loss), 'eik', float(eik),
-          'mask mean', float(res['mask'].mean()))
+    g32 = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    g64, o64, l64 = float64_gradients(model, inputs, draws, lambda r, i: ((r['rgb'] - i['img']) ** 2).mean() + 0.1 * ((r['normal_pts'].norm(dim=-1) - 1.0) ** 2).mean(), cur_epoch=20000)
+    worst = store_fp32_error(out, '', g32, g64, o64, res)
+    print('neus: the reference fp32 gradient against its float64 evaluation, relative to the max: worst',
+          sorted(((round(v, 5), k) for k, v in worst.items()), reverse=True)[:4], 'loss', float(loss), l64)
+    print('neus: hit rays', int((res['mask'] > 0).sum()), 'of', keep, 'scale', out['train_scale'], 'loss', float(loss), 'eik', float(eik),
+          'mask mean', float(res['mask'].mean()), 'draws', [tuple(d.shape) for d in draws])
     save(fixture, out)
 
 
 if __name__ == '__main__':
-    nerf_like('nerf', 'g22_nerf_fullwidth', 2200)
-    neus('g23_neus_fullwidth', 2300)
-    nerf_like('hdrnerf', 'g24_hdrnerf_fullwidth', 2400, hdr=True)
+    which = sys.argv[1:] or ['g22', 'g23', 'g24']
+    if 'g22' in which:
+        nerf_like('nerf', 'g22_nerf_fullwidth', 2200)
+    if 'g23' in which:
+        neus('g23_neus_fullwidth', 2300)
+    if 'g24' in which:
+        nerf_like('hdrnerf', 'g24_hdrnerf_fullwidth', 2400, hdr=True)

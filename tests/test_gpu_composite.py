@@ -1,0 +1,196 @@
+"""BASELINE config 4 AS A COMPOSITE against runs of the reference's FullModel (golden G25, tests/golden/make_golden_composite.py):
+  ngpmv_   NeuS on the hash grid in the occupancy-pruned volume + MultiVol cascade background (capture_qqtiger_neusngp_multivol.yaml),
+  neuspp_  NeuS 8 x 256 + NeRF++ inverted-sphere background (capture_qqtiger_neus_nerfpp.yaml, the yaml's full widths),
+both `bkg_blend: rgb`, built by `build_model` of the mirror from the same yaml, reference state_dict, the reference run's taped uniforms
+(`perturb: True` as the yamls have it), samplers K2 / K3 / K11 on the HIP kernels with the pcg32 streams of the run.  Bars: sample
+positions and masks bit for bit, outputs 1e-4 (north_star), loss 1e-5, every gradient within 1e-3 of its max."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+import seeded_weights as SW
+from conftest import ROOT, load_golden
+from parity_bars import check_against_float64, grad_bar
+from rand_feed import RandFeed
+
+pytestmark = pytest.mark.gpu
+CFG = os.path.join(ROOT, 'configs')
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def close(a, b, rtol=1e-4, atol=1e-4):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def close_normals(a, b):
+    """per-SAMPLE sdf gradients (not an rgb / depth output): d/dx of a 2^9-frequency embedding (or of a hash level of resolution 64+)
+    turns an ulp of the position into ~1e-4 of phase, so single components differ by a few 1e-4 between any two fp32 evaluations;
+    a MOVED sample would differ by O(1).  Bar: every component within 1e-3, all but 0.1 % within 2e-4."""
+    np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-3)
+    assert (np.abs(a - b) > 2e-4 + 2e-4 * np.abs(b)).mean() < 1e-3
+
+
+class Sub:
+    """the entries of one composite (a key prefix) of the fixture, with the npz interface the helpers expect"""
+
+    def __init__(self, g, tag):
+        self.g, self.tag = g, tag
+        self.files = [k[len(tag):] for k in g.files if k.startswith(tag)]
+
+    def __getitem__(self, k):
+        return self.g[self.tag + k]
+
+
+def _loss(out, inputs):
+    eik = ((out['normal_pts'].norm(dim=-1) - 1.0) ** 2).mean()
+    return ((out['rgb'] - inputs['img']) ** 2).mean() + 0.1 * eik, eik
+
+
+def _check_all_grads(m, g, rtol=1e-3):
+    n_full = n_sum = 0
+    floor = rtol
+    for n, p in m.named_parameters():
+        rtol = grad_bar(g, n, floor)        # 1e-3, or 1.25 x the reference's own fp32-vs-float64 error where that is larger (parity_bars.py)
+        if p.grad is not None:
+            check_against_float64(g, n, p.grad.cpu().numpy(), rtol)
+        if ('gsum.' + n + '.max') in g.files:
+            SW.check_grad({k: g['gsum.' + n + '.' + k] for k in ('head', 'mod16', 'sum', 'abs', 'max', 'proj')}, p.grad.cpu().numpy(), rtol=rtol, name=n)
+            n_sum += 1
+        elif ('grad.' + n) in g.files:
+            ref = g['grad.' + n]
+            assert np.abs(p.grad.cpu().numpy() - ref).max() <= rtol * np.abs(ref).max() + 1e-8, n
+            n_full += 1
+        else:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+    return n_full, n_sum
+
+
+def test_neus_on_hashgrid_with_multivol_background_matches_reference_composite(gpu):
+    """config 4 as the reference names it: Neus(volume bound K2 / K3, hash encoder, normals through the encoder) + MultiVol (K11) blended
+    by `rgb += T_fg,last * rgb_bkg` (full_model.py:278-330)."""
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.models.base_modules.obj_bound import volume_bound as VB
+    from arcnerf_amd.ops import functional as Fn
+    from arcnerf_amd.ops.multivol_func import multivol_rng
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    g = Sub(load_golden('g25_composite_models'), 'ngpmv_')
+    with tempfile.NamedTemporaryFile('w', suffix='.yaml', delete=False) as f:
+        f.write(str(g['config_yaml']))
+    try:
+        m = build_model(load_configs(f.name, [])).to(gpu)
+    finally:
+        os.unlink(f.name)
+    fg, bkg = m.fg_model, m.bkg_model
+    assert type(fg).__name__ == 'Neus' and type(bkg).__name__ == 'MultiVol'
+    sd = {k[3:]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith('sd.')}
+    for name, seed in (('fg_model.geo_net.embed_fn.embeddings', 1), ('bkg_model.geo_net.embed_fn.embeddings', 2)):
+        shape = dict(m.named_parameters())[name].shape
+        sd[name] = (torch.rand(shape, generator=torch.Generator().manual_seed(seed)) - 0.5) * 0.2
+        assert abs(float(sd[name].double().sum()) - float(g['tablesum.' + name])) < 1e-6     # the very table of the reference run
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith(('.volume_pts', '.grid_pts', '.corner')) for k in missing), (missing, unexpected)
+    inputs = {k[3:]: torch.from_numpy(g[k]).to(gpu) for k in g.files if k.startswith('in_')}
+    assert not [k for k in g.files if k.startswith('draw_')]      # this composite draws no uniforms (marchers jitter with their own pcg32)
+
+    # record what the two samplers hand to the model
+    seen = {'k3': [], 'k11': []}
+    real_k3, real_k11 = VB.sparse_volume_sampling, Fn.sparse_sampling_in_multivol_bitfield
+
+    def rec_k3(*a, **k):
+        z, msk = real_k3(*a, **k)
+        seen['k3'].append((z.clone(), msk.clone()))
+        return z, msk
+
+    def rec_k11(*a, **k):
+        r = real_k11(*a, **k)
+        seen['k11'].append((r[0].clone(), r[1].clone() if r[1] is not None else None, r[2].clone() if len(r) > 2 and r[2] is not None else None))
+        return r
+    VB.sparse_volume_sampling, Fn.sparse_sampling_in_multivol_bitfield = rec_k3, rec_k11
+    sampler_rng(reset=True)
+    multivol_rng(reset=True)
+    try:
+        out = m({k: v.clone() for k, v in inputs.items()}, inference_only=True)
+        assert set(out.keys()) == {k[6:] for k in g.files if k.startswith('infer_')}
+        for k in out:
+            close(out[k].detach().cpu().numpy(), g['infer_' + k])
+        out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=20000)
+    finally:
+        VB.sparse_volume_sampling, Fn.sparse_sampling_in_multivol_bitfield = real_k3, real_k11
+        sampler_rng(reset=True)
+        multivol_rng(reset=True)
+    # sample indices bit-exact: both launches of both marchers (inference, training)
+    assert len(seen['k3']) == 2 and len(seen['k11']) == 2
+    for c in range(2):
+        z, msk = (t.cpu().numpy() for t in seen['k3'][c])
+        ref_m = np.unpackbits(g['k3_call{}_mask'.format(c)], axis=1, bitorder='little')[:, :msk.shape[1]].astype(bool)
+        assert np.array_equal(msk, ref_m)
+        w = g['k3_call{}_zvals'.format(c)].shape[1]
+        assert np.array_equal(z[:, :w].view(np.uint32), g['k3_call{}_zvals'.format(c)].view(np.uint32))
+        z, msk, cnt = seen['k11'][c]
+        z = z.cpu().numpy()
+        ref_m = np.unpackbits(g['k11_call{}_mask'.format(c)], axis=1, bitorder='little')[:, :z.shape[1]].astype(bool)
+        if msk is not None:
+            assert np.array_equal(msk.cpu().numpy(), ref_m)
+        if cnt is not None:
+            assert np.array_equal(cnt.cpu().numpy().astype(np.int64), ref_m.sum(1))
+        w = g['k11_call{}_zvals'.format(c)].shape[1]
+        valid = ref_m[:, :w]
+        assert np.array_equal(z[:, :w].view(np.uint32)[valid], g['k11_call{}_zvals'.format(c)].view(np.uint32)[valid])
+    for k in [k[6:] for k in g.files if k.startswith('train_') and k not in ('train_loss', 'train_eikonal')]:
+        if k == 'normal_pts':
+            close_normals(out[k].detach().cpu().numpy(), g['train_' + k])
+        else:
+            close(out[k].detach().cpu().numpy(), g['train_' + k])
+    loss, eik = _loss(out, inputs)
+    assert abs(float(eik) - float(g['train_eikonal'])) < 2e-5 and abs(float(loss) - float(g['train_loss'])) < 1e-5
+    m.zero_grad()
+    loss.backward()
+    n_full, _ = _check_all_grads(m, g)
+    assert n_full == 13 and 'grad.fg_model.geo_net.embed_fn.embeddings' in g.files and 'grad.bkg_model.geo_net.embed_fn.embeddings' in g.files
+
+
+def test_neus_with_nerfpp_background_matches_reference_composite(gpu):
+    """BASELINE's "NeuS(-NGP) with NeRF++ background": Neus 8 x 256 (sphere bound, four up-sampling rounds, Eikonal through the double
+    backward) + NeRFPP (inverted-sphere 4-D inputs, multi-sphere shells), FULL widths of capture_qqtiger_neus_nerfpp.yaml."""
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    g = Sub(load_golden('g25_composite_models'), 'neuspp_')
+    m = build_model(load_configs(os.path.join(CFG, 'neus_nerfpp.yaml'), [str(v) for v in g['overrides']])).to(gpu)
+    fg, bkg = m.fg_model, m.bkg_model
+    assert type(fg).__name__ == 'Neus' and type(bkg).__name__ == 'NeRFPP' and fg.geo_net.W == 256 and bkg.coarse_geo_net.W == 256
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in SW.state_dict_from_fixture(g).items()})    # strict
+    inputs = {k[3:]: torch.from_numpy(g[k]).to(gpu) for k in g.files if k.startswith('in_')}
+    assert float(g['tie_margin'].min()) >= 2e-6 and fg.get_ray_cfgs('perturb') is True and bkg.get_ray_cfgs('perturb') is True
+    out = m({k: v.clone() for k, v in inputs.items()}, inference_only=True)
+    assert set(out.keys()) == {k[6:] for k in g.files if k.startswith('infer_')}
+    for k in out:
+        close(out[k].detach().cpu().numpy(), g['infer_' + k])
+    draws = [g[k] for k in sorted(k for k in g.files if k.startswith('draw_'))]
+    assert len(draws) == 6      # coarse depths, four up-sampling rounds, the background's shell radii
+    with RandFeed(draws, gpu):
+        out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=20000)
+    for k in [k[6:] for k in g.files if k.startswith('train_') and k not in ('train_loss', 'train_eikonal')]:
+        if k == 'normal_pts':
+            close_normals(out[k].detach().cpu().numpy(), g['train_' + k])
+        else:
+            close(out[k].detach().cpu().numpy(), g['train_' + k])
+    loss, eik = _loss(out, inputs)
+    assert abs(float(eik) - float(g['train_eikonal'])) < 1e-5 and abs(float(loss) - float(g['train_loss'])) < 1e-5
+    m.zero_grad()
+    loss.backward()
+    # the reference's own fp32 gradient is further than 1e-3 from its float64 evaluation on exactly these (the Eikonal term through the
+    # 2^9-frequency embedding): 4.7e-3 / 4.4e-3
+    assert sorted(k[7:] for k in g.files if k.startswith('f64err.') and float(g[k]) > 8e-4) == \
+        ['fg_model.geo_net.layers.0.weight_v', 'fg_model.geo_net.layers.5.weight_v']
+    n_full, n_sum = _check_all_grads(m, g)
+    assert n_full >= 35 and n_sum >= 20

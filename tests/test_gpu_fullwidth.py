@@ -9,6 +9,8 @@ import pytest
 import torch
 
 import seeded_weights as SW
+from parity_bars import check_against_float64, grad_bar, out_bar
+from rand_feed import RandFeed
 from conftest import ROOT, load_golden
 
 pytestmark = pytest.mark.gpu
@@ -22,7 +24,8 @@ def gpu():
     return torch.device('cuda:0')
 
 
-def close(a, b, rtol=2e-4, atol=2e-4):
+def close(a, b, rtol=1e-4, atol=1e-4):
+    """north_star: RGB / depth within 1e-4 fp32"""
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
 
 
@@ -36,10 +39,14 @@ def _build(gpu, cfg_name, g):
     return m, inputs
 
 
-def _check_grads(m, g, rtol, loose=(), loose_rtol=1e-2):
+def _check_grads(m, g, rtol):
+    """every gradient within `rtol` of its max - or, for the tensors on which the reference's own fp32 evaluation is further than that
+    from its float64 evaluation, within 1.25 x that measured error, of the fp32 AND of the float64 reference (tests/parity_bars.py)"""
     checked = seeded = 0
     for n, p in m.named_parameters():
-        r = loose_rtol if n.endswith(tuple(loose)) and loose else rtol
+        r = grad_bar(g, n, rtol)
+        if p.grad is not None:
+            check_against_float64(g, n, p.grad.cpu().numpy(), r)
         if ('gsum.' + n + '.max') in g.files:
             SW.check_grad({k: g['gsum.' + n + '.' + k] for k in ('head', 'mod16', 'sum', 'abs', 'max', 'proj')}, p.grad.cpu().numpy(), rtol=r, name=n)
             seeded += 1
@@ -85,25 +92,31 @@ def test_neus_full_width(gpu):
     assert set(out.keys()) == {'rgb', 'depth', 'mask', 'normal'}
     for k in ('rgb', 'depth', 'mask', 'normal'):
         close(out[k].detach().cpu().numpy(), g['infer_' + k])
-    m.fg_model.set_ray_cfgs('perturb', False)
+    # the training pass runs as the yaml has it, `perturb: True`, on the reference run's own uniforms (tests/rand_feed.py): every
+    # inverse-CDF decision of the stored rays has a margin >= 2e-6 in cdf units (picked from a pool by tests/golden/tie_probe.py, the
+    # margins travel in the fixture), so no sample sits on a tie.  Outputs 1e-4, every gradient 1e-3 of its max - except the two sdf-net
+    # matrices fed by the 2^9-frequency position embedding, where the REFERENCE's fp32 gradient is 1.8e-2 / 1.3e-2 from its own float64
+    # evaluation (stored: f64err.*): those are held at 1.25 x that, against the fp32 and against the float64 reference
+    assert sorted(k[7:] for k in g.files if k.startswith('f64err.') and float(g[k]) > 8e-4) == \
+        ['fg_model.geo_net.layers.0.weight_v', 'fg_model.geo_net.layers.5.weight_v']
+    assert m.fg_model.get_ray_cfgs('perturb') is True and float(g['tie_margin'].min()) >= 2e-6
     m.fg_model.set_ray_cfgs('noise_std', 0.0)
-    out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=20000)
+    draws = [g[k] for k in sorted(k for k in g.files if k.startswith('draw_'))]
+    with RandFeed(draws, gpu):
+        out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=20000)
     for k in ('rgb', 'depth', 'mask', 'normal'):
         close(out[k].detach().cpu().numpy(), g['train_' + k])
-    bad = np.abs(out['normal_pts'].detach().cpu().numpy() - g['train_normal_pts']) > 2e-4 + 2e-4 * np.abs(g['train_normal_pts'])
-    assert bad.mean() < 1e-3, bad.mean()
+    # EVERY sample's sdf gradient (a moved sample would be off by O(1); an ulp of the position is ~1e-4 of phase at 2^9 frequencies)
+    npts, ref = out['normal_pts'].detach().cpu().numpy(), g['train_normal_pts']
+    close(npts, ref, 1e-3, 1e-3)
+    assert (np.abs(npts - ref) > 2e-4 + 2e-4 * np.abs(ref)).mean() < 1e-3
     prm = out['params'][0] if isinstance(out['params'], list) else out['params']
     assert abs(prm['scale'] - float(g['train_scale'])) < 1e-3
     eik = ((out['normal_pts'].norm(dim=-1) - 1.0) ** 2).mean()
     loss = ((out['rgb'] - inputs['img']) ** 2).mean() + 0.1 * eik
     assert abs(float(eik) - float(g['train_eikonal'])) < 1e-5 and abs(float(loss) - float(g['train_loss'])) < 1e-5
     loss.backward()
-    # one of the 40 rays has an up-sampled position on the other side of a near-tie of the inverse CDF (tools/diag_neus_fullwidth.py:
-    # every gradient agrees to <= 1.3e-4 of its max except the two matrices that multiply the 2^9-frequency position embedding, which
-    # feel that single sample).  Which side the sample lands on depends on the last bits of the sdf values, i.e. on the arithmetic
-    # variant: 0.3e-2 .. 2.4e-2 over {split, exact-f32} products x {libm, hardware exp2 / log2} softplus (all of them 1e-7 apart in sdf;
-    # the reference's own CPU and GPU runs differ by as much).  Everything else is held at 1e-3.
-    checked, seeded = _check_grads(m, g, 1e-3, loose=('geo_net.layers.0.weight_v', 'geo_net.layers.5.weight_v'), loose_rtol=3e-2)
+    checked, seeded = _check_grads(m, g, 1e-3)
     assert checked >= 20 and seeded >= 12 and 'grad.fg_model.inv_s' in g.files
 
 

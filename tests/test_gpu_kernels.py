@@ -837,6 +837,34 @@ def test_get_rays_vs_reference_golden_and_oracle(F, oracle):
         get_rays(W, H, dev(K), dev(c2w), index=dev(idx), n_rays=5)
 
 
+def test_sample_pdf_one_kernel_vs_oracle_and_reference(F, oracle):
+    """arcn_sample_pdf (weights -> cdf with torch's CPU cumsum semantics -> inverse CDF -> sort): cdf and samples bit-identical to the
+    oracle's restatement for the lattice and for per-ray uniforms; against golden G2 (the reference's own cdf / samples) the cdf agrees
+    to the normaliser's last ulp and the samples wherever no decision sits on a tie"""
+    g = load_golden('g2_resampling')
+    bins, w = g['bins'], g['weights']
+    for u in (g['u_det'][:1], g['u_det'], g['u']):
+        s, cdf = F.sample_pdf(dev(bins), dev(w), dev(np.ascontiguousarray(u)), want_cdf=True)
+        ref_cdf = oracle.weights_to_cdf(w)
+        assert np.array_equal(host(cdf).view(np.uint32), ref_cdf.view(np.uint32))
+        uu = np.broadcast_to(u, (bins.shape[0], u.shape[1]))
+        ref_s = oracle.sample_cdf(bins, ref_cdf, np.ascontiguousarray(uu))[0]
+        assert np.array_equal(host(s).view(np.uint32), ref_s.view(np.uint32))
+        close(host(cdf), g['cdf'], rtol=3e-7, atol=1.5e-7)
+    bad = np.abs(host(F.sample_pdf(dev(bins), dev(w), dev(np.ascontiguousarray(g['u_det'][:1])))) - g['samples_det']) > 1e-4
+    assert bad.mean() < 2e-3
+    # ragged sizes: 2 bins, 1 sample; many samples
+    rng = np.random.default_rng(0)
+    for n_pts, n_s in ((2, 1), (3, 7), (193, 128), (1025, 64)):
+        b = np.sort(rng.random((5, n_pts)).astype(np.float32), axis=1)
+        ww = (rng.random((5, n_pts - 1)) ** 8).astype(np.float32)
+        u = rng.random((5, n_s)).astype(np.float32)
+        s, cdf = F.sample_pdf(dev(b), dev(ww), dev(u), want_cdf=True)
+        ref_cdf = oracle.weights_to_cdf(ww)
+        assert np.array_equal(host(cdf).view(np.uint32), ref_cdf.view(np.uint32))
+        assert np.array_equal(host(s).view(np.uint32), oracle.sample_cdf(b, ref_cdf, u)[0].view(np.uint32))
+
+
 def test_fused_adam_optimizer_matches_torch_adam(F):
     """arcnerf_amd.optim.FusedAdam (torch.optim front end of arcn_adam_ema_step) against torch.optim.Adam: several steps, weight
     decay, ragged sizes, changing gradients; state_dict layout; fused gradient clear"""

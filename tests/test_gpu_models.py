@@ -549,29 +549,36 @@ def _model_from_yaml_text(text, gpu, overrides=()):
 
 def test_neus_on_hashgrid_matches_reference_fullmodel(gpu):
     """G18: NeuS whose sdf net sits on the hash encoder (the reference's torch backend, differentiated twice by autograd, against
-    the kernel graph table-node + xyz-node + arcn_hashgrid_bwd_bwd).  Reference state_dict, strict; outputs within 2e-4; the
-    gradients of rgb-MSE + 0.1 Eikonal - which reach the TABLE through the normals - within 2e-3 of their max."""
+    the kernel graph table-node + xyz-node + arcn_hashgrid_bwd_bwd).  Reference state_dict, strict.  Inference on the deterministic
+    lattice; the training pass as the yaml has it (`perturb: True`) on the reference run's taped uniforms (tests/rand_feed.py) with
+    rays picked so that no inverse-CDF decision sits on a tie (margins stored in the fixture, tests/golden/tie_probe.py): outputs
+    within 1e-4, no exceptions; the gradients of rgb-MSE + 0.1 Eikonal - which reach the TABLE through the normals - within 1e-3 of
+    their max."""
+    from rand_feed import RandFeed
     g = load_golden('g18_neus_ngp_model')
     m = _model_from_yaml_text(str(g['config_yaml']), gpu)
     assert type(m.fg_model.geo_net.embed_fn).__name__ == 'HashGridEmbedder'
     m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd.')})
     inputs = {k[3:]: torch.from_numpy(g[k]).to(gpu) for k in g.files if k.startswith('in_')}
+    assert float(g['tie_margin'].min()) >= 2e-6 and m.fg_model.get_ray_cfgs('perturb') is True
+    # ... and so that the reference's own outputs move by < 1e-5 when a ray origin moves by one ulp (a random +-0.1 hash table is a rough
+    # field: a third of all rays move by more than 2e-5 and are not in the fixture); the reference's gradients then move by <= 4e-4
+    assert float(g['ulp_sensitivity'].max()) < 1e-5 and max(float(g[k]) for k in g.files if k.startswith('ulperr.')) < 5e-4
+
     def near(a, b):
-        """within 2e-4, except for the odd ray where an up-sampled position falls on the other side of a near-tie in the
-        inverse CDF (the hash features make the sdf rougher than in G13): those stay within 2e-3 and under 2 % of the rays"""
-        off = np.abs(a - b) > 2e-4 + 2e-4 * np.abs(b)
-        assert off.mean() < 0.02, off.mean()
-        close(a, b, rtol=2e-3, atol=2e-3)
+        close(a, b, rtol=1e-4, atol=1e-4)
 
     out = m({k: v.clone() for k, v in inputs.items()}, inference_only=True)
     for k in ('rgb', 'depth', 'mask', 'normal'):
         near(out[k].detach().cpu().numpy(), g['infer_' + k])
-    m.fg_model.set_ray_cfgs('perturb', False)
-    out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=20000)
+    draws = [g[k] for k in sorted(k for k in g.files if k.startswith('draw_'))]
+    with RandFeed(draws, gpu):
+        out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=20000)
     for k in ('rgb', 'depth', 'mask', 'normal'):
         near(out[k].detach().cpu().numpy(), g['train_' + k])
-    bad = np.abs(out['normal_pts'].detach().cpu().numpy() - g['train_normal_pts']) > 5e-4 + 5e-4 * np.abs(g['train_normal_pts'])
-    assert bad.mean() < 2e-3, bad.mean()
+    npts, ref = out['normal_pts'].detach().cpu().numpy(), g['train_normal_pts']     # every sample's sdf gradient: no moved sample
+    close(npts, ref, rtol=1e-3, atol=1e-3)
+    assert (np.abs(npts - ref) > 2e-4 + 2e-4 * np.abs(ref)).mean() < 2e-3
     eik = ((out['normal_pts'].norm(dim=-1) - 1.0) ** 2).mean()
     loss = ((out['rgb'] - inputs['img']) ** 2).mean() + 0.1 * eik
     assert abs(float(eik) - float(g['train_eikonal'])) < 2e-5 and abs(float(loss) - float(g['train_loss'])) < 2e-5
@@ -582,7 +589,7 @@ def test_neus_on_hashgrid_matches_reference_fullmodel(gpu):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
         ref = g['grad.' + n]
-        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-8, n
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-8, n
         checked += 1
     assert checked == 7 and 'grad.fg_model.geo_net.embed_fn.embeddings' in g.files
 

@@ -86,8 +86,14 @@ def test_g2_resampling(oracle):
     s, inds = oracle.sample_cdf(g['bins'], g['cdf'], g['u'])
     assert (inds == g['inds_rnd']).all()
     close(s, g['samples_rnd'], rtol=1e-6, atol=1e-6)
-    # full sample_pdf (own cdf): continuous in the cdf, so only a float tolerance
-    close(oracle.weights_to_cdf(g['weights']), g['cdf'], rtol=1e-5, atol=2e-6)
+    # full sample_pdf (own cdf).  The cumsum is restated exactly (double running sum, every prefix rounded to float: torch's CPU kernel);
+    # the normaliser is not (torch.sum's vectorised float order depends on the host ISA), so the cdf agrees to the normaliser's last
+    # ulp or two - and bit for bit on the rows where the two normalisers coincide
+    own_cdf = oracle.weights_to_cdf(g['weights'])
+    close(own_cdf, g['cdf'], rtol=3e-7, atol=1.5e-7)
+    w = g['weights'] + np.float32(1e-5)
+    exact_rows = (own_cdf == g['cdf']).all(1)
+    assert exact_rows.mean() > 0.3
     # (the `denom < eps -> 1` rule of sample_cdf is discontinuous, so a last-ulp cdf difference may move a
     #  handful of samples inside a near-empty bin: bound their count instead of their value)
     own = oracle.sample_pdf(g['bins'], g['weights'], 128)

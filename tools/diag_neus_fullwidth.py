@@ -9,8 +9,14 @@ gpu = torch.device('cuda:0')
 m = build_model(load_configs('/root/repo/configs/neus.yaml', [str(v) for v in g['overrides']])).to(gpu)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in SW.state_dict_from_fixture(g).items()})
 inputs = {k[3:]: torch.from_numpy(g[k]).to(gpu) for k in g.files if k.startswith('in_')}
-m.fg_model.set_ray_cfgs('perturb', False); m.fg_model.set_ray_cfgs('noise_std', 0.0)
-out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=20000)
+m.fg_model.set_ray_cfgs('noise_std', 0.0)
+from rand_feed import RandFeed
+seen_z, real_mid = [], m.fg_model.handle_mid_pts
+m.fg_model.handle_mid_pts = lambda z, mk: (seen_z.append(z.detach().clone()), real_mid(z, mk))[1]
+with RandFeed([g[k] for k in sorted(k for k in g.files if k.startswith('draw_'))], gpu):
+    out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=20000)
+if 'train_zvals_upsampled' in g.files:
+    dz = np.abs(seen_z[0].cpu().numpy() - g['train_zvals_upsampled']); print('zvals max diff', dz.max(), 'rays > 1e-5', np.unique(np.nonzero(dz > 1e-5)[0]), 'count > 1e-6', (dz > 1e-6).sum())
 npts = out['normal_pts'].detach().cpu().numpy(); ref = g['train_normal_pts']
 bad = np.abs(npts - ref) > 2e-4 + 2e-4*np.abs(ref)
 print('normal_pts bad frac', bad.mean(), 'rows with bad', np.unique(np.nonzero(bad)[0]).size, 'max diff', np.abs(npts-ref).max())
