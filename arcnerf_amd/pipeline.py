@@ -791,6 +791,34 @@ def synthetic_rays(n_rays, seed=0, device='cuda', radius=3.0 / 1.05, hw=800, cam
     return c.float().to(device).contiguous(), d.float().to(device).contiguous()
 
 
+def morton3d(x, y, z):
+    """instant-ngp's cell order of the Morton density grids (bitfield_func / multivol_func, arcnerf/ops/include/volume_func.h:142-160):
+    bit i of x, y, z -> bits 3i, 3i+1, 3i+2.  numpy integer arrays, coordinates < 1024."""
+    def spread(v):
+        v = v.astype(np.uint32) & 0x3ff
+        v = (v | (v << 16)) & 0x30000ff
+        v = (v | (v << 8)) & 0x300f00f
+        v = (v | (v << 4)) & 0x30c30c3
+        return (v | (v << 2)) & 0x9249249
+    return spread(x) | (spread(y) << 1) | (spread(z) << 2)
+
+
+def synthetic_cascade_bits(n_grid=128, n_levels=4, frac=0.05, seed=0):
+    """Packed occupancy bits of a MultiVol cascade (level after level, Morton order inside a level, 8 cells per byte, LSB first): every
+    level gets its own union of blobs filling about `frac` of it - the converged state of a pruned background, like synthetic_bitfield
+    for the foreground volume."""
+    ax = np.arange(n_grid)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing='ij')
+    order = morton3d(X.reshape(-1), Y.reshape(-1), Z.reshape(-1)).astype(np.int64)
+    out = []
+    for lv in range(n_levels):
+        bf = synthetic_bitfield(n_grid, frac, seed=seed + 17 * lv + 1).reshape(-1)
+        cells = np.zeros(n_grid ** 3, bool)
+        cells[order] = bf
+        out.append(np.packbits(cells, bitorder='little'))
+    return np.concatenate(out)
+
+
 def synthetic_bitfield(n_grid=128, frac=0.05, seed=0):
     """Union of a few boxes / spheres filling about `frac` of the grid (numpy, flat index x*n*n+y*n+z)."""
     rng = np.random.default_rng(seed)

@@ -35,8 +35,10 @@ def parse():
     ap.add_argument('--warmup', type=int, default=16)
     ap.add_argument('--target-samples', type=int, default=1 << 18, help='valid samples per step (log_max_allowance 18)')
     ap.add_argument('--occupancy', type=float, default=0.05)
+    ap.add_argument('--bkg-occupancy', type=float, default=-1.0, help='config 4: occupied fraction of every level of the background cascade (default: the same as --occupancy; 1.0 = the unpruned start-of-training grid)')
     ap.add_argument('--no-occ-update', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the short runs of BASELINE configs 1 / 3 / 4 / 5 appended to the default line')
     ap.add_argument('--cpu-rays', type=int, default=131072)
     ap.add_argument('--config', default='ngp', choices=['ngp', 'nerf', 'neus', 'neus_ngp_multivol', 'hdrnerf'],
                     help='BASELINE.json configs: ngp = config 2 (default, the headline), nerf = 1, neus = 3, neus_ngp_multivol = 4, hdrnerf = 5')
@@ -183,7 +185,7 @@ MODULE_CONFIGS = {
 }
 
 
-def bench_module(args, name):
+def bench_module(args, name, emit=True):
     """One training step of the module path per `step`; samples = foreground net evaluations (rays x samples per ray of the final
     differentiated pass; the hierarchical up-sampling passes of NeuS are extra work inside the step, not counted)."""
     spec = MODULE_CONFIGS[name]
@@ -208,8 +210,17 @@ def bench_module(args, name):
     if args.chunk_pts:
         m.set_chunk_pts(args.chunk_pts)
     fg = m.fg_model
+    bkg_occ = None
     if name == 'neus_ngp_multivol':
+        # both occupancy structures in the same (converged) pruning state: the foreground volume AND every level of the background cascade
+        # filled to --occupancy by synthetic blobs.  Round 2 left the cascade at its all-occupied initial state (--bkg-occupancy 1.0), which
+        # put 1.9e6 background samples next to 1.2e5 foreground ones.
+        from arcnerf_amd.pipeline import synthetic_cascade_bits
         fg.obj_bound.volume.update_bitfield(torch.from_numpy(synthetic_bitfield(128, args.occupancy, seed=0)).to(dev), ops='overwrite')
+        bkg_occ = args.occupancy if args.bkg_occupancy < 0 else args.bkg_occupancy
+        if bkg_occ < 1.0:
+            bits = synthetic_cascade_bits(m.bkg_model.n_grid, m.bkg_model.n_levels, bkg_occ, seed=5)
+            m.bkg_model.density_bitfield.copy_(torch.from_numpy(bits).to(dev))
     radius = 2.2 if name == 'neus_ngp_multivol' else (3.0 if name == 'neus' else 4.0)
     pool = []
     g = torch.Generator(device='cpu').manual_seed(77 + rank)
@@ -313,7 +324,7 @@ def bench_module(args, name):
                             'peak_split = the dense bf16 MFMA peak / 6 terms = what the split form could do at full clock (the kernels sit on the '
                             '1400 W package limit at 1.93-1.97 GHz, DESIGN.md 5b)'}
     cpu = None
-    if world == 1 and not args.no_cpu_baseline and name == 'nerf':
+    if world == 1 and not args.no_cpu_baseline and name == 'nerf' and emit:
         cpu = cpu_baseline_nerf()
     out = {'metric': 'ray-samples/sec (train)', 'value': total / wall, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
            'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -321,12 +332,14 @@ def bench_module(args, name):
            'config': {'workload': '{} ({}), {} rays/step/GPU, {} net evaluations/step/GPU, module path build_model({}) + FusedAdam'.format(
                name, spec['desc'], n_rays, evals_per_step, spec['yaml']), 'rays_per_step_per_gpu': n_rays,
                'samples_per_step_per_gpu': evals_per_step, 'n_params': flat_numel, 'parallelism': 'ray-sharded dp{}'.format(world),
-               'chunk_pts': int(m.get_chunk_pts())},
+               'chunk_pts': int(m.get_chunk_pts()), 'occupancy': args.occupancy, 'bkg_occupancy': bkg_occ},
            'rccl': dist_report(dist, world, LAUNCH, flat_grads.numel() * 4, 1, per_rank, rccl_extra),
            'roofline': roofline, 'cpu_baseline': cpu}
-    print(json.dumps(out))
+    if emit:
+        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    return out
 
 
 def cpu_baseline_nerf(rays_all=4096):
@@ -528,13 +541,22 @@ def main():
     hash_kernels = {'hashgrid_fwd': BYTES_HASH_FWD, 'hashgrid_bwd': BYTES_HASH_BWD}
     dom = max(hash_kernels, key=lambda k: ksum.get(k, 0.0))
     # hashgrid_fwd is also launched by the occupancy refresh (different size): use the per-step average of its launches
-    traffic = None
+    traffic, traffic_stale = None, None
     pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(dom)
+            import hashlib
+            rec = json.load(open(pmc))
+            traffic = rec.get(dom)
+            # the counters were collected on a particular version of the kernels: say so when the sources have moved since
+            shas = rec.get('_source_sha256')
+            if shas is None:
+                traffic_stale = True
+            else:
+                csrc = os.path.join(ROOT, 'arcnerf_amd', 'csrc')
+                traffic_stale = any(hashlib.sha256(open(os.path.join(csrc, f), 'rb').read()).hexdigest() != h for f, h in shas.items())
         except Exception:
-            traffic = None
+            traffic, traffic_stale = None, None
     dur_s = ksum[dom] * 1e-3
     ach = hash_kernels[dom] * s_per_launch / dur_s
     if dom == 'hashgrid_fwd':
@@ -547,7 +569,7 @@ def main():
                 'frac': ach / HBM_PEAK, 'traffic': traffic, 'avg_launch_ms': ksum[dom],
                 # PMC counters cannot be collected inside a timed run: the figure is the per-launch HBM bytes of the committed
                 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/profile_round.sh)
-                'traffic_source': 'profiles/pmc_traffic.json' if traffic is not None else None}
+                'traffic_source': 'profiles/pmc_traffic.json' if traffic is not None else None, 'traffic_stale': traffic_stale}
 
     # The hash LOOKUP on its own (north_star names it): besides the algorithmic HBM accounting, the bound this gather actually
     # sits on.  Every 8-byte corner read of a hashed level drags one 128-byte line from the XCD's L2 into the CU's L1
@@ -581,6 +603,27 @@ def main():
         except Exception as e:   # never lose the headline line to the side leg
             cpu['scripts_cpu_sh'] = {'error': repr(e)}
 
+    # BASELINE configs 1 / 3 / 4 / 5 through the module path, AFTER the headline measurement (which they cannot disturb): a few steps each,
+    # so that the driver's record carries them too (the reference times every model: tests_benchmark.py:22-185).  `bench.py --config X`
+    # is the full line of one of them.
+    others = None
+    if world == 1 and not args.no_other_configs:
+        import copy
+        others = {}
+        timers.reset(())           # no event brackets around the module-path configs' launches
+        for name in ('nerf', 'neus', 'neus_ngp_multivol', 'hdrnerf'):
+            a2 = copy.copy(args)
+            a2.steps, a2.warmup, a2.rays, a2.chunk_pts, a2.no_cpu_baseline = 8, 3, 0, 0, True
+            try:
+                r = bench_module(a2, name, emit=False)
+                others[name] = {'ms_per_step': r['ms_per_step'], 'samples_per_s': r['value'], 'steps': 8, 'warmup': 3,
+                                'rays_per_step': r['config']['rays_per_step_per_gpu'], 'samples_per_step': r['config']['samples_per_step_per_gpu'],
+                                'roofline_frac': (r['roofline'] or {}).get('frac'), 'roofline_bound': (r['roofline'] or {}).get('bound'),
+                                'workload': r['config']['workload']}
+            except Exception as e:      # never lose the headline line to a side leg
+                others[name] = {'error': repr(e)}
+            torch.cuda.empty_cache()
+
     out = {
         'metric': 'ray-samples/sec (train), NGP Lego 800x800', 'value': total_samples / wall, 'unit': 'samples/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
@@ -599,6 +642,7 @@ def main():
         'roofline_lookup': lookup,
         'cpu_baseline': cpu,
         'kernel_ms': ktable,
+        'other_configs': others,
     }
     print(json.dumps(out))
     if dist is not None:

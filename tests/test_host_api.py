@@ -241,3 +241,14 @@ def test_refresh_cell_subset_is_a_bijection_and_spatially_uniform():
             c = np.bincount(axis, minlength=n_grid)
             e, s_ = n / 4 / n_grid, np.sqrt(n / 4 / n_grid)
             assert np.abs(c - e).max() < 5 * s_, (seed, c)
+
+
+def test_morton_order_of_the_synthetic_cascade_matches_the_oracle(oracle):
+    """pipeline.morton3d (used to lay synthetic occupancy into a MultiVol cascade for bench.py) is the Morton code of the oracle / kernels"""
+    import numpy as np
+    from arcnerf_amd.pipeline import morton3d, synthetic_cascade_bits
+    rng = np.random.default_rng(0)
+    xyz = rng.integers(0, 128, size=(4096, 3)).astype(np.uint32)
+    assert np.array_equal(morton3d(xyz[:, 0], xyz[:, 1], xyz[:, 2]).astype(np.int64), oracle.morton3d(xyz).astype(np.int64))
+    bits = synthetic_cascade_bits(16, 2, 0.1, seed=0)
+    assert bits.shape == (2 * 16 ** 3 // 8,) and 0.08 < np.unpackbits(bits).mean() < 0.3

@@ -3,7 +3,7 @@ ROOT=$(pwd)
 cd arcnerf_amd/lib; cp libarcnerf_hip.so keep.so
 for v in old new; do
   cp alt_$v.so libarcnerf_hip.so
-  (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/abp_$v && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/abp_$v -o p --output-format csv -- python $ROOT/bench.py --steps 48 --warmup 8 --no-cpu-baseline > /dev/null 2>&1)
+  (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/abp_$v && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/abp_$v -o p --output-format csv -- python $ROOT/bench.py --steps 48 --warmup 8 --no-cpu-baseline --no-other-configs > /dev/null 2>&1)
   echo "== $v"; python - <<PY
 import csv,glob
 f=glob.glob('/tmp/abp_$v/**/*kernel_stats.csv', recursive=True)[0]

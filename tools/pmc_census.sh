@@ -3,8 +3,8 @@
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/cen_1 /tmp/cen_2
-timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d /tmp/cen_1 -o c --output-format csv -- python $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline > /dev/null 2>&1
-timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS -d /tmp/cen_2 -o c --output-format csv -- python $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d /tmp/cen_1 -o c --output-format csv -- python $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS -d /tmp/cen_2 -o c --output-format csv -- python $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
 python - <<'PY'
 import csv, glob
 from collections import defaultdict

@@ -3,7 +3,7 @@
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/lds_1
-timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE -d /tmp/lds_1 -o c --output-format csv -- python $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline > /tmp/lds_1.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE -d /tmp/lds_1 -o c --output-format csv -- python $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-other-configs > /tmp/lds_1.log 2>&1
 tail -3 /tmp/lds_1.log | cut -c1-300
 python - <<'PY'
 import csv, glob

@@ -5,7 +5,7 @@ usage: python tools/pmc_traffic.py gpurun_out/<tag>   (expects pmc_FETCH_SIZE/ a
 Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both counters are in KiB; on gfx950 FETCH_SIZE
 tallies 128-byte read requests at 64 bytes, so streaming reads are doubled (calibrated on adam_ema_kernel, whose traffic is
 known exactly: 4 floats read + 4 written per parameter with the EMA shadow in the parameter buffer, 5 + 5 with a separate one)."""
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
 
 ENTRY = {  # C entry point -> device kernels it launches (substring match on the demangled name)
@@ -58,6 +58,9 @@ def main(root):
                          'hbm_bytes_per_launch': 2.0 * fr + wb}
         out[entry] = 2.0 * fr + wb
     out['_detail'] = detail
+    # which kernels were measured: bench.py compares these with the sources it runs on and reports `traffic_stale` on a mismatch
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'arcnerf_amd', 'csrc')
+    out['_source_sha256'] = {f: hashlib.sha256(open(os.path.join(csrc, f), 'rb').read()).hexdigest() for f in ('hashgrid.hip', 'mlp.hip', 'optim.hip', 'common.hpp')}
     out['_note'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 8 --warmup 4), median over the '
                     'training launches, KiB*1024, summed over the kernels of an entry point (mlp_* = the two nets of a step are '
                     'different launches of one kernel: value is their median). FETCH_SIZE doubled per MI355X_MICROARCH.md '

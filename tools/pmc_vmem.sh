@@ -3,8 +3,8 @@
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/vm_1 /tmp/vm_2
-timeout 400 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum SQ_WAVES GRBM_GUI_ACTIVE -d /tmp/vm_1 -o c --output-format csv -- python $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline > /tmp/vm_1.log 2>&1
-timeout 400 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum TA_BUSY_avr GRBM_GUI_ACTIVE -d /tmp/vm_2 -o c --output-format csv -- python $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline > /tmp/vm_2.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum SQ_WAVES GRBM_GUI_ACTIVE -d /tmp/vm_1 -o c --output-format csv -- python $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-other-configs > /tmp/vm_1.log 2>&1
+timeout 400 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum TA_BUSY_avr GRBM_GUI_ACTIVE -d /tmp/vm_2 -o c --output-format csv -- python $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-other-configs > /tmp/vm_2.log 2>&1
 tail -2 /tmp/vm_1.log | cut -c1-200; tail -2 /tmp/vm_2.log | cut -c1-200
 python - <<'PY'
 import csv, glob

@@ -9,10 +9,10 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG --output-format csv -- \
-    python $ROOT/bench.py --steps 32 --warmup 8 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
+    python $ROOT/bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-other-configs > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 for C in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --pmc $C -d $OUT/pmc_$C -o $TAG --output-format csv -- \
-        python $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.log
+        python $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-other-configs > /dev/null 2> $OUT/pmc_$C.log
 done
 cd $ROOT
 python tools/pmc_traffic.py $OUT > $OUT/pmc_traffic.json
