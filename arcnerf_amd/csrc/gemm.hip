@@ -902,7 +902,7 @@ static int gemm_rows_split(bool trans_w, const float *in, const float *mask, con
                        reinterpret_cast<gu4 *>(ws));
     const int oa = is_aligned(out, ld_out);
     const unsigned gx = (unsigned)ceil_div<int64_t>(S, 128);
-    static const int big = [] { const char *e = getenv("ARCN_SPLIT_BN256"); return e ? atoi(e) : 1; }();
+    static const int big = 1;
 #define ARCN_RS(MT_, NBLK_, OFF_)                                                                                                          \
     do {                                                                                                                                   \
         dim3 grid(gx, (unsigned)(NBLK_));                                                                                                  \
@@ -1011,7 +1011,7 @@ ARCN_EXPORT int arcn_gemm_tn_split(const float *dy, const float *mask, const uin
         // one full round of workgroups: 256 CUs x 3 (unmasked: 168 registers) or x 2 (masked) resident workgroups; the generic choice
         // (1024 / tiles) is 1.33 rounds of the unmasked kernel - a third of the chip idle for the second round - and twice the partials
         const int tiles = ceil_div<int>(N, 128) * ceil_div<int>(K, 128);
-        static const int slots_u = [] { const char *e = getenv("ARCN_TN_SLOTS"); return e ? atoi(e) : 768; }();
+        static const int slots_u = 768;
         const int slots = (mk != 0 || db) ? 512 : slots_u;
         slabs = tn_slabs(n_rows, N, K, 128, 128);
         if (slabs > slots / tiles) slabs = slots / tiles > 0 ? slots / tiles : 1;

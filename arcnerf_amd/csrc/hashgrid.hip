@@ -469,7 +469,9 @@ hashgrid_fwd_bal_kernel(const float *__restrict__ xyz, const float *__restrict__
             }
             float vals[8][F];
             const float *lt = table + lp.offset * F;
-            if (PAIR && F == 2 && lp.mask) {
+            // (a level whose first row is not 16-byte aligned - an odd row offset after dense levels of odd size, or a table segment at
+            // an odd 8-byte offset of a flat parameter buffer - takes the 8-byte loads: the dwordx4 below must not straddle)
+            if (PAIR && F == 2 && lp.mask && (reinterpret_cast<uintptr_t>(lt) & 15) == 0) {
                 // the two x-neighbours of a (y, z) corner pair: rows r and r' = ((cx+1) ^ A) & mask.  cx even -> r' = r ^ 1: both in
                 // one aligned 16-byte word (one dwordx4); cx odd -> a second 8-byte load under the lane mask
                 const bool even = (c[0] & 1u) == 0u;
@@ -1341,8 +1343,8 @@ static float fwd_level_cost(const LevelParams &lp) {
     // one-XCD time of the level minus the launch overhead, pair loads on (tools/exp_gather.py --levels with ARCN_GATHER_ONE_XCD=1)
     static const float res_pts[] = {64.f, 80.f, 111.f, 153.f, 212.f, 294.f, 406.f, 561.f, 776.f, 1072.f, 1482.f, 2047.f, 8192.f};
     static const float mem_pts[] = {0.0f, 1.0f, 2.9f, 6.4f, 10.5f, 16.9f, 24.4f, 32.6f, 38.0f, 40.9f, 42.6f, 42.5f, 43.0f};
-    static const float floor_cost = [] { const char *e = getenv("ARCN_GATHER_FLOOR"); return e ? (float)atof(e) : 10.0f; }();
-    static const float mod_cost = [] { const char *e = getenv("ARCN_GATHER_MODCOST"); return e ? (float)atof(e) : 3.0f; }();
+    static const float floor_cost = 10.0f;
+    static const float mod_cost = 3.0f;
     const float r = (float)lp.res;
     float mem = 0.f;
     const int np = (int)(sizeof(res_pts) / sizeof(res_pts[0]));
@@ -1379,7 +1381,7 @@ static int build_fwd_plan(const GridParams &g, int64_t n, FwdPlan &plan, int &wg
         for (int k = i + 1; k < g.L; ++k)
             if (cost[order[k]] > cost[order[i]]) { int t = order[i]; order[i] = order[k]; order[k] = t; }
     const int64_t tiles = ceil_div<int64_t>(n, 256);
-    static const int max_wg = [] { const char *e = getenv("ARCN_GATHER_WGS"); return e ? atoi(e) : 1024; }();
+    static const int max_wg = 1024;
     int64_t want = ceil_div<int64_t>(tiles * g.L, 8);    // one tile per workgroup when there is little work
     wg_per_xcd = (int)(want < max_wg ? want : max_wg);
     if (wg_per_xcd < 1) wg_per_xcd = 1;
@@ -1412,12 +1414,12 @@ static int build_fwd_plan(const GridParams &g, int64_t n, FwdPlan &plan, int &wg
             int x = 0;   // the least loaded queue that can still take a segment
             float best = 1e30f;
             for (int q = 0; q < (one_xcd ? 1 : 8); ++q) {
-                static const float odd_bias = [] { const char *e = getenv("ARCN_GATHER_ODD_SCALE"); return e ? (float)atof(e) : 1.0f; }();
+                static const float odd_bias = 1.0f;
                 const float eff = load[q] / ((q & 1) ? odd_bias : 2.0f - odd_bias);
                 if (plan.n_seg[q] < kFwdSegs && eff < best) { best = eff; x = q; }
             }
             if (best > 1e29f) return einval("hashgrid_fwd_xcd: plan overflow");
-            static const float odd_scale = [] { const char *e = getenv("ARCN_GATHER_ODD_SCALE"); return e ? (float)atof(e) : 1.0f; }();
+            static const float odd_scale = 1.0f;
             const float room = share * ((x & 1) ? odd_scale : 2.0f - odd_scale) - load[x];
             const float take = (room <= 1e-4f * total || left <= room) ? left : room;
             const float f1 = (take >= left) ? 1.f : f0 + (1.f - f0) * (take / left);
@@ -1481,7 +1483,7 @@ ARCN_EXPORT int arcn_hashgrid_fwd_xcd(const float *xyz, const float *table, cons
     }
     int per = 0;
     for (int x = 0; x < 8; ++x) per = fill[x] > per ? fill[x] : per;
-    static const int xcd_tiles = [] { const char *e = getenv("ARCN_HASH_FWD_TILES"); return e ? atoi(e) : 512; }();
+    static const int xcd_tiles = 512;
     int64_t tiles = ceil_div<int64_t>(n, 256);
     if (tiles > xcd_tiles) tiles = xcd_tiles;
     plan.tiles = (int)tiles;

@@ -54,47 +54,10 @@ __device__ __forceinline__ float act_grad_from_y(float y, int act, float beta) {
 // Stage W (rows x cols, row-major, leading dimension ld) — or its transpose — into LDS in MFMA A-fragment order:
 //   element A[r][c] -> lds[((mt*T + t)*64 + g*16 + i)*4 + ks],  r = 16mt+i, c = 16t+4g+ks, zero padded to 16 multiples.
 // TRANSPOSED: A = W^T, i.e. A[r][c] = W[c][r] with W (cols x rows).
-// ARCN_MLP_SPLIT_BF16 (experiment, off): every f32 operand as hi + lo bf16 halves and the product as three bf16 MFMAs
-// (hi*hi + hi*lo + lo*hi; v_mfma_f32_16x16x16_bf16 takes exactly the 16 reduction elements 16t + 4g + ks that four 16x16x4 f32 MFMAs
-// take, with the same lane <-> element map, so fragments, permutation and accumulators are unchanged).  The weight fragments are split
-// when they are staged: the 16-byte slot of lane (g, i) holds [hi(ks 0..3) | lo(ks 0..3)].
-// ARCN_MLP_SPLIT_BF16 == 3: THREE planes (hi + mid + lo, exact) and the six partial products down to 2^-16 - f32 accuracy, as in
-// gemm.hip; the slot of lane (g, i) grows to 24 bytes [hi | mid | lo] (kFragLane floats per lane).
-#ifndef ARCN_MLP_SPLIT_BF16
-#define ARCN_MLP_SPLIT_BF16 0
-#endif
-constexpr int kFragLane = ARCN_MLP_SPLIT_BF16 == 3 ? 6 : 4;   // floats per lane of a weight fragment
+// (Round 2 tried the products of these kernels as split-bf16 MFMAs - two planes: 5.6 % faster but the table gradient misses its 1e-3 bar;
+// three planes: exact and SLOWER than f32 MFMA here - and the code was removed in round 3; DESIGN.md section 5 keeps the numbers.)
+constexpr int kFragLane = 4;                                   // floats per lane of a weight fragment
 constexpr int kFragTile = 64 * kFragLane;                      // floats per 16 x 16 fragment
-typedef short bf4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-// v = hi + lo (+ 2^-17 relative): hi = bf16(v) round to nearest even, lo = bf16(v - hi)
-__device__ __forceinline__ void split_bf16(const f4 &v, bf4 &hi, bf4 &lo) {
-    const uint32_t h01 = cvt_pk_bf16(v.x, v.y), h23 = cvt_pk_bf16(v.z, v.w);
-    const float r0 = v.x - __uint_as_float(h01 << 16), r1 = v.y - __uint_as_float(h01 & 0xffff0000u);
-    const float r2 = v.z - __uint_as_float(h23 << 16), r3 = v.w - __uint_as_float(h23 & 0xffff0000u);
-    const uint32_t l01 = cvt_pk_bf16(r0, r1), l23 = cvt_pk_bf16(r2, r3);
-    hi = __builtin_bit_cast(bf4, make_uint2(h01, h23));
-    lo = __builtin_bit_cast(bf4, make_uint2(l01, l23));
-}
-
-// v = hi + mid + lo exactly (three bf16, 24 significand bits)
-__device__ __forceinline__ void split_bf16_3(const f4 &v, bf4 &hi, bf4 &mid, bf4 &lo) {
-    const uint32_t h01 = cvt_pk_bf16(v.x, v.y), h23 = cvt_pk_bf16(v.z, v.w);
-    const float r0 = v.x - __uint_as_float(h01 << 16), r1 = v.y - __uint_as_float(h01 & 0xffff0000u);
-    const float r2 = v.z - __uint_as_float(h23 << 16), r3 = v.w - __uint_as_float(h23 & 0xffff0000u);
-    const uint32_t m01 = cvt_pk_bf16(r0, r1), m23 = cvt_pk_bf16(r2, r3);
-    const float s0 = r0 - __uint_as_float(m01 << 16), s1 = r1 - __uint_as_float(m01 & 0xffff0000u);
-    const float s2 = r2 - __uint_as_float(m23 << 16), s3 = r3 - __uint_as_float(m23 & 0xffff0000u);
-    hi = __builtin_bit_cast(bf4, make_uint2(h01, h23));
-    mid = __builtin_bit_cast(bf4, make_uint2(m01, m23));
-    lo = __builtin_bit_cast(bf4, make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3)));
-}
 
 template <bool TRANSPOSED>
 __device__ __forceinline__ void stage_fragments(float *lds, const float *__restrict__ W, int rows, int cols) {
@@ -120,24 +83,7 @@ __device__ __forceinline__ void stage_fragments(float *lds, const float *__restr
 #pragma unroll
         for (int u = 0; u < kBatch; ++u)
             if (dst[u] >= 0) {
-#if ARCN_MLP_SPLIT_BF16 == 3
-                const uint32_t h = cvt_pk_bf16(v[u], 0.f) & 0xffffu;
-                const float r = v[u] - __uint_as_float(h << 16);
-                const uint32_t md = cvt_pk_bf16(r, 0.f) & 0xffffu;
-                const uint32_t lw = cvt_pk_bf16(r - __uint_as_float(md << 16), 0.f) & 0xffffu;
-                unsigned short *slot = reinterpret_cast<unsigned short *>(lds) + (dst[u] >> 2) * 12 + (dst[u] & 3);
-                slot[0] = (unsigned short)h;
-                slot[4] = (unsigned short)md;
-                slot[8] = (unsigned short)lw;
-#elif ARCN_MLP_SPLIT_BF16
-                const uint32_t h = cvt_pk_bf16(v[u], 0.f) & 0xffffu;
-                const uint32_t lw = cvt_pk_bf16(v[u] - __uint_as_float(h << 16), 0.f) & 0xffffu;
-                unsigned short *slot = reinterpret_cast<unsigned short *>(lds) + (dst[u] >> 2) * 8 + (dst[u] & 3);
-                slot[0] = (unsigned short)h;
-                slot[4] = (unsigned short)lw;
-#else
                 lds[dst[u]] = v[u];
-#endif
             }
     }
 }
@@ -204,56 +150,6 @@ __device__ __forceinline__ void store_tiles(const f4 (&v)[WT][NT], float *__rest
 template <int WT, int NT>
 __device__ __forceinline__ void gemm_tiles(f4 (&out)[WT][NT], const f4 (&in)[WT][NT], const float *lds_frag, int MT, int T,
                                            int lane) {
-#if ARCN_MLP_SPLIT_BF16 == 3
-    bf4 bh[WT][NT], bm[WT][NT], bl[WT][NT];
-#pragma unroll
-    for (int t = 0; t < WT; ++t)
-        if (t < T) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) split_bf16_3(in[t][nt], bh[t][nt], bm[t][nt], bl[t][nt]);
-        }
-#pragma unroll
-    for (int mt = 0; mt < WT; ++mt) {
-        if (mt < MT) {
-#pragma unroll
-            for (int t = 0; t < WT; ++t) {
-                if (t < T) {
-                    const uint2 *ap = reinterpret_cast<const uint2 *>(lds_frag + ((mt * T + t) * 64 + lane) * kFragLane);
-                    const bf4 ah = __builtin_bit_cast(bf4, ap[0]), am = __builtin_bit_cast(bf4, ap[1]), al = __builtin_bit_cast(bf4, ap[2]);
-#define ARCN_T(A_, B_) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) out[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A_, B_[t][nt], out[mt][nt], 0, 0, 0);
-                    ARCN_T(ah, bl) ARCN_T(al, bh) ARCN_T(am, bm) ARCN_T(ah, bm) ARCN_T(am, bh) ARCN_T(ah, bh)
-#undef ARCN_T
-                }
-            }
-        }
-    }
-#elif ARCN_MLP_SPLIT_BF16
-    bf4 bh[WT][NT], bl[WT][NT];
-#pragma unroll
-    for (int t = 0; t < WT; ++t)
-        if (t < T) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) split_bf16(in[t][nt], bh[t][nt], bl[t][nt]);
-        }
-#pragma unroll
-    for (int mt = 0; mt < WT; ++mt) {
-        if (mt < MT) {
-#pragma unroll
-            for (int t = 0; t < WT; ++t) {
-                if (t < T) {
-                    const uint4 a = *reinterpret_cast<const uint4 *>(lds_frag + ((mt * T + t) * 64 + lane) * 4);
-                    const bf4 ah = __builtin_bit_cast(bf4, make_uint2(a.x, a.y)), al = __builtin_bit_cast(bf4, make_uint2(a.z, a.w));
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) out[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh[t][nt], out[mt][nt], 0, 0, 0);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) out[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl[t][nt], out[mt][nt], 0, 0, 0);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) out[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh[t][nt], out[mt][nt], 0, 0, 0);
-                }
-            }
-        }
-    }
-#else
 #pragma unroll
     for (int mt = 0; mt < WT; ++mt) {
         if (mt < MT) {
@@ -273,7 +169,6 @@ __device__ __forceinline__ void gemm_tiles(f4 (&out)[WT][NT], const f4 (&in)[WT]
             }
         }
     }
-#endif
 }
 
 // ---- forward ------------------------------------------------------------------------------------------
@@ -1105,20 +1000,10 @@ static int set_lds(Kern k, size_t bytes) {
     return ARCN_OK;
 }
 
-inline unsigned tile_grid(int64_t n, int spb, bool forward = false) {
-    int64_t b = ceil_div<int64_t>(n, spb);
-    static int64_t cap = 0, cap_fwd = 0;  // resident workgroups re-use the staged weights across tiles
-    if (!cap) {
-        const char *e = getenv("ARCN_MLP_GRID");
-        cap = e ? atoll(e) : 512;
-        if (cap < 1) cap = 1024;
-        // the specialised forward kernels need 164 VGPRs: three waves per SIMD fit, i.e. three workgroups per CU
-        const char *f = getenv("ARCN_MLP_GRID_FWD");
-        cap_fwd = f ? atoll(f) : cap;
-        if (cap_fwd < 1) cap_fwd = cap;
-    }
-    const int64_t c = forward ? cap_fwd : cap;
-    return (unsigned)(b > c ? c : (b < 1 ? 1 : b));
+inline unsigned tile_grid(int64_t n, int spb, bool /*forward*/ = false) {
+    // resident workgroups re-use the staged weights across tiles: 512 = two per CU (measured best for forward and backward kernels alike)
+    const int64_t b = ceil_div<int64_t>(n, spb), cap = 512;
+    return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
 }  // namespace arcn
@@ -1169,7 +1054,7 @@ static int mlp_fwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
     if (P.has_bias && !biases) return einval("mlp_fwd: biases required");
     const size_t lds_bytes = sizeof(float) * (size_t)lds_floats;
     if (lds_bytes > 144 * 1024) return einval("mlp_fwd: network too large for the LDS-resident fused kernel");
-    static const int fwd_nt = getenv("ARCN_MLP_NT") ? atoi(getenv("ARCN_MLP_NT")) : 2;  // 4 waves/SIMD beat 2 with wider tiles
+    static const int fwd_nt = 2;  // 4 waves/SIMD beat 2 with wider tiles
     static const int fixed_ok = getenv("ARCN_MLP_FIXED_FWD") ? atoi(getenv("ARCN_MLP_FIXED_FWD")) : 1;
     MlpCat cat = {};
     if (cat_in) cat = *cat_in;
@@ -1265,7 +1150,7 @@ static int mlp_bwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
     if (P.n_layers > 1 && !acts) return einval("mlp_bwd: saved activations required");
     const size_t lds_bytes = sizeof(float) * (size_t)lds_floats;
     if (lds_bytes > 144 * 1024) return einval("mlp_bwd: network too large for the LDS-resident fused kernel");
-    static const int bwd_nt = getenv("ARCN_MLP_BWD_NT") ? atoi(getenv("ARCN_MLP_BWD_NT")) : 2;
+    static const int bwd_nt = 2;
     static const int fused_ok = getenv("ARCN_MLP_FUSED_BWD") ? atoi(getenv("ARCN_MLP_FUSED_BWD")) : 1;
     MlpCat cat = {};
     if (cat_in) cat = *cat_in;
@@ -1298,7 +1183,7 @@ static int mlp_bwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
                            as_stream(stream), x, x_stride, cat, weights, P, out, acts, dout, dx, partials, (int)grid, n_cap, n,   \
                            n_ptr);                                                                                               \
     } while (0)
-            static const int fused_nt3 = getenv("ARCN_MLP_FUSED_NT3") ? atoi(getenv("ARCN_MLP_FUSED_NT3")) : 1;
+            static const int fused_nt3 = 1;
             if (cat_in) {
                 if (sig == 2441) ARCN_FUSED(2, 4, 4, 1, 1, 2); else ARCN_FUSED(2, 4, 1, 0, 2, 2);
             } else if (x_stride) {

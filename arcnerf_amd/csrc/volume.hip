@@ -785,7 +785,13 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
                 const int first_incl = incl_m ? __builtin_ctzll(incl_m) : 64;          // closest predecessor with an inclusive prefix
                 const uint64_t needed = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1ull);   // lanes 0 .. first_incl
                 if (none_m & needed) {   // somebody in the needed range has not published yet: it holds a lower ticket, it is running
-                    if (++spins > (1u << 24)) break;
+                    if (++spins > (1u << 24)) {
+                        // a predecessor never published (it cannot happen while tickets are handed out in launch order; a bound on
+                        // the poll keeps a broken device from hanging the queue): raise the sticky error word - the block that
+                        // writes the total reports offsets[n_rays] = -1, an empty batch for every consumer - and stop waiting
+                        if (lane == 0) __hip_atomic_store(pk.lookback + 1 + (n_rays + 3) / 4, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(2);
                     continue;
                 }
@@ -797,14 +803,16 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
                 base -= 64;
             }
             if (lane == 0) {
+                // (release: the error word a predecessor may have raised is visible to whoever reads this prefix)
                 if (blk != 0)
-                    __hip_atomic_store(status + blk, (2ull << 62) | (unsigned long long)(uint32_t)(excl + agg), __ATOMIC_RELAXED,
+                    __hip_atomic_store(status + blk, (2ull << 62) | (unsigned long long)(uint32_t)(excl + agg), __ATOMIC_RELEASE,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 s_base = (int32_t)excl;
                 const int64_t n_blk = (n_rays + 3) / 4;
                 if ((int64_t)blk == n_blk - 1) {
                     const long long tot = excl + agg;
-                    pk.offsets[n_rays] = (int32_t)(tot < pk.capacity ? tot : pk.capacity);
+                    const unsigned long long err = __hip_atomic_load(pk.lookback + 1 + n_blk, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    pk.offsets[n_rays] = err ? -1 : (int32_t)(tot < pk.capacity ? tot : pk.capacity);
                 }
             }
         }

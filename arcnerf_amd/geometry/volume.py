@@ -52,12 +52,7 @@ def select_refresh_cells(bitfield_flat, n_cells, cache, rng):
         cache['arange'] = torch.arange(n_cells, device=dev)
     buf, ar = cache['cell_buf'], cache['arange']
     if n_cells & (n_cells - 1) == 0:
-        if os.environ.get('ARCN_REFRESH_AFFINE', '0') == '1':   # round-1 selection (an arithmetic progression), for A/B only
-            a = int(rng.integers(0, n_cells // 2)) * 2 + 1
-            c = int(rng.integers(0, n_cells))
-            buf[:n_s] = (ar[:n_s] * a + c) & (n_cells - 1)
-        else:
-            buf[:n_s] = mix_permutation(ar[:n_s], n_cells, rng)
+        buf[:n_s] = mix_permutation(ar[:n_s], n_cells, rng)
     else:
         buf[:n_s] = torch.randperm(n_cells, device=dev)[:n_s]
     csum = torch.cumsum(bitfield_flat.to(torch.int32), 0)

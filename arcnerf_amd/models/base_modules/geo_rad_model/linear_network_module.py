@@ -16,7 +16,6 @@ from ..linear import DenseLayer, Linear, SirenLayer
 from .encoder_mlp_network import EncoderMLPGeoNet, EncoderMLPRadainceNet
 
 
-_KEEP_PAD = os.environ.get('ARCN_GEO_SPLIT_NODE', '1') != '0'   # A/B: the final product's padded tensor split once (handle_output)
 
 
 @MODULE_REGISTRY.register()
@@ -114,7 +113,7 @@ class GeoNet(EncoderMLPGeoNet):
             x_embed = pad_cols4(x_embed)
         out = x_embed
         for i in range(self.D + 1):
-            if i == self.D and self.W_feat > 0 and type(self.layers[i]) is Linear and not hasattr(self.layers[i], 'weight_g') and _KEEP_PAD:
+            if i == self.D and self.W_feat > 0 and type(self.layers[i]) is Linear and not hasattr(self.layers[i], 'weight_g'):
                 from ....ops.autograd import linear
                 out = linear(out, self.layers[i].weight, self.layers[i].bias, keep_pad=True)    # handle_output splits the padded tensor
             else:

@@ -474,8 +474,8 @@ class SdfMlpJacFn(torch.autograd.Function):
 class LinearReluFn(torch.autograd.Function):
     """y = relu(x @ w.T + bias) in ONE kernel (bias + activation in the product's epilogue); backward with the activation's mask
     folded into the operand loads of the two gradient products (dpre = dy * (y > 0) is never written): per layer and direction one
-    launch instead of the library's GEMM + elementwise passes.  First order only (the ReLU stacks of NeRF / HDR-NeRF / the radiance
-    nets; a second differentiation raises instead of being silently wrong - softplus sdf nets take the generic `linear`)."""
+    launch instead of the library's GEMM + elementwise passes.  Under create_graph (a second differentiation through the input gradient
+    of a ReLU stack: Eikonal / normal losses) the backward is rebuilt from the products that are closed under differentiation."""
 
     @staticmethod
     def forward(ctx, x, w, bias):
@@ -486,18 +486,31 @@ class LinearReluFn(torch.autograd.Function):
         if any(ctx.needs_input_grad) and F.relu_bits_supported(x, k_in, n_out) and F._use_split(x, n_out, k_in) and n_out > 64:
             y, bits = F.gemm_nt(x, w, bias, act='relu', want_bits=True)
             ctx.use_bits = True
-            ctx.save_for_backward(x, w, bits)
+            ctx.save_for_backward(x, w, bits, bias if bias is not None else x.new_empty(0))
         else:
             y = F.gemm_nt(x, w, bias, act='relu')
             ctx.use_bits = False
-            ctx.save_for_backward(x, w, y)
+            ctx.save_for_backward(x, w, y, x.new_empty(0))
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, g):
-        x, w, m = ctx.saved_tensors
+        x, w, m, bias = ctx.saved_tensors
         g = g.contiguous()
+        if torch.is_grad_enabled():
+            # create_graph: somebody differentiates THROUGH this backward (an Eikonal / normal loss on a ReLU sdf net, a radiance mode
+            # with 'n' on a ReLU geometry net: base_network.py:30-44).  The masked kernels are first order only, so the gradient is built
+            # from the three products that are closed under differentiation; the mask itself is piecewise constant.
+            with torch.no_grad():     # only the bits were kept: the mask is recomputed from the layer's own forward
+                y = F.gemm_nt(x, w, bias if ctx.has_bias else None, act='relu') if ctx.use_bits else m
+                mask = (y > 0).to(g.dtype)
+            gm = g * mask
+            dx = GemmNN.apply(gm, w) if ctx.needs_input_grad[0] else None
+            dw = GemmTN.apply(gm, x) if ctx.needs_input_grad[1] else None
+            db = gm.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            return dx, dw, db
+        if g.data_ptr() % 16 != 0:
+            g = g.clone()      # a view at an odd offset: the masked forms of the products want 16-byte aligned rows (a fresh buffer is)
         kw = {'mask_bits': m} if ctx.use_bits else {'mask': m}
         dx = F.gemm_nn(g, w, **kw) if ctx.needs_input_grad[0] else None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]

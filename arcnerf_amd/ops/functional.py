@@ -594,7 +594,7 @@ def mlp_fwd(x, weights, biases, desc, save_acts=False, n_dev=None, out=None, act
 # ARCN_GEMM_SPLIT=0: the exact-f32 MFMA kernels everywhere; 1 (default): layers with more than 64 outputs run on the bf16 matrix rate
 # with every operand split into three bf16 planes (six products, f32 accuracy; csrc/gemm.hip)
 _GEMM_SPLIT = os.environ.get('ARCN_GEMM_SPLIT', '1') != '0'
-_GEMM_SPLIT_MIN_OUT = int(os.environ.get('ARCN_GEMM_SPLIT_MIN_OUT', '65'))
+_GEMM_SPLIT_MIN_OUT = 65
 
 
 def _use_split(rows, k_red, n_out):

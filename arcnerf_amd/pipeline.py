@@ -249,9 +249,9 @@ class NgpPipeline:
         self._occ_state_event = None    # last refresh finished: readers of .bitfield / .opafield wait for it
         self.prefetch_at = int(os.environ.get('ARCN_PREFETCH_AT', '1' if self.prefetch_depth == 1 else '3'))
         # multi-rank: the compute units idle while the gradient all-reduce is on the wire - march the next batch there
-        self.prefetch_at_dist = int(os.environ.get('ARCN_PREFETCH_AT_DIST', '3'))
+        self.prefetch_at_dist = 3
         self._prefetch_now = self.prefetch_at
-        self.aux_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get('ARCN_AUX_PRIORITY', '0'))) if dev.type == 'cuda' else None
+        self.aux_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
         self.use_streams = self.aux_stream is not None
         b['feat'] = torch.zeros((S, E), dtype=f32, device=dev)
         b['geo_out'] = torch.zeros((S, field.geo_out_dim), dtype=f32, device=dev)

@@ -161,7 +161,9 @@ int arcn_march_count(const float *rays_o, const float *rays_d, const float *aabb
 /* The three passes above in ONE launch (no dense scratch): a wave keeps its ray's samples in LDS, the workgroups' counts go through a
  * chained scan (decoupled look-back, ray blocks handed out by ticket), the waves copy their samples to their final offsets.
  * Same outputs as the three-pass form, bit for bit (offsets clamped to `capacity`, p_dense = largest per-ray count).
- * workspace: arcn_march_packed_workspace_bytes(n_rays) bytes of device memory (zeroed by the call). */
+ * workspace: arcn_march_packed_workspace_bytes(n_rays) bytes of device memory (zeroed by the call).  Should the look-back ever give up
+ * on a predecessor (2^24 polls), offsets[n_rays] is set to -1: every consumer of the device-side count sees an empty batch instead of
+ * offsets built from an incomplete prefix. */
 int64_t arcn_march_packed_workspace_bytes(int64_t n_rays);
 int arcn_march_packed(const float *rays_o, const float *rays_d, const float *aabb, int n_grid, const uint8_t *bitfield,
                       int bitfield_is_packed, int n_pts, float dt, float near_distance, int aabb_torch_semantics, uint64_t rng_state,

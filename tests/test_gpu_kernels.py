@@ -1227,6 +1227,45 @@ def test_linear_layers_double_backward_vs_torch():
         assert (a - b_).abs().max() <= 2e-4 * b_.abs().max() + 1e-7
 
 
+def test_relu_layers_double_backward_vs_torch():
+    """the fused DenseLayer (LinearReluFn: bias + ReLU in the epilogue, bit masks in the backward) under create_graph: an sdf / geometry
+    net with ReLU hidden layers whose input gradient (the normal) enters the loss - the reference's layers are plain torch ops,
+    differentiable to any order (base_network.py:30-44); wide layers (bit-mask path) and narrow ones (float-mask path)"""
+    from arcnerf_amd.ops.autograd import linear, linear_relu
+    g = torch.Generator().manual_seed(9)
+    S = 2048
+    x0 = torch.randn(S, 40, generator=g).cuda()
+    Ws = [(torch.randn(o, i, generator=g) / i ** 0.5).cuda().requires_grad_(True) for o, i in ((256, 40), (64, 256), (9, 64))]
+    bs = [(torch.randn(o, generator=g) * 0.1).cuda().requires_grad_(True) for o in (256, 64, 9)]
+
+    def net(x, hip):
+        lr = linear_relu if hip else (lambda a, w, b: torch.relu(torch.nn.functional.linear(a, w, b)))
+        ln = linear if hip else torch.nn.functional.linear
+        return ln(lr(lr(x, Ws[0], bs[0]), Ws[1], bs[1]), Ws[2], bs[2])
+
+    res = {}
+    for name in ('hip', 'torch'):
+        x = x0.clone().requires_grad_(True)
+        out = net(x, name == 'hip')
+        sdf = out[:, :1]
+        nrm = torch.autograd.grad(sdf, x, torch.ones_like(sdf), create_graph=True)[0]
+        loss = (out[:, 1:] ** 2).mean() + 0.1 * ((nrm[:, :3].norm(dim=-1) - 1.0) ** 2).mean()
+        for p in Ws + bs:
+            p.grad = None
+        loss.backward()
+        res[name] = [out.detach(), nrm.detach(), x.grad.clone()] + [p.grad.clone() for p in Ws + bs]
+    for a, b_ in zip(res['hip'], res['torch']):
+        assert (a - b_).abs().max() <= 2e-4 * b_.abs().max() + 1e-7
+    # a gradient that arrives as a view at an odd offset (not 16-byte aligned) must not trip the bit-mask products
+    x = x0.clone().requires_grad_(True)
+    y = linear_relu(x, Ws[0], bs[0])
+    up = torch.randn(S * 256 + 1, generator=g).cuda()[1:].view(S, 256)
+    assert up.data_ptr() % 16 != 0
+    gx, = torch.autograd.grad(y, x, up)
+    ref, = torch.autograd.grad(torch.relu(torch.nn.functional.linear(x, Ws[0], bs[0])), x, up)
+    assert (gx - ref).abs().max() <= 2e-4 * ref.abs().max()
+
+
 @pytest.mark.parametrize('S,K,Nn,bias', [(3000, 63, 256, True), (2049, 319, 256, True), (1500, 283, 128, True), (1000, 32, 64, False), (777, 256, 257, True)])
 def test_fused_linear_relu_layer_vs_torch(S, K, Nn, bias):
     """LinearReluFn (bias + ReLU in the epilogue of arcn_gemm_nt, the ReLU mask folded into arcn_gemm_nn / arcn_gemm_tn, bias gradient on

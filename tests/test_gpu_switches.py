@@ -1,0 +1,78 @@
+"""Every ARCN_* environment switch (README.md) at its NON-default value: the code behind it must still give the default path's results.
+The switches are read once per process, so each group runs tests/switch_smoke.py in a subprocess; groups combine switches that act on
+different kernels.  (ARCN_GRAD_SEGMENTS / ARCN_DIST_BACKEND are exercised by tests/test_gpu_distributed.py; ARCN_GATHER_ONE_XCD /
+ARCN_GATHER_ONLY_XCD / ARCN_SCATTER_LEVELS restrict the hash kernels to a subset of the chip / levels for the counter passes of
+tools/pmc_gather.sh and tools/scatter_levels.sh - they change the result by design and are only run, not compared.)"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+GROUPS = {
+    'ngp': [
+        {'ARCN_PREFETCH_DEPTH': '1', 'ARCN_OCC_ASYNC': '0', 'ARCN_FUSED_COMPOSITE': '0', 'ARCN_EMA_ALIAS': '0', 'ARCN_GATHER_VARIANT': '0',
+         'ARCN_SCATTER_CAS': '0', 'ARCN_MLP_FIXED_FWD': '0', 'ARCN_MLP_FUSED_BWD': '0'},
+        {'ARCN_MARCH_FUSED': '1', 'ARCN_DEFER_DW': '1', 'ARCN_PREFETCH_AT': '1', 'ARCN_SCATTER_LOCK': '0'},
+        {'ARCN_DEFER_DW': '2', 'ARCN_PREFETCH_AT': '2', 'ARCN_SCATTER_LOCK': '0xffffffff', 'ARCN_MAIN_PRIORITY': '0'},
+    ],
+    'nets': [
+        {'ARCN_GEMM_SPLIT': '0', 'ARCN_LINEAR_FUSED_RELU': '0', 'ARCN_LINEAR_SOFTPLUS': '0', 'ARCN_TONEMAP_FUSED': '0', 'ARCN_NEUS_UPSAMPLE_GRAPH': '1'},
+        {'ARCN_RELU_BITS': '0', 'ARCN_SOFTPLUS_FUSED': '0'},
+        {'ARCN_LINEAR_GEMM': '0'},
+    ],
+    'neusngp': [
+        {'ARCN_SDF_JACOBIAN': '0', 'ARCN_LINEAR_FUSED': '0', 'ARCN_PACKED_OVERFLOW_CHECK': '0'},
+    ],
+}
+_default = {}
+
+
+def _run(which, env_extra, tmp):
+    env = {k: v for k, v in os.environ.items() if not k.startswith('ARCN_')}
+    env.update(env_extra)
+    path = os.path.join(tmp, which + '_' + '_'.join(sorted(env_extra)) + '.npz')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'switch_smoke.py'), which, path], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (env_extra, r.stderr[-3000:])
+    return dict(np.load(path))
+
+
+@pytest.mark.parametrize('which,idx', [(w, i) for w, gs in GROUPS.items() for i in range(len(gs))])
+def test_switches_at_non_default_values_give_the_default_results(which, idx):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    with tempfile.TemporaryDirectory() as tmp:
+        if which not in _default:
+            _default[which] = _run(which, {}, tmp)
+        ref, got = _default[which], _run(which, GROUPS[which][idx], tmp)
+    assert set(ref) == set(got)
+    for k in ref:
+        a, b = got[k], ref[k]
+        if k == 'ngp_params':
+            # Adam (eps 1e-15) turns the summation-order noise of a near-zero gradient entry into a full-size step of either sign: all but a
+            # handful of the 4.5e5 parameters within 2 % of the distance travelled, none further than two steps; the renders below are exact
+            far = np.abs(a - b) > 2e-2 * float(ref['ngp_moved'])
+            assert far.mean() < 1e-3 and np.abs(a - b).max() <= 2.0 * float(ref['ngp_moved']), (k, far.mean(), np.abs(a - b).max())
+        elif k == 'ngp_moved':
+            assert float(a) > 1e-3
+        elif k.endswith('_grad'):
+            assert np.abs(a - b).max() <= 2e-3 * np.abs(b).max() + 1e-9, (k, np.abs(a - b).max() / np.abs(b).max())
+        else:
+            np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-3, err_msg=k)
+
+
+def test_profiling_aids_run():
+    """the level / XCD restrictions used by the counter passes: the kernels run (results are partial by design)"""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    with tempfile.TemporaryDirectory() as tmp:
+        for env in ({'ARCN_SCATTER_LEVELS': '0x00f0'}, {'ARCN_GATHER_ONE_XCD': '1'}, {'ARCN_GATHER_ONLY_XCD': '3'}):
+            out = _run('ngp', env, tmp)
+            assert np.isfinite(out['ngp_params']).all()
