@@ -138,18 +138,32 @@ class NeRF(FgModel):
             if it does not fit, the buffers are rebuilt 1.25x larger than needed and the SAME launch of the sampler's pcg32 stream is
             repeated - nothing is ever truncated;
           training: a host read per step would serialise the host with the device (measured: 1.04 -> 3.75 ms/step with
-            torch.optim.Adam), so the total travels to pinned memory asynchronously and is checked at the NEXT call - an overflowed
-            step is reported with a warning and the buffers grow before the following step (the reference-sized first steps of a
-            training run are the only place this happens: the dynamic batch size keeps later steps near 2^18 samples)."""
+            torch.optim.Adam), so the total travels to pinned memory asynchronously and is read at the NEXT call, where it (a) sizes
+            the buffers for the coming step - 1.5x the last step's samples per ray must fit, else they grow before marching - and (b)
+            reports a step that overflowed all the same (samples per ray more than 1.5x the previous step's) with a warning.  The
+            FIRST training step has no history and takes the exact path (one host read): with the all-ones bitfield of a fresh model
+            it needs R * n_sample samples, four times the default capacity at 4096 rays, and nothing is dropped."""
         self._check_deferred_overflow(rays_o.device)
         pipe = self._packed_pipeline(rays_o.device)
         R = rays_o.shape[0]
+        check = R * pipe.cfg.n_sample > pipe.cap and os.environ.get('ARCN_PACKED_OVERFLOW_CHECK', '1') != '0'
+        if check and not exact:
+            # training: no sample may be dropped either (the reference's dense tensors hold them all, fg_model.py:252-262).  The last
+            # step's samples-per-ray (read back a step late, no stall) bounds this one: grow BEFORE marching when 1.5x that rate does not
+            # fit; without a history (the first step of a run, all-ones bitfield: R * n_sample samples) take the exact path once.
+            rate = getattr(self, '_samples_per_ray', None)
+            if rate is None:
+                exact = True
+            elif rate * R * 1.5 > pipe.cap:
+                pipe = self._packed_pipeline(rays_o.device, min_samples=min(R * pipe.cfg.n_sample, (int(rate * R * 1.5) + 1023) // 1024 * 1024))
+                check = R * pipe.cfg.n_sample > pipe.cap
         state = pipe.rng.state
         pipe.sample(rays_o, rays_d)
-        if R * pipe.cfg.n_sample > pipe.cap and os.environ.get('ARCN_PACKED_OVERFLOW_CHECK', '1') != '0':
+        if check:
             total = pipe.buf['counts'][:R].sum(dtype=torch.int64)
             if exact:
                 need = int(total)
+                self._samples_per_ray = need / max(1, R)
                 if need > pipe.cap:
                     pipe = self._packed_pipeline(rays_o.device, min_samples=(need * 5 // 4 + 1023) // 1024 * 1024)
                     pipe.rng.set_state(state)
@@ -172,6 +186,7 @@ class NeRF(FgModel):
         ev, cap, R = pend
         ev.synchronize()    # recorded a whole step ago: no wait in practice
         need = int(self._ovf_host[0])
+        self._samples_per_ray = need / max(1, R)
         if need > cap:
             import warnings
             warnings.warn('packed NGP path: the previous training step asked for {} samples for {} rays but the buffers hold {}; the '
@@ -179,6 +194,12 @@ class NeRF(FgModel):
                           '{} samples now (set model.chunk_rays lower, or render with inference_only=True for the exact '
                           'path).'.format(need, R, cap, (need * 5 // 4 + 1023) // 1024 * 1024))
             self._packed_pipeline(device, min_samples=(need * 5 // 4 + 1023) // 1024 * 1024)
+
+    def train(self, mode=True):
+        """leaving training mode (evaluation, the end of a run) also reports an overflow of the LAST training step"""
+        if not mode and getattr(self, '_pending_ovf', None) is not None:
+            self._check_deferred_overflow(next(self.parameters()).device)
+        return super().train(mode)
 
     def _forward_packed(self, inputs, inference_only):
         rays_o, rays_d, bkg = inputs['rays_o'].contiguous().float(), inputs['rays_d'].contiguous().float(), inputs['bkg_color']

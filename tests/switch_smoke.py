@@ -38,6 +38,7 @@ def ngp(out):
     out['ngp_moved'] = np.array(float((fld.params - p0).abs().max()))
     rgb, depth, mask = pipe.forward(batches[4][0], batches[4][1], batches[4][3], train=False)
     out['ngp_rgb'], out['ngp_depth'] = rgb.cpu().numpy(), depth.cpu().numpy()
+    out['ngp_loss'] = np.array(float((rgb - batches[4][2]).abs().mean()))
 
 
 def _module(name, overrides, n_rays, radius, seed, extra=None):

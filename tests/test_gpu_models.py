@@ -248,24 +248,36 @@ def test_packed_path_grows_instead_of_dropping_samples(gpu):
     out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False)
     ((out['rgb_coarse'] - inputs['img']) ** 2).mean().backward()
     assert float(fg.coarse_geo_net.embed_fn.embeddings.grad.abs().max()) > 0
-    # TRAINING on a fresh model: no host read per step - the overflow of step 1 is reported (warning) and repaired at step 2, whose
-    # outputs then equal the dense path's on every ray
+    # TRAINING on a fresh model (the first steps of a run: all-ones bitfield, R * n_sample samples): NO sample is dropped in any step -
+    # the first step has no history and takes the exact path (one host read), the following ones size the buffers from the last step's
+    # samples per ray (read back a step late, no stall) - and every step equals the dense path (fg_model.py:252-262), gradients included
     import warnings
     m2 = _ngp_model(gpu, ['--model.rays.noise_std', '0.0'])
     fg2 = m2.fg_model
     fg2.obj_bound.volume.update_bitfield(torch.ones(32, 32, 32, dtype=torch.bool, device=gpu), ops='overwrite')
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter('always')
-        m2({k: v.clone() for k, v in inputs.items()}, inference_only=False)
-        assert fg2._pipe.cap == (1 << 20) and not [w for w in caught if 'packed NGP path' in str(w.message)]
-        sampler_rng(reset=True)
-        o2 = m2({k: v.clone() for k, v in inputs.items()}, inference_only=False)
-        assert [w for w in caught if 'packed NGP path' in str(w.message)] and fg2._pipe.cap > (1 << 20)
-    fg2.use_packed_path = False
-    sampler_rng(reset=True)
-    o2d = m2({k: v.clone() for k, v in inputs.items()}, inference_only=False)
-    for k in o2:
-        close(o2[k].detach().cpu().numpy(), o2d[k].detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+        steps = {}
+        for packed in (True, False):
+            fg2.use_packed_path = packed
+            sampler_rng(reset=True)
+            for step in range(2):
+                m2.zero_grad()
+                n = 12000 if step == 0 else 6000           # the ray count changes between steps (dynamic batch size)
+                sub = {k: v[:, :n].contiguous() for k, v in inputs.items()}
+                o2 = m2({k: v.clone() for k, v in sub.items()}, inference_only=False)
+                ((o2['rgb_coarse'] - sub['img']) ** 2).mean().backward()
+                steps[(packed, step)] = ({k: v.detach().cpu().numpy() for k, v in o2.items()},
+                                         fg2.coarse_geo_net.embed_fn.embeddings.grad.detach().cpu().numpy().copy())
+                if packed and step == 0:
+                    assert fg2._pipe.cap > (1 << 20) and int(fg2._pipe.n_dev.item()) > (1 << 20)    # grown within the step itself
+        m2.eval()     # flushes the deferred check of the last training step
+        assert not [w for w in caught if 'packed NGP path' in str(w.message)]
+    for step in range(2):
+        for k in steps[(True, step)][0]:
+            close(steps[(True, step)][0][k], steps[(False, step)][0][k], rtol=1e-5, atol=1e-5)
+        ref = steps[(False, step)][1]
+        assert np.abs(steps[(True, step)][1] - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-9
 
 
 def test_ngp_model_trains_with_torch_adam_and_prunes(gpu):

