@@ -569,6 +569,8 @@ struct BinPlan {
     int32_t n_bins;
     int32_t chunk_floats;                     // LDS accumulator floats per workgroup (rows per chunk * F)
     int32_t use_cas;                          // consumer, F = 2: 64-bit compare-and-swap on the row instead of the bit lock
+    int32_t det;                              // ARCN_DETERMINISTIC=1: order-independent fixed-point accumulation (see scatter_accum_kernel)
+    int32_t aux_first;                        // counters[aux_first] = bits of max |dout| (det), counters[aux_first + 1] = a bin overflowed
     int64_t n_recs;
 };
 
@@ -583,10 +585,11 @@ __device__ __forceinline__ void overflow_add(float *__restrict__ dtable, const L
 // place one record at position pos of its bin; beyond the bin's capacity it is applied to dtable directly
 template <int F>
 __device__ __forceinline__ void emit_record(uint4 *__restrict__ lrecs, float *__restrict__ dtable, const LevelParams &lp, int bin,
-                                            uint32_t pos, uint32_t cap, int shift, const uint4 &rec) {
+                                            uint32_t pos, uint32_t cap, int shift, const uint4 &rec, uint32_t *ovf_flag = nullptr) {
     if (pos < cap) {
         lrecs[(int64_t)bin * cap + pos] = rec;
     } else {
+        if (ovf_flag) *ovf_flag = 1u;   // deterministic mode: these float atomics are not order-independent - say so (arcn_hashgrid_bwd_status)
         const uint32_t base_row = (uint32_t)bin << shift;
         const uint32_t i0 = rec.x & 0xffffu, i1 = rec.x >> 16;
         const float wx = __uint_as_float(rec.y), a0 = __uint_as_float(rec.z), a1 = __uint_as_float(rec.w);
@@ -682,6 +685,14 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
     const float p[3] = {np_[0], np_[1], np_[2]};
     const Cell cell = locate_fastcell(p, g, lp, s < cnt);
     const float g0 = cell.valid ? ng0 : 0.f, g1 = cell.valid ? ng1 : 0.f;
+    if (plan.det) {
+        // the fixed-point scale of the consumer comes from the largest |gradient| of the launch: a max is order-independent
+        float m = fmaxf(fabsf(g0), fabsf(g1));
+        if (!(m == m)) m = 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if (lane == 0 && m > 0.f) atomicMax(&counters[plan.aux_first], __float_as_uint(m));
+    }
     // runs of consecutive samples (lanes) in the same cell: head lanes, and for every lane the last lane of its run
     const uint32_t kxy = cell.valid ? (cell.c[0] | (cell.c[1] << 16)) : 0xffffffffu;
     const uint32_t kz = cell.valid ? cell.c[2] : (uint32_t)lane;
@@ -832,7 +843,7 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
     for (int k = 0; k < 8; ++k) {
         if (k >= n_slots || sbin[k] < 0) continue;
         const uint4 rec = make_uint4(sidx[k], __float_as_uint(swx[k]), __float_as_uint(sa[k]), __float_as_uint(sb[k]));
-        emit_record<F>(lrecs, dtable, lp, sbin[k], gbase[sbin[k]] + rank[k], cap, shift, rec);
+        emit_record<F>(lrecs, dtable, lp, sbin[k], gbase[sbin[k]] + rank[k], cap, shift, rec, plan.det ? &counters[plan.aux_first + 1] : nullptr);
     }
     // no barrier here: the next tile counts into the other histogram and reserves into the other gbase; this tile's gbase is
     // overwritten two tiles later, behind two more barriers
@@ -892,6 +903,12 @@ scatter_bin_dir_kernel(const float *__restrict__ xyz, const float *__restrict__ 
                     sa[q] = g0 * D;
                     sb[q] = g1 * D;
                 }
+                if (plan.det) {   // deterministic mode: the consumer's fixed-point scale comes from the largest contribution (order-independent)
+                    float m = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) m = fmaxf(m, fmaxf(fabsf(sa[q]), fabsf(sb[q])));
+                    if (m == m && m > 0.f) atomicMax(&counters[plan.aux_first], __float_as_uint(m));
+                }
             }
         }
 #pragma unroll
@@ -909,7 +926,7 @@ scatter_bin_dir_kernel(const float *__restrict__ xyz, const float *__restrict__ 
         for (int q = 0; q < 8; ++q) {
             if (sbin[q] < 0) continue;
             const uint4 rec = make_uint4(sidx[q], 0u, __float_as_uint(sa[q]), __float_as_uint(sb[q]));
-            emit_record<F>(lrecs, dtable, lp, sbin[q], gbase[sbin[q]] + rank[q], cap, shift, rec);
+            emit_record<F>(lrecs, dtable, lp, sbin[q], gbase[sbin[q]] + rank[q], cap, shift, rec, plan.det ? &counters[plan.aux_first + 1] : nullptr);
         }
     }
 }
@@ -936,6 +953,47 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
     const uint32_t row_lo = (uint32_t)chunk << plan.chunk_shift[l];
     const uint32_t row_hi_raw = row_lo + (1u << plan.chunk_shift[l]);
     const int n_rows = (int)((row_hi_raw < lp.size ? row_hi_raw : lp.size) - row_lo);
+    if (plan.det) {
+        // DETERMINISTIC mode (ARCN_DETERMINISTIC=1).  Float sums depend on the order in which the records of a row arrive - the order
+        // of the bins' reservation atomics and of the compare-and-swap winners, different in every run (identical runs of the full
+        // training differed by +-1.3 dB PSNR at 10k iterations).  Here every contribution is converted to 64-bit FIXED
+        // POINT (scaled by a power of two taken from the launch's largest |gradient|: max * 2^k < 2^38, so 2^24 terms cannot
+        // overflow) and accumulated with 64-bit integer LDS atomics: integer addition is associative, the sums are the same bits
+        // whatever the order, and the conversion of a float times a power of two is exact down to max * 2^-37.  One owner per chunk
+        // (no split merges), 16 bytes of LDS per row.
+        unsigned long long *iacc = reinterpret_cast<unsigned long long *>(acc);
+        for (int i = threadIdx.x; i < n_rows * F; i += kTiledThreads) iacc[i] = 0ull;
+        __syncthreads();
+        const uint32_t mbits = counters[plan.aux_first];
+        int e2 = (int)((mbits >> 23) & 0xffu) - 127;
+        if (e2 < -126) e2 = -126;
+        int k2 = 37 - e2;
+        if (k2 > 127) k2 = 127;
+        if (k2 < -126) k2 = -126;
+        const float scale = __uint_as_float((uint32_t)(k2 + 127) << 23);
+        const uint4 *prd = recs + plan.rec_first[l] + (int64_t)chunk * cap + lo;
+        for (uint32_t i = threadIdx.x; i < hi - lo; i += kTiledThreads) {
+            const uint4 r = prd[i];
+            const uint32_t i0 = r.x & 0xffffu, i1 = r.x >> 16;
+            if (i0 == 0xffffu) continue;
+            const float wx = __uint_as_float(r.y), a0 = __uint_as_float(r.z), a1 = __uint_as_float(r.w);
+            const float wl = 1.0f - wx;
+            atomicAdd(iacc + i0 * F, (unsigned long long)__float2ll_rn((a0 * wl) * scale));
+            if (F > 1) atomicAdd(iacc + i0 * F + (F > 1 ? 1 : 0), (unsigned long long)__float2ll_rn((a1 * wl) * scale));
+            if (i1 != 0xffffu) {
+                atomicAdd(iacc + i1 * F, (unsigned long long)__float2ll_rn((a0 * wx) * scale));
+                if (F > 1) atomicAdd(iacc + i1 * F + (F > 1 ? 1 : 0), (unsigned long long)__float2ll_rn((a1 * wx) * scale));
+            }
+        }
+        __syncthreads();
+        const double inv = (double)__uint_as_float((uint32_t)(127 - k2) << 23);
+        float *dstd = dtable + ((int64_t)lp.offset + row_lo) * F;
+        for (int j = threadIdx.x; j < n_rows * F; j += kTiledThreads) {
+            const long long v = (long long)iacc[j];
+            if (v != 0) dstd[j] += (float)((double)v * inv);
+        }
+        return;
+    }
     uint32_t *locks = reinterpret_cast<uint32_t *>(acc + plan.chunk_floats);
     {
         float4 *acc4 = reinterpret_cast<float4 *>(acc);
@@ -1118,6 +1176,7 @@ static int build_bin_plan(const GridParams &g, int64_t n, BinPlan &plan) {
         return (v >= 1024 && v <= kChunkFloats && !(v & (v - 1))) ? v : 16384;
     }();
     plan.chunk_floats = chunk_floats;
+    { static const int det = [] { const char *e = getenv("ARCN_DETERMINISTIC"); return e ? atoi(e) : 0; }(); plan.det = det ? 1 : 0; }
     { static const int cas = [] { const char *e = getenv("ARCN_SCATTER_CAS"); return e ? atoi(e) : 1; }(); plan.use_cas = cas; }
     const int rows_cap = chunk_floats / g.F;
     int bins = 0;
@@ -1145,10 +1204,14 @@ static int build_bin_plan(const GridParams &g, int64_t n, BinPlan &plan) {
         const bool locked = (plan.lock_levels >> l) & 1u;
         const int64_t mean = (paired ? 4 : 8) * n / nc;
         int64_t cap = nc == 1 ? 8 * n : 2 * mean + 1024;
+        // deterministic mode must not take the overflow path (global float atomics): the dense (un-hashed) levels, whose bins are
+        // regions of space and fill unevenly, get room for two records per sample in EVERY bin (their runs are merged first: ~n / 8
+        // records per level in the bench workload); the hashed levels spread evenly, 2x the mean is hundreds of sigmas away
+        if (plan.det && nc > 1 && g.lv[l].mask == 0 && cap < 2 * n + 1024) cap = 2 * n + 1024;
         if (cap > 8 * n) cap = 8 * n;
         if (cap > 0x7fffffffll) return einval("hashgrid_bwd: too many samples for the binned scatter");
         // one exclusive owner per chunk (plain-store flush); splits only where float atomics make the items long
-        int ns = locked ? 1 : (int)(64 / nc);
+        int ns = (locked || plan.det) ? 1 : (int)(64 / nc);
         if (ns < 1) ns = 1;
         while (ns > 1 && cap / ns < 8192) ns >>= 1;
         plan.n_chunks[l] = (int)nc;
@@ -1161,6 +1224,7 @@ static int build_bin_plan(const GridParams &g, int64_t n, BinPlan &plan) {
         recs += nc * cap;
     }
     plan.n_bins = bins;
+    plan.aux_first = bins;      // two words behind the bin counters (zeroed with them)
     plan.n_recs = recs;
     // dispatch: levels with the longest items (largest bins per workgroup) first, ties finest first
     int order[ARCN_MAX_LEVELS];
@@ -1185,7 +1249,7 @@ static int build_bin_plan(const GridParams &g, int64_t n, BinPlan &plan) {
     return ARCN_OK;
 }
 
-static inline int64_t bin_counter_floats(const BinPlan &plan) { return ((int64_t)plan.n_bins + 63) / 64 * 64; }
+static inline int64_t bin_counter_floats(const BinPlan &plan) { return ((int64_t)plan.n_bins + 2 + 63) / 64 * 64; }
 
 }  // namespace arcn
 
@@ -1226,9 +1290,10 @@ static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *
         if (rc) return rc;
         uint32_t *counters = reinterpret_cast<uint32_t *>(workspace);
         uint4 *recs = reinterpret_cast<uint4 *>(workspace + bin_counter_floats(plan));
-        hipError_t e = hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)plan.n_bins, as_stream(stream));
+        hipError_t e = hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)(plan.n_bins + 2), as_stream(stream));
         if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
-        const size_t lds = sizeof(float) * (size_t)plan.chunk_floats + sizeof(uint32_t) * (size_t)(plan.chunk_floats / 32);
+        const size_t lds = plan.det ? sizeof(unsigned long long) * (size_t)plan.chunk_floats
+                                    : sizeof(float) * (size_t)plan.chunk_floats + sizeof(uint32_t) * (size_t)(plan.chunk_floats / 32);
         e = g.F == 1
             ? hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_accum_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
             : hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_accum_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1288,9 +1353,10 @@ ARCN_EXPORT int arcn_hashgrid_bwd_bwd(const float *xyz, const float *gdx, const 
         if (rc) return rc;
         uint32_t *counters = reinterpret_cast<uint32_t *>(workspace);
         uint4 *recs = reinterpret_cast<uint4 *>(workspace + bin_counter_floats(plan));
-        hipError_t e = hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)plan.n_bins, as_stream(stream));
+        hipError_t e = hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)(plan.n_bins + 2), as_stream(stream));
         if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
-        const size_t lds = sizeof(float) * (size_t)plan.chunk_floats + sizeof(uint32_t) * (size_t)(plan.chunk_floats / 32);
+        const size_t lds = plan.det ? sizeof(unsigned long long) * (size_t)plan.chunk_floats
+                                    : sizeof(float) * (size_t)plan.chunk_floats + sizeof(uint32_t) * (size_t)(plan.chunk_floats / 32);
         e = g.F == 1
             ? hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_accum_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
             : hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_accum_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1324,6 +1390,20 @@ ARCN_EXPORT int arcn_hashgrid_bwd_lm(const float *xyz, const float *dout_lm, int
     if (dout_stride < n) return einval("hashgrid_bwd_lm: level stride smaller than n");
     if (!workspace) return einval("hashgrid_bwd_lm: workspace required");
     return hashgrid_bwd_impl(xyz, nullptr, dout_lm, dout_stride, desc_host, dtable, nullptr, workspace, workspace_floats, n, n_ptr, stream);
+}
+
+ARCN_EXPORT int64_t arcn_hashgrid_bwd_status_offset(const arcn_hashgrid_desc *desc_host, int64_t n) {
+    if (!desc_host || n <= 0) return -1;
+    GridParams g;
+    if (build_params(desc_host, g)) return -1;
+    BinPlan plan;
+    if (build_bin_plan(g, n, plan)) return -1;
+    return plan.aux_first;
+}
+
+ARCN_EXPORT int arcn_deterministic(void) {
+    static const int det = [] { const char *e = getenv("ARCN_DETERMINISTIC"); return e ? atoi(e) : 0; }();
+    return det ? 1 : 0;
 }
 
 ARCN_EXPORT int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc *desc_host, int64_t n) {

@@ -399,6 +399,19 @@ def hashgrid_bwd_workspace(desc, n, device):
     return torch.empty(max(1, floats), dtype=torch.float32, device=device)
 
 
+def deterministic():
+    """True when the library runs its order-independent scatter (ARCN_DETERMINISTIC=1, read once at load)"""
+    return bool(N.lib().arcn_deterministic())
+
+
+def hashgrid_bwd_status(desc, n, workspace):
+    """(largest |gradient| of the last binned scatter run with this workspace at capacity n, whether a bin overflowed into the
+    order-dependent direct atomics) - a host read; deterministic runs check the flag is False"""
+    off = int(N.lib().arcn_hashgrid_bwd_status_offset(C.addressof(desc), int(n)))
+    words = workspace[off:off + 2].view(torch.int32).cpu()
+    return float(words[:1].view(torch.float32)[0]), bool(int(words[1]) != 0)
+
+
 def hashgrid_bwd(xyz, table, dout, desc, want_dtable=True, want_dxyz=False, n_dev=None, dtable=None, workspace=None):
     """workspace: True (allocate) or a float tensor from hashgrid_bwd_workspace -> owner-computes scatter; None -> atomics"""
     _req(xyz, table, dout)

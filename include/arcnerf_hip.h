@@ -222,6 +222,13 @@ int arcn_hashgrid_bwd(const float *xyz, const float *table, const float *dout, c
                       float *dtable, float *dxyz, float *workspace, int64_t workspace_floats, int64_t n,
                       const int32_t *n_ptr, void *stream);
 int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc *desc_host, int64_t n);
+/* ARCN_DETERMINISTIC=1 in the environment (read once): the binned scatter accumulates in 64-bit fixed point with integer LDS atomics
+ * (order-independent sums: two runs of a training give bit-identical parameters; the reference's CPU path is deterministic too) instead
+ * of float compare-and-swap.  arcn_deterministic() reports the mode.  After arcn_hashgrid_bwd / _lm / _bwd_bwd with a workspace, the two
+ * uint32 words at workspace[arcn_hashgrid_bwd_status_offset(desc, n)] hold {bits of the launch's largest |gradient|, 1 if a bin
+ * overflowed into the (order-dependent) direct float atomics}: a deterministic run checks the second word is 0. */
+int arcn_deterministic(void);
+int64_t arcn_hashgrid_bwd_status_offset(const arcn_hashgrid_desc *desc, int64_t n);
 /* binned scatter with LEVEL-MAJOR gradients dout_lm[(l * dout_stride + s) * F + f] (the layout arcn_hashgrid_fwd_xcd writes
  * and arcn_mlp_bwd_lm produces); workspace required, dtable only. */
 int arcn_hashgrid_bwd_lm(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host,

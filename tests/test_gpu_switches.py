@@ -24,6 +24,7 @@ GROUPS = {
         # one batch in flight instead of two: the batches meet the sampler's pcg32 launches in a different order (jitter of the ray
         # starts), so the trajectory is another draw of the same training - compared through the loss it reaches, not bit by bit
         {'ARCN_PREFETCH_DEPTH': '1'},
+        {'ARCN_DETERMINISTIC': '1'},     # the order-independent fixed-point scatter: same gradients as the float one
     ],
     'nets': [
         {'ARCN_GEMM_SPLIT': '0', 'ARCN_LINEAR_FUSED_RELU': '0', 'ARCN_LINEAR_SOFTPLUS': '0', 'ARCN_TONEMAP_FUSED': '0', 'ARCN_NEUS_UPSAMPLE_GRAPH': '1'},
@@ -32,6 +33,7 @@ GROUPS = {
     ],
     'neusngp': [
         {'ARCN_SDF_JACOBIAN': '0', 'ARCN_LINEAR_FUSED': '0', 'ARCN_PACKED_OVERFLOW_CHECK': '0'},
+        {'ARCN_DETERMINISTIC': '1'},     # ... including the second-order table scatter
     ],
 }
 _default = {}

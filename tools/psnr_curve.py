@@ -142,4 +142,8 @@ for it in range(1, MAX_IT + 1):
         print(json.dumps(out['points'][-1]), file=sys.stderr, flush=True)
         t_last = time.perf_counter()
 if MAX_IT > 0:
+    import hashlib
+    out['deterministic'] = F.deterministic()     # ARCN_DETERMINISTIC=1: two runs print the same sha and the same curve
+    out['params_sha256'] = hashlib.sha256(fld.params.cpu().numpy().tobytes()).hexdigest()
+    out['scatter_overflowed'] = F.hashgrid_bwd_status(fld.grid_desc, pipe.cap, pipe.hash_ws)[1]
     print(json.dumps(out))
