@@ -972,17 +972,27 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
         if (k2 < -126) k2 = -126;
         const float scale = __uint_as_float((uint32_t)(k2 + 127) << 23);
         const uint4 *prd = recs + plan.rec_first[l] + (int64_t)chunk * cap + lo;
-        for (uint32_t i = threadIdx.x; i < hi - lo; i += kTiledThreads) {
-            const uint4 r = prd[i];
-            const uint32_t i0 = r.x & 0xffffu, i1 = r.x >> 16;
-            if (i0 == 0xffffu) continue;
-            const float wx = __uint_as_float(r.y), a0 = __uint_as_float(r.z), a1 = __uint_as_float(r.w);
-            const float wl = 1.0f - wx;
-            atomicAdd(iacc + i0 * F, (unsigned long long)__float2ll_rn((a0 * wl) * scale));
-            if (F > 1) atomicAdd(iacc + i0 * F + (F > 1 ? 1 : 0), (unsigned long long)__float2ll_rn((a1 * wl) * scale));
-            if (i1 != 0xffffu) {
-                atomicAdd(iacc + i1 * F, (unsigned long long)__float2ll_rn((a0 * wx) * scale));
-                if (F > 1) atomicAdd(iacc + i1 * F + (F > 1 ? 1 : 0), (unsigned long long)__float2ll_rn((a1 * wx) * scale));
+        // four records per thread and trip, all loads issued before the first atomic (a bin is ~32 records per thread: one load in
+        // flight per thread would run at memory latency)
+        const uint32_t lend = hi - lo;
+        const uint4 none = make_uint4(0xffffffffu, 0u, 0u, 0u);
+        for (uint32_t i0g = threadIdx.x; i0g < lend; i0g += kTiledThreads * 4) {
+            uint4 rr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rr[u] = (i0g + u * kTiledThreads < lend) ? prd[i0g + u * kTiledThreads] : none;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint4 r = rr[u];
+                const uint32_t i0 = r.x & 0xffffu, i1 = r.x >> 16;
+                if (i0 == 0xffffu) continue;
+                const float wx = __uint_as_float(r.y), a0 = __uint_as_float(r.z), a1 = __uint_as_float(r.w);
+                const float wl = 1.0f - wx;
+                atomicAdd(iacc + i0 * F, (unsigned long long)__float2ll_rn((a0 * wl) * scale));
+                if (F > 1) atomicAdd(iacc + i0 * F + (F > 1 ? 1 : 0), (unsigned long long)__float2ll_rn((a1 * wl) * scale));
+                if (i1 != 0xffffu) {
+                    atomicAdd(iacc + i1 * F, (unsigned long long)__float2ll_rn((a0 * wx) * scale));
+                    if (F > 1) atomicAdd(iacc + i1 * F + (F > 1 ? 1 : 0), (unsigned long long)__float2ll_rn((a1 * wx) * scale));
+                }
             }
         }
         __syncthreads();

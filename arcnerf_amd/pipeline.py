@@ -320,6 +320,15 @@ class NgpPipeline:
         self.generation = 0
         self.set_bitfield(self.bitfield)
 
+    def sample_count(self):
+        """Valid samples of the batch marched LAST (with prefetch: the batch marched ahead on the sampling stream) as a python int.
+        A host read: it waits for the sampling stream first - `int(pipe.n_dev.item())` from the main stream races with a marcher that
+        is still running and returns whatever the buffer holds (the dynamic batch size of tools/psnr_curve.py was fed that way in
+        rounds 1-2: one source of its run-to-run spread)."""
+        if self.aux_stream is not None:
+            self.aux_stream.synchronize()
+        return int(self.n_dev.item())
+
     # ---- parameter binding -------------------------------------------------------------------------
     def bind_params(self, tensors):
         """Run on externally owned flat fp32 tensors {'table','geo_w','rad_w'[,'geo_b','rad_b']} (e.g. nn.Parameters of the

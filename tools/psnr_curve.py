@@ -99,6 +99,9 @@ for v in range(1000, 1004):
     test.append((o, d, render_truth(o, d)))
 torch.cuda.synchronize()
 t_data = time.perf_counter() - t0
+import hashlib as _hh
+DATA_SHA = _hh.sha256(b''.join(t[2].cpu().numpy().tobytes() for t in train[:8]) + b''.join(t[0].cpu().numpy().tobytes() + t[1].cpu().numpy().tobytes() for t in train[:8])).hexdigest()[:12]
+print('data sha', DATA_SHA, file=sys.stderr)
 
 cfg = NgpConfig(white_bkg=True)
 fld = NgpField(cfg, device=dev, seed=0)
@@ -117,6 +120,9 @@ def psnr():
 
 
 budget = 1 << 18
+# the density noise and the refresh jitter come from torch's default CUDA generator, whose initial seed is RANDOM per process on this stack
+# (rounds 1-2 ran unseeded: part of the +-1.3 dB run-to-run band reported there was simply a different noise draw); PC_SEED picks the draw
+torch.manual_seed(int(os.environ.get('PC_SEED', '0')))
 n_rays = 512
 out = {'scene': 'analytic: 6 soft blobs, textured, view dependent, white background', 'data_seconds': t_data, 'points': []}
 samples_total, t_train = 0, 0.0
@@ -126,10 +132,11 @@ for it in range(1, MAX_IT + 1):
     cfg.lr = lr0 * (0.33 ** sum(1 for s in (20000, 30000, 40000, 50000) if it > s))
     o, d, tgt, bkg = train[it % len(train)]
     nxt = train[(it + 1) % len(train)]
-    loss = pipe.train_step(o[:n_rays], d[:n_rays], tgt[:n_rays], bkg_color=None, next_rays=(nxt[0][:n_rays], nxt[1][:n_rays]))
-    pipe.update_occupancy(it, apply=True)
+    loss = pipe.train_step(o[:n_rays], d[:n_rays], tgt[:n_rays], bkg_color=None, next_rays=None if os.environ.get('PC_NOPREFETCH') else (nxt[0][:n_rays], nxt[1][:n_rays]))
+    if not os.environ.get('PC_NOOCC'):
+        pipe.update_occupancy(it, apply=True)
     if it % 16 == 0:   # dynamic batch size: rays for the valid-sample budget (one host read every 16 steps, like the reference)
-        s = max(1, int(pipe.n_dev.item()))
+        s = max(1, pipe.sample_count())
         samples_total += 16 * s
         n_rays = int(min(R_MAX, max(128, (int(n_rays * budget / s) + 127) // 128 * 128)))
     if it in REPORT:
@@ -137,12 +144,14 @@ for it in range(1, MAX_IT + 1):
         t_train += time.perf_counter() - t_last
         p = psnr()
         occ = float(pipe.bitfield.float().mean())
-        out['points'].append({'iter': it, 'psnr': p, 'loss': float(loss), 'train_seconds': t_train, 'occupied': occ,
+        import hashlib as _h
+        out['points'].append({'iter': it, 'psnr': p, 'loss': float(loss), 'train_seconds': t_train, 'occupied': occ, 'params_sha': _h.sha256(fld.params.cpu().numpy().tobytes()).hexdigest()[:12],
                               'rays_per_step': n_rays, 'samples_per_s_incl_host': samples_total / max(t_train, 1e-9)})
         print(json.dumps(out['points'][-1]), file=sys.stderr, flush=True)
         t_last = time.perf_counter()
 if MAX_IT > 0:
     import hashlib
+    out['seed'] = int(os.environ.get('PC_SEED', '0'))
     out['deterministic'] = F.deterministic()     # ARCN_DETERMINISTIC=1: two runs print the same sha and the same curve
     out['params_sha256'] = hashlib.sha256(fld.params.cpu().numpy().tobytes()).hexdigest()
     out['scatter_overflowed'] = F.hashgrid_bwd_status(fld.grid_desc, pipe.cap, pipe.hash_ws)[1]
