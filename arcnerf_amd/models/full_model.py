@@ -187,6 +187,10 @@ class FullModel(nn.Module):
 
     def process_fg_bkg_model(self, fg_model, bkg_model, flat_inputs, inference_only, get_progress, cur_epoch, total_epoch):
         get_progress_fg = True if bkg_model is not None else get_progress   # blending needs the foreground's progress
+        if bkg_model is not None and not get_progress and self.bkg_blend == 'rgb' and not self.fg_only:
+            # ... of which `rgb` blending reads one number per ray, trans_shift[:, -1] (blend_bkg_rgb): a foreground with a packed path
+            # may return just that (truthy, so every other model gives its full progress as before)
+            get_progress_fg = 't_last'
         fg_output = fg_model.forward(flat_inputs, inference_only, get_progress_fg, cur_epoch, total_epoch)
         bkg_output = None
         if bkg_model is not None and not self.fg_only:

@@ -15,7 +15,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..geometry.ray import get_ray_points_by_zvals, normalize
-from ..ops.autograd import SdfToAlphaFn
+from ..ops import functional as Fn
+from ..ops.autograd import NeusPackedRenderFn, NeusSlotsFn, SdfToAlphaFn
 from ..render.ray_helper import alpha_to_weights, sample_pdf
 from ..utils.cfgs_utils import get_value_from_cfgs_field
 from ..utils.registry import MODEL_REGISTRY
@@ -43,6 +44,73 @@ class Neus(SdfModel):
 
     def get_net(self):
         return self.geo_net, self.radiance_net
+
+    # ---- packed path: a pruned foreground without the padded (rays, P) tensors ------------------------------------------------------
+    use_packed_path = True    # set False to force the dense reference-shaped path (tests compare the two)
+
+    def packed_path_eligible(self):
+        """occupancy-marched foreground (VolumeBound with the sparse sampler), no importance sampling (the marcher's samples are the
+        samples: `n_importance` 0 as in capture_qqtiger_neusngp_multivol.yaml), no hard-coded near / far, no white background"""
+        from .base_modules.obj_bound import VolumeBound
+        b = self.obj_bound
+        return (self.use_packed_path and isinstance(b, VolumeBound) and b.uses_sparse_sampling() and self.get_ray_cfgs('n_importance') <= 0
+                and self.get_ray_cfgs('near') is None and self.get_ray_cfgs('far') is None and not self.get_ray_cfgs('white_bkg')
+                and not self.get_ray_cfgs('bounding_radius'))
+
+    def forward(self, inputs, inference_only=False, get_progress=False, cur_epoch=0, total_epoch=300000):
+        """get_progress may be the string 't_last' (FullModel's rgb blending needs only the foreground's last transmittance,
+        full_model.py:278-330): the packed path then returns `progress_trans_shift` as (rays, 1) and nothing per sample"""
+        if (get_progress is False or get_progress == 't_last') and inputs['rays_o'].is_cuda and self.packed_path_eligible():
+            return self._forward_packed(inputs, inference_only, get_progress == 't_last', cur_epoch)
+        return super().forward(inputs, inference_only, bool(get_progress), cur_epoch, total_epoch)
+
+    def _forward_packed(self, inputs, inference_only, want_t_last, cur_epoch):
+        """March (K2 + K3 in one launch) -> section layout of the marched samples (arcn_neus_sections) -> the nets on the packed mid
+        points (the same autograd graph as the dense path: hash encoder, sdf net with its input Jacobian, radiance net) -> ONE render
+        kernel per direction (slope, cos annealing, sdf_to_alpha, weights, sums, invalid-ray defaults).  One host read (the number of
+        points and the longest ray) where the dense path has five; no boolean-mask gathers, no padded scatters, no (rays, P) tensor
+        except the `normal_pts` output the Eikonal loss consumes (a gather of the packed normals, padded slots included)."""
+        from ..ops.volume_func import sampler_rng
+        rays_o, rays_d = inputs['rays_o'].contiguous().float(), inputs['rays_d'].contiguous().float()
+        bkg_color = inputs['bkg_color']
+        n_rays = rays_o.shape[0]
+        vol, n_pts = self.obj_bound.volume, self.get_n_coarse_sample()
+        train = not inference_only
+        with torch.no_grad():
+            rng = sampler_rng()
+            zd, counts, _, _ = Fn.march_count(rays_o, rays_d, vol.get_range().permute(1, 0).contiguous(), vol.get_n_grid(),
+                                              vol.get_voxel_bitfield(), n_pts, vol.get_diag_len() / n_pts,
+                                              self.obj_bound.get_optim_cfgs('near_distance'), rng.state, rng.inc)
+            rng.advance()
+            pk = Fn.neus_pack(zd, counts, float(self.get_ray_cfgs('n_sample')))
+            total = pk['total']
+            if total > 0:
+                pts, dirs = Fn.packed_points(rays_o, rays_d, pk['t_mid'], pk['ray_id'])
+        dflt_rgb = self.render_cfgs['bkg_color']
+        nv = torch.tensor(self.render_cfgs['normal'], dtype=torch.float32)
+        dflt_nrm = (nv / (nv.norm() + 1e-8)).tolist()
+        if total > 0:
+            if train:
+                self.adjust_dynamicbs_factor(n_valid=pk['offsets'][n_rays])
+            sdf, radiance, normal = chunk_processing(self._forward_pts_dir, self.chunk_pts, False, self.geo_net, self.radiance_net, pts, dirs)
+        else:   # nothing marched anywhere: every ray takes the defaults
+            sdf = rays_o.new_zeros((1,))
+            radiance = normal = rays_o.new_zeros((1, 3))
+        cos_anneal = 1.0 if inference_only else self.get_cos_anneal(cur_epoch)
+        scale = self.forward_scale()
+        rgb, depth, mask, nrm, t_last = NeusPackedRenderFn.apply(sdf, radiance, normal, scale, pk, rays_d, cos_anneal,
+                                                                 bkg_color.contiguous().float() if bkg_color is not None else None,
+                                                                 float(self.render_cfgs['depth_far']), dflt_rgb, dflt_nrm)
+        out = {'rgb': rgb, 'depth': depth, 'mask': mask, 'normal': nrm}
+        if train:
+            out['params'] = {'scale': float(scale.detach())}
+            # the dense (rays, P, 3) per-slot normals of the reference's output (padded slots repeat the ray's last point, rays without
+            # samples hold the default normal): one kernel each way (an index_select would send the gradients of every padded slot
+            # through atomics on one row)
+            out['normal_pts'] = NeusSlotsFn.apply(normal, pk['offsets'], pk['p_dense'], dflt_nrm)
+        if want_t_last:
+            out['progress_trans_shift'] = t_last[:, None]
+        return out
 
     def get_params(self):
         """inv_s = -log(init_var) / speed_factor, learnable (neus_model.py:45-53)"""

@@ -221,6 +221,49 @@ class PackedCompositeFn(torch.autograd.Function):
         return d_sigma, d_rad, None, None, None, None, None, None
 
 
+class NeusPackedRenderFn(torch.autograd.Function):
+    """rgb (R,3), depth, mask (R), normal (R,3), t_last (R) of NeuS from PACKED per-point sdf / radiance / normal (csrc/neus.hip): slope,
+    cos annealing, sdf_to_alpha, weights and sums in one kernel per direction; the numbers of the reference's padded chain
+    (neus_model.py:63-104).  Gradients for sdf, radiance, normal and the scale s."""
+
+    @staticmethod
+    def forward(ctx, sdf, radiance, normal, s, pk, rays_d, cos_anneal, bkg_color, depth_far, dflt_rgb, dflt_nrm):
+        sdf, radiance, normal = sdf.contiguous(), radiance.contiguous(), normal.contiguous()
+        s_dev = s.detach().reshape(1).contiguous()
+        out = F.neus_render_fwd(sdf, radiance, normal, pk, rays_d, s_dev, cos_anneal, bkg_color, depth_far, dflt_rgb, dflt_nrm)
+        ctx.save_for_backward(sdf, radiance, normal, s_dev, rays_d, *( [bkg_color] if bkg_color is not None else []))
+        ctx.pk, ctx.cos_anneal, ctx.has_bkg, ctx.s_shape = pk, float(cos_anneal), bkg_color is not None, s.shape
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_rgb, d_depth, d_mask, d_nrm, d_tlast):
+        sdf, radiance, normal, s_dev, rays_d = ctx.saved_tensors[:5]
+        bkg = ctx.saved_tensors[5] if ctx.has_bkg else None
+        d_sdf, d_rad, d_normal, d_s_ray = F.neus_render_bwd(sdf, radiance, normal, ctx.pk, rays_d, s_dev, ctx.cos_anneal, bkg,
+                                                             d_rgb.contiguous(), d_depth.contiguous(), d_mask.contiguous(),
+                                                             d_nrm.contiguous(), d_tlast.contiguous())
+        d_s = d_s_ray.sum().reshape(ctx.s_shape) if ctx.needs_input_grad[3] else None
+        return d_sdf, d_rad, d_normal, d_s, None, None, None, None, None, None, None
+
+
+class NeusSlotsFn(torch.autograd.Function):
+    """packed per-point normals (S, 3) -> the dense (rays, P, 3) `normal_pts` of the reference's output (padded slots repeat a ray's last
+    point, rays without samples hold the default normal); backward = the transpose, without atomics"""
+
+    @staticmethod
+    def forward(ctx, packed, offsets, p_dense, dflt):
+        ctx.save_for_backward(offsets)
+        ctx.p_dense, ctx.n = int(p_dense), packed.shape[0]
+        return F.neus_slots_fwd(packed.contiguous(), offsets, p_dense, dflt)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        offsets, = ctx.saved_tensors
+        return F.neus_slots_bwd(g.contiguous(), offsets, ctx.p_dense, ctx.n)[:ctx.n], None, None, None
+
+
 class SdfToAlphaFn(torch.autograd.Function):
     """NeuS sdf_to_alpha (arcnerf/models/neus_model.py:242-265) with gradients w.r.t. the mid-point sdf, the slope and the
     scale s (a tensor: exp(10 * inv_s) of the learnable parameter; a float scale gets no gradient).  zvals carry no gradient,

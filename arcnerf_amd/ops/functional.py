@@ -863,6 +863,110 @@ def sample_cdf(bins, cdf, u, eps=1e-5, sort=True, want_inds=False):
 # ------------------------------------------------------------------------------------------------
 # occupancy update, optimiser
 # ------------------------------------------------------------------------------------------------
+# ------------------------------------------------------------------------------------------------
+# NeuS on packed samples (csrc/neus.hip)
+# ------------------------------------------------------------------------------------------------
+def march_count(rays_o, rays_d, aabb23, n_grid, bitfield, n_pts, dt, near_distance, rng_state, rng_inc, packed_bits=False, torch_aabb=False):
+    """bounds (K2) + occupancy marching (K3), one launch: -> zvals_dense (R, n_pts) valid-first (tails NOT filled), counts (R) int32, near, far"""
+    _req(rays_o, rays_d, aabb23, bitfield)
+    o, d, aabb = _f32(rays_o), _f32(rays_d), _f32(aabb23)
+    bf = bitfield.contiguous().view(torch.uint8)
+    R, dev = o.shape[0], o.device
+    z = torch.empty((R, n_pts), dtype=torch.float32, device=dev)
+    counts = torch.empty(R, dtype=torch.int32, device=dev)
+    near = torch.empty(R, dtype=torch.float32, device=dev)
+    far = torch.empty(R, dtype=torch.float32, device=dev)
+    N.check(N.lib().arcn_march_count(N.ptr(o), N.ptr(d), N.ptr(aabb), int(n_grid), N.ptr(bf), int(packed_bits), int(n_pts), float(dt),
+                                    float(near_distance), int(torch_aabb), int(rng_state), int(rng_inc), N.ptr(z), N.ptr(counts),
+                                    N.ptr(near), N.ptr(far), R, N.stream()), 'march_count')
+    return z, counts, near, far
+
+
+def neus_pack(zvals_dense, counts, n_sample_cfg, want_map=False):
+    """The section layout of NeuS for marched samples (see csrc/neus.hip) -> dict(t_mid, lo, hi, ray_id (total), offsets (R+1) int32,
+    kmax (1) int32 device, p_dense int, total int, slot_map (R, p_dense) int64 | None).  ONE host read (total and the longest ray)."""
+    _req(zvals_dense, counts)
+    R, n_pts = zvals_dense.shape
+    dev = zvals_dense.device
+    L = N.lib()
+    kmax = torch.zeros(1, dtype=torch.int32, device=dev)
+    tmp = torch.empty(R + 1, dtype=torch.int32, device=dev)
+    N.check(L.arcn_exclusive_scan_i32(N.ptr(counts), N.ptr(tmp), R, int(R * n_pts), N.ptr(kmax), N.stream()), 'exclusive_scan_i32')
+    n_eval = torch.empty(R, dtype=torch.int32, device=dev)
+    N.check(L.arcn_neus_count(N.ptr(counts), N.ptr(kmax), R, N.ptr(n_eval), N.stream()), 'neus_count')
+    offsets = torch.empty(R + 1, dtype=torch.int32, device=dev)
+    N.check(L.arcn_exclusive_scan_i32(N.ptr(n_eval), N.ptr(offsets), R, int(R * (n_pts + 1)), None, N.stream()), 'exclusive_scan_i32')
+    total, k_h = torch.stack([offsets[R], kmax[0]]).tolist()
+    p_dense = max(2, int(k_h))
+    out = {'offsets': offsets, 'kmax': kmax, 'p_dense': p_dense, 'total': int(total), 'n_eval': n_eval}
+    n_alloc = max(1, int(total))
+    out['t_mid'] = torch.empty(n_alloc, dtype=torch.float32, device=dev)
+    out['lo'] = torch.empty(n_alloc, dtype=torch.float32, device=dev)
+    out['hi'] = torch.empty(n_alloc, dtype=torch.float32, device=dev)
+    out['ray_id'] = torch.empty(n_alloc, dtype=torch.int32, device=dev)
+    out['slot_map'] = torch.empty((R, p_dense), dtype=torch.int64, device=dev) if want_map else None
+    N.check(L.arcn_neus_sections(N.ptr(zvals_dense), N.ptr(counts), N.ptr(offsets), int(n_pts), float(n_sample_cfg), R, p_dense,
+                                 N.ptr(out['t_mid']), N.ptr(out['lo']), N.ptr(out['hi']), N.ptr(out['ray_id']), N.ptr(out['slot_map']),
+                                 N.stream()), 'neus_sections')
+    if total > 0:      # (total == 0: the one-element buffers stay, nothing reads them)
+        for k in ('t_mid', 'lo', 'hi', 'ray_id'):
+            out[k] = out[k][:int(total)]
+    return out
+
+
+def neus_slots_fwd(packed, offsets, p_dense, dflt):
+    _req(packed, offsets)
+    R = offsets.shape[0] - 1
+    dense = torch.empty((R, int(p_dense), 3), dtype=torch.float32, device=packed.device)
+    N.check(N.lib().arcn_neus_slots_fwd(N.ptr(_f32(packed)), N.ptr(offsets), R, int(p_dense), _vec3(dflt), N.ptr(dense), N.stream()), 'neus_slots_fwd')
+    return dense
+
+
+def neus_slots_bwd(d_dense, offsets, p_dense, n_points):
+    _req(d_dense, offsets)
+    R = offsets.shape[0] - 1
+    d_packed = torch.zeros((max(1, int(n_points)), 3), dtype=torch.float32, device=d_dense.device)
+    N.check(N.lib().arcn_neus_slots_bwd(N.ptr(_f32(d_dense)), N.ptr(offsets), R, int(p_dense), N.ptr(d_packed), N.stream()), 'neus_slots_bwd')
+    return d_packed
+
+
+def _vec3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def neus_render_fwd(sdf, radiance, normal, pk, rays_d, s_dev, cos_anneal, bkg_color, depth_far, dflt_rgb, dflt_nrm):
+    _req(sdf, radiance, normal, rays_d, s_dev, bkg_color)
+    R = rays_d.shape[0]
+    dev = rays_d.device
+    bk, bk_rows = _bkg(bkg_color, R)
+    rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    nrm = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    depth = torch.empty(R, dtype=torch.float32, device=dev)
+    mask = torch.empty(R, dtype=torch.float32, device=dev)
+    t_last = torch.empty(R, dtype=torch.float32, device=dev)
+    N.check(N.lib().arcn_neus_render_fwd(N.ptr(sdf), N.ptr(radiance), N.ptr(normal), N.ptr(pk['t_mid']), N.ptr(pk['lo']), N.ptr(pk['hi']),
+                                        N.ptr(pk['offsets']), N.ptr(rays_d), N.ptr(s_dev), float(cos_anneal), N.ptr(bk), bk_rows,
+                                        N.ptr(pk['kmax']), float(depth_far), _vec3(dflt_rgb), _vec3(dflt_nrm), R, N.ptr(rgb), N.ptr(depth),
+                                        N.ptr(mask), N.ptr(nrm), N.ptr(t_last), N.stream()), 'neus_render_fwd')
+    return rgb, depth, mask, nrm, t_last
+
+
+def neus_render_bwd(sdf, radiance, normal, pk, rays_d, s_dev, cos_anneal, bkg_color, d_rgb, d_depth, d_mask, d_nrm, d_tlast):
+    _req(sdf, radiance, normal, rays_d, s_dev, bkg_color, d_rgb, d_depth, d_mask, d_nrm, d_tlast)
+    R = rays_d.shape[0]
+    bk, bk_rows = _bkg(bkg_color, R)
+    d_sdf = torch.empty_like(sdf)
+    d_rad = torch.empty_like(radiance)
+    d_normal = torch.empty_like(normal)
+    d_s_ray = torch.empty(R, dtype=torch.float32, device=sdf.device)
+    N.check(N.lib().arcn_neus_render_bwd(N.ptr(sdf), N.ptr(radiance), N.ptr(normal), N.ptr(pk['t_mid']), N.ptr(pk['lo']), N.ptr(pk['hi']),
+                                        N.ptr(pk['offsets']), N.ptr(rays_d), N.ptr(s_dev), float(cos_anneal), N.ptr(bk), bk_rows,
+                                        N.ptr(pk['kmax']), R, N.ptr(_f32(d_rgb)), N.ptr(_f32(d_depth)), N.ptr(_f32(d_mask)),
+                                        N.ptr(_f32(d_nrm)), N.ptr(_f32(d_tlast)), N.ptr(d_sdf), N.ptr(d_rad), N.ptr(d_normal),
+                                        N.ptr(d_s_ray), N.stream()), 'neus_render_bwd')
+    return d_sdf, d_rad, d_normal, d_s_ray
+
+
 def sample_pdf(bins, weights, u, eps=1e-5, sort=True, want_cdf=False):
     """bins (R, n_pts), weights (R, n_pts-1), u (1 | R, n_sample) -> samples (R, n_sample) sorted [, cdf (R, n_pts)]"""
     _req(bins, weights, u)

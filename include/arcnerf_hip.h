@@ -433,6 +433,43 @@ int arcn_sdf_to_alpha_fwd(const float *mid_sdf, const float *zvals, const float 
 int arcn_sdf_to_alpha_bwd(const float *mid_sdf, const float *zvals, const float *mid_slope, const float *s_dev, int clip,
                           const float *d_alpha, float *d_sdf, float *d_slope, float *d_s, int64_t R, int P, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * NeuS on packed samples (arcnerf/models/neus_model.py:63-104 `_forward`, :174-202 `handle_mid_pts` in its masked layout, :242-265
+ * `sdf_to_alpha`; models/sdf_model.py:42-101 valid-point gather + padded fill; render/ray_helper.py:476-620 alpha= branch): the numbers of
+ * the reference's padded (rays, P) chain, P = max(2, longest ray), without any (rays, P) tensor.
+ *   arcn_neus_count     n_eval[r] = counts[r] > 0 ? min(counts[r] + 1, P) : 0  (points the nets see per ray: the section mid points plus
+ *                       the point behind the last sample; *kmax_dev = the largest count, device int32)
+ *   arcn_neus_sections  zvals_dense (n_rays, n_pts) valid-first depths of the marcher, offsets = exclusive scan of n_eval (offsets[n_rays]
+ *                       = total) -> t_mid / sec_lo / sec_hi (total) mid point and ends of every evaluated section, ray_id (total),
+ *                       slot_map (n_rays, p_dense) int64 optional: padded slot -> packed row (tails: the ray's last row; rays without
+ *                       samples: row `total`) for gathering the dense `normal_pts` output.  n_sample_cfg = rays.n_sample of the config.
+ *   arcn_neus_render_*  per ray: slope = d . normal, cos-annealed, alpha = sdf_to_alpha(sdf, section, slope, *s_dev), weights, rgb
+ *                       (+ T_last * bkg), depth, mask, normal = sum w normalize(normal), t_last = trans_shift[:, -1]; the padded slots
+ *                       (zero-length sections repeating the last point: alpha = 1e-5 / (sigmoid(s sdf) + 1e-5), not 0) are walked too.
+ *                       Rays without samples take FgModel's defaults (bkg colour | dflt_rgb, depth_far, 0, dflt_nrm, 1); dflt_* are HOST
+ *                       pointers to 3 floats.  bwd: d_sdf (total), d_radiance / d_normal (total, 3), d_s_ray (n_rays, optional: per-ray
+ *                       partials of d s).
+ * ---------------------------------------------------------------------------------------------- */
+int arcn_neus_count(const int32_t *counts, const int32_t *kmax_dev, int64_t n_rays, int32_t *n_eval, void *stream);
+int arcn_neus_sections(const float *zvals_dense, const int32_t *counts, const int32_t *offsets, int n_pts, float n_sample_cfg,
+                       int64_t n_rays, int p_dense, float *t_mid, float *sec_lo, float *sec_hi, int32_t *ray_id, int64_t *slot_map,
+                       void *stream);
+/* the dense (n_rays, p_dense, 3) view of a packed (total, 3) per-point quantity the reference returns (`normal_pts`): slot j of a ray =
+ * its point min(j, n - 1), rays without points = dflt_host[0..2]; bwd = its transpose (the aliased tail summed by the ray's wave). */
+int arcn_neus_slots_fwd(const float *packed, const int32_t *offsets, int64_t n_rays, int p_dense, const float *dflt_host, float *dense,
+                        void *stream);
+int arcn_neus_slots_bwd(const float *d_dense, const int32_t *offsets, int64_t n_rays, int p_dense, float *d_packed, void *stream);
+int arcn_neus_render_fwd(const float *sdf, const float *radiance, const float *normal, const float *t_mid, const float *sec_lo,
+                         const float *sec_hi, const int32_t *offsets, const float *rays_d, const float *s_dev, float cos_anneal,
+                         const float *bkg, int64_t bkg_rows, const int32_t *kmax_dev, float depth_far, const float *dflt_rgb_host,
+                         const float *dflt_nrm_host, int64_t n_rays, float *rgb, float *depth, float *mask, float *nrm, float *t_last,
+                         void *stream);
+int arcn_neus_render_bwd(const float *sdf, const float *radiance, const float *normal, const float *t_mid, const float *sec_lo,
+                         const float *sec_hi, const int32_t *offsets, const float *rays_d, const float *s_dev, float cos_anneal,
+                         const float *bkg, int64_t bkg_rows, const int32_t *kmax_dev, int64_t n_rays, const float *d_rgb,
+                         const float *d_depth, const float *d_mask, const float *d_nrm, const float *d_tlast, float *d_sdf,
+                         float *d_radiance, float *d_normal, float *d_s_ray, void *stream);
+
 /* sample_cdf (ray_helper.py:432-473): bins/cdf (R,n_pts), u (R,n_sample) -> samples (R,n_sample) sorted,
  * inds (R,n_sample) int32 optional (searchsorted right=True). */
 int arcn_sample_cdf(const float *bins, const float *cdf, const float *u, int64_t R, int n_pts, int n_sample, float eps,

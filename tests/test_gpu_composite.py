@@ -74,9 +74,11 @@ def _check_all_grads(m, g, rtol=1e-3):
     return n_full, n_sum
 
 
-def test_neus_on_hashgrid_with_multivol_background_matches_reference_composite(gpu):
+@pytest.mark.parametrize('packed_fg', [False, True])
+def test_neus_on_hashgrid_with_multivol_background_matches_reference_composite(gpu, packed_fg):
     """config 4 as the reference names it: Neus(volume bound K2 / K3, hash encoder, normals through the encoder) + MultiVol (K11) blended
-    by `rgb += T_fg,last * rgb_bkg` (full_model.py:278-330)."""
+    by `rgb += T_fg,last * rgb_bkg` (full_model.py:278-330).  packed_fg: the foreground on its packed path (csrc/neus.hip: no padded
+    (rays, P) tensors, K2 + K3 fused) instead of the dense reference-shaped one - same bars against the same reference run."""
     from arcnerf_amd.models import build_model
     from arcnerf_amd.models.base_modules.obj_bound import volume_bound as VB
     from arcnerf_amd.ops import functional as Fn
@@ -91,7 +93,8 @@ def test_neus_on_hashgrid_with_multivol_background_matches_reference_composite(g
     finally:
         os.unlink(f.name)
     fg, bkg = m.fg_model, m.bkg_model
-    assert type(fg).__name__ == 'Neus' and type(bkg).__name__ == 'MultiVol'
+    assert type(fg).__name__ == 'Neus' and type(bkg).__name__ == 'MultiVol' and fg.packed_path_eligible()
+    fg.use_packed_path = packed_fg
     sd = {k[3:]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith('sd.')}
     for name, seed in (('fg_model.geo_net.embed_fn.embeddings', 1), ('bkg_model.geo_net.embed_fn.embeddings', 2)):
         shape = dict(m.named_parameters())[name].shape
@@ -129,13 +132,14 @@ def test_neus_on_hashgrid_with_multivol_background_matches_reference_composite(g
         sampler_rng(reset=True)
         multivol_rng(reset=True)
     # sample indices bit-exact: both launches of both marchers (inference, training)
-    assert len(seen['k3']) == 2 and len(seen['k11']) == 2
+    assert len(seen['k3']) == (0 if packed_fg else 2) and len(seen['k11']) == 2
     for c in range(2):
-        z, msk = (t.cpu().numpy() for t in seen['k3'][c])
-        ref_m = np.unpackbits(g['k3_call{}_mask'.format(c)], axis=1, bitorder='little')[:, :msk.shape[1]].astype(bool)
-        assert np.array_equal(msk, ref_m)
-        w = g['k3_call{}_zvals'.format(c)].shape[1]
-        assert np.array_equal(z[:, :w].view(np.uint32), g['k3_call{}_zvals'.format(c)].view(np.uint32))
+        if not packed_fg:      # (the packed path marches inside one fused launch; its samples are pinned by test_neus_packed_path_* below)
+            z, msk = (t.cpu().numpy() for t in seen['k3'][c])
+            ref_m = np.unpackbits(g['k3_call{}_mask'.format(c)], axis=1, bitorder='little')[:, :msk.shape[1]].astype(bool)
+            assert np.array_equal(msk, ref_m)
+            w = g['k3_call{}_zvals'.format(c)].shape[1]
+            assert np.array_equal(z[:, :w].view(np.uint32), g['k3_call{}_zvals'.format(c)].view(np.uint32))
         z, msk, cnt = seen['k11'][c]
         z = z.cpu().numpy()
         ref_m = np.unpackbits(g['k11_call{}_mask'.format(c)], axis=1, bitorder='little')[:, :z.shape[1]].astype(bool)

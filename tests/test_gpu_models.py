@@ -606,6 +606,66 @@ def test_neus_on_hashgrid_matches_reference_fullmodel(gpu):
     assert checked == 7 and 'grad.fg_model.geo_net.embed_fn.embeddings' in g.files
 
 
+def test_neus_packed_path_equals_dense_reference_shaped_path(gpu):
+    """Neus on the occupancy-marched volume: the packed path (K2 + K3 fused, section layout, one render kernel per direction) against the
+    dense path (padded (rays, P) tensors, masks, gathers / scatters: the reference's shape) on the same sampler stream - inference and
+    training outputs incl. the per-slot `normal_pts` and the last transmittance FullModel blends with, every gradient (hash table through
+    the normals, sdf / radiance nets, the variance parameter); rays that miss the volume or find no occupied cell take the defaults."""
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    from arcnerf_amd.pipeline import synthetic_bitfield, synthetic_rays
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    ov = ['--model.obj_bound.volume.n_grid', '32', '--model.rays.n_sample', '128', '--model.geometry.encoder.n_levels', '8',
+          '--model.geometry.encoder.hashmap_size', '13', '--model.geometry.encoder.max_res', '128', '--model.background', 'None']
+    torch.manual_seed(7)
+    cfgs = load_configs(os.path.join(CFG, 'neus_ngp_multivol.yaml'), ov[:-2])
+    del cfgs.model.background
+    m = build_model(cfgs).to(gpu)
+    fg = m.fg_model
+    assert type(fg).__name__ == 'Neus' and fg.packed_path_eligible() and m.bkg_model is None
+    fg.obj_bound.volume.update_bitfield(torch.from_numpy(synthetic_bitfield(32, 0.25, seed=3)).to(gpu), ops='overwrite')
+    with torch.no_grad():
+        fg.geo_net.embed_fn.embeddings.mul_(300.0)
+    n = 1500
+    o, d = synthetic_rays(n, seed=9, device=gpu, radius=2.2)
+    d[-100:] = -d[-100:]                       # rays looking away: no intersection
+    g_ = torch.Generator().manual_seed(1)
+    inputs = {'rays_o': o.view(1, -1, 3), 'rays_d': d.view(1, -1, 3).contiguous(), 'rays_r': torch.zeros(1, n, 1, device=gpu),
+              'bkg_color': torch.rand(1, n, 3, generator=g_).to(gpu), 'img': torch.rand(1, n, 3, generator=g_).to(gpu)}
+    res = {}
+    for packed in (True, False):
+        fg.use_packed_path = packed
+        sampler_rng(reset=True)
+        m.zero_grad()
+        o_inf = m({k: v.clone() for k, v in inputs.items()}, inference_only=True)
+        o_tr = m({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=20000)
+        t_last = fg.forward({k: v.view(-1, v.shape[-1]).clone() for k, v in inputs.items()}, False, 't_last' if packed else True, 20000)['progress_trans_shift'][:, -1]
+        loss = ((o_tr['rgb'] - inputs['img']) ** 2).mean() + 0.1 * ((o_tr['normal_pts'].norm(dim=-1) - 1.0) ** 2).mean() + \
+            (o_tr['depth'] * 0.01).mean() + (o_tr['normal'] ** 2).mean()
+        loss.backward()
+        res[packed] = ({**{'i_' + k: v.detach().cpu().numpy() for k, v in o_inf.items()},
+                        **{'t_' + k: v.detach().cpu().numpy() for k, v in o_tr.items() if torch.is_tensor(v)}, 't_last': t_last.detach().cpu().numpy()},
+                       {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters() if p.grad is not None}, o_tr['params'])
+    sampler_rng(reset=True)
+    assert set(res[True][0]) == set(res[False][0]) and 't_normal_pts' in res[True][0] and res[True][0]['t_normal_pts'].shape[0] == 1
+    for k in res[True][0]:
+        close(res[True][0][k], res[False][0][k], rtol=1e-5, atol=1e-5)
+    scl = [(p_[0] if isinstance(p_, list) else p_)['scale'] for p_ in (res[True][2], res[False][2])]
+    assert abs(scl[0] - scl[1]) < 1e-6
+    assert set(res[True][1]) == set(res[False][1]) and len(res[True][1]) == 7
+    for k in res[False][1]:
+        ref = res[False][1][k]
+        assert np.abs(res[True][1][k] - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-9, k
+    miss = res[True][0]['t_mask'][0] == 0
+    assert miss.sum() >= 100 and (res[True][0]['t_depth'][0][miss] == 10.0).all()
+    np.testing.assert_array_equal(res[True][0]['t_rgb'][0][miss], inputs['bkg_color'].cpu().numpy()[0][miss])
+    # nothing marched at all: an empty occupancy grid
+    fg.use_packed_path = True
+    fg.obj_bound.volume.update_bitfield(torch.zeros(32, 32, 32, dtype=torch.bool, device=gpu), ops='overwrite')
+    out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=20000)
+    assert float(out['mask'].abs().max()) == 0.0 and out['normal_pts'].shape[:2] == (1, n)
+
+
 def test_neus_ngp_with_multivol_background_trains(gpu):
     """BASELINE config 4 family, reduced (configs/neus_ngp_multivol.yaml): NeuS on the hash grid inside the occupancy-pruned
     volume (sparse sampler, masked samples, second-order path) + MultiVol background, rgb blending.  A few optimiser steps with

@@ -36,7 +36,7 @@ def timed(name, fn):
 
 def step(record):
     T = timed if record else (lambda n_, f: f())
-    fg_out = T('fg forward', lambda: m.fg_model.forward(dict(flat), False, True, 20000, 300000))
+    fg_out = T('fg forward', lambda: m.fg_model.forward(dict(flat), False, 't_last', 20000, 300000))
     bkg_out = T('bkg forward', lambda: m.bkg_model.forward(dict(flat), False, False, 20000, 300000))
     out = T('blend', lambda: m.reshape_output(m.detach_progress(m.blend_output(fg_out, bkg_out, False, False)), b, n))
     loss = T('loss', lambda: ((out['rgb'] - inp['img']) ** 2).mean() + 0.1 * ((out['normal_pts'].norm(dim=-1) - 1.0) ** 2).mean())
