@@ -1318,14 +1318,17 @@ static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *
         if (bx > wgs) bx = wgs;  // persistent workgroups per level
         dim3 bgrid((unsigned)bx, (unsigned)g.L);
         dim3 agrid((unsigned)plan.item_first[g.L]);
-#define ARCN_BIN(F_, T_) hipLaunchKernelGGL((scatter_bin_kernel<F_, T_>), bgrid, dim3(T_), 0, as_stream(stream), xyz, dout, dout_lm_stride, g, plan, counters, recs, dtable, n, n_ptr)
+#define ARCN_BIN(F_, T_) hipLaunchKernelGGL((scatter_bin_kernel<F_, T_>), bgrid, dim3(T_), 0, st_bin, xyz, dout, dout_lm_stride, g, plan, counters, recs, dtable, n, n_ptr)
+#define ARCN_ACC(F_) hipLaunchKernelGGL(scatter_accum_kernel<F_>, agrid, dim3(kTiledThreads), lds, st_acc, recs, counters, g, plan, dtable)
+        hipStream_t st_bin = as_stream(stream), st_acc = as_stream(stream);
         if (g.F == 1) {
             if (bin_threads == 1024) ARCN_BIN(1, 1024); else ARCN_BIN(1, 512);
-            hipLaunchKernelGGL(scatter_accum_kernel<1>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable);
+            ARCN_ACC(1);
         } else {
             if (bin_threads == 1024) ARCN_BIN(2, 1024); else ARCN_BIN(2, 512);
-            hipLaunchKernelGGL(scatter_accum_kernel<2>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable);
+            ARCN_ACC(2);
         }
+#undef ARCN_ACC
 #undef ARCN_BIN
         return check_launch("hashgrid_bwd_binned");
     }

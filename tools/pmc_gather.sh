@@ -12,4 +12,4 @@ for SET in \
   "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_TAG_STALL_sum TCC_BUSY_avr" ; do
   sets+=("$SET")
 done
-bash tools/pmc_kernel.sh "tools/exp_gather.py $ARGS" hashgrid_fwd_xcd "${sets[@]}" > $OUT 2>&1
+bash tools/pmc_kernel.sh "tools/exp_gather.py $ARGS" hashgrid_fwd_ "${sets[@]}" > $OUT 2>&1
