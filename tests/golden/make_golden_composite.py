@@ -212,6 +212,74 @@ def ngpmv(out):
     ref_volume.aabb_ray_intersection = _orig_aabb
 
 
+# ---- ngppp_: NeuS on the hash grid + NeRF++ background (BASELINE config 4 as BASELINE.json words it) ---------------------------------
+def edited_ngppp():
+    """The reference ships NeuS-NGP with the MultiVol background and plain NeuS with NeRF++; BASELINE.json's config 4 names the cross
+    product "NeuS-NGP with NeRF++ background".  Built from the two yamls' own blocks: the foreground block of
+    capture_qqtiger_neusngp_multivol.yaml (reduced grids as in ngpmv_) + the `background` block of capture_qqtiger_neus_nerfpp.yaml
+    with its nets narrowed (the full-width NeRF++ nets are covered by neuspp_)."""
+    fgcfg = yaml.safe_load(edited_ngpmv())['model']
+    bk = yaml.safe_load(open('/root/reference/configs/expr/Capture/qqtiger/capture_qqtiger_neus_nerfpp.yaml'))['model']['background']
+    bk['geometry'].update({'W': 64, 'D': 4, 'skips': [2], 'W_feat': 64})
+    bk['radiance'].update({'W': 32, 'W_feat_in': 64})
+    bk['chunk_pts'] = 4096
+    fgcfg['background'] = bk
+    return yaml.dump({'model': fgcfg}, default_flow_style=False)
+
+
+def ngppp(out):
+    tag = 'ngppp_'
+    text = edited_ngppp()
+    ref_volume.aabb_ray_intersection = oracle_k2
+    torch.manual_seed(2521)
+    model = build_model_checked(text)
+    fg, bkg = model.fg_model, model.bkg_model
+    assert type(fg).__name__ == 'Neus' and type(bkg).__name__ == 'NeRFPP' and type(fg.geo_net.embed_fn).__name__ == 'HashGridEmbedder'
+    rng = np.random.default_rng(26)
+    with torch.no_grad():
+        emb = fg.geo_net.embed_fn.embeddings
+        emb.copy_((torch.rand(emb.shape, generator=torch.Generator().manual_seed(3)) - 0.5) * 0.2)
+        fg.obj_bound.volume.get_voxel_bitfield().copy_(torch.from_numpy(rng.random((16, 16, 16)) < 0.45))
+        for n_, p in bkg.named_parameters():
+            if n_.endswith('coarse_geo_net.layers.4.weight'):
+                p[:1] += 0.35      # background density that matters
+    g = torch.Generator().manual_seed(2522)
+    N = 128
+    o = torch.randn(1, N, 3, generator=g)
+    o = o / o.norm(dim=-1, keepdim=True) * (1.2 + 1.2 * torch.rand(1, N, 1, generator=g))
+    d = -o + (torch.rand(1, N, 3, generator=g) - 0.5) * 1.4
+    d[:, 112:] = torch.randn(1, 16, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    inputs = {'rays_o': o, 'rays_d': d, 'rays_r': torch.zeros(1, N, 1), 'img': torch.rand(1, N, 3, generator=g),
+              'bkg_color': torch.rand(1, N, 3, generator=g)}
+    out[tag + 'config_yaml'] = np.array(text)
+    for k, v in model.state_dict().items():
+        if k.endswith('embed_fn.embeddings'):
+            out[tag + 'tablesum.' + k] = np.array(v.double().sum().item())
+        elif not k.endswith(('.volume_pts', '.grid_pts', '.corner')):
+            out[tag + 'sd.' + k] = v.numpy()
+    for k, v in inputs.items():
+        out[tag + 'in_' + k] = v.numpy()
+    _state.update(rng_vol=orc.Pcg32(9121), rng_mv=orc.Pcg32(9121), k3=[], k11=[])
+    tape = RandTape(2523)
+    with tape.record():
+        res = model({k: v.clone() for k, v in inputs.items()}, inference_only=True)
+    assert not tape.draws
+    for k, v in res.items():
+        out[tag + 'infer_' + k] = v.detach().numpy()
+    with tape.record():      # the background's shell radii are perturbed (torch.rand); the foreground's marcher jitters with its own pcg32
+        res = model({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=20000)
+    for i, t in enumerate(tape.draws):
+        out[tag + 'draw_{:02d}'.format(i)] = t.numpy()
+    loss, eik, n_grad = store_run(out, tag, model, inputs, res)
+    for c, (z, m) in enumerate(_state['k3']):
+        out[tag + 'k3_call{}_zvals'.format(c)] = z[:, :max(2, int(m.sum(1).max()))]
+        out[tag + 'k3_call{}_mask'.format(c)] = np.packbits(m, axis=1, bitorder='little')
+    print(tag, 'loss', loss, 'eik', eik, 'params with grad', n_grad, 'draws', [tuple(t.shape) for t in tape.draws],
+          'rays with fg samples', [int((m.sum(1) > 0).sum()) for _, m in _state['k3']], 'mask mean', float(res['mask'].mean()))
+    ref_volume.aabb_ray_intersection = _orig_aabb
+
+
 def build_model_checked(text, overrides=()):
     m = build_from_text(text, overrides)
     assert m.bkg_model is not None
@@ -304,6 +372,7 @@ def neuspp(out, pool=400, keep=40, margin=2e-6, pos_noise=5e-6):
 if __name__ == '__main__':
     out = {}
     ngpmv(out)
+    ngppp(out)
     neuspp(out)
     path = os.path.join(HERE, 'g25_composite_models.npz')
     np.savez_compressed(path, **out)

@@ -163,6 +163,68 @@ def test_neus_on_hashgrid_with_multivol_background_matches_reference_composite(g
     assert n_full == 13 and 'grad.fg_model.geo_net.embed_fn.embeddings' in g.files and 'grad.bkg_model.geo_net.embed_fn.embeddings' in g.files
 
 
+@pytest.mark.parametrize('packed_fg', [False, True])
+def test_neus_on_hashgrid_with_nerfpp_background_matches_reference_composite(gpu, packed_fg):
+    """BASELINE.json's wording of config 4, "NeuS-NGP (hashgrid + volume prune) with NeRF++ background": the foreground block of
+    capture_qqtiger_neusngp_multivol.yaml + the background block of capture_qqtiger_neus_nerfpp.yaml (nets narrowed), run through the
+    reference's FullModel (golden G25 ngppp_): K3 samples bit for bit, outputs 1e-4, loss 1e-5, all 21 gradients 1e-3; the background's
+    shell perturbation on the reference's tape; dense and packed foreground."""
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.models.base_modules.obj_bound import volume_bound as VB
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    g = Sub(load_golden('g25_composite_models'), 'ngppp_')
+    with tempfile.NamedTemporaryFile('w', suffix='.yaml', delete=False) as f:
+        f.write(str(g['config_yaml']))
+    try:
+        m = build_model(load_configs(f.name, [])).to(gpu)
+    finally:
+        os.unlink(f.name)
+    fg, bkg = m.fg_model, m.bkg_model
+    assert type(fg).__name__ == 'Neus' and type(bkg).__name__ == 'NeRFPP' and fg.packed_path_eligible()
+    fg.use_packed_path = packed_fg
+    sd = {k[3:]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith('sd.')}
+    name = 'fg_model.geo_net.embed_fn.embeddings'
+    sd[name] = (torch.rand(dict(m.named_parameters())[name].shape, generator=torch.Generator().manual_seed(3)) - 0.5) * 0.2
+    assert abs(float(sd[name].double().sum()) - float(g['tablesum.' + name])) < 1e-6
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith(('.volume_pts', '.grid_pts', '.corner')) for k in missing), (missing, unexpected)
+    inputs = {k[3:]: torch.from_numpy(g[k]).to(gpu) for k in g.files if k.startswith('in_')}
+    seen, real_k3 = [], VB.sparse_volume_sampling
+
+    def rec_k3(*a, **k):
+        z, msk = real_k3(*a, **k)
+        seen.append((z.clone(), msk.clone()))
+        return z, msk
+    VB.sparse_volume_sampling = rec_k3
+    sampler_rng(reset=True)
+    draws = [g[k] for k in sorted(k for k in g.files if k.startswith('draw_'))]
+    try:
+        out = m({k: v.clone() for k, v in inputs.items()}, inference_only=True)
+        assert set(out.keys()) == {k[6:] for k in g.files if k.startswith('infer_')}
+        for k in out:
+            close(out[k].detach().cpu().numpy(), g['infer_' + k])
+        with RandFeed(draws, gpu):
+            out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=20000)
+    finally:
+        VB.sparse_volume_sampling = real_k3
+        sampler_rng(reset=True)
+    assert len(seen) == (0 if packed_fg else 2)
+    for c, (z, msk) in enumerate(seen):
+        ref_m = np.unpackbits(g['k3_call{}_mask'.format(c)], axis=1, bitorder='little')[:, :msk.shape[1]].astype(bool)
+        assert np.array_equal(msk.cpu().numpy(), ref_m)
+        w = g['k3_call{}_zvals'.format(c)].shape[1]
+        assert np.array_equal(z.cpu().numpy()[:, :w].view(np.uint32), g['k3_call{}_zvals'.format(c)].view(np.uint32))
+    for k in [k[6:] for k in g.files if k.startswith('train_') and k not in ('train_loss', 'train_eikonal')]:
+        (close_normals if k == 'normal_pts' else close)(out[k].detach().cpu().numpy(), g['train_' + k])
+    loss, eik = _loss(out, inputs)
+    assert abs(float(eik.detach()) - float(g['train_eikonal'])) < 2e-5 and abs(float(loss.detach()) - float(g['train_loss'])) < 1e-5
+    m.zero_grad()
+    loss.backward()
+    n_full, _ = _check_all_grads(m, g)
+    assert n_full == 21 and 'grad.fg_model.geo_net.embed_fn.embeddings' in g.files
+
+
 def test_neus_with_nerfpp_background_matches_reference_composite(gpu):
     """BASELINE's "NeuS(-NGP) with NeRF++ background": Neus 8 x 256 (sphere bound, four up-sampling rounds, Eikonal through the double
     backward) + NeRFPP (inverted-sphere 4-D inputs, multi-sphere shells), FULL widths of capture_qqtiger_neus_nerfpp.yaml."""
