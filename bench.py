@@ -38,6 +38,7 @@ def parse():
     ap.add_argument('--bkg-occupancy', type=float, default=-1.0, help='config 4: occupied fraction of every level of the background cascade (default: the same as --occupancy; 1.0 = the unpruned start-of-training grid)')
     ap.add_argument('--no-occ-update', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-psnr', action='store_true', help='skip the short PSNR@iter run on the analytic scene appended to the default line')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the short runs of BASELINE configs 1 / 3 / 4 / 5 appended to the default line')
     ap.add_argument('--cpu-rays', type=int, default=131072)
     ap.add_argument('--config', default='ngp', choices=['ngp', 'nerf', 'neus', 'neus_ngp_multivol', 'hdrnerf'],
@@ -624,6 +625,26 @@ def main():
                 others[name] = {'error': repr(e)}
             torch.cuda.empty_cache()
 
+    # PSNR@iter, the second half of BASELINE's metric: no dataset on the box, so the scene is analytic (tools/psnr_curve.py: six soft
+    # textured blobs, 100 training views of 800x800 cameras, held-out views; the product path exactly as above with the occupancy
+    # refresh APPLIED from an all-occupied grid and the dynamic batch size) - a short run rides along after everything that is timed
+    psnr = None
+    if world == 1 and not args.no_other_configs and not args.no_psnr:
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location('psnr_curve', os.path.join(ROOT, 'tools', 'psnr_curve.py'))
+            pc = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(pc)
+            timers.reset(())
+            torch.cuda.empty_cache()
+            r = pc.run(2000, seed=0, verbose=False)
+            psnr = {'scene': r['scene'] + ' (analytic: there is no dataset on the box)', 'seed': 0, 'deterministic_mode': r.get('deterministic'),
+                    'psnr_at_iter': {str(p_['iter']): round(p_['psnr'], 2) for p_ in r['points']},
+                    'train_seconds_at_iter': {str(p_['iter']): round(p_['train_seconds'], 2) for p_ in r['points']},
+                    'note': 'profiles/r3_psnr_curve_*.json hold the 10k-iteration curves (31 dB; bit-identical between runs with ARCN_DETERMINISTIC=1)'}
+        except Exception as e:
+            psnr = {'error': repr(e)}
+
     out = {
         'metric': 'ray-samples/sec (train), NGP Lego 800x800', 'value': total_samples / wall, 'unit': 'samples/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
@@ -643,6 +664,7 @@ def main():
         'cpu_baseline': cpu,
         'kernel_ms': ktable,
         'other_configs': others,
+        'psnr_analytic_scene': psnr,
     }
     print(json.dumps(out))
     if dist is not None:

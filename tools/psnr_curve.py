@@ -23,136 +23,142 @@ from arcnerf_amd.ops import functional as F
 from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline
 from arcnerf_amd.render.ray_helper import get_rays
 
-dev = torch.device('cuda:0')
-MAX_IT = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-REPORT = [i for i in (100, 500, 2000, 10000, 30000, 50000) if i <= MAX_IT]
-HW, ANGLE, RADIUS = 800, 0.6911, 3.0 / 1.05
-g = torch.Generator(device='cpu').manual_seed(0)
+def run(MAX_IT=10000, seed=0, verbose=True):
+    """train the NGP pipeline on the analytic scene for MAX_IT iterations -> dict (see the module docstring)"""
+    dev = torch.device('cuda:0')
+    REPORT = [i for i in (100, 500, 2000, 10000, 30000, 50000) if i <= MAX_IT]
+    HW, ANGLE, RADIUS = 800, 0.6911, 3.0 / 1.05
+    g = torch.Generator(device='cpu').manual_seed(0)
 
-# ---- analytic scene -----------------------------------------------------------------------------------------------------
-rng = np.random.default_rng(3)
-CENTERS = torch.tensor((rng.random((6, 3)) - 0.5) * 1.0, dtype=torch.float32, device=dev)
-RADII = torch.tensor(rng.random(6) * 0.18 + 0.12, dtype=torch.float32, device=dev)
-PHASE = torch.tensor(rng.random((6, 3)) * 6.28, dtype=torch.float32, device=dev)
-
-
-def field(x, d):
-    """density (N,), colour (N,3) of the analytic scene"""
-    r2 = ((x[:, None, :] - CENTERS[None]) ** 2).sum(-1) / (RADII[None] ** 2)            # (N, 6)
-    w = torch.sigmoid((1.0 - r2) * 12.0)                                                # soft blob membership
-    sigma = 60.0 * w.max(dim=1)[0]
-    base = 0.5 + 0.5 * torch.sin(PHASE[None] + 4.0 * x[:, None, :])                     # (N, 6, 3) per-blob texture
-    col = (w[..., None] * base).sum(1) / (w.sum(1, keepdim=True) + 1e-6)
-    col = (col * (0.75 + 0.25 * (d * x).sum(-1, keepdim=True).tanh())).clamp(0, 1)      # mild view dependence
-    return sigma, col
+    # ---- analytic scene -----------------------------------------------------------------------------------------------------
+    rng = np.random.default_rng(3)
+    CENTERS = torch.tensor((rng.random((6, 3)) - 0.5) * 1.0, dtype=torch.float32, device=dev)
+    RADII = torch.tensor(rng.random(6) * 0.18 + 0.12, dtype=torch.float32, device=dev)
+    PHASE = torch.tensor(rng.random((6, 3)) * 6.28, dtype=torch.float32, device=dev)
 
 
-@torch.no_grad()
-def render_truth(o, d, n=2048, chunk=2048):
-    out = []
-    for lo in range(0, o.shape[0], chunk):
-        oo, dd = o[lo:lo + chunk], d[lo:lo + chunk]
-        aabb = torch.tensor([[[-1.0, 1.0]] * 3], device=dev)
-        near, far, _, hit = F.aabb_intersection_torch(oo, dd, aabb, 1e-7)
-        z = near + (far - near) * torch.linspace(0, 1, n, device=dev)[None]
-        x = (oo[:, None] + dd[:, None] * z[..., None]).reshape(-1, 3)
-        s, c = field(x, dd[:, None].expand(-1, n, -1).reshape(-1, 3))
-        s = s.view(-1, n) * hit.float()
-        res = F.ray_marching_fwd(s, c.view(-1, n, 3), z.contiguous(), white_bkg=True)
-        out.append(res['rgb'])
-    return torch.cat(out)
+    def field(x, d):
+        """density (N,), colour (N,3) of the analytic scene"""
+        r2 = ((x[:, None, :] - CENTERS[None]) ** 2).sum(-1) / (RADII[None] ** 2)            # (N, 6)
+        w = torch.sigmoid((1.0 - r2) * 12.0)                                                # soft blob membership
+        sigma = 60.0 * w.max(dim=1)[0]
+        base = 0.5 + 0.5 * torch.sin(PHASE[None] + 4.0 * x[:, None, :])                     # (N, 6, 3) per-blob texture
+        col = (w[..., None] * base).sum(1) / (w.sum(1, keepdim=True) + 1e-6)
+        col = (col * (0.75 + 0.25 * (d * x).sum(-1, keepdim=True).tanh())).clamp(0, 1)      # mild view dependence
+        return sigma, col
 
 
-def camera(seed):
-    gg = torch.Generator(device='cpu').manual_seed(seed)
-    c = torch.randn(3, generator=gg)
-    c = c / c.norm() * RADIUS
-    fwd = -c / c.norm()
-    right = torch.linalg.cross(fwd, torch.tensor([0.0, 0.0, 1.0]))
-    right = right / right.norm()
-    up = torch.linalg.cross(right, fwd)
-    c2w = torch.eye(4)
-    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, -up, fwd, c      # x right, y down, z forward (pinhole, z = 1 plane)
-    focal = 0.5 * HW / math.tan(0.5 * ANGLE)
-    K = torch.tensor([[focal, 0.0, HW / 2], [0.0, focal, HW / 2], [0.0, 0.0, 1.0]])
-    return K.to(dev), c2w.to(dev)
+    @torch.no_grad()
+    def render_truth(o, d, n=2048, chunk=2048):
+        out = []
+        for lo in range(0, o.shape[0], chunk):
+            oo, dd = o[lo:lo + chunk], d[lo:lo + chunk]
+            aabb = torch.tensor([[[-1.0, 1.0]] * 3], device=dev)
+            near, far, _, hit = F.aabb_intersection_torch(oo, dd, aabb, 1e-7)
+            z = near + (far - near) * torch.linspace(0, 1, n, device=dev)[None]
+            x = (oo[:, None] + dd[:, None] * z[..., None]).reshape(-1, 3)
+            s, c = field(x, dd[:, None].expand(-1, n, -1).reshape(-1, 3))
+            s = s.view(-1, n) * hit.float()
+            res = F.ray_marching_fwd(s, c.view(-1, n, 3), z.contiguous(), white_bkg=True)
+            out.append(res['rgb'])
+        return torch.cat(out)
 
 
-def rays_of(seed, n):
-    K, c2w = camera(seed)
-    gg = torch.Generator(device='cpu').manual_seed(10_000 + seed)
-    idx = torch.stack([torch.randint(0, HW, (n,), generator=gg), torch.randint(0, HW, (n,), generator=gg)], -1).to(dev)
-    o, d, _, _ = get_rays(HW, HW, K, c2w, index=idx, center_pixel=True)
-    return o, d
+    def camera(seed):
+        gg = torch.Generator(device='cpu').manual_seed(seed)
+        c = torch.randn(3, generator=gg)
+        c = c / c.norm() * RADIUS
+        fwd = -c / c.norm()
+        right = torch.linalg.cross(fwd, torch.tensor([0.0, 0.0, 1.0]))
+        right = right / right.norm()
+        up = torch.linalg.cross(right, fwd)
+        c2w = torch.eye(4)
+        c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, -up, fwd, c      # x right, y down, z forward (pinhole, z = 1 plane)
+        focal = 0.5 * HW / math.tan(0.5 * ANGLE)
+        K = torch.tensor([[focal, 0.0, HW / 2], [0.0, focal, HW / 2], [0.0, 0.0, 1.0]])
+        return K.to(dev), c2w.to(dev)
 
 
-# ---- data: 100 training views x 32768 random pixels, 4 held-out views x 16384 pixels ----------------------------------------
-t0 = time.perf_counter()
-R_MAX = 32768
-train = []
-for v in range(100):
-    o, d = rays_of(v, R_MAX)
-    train.append((o, d, render_truth(o, d), torch.ones(R_MAX, 3, device=dev)))
-test = []
-for v in range(1000, 1004):
-    o, d = rays_of(v, 16384)
-    test.append((o, d, render_truth(o, d)))
-torch.cuda.synchronize()
-t_data = time.perf_counter() - t0
-import hashlib as _hh
-DATA_SHA = _hh.sha256(b''.join(t[2].cpu().numpy().tobytes() for t in train[:8]) + b''.join(t[0].cpu().numpy().tobytes() + t[1].cpu().numpy().tobytes() for t in train[:8])).hexdigest()[:12]
-print('data sha', DATA_SHA, file=sys.stderr)
-
-cfg = NgpConfig(white_bkg=True)
-fld = NgpField(cfg, device=dev, seed=0)
-pipe = NgpPipeline(fld, max_rays=R_MAX, max_samples=1 << 20)     # all-occupied start, refresh applied below
+    def rays_of(seed, n):
+        K, c2w = camera(seed)
+        gg = torch.Generator(device='cpu').manual_seed(10_000 + seed)
+        idx = torch.stack([torch.randint(0, HW, (n,), generator=gg), torch.randint(0, HW, (n,), generator=gg)], -1).to(dev)
+        o, d, _, _ = get_rays(HW, HW, K, c2w, index=idx, center_pixel=True)
+        return o, d
 
 
-@torch.no_grad()
-def psnr():
-    mse, n = 0.0, 0
-    for o, d, tgt in test:
-        for lo in range(0, o.shape[0], 8192):
-            rgb, _, _ = pipe.forward(o[lo:lo + 8192], d[lo:lo + 8192], None, train=False)
-            mse += float(((rgb - tgt[lo:lo + 8192]) ** 2).sum())
-            n += rgb.numel()
-    return -10.0 * math.log10(mse / n)
+    # ---- data: 100 training views x 32768 random pixels, 4 held-out views x 16384 pixels ----------------------------------------
+    t0 = time.perf_counter()
+    R_MAX = 32768
+    train = []
+    for v in range(100):
+        o, d = rays_of(v, R_MAX)
+        train.append((o, d, render_truth(o, d), torch.ones(R_MAX, 3, device=dev)))
+    test = []
+    for v in range(1000, 1004):
+        o, d = rays_of(v, 16384)
+        test.append((o, d, render_truth(o, d)))
+    torch.cuda.synchronize()
+    t_data = time.perf_counter() - t0
+    import hashlib as _hh
+    DATA_SHA = _hh.sha256(b''.join(t[2].cpu().numpy().tobytes() for t in train[:8]) + b''.join(t[0].cpu().numpy().tobytes() + t[1].cpu().numpy().tobytes() for t in train[:8])).hexdigest()[:12]
+    print('data sha', DATA_SHA, file=sys.stderr)
+
+    cfg = NgpConfig(white_bkg=True)
+    fld = NgpField(cfg, device=dev, seed=0)
+    pipe = NgpPipeline(fld, max_rays=R_MAX, max_samples=1 << 20)     # all-occupied start, refresh applied below
 
 
-budget = 1 << 18
-# the density noise and the refresh jitter come from torch's default CUDA generator, whose initial seed is RANDOM per process on this stack
-# (rounds 1-2 ran unseeded: part of the +-1.3 dB run-to-run band reported there was simply a different noise draw); PC_SEED picks the draw
-torch.manual_seed(int(os.environ.get('PC_SEED', '0')))
-n_rays = 512
-out = {'scene': 'analytic: 6 soft blobs, textured, view dependent, white background', 'data_seconds': t_data, 'points': []}
-samples_total, t_train = 0, 0.0
-lr0 = cfg.lr
-t_last = time.perf_counter()
-for it in range(1, MAX_IT + 1):
-    cfg.lr = lr0 * (0.33 ** sum(1 for s in (20000, 30000, 40000, 50000) if it > s))
-    o, d, tgt, bkg = train[it % len(train)]
-    nxt = train[(it + 1) % len(train)]
-    loss = pipe.train_step(o[:n_rays], d[:n_rays], tgt[:n_rays], bkg_color=None, next_rays=None if os.environ.get('PC_NOPREFETCH') else (nxt[0][:n_rays], nxt[1][:n_rays]))
-    if not os.environ.get('PC_NOOCC'):
+    @torch.no_grad()
+    def psnr():
+        mse, n = 0.0, 0
+        for o, d, tgt in test:
+            for lo in range(0, o.shape[0], 8192):
+                rgb, _, _ = pipe.forward(o[lo:lo + 8192], d[lo:lo + 8192], None, train=False)
+                mse += float(((rgb - tgt[lo:lo + 8192]) ** 2).sum())
+                n += rgb.numel()
+        return -10.0 * math.log10(mse / n)
+
+
+    budget = 1 << 18
+    # the density noise and the refresh jitter come from torch's default CUDA generator, whose initial seed is RANDOM per process on this stack
+    # (rounds 1-2 ran unseeded: part of the +-1.3 dB run-to-run band reported there was simply a different noise draw); PC_SEED picks the draw
+    torch.manual_seed(int(seed))
+    n_rays = 512
+    out = {'scene': 'analytic: 6 soft blobs, textured, view dependent, white background', 'data_seconds': t_data, 'points': []}
+    samples_total, t_train = 0, 0.0
+    lr0 = cfg.lr
+    t_last = time.perf_counter()
+    for it in range(1, MAX_IT + 1):
+        cfg.lr = lr0 * (0.33 ** sum(1 for s in (20000, 30000, 40000, 50000) if it > s))
+        o, d, tgt, bkg = train[it % len(train)]
+        nxt = train[(it + 1) % len(train)]
+        loss = pipe.train_step(o[:n_rays], d[:n_rays], tgt[:n_rays], bkg_color=None, next_rays=(nxt[0][:n_rays], nxt[1][:n_rays]))
         pipe.update_occupancy(it, apply=True)
-    if it % 16 == 0:   # dynamic batch size: rays for the valid-sample budget (one host read every 16 steps, like the reference)
-        s = max(1, pipe.sample_count())
-        samples_total += 16 * s
-        n_rays = int(min(R_MAX, max(128, (int(n_rays * budget / s) + 127) // 128 * 128)))
-    if it in REPORT:
-        torch.cuda.synchronize()
-        t_train += time.perf_counter() - t_last
-        p = psnr()
-        occ = float(pipe.bitfield.float().mean())
-        import hashlib as _h
-        out['points'].append({'iter': it, 'psnr': p, 'loss': float(loss), 'train_seconds': t_train, 'occupied': occ, 'params_sha': _h.sha256(fld.params.cpu().numpy().tobytes()).hexdigest()[:12],
-                              'rays_per_step': n_rays, 'samples_per_s_incl_host': samples_total / max(t_train, 1e-9)})
-        print(json.dumps(out['points'][-1]), file=sys.stderr, flush=True)
-        t_last = time.perf_counter()
-if MAX_IT > 0:
-    import hashlib
-    out['seed'] = int(os.environ.get('PC_SEED', '0'))
-    out['deterministic'] = F.deterministic()     # ARCN_DETERMINISTIC=1: two runs print the same sha and the same curve
-    out['params_sha256'] = hashlib.sha256(fld.params.cpu().numpy().tobytes()).hexdigest()
-    out['scatter_overflowed'] = F.hashgrid_bwd_status(fld.grid_desc, pipe.cap, pipe.hash_ws)[1]
-    print(json.dumps(out))
+        if it % 16 == 0:   # dynamic batch size: rays for the valid-sample budget (one host read every 16 steps, like the reference)
+            s = max(1, pipe.sample_count())
+            samples_total += 16 * s
+            n_rays = int(min(R_MAX, max(128, (int(n_rays * budget / s) + 127) // 128 * 128)))
+        if it in REPORT:
+            torch.cuda.synchronize()
+            t_train += time.perf_counter() - t_last
+            p = psnr()
+            occ = float(pipe.bitfield.float().mean())
+            import hashlib as _h
+            out['points'].append({'iter': it, 'psnr': p, 'loss': float(loss), 'train_seconds': t_train, 'occupied': occ, 'params_sha': _h.sha256(fld.params.cpu().numpy().tobytes()).hexdigest()[:12],
+                                  'rays_per_step': n_rays, 'samples_per_s_incl_host': samples_total / max(t_train, 1e-9)})
+            if verbose:
+                print(json.dumps(out['points'][-1]), file=sys.stderr, flush=True)
+            t_last = time.perf_counter()
+    if MAX_IT > 0:
+        import hashlib
+        out['seed'] = int(seed)
+        out['deterministic'] = F.deterministic()     # ARCN_DETERMINISTIC=1: two runs print the same sha and the same curve
+        out['params_sha256'] = hashlib.sha256(fld.params.cpu().numpy().tobytes()).hexdigest()
+        out['scatter_overflowed'] = F.hashgrid_bwd_status(fld.grid_desc, pipe.cap, pipe.hash_ws)[1]
+        pass
+    return out
+
+
+if __name__ == '__main__':
+    print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 10000, int(os.environ.get('PC_SEED', '0')))))
