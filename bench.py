@@ -264,6 +264,18 @@ def bench_module(args, name, emit=True):
                 valid_calls[0] += 1
             return orig_adjust(mask_pts, n_valid)
         fg.adjust_dynamicbs_factor = counting_adjust
+    bkg_samples = [0, 0]
+    if name == 'neus_ngp_multivol':
+        # the background's packed samples: the one host read its path makes anyway (ops.functional.pack_dense_samples) is tallied
+        from arcnerf_amd.ops import functional as Fn
+        real_pack = Fn.pack_dense_samples
+
+        def counting_pack(zvals, counts):
+            r = real_pack(zvals, counts)
+            bkg_samples[0] += int(r[4])
+            bkg_samples[1] += 1
+            return r
+        Fn.pack_dense_samples = counting_pack
 
     def step(i):
         inp = pool[i % len(pool)]
@@ -281,6 +293,7 @@ def bench_module(args, name, emit=True):
     torch.cuda.synchronize()
     valid_acc.zero_()
     valid_calls[0] = 0
+    bkg_samples[0] = bkg_samples[1] = 0
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -324,6 +337,19 @@ def bench_module(args, name, emit=True):
                             '(the products are f32-accurate; each is six bf16 MFMAs, so the matrix pipe itself does 6/8 of the f32 MFMA cycles); '
                             'peak_split = the dense bf16 MFMA peak / 6 terms = what the split form could do at full clock (the kernels sit on the '
                             '1400 W package limit at 1.93-1.97 GHz, DESIGN.md 5b)'}
+    if name == 'neus_ngp_multivol':
+        Fn.pack_dense_samples = real_pack
+        s_bkg = bkg_samples[0] / max(1, bkg_samples[1])
+        # HBM accounting of the hash-grid passes over the WHOLE step (SURVEY.md 8d per-sample figures): the background model encodes and
+        # scatters once per sample; the foreground (sdf net with normals through the encoder) gathers twice (values, d enc / d x) and
+        # scatters twice (first order, second order with 8 single-row records per sample and level)
+        alg = (BYTES_HASH_FWD + BYTES_HASH_BWD) * s_bkg + (2 * BYTES_HASH_FWD + 2 * BYTES_HASH_BWD) * evals_per_step
+        ach = alg / (wall / args.steps)
+        roofline = {'kernel': 'hash-grid gathers + binned scatters of the foreground (first and second order) and the background model, over the WHOLE step',
+                    'bound': 'hbm', 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': None,
+                    'fg_points_per_step': evals_per_step, 'bkg_samples_per_step': s_bkg,
+                    'note': 'a module-path step: 2.7 ms of kernels in 3.6 ms, of which the hash passes are ~1.2 ms (profiles/r3d_*); the step is '
+                            'launch / host bound, not bandwidth bound - the fraction says how far, it is not a kernel figure'}
     cpu = None
     if world == 1 and not args.no_cpu_baseline and name == 'nerf' and emit:
         cpu = cpu_baseline_nerf()
@@ -619,7 +645,7 @@ def main():
                 r = bench_module(a2, name, emit=False)
                 others[name] = {'ms_per_step': r['ms_per_step'], 'samples_per_s': r['value'], 'steps': 8, 'warmup': 3,
                                 'rays_per_step': r['config']['rays_per_step_per_gpu'], 'samples_per_step': r['config']['samples_per_step_per_gpu'],
-                                'roofline_frac': (r['roofline'] or {}).get('frac'), 'roofline_bound': (r['roofline'] or {}).get('bound'),
+                                'roofline_frac': (r['roofline'] or {}).get('frac'), 'roofline_bound': (r['roofline'] or {}).get('bound'), 'bkg_samples_per_step': (r['roofline'] or {}).get('bkg_samples_per_step'),
                                 'workload': r['config']['workload']}
             except Exception as e:      # never lose the headline line to a side leg
                 others[name] = {'error': repr(e)}
