@@ -7,7 +7,6 @@ Differences by design (MI355X, 288 GB is not a reason to stream 50 MB of lattice
   - voxel flat index is x*n*n + y*n + z everywhere (volume_func.h:59-66), the bitfield is kept flat + bool like the
     reference (checkpoint compatible) and a packed 1-bit copy is derived for the marcher.
 """
-import os
 
 import torch
 import torch.nn as nn
