@@ -14,6 +14,7 @@
 // xyz loads broadcast, the (n, L*F) row-major output is written fully coalesced (8 B per lane, 512 B per wave).
 // Algorithmic HBM bytes per sample (NGP config, F=2, L=16, fp32): 16*8*2*4 gathered + 12 in + 128 out = 1164 B.
 #include "common.hpp"
+#include "adam.hpp"
 
 namespace arcn {
 
@@ -931,10 +932,21 @@ scatter_bin_dir_kernel(const float *__restrict__ xyz, const float *__restrict__ 
     }
 }
 
+// Optimiser fused into the consumer (arcn_hashgrid_bwd_lm_adam): the owner of a chunk holds the chunk's COMPLETE gradient in LDS, so it
+// applies Adam (+ EMA write-back) to its rows right there - parameter and moments read and written once, the gradient never goes to
+// HBM (the separate pass re-reads it and clears it: 28 B/param; here 24 B/param and no launch) - while the other owners are still in
+// their LDS phase.  Levels with one owner per chunk only (fuse_levels); the caller runs the plain kernel on everything else.
+struct AdamFuse {
+    float *param, *m, *v;      // table segment of the flat parameter buffer / exp_avg / exp_avg_sq (row 0 of level 0)
+    AdamHyper h;
+    uint32_t fuse_levels;      // 0 = not fused
+    int32_t ema_in_param;      // EMA shadow aliased onto the parameter (else no EMA)
+};
+
 template <int F>
 __global__ void __launch_bounds__(kTiledThreads)
 scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict__ counters, GridParams g, BinPlan plan,
-                     float *__restrict__ dtable) {
+                     float *__restrict__ dtable, AdamFuse fz) {
     extern __shared__ __attribute__((aligned(16))) float acc[];
     int k = 0;
     while (k + 1 < g.L && (int)blockIdx.x >= plan.item_first[k + 1]) ++k;
@@ -949,7 +961,8 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
     cnt = cnt < cap ? cnt : cap;
     const uint32_t per = (cnt + ns - 1) / ns;
     const uint32_t lo = per * split, hi = (lo + per < cnt) ? lo + per : cnt;
-    if (lo >= hi) return;
+    const bool fused = (fz.fuse_levels >> l) & 1u;       // (Adam moves every row, touched or not: an empty bin still has work)
+    if (lo >= hi && !fused) return;
     const uint32_t row_lo = (uint32_t)chunk << plan.chunk_shift[l];
     const uint32_t row_hi_raw = row_lo + (1u << plan.chunk_shift[l]);
     const int n_rows = (int)((row_hi_raw < lp.size ? row_hi_raw : lp.size) - row_lo);
@@ -1013,7 +1026,7 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
     __syncthreads();
     const bool locked = (plan.lock_levels >> l) & 1u;
     const uint4 *pr = recs + plan.rec_first[l] + (int64_t)chunk * cap + lo;
-    const uint32_t len = hi - lo;
+    const uint32_t len = hi > lo ? hi - lo : 0u;
     // A bin is only ~32 records per thread: with one load in flight per thread the loop would be bound by memory latency.
     // Each trip takes kUnroll records per thread (the next group's loads are issued before the current group is applied).
     constexpr int kUnroll = 4;
@@ -1107,6 +1120,58 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
         }
     }
     __syncthreads();
+    if (fused) {
+        const int64_t base = ((int64_t)lp.offset + row_lo) * F;
+        float *P = fz.param + base, *M = fz.m + base, *V = fz.v + base;
+        const AdamHyper h = fz.h;
+        const int nf = n_rows * F;
+        if ((base & 3) == 0) {
+            const int n4 = nf >> 2;
+            constexpr int kB = 4;
+            for (int j0 = threadIdx.x; j0 < n4; j0 += kTiledThreads * kB) {
+                float4 p4[kB], m4[kB], v4[kB];
+#pragma unroll
+                for (int u = 0; u < kB; ++u) {
+                    const int j = j0 + u * kTiledThreads;
+                    if (j < n4) {
+                        p4[u] = reinterpret_cast<const float4 *>(P)[j];
+                        m4[u] = reinterpret_cast<const float4 *>(M)[j];
+                        v4[u] = reinterpret_cast<const float4 *>(V)[j];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kB; ++u) {
+                    const int j = j0 + u * kTiledThreads;
+                    if (j < n4) {
+                        const float4 g4 = reinterpret_cast<const float4 *>(acc)[j];
+                        float pp[4] = {p4[u].x, p4[u].y, p4[u].z, p4[u].w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
+                        float mm[4] = {m4[u].x, m4[u].y, m4[u].z, m4[u].w}, vv[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float old = pp[k];
+                            adam1(pp[k], gg[k], mm[k], vv[k], fz.ema_in_param ? &old : nullptr, h.lr, h.b1, h.b2, h.eps, h.wd, h.ema_decay,
+                                  h.gscale, h.bc1, h.bc2_sqrt, h.deb_old, h.deb_new);
+                        }
+                        reinterpret_cast<float4 *>(P)[j] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+                        reinterpret_cast<float4 *>(M)[j] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+                        reinterpret_cast<float4 *>(V)[j] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    }
+                }
+            }
+            for (int j = (n4 << 2) + threadIdx.x; j < nf; j += kTiledThreads) {
+                float old = P[j];
+                adam1(P[j], acc[j], M[j], V[j], fz.ema_in_param ? &old : nullptr, h.lr, h.b1, h.b2, h.eps, h.wd, h.ema_decay, h.gscale, h.bc1,
+                      h.bc2_sqrt, h.deb_old, h.deb_new);
+            }
+        } else {
+            for (int j = threadIdx.x; j < nf; j += kTiledThreads) {
+                float old = P[j];
+                adam1(P[j], acc[j], M[j], V[j], fz.ema_in_param ? &old : nullptr, h.lr, h.b1, h.b2, h.eps, h.wd, h.ema_decay, h.gscale, h.bc1,
+                      h.bc2_sqrt, h.deb_old, h.deb_new);
+            }
+        }
+        return;
+    }
     float *dst = dtable + ((int64_t)lp.offset + row_lo) * F;
     if (ns == 1) {
         // exclusive owner: plain coalesced 16-byte stores (+= so that callers accumulating over several launches stay correct);
@@ -1285,7 +1350,8 @@ ARCN_EXPORT int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc 
 
 static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *dout, int64_t dout_lm_stride,
                              const arcn_hashgrid_desc *desc_host, float *dtable, float *dxyz, float *workspace,
-                             int64_t workspace_floats, int64_t n, const int32_t *n_ptr, void *stream) {
+                             int64_t workspace_floats, int64_t n, const int32_t *n_ptr, void *stream, const AdamFuse *fuse = nullptr,
+                             uint32_t *fused_levels_out = nullptr) {
     if (n <= 0) return ARCN_OK;
     if (!xyz || !dout || (!dtable && !dxyz) || (dxyz && !table)) return einval("hashgrid_bwd: missing argument");
     GridParams g;
@@ -1319,8 +1385,16 @@ static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *
         dim3 bgrid((unsigned)bx, (unsigned)g.L);
         dim3 agrid((unsigned)plan.item_first[g.L]);
 #define ARCN_BIN(F_, T_) hipLaunchKernelGGL((scatter_bin_kernel<F_, T_>), bgrid, dim3(T_), 0, st_bin, xyz, dout, dout_lm_stride, g, plan, counters, recs, dtable, n, n_ptr)
-#define ARCN_ACC(F_) hipLaunchKernelGGL(scatter_accum_kernel<F_>, agrid, dim3(kTiledThreads), lds, st_acc, recs, counters, g, plan, dtable)
+#define ARCN_ACC(F_) hipLaunchKernelGGL(scatter_accum_kernel<F_>, agrid, dim3(kTiledThreads), lds, st_acc, recs, counters, g, plan, dtable, fz)
         hipStream_t st_bin = as_stream(stream), st_acc = as_stream(stream);
+        AdamFuse fz{};
+        if (fuse && !plan.det) {
+            fz = *fuse;
+            fz.fuse_levels = 0u;
+            for (int l = 0; l < g.L; ++l)
+                if (plan.n_splits[l] == 1 && ((plan.active_levels >> l) & 1u)) fz.fuse_levels |= 1u << l;
+        }
+        if (fused_levels_out) *fused_levels_out = fz.fuse_levels;
         if (g.F == 1) {
             if (bin_threads == 1024) ARCN_BIN(1, 1024); else ARCN_BIN(1, 512);
             ARCN_ACC(1);
@@ -1379,10 +1453,10 @@ ARCN_EXPORT int arcn_hashgrid_bwd_bwd(const float *xyz, const float *gdx, const 
         dim3 bgrid((unsigned)bx, (unsigned)g.L), agrid((unsigned)plan.item_first[g.L]);
         if (g.F == 1) {
             hipLaunchKernelGGL(scatter_bin_dir_kernel<1>, bgrid, dim3(1024), 0, as_stream(stream), xyz, gdx, dout, g, plan, counters, recs, dtable, n, n_ptr);
-            hipLaunchKernelGGL(scatter_accum_kernel<1>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable);
+            hipLaunchKernelGGL(scatter_accum_kernel<1>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable, AdamFuse{});
         } else {
             hipLaunchKernelGGL(scatter_bin_dir_kernel<2>, bgrid, dim3(1024), 0, as_stream(stream), xyz, gdx, dout, g, plan, counters, recs, dtable, n, n_ptr);
-            hipLaunchKernelGGL(scatter_accum_kernel<2>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable);
+            hipLaunchKernelGGL(scatter_accum_kernel<2>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable, AdamFuse{});
         }
         if ((rc = check_launch("hashgrid_bwd_bwd_binned"))) return rc;
         if (!ddout && !d2xyz) return ARCN_OK;
@@ -1403,6 +1477,39 @@ ARCN_EXPORT int arcn_hashgrid_bwd_lm(const float *xyz, const float *dout_lm, int
     if (dout_stride < n) return einval("hashgrid_bwd_lm: level stride smaller than n");
     if (!workspace) return einval("hashgrid_bwd_lm: workspace required");
     return hashgrid_bwd_impl(xyz, nullptr, dout_lm, dout_stride, desc_host, dtable, nullptr, workspace, workspace_floats, n, n_ptr, stream);
+}
+
+ARCN_EXPORT int64_t arcn_hashgrid_bwd_fusable_levels(const arcn_hashgrid_desc *desc_host, int64_t n) {
+    if (!desc_host || n <= 0) return 0;
+    GridParams g;
+    if (build_params(desc_host, g) || g.F > 2) return 0;
+    BinPlan plan;
+    if (build_bin_plan(g, n, plan) || plan.det) return 0;
+    int64_t mask = 0;
+    for (int l = 0; l < g.L; ++l)
+        if (plan.n_splits[l] == 1 && ((plan.active_levels >> l) & 1u)) mask |= (int64_t)1 << l;
+    return mask;
+}
+
+ARCN_EXPORT int arcn_hashgrid_bwd_lm_adam(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host,
+                                          float *dtable, float *table, float *exp_avg, float *exp_avg_sq, float lr, float beta1, float beta2,
+                                          float eps, float weight_decay, float ema_decay, float grad_scale, int step, int ema_step,
+                                          float *workspace, int64_t workspace_floats, int64_t n, const int32_t *n_ptr,
+                                          uint32_t *fused_levels_host, void *stream) {
+    if (dout_stride < n) return einval("hashgrid_bwd_lm_adam: level stride smaller than n");
+    if (!workspace || !table || !exp_avg || !exp_avg_sq || !fused_levels_host || step < 1)
+        return einval("hashgrid_bwd_lm_adam: missing / invalid argument");
+    if ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
+        return einval("hashgrid_bwd_lm_adam: parameter and moment buffers must be 16-byte aligned");
+    const bool ema = ema_decay >= 0.f;
+    if (ema && ema_step < 1) return einval("hashgrid_bwd_lm_adam: ema_step is 1-based");
+    AdamFuse fz{};
+    fz.param = table; fz.m = exp_avg; fz.v = exp_avg_sq;
+    fz.h = make_adam_hyper(lr, beta1, beta2, eps, weight_decay, ema ? ema_decay : 0.f, grad_scale, step, ema_step, ema);
+    fz.ema_in_param = ema ? 1 : 0;
+    *fused_levels_host = 0u;
+    return hashgrid_bwd_impl(xyz, nullptr, dout_lm, dout_stride, desc_host, dtable, nullptr, workspace, workspace_floats, n, n_ptr, stream, &fz,
+                             fused_levels_host);
 }
 
 ARCN_EXPORT int64_t arcn_hashgrid_bwd_status_offset(const arcn_hashgrid_desc *desc_host, int64_t n) {

@@ -7,26 +7,11 @@
 // in both): a caller that is the only writer of `param` passes ema == param, the kernel then takes the parameter it has just read
 // as the old average and writes no second copy (28 B/param in all, bit-identical to keeping the shadow).
 #include "common.hpp"
+#include "adam.hpp"
 
 namespace arcn {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, float *e, float lr, float b1, float b2, float eps,
-                                      float wd, float ema_decay, float gscale, float bc1, float bc2_sqrt, float deb_old,
-                                      float deb_new) {
-    g = g * gscale;
-    if (wd != 0.f) g = g + wd * p;
-    m = b1 * m + (1.0f - b1) * g;
-    v = b2 * v + (1.0f - b2) * g * g;
-    const float denom = sqrtf(v) / bc2_sqrt + eps;
-    p = p - (lr / bc1) * (m / denom);
-    if (e) {
-        const float avg = ((1.0f - ema_decay) * p + ema_decay * (*e) * deb_old) * deb_new;
-        *e = avg;
-        p = avg;
-    }
-}
 
 __global__ void __launch_bounds__(256) adam_ema_kernel(float *__restrict__ param, float *__restrict__ grad,
                                                        float *__restrict__ m, float *__restrict__ v, float *__restrict__ ema,
@@ -77,13 +62,9 @@ ARCN_EXPORT int arcn_adam_ema_step(float *param, float *grad, float *exp_avg, fl
     if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
          reinterpret_cast<uintptr_t>(exp_avg_sq) | reinterpret_cast<uintptr_t>(ema)) & 15)
         return einval("adam_ema_step: buffers must be 16-byte aligned");
-    // bias corrections in double like torch (1 - beta**step), passed as fp32
-    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     if (ema && ema_step < 1) return einval("adam_ema_step: ema_step is 1-based");
-    const double d = (double)ema_decay;
-    const float deb_old = ema ? (float)(1.0 - pow(d, (double)(ema_step - 1))) : 0.f;
-    const float deb_new = ema ? (float)(1.0 / (1.0 - pow(d, (double)ema_step))) : 0.f;
+    const AdamHyper h = make_adam_hyper(lr, beta1, beta2, eps, weight_decay, ema_decay, grad_scale, step, ema_step, ema != nullptr);
+    const float bc1 = h.bc1, bc2_sqrt = h.bc2_sqrt, deb_old = h.deb_old, deb_new = h.deb_new;
     int64_t blocks = ceil_div<int64_t>((n >> 2) + 1, 256);
     if (blocks > 2048) blocks = 2048;
     const int ema_in_param = ema == param;  // the running average lives in the parameter itself (see the file header)

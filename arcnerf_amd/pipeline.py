@@ -284,6 +284,13 @@ class NgpPipeline:
         self.fused_composite = bool(int(os.environ.get('ARCN_FUSED_COMPOSITE', '1')))
         # XCD-owned-levels scatter workspace (owner + tile counters); None selects the plain agent-scope kernel
         self.hash_ws = F.hashgrid_bwd_workspace(self.field.grid_desc, S, dev) if xcd_scatter else None  # scatter bins
+        # single-GPU step: the optimiser of the table levels whose chunks have ONE owner is applied by that owner inside the scatter
+        # (arcn_hashgrid_bwd_lm_adam); `_adam_rest` = the slices of the flat buffer the plain kernel still has to visit
+        self._adam_rest = None
+        self._fused_step = False
+        self._fuse_next = False
+        if xcd_scatter and self.hash_ws is not None and bool(int(os.environ.get('ARCN_FUSE_ADAM', '1'))) and field.n_params > 0:
+            self._adam_rest = self._plan_fused_adam(S)
         # level-major features between the hash grid and the geometry net (XCD-affine gather, coalesced everywhere): the shapes
         # the *_lm entry points are wired for; anything else keeps the row-major buffers
         self.ray_sh = (cfg.sh_degree >= 1 and field.feat_off == 0 and field.geo_out_dim % 4 == 0 and cfg.W_feat % 4 == 0 and
@@ -594,8 +601,25 @@ class NgpPipeline:
             if self.red_stream is not None:
                 self._reduce_on_side(fld.geo_desc, b['geo_scratch'], self._g('geo_w'), S)
             self._prefetch_point(2)
-            N.check(L.arcn_hashgrid_bwd_lm(N.ptr(b['xyz']), N.ptr(b['d_feat']), S, N.C.addressof(fld.grid_desc), N.ptr(self._g('table')),
-                                           N.ptr(self.hash_ws), self.hash_ws.numel(), S, n_dev.data_ptr(), st), 'hashgrid_bwd_lm')
+            if self._fuse_next and self._adam_rest is not None and self._pb is None and self._gb is None and self.ema is fld.params:
+                # scatter + optimiser of the one-owner levels in one pass (the refresh on its own stream still reads the parameters)
+                if self._occ_params_event is not None:
+                    torch.cuda.current_stream().wait_event(self._occ_params_event)
+                    self._occ_params_event = None
+                fused = N.C.c_uint32(0)
+                t_lo = fld._seg['table'][0]
+                N.check(L.arcn_hashgrid_bwd_lm_adam(N.ptr(b['xyz']), N.ptr(b['d_feat']), S, N.C.addressof(fld.grid_desc), N.ptr(self._g('table')),
+                                                    N.ptr(fld.view('table')), self.exp_avg[t_lo:].data_ptr(), self.exp_avg_sq[t_lo:].data_ptr(),
+                                                    float(cfg.lr), float(cfg.betas[0]), float(cfg.betas[1]), float(cfg.eps),
+                                                    float(cfg.weight_decay), -1.0 if cfg.ema_decay is None else float(cfg.ema_decay), 1.0, self.step_count + 1,
+                                                    self.step_count + 1, N.ptr(self.hash_ws), self.hash_ws.numel(), S, n_dev.data_ptr(),
+                                                    N.C.byref(fused), st), 'hashgrid_bwd_lm_adam')
+                assert fused.value == self._fused_mask, (fused.value, self._fused_mask)
+                self._fused_step = True
+            else:
+                N.check(L.arcn_hashgrid_bwd_lm(N.ptr(b['xyz']), N.ptr(b['d_feat']), S, N.C.addressof(fld.grid_desc), N.ptr(self._g('table')),
+                                               N.ptr(self.hash_ws), self.hash_ws.numel(), S, n_dev.data_ptr(), st), 'hashgrid_bwd_lm')
+            self._fuse_next = False
             if self.defer_dw == 1:
                 # the two tiny dW reductions run here, after the scatter, instead of between the big backward kernels where
                 # they queue behind the overlapped marching (27 us each there, 6 us here)
@@ -638,6 +662,30 @@ class NgpPipeline:
         loss, d = F.huber_loss_grad(rgb, target, cfg.huber_delta, cfg.loss_weight, dx=b['d_rgb'][:R], loss=b['loss'])
         return loss[0], d
 
+    def _plan_fused_adam(self, S):
+        """-> list of (lo, hi) slices of the flat buffer left to the plain Adam kernel when the scatter applies the optimiser to its
+        one-owner levels, or None when that form does not apply (deterministic mode, a separate EMA shadow, no such level, a slice
+        that would not start 16-byte aligned)"""
+        fld = self.field
+        mask = int(N.lib().arcn_hashgrid_bwd_fusable_levels(N.C.addressof(fld.grid_desc), int(S)))
+        if mask == 0 or 'table' not in fld._seg:
+            return None
+        t_lo, t_n = fld._seg['table'][0], fld._seg['table'][1]
+        Fq = self.cfg.n_feat_per_entry
+        cuts, pos = [], 0
+        for l in range(len(fld.resolutions)):
+            a, b_ = t_lo + fld.offsets[l] * Fq, t_lo + fld.offsets[l + 1] * Fq
+            if (mask >> l) & 1:
+                if a > pos:
+                    cuts.append((pos, a))
+                pos = b_
+        if pos < fld.n_params:
+            cuts.append((pos, fld.n_params))
+        if any(lo % 4 for lo, _ in cuts) or t_lo % 4:
+            return None
+        self._fused_mask = mask
+        return cuts
+
     def optimizer_step(self, world_size=1, lo=None, hi=None, advance=True):
         """fused Adam + EMA (+ gradient clear) on the whole flat buffer or on its slice [lo, hi) (pipelined gradient sync:
         one call per segment, `advance` only on the first so every segment sees the same step count)."""
@@ -647,10 +695,16 @@ class NgpPipeline:
             self._occ_params_event = None
         if advance:
             self.step_count += 1
-        sl = slice(lo, hi)
-        F.adam_ema_step(fld.params[sl], fld.grads[sl], self.exp_avg[sl], self.exp_avg_sq[sl], self.ema[sl], self.step_count, lr=cfg.lr,
-                        betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, ema_decay=cfg.ema_decay,
-                        grad_scale=1.0 / world_size, zero_grad=True)
+        if self._fused_step:        # the scatter of this step already updated its levels: the rest of the flat buffer
+            self._fused_step = False
+            assert lo is None and hi is None and world_size == 1
+            slices = [slice(a, b_) for a, b_ in self._adam_rest]
+        else:
+            slices = [slice(lo, hi)]
+        for sl in slices:
+            F.adam_ema_step(fld.params[sl], fld.grads[sl], self.exp_avg[sl], self.exp_avg_sq[sl], self.ema[sl], self.step_count, lr=cfg.lr,
+                            betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, ema_decay=cfg.ema_decay,
+                            grad_scale=1.0 / world_size, zero_grad=True)
 
     def train_step(self, rays_o, rays_d, target_rgb, bkg_color=None, all_reduce=None, world_size=1, next_rays=None, grad_sync=None):
         """fwd + loss + bwd (+ one gradient all-reduce) + Adam/EMA.  Returns the loss tensor (device, no sync).
@@ -666,6 +720,8 @@ class NgpPipeline:
             loss, d_rgb = self.last_loss, b['d_rgb'][:rays_o.shape[0]]
         else:
             loss, d_rgb = self.huber_grad(rgb, target_rgb)
+        # one GPU: nothing has to be summed across ranks between the scatter and the optimiser, so the scatter applies it (see backward)
+        self._fuse_next = grad_sync is None and all_reduce is None and world_size == 1
         self.backward(rays_o, rays_d, d_rgb)
         if grad_sync is not None:
             # segmented all-reduce pipelined with the optimiser (distributed.PipelinedGradSync)

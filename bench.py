@@ -116,7 +116,7 @@ TABLE_KERNELS = ROOFLINE_KERNELS + ('mlp_fwd', 'mlp_bwd', 'mlp_bwd_dw', 'march_c
 
 
 # entry points of the level-major path are reported under the name of the op they implement
-ALIASES = {'hashgrid_fwd_xcd': 'hashgrid_fwd', 'hashgrid_bwd_lm': 'hashgrid_bwd', 'mlp_fwd_lm': 'mlp_fwd', 'mlp_bwd_lm': 'mlp_bwd',
+ALIASES = {'hashgrid_fwd_xcd': 'hashgrid_fwd', 'hashgrid_bwd_lm': 'hashgrid_bwd', 'hashgrid_bwd_lm_adam': 'hashgrid_bwd', 'mlp_fwd_lm': 'mlp_fwd', 'mlp_bwd_lm': 'mlp_bwd',
            'mlp_fwd_cat': 'mlp_fwd', 'mlp_bwd_cat': 'mlp_bwd'}
 
 
@@ -586,17 +586,26 @@ def main():
             traffic, traffic_stale = None, None
     dur_s = ksum[dom] * 1e-3
     ach = hash_kernels[dom] * s_per_launch / dur_s
+    # one GPU: the scatter's consumer also applies the optimiser to the table levels it owns (arcn_hashgrid_bwd_lm_adam): that launch
+    # moves parameter + two moments in and out once, 24 B per fused parameter, on top of the scatter's own bytes
+    n_fused = 0
+    if dom == 'hashgrid_bwd' and world == 1 and getattr(pipe, '_adam_rest', None) is not None:
+        n_fused = field.n_params - sum(b_ - a_ for a_, b_ in pipe._adam_rest)
+        ach = (hash_kernels[dom] * s_per_launch + 24.0 * n_fused) / dur_s
     if dom == 'hashgrid_fwd':
         # mean over launches mixes train (S) and occupancy-refresh (n_cells/2) sizes: weight the bytes accordingly
         occ_launch = 0 if args.no_occ_update else sum(1 for e in range(epoch0 + args.warmup, epoch0 + args.warmup + args.steps) if e % cfg.epoch_optim == 0)
         occ_pts = cfg.n_grid ** 3 // 4 + min(cfg.n_grid ** 3 // 4, int(bf.sum()))
         tot_pts = s_per_launch * args.steps + occ_pts * occ_launch
         ach = BYTES_HASH_FWD * tot_pts / (dur_s * n_launch[dom])
-    roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+    roofline = {'kernel': dom if not n_fused else 'hashgrid_bwd (binned scatter) + Adam / EMA of the table levels its chunk owners hold (arcn_hashgrid_bwd_lm_adam)', 'bound': 'hbm', 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                 'frac': ach / HBM_PEAK, 'traffic': traffic, 'avg_launch_ms': ksum[dom],
                 # PMC counters cannot be collected inside a timed run: the figure is the per-launch HBM bytes of the committed
                 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/profile_round.sh)
-                'traffic_source': 'profiles/pmc_traffic.json' if traffic is not None else None, 'traffic_stale': traffic_stale}
+                'traffic_source': 'profiles/pmc_traffic.json' if traffic is not None else None, 'traffic_stale': traffic_stale,
+                'algorithmic_bytes_per_launch': {'scatter': hash_kernels[dom] * s_per_launch, 'fused_optimizer': 24.0 * n_fused},
+                'fused_optimizer_params': n_fused,
+                'frac_scatter_bytes_only': hash_kernels[dom] * s_per_launch / dur_s / HBM_PEAK}
 
     # The hash LOOKUP on its own (north_star names it): besides the algorithmic HBM accounting, the bound this gather actually
     # sits on.  Every 8-byte corner read of a hashed level drags one 128-byte line from the XCD's L2 into the CU's L1

@@ -234,6 +234,20 @@ int64_t arcn_hashgrid_bwd_status_offset(const arcn_hashgrid_desc *desc, int64_t 
 int arcn_hashgrid_bwd_lm(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host,
                          float *dtable, float *workspace, int64_t workspace_floats, int64_t n, const int32_t *n_ptr,
                          void *stream);
+/* arcn_hashgrid_bwd_lm with the OPTIMISER fused into the scatter's consumer (single-GPU training step; with several ranks the summed
+ * gradient only exists after the all-reduce, so they keep the two calls): the owner workgroup of a table chunk holds the chunk's complete
+ * gradient in LDS and applies arcn_adam_ema_step's update (torch.optim.Adam + EMA.ema_step written back, arcnerf/trainer/ema.py:29-43) to
+ * its rows of `table` / `exp_avg` / `exp_avg_sq` (each pointing at row 0 of level 0) - the gradient of those levels never goes to HBM.
+ * Applies to the levels with one owner per chunk; *fused_levels_host (HOST pointer) receives their bit mask, the other levels' gradient is
+ * accumulated into dtable as usual and the caller runs arcn_adam_ema_step on their rows (and on every other parameter).
+ * ema_decay < 0: plain Adam; >= 0: the EMA with its shadow aliased onto the parameter (the ema == param form of arcn_adam_ema_step).
+ * Not available with ARCN_DETERMINISTIC=1 (mask 0: nothing fused, plain scatter). */
+/* bit mask of the levels arcn_hashgrid_bwd_lm_adam would apply the optimiser to for a workspace plan of n samples (0: none) */
+int64_t arcn_hashgrid_bwd_fusable_levels(const arcn_hashgrid_desc *desc_host, int64_t n);
+int arcn_hashgrid_bwd_lm_adam(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host, float *dtable,
+                              float *table, float *exp_avg, float *exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, float ema_decay, float grad_scale, int step, int ema_step, float *workspace,
+                              int64_t workspace_floats, int64_t n, const int32_t *n_ptr, uint32_t *fused_levels_host, void *stream);
 
 /* FreqEmbedder.forward (encoding/freq_encoder.py:65-88): out (n, D*(include_input + 2*n_freqs)). */
 int arcn_freq_fwd(const float *x, int D, int n_freqs, int include_input, float *out, int64_t n, void *stream);

@@ -366,3 +366,46 @@ def test_fused_marcher_equals_three_pass_form(gpu, R, cap):
         assert torch.equal(x, y)
     if cap == 9000:
         assert a[0] == 9000      # clamped
+
+
+def test_scatter_with_fused_optimiser_equals_scatter_then_adam():
+    """arcn_hashgrid_bwd_lm_adam (single-GPU step: the owner of a table chunk applies Adam + EMA to its rows inside the scatter) against
+    the two-pass form several ranks run (arcn_hashgrid_bwd_lm, then arcn_adam_ema_step): from the same state and batch the first moment
+    (= (1 - beta1) x the gradient: 1e-5 of its max - the float scatter's own order noise), the second moment, and the parameters (all
+    but a handful within 2 % of the step, Adam's eps 1e-15 amplifies noise on near-zero gradients); the levels the scatter does not
+    fuse and the MLP weights go through the plain kernel in both forms; three steps, the step counters stay in line."""
+    import os
+    from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline, synthetic_bitfield, synthetic_rays
+    dev = torch.device('cuda:0')
+    cfg = NgpConfig(noise_std=0.0, lr=1e-2)
+    res = {}
+    for fused in (True, False):
+        os.environ['ARCN_FUSE_ADAM'] = '1' if fused else '0'
+        try:
+            fld = NgpField(cfg, device=dev, seed=3)
+            fld.view('table').mul_(1000.0)
+            pipe = NgpPipeline(fld, max_rays=4096, max_samples=1 << 19)
+        finally:
+            os.environ.pop('ARCN_FUSE_ADAM')
+        assert (pipe._adam_rest is not None) == fused
+        pipe.set_bitfield(torch.from_numpy(synthetic_bitfield(cfg.n_grid, 0.05, seed=5)))
+        g = torch.Generator().manual_seed(11)
+        p0 = fld.params.clone()
+        for i in range(3):
+            o, d = synthetic_rays(4096, seed=40 + i, device=dev)
+            pipe.train_step(o, d, torch.rand(4096, 3, generator=g).to(dev), bkg_color=torch.rand(4096, 3, generator=g).to(dev))
+            if i == 0:
+                first = (pipe.exp_avg.clone(), pipe.exp_avg_sq.clone(), fld.params.clone())
+        torch.cuda.synchronize()
+        assert pipe.step_count == 3 and float(fld.grads.abs().max()) == 0.0        # every gradient consumed and cleared
+        res[fused] = (first, fld.params.clone(), p0)
+    if True:
+        rest = NgpPipeline(NgpField(cfg, device=dev, seed=3), max_rays=4096, max_samples=1 << 19)._adam_rest
+        assert rest and rest[0][0] == 0 and sum(b - a for a, b in rest) < 0.1 * res[True][1].numel()      # > 90 % of the parameters fused
+    (m_a, v_a, p_a), (m_b, v_b, p_b) = res[True][0], res[False][0]
+    assert float((m_a - m_b).abs().max()) <= 1e-5 * float(m_b.abs().max())
+    assert float((v_a - v_b).abs().max()) <= 1e-5 * float(v_b.abs().max())
+    step = float((p_b - res[False][2]).abs().max())
+    assert step > 1e-3 and float(((p_a - p_b).abs() > 0.02 * step).float().mean()) < 1e-3
+    far = ((res[True][1] - res[False][1]).abs() > 0.05 * float((res[False][1] - res[False][2]).abs().max())).float().mean()
+    assert float(far) < 5e-3

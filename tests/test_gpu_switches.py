@@ -25,6 +25,7 @@ GROUPS = {
         # starts), so the trajectory is another draw of the same training - compared through the loss it reaches, not bit by bit
         {'ARCN_PREFETCH_DEPTH': '1'},
         {'ARCN_DETERMINISTIC': '1'},     # the order-independent fixed-point scatter: same gradients as the float one
+        {'ARCN_FUSE_ADAM': '0'},         # scatter and optimiser as two passes (what several ranks run) instead of the fused consumer
     ],
     'nets': [
         {'ARCN_GEMM_SPLIT': '0', 'ARCN_LINEAR_FUSED_RELU': '0', 'ARCN_LINEAR_SOFTPLUS': '0', 'ARCN_TONEMAP_FUSED': '0', 'ARCN_NEUS_UPSAMPLE_GRAPH': '1'},
