@@ -60,7 +60,7 @@ def main(root):
     out['_detail'] = detail
     # which kernels were measured: bench.py compares these with the sources it runs on and reports `traffic_stale` on a mismatch
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'arcnerf_amd', 'csrc')
-    out['_source_sha256'] = {f: hashlib.sha256(open(os.path.join(csrc, f), 'rb').read()).hexdigest() for f in ('hashgrid.hip', 'mlp.hip', 'optim.hip', 'common.hpp')}
+    out['_source_sha256'] = {f: hashlib.sha256(open(os.path.join(csrc, f), 'rb').read()).hexdigest() for f in ('hashgrid.hip', 'mlp.hip', 'optim.hip', 'adam.hpp', 'common.hpp')}
     out['_note'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 8 --warmup 4), median over the '
                     'training launches, KiB*1024, summed over the kernels of an entry point (mlp_* = the two nets of a step are '
                     'different launches of one kernel: value is their median). FETCH_SIZE doubled per MI355X_MICROARCH.md '
