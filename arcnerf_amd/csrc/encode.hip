@@ -29,6 +29,29 @@ __global__ void __launch_bounds__(256) freq_fwd_kernel(const float *__restrict__
     }
 }
 
+// the same encoding written into n_cols >= od columns of a wider row-major buffer (row stride ld_out): columns od .. n_cols - 1 are set to
+// zero (the pad of an odd width up to the 16-byte row granule of the products that read the buffer)
+__global__ void __launch_bounds__(256) freq_fwd_cols_kernel(const float *__restrict__ x, int D, int n_freqs, int include_input,
+                                                            float *__restrict__ out, int64_t ld_out, int n_cols, int64_t n) {
+    const int od = D * (include_input ? 1 : 0) + 2 * D * n_freqs;
+    const int64_t total = n * n_cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / n_cols;
+        int c = (int)(i - s * n_cols);
+        float *o = out + s * ld_out + c;
+        if (c >= od) { *o = 0.f; continue; }
+        if (include_input) {
+            if (c < D) { *o = x[s * D + c]; continue; }
+            c -= D;
+        }
+        const int f = c / (2 * D);
+        const int rem = c - f * 2 * D;
+        const int k = rem % D;
+        const float a = x[s * D + k] * ldexpf(1.0f, f);
+        *o = rem < D ? sinf(a) : cosf(a);
+    }
+}
+
 __global__ void __launch_bounds__(256) freq_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dout, int D,
                                                        int n_freqs, int include_input, float *__restrict__ dx, int64_t n) {
     const int od = D * (include_input ? 1 : 0) + 2 * D * n_freqs;
@@ -432,6 +455,20 @@ ARCN_EXPORT int arcn_freq_fwd(const float *x, int D, int n_freqs, int include_in
     hipLaunchKernelGGL(freq_fwd_kernel, dim3(grid_for(n * od)), dim3(256), 0, as_stream(stream), x, D, n_freqs,
                        include_input, out, n);
     return check_launch("freq_fwd");
+}
+
+/* arcn_freq_fwd into columns of a wider buffer: row s of the encoding goes to out[s * ld_out + 0 .. od - 1], the columns od .. n_cols - 1
+ * behind it are zeroed (freq_encoder.py:10-88; the skip / radiance-input concatenations of linear_network_module.py:174-197 and
+ * encoder_mlp_network.py:62-118 then need no copy of the encoding) */
+ARCN_EXPORT int arcn_freq_fwd_cols(const float *x, int D, int n_freqs, int include_input, float *out, int64_t ld_out, int n_cols, int64_t n,
+                                   void *stream) {
+    if (n <= 0) return ARCN_OK;
+    const int od = D * (include_input ? 1 : 0) + 2 * D * n_freqs;
+    if (!x || !out || D < 1 || n_freqs < 0 || (n_freqs == 0 && !include_input) || n_cols < od || ld_out < n_cols)
+        return einval("freq_fwd_cols: bad argument");
+    hipLaunchKernelGGL(freq_fwd_cols_kernel, dim3(grid_for(n * n_cols)), dim3(256), 0, as_stream(stream), x, D, n_freqs, include_input, out, ld_out,
+                       n_cols, n);
+    return check_launch("freq_fwd_cols");
 }
 
 ARCN_EXPORT int arcn_freq_bwd(const float *x, const float *dout, int D, int n_freqs, int include_input, float *dx,

@@ -885,9 +885,27 @@ ARCN_EXPORT int64_t arcn_gemm_split_bytes(int n_out, int k_red) {
     return (int64_t)(ceil_div<int>(k_red, 32) + 1) * ceil_div<int>(n_out, 16) * 3 * 64 * 16;
 }
 
+static void split_weights(const float *W, int ld_w, bool trans_w, int No, int Ki, void *ws, void *stream) {
+    const int frag_tiles = (ceil_div<int>(Ki, 32) + 1) * ceil_div<int>(No, 16);
+    hipLaunchKernelGGL(gemm_split_w_kernel, dim3((unsigned)ceil_div<int>(frag_tiles, 4)), dim3(256), 0, as_stream(stream), W, ld_w, trans_w ? 1 : 0, No, Ki,
+                       reinterpret_cast<gu4 *>(ws));
+}
+
+/* The weight operand of arcn_gemm_nt_split (transposed = 0: w (n_out, k_red) row-major, row stride ld_w) or of arcn_gemm_nn_split
+ * (transposed = 1: w (k_red, n_out), the layer's weight used the other way round) as three bf16 planes in MFMA fragment order, written to
+ * ws (>= arcn_gemm_split_bytes(n_out, k_red) bytes).  A caller that evaluates the same layer on several chunks of samples splits once
+ * and passes ws_ready = 1 to the products (linear_network_module.py:174-197 runs under chunk_processing: 8 chunks per training step). */
+ARCN_EXPORT int arcn_gemm_split_weights(const float *w, int ld_w, int transposed, int n_out, int k_red, void *ws, int64_t ws_bytes, void *stream) {
+    if (!w || !ws || n_out < 1 || k_red < 1 || ld_w < (transposed ? n_out : k_red)) return einval("gemm_split_weights: missing / invalid argument");
+    if ((reinterpret_cast<uintptr_t>(ws) & 15u) != 0 || ws_bytes < arcn_gemm_split_bytes(n_out, k_red))
+        return einval("gemm_split_weights: workspace misaligned or smaller than arcn_gemm_split_bytes");
+    split_weights(w, ld_w, transposed != 0, n_out, k_red, ws, stream);
+    return check_launch("gemm_split_weights");
+}
+
 static int gemm_rows_split(bool trans_w, const float *in, const float *mask, const uint32_t *mask_bits, int64_t ld_in, const float *W, int ld_w,
                            const float *bias, float *out, uint32_t *relu_bits, int64_t ld_out, int64_t S, const int32_t *n_ptr, int Ki, int No, int act,
-                           float beta, void *ws, int64_t ws_bytes, void *stream) {
+                           float beta, void *ws, int64_t ws_bytes, int ws_ready, void *stream) {
     if (S <= 0) return ARCN_OK;
     if (!in || !W || !out || !ws || Ki < 1 || No < 1) return einval("gemm_split: missing / invalid argument");
     if (!is_aligned(in, ld_in) || (Ki & 3) != 0 || (reinterpret_cast<uintptr_t>(ws) & 15u) != 0 || (mask && !is_aligned(mask, ld_in)))
@@ -897,9 +915,7 @@ static int gemm_rows_split(bool trans_w, const float *in, const float *mask, con
     const int mk = mask_bits ? 2 : (mask ? 1 : 0);
     if (mask_bits) mask = reinterpret_cast<const float *>(mask_bits);
     if (ws_bytes < arcn_gemm_split_bytes(No, Ki)) return einval("gemm_split: workspace smaller than arcn_gemm_split_bytes");
-    const int frag_tiles = (ceil_div<int>(Ki, 32) + 1) * ceil_div<int>(No, 16);
-    hipLaunchKernelGGL(gemm_split_w_kernel, dim3((unsigned)ceil_div<int>(frag_tiles, 4)), dim3(256), 0, as_stream(stream), W, ld_w, trans_w ? 1 : 0, No, Ki,
-                       reinterpret_cast<gu4 *>(ws));
+    if (!ws_ready) split_weights(W, ld_w, trans_w, No, Ki, ws, stream);   // (ws_ready: the caller did, arcn_gemm_split_weights)
     const int oa = is_aligned(out, ld_out);
     const unsigned gx = (unsigned)ceil_div<int64_t>(S, 128);
     static const int big = 1;
@@ -945,16 +961,17 @@ static int gemm_rows_split(bool trans_w, const float *in, const float *mask, con
  * NULL; act = ReLU, N % 4 == 0): ceil(n_rows / 8) x N / 4 words, word [s / 8][f / 4] bit 4 (s % 8) + (f % 4) = (y[s][f] > 0) - the mask
  * the layer's backward needs, 1/32 of the bytes of y. */
 ARCN_EXPORT int arcn_gemm_nt_split(const float *x, int64_t ld_x, const float *w, const float *bias, float *y, uint32_t *relu_bits, int64_t ld_y,
-                                   int64_t n_rows, const int32_t *n_ptr, int K, int N, int act, float beta, void *ws, int64_t ws_bytes, void *stream) {
-    return gemm_rows_split(false, x, nullptr, nullptr, ld_x, w, K, bias, y, relu_bits, ld_y, n_rows, n_ptr, K, N, act, beta, ws, ws_bytes, stream);
+                                   int64_t n_rows, const int32_t *n_ptr, int K, int N, int act, float beta, void *ws, int64_t ws_bytes, int ws_ready,
+                                   void *stream) {
+    return gemm_rows_split(false, x, nullptr, nullptr, ld_x, w, K, bias, y, relu_bits, ld_y, n_rows, n_ptr, K, N, act, beta, ws, ws_bytes, ws_ready, stream);
 }
 
 /* arcn_gemm_nn likewise: dy rows 16-byte aligned, N a multiple of 4; `ws` = arcn_gemm_split_bytes(K, N) bytes.  mask_bits (may be NULL,
  * then `mask` applies): the relu_bits of the layer's forward instead of its float output as the mask. */
 ARCN_EXPORT int arcn_gemm_nn_split(const float *dy, const float *mask, const uint32_t *mask_bits, int64_t ld_dy, const float *w, float *dx, int64_t ld_dx,
-                                   int64_t n_rows, const int32_t *n_ptr, int N, int K, void *ws, int64_t ws_bytes, void *stream) {
+                                   int64_t n_rows, const int32_t *n_ptr, int N, int K, void *ws, int64_t ws_bytes, int ws_ready, void *stream) {
     return gemm_rows_split(true, dy, mask, mask_bits, ld_dy, w, K, nullptr, dx, nullptr, ld_dx, n_rows, n_ptr, N, K, ARCN_ACT_NONE, 1.0f, ws, ws_bytes,
-                           stream);
+                           ws_ready, stream);
 }
 
 ARCN_EXPORT int64_t arcn_gemm_tn_scratch_floats(int64_t n_rows, int N, int K) {

@@ -99,10 +99,20 @@ class Base3dModel(nn.Module):
         sigma, feature = geo_net(pts)
         return sigma[..., 0], radiance_net(pts, rays_d, None, feature)
 
+    def field_on_points(self, geo_net, radiance_net, pts, dirs):
+        """(sigma (n), radiance (n, 3)) for points / directions in chunks of chunk_pts: one autograd node where the two nets are the
+        plain frequency-encoded ReLU stacks (ops.field_chain), else _forward_pts_dir per chunk as the reference has it
+        (base_3d_model.py:335-366)"""
+        from ..ops.field_chain import field_chain
+        out = field_chain(geo_net, radiance_net, pts, dirs, self.chunk_pts)
+        if out is not None:
+            return out
+        return chunk_processing(self._forward_pts_dir, self.chunk_pts, False, geo_net, radiance_net, pts, dirs)
+
     def forward_pts_dir(self, pts, view_dir=None):
         geo_net, radiance_net = self.get_net()
         rays_d = torch.zeros_like(pts) if view_dir is None else normalize(view_dir)
-        return chunk_processing(self._forward_pts_dir, self.chunk_pts, False, geo_net, radiance_net, pts, rays_d)
+        return self.field_on_points(geo_net, radiance_net, pts, rays_d)
 
     def forward_pts(self, pts):
         geo_net, _ = self.get_net()

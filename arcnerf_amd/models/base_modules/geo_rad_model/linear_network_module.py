@@ -116,6 +116,15 @@ class GeoNet(EncoderMLPGeoNet):
             if i == self.D and self.W_feat > 0 and type(self.layers[i]) is Linear and not hasattr(self.layers[i], 'weight_g'):
                 from ....ops.autograd import linear
                 out = linear(out, self.layers[i].weight, self.layers[i].bias, keep_pad=True)    # handle_output splits the padded tensor
+            elif i in self.skips and type(self.layers[i]) is DenseLayer and type(self.layers[i].activation) is nn.ReLU and \
+                    not hasattr(self.layers[i], 'weight_g'):
+                # the layer in front of a skip concatenation writes its columns of the concatenated tensor itself
+                from ....ops.autograd import linear_relu_cat
+                cat = linear_relu_cat(out, self.layers[i].weight, self.layers[i].bias, x_embed)
+                out = cat if cat is not None else torch.cat([self.layers[i](out), x_embed], dim=-1)
+                if self.norm_skip:
+                    out = out / math.sqrt(2)
+                continue
             else:
                 out = self.layers[i](out)
             if i in self.skips:

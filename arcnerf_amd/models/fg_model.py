@@ -155,8 +155,7 @@ class FgModel(Base3dModel):
             dirs = rays_d.index_select(0, torch.div(flat, n_pts, rounding_mode='floor'))   # the expanded view is never materialised
             if not inference_only:
                 self.adjust_dynamicbs_factor(mask_pts)
-        _sigma, _radiance = chunk_processing(self._forward_pts_dir, self.chunk_pts, False, geo_net, radiance_net, pts.contiguous(),
-                                             dirs.contiguous())
+        _sigma, _radiance = self.field_on_points(geo_net, radiance_net, pts.contiguous(), dirs.contiguous())
         if mask_pts is None:
             return _sigma.view(n_rays, -1), _radiance.view(n_rays, -1, 3)
         last = torch.cumsum(mask_pts.sum(dim=1), dim=0) - 1

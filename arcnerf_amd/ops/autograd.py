@@ -526,6 +526,11 @@ class LinearReluFn(torch.autograd.Function):
         # masked gradient products read dy + bits instead of dy + y
         n_out, k_in = w.shape
         ctx.has_bias = bias is not None
+        # the weight split of the input-gradient product, taken now where one forward runs the layer on several chunks (one split for
+        # all of them, F.split_weight_scope); None: the backward product splits for itself
+        ctx.ws_nn = None
+        if ctx.needs_input_grad[0] and F.in_split_scope() and F._use_split(x, n_out, k_in):
+            ctx.ws_nn = F.split_weights(w, True)
         if any(ctx.needs_input_grad) and F.relu_bits_supported(x, k_in, n_out) and F._use_split(x, n_out, k_in) and n_out > 64:
             y, bits = F.gemm_nt(x, w, bias, act='relu', want_bits=True)
             ctx.use_bits = True
@@ -555,7 +560,7 @@ class LinearReluFn(torch.autograd.Function):
         if g.data_ptr() % 16 != 0:
             g = g.clone()      # a view at an odd offset: the masked forms of the products want 16-byte aligned rows (a fresh buffer is)
         kw = {'mask_bits': m} if ctx.use_bits else {'mask': m}
-        dx = F.gemm_nn(g, w, **kw) if ctx.needs_input_grad[0] else None
+        dx = F.gemm_nn(g, w, ws=ctx.ws_nn, **kw) if ctx.needs_input_grad[0] else None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         dw = db = None
         if ctx.needs_input_grad[1] and want_db:
@@ -567,6 +572,78 @@ class LinearReluFn(torch.autograd.Function):
         return dx, dw, db
 
 
+class LinearReluCatFn(torch.autograd.Function):
+    """cat([relu(x @ w.T + bias), tail], -1) - a DenseLayer followed by the skip concatenation of GeoNet
+    (linear_network_module.py:174-197) - without the concatenation pass: the product writes its columns of the (S, N + T) result at
+    that row stride, the tail is one strided copy of T columns (64 of 320 for the positional embedding), and the gradient products read
+    their N columns of the incoming gradient in place.  N and N + T multiples of 4 (16-byte aligned rows)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, tail):
+        n_out, k_in = w.shape
+        S, T = x.shape[0], tail.shape[1]
+        ctx.has_bias, ctx.n_out = bias is not None, n_out
+        buf = torch.empty((S, n_out + T), dtype=torch.float32, device=x.device)
+        y = buf[:, :n_out]
+        ctx.ws_nn = None
+        if ctx.needs_input_grad[0] and F.in_split_scope() and F._use_split(x, n_out, k_in):
+            ctx.ws_nn = F.split_weights(w, True)
+        if any(ctx.needs_input_grad[:3]) and F.relu_bits_supported(x, k_in, n_out) and F._use_split(x, n_out, k_in) and n_out > 64:
+            _, bits = F.gemm_nt(x, w, bias, act='relu', want_bits=True, out=y)
+            ctx.use_bits = True
+            ctx.save_for_backward(x, w, bits, bias if bias is not None else x.new_empty(0))
+        else:
+            F.gemm_nt(x, w, bias, act='relu', out=y)
+            ctx.use_bits = False
+            ctx.save_for_backward(x, w, buf, x.new_empty(0))
+        buf[:, n_out:].copy_(tail)
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, m, bias = ctx.saved_tensors
+        n = ctx.n_out
+        g = g.contiguous()
+        d_tail = g[:, n:] if ctx.needs_input_grad[3] else None
+        if torch.is_grad_enabled():      # create_graph: see LinearReluFn.backward
+            with torch.no_grad():
+                y = F.gemm_nt(x, w, bias if ctx.has_bias else None, act='relu') if ctx.use_bits else m[:, :n]
+                mask = (y > 0).to(g.dtype)
+            gm = g[:, :n] * mask
+            dx = GemmNN.apply(gm, w) if ctx.needs_input_grad[0] else None
+            dw = GemmTN.apply(gm, x) if ctx.needs_input_grad[1] else None
+            db = gm.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            return dx, dw, db, d_tail
+        if g.data_ptr() % 16 != 0:
+            g = g.clone()
+            d_tail = g[:, n:] if ctx.needs_input_grad[3] else None
+        gv = g[:, :n]
+        kw = {'mask_bits': m} if ctx.use_bits else {'mask': m[:, :n]}
+        dx = F.gemm_nn(gv, w, ws=ctx.ws_nn, **kw) if ctx.needs_input_grad[0] else None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dw = db = None
+        if ctx.needs_input_grad[1] and want_db:
+            dw, db = F.gemm_tn(gv, x, want_colsum=True, **kw)
+        elif ctx.needs_input_grad[1]:
+            dw = F.gemm_tn(gv, x, **kw)
+        elif want_db:
+            db = F.gemm_tn(gv, F._ones_cols(g.shape[0], g.device), **kw)[:, 0].contiguous()
+        return dx, dw, db, d_tail
+
+
+def linear_relu_cat(x, weight, bias, tail):
+    """cat([relu(F.linear(x, weight, bias)), tail], -1) with the layer's product writing straight into the concatenated buffer
+    (LinearReluCatFn); None where that form does not apply (the caller then concatenates as the reference does)"""
+    import os
+    n_out, k_in = weight.shape
+    if not _use_hip_linear(x, weight) or os.environ.get('ARCN_LINEAR_FUSED_RELU', '1') == '0' or os.environ.get('ARCN_SKIP_CAT_FUSED', '1') == '0':
+        return None
+    if x.dim() != 2 or tail.dim() != 2 or tail.dtype != torch.float32 or n_out % 4 or (n_out + tail.shape[1]) % 4 or tail.shape[0] != x.shape[0]:
+        return None
+    x2, w, b, _, npad = _padded_operands(x, weight, bias)
+    return LinearReluCatFn.apply(x2, w, b, tail)
+
+
 def _padded_operands(x, weight, bias):
     """the kernels move 16 bytes per lane when every row starts 16-byte aligned: feature dimensions that are not multiples of 4 (63,
     319, 283 inputs; 257, 17, 3 outputs) are zero-padded - the weight / bias pads are tiny, the input pad is one copy, and the padded
@@ -574,8 +651,9 @@ def _padded_operands(x, weight, bias):
     n_out, k_in = weight.shape
     kp, npad = (-k_in) % 4, (-n_out) % 4
     pad = torch.nn.functional.pad
-    w = pad(weight, (0, kp, 0, npad)) if (kp or npad) else weight
-    b = pad(bias, (0, npad)) if (bias is not None and npad) else bias
+    # (under chunk_processing the padded forms are made once for all chunks: one pad, one node for the chunks' gradients to meet in)
+    w = F.scope_cached(('padw', weight.data_ptr(), weight._version, n_out, k_in), weight, lambda: pad(weight, (0, kp, 0, npad))) if (kp or npad) else weight
+    b = F.scope_cached(('padb', bias.data_ptr(), bias._version, n_out), bias, lambda: pad(bias, (0, npad))) if (bias is not None and npad) else bias
     x2 = x.reshape(-1, x.shape[-1])
     if x2.shape[-1] == k_in + kp:      # already padded by the caller (pad_cols4: one pad shared by a layer input and a skip concat)
         x2 = x2.contiguous()

@@ -4,6 +4,7 @@ torch is used for device memory and the current HIP stream only; every numerical
 gfx950 kernel in libarcnerf_hip.so.  All functions require CUDA(HIP) tensors and raise RuntimeError otherwise —
 there is deliberately no CPU fallback.
 """
+import contextlib
 import os
 import ctypes as C
 
@@ -458,6 +459,18 @@ def freq_fwd(x, n_freqs, include_input=True):
     return out
 
 
+def freq_fwd_cols(x, n_freqs, include_input, out):
+    """the encoding of x (n, D) into the columns of `out`, a (n, n_cols) column slice of a wider row-major buffer; columns behind the
+    encoding's own width are zeroed"""
+    _req(x, out)
+    x = _f32(x)
+    n, D = x.shape
+    assert out.dim() == 2 and out.shape[0] == n and out.dtype == torch.float32 and out.stride(1) == 1
+    N.check(N.lib().arcn_freq_fwd_cols(N.ptr(x), D, int(n_freqs), int(include_input), out.data_ptr(), out.stride(0) if n > 1 else out.shape[1],
+                                     out.shape[1], n, N.stream()), 'freq_fwd_cols')
+    return out
+
+
 def freq_bwd(x, dout, n_freqs, include_input=True):
     _req(x, dout)
     x, dout = _f32(x), _f32(dout)
@@ -618,76 +631,175 @@ def _split_ws(n_out, k_red, device):
     return torch.empty(int(N.lib().arcn_gemm_split_bytes(n_out, k_red)), dtype=torch.uint8, device=device)
 
 
+# The weights of a layer as split bf16 planes, ONCE for all the chunks of samples one forward pass runs the layer on (chunk_processing
+# opens the scope around its loop: the arguments it does not slice - the networks - are the same objects in every iteration).  Inside
+# a scope the split of a weight tensor is kept under its storage address (the tensor itself is kept too, so the address cannot be
+# handed out again) together with the zero-padded forms ops.autograd makes of odd-width layers; outside nothing is cached and every
+# product splits for itself.
+_SPLIT_SCOPE = None
+_SPLIT_SCOPE_ON = os.environ.get('ARCN_SPLIT_SCOPE', '1') != '0'     # 0: every product splits its weights itself (A/B)
+
+
+@contextlib.contextmanager
+def split_weight_scope():
+    global _SPLIT_SCOPE
+    opened = _SPLIT_SCOPE is None and _SPLIT_SCOPE_ON
+    if opened:
+        _SPLIT_SCOPE = {}
+    try:
+        yield
+    finally:
+        if opened:
+            _SPLIT_SCOPE = None
+
+
+def scope_cached(key, keep, make):
+    """make() once per split_weight_scope for `key` (anything hashable naming tensors by address; `keep` = those tensors, held so
+    that the addresses stay theirs); plain make() outside a scope"""
+    if _SPLIT_SCOPE is None:
+        return make()
+    hit = _SPLIT_SCOPE.get(key)
+    if hit is None:
+        hit = (make(), keep)
+        _SPLIT_SCOPE[key] = hit
+    return hit[0]
+
+
+def split_weights(w, transposed):
+    """ws of arcn_gemm_split_weights for the layer weight w (N, K): transposed = False for gemm_nt (outputs N, reduction K), True for
+    gemm_nn (outputs K, reduction N)"""
+    Nn, K = w.shape
+    n_out, k_red = (K, Nn) if transposed else (Nn, K)
+
+    def make():
+        ws = _split_ws(n_out, k_red, w.device)
+        N.check(N.lib().arcn_gemm_split_weights(N.ptr(w), K, 1 if transposed else 0, n_out, k_red, N.ptr(ws), ws.numel(), N.stream()), 'gemm_split_weights')
+        return ws
+    return scope_cached(('split', w.data_ptr(), w._version, Nn, K, bool(transposed)), w, make)
+
+
+def in_split_scope():
+    return _SPLIT_SCOPE is not None
+
+
 def relu_bits_supported(rows, k_red, n_out):
     """whether gemm_nt(..., want_bits=True) can write the ReLU mask of its output as bits (split kernels, outputs in multiples of 32)"""
     return _use_split(rows, k_red, n_out) and n_out % 4 == 0 and os.environ.get('ARCN_RELU_BITS', '1') != '0'
 
 
-def gemm_nt(x, w, bias=None, act=None, beta=1.0, want_bits=False):
+def _rows(t):
+    """(tensor, leading dimension) of a 2-D fp32 row operand: a column slice of a wider row-major buffer (unit column stride) is taken
+    as it is - the kernels read and write rows at any stride -, anything else is made contiguous"""
+    if t is None:
+        return None, 0
+    if t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) == 1 and t.stride(0) >= t.shape[1] and t.shape[0] > 1:
+        return t, t.stride(0)
+    t = t.contiguous().float()
+    return t, t.shape[1]
+
+
+def _aligned_rows(t, ld):
+    return t.data_ptr() % 16 == 0 and ld % 4 == 0
+
+
+def gemm_nt(x, w, bias=None, act=None, beta=1.0, want_bits=False, ws=None, out=None):
     """y (S,N) = act(x (S,K) @ w (N,K).T + bias); want_bits (act = relu, relu_bits_supported): also the (ceil(S / 8), N / 4) int32 words
-    [s // 8, f // 4] whose bit 4 (s % 8) + (f % 4) is (y[s, f] > 0) - the mask gemm_nn / gemm_tn take as `mask_bits` (1/32 of y's bytes)"""
-    _req(x, w, bias)
-    x, w, bias = _f32(x), _f32(w), _f32(bias)
+    [s // 8, f // 4] whose bit 4 (s % 8) + (f % 4) is (y[s, f] > 0) - the mask gemm_nn / gemm_tn take as `mask_bits` (1/32 of y's bytes).
+    x and `out` (where the result goes if given) may be column slices of wider row-major buffers; ws: split_weights(w, False)"""
+    _req(x, w, bias, out)
+    (x, ld_x), w, bias = _rows(x), _f32(w), _f32(bias)
     S, K = x.shape
     Nn = w.shape[0]
     assert w.shape[1] == K
-    y = torch.empty((S, Nn), dtype=torch.float32, device=x.device)
-    if _use_split(x, K, Nn):
-        ws = _split_ws(Nn, K, x.device)
+    if out is None:
+        y, ld_y = torch.empty((S, Nn), dtype=torch.float32, device=x.device), Nn
+    else:
+        y, ld_y = out, out.stride(0)
+        assert out.shape == (S, Nn) and out.dtype == torch.float32 and out.stride(1) == 1
+    if _use_split(x, K, Nn) and ld_x % 4 == 0:
+        ready = ws is not None or in_split_scope()
+        if ws is None:
+            ws = split_weights(w, False) if ready else _split_ws(Nn, K, x.device)
         bits = None
         if want_bits:
             assert act == 'relu' and Nn % 4 == 0
             bits = torch.empty(((S + 7) // 8, Nn // 4), dtype=torch.int32, device=x.device)
-        N.check(N.lib().arcn_gemm_nt_split(N.ptr(x), K, N.ptr(w), N.ptr(bias), N.ptr(y), N.ptr(bits), Nn, S, None, K, Nn, N.ACT[act], float(beta),
-                                         N.ptr(ws), ws.numel(), N.stream()), 'gemm_nt_split')
+        N.check(N.lib().arcn_gemm_nt_split(x.data_ptr(), ld_x, N.ptr(w), N.ptr(bias), y.data_ptr(), N.ptr(bits), ld_y, S, None, K, Nn, N.ACT[act],
+                                         float(beta), N.ptr(ws), ws.numel(), 1 if ready else 0, N.stream()), 'gemm_nt_split')
         return (y, bits) if want_bits else y
     assert not want_bits
-    N.check(N.lib().arcn_gemm_nt(N.ptr(x), K, N.ptr(w), N.ptr(bias), N.ptr(y), Nn, S, None, K, Nn, N.ACT[act], float(beta), N.stream()), 'gemm_nt')
+    N.check(N.lib().arcn_gemm_nt(x.data_ptr(), ld_x, N.ptr(w), N.ptr(bias), y.data_ptr(), ld_y, S, None, K, Nn, N.ACT[act], float(beta), N.stream()),
+            'gemm_nt')
     return y
 
 
-def gemm_nn(dy, w, mask=None, mask_bits=None):
-    """dx (S,K) = (dy * (mask > 0)) (S,N) @ w (N,K); mask_bits: the forward's ReLU bit words instead of the float mask"""
+def gemm_nn(dy, w, mask=None, mask_bits=None, ws=None):
+    """dx (S,K) = (dy * (mask > 0)) (S,N) @ w (N,K); mask_bits: the forward's ReLU bit words instead of the float mask.  dy (and a float
+    mask, at the SAME row stride) may be column slices of wider buffers; ws: split_weights(w, True)"""
     _req(dy, w, mask, mask_bits)
-    dy, w, mask = _f32(dy), _f32(w), _f32(mask)
+    (dy, ld), w = _rows(dy), _f32(w)
+    if mask is not None:
+        mask, ld_m = _rows(mask)
+        if ld_m != ld:      # the kernels address dy and its mask with one stride
+            dy, mask = dy.contiguous(), mask.contiguous()
+            ld = dy.shape[1]
     S, Nn = dy.shape
     K = w.shape[1]
     assert w.shape[0] == Nn
     dx = torch.empty((S, K), dtype=torch.float32, device=dy.device)
-    if _use_split(dy, Nn, K):
-        ws = _split_ws(K, Nn, dy.device)
-        N.check(N.lib().arcn_gemm_nn_split(N.ptr(dy), N.ptr(mask), N.ptr(mask_bits), Nn, N.ptr(w), N.ptr(dx), K, S, None, Nn, K, N.ptr(ws), ws.numel(),
-                                         N.stream()), 'gemm_nn_split')
+    if _use_split(dy, Nn, K) and ld % 4 == 0:
+        ready = ws is not None or in_split_scope()
+        if ws is None:
+            ws = split_weights(w, True) if ready else _split_ws(K, Nn, dy.device)
+        N.check(N.lib().arcn_gemm_nn_split(dy.data_ptr(), None if mask is None else mask.data_ptr(), N.ptr(mask_bits), ld, N.ptr(w), N.ptr(dx), K, S,
+                                         None, Nn, K, N.ptr(ws), ws.numel(), 1 if ready else 0, N.stream()), 'gemm_nn_split')
         return dx
     assert mask_bits is None, 'bit masks are read by the split products only'
-    N.check(N.lib().arcn_gemm_nn(N.ptr(dy), N.ptr(mask), Nn, N.ptr(w), N.ptr(dx), K, S, None, Nn, K, N.stream()), 'gemm_nn')
+    N.check(N.lib().arcn_gemm_nn(dy.data_ptr(), None if mask is None else mask.data_ptr(), ld, N.ptr(w), N.ptr(dx), K, S, None, Nn, K, N.stream()),
+            'gemm_nn')
     return dx
 
 
-def gemm_tn(dy, x, mask=None, want_colsum=False, mask_bits=None):
+def gemm_tn(dy, x, mask=None, want_colsum=False, mask_bits=None, out=None, db_out=None, accumulate=False):
     """dw (N,K) = (dy * (mask > 0)) (S,N).T @ x (S,K), reduced over the rows in a fixed order; want_colsum: also the column sums (N) of
     dy * (mask > 0) - a layer's bias gradient - from the same pass where the split kernel runs, else from a second product with ones;
-    mask_bits: the forward's ReLU bit words instead of the float mask"""
+    mask_bits: the forward's ReLU bit words instead of the float mask.  dy (+ float mask, same stride) and x may be column slices.
+    out / db_out (contiguous) receive the results; accumulate: they are ADDED to (a caller that sums a layer's gradient over chunks)"""
     _req(dy, x, mask, mask_bits)
-    dy, x, mask = _f32(dy), _f32(x), _f32(mask)
+    (dy, ld), (x, ld_x) = _rows(dy), _rows(x)
+    if mask is not None:
+        mask, ld_m = _rows(mask)
+        if ld_m != ld:
+            dy, mask = dy.contiguous(), mask.contiguous()
+            ld = dy.shape[1]
     S, Nn = dy.shape
     K = x.shape[1]
     assert x.shape[0] == S
-    dw = torch.empty((Nn, K), dtype=torch.float32, device=dy.device)
+    dw = torch.empty((Nn, K), dtype=torch.float32, device=dy.device) if out is None else out
+    assert dw.shape == (Nn, K) and dw.is_contiguous() and dw.dtype == torch.float32 and (out is not None or not accumulate)
+    acc = 1 if accumulate else 0
     nf = max(1, int(N.lib().arcn_gemm_tn_scratch_floats(S, Nn, K)))
     scratch = torch.empty(nf, dtype=torch.float32, device=dy.device)
-    split = _GEMM_SPLIT and (Nn > 64 or K > 64) and Nn % 4 == 0 and K % 4 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+    mptr = None if mask is None else mask.data_ptr()
+    split = _GEMM_SPLIT and (Nn > 64 or K > 64) and Nn % 4 == 0 and K % 4 == 0 and _aligned_rows(dy, ld) and _aligned_rows(x, ld_x)
     if split:
-        db = torch.empty(Nn, dtype=torch.float32, device=dy.device) if want_colsum else None
-        N.check(N.lib().arcn_gemm_tn_split(N.ptr(dy), N.ptr(mask), N.ptr(mask_bits), Nn, N.ptr(x), K, N.ptr(dw), N.ptr(db), N.ptr(scratch), nf, S, None,
-                                         Nn, K, 0, N.stream()), 'gemm_tn_split')
+        db = (torch.empty(Nn, dtype=torch.float32, device=dy.device) if db_out is None else db_out) if want_colsum else None
+        N.check(N.lib().arcn_gemm_tn_split(dy.data_ptr(), mptr, N.ptr(mask_bits), ld, x.data_ptr(), ld_x, N.ptr(dw), N.ptr(db), N.ptr(scratch), nf, S,
+                                         None, Nn, K, acc, N.stream()), 'gemm_tn_split')
         return (dw, db) if want_colsum else dw
     assert mask_bits is None, 'bit masks are read by the split products only'
-    N.check(N.lib().arcn_gemm_tn(N.ptr(dy), N.ptr(mask), Nn, N.ptr(x), K, N.ptr(dw), N.ptr(scratch), nf, S, None, Nn, K, 0, N.stream()), 'gemm_tn')
+    N.check(N.lib().arcn_gemm_tn(dy.data_ptr(), mptr, ld, x.data_ptr(), ld_x, N.ptr(dw), N.ptr(scratch), nf, S, None, Nn, K, acc, N.stream()), 'gemm_tn')
     if not want_colsum:
         return dw
     ones = _ones_cols(S, dy.device)
-    return dw, gemm_tn(dy, ones, mask)[:, 0].contiguous()
+    db = gemm_tn(dy, ones, mask)[:, 0]
+    if db_out is None:
+        return dw, db.contiguous()
+    if accumulate:
+        db_out += db
+    else:
+        db_out.copy_(db)
+    return dw, db_out
 
 
 _ONES = {}

@@ -5,6 +5,8 @@ concatenates the per-chunk outputs (tensors, arrays, dicts of them; anything els
 chunk_size <= 0 or no array argument => one direct call.  Outputs are gathered per field and concatenated ONCE
 (the reference re-concatenates after every chunk, an O(n^2) copy pattern).
 """
+import contextlib
+
 import numpy as np
 import torch
 
@@ -70,26 +72,29 @@ def chunk_processing(func, chunk_size, gpu_on_func, *args):
     if n == 0:
         return func(*args)
     fields = None
-    for lo in range(0, n, chunk_size):
-        moved = False
-        sliced = []
-        for a in args:
-            s, m = _slice(a, lo, lo + chunk_size, gpu_on_func)
-            moved |= m
-            sliced.append(s)
-        out = func(*sliced)
-        out = list(out) if isinstance(out, (tuple, list)) else [out]
-        if moved:
-            out = [{k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in o.items()} if isinstance(o, dict)
-                   else (o.cpu() if isinstance(o, torch.Tensor) else o) for o in out]
-        if fields is None:
-            fields = [({k: [] for k in o} if isinstance(o, dict) else []) for o in out]
-        for acc, o in zip(fields, out):
-            if isinstance(o, dict):
-                for k, v in o.items():
-                    acc[k].append(v)
-            else:
-                acc.append(o)
+    # (the networks are the same objects in every iteration: their split / padded weights are made once, ops.functional.split_weight_scope)
+    from ..ops.functional import split_weight_scope
+    with split_weight_scope() if n > chunk_size else contextlib.nullcontext():
+        for lo in range(0, n, chunk_size):
+            moved = False
+            sliced = []
+            for a in args:
+                s, m = _slice(a, lo, lo + chunk_size, gpu_on_func)
+                moved |= m
+                sliced.append(s)
+            out = func(*sliced)
+            out = list(out) if isinstance(out, (tuple, list)) else [out]
+            if moved:
+                out = [{k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in o.items()} if isinstance(o, dict)
+                       else (o.cpu() if isinstance(o, torch.Tensor) else o) for o in out]
+            if fields is None:
+                fields = [({k: [] for k in o} if isinstance(o, dict) else []) for o in out]
+            for acc, o in zip(fields, out):
+                if isinstance(o, dict):
+                    for k, v in o.items():
+                        acc[k].append(v)
+                else:
+                    acc.append(o)
     if fields is None:
         return None
     merged = [({k: _cat(v) for k, v in f.items()} if isinstance(f, dict) else _cat(f)) for f in fields]

@@ -251,6 +251,10 @@ int arcn_hashgrid_bwd_lm_adam(const float *xyz, const float *dout_lm, int64_t do
 
 /* FreqEmbedder.forward (encoding/freq_encoder.py:65-88): out (n, D*(include_input + 2*n_freqs)). */
 int arcn_freq_fwd(const float *x, int D, int n_freqs, int include_input, float *out, int64_t n, void *stream);
+/* the same encoding into n_cols >= od columns of a wider row-major buffer (row stride ld_out floats); the columns behind the od of the
+ * encoding are zeroed: the positional block of GeoNet's skip concatenation (linear_network_module.py:174-197) and the view block of the
+ * radiance input (encoder_mlp_network.py:62-118) are written where the next layer reads them */
+int arcn_freq_fwd_cols(const float *x, int D, int n_freqs, int include_input, float *out, int64_t ld_out, int n_cols, int64_t n, void *stream);
 int arcn_freq_bwd(const float *x, const float *dout, int D, int n_freqs, int include_input, float *dx, int64_t n,
                   void *stream);
 /* SHEmbedder torch branch (encoding/sh_encoder.py:101-185): out (n, degree^2 + 3*include_input). */
@@ -326,12 +330,18 @@ int arcn_gemm_tn(const float *dy, const float *mask, int64_t ld_dy, const float 
  * f32 multiply's own rounding); 6 v_mfma_f32_16x16x32_bf16 replace 8 v_mfma_f32_16x16x4_f32 per 32 reduction elements (2.67 x the
  * matrix rate).  Same meaning and layouts as above.  Requirements: row operands (x, dy, mask) with 16-byte aligned rows, reduction
  * length (K for nt, N for nn) and, for tn, N and K multiples of 4; `ws` = device scratch of arcn_gemm_split_bytes(outputs, reduction
- * length) bytes that receives the split weights (nt: (N, K), nn: (K, N)).  Inf / NaN operands give NaN. */
+ * length) bytes that receives the split weights (nt: (N, K), nn: (K, N)).  Inf / NaN operands give NaN.
+ * ws_ready = 0: the product splits w into ws itself (one small launch per call); ws_ready = 1: ws already holds
+ * arcn_gemm_split_weights(w, ...) of this very weight - the reference evaluates a layer on 8 chunks of samples per training step
+ * (chunk_processing around linear_network_module.py:174-197), the weights are split once for all of them.
+ * arcn_gemm_split_weights: transposed = 0 for arcn_gemm_nt_split (w (n_out, k_red), row stride ld_w), 1 for arcn_gemm_nn_split (the layer's
+ * (N, K) weight read as (k_red = N, n_out = K)). */
 int64_t arcn_gemm_split_bytes(int n_out, int k_red);
+int arcn_gemm_split_weights(const float *w, int ld_w, int transposed, int n_out, int k_red, void *ws, int64_t ws_bytes, void *stream);
 int arcn_gemm_nt_split(const float *x, int64_t ld_x, const float *w, const float *bias, float *y, uint32_t *relu_bits, int64_t ld_y, int64_t n_rows,
-                       const int32_t *n_ptr, int K, int N, int act, float beta, void *ws, int64_t ws_bytes, void *stream);
+                       const int32_t *n_ptr, int K, int N, int act, float beta, void *ws, int64_t ws_bytes, int ws_ready, void *stream);
 int arcn_gemm_nn_split(const float *dy, const float *mask, const uint32_t *mask_bits, int64_t ld_dy, const float *w, float *dx, int64_t ld_dx,
-                       int64_t n_rows, const int32_t *n_ptr, int N, int K, void *ws, int64_t ws_bytes, void *stream);
+                       int64_t n_rows, const int32_t *n_ptr, int N, int K, void *ws, int64_t ws_bytes, int ws_ready, void *stream);
 /* tn: db (N floats, may be NULL) (+)= the column sums of dy' = the layer's bias gradient, summed from the operand as it is staged.
  * ReLU masks as BITS: arcn_gemm_nt_split(act = ReLU, N % 4 == 0) writes relu_bits (ceil(n_rows / 8) x N / 4 uint32: word [s / 8][f / 4],
  * bit 4 (s % 8) + (f % 4) = (y[s][f] > 0)); nn / tn take them as mask_bits instead of the float `mask` (which then is ignored): the

@@ -1315,3 +1315,124 @@ def test_balanced_gather_is_bit_identical_for_any_launch_size(side):
         N.check(lib.arcn_hashgrid_fwd_xcd(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(lm), 1, n, n, None, st))
         assert torch.equal(rm, ref), n
         assert torch.equal(lm.permute(1, 0, 2).reshape(n, 32), ref), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('S,K,Nn,T,bias', [(1000, 256, 256, 64, True), (131, 64, 128, 4, False), (4099, 320, 256, 64, True), (77, 32, 32, 12, True)])
+def test_layer_writing_into_the_skip_concatenation_vs_torch(S, K, Nn, T, bias):
+    """LinearReluCatFn: cat([relu(F.linear(x, w, b)), tail]) with the product writing its columns of the concatenated buffer at that row
+    stride and the gradient products reading theirs in place (GeoNet's skip, linear_network_module.py:174-197) - bit-identical with
+    the layer followed by torch.cat, gradients of x, w, b and of the tail included."""
+    from arcnerf_amd.ops.autograd import linear_relu, linear_relu_cat
+    g = torch.Generator().manual_seed(S + Nn)
+    x0 = torch.randn(S, K, generator=g).cuda()
+    t0 = torch.randn(S, T, generator=g).cuda()
+    w0 = (torch.randn(Nn, K, generator=g) / K ** 0.5).cuda()
+    b0 = (torch.randn(Nn, generator=g) * 0.3).cuda() if bias else None
+    up = torch.randn(S, Nn + T, generator=g).cuda()
+
+    def run(fused):
+        x, t, w = x0.clone().requires_grad_(True), t0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        b = b0.clone().requires_grad_(True) if bias else None
+        out = linear_relu_cat(x, w, b, t) if fused else torch.cat([linear_relu(x, w, b), t], dim=-1)
+        assert out is not None and out.shape == (S, Nn + T)
+        (out * up).sum().backward()
+        return [out.detach(), x.grad, w.grad, t.grad] + ([b.grad] if bias else [])
+    for a, b_ in zip(run(True), run(False)):
+        assert torch.equal(a, b_)
+
+
+@pytest.mark.gpu
+def test_weights_split_once_for_all_chunks_is_bit_identical():
+    """chunk_processing opens ops.functional.split_weight_scope: a layer evaluated on several chunks takes ONE split of its weights
+    (arcn_gemm_split_weights + ws_ready = 1) and one zero-padded copy of an odd-width weight; outputs and gradients equal the per-call
+    splits bit for bit, and nothing is kept once the scope is left."""
+    from arcnerf_amd.ops import functional as Fn
+    from arcnerf_amd.ops.autograd import linear, linear_relu
+    from arcnerf_amd.utils.torch_utils import chunk_processing
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(3000, 63, generator=g).cuda()
+    w1 = (torch.randn(256, 63, generator=g) / 8).cuda()
+    b1 = (torch.randn(256, generator=g) * 0.1).cuda()
+    w2 = (torch.randn(256, 256, generator=g) / 16).cuda()
+    w3 = (torch.randn(257, 256, generator=g) / 16).cuda()
+    up = torch.randn(3000, 257, generator=g).cuda()
+
+    def run(chunk):
+        ps = [p.clone().requires_grad_(True) for p in (w1, b1, w2, w3)]
+        x = x0.clone().requires_grad_(True)
+
+        def net(xc):
+            return linear(linear_relu(linear_relu(xc, ps[0], ps[1]), ps[2], None), ps[3], None)
+        y = chunk_processing(net, chunk, False, x)
+        (y * up).sum().backward()
+        return [y.detach(), x.grad] + [p.grad for p in ps]
+    a, b = run(1024), run(0)          # three chunks inside a scope / one call without
+    assert Fn._SPLIT_SCOPE is None
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for ga, gb in zip(a[2:], b[2:]):  # (weight gradients: three partial sums against one - summation order, not bits)
+        assert (ga - gb).abs().max() <= 2e-6 * gb.abs().max()
+    # the same chunks with and without the scope: every bit
+    calls = []
+    real = Fn.split_weight_scope
+    import contextlib
+    Fn.split_weight_scope = lambda: (calls.append(1), contextlib.nullcontext())[1]
+    try:
+        import arcnerf_amd.utils.torch_utils as tu
+        c = run(1024)
+    finally:
+        Fn.split_weight_scope = real
+    assert calls, 'chunk_processing did not ask for the scope'
+    for ga, gc in zip(a, c):
+        assert torch.equal(ga, gc)
+
+
+@pytest.mark.parametrize('W,D,skips,Wr,Dr,bias,out_act,n,chunk', [
+    (256, 8, [4], 128, 1, True, None, 5000, 2048),                    # configs/nerf.yaml, three chunks (the last one ragged)
+    (256, 8, [4], 128, 1, True, 'identity', 3000, 0),                 # configs/hdrnerf.yaml: no sigmoid, one chunk
+    (128, 4, [1, 2], 64, 2, False, None, 1500, 700),                  # two skips, three radiance layers, no biases, float masks in the radiance net
+    (64, 2, [], 32, 1, True, None, 333, 100)])                        # no skip, everything on the exact-f32 kernels
+def test_field_chain_equals_the_layer_by_layer_modules(W, D, skips, Wr, Dr, bias, out_act, n, chunk):
+    """ops.field_chain.FieldChainFn (GeoNet + RadianceNet 'vf' as one node over all chunks, concatenation-free buffers, weight gradients
+    summed by the products) against the same modules evaluated layer by layer under chunk_processing
+    (linear_network_module.py:16-335, base_3d_model.py:335-366): outputs to f32 summation order (the permuted layouts move sigma and
+    the radiance net's first-layer k-sum to other tiles), every parameter gradient to the order of the chunk sums."""
+    from arcnerf_amd.models.base_3d_model import Base3dModel
+    from arcnerf_amd.models.base_modules.geo_rad_model.linear_network_module import GeoNet, RadianceNet
+    from arcnerf_amd.ops.field_chain import field_chain
+    from arcnerf_amd.utils.cfgs_utils import dict_to_obj
+    from arcnerf_amd.utils.torch_utils import chunk_processing
+    torch.manual_seed(W + D)
+    geo = GeoNet(W=W, D=D, skips=skips, encoder=dict_to_obj({'type': 'FreqEmbedder', 'input_dim': 3, 'n_freqs': 10}), W_feat=W, use_bias=bias,
+                 geometric_init=False).cuda()
+    rad = RadianceNet(mode='vf', W=Wr, D=Dr, encoder=dict_to_obj({'view': {'type': 'FreqEmbedder', 'input_dim': 3, 'n_freqs': 4}}), W_feat_in=W,
+                      use_bias=bias, out_act_cfg=None if out_act is None else dict_to_obj({'type': out_act})).cuda()
+    g = torch.Generator().manual_seed(n)
+    pts = (torch.rand(n, 3, generator=g) * 4 - 2).cuda()
+    dirs = torch.randn(n, 3, generator=g).cuda()
+    up_s, up_r = torch.randn(n, generator=g).cuda(), torch.randn(n, 3, generator=g).cuda()
+    params = list(geo.parameters()) + list(rad.parameters())
+
+    def grads(sigma, radiance):
+        for p in params:
+            p.grad = None
+        ((sigma * up_s).sum() + (radiance * up_r).sum()).backward()
+        return [p.grad.clone() for p in params]
+    out = field_chain(geo, rad, pts, dirs, chunk)
+    assert out is not None, 'the pair was expected to be eligible'
+    got = [o.detach().clone() for o in out], grads(*out)
+    ref_out = chunk_processing(Base3dModel._forward_pts_dir, chunk, False, geo, rad, pts, dirs)
+    ref = [o.detach().clone() for o in ref_out], grads(*ref_out)
+    assert got[0][0].shape == ref[0][0].shape == (n,) and got[0][1].shape == ref[0][1].shape == (n, 3)
+    # (sigma is the 257th output there - the split kernel's 256-wide block - and the 257th here, on the exact-f32 remainder kernel)
+    assert (got[0][0] - ref[0][0]).abs().max() <= 2e-6 * max(1.0, float(ref[0][0].abs().max()))
+    assert (got[0][1] - ref[0][1]).abs().max() <= 2e-6 * max(1.0, float(ref[0][1].abs().max()))
+    for a, b in zip(got[1], ref[1]):
+        assert a.shape == b.shape
+        assert (a - b).abs().max() <= 5e-6 * float(b.abs().max()) + 1e-9
+    # without a graph (rendering): the same outputs, nothing kept
+    with torch.no_grad():
+        s2, r2 = field_chain(geo, rad, pts, dirs, chunk)
+    assert torch.equal(s2, got[0][0]) and torch.equal(r2, got[0][1])
+    # inputs that want a gradient (normals from a density field) are not the node's business
+    assert field_chain(geo, rad, pts.clone().requires_grad_(True), dirs, chunk) is None
