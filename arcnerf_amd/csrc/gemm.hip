@@ -21,6 +21,7 @@
 // Orientation (as in mlp.hip): MFMA rows = output features, MFMA columns = samples (nt / nn) or input features (tn); with the K order
 // k = 16 t + 4 g + ks a lane's four consecutive reduction elements are one 16-byte LDS read that feeds four MFMAs.  Operand tiles are
 // staged through LDS in that fragment order, double buffered, 32 reduction elements per stage (128 B per row: whole cache lines).
+#include <type_traits>
 #include "common.hpp"
 
 namespace arcn {
@@ -468,7 +469,10 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
                        int act, float beta, int out_aligned) {
     constexpr int BN = 16 * MT * WAVES_N, BM = 128;
     static_assert(16 * NT * (4 / WAVES_N) == BM, "the staging below is written for 128 samples per workgroup");
-    __shared__ __attribute__((aligned(16))) gu4 Xs[2][(BM / 16) * 3 * 64];
+    // a sample tile's three planes take 192 16-byte slots; tiles start 193 apart, so tile n sits n bank groups further on: the four rows of
+    // a write phase are four TILES (below) and must not meet in one bank group, while a lane's read address stays base + n * constant
+    constexpr int kTileSlots = 193;
+    __shared__ __attribute__((aligned(16))) gu4 Xs[2][(BM / 16) * kTileSlots];
     const int64_t cnt = dev_count(S, n_ptr);
     const int64_t s_base = (int64_t)blockIdx.x * BM;
     if (s_base >= cnt) return;
@@ -525,8 +529,10 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
                 }
             gu4 hi, md, lo;
             split3(x, hi, md, lo);
-            // slot of row i rotated by 4 g: the 16 lanes of one write phase (4 rows x 4 groups) land in 16 different 16-byte bank groups
-            gu4 *dst = &Xs[buf][(sl >> 4) * 192 + g * 16 + ((sl + 4 * g) & 15)];
+            // row sl = 8 j + n is column j of sample tile n: the eight tiles of a lane are eight CONSECUTIVE rows, i.e. one word of the ReLU
+            // bit mask is a lane's own business in the epilogue (no cross-lane gather).  Slot of column j rotated by 4 g, tile n by n (its
+            // base): the 16 lanes of one write phase (4 rows = 4 tiles x 4 groups) land in 16 different 16-byte bank groups
+            gu4 *dst = &Xs[buf][(sl & 7) * kTileSlots + g * 16 + (((sl >> 3) + 4 * g) & 15)];
             dst[0] = hi;
             dst[64] = md;
             dst[128] = lo;
@@ -545,16 +551,29 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
         }
     };
 
+    // lane (g, j): outputs 16 mt + 4 g + 0..3 of sample 8 j + nt.  The bias is the accumulators' starting value: its loads travel with
+    // the first operand stage instead of waiting at the end of the kernel, and the epilogue has nothing to add
+    static_assert(NT == 8 && WAVES_N == 4, "row = 8 j + tile: eight sample tiles per wave, all waves along the outputs");
+    const int g = lane >> 4, j = lane & 15;
     gf4 acc[MT][NT];
 #pragma unroll
-    for (int a = 0; a < MT; ++a)
+    for (int a = 0; a < MT; ++a) {
+        const int no = n_base + (wave_n * MT + a) * 16 + 4 * g;
+        gf4 bv = gf4{0.f, 0.f, 0.f, 0.f};
+        if (bias && no < No) {
+            bv.x = bias[no];
+            if (no + 1 < No) bv.y = bias[no + 1];
+            if (no + 2 < No) bv.z = bias[no + 2];
+            if (no + 3 < No) bv.w = bias[no + 3];
+        }
 #pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = gf4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NT; ++b) acc[a][b] = bv;
+    }
 
     auto compute = [&](int buf, const gu4 (&w)[MT][3]) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const gu4 *xb = &Xs[buf][(wave_m * NT + n) * 192 + (lane & 48) + ((lane + ((lane >> 4) << 2)) & 15)];
+            const gu4 *xb = &Xs[buf][(wave_m * NT + n) * kTileSlots + (lane & 48) + ((lane + ((lane >> 4) << 2)) & 15)];
             gu4 b[3];
             b[0] = xb[0];
             b[1] = xb[64];
@@ -595,65 +614,49 @@ gemm_rows_split_kernel(const float *__restrict__ in, const float *__restrict__ m
         stash(0, ra);
         __syncthreads();
     }
-    // lane (g, j): outputs 16 mt + 4 g + 0..3 of sample 16 nt + j
-    const int g = lane >> 4, j = lane & 15;
-    gf4 bvm[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int no = n_base + (wave_n * MT + m) * 16 + 4 * g;
-        bvm[m] = gf4{0.f, 0.f, 0.f, 0.f};
-        if (bias && no < No) {
-            bvm[m].x = bias[no];
-            if (no + 1 < No) bvm[m].y = bias[no + 1];
-            if (no + 2 < No) bvm[m].z = bias[no + 2];
-            if (no + 3 < No) bvm[m].w = bias[no + 3];
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int no = n_base + (wave_n * MT + m) * 16 + 4 * g;
-        if (no >= No) continue;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int64_t s = s_base + (wave_m * NT + n) * 16 + j;
-            if (s >= cnt) continue;
-            gf4 v = acc[m][n] + bvm[m];
-            if (act != ARCN_ACT_NONE) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gemm_act(v[r], act, beta);
-            }
-            float *dst = out + s * ld_out + no;
-            if (out_aligned && no + 3 < No) *reinterpret_cast<gf4 *>(dst) = v;
-            else {
-                dst[0] = v.x;
-                if (no + 1 < No) dst[1] = v.y;
-                if (no + 2 < No) dst[2] = v.z;
-                if (no + 3 < No) dst[3] = v.w;
-            }
-        }
-    }
-    // ReLU bit mask of the outputs: a lane's four outputs of a sample are a nibble; the eight lanes j = 8 o .. 8 o + 7 of a lane group
-    // hold the eight rows of one word (every lane runs the exchange, the first lane of an octet stores)
-    if (BITS_OUT && relu_bits) {
-        const int quads = No >> 2;
+    // Epilogue with the activation as a compile-time constant (ACT < 0: whatever `act` says, at run time).  ReLU bit mask of the outputs:
+    // a lane's four outputs of a sample are a nibble and its eight sample tiles are the eight rows 8 j .. 8 j + 7 of ONE word - built in
+    // the lane, one 4-byte store per output tile (the four lane groups write 16 contiguous bytes).
+    const int quads = No >> 2;
+    const int64_t s0 = s_base + 8 * j;
+    auto finish = [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int no = n_base + (wave_n * MT + m) * 16 + 4 * g;
+            uint32_t wd = 0u;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                const int64_t s = s_base + (wave_m * NT + n) * 16 + j;
-                const gf4 v = acc[m][n] + bvm[m];
-                uint32_t wd = 0u;
+                const int64_t s = s0 + n;
+                gf4 v = acc[m][n];
+                if (ACT == ARCN_ACT_RELU) {
+                    uint32_t nib = 0u;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) wd |= (uint32_t)(v[r] > 0.f) << (4 * (j & 7) + r);
-                wd = s < cnt ? wd : 0u;
-                wd |= (uint32_t)__shfl_xor((int)wd, 1);
-                wd |= (uint32_t)__shfl_xor((int)wd, 2);
-                wd |= (uint32_t)__shfl_xor((int)wd, 4);
-                if ((j & 7) == 0 && s < cnt && no < No) relu_bits[(s >> 3) * quads + (no >> 2)] = wd;
+                    for (int r = 0; r < 4; ++r) {
+                        nib |= (uint32_t)(v[r] > 0.f) << r;
+                        v[r] = v[r] > 0.f ? v[r] : 0.f;
+                    }
+                    if (BITS_OUT) wd |= (s < cnt ? nib : 0u) << (4 * n);
+                } else if (ACT < 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gemm_act(v[r], act, beta);
+                }
+                if (s >= cnt || no >= No) continue;
+                float *dst = out + s * ld_out + no;
+                if (out_aligned && no + 3 < No) *reinterpret_cast<gf4 *>(dst) = v;
+                else {
+                    dst[0] = v.x;
+                    if (no + 1 < No) dst[1] = v.y;
+                    if (no + 2 < No) dst[2] = v.z;
+                    if (no + 3 < No) dst[3] = v.w;
+                }
             }
+            if (BITS_OUT && ACT == ARCN_ACT_RELU && relu_bits && s0 < cnt && no < No) relu_bits[(s0 >> 3) * quads + (no >> 2)] = wd;
         }
-    }
+    };
+    if (act == ARCN_ACT_RELU) finish(std::integral_constant<int, ARCN_ACT_RELU>{});
+    else if (BITS_OUT || act == ARCN_ACT_NONE) finish(std::integral_constant<int, ARCN_ACT_NONE>{});
+    else finish(std::integral_constant<int, -1>{});
 }
 
 // partial (slab, N, K) = sum over the slab's samples of A (S,N)^T . B (S,K), split form.  128 x 128 outputs per workgroup (waves 2 x 2,
