@@ -52,6 +52,31 @@ __global__ void __launch_bounds__(256) freq_fwd_cols_kernel(const float *__restr
     }
 }
 
+// J v for the encoding's Jacobian J = d enc / d x (od x D, block diagonal per input dimension): out[c] = v[k] for the identity block,
+// 2^f cos(2^f x_k) v[k] for sin(2^f x_k), -2^f sin(2^f x_k) v[k] for cos(2^f x_k); columns od .. n_cols - 1 zero.  The adjoint of freq_bwd's
+// J^T g: what the second differentiation of a normal n = J^T g (an Eikonal loss on a frequency-encoded sdf net) sends back to g.
+__global__ void __launch_bounds__(256) freq_jvp_cols_kernel(const float *__restrict__ x, const float *__restrict__ v, int D, int n_freqs,
+                                                            int include_input, float *__restrict__ out, int64_t ld_out, int n_cols, int64_t n) {
+    const int od = D * (include_input ? 1 : 0) + 2 * D * n_freqs;
+    const int64_t total = n * n_cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / n_cols;
+        int c = (int)(i - s * n_cols);
+        float *o = out + s * ld_out + c;
+        if (c >= od) { *o = 0.f; continue; }
+        if (include_input) {
+            if (c < D) { *o = v[s * D + c]; continue; }
+            c -= D;
+        }
+        const int f = c / (2 * D);
+        const int rem = c - f * 2 * D;
+        const int k = rem % D;
+        const float sc = ldexpf(1.0f, f);
+        const float a = x[s * D + k] * sc;
+        *o = (rem < D ? cosf(a) : -sinf(a)) * sc * v[s * D + k];
+    }
+}
+
 __global__ void __launch_bounds__(256) freq_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dout, int D,
                                                        int n_freqs, int include_input, float *__restrict__ dx, int64_t n) {
     const int od = D * (include_input ? 1 : 0) + 2 * D * n_freqs;
@@ -469,6 +494,19 @@ ARCN_EXPORT int arcn_freq_fwd_cols(const float *x, int D, int n_freqs, int inclu
     hipLaunchKernelGGL(freq_fwd_cols_kernel, dim3(grid_for(n * n_cols)), dim3(256), 0, as_stream(stream), x, D, n_freqs, include_input, out, ld_out,
                        n_cols, n);
     return check_launch("freq_fwd_cols");
+}
+
+/* out (n rows, n_cols >= od columns at row stride ld_out) = (d enc / d x) v for v (n, D): the adjoint of arcn_freq_bwd with respect to its
+ * dout (freq_encoder.py:10-88 differentiated twice: base_network.py:30-44 takes normals = d sdf / d x with create_graph = True) */
+ARCN_EXPORT int arcn_freq_jvp_cols(const float *x, const float *v, int D, int n_freqs, int include_input, float *out, int64_t ld_out, int n_cols,
+                                   int64_t n, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    const int od = D * (include_input ? 1 : 0) + 2 * D * n_freqs;
+    if (!x || !v || !out || D < 1 || n_freqs < 0 || (n_freqs == 0 && !include_input) || n_cols < od || ld_out < n_cols)
+        return einval("freq_jvp_cols: bad argument");
+    hipLaunchKernelGGL(freq_jvp_cols_kernel, dim3(grid_for(n * n_cols)), dim3(256), 0, as_stream(stream), x, v, D, n_freqs, include_input, out,
+                       ld_out, n_cols, n);
+    return check_launch("freq_jvp_cols");
 }
 
 ARCN_EXPORT int arcn_freq_bwd(const float *x, const float *dout, int D, int n_freqs, int include_input, float *dx,

@@ -92,7 +92,7 @@ class Neus(SdfModel):
         if total > 0:
             if train:
                 self.adjust_dynamicbs_factor(n_valid=pk['offsets'][n_rays])
-            sdf, radiance, normal = chunk_processing(self._forward_pts_dir, self.chunk_pts, False, self.geo_net, self.radiance_net, pts, dirs)
+            sdf, radiance, normal = self.field_with_normal(self.geo_net, self.radiance_net, pts, dirs)
         else:   # nothing marched anywhere: every ray takes the defaults
             sdf = rays_o.new_zeros((1,))
             radiance = normal = rays_o.new_zeros((1, 3))

@@ -23,10 +23,22 @@ class SdfModel(FgModel):
         assert grad_dir == 'ascent', 'Invalid grad_dir for sdf model...'
         return render_surface(self, inputs, method, n_step, n_iter, threshold, level, grad_dir, with_normal=True)
 
+    def field_with_normal(self, geo_net, radiance_net, pts, dirs):
+        """(sdf (n), radiance (n, 3), normal (n, 3)) in chunks of chunk_pts: the sdf net and its input gradient as one first-order node
+        where the net is the frequency-encoded softplus stack (ops.sdf_chain), the radiance net on top of it per chunk; else
+        _forward_pts_dir per chunk as the reference has it (sdf_model.py:42-101)"""
+        from ..ops.sdf_chain import sdf_chain
+        res = sdf_chain(geo_net, pts, self.chunk_pts)
+        if res is None:
+            return chunk_processing(self._forward_pts_dir, self.chunk_pts, False, geo_net, radiance_net, pts, dirs)
+        sdf, feature, normal = res
+        radiance = chunk_processing(radiance_net, self.chunk_pts, False, pts, dirs, normal, feature)
+        return sdf[..., 0].contiguous(), radiance, normal
+
     def forward_pts_dir(self, pts, view_dir=None):
         geo_net, radiance_net = self.get_net()
         rays_d = torch.zeros_like(pts) if view_dir is None else normalize(view_dir)
-        sigma, rgb, _ = chunk_processing(self._forward_pts_dir, self.chunk_pts, False, geo_net, radiance_net, pts, rays_d)
+        sigma, rgb, _ = self.field_with_normal(geo_net, radiance_net, pts, rays_d)
         return sigma, rgb
 
     def get_sdf_radiance_normal_by_mask_pts(self, geo_net, radiance_net, rays_o, rays_d, zvals, mask_pts=None, inference_only=False):
@@ -43,7 +55,7 @@ class SdfModel(FgModel):
             dirs = rays_d.index_select(0, torch.div(flat, n_pts, rounding_mode='floor'))
             if not inference_only:
                 self.adjust_dynamicbs_factor(mask_pts)
-        _sdf, _radiance, _normal = chunk_processing(self._forward_pts_dir, self.chunk_pts, False, geo_net, radiance_net, pts, dirs)
+        _sdf, _radiance, _normal = self.field_with_normal(geo_net, radiance_net, pts, dirs)
         if mask_pts is None:
             return _sdf.view(n_rays, -1), _radiance.view(n_rays, -1, 3), _normal.view(n_rays, -1, 3)
         last = torch.cumsum(mask_pts.sum(dim=1), dim=0) - 1

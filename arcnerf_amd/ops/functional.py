@@ -471,6 +471,17 @@ def freq_fwd_cols(x, n_freqs, include_input, out):
     return out
 
 
+def freq_jvp_cols(x, v, n_freqs, include_input, out):
+    """(d enc / d x) v into the columns of `out` (n, n_cols), columns behind the encoding's width zeroed: the adjoint of freq_bwd"""
+    _req(x, v, out)
+    x, v = _f32(x), _f32(v)
+    n, D = x.shape
+    assert v.shape == x.shape and out.dim() == 2 and out.shape[0] == n and out.dtype == torch.float32 and out.stride(1) == 1
+    N.check(N.lib().arcn_freq_jvp_cols(N.ptr(x), N.ptr(v), D, int(n_freqs), int(include_input), out.data_ptr(), out.stride(0) if n > 1 else out.shape[1],
+                                     out.shape[1], n, N.stream()), 'freq_jvp_cols')
+    return out
+
+
 def freq_bwd(x, dout, n_freqs, include_input=True):
     _req(x, dout)
     x, dout = _f32(x), _f32(dout)

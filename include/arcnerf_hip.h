@@ -255,6 +255,10 @@ int arcn_freq_fwd(const float *x, int D, int n_freqs, int include_input, float *
  * encoding are zeroed: the positional block of GeoNet's skip concatenation (linear_network_module.py:174-197) and the view block of the
  * radiance input (encoder_mlp_network.py:62-118) are written where the next layer reads them */
 int arcn_freq_fwd_cols(const float *x, int D, int n_freqs, int include_input, float *out, int64_t ld_out, int n_cols, int64_t n, void *stream);
+/* out (n, n_cols at row stride ld_out) = (d enc / d x) v for v (n, D) - the adjoint of arcn_freq_bwd (which is (d enc / d x)^T dout) with
+ * respect to dout: the second differentiation of a normal taken through the encoding (base_network.py:30-44, create_graph = True) */
+int arcn_freq_jvp_cols(const float *x, const float *v, int D, int n_freqs, int include_input, float *out, int64_t ld_out, int n_cols, int64_t n,
+                       void *stream);
 int arcn_freq_bwd(const float *x, const float *dout, int D, int n_freqs, int include_input, float *dx, int64_t n,
                   void *stream);
 /* SHEmbedder torch branch (encoding/sh_encoder.py:101-185): out (n, degree^2 + 3*include_input). */

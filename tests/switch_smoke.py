@@ -57,12 +57,13 @@ def _module(name, overrides, n_rays, radius, seed, extra=None):
 
 
 def nets(out):
-    m, inp = _module('nerf', ['--model.rays.perturb', 'False', '--model.rays.noise_std', '0.0'], 256, 4.0, 1)
+    # (chunk_pts below the number of points: the chunk loops - weight splits shared across chunks, gradients summed over them - are run)
+    m, inp = _module('nerf', ['--model.rays.perturb', 'False', '--model.rays.noise_std', '0.0', '--model.chunk_pts', '20000'], 256, 4.0, 1)
     r = m(dict(inp), inference_only=False)
     (((r['rgb_fine'] - inp['img']) ** 2).mean() + ((r['rgb_coarse'] - inp['img']) ** 2).mean()).backward()
     out['nerf_rgb'] = r['rgb_fine'].detach().cpu().numpy()
     out['nerf_grad'] = torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None]).cpu().numpy()
-    m, inp = _module('neus', ['--model.rays.perturb', 'False'], 128, 3.0, 2)
+    m, inp = _module('neus', ['--model.rays.perturb', 'False', '--model.chunk_pts', '6000'], 128, 3.0, 2)
     r = m(dict(inp), inference_only=False, cur_epoch=20000)
     (((r['rgb'] - inp['img']) ** 2).mean() + 0.1 * ((r['normal_pts'].norm(dim=-1) - 1.0) ** 2).mean()).backward()
     out['neus_rgb'] = r['rgb'].detach().cpu().numpy()

@@ -1436,3 +1436,48 @@ def test_field_chain_equals_the_layer_by_layer_modules(W, D, skips, Wr, Dr, bias
     assert torch.equal(s2, got[0][0]) and torch.equal(r2, got[0][1])
     # inputs that want a gradient (normals from a density field) are not the node's business
     assert field_chain(geo, rad, pts.clone().requires_grad_(True), dirs, chunk) is None
+
+
+@pytest.mark.parametrize('W,D,skips,reduce,norm,wn,bias,n,chunk', [
+    (256, 8, [4], True, True, True, True, 3000, 1024),      # configs/neus.yaml: reduced + normalised skip, weight norm, three chunks
+    (128, 4, [1], False, False, False, True, 1500, 0),      # plain skip (319-style odd concatenation width), no weight norm, one chunk
+    (64, 3, [], False, False, True, False, 700, 300)])      # no skip, no biases, everything on the exact-f32 kernels
+def test_sdf_chain_equals_the_double_backward_of_the_modules(W, D, skips, reduce, norm, wn, bias, n, chunk):
+    """ops.sdf_chain.SdfChainFn (softplus sdf net + its input gradient as ONE first-order node with a hand-written backward for the
+    second-order terms) against GeoNet.forward_with_grad - torch.autograd.grad(create_graph=True) through the layer modules - under a
+    loss that uses the sdf, the feature and the normal (an Eikonal term among them), base_network.py:30-44: outputs and the gradient
+    of every parameter (weight-norm g and v included)."""
+    from arcnerf_amd.models.base_modules.geo_rad_model.linear_network_module import GeoNet
+    from arcnerf_amd.ops.sdf_chain import sdf_chain
+    from arcnerf_amd.utils.cfgs_utils import dict_to_obj
+    from arcnerf_amd.utils.torch_utils import chunk_processing
+    torch.manual_seed(W + D)
+    geo = GeoNet(W=W, D=D, skips=skips, encoder=dict_to_obj({'type': 'FreqEmbedder', 'input_dim': 3, 'n_freqs': 10}), W_feat=W, use_bias=bias,
+                 skip_reduce_output=reduce, norm_skip=norm, act_cfg=dict_to_obj({'type': 'softplus', 'beta': 100}), geometric_init=True,
+                 radius_init=0.75, weight_norm=wn).cuda()
+    g = torch.Generator().manual_seed(n)
+    pts = (torch.rand(n, 3, generator=g) * 2 - 1).cuda()
+    up_f = (torch.randn(n, W, generator=g) * 0.1).cuda()
+    up_n = torch.randn(n, 3, generator=g).cuda()
+    params = [p for p in geo.parameters()]
+
+    def loss_grads(sdf, feat, normal):
+        for p in params:
+            p.grad = None
+        loss = (sdf[:, 0] ** 2).sum() + (feat * up_f).sum() + ((normal.norm(dim=-1) - 1.0) ** 2).sum() + (normal * up_n).sum()
+        loss.backward()
+        return [p.grad.clone() for p in params]
+    out = sdf_chain(geo, pts, chunk)
+    assert out is not None, 'the net was expected to be eligible'
+    got = [o.detach().clone() for o in out], loss_grads(*out)
+    ref_out = chunk_processing(lambda x: geo.forward_with_grad(x), chunk, False, pts.clone())
+    ref = [o.detach().clone() for o in ref_out], loss_grads(*ref_out)
+    for a, b, name in zip(got[0], ref[0], ('sdf', 'feature', 'normal')):
+        assert a.shape == b.shape, name
+        assert (a - b).abs().max() <= 3e-6 * max(1.0, float(b.abs().max())), name
+    for a, b, (name, _) in zip(got[1], ref[1], geo.named_parameters()):
+        assert a.shape == b.shape, name
+        assert (a - b).abs().max() <= 2e-5 * float(b.abs().max()) + 1e-8, (name, float((a - b).abs().max()), float(b.abs().max()))
+    with torch.no_grad():          # rendering: normals without a graph
+        s2, f2, n2 = sdf_chain(geo, pts, chunk)
+    assert torch.equal(n2, got[0][2]) and torch.equal(s2, got[0][0])
