@@ -186,8 +186,8 @@ __device__ __forceinline__ void softplus_s(float z, float beta, int from_y, floa
 }
 
 template <bool VEC>
-__global__ void __launch_bounds__(256) softplus_grad_kernel(const float *__restrict__ z, const float *__restrict__ g, float *__restrict__ out, int64_t n,
-                                                            float beta, int from_y) {
+__global__ void __launch_bounds__(256) softplus_grad_kernel(const float *__restrict__ z, const float *__restrict__ g, const float *__restrict__ g2,
+                                                            float *__restrict__ out, int64_t n, float beta, int from_y) {
     constexpr int W = VEC ? 4 : 1;
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * W; i < n; i += (int64_t)gridDim.x * blockDim.x * W) {
         float zv[W], gv[W], ov[W];
@@ -195,7 +195,13 @@ __global__ void __launch_bounds__(256) softplus_grad_kernel(const float *__restr
             *reinterpret_cast<f4v *>(zv) = *reinterpret_cast<const f4v *>(z + i);
             if (g) *reinterpret_cast<f4v *>(gv) = *reinterpret_cast<const f4v *>(g + i);
             else gv[0] = gv[1] = gv[2] = gv[3] = 1.f;      // g == NULL: the derivative s itself
-        } else { zv[0] = z[i]; gv[0] = g ? g[i] : 1.f; }
+            if (g2) {                                      // a second gradient arriving at the same activation: summed on the way in
+                float g2v[W];
+                *reinterpret_cast<f4v *>(g2v) = *reinterpret_cast<const f4v *>(g2 + i);
+#pragma unroll
+                for (int k = 0; k < W; ++k) gv[k] += g2v[k];
+            }
+        } else { zv[0] = z[i]; gv[0] = (g ? g[i] : 1.f) + (g2 ? g2[i] : 0.f); }
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             float s, ds;
@@ -545,14 +551,25 @@ static inline bool vec4_ok(int64_t n, const void *a, const void *b, const void *
     return (n & 3) == 0 && (m & 15u) == 0;
 }
 
-ARCN_EXPORT int arcn_softplus_grad(const float *z, const float *g, float *out, int64_t n, float beta, int from_y, void *stream) {
+static int softplus_grad_launch(const float *z, const float *g, const float *g2, float *out, int64_t n, float beta, int from_y, void *stream) {
     if (n <= 0) return ARCN_OK;
     if (!z || !out) return einval("softplus_grad: missing argument");
-    if (vec4_ok(n, z, g, out, nullptr, nullptr))
-        hipLaunchKernelGGL(softplus_grad_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), z, g, out, n, beta, from_y);
+    if (vec4_ok(n, z, g, out, g2, nullptr))
+        hipLaunchKernelGGL(softplus_grad_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), z, g, g2, out, n, beta, from_y);
     else
-        hipLaunchKernelGGL(softplus_grad_kernel<false>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), z, g, out, n, beta, from_y);
+        hipLaunchKernelGGL(softplus_grad_kernel<false>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), z, g, g2, out, n, beta, from_y);
     return check_launch("softplus_grad");
+}
+
+ARCN_EXPORT int arcn_softplus_grad(const float *z, const float *g, float *out, int64_t n, float beta, int from_y, void *stream) {
+    return softplus_grad_launch(z, g, nullptr, out, n, beta, from_y, stream);
+}
+
+/* out = (g + g2) * sigmoid(beta z): arcn_softplus_grad for an activation that two gradients arrive at (the ordinary chain and the
+ * curvature term of a normal's second differentiation, base_network.py:30-44), without the pass that adds them first */
+ARCN_EXPORT int arcn_softplus_grad_sum(const float *z, const float *g, const float *g2, float *out, int64_t n, float beta, int from_y, void *stream) {
+    if (!g || !g2) return einval("softplus_grad_sum: two gradients expected");
+    return softplus_grad_launch(z, g, g2, out, n, beta, from_y, stream);
 }
 
 ARCN_EXPORT int arcn_softplus_grad2(const float *z, const float *g, const float *h, float *dg, float *dz, int64_t n, float beta, int from_y,

@@ -552,6 +552,15 @@ def softplus_grad(z, g, beta, from_y=False):
     return out
 
 
+def softplus_grad_sum(z, g, g2, beta, from_y=False):
+    """(g + g2) * sigmoid(beta z) in one pass (softplus_grad of the sum of two incoming gradients)"""
+    _req(z, g, g2)
+    z, g, g2 = _f32(z), _f32(g), _f32(g2)
+    out = torch.empty_like(z)
+    N.check(N.lib().arcn_softplus_grad_sum(N.ptr(z), N.ptr(g), N.ptr(g2), N.ptr(out), z.numel(), float(beta), int(from_y), N.stream()), 'softplus_grad_sum')
+    return out
+
+
 def softplus_grad2(z, g, h, beta, want_dg=True, want_dz=True, from_y=False):
     """backward of softplus_grad for an incoming h: (h * s, h * g * beta s (1 - s)), s = sigmoid(beta z), in one pass; from_y: the second
     is the gradient with respect to y, h * g * beta (1 - s)"""

@@ -152,8 +152,8 @@ class SdfChainFn(torch.autograd.Function):
                         ebar = e0.contiguous() if ebar is None else ebar + e0
                     elif (i - 1) in skips:
                         wo = spec.out_dims[i - 1]
-                        g = torch.zeros((S, ws[i - 1].shape[0]), dtype=torch.float32, device=dev) if ws[i - 1].shape[0] != wo else \
-                            torch.empty((S, wo), dtype=torch.float32, device=dev)
+                        g = torch.empty((S, ws[i - 1].shape[0]), dtype=torch.float32, device=dev)
+                        g[:, wo:].zero_()
                         if spec.norm_skip:      # (the division the module path's autograd performs, not a multiplication by the reciprocal)
                             torch.div(abar[:, :wo], _SQ2, out=g[:, :wo])
                             tail = abar[:, wo:wo + ed] / _SQ2
@@ -211,7 +211,8 @@ class SdfChainFn(torch.autograd.Function):
                         d_row0[:ghat.shape[1]] += ghat.sum(0)
                     elif i in skips:
                         wo = spec.out_dims[i]
-                        ahat = torch.zeros((S, ws[i + 1].shape[1]), dtype=torch.float32, device=dev)
+                        ahat = torch.empty((S, ws[i + 1].shape[1]), dtype=torch.float32, device=dev)
+                        ahat[:, wo + ed:].zero_()
                         torch.div(ghat[:, :wo], div, out=ahat[:, :wo])
                         torch.div(ehat[:, :ed], div, out=ahat[:, wo:wo + ed])
                     else:
@@ -223,14 +224,12 @@ class SdfChainFn(torch.autograd.Function):
             for i in range(D - 1, -1, -1):
                 if i in skips:
                     wo = spec.out_dims[i]
-                    hbar = torch.zeros((S, ws[i].shape[0]), dtype=torch.float32, device=dev) if ws[i].shape[0] != wo else \
-                        torch.empty((S, wo), dtype=torch.float32, device=dev)
+                    hbar = torch.empty((S, ws[i].shape[0]), dtype=torch.float32, device=dev)
+                    hbar[:, wo:].zero_()
                     torch.div(abar[:, :wo], div, out=hbar[:, :wo])
                 else:
-                    hbar = abar                               # (the product's own fresh buffer: summed into in place)
-                if dys[i] is not None:
-                    hbar.add_(dys[i])
-                zbar = F.softplus_grad(hs[i], hbar, beta, True)
+                    hbar = abar
+                zbar = F.softplus_grad(hs[i], hbar, beta, True) if dys[i] is None else F.softplus_grad_sum(hs[i], hbar, dys[i], beta, True)
                 tn(zbar, ins[i], i, True)
                 if i > 0:
                     abar = F.gemm_nn(zbar, ws[i], ws=ctx.ws_nn[i])

@@ -405,6 +405,9 @@ int arcn_tonemap_bwd(const float *x, const float *y, const float *dy, const floa
  * from_y = 1: `z` holds y = softplus(z) instead (a layer with the activation in its product's epilogue keeps no z): s = 1 - e^(-beta y), and
  * dz becomes the gradient with respect to y, h * g * beta (1 - s) (the chain through y multiplies by s again). */
 int arcn_softplus_grad(const float *z, const float *g, float *out, int64_t n, float beta, int from_y, void *stream);
+/* out = (g + g2) * sigmoid(beta z): arcn_softplus_grad for an activation two gradients arrive at - the ordinary chain and the curvature
+ * term of a normal's second differentiation (base_network.py:30-44) - without a pass that adds them first */
+int arcn_softplus_grad_sum(const float *z, const float *g, const float *g2, float *out, int64_t n, float beta, int from_y, void *stream);
 int arcn_softplus_grad2(const float *z, const float *g, const float *h, float *dg, float *dz, int64_t n, float beta, int from_y, void *stream);
 int arcn_act_bwd(const float *x, const float *y, const float *dy, float *dx, int64_t n, int act, float beta,
                  void *stream);
