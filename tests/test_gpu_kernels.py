@@ -1481,3 +1481,49 @@ def test_sdf_chain_equals_the_double_backward_of_the_modules(W, D, skips, reduce
     with torch.no_grad():          # rendering: normals without a graph
         s2, f2, n2 = sdf_chain(geo, pts, chunk)
     assert torch.equal(n2, got[0][2]) and torch.equal(s2, got[0][0])
+
+
+@pytest.mark.parametrize('n,chunk', [(1, 0), (1, 4), (9, 4), (130, 128), (257, 1)])
+def test_field_and_sdf_nodes_on_tiny_and_ragged_batches(n, chunk):
+    """the one-node fields on 1 point, on chunks of 1 and on batches that end in a ragged chunk: outputs and parameter gradients equal
+    the module path (chunk_processing of the same nets)"""
+    from arcnerf_amd.models.base_3d_model import Base3dModel
+    from arcnerf_amd.models.base_modules.geo_rad_model.linear_network_module import GeoNet, RadianceNet
+    from arcnerf_amd.ops.field_chain import field_chain
+    from arcnerf_amd.ops.sdf_chain import sdf_chain
+    from arcnerf_amd.utils.cfgs_utils import dict_to_obj
+    from arcnerf_amd.utils.torch_utils import chunk_processing
+    torch.manual_seed(3)
+    enc = dict_to_obj({'type': 'FreqEmbedder', 'input_dim': 3, 'n_freqs': 6})
+    geo = GeoNet(W=128, D=3, skips=[1], encoder=enc, W_feat=128, geometric_init=False).cuda()
+    rad = RadianceNet(mode='vf', W=128, D=1, encoder=dict_to_obj({'view': {'type': 'FreqEmbedder', 'input_dim': 3, 'n_freqs': 2}}), W_feat_in=128).cuda()
+    sdf = GeoNet(W=128, D=3, skips=[1], encoder=enc, W_feat=128, skip_reduce_output=True, norm_skip=True,
+                 act_cfg=dict_to_obj({'type': 'softplus', 'beta': 100}), geometric_init=True, weight_norm=True).cuda()
+    g = torch.Generator().manual_seed(n)
+    pts, dirs = (torch.rand(n, 3, generator=g) - 0.5).cuda(), torch.randn(n, 3, generator=g).cuda()
+
+    def grads(params, loss):
+        for p in params:
+            p.grad = None
+        loss.backward()
+        return [p.grad.clone() for p in params]
+    ps = list(geo.parameters()) + list(rad.parameters())
+    s1, r1 = field_chain(geo, rad, pts, dirs, chunk)
+    g1 = grads(ps, s1.sum() + (r1 ** 2).sum())
+    s0, r0 = chunk_processing(Base3dModel._forward_pts_dir, chunk, False, geo, rad, pts, dirs)
+    g0 = grads(ps, s0.sum() + (r0 ** 2).sum())
+    assert s1.shape == s0.shape and r1.shape == r0.shape
+    s1, r1, s0, r0 = s1.detach(), r1.detach(), s0.detach(), r0.detach()
+    assert (s1 - s0).abs().max() <= 2e-6 * max(1.0, float(s0.abs().max())) and (r1 - r0).abs().max() <= 2e-6
+    for a, b in zip(g1, g0):
+        assert (a - b).abs().max() <= 1e-5 * float(b.abs().max()) + 1e-9
+    ps = list(sdf.parameters())
+    d1, f1, n1 = sdf_chain(sdf, pts, chunk)
+    g1 = grads(ps, d1.sum() + f1.sum() * 0.01 + ((n1.norm(dim=-1) - 1) ** 2).sum())
+    d0, f0, n0 = chunk_processing(lambda x: sdf.forward_with_grad(x), chunk, False, pts.clone())
+    g0 = grads(ps, d0.sum() + f0.sum() * 0.01 + ((n0.norm(dim=-1) - 1) ** 2).sum())
+    assert d1.shape == d0.shape and f1.shape == f0.shape and n1.shape == n0.shape
+    for a, b in ((d1.detach(), d0.detach()), (f1.detach(), f0.detach()), (n1.detach(), n0.detach())):
+        assert (a - b).abs().max() <= 3e-6 * max(1.0, float(b.abs().max()))
+    for a, b in zip(g1, g0):
+        assert (a - b).abs().max() <= 3e-5 * float(b.abs().max()) + 1e-8
