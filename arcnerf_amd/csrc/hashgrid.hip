@@ -1243,13 +1243,10 @@ static int build_bin_plan(const GridParams &g, int64_t n, BinPlan &plan) {
         const char *e = getenv("ARCN_SCATTER_LOCK");
         return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffffffu;
     }();
-    static const int chunk_floats = [] {
-        const char *e = getenv("ARCN_SCATTER_CHUNK_FLOATS");  // tuning aid; power of two <= 32768
-        // 8192-row owner chunks (64 KiB of LDS, two consumer workgroups per CU): 704 owners on 512 slots instead of 352 on 256 -
-        // step 0.680 -> 0.664 ms against the 16384-row chunks, scatter 0.213 -> 0.196 ms per launch (A/B in one session)
-        int v = e ? atoi(e) : 16384;
-        return (v >= 1024 && v <= kChunkFloats && !(v & (v - 1))) ? v : 16384;
-    }();
+    // 8192-row owner chunks (64 KiB of LDS, two consumer workgroups per CU): 704 owners on 512 slots instead of 352 on 256 -
+    // step 0.680 -> 0.664 ms against the 16384-row chunks, scatter 0.213 -> 0.196 ms per launch (A/B in one session)
+    constexpr int chunk_floats = 16384;
+    static_assert(chunk_floats <= kChunkFloats, "owner chunk larger than the consumer's LDS accumulator");
     plan.chunk_floats = chunk_floats;
     { static const int det = [] { const char *e = getenv("ARCN_DETERMINISTIC"); return e ? atoi(e) : 0; }(); plan.det = det ? 1 : 0; }
     { static const int cas = [] { const char *e = getenv("ARCN_SCATTER_CAS"); return e ? atoi(e) : 1; }(); plan.use_cas = cas; }
@@ -1366,7 +1363,7 @@ static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *
         if (rc) return rc;
         uint32_t *counters = reinterpret_cast<uint32_t *>(workspace);
         uint4 *recs = reinterpret_cast<uint4 *>(workspace + bin_counter_floats(plan));
-        hipError_t e = hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)(plan.n_bins + 2), as_stream(stream));
+        hipError_t e = hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)bin_counter_floats(plan), as_stream(stream));   // (the whole 256-byte padded block: ONE fill launch, an odd size is two)
         if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
         const size_t lds = plan.det ? sizeof(unsigned long long) * (size_t)plan.chunk_floats
                                     : sizeof(float) * (size_t)plan.chunk_floats + sizeof(uint32_t) * (size_t)(plan.chunk_floats / 32);
@@ -1374,11 +1371,11 @@ static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *
             ? hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_accum_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
             : hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_accum_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
-        static const int bin_wgs = [] { const char *e = getenv("ARCN_SCATTER_BIN_WGS"); return e ? atoi(e) : 32; }();
+        constexpr int bin_wgs = 32;   // persistent producer workgroups per level (16 / 64 measured slower)
         // producer workgroup size = samples per tile.  The kernel needs ~124 VGPRs, so a 1024-thread workgroup owns a whole CU;
         // two 512-thread workgroups per CU (covering each other's barrier phases) measured SLOWER, 0.262 vs 0.249 ms for the
-        // whole scatter (twice the per-bin global atomics, half the run length per bin): ARCN_SCATTER_BIN_THREADS=512 keeps it
-        static const int bin_threads = [] { const char *e = getenv("ARCN_SCATTER_BIN_THREADS"); int v = e ? atoi(e) : 1024; return v == 512 ? 512 : 1024; }();
+        // whole scatter (twice the per-bin global atomics, half the run length per bin)
+        constexpr int bin_threads = 1024;
         int64_t bx = ceil_div<int64_t>(n, bin_threads);
         const int64_t wgs = (int64_t)bin_wgs * (1024 / bin_threads);
         if (bx > wgs) bx = wgs;  // persistent workgroups per level
@@ -1396,10 +1393,10 @@ static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *
         }
         if (fused_levels_out) *fused_levels_out = fz.fuse_levels;
         if (g.F == 1) {
-            if (bin_threads == 1024) ARCN_BIN(1, 1024); else ARCN_BIN(1, 512);
+            ARCN_BIN(1, 1024);
             ARCN_ACC(1);
         } else {
-            if (bin_threads == 1024) ARCN_BIN(2, 1024); else ARCN_BIN(2, 512);
+            ARCN_BIN(2, 1024);
             ARCN_ACC(2);
         }
 #undef ARCN_ACC
@@ -1440,7 +1437,7 @@ ARCN_EXPORT int arcn_hashgrid_bwd_bwd(const float *xyz, const float *gdx, const 
         if (rc) return rc;
         uint32_t *counters = reinterpret_cast<uint32_t *>(workspace);
         uint4 *recs = reinterpret_cast<uint4 *>(workspace + bin_counter_floats(plan));
-        hipError_t e = hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)(plan.n_bins + 2), as_stream(stream));
+        hipError_t e = hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)bin_counter_floats(plan), as_stream(stream));   // (the whole 256-byte padded block: ONE fill launch, an odd size is two)
         if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
         const size_t lds = plan.det ? sizeof(unsigned long long) * (size_t)plan.chunk_floats
                                     : sizeof(float) * (size_t)plan.chunk_floats + sizeof(uint32_t) * (size_t)(plan.chunk_floats / 32);
