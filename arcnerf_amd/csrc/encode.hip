@@ -154,6 +154,15 @@ __global__ void __launch_bounds__(256) act_fwd_kernel(const float *__restrict__ 
         y[i] = act_fwd(x[i], act, beta);
 }
 
+// y[i] = act(x[i * ld]) * scale for the first *n_ptr (or n) rows: the estimated opacity sigma * dt of an occupancy refresh straight from
+// the density column of the geometry net's output
+__global__ void __launch_bounds__(256) act_col_scale_kernel(const float *__restrict__ x, int64_t ld, float *__restrict__ y, int64_t n,
+                                                            const int32_t *__restrict__ n_ptr, int act, float beta, float scale) {
+    const int64_t cnt = dev_count(n, n_ptr);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = act_fwd(x[i * ld], act, beta) * scale;
+}
+
 __global__ void __launch_bounds__(256) act_bwd_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                       const float *__restrict__ dy, float *__restrict__ dx, int64_t n,
                                                       int act, float beta) {
@@ -536,6 +545,16 @@ ARCN_EXPORT int arcn_act_fwd(const float *x, float *y, int64_t n, int act, float
     if (!x || !y) return einval("act_fwd: missing argument");
     hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, y, n, act, beta);
     return check_launch("act_fwd");
+}
+
+/* y (n) = act(x[:, 0]) * scale for x (n rows at stride ld): get_est_opacity = sigma * dt of an occupancy refresh (base_3d_model.py:368-389)
+ * from the density column of the geometry net's output in one pass; rows behind *n_ptr (may be NULL) are left alone */
+ARCN_EXPORT int arcn_act_col_scale(const float *x, int64_t ld, float *y, int64_t n, const int32_t *n_ptr, int act, float beta, float scale,
+                                   void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!x || !y || ld < 1) return einval("act_col_scale: missing / invalid argument");
+    hipLaunchKernelGGL(act_col_scale_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, ld, y, n, n_ptr, act, beta, scale);
+    return check_launch("act_col_scale");
 }
 
 ARCN_EXPORT int arcn_act_bwd(const float *x, const float *y, const float *dy, float *dx, int64_t n, int act, float beta,

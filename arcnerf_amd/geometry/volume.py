@@ -15,17 +15,27 @@ from ..ops import functional as F
 from .ray import aabb_ray_intersection
 
 
+def mix_constants(n, rng):
+    """the two (multiplier, increment) pairs of mix_permutation for a cell range of n = 2^k, drawn from `rng` (multipliers odd and
+    not tiny); also what arcn_refresh_cells_points takes as perm_a / perm_c"""
+    k = n.bit_length() - 1
+    out = []
+    for _ in range(2):
+        a = int(rng.integers(0, n // 2)) * 2 + 1
+        a |= 1 << max(1, k // 2)           # keep the multiplier from being tiny
+        c = int(rng.integers(0, n))
+        out.append((a & (n - 1), c))
+    return out
+
+
 def mix_permutation(idx, n, rng):
     """idx (int64 tensor of values in [0, n), n a power of two) -> pi(idx) for a bijection pi of [0, n) drawn from `rng`:
     x -> a*x + c (a odd), x -> x ^ (x >> s): both invertible modulo 2^k; two rounds with independent constants."""
     k = n.bit_length() - 1
     m = n - 1
     x = idx
-    for _ in range(2):
-        a = int(rng.integers(0, n // 2)) * 2 + 1
-        a |= 1 << max(1, k // 2)           # keep the multiplier from being tiny
-        c = int(rng.integers(0, n))
-        x = (x * (a & m) + c) & m
+    for a, c in (rng if isinstance(rng, list) else mix_constants(n, rng)):
+        x = (x * a + c) & m
         x = x ^ (x >> max(1, (k + 1) // 2))
         x = (x * 0x9E3779B1) & m           # odd constant: a second multiply after the shift spreads the high bits
         x = x ^ (x >> max(1, k // 3))

@@ -459,6 +459,20 @@ def freq_fwd(x, n_freqs, include_input=True):
     return out
 
 
+def refresh_cells_points(bitfield_bool, n_grid, perm, voxel_size, min_xyz, rng_state, rng_inc, cells, pts, n_valid, workspace):
+    """cells / jittered points of an occupancy refresh (arcn_refresh_cells_points): perm = [(a0, c0), (a1, c1)] of
+    geometry.volume.mix_constants; cells (2 n_s) int64, pts (2 n_s, 3) float32, n_valid (1) int32, workspace uint8 - all caller-owned"""
+    _req(bitfield_bool, cells, pts, n_valid, workspace)
+    assert bitfield_bool.dtype in (torch.bool, torch.uint8) and bitfield_bool.is_contiguous() and cells.dtype == torch.int64 and n_valid.dtype == torch.int32
+    pa = (C.c_uint64 * 2)(int(perm[0][0]), int(perm[1][0]))
+    pc = (C.c_uint64 * 2)(int(perm[0][1]), int(perm[1][1]))
+    mn = (C.c_float * 3)(*[float(v) for v in min_xyz])
+    N.check(N.lib().arcn_refresh_cells_points(bitfield_bool.data_ptr(), int(n_grid), C.cast(pa, C.c_void_p), C.cast(pc, C.c_void_p), float(voxel_size),
+                                            C.cast(mn, C.c_void_p), int(rng_state), int(rng_inc), N.ptr(cells), N.ptr(pts), N.ptr(n_valid), N.ptr(workspace),
+                                            workspace.numel(), N.stream()), 'refresh_cells_points')
+    return cells, pts, n_valid
+
+
 def freq_fwd_cols(x, n_freqs, include_input, out):
     """the encoding of x (n, D) into the columns of `out`, a (n, n_cols) column slice of a wider row-major buffer; columns behind the
     encoding's own width are zeroed"""
@@ -506,6 +520,16 @@ def act_fwd(x, act, beta=1.0):
     x = _f32(x)
     y = torch.empty_like(x)
     N.check(N.lib().arcn_act_fwd(N.ptr(x), N.ptr(y), x.numel(), N.ACT[act], float(beta), N.stream()), 'act_fwd')
+    return y
+
+
+def act_col_scale(x, act, scale, n_dev=None, out=None, beta=1.0):
+    """act(x[:, 0]) * scale for a (n, C) row-major x, rows behind the device count left alone"""
+    _req(x, out)
+    assert x.dim() == 2 and x.is_contiguous() and x.dtype == torch.float32
+    n = x.shape[0]
+    y = torch.empty(n, dtype=torch.float32, device=x.device) if out is None else out
+    N.check(N.lib().arcn_act_col_scale(N.ptr(x), x.shape[1], N.ptr(y), n, _nptr(n_dev), N.ACT[act], float(beta), float(scale), N.stream()), 'act_col_scale')
     return y
 
 

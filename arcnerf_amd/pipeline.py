@@ -792,18 +792,32 @@ class NgpPipeline:
         ng = cfg.n_grid
         n_cells = ng ** 3
         n_dev = None
-        if cfg.epoch_optim_warmup is not None and cur_epoch < cfg.epoch_optim_warmup:
-            cell = self._cached('arange_cells', lambda: torch.arange(n_cells, device=dev))
-        else:
-            cell, n_dev = self._select_cells(n_cells)
         vs = cfg.side / ng
-        ix = torch.div(cell, ng * ng, rounding_mode='floor')
-        iy = torch.div(cell, ng, rounding_mode='floor') % ng
-        iz = cell % ng
-        idx3 = torch.stack([ix, iy, iz], -1).float()
-        mn = self._cached('mn', lambda: torch.tensor(fld.min_xyz, device=dev))
-        pts = idx3 * vs + 0.5 * vs + mn
-        pts = pts + (torch.rand_like(pts) - 0.5) * vs
+        warm = cfg.epoch_optim_warmup is not None and cur_epoch < cfg.epoch_optim_warmup
+        if not warm and ng >= 16 and ng & (ng - 1) == 0 and self.bitfield.data_ptr() % 8 == 0:
+            # cells (n / 4 uniform + the first n / 4 occupied, both in flat order) and their jittered points by four small launches
+            from .geometry.volume import mix_constants
+            rng = self._cached('np_rng', lambda: np.random.default_rng(12345))
+            rb = self._cached('refresh_native', lambda: {
+                'cells': torch.zeros(2 * (n_cells // 4), dtype=torch.int64, device=dev),
+                'pts': torch.zeros((2 * (n_cells // 4), 3), dtype=torch.float32, device=dev),
+                'n_valid': torch.zeros(1, dtype=torch.int32, device=dev),
+                'ws': torch.empty(n_cells + 8 * (n_cells // 4096 + 2), dtype=torch.uint8, device=dev)})
+            F.refresh_cells_points(self.bitfield, ng, mix_constants(n_cells, rng), vs, fld.min_xyz, int(rng.integers(0, 1 << 62)),
+                                   int(rng.integers(0, 1 << 62)) * 2 + 1, rb['cells'], rb['pts'], rb['n_valid'], rb['ws'])
+            cell, pts, n_dev = rb['cells'], rb['pts'], rb['n_valid']
+        else:
+            if warm:
+                cell = self._cached('arange_cells', lambda: torch.arange(n_cells, device=dev))
+            else:
+                cell, n_dev = self._select_cells(n_cells)
+            ix = torch.div(cell, ng * ng, rounding_mode='floor')
+            iy = torch.div(cell, ng, rounding_mode='floor') % ng
+            iz = cell % ng
+            idx3 = torch.stack([ix, iy, iz], -1).float()
+            mn = self._cached('mn', lambda: torch.tensor(fld.min_xyz, device=dev))
+            pts = idx3 * vs + 0.5 * vs + mn
+            pts = pts + (torch.rand_like(pts) - 0.5) * vs
         n = pts.shape[0]
         if self._occ_scratch is None or self._occ_scratch['feat'].shape[0] < n:
             self._occ_scratch = {
@@ -824,8 +838,11 @@ class NgpPipeline:
         else:
             F.hashgrid_fwd(pts, self._p('table'), fld.grid_desc, out=sc['feat'][:n], n_dev=n_dev)
             F.mlp_fwd(sc['feat'][:n], self._p('geo_w'), self._p('geo_b'), fld.geo_desc, out=sc['geo_out'][:n], n_dev=n_dev)
-        sigma = F.act_fwd(sc['geo_out'][:n, 0].contiguous(), cfg.sigma_act)
-        opacity = sigma * cfg.dt  # get_est_opacity (base_3d_model.py:386-389)
+        if n_dev is not None:
+            opacity = F.act_col_scale(sc['geo_out'][:n], cfg.sigma_act, cfg.dt, n_dev=n_dev, out=self._cached('occ_opacity', lambda: torch.zeros(n, dtype=torch.float32, device=dev)))
+        else:
+            sigma = F.act_fwd(sc['geo_out'][:n, 0].contiguous(), cfg.sigma_act)
+            opacity = sigma * cfg.dt  # get_est_opacity (base_3d_model.py:386-389)
         F.opafield_scatter_update(self.opafield, cell, opacity, ema=cfg.ema_optim_decay, cell_max=sc['cell_max'],
                                   touched=sc['touched'], n_dev=n_dev)
         new_bits = torch.empty_like(self.bitfield)

@@ -387,6 +387,9 @@ int64_t arcn_mlp_scratch_floats(const arcn_mlp_desc *desc_host, int64_t n_cap);
 
 /* elementwise activation (TruncExp F1 etc.) */
 int arcn_act_fwd(const float *x, float *y, int64_t n, int act, float beta, void *stream);
+/* y (n) = act(x[i * ld]) * scale, rows behind *n_ptr (may be NULL) left alone: the estimated opacity sigma * dt of an occupancy refresh
+ * (base_3d_model.py:368-389 get_est_opacity) from the density column of the geometry net's output, one pass */
+int arcn_act_col_scale(const float *x, int64_t ld, float *y, int64_t n, const int32_t *n_ptr, int act, float beta, float scale, void *stream);
 /* One elementwise pass of ops.autograd.SdfMlpJacFn's backward (the NeuS-on-hash-grid sdf net with its Jacobian as an explicit output):
  * dz = dh s + c_j u s (1 - s), su = s u over an (n, H) hidden layer, c (H) = beta W2[0]; dz / su may alias dh / u. */
 int arcn_sdf_jac_dz(const float *dh, const float *u, const float *s, const float *c, float *dz, float *su, int64_t n, int H, void *stream);
@@ -529,6 +532,18 @@ int arcn_opafield_scatter_update(float *opafield, const int64_t *cell_idx, const
  * workspace: 2 floats (device). */
 int arcn_update_bitfield_by_opafield(const float *opafield, uint8_t *bitfield, int64_t n, float threshold,
                                      float *workspace, void *stream);
+/* Cells and sample points of one occupancy refresh after the warm-up (VolumeBound.optimize, volume_bound.py:178-190, which draws
+ * torch.randperm(n)[:n / 4] and takes get_occupied_voxel_idx()[:n / 4]): n_s = n_grid^3 / 4 cells drawn uniformly without repetition - the
+ * image of [0, n_s) under the seeded bijection (perm_a[2] odd, perm_c[2]; two rounds of x -> a x + c, xor-shift, odd multiply, xor-shift
+ * modulo n_grid^3, a power of two) - followed by the first n_s occupied cells of the boolean bitfield in flat-index order; both halves
+ * leave ORDERED - the uniform half along the Z-curve of the grid, the occupied half by flat index - so that spatial neighbours stay
+ * neighbours in the hash gather that follows.  cells_out (2 n_s int64), n_valid
+ * (device int32) = n_s + min(occupied, n_s), entries behind it are not written; pts_out (2 n_s, 3) = voxel centre + a uniform jitter of
+ * one voxel from the pcg32 stream (rng_state, rng_inc).  workspace: >= n_grid^3 + 8 (n_grid^3 / 4096 + 1) bytes, 8-byte aligned like the
+ * bitfield.  Four small launches, no host synchronisation (the torch formulation was ~45). */
+int arcn_refresh_cells_points(const uint8_t *bitfield_bool, int n_grid, const uint64_t *perm_a, const uint64_t *perm_c, float voxel_size,
+                              const float *min_xyz_host, uint64_t rng_state, uint64_t rng_inc, int64_t *cells_out, float *pts_out,
+                              int32_t *n_valid, uint8_t *workspace, int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser over one flat fp32 buffer: torch.optim.Adam(lr, betas, eps, weight_decay) semantics

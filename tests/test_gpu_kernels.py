@@ -1527,3 +1527,49 @@ def test_field_and_sdf_nodes_on_tiny_and_ragged_batches(n, chunk):
         assert (a - b).abs().max() <= 3e-6 * max(1.0, float(b.abs().max()))
     for a, b in zip(g1, g0):
         assert (a - b).abs().max() <= 3e-5 * float(b.abs().max()) + 1e-8
+
+
+@pytest.mark.parametrize('ng,frac', [(16, 0.05), (32, 0.6), (64, 0.0), (128, 0.05)])
+def test_refresh_cells_and_points_vs_the_torch_selection(ng, frac):
+    """arcn_refresh_cells_points against geometry.volume.select_refresh_cells (VolumeBound.optimize, volume_bound.py:178-190): the uniform
+    part is the SAME set of n / 4 distinct cells (the image of the seeded bijection), in Z-curve order; the occupied part is the first n / 4 occupied
+    cells in flat order; n_valid counts both; every point lies inside its cell's voxel and the jitter is uniform (mean, variance)."""
+    from arcnerf_amd.geometry.volume import mix_constants, mix_permutation
+    from arcnerf_amd.ops import functional as Fn
+    n = ng ** 3
+    n_s = n // 4
+    g = torch.Generator().manual_seed(ng)
+    bf = (torch.rand(n, generator=g) < frac).cuda()
+    perm = mix_constants(n, np.random.default_rng(ng))
+    cells = torch.full((2 * n_s,), -1, dtype=torch.int64, device='cuda')
+    pts = torch.zeros(2 * n_s, 3, device='cuda')
+    n_valid = torch.zeros(1, dtype=torch.int32, device='cuda')
+    ws = torch.empty(n + 8 * (n // 4096 + 2), dtype=torch.uint8, device='cuda')
+    side, mn = 3.0, (-1.5, -1.2, -1.8)
+    vs = side / ng
+    Fn.refresh_cells_points(bf, ng, perm, vs, mn, 12345, 77, cells, pts, n_valid, ws)
+    want_uni = torch.sort(mix_permutation(torch.arange(n_s), n, perm))[0]
+    got_uni = cells[:n_s].cpu()
+    assert torch.equal(torch.sort(got_uni)[0], want_uni) and want_uni.unique().numel() == n_s
+    # ... handed out along the Z-curve: Morton codes strictly increasing
+    def spread(v):
+        out = torch.zeros_like(v)
+        for b in range(10):
+            out |= ((v >> b) & 1) << (3 * b)
+        return out
+    code = spread(torch.div(got_uni, ng * ng, rounding_mode='floor')) | (spread(torch.div(got_uni, ng, rounding_mode='floor') % ng) << 1) | (spread(got_uni % ng) << 2)
+    assert bool((code[1:] > code[:-1]).all())
+    occ = torch.nonzero(bf.cpu())[:n_s, 0]
+    nv = int(n_valid)
+    assert nv == n_s + occ.numel()
+    assert torch.equal(cells[n_s:nv].cpu(), occ)
+    c = cells[:nv]
+    idx3 = torch.stack([torch.div(c, ng * ng, rounding_mode='floor'), torch.div(c, ng, rounding_mode='floor') % ng, c % ng], -1).float()
+    lo = idx3 * vs + torch.tensor(mn, device='cuda')
+    u = (pts[:nv] - lo) / vs
+    assert float(u.min()) >= -1e-4 and float(u.max()) <= 1.0 + 1e-4
+    assert abs(float(u.mean()) - 0.5) < 0.01 and abs(float(u.var()) - 1.0 / 12.0) < 0.01
+    # another stream position gives another jitter, the same cells
+    pts2 = torch.zeros_like(pts)
+    Fn.refresh_cells_points(bf, ng, perm, vs, mn, 999, 77, cells, pts2, n_valid, ws)
+    assert not torch.equal(pts2[:nv], pts[:nv])
