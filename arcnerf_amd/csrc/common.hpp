@@ -124,6 +124,11 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_take(float fill, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
+// the same with zero for a source outside the row (bound_ctrl): foldable into the DPP form of the VOP2 instruction that consumes it
+template <int CTRL>
+__device__ __forceinline__ float dpp_zero(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 template <int CTRL>
 __device__ __forceinline__ int dpp_take_i(int fill, int v) {
     return __builtin_amdgcn_update_dpp(fill, v, CTRL, 0xf, 0xf, false);

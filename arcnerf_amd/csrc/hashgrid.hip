@@ -778,13 +778,12 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
             const bool take = lane + (D) <= tail;                                     \
             more = __ballot(take) != 0ull;                                            \
             if (more) {                                                               \
+                /* va += (lane i + D's va) * m, m = 1 inside the run, 0 past its end: ONE v_fmac_f32_dpp per value (m = 1 is the plain */ \
+                /* sum bit for bit; a select + add were three instructions and a DPP hazard stall) */                                     \
+                const float m = take ? 1.0f : 0.0f;                                   \
                 _Pragma("unroll") for (int q = 0; q < 8; ++q) {                       \
-                    const float ua = dpp_take<0x100 + (D)>(0.f, va[q]);               \
-                    va[q] += take ? ua : 0.f;                                         \
-                    if (F > 1) {                                                      \
-                        const float ub = dpp_take<0x100 + (D)>(0.f, vb[q]);           \
-                        vb[q] += take ? ub : 0.f;                                     \
-                    }                                                                 \
+                    va[q] = __builtin_fmaf(dpp_zero<0x100 + (D)>(va[q]), m, va[q]);   \
+                    if (F > 1) vb[q] = __builtin_fmaf(dpp_zero<0x100 + (D)>(vb[q]), m, vb[q]); \
                 }                                                                     \
             }                                                                         \
         }
@@ -802,14 +801,14 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
             if ((true_heads >> b) & 1ull) continue;
             const uint64_t below = all_heads & ((1ull << b) - 1ull);  // never empty: lane b-16 is a head
             const int piece = 63 - (int)__builtin_clzll(below);
-            const bool joins = lane >= piece && lane < b;
+            const float mj = (lane >= piece && lane < b) ? 1.0f : 0.0f;     // (the same masked multiply-add as in the steps above)
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float ua = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, va[q]), b));
-                va[q] += joins ? ua : 0.f;
+                va[q] = __builtin_fmaf(ua, mj, va[q]);
                 if (F > 1) {
                     const float ub = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vb[q]), b));
-                    vb[q] += joins ? ub : 0.f;
+                    vb[q] = __builtin_fmaf(ub, mj, vb[q]);
                 }
             }
         }
