@@ -475,19 +475,27 @@ hashgrid_fwd_bal_kernel(const float *__restrict__ xyz, const float *__restrict__
             if (PAIR && F == 2 && lp.mask && (reinterpret_cast<uintptr_t>(lt) & 15) == 0) {
                 // the two x-neighbours of a (y, z) corner pair: rows r and r' = ((cx+1) ^ A) & mask.  cx even -> r' = r ^ 1: both in
                 // one aligned 16-byte word (one dwordx4); cx odd -> a second 8-byte load under the lane mask
+                // ALL the loads are issued before the first is consumed - the four 16-byte words, then (one branch) the four 8-byte
+                // words of the odd lanes: written pair by pair the compiler waited for each word before it issued the next (the
+                // selects below sat between the loads: `s_waitcnt vmcnt(0)` four times per sample and level, one load in flight per
+                // wave in a kernel whose bound is the number of requests in flight)
                 const bool even = (c[0] & 1u) == 0u;
+                float4 t4[4];
+                float2 o2[4];
+#pragma unroll
+                for (int yz = 0; yz < 4; ++yz) t4[yz] = *reinterpret_cast<const float4 *>(lt + (size_t)(rows[(yz & 1) + ((yz >> 1) << 2)] & ~1u) * 2);
+                if (!even) {
+#pragma unroll
+                    for (int yz = 0; yz < 4; ++yz) o2[yz] = *reinterpret_cast<const float2 *>(lt + (size_t)rows[(yz & 1) + ((yz >> 1) << 2) + 2] * 2);
+                }
 #pragma unroll
                 for (int yz = 0; yz < 4; ++yz) {
                     const int q0 = (yz & 1) + ((yz >> 1) << 2), q1 = q0 + 2;
-                    const uint32_t r0 = rows[q0];
-                    const float4 t4 = *reinterpret_cast<const float4 *>(lt + (size_t)(r0 & ~1u) * 2);
-                    const bool hi = (r0 & 1u) != 0u;
-                    vals[q0][0] = hi ? t4.z : t4.x;
-                    vals[q0][1] = hi ? t4.w : t4.y;
-                    float2 o2 = make_float2(hi ? t4.x : t4.z, hi ? t4.y : t4.w);
-                    if (!even) o2 = *reinterpret_cast<const float2 *>(lt + (size_t)rows[q1] * 2);
-                    vals[q1][0] = o2.x;
-                    vals[q1][1] = o2.y;
+                    const bool hi = (rows[q0] & 1u) != 0u;
+                    vals[q0][0] = hi ? t4[yz].z : t4[yz].x;
+                    vals[q0][1] = hi ? t4[yz].w : t4[yz].y;
+                    vals[q1][0] = even ? (hi ? t4[yz].x : t4[yz].z) : o2[yz].x;
+                    vals[q1][1] = even ? (hi ? t4[yz].y : t4[yz].w) : o2[yz].y;
                 }
             } else {
 #pragma unroll
