@@ -380,6 +380,47 @@ __device__ __forceinline__ uint32_t mod_size(uint64_t h, const LevelParams &lp) 
     return (uint32_t)r;
 }
 
+// rows of the 8 corners of cell c (corner q: x = (q >> 1) & 1, y = q & 1, z = q >> 2).  Power-of-two levels: xor + mask.  Other levels
+// with kb > 0 ((res + 1) < 2^kb <= size): the hash of a corner is B ^ cx with B = hy ^ hz shared by the two x neighbours, and
+// B ^ cx = (B & ~low) + ((B & low) ^ cx) for low = 2^kb - 1 > cx - ONE 64-bit modulo per (y, z) pair and a conditional subtract per
+// corner instead of eight modulos (each a f64 multiply + floor + fix-up, ~28 instructions).  kb = 0: the direct form.
+__device__ __forceinline__ void corner_rows(const uint32_t c[3], const LevelParams &lp, int kb, uint32_t rows[8]) {
+    if (lp.mask) {
+        const uint32_t hy0 = c[1] * 2654435761u, hy1 = hy0 + 2654435761u;
+        const uint32_t hz0 = c[2] * 805459861u, hz1 = hz0 + 805459861u;
+        const uint32_t A[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};   // index y + 2 z
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rows[q] = ((c[0] + ((q >> 1) & 1)) ^ A[(q & 1) + 2 * (q >> 2)]) & lp.mask;
+    } else if (kb > 0) {
+        const uint64_t hy0 = (uint64_t)c[1] * 2654435761ull, hy1 = hy0 + 2654435761ull;
+        const uint64_t hz0 = (uint64_t)c[2] * 805459861ull, hz1 = hz0 + 805459861ull;
+        const uint64_t B[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+        const uint64_t lowmask = (1ull << kb) - 1ull;
+#pragma unroll
+        for (int yz = 0; yz < 4; ++yz) {
+            const uint32_t mh = mod_size(B[yz] & ~lowmask, lp);
+            const uint32_t bl = (uint32_t)(B[yz] & lowmask);
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                uint32_t r = mh + (bl ^ (c[0] + x));
+                if (r >= lp.size) r -= lp.size;
+                rows[(x << 1) + (yz & 1) + ((yz >> 1) << 2)] = r;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rows[q] = hash_row(c[0] + ((q >> 1) & 1), c[1] + (q & 1), c[2] + (q >> 2), lp);
+    }
+}
+
+// modulo sharing needs (res + 1) < 2^kb <= size (0: not applicable)
+static int level_lowbits(const LevelParams &lp) {
+    if (lp.mask) return 0;
+    int kb = 0;
+    while ((1u << kb) <= (uint32_t)(lp.res + 1)) ++kb;
+    return (1ull << kb) > (uint64_t)lp.size ? 0 : kb;
+}
+
 template <int F, bool LM, bool PAIR, int NT = 0>
 __global__ void __launch_bounds__(256)
 hashgrid_fwd_bal_kernel(const float *__restrict__ xyz, const float *__restrict__ table, GridParams g, FwdPlan plan,
@@ -442,32 +483,7 @@ hashgrid_fwd_bal_kernel(const float *__restrict__ xyz, const float *__restrict__
                 w[a] = ww < 0.0f ? 0.0f : (ww > 1.0f ? 1.0f : ww);
             }
             uint32_t rows[8];   // corner q: x = (q>>1)&1, y = q&1, z = q>>2
-            if (lp.mask) {
-                const uint32_t hy0 = c[1] * 2654435761u, hy1 = hy0 + 2654435761u;
-                const uint32_t hz0 = c[2] * 805459861u, hz1 = hz0 + 805459861u;
-                const uint32_t A[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};   // index y + 2 z
-#pragma unroll
-                for (int q = 0; q < 8; ++q) rows[q] = ((c[0] + ((q >> 1) & 1)) ^ A[(q & 1) + 2 * (q >> 2)]) & lp.mask;
-            } else if (kb > 0) {
-                const uint64_t hy0 = (uint64_t)c[1] * 2654435761ull, hy1 = hy0 + 2654435761ull;
-                const uint64_t hz0 = (uint64_t)c[2] * 805459861ull, hz1 = hz0 + 805459861ull;
-                const uint64_t B[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
-                const uint64_t lowmask = (1ull << kb) - 1ull;
-#pragma unroll
-                for (int yz = 0; yz < 4; ++yz) {
-                    const uint32_t mh = mod_size(B[yz] & ~lowmask, lp);
-                    const uint32_t bl = (uint32_t)(B[yz] & lowmask);
-#pragma unroll
-                    for (int x = 0; x < 2; ++x) {
-                        uint32_t r = mh + (bl ^ (c[0] + x));
-                        if (r >= lp.size) r -= lp.size;
-                        rows[(x << 1) + (yz & 1) + ((yz >> 1) << 2)] = r;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) rows[q] = hash_row(c[0] + ((q >> 1) & 1), c[1] + (q & 1), c[2] + (q >> 2), lp);
-            }
+            corner_rows(c, lp, kb, rows);
             float vals[8][F];
             const float *lt = table + lp.offset * F;
             // (a level whose first row is not 16-byte aligned - an odd row offset after dense levels of odd size, or a table segment at
@@ -580,6 +596,7 @@ struct BinPlan {
     int32_t use_cas;                          // consumer, F = 2: 64-bit compare-and-swap on the row instead of the bit lock
     int32_t det;                              // ARCN_DETERMINISTIC=1: order-independent fixed-point accumulation (see scatter_accum_kernel)
     int32_t aux_first;                        // counters[aux_first] = bits of max |dout| (det), counters[aux_first + 1] = a bin overflowed
+    int8_t lowbits[ARCN_MAX_LEVELS];          // corner_rows' kb of the level (shared 64-bit modulo on the non-power-of-two levels)
     int64_t n_recs;
 };
 
@@ -737,11 +754,12 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
         }
     } else if (!reduce) {
         if (cell.valid) {
+            uint32_t rows[8];
+            corner_rows(cell.c, lp, plan.lowbits[l], rows);
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr) {
                 const uint32_t oy = pr & 1, oz = pr >> 1;
-                const uint32_t r0 = hash_row(cell.c[0], cell.c[1] + oy, cell.c[2] + oz, lp);
-                const uint32_t r1 = hash_row(cell.c[0] + 1u, cell.c[1] + oy, cell.c[2] + oz, lp);
+                const uint32_t r0 = rows[oy + (oz << 2)], r1 = rows[2 + oy + (oz << 2)];
                 const float wyz = (oy ? cell.w[1] : 1.0f - cell.w[1]) * (oz ? cell.w[2] : 1.0f - cell.w[2]);
                 const float a0 = g0 * wyz, a1 = g1 * wyz;
                 const int c0 = (int)(r0 >> shift), c1 = (int)(r1 >> shift);
@@ -821,10 +839,11 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
             }
         }
         if (true_head && cell.valid) {
+            uint32_t rows[8];
+            corner_rows(cell.c, lp, plan.lowbits[l], rows);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
-                const uint32_t r = hash_row(cell.c[0] + ox, cell.c[1] + oy, cell.c[2] + oz, lp);
+                const uint32_t r = rows[q];
                 sbin[q] = (int)(r >> shift);
                 sidx[q] = (r & cmask) | 0xffff0000u;
                 swx[q] = 0.f;
@@ -1305,6 +1324,7 @@ static int build_bin_plan(const GridParams &g, int64_t n, BinPlan &plan) {
     plan.n_bins = bins;
     plan.aux_first = bins;      // two words behind the bin counters (zeroed with them)
     plan.n_recs = recs;
+    for (int l = 0; l < ARCN_MAX_LEVELS; ++l) plan.lowbits[l] = l < g.L ? (int8_t)level_lowbits(g.lv[l]) : 0;
     // dispatch: levels with the longest items (largest bins per workgroup) first, ties finest first
     int order[ARCN_MAX_LEVELS];
     for (int l = 0; l < g.L; ++l) order[l] = g.L - 1 - l;
@@ -1572,13 +1592,7 @@ static int build_fwd_plan(const GridParams &g, int64_t n, FwdPlan &plan, int &wg
         order[l] = l;
         cost[l] = fwd_level_cost(g.lv[l]);
         total += cost[l];
-        // modulo sharing needs (res + 1) < 2^kb <= size
-        int kb = 0;
-        if (!g.lv[l].mask) {
-            while ((1u << kb) <= (uint32_t)(g.lv[l].res + 1)) ++kb;
-            if ((1ull << kb) > (uint64_t)g.lv[l].size) kb = 0;
-        }
-        plan.lowbits[l] = kb;
+        plan.lowbits[l] = level_lowbits(g.lv[l]);
     }
     for (int l = g.L; l < ARCN_MAX_LEVELS; ++l) plan.lowbits[l] = 0;
     for (int i = 0; i < g.L; ++i)
