@@ -1172,6 +1172,17 @@ def update_bitfield_by_opafield(opafield, bitfield, threshold):
     return bitfield
 
 
+def adam_ema_step_runs(param, grad, exp_avg, exp_avg_sq, ema, runs, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, ema_decay=0.95,
+                       grad_scale=1.0, ema_step=None, zero_grad=False):
+    """adam_ema_step on the runs [(lo, hi), ...] (at most four, every lo a multiple of 4) of the flat buffers in ONE launch"""
+    _req(param, grad, exp_avg, exp_avg_sq, ema)
+    flat = (C.c_int64 * (2 * len(runs)))(*[v for lo, hi in runs for v in (int(lo), int(hi) - int(lo))])
+    N.check(N.lib().arcn_adam_ema_step_runs(N.ptr(param), N.ptr(grad), N.ptr(exp_avg), N.ptr(exp_avg_sq), N.ptr(ema), C.cast(flat, C.c_void_p), len(runs),
+                                           float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), float(ema_decay),
+                                           float(grad_scale), int(step), int(step if ema_step is None else ema_step), int(zero_grad), N.stream()),
+            'adam_ema_step_runs')
+
+
 def adam_ema_step(param, grad, exp_avg, exp_avg_sq, ema, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                   ema_decay=0.95, grad_scale=1.0, ema_step=None, zero_grad=False):
     """torch.optim.Adam step + the reference's EMA.ema_step (average written back into param), one pass."""

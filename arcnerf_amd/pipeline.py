@@ -698,6 +698,11 @@ class NgpPipeline:
         if self._fused_step:        # the scatter of this step already updated its levels: the rest of the flat buffer
             self._fused_step = False
             assert lo is None and hi is None and world_size == 1
+            if 1 < len(self._adam_rest) <= 4:      # the small levels in front of the fused ones and the MLP weights behind them: one launch
+                F.adam_ema_step_runs(fld.params, fld.grads, self.exp_avg, self.exp_avg_sq, self.ema, self._adam_rest, self.step_count, lr=cfg.lr,
+                                     betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, ema_decay=cfg.ema_decay, grad_scale=1.0,
+                                     zero_grad=True)
+                return
             slices = [slice(a, b_) for a, b_ in self._adam_rest]
         else:
             slices = [slice(lo, hi)]

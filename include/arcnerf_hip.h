@@ -559,6 +559,12 @@ int arcn_refresh_cells_points(const uint8_t *bitfield_bool, int n_grid, const ui
 int arcn_adam_ema_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, float *ema, int64_t n, float lr,
                        float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale,
                        int step, int ema_step, int zero_grad, void *stream);
+/* arcn_adam_ema_step on up to four runs [lo, lo + n) of the SAME flat buffers in one launch (runs_host: lo0, n0, lo1, n1, ...; every lo a
+ * multiple of 4 floats): what is left of the flat parameter buffer of a single-GPU step once the scatter's chunk owners have applied
+ * the optimiser to their table levels (arcn_hashgrid_bwd_lm_adam) - the small levels in front of them and the MLP weights behind. */
+int arcn_adam_ema_step_runs(float *param, float *grad, float *exp_avg, float *exp_avg_sq, float *ema, const int64_t *runs_host, int n_runs,
+                            float lr, float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale, int step,
+                            int ema_step, int zero_grad, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1573,3 +1573,24 @@ def test_refresh_cells_and_points_vs_the_torch_selection(ng, frac):
     pts2 = torch.zeros_like(pts)
     Fn.refresh_cells_points(bf, ng, perm, vs, mn, 999, 77, cells, pts2, n_valid, ws)
     assert not torch.equal(pts2[:nv], pts[:nv])
+
+
+def test_adam_runs_in_one_launch_equal_separate_launches():
+    """arcn_adam_ema_step_runs (what is left of the flat buffer beside the levels the scatter's owners update, one launch) against one
+    arcn_adam_ema_step per run: parameters, moments, cleared gradients bit for bit; the gaps between the runs untouched"""
+    from arcnerf_amd.ops import functional as Fn
+    n = 40000
+    g = torch.Generator().manual_seed(0)
+    base = [torch.randn(n, generator=g).cuda() for _ in range(4)]
+    base[3] = base[3].abs()
+    runs = [(0, 9826), (12000, 12000 + 4), (20000, 20000 + 7777), (39996, 40000)]
+    a = [t.clone() for t in base]
+    b = [t.clone() for t in base]
+    kw = dict(lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6, ema_decay=0.95, grad_scale=0.5, zero_grad=True)
+    Fn.adam_ema_step_runs(a[0], a[1], a[2], a[3], a[0], runs, 3, **kw)
+    for lo, hi in runs:
+        Fn.adam_ema_step(b[0][lo:hi], b[1][lo:hi], b[2][lo:hi], b[3][lo:hi], b[0][lo:hi], 3, **kw)
+    for x, y, z in zip(a, b, base):
+        assert torch.equal(x, y)
+        assert torch.equal(x[9826:12000], z[9826:12000]) and torch.equal(x[12004:20000], z[12004:20000])
+    assert float(a[1][:9826].abs().max()) == 0.0 and not torch.equal(a[0][:9826], base[0][:9826])
