@@ -252,8 +252,8 @@ __global__ void __launch_bounds__(1024) refresh_scan_kernel(int32_t *__restrict_
 // ranked writes: cells_out[0 .. n_uniform) = marked cells, cells_out[n_s + r] = r-th occupied cell (r < n_s), both in flat order, and
 // the jittered point of each: centre of the voxel + (u - 0.5) * voxel size, u from a pcg32 stream advanced to 3 x the output slot
 __global__ void __launch_bounds__(256) refresh_write_kernel(const uint8_t *__restrict__ sel, const uint8_t *__restrict__ occ, int64_t n_cells,
-                                                            const int32_t *__restrict__ blk, int n_blocks, int64_t n_s, int n_grid, float vs,
-                                                            float mn0, float mn1, float mn2, Pcg32 rng, int64_t *__restrict__ cells_out,
+                                                            const int32_t *__restrict__ blk, int n_blocks, int64_t n_s, int n_grid, float vs0, float vs1,
+                                                            float vs2, float mn0, float mn1, float mn2, Pcg32 rng, int64_t *__restrict__ cells_out,
                                                             float *__restrict__ pts_out) {
     __shared__ int32_t s_wave[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(256) refresh_write_kernel(const uint8_t *__res
         for (int w = 0; w < wv; ++w) rank[row] += s_wave[row][w];
         rank[row] += blk[(int64_t)row * n_blocks + blockIdx.x];
     }
-    const float mn[3] = {mn0, mn1, mn2};
+    const float mn[3] = {mn0, mn1, mn2}, vsz[3] = {vs0, vs1, vs2};
     const int lg = 31 - __clz(n_grid);                  // n_grid is a power of two: the index split is shifts and masks
 #pragma unroll
     for (int row = 0; row < 2; ++row) {
@@ -297,11 +297,11 @@ __global__ void __launch_bounds__(256) refresh_write_kernel(const uint8_t *__res
             const float idx3[3] = {(float)(cell >> (2 * lg)), (float)((cell >> lg) & (uint32_t)(n_grid - 1)), (float)(cell & (uint32_t)(n_grid - 1))};
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                float p = idx3[a] * vs;          // the reference's order: index * size + half a voxel + origin, then the jitter
-                p = p + 0.5f * vs;
+                float p = idx3[a] * vsz[a];      // the reference's order: index * size + half a voxel + origin, then the jitter
+                p = p + 0.5f * vsz[a];
                 p = p + mn[a];
                 const float u = g.next_float();
-                pts_out[slot * 3 + a] = p + (u - 0.5f) * vs;
+                pts_out[slot * 3 + a] = p + (u - 0.5f) * vsz[a];
             }
             ++r;
         }
@@ -399,12 +399,12 @@ ARCN_EXPORT int arcn_count_bitfield(const uint8_t *bitfield, float *counter, int
  * cells drawn uniformly without repetition (the image of [0, n_s) under the seeded bijection perm_a / perm_c, geometry/volume.py
  * mix_permutation; n_grid a power of two) followed by the first n_s occupied cells of the boolean bitfield in flat-index order, both
  * halves ordered (the uniform half along the Z-curve, the occupied half by flat index); cells_out (2 n_s int64), n_valid = n_s + min(occupied, n_s) (device int32; entries behind it are not
- * written), pts_out (2 n_s, 3) = voxel centre + uniform jitter of one voxel (pcg32 stream rng_state / rng_inc).  workspace: n_grid^3 +
+ * written), pts_out (2 n_s, 3) = voxel centre + uniform jitter of one voxel (per-axis voxel sizes; pcg32 stream rng_state / rng_inc).  workspace: n_grid^3 +
  * 8 * (n_grid^3 / 4096 + 1) bytes.  No host synchronisation. */
-ARCN_EXPORT int arcn_refresh_cells_points(const uint8_t *bitfield_bool, int n_grid, const uint64_t *perm_a, const uint64_t *perm_c, float voxel_size,
-                                          const float *min_xyz_host, uint64_t rng_state, uint64_t rng_inc, int64_t *cells_out, float *pts_out,
+ARCN_EXPORT int arcn_refresh_cells_points(const uint8_t *bitfield_bool, int n_grid, const uint64_t *perm_a, const uint64_t *perm_c,
+                                          const float *voxel_size_host, const float *min_xyz_host, uint64_t rng_state, uint64_t rng_inc, int64_t *cells_out, float *pts_out,
                                           int32_t *n_valid, uint8_t *workspace, int64_t workspace_bytes, void *stream) {
-    if (!bitfield_bool || !perm_a || !perm_c || !min_xyz_host || !cells_out || !pts_out || !n_valid || !workspace)
+    if (!bitfield_bool || !perm_a || !perm_c || !voxel_size_host || !min_xyz_host || !cells_out || !pts_out || !n_valid || !workspace)
         return einval("refresh_cells_points: missing argument");
     if (n_grid < 16 || n_grid > 1024 || (n_grid & (n_grid - 1))) return einval("refresh_cells_points: n_grid must be a power of two in 16 .. 1024");
     const int64_t n_cells = (int64_t)n_grid * n_grid * n_grid, n_s = n_cells / 4;
@@ -430,7 +430,7 @@ ARCN_EXPORT int arcn_refresh_cells_points(const uint8_t *bitfield_bool, int n_gr
     hipLaunchKernelGGL(refresh_scan_kernel, dim3(1), dim3(1024), 0, st, blk, n_blocks, n_s, n_valid);
     Pcg32 rng{rng_state, rng_inc};
     hipLaunchKernelGGL(refresh_write_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, sel, bitfield_bool, n_cells, blk, n_blocks, n_s, n_grid,
-                       voxel_size, min_xyz_host[0], min_xyz_host[1], min_xyz_host[2], rng, cells_out, pts_out);
+                       voxel_size_host[0], voxel_size_host[1], voxel_size_host[2], min_xyz_host[0], min_xyz_host[1], min_xyz_host[2], rng, cells_out, pts_out);
     return check_launch("refresh_cells_points");
 }
 

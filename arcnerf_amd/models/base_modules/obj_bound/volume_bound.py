@@ -95,17 +95,42 @@ class VolumeBound(BasicBound):
         n = vol.get_n_grid()
         dev = vol.get_device()
         n_dev = None
+        pts = None
         if warmup is not None and cur_epoch < warmup:
             cell = torch.arange(vol.get_n_voxel(), device=dev)
         else:
             if not hasattr(self, '_refresh_cache'):
                 self._refresh_cache, self._refresh_rng = {}, np.random.default_rng(12345)
-            # entries past n_dev are stale cells from an earlier refresh: evaluated by the net (harmless) and skipped by the
-            # scatter, which honours the device-side count
-            cell, n_dev = select_refresh_cells(vol.get_voxel_bitfield(flatten=True), vol.get_n_voxel(), self._refresh_cache,
-                                               self._refresh_rng)
-        pts = vol.get_voxel_pts_by_voxel_idx(vol.convert_flatten_index_to_xyz_index(cell, n).float())
-        pts = pts + (torch.rand_like(pts) - 0.5) * vol.get_voxel_size(to_list=False)[None, :]
+            bits = vol.get_voxel_bitfield(flatten=True)
+            if bits.is_cuda and bits.is_contiguous() and bits.data_ptr() % 8 == 0 and n >= 16 and n & (n - 1) == 0:
+                # cells (n / 4 uniform along the Z-curve + the first n / 4 occupied) and their jittered points in four small launches
+                # (arcn_refresh_cells_points; the torch formulation below is ~45)
+                from ....geometry.volume import mix_constants
+                from ....ops import functional as Fn
+                nc, rng, ch = vol.get_n_voxel(), self._refresh_rng, self._refresh_cache
+                if 'native' not in ch:
+                    ch['native'] = {'cells': torch.zeros(2 * (nc // 4), dtype=torch.int64, device=dev),
+                                    'pts': torch.zeros((2 * (nc // 4), 3), dtype=torch.float32, device=dev),
+                                    'n_valid': torch.zeros(1, dtype=torch.int32, device=dev),
+                                    'ws': torch.empty(nc + 8 * (nc // 4096 + 2), dtype=torch.uint8, device=dev)}
+                rb = ch['native']
+                # host copies of the voxel size and the lower corner: read once (one synchronisation) unless the volume is learnable
+                fixed = not (vol.origin.requires_grad or vol.xyz_len.requires_grad)
+                if not fixed or ch.get('geom_n') != n:
+                    ch['geom'] = (vol.get_voxel_size(), vol.get_range()[:, 0].tolist())
+                    ch['geom_n'] = n
+                vsz, mn = ch['geom']
+                Fn.refresh_cells_points(bits, n, mix_constants(nc, rng), vsz, mn,
+                                        int(rng.integers(0, 1 << 62)), int(rng.integers(0, 1 << 62)) * 2 + 1, rb['cells'], rb['pts'], rb['n_valid'],
+                                        rb['ws'])
+                cell, pts, n_dev = rb['cells'], rb['pts'], rb['n_valid']
+            else:
+                # entries past n_dev are stale cells from an earlier refresh: evaluated by the net (harmless) and skipped by the
+                # scatter, which honours the device-side count
+                cell, n_dev = select_refresh_cells(bits, vol.get_n_voxel(), self._refresh_cache, self._refresh_rng)
+        if pts is None:
+            pts = vol.get_voxel_pts_by_voxel_idx(vol.convert_flatten_index_to_xyz_index(cell, n).float())
+            pts = pts + (torch.rand_like(pts) - 0.5) * vol.get_voxel_size(to_list=False)[None, :]
         dt = vol.get_diag_len() / float(n_pts)
         opacity = get_est_opacity(dt, pts.contiguous())
         vol.update_opafield_by_flat_idx(cell, opacity, ema=self.get_optim_cfgs('ema_optim_decay'), n_dev=n_dev)

@@ -467,7 +467,8 @@ def refresh_cells_points(bitfield_bool, n_grid, perm, voxel_size, min_xyz, rng_s
     pa = (C.c_uint64 * 2)(int(perm[0][0]), int(perm[1][0]))
     pc = (C.c_uint64 * 2)(int(perm[0][1]), int(perm[1][1]))
     mn = (C.c_float * 3)(*[float(v) for v in min_xyz])
-    N.check(N.lib().arcn_refresh_cells_points(bitfield_bool.data_ptr(), int(n_grid), C.cast(pa, C.c_void_p), C.cast(pc, C.c_void_p), float(voxel_size),
+    vsz = (C.c_float * 3)(*([float(voxel_size)] * 3 if isinstance(voxel_size, (int, float)) else [float(v) for v in voxel_size]))
+    N.check(N.lib().arcn_refresh_cells_points(bitfield_bool.data_ptr(), int(n_grid), C.cast(pa, C.c_void_p), C.cast(pc, C.c_void_p), C.cast(vsz, C.c_void_p),
                                             C.cast(mn, C.c_void_p), int(rng_state), int(rng_inc), N.ptr(cells), N.ptr(pts), N.ptr(n_valid), N.ptr(workspace),
                                             workspace.numel(), N.stream()), 'refresh_cells_points')
     return cells, pts, n_valid

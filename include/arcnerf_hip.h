@@ -539,10 +539,10 @@ int arcn_update_bitfield_by_opafield(const float *opafield, uint8_t *bitfield, i
  * leave ORDERED - the uniform half along the Z-curve of the grid, the occupied half by flat index - so that spatial neighbours stay
  * neighbours in the hash gather that follows.  cells_out (2 n_s int64), n_valid
  * (device int32) = n_s + min(occupied, n_s), entries behind it are not written; pts_out (2 n_s, 3) = voxel centre + a uniform jitter of
- * one voxel from the pcg32 stream (rng_state, rng_inc).  workspace: >= n_grid^3 + 8 (n_grid^3 / 4096 + 1) bytes, 8-byte aligned like the
+ * one voxel (voxel_size_host[3]: the volume's xyz_len / n_grid) from the pcg32 stream (rng_state, rng_inc).  workspace: >= n_grid^3 + 8 (n_grid^3 / 4096 + 1) bytes, 8-byte aligned like the
  * bitfield.  Four small launches, no host synchronisation (the torch formulation was ~45). */
-int arcn_refresh_cells_points(const uint8_t *bitfield_bool, int n_grid, const uint64_t *perm_a, const uint64_t *perm_c, float voxel_size,
-                              const float *min_xyz_host, uint64_t rng_state, uint64_t rng_inc, int64_t *cells_out, float *pts_out,
+int arcn_refresh_cells_points(const uint8_t *bitfield_bool, int n_grid, const uint64_t *perm_a, const uint64_t *perm_c,
+                              const float *voxel_size_host, const float *min_xyz_host, uint64_t rng_state, uint64_t rng_inc, int64_t *cells_out, float *pts_out,
                               int32_t *n_valid, uint8_t *workspace, int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
