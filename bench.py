@@ -122,16 +122,29 @@ ALIASES = {'hashgrid_fwd_xcd': 'hashgrid_fwd', 'hashgrid_bwd_lm': 'hashgrid_bwd'
 
 class KernelTimers:
     """HIP events (torch.cuda.Event on the launch stream == torch's current stream) around individual C-ABI entry points.
-    Only the names in `enabled` are bracketed: two event records per launch are not free on a 1 ms step, so the timed
-    region brackets the roofline candidates only and the full per-kernel table comes from a separate, untimed pass."""
+    Only the names in `enabled` are bracketed, and of those every `every`-th launch: two event records per launch are not free on a
+    0.6 ms step, so the timed region brackets the roofline candidates only (a quarter of their launches) and the full per-kernel table
+    comes from a separate, untimed pass."""
 
     def __init__(self):
         self.pairs = {}
         self.enabled = set()
+        # every 4th launch of a bracketed entry point carries the two event records: bracketing EVERY launch cost 1.6 % of the step (0.625 vs
+        # 0.612 ms with none, three alternations in one session; the records keep the neighbouring kernels from overlapping), every 4th 0.5 %
+        self.every = 4
+        self.calls = {}
+        self.main = None
 
     def wrap(self, name, fn):
         def inner(*a, **k):
             if name not in self.enabled:
+                return fn(*a, **k)
+            # (the launches of the occupancy refresh on its side stream - another size, another stream - are not the step's)
+            if self.main is not None and torch.cuda.current_stream() != self.main:
+                return fn(*a, **k)
+            c = self.calls.get(name, 0)
+            self.calls[name] = c + 1
+            if c % self.every:
                 return fn(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -143,7 +156,9 @@ class KernelTimers:
 
     def reset(self, enabled):
         self.pairs = {}
+        self.calls = {}
         self.enabled = set(enabled)
+        self.main = torch.cuda.current_stream() if torch.cuda.is_available() else None
 
     def summary(self):
         return {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in self.pairs.items()}
@@ -537,10 +552,12 @@ def main():
     ktable = None
     if world == 1:
         timers.reset(TABLE_KERNELS)
+        timers.every = 1
         for i in range(min(16, args.steps)):
             run(args.warmup + args.steps + i, epoch0 + args.warmup + args.steps + i)
         torch.cuda.synchronize()
         ktable = timers.summary()
+        timers.every = 4
     # the training gather on its own (nothing else on the device): in the step it runs next to the sampling stream's marcher
     alone_ms = alone_pts = None
     if world == 1:
@@ -592,14 +609,8 @@ def main():
     if dom == 'hashgrid_bwd' and world == 1 and getattr(pipe, '_adam_rest', None) is not None:
         n_fused = field.n_params - sum(b_ - a_ for a_, b_ in pipe._adam_rest)
         ach = (hash_kernels[dom] * s_per_launch + 24.0 * n_fused) / dur_s
-    if dom == 'hashgrid_fwd':
-        # mean over launches mixes train (S) and occupancy-refresh (n_cells/2) sizes: weight the bytes accordingly
-        occ_launch = 0 if args.no_occ_update else sum(1 for e in range(epoch0 + args.warmup, epoch0 + args.warmup + args.steps) if e % cfg.epoch_optim == 0)
-        occ_pts = cfg.n_grid ** 3 // 4 + min(cfg.n_grid ** 3 // 4, int(bf.sum()))
-        tot_pts = s_per_launch * args.steps + occ_pts * occ_launch
-        ach = BYTES_HASH_FWD * tot_pts / (dur_s * n_launch[dom])
     roofline = {'kernel': dom if not n_fused else 'hashgrid_bwd (binned scatter) + Adam / EMA of the table levels its chunk owners hold (arcn_hashgrid_bwd_lm_adam)', 'bound': 'hbm', 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                'frac': ach / HBM_PEAK, 'traffic': traffic, 'avg_launch_ms': ksum[dom],
+                'frac': ach / HBM_PEAK, 'traffic': traffic, 'avg_launch_ms': ksum[dom], 'launches_timed': n_launch.get(dom), 'launches_in_region': args.steps,
                 # PMC counters cannot be collected inside a timed run: the figure is the per-launch HBM bytes of the committed
                 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/profile_round.sh)
                 'traffic_source': 'profiles/pmc_traffic.json' if traffic is not None else None, 'traffic_stale': traffic_stale,
@@ -613,9 +624,7 @@ def main():
     # gather hit L1; the coarse levels do hit, which is why the kernel can finish faster than that bound.
     lookup = None
     if ksum.get('hashgrid_fwd'):
-        occ_launch = 0 if args.no_occ_update else sum(1 for e in range(epoch0 + args.warmup, epoch0 + args.warmup + args.steps) if e % cfg.epoch_optim == 0)
-        occ_pts = cfg.n_grid ** 3 // 4 + min(cfg.n_grid ** 3 // 4, int(bf.sum()))
-        pts = (s_per_launch * args.steps + occ_pts * occ_launch) / max(1, n_launch['hashgrid_fwd'])
+        pts = s_per_launch          # (only the step's own launches are bracketed: KernelTimers skips the refresh's side stream)
         sec = ksum['hashgrid_fwd'] * 1e-3
         l2_lines = 16 * 8 * 128.0 * pts
         lookup = {'kernel': 'hashgrid_fwd', 'bound': 'hbm', 'achieved': BYTES_HASH_FWD * pts / sec / 1e9, 'peak': HBM_PEAK / 1e9,
