@@ -184,6 +184,8 @@ class FieldChainFn(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, d_sigma, d_rgb4):
+        if ctx.saved is None:
+            raise RuntimeError('FieldChainFn: the activations of this pass were released by its first backward (retain_graph is not supported)')
         spec, (gw, gb, rw, rb) = ctx.spec, ctx.prep
         D, W, Wf, skips, nr = spec.D, spec.W, spec.W_feat, set(spec.skips), len(spec.rad_widths)
         dev = gw[0].device

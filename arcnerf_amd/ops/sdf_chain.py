@@ -178,6 +178,8 @@ class SdfChainFn(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, d_out, d_n):
+        if ctx.saved is None:
+            raise RuntimeError('SdfChainFn: the activations of this pass were released by its first backward (retain_graph is not supported)')
         spec, ws, bs = ctx.spec, ctx.ws, ctx.bs
         D, skips, ed, beta = spec.D, set(spec.skips), spec.ed, spec.beta
         dev = ws[0].device
