@@ -39,7 +39,7 @@ class NeRFPP(BkgModel):
             radius = torch.norm(pts, dim=-1)[..., None]
         pts = torch.cat([pts / radius, 1 / radius], dim=-1).view(-1, 4)
         dirs = torch.repeat_interleave(rays_d, n_pts, dim=0)
-        sigma, radiance = chunk_processing(self._forward_pts_dir, self.chunk_pts, False, geo_net, radiance_net, pts, dirs)
+        sigma, radiance = self.field_on_points(geo_net, radiance_net, pts.contiguous(), dirs.contiguous())
         return self.ray_marching(sigma.view(-1, n_pts), radiance.view(-1, n_pts, 3), zvals, inference_only=inference_only)
 
     def forward(self, inputs, inference_only=False, get_progress=False, cur_epoch=0, total_epoch=300000):

@@ -55,7 +55,7 @@ def make_spec(geo, rad, chunk):
     from ..models.base_modules.linear import DenseLayer, Linear
     if os.environ.get('ARCN_FIELD_CHAIN', '1') == '0' or type(geo) is not GeoNet or type(rad) is not RadianceNet:
         return None
-    if type(geo.embed_fn) is not FreqEmbedder or geo.embed_fn.input_dim != 3 or geo.embed_fn.n_freqs < 1:
+    if type(geo.embed_fn) is not FreqEmbedder or geo.embed_fn.n_freqs < 1:      # (any input width: NeRF++ feeds (x / r, 1 / r))
         return None
     if geo.norm_skip or geo.out_act is not None or geo.W_feat <= 0 or geo.W_feat % 4 or geo.W % 4 or geo.D < 1:
         return None
@@ -127,7 +127,7 @@ def _relu_layer(x_in, w, b, out, want_mask):
 
 
 class FieldChainFn(torch.autograd.Function):
-    """(sigma (n), pre-activation rgb padded to 4 columns (n, 4)) = field(pts (n, 3), unit dirs (n, 3)); params = weight, bias (or None)
+    """(sigma (n), pre-activation rgb padded to 4 columns (n, 4)) = field(pts (n, D), unit dirs (n, 3)); params = weight, bias (or None)
     of the geometry layers 0 .. D, then of the radiance layers"""
 
     @staticmethod
@@ -251,13 +251,15 @@ def field_chain(geo_net, radiance_net, pts, dirs, chunk_pts):
     """(sigma (n), radiance (n, 3)) of _forward_pts_dir over all points through FieldChainFn, or None where the node does not apply"""
     if not (torch.is_tensor(pts) and pts.is_cuda and pts.dtype == torch.float32 and pts.dim() == 2 and pts.shape[0] > 0):
         return None
-    if dirs is None or dirs.shape != pts.shape or dirs.dtype != torch.float32 or pts.requires_grad or dirs.requires_grad:
+    if dirs is None or dirs.dim() != 2 or dirs.shape[0] != pts.shape[0] or dirs.shape[1] != 3 or dirs.dtype != torch.float32:
+        return None
+    if pts.requires_grad or dirs.requires_grad:
         return None
     from .autograd import _hip_linear_enabled
     if not _hip_linear_enabled() or os.environ.get('ARCN_LINEAR_FUSED_RELU', '1') == '0':
         return None
     spec = make_spec(geo_net, radiance_net, chunk_pts)
-    if spec is None:
+    if spec is None or pts.shape[1] != geo_net.embed_fn.input_dim:
         return None
     params = []
     for layer in list(geo_net.layers) + list(radiance_net.layers):

@@ -1391,7 +1391,8 @@ def test_weights_split_once_for_all_chunks_is_bit_identical():
     (256, 8, [4], 128, 1, True, None, 5000, 2048),                    # configs/nerf.yaml, three chunks (the last one ragged)
     (256, 8, [4], 128, 1, True, 'identity', 3000, 0),                 # configs/hdrnerf.yaml: no sigmoid, one chunk
     (128, 4, [1, 2], 64, 2, False, None, 1500, 700),                  # two skips, three radiance layers, no biases, float masks in the radiance net
-    (64, 2, [], 32, 1, True, None, 333, 100)])                        # no skip, everything on the exact-f32 kernels
+    (64, 2, [], 32, 1, True, None, 333, 100),                         # no skip, everything on the exact-f32 kernels
+    (256, 8, [4], 128, 1, True, None, 2500, 1000)])                   # (n = 2500: 4-D inputs (x / r, 1 / r), the NeRF++ background)
 def test_field_chain_equals_the_layer_by_layer_modules(W, D, skips, Wr, Dr, bias, out_act, n, chunk):
     """ops.field_chain.FieldChainFn (GeoNet + RadianceNet 'vf' as one node over all chunks, concatenation-free buffers, weight gradients
     summed by the products) against the same modules evaluated layer by layer under chunk_processing
@@ -1403,12 +1404,13 @@ def test_field_chain_equals_the_layer_by_layer_modules(W, D, skips, Wr, Dr, bias
     from arcnerf_amd.utils.cfgs_utils import dict_to_obj
     from arcnerf_amd.utils.torch_utils import chunk_processing
     torch.manual_seed(W + D)
-    geo = GeoNet(W=W, D=D, skips=skips, encoder=dict_to_obj({'type': 'FreqEmbedder', 'input_dim': 3, 'n_freqs': 10}), W_feat=W, use_bias=bias,
+    din = 4 if n == 2500 else 3
+    geo = GeoNet(W=W, D=D, skips=skips, encoder=dict_to_obj({'type': 'FreqEmbedder', 'input_dim': din, 'n_freqs': 10}), W_feat=W, use_bias=bias,
                  geometric_init=False).cuda()
     rad = RadianceNet(mode='vf', W=Wr, D=Dr, encoder=dict_to_obj({'view': {'type': 'FreqEmbedder', 'input_dim': 3, 'n_freqs': 4}}), W_feat_in=W,
                       use_bias=bias, out_act_cfg=None if out_act is None else dict_to_obj({'type': out_act})).cuda()
     g = torch.Generator().manual_seed(n)
-    pts = (torch.rand(n, 3, generator=g) * 4 - 2).cuda()
+    pts = (torch.rand(n, din, generator=g) * 4 - 2).cuda()
     dirs = torch.randn(n, 3, generator=g).cuda()
     up_s, up_r = torch.randn(n, generator=g).cuda(), torch.randn(n, 3, generator=g).cuda()
     params = list(geo.parameters()) + list(rad.parameters())
