@@ -32,7 +32,10 @@ class SdfModel(FgModel):
         if res is None:
             return chunk_processing(self._forward_pts_dir, self.chunk_pts, False, geo_net, radiance_net, pts, dirs)
         sdf, feature, normal = res
-        radiance = chunk_processing(radiance_net, self.chunk_pts, False, pts, dirs, normal, feature)
+        from ..ops.radiance_chain import radiance_chain
+        radiance = radiance_chain(radiance_net, pts, dirs, normal, feature, self.chunk_pts)
+        if radiance is None:
+            radiance = chunk_processing(radiance_net, self.chunk_pts, False, pts, dirs, normal, feature)
         return sdf[..., 0].contiguous(), radiance, normal
 
     def forward_pts_dir(self, pts, view_dir=None):

@@ -1596,3 +1596,45 @@ def test_adam_runs_in_one_launch_equal_separate_launches():
         assert torch.equal(x, y)
         assert torch.equal(x[9826:12000], z[9826:12000]) and torch.equal(x[12004:20000], z[12004:20000])
     assert float(a[1][:9826].abs().max()) == 0.0 and not torch.equal(a[0][:9826], base[0][:9826])
+
+
+@pytest.mark.parametrize('mode,W,D,wn,bias,pf,n,chunk', [
+    ('pvnf', 256, 4, True, True, 0, 3000, 1024),       # configs/neus.yaml: raw positions, weight norm, three chunks
+    ('vnf', 128, 2, False, True, 0, 700, 0),           # no position block, one chunk
+    ('pf', 64, 2, False, False, 4, 333, 100)])         # encoded positions, no biases, everything on the exact-f32 kernels
+def test_radiance_chain_equals_the_layer_by_layer_module(mode, W, D, wn, bias, pf, n, chunk):
+    """ops.radiance_chain.RadianceChainFn against RadianceNet.forward under chunk_processing (encoder_mlp_network.py:62-118,
+    linear_network_module.py:318-335): radiance, the gradients of every parameter (weight-norm g / v included) and of the normal and
+    feature inputs (what NeuS's sdf node differentiates further)."""
+    from arcnerf_amd.models.base_modules.geo_rad_model.linear_network_module import RadianceNet
+    from arcnerf_amd.ops.radiance_chain import radiance_chain
+    from arcnerf_amd.utils.cfgs_utils import dict_to_obj
+    from arcnerf_amd.utils.torch_utils import chunk_processing
+    torch.manual_seed(W + D)
+    enc = dict_to_obj({'pts': {'type': 'FreqEmbedder', 'input_dim': 3, 'n_freqs': pf}, 'view': {'type': 'FreqEmbedder', 'input_dim': 3, 'n_freqs': 4}})
+    Wf = 256 if W == 256 else 64
+    rad = RadianceNet(mode=mode, W=W, D=D, encoder=enc, W_feat_in=Wf, use_bias=bias, weight_norm=wn).cuda()
+    g = torch.Generator().manual_seed(n)
+    x, dirs = (torch.rand(n, 3, generator=g) - 0.5).cuda(), torch.randn(n, 3, generator=g).cuda()
+    nrm0, feat0 = torch.randn(n, 3, generator=g).cuda(), (torch.randn(n, Wf + 4, generator=g) * 0.3).cuda()
+    up = torch.randn(n, 3, generator=g).cuda()
+    params = list(rad.parameters())
+
+    def run(fn):
+        nrm = nrm0.clone().requires_grad_(True)
+        fbuf = feat0.clone().requires_grad_(True)
+        feat = fbuf[:, 1:1 + Wf]              # a column slice of a wider buffer, as the sdf node hands the feature over
+        for p in params:
+            p.grad = None
+        out = fn(x, dirs, nrm, feat)
+        (out * up).sum().backward()
+        return [out.detach().clone(), nrm.grad.clone() if 'n' in mode else None, fbuf.grad.clone()] + [p.grad.clone() for p in params]
+    got = run(lambda a, b, c, d: radiance_chain(rad, a, b, c, d, chunk))
+    assert got[0] is not None and got[0].shape == (n, 3)
+    ref = run(lambda a, b, c, d: chunk_processing(rad, chunk, False, a, b, c, d))
+    assert (got[0] - ref[0]).abs().max() <= 2e-6
+    for a, b in zip(got[1:], ref[1:]):
+        if a is None and b is None:
+            continue
+        assert a.shape == b.shape
+        assert (a - b).abs().max() <= 1e-5 * float(b.abs().max()) + 1e-9

@@ -31,8 +31,8 @@ GROUPS = {
         {'ARCN_GEMM_SPLIT': '0', 'ARCN_LINEAR_FUSED_RELU': '0', 'ARCN_LINEAR_SOFTPLUS': '0', 'ARCN_TONEMAP_FUSED': '0', 'ARCN_NEUS_UPSAMPLE_GRAPH': '1'},
         {'ARCN_RELU_BITS': '0', 'ARCN_SOFTPLUS_FUSED': '0'},
         {'ARCN_LINEAR_GEMM': '0'},
-        {'ARCN_FIELD_CHAIN': '0', 'ARCN_SDF_CHAIN': '0'},        # the layer-by-layer modules instead of the one-node fields (several chunks)
-        {'ARCN_FIELD_CHAIN': '0', 'ARCN_SDF_CHAIN': '0', 'ARCN_SKIP_CAT_FUSED': '0', 'ARCN_SPLIT_SCOPE': '0'},   # ... and without their share of it
+        {'ARCN_FIELD_CHAIN': '0', 'ARCN_SDF_CHAIN': '0', 'ARCN_RADIANCE_CHAIN': '0'},        # the layer-by-layer modules instead of the one-node fields (several chunks)
+        {'ARCN_FIELD_CHAIN': '0', 'ARCN_SDF_CHAIN': '0', 'ARCN_RADIANCE_CHAIN': '0', 'ARCN_SKIP_CAT_FUSED': '0', 'ARCN_SPLIT_SCOPE': '0'},   # ... and without their share of it
     ],
     'neusngp': [
         {'ARCN_SDF_JACOBIAN': '0', 'ARCN_LINEAR_FUSED': '0', 'ARCN_PACKED_OVERFLOW_CHECK': '0'},
