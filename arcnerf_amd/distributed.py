@@ -18,15 +18,26 @@ import torch
 import torch.distributed as dist
 
 
+def forced():
+    """ARCN_DIST_FORCE=1: build the process group and issue every collective even at world size 1 (a one-rank RCCL communicator:
+    the whole distributed code path - communicator setup, the collectives' stream hand-over, the segmented gradient sync - runs on a
+    one-GPU box; tests/test_gpu_distributed.py)."""
+    return os.environ.get('ARCN_DIST_FORCE', '0') == '1'
+
+
+def _active(group=None):
+    return dist.is_initialized() and (dist.get_world_size(group) > 1 or forced())
+
+
 def env_world():
     return int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_RANK', '0'))
 
 
 def init_from_env(backend=None, device=None):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun style).
-    Returns (rank, world).  No-op for world == 1."""
+    Returns (rank, world).  No-op for world == 1 (unless ARCN_DIST_FORCE=1)."""
     rank, world, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -68,7 +79,7 @@ def allreduce_grads(flat_grads, world=None, group=None):
     """SUM all-reduce of the flat gradient buffer in place (the average is applied by the optimiser's grad_scale)."""
     if world is None:
         world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world > 1:
+    if world > 1 or _active(group):
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
     return flat_grads
 
@@ -99,7 +110,7 @@ class PipelinedGradSync:
 
     def launch(self, flat_grads):
         self.works = []
-        if not (dist.is_initialized() and dist.get_world_size(self.group) > 1):
+        if not _active(self.group):
             return
         for lo, hi in self.segments:
             self.works.append(dist.all_reduce(flat_grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -111,14 +122,14 @@ class PipelinedGradSync:
 
 def broadcast_bitfield(bits, src=0, group=None):
     """Make every rank march the same occupancy: broadcast the packed bitfield (uint8, n_grid^3/8 bytes) from `src`."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dist.broadcast(bits, src=src, group=group)
     return bits
 
 
 def broadcast_params(flat_params, src=0, group=None):
     """Initial parameter sync (what DDP does at construction)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dist.broadcast(flat_params, src=src, group=group)
     return flat_params
 
@@ -126,6 +137,6 @@ def broadcast_params(flat_params, src=0, group=None):
 def max_over_ranks(value, device=None, group=None):
     """max of a python float over ranks (timing in bench.py)"""
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())

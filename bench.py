@@ -212,7 +212,8 @@ def bench_module(args, name, emit=True):
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('ARCN_DIST_FORCE', '0') == '1'   # ARCN_DIST_FORCE=1: a one-rank communicator runs the same path
+    if use_dist:
         import torch.distributed as dist
         from arcnerf_amd import distributed as D
         D.init_from_env(backend=os.environ.get('ARCN_DIST_BACKEND', 'nccl'), device=dev)
@@ -255,7 +256,7 @@ def bench_module(args, name, emit=True):
     opt.grad_scale = 1.0 / world
     flat_grads = opt.flat_grads()
     flat_numel = sum(p.numel() for p in params)
-    if world > 1:
+    if use_dist:
         D.broadcast_params(opt.flat_params(), src=0)   # what DDP does at construction
 
     def loss_of(out, inp):
@@ -298,7 +299,7 @@ def bench_module(args, name, emit=True):
         loss = loss_of(out, inp)
         opt.zero_grad()
         loss.backward()
-        if world > 1:   # DDP semantics (average of the ranks' gradients): SUM all-reduce of the flat buffer, 1 / world in the optimiser
+        if use_dist:   # DDP semantics (average of the ranks' gradients): SUM all-reduce of the flat buffer, 1 / world in the optimiser
             dist.all_reduce(flat_grads)
         opt.step()
         return loss
@@ -434,7 +435,8 @@ def main():
         torch.cuda.set_stream(torch.cuda.Stream(priority=main_priority))
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('ARCN_DIST_FORCE', '0') == '1'   # ARCN_DIST_FORCE=1: a one-rank communicator runs the same path
+    if use_dist:
         import torch.distributed as dist
         from arcnerf_amd import distributed as D
         # ARCN_DIST_BACKEND=gloo lets several ranks share one GPU for functional testing; the real runs use RCCL
@@ -464,10 +466,10 @@ def main():
 
     timers = KernelTimers()
     instrument(timers)
-    all_reduce = (lambda t: D.allreduce_grads(t, world)) if world > 1 else None
+    all_reduce = (lambda t: D.allreduce_grads(t, world)) if use_dist else None
     # gradient sync: K async segments pipelined with the optimiser (default) or one flat all-reduce (ARCN_GRAD_SEGMENTS=0)
     n_seg = int(os.environ.get('ARCN_GRAD_SEGMENTS', '4'))
-    grad_sync = D.PipelinedGradSync(field.n_params, n_seg) if (world > 1 and n_seg > 0) else None
+    grad_sync = D.PipelinedGradSync(field.n_params, n_seg) if (use_dist and n_seg > 0) else None
     sample_log = torch.zeros(args.steps + args.warmup + 16, dtype=torch.int64, device=dev)
 
     def run(step_idx, epoch):

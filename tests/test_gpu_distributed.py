@@ -175,3 +175,44 @@ def test_bench_refuses_more_rccl_ranks_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n), '--steps', '1', '--warmup', '0'], env=env, cwd=root,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and 'one GPU per rank' in r.stderr
+
+
+@pytest.mark.parametrize('config,segments', [('ngp', '4'), ('ngp', '0'), ('neus_ngp_multivol', '4')])
+def test_bench_under_torchrun_on_a_one_rank_rccl_communicator(config, segments):
+    """The driver's N > 1 command form (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
+    bench.py --gpus N`) with N = 1 and ARCN_DIST_FORCE=1: the process group is built on RCCL (backend "nccl"), and the gradient
+    exchange (segmented / flat), the parameter broadcast, the barriers around the timed region, the max-over-ranks reduction and the
+    all-gather of the per-rank samples all run through a real RCCL communicator on this box's one GPU - everything of the multi-GPU
+    path except a second rank."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'ARCN_DIST_BACKEND'):
+        env.pop(k, None)
+    env.update({'ARCN_DIST_FORCE': '1', 'ARCN_GRAD_SEGMENTS': segments, 'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    extra = ['--gpus', '1', '--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-other-configs', '--no-psnr']
+    if config != 'ngp':
+        extra += ['--config', config, '--rays', '1024']
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py')] + extra
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    rc = out['rccl']
+    assert out['n_gpus'] == 1 and rc is not None and rc['backend'] == 'nccl' and rc['world_size_seen'] == 1
+    assert rc['allreduce_alone_ms'] > 0 and out['value'] > 0
+    if config == 'ngp':
+        assert rc['collectives_per_step'] == (1 if segments == '0' else int(segments))
+        # a one-rank SUM is the identity: the step trains like the single-GPU step (two-pass optimiser form)
+        assert 1e8 < out['value'] < 1e9
