@@ -39,4 +39,59 @@ inline AdamHyper make_adam_hyper(float lr, float beta1, float beta2, float eps, 
     return h;
 }
 
+
+#ifdef __HIPCC__
+typedef float adam_f4 __attribute__((ext_vector_type(4)));
+
+struct AdamArgs {
+    float lr, b1, b2, eps, wd, ema_decay, gscale, bc1, bc2_sqrt, deb_old, deb_new;
+    int zero_grad, ema_in_param;
+};
+
+// workgroup `bid` of `nblocks` over one contiguous run of n parameters
+__device__ __forceinline__ void adam_ema_run(float *__restrict__ param, float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v,
+                                             float *__restrict__ ema, int64_t n, int bid, int nblocks, const AdamArgs &a) {
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)nblocks * blockDim.x;
+    for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        adam_f4 p4 = reinterpret_cast<adam_f4 *>(param)[i];
+        const adam_f4 g4 = reinterpret_cast<const adam_f4 *>(grad)[i];
+        adam_f4 m4 = reinterpret_cast<adam_f4 *>(m)[i];
+        adam_f4 v4 = reinterpret_cast<adam_f4 *>(v)[i];
+        adam_f4 e4 = {0.f, 0.f, 0.f, 0.f};
+        if (a.ema_in_param) e4 = p4;
+        else if (ema) e4 = reinterpret_cast<adam_f4 *>(ema)[i];
+        const bool avg = ema || a.ema_in_param;
+        float p[4] = {p4.x, p4.y, p4.z, p4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
+        float vv[4] = {v4.x, v4.y, v4.z, v4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            adam1(p[k], g[k], mm[k], vv[k], avg ? &ee[k] : nullptr, a.lr, a.b1, a.b2, a.eps, a.wd, a.ema_decay, a.gscale, a.bc1, a.bc2_sqrt, a.deb_old,
+                  a.deb_new);
+        reinterpret_cast<adam_f4 *>(param)[i] = adam_f4{p[0], p[1], p[2], p[3]};
+        reinterpret_cast<adam_f4 *>(m)[i] = adam_f4{mm[0], mm[1], mm[2], mm[3]};
+        reinterpret_cast<adam_f4 *>(v)[i] = adam_f4{vv[0], vv[1], vv[2], vv[3]};
+        if (ema) reinterpret_cast<adam_f4 *>(ema)[i] = adam_f4{ee[0], ee[1], ee[2], ee[3]};
+        if (a.zero_grad) reinterpret_cast<adam_f4 *>(grad)[i] = adam_f4{0.f, 0.f, 0.f, 0.f};
+    }
+    // tail
+    const int64_t t = (n4 << 2) + (int64_t)bid * blockDim.x + threadIdx.x;
+    if (t < n) {
+        float old = param[t];
+        adam1(param[t], grad[t], m[t], v[t], a.ema_in_param ? &old : (ema ? &ema[t] : nullptr), a.lr, a.b1, a.b2, a.eps, a.wd, a.ema_decay, a.gscale,
+              a.bc1, a.bc2_sqrt, a.deb_old, a.deb_new);
+        if (a.zero_grad) grad[t] = 0.f;
+    }
+}
+
+
+// up to four runs [lo, lo + n) of the SAME flat buffers in one launch: the first b[0] workgroups take run 0, the next b[1] run 1, ...
+struct AdamRuns {
+    int64_t lo[4], n[4];
+    int b[4];
+    int count;
+};
+
+#endif
+
 }  // namespace arcn

@@ -1375,7 +1375,7 @@ ARCN_EXPORT int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc 
 static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *dout, int64_t dout_lm_stride,
                              const arcn_hashgrid_desc *desc_host, float *dtable, float *dxyz, float *workspace,
                              int64_t workspace_floats, int64_t n, const int32_t *n_ptr, void *stream, const AdamFuse *fuse = nullptr,
-                             uint32_t *fused_levels_out = nullptr) {
+                             uint32_t *fused_levels_out = nullptr, bool counters_clear = false) {
     if (n <= 0) return ARCN_OK;
     if (!xyz || !dout || (!dtable && !dxyz) || (dxyz && !table)) return einval("hashgrid_bwd: missing argument");
     GridParams g;
@@ -1390,7 +1390,8 @@ static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *
         if (rc) return rc;
         uint32_t *counters = reinterpret_cast<uint32_t *>(workspace);
         uint4 *recs = reinterpret_cast<uint4 *>(workspace + bin_counter_floats(plan));
-        hipError_t e = hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)bin_counter_floats(plan), as_stream(stream));   // (the whole 256-byte padded block: ONE fill launch, an odd size is two)
+        // (the whole 256-byte padded block: ONE fill launch, an odd size is two; none when the caller's previous pass left it clear)
+        hipError_t e = counters_clear ? hipSuccess : hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)bin_counter_floats(plan), as_stream(stream));
         if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
         const size_t lds = plan.det ? sizeof(unsigned long long) * (size_t)plan.chunk_floats
                                     : sizeof(float) * (size_t)plan.chunk_floats + sizeof(uint32_t) * (size_t)(plan.chunk_floats / 32);
@@ -1518,7 +1519,7 @@ ARCN_EXPORT int64_t arcn_hashgrid_bwd_fusable_levels(const arcn_hashgrid_desc *d
 ARCN_EXPORT int arcn_hashgrid_bwd_lm_adam(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host,
                                           float *dtable, float *table, float *exp_avg, float *exp_avg_sq, float lr, float beta1, float beta2,
                                           float eps, float weight_decay, float ema_decay, float grad_scale, int step, int ema_step,
-                                          float *workspace, int64_t workspace_floats, int64_t n, const int32_t *n_ptr,
+                                          float *workspace, int64_t workspace_floats, int counters_clear, int64_t n, const int32_t *n_ptr,
                                           uint32_t *fused_levels_host, void *stream) {
     if (dout_stride < n) return einval("hashgrid_bwd_lm_adam: level stride smaller than n");
     if (!workspace || !table || !exp_avg || !exp_avg_sq || !fused_levels_host || step < 1)
@@ -1533,7 +1534,16 @@ ARCN_EXPORT int arcn_hashgrid_bwd_lm_adam(const float *xyz, const float *dout_lm
     fz.ema_in_param = ema ? 1 : 0;
     *fused_levels_host = 0u;
     return hashgrid_bwd_impl(xyz, nullptr, dout_lm, dout_stride, desc_host, dtable, nullptr, workspace, workspace_floats, n, n_ptr, stream, &fz,
-                             fused_levels_host);
+                             fused_levels_host, counters_clear != 0);
+}
+
+ARCN_EXPORT int64_t arcn_hashgrid_bwd_counter_words(const arcn_hashgrid_desc *desc_host, int64_t n) {
+    if (!desc_host || n <= 0) return 0;
+    GridParams g;
+    if (build_params(desc_host, g) || g.F > 2) return 0;
+    BinPlan plan;
+    if (build_bin_plan(g, n, plan)) return 0;
+    return bin_counter_floats(plan);
 }
 
 ARCN_EXPORT int64_t arcn_hashgrid_bwd_status_offset(const arcn_hashgrid_desc *desc_host, int64_t n) {

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "adam.hpp"
 
 namespace arcn {
 
@@ -914,19 +915,26 @@ mlp_bwd_dw_kernel(const float *__restrict__ x, const float *__restrict__ acts, c
 // (the kernel is pure load latency: 512 slots x 16 KiB per layer), the slices meet in LDS and slice 0 adds the total into dW with
 // a plain read-modify-write: one owner per element, no atomics, and a fixed summation order (bit-reproducible gradients).
 constexpr int kReduceElems = 64, kReduceSlices = 16;
-__global__ void __launch_bounds__(kReduceElems * kReduceSlices)
-mlp_dw_reduce_kernel(const float *__restrict__ partials, const float *__restrict__ bias_partials, DwParams P, int n_slots,
-                     float *__restrict__ dweights, float *__restrict__ dbiases) {
-    __shared__ float part[kReduceSlices][kReduceElems];
+
+// Optional tail of the reduction: the owner of a weight element applies the optimiser to it right away (arcn_ngp_step_tail) - the
+// flat parameter / moment buffers at the net's weight segment, the very adam1 of adam_ema_kernel on gradient = dW as accumulated.
+struct DwAdam {
+    float *param, *m, *v, *ema;   // at the first weight of the net; param == nullptr: plain reduction
+    AdamArgs a;
+};
+
+__device__ __forceinline__ void dw_reduce_block(const float *__restrict__ partials, const float *__restrict__ bias_partials, const DwParams &P,
+                                                int n_slots, int bx, int by, float *__restrict__ dweights, float *__restrict__ dbiases,
+                                                float (&part)[kReduceSlices][kReduceElems], const DwAdam &opt) {
     int l = 0;
-    while (l + 1 < P.n_layers && (int)blockIdx.y >= P.quad_first[l + 1]) ++l;
-    const int q = blockIdx.y - P.quad_first[l];
+    while (l + 1 < P.n_layers && by >= P.quad_first[l + 1]) ++l;
+    const int q = by - P.quad_first[l];
     const int N = P.dims[l + 1], K = P.dims[l];
     const int qn = (tiles16(K) + 3) / 4;
     const int mt0 = (q / qn) * 4, nt0 = (q % qn) * 4;
     const int el = threadIdx.x % kReduceElems, z = threadIdx.x / kReduceElems;
-    const int e = blockIdx.x * kReduceElems + el;  // 0..4095 inside the 64x64 quadrant, fragment order
-    const float *src = partials + (int64_t)blockIdx.y * n_slots * 4096 + e;
+    const int e = bx * kReduceElems + el;  // 0..4095 inside the 64x64 quadrant, fragment order
+    const float *src = partials + (int64_t)by * n_slots * 4096 + e;
     const int tile = e >> 8, ln = (e >> 2) & 63, r = e & 3;
     const int a = tile >> 2, b = tile & 3;
     // accumulator layout: row = 4*(ln>>4) + r (output neuron), col = ln & 15 (input neuron)
@@ -950,17 +958,80 @@ mlp_dw_reduce_kernel(const float *__restrict__ partials, const float *__restrict
         float tot = part[0][el];
 #pragma unroll
         for (int k = 1; k < kReduceSlices; ++k) tot += part[k][el];
-        float *dst = &dweights[P.w_off[l] + (int64_t)row * K + col];
-        *dst = *dst + tot;
+        const int64_t at = P.w_off[l] + (int64_t)row * K + col;
+        float *dst = &dweights[at];
+        const float g = *dst + tot;
+        if (opt.param) {
+            const AdamArgs &h = opt.a;
+            float old = opt.param[at];
+            adam1(opt.param[at], g, opt.m[at], opt.v[at], h.ema_in_param ? &old : (opt.ema ? &opt.ema[at] : nullptr), h.lr, h.b1, h.b2, h.eps, h.wd,
+                  h.ema_decay, h.gscale, h.bc1, h.bc2_sqrt, h.deb_old, h.deb_new);
+            *dst = h.zero_grad ? 0.f : g;
+        } else {
+            *dst = g;
+        }
     }
-    if (P.has_bias && dbiases && bias_partials && nt0 == 0 && blockIdx.x == 0 && threadIdx.x < 64) {
-        const float *bs = bias_partials + (int64_t)blockIdx.y * n_slots * 64 + threadIdx.x;
+    if (P.has_bias && dbiases && bias_partials && nt0 == 0 && bx == 0 && threadIdx.x < 64) {
+        const float *bs = bias_partials + (int64_t)by * n_slots * 64 + threadIdx.x;
         float bv = 0.f;
         for (int k = 0; k < n_slots; ++k) bv += bs[(int64_t)k * 64];
         const int brow = 16 * mt0 + threadIdx.x;  // threadIdx.x = a*16 + i
         // several quadrants of one layer (nt0 == 0 for each row block) own different rows: still one writer per element
         if (brow < N && bv != 0.f) dbiases[P.b_off[l] + brow] += bv;
     }
+}
+
+__global__ void __launch_bounds__(kReduceElems * kReduceSlices)
+mlp_dw_reduce_kernel(const float *__restrict__ partials, const float *__restrict__ bias_partials, DwParams P, int n_slots,
+                     float *__restrict__ dweights, float *__restrict__ dbiases) {
+    __shared__ float part[kReduceSlices][kReduceElems];
+    dw_reduce_block(partials, bias_partials, P, n_slots, blockIdx.x, blockIdx.y, dweights, dbiases, part, DwAdam{});
+}
+
+// The end of the single-GPU NGP step in ONE launch (arcn_ngp_step_tail): the dW reductions of both nets with the optimiser applied by
+// each element's owner, the optimiser on what else is left of the flat buffer (the table levels the scatter did not take), and the
+// scatter's bin counters cleared for the next step.  Four launches of 5 - 7 us each (two reductions, optimiser, memset) were 4 % of
+// the step.
+struct TailNet {
+    const float *partials;
+    DwParams P;
+    int n_slots, blocks;       // blocks = (4096 / kReduceElems) * n_layers
+    int64_t w_seg;             // first weight of the net in the flat buffers
+};
+
+__global__ void __launch_bounds__(kReduceElems * kReduceSlices)
+ngp_step_tail_kernel(TailNet na, TailNet nb, float *__restrict__ param, float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v,
+                     float *__restrict__ ema, AdamRuns r, AdamArgs a, uint32_t *__restrict__ clear, int64_t clear_words, int clear_blocks) {
+    __shared__ float part[kReduceSlices][kReduceElems];
+    int bid = blockIdx.x;
+    constexpr int per = 4096 / kReduceElems;
+    // (two explicit branches: a net picked by reference makes the compiler copy both argument structs to scratch memory)
+    if (bid < na.blocks) {
+        DwAdam opt{param + na.w_seg, m + na.w_seg, v + na.w_seg, ema ? ema + na.w_seg : nullptr, a};
+        dw_reduce_block(na.partials, nullptr, na.P, na.n_slots, bid % per, bid / per, grad + na.w_seg, nullptr, part, opt);
+        return;
+    }
+    bid -= na.blocks;
+    if (bid < nb.blocks) {
+        DwAdam opt{param + nb.w_seg, m + nb.w_seg, v + nb.w_seg, ema ? ema + nb.w_seg : nullptr, a};
+        dw_reduce_block(nb.partials, nullptr, nb.P, nb.n_slots, bid % per, bid / per, grad + nb.w_seg, nullptr, part, opt);
+        return;
+    }
+    bid -= nb.blocks;
+    if (bid < clear_blocks) {
+        for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i < clear_words; i += (int64_t)clear_blocks * blockDim.x) clear[i] = 0u;
+        return;
+    }
+    bid -= clear_blocks;
+    // the run of this workgroup, by constant indices (a dynamic index into the argument struct goes through scratch memory)
+    int64_t lo = r.lo[0], cnt = r.n[0];
+    int nb_run = r.b[0], first = 0, start = r.b[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        if (k < r.count && bid >= start) { lo = r.lo[k]; cnt = r.n[k]; nb_run = r.b[k]; first = start; }
+        start += r.b[k];
+    }
+    adam_ema_run(param + lo, grad + lo, m + lo, v + lo, ema ? ema + lo : nullptr, cnt, bid - first, nb_run, a);
 }
 
 static int build_mlp_params(const arcn_mlp_desc *d, MlpParams &P, bool transposed, int *lds_floats, int *max_dim) {
@@ -1271,6 +1342,77 @@ ARCN_EXPORT int arcn_mlp_bwd_reduce(const arcn_mlp_desc *desc_host, float *scrat
     hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(4096 / kReduceElems, (unsigned)P.n_layers), dim3(kReduceElems * kReduceSlices), 0, as_stream(stream), partials,
                        static_cast<const float *>(nullptr), D, (int)grid, dweights, static_cast<float *>(nullptr));
     return check_launch("mlp_bwd_reduce");
+}
+
+static int tail_net(const arcn_mlp_desc *desc_host, float *scratch, int64_t n_cap, int64_t n, int64_t w_seg, TailNet &t) {
+    MlpParams P;
+    int lds_floats, md, rc;
+    if ((rc = build_mlp_params(desc_host, P, true, &lds_floats, &md))) return rc;
+    if (P.has_bias || P.n_layers < 2 || P.n_layers > 3 || md > 64) return einval("ngp_step_tail: not a fused-backward shape");
+    int64_t grid = tile_grid(n, 64);
+    if (grid > dw_slabs(n_cap)) grid = dw_slabs(n_cap);
+    t.P.n_layers = P.n_layers;
+    t.P.has_bias = 0;
+    for (int l = 0; l <= P.n_layers; ++l) t.P.dims[l] = P.dims[l];
+    for (int l = 0; l < P.n_layers; ++l) { t.P.w_off[l] = P.w_off[l]; t.P.b_off[l] = P.b_off[l]; t.P.quad_first[l] = l; }
+    t.P.quad_first[P.n_layers] = P.n_layers;
+    t.partials = scratch + arcn_mlp_dpre_floats(desc_host, n_cap);
+    t.n_slots = (int)grid;
+    t.blocks = (4096 / kReduceElems) * P.n_layers;
+    t.w_seg = w_seg;
+    return ARCN_OK;
+}
+
+/* The tail of a single-GPU training step of the packed NGP pipeline in one launch.  Replaces, with the same arithmetic,
+ *   arcn_mlp_bwd_reduce(desc_a, scratch_a, grad + w_seg_a, ...), arcn_mlp_bwd_reduce(desc_b, scratch_b, grad + w_seg_b, ...)   (deferred dW sums)
+ *   arcn_adam_ema_step_runs(param, grad, ..., runs = [the runs given here] + the two weight segments, zero_grad = 1)
+ *   and the clearing of `clear_words` 32-bit words at `clear` (the scatter's bin counters, arcn_hashgrid_bwd_counter_block).
+ * The two nets' weight segments [w_seg, w_seg + n_weights) must not overlap the runs.  Same n_cap / n as the backward calls that left
+ * the partials in the scratch buffers.  Reference: the optimiser step of common/trainer/basic_trainer.py:560-577 on the MLP
+ * parameters (torch.optim.Adam, common/trainer/optimizer.py:6-54) + EMA write-back (arcnerf/trainer/ema.py:29-43). */
+ARCN_EXPORT int arcn_ngp_step_tail(const arcn_mlp_desc *desc_a, float *scratch_a, int64_t w_seg_a, const arcn_mlp_desc *desc_b, float *scratch_b,
+                                   int64_t w_seg_b, int64_t n_cap, int64_t n, float *param, float *grad, float *exp_avg, float *exp_avg_sq,
+                                   float *ema, const int64_t *runs_host, int n_runs, float lr, float beta1, float beta2, float eps,
+                                   float weight_decay, float ema_decay, float grad_scale, int step, int ema_step, uint32_t *clear,
+                                   int64_t clear_words, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!desc_a || !desc_b || !scratch_a || !scratch_b || !param || !grad || !exp_avg || !exp_avg_sq || n_runs < 0 || n_runs > 4 || step < 1 ||
+        (n_runs && !runs_host) || w_seg_a < 0 || w_seg_b < 0 || (clear_words > 0 && !clear))
+        return einval("ngp_step_tail: missing/invalid argument");
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq) | reinterpret_cast<uintptr_t>(ema)) & 15)
+        return einval("ngp_step_tail: buffers must be 16-byte aligned");
+    if (ema && ema_step < 1) return einval("ngp_step_tail: ema_step is 1-based");
+    TailNet na{}, nb{};
+    int rc;
+    if ((rc = tail_net(desc_a, scratch_a, n_cap, n, w_seg_a, na))) return rc;
+    if ((rc = tail_net(desc_b, scratch_b, n_cap, n, w_seg_b, nb))) return rc;
+    AdamRuns r{};
+    int total = 0;
+    constexpr int kThreads = kReduceElems * kReduceSlices;
+    for (int k = 0; k < n_runs; ++k) {
+        const int64_t lo = runs_host[2 * k], cnt = runs_host[2 * k + 1];
+        if (lo < 0 || cnt < 0 || (lo & 3)) return einval("ngp_step_tail: a run must start at a multiple of 4 floats");
+        if (cnt == 0) continue;
+        int64_t blocks = ceil_div<int64_t>((cnt >> 2) + 1, kThreads);
+        if (blocks > 512) blocks = 512;
+        r.lo[r.count] = lo; r.n[r.count] = cnt; r.b[r.count] = (int)blocks;
+        total += (int)blocks;
+        ++r.count;
+    }
+    const AdamHyper h = make_adam_hyper(lr, beta1, beta2, eps, weight_decay, ema_decay, grad_scale, step, ema_step, ema != nullptr);
+    const int ema_in_param = ema == param;
+    const AdamArgs a{lr, beta1, beta2, eps, weight_decay, ema_decay, grad_scale, h.bc1, h.bc2_sqrt, h.deb_old, h.deb_new, 1, ema_in_param};
+    int clear_blocks = 0;
+    if (clear_words > 0) {
+        clear_blocks = (int)ceil_div<int64_t>(clear_words, (int64_t)kThreads * 4);
+        if (clear_blocks > 64) clear_blocks = 64;
+    }
+    if (r.count == 0) { r.count = 1; r.b[0] = 0; }   // nothing left for the plain optimiser: no blocks behind the reductions
+    const unsigned grid = (unsigned)(na.blocks + nb.blocks + clear_blocks + total);
+    hipLaunchKernelGGL(ngp_step_tail_kernel, dim3(grid), dim3(kThreads), 0, as_stream(stream), na, nb, param, grad, exp_avg, exp_avg_sq,
+                       ema_in_param ? static_cast<float *>(nullptr) : ema, r, a, clear, clear_words, clear_blocks);
+    return check_launch("ngp_step_tail");
 }
 
 ARCN_EXPORT int arcn_mlp_bwd_dw(const float *x, const arcn_mlp_desc *desc_host, const float *acts, float *scratch,

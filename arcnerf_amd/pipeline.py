@@ -308,6 +308,34 @@ class NgpPipeline:
         self.defer_dw = int(os.environ.get('ARCN_DEFER_DW', '0')) if self.level_major else 0
         self.red_stream = torch.cuda.Stream(device=dev) if (dev.type == 'cuda' and self.defer_dw == 2) else None
         self._red_event = None
+        # single-GPU step with the optimiser inside the scatter: the two dW reductions, the optimiser on the rest of the flat buffer and
+        # the clearing of the scatter's bin counters as ONE launch at the end of the step (arcn_ngp_step_tail; ARCN_STEP_TAIL=0: four)
+        self._tail = None
+        self._tail_step = False
+        self._ws_clear = False
+        if (self._adam_rest is not None and self.level_major and self.fused_glue and self.defer_dw == 0 and not cfg.has_bias and
+                bool(int(os.environ.get('ARCN_STEP_TAIL', '1')))):
+            gw, rw = field._seg['geo_w'], field._seg['rad_w']
+            inside = lambda run, seg: seg[0] >= run[0] and seg[0] + seg[1] <= run[1]
+            rest, ok = [], True
+            for run in self._adam_rest:     # the weight segments leave the plain optimiser's runs (they sit at the end of the last one)
+                segs = sorted(sg for sg in (gw, rw) if inside(run, sg))
+                lo = run[0]
+                for sg in segs:
+                    if sg[0] > lo:
+                        rest.append((lo, sg[0]))
+                    lo = sg[0] + sg[1]
+                if run[1] > lo:
+                    rest.append((lo, run[1]))
+            ok = (sum(1 for run in self._adam_rest for sg in (gw, rw) if inside(run, sg)) == 2 and len(rest) <= 4 and
+                  all(lo % 4 == 0 for lo, _ in rest))
+            if ok:
+                self._tail = {'runs': rest, 'geo_w': gw[0], 'rad_w': rw[0],
+                              'clear_words': int(N.lib().arcn_hashgrid_bwd_counter_words(N.C.addressof(field.grid_desc), int(S)))}
+                # the tail launch is pure load latency (13 us alone, 50 us with the marcher's waves resident next to it): the next batch's
+                # marching is issued behind it, not in front (0.607 against 0.609 ms per step, 0.618 with the four launches)
+                if 'ARCN_PREFETCH_AT' not in os.environ and self.prefetch_depth != 1:
+                    self.prefetch_at = 4
         # optimiser state
         n = field.n_params
         self.exp_avg = torch.zeros(n, dtype=f32, device=dev)
@@ -576,13 +604,16 @@ class NgpPipeline:
                                                 N.ptr(b['d_sigma']), N.ptr(b['d_rgb_s']), st), 'composite_packed_bwd')
         self._composite_bwd_done = False
         S = self.cap
+        # the step's tail launch (optimizer_step) sums the dW partials and applies the optimiser: the nets leave them in their scratch
+        tail = bool(self._fuse_next and self._tail is not None and self._adam_rest is not None and self._pb is None and self._gb is None and
+                    self.ema is self.field.params)
         # dx and dW of each net come out of ONE fused kernel (arcn_mlp_bwd with dweights): dpre never leaves the registers
         if self.fused_glue:
             # ... and the radiance net writes d geo_out directly (feature half of its input gradient + sigma's gradient in col 0)
             N.check(L.arcn_mlp_bwd_cat(N.ptr(b['geo_out']), N.ptr(b['sh_ray']), N.ptr(b['ray_id']), int(cfg.rad_mode == 'fv'),
                                        N.ptr(self._p('rad_w')), N.C.addressof(fld.rad_desc), N.ptr(b['rgb_s']), N.ptr(b['rad_acts']),
                                        N.ptr(b['d_rgb_s']), N.ptr(b['d_geo_out']), N.ptr(b['d_sigma']), N.ACT[cfg.sigma_act],
-                                       N.ptr(self._g('rad_w')), N.ptr(b['rad_scratch']), int(self.defer_dw > 0), S, S, n_dev.data_ptr(), st),
+                                       N.ptr(self._g('rad_w')), N.ptr(b['rad_scratch']), int(self.defer_dw > 0 or tail), S, S, n_dev.data_ptr(), st),
                     'mlp_bwd_cat(rad)')
             if self.red_stream is not None:
                 self._reduce_on_side(fld.rad_desc, b['rad_scratch'], self._g('rad_w'), S)
@@ -597,7 +628,7 @@ class NgpPipeline:
         if self.level_major:
             N.check(L.arcn_mlp_bwd_lm(N.ptr(b['feat']), S, N.ptr(self._p('geo_w')), N.C.addressof(fld.geo_desc), N.ptr(b['geo_out']),
                                       N.ptr(b['geo_acts']), N.ptr(b['d_geo_out']), N.ptr(b['d_feat']), N.ptr(self._g('geo_w')),
-                                      N.ptr(b['geo_scratch']), int(self.defer_dw > 0), S, S, n_dev.data_ptr(), st), 'mlp_bwd_lm(geo)')
+                                      N.ptr(b['geo_scratch']), int(self.defer_dw > 0 or tail), S, S, n_dev.data_ptr(), st), 'mlp_bwd_lm(geo)')
             if self.red_stream is not None:
                 self._reduce_on_side(fld.geo_desc, b['geo_scratch'], self._g('geo_w'), S)
             self._prefetch_point(2)
@@ -612,13 +643,17 @@ class NgpPipeline:
                                                     N.ptr(fld.view('table')), self.exp_avg[t_lo:].data_ptr(), self.exp_avg_sq[t_lo:].data_ptr(),
                                                     float(cfg.lr), float(cfg.betas[0]), float(cfg.betas[1]), float(cfg.eps),
                                                     float(cfg.weight_decay), -1.0 if cfg.ema_decay is None else float(cfg.ema_decay), 1.0, self.step_count + 1,
-                                                    self.step_count + 1, N.ptr(self.hash_ws), self.hash_ws.numel(), S, n_dev.data_ptr(),
-                                                    N.C.byref(fused), st), 'hashgrid_bwd_lm_adam')
+                                                    self.step_count + 1, N.ptr(self.hash_ws), self.hash_ws.numel(), int(self._ws_clear), S,
+                                                    n_dev.data_ptr(), N.C.byref(fused), st), 'hashgrid_bwd_lm_adam')
                 assert fused.value == self._fused_mask, (fused.value, self._fused_mask)
                 self._fused_step = True
+                self._tail_step = tail
+                self._ws_clear = False
             else:
+                assert not tail
                 N.check(L.arcn_hashgrid_bwd_lm(N.ptr(b['xyz']), N.ptr(b['d_feat']), S, N.C.addressof(fld.grid_desc), N.ptr(self._g('table')),
                                                N.ptr(self.hash_ws), self.hash_ws.numel(), S, n_dev.data_ptr(), st), 'hashgrid_bwd_lm')
+                self._ws_clear = False
             self._fuse_next = False
             if self.defer_dw == 1:
                 # the two tiny dW reductions run here, after the scatter, instead of between the big backward kernels where
@@ -698,6 +733,20 @@ class NgpPipeline:
         if self._fused_step:        # the scatter of this step already updated its levels: the rest of the flat buffer
             self._fused_step = False
             assert lo is None and hi is None and world_size == 1
+            if self._tail_step:
+                self._tail_step = False
+                t, b = self._tail, self.buf
+                S = self.cap
+                flat = (N.C.c_int64 * max(2, 2 * len(t['runs'])))(*[v for a, b_ in t['runs'] for v in (int(a), int(b_) - int(a))])
+                N.check(N.lib().arcn_ngp_step_tail(N.C.addressof(fld.geo_desc), N.ptr(b['geo_scratch']), t['geo_w'], N.C.addressof(fld.rad_desc),
+                                                   N.ptr(b['rad_scratch']), t['rad_w'], S, S, N.ptr(fld.params), N.ptr(fld.grads),
+                                                   N.ptr(self.exp_avg), N.ptr(self.exp_avg_sq), N.ptr(self.ema), N.C.cast(flat, N.C.c_void_p),
+                                                   len(t['runs']), float(cfg.lr), float(cfg.betas[0]), float(cfg.betas[1]), float(cfg.eps),
+                                                   float(cfg.weight_decay), float(-1.0 if cfg.ema_decay is None else cfg.ema_decay), 1.0,
+                                                   self.step_count, self.step_count, N.ptr(self.hash_ws), t['clear_words'], N.stream()),
+                        'ngp_step_tail')
+                self._ws_clear = True
+                return
             if 1 < len(self._adam_rest) <= 4:      # the small levels in front of the fused ones and the MLP weights behind them: one launch
                 F.adam_ema_step_runs(fld.params, fld.grads, self.exp_avg, self.exp_avg_sq, self.ema, self._adam_rest, self.step_count, lr=cfg.lr,
                                      betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, ema_decay=cfg.ema_decay, grad_scale=1.0,

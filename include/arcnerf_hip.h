@@ -241,13 +241,18 @@ int arcn_hashgrid_bwd_lm(const float *xyz, const float *dout_lm, int64_t dout_st
  * Applies to the levels with one owner per chunk; *fused_levels_host (HOST pointer) receives their bit mask, the other levels' gradient is
  * accumulated into dtable as usual and the caller runs arcn_adam_ema_step on their rows (and on every other parameter).
  * ema_decay < 0: plain Adam; >= 0: the EMA with its shadow aliased onto the parameter (the ema == param form of arcn_adam_ema_step).
- * Not available with ARCN_DETERMINISTIC=1 (mask 0: nothing fused, plain scatter). */
+ * Not available with ARCN_DETERMINISTIC=1 (mask 0: nothing fused, plain scatter).  counters_clear: see arcn_hashgrid_bwd_counter_words. */
 /* bit mask of the levels arcn_hashgrid_bwd_lm_adam would apply the optimiser to for a workspace plan of n samples (0: none) */
 int64_t arcn_hashgrid_bwd_fusable_levels(const arcn_hashgrid_desc *desc_host, int64_t n);
 int arcn_hashgrid_bwd_lm_adam(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host, float *dtable,
                               float *table, float *exp_avg, float *exp_avg_sq, float lr, float beta1, float beta2, float eps,
                               float weight_decay, float ema_decay, float grad_scale, int step, int ema_step, float *workspace,
-                              int64_t workspace_floats, int64_t n, const int32_t *n_ptr, uint32_t *fused_levels_host, void *stream);
+                              int64_t workspace_floats, int counters_clear, int64_t n, const int32_t *n_ptr, uint32_t *fused_levels_host,
+                              void *stream);
+/* The scatter starts from a cleared block of bin counters: the first arcn_hashgrid_bwd_counter_words(desc, n) 32-bit words of its
+ * workspace.  counters_clear = 1 above says the caller has cleared them since the previous scatter on this workspace
+ * (arcn_ngp_step_tail does, in the launch that ends the step), so the scatter skips its own fill launch. */
+int64_t arcn_hashgrid_bwd_counter_words(const arcn_hashgrid_desc *desc_host, int64_t n);
 
 /* FreqEmbedder.forward (encoding/freq_encoder.py:65-88): out (n, D*(include_input + 2*n_freqs)). */
 int arcn_freq_fwd(const float *x, int D, int n_freqs, int include_input, float *out, int64_t n, void *stream);
@@ -565,6 +570,21 @@ int arcn_adam_ema_step(float *param, float *grad, float *exp_avg, float *exp_avg
 int arcn_adam_ema_step_runs(float *param, float *grad, float *exp_avg, float *exp_avg_sq, float *ema, const int64_t *runs_host, int n_runs,
                             float lr, float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale, int step,
                             int ema_step, int zero_grad, void *stream);
+
+/* The end of a single-GPU training step of the packed NGP pipeline in ONE launch (the four launches it replaces - two dW reductions, the
+ * optimiser on the rest of the flat buffer, the scatter's counter fill - were 5 - 7 us each, 4 % of the step), same arithmetic as
+ *   arcn_mlp_bwd_reduce(desc_a, scratch_a, grad + w_seg_a, n_cap, n), arcn_mlp_bwd_reduce(desc_b, scratch_b, grad + w_seg_b, n_cap, n)
+ *     (the deferred dW sums of arcn_mlp_bwd_cat / arcn_mlp_bwd_lm called with defer_reduce = 1), then
+ *   arcn_adam_ema_step_runs(param, grad, ..., [runs_host] + the two nets' weight segments, zero_grad = 1)
+ *     (torch.optim.Adam as configured by common/trainer/optimizer.py:6-54, EMA.ema_step written back, arcnerf/trainer/ema.py:29-43;
+ *      the step of common/trainer/basic_trainer.py:560-577), the owner of a dW element applying the update to it,
+ *   and clear_words 32-bit words cleared at `clear` (the scatter's bin counters: arcn_hashgrid_bwd_counter_words; NULL / 0: none).
+ * w_seg_a / w_seg_b: first weight of each net in the flat buffers (the nets' weights must not overlap the runs).  Bias-free nets of
+ * 2 - 3 layers up to 64 wide (the fused-backward shapes). */
+int arcn_ngp_step_tail(const arcn_mlp_desc *desc_a, float *scratch_a, int64_t w_seg_a, const arcn_mlp_desc *desc_b, float *scratch_b,
+                       int64_t w_seg_b, int64_t n_cap, int64_t n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, float *ema,
+                       const int64_t *runs_host, int n_runs, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       float ema_decay, float grad_scale, int step, int ema_step, uint32_t *clear, int64_t clear_words, void *stream);
 
 #ifdef __cplusplus
 }

@@ -409,3 +409,84 @@ def test_scatter_with_fused_optimiser_equals_scatter_then_adam():
     assert step > 1e-3 and float(((p_a - p_b).abs() > 0.02 * step).float().mean()) < 1e-3
     far = ((res[True][1] - res[False][1]).abs() > 0.05 * float((res[False][1] - res[False][2]).abs().max())).float().mean()
     assert float(far) < 5e-3
+
+
+def test_step_tail_launch_equals_the_four_launches_it_replaces():
+    """arcn_ngp_step_tail (two dW reductions with the optimiser applied by each element's owner + the optimiser on the remaining runs +
+    the scatter's counter block cleared, ONE launch) against arcn_mlp_bwd_reduce x 2, arcn_adam_ema_step_runs and a memset on the same
+    partials and state: bit-identical parameters, moments and (cleared) gradients, three steps so the bias corrections move.  Then the
+    pipeline: ARCN_STEP_TAIL=1 (default) and =0 train three steps from the same state; everything that does not come out of the float
+    scatter's summation order - the MLP weights' first step - agrees to rounding, and the counters are clear when the scatter says so."""
+    import ctypes as C
+    import os
+    from arcnerf_amd import _native as N
+    from arcnerf_amd.ops import functional as F
+    from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline, synthetic_bitfield, synthetic_rays
+    dev = torch.device('cuda:0')
+    cfg = NgpConfig(noise_std=0.0, lr=1e-2)
+    fld = NgpField(cfg, device=dev, seed=3)
+    S = 1 << 16
+    L = N.lib()
+    g = torch.Generator().manual_seed(5)
+    n_p = fld.n_params
+    gw, rw = fld._seg['geo_w'], fld._seg['rad_w']
+    geo_scr = torch.randn(int(L.arcn_mlp_scratch_floats(C.addressof(fld.geo_desc), S)), generator=g).to(dev)
+    rad_scr = torch.randn(int(L.arcn_mlp_scratch_floats(C.addressof(fld.rad_desc), S)), generator=g).to(dev)
+    runs = [(0, 4096), (8192, 8192 + 1000 * 4)]
+    state = {}
+    for tail in (True, False):
+        p = fld.params.clone()
+        gr = torch.zeros(n_p, device=dev)
+        gr[:16384] = torch.randn(16384, generator=torch.Generator().manual_seed(9)).to(dev)
+        m, v = torch.zeros(n_p, device=dev), torch.zeros(n_p, device=dev)
+        clear = torch.full((1000,), 7, dtype=torch.int32, device=dev)
+        for step in (1, 2, 3):
+            if step > 1:
+                gr[:16384] = torch.randn(16384, generator=torch.Generator().manual_seed(9 + step)).to(dev)
+            if tail:
+                flat = (C.c_int64 * 4)(*[x for a, b in runs for x in (a, b - a)])
+                N.check(L.arcn_ngp_step_tail(C.addressof(fld.geo_desc), N.ptr(geo_scr), gw[0], C.addressof(fld.rad_desc), N.ptr(rad_scr), rw[0], S, S,
+                                             N.ptr(p), N.ptr(gr), N.ptr(m), N.ptr(v), N.ptr(p), C.cast(flat, C.c_void_p), 2, 1e-2, 0.9, 0.99, 1e-15,
+                                             0.0, 0.95, 1.0, step, step, N.ptr(clear), 1000, N.stream()), 'tail')
+            else:
+                N.check(L.arcn_mlp_bwd_reduce(C.addressof(fld.geo_desc), N.ptr(geo_scr), N.ptr(gr[gw[0]:]), S, S, N.stream()), 'reduce')
+                N.check(L.arcn_mlp_bwd_reduce(C.addressof(fld.rad_desc), N.ptr(rad_scr), N.ptr(gr[rw[0]:]), S, S, N.stream()), 'reduce')
+                F.adam_ema_step_runs(p, gr, m, v, p, runs + [(gw[0], gw[0] + gw[1]), (rw[0], rw[0] + rw[1])], step, lr=1e-2, betas=(0.9, 0.99),
+                                     eps=1e-15, weight_decay=0.0, ema_decay=0.95, grad_scale=1.0, zero_grad=True)
+                clear.zero_()
+        torch.cuda.synchronize()
+        state[tail] = (p, m, v, gr, clear)
+    for a, b in zip(state[True], state[False]):
+        assert torch.equal(a, b)
+    assert float(state[True][0][gw[0]:rw[0] + rw[1]].sub(fld.params[gw[0]:rw[0] + rw[1]]).abs().max()) > 1e-3   # the weights did move
+    gr = state[True][3]   # cleared where the optimiser went (runs and weight segments), untouched between the runs
+    assert float(gr[:4096].abs().max()) == 0.0 and float(gr[gw[0]:rw[0] + rw[1]].abs().max()) == 0.0 and float(gr[4096:8192].abs().max()) > 0
+
+    res = {}
+    for tail in ('1', '0'):
+        os.environ['ARCN_STEP_TAIL'] = tail
+        try:
+            f2 = NgpField(cfg, device=dev, seed=3)
+            f2.view('table').mul_(1000.0)
+            pipe = NgpPipeline(f2, max_rays=4096, max_samples=1 << 19)
+        finally:
+            os.environ.pop('ARCN_STEP_TAIL')
+        assert (pipe._tail is not None) == (tail == '1')
+        pipe.set_bitfield(torch.from_numpy(synthetic_bitfield(cfg.n_grid, 0.05, seed=5)))
+        gg = torch.Generator().manual_seed(11)
+        p0 = f2.params.clone()
+        for i in range(3):
+            o, d = synthetic_rays(4096, seed=40 + i, device=dev)
+            pipe.train_step(o, d, torch.rand(4096, 3, generator=gg).to(dev), bkg_color=torch.rand(4096, 3, generator=gg).to(dev))
+            if i == 0:
+                first = f2.params[gw[0]:rw[0] + rw[1]].clone()
+        torch.cuda.synchronize()
+        assert pipe.step_count == 3 and float(f2.grads.abs().max()) == 0.0
+        if tail == '1':
+            assert pipe._ws_clear and int(pipe.hash_ws.view(torch.int32)[:pipe._tail['clear_words']].abs().max()) == 0
+        res[tail] = (first, f2.params.clone())
+    w0 = fld.params[gw[0]:rw[0] + rw[1]]
+    moved = float((res['0'][0] - w0).abs().max())
+    assert moved > 1e-3 and float((res['1'][0] - res['0'][0]).abs().max()) <= 1e-3 * moved      # dW partials are deterministic: rounding only
+    far = ((res['1'][1] - res['0'][1]).abs() > 0.05 * float((res['0'][1] - p0).abs().max())).float().mean()
+    assert float(far) < 5e-3
