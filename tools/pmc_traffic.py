@@ -11,7 +11,7 @@ from collections import defaultdict
 ENTRY = {  # C entry point -> device kernels it launches (substring match on the demangled name)
     'hashgrid_bwd': ['scatter_bin_kernel', 'scatter_accum_kernel'],
     'hashgrid_fwd': ['hashgrid_fwd_bal_kernel', 'hashgrid_fwd_xcd_kernel'],
-    'adam_ema_step': ['adam_ema_kernel', 'adam_ema_runs_kernel'],
+    'adam_ema_step': ['adam_ema_kernel', 'adam_ema_runs_kernel', 'ngp_step_tail_kernel'],
     'mlp_bwd': ['mlp_bwd_fused_kernel'],
     'mlp_fwd': ['mlp_fwd_fixed_kernel'],
 }
