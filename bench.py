@@ -41,8 +41,8 @@ def parse():
     ap.add_argument('--no-psnr', action='store_true', help='skip the short PSNR@iter run on the analytic scene appended to the default line')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the short runs of BASELINE configs 1 / 3 / 4 / 5 appended to the default line')
     ap.add_argument('--cpu-rays', type=int, default=131072)
-    ap.add_argument('--config', default='ngp', choices=['ngp', 'nerf', 'neus', 'neus_ngp_multivol', 'hdrnerf'],
-                    help='BASELINE.json configs: ngp = config 2 (default, the headline), nerf = 1, neus = 3, neus_ngp_multivol = 4, hdrnerf = 5')
+    ap.add_argument('--config', default='ngp', choices=['ngp', 'ngp_module', 'nerf', 'neus', 'neus_ngp_multivol', 'hdrnerf'],
+                    help='BASELINE.json configs: ngp = config 2 (default, the headline; ngp_module = the same model through the drop-in module path build_model(nerf_ngp.yaml)), nerf = 1, neus = 3, neus_ngp_multivol = 4, hdrnerf = 5')
     ap.add_argument('--rays', type=int, default=0, help='rays per step per GPU for the module-path configs (0 = the config default)')
     ap.add_argument('--chunk-pts', type=int, default=0, help='points per net evaluation chunk of the module-path configs (0 = the yaml value, the reference\'s 4096*32: a memory knob sized for an 11 GB card; the chunks are independent, so it changes launch sizes only)')
     return ap.parse_args()
@@ -196,6 +196,11 @@ MODULE_CONFIGS = {
                     desc='HDR-NeRF: nerf nets + three 1->128->1 tone mappers, per-ray exposure, LDR + HDR compositing, Adam'),
     'neus': dict(yaml='neus.yaml', rays=2048, evals=64 + 64, flop=2 * (39 * 256 + 3 * 256 * 256 + 256 * 217 + 3 * 256 * 256 + 256 * 257 + (3 + 27 + 3 + 256) * 256 + 3 * 256 * 256 + 256 * 3),
                  desc='NeuS sdf net 8x256 softplus-100 + radiance 4x256, 64+64 samples/ray, 4 up-sampling rounds, normals + Eikonal (double backward), Adam'),
+    # config 2 as a user of the reference's API gets it: configs/nerf_ngp.yaml (= the reference's configs/models/nerf_ngp.yaml) through
+    # build_model -> FullModel.forward -> loss.backward() -> optimizer.step(): marching inline (the module API does not see the next
+    # batch), scatter and optimiser as two passes, the occupancy refresh of VolumeBound.optimize at its cadence
+    'ngp_module': dict(yaml='nerf_ngp.yaml', rays=8320, evals=None, flop=None,
+                       desc='instant-ngp of config 2 through the drop-in module path (hash grid + fused MLPs + volume prune 128^3, packed samples inside NeRF._forward_packed), Adam'),
     'neus_ngp_multivol': dict(yaml='neus_ngp_multivol.yaml', rays=4096, evals=None, flop=None,
                               desc='NeuS on the hash grid in the pruned volume + MultiVol background (hash grid + fused MLPs), Adam'),
 }
@@ -238,7 +243,9 @@ def bench_module(args, name, emit=True):
         if bkg_occ < 1.0:
             bits = synthetic_cascade_bits(m.bkg_model.n_grid, m.bkg_model.n_levels, bkg_occ, seed=5)
             m.bkg_model.density_bitfield.copy_(torch.from_numpy(bits).to(dev))
-    radius = 2.2 if name == 'neus_ngp_multivol' else (3.0 if name == 'neus' else 4.0)
+    if name == 'ngp_module':
+        fg.obj_bound.volume.update_bitfield(torch.from_numpy(synthetic_bitfield(128, args.occupancy, seed=0)).to(dev), ops='overwrite')
+    radius = 2.2 if name == 'neus_ngp_multivol' else (3.0 if name == 'neus' else (3.0 / 1.05 if name == 'ngp_module' else 4.0))
     pool = []
     g = torch.Generator(device='cpu').manual_seed(77 + rank)
     for i in range(4):
@@ -260,6 +267,8 @@ def bench_module(args, name, emit=True):
         D.broadcast_params(opt.flat_params(), src=0)   # what DDP does at construction
 
     def loss_of(out, inp):
+        if name == 'ngp_module':      # ImgLoss(Huber, delta 0.1) of the reference's NGP recipe (arcnerf/loss/img_loss.py:60-100)
+            return torch.nn.functional.huber_loss(out['rgb_coarse'], inp['img'], delta=0.1)
         if name in ('nerf', 'hdrnerf'):
             l = ((out['rgb_fine'] - inp['img']) ** 2).mean() + ((out['rgb_coarse'] - inp['img']) ** 2).mean()
             if name == 'hdrnerf':
@@ -366,6 +375,13 @@ def bench_module(args, name, emit=True):
                     'fg_points_per_step': evals_per_step, 'bkg_samples_per_step': s_bkg,
                     'note': 'a module-path step: 2.7 ms of kernels in 3.6 ms, of which the hash passes are ~1.2 ms (profiles/r3d_*); the step is '
                             'launch / host bound, not bandwidth bound - the fraction says how far, it is not a kernel figure'}
+    if name == 'ngp_module':
+        alg = (BYTES_HASH_FWD + BYTES_HASH_BWD) * evals_per_step
+        ach = alg / (wall / args.steps)
+        roofline = {'kernel': 'hash-grid gather + binned scatter, over the WHOLE step of the module path', 'bound': 'hbm', 'achieved': ach / 1e9,
+                    'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': None,
+                    'note': 'the same kernels as the headline step behind the reference-shaped API: marching inline on the step\'s stream, '
+                            'scatter and optimiser as two passes (FusedAdam over the flat buffer, no EMA pass), VolumeBound.optimize at its cadence'}
     cpu = None
     if world == 1 and not args.no_cpu_baseline and name == 'nerf' and emit:
         cpu = cpu_baseline_nerf()
@@ -658,7 +674,7 @@ def main():
         import copy
         others = {}
         timers.reset(())           # no event brackets around the module-path configs' launches
-        for name in ('nerf', 'neus', 'neus_ngp_multivol', 'hdrnerf'):
+        for name in ('ngp_module', 'nerf', 'neus', 'neus_ngp_multivol', 'hdrnerf'):
             a2 = copy.copy(args)
             a2.steps, a2.warmup, a2.rays, a2.chunk_pts, a2.no_cpu_baseline = 8, 3, 0, 0, True
             try:
