@@ -29,13 +29,22 @@ class _PackedRenderFn(torch.autograd.Function):
     def forward(ctx, rays_o, rays_d, bkg, table, geo_w, rad_w, pipe, train, noise_std):
         pipe.bind_params({'table': table.detach().view(-1), 'geo_w': geo_w.detach(), 'rad_w': rad_w.detach()})
         noise = pipe.buf['noise'].normal_(0.0, noise_std) if (train and noise_std > 0) else None
-        rgb, depth, mask = pipe.forward(rays_o, rays_d, bkg, train=train, noise=noise, presampled=True)
+        # the compositor writes the per-ray outputs and nothing reads them back: hand it a fresh allocation (no launch) for this call
+        # instead of cloning the pipeline's own buffers afterwards (three copy kernels per call)
+        R, b = rays_o.shape[0], pipe.buf
+        o = torch.empty(5 * R, dtype=torch.float32, device=rays_o.device)
+        own = (b['rgb'], b['depth'], b['mask'])
+        b['rgb'], b['depth'], b['mask'] = o[:3 * R].view(R, 3), o[3 * R:4 * R], o[4 * R:]
+        try:
+            rgb, depth, mask = pipe.forward(rays_o, rays_d, bkg, train=train, noise=noise, presampled=True)
+        finally:
+            b['rgb'], b['depth'], b['mask'] = own
         ctx.pipe, ctx.gen = pipe, pipe.generation
         ctx.save_for_backward(rays_o, rays_d, table, geo_w, rad_w)
-        R = rays_o.shape[0]
-        counts = pipe.buf['counts'][:R].clone()
+        ctx.set_materialize_grads(False)   # an output the loss does not read arrives as None, not as a zero-filled tensor
+        counts = b['counts'][:R].clone()
         ctx.mark_non_differentiable(counts)
-        return rgb.clone(), depth.clone(), mask.clone(), counts
+        return rgb, depth, mask, counts
 
     @staticmethod
     @once_differentiable
@@ -45,11 +54,22 @@ class _PackedRenderFn(torch.autograd.Function):
             raise RuntimeError('the packed NGP path keeps ONE forward per backward: raise model.chunk_rays above the number '
                                'of rays of a training step (the reference default 32768 does) or call backward per chunk')
         rays_o, rays_d, table, geo_w, rad_w = ctx.saved_tensors
-        g = {'table': torch.zeros_like(table).view(-1), 'geo_w': torch.zeros_like(geo_w), 'rad_w': torch.zeros_like(rad_w)}
+        # The kernels ACCUMULATE into the gradient buffers they are given.  A parameter whose .grad is a view of FusedAdam's flat gradient
+        # buffer (optim.FusedAdam.flatten marks it) gets its gradient added there directly: no zero-filled temporary, no AccumulateGrad
+        # pass (48.8 MB written, read and added again for the table) - the node then returns None for that input.
+        direct = {k: (getattr(t, '_arcn_direct_grad', False) and t.grad is not None and t.grad.is_contiguous())
+                  for k, t in (('table', table), ('geo_w', geo_w), ('rad_w', rad_w))}
+        g = {'table': (table.grad if direct['table'] else torch.zeros_like(table)).view(-1),
+             'geo_w': geo_w.grad if direct['geo_w'] else torch.zeros_like(geo_w),
+             'rad_w': rad_w.grad if direct['rad_w'] else torch.zeros_like(rad_w)}
         pipe.bind_grads(g)
-        pipe.backward(rays_o, rays_d, d_rgb.contiguous(), d_depth.contiguous(), d_mask.contiguous())
+        if d_rgb is None:
+            d_rgb = torch.zeros((rays_o.shape[0], 3), dtype=torch.float32, device=rays_o.device)
+        pipe.backward(rays_o, rays_d, d_rgb.contiguous(), None if d_depth is None else d_depth.contiguous(),
+                      None if d_mask is None else d_mask.contiguous())
         pipe.bind_grads(None)
-        return None, None, None, g['table'].view_as(table), g['geo_w'], g['rad_w'], None, None, None
+        return (None, None, None, None if direct['table'] else g['table'].view_as(table), None if direct['geo_w'] else g['geo_w'],
+                None if direct['rad_w'] else g['rad_w'], None, None, None)
 
 
 @MODEL_REGISTRY.register()

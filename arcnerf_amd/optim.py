@@ -30,14 +30,16 @@ class FusedAdam(torch.optim.Optimizer):
         self._flat = None         # per param group: dict(params, grads, exp_avg, exp_avg_sq, ema, slots) once flatten() ran
 
     # ---- one flat buffer per parameter group --------------------------------------------------------------------------------------
-    def flatten(self):
+    def flatten(self, direct_grads=True):
         """Re-home the parameters of every group into ONE contiguous fp32 buffer per group, their gradients into one flat gradient
         buffer (`p.grad` becomes a view; autograd accumulates into it in place) and the Adam state into flat buffers too: `step()` is
         then one kernel launch per group, `flat_grads()` is what a data-parallel step all-reduces with ONE collective and no
         gather / scatter copies (the reference wraps the model in DistributedDataParallel, common/trainer/basic_trainer.py:197-198,
         whose buckets are the same idea), and `zero_grad()` is one memset.  Segments are padded to 16 bytes; the pad elements have zero
         parameter, gradient and state, which Adam leaves at zero.  state_dict() keeps torch.optim.Adam's per-parameter layout (the
-        entries are views).  Returns self."""
+        entries are views).  direct_grads: mark the parameters so that hand-written backward nodes whose kernels accumulate (the packed NGP
+        render) add their gradient straight into the flat buffer instead of handing autograd a zero-filled temporary for AccumulateGrad
+        to add (tensor hooks on such a parameter do not see that contribution; pass False when hooks must).  Returns self."""
         self._flat = []
         for group in self.param_groups:
             ps = [p for p in group['params'] if p.requires_grad]
@@ -67,6 +69,7 @@ class FusedAdam(torch.optim.Optimizer):
                         fb['ema'][o:o + n].copy_(src.reshape(-1))
                     p.data = fb['params'][o:o + n].view(p.shape)
                     p.grad = fb['grads'][o:o + n].view(p.shape)
+                    p._arcn_direct_grad = bool(direct_grads)
                     st['step'] = fb['step']
                     st['exp_avg'] = fb['exp_avg'][o:o + n].view(p.shape)
                     st['exp_avg_sq'] = fb['exp_avg_sq'][o:o + n].view(p.shape)

@@ -58,6 +58,8 @@ def _slice(a, lo, hi, to_gpu):
 
 def _cat(parts):
     first = parts[0]
+    if len(parts) == 1 and isinstance(first, (torch.Tensor, np.ndarray)):
+        return first     # one chunk: its outputs are the result (the reference's torch.cat of one tensor is a copy of it)
     if isinstance(first, torch.Tensor):
         return torch.cat(parts, dim=0)
     if isinstance(first, np.ndarray):

@@ -277,18 +277,11 @@ def bench_module(args, name, emit=True):
         return ((out['rgb'] - inp['img']) ** 2).mean() + 0.1 * ((out['normal_pts'].norm(dim=-1) - 1.0) ** 2).mean()
 
     n_eval = [0]
-    valid_acc, valid_calls = torch.zeros(1, device=dev), [0]
-    if spec['evals'] is None:
-        # pruned volume: count the valid foreground samples where the model itself measures them (FgModel.adjust_dynamicbs_factor is
-        # called with the sample mask of every net evaluation pass, fg_model.py:100-115); accumulated on the device, read once
-        orig_adjust = fg.adjust_dynamicbs_factor
-
-        def counting_adjust(mask_pts=None, n_valid=None):
-            if mask_pts is not None or n_valid is not None:
-                valid_acc.add_((mask_pts.sum() if n_valid is None else n_valid).float())
-                valid_calls[0] += 1
-            return orig_adjust(mask_pts, n_valid)
-        fg.adjust_dynamicbs_factor = counting_adjust
+    # pruned volume (evals None): the valid foreground samples are counted where the model itself measures them - FgModel.adjust_dynamicbs_factor
+    # (fg_model.py:100-115) keeps every step's count in a device ring until the dynamic batch size is read; the bench reads that ring
+    # once after the timed region (no extra launch inside it)
+    if spec['evals'] is None and fg.render_cfgs['max_allowance'] <= 0:
+        fg.render_cfgs['max_allowance'] = 1 << 18   # a yaml without dynamic batch size: switch the MEASUREMENT on (nothing resizes the batches here)
     bkg_samples = [0, 0]
     if name == 'neus_ngp_multivol':
         # the background's packed samples: the one host read its path makes anyway (ops.functional.pack_dense_samples) is tallied
@@ -316,8 +309,8 @@ def bench_module(args, name, emit=True):
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    valid_acc.zero_()
-    valid_calls[0] = 0
+    if spec['evals'] is None:
+        fg.reset_measurement()
     bkg_samples[0] = bkg_samples[1] = 0
     if dist is not None:
         dist.barrier()
@@ -331,7 +324,8 @@ def bench_module(args, name, emit=True):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if spec['evals'] is None:
-        n_eval[0] = int(float(valid_acc.item()) / max(1, args.steps)) if valid_calls[0] else n_rays
+        k = int(getattr(fg, '_dynbs_pending', 0))
+        n_eval[0] = int(sum(fg._dynbs_ring[:k].tolist()) / max(1, args.steps)) if k else n_rays
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
