@@ -147,7 +147,13 @@ class NeRF(FgModel):
         if isinstance(self.obj_bound, BitfieldBound):
             self._pipe.set_occupancy_bits(self.obj_bound.density_bitfield, 2)  # Morton bits, marched in place
         else:
-            self._pipe.set_bitfield(self.obj_bound.volume.get_voxel_bitfield(flatten=True))
+            # the bool grid is packed to bits for the marcher (seven torch launches over 2 M voxels): only when it has changed - every
+            # writer of Volume.bitfield works in place, which moves the tensor's version counter
+            bf = self.obj_bound.volume.get_voxel_bitfield(flatten=True)
+            key = (id(self._pipe), bf.data_ptr(), bf._version)
+            if getattr(self, '_bits_key', None) != key:
+                self._pipe.set_bitfield(bf)
+                self._bits_key = key
         return self._pipe
 
     def _sample_packed(self, rays_o, rays_d, exact):
@@ -233,7 +239,11 @@ class NeRF(FgModel):
         if not inference_only:
             self.adjust_dynamicbs_factor(n_valid=pipe.n_dev[0])
         # defaults of FgModel.update_values_for_invalid_rays for rays without samples
-        depth = torch.where(hit, depth, torch.full_like(depth, float(self.render_cfgs['depth_far'])))
+        far = getattr(self, '_depth_far_dev', None)    # (a one-element tensor kept on the device: no fill launch per call)
+        if far is None or far.device != depth.device or float(self.render_cfgs['depth_far']) != self._depth_far_val:
+            self._depth_far_val = float(self.render_cfgs['depth_far'])
+            far = self._depth_far_dev = torch.full((1,), self._depth_far_val, dtype=depth.dtype, device=depth.device)
+        depth = torch.where(hit, depth, far)
         if bkg is None:
             dflt = torch.tensor(self.render_cfgs['bkg_color'], dtype=rgb.dtype, device=rgb.device)[None]
             rgb = torch.where(hit[:, None], rgb, dflt.expand_as(rgb))

@@ -225,6 +225,76 @@ def test_ngp_packed_path_equals_dense_reference_shaped_path(gpu):
     np.testing.assert_array_equal(outs[True]['rgb'][miss], inputs['bkg_color'].cpu().numpy()[miss])
 
 
+def test_packed_path_follows_in_place_changes_of_the_occupancy_grid(gpu):
+    """The packed path packs the volume's bool grid to bits only when it has changed (the tensor's version counter): every in-place
+    writer - update_bitfield and / or / overwrite, reset_voxel_bitfield, load_state_dict - must be seen by the next forward, and with
+    FusedAdam.flatten() the gradients land in the flat buffer directly (no AccumulateGrad pass), equal to the unflattened model's."""
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    from arcnerf_amd.optim import FusedAdam
+    m = _ngp_model(gpu, ['--model.rays.noise_std', '0.0'])
+    fg, vol = m.fg_model, m.fg_model.obj_bound.volume
+    inputs = _rays(gpu)
+    g = torch.Generator().manual_seed(3)
+    grids = [torch.rand(vol.bitfield.shape, generator=g).to(gpu) < p_ for p_ in (0.3, 0.05)]
+
+    def rewind():      # the same jitter stream for every pass (the pipeline keeps the generator object it was built with)
+        r = sampler_rng(reset=True)
+        if fg._pipe is not None:
+            fg._pipe.rng = r
+
+    def render():
+        rewind()
+        return m({k: v.clone() for k, v in inputs.items()}, inference_only=True)['rgb'].clone()
+
+    def expect(grid):      # a fresh packing of the same grid
+        rewind()
+        fg._bits_key = None
+        fg._pipe.set_bitfield(grid.reshape(-1))
+        fg._bits_key = (id(fg._pipe), vol.bitfield.data_ptr(), vol.bitfield._version)
+        return m({k: v.clone() for k, v in inputs.items()}, inference_only=True)['rgb'].clone()
+
+    vol.update_bitfield(grids[0], ops='overwrite')
+    a = render()
+    key = fg._bits_key
+    assert torch.equal(render(), a) and fg._bits_key == key           # unchanged grid: not packed again
+    vol.update_bitfield(grids[1], ops='and')
+    b = render()
+    assert fg._bits_key != key and not torch.equal(a, b) and torch.equal(b, expect(grids[0] & grids[1]))
+    vol.update_bitfield(grids[1], ops='or')
+    assert torch.equal(render(), expect(grids[1]))
+    vol.reset_voxel_bitfield(True)
+    c = render()
+    assert torch.equal(c, expect(torch.ones_like(grids[0]))) and not torch.equal(c, b)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    vol.update_bitfield(grids[0], ops='overwrite')
+    d = render()
+    m.load_state_dict(sd)
+    assert torch.equal(render(), c) and not torch.equal(d, c)
+
+    # gradients straight into FusedAdam's flat buffer == the unflattened model's .grad
+    vol.update_bitfield(grids[0], ops='overwrite')
+    grads = {}
+    for flat in (False, True):
+        if flat:
+            opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=1e-3).flatten()
+            assert all(getattr(p, '_arcn_direct_grad', False) for p in m.parameters() if p.requires_grad)
+        m.zero_grad() if not flat else opt.zero_grad()
+        rewind()
+        out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False)
+        ((out['rgb_coarse'] - inputs['img']) ** 2).mean().backward()
+        grads[flat] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+        if flat:     # twice: the second backward ADDS to the flat buffer like AccumulateGrad would
+            rewind()
+            out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False)
+            ((out['rgb_coarse'] - inputs['img']) ** 2).mean().backward()
+            twice = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    assert set(grads[True]) == set(grads[False]) and len(grads[True]) == 3
+    for n in grads[True]:
+        ref = grads[False][n]
+        assert float((grads[True][n] - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-12, n
+        assert float((twice[n] - 2 * ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-12, n
+
+
 def test_packed_path_grows_instead_of_dropping_samples(gpu):
     """An all-occupied grid and a large chunk ask for more samples than the packed buffers hold (1.6 M > 2^20): the path must notice,
     grow and repeat the launch - the reference's dense tensors never drop a sample.  Same outputs as the dense path on every ray."""
