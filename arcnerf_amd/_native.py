@@ -87,8 +87,13 @@ def ptr(t):
 
 
 def stream():
+    """Raw handle of torch's current stream on the current device.  Through the C binding the compiled-kernel launchers of torch use
+    (0.3 us); `torch.cuda.current_stream().cuda_stream` builds a Python Stream object first (7 us per call - every launch asks)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+    except AttributeError:
+        return torch.cuda.current_stream().cuda_stream
 
 
 def make_hashgrid_desc(resolutions, offsets, n_feat, min_xyz, max_xyz):
