@@ -9,6 +9,18 @@ from torch.autograd.function import once_differentiable
 from . import functional as F
 
 
+def direct_grad(p):
+    """The gradient buffer a hand-written backward may ADD a parameter's gradient into directly, or None: the .grad of a parameter that
+    lives in FusedAdam's flat buffers (optim.FusedAdam.flatten marks it `_arcn_direct_grad`).  A node that used it returns None for that
+    input: no zero-filled temporary, no AccumulateGrad pass over it (48.8 MB written, read and added again per table scatter)."""
+    if not getattr(p, '_arcn_direct_grad', False):     # (asked first: reading .grad of a non-leaf tensor warns)
+        return None
+    g = p.grad
+    if g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.shape == p.shape:
+        return g
+    return None
+
+
 class HashGridFn(torch.autograd.Function):
     """out (n, L*F) = hash-grid encode(xyz; table): the node that carries the TABLE gradient (binned scatter).
 
@@ -33,7 +45,10 @@ class HashGridFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:   # direct use with a differentiable xyz (first order only): both in one kernel
                 dtable, dxyz = F.hashgrid_bwd(xyz, table, dout.contiguous(), ctx.desc, want_dtable=True, want_dxyz=True)
             else:
-                dtable, _ = F.hashgrid_bwd(xyz, table, dout.contiguous(), ctx.desc, workspace=ctx.ws)
+                into = direct_grad(table)
+                dtable, _ = F.hashgrid_bwd(xyz, table, dout.contiguous(), ctx.desc, workspace=ctx.ws, dtable=into)
+                if into is not None:
+                    return dxyz, None, None, None
             dtable = dtable.view_as(table)
         elif ctx.needs_input_grad[0]:
             _, dxyz = F.hashgrid_bwd(xyz, table, dout.contiguous(), ctx.desc, want_dtable=False, want_dxyz=True)
@@ -56,9 +71,10 @@ class HashGridDxFn(torch.autograd.Function):
     def backward(ctx, gdx):
         xyz, table, dout = ctx.saved_tensors
         need_x, need_t, need_d = ctx.needs_input_grad[:3]
+        into = direct_grad(table) if need_t else None
         ddout, dtable, d2x = F.hashgrid_bwd_bwd(xyz, gdx.contiguous(), table, dout, ctx.desc, want_ddout=need_d, want_dtable=need_t,
-                                                want_d2xyz=need_x)
-        return d2x, (dtable.view_as(table) if dtable is not None else None), ddout, None
+                                                want_d2xyz=need_x, dtable=into)
+        return d2x, (dtable.view_as(table) if (dtable is not None and into is None) else None), ddout, None
 
 
 class HashGridXyzFn(torch.autograd.Function):
@@ -139,8 +155,9 @@ class FusedMlpFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, weights, biases, out, acts = ctx.saved_tensors
         b = biases if ctx.has_bias else None
-        dx, dw, db = F.mlp_bwd(x, weights, b, ctx.desc, out, acts, dout.contiguous(), want_dx=ctx.needs_input_grad[0])
-        return dx, dw, (db if ctx.has_bias else None), None
+        gw, gb = direct_grad(weights), (direct_grad(b) if b is not None else None)   # (the kernels add into the buffers they are given)
+        dx, dw, db = F.mlp_bwd(x, weights, b, ctx.desc, out, acts, dout.contiguous(), want_dx=ctx.needs_input_grad[0], dweights=gw, dbiases=gb)
+        return dx, (None if gw is not None else dw), ((None if gb is not None else db) if ctx.has_bias else None), None
 
 
 class RayMarchingFn(torch.autograd.Function):

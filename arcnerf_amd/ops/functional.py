@@ -432,14 +432,17 @@ def hashgrid_bwd(xyz, table, dout, desc, want_dtable=True, want_dxyz=False, n_de
     return dtable, dxyz
 
 
-def hashgrid_bwd_bwd(xyz, gdx, table, dout, desc, want_ddout=True, want_dtable=True, want_d2xyz=False, workspace=True):
+def hashgrid_bwd_bwd(xyz, gdx, table, dout, desc, want_ddout=True, want_dtable=True, want_d2xyz=False, workspace=True, dtable=None):
     """second-order pieces of the encoding's input gradient (see arcn_hashgrid_bwd_bwd) -> ddout, dtable, d2xyz (None if unwanted).
     workspace True: binned table scatter (allocates its scratch); None: one float atomic per corner."""
     _req(xyz, gdx, table, dout)
     xyz, gdx, table, dout = _f32(xyz), _f32(gdx), _f32(table), _f32(dout)
     n = xyz.shape[0]
     ddout = torch.empty_like(dout) if want_ddout else None
-    dtable = torch.zeros_like(table) if want_dtable else None
+    if not want_dtable:
+        dtable = None
+    elif dtable is None:      # (a given buffer is accumulated into)
+        dtable = torch.zeros_like(table)
     d2xyz = torch.zeros((n, 3), dtype=torch.float32, device=xyz.device) if want_d2xyz else None
     ws = None
     if want_dtable and workspace is not None and table.shape[-1] <= 2 and n > 0:

@@ -30,7 +30,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._flat = None         # per param group: dict(params, grads, exp_avg, exp_avg_sq, ema, slots) once flatten() ran
 
     # ---- one flat buffer per parameter group --------------------------------------------------------------------------------------
-    def flatten(self, direct_grads=True):
+    def flatten(self, direct_grads=None):
         """Re-home the parameters of every group into ONE contiguous fp32 buffer per group, their gradients into one flat gradient
         buffer (`p.grad` becomes a view; autograd accumulates into it in place) and the Adam state into flat buffers too: `step()` is
         then one kernel launch per group, `flat_grads()` is what a data-parallel step all-reduces with ONE collective and no
@@ -40,6 +40,9 @@ class FusedAdam(torch.optim.Optimizer):
         entries are views).  direct_grads: mark the parameters so that hand-written backward nodes whose kernels accumulate (the packed NGP
         render) add their gradient straight into the flat buffer instead of handing autograd a zero-filled temporary for AccumulateGrad
         to add (tensor hooks on such a parameter do not see that contribution; pass False when hooks must).  Returns self."""
+        if direct_grads is None:
+            import os
+            direct_grads = os.environ.get('ARCN_DIRECT_GRADS', '1') != '0'
         self._flat = []
         for group in self.param_groups:
             ps = [p for p in group['params'] if p.requires_grad]

@@ -787,6 +787,62 @@ def test_neus_ngp_with_multivol_background_trains(gpu):
     multivol_rng(reset=True)
 
 
+def test_direct_gradient_accumulation_equals_autograd_accumulation(gpu):
+    """FusedAdam.flatten() marks its parameters so that the hash-grid nodes (first and second order), the fused-MLP node and the packed
+    renders ADD their gradients into the flat buffer themselves and return None to autograd.  On the reduced config-4 model (NeuS on the
+    hash grid + MultiVol background: every one of those nodes runs) the flat buffer after backward() equals the .grad of the same model
+    without an optimiser and of flatten(direct_grads=False); a second backward adds a second copy."""
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.optim import FusedAdam
+    from arcnerf_amd.ops.multivol_func import multivol_rng
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    from arcnerf_amd.pipeline import synthetic_bitfield, synthetic_rays
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    small = ['n_levels', '8', 'hashmap_size', '13', 'max_res', '128']
+    ov = ['--model.obj_bound.volume.n_grid', '32', '--model.rays.n_sample', '96', '--model.rays.n_importance', '0',
+          '--model.background.rays.n_sample', '96', '--model.background.basic_volume.n_grid', '16',
+          '--model.background.basic_volume.n_cascade', '3', '--model.background.geometry.encoder.side', '6.0',
+          '--model.background.rays.cone_angle', '0.03125']
+    for pre in ('--model.geometry.encoder.', '--model.background.geometry.encoder.'):
+        for k, v in zip(small[::2], small[1::2]):
+            ov += [pre + k, v]
+    o, d = synthetic_rays(512, seed=3, device=gpu, radius=2.2)
+    inputs = {'rays_o': o.view(1, -1, 3), 'rays_d': d.view(1, -1, 3), 'rays_r': torch.zeros(1, 512, 1, device=gpu),
+              'bkg_color': torch.zeros(1, 512, 3, device=gpu)}
+    tgt = (inputs['rays_d'] * 0.5 + 0.5).clamp(0, 1)
+    grads = {}
+    for mode in ('plain', 'flat', 'direct'):
+        torch.manual_seed(11)
+        m = build_model(load_configs(os.path.join(CFG, 'neus_ngp_multivol.yaml'), ov)).to(gpu)
+        m.fg_model.obj_bound.volume.update_bitfield(torch.from_numpy(synthetic_bitfield(32, 0.3, seed=0)).to(gpu), ops='overwrite')
+        with torch.no_grad():
+            for e in (m.fg_model.geo_net.embed_fn.embeddings, m.bkg_model.geo_net.embed_fn.embeddings):
+                e.mul_(300.0)
+        if mode != 'plain':
+            opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=1e-3).flatten(direct_grads=(mode == 'direct'))
+            assert all(getattr(p, '_arcn_direct_grad', None) == (mode == 'direct') for p in m.parameters() if p.requires_grad)
+            opt.zero_grad()
+        for rep in range(2 if mode == 'direct' else 1):
+            sampler_rng(reset=True)
+            multivol_rng(reset=True)
+            out = m({k: v.clone() for k, v in inputs.items()}, inference_only=False, cur_epoch=20000)
+            (((out['rgb'] - tgt) ** 2).mean() + 0.1 * ((out['normal_pts'].norm(dim=-1) - 1.0) ** 2).mean()).backward()
+            if rep == 0:
+                grads[mode] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+        if mode == 'direct':
+            twice = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    sampler_rng(reset=True)
+    multivol_rng(reset=True)
+    assert set(grads['plain']) == set(grads['flat']) == set(grads['direct']) and len(grads['plain']) >= 8
+    for n, ref in grads['plain'].items():
+        scale = float(ref.abs().max())
+        assert scale > 0, n
+        # (the table scatters sum in float: run-to-run order noise ~1e-6 of the largest entry)
+        assert float((grads['flat'][n] - ref).abs().max()) <= 1e-4 * scale, n
+        assert float((grads['direct'][n] - ref).abs().max()) <= 1e-4 * scale, n
+        assert float((twice[n] - 2.0 * ref).abs().max()) <= 2e-4 * scale, n
+
+
 def test_surface_render_matches_reference(gpu):
     """G19: FullModel.surface_render of the reference on the G13 NeuS model (sphere tracing; secant search on the zero level,
     normals included) and on the G9 NeRF model (secant search on a density level).  The hit masks are identical, depth / rgb /
