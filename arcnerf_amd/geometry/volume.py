@@ -115,18 +115,31 @@ class Volume(nn.Module):
     def get_n_voxel(self):
         return self.n_grid ** 3
 
+    def _host_value(self, name, src, make):
+        """A Python-number view of a small device tensor, read back ONCE per version of the tensor: every float() of a device scalar is a
+        host / device synchronisation, and the samplers ask for the diagonal on every call (the reference re-reads it each time,
+        geometry/volume.py:330-360 there).  In-place writers and re-registered buffers move the key."""
+        key = (src.data_ptr(), src._version, str(src.device))
+        cache = self.__dict__.setdefault('_host_cache', {})
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            hit = cache[name] = (key, make())
+        return hit[1]
+
     def get_len(self):
-        return tuple(float(v) for v in self.xyz_len)
+        return self._host_value('len', self.xyz_len, lambda: tuple(float(v) for v in self.xyz_len.detach().tolist()))
 
     def get_origin(self):
         return self.origin
 
     def get_diag_len(self):
-        return float(torch.sqrt(((self.range[:, 1] - self.range[:, 0]) ** 2).sum()))
+        return self._host_value('diag', self.range, lambda: float(torch.sqrt(((self.range[:, 1] - self.range[:, 0]) ** 2).sum())))
 
     def get_voxel_size(self, to_list=True):
-        s = (self.range[:, 1] - self.range[:, 0]) / self.n_grid
-        return tuple(float(v) for v in s) if to_list else s
+        if to_list:
+            return self._host_value('voxel%d' % self.n_grid, self.range,
+                                    lambda: tuple(float(v) for v in ((self.range[:, 1] - self.range[:, 0]) / self.n_grid).tolist()))
+        return (self.range[:, 1] - self.range[:, 0]) / self.n_grid
 
     @staticmethod
     def convert_flatten_index_to_xyz_index(flat, n):

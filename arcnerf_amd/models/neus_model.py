@@ -103,7 +103,9 @@ class Neus(SdfModel):
                                                                  float(self.render_cfgs['depth_far']), dflt_rgb, dflt_nrm)
         out = {'rgb': rgb, 'depth': depth, 'mask': mask, 'normal': nrm}
         if train:
-            out['params'] = {'scale': float(scale.detach())}
+            # (the reference hands out a Python float, neus_model.py:100-104 - a host read per step; the packed path keeps the 0-d device
+            # tensor: float(), format() and logging work on it, and nothing waits for the device here)
+            out['params'] = {'scale': scale.detach().reshape(())}
             # the dense (rays, P, 3) per-slot normals of the reference's output (padded slots repeat the ray's last point, rays without
             # samples hold the default normal): one kernel each way (an index_select would send the gradients of every padded slot
             # through atomics on one row)
