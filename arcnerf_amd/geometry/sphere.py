@@ -26,10 +26,20 @@ class Sphere(nn.Module):
         for k in range(3):
             self.origin[k] = origin[k]
 
+    def _host_value(self, name, src, make):
+        """Python numbers of a small device tensor, read back once per version of it (every read is a host / device synchronisation and
+        the ray-sphere intersection asks on every call); the in-place setters move the key."""
+        key = (src.data_ptr(), src._version, str(src.device))
+        cache = self.__dict__.setdefault('_host_cache', {})
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            hit = cache[name] = (key, make())
+        return hit[1]
+
     def get_origin(self, in_tuple=False):
         """origin as a (3,) tensor, or a tuple of floats"""
         if in_tuple:
-            return tuple(float(v) for v in self.origin.detach().cpu().tolist())
+            return self._host_value('origin', self.origin, lambda: tuple(float(v) for v in self.origin.detach().cpu().tolist()))
         return self.origin
 
     @torch.no_grad()
@@ -39,7 +49,7 @@ class Sphere(nn.Module):
     def get_radius(self, in_float=False):
         """radius as a (1,) tensor, or a float"""
         if in_float:
-            return float(self.radius.detach().cpu()[0])
+            return self._host_value('radius', self.radius, lambda: float(self.radius.detach().cpu()[0]))
         return self.radius
 
     def ray_sphere_intersection(self, rays_o, rays_d):

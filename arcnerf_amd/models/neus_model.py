@@ -144,7 +144,7 @@ class Neus(SdfModel):
         output = self.ray_marching(sdf, radiance, mid_zvals, alpha=alpha, inference_only=inference_only, bkg_color=bkg_color)
         output['normal'] = torch.sum(output['weights'].unsqueeze(-1) * normalize(normal_pts), -2)
         if not inference_only:
-            output['params'] = {'scale': float(self.forward_scale().detach())}
+            output['params'] = {'scale': self.forward_scale().detach().reshape(())}   # (0-d device tensor: no host read per step)
             output['normal_pts'] = normal_pts
         return self.output_get_progress(output, get_progress)
 

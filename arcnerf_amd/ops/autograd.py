@@ -290,7 +290,7 @@ class SdfToAlphaFn(torch.autograd.Function):
     def forward(ctx, mid_sdf, zvals, mid_slope, s, clip):
         ctx.clip = bool(clip)
         ctx.s_is_tensor = torch.is_tensor(s)
-        s_t = s if ctx.s_is_tensor else torch.tensor([float(s)], dtype=torch.float32, device=zvals.device)
+        s_t = s if ctx.s_is_tensor else F.scalar_tensor(s, zvals.device)
         ctx.save_for_backward(mid_sdf, zvals, mid_slope, s_t)
         return F.sdf_to_alpha_fwd(mid_sdf, zvals, mid_slope, s_t, clip=ctx.clip)
 

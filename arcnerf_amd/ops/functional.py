@@ -73,12 +73,27 @@ def aabb_intersection_torch(rays_o, rays_d, aabb_v32, eps=1e-7, want_pts=True):
     return near, far, pts, mask
 
 
+_SCALARS = {}
+
+
+def scalar_tensor(value, device):
+    """(1,) float32 device tensor holding a Python number, made once per (value, device): torch.tensor([v], device=cuda) is a pageable
+    host-to-device copy - the host waits for it - and the samplers / sdf_to_alpha ask with the same few values on every call."""
+    key = (float(value), str(device))
+    t = _SCALARS.get(key)
+    if t is None:
+        if len(_SCALARS) > 256:
+            _SCALARS.clear()
+        t = _SCALARS[key] = torch.tensor([float(value)], dtype=torch.float32, device=device)
+    return t
+
+
 def sphere_intersection(rays_o, rays_d, radius, origin=(0.0, 0.0, 0.0), want_pts=True):
     """sphere_ray_intersection of geometry/ray.py:180-255; radius float or (N_r,) tensor."""
     _req(rays_o, rays_d)
     o, d = _f32(rays_o), _f32(rays_d)
     if not torch.is_tensor(radius):
-        radius = torch.tensor([float(radius)], dtype=torch.float32, device=o.device)
+        radius = scalar_tensor(radius, o.device)
     rad = _f32(radius.to(o.device)).view(-1)
     R, K = o.shape[0], rad.shape[0]
     near = torch.zeros((R, K), dtype=torch.float32, device=o.device)
@@ -979,7 +994,7 @@ def _scale_tensor(s, device):
     if torch.is_tensor(s):
         _req(s)
         return _f32(s).reshape(1)
-    return torch.tensor([float(s)], dtype=torch.float32, device=device)
+    return scalar_tensor(s, device)
 
 
 def sdf_to_alpha_fwd(mid_sdf, zvals, mid_slope, s, clip=True):
