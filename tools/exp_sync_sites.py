@@ -22,6 +22,8 @@ sites = {}
 def show(message, category, filename, lineno, file=None, line=None):
     st = [f for f in traceback.extract_stack() if '/arcnerf_amd/' in f.filename or 'bench' in f.filename]
     key = ' <- '.join('%s:%d' % (os.path.basename(f.filename), f.lineno) for f in reversed(st[-4:]))
+    if not key:
+        key = 'outside the package: ' + ' <- '.join('%s:%d' % (os.path.basename(f.filename), f.lineno) for f in reversed(traceback.extract_stack()[-8:-2]))
     sites[key] = sites.get(key, 0) + 1
 
 
