@@ -61,21 +61,42 @@ class MultiVol(BkgModel, MortonDensityGrid):
     def get_sigma_radiance_by_mask_pts(self, geo_net, radiance_net, rays_o, rays_d, zvals, mask_pts):
         return nets_on_valid_samples(self._forward_pts_dir, self.chunk_pts, geo_net, radiance_net, rays_o, rays_d, zvals, mask_pts)
 
+    @torch.no_grad()
+    def _sample_begin(self, rays_o, rays_d):
+        """bounds + cascade marcher + scan queued, the sample total on its way to the host (no wait here)"""
+        n_pts = self.get_ray_cfgs('n_sample')
+        near, far = self.get_near_far_from_rays(rays_o, rays_d)
+        rng = multivol_rng()
+        zvals, _, counts = Fn.sparse_sampling_in_multivol_bitfield(
+            rays_o, rays_d, near, far, n_pts, self.cone_angle, self.min_step, self.max_step,
+            self.basic_volume.get_range().permute(1, 0).contiguous(), self.max_volume.get_range().permute(1, 0).contiguous(),
+            self.n_grid, self.n_cascade, self.density_bitfield, self.get_optim_cfgs('near_distance'), self.inclusive, rng.state,
+            rng.inc, want_counts=True)
+        rng.advance()
+        return Fn.pack_dense_samples_begin(zvals, counts)
+
+    def presample(self, inputs):
+        """FullModel calls this BEFORE the foreground model runs (same rays): the background's sampler is queued and its sample count
+        travels to the host while the foreground marches and waits for ITS count - one wait for the two host reads of a step instead
+        of two.  The sampler has its own generator (ops.multivol_func.multivol_rng), so the order of the two samplers does not change
+        either stream.  Used by the next forward() on the same ray tensors, dropped otherwise."""
+        rays_o, rays_d = inputs['rays_o'], inputs['rays_d']
+        if not (self.use_packed_path and rays_o.is_cuda and rays_o.is_contiguous() and rays_d.is_contiguous()
+                and rays_o.dtype == torch.float32 and rays_d.dtype == torch.float32):
+            return
+        self._presampled = ((rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], rays_o._version, rays_d._version),
+                            self._sample_begin(rays_o, rays_d))
+
     def _forward_packed(self, rays_o, rays_d, inference_only):
         """Same result as the dense path below when only rgb / depth / mask are wanted, without the padded (rays, slots) tensors:
         the sampler's per-ray counts are scanned into offsets, the valid samples compacted (kernels, one host read for the total),
         the nets see the packed points and the packed compositor does the rest - no boolean-mask gathers or scatters."""
-        n_rays, n_pts = rays_o.shape[0], self.get_ray_cfgs('n_sample')
+        n_rays = rays_o.shape[0]
+        pre, self._presampled = getattr(self, '_presampled', None), None
+        if pre is None or pre[0] != (rays_o.data_ptr(), rays_d.data_ptr(), n_rays, rays_o._version, rays_d._version):
+            pre = (None, self._sample_begin(rays_o, rays_d))
         with torch.no_grad():
-            near, far = self.get_near_far_from_rays(rays_o, rays_d)
-            rng = multivol_rng()
-            zvals, _, counts = Fn.sparse_sampling_in_multivol_bitfield(
-                rays_o, rays_d, near, far, n_pts, self.cone_angle, self.min_step, self.max_step,
-                self.basic_volume.get_range().permute(1, 0).contiguous(), self.max_volume.get_range().permute(1, 0).contiguous(),
-                self.n_grid, self.n_cascade, self.density_bitfield, self.get_optim_cfgs('near_distance'), self.inclusive, rng.state,
-                rng.inc, want_counts=True)
-            rng.advance()
-            t, ray_id, offsets, p_dense, total = Fn.pack_dense_samples(zvals, counts)
+            t, ray_id, offsets, p_dense, total = Fn.pack_dense_samples_end(pre[1])
             if total > 0:
                 xyz, dirs = Fn.packed_points(rays_o, rays_d, t, ray_id)
         if total == 0:   # nothing sampled anywhere: empty rays composite to 0 (+ white background)

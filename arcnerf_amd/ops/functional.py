@@ -361,25 +361,42 @@ def march_packed(rays_o, rays_d, aabb23, n_grid, bitfield, n_pts, dt, near_dista
     return {'t': t, 'ray_id': ray_id, 'offsets': offsets, 'counts': counts, 'near': near, 'far': far}
 
 
-def pack_dense_samples(zvals, counts):
-    """Dense sampler output (R, n_pts) with per-ray counts (valid samples first) -> the packed form the compositor and
-    packed_points consume: t (total,), ray_id (total,) int32, offsets (R+1,) int32, p_dense (1,) int32 = max(counts), total.
-    ONE host read (the total, to size the packed tensors); exclusive scan + compaction are kernels."""
+def pack_dense_samples_begin(zvals, counts):
+    """First half of pack_dense_samples: the scan, and the total on its way to pinned host memory (asynchronous copy + event) - the
+    caller may queue other work before pack_dense_samples_end waits for it."""
     _req(zvals, counts)
     z = _f32(zvals)
     R, n_pts = z.shape
     cnt = counts.contiguous().to(torch.int32)
     offsets = torch.empty(R + 1, dtype=torch.int32, device=z.device)
     p_dense = torch.zeros(1, dtype=torch.int32, device=z.device)
-    L = N.lib()
-    N.check(L.arcn_exclusive_scan_i32(N.ptr(cnt), N.ptr(offsets), R, int(R * n_pts), N.ptr(p_dense), N.stream()), 'exclusive_scan_i32')
-    total = int(offsets[R].item())
+    N.check(N.lib().arcn_exclusive_scan_i32(N.ptr(cnt), N.ptr(offsets), R, int(R * n_pts), N.ptr(p_dense), N.stream()), 'exclusive_scan_i32')
+    host = torch.empty(1, dtype=torch.int32).pin_memory()
+    host.copy_(offsets[R:R + 1], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return {'z': z, 'cnt': cnt, 'offsets': offsets, 'p_dense': p_dense, 'host': host, 'event': ev}
+
+
+def pack_dense_samples_end(h):
+    """Second half: wait for the total (the ONE host read), size the packed tensors, compact."""
+    h['event'].synchronize()
+    total = int(h['host'][0])
+    z, cnt, offsets = h['z'], h['cnt'], h['offsets']
+    R, n_pts = z.shape
     t = torch.empty(max(total, 1), dtype=torch.float32, device=z.device)
     ray_id = torch.empty(max(total, 1), dtype=torch.int32, device=z.device)
     if total > 0:
-        N.check(L.arcn_march_write(N.ptr(z), N.ptr(cnt), N.ptr(offsets), int(n_pts), N.ptr(t), N.ptr(ray_id), R, total, N.stream()),
+        N.check(N.lib().arcn_march_write(N.ptr(z), N.ptr(cnt), N.ptr(offsets), int(n_pts), N.ptr(t), N.ptr(ray_id), R, total, N.stream()),
                 'march_write')
-    return t[:total], ray_id[:total], offsets, p_dense, total
+    return t[:total], ray_id[:total], offsets, h['p_dense'], total
+
+
+def pack_dense_samples(zvals, counts):
+    """Dense sampler output (R, n_pts) with per-ray counts (valid samples first) -> the packed form the compositor and
+    packed_points consume: t (total,), ray_id (total,) int32, offsets (R+1,) int32, p_dense (1,) int32 = max(counts), total.
+    ONE host read (the total, to size the packed tensors); exclusive scan + compaction are kernels."""
+    return pack_dense_samples_end(pack_dense_samples_begin(zvals, counts))
 
 
 def packed_points(rays_o, rays_d, t, ray_id, n=None, n_dev=None, want_dirs=True):

@@ -286,14 +286,14 @@ def bench_module(args, name, emit=True):
     if name == 'neus_ngp_multivol':
         # the background's packed samples: the one host read its path makes anyway (ops.functional.pack_dense_samples) is tallied
         from arcnerf_amd.ops import functional as Fn
-        real_pack = Fn.pack_dense_samples
+        real_pack = Fn.pack_dense_samples_end
 
-        def counting_pack(zvals, counts):
-            r = real_pack(zvals, counts)
+        def counting_pack(handle):
+            r = real_pack(handle)
             bkg_samples[0] += int(r[4])
             bkg_samples[1] += 1
             return r
-        Fn.pack_dense_samples = counting_pack
+        Fn.pack_dense_samples_end = counting_pack
 
     def step(i):
         inp = pool[i % len(pool)]
@@ -357,7 +357,7 @@ def bench_module(args, name, emit=True):
                             'peak_split = the dense bf16 MFMA peak / 6 terms = what the split form could do at full clock (the kernels sit on the '
                             '1400 W package limit at 1.93-1.97 GHz, DESIGN.md 5b)'}
     if name == 'neus_ngp_multivol':
-        Fn.pack_dense_samples = real_pack
+        Fn.pack_dense_samples_end = real_pack
         s_bkg = bkg_samples[0] / max(1, bkg_samples[1])
         # HBM accounting of the hash-grid passes over the WHOLE step (SURVEY.md 8d per-sample figures): the background model encodes and
         # scatters once per sample; the foreground (sdf net with normals through the encoder) gathers twice (values, d enc / d x) and

@@ -38,6 +38,7 @@ GROUPS = {
     'neusngp': [
         {'ARCN_SDF_JACOBIAN': '0', 'ARCN_LINEAR_FUSED': '0', 'ARCN_PACKED_OVERFLOW_CHECK': '0'},
         {'ARCN_DETERMINISTIC': '1'},     # ... including the second-order table scatter
+        {'ARCN_BKG_PRESAMPLE': '0'},     # the background's sampler queued after the foreground instead of before it
     ],
 }
 _default = {}
