@@ -490,3 +490,41 @@ def test_step_tail_launch_equals_the_four_launches_it_replaces():
     assert moved > 1e-3 and float((res['1'][0] - res['0'][0]).abs().max()) <= 1e-3 * moved      # dW partials are deterministic: rounding only
     far = ((res['1'][1] - res['0'][1]).abs() > 0.05 * float((res['0'][1] - p0).abs().max())).float().mean()
     assert float(far) < 5e-3
+
+
+def test_step_tail_argument_errors_and_empty_input():
+    """arcn_ngp_step_tail: n = 0 is a no-op that returns OK; a run that does not start at a multiple of four floats, a missing buffer,
+    more than four runs, a zero step count and a net outside the fused-backward shapes are refused with an error message (nothing is
+    launched), like the entry points it replaces."""
+    import ctypes as C
+    from arcnerf_amd import _native as N
+    from arcnerf_amd.pipeline import NgpConfig, NgpField
+    dev = torch.device('cuda:0')
+    fld = NgpField(NgpConfig(), device=dev, seed=1)
+    L = N.lib()
+    S = 4096
+    gw, rw = fld._seg['geo_w'], fld._seg['rad_w']
+    scr_g = torch.zeros(int(L.arcn_mlp_scratch_floats(C.addressof(fld.geo_desc), S)), device=dev)
+    scr_r = torch.zeros(int(L.arcn_mlp_scratch_floats(C.addressof(fld.rad_desc), S)), device=dev)
+    p, g = fld.params.clone(), torch.zeros_like(fld.params)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+
+    def call(n=S, runs=((0, 4096),), step=1, geo_desc=None, param=p, scratch=scr_g, n_runs=None):
+        flat = (C.c_int64 * 16)(*([x for a, b in runs for x in (a, b - a)] + [0] * (16 - 2 * len(runs))))
+        return L.arcn_ngp_step_tail(C.addressof(geo_desc or fld.geo_desc), N.ptr(scratch), gw[0], C.addressof(fld.rad_desc), N.ptr(scr_r), rw[0], S, n,
+                                    N.ptr(param), N.ptr(g), N.ptr(m), N.ptr(v), N.ptr(param), C.cast(flat, C.c_void_p),
+                                    len(runs) if n_runs is None else n_runs, 1e-2, 0.9, 0.99, 1e-15, 0.0, 0.95, 1.0, step, step, None, 0, N.stream())
+
+    before = p.clone()
+    assert call(n=0) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(p, before)
+    for bad in (dict(runs=((2, 4098),)), dict(param=None), dict(n_runs=5), dict(step=0), dict(scratch=None)):
+        assert call(**bad) != 0 and L.arcn_last_error()
+    biased = N.make_mlp_desc([32, 64, 16], 'relu', None, has_bias=True)
+    assert call(geo_desc=biased) != 0 and b'fused-backward shape' in L.arcn_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(p, before)          # nothing was launched by the refused calls
+    assert call() == 0                     # and a valid call still goes through afterwards
+    torch.cuda.synchronize()
+    assert not torch.equal(p[:4096], before[:4096])
