@@ -453,13 +453,17 @@ __device__ __forceinline__ void zero_padded_rows(f4 (&h)[4][NT], int N, int g) {
     }
 }
 
-template <int T0, int T1, int T2, int T3, int NT, int XMODE>  // XMODE: 0 row-major x, 1 level-major x, 2 concat (MlpCat)
+// AH / AO >= 0: the hidden / output activation as a compile-time constant (the level-major and concat entry points with ReLU hidden
+// layers and a linear or sigmoid output: the NGP nets).  With the runtime switch the compiler clones the tile loop per activation: the
+// radiance forward was 90 KB of code and 160 registers, 11.5 KB and 104 with the constants - room for a third workgroup per CU.
+template <int T0, int T1, int T2, int T3, int NT, int XMODE, int AH = -1, int AO = -1>  // XMODE: 0 row-major x, 1 level-major x, 2 concat (MlpCat)
 __global__ void __launch_bounds__(256)
 mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, const float *__restrict__ weights, MlpParams P,
                      float *__restrict__ out, float *__restrict__ acts, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
     constexpr int NL = T3 ? 3 : 2;
     constexpr int TA = T3 ? T3 : 1;
     constexpr bool FRAG = XMODE != 0;  // saved activations in tile order (store_tiles_frag): the level-major / concat entry points
+    const int act_h = AH >= 0 ? AH : P.act_hidden, act_o = AO >= 0 ? AO : P.act_out;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     for (int l = 0; l < NL; ++l) stage_fragments<false>(lds + P.lds_off[l], weights + P.w_off[l], P.dims[l + 1], P.dims[l]);
     __syncthreads();
@@ -484,7 +488,7 @@ mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
         // layer 0: T0 -> T1 tiles
         zero(o);
         gemm_tiles<4, NT>(o, h, w0, T1, T0, lane);
-        act_tiles<T1, NT>(o, P.act_hidden, P.beta);
+        act_tiles<T1, NT>(o, act_h, P.beta);
         // the two-layer tile-order nets get no activations at all: their backward recomputes layer 0 from x (32 x 64 MACs per sample
         // against 256 B written here and read there: geometry net forward 40 -> 32 us, backward +1 us; for the three-layer net the
         // backward is MFMA-bound and the same trade loses, 58 -> 55 forward but 86 -> 96 us backward)
@@ -497,10 +501,10 @@ mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
         zero(h);
         gemm_tiles<4, NT>(h, o, w1, T2, T1, lane);
         if (NL == 2) {
-            act_tiles<T2, NT>(h, P.act_out, P.beta);
+            act_tiles<T2, NT>(h, act_o, P.beta);
             store_tiles_fast<T2, NT>(h, out, P.dims[2], s0, cnt, g, j);
         } else {
-            act_tiles<T2, NT>(h, P.act_hidden, P.beta);
+            act_tiles<T2, NT>(h, act_h, P.beta);
             if (acts) {
                 if (FRAG) store_tiles_frag<T2, NT>(h, acts + pad16(n_cap) * P.dims[1], s0, cnt, lane);
                 else store_tiles_fast<T2, NT>(h, acts + n_cap * P.dims[1], P.dims[2], s0, cnt, g, j);
@@ -509,7 +513,7 @@ mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
             // layer 2: T2 -> T3 tiles
             zero(o);
             gemm_tiles<4, NT>(o, h, w2, TA, T2, lane);
-            act_tiles<TA, NT>(o, P.act_out, P.beta);
+            act_tiles<TA, NT>(o, act_o, P.beta);
             store_tiles_fast<TA, NT>(o, out, P.dims[3], s0, cnt, g, j);
         }
     }
@@ -590,7 +594,7 @@ mlp_bwd_dx_kernel(const float *__restrict__ weights, MlpParams P, const float *_
 // waves are summed through LDS and the workgroup writes ONE partial per layer for mlp_dw_reduce_kernel.
 // T0..T3 = 16-wide tiles per layer boundary (T3 = 0: two layers); the dims themselves stay run-time (ragged widths are zero
 // padded by load_tiles / stage_fragments, so e.g. the 3-wide RGB output uses the T3 = 1 instance).
-template <int T0, int T1, int T2, int T3, int NT, int XMODE>
+template <int T0, int T1, int T2, int T3, int NT, int XMODE, int AH = -1, int AO = -1>   // AH / AO: see mlp_fwd_fixed_kernel
 __global__ void __launch_bounds__(256, 2)  // 2 workgroups per CU = 2 waves per SIMD: at most 256 VGPR + AGPR per lane
 mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, const float *__restrict__ weights, MlpParams P, const float *__restrict__ out,
                      const float *__restrict__ acts, const float *__restrict__ dout, float *__restrict__ dx,
@@ -606,6 +610,7 @@ mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
     }
     constexpr bool FRAG = XMODE != 0;        // tile-order activations from the matching forward (store_tiles_frag)
     constexpr bool RECOMP = FRAG && NL == 2;  // ... which saved none for a two-layer net: layer 0 is recomputed from x
+    const int act_h = AH >= 0 ? AH : P.act_hidden, act_o = AO >= 0 ? AO : P.act_out;
     // forward fragments of W_0 behind the transposition tiles
     const float *w0_fwd = lds + lds_w + 8192;
     if (RECOMP) stage_fragments<false>(lds + lds_w + 8192, weights + P.w_off[0], P.dims[1], P.dims[0]);
@@ -706,16 +711,16 @@ mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
         f4 d[WT][NT], y[WT][NT], yp[WT][NT];
         constexpr int TL = T3 ? T3 : T2;  // tiles of the network output
         load_tiles_fast<TL, NT>(d, dout, P.dims[NL], s0, cnt, g, j);
-        if (P.act_out != ARCN_ACT_NONE) {
+        if (act_o != ARCN_ACT_NONE) {
             load_tiles_fast<TL, NT>(y, out, P.dims[NL], s0, cnt, g, j);
-            apply_act_grad(d, y, P.act_out, std::integral_constant<int, TL>{});
+            apply_act_grad(d, y, act_o, std::integral_constant<int, TL>{});
         }
         if (NL == 3) {
             if (FRAG) load_tiles_frag<T2, NT>(yp, acts + a2_off, s0, cnt, lane);
             else load_tiles_fast<T2, NT>(yp, acts + a2_off, P.dims[2], s0, cnt, g, j);
             accumulate(acc2, d, yp, std::integral_constant<int, TA>{}, std::integral_constant<int, T2>{});
             back(d, 2, T2, TA);
-            if (P.act_hidden != ARCN_ACT_NONE) apply_act_grad(d, yp, P.act_hidden, std::integral_constant<int, T2>{});
+            if (act_h != ARCN_ACT_NONE) apply_act_grad(d, yp, act_h, std::integral_constant<int, T2>{});
         }
         f4 xt[WT][NT];
         if (RECOMP) {
@@ -727,7 +732,7 @@ mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) yp[mt][nt] = f4{0.f, 0.f, 0.f, 0.f};
             gemm_tiles<WT, NT>(yp, xt, w0_fwd, T1, T0, lane);
-            act_tiles<T1, NT>(yp, P.act_hidden, P.beta);
+            act_tiles<T1, NT>(yp, act_h, P.beta);
         } else if (FRAG) {
             load_tiles_frag<T1, NT>(yp, acts + a1_off, s0, cnt, lane);
         } else {
@@ -735,7 +740,7 @@ mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
         }
         accumulate(acc1, d, yp, std::integral_constant<int, T2>{}, std::integral_constant<int, T1>{});
         back(d, 1, T1, T2);
-        if (P.act_hidden != ARCN_ACT_NONE) apply_act_grad(d, yp, P.act_hidden, std::integral_constant<int, T1>{});
+        if (act_h != ARCN_ACT_NONE) apply_act_grad(d, yp, act_h, std::integral_constant<int, T1>{});
         if (RECOMP) {
 #pragma unroll
             for (int mt = 0; mt < WT; ++mt)
@@ -1071,9 +1076,11 @@ static int set_lds(Kern k, size_t bytes) {
     return ARCN_OK;
 }
 
-inline unsigned tile_grid(int64_t n, int spb, bool /*forward*/ = false) {
-    // resident workgroups re-use the staged weights across tiles: 512 = two per CU (measured best for forward and backward kernels alike)
-    const int64_t b = ceil_div<int64_t>(n, spb), cap = 512;
+// resident workgroups re-use the staged weights across tiles: 512 = two per CU (measured best for the kernels with a runtime activation
+// switch, forward and backward alike); the slim forward kernels (activations compiled in, ~100 registers) take three per CU
+constexpr int kSlimGrid = 768;
+inline unsigned tile_grid(int64_t n, int spb, int64_t cap = 512) {
+    const int64_t b = ceil_div<int64_t>(n, spb);
     return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
@@ -1136,15 +1143,20 @@ static int mlp_fwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
     if ((fixed_ok || x_stride || cat_in) && !P.has_bias && (P.n_layers == 2 || P.n_layers == 3) && md <= 64) {
         const int sig = tiles16(P.dims[0]) * 1000 + tiles16(P.dims[1]) * 100 + tiles16(P.dims[2]) * 10 +
                         (P.n_layers == 3 ? tiles16(P.dims[3]) : 0);
-#define ARCN_FIXED(T0, T1, T2, T3, XMODE)                                                                                        \
+#define ARCN_FIXED_A(T0, T1, T2, T3, XMODE, AH, AO, CAP)                                                                          \
     do {                                                                                                                         \
-        if ((rc = set_lds(mlp_fwd_fixed_kernel<T0, T1, T2, T3, 2, XMODE>, lds_bytes))) return rc;                                 \
-        hipLaunchKernelGGL((mlp_fwd_fixed_kernel<T0, T1, T2, T3, 2, XMODE>), dim3(tile_grid(n, 128, true)), dim3(256), lds_bytes,       \
+        if ((rc = set_lds(mlp_fwd_fixed_kernel<T0, T1, T2, T3, 2, XMODE, AH, AO>, lds_bytes))) return rc;                         \
+        hipLaunchKernelGGL((mlp_fwd_fixed_kernel<T0, T1, T2, T3, 2, XMODE, AH, AO>), dim3(tile_grid(n, 128, CAP)), dim3(256), lds_bytes, \
                            as_stream(stream), x, x_stride, cat, weights, P, out, acts, n_cap, n, n_ptr);                          \
         return check_launch("mlp_fwd_fixed");                                                                                    \
     } while (0)
+#define ARCN_FIXED(T0, T1, T2, T3, XMODE) ARCN_FIXED_A(T0, T1, T2, T3, XMODE, -1, -1, 512)
+        // the NGP nets (ReLU hidden layers; linear geometry output, sigmoid radiance output) with their activations compiled in
+        const bool relu_lin = P.act_hidden == ARCN_ACT_RELU && P.act_out == ARCN_ACT_NONE;
+        const bool relu_sig = P.act_hidden == ARCN_ACT_RELU && P.act_out == ARCN_ACT_SIGMOID;
         if (cat_in) {
             if (P.dims[0] != 32) return einval("mlp_fwd_cat: the input must be 16 + 16 columns");
+            if (sig == 2441 && relu_sig) ARCN_FIXED_A(2, 4, 4, 1, 2, ARCN_ACT_RELU, ARCN_ACT_SIGMOID, kSlimGrid);
             switch (sig) {
             case 2441: ARCN_FIXED(2, 4, 4, 1, 2);
             case 2410: ARCN_FIXED(2, 4, 1, 0, 2);
@@ -1152,6 +1164,7 @@ static int mlp_fwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
             }
         } else if (x_stride) {
             if (P.dims[0] & 15) return einval("mlp_fwd_lm: input width must be a multiple of 16");
+            if (sig == 2410 && relu_lin) ARCN_FIXED_A(2, 4, 1, 0, 1, ARCN_ACT_RELU, ARCN_ACT_NONE, kSlimGrid);
             switch (sig) {
             case 2410: ARCN_FIXED(2, 4, 1, 0, 1);
             case 4410: ARCN_FIXED(4, 4, 1, 0, 1);
@@ -1167,6 +1180,7 @@ static int mlp_fwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
             }
         }
 #undef ARCN_FIXED
+#undef ARCN_FIXED_A
     }
     if (cat_in) return einval("mlp_fwd_cat: only wired for bias-free nets 32 -> 64 [-> 64] -> <=16");
     if (x_stride) return einval("mlp_fwd_lm: level-major input is only wired for bias-free 2-layer nets (32|64 -> 64 -> <=16)");
@@ -1247,18 +1261,25 @@ static int mlp_bwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
             for (int l = 0; l <= P.n_layers; ++l) D.dims[l] = P.dims[l];
             for (int l = 0; l < P.n_layers; ++l) { D.w_off[l] = P.w_off[l]; D.b_off[l] = P.b_off[l]; D.quad_first[l] = l; }
             D.quad_first[P.n_layers] = P.n_layers;
-#define ARCN_FUSED(T0, T1, T2, T3, NT, XMODE)                                                                                   \
+#define ARCN_FUSED_A(T0, T1, T2, T3, NT, XMODE, AH, AO)                                                                         \
     do {                                                                                                                         \
-        if ((rc = set_lds(mlp_bwd_fused_kernel<T0, T1, T2, T3, NT, XMODE>, fused_lds))) return rc;                                \
-        hipLaunchKernelGGL((mlp_bwd_fused_kernel<T0, T1, T2, T3, NT, XMODE>), dim3((unsigned)grid), dim3(256), fused_lds,        \
+        if ((rc = set_lds(mlp_bwd_fused_kernel<T0, T1, T2, T3, NT, XMODE, AH, AO>, fused_lds))) return rc;                        \
+        hipLaunchKernelGGL((mlp_bwd_fused_kernel<T0, T1, T2, T3, NT, XMODE, AH, AO>), dim3((unsigned)grid), dim3(256), fused_lds, \
                            as_stream(stream), x, x_stride, cat, weights, P, out, acts, dout, dx, partials, (int)grid, n_cap, n,   \
                            n_ptr);                                                                                               \
     } while (0)
+#define ARCN_FUSED(T0, T1, T2, T3, NT, XMODE) ARCN_FUSED_A(T0, T1, T2, T3, NT, XMODE, -1, -1)
             static const int fused_nt3 = 1;
+            const bool relu_lin = P.act_hidden == ARCN_ACT_RELU && P.act_out == ARCN_ACT_NONE;
+            const bool relu_sig = P.act_hidden == ARCN_ACT_RELU && P.act_out == ARCN_ACT_SIGMOID;
             if (cat_in) {
-                if (sig == 2441) ARCN_FUSED(2, 4, 4, 1, 1, 2); else ARCN_FUSED(2, 4, 1, 0, 2, 2);
+                if (sig == 2441 && relu_sig) ARCN_FUSED_A(2, 4, 4, 1, 1, 2, ARCN_ACT_RELU, ARCN_ACT_SIGMOID);
+                else if (sig == 2441) ARCN_FUSED(2, 4, 4, 1, 1, 2);
+                else ARCN_FUSED(2, 4, 1, 0, 2, 2);
             } else if (x_stride) {
-                if (sig == 2410) ARCN_FUSED(2, 4, 1, 0, 2, 1); else ARCN_FUSED(4, 4, 1, 0, 2, 1);
+                if (sig == 2410 && relu_lin) ARCN_FUSED_A(2, 4, 1, 0, 2, 1, ARCN_ACT_RELU, ARCN_ACT_NONE);
+                else if (sig == 2410) ARCN_FUSED(2, 4, 1, 0, 2, 1);
+                else ARCN_FUSED(4, 4, 1, 0, 2, 1);
             } else switch (sig) {
             case 2410: ARCN_FUSED(2, 4, 1, 0, 2, 0); break;
             case 4410: ARCN_FUSED(4, 4, 1, 0, 2, 0); break;
@@ -1266,6 +1287,7 @@ static int mlp_bwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
             default: ARCN_FUSED(4, 4, 4, 1, 1, 0); break;
             }
 #undef ARCN_FUSED
+#undef ARCN_FUSED_A
             // defer_reduce: the per-workgroup partials stay in `scratch`; arcn_mlp_bwd_reduce adds them into dweights later
             if (!defer_reduce)
                 hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(4096 / kReduceElems, (unsigned)P.n_layers), dim3(kReduceElems * kReduceSlices), 0, as_stream(stream), partials,
