@@ -420,10 +420,28 @@ class NgpPipeline:
     def _share_bits_with_aux(self):
         """occupancy bits produced / handed over on the current stream are read by marchers on the sampling stream: order the
         sampling stream behind their producer and tell the allocator about the second consumer"""
+        self._build_cull_grid()
         aux = getattr(self, 'aux_stream', None)
         if aux is not None and self._bits is not None and self._bits.is_cuda:
             aux.wait_stream(torch.cuda.current_stream())
             self._bits.record_stream(aux)
+            if self._coarse is not None:
+                self._coarse.record_stream(aux)
+
+    def _build_cull_grid(self):
+        """the marcher's ray-culling grid (arcn_march_cull_grid) of the occupancy just handed over; ARCN_MARCH_CULL=0: none"""
+        self._coarse = None
+        ng = self.cfg.n_grid
+        # (only for the bits this pipeline packs itself, set_bitfield: a Morton bitfield handed over by set_occupancy_bits is updated in
+        # place by its owner's kernels, behind any version counter - a stale culling grid would drop samples)
+        if (self._bits is None or not self._bits.is_cuda or self.packed_bits != 1 or ng < 16 or ng % 4 or
+                os.environ.get('ARCN_MARCH_CULL', '1') == '0'):
+            return
+        cells = (ng // 4) ** 3
+        coarse = torch.empty(cells, dtype=torch.uint8, device=self._bits.device)
+        tmp = torch.empty(cells, dtype=torch.uint8, device=self._bits.device)
+        N.check(N.lib().arcn_march_cull_grid(N.ptr(self._bits), int(self.packed_bits), ng, N.ptr(coarse), N.ptr(tmp), N.stream()), 'march_cull_grid')
+        self._coarse = coarse
 
     def _occ(self):
         return self._bits if self.packed_bits else self._bitfield
@@ -505,10 +523,16 @@ class NgpPipeline:
                                         N.ptr(b['march_ws']), R, st), 'march_packed')
             self.rng.advance()
         else:
-            N.check(L.arcn_march_count(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
-                                       int(self.packed_bits), cfg.n_sample, cfg.dt, cfg.near_distance, int(self.torch_aabb),
-                                       self.rng.state, self.rng.inc, N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['near']),
-                                       N.ptr(b['far']), R, st), 'march_count')
+            if getattr(self, '_coarse', None) is not None:     # rays that pass no occupied block leave before they march (same outputs)
+                N.check(L.arcn_march_count_culled(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
+                                                  int(self.packed_bits), N.ptr(self._coarse), cfg.n_sample, cfg.dt, cfg.near_distance,
+                                                  int(self.torch_aabb), self.rng.state, self.rng.inc, N.ptr(b['scratch_t']),
+                                                  N.ptr(b['counts']), N.ptr(b['near']), N.ptr(b['far']), R, st), 'march_count_culled')
+            else:
+                N.check(L.arcn_march_count(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
+                                           int(self.packed_bits), cfg.n_sample, cfg.dt, cfg.near_distance, int(self.torch_aabb),
+                                           self.rng.state, self.rng.inc, N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['near']),
+                                           N.ptr(b['far']), R, st), 'march_count')
             self.rng.advance()
             # offsets (clamped to the capacity) and the dense width the reference would have used, max(2, max count)
             N.check(L.arcn_exclusive_scan_i32(N.ptr(b['counts']), N.ptr(b['offsets']), R, self.cap, N.ptr(b['p_dense']), st), 'scan')

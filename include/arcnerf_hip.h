@@ -158,6 +158,17 @@ int arcn_march_count(const float *rays_o, const float *rays_d, const float *aabb
                      int bitfield_is_packed, int n_pts, float dt, float near_distance, int aabb_torch_semantics,
                      uint64_t rng_state, uint64_t rng_inc, float *scratch_t, int32_t *counts, float *near_out,
                      float *far_out, int64_t n_rays, void *stream);
+/* Ray culling for pass 1.  arcn_march_cull_grid: coarse ((n_grid / 4)^3 bytes) = 1 where any voxel of a 4^3 block or of one of its 26
+ * neighbour blocks is occupied (tmp: same size; n_grid a multiple of 4, >= 16; rebuild whenever the bitfield changes).
+ * arcn_march_count_culled = arcn_march_count with that grid: before marching, a wave tests 64 points spread over its ray's [near, far]
+ * (at most one block apart per axis, else the ray is marched as usual) and leaves with count 0 when none of them sees an occupied
+ * block - what the reference's loop (volume_func_kernel.cu:174-236) produces after stepping through its empty voxels.  Outputs are
+ * bit-identical to arcn_march_count. */
+int arcn_march_cull_grid(const uint8_t *bitfield, int bitfield_is_packed, int n_grid, uint8_t *coarse, uint8_t *tmp, void *stream);
+int arcn_march_count_culled(const float *rays_o, const float *rays_d, const float *aabb, int n_grid, const uint8_t *bitfield,
+                            int bitfield_is_packed, const uint8_t *coarse, int n_pts, float dt, float near_distance,
+                            int aabb_torch_semantics, uint64_t rng_state, uint64_t rng_inc, float *scratch_t, int32_t *counts,
+                            float *near_out, float *far_out, int64_t n_rays, void *stream);
 /* The three passes above in ONE launch (no dense scratch): a wave keeps its ray's samples in LDS, the workgroups' counts go through a
  * chained scan (decoupled look-back, ray blocks handed out by ticket), the waves copy their samples to their final offsets.
  * Same outputs as the three-pass form, bit for bit (offsets clamped to `capacity`, p_dense = largest per-ray count).

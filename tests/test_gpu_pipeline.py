@@ -528,3 +528,82 @@ def test_step_tail_argument_errors_and_empty_input():
     assert call() == 0                     # and a valid call still goes through afterwards
     torch.cuda.synchronize()
     assert not torch.equal(p[:4096], before[:4096])
+
+
+@pytest.mark.parametrize('mode', [0, 1, 2])
+def test_culled_marcher_is_bit_identical(mode):
+    """arcn_march_count_culled (rays that pass no occupied 4^3 block - dilated by one block - leave before marching) against
+    arcn_march_count: counts, the emitted t of every ray, near and far, bit for bit; cameras outside and INSIDE the volume, grazing rays,
+    occupancies 0 / 0.3 % / 5 % / 40 % / 100 %, the three bitfield layouts; and the culling does cull (most rays of the sparse grids)."""
+    import ctypes as C
+    from arcnerf_amd import _native as N
+    from arcnerf_amd.pipeline import synthetic_bitfield, synthetic_rays
+    dev = torch.device('cuda:0')
+    L = N.lib()
+    ng, n_pts = 64, 512
+    aabb = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], device=dev)
+    dt = (12.0 ** 0.5) / n_pts
+    g = torch.Generator().manual_seed(7)
+    o1, d1 = synthetic_rays(3000, seed=1, device=dev)
+    o2 = (torch.rand(1500, 3, generator=g) * 1.6 - 0.8).to(dev)                    # cameras inside the volume
+    d2 = torch.nn.functional.normalize(torch.randn(1500, 3, generator=g), dim=-1).to(dev)
+    o3 = torch.tensor([[-3.0, 0.999, 0.3]], device=dev).repeat(500, 1) + torch.rand(500, 3, generator=g).to(dev) * 1e-3   # grazing a face
+    d3 = torch.nn.functional.normalize(torch.tensor([[1.0, 0.0, 0.0]]).repeat(500, 1) + torch.randn(500, 3, generator=g) * 2e-3, dim=-1).to(dev)
+    o, d = torch.cat([o1, o2, o3]).contiguous(), torch.cat([d1, d2, d3]).contiguous()
+    R = o.shape[0]
+
+    def morton_bits(grid):     # Morton-ordered bits of a (ng, ng, ng) bool grid, like BitfieldBound.density_bitfield
+        idx = torch.arange(ng, device=dev)
+
+        def spread(v):
+            v = v.long()
+            r = torch.zeros_like(v)
+            for bit in range(10):
+                r |= ((v >> bit) & 1) << (3 * bit)
+            return r
+        m = (spread(idx)[:, None, None] | (spread(idx)[None, :, None] << 1) | (spread(idx)[None, None, :] << 2)).reshape(-1)
+        flat = torch.zeros(ng ** 3, dtype=torch.bool, device=dev)
+        flat[m] = grid.reshape(-1)
+        return flat
+
+    culled_rays = []
+    for occ in (0.0, 0.003, 0.05, 0.4, 1.0):
+        if occ in (0.0, 1.0):
+            grid = torch.full((ng, ng, ng), bool(occ), device=dev)
+        elif occ > 0.1:       # (the blob generator is slow for dense grids: thick random slabs instead)
+            coarse_rand = torch.rand((ng // 8,) * 3, generator=torch.Generator().manual_seed(5)) < occ
+            grid = coarse_rand.repeat_interleave(8, 0).repeat_interleave(8, 1).repeat_interleave(8, 2).to(dev)
+        else:
+            grid = torch.from_numpy(synthetic_bitfield(ng, occ, seed=3)).to(dev).view(ng, ng, ng)
+        flat = morton_bits(grid) if mode == 2 else grid.reshape(-1)
+        if mode == 0:
+            bf = flat.to(torch.uint8).contiguous()
+        else:
+            w = 2 ** torch.arange(8, device=dev, dtype=torch.int32)
+            bf = (flat.view(-1, 8).to(torch.int32) * w).sum(-1).to(torch.uint8).contiguous()
+        cells = (ng // 4) ** 3
+        coarse, tmp = torch.empty(cells, dtype=torch.uint8, device=dev), torch.empty(cells, dtype=torch.uint8, device=dev)
+        N.check(L.arcn_march_cull_grid(N.ptr(bf), mode, ng, N.ptr(coarse), N.ptr(tmp), N.stream()), 'cull_grid')
+        # the grid itself: a block is set iff a voxel of it or of a neighbouring block is occupied
+        blocks = grid.view(ng // 4, 4, ng // 4, 4, ng // 4, 4).any(dim=5).any(dim=3).any(dim=1).float()[None, None]
+        want = torch.nn.functional.max_pool3d(blocks, 3, stride=1, padding=1)[0, 0] > 0
+        assert torch.equal(coarse.view(ng // 4, ng // 4, ng // 4) != 0, want)
+        res = {}
+        for cull in (False, True):
+            scr = torch.full((R, n_pts), -1.0, device=dev)
+            cnt = torch.full((R,), -7, dtype=torch.int32, device=dev)
+            near, far = torch.empty(R, device=dev), torch.empty(R, device=dev)
+            args = [N.ptr(o), N.ptr(d), N.ptr(aabb), ng, N.ptr(bf), mode]
+            tail = [n_pts, dt, 0.05, 0, 1234567, 77, N.ptr(scr), N.ptr(cnt), N.ptr(near), N.ptr(far), R, N.stream()]
+            if cull:
+                N.check(L.arcn_march_count_culled(*args, N.ptr(coarse), *tail), 'culled')
+            else:
+                N.check(L.arcn_march_count(*args, *tail), 'plain')
+            keep = torch.arange(n_pts, device=dev)[None] < cnt[:, None]
+            res[cull] = (cnt, torch.where(keep, scr, torch.zeros_like(scr)), near, far)
+        for a, b in zip(res[True], res[False]):
+            assert torch.equal(a, b)
+        if 0.0 < occ < 1.0:
+            assert int(res[True][0].sum()) > 0
+        culled_rays.append(int((res[True][0] == 0).sum()))
+    assert culled_rays[0] == R and culled_rays[1] > 0.8 * R and culled_rays[4] < 0.5 * R

@@ -26,7 +26,7 @@ GROUPS = {
         {'ARCN_PREFETCH_DEPTH': '1'},
         {'ARCN_DETERMINISTIC': '1'},     # the order-independent fixed-point scatter: same gradients as the float one
         {'ARCN_FUSE_ADAM': '0'},         # scatter and optimiser as two passes (what several ranks run) instead of the fused consumer
-        {'ARCN_STEP_TAIL': '0'},         # dW reductions, rest of the optimiser and the counter fill as four launches instead of one
+        {'ARCN_STEP_TAIL': '0', 'ARCN_MARCH_CULL': '0'},   # dW reductions, rest of the optimiser and the counter fill as four launches instead of one; no ray culling
     ],
     'nets': [
         {'ARCN_GEMM_SPLIT': '0', 'ARCN_LINEAR_FUSED_RELU': '0', 'ARCN_LINEAR_SOFTPLUS': '0', 'ARCN_TONEMAP_FUSED': '0', 'ARCN_NEUS_UPSAMPLE_GRAPH': '1'},
