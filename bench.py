@@ -477,8 +477,10 @@ def main():
     timers = KernelTimers()
     instrument(timers)
     all_reduce = (lambda t: D.allreduce_grads(t, world)) if use_dist else None
-    # gradient sync: K async segments pipelined with the optimiser (default) or one flat all-reduce (ARCN_GRAD_SEGMENTS=0)
-    n_seg = int(os.environ.get('ARCN_GRAD_SEGMENTS', '4'))
+    # gradient sync: ONE flat all-reduce (default) or K async segments pipelined with the optimiser (ARCN_GRAD_SEGMENTS=K).  Measured on a
+    # one-rank RCCL communicator (tools/ab_dist1.sh): four segments cost 0.04 ms of extra launches and stream hand-overs per step and can
+    # hide at most 3/4 of the 0.06 ms optimiser pass behind the ring - and each further collective adds its ring latency
+    n_seg = int(os.environ.get('ARCN_GRAD_SEGMENTS', '0'))
     grad_sync = D.PipelinedGradSync(field.n_params, n_seg) if (use_dist and n_seg > 0) else None
     sample_log = torch.zeros(args.steps + args.warmup + 16, dtype=torch.int64, device=dev)
 
