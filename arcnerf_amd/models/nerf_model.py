@@ -186,9 +186,8 @@ class NeRF(FgModel):
         state = pipe.rng.state
         pipe.sample(rays_o, rays_d)
         if check:
-            total = pipe.buf['counts'][:R].sum(dtype=torch.int64)
             if exact:
-                need = int(total)
+                need = int(pipe.buf['counts'][:R].sum(dtype=torch.int64))
                 self._samples_per_ray = need / max(1, R)
                 if need > pipe.cap:
                     pipe = self._packed_pipeline(rays_o.device, min_samples=(need * 5 // 4 + 1023) // 1024 * 1024)
@@ -196,12 +195,14 @@ class NeRF(FgModel):
                     pipe.sample(rays_o, rays_d)
                     assert int(pipe.n_dev.item()) == need
             else:
+                # the scan's total (offsets[R]) is exact unless it was clamped to the capacity: one asynchronous copy of that word per step;
+                # the per-ray counts are only summed when it reads "full" (then: with them, the number the buffers must grow to)
                 if getattr(self, '_ovf_host', None) is None:
-                    self._ovf_host = torch.zeros(1, dtype=torch.int64).pin_memory()
-                self._ovf_host.copy_(total.view(1), non_blocking=True)
+                    self._ovf_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                self._ovf_host.copy_(pipe.n_dev, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
-                self._pending_ovf = (ev, pipe.cap, R)
+                self._pending_ovf = (ev, pipe.cap, R, pipe.buf['counts'])
         return pipe
 
     def _check_deferred_overflow(self, device):
@@ -209,9 +210,13 @@ class NeRF(FgModel):
         if pend is None:
             return
         self._pending_ovf = None
-        ev, cap, R = pend
+        ev, cap, R, counts = pend
         ev.synchronize()    # recorded a whole step ago: no wait in practice
         need = int(self._ovf_host[0])
+        if need >= cap and counts is not None:
+            # the scan clamped: the exact demand from the per-ray counts (still those of that step unless this model has sampled since -
+            # then the sum is the newer step's demand, just as good a number to grow to)
+            need = max(need, int(counts[:R].sum(dtype=torch.int64)))
         self._samples_per_ray = need / max(1, R)
         if need > cap:
             import warnings
