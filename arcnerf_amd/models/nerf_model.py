@@ -113,7 +113,10 @@ class NeRF(FgModel):
     def _packed_pipeline(self, device, min_samples=0):
         if self._pipe is not None and self._pipe.cap < min_samples:
             self._pipe = None   # grow: the buffers are rebuilt at the new capacity
+        if self._pipe is None:
+            self._bits_key = None   # (a new pipeline has no occupancy yet - and may reuse the id() of the one just dropped)
         if self._pipe is None or self._pipe.field.device != device:
+            self._bits_key = None
             g, r, vol = self.coarse_geo_net, self.coarse_radiance_net, self.obj_bound.volume
             e = g.embed_fn
             side = float(e.max_xyz[0] - e.min_xyz[0])
