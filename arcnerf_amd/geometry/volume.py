@@ -99,6 +99,7 @@ class Volume(nn.Module):
         mn = self.origin.detach() - self.xyz_len.detach() / 2.0
         mx = self.origin.detach() + self.xyz_len.detach() / 2.0
         self.register_buffer('range', torch.stack([mn, mx], dim=-1))  # (3, 2)
+        self.__dict__.pop('_host_cache', None)    # (a re-registered buffer may reuse the address AND version of the one it replaces)
 
     def get_range(self):
         return self.range
