@@ -115,6 +115,12 @@ def test_chunk_processing_semantics():
     assert chunk_processing(lambda s: s * 2, 4, False, 'ab') == 'abab'              # no array argument: direct call
     with pytest.raises(AssertionError):
         chunk_processing(lambda p, q: p, 4, False, torch.zeros(3), torch.zeros(4))
+    # one chunk: its outputs ARE the result (no concatenation pass); several chunks: concatenated copies
+    one = chunk_processing(lambda t: {'y': t + 1}, 16, False, a)
+    assert torch.equal(one['y'], a + 1)
+    keep = []
+    res = chunk_processing(lambda t: keep.append(t + 1) or keep[-1], 16, False, a)
+    assert res is keep[0]
 
 
 def test_product_path_has_no_cpu_fallback():
@@ -252,3 +258,62 @@ def test_morton_order_of_the_synthetic_cascade_matches_the_oracle(oracle):
     assert np.array_equal(morton3d(xyz[:, 0], xyz[:, 1], xyz[:, 2]).astype(np.int64), oracle.morton3d(xyz).astype(np.int64))
     bits = synthetic_cascade_bits(16, 2, 0.1, seed=0)
     assert bits.shape == (2 * 16 ** 3 // 8,) and 0.08 < np.unpackbits(bits).mean() < 0.3
+
+
+def test_dynamic_batch_size_ring_matches_the_reference_arithmetic():
+    """FgModel.adjust_dynamicbs_factor keeps each step's valid-sample count in a device ring (one copy per step, no host read) and
+    get_dynamicbs_factor does the reference's arithmetic on read-back (arcnerf/models/fg_model.py:105-128: a Python float accumulating
+    max_allowance / (n + 1), divided by the number of measurements, then reset) - also when the ring wraps before anybody asks."""
+    m = build_model(load_configs(os.path.join(CFG, 'nerf_ngp.yaml'), ['--model.obj_bound.volume.n_grid', '16']))
+    fg = m.fg_model
+    cap = float(fg.render_cfgs['max_allowance'])
+    assert cap > 0
+    g = torch.Generator().manual_seed(0)
+    counts = torch.randint(1, 400000, (37,), generator=g)
+    for c in counts:
+        fg.adjust_dynamicbs_factor(n_valid=c.to(torch.int32).reshape(1)[0])
+    ref = sum(cap / (float(c) + 1.0) for c in counts.tolist()) / len(counts)
+    assert fg.get_dynamicbs_factor() == ref
+    assert fg.render_cfgs['measured_count'] == 0 and fg.get_dynamicbs_factor() == 1       # reset; nothing measured -> 1
+    mask = torch.zeros(5, 7, dtype=torch.bool)
+    mask[1, :3] = True
+    fg.adjust_dynamicbs_factor(mask_pts=mask)                                               # the reference's signature: a sample mask
+    assert fg.get_dynamicbs_factor() == cap / 4.0
+    fg._DYNBS_RING = 8                                                                      # wrap: drained into the running sum
+    fg._dynbs_ring = None
+    for c in counts:
+        fg.adjust_dynamicbs_factor(n_valid=c.reshape(1)[0])
+    got = fg.get_dynamicbs_factor()
+    assert abs(got - ref) <= 1e-12 * ref
+    fg.render_cfgs['max_allowance'] = -1                                                    # switched off: nothing is recorded
+    fg.adjust_dynamicbs_factor(n_valid=counts[0])
+    assert fg.render_cfgs['measured_count'] == 0
+
+
+def test_host_value_caches_follow_their_tensors():
+    """Volume.get_diag_len / get_len / get_voxel_size and Sphere radius / origin hand out Python numbers read back once per VERSION of
+    the tensor they come from (each read of a device scalar is a host / device synchronisation; the samplers ask every step): in-place
+    writers, re-registered buffers and the setters must all be seen; scalar_tensor keeps one device tensor per value."""
+    from arcnerf_amd.geometry.sphere import Sphere
+    from arcnerf_amd.geometry.volume import Volume
+    from arcnerf_amd.ops import functional as F
+    v = Volume(n_grid=8, origin=(0.0, 0.0, 0.0), side=2.0)
+    assert abs(v.get_diag_len() - 12.0 ** 0.5) < 1e-6 and v.get_len() == (2.0, 2.0, 2.0) and v.get_voxel_size() == (0.25, 0.25, 0.25)
+    first = v._host_cache['diag']
+    assert v.get_diag_len() == first[1] and v._host_cache['diag'] is first                  # served from the cache
+    with torch.no_grad():
+        v.range.mul_(2.0)                                                                   # an in-place writer moves the version
+    assert abs(v.get_diag_len() - 2.0 * 12.0 ** 0.5) < 1e-6 and v.get_voxel_size() == (0.5, 0.5, 0.5)
+    with torch.no_grad():
+        v.xyz_len.fill_(4.0)
+    v.cal_range()                                                                           # a re-registered buffer drops the cache
+    assert abs(v.get_diag_len() - 48.0 ** 0.5) < 1e-6 and v.get_len() == (4.0, 4.0, 4.0)
+    v.set_n_grid(16)
+    assert v.get_voxel_size() == (0.25, 0.25, 0.25)
+    s = Sphere(origin=(0.0, 0.0, 0.0), radius=1.5)
+    assert s.get_radius(in_float=True) == 1.5 and s.get_origin(in_tuple=True) == (0.0, 0.0, 0.0)
+    s.set_radius(2.5)
+    s.set_origin((1.0, 2.0, 3.0))
+    assert s.get_radius(in_float=True) == 2.5 and s.get_origin(in_tuple=True) == (1.0, 2.0, 3.0)
+    a, b = F.scalar_tensor(64.0, 'cpu'), F.scalar_tensor(64, 'cpu')
+    assert a is b and float(a) == 64.0 and F.scalar_tensor(128.0, 'cpu') is not a
