@@ -1648,7 +1648,10 @@ static int build_fwd_plan(const GridParams &g, int64_t n, FwdPlan &plan, int &wg
                 if (plan.n_seg[q] < kFwdSegs && eff < best) { best = eff; x = q; }
             }
             if (best > 1e29f) return einval("hashgrid_fwd_xcd: plan overflow");
-            static const float odd_scale = 1.0f;
+            // the odd XCDs finish a given queue ~4 us later than the even ones, for any plan (round 2): with one tile per workgroup a smaller
+            // share evens them out - 0.92: 59.9 us alone against 62.5 (0.617 of 8 TB/s), 78.5 against 81.4 us in the step; 0.96 is WORSE
+            // (64.7 us: where the cuts of the filler levels land matters), 0.90 - 0.94 all within 1 us
+            static const float odd_scale = 0.92f;
             const float room = share * ((x & 1) ? odd_scale : 2.0f - odd_scale) - load[x];
             const float take = (room <= 1e-4f * total || left <= room) ? left : room;
             const float f1 = (take >= left) ? 1.f : f0 + (1.f - f0) * (take / left);
