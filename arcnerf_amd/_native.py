@@ -26,7 +26,7 @@ class MlpDesc(C.Structure):
                 ('has_bias', C.c_int32), ('softplus_beta', C.c_float)]
 
 
-_SCALARS = {'int': C.c_int, 'int32_t': C.c_int32, 'int64_t': C.c_int64, 'uint64_t': C.c_uint64, 'float': C.c_float,
+_SCALARS = {'int': C.c_int, 'int32_t': C.c_int32, 'uint32_t': C.c_uint32, 'int64_t': C.c_int64, 'uint64_t': C.c_uint64, 'float': C.c_float,
             'double': C.c_double}
 
 

@@ -870,7 +870,7 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
     for (int k = 0; k < 8; ++k) {
         if (k >= n_slots || sbin[k] < 0) continue;
         const uint4 rec = make_uint4(sidx[k], __float_as_uint(swx[k]), __float_as_uint(sa[k]), __float_as_uint(sb[k]));
-        emit_record<F>(lrecs, dtable, lp, sbin[k], gbase[sbin[k]] + rank[k], cap, shift, rec, plan.det ? &counters[plan.aux_first + 1] : nullptr);
+        emit_record<F>(lrecs, dtable, lp, sbin[k], gbase[sbin[k]] + rank[k], cap, shift, rec, &counters[plan.aux_first + 1]);
     }
     // no barrier here: the next tile counts into the other histogram and reserves into the other gbase; this tile's gbase is
     // overwritten two tiles later, behind two more barriers
@@ -953,7 +953,7 @@ scatter_bin_dir_kernel(const float *__restrict__ xyz, const float *__restrict__ 
         for (int q = 0; q < 8; ++q) {
             if (sbin[q] < 0) continue;
             const uint4 rec = make_uint4(sidx[q], 0u, __float_as_uint(sa[q]), __float_as_uint(sb[q]));
-            emit_record<F>(lrecs, dtable, lp, sbin[q], gbase[sbin[q]] + rank[q], cap, shift, rec, plan.det ? &counters[plan.aux_first + 1] : nullptr);
+            emit_record<F>(lrecs, dtable, lp, sbin[q], gbase[sbin[q]] + rank[q], cap, shift, rec, &counters[plan.aux_first + 1]);
         }
     }
 }
@@ -984,6 +984,7 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
     const LevelParams lp = g.lv[l];
     const uint32_t cap = (uint32_t)plan.cap[l];
     uint32_t cnt = counters[plan.bin_first[l] + chunk];
+    const bool bin_overflowed = cnt > cap;      // the producer applied the records past the capacity to dtable directly (emit_record)
     cnt = cnt < cap ? cnt : cap;
     const uint32_t per = (cnt + ns - 1) / ns;
     const uint32_t lo = per * split, hi = (lo + per < cnt) ? lo + per : cnt;
@@ -1151,6 +1152,16 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
         float *P = fz.param + base, *M = fz.m + base, *V = fz.v + base;
         const AdamHyper h = fz.h;
         const int nf = n_rows * F;
+        if (bin_overflowed) {
+            // this chunk's bin ran over: part of its gradient sits in dtable (the producer's direct atomics, complete since the producer
+            // kernel has ended).  Fold it into the accumulator and leave dtable clear - nothing else reads a fused level's dtable rows.
+            float *D = dtable + base;
+            for (int j = threadIdx.x; j < nf; j += kTiledThreads) {
+                acc[j] += D[j];
+                D[j] = 0.f;
+            }
+            __syncthreads();
+        }
         if ((base & 3) == 0) {
             const int n4 = nf >> 2;
             constexpr int kB = 4;
@@ -1375,7 +1386,7 @@ ARCN_EXPORT int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc 
 static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *dout, int64_t dout_lm_stride,
                              const arcn_hashgrid_desc *desc_host, float *dtable, float *dxyz, float *workspace,
                              int64_t workspace_floats, int64_t n, const int32_t *n_ptr, void *stream, const AdamFuse *fuse = nullptr,
-                             uint32_t *fused_levels_out = nullptr, bool counters_clear = false) {
+                             uint32_t *fused_levels_out = nullptr, bool counters_clear = false, uint32_t level_mask = 0xffffffffu) {
     if (n <= 0) return ARCN_OK;
     if (!xyz || !dout || (!dtable && !dxyz) || (dxyz && !table)) return einval("hashgrid_bwd: missing argument");
     GridParams g;
@@ -1388,6 +1399,7 @@ static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *
         BinPlan plan;
         rc = build_bin_plan(g, n, plan);
         if (rc) return rc;
+        plan.active_levels &= level_mask;      // arcn_hashgrid_bwd_lm_levels: the workgroups of the other levels leave at once
         uint32_t *counters = reinterpret_cast<uint32_t *>(workspace);
         uint4 *recs = reinterpret_cast<uint4 *>(workspace + bin_counter_floats(plan));
         // (the whole 256-byte padded block: ONE fill launch, an odd size is two; none when the caller's previous pass left it clear)
@@ -1502,6 +1514,16 @@ ARCN_EXPORT int arcn_hashgrid_bwd_lm(const float *xyz, const float *dout_lm, int
     if (dout_stride < n) return einval("hashgrid_bwd_lm: level stride smaller than n");
     if (!workspace) return einval("hashgrid_bwd_lm: workspace required");
     return hashgrid_bwd_impl(xyz, nullptr, dout_lm, dout_stride, desc_host, dtable, nullptr, workspace, workspace_floats, n, n_ptr, stream);
+}
+
+ARCN_EXPORT int arcn_hashgrid_bwd_lm_levels(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host,
+                                            float *dtable, float *workspace, int64_t workspace_floats, int64_t n, const int32_t *n_ptr,
+                                            uint32_t level_mask, void *stream) {
+    if (dout_stride < n) return einval("hashgrid_bwd_lm_levels: level stride smaller than n");
+    if (!workspace) return einval("hashgrid_bwd_lm_levels: workspace required");
+    if (level_mask == 0u) return ARCN_OK;
+    return hashgrid_bwd_impl(xyz, nullptr, dout_lm, dout_stride, desc_host, dtable, nullptr, workspace, workspace_floats, n, n_ptr, stream,
+                             nullptr, nullptr, false, level_mask);
 }
 
 ARCN_EXPORT int64_t arcn_hashgrid_bwd_fusable_levels(const arcn_hashgrid_desc *desc_host, int64_t n) {

@@ -120,6 +120,91 @@ class PipelinedGradSync:
             self.works[i].wait()
 
 
+class LevelGroupedGradSync:
+    """The gradient exchange overlapped with the hash-grid scatter (NgpPipeline.train_step(grad_sync=...)).
+
+    The table gradient is 99.9 % of the flat buffer and it is the LAST thing the backward produces, so a flat all-reduce starts when
+    the compute is over (48.8 MB, ~0.28 ms at 8 GPUs, nothing to hide behind).  DistributedDataParallel hides its buckets
+    behind the rest of the backward (common/trainer/basic_trainer.py:197-198); the equivalent here: the scatter runs in level GROUPS
+    (arcn_hashgrid_bwd_lm_levels), finest levels first, and each group's slice of the flat buffer goes on the wire (`async_op=True`: on
+    the communicator's stream, behind the kernels already queued) while the next group is still being scattered; the optimiser then
+    updates a group's slice as soon as it has arrived while the later groups are still in flight.  Groups of 8 levels keep the
+    scatter's producer at one full wave of workgroups per launch (32 per level x 8 = 256 CUs).
+
+    The MLP weights' gradients are complete before the scatter starts and sit BEHIND the table in the flat buffer: they travel with the
+    first group, whose slice is [first level of the group, end of the buffer).  Same arithmetic as one flat SUM all-reduce: every
+    element is summed across ranks exactly once (tests/test_distributed_gloo.py: bit-identical)."""
+
+    def __init__(self, field, boundaries=(8,), group=None):
+        """field: an NgpField (level offsets + flat layout); boundaries: the first level of every group but the last, descending
+        (default (8,): levels 8..L-1 + everything behind the table first, then levels 0..7)"""
+        self.group = group
+        L = len(field.resolutions)
+        Fq = field.cfg.n_feat_per_entry
+        t_lo, t_n = field._seg['table']
+        if t_lo != 0:
+            raise ValueError('LevelGroupedGradSync expects the table at the start of the flat buffer')
+        cuts = sorted({int(b) for b in boundaries if 0 < int(b) < L}, reverse=True)
+        # a slice has to start 16-byte aligned for the optimiser kernel: move a boundary down to the next level that does
+        fixed = []
+        for b in cuts:
+            while b > 0 and (field.offsets[b] * Fq) % 4:
+                b -= 1
+            if b > 0 and b not in fixed:
+                fixed.append(b)
+        levels_hi = L
+        self.groups = []
+        hi = field.n_params
+        for b in fixed + [0]:
+            mask = sum(1 << l for l in range(b, levels_hi))
+            lo = field.offsets[b] * Fq
+            self.groups.append((mask, lo, hi))
+            hi, levels_hi = lo, b
+        self.segments = [(lo, hi) for _, lo, hi in self.groups]
+        self.works = [None] * len(self.groups)
+        # timing=True: per step two events - the end of the last group's scatter (compute stream) and the end of the last collective
+        # (a probe stream that only waits for it) - whose distance is the part of the exchange nothing hid (exposed_ms)
+        self.timing = False
+        self._probe = None
+        self._marks = []
+
+    def launch_group(self, i, flat_grads):
+        _, lo, hi = self.groups[i]
+        self.works[i] = None
+        last = i == len(self.groups) - 1
+        t0 = None
+        if self.timing and last and flat_grads.is_cuda:
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record()
+        if _active(self.group):
+            self.works[i] = dist.all_reduce(flat_grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if t0 is not None:
+            if self._probe is None:
+                self._probe = torch.cuda.Stream(device=flat_grads.device)
+            t1 = torch.cuda.Event(enable_timing=True)
+            self._probe.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._probe):
+                if self.works[i] is not None:
+                    self.works[i].wait()
+                t1.record(self._probe)
+            self._marks.append((t0, t1))
+
+    def exposed_ms(self, last_n=None):
+        """per step: time from the end of the compute that produced the last group's gradient to the end of the last collective
+        (host read: synchronises); needs timing=True"""
+        marks = self._marks if last_n is None else self._marks[-last_n:]
+        out = []
+        for t0, t1 in marks:
+            t1.synchronize()
+            out.append(max(0.0, t0.elapsed_time(t1)))
+        return out
+
+    def wait(self, i):
+        if self.works[i] is not None:
+            self.works[i].wait()
+            self.works[i] = None
+
+
 def broadcast_bitfield(bits, src=0, group=None):
     """Make every rank march the same occupancy: broadcast the packed bitfield (uint8, n_grid^3/8 bytes) from `src`."""
     if _active(group):

@@ -30,6 +30,8 @@ class Sphere(nn.Module):
         """Python numbers of a small device tensor, read back once per version of it (every read is a host / device synchronisation and
         the ray-sphere intersection asks on every call); the in-place setters move the key."""
         key = (src.data_ptr(), src._version, str(src.device))
+        if src.requires_grad:      # a learnable tensor is updated by raw-pointer kernels (FusedAdam) that do not move its version: no cache
+            return make()
         cache = self.__dict__.setdefault('_host_cache', {})
         hit = cache.get(name)
         if hit is None or hit[0] != key:

@@ -42,7 +42,24 @@ def mix_permutation(idx, n, rng):
     return x
 
 
-def select_refresh_cells(bitfield_flat, n_cells, cache, rng):
+# The random draws of an occupancy refresh (VolumeBound.optimize, volume_bound.py:178-193: torch.randperm for the uniformly chosen quarter,
+# torch.rand_like for the jitter inside a cell).  By default they come from seeded on-device generators (mix_permutation, the pcg32 of
+# arcn_refresh_cells_points, torch.rand_like).  A tape installed with set_refresh_tape() supplies them instead: an object with
+# draws(cur_epoch, n_cells, device) -> (perm int64 (n_cells,), uniforms float32 (n_cells, 3)) - e.g. the draws a run of the reference's
+# own loop consumed, so that the run can be reproduced cell for cell (tests/test_gpu_trajectory.py).
+_refresh_tape = None
+
+
+def set_refresh_tape(tape):
+    global _refresh_tape
+    _refresh_tape = tape
+
+
+def refresh_tape():
+    return _refresh_tape
+
+
+def select_refresh_cells(bitfield_flat, n_cells, cache, rng, perm=None):
     """Cells refreshed by VolumeBound.optimize after its warm-up (volume_bound.py:178-190): n/4 cells drawn uniformly
     without repetition + the first n/4 occupied cells in flat-index order (`get_occupied_voxel_idx()[:n]`).
 
@@ -53,14 +70,17 @@ def select_refresh_cells(bitfield_flat, n_cells, cache, rng):
     compaction through cumsum + scatter, and the number
     of valid entries is returned as a DEVICE int32 scalar — torch.nonzero/torch.where would stall the launch queue at every
     refresh.  Returns (cells int64 (2*(n/4),), n_valid int32 (1,)).  `cache` is a dict for persistent buffers, `rng` a
-    numpy Generator (host side, only the two affine constants are drawn from it)."""
+    numpy Generator (host side, only the two affine constants are drawn from it); perm: a given permutation of the cells (a tape)
+    instead of the seeded bijection."""
     dev = bitfield_flat.device
     n_s = n_cells // 4
     if 'cell_buf' not in cache:
         cache['cell_buf'] = torch.zeros(2 * n_s + 1, dtype=torch.int64, device=dev)
         cache['arange'] = torch.arange(n_cells, device=dev)
     buf, ar = cache['cell_buf'], cache['arange']
-    if n_cells & (n_cells - 1) == 0:
+    if perm is not None:
+        buf[:n_s] = perm[:n_s]
+    elif n_cells & (n_cells - 1) == 0:
         buf[:n_s] = mix_permutation(ar[:n_s], n_cells, rng)
     else:
         buf[:n_s] = torch.randperm(n_cells, device=dev)[:n_s]
@@ -121,11 +141,17 @@ class Volume(nn.Module):
         host / device synchronisation, and the samplers ask for the diagonal on every call (the reference re-reads it each time,
         geometry/volume.py:330-360 there).  In-place writers and re-registered buffers move the key."""
         key = (src.data_ptr(), src._version, str(src.device))
+        if src.requires_grad:      # a learnable tensor is updated by raw-pointer kernels (FusedAdam) that do not move its version: no cache
+            return make()
         cache = self.__dict__.setdefault('_host_cache', {})
         hit = cache.get(name)
         if hit is None or hit[0] != key:
             hit = cache[name] = (key, make())
         return hit[1]
+
+    def _range_key(self):
+        """the tensor whose version keys the cached values derived from `range`: a learnable origin / xyz_len turns the cache off"""
+        return self.origin if self.origin.requires_grad else (self.xyz_len if self.xyz_len.requires_grad else self.range)
 
     def get_len(self):
         return self._host_value('len', self.xyz_len, lambda: tuple(float(v) for v in self.xyz_len.detach().tolist()))
@@ -134,11 +160,11 @@ class Volume(nn.Module):
         return self.origin
 
     def get_diag_len(self):
-        return self._host_value('diag', self.range, lambda: float(torch.sqrt(((self.range[:, 1] - self.range[:, 0]) ** 2).sum())))
+        return self._host_value('diag', self._range_key(), lambda: float(torch.sqrt(((self.range[:, 1] - self.range[:, 0]) ** 2).sum())))
 
     def get_voxel_size(self, to_list=True):
         if to_list:
-            return self._host_value('voxel%d' % self.n_grid, self.range,
+            return self._host_value('voxel%d' % self.n_grid, self._range_key(),
                                     lambda: tuple(float(v) for v in ((self.range[:, 1] - self.range[:, 0]) / self.n_grid).tolist()))
         return (self.range[:, 1] - self.range[:, 0]) / self.n_grid
 

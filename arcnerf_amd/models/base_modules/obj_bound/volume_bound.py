@@ -9,7 +9,7 @@ import torch
 
 import numpy as np
 
-from ....geometry.volume import Volume, select_refresh_cells
+from ....geometry.volume import Volume, refresh_tape, select_refresh_cells
 from ....ops import volume_func as _vf
 from ....ops.volume_func import sparse_volume_sampling
 from ....render.ray_helper import get_zvals_from_near_far_fix_step, handle_valid_mask_zvals
@@ -96,13 +96,19 @@ class VolumeBound(BasicBound):
         dev = vol.get_device()
         n_dev = None
         pts = None
+        tape = refresh_tape()
+        perm = uni = None
+        if tape is not None:    # the draws of a recorded run instead of the seeded generators (geometry/volume.py:set_refresh_tape)
+            perm, uni = tape.draws(cur_epoch, vol.get_n_voxel(), dev)
         if warmup is not None and cur_epoch < warmup:
             cell = torch.arange(vol.get_n_voxel(), device=dev)
         else:
             if not hasattr(self, '_refresh_cache'):
                 self._refresh_cache, self._refresh_rng = {}, np.random.default_rng(12345)
             bits = vol.get_voxel_bitfield(flatten=True)
-            if bits.is_cuda and bits.is_contiguous() and bits.data_ptr() % 8 == 0 and n >= 16 and n & (n - 1) == 0:
+            if tape is not None:
+                cell, n_dev = select_refresh_cells(bits, vol.get_n_voxel(), self._refresh_cache, self._refresh_rng, perm=perm)
+            elif bits.is_cuda and bits.is_contiguous() and bits.data_ptr() % 8 == 0 and n >= 16 and n & (n - 1) == 0:
                 # cells (n / 4 uniform along the Z-curve + the first n / 4 occupied) and their jittered points in four small launches
                 # (arcn_refresh_cells_points; the torch formulation below is ~45)
                 from ....geometry.volume import mix_constants
@@ -130,7 +136,8 @@ class VolumeBound(BasicBound):
                 cell, n_dev = select_refresh_cells(bits, vol.get_n_voxel(), self._refresh_cache, self._refresh_rng)
         if pts is None:
             pts = vol.get_voxel_pts_by_voxel_idx(vol.convert_flatten_index_to_xyz_index(cell, n).float())
-            pts = pts + (torch.rand_like(pts) - 0.5) * vol.get_voxel_size(to_list=False)[None, :]
+            noise = (torch.rand_like(pts) if uni is None else uni[:pts.shape[0]]) - 0.5
+            pts = pts + noise * vol.get_voxel_size(to_list=False)[None, :]
         dt = vol.get_diag_len() / float(n_pts)
         opacity = get_est_opacity(dt, pts.contiguous())
         vol.update_opafield_by_flat_idx(cell, opacity, ema=self.get_optim_cfgs('ema_optim_decay'), n_dev=n_dev)

@@ -62,43 +62,32 @@ class FgModel(Base3dModel):
         return self.obj_bound.set_optim_cfgs(key, value)
 
     # ---- dynamic batch size (fg_model.py:100-130): factor = mean over steps of max_allowance / (valid samples + 1) ----
-    def reset_measurement(self):
-        self.render_cfgs['measured_batch_size'] = 0
-        self.render_cfgs['measured_count'] = 0
-        self._dynbs_pending = 0
+    # (trainer.DynamicBsMeter: the step's count is one device copy into a ring, the reference's double arithmetic runs when the factor
+    # is read; render_cfgs['measured_count'] / ['measured_batch_size'] stay readable like the reference's)
+    def _meter(self):
+        m = getattr(self, '_dynbs_meter', None)
+        if m is None or m.max_allowance != self.render_cfgs['max_allowance']:
+            from ..trainer.dynamic_bs import DynamicBsMeter
+            m = self._dynbs_meter = DynamicBsMeter(self.render_cfgs['max_allowance'])
+        return m
 
-    _DYNBS_RING = 4096
+    def _sync_measurement(self):
+        m = self._meter()
+        self.render_cfgs['measured_batch_size'], self.render_cfgs['measured_count'] = m.measured_batch_size, m.measured_count
+
+    def reset_measurement(self):
+        self._meter().reset()
+        self._sync_measurement()
 
     def adjust_dynamicbs_factor(self, mask_pts=None, n_valid=None):
-        """The reference adds max_allowance / (valid samples + 1) to a Python float every step (fg_model.py:105-116: one host read per
-        step).  Here the step's count is ONE device copy into a ring; get_dynamicbs_factor (every update_epoch steps) reads the ring back
-        and does the reference's double arithmetic on the exact integer counts."""
-        cap = self.render_cfgs['max_allowance']
-        if cap <= 0 or (mask_pts is None and n_valid is None):
+        if self.render_cfgs['max_allowance'] <= 0 or (mask_pts is None and n_valid is None):
             return
-        n = mask_pts.sum() if n_valid is None else n_valid
-        ring = getattr(self, '_dynbs_ring', None)
-        if ring is None or ring.device != n.device:
-            ring = self._dynbs_ring = torch.zeros(self._DYNBS_RING, dtype=torch.int64, device=n.device)
-            self._dynbs_pending = 0
-        if getattr(self, '_dynbs_pending', 0) >= self._DYNBS_RING:
-            self._drain_dynbs_ring()
-        ring[self._dynbs_pending].copy_(n.reshape(()))
-        self._dynbs_pending += 1
-        self.render_cfgs['measured_count'] += 1
-
-    def _drain_dynbs_ring(self):
-        k = getattr(self, '_dynbs_pending', 0)
-        if k:
-            cap = float(self.render_cfgs['max_allowance'])
-            self.render_cfgs['measured_batch_size'] += sum(cap / (float(v) + 1.0) for v in self._dynbs_ring[:k].tolist())
-            self._dynbs_pending = 0
+        self._meter().add(mask_pts.sum() if n_valid is None else n_valid)
+        self.render_cfgs['measured_count'] = self._meter().measured_count
 
     def get_dynamicbs_factor(self):
-        self._drain_dynbs_ring()
-        cnt = self.render_cfgs['measured_count']
-        f = float(self.render_cfgs['measured_batch_size']) / cnt if cnt > 0 else 1
-        self.reset_measurement()
+        f = self._meter().factor()
+        self._sync_measurement()
         return f
 
     # ---- bounds / samples ----------------------------------------------------------------------------

@@ -11,6 +11,7 @@ import os
 import torch
 from torch.autograd.function import once_differentiable
 
+from ..ops.autograd import direct_grad
 from ..pipeline import NgpConfig, NgpField, NgpPipeline
 from ..render.ray_helper import sample_pdf
 from ..utils.cfgs_utils import get_value_from_cfgs_field
@@ -57,8 +58,8 @@ class _PackedRenderFn(torch.autograd.Function):
         # The kernels ACCUMULATE into the gradient buffers they are given.  A parameter whose .grad is a view of FusedAdam's flat gradient
         # buffer (optim.FusedAdam.flatten marks it) gets its gradient added there directly: no zero-filled temporary, no AccumulateGrad
         # pass (48.8 MB written, read and added again for the table) - the node then returns None for that input.
-        direct = {k: (getattr(t, '_arcn_direct_grad', False) and t.grad is not None and t.grad.is_contiguous())
-                  for k, t in (('table', table), ('geo_w', geo_w), ('rad_w', rad_w))}
+        # (direct_grad asks the engine whether THIS run accumulates into .grad: torch.autograd.grad(...) must not touch it)
+        direct = {k: direct_grad(t) is not None for k, t in (('table', table), ('geo_w', geo_w), ('rad_w', rad_w))}
         g = {'table': (table.grad if direct['table'] else torch.zeros_like(table)).view(-1),
              'geo_w': geo_w.grad if direct['geo_w'] else torch.zeros_like(geo_w),
              'rad_w': rad_w.grad if direct['rad_w'] else torch.zeros_like(rad_w)}

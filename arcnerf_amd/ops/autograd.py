@@ -9,16 +9,36 @@ from torch.autograd.function import once_differentiable
 from . import functional as F
 
 
+def _accumulate_node(p):
+    """the AccumulateGrad node of a leaf parameter (cached on the tensor; autograd keeps one per leaf)"""
+    node = getattr(p, '_arcn_acc_node', None)
+    if node is None:
+        with torch.enable_grad():
+            node = p.view_as(p).grad_fn.next_functions[0][0]
+        p._arcn_acc_node = node
+    return node
+
+
 def direct_grad(p):
     """The gradient buffer a hand-written backward may ADD a parameter's gradient into directly, or None: the .grad of a parameter that
     lives in FusedAdam's flat buffers (optim.FusedAdam.flatten marks it `_arcn_direct_grad`).  A node that used it returns None for that
-    input: no zero-filled temporary, no AccumulateGrad pass over it (48.8 MB written, read and added again per table scatter)."""
+    input: no zero-filled temporary, no AccumulateGrad pass over it (48.8 MB written, read and added again per table scatter).
+
+    Only when the engine run that called us WOULD accumulate into that .grad: `loss.backward()` does, `torch.autograd.grad(geo, x)`
+    (BaseGeoNet.forward_with_grad: normals) does not and must leave every .grad alone, and `torch.autograd.grad(loss, [p])` wants the
+    gradient returned.  Asked from the engine itself (`_will_engine_execute_node` on the parameter's AccumulateGrad node; it raises for
+    a captured leaf) - to be called from inside a backward()."""
     if not getattr(p, '_arcn_direct_grad', False):     # (asked first: reading .grad of a non-leaf tensor warns)
         return None
     g = p.grad
-    if g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.shape == p.shape:
-        return g
-    return None
+    if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.shape != p.shape:
+        return None
+    try:
+        if not torch._C._will_engine_execute_node(_accumulate_node(p)):
+            return None
+    except (RuntimeError, AttributeError):
+        return None
+    return g
 
 
 class HashGridFn(torch.autograd.Function):

@@ -27,6 +27,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.zero_grad_on_step = zero_grad_on_step
         self.ema_in_param = bool(ema_in_param and ema_decay is not None)
         self.grad_scale = 1.0     # multiplies every gradient as it is read: 1 / world after a SUM all-reduce (DDP's average, no extra pass)
+        self.ema_n_step = None    # EMA.n_step when it differs from Adam's step count (set_ema_n_step: a resumed job); None = Adam's
         self._flat = None         # per param group: dict(params, grads, exp_avg, exp_avg_sq, ema, slots) once flatten() ran
 
     # ---- one flat buffer per parameter group --------------------------------------------------------------------------------------
@@ -42,7 +43,10 @@ class FusedAdam(torch.optim.Optimizer):
         to add (tensor hooks on such a parameter do not see that contribution; pass False when hooks must).  Returns self."""
         if direct_grads is None:
             import os
-            direct_grads = os.environ.get('ARCN_DIRECT_GRADS', '1') != '0'
+            direct_grads = getattr(self, '_direct_grads', None)
+            if direct_grads is None:
+                direct_grads = os.environ.get('ARCN_DIRECT_GRADS', '1') != '0'
+        self._direct_grads = bool(direct_grads)      # a later re-flatten (load_state_dict) keeps the caller's choice
         self._flat = []
         for group in self.param_groups:
             ps = [p for p in group['params'] if p.requires_grad]
@@ -81,6 +85,17 @@ class FusedAdam(torch.optim.Optimizer):
             self._flat.append(fb)
         return self
 
+    def set_ema_n_step(self, n_step):
+        """EMA.set_n_step (arcnerf/trainer/ema.py:25-27; the trainer passes progress.start_epoch, arcnerf_trainer.py:70): the running
+        average is de-biased with ITS step count, Adam's bias correction with the optimiser state's"""
+        self.ema_n_step = int(n_step)
+
+    def _next_ema_step(self):
+        if self.ema_n_step is None:
+            return None
+        self.ema_n_step += 1
+        return self.ema_n_step
+
     def flat_grads(self, group=0):
         """The flat gradient buffer of a parameter group (after flatten()): the tensor to all-reduce."""
         if self._flat is None:
@@ -104,6 +119,9 @@ class FusedAdam(torch.optim.Optimizer):
             self.flatten()
 
     def _step_flat(self):
+        if len(self.param_groups) != len(self._flat):
+            raise RuntimeError('FusedAdam (flat): a parameter group was added after flatten(); call flatten() again')
+        ema_step = self._next_ema_step()
         for group, fb in zip(self.param_groups, self._flat):
             for p, (o, n) in zip(fb['list'], fb['slots']):
                 if p.grad is None or p.grad.data_ptr() != fb['grads'].data_ptr() + 4 * o or p.data_ptr() != fb['params'].data_ptr() + 4 * o:
@@ -115,7 +133,7 @@ class FusedAdam(torch.optim.Optimizer):
             F.adam_ema_step(fb['params'], fb['grads'], fb['exp_avg'], fb['exp_avg_sq'], fb['params'] if self.ema_in_param else fb['ema'],
                             fb['step'], lr=group['lr'], betas=group['betas'], eps=group['eps'], weight_decay=group['weight_decay'],
                             ema_decay=self.ema_decay if self.ema_decay is not None else 0.0, grad_scale=self.grad_scale,
-                            zero_grad=self.zero_grad_on_step)
+                            ema_step=ema_step, zero_grad=self.zero_grad_on_step)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -126,6 +144,7 @@ class FusedAdam(torch.optim.Optimizer):
         if self._flat is not None:
             self._step_flat()
             return loss
+        ema_step = self._next_ema_step()
         for group in self.param_groups:
             for p in group['params']:
                 if p.grad is None:
@@ -145,5 +164,5 @@ class FusedAdam(torch.optim.Optimizer):
                 F.adam_ema_step(p, p.grad, st['exp_avg'], st['exp_avg_sq'], p if self.ema_in_param else st.get('ema'), st['step'], lr=group['lr'],
                                 betas=group['betas'], eps=group['eps'], weight_decay=group['weight_decay'],
                                 ema_decay=self.ema_decay if self.ema_decay is not None else 0.0, grad_scale=self.grad_scale,
-                                zero_grad=self.zero_grad_on_step)
+                                ema_step=ema_step, zero_grad=self.zero_grad_on_step)
         return loss

@@ -345,6 +345,7 @@ class NgpPipeline:
         # ARCN_EMA_ALIAS=0 keeps the separate copy
         self.ema = field.params if bool(int(os.environ.get('ARCN_EMA_ALIAS', '1'))) else field.params.clone()
         self.step_count = 0
+        self.ema_n_step = 0     # EMA.n_step (ema.py:14,25-27): equal to step_count unless a resumed job set it (set_ema_n_step)
         # occupancy (Volume bitfield/opafield, volume.py:741-760,959-969)
         ng = cfg.n_grid
         self._bitfield = torch.ones(ng ** 3, dtype=torch.bool, device=dev)
@@ -354,6 +355,11 @@ class NgpPipeline:
         self._pb = self._gb = None
         self.generation = 0
         self.set_bitfield(self.bitfield)
+
+    def set_ema_n_step(self, n_step):
+        """EMA.set_n_step (arcnerf/trainer/ema.py:25-27): the trainer calls it with progress.start_epoch (arcnerf_trainer.py:70), so the
+        running average of a resumed job is de-biased with the epoch count while Adam's own step count comes from its state"""
+        self.ema_n_step = int(n_step)
 
     def sample_count(self):
         """Valid samples of the batch marched LAST (with prefetch: the batch marched ahead on the sampling stream) as a python int.
@@ -453,11 +459,11 @@ class NgpPipeline:
             self._cache[key] = make()
         return self._cache[key]
 
-    def _select_cells(self, n_cells):
+    def _select_cells(self, n_cells, perm=None):
         from .geometry.volume import select_refresh_cells
         cache = self._cached('refresh_cache', dict)
         rng = self._cached('np_rng', lambda: np.random.default_rng(12345))
-        return select_refresh_cells(self.bitfield, n_cells, cache, rng)
+        return select_refresh_cells(self.bitfield, n_cells, cache, rng, perm=perm)
 
     # ---- forward --------------------------------------------------------------------------------
     def prefetch_samples(self, rays_o, rays_d, noise=False):
@@ -667,14 +673,30 @@ class NgpPipeline:
                                                     N.ptr(fld.view('table')), self.exp_avg[t_lo:].data_ptr(), self.exp_avg_sq[t_lo:].data_ptr(),
                                                     float(cfg.lr), float(cfg.betas[0]), float(cfg.betas[1]), float(cfg.eps),
                                                     float(cfg.weight_decay), -1.0 if cfg.ema_decay is None else float(cfg.ema_decay), 1.0, self.step_count + 1,
-                                                    self.step_count + 1, N.ptr(self.hash_ws), self.hash_ws.numel(), int(self._ws_clear), S,
+                                                    self.ema_n_step + 1, N.ptr(self.hash_ws), self.hash_ws.numel(), int(self._ws_clear), S,
                                                     n_dev.data_ptr(), N.C.byref(fused), st), 'hashgrid_bwd_lm_adam')
-                assert fused.value == self._fused_mask, (fused.value, self._fused_mask)
+                if fused.value != self._fused_mask:
+                    raise RuntimeError('hashgrid_bwd_lm_adam fused levels {:#x}, the optimiser plan expects {:#x}'.format(fused.value, self._fused_mask))
                 self._fused_step = True
                 self._tail_step = tail
                 self._ws_clear = False
+            elif getattr(self, '_level_sync', None) is not None:
+                # data-parallel step: the scatter in level groups, each group's slice of the flat gradient on the wire (asynchronous
+                # all-reduce on the communicator's stream) while the next group is scattered (distributed.LevelGroupedGradSync)
+                if tail:
+                    raise RuntimeError('the step tail was planned for a step whose scatter does not apply the optimiser')
+                sync = self._level_sync
+                for gi, (mask, _, _) in enumerate(sync.groups):
+                    N.check(L.arcn_hashgrid_bwd_lm_levels(N.ptr(b['xyz']), N.ptr(b['d_feat']), S, N.C.addressof(fld.grid_desc), N.ptr(self._g('table')),
+                                                          N.ptr(self.hash_ws), self.hash_ws.numel(), S, n_dev.data_ptr(), int(mask), st),
+                            'hashgrid_bwd_lm_levels')
+                    if gi == 0:
+                        self._join_reductions()      # the first slice carries the MLP weights' gradients
+                    sync.launch_group(gi, fld.grads)
+                self._ws_clear = False
             else:
-                assert not tail
+                if tail:
+                    raise RuntimeError('the step tail was planned for a step whose scatter does not apply the optimiser')
                 N.check(L.arcn_hashgrid_bwd_lm(N.ptr(b['xyz']), N.ptr(b['d_feat']), S, N.C.addressof(fld.grid_desc), N.ptr(self._g('table')),
                                                N.ptr(self.hash_ws), self.hash_ws.numel(), S, n_dev.data_ptr(), st), 'hashgrid_bwd_lm')
                 self._ws_clear = False
@@ -754,9 +776,11 @@ class NgpPipeline:
             self._occ_params_event = None
         if advance:
             self.step_count += 1
+            self.ema_n_step += 1
         if self._fused_step:        # the scatter of this step already updated its levels: the rest of the flat buffer
             self._fused_step = False
-            assert lo is None and hi is None and world_size == 1
+            if lo is not None or hi is not None or world_size != 1:
+                raise RuntimeError('the scatter of this step already applied the optimiser to its levels: single-GPU, whole-buffer step only')
             if self._tail_step:
                 self._tail_step = False
                 t, b = self._tail, self.buf
@@ -767,14 +791,14 @@ class NgpPipeline:
                                                    N.ptr(self.exp_avg), N.ptr(self.exp_avg_sq), N.ptr(self.ema), N.C.cast(flat, N.C.c_void_p),
                                                    len(t['runs']), float(cfg.lr), float(cfg.betas[0]), float(cfg.betas[1]), float(cfg.eps),
                                                    float(cfg.weight_decay), float(-1.0 if cfg.ema_decay is None else cfg.ema_decay), 1.0,
-                                                   self.step_count, self.step_count, N.ptr(self.hash_ws), t['clear_words'], N.stream()),
+                                                   self.step_count, self.ema_n_step, N.ptr(self.hash_ws), t['clear_words'], N.stream()),
                         'ngp_step_tail')
                 self._ws_clear = True
                 return
             if 1 < len(self._adam_rest) <= 4:      # the small levels in front of the fused ones and the MLP weights behind them: one launch
                 F.adam_ema_step_runs(fld.params, fld.grads, self.exp_avg, self.exp_avg_sq, self.ema, self._adam_rest, self.step_count, lr=cfg.lr,
                                      betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, ema_decay=cfg.ema_decay, grad_scale=1.0,
-                                     zero_grad=True)
+                                     ema_step=self.ema_n_step, zero_grad=True)
                 return
             slices = [slice(a, b_) for a, b_ in self._adam_rest]
         else:
@@ -782,7 +806,7 @@ class NgpPipeline:
         for sl in slices:
             F.adam_ema_step(fld.params[sl], fld.grads[sl], self.exp_avg[sl], self.exp_avg_sq[sl], self.ema[sl], self.step_count, lr=cfg.lr,
                             betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, ema_decay=cfg.ema_decay,
-                            grad_scale=1.0 / world_size, zero_grad=True)
+                            grad_scale=1.0 / world_size, ema_step=self.ema_n_step, zero_grad=True)
 
     def train_step(self, rays_o, rays_d, target_rgb, bkg_color=None, all_reduce=None, world_size=1, next_rays=None, grad_sync=None):
         """fwd + loss + bwd (+ one gradient all-reduce) + Adam/EMA.  Returns the loss tensor (device, no sync).
@@ -800,7 +824,19 @@ class NgpPipeline:
             loss, d_rgb = self.huber_grad(rgb, target_rgb)
         # one GPU: nothing has to be summed across ranks between the scatter and the optimiser, so the scatter applies it (see backward)
         self._fuse_next = grad_sync is None and all_reduce is None and world_size == 1
+        grouped = grad_sync is not None and hasattr(grad_sync, 'launch_group')
+        if grouped and not (self.level_major and self._pb is None and self._gb is None and self.defer_dw != 1):
+            raise RuntimeError('LevelGroupedGradSync needs the level-major scatter on the field\'s own flat buffers')
+        self._level_sync = grad_sync if grouped else None
         self.backward(rays_o, rays_d, d_rgb)
+        self._level_sync = None
+        if grouped:
+            # the groups are already on the wire (issued inside the backward, behind their part of the scatter)
+            self._prefetch_point(3)
+            for i, (lo, hi) in enumerate(grad_sync.segments):
+                grad_sync.wait(i)
+                self.optimizer_step(world_size, lo, hi, advance=(i == 0))
+            return loss
         if grad_sync is not None:
             # segmented all-reduce pipelined with the optimiser (distributed.PipelinedGradSync)
             grad_sync.launch(self.field.grads)
@@ -872,7 +908,11 @@ class NgpPipeline:
         n_dev = None
         vs = cfg.side / ng
         warm = cfg.epoch_optim_warmup is not None and cur_epoch < cfg.epoch_optim_warmup
-        if not warm and ng >= 16 and ng & (ng - 1) == 0 and self.bitfield.data_ptr() % 8 == 0:
+        from .geometry.volume import refresh_tape
+        tape, perm, uni = refresh_tape(), None, None
+        if tape is not None:     # the draws of a recorded run instead of the seeded generators (geometry/volume.py:set_refresh_tape)
+            perm, uni = tape.draws(cur_epoch, n_cells, dev)
+        if tape is None and not warm and ng >= 16 and ng & (ng - 1) == 0 and self.bitfield.data_ptr() % 8 == 0:
             # cells (n / 4 uniform + the first n / 4 occupied, both in flat order) and their jittered points by four small launches
             from .geometry.volume import mix_constants
             rng = self._cached('np_rng', lambda: np.random.default_rng(12345))
@@ -888,14 +928,14 @@ class NgpPipeline:
             if warm:
                 cell = self._cached('arange_cells', lambda: torch.arange(n_cells, device=dev))
             else:
-                cell, n_dev = self._select_cells(n_cells)
+                cell, n_dev = self._select_cells(n_cells, perm)
             ix = torch.div(cell, ng * ng, rounding_mode='floor')
             iy = torch.div(cell, ng, rounding_mode='floor') % ng
             iz = cell % ng
             idx3 = torch.stack([ix, iy, iz], -1).float()
             mn = self._cached('mn', lambda: torch.tensor(fld.min_xyz, device=dev))
             pts = idx3 * vs + 0.5 * vs + mn
-            pts = pts + (torch.rand_like(pts) - 0.5) * vs
+            pts = pts + ((torch.rand_like(pts) if uni is None else uni[:pts.shape[0]]) - 0.5) * vs
         n = pts.shape[0]
         if self._occ_scratch is None or self._occ_scratch['feat'].shape[0] < n:
             self._occ_scratch = {

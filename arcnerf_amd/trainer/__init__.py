@@ -1,0 +1,11 @@
+"""The step either side of the path: what the reference's trainer does around `model(feed_in)` every iteration -
+`step_optimize` (arcnerf/trainer/arcnerf_trainer.py:319-333), the dynamic batch size of its ray pipeline
+(arcnerf/trainer/pipeline.py:204-241) and the EMA it applies after the optimiser (arcnerf/trainer/ema.py).  Datasets, logging,
+checkpoint rotation and evaluation are the caller's (out of scope)."""
+from .dynamic_bs import DynamicBsMeter
+from .ema import EMA
+from .loss import AllLoss, HuberLoss, ImgLoss, build_loss
+from .pipeline import Pipeline
+from .step import step_optimize, train_epoch
+
+__all__ = ['AllLoss', 'DynamicBsMeter', 'EMA', 'HuberLoss', 'ImgLoss', 'build_loss', 'Pipeline', 'step_optimize', 'train_epoch']

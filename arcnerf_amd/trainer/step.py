@@ -1,0 +1,27 @@
+"""One iteration as the reference's trainer runs it (arcnerf/trainer/arcnerf_trainer.py:494-548 train_epoch, :319-333 step_optimize)."""
+import torch
+
+
+def step_optimize(model, feed_in, loss_factory, optimizer, ema=None, epoch=0, total_epoch=300000, get_progress=False, clip_value=0.0):
+    """output = model(feed_in); loss = loss_factory(feed_in, output); zero_grad; backward; [clip]; optimizer.step; ema.ema_step
+    loss_factory: callable (feed_in, output) -> {'sum': tensor, ...} like arcnerf.loss.AllLoss (or a tensor)."""
+    output = model(feed_in, get_progress=get_progress, cur_epoch=epoch, total_epoch=total_epoch)
+    loss = loss_factory(feed_in, output)
+    total = loss['sum'] if isinstance(loss, dict) else loss
+    if not getattr(optimizer, 'zero_grad_on_step', False):     # (FusedAdam clears the gradients while it reads them)
+        optimizer.zero_grad()
+    total.backward()
+    if clip_value > 0.0:
+        torch.nn.utils.clip_grad_value_(model.parameters(), clip_value)
+    optimizer.step()
+    if ema is not None:
+        ema.ema_step()
+    return output, loss
+
+
+def train_epoch(model, get_batch, loss_factory, optimizer, ema, pipeline, epoch, total_epoch=300000):
+    """train_epoch's order: model.optimize(epoch) (the bound's periodic refresh), the dynamic batch size, then the step.
+    get_batch(n_rays) -> feed_in dict."""
+    model.optimize(epoch)
+    n_rays = pipeline.fetch_step_update_dynamic_bs(epoch, model)
+    return step_optimize(model, get_batch(n_rays), loss_factory, optimizer, ema, epoch, total_epoch)

@@ -476,12 +476,30 @@ def main():
 
     timers = KernelTimers()
     instrument(timers)
-    all_reduce = (lambda t: D.allreduce_grads(t, world)) if use_dist else None
-    # gradient sync: ONE flat all-reduce (default) or K async segments pipelined with the optimiser (ARCN_GRAD_SEGMENTS=K).  Measured on a
-    # one-rank RCCL communicator (tools/ab_dist1.sh): four segments cost 0.04 ms of extra launches and stream hand-overs per step and can
-    # hide at most 3/4 of the 0.06 ms optimiser pass behind the ring - and each further collective adds its ring latency
-    n_seg = int(os.environ.get('ARCN_GRAD_SEGMENTS', '0'))
-    grad_sync = D.PipelinedGradSync(field.n_params, n_seg) if (use_dist and n_seg > 0) else None
+    # gradient sync of the N > 1 step.  Default: the scatter in two level groups, each group's slice on the wire while the
+    # next is scattered and the optimiser per group as it arrives (distributed.LevelGroupedGradSync; ARCN_GRAD_LEVEL_CUTS=8 / =11,5).
+    # ARCN_GRAD_SEGMENTS=0: ONE flat all-reduce after the backward (the A/B partner); =K: K equal async segments behind the backward.
+    seg_env = os.environ.get('ARCN_GRAD_SEGMENTS')
+    exposed_marks = []
+    all_reduce, grad_sync, sync_name = None, None, None
+    if use_dist:
+        if seg_env is None and pipe.level_major:
+            cuts = tuple(int(v) for v in os.environ.get('ARCN_GRAD_LEVEL_CUTS', '8').split(',') if v.strip())
+            grad_sync = D.LevelGroupedGradSync(field, cuts)
+            grad_sync.timing = True
+            spans = ['{}-{}'.format(min(l for l in range(32) if (m >> l) & 1), max(l for l in range(32) if (m >> l) & 1)) for m, _, _ in grad_sync.groups]
+            sync_name = 'level groups {} overlapped with the scatter, optimiser per group'.format(spans)
+        elif seg_env is not None and int(seg_env) > 0:
+            grad_sync = D.PipelinedGradSync(field.n_params, int(seg_env))
+            sync_name = '{} async segments pipelined with the optimiser pass'.format(len(grad_sync.segments))
+        else:
+            def all_reduce(t):      # the flat form: everything between these two events is exposed
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                D.allreduce_grads(t, world)
+                e1.record()
+                exposed_marks.append((e0, e1))
+            sync_name = 'one flat all-reduce'
     sample_log = torch.zeros(args.steps + args.warmup + 16, dtype=torch.int64, device=dev)
 
     def run(step_idx, epoch):
@@ -556,8 +574,15 @@ def main():
         dist.all_reduce(samples)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         rccl_extra = time_allreduce_alone(dist, field.grads)
-        rccl_extra['grad_sync'] = ('{} async segments pipelined with the optimiser pass'.format(len(grad_sync.segments)) if grad_sync is not None
-                                   else 'one flat all-reduce')
+        rccl_extra['grad_sync'] = sync_name
+        # the part of the exchange nothing hid: end of the last scatter group (flat form: of the backward) -> end of the last collective
+        if grad_sync is not None and hasattr(grad_sync, 'exposed_ms'):
+            ex = grad_sync.exposed_ms(last_n=args.steps)
+        else:
+            ex = [a.elapsed_time(b) for a, b in exposed_marks[-args.steps:]]
+        if ex:
+            rccl_extra['exposed_ms'] = sum(ex) / len(ex)
+            rccl_extra['exposed_ms_max'] = max(ex)
     total_samples = int(samples.item())
     wall = float(tmax.item())
     ksum = timers.summary()

@@ -142,3 +142,58 @@ def test_pipelined_gradient_sync_equals_flat_allreduce():
     assert np.array_equal(f0, s0) and np.array_equal(f1, s1) and np.array_equal(s0, s1)
     assert np.array_equal(u0, u1) and np.array_equal(u0, -0.1 * s0)
     assert len(segs0) == 4
+
+
+def _level_sync_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    D.init_from_env(backend='gloo')
+    from arcnerf_amd.pipeline import NgpConfig, NgpField
+    fld = NgpField(NgpConfig(hashmap_size=12), device='cpu', seed=0)
+    n = fld.n_params
+    g = torch.Generator().manual_seed(300 + rank)
+    grads = torch.randn(n, generator=g)
+    flat = grads.clone()
+    D.allreduce_grads(flat, world)
+    out = {}
+    for cuts in ((8,), (11, 5), (3,)):
+        sync = D.LevelGroupedGradSync(fld, cuts)
+        seg = grads.clone()
+        for gi in range(len(sync.groups)):           # what NgpPipeline.backward does: scatter group gi, then put its slice on the wire
+            sync.launch_group(gi, seg)
+        for gi in range(len(sync.groups)):
+            sync.wait(gi)
+        out[cuts] = (seg.numpy(), sync.groups)
+    ret[rank] = (flat.numpy(), out, n, list(fld.offsets))
+    dist.destroy_process_group()
+
+
+def test_level_grouped_gradient_sync_equals_flat_allreduce():
+    """distributed.LevelGroupedGradSync (the N > 1 step's default: the table gradient leaves in level groups while the scatter is still
+    running): the groups' level masks cover every level once, their slices tile the flat buffer exactly once (the MLP weights ride with
+    the first group), every slice starts 16-byte aligned, and the sums are bit-identical to ONE flat all-reduce on both ranks."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_level_sync_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(p.exitcode == 0 for p in procs)
+    f0, o0, n, offs = ret[0]
+    f1, o1, _, _ = ret[1]
+    assert np.array_equal(f0, f1)
+    for cuts in o0:
+        s0, groups = o0[cuts]
+        assert np.array_equal(s0, f0) and np.array_equal(o1[cuts][0], f0)
+        assert len(groups) == len(cuts) + 1
+        masks = [m for m, _, _ in groups]
+        assert sum(masks) == (1 << 16) - 1 and all(a & b == 0 for i, a in enumerate(masks) for b in masks[i + 1:])
+        spans = sorted((lo, hi) for _, lo, hi in groups)
+        assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert all(lo % 4 == 0 for lo, _ in spans)
+        assert groups[0][2] == n                                     # first group on the wire: the finest levels + the MLP weights
+        for m, lo, hi in groups:                                     # a group's slice = its levels' rows (+ the tail for the first)
+            first = min(l for l in range(16) if (m >> l) & 1)
+            assert lo == offs[first] * 2

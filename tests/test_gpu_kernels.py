@@ -957,6 +957,30 @@ def test_fused_adam_flat_buffer_equals_per_parameter_steps(F):
         oa.step()
 
 
+def test_direct_gradients_only_when_the_engine_accumulates(F):
+    """Parameters re-homed by FusedAdam.flatten() let hand-written backward nodes add dW straight into the flat gradient buffer - but only
+    in an engine run that WOULD accumulate into .grad: `torch.autograd.grad(y, x)` (BaseGeoNet.forward_with_grad, the normals
+    of a geometry net evaluated between steps) leaves the buffer untouched, `torch.autograd.grad(y, params)` returns the gradient, and
+    `backward()` puts the same gradient into the buffer; a non-default flatten(direct_grads=False) survives load_state_dict."""
+    from arcnerf_amd.models.base_modules.geo_rad_model.tcnn_fusedmlp_module import FusedLayers
+    from arcnerf_amd.optim import FusedAdam
+    torch.manual_seed(3)
+    layers = FusedLayers([32, 64, 16], 'ReLU', 'None').cuda()
+    opt = FusedAdam(layers.parameters(), lr=1e-2).flatten()
+    fg = opt.flat_grads()
+    x = torch.randn(1000, 32, device='cuda', requires_grad=True)
+    gx, = torch.autograd.grad(layers(x).sum(), x)
+    assert float(gx.abs().max()) > 0 and float(fg.abs().max()) == 0.0
+    gp, = torch.autograd.grad(layers(x).sum(), layers.params)
+    assert float(gp.abs().max()) > 0 and float(fg.abs().max()) == 0.0
+    layers(x).sum().backward()
+    assert layers.params.grad.data_ptr() == fg.data_ptr()
+    assert float((layers.params.grad - gp).abs().max()) <= 1e-5 * float(gp.abs().max())
+    opt2 = FusedAdam(FusedLayers([32, 64, 16], 'ReLU', 'None').cuda().parameters(), lr=1e-2).flatten(direct_grads=False)
+    opt2.load_state_dict(opt2.state_dict())
+    assert all(p._arcn_direct_grad is False for g in opt2.param_groups for p in g['params'])
+
+
 def test_first_order_only_nodes_refuse_a_second_differentiation(F):
     """the fused MLP has a hand-written first-order backward: asking autograd to differentiate THROUGH that backward (an sdf net on
     the fused kernels with normals by create_graph) must raise, not return gradients that silently ignore the path"""

@@ -411,6 +411,56 @@ def test_scatter_with_fused_optimiser_equals_scatter_then_adam():
     assert float(far) < 5e-3
 
 
+def test_fused_optimiser_takes_the_gradient_of_an_overflowed_bin():
+    """A bin of the binned scatter that runs over its capacity hands the excess records to dtable with direct atomics (emit_record).  The
+    consumer with the fused optimiser (arcn_hashgrid_bwd_lm_adam) must fold those rows into the gradient it applies and leave dtable
+    clear - round 3 dropped them.  max_res 4096 gives a DENSE level (71^3 rows, 44 chunks, one owner each => fused)
+    whose bins are slabs of space; a batch confined to one small blob puts nearly every record of that level into one bin.  The first
+    moment after one step (= 0.1 x the gradient) of the fused form equals the two-pass form's, on the overflowed level too; the gradient
+    buffer is clear afterwards in both."""
+    import os
+    import numpy as np
+    from arcnerf_amd.ops import functional as F
+    from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline, synthetic_rays
+    dev = torch.device('cuda:0')
+    cfg = NgpConfig(noise_std=0.0, lr=1e-2, max_res=4096)
+    ax = (np.arange(cfg.n_grid) + 0.5) / cfg.n_grid * 2 - 1
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing='ij')
+    blob = ((X - 0.31) ** 2 + (Y + 0.22) ** 2 + (Z - 0.13) ** 2) < 0.09 ** 2
+    res = {}
+    os.environ['ARCN_STEP_TAIL'] = '0'          # (the tail launch clears the status words with the bin counters)
+    try:
+        for fused in (True, False):
+            os.environ['ARCN_FUSE_ADAM'] = '1' if fused else '0'
+            fld = NgpField(cfg, device=dev, seed=3)
+            fld.view('table').mul_(1000.0)
+            pipe = NgpPipeline(fld, max_rays=8192, max_samples=1 << 19)
+            assert (pipe._adam_rest is not None) == fused
+            dense = [l for l in range(cfg.n_levels) if (fld.resolutions[l] + 1) ** 3 <= 2 ** cfg.hashmap_size]
+            lvl = dense[-1]
+            if fused:
+                assert (pipe._fused_mask >> lvl) & 1, 'the largest dense level is expected to be fused in this configuration'
+            pipe.set_bitfield(torch.from_numpy(blob))
+            g = torch.Generator().manual_seed(11)
+            o, d = synthetic_rays(8192, seed=40, device=dev)
+            pipe.train_step(o, d, torch.rand(8192, 3, generator=g).to(dev), bkg_color=torch.rand(8192, 3, generator=g).to(dev))
+            torch.cuda.synchronize()
+            assert int(pipe.n_dev.item()) > 20000
+            _, overflowed = F.hashgrid_bwd_status(fld.grid_desc, pipe.cap, pipe.hash_ws)
+            assert overflowed, 'the workload of this test must overflow a bin'
+            assert float(fld.grads.abs().max()) == 0.0
+            t_lo = fld._seg['table'][0]
+            a, b = t_lo + fld.offsets[lvl] * 2, t_lo + fld.offsets[lvl + 1] * 2
+            res[fused] = (pipe.exp_avg[a:b].clone(), pipe.exp_avg.clone())
+    finally:
+        os.environ.pop('ARCN_STEP_TAIL')
+        os.environ.pop('ARCN_FUSE_ADAM', None)
+    (la, fa), (lb, fb) = res[True], res[False]
+    assert float(lb.abs().max()) > 0
+    assert float((la - lb).abs().max()) <= 1e-4 * float(lb.abs().max())
+    assert float((fa - fb).abs().max()) <= 1e-4 * float(fb.abs().max())
+
+
 def test_step_tail_launch_equals_the_four_launches_it_replaces():
     """arcn_ngp_step_tail (two dW reductions with the optimiser applied by each element's owner + the optimiser on the remaining runs +
     the scatter's counter block cleared, ONE launch) against arcn_mlp_bwd_reduce x 2, arcn_adam_ema_step_runs and a memset on the same

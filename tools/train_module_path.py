@@ -48,7 +48,7 @@ for it in range(1, MAX_IT + 1):
     inputs = {'rays_o': o[None, :n_rays], 'rays_d': d[None, :n_rays], 'rays_r': torch.zeros(1, n_rays, 1, device=dev),
               'bkg_color': torch.ones(1, n_rays, 3, device=dev)}
     out = m(inputs, inference_only=False, cur_epoch=it)
-    loss = torch.nn.functional.huber_loss(out['rgb_coarse'][0], tgt[:n_rays], delta=0.1) * 3000.0
+    loss = torch.nn.functional.huber_loss(out['rgb_coarse'][0], tgt[:n_rays], delta=0.1) * (3000.0 / 0.1)   # the reference's Huber is torch's / delta (loss/img_loss.py:80-100)
     loss.backward()
     opt.step()
     m.optimize(cur_epoch=it)
