@@ -414,51 +414,54 @@ def test_scatter_with_fused_optimiser_equals_scatter_then_adam():
 def test_fused_optimiser_takes_the_gradient_of_an_overflowed_bin():
     """A bin of the binned scatter that runs over its capacity hands the excess records to dtable with direct atomics (emit_record).  The
     consumer with the fused optimiser (arcn_hashgrid_bwd_lm_adam) must fold those rows into the gradient it applies and leave dtable
-    clear - round 3 dropped them.  max_res 4096 gives a DENSE level (71^3 rows, 44 chunks, one owner each => fused)
-    whose bins are slabs of space; a batch confined to one small blob puts nearly every record of that level into one bin.  The first
-    moment after one step (= 0.1 x the gradient) of the fused form equals the two-pass form's, on the overflowed level too; the gradient
-    buffer is clear afterwards in both."""
-    import os
-    import numpy as np
+    clear - round 3 dropped them.  Every level's rows are hashed (the coarse ones modulo (res + 1)^3), so a bin only
+    overflows when a batch keeps hitting the SAME rows without forming runs the producer can merge: here the points alternate between
+    two fixed positions, i.e. each level's records go to 16 rows - every multi-bin level overflows.  One call through the C ABI:
+    the first moment the fused consumer leaves (0.1 x the gradient it applied) equals 0.1 x the gradient of arcn_hashgrid_bwd_lm on
+    every fused level, and the fused levels' rows of dtable are clear afterwards."""
+    import ctypes as C
+    from arcnerf_amd import _native as N
     from arcnerf_amd.ops import functional as F
-    from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline, synthetic_rays
+    from arcnerf_amd.pipeline import NgpConfig, NgpField
     dev = torch.device('cuda:0')
-    cfg = NgpConfig(noise_std=0.0, lr=1e-2, max_res=4096)
-    ax = (np.arange(cfg.n_grid) + 0.5) / cfg.n_grid * 2 - 1
-    X, Y, Z = np.meshgrid(ax, ax, ax, indexing='ij')
-    blob = ((X - 0.31) ** 2 + (Y + 0.22) ** 2 + (Z - 0.13) ** 2) < 0.09 ** 2
-    res = {}
-    os.environ['ARCN_STEP_TAIL'] = '0'          # (the tail launch clears the status words with the bin counters)
-    try:
-        for fused in (True, False):
-            os.environ['ARCN_FUSE_ADAM'] = '1' if fused else '0'
-            fld = NgpField(cfg, device=dev, seed=3)
-            fld.view('table').mul_(1000.0)
-            pipe = NgpPipeline(fld, max_rays=8192, max_samples=1 << 19)
-            assert (pipe._adam_rest is not None) == fused
-            dense = [l for l in range(cfg.n_levels) if (fld.resolutions[l] + 1) ** 3 <= 2 ** cfg.hashmap_size]
-            lvl = dense[-1]
-            if fused:
-                assert (pipe._fused_mask >> lvl) & 1, 'the largest dense level is expected to be fused in this configuration'
-            pipe.set_bitfield(torch.from_numpy(blob))
-            g = torch.Generator().manual_seed(11)
-            o, d = synthetic_rays(8192, seed=40, device=dev)
-            pipe.train_step(o, d, torch.rand(8192, 3, generator=g).to(dev), bkg_color=torch.rand(8192, 3, generator=g).to(dev))
-            torch.cuda.synchronize()
-            assert int(pipe.n_dev.item()) > 20000
-            _, overflowed = F.hashgrid_bwd_status(fld.grid_desc, pipe.cap, pipe.hash_ws)
-            assert overflowed, 'the workload of this test must overflow a bin'
-            assert float(fld.grads.abs().max()) == 0.0
-            t_lo = fld._seg['table'][0]
-            a, b = t_lo + fld.offsets[lvl] * 2, t_lo + fld.offsets[lvl + 1] * 2
-            res[fused] = (pipe.exp_avg[a:b].clone(), pipe.exp_avg.clone())
-    finally:
-        os.environ.pop('ARCN_STEP_TAIL')
-        os.environ.pop('ARCN_FUSE_ADAM', None)
-    (la, fa), (lb, fb) = res[True], res[False]
-    assert float(lb.abs().max()) > 0
-    assert float((la - lb).abs().max()) <= 1e-4 * float(lb.abs().max())
-    assert float((fa - fb).abs().max()) <= 1e-4 * float(fb.abs().max())
+    cfg = NgpConfig()
+    fld = NgpField(cfg, device=dev, seed=3)
+    L = N.lib()
+    S = 1 << 15
+    g = torch.Generator().manual_seed(21)
+    pts = torch.tensor([[0.3123, -0.2291, 0.1377], [-0.4411, 0.5172, -0.0923]])
+    xyz = pts[torch.arange(S) % 2].to(dev).contiguous()
+    d_feat = torch.randn(cfg.n_levels, S, 2, generator=g).to(dev).contiguous()        # level-major
+    desc = fld.grid_desc
+    n_table = fld.n_table
+    ws = F.hashgrid_bwd_workspace(desc, S, dev)
+    # two-pass form: the gradient
+    grad = torch.zeros(n_table, device=dev)
+    N.check(L.arcn_hashgrid_bwd_lm(N.ptr(xyz), N.ptr(d_feat), S, C.addressof(desc), N.ptr(grad), N.ptr(ws), ws.numel(), S, None, N.stream()), 'bwd_lm')
+    torch.cuda.synchronize()
+    _, overflowed = F.hashgrid_bwd_status(desc, S, ws)
+    assert overflowed, 'the workload of this test must overflow a bin'
+    # fused form from zero moments: m = (1 - beta1) g on the fused levels
+    dtable = torch.zeros(n_table, device=dev)
+    table = fld.view('table').clone()
+    m, v = torch.zeros(n_table, device=dev), torch.zeros(n_table, device=dev)
+    fused = C.c_uint32(0)
+    N.check(L.arcn_hashgrid_bwd_lm_adam(N.ptr(xyz), N.ptr(d_feat), S, C.addressof(desc), N.ptr(dtable), N.ptr(table), N.ptr(m), N.ptr(v), 1e-2, 0.9, 0.99,
+                                        1e-15, 0.0, 0.95, 1.0, 1, 1, N.ptr(ws), ws.numel(), 0, S, None, C.byref(fused), N.stream()), 'bwd_lm_adam')
+    torch.cuda.synchronize()
+    assert fused.value != 0
+    checked = 0
+    for l in range(cfg.n_levels):
+        a, b = fld.offsets[l] * 2, fld.offsets[l + 1] * 2
+        if (fused.value >> l) & 1:
+            ref = 0.1 * grad[a:b]
+            assert float(ref.abs().max()) > 0
+            assert float((m[a:b] - ref).abs().max()) <= 1e-4 * float(ref.abs().max()), l
+            assert float(dtable[a:b].abs().max()) == 0.0, l
+            checked += 1
+        else:
+            assert float((dtable[a:b] - grad[a:b]).abs().max()) <= 1e-4 * float(grad[a:b].abs().max()), l
+    assert checked >= 8
 
 
 def test_step_tail_launch_equals_the_four_launches_it_replaces():
