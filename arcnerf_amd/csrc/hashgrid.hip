@@ -1518,12 +1518,12 @@ ARCN_EXPORT int arcn_hashgrid_bwd_lm(const float *xyz, const float *dout_lm, int
 
 ARCN_EXPORT int arcn_hashgrid_bwd_lm_levels(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host,
                                             float *dtable, float *workspace, int64_t workspace_floats, int64_t n, const int32_t *n_ptr,
-                                            uint32_t level_mask, void *stream) {
+                                            uint32_t level_mask, int counters_clear, void *stream) {
     if (dout_stride < n) return einval("hashgrid_bwd_lm_levels: level stride smaller than n");
     if (!workspace) return einval("hashgrid_bwd_lm_levels: workspace required");
     if (level_mask == 0u) return ARCN_OK;
     return hashgrid_bwd_impl(xyz, nullptr, dout_lm, dout_stride, desc_host, dtable, nullptr, workspace, workspace_floats, n, n_ptr, stream,
-                             nullptr, nullptr, false, level_mask);
+                             nullptr, nullptr, counters_clear != 0, level_mask);
 }
 
 ARCN_EXPORT int64_t arcn_hashgrid_bwd_fusable_levels(const arcn_hashgrid_desc *desc_host, int64_t n) {

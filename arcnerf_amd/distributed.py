@@ -145,22 +145,22 @@ class LevelGroupedGradSync:
         if t_lo != 0:
             raise ValueError('LevelGroupedGradSync expects the table at the start of the flat buffer')
         cuts = sorted({int(b) for b in boundaries if 0 < int(b) < L}, reverse=True)
-        # a slice has to start 16-byte aligned for the optimiser kernel: move a boundary down to the next level that does
-        fixed = []
-        for b in cuts:
-            while b > 0 and (field.offsets[b] * Fq) % 4:
-                b -= 1
-            if b > 0 and b not in fixed:
-                fixed.append(b)
         levels_hi = L
-        self.groups = []
+        self.groups = []        # (level mask, lo, hi): what is scattered together and the slice that then goes on the wire
         hi = field.n_params
-        for b in fixed + [0]:
+        for b in cuts + [0]:
             mask = sum(1 << l for l in range(b, levels_hi))
             lo = field.offsets[b] * Fq
             self.groups.append((mask, lo, hi))
             hi, levels_hi = lo, b
-        self.segments = [(lo, hi) for _, lo, hi in self.groups]
+        # the optimiser's slices start 16-byte aligned: a group's pass begins at the next multiple of 4 floats, the (at most 3) elements in
+        # front of it are updated with the following group, whose wait comes later - they have arrived by then
+        self.segments = []
+        ahi = field.n_params
+        for _, lo, _ in self.groups:
+            alo = -(-lo // 4) * 4 if lo > 0 else 0
+            self.segments.append((alo, ahi))
+            ahi = alo
         self.works = [None] * len(self.groups)
         # timing=True: per step two events - the end of the last group's scatter (compute stream) and the end of the last collective
         # (a probe stream that only waits for it) - whose distance is the part of the exchange nothing hid (exposed_ms)
@@ -210,6 +210,17 @@ def broadcast_bitfield(bits, src=0, group=None):
     if _active(group):
         dist.broadcast(bits, src=src, group=group)
     return bits
+
+
+def broadcast_occupancy(opafield, bitfield, src=0, group=None):
+    """NgpPipeline.occupancy_sync: rank `src`'s opacity field and bool bitfield to every rank before a refreshed occupancy is applied
+    (the reference's DDP re-broadcasts these buffers on every forward, common/trainer/basic_trainer.py:198).  With the same refresh seed
+    and bit-identical parameters the ranks compute the same fields anyway; this makes it hold by construction."""
+    if _active(group):
+        dist.broadcast(opafield, src=src, group=group)
+        as_bytes = bitfield.view(torch.uint8) if bitfield.dtype == torch.bool else bitfield
+        dist.broadcast(as_bytes, src=src, group=group)
+    return opafield, bitfield
 
 
 def broadcast_params(flat_params, src=0, group=None):

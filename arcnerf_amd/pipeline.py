@@ -354,6 +354,7 @@ class NgpPipeline:
         self._occ_scratch = None
         self._pb = self._gb = None
         self.generation = 0
+        self.occupancy_sync = None      # callable(opafield, new_bitfield) run on the refresh stream before a refreshed bitfield is applied
         self.set_bitfield(self.bitfield)
 
     def set_ema_n_step(self, n_step):
@@ -688,7 +689,7 @@ class NgpPipeline:
                 sync = self._level_sync
                 for gi, (mask, _, _) in enumerate(sync.groups):
                     N.check(L.arcn_hashgrid_bwd_lm_levels(N.ptr(b['xyz']), N.ptr(b['d_feat']), S, N.C.addressof(fld.grid_desc), N.ptr(self._g('table')),
-                                                          N.ptr(self.hash_ws), self.hash_ws.numel(), S, n_dev.data_ptr(), int(mask), st),
+                                                          N.ptr(self.hash_ws), self.hash_ws.numel(), S, n_dev.data_ptr(), int(mask), int(gi > 0), st),
                             'hashgrid_bwd_lm_levels')
                     if gi == 0:
                         self._join_reductions()      # the first slice carries the MLP weights' gradients
@@ -966,6 +967,11 @@ class NgpPipeline:
         new_bits = torch.empty_like(self.bitfield)
         F.update_bitfield_by_opafield(self.opafield, new_bits, cfg.opa_thres)
         if apply:
+            if self.occupancy_sync is not None:
+                # data-parallel training: every rank marches rank 0's occupancy, like the buffers DistributedDataParallel re-broadcasts
+                # on every forward (common/trainer/basic_trainer.py:198, broadcast_buffers) - here once per APPLIED refresh, on the
+                # refresh's own stream (distributed.broadcast_occupancy: the opacity field + the bool bitfield, 10 MiB at 128^3)
+                self.occupancy_sync(self._opafield, new_bits)
             self.set_bitfield(new_bits)
 
 

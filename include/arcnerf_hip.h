@@ -248,10 +248,11 @@ int arcn_hashgrid_bwd_lm(const float *xyz, const float *dout_lm, int64_t dout_st
 /* arcn_hashgrid_bwd_lm restricted to the levels of `level_mask` (bit l = level l): the data-parallel step scatters the table gradient in
  * level GROUPS so that a group's all-reduce (its contiguous slice of the flat gradient buffer) is on the wire while the next group is
  * still being scattered - what DistributedDataParallel's buckets do for the reference (common/trainer/basic_trainer.py:197-198).  The
- * calls of one step must cover every level once; each call clears the bin counters, so calls on one workspace are stream-ordered. */
+ * calls of one step must cover every level once, stream-ordered on one workspace.  counters_clear = 0: the call clears the block of bin
+ * counters first (the first group of a step); 1: a previous group of the same step did (levels use disjoint counters). */
 int arcn_hashgrid_bwd_lm_levels(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host,
                                 float *dtable, float *workspace, int64_t workspace_floats, int64_t n, const int32_t *n_ptr,
-                                uint32_t level_mask, void *stream);
+                                uint32_t level_mask, int counters_clear, void *stream);
 /* arcn_hashgrid_bwd_lm with the OPTIMISER fused into the scatter's consumer (single-GPU training step; with several ranks the summed
  * gradient only exists after the all-reduce, so they keep the two calls): the owner workgroup of a table chunk holds the chunk's complete
  * gradient in LDS and applies arcn_adam_ema_step's update (torch.optim.Adam + EMA.ema_step written back, arcnerf/trainer/ema.py:29-43) to

@@ -162,7 +162,7 @@ def _level_sync_worker(rank, world, port, ret):
             sync.launch_group(gi, seg)
         for gi in range(len(sync.groups)):
             sync.wait(gi)
-        out[cuts] = (seg.numpy(), sync.groups)
+        out[cuts] = (seg.numpy(), sync.groups, sync.segments)
     ret[rank] = (flat.numpy(), out, n, list(fld.offsets))
     dist.destroy_process_group()
 
@@ -170,7 +170,7 @@ def _level_sync_worker(rank, world, port, ret):
 def test_level_grouped_gradient_sync_equals_flat_allreduce():
     """distributed.LevelGroupedGradSync (the N > 1 step's default: the table gradient leaves in level groups while the scatter is still
     running): the groups' level masks cover every level once, their slices tile the flat buffer exactly once (the MLP weights ride with
-    the first group), every slice starts 16-byte aligned, and the sums are bit-identical to ONE flat all-reduce on both ranks."""
+    the first group), the optimiser's slices start 16-byte aligned, and the sums are bit-identical to ONE flat all-reduce on both ranks."""
     world = 2
     ctx = mp.get_context('spawn')
     ret = ctx.Manager().dict()
@@ -185,14 +185,17 @@ def test_level_grouped_gradient_sync_equals_flat_allreduce():
     f1, o1, _, _ = ret[1]
     assert np.array_equal(f0, f1)
     for cuts in o0:
-        s0, groups = o0[cuts]
+        s0, groups, segments = o0[cuts]
         assert np.array_equal(s0, f0) and np.array_equal(o1[cuts][0], f0)
         assert len(groups) == len(cuts) + 1
         masks = [m for m, _, _ in groups]
         assert sum(masks) == (1 << 16) - 1 and all(a & b == 0 for i, a in enumerate(masks) for b in masks[i + 1:])
         spans = sorted((lo, hi) for _, lo, hi in groups)
         assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
-        assert all(lo % 4 == 0 for lo, _ in spans)
+        # the optimiser's slices: 16-byte aligned starts, tiling the buffer too, each one inside what has arrived when its group was waited for
+        segs = sorted(segments)
+        assert segs[0][0] == 0 and segs[-1][1] == n and all(a[1] == b[0] for a, b in zip(segs, segs[1:])) and all(lo % 4 == 0 for lo, _ in segs)
+        assert all(alo >= lo and alo - lo < 4 for (alo, _), (_, lo, _) in zip(segments, groups))
         assert groups[0][2] == n                                     # first group on the wire: the finest levels + the MLP weights
         for m, lo, hi in groups:                                     # a group's slice = its levels' rows (+ the tail for the first)
             first = min(l for l in range(16) if (m >> l) & 1)

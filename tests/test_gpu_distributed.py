@@ -24,9 +24,10 @@ def _free_port():
     return p
 
 
-def _setup(dev):
+def _setup(dev, mode='flat'):
     from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline, synthetic_bitfield, synthetic_rays
-    cfg = NgpConfig(n_levels=8, hashmap_size=15, max_res=512, n_grid=64, n_sample=512, noise_std=0.0, lr=1e-2)
+    # (the level-grouped exchange belongs to the level-major step: 16 levels x 2 features, like the config)
+    cfg = NgpConfig(n_levels=16 if mode == 'levels' else 8, hashmap_size=15, max_res=512, n_grid=64, n_sample=512, noise_std=0.0, lr=1e-2)
     fld = NgpField(cfg, device=dev, seed=3)
     fld.view('table').mul_(1000.0)
     pipe = NgpPipeline(fld, max_rays=2048, max_samples=1 << 17)
@@ -45,9 +46,13 @@ def _worker(rank, world, port, mode, path):
     D.init_from_env(backend='gloo')
     dev = torch.device('cuda:0')
     torch.cuda.set_device(dev)
-    cfg, fld, pipe, batches = _setup(dev)
+    cfg, fld, pipe, batches = _setup(dev, mode)
     D.broadcast_params(fld.params, src=0)
     sync = D.PipelinedGradSync(fld.n_params, 4) if mode == 'pipelined' else None
+    if mode == 'levels':
+        assert pipe.level_major
+        sync = D.LevelGroupedGradSync(fld, (11, 5))
+        assert len(sync.groups) == 3
     reduced = []
 
     def flat_all_reduce(t):
@@ -78,7 +83,7 @@ def _rank_rng_state(pipe, rank):
     return F.Pcg32Host(9121 + rank).state
 
 
-@pytest.mark.parametrize('mode', ['flat', 'pipelined'])
+@pytest.mark.parametrize('mode', ['flat', 'pipelined', 'levels'])
 def test_two_ranks_train_like_one_process_accumulating_both_shards(mode):
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
@@ -99,7 +104,7 @@ def test_two_ranks_train_like_one_process_accumulating_both_shards(mode):
     # single-process replay: both shards' gradients accumulated into the flat buffer, one optimiser pass with grad_scale 1/world
     from arcnerf_amd import distributed as D
     dev = torch.device('cuda:0')
-    cfg, fld, pipe, batches = _setup(dev)
+    cfg, fld, pipe, batches = _setup(dev, mode)
     p0 = fld.params.cpu().numpy().copy()
     for step, (o, d, tgt, bkg) in enumerate(batches):
         fld.grads.zero_()
@@ -123,6 +128,52 @@ def test_two_ranks_train_like_one_process_accumulating_both_shards(mode):
     # Adam (eps 1e-15) turns the summation-order noise of near-zero gradient entries into full-size steps of either sign: parameters
     # agree to a fraction of a percent of the distance they travelled, not bit for bit
     assert np.abs(got[0] - ref).max() <= 1e-2 * moved, (np.abs(got[0] - ref).max(), moved)
+
+
+def _ddp_worker(rank, world, port, path):
+    import sys
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    import train_ddp
+    from arcnerf_amd import distributed as D
+    from arcnerf_amd.pipeline import NgpConfig
+    D.init_from_env(backend='gloo')
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    cfg = NgpConfig(hashmap_size=14, max_res=512, n_grid=32, n_sample=512, noise_std=0.0, lr=1e-2, epoch_optim=8, epoch_optim_warmup=16, white_bkg=True)
+    out = train_ddp.train(cfg, dev, rank, world, steps=40, n_rays=1024, n_batches=4, sync='levels', balance=True, max_samples=1 << 17)
+    torch.save(out, path + '.rank{}.pt'.format(rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_train_with_applied_refreshes_and_balanced_shards():
+    """tools/train_ddp.train on two ranks for 40 steps: the level-grouped gradient exchange, shards balanced by the per-ray sample counts of
+    a batch's previous visit (distributed.balanced_shards), and FIVE applied occupancy refreshes (epoch_optim 8: one in the warm-up, four
+    after it) each followed by the broadcast of rank 0's fields (distributed.broadcast_occupancy) - what DDP's broadcast_buffers does
+    for the reference (common/trainer/basic_trainer.py:198).  Both ranks end with bit-identical parameters, bitfields and opacity fields;
+    the occupancy was pruned; the shards tile the batch and moved away from the equal split once counts were known."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    world = 2
+    ctx = mp.get_context('spawn')
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'ddp')
+        procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, path)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(600)
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        a, b = [torch.load(path + '.rank{}.pt'.format(r)) for r in range(world)]
+    assert a['steps'] == b['steps'] == 40
+    assert torch.equal(a['params'], b['params']) and torch.equal(a['bitfield'], b['bitfield']) and torch.equal(a['opafield'], b['opafield'])
+    occ = float(a['bitfield'].float().mean())
+    assert 0.0 < occ < 0.9, occ
+    for (lo0, hi0), (lo1, hi1) in zip(a['shards'], b['shards']):
+        assert lo0 == 0 and hi0 == lo1 and hi1 == 1024
+    assert all(s == (0, 512) for s in a['shards'][:4]) and any(s != (0, 512) for s in a['shards'][4:])
 
 
 def _run_bench(extra, timeout=900):
@@ -177,7 +228,7 @@ def test_bench_refuses_more_rccl_ranks_than_gpus():
     assert r.returncode != 0 and 'one GPU per rank' in r.stderr
 
 
-@pytest.mark.parametrize('config,segments', [('ngp', '4'), ('ngp', '0'), ('neus_ngp_multivol', '4')])
+@pytest.mark.parametrize('config,segments', [('ngp', None), ('ngp', '4'), ('ngp', '0'), ('neus_ngp_multivol', '4')])
 def test_bench_under_torchrun_on_a_one_rank_rccl_communicator(config, segments):
     """The driver's N > 1 command form (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
     bench.py --gpus N`) with N = 1 and ARCN_DIST_FORCE=1: the process group is built on RCCL (backend "nccl"), and the gradient
@@ -194,7 +245,10 @@ def test_bench_under_torchrun_on_a_one_rank_rccl_communicator(config, segments):
     env = dict(os.environ)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'ARCN_DIST_BACKEND'):
         env.pop(k, None)
-    env.update({'ARCN_DIST_FORCE': '1', 'ARCN_GRAD_SEGMENTS': segments, 'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
+    env.update({'ARCN_DIST_FORCE': '1', 'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
+    env.pop('ARCN_GRAD_SEGMENTS', None)
+    if segments is not None:        # None: the default of the N > 1 step, the level-grouped exchange overlapped with the scatter
+        env['ARCN_GRAD_SEGMENTS'] = segments
     sock = socket.socket()
     sock.bind(('127.0.0.1', 0))
     port = sock.getsockname()[1]
@@ -213,6 +267,8 @@ def test_bench_under_torchrun_on_a_one_rank_rccl_communicator(config, segments):
     assert out['n_gpus'] == 1 and rc is not None and rc['backend'] == 'nccl' and rc['world_size_seen'] == 1
     assert rc['allreduce_alone_ms'] > 0 and out['value'] > 0
     if config == 'ngp':
-        assert rc['collectives_per_step'] == (1 if segments == '0' else int(segments))
+        assert rc['collectives_per_step'] == (2 if segments is None else (1 if segments == '0' else int(segments)))
+        if segments in (None, '0'):
+            assert rc['exposed_ms'] >= 0.0 and ('level groups' in rc['grad_sync']) == (segments is None)
         # a one-rank SUM is the identity: the step trains like the single-GPU step (two-pass optimiser form)
         assert 1e8 < out['value'] < 1e9
