@@ -425,6 +425,9 @@ template <int F, bool LM, bool PAIR, int NT = 0>
 __global__ void __launch_bounds__(256)
 hashgrid_fwd_bal_kernel(const float *__restrict__ xyz, const float *__restrict__ table, GridParams g, FwdPlan plan,
                         float *__restrict__ out, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
+#ifdef ARCN_GATHER_PRIO
+    __builtin_amdgcn_s_setprio(ARCN_GATHER_PRIO);   // experiment: the gather's waves ahead of a co-resident marcher's on the SIMD's issue port
+#endif
     const int64_t cnt = dev_count(n, n_ptr);
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;

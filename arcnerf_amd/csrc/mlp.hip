@@ -23,6 +23,10 @@
 #include "common.hpp"
 #include "adam.hpp"
 
+#ifndef ARCN_MLP_PREFETCH
+#define ARCN_MLP_PREFETCH 1   // forward nets: a tile's input requested one tile ahead (0: loaded where it is consumed)
+#endif
+
 namespace arcn {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -465,20 +469,44 @@ mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
     constexpr bool FRAG = XMODE != 0;  // saved activations in tile order (store_tiles_frag): the level-major / concat entry points
     const int act_h = AH >= 0 ? AH : P.act_hidden, act_o = AO >= 0 ? AO : P.act_out;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    for (int l = 0; l < NL; ++l) stage_fragments<false>(lds + P.lds_off[l], weights + P.w_off[l], P.dims[l + 1], P.dims[l]);
-    __syncthreads();
     const int64_t cnt = dev_count(n, n_ptr);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
     constexpr int SPW = 16 * NT;
     const int64_t n_tiles = ceil_div_dev(cnt, (int64_t)SPW * 4);
+    auto load_x = [&](f4 (&dst)[4][NT], int64_t s0) {
+        if (XMODE == 2) load_tiles_cat<NT>(dst, x, cat, s0, cnt, g, j, true);
+        else if (XMODE == 1) load_tiles_lm2<T0, NT>(dst, x, x_stride, s0, cnt, g, j);
+        else load_tiles_fast<T0, NT>(dst, x, P.dims[0], s0, cnt, g, j);
+    };
+#if ARCN_MLP_PREFETCH
+    // A workgroup lives for 2 - 3 tiles, and a tile is ~1.5 us of MFMA work behind ~2 us of load latency (the concat input is a
+    // dependent chain: ray id -> that ray's harmonics): the input of a tile is requested one tile AHEAD - the first one before the
+    // weights are staged - so the loads travel under the previous tile's products instead of in front of this one's
+    f4 hn[4][NT];
+    {
+        const int64_t s0 = (int64_t)blockIdx.x * SPW * 4 + (int64_t)wave * SPW;
+        if (blockIdx.x < n_tiles && s0 < cnt) load_x(hn, s0);
+    }
+#endif
+    for (int l = 0; l < NL; ++l) stage_fragments<false>(lds + P.lds_off[l], weights + P.w_off[l], P.dims[l + 1], P.dims[l]);
+    __syncthreads();
     const float *w0 = lds + P.lds_off[0], *w1 = lds + P.lds_off[1], *w2 = lds + P.lds_off[NL - 1];
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t s0 = tile * SPW * 4 + (int64_t)wave * SPW;
         if (s0 >= cnt) continue;
         f4 h[4][NT], o[4][NT];
-        if (XMODE == 2) load_tiles_cat<NT>(h, x, cat, s0, cnt, g, j, true);
-        else if (XMODE == 1) load_tiles_lm2<T0, NT>(h, x, x_stride, s0, cnt, g, j);
-        else load_tiles_fast<T0, NT>(h, x, P.dims[0], s0, cnt, g, j);
+#if ARCN_MLP_PREFETCH
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) h[t][nt] = hn[t][nt];
+        {
+            const int64_t tn = tile + gridDim.x, sn = tn * SPW * 4 + (int64_t)wave * SPW;
+            if (tn < n_tiles && sn < cnt) load_x(hn, sn);
+        }
+#else
+        load_x(h, s0);
+#endif
         auto zero = [&](f4 (&a)[4][NT]) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)

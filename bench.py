@@ -295,8 +295,16 @@ def bench_module(args, name, emit=True):
             return r
         Fn.pack_dense_samples_end = counting_pack
 
+    # the drop-in NGP step as ONE HIP-graph launch (trainer.GraphedTrainStep; ARCN_MODULE_GRAPH=0: every kernel issued eagerly)
+    graphed = None
+    if name == 'ngp_module' and not use_dist and os.environ.get('ARCN_MODULE_GRAPH', '1') != '0':
+        from arcnerf_amd.trainer import GraphedTrainStep
+        graphed = GraphedTrainStep(m, lambda inp, out: {'sum': loss_of(out, inp)}, opt)
+
     def step(i):
         inp = pool[i % len(pool)]
+        if graphed is not None:
+            return graphed({k: v for k, v in inp.items()}, 20000 + i)[1]['sum']
         out = m({k: v for k, v in inp.items()}, inference_only=False, cur_epoch=20000 + i)
         loss = loss_of(out, inp)
         opt.zero_grad()
@@ -324,8 +332,9 @@ def bench_module(args, name, emit=True):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if spec['evals'] is None:
-        k = int(getattr(fg, '_dynbs_pending', 0))
-        n_eval[0] = int(sum(fg._dynbs_ring[:k].tolist()) / max(1, args.steps)) if k else n_rays
+        meter = fg._meter()
+        k = int(meter._pending)
+        n_eval[0] = int(sum(meter._ring[:k].tolist()) / max(1, args.steps)) if k else n_rays
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -385,7 +394,10 @@ def bench_module(args, name, emit=True):
            'config': {'workload': '{} ({}), {} rays/step/GPU, {} net evaluations/step/GPU, module path build_model({}) + FusedAdam'.format(
                name, spec['desc'], n_rays, evals_per_step, spec['yaml']), 'rays_per_step_per_gpu': n_rays,
                'samples_per_step_per_gpu': evals_per_step, 'n_params': flat_numel, 'parallelism': 'ray-sharded dp{}'.format(world),
-               'chunk_pts': int(m.get_chunk_pts()), 'occupancy': args.occupancy, 'bkg_occupancy': bkg_occ},
+               'chunk_pts': int(m.get_chunk_pts()), 'occupancy': args.occupancy, 'bkg_occupancy': bkg_occ,
+               'graph_host_ms_per_replay': ({k: round(v / max(1, graphed.replays) * 1e3, 4) for k, v in graphed.host_s.items()} if graphed is not None else None),
+               'launch': ('one HIP-graph replay per step (trainer.GraphedTrainStep, {} replays in this run)'.format(graphed.replays) if graphed is not None
+                          else 'every kernel issued eagerly')},
            'rccl': dist_report(dist, world, LAUNCH, flat_grads.numel() * 4, 1, per_rank, rccl_extra),
            'roofline': roofline, 'cpu_baseline': cpu}
     if emit:
@@ -624,13 +636,14 @@ def main():
     hash_kernels = {'hashgrid_fwd': BYTES_HASH_FWD, 'hashgrid_bwd': BYTES_HASH_BWD}
     dom = max(hash_kernels, key=lambda k: ksum.get(k, 0.0))
     # hashgrid_fwd is also launched by the occupancy refresh (different size): use the per-step average of its launches
-    traffic, traffic_stale = None, None
+    traffic, traffic_stale, step_bytes, mfma_busy = None, None, None, None
     pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(pmc):
         try:
             import hashlib
             rec = json.load(open(pmc))
             traffic = rec.get(dom)
+            step_bytes, mfma_busy = rec.get('_step_total_bytes'), rec.get('_mfma_busy')
             # the counters were collected on a particular version of the kernels: say so when the sources have moved since
             shas = rec.get('_source_sha256')
             if shas is None:
@@ -641,21 +654,33 @@ def main():
         except Exception:
             traffic, traffic_stale = None, None
     dur_s = ksum[dom] * 1e-3
+    # achieved = the kernel's ALGORITHMIC bytes per launch (2188 B per sample for the scatter, 1164 for the gather) / its
+    # average launch duration.  On one GPU the scatter's consumer also applies the optimiser to the table levels it owns
+    # (arcn_hashgrid_bwd_lm_adam: parameter + two moments in and out once, 24 B per fused parameter): those bytes are real traffic of the
+    # same launch but not part of 8(d)'s figure - they are reported beside it (`with_fused_optimizer`), not in `frac`.
     ach = hash_kernels[dom] * s_per_launch / dur_s
-    # one GPU: the scatter's consumer also applies the optimiser to the table levels it owns (arcn_hashgrid_bwd_lm_adam): that launch
-    # moves parameter + two moments in and out once, 24 B per fused parameter, on top of the scatter's own bytes
     n_fused = 0
+    fused_side = None
     if dom == 'hashgrid_bwd' and world == 1 and getattr(pipe, '_adam_rest', None) is not None:
         n_fused = field.n_params - sum(b_ - a_ for a_, b_ in pipe._adam_rest)
-        ach = (hash_kernels[dom] * s_per_launch + 24.0 * n_fused) / dur_s
-    roofline = {'kernel': dom if not n_fused else 'hashgrid_bwd (binned scatter) + Adam / EMA of the table levels its chunk owners hold (arcn_hashgrid_bwd_lm_adam)', 'bound': 'hbm', 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+        ach2 = (hash_kernels[dom] * s_per_launch + 24.0 * n_fused) / dur_s
+        fused_side = {'what': 'the same launch also runs Adam + EMA on the table levels its chunk owners hold: 24 B per fused parameter', 'fused_optimizer_params': n_fused,
+                      'algorithmic_bytes_per_launch': {'scatter': hash_kernels[dom] * s_per_launch, 'fused_optimizer': 24.0 * n_fused},
+                      'achieved': ach2 / 1e9, 'frac': ach2 / HBM_PEAK}
+    step_s = wall / args.steps
+    roofline = {'kernel': dom if not n_fused else 'hashgrid_bwd (binned scatter; its consumer also applies the optimiser to the levels it owns, see with_fused_optimizer)', 'bound': 'hbm', 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                 'frac': ach / HBM_PEAK, 'traffic': traffic, 'avg_launch_ms': ksum[dom], 'launches_timed': n_launch.get(dom), 'launches_in_region': args.steps,
+                'algorithmic_bytes_per_sample': hash_kernels[dom],
                 # PMC counters cannot be collected inside a timed run: the figure is the per-launch HBM bytes of the committed
                 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/profile_round.sh)
                 'traffic_source': 'profiles/pmc_traffic.json' if traffic is not None else None, 'traffic_stale': traffic_stale,
-                'algorithmic_bytes_per_launch': {'scatter': hash_kernels[dom] * s_per_launch, 'fused_optimizer': 24.0 * n_fused},
-                'fused_optimizer_params': n_fused,
-                'frac_scatter_bytes_only': hash_kernels[dom] * s_per_launch / dur_s / HBM_PEAK}
+                'traffic_frac': (traffic / dur_s / HBM_PEAK) if traffic else None,
+                'with_fused_optimizer': fused_side,
+                # the WHOLE step against the HBM roof: counter bytes of every kernel of a step / the step time.  Nothing in this step is
+                # bandwidth-bound (the gather waits on L2-miss latency, the scatter on instruction issue and LDS atomics, the nets on MFMA
+                # issue): this is the number that says so
+                'hbm_step': {'bytes_per_step': step_bytes, 'frac': (step_bytes / step_s / HBM_PEAK) if step_bytes else None, 'source': 'profiles/pmc_traffic.json:_step_total_bytes', 'stale': traffic_stale},
+                'mfma_busy': {'per_kernel': mfma_busy, 'of': 'exact-f32 MFMA issue slots (v_mfma_f32_16x16x4_f32, 157 TFLOP/s)', 'source': 'profiles/pmc_traffic.json:_mfma_busy', 'stale': traffic_stale} if mfma_busy else None}
 
     # The hash LOOKUP on its own (north_star names it): besides the algorithmic HBM accounting, the bound this gather actually
     # sits on.  Every 8-byte corner read of a hashed level drags one 128-byte line from the XCD's L2 into the CU's L1

@@ -58,6 +58,25 @@ def main(root):
                          'hbm_bytes_per_launch': 2.0 * fr + wb}
         out[entry] = 2.0 * fr + wb
     out['_detail'] = detail
+    # the whole step: every kernel's per-launch median (training-sized launches), summed - what `roofline.hbm_step` divides by the step time
+    # (kernels launched more than once per step with one name - fills - are counted once: a slight under-estimate of small launches)
+    total = 0.0
+    names = set(rd) | set(wr)
+    for name in names:
+        total += 2.0 * (median_train(rd[name]) * 1024.0 if name in rd else 0.0) + (median_train(wr[name]) * 1024.0 if name in wr else 0.0)
+    out['_step_total_bytes'] = total
+    # MFMA utilisation of the net kernels, when the third pass exists (pmc_MFMA: SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE):
+    # busy SIMD-cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); the busy cycles are 32 per v_mfma_f32_16x16x4_f32 exactly
+    mf = os.path.join(root, 'pmc_MFMA')
+    if os.path.isdir(mf):
+        busy, act = per_kernel(mf, 'SQ_VALU_MFMA_BUSY_CYCLES'), per_kernel(mf, 'GRBM_GUI_ACTIVE')
+        mm = {}
+        for name in busy:
+            if 'mlp_' in name and name in act:
+                b, a = median_train(busy[name]), median_train(act[name])
+                if a > 0:
+                    mm[name.split('(')[0].replace('void arcn::', '')] = b / (a / 8.0 * 1024.0)
+        out['_mfma_busy'] = mm
     # which kernels were measured: bench.py compares these with the sources it runs on and reports `traffic_stale` on a mismatch
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'arcnerf_amd', 'csrc')
     out['_source_sha256'] = {f: hashlib.sha256(open(os.path.join(csrc, f), 'rb').read()).hexdigest() for f in ('hashgrid.hip', 'mlp.hip', 'optim.hip', 'adam.hpp', 'common.hpp')}

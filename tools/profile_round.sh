@@ -14,6 +14,8 @@ for C in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --pmc $C -d $OUT/pmc_$C -o $TAG --output-format csv -- \
         python $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-other-configs > /dev/null 2> $OUT/pmc_$C.log
 done
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_MFMA -o $TAG --output-format csv -- \
+    python $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-other-configs > /dev/null 2> $OUT/pmc_MFMA.log
 cd $ROOT
 python tools/pmc_traffic.py $OUT > $OUT/pmc_traffic.json
 ls -R $OUT | head -40
