@@ -13,7 +13,7 @@ HEADER = os.path.join(ROOT, 'include', 'arcnerf_hip.h')
 LIB_PATH = os.path.join(_HERE, 'lib', 'libarcnerf_hip.so')
 
 MAX_LEVELS = 32
-ACT = {None: 0, 'none': 0, 'relu': 1, 'sigmoid': 2, 'truncexp': 3, 'exponential': 3, 'softplus': 4}
+ACT = {None: 0, 'none': 0, 'relu': 1, 'sigmoid': 2, 'truncexp': 3, 'exponential': 3, 'softplus': 4, 'squareplus': 5, 'sine': 6}
 
 
 class HashGridDesc(C.Structure):

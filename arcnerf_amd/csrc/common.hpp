@@ -95,6 +95,8 @@ __device__ __forceinline__ float act_fwd(float v, int act, float beta) {
     case ARCN_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
     case ARCN_ACT_TRUNCEXP: return expf(v);
     case ARCN_ACT_SOFTPLUS: { float bv = beta * v; return bv > 20.f ? v : log1pf(expf(bv)) / beta; }
+    case ARCN_ACT_SQUAREPLUS: { float X = 10.f * v; return 0.5f * (X + sqrtf(X * X + 4.f)) / 10.f; }
+    case ARCN_ACT_SINE: return sinf(v);
     default: return v;
     }
 }
@@ -106,7 +108,21 @@ __device__ __forceinline__ float act_grad(float v, float y, int act, float beta)
     case ARCN_ACT_SIGMOID: return y * (1.0f - y);
     case ARCN_ACT_TRUNCEXP: { float c = v < -15.f ? -15.f : (v > 15.f ? 15.f : v); return expf(c); }
     case ARCN_ACT_SOFTPLUS: { float bv = beta * v; return bv > 20.f ? 1.f : 1.0f / (1.0f + expf(-bv)); }
+    case ARCN_ACT_SQUAREPLUS: { float Y = 10.f * y, t = Y * Y; return t / (t + 1.f); }
+    case ARCN_ACT_SINE: return cosf(v);
     default: return 1.f;
+    }
+}
+
+// second derivative wrt the pre-activation (the derivative of act_grad as a function of v)
+__device__ __forceinline__ float act_grad2(float v, int act, float beta) {
+    switch (act) {
+    case ARCN_ACT_SIGMOID: { float y = 1.0f / (1.0f + expf(-v)); return y * (1.0f - y) * (1.0f - 2.0f * y); }
+    case ARCN_ACT_TRUNCEXP: return (v > -15.f && v < 15.f) ? expf(v) : 0.f;
+    case ARCN_ACT_SOFTPLUS: { float bv = beta * v; if (bv > 20.f) return 0.f; float sg = 1.0f / (1.0f + expf(-bv)); return beta * sg * (1.0f - sg); }
+    case ARCN_ACT_SQUAREPLUS: { float X = 10.f * v, Y = 0.5f * (X + sqrtf(X * X + 4.f)), t = Y * Y + 1.f; return 10.f * 2.f * Y * Y * Y / (t * t * t); }
+    case ARCN_ACT_SINE: return -sinf(v);
+    default: return 0.f;      // identity, ReLU
     }
 }
 

@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const float *__restrict__ 
                                                       const float *__restrict__ dy, float *__restrict__ dx, int64_t n,
                                                       int act, float beta) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        dx[i] = dy[i] * act_grad(x[i], y ? y[i] : 0.f, act, beta);
+        dx[i] = dy[i] * act_grad(x[i], y ? y[i] : act_fwd(x[i], act, beta), act, beta);
 }
 
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -538,6 +538,23 @@ ARCN_EXPORT int arcn_sh_fwd(const float *dirs, int degree, int include_input, fl
     if (!dirs || !out || degree < 1 || degree > 5) return einval("sh_fwd: degree must be 1..5");
     hipLaunchKernelGGL(sh_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), dirs, degree, include_input, out, n);
     return check_launch("sh_fwd");
+}
+
+__global__ void __launch_bounds__(256) act_bwd_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ g,
+                                                          float *__restrict__ ddy, float *__restrict__ d2x, int64_t n, int act, float beta) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i], gi = g[i];
+        if (ddy) ddy[i] = gi * act_grad(v, act_fwd(v, act, beta), act, beta);
+        if (d2x) d2x[i] = gi * dy[i] * act_grad2(v, act, beta);
+    }
+}
+
+ARCN_EXPORT int arcn_act_bwd_bwd(const float *x, const float *dy, const float *g, float *ddy, float *d2x, int64_t n, int act, float beta,
+                                 void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!x || !dy || !g || (!ddy && !d2x)) return einval("act_bwd_bwd: missing argument");
+    hipLaunchKernelGGL(act_bwd_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, dy, g, ddy, d2x, n, act, beta);
+    return check_launch("act_bwd_bwd");
 }
 
 ARCN_EXPORT int arcn_act_fwd(const float *x, float *y, int64_t n, int act, float beta, void *stream) {

@@ -274,71 +274,13 @@ hashgrid_bwd_bwd_kernel(const float *__restrict__ xyz, const float *__restrict__
     }
 }
 
-// ---- forward, XCD-affine ---------------------------------------------------------------------------------------------------
+// ---- forward, XCD-affine: the idea (round 1; the kernel that implements it is the cost-balanced one below) -------------------------
 // MI355X: 8 XCDs, each with a private 4 MiB L2; one fine level of the table is exactly 4 MiB.  The kernel above lets every
 // XCD touch all 16 levels (48.8 MB), so fine-level gathers miss L2 and are served by the Infinity Cache.  Here a workgroup
 // handles ONE level for 256 consecutive samples and the level is chosen from the workgroup's position in the dispatch order
 // (workgroup b runs on XCD b % 8 - observed, used for speed only, any placement is correct): XCD x works through level x for
 // all its tiles, then level L-1-x, so at any time an XCD's L2 mostly holds a single level.
 // LM: level-major output out[(l * n_cap + s) * F + f] (coalesced stores); otherwise the usual row-major (n, L*F).
-struct LmPlan {
-    int32_t levels[8][4];   // up to 4 levels per XCD slot (-1 = none)
-    int32_t tiles;          // workgroups per (XCD, level): each walks the 256-sample tiles with this stride
-};
-
-template <int F, bool LM>
-__global__ void __launch_bounds__(256)
-hashgrid_fwd_xcd_kernel(const float *__restrict__ xyz, const float *__restrict__ table, GridParams g, LmPlan plan,
-                        float *__restrict__ out, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
-    const int64_t cnt = dev_count(n, n_ptr);
-    const int xcd = blockIdx.x & 7;
-    const int j = blockIdx.x >> 3;  // position inside this XCD's queue
-    const int li = j / plan.tiles, slot = j - li * plan.tiles;
-    const int l = plan.levels[xcd][li];
-    if (l < 0) return;
-    const LevelParams lp = g.lv[l];
-    // plan.tiles workgroups per (XCD, level) walk the 256-sample tiles: the grid does not grow with the buffer capacity (a
-    // capacity-sized grid dispatched 3 empty workgroups for every busy one)
-    for (int64_t s = (int64_t)slot * 256 + threadIdx.x; s < cnt; s += (int64_t)plan.tiles * 256) {
-    const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
-    const Cell cell = locate(p, g, lp);
-    float acc[F];
-#pragma unroll
-    for (int f = 0; f < F; ++f) acc[f] = 0.f;
-    if (cell.valid) {
-        uint32_t rows[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) rows[q] = hash_row(cell.c[0] + ((q >> 1) & 1), cell.c[1] + (q & 1), cell.c[2] + (q >> 2), lp);
-        float vals[8][F];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float *src = table + ((int64_t)rows[q] + lp.offset) * F;
-            if (F == 2) {
-                float2 t2 = *reinterpret_cast<const float2 *>(src);
-                vals[q][0] = t2.x;
-                vals[q][1 % F] = t2.y;
-            } else {
-#pragma unroll
-                for (int f = 0; f < F; ++f) vals[q][f] = src[f];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
-            const float wt = ((ox ? cell.w[0] : 1.0f - cell.w[0]) * (oy ? cell.w[1] : 1.0f - cell.w[1])) * (oz ? cell.w[2] : 1.0f - cell.w[2]);
-#pragma unroll
-            for (int f = 0; f < F; ++f) { float a = vals[q][f] * wt; acc[f] = acc[f] + a; }
-        }
-    }
-    float *o = LM ? out + ((int64_t)l * n_cap + s) * F : out + (s * g.L + l) * F;
-    if (F == 2) *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1 % F]);
-    else {
-#pragma unroll
-        for (int f = 0; f < F; ++f) o[f] = acc[f];
-    }
-    }
-}
-
 // ---- forward, XCD-affine, cost-balanced (v2) ----------------------------------------------------------------------------------
 // Measured per-level cost of the kernel above on ONE XCD (2.6e5 samples, tools/exp_gather.py --levels): 18 us for the coarse
 // power-of-two levels (an instruction floor: six correctly rounded fp32 divisions and eight hashes per lane), 28 us for the
@@ -421,13 +363,10 @@ static int level_lowbits(const LevelParams &lp) {
     return (1ull << kb) > (uint64_t)lp.size ? 0 : kb;
 }
 
-template <int F, bool LM, bool PAIR, int NT = 0>
+template <int F, bool LM, bool PAIR>
 __global__ void __launch_bounds__(256)
 hashgrid_fwd_bal_kernel(const float *__restrict__ xyz, const float *__restrict__ table, GridParams g, FwdPlan plan,
                         float *__restrict__ out, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
-#ifdef ARCN_GATHER_PRIO
-    __builtin_amdgcn_s_setprio(ARCN_GATHER_PRIO);   // experiment: the gather's waves ahead of a co-resident marcher's on the SIMD's issue port
-#endif
     const int64_t cnt = dev_count(n, n_ptr);
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;
@@ -447,11 +386,7 @@ hashgrid_fwd_bal_kernel(const float *__restrict__ xyz, const float *__restrict__
     for (int64_t t = t0 + slot; t < t1; t += nslot) {
         const int64_t s = (t << 8) + threadIdx.x;
         if (s >= cnt) break;
-        // NT: positions and features stream through once per level; marked non-temporal they do not displace the level's table
-        // lines from the XCD's L2 (the table of a fine level is exactly the size of that L2)
-        const float p[3] = {(NT & 1) ? __builtin_nontemporal_load(xyz + 3 * s) : xyz[3 * s],
-                            (NT & 1) ? __builtin_nontemporal_load(xyz + 3 * s + 1) : xyz[3 * s + 1],
-                            (NT & 1) ? __builtin_nontemporal_load(xyz + 3 * s + 2) : xyz[3 * s + 2]};
+        const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
         float nn[3], v[3];
         bool amb = false;
 #pragma unroll
@@ -540,13 +475,7 @@ hashgrid_fwd_bal_kernel(const float *__restrict__ xyz, const float *__restrict__
         }
         float *o = LM ? out + ((int64_t)l * n_cap + s) * F : out + (s * g.L + l) * F;
         if (F == 2) {
-            if (NT & 2) {
-                typedef float v2f __attribute__((ext_vector_type(2)));
-                v2f val = {acc[0], acc[1 % F]};
-                __builtin_nontemporal_store(val, reinterpret_cast<v2f *>(o));
-            } else {
-                *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1 % F]);
-            }
+            *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1 % F]);
         } else {
 #pragma unroll
             for (int f = 0; f < F; ++f) o[f] = acc[f];
@@ -590,13 +519,12 @@ struct BinPlan {
     int32_t bin_first[ARCN_MAX_LEVELS];       // index of the level's first counter
     int32_t cap[ARCN_MAX_LEVELS];             // records per bin
     int64_t rec_first[ARCN_MAX_LEVELS];       // first record of the level's bin 0
-    uint32_t lock_levels;                     // consumer, bit l: row locks (else float atomics)
-    uint32_t active_levels;                   // debugging aid (ARCN_SCATTER_LEVELS): levels that are processed at all
+    uint32_t lock_levels;                     // consumer, bit l: exclusive row updates - 64-bit compare-and-swap (F = 2) or a row bit lock (F = 1) - else float atomics
+    uint32_t active_levels;                   // levels this launch processes (arcn_hashgrid_bwd_lm_levels: a level group)
     uint32_t pair_levels;                     // hashed power-of-two levels with more than one chunk: <= 4 pair records per sample
     uint32_t nosplit_levels;                  // chunk rows > res on a hashed level: both rows of an x pair ALWAYS share the chunk
     int32_t n_bins;
     int32_t chunk_floats;                     // LDS accumulator floats per workgroup (rows per chunk * F)
-    int32_t use_cas;                          // consumer, F = 2: 64-bit compare-and-swap on the row instead of the bit lock
     int32_t det;                              // ARCN_DETERMINISTIC=1: order-independent fixed-point accumulation (see scatter_accum_kernel)
     int32_t aux_first;                        // counters[aux_first] = bits of max |dout| (det), counters[aux_first + 1] = a bin overflowed
     int8_t lowbits[ARCN_MAX_LEVELS];          // corner_rows' kb of the level (shared 64-bit modulo on the non-power-of-two levels)
@@ -1082,7 +1010,7 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
             const bool have = i0 != 0xffffu;
             const float wx = __uint_as_float(r.y), a0 = __uint_as_float(r.z), a1 = __uint_as_float(r.w);
             const float wl = 1.0f - wx;
-            if (locked && F == 2 && plan.use_cas) {
+            if (locked && F == 2) {
                 // lock-free: read the 8-byte row, add, 64-bit compare-and-swap; two LDS operations per row update when nobody
                 // interferes (the bit lock needs four: or, read, write, and).  The comparison is bitwise, so NaNs and signed
                 // zeros are handled; a lost race just retries with the value the swap returned.
@@ -1096,7 +1024,7 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
                         unsigned long long *cell = rows + tgt;
                         // first guess: the row is still zero (true for its first update, and then ONE operation does it); a wrong
                         // guess costs what the explicit read would have cost, the failed swap returns the current value
-                        unsigned long long seen = plan.use_cas == 2 ? *cell : 0ull;
+                        unsigned long long seen = 0ull;
                         while (true) {
                             float2 v = __builtin_bit_cast(float2, seen);
                             v.x += va;
@@ -1279,25 +1207,16 @@ static int build_params(const arcn_hashgrid_desc *d, GridParams &g) {
 
 // Owner chunks, bins and dispatch order of the v3 backward for a capacity of n samples.
 static int build_bin_plan(const GridParams &g, int64_t n, BinPlan &plan) {
-    static const uint32_t lock_override = [] {
-        const char *e = getenv("ARCN_SCATTER_LOCK");
-        return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffffffu;
-    }();
     // 8192-row owner chunks (64 KiB of LDS, two consumer workgroups per CU): 704 owners on 512 slots instead of 352 on 256 -
     // step 0.680 -> 0.664 ms against the 16384-row chunks, scatter 0.213 -> 0.196 ms per launch (A/B in one session)
     constexpr int chunk_floats = 16384;
     static_assert(chunk_floats <= kChunkFloats, "owner chunk larger than the consumer's LDS accumulator");
     plan.chunk_floats = chunk_floats;
     { static const int det = [] { const char *e = getenv("ARCN_DETERMINISTIC"); return e ? atoi(e) : 0; }(); plan.det = det ? 1 : 0; }
-    { static const int cas = [] { const char *e = getenv("ARCN_SCATTER_CAS"); return e ? atoi(e) : 1; }(); plan.use_cas = cas; }
     const int rows_cap = chunk_floats / g.F;
     int bins = 0;
     int64_t recs = 0;
-    static const uint32_t active = [] {
-        const char *e = getenv("ARCN_SCATTER_LEVELS");
-        return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffffffu;
-    }();
-    plan.active_levels = active;
+    plan.active_levels = 0xffffffffu;      // (arcn_hashgrid_bwd_lm_levels narrows it to a level group)
     plan.lock_levels = 0u;
     plan.pair_levels = 0u;
     plan.nosplit_levels = 0u;
@@ -1312,7 +1231,7 @@ static int build_bin_plan(const GridParams &g, int64_t n, BinPlan &plan) {
         const bool paired = g.lv[l].mask != 0 && nc > 1;
         if (paired) plan.pair_levels |= 1u << l;
         if (g.lv[l].mask != 0 && ((int64_t)1 << shift) > g.lv[l].res) plan.nosplit_levels |= 1u << l;
-        if (paired && ((lock_override >> l) & 1u)) plan.lock_levels |= 1u << l;
+        if (paired) plan.lock_levels |= 1u << l;
         const bool locked = (plan.lock_levels >> l) & 1u;
         const int64_t mean = (paired ? 4 : 8) * n / nc;
         int64_t cap = nc == 1 ? 8 * n : 2 * mean + 1024;
@@ -1726,50 +1645,18 @@ ARCN_EXPORT int arcn_hashgrid_fwd_xcd(const float *xyz, const float *table, cons
     int rc = build_params(desc_host, g);
     if (rc) return rc;
     if (g.F > 2) return einval("hashgrid_fwd_xcd: n_feat 1 or 2");
-    static const int variant = [] { const char *e = getenv("ARCN_GATHER_VARIANT"); return e ? atoi(e) : 3; }();
-    if (variant == 0) {
-    LmPlan plan;
-    for (int x = 0; x < 8; ++x) for (int k = 0; k < 4; ++k) plan.levels[x][k] = -1;
-    int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // pair a coarse (cache friendly) level with a fine one on every XCD: slot = min(l, L-1-l) mod 8
-    for (int l = 0; l < g.L; ++l) {
-        const int m = l < g.L - 1 - l ? l : g.L - 1 - l;
-        const int x = m & 7;
-        if (fill[x] >= 4) return einval("hashgrid_fwd_xcd: too many levels");
-        plan.levels[x][fill[x]++] = l;
-    }
-    int per = 0;
-    for (int x = 0; x < 8; ++x) per = fill[x] > per ? fill[x] : per;
-    static const int xcd_tiles = 512;
-    int64_t tiles = ceil_div<int64_t>(n, 256);
-    if (tiles > xcd_tiles) tiles = xcd_tiles;
-    plan.tiles = (int)tiles;
-    dim3 grid((unsigned)(8 * per * plan.tiles));
-#define ARCN_XCD(F_, LM_) hipLaunchKernelGGL((hashgrid_fwd_xcd_kernel<F_, LM_>), grid, dim3(256), 0, as_stream(stream), xyz, table, g, plan, out, n_cap, n, n_ptr)
-    if (g.F == 1) { if (level_major) ARCN_XCD(1, true); else ARCN_XCD(1, false); }
-    else { if (level_major) ARCN_XCD(2, true); else ARCN_XCD(2, false); }
-#undef ARCN_XCD
-    } else {
     FwdPlan plan;
     int wg_per_xcd = 0;
     rc = build_fwd_plan(g, n, plan, wg_per_xcd);
     if (rc) return rc;
-    {   // calibration aid: only one XCD's queue runs
+    {   // calibration aid (tools/pmc_gather.sh): only one XCD's queue runs
         static const int only = [] { const char *e = getenv("ARCN_GATHER_ONLY_XCD"); return e ? atoi(e) : -1; }();
         if (only >= 0) for (int x = 0; x < 8; ++x) if (x != only) plan.n_seg[x] = 0;
     }
     dim3 grid((unsigned)(8 * wg_per_xcd));
 #define ARCN_BAL(F_, LM_, P_) hipLaunchKernelGGL((hashgrid_fwd_bal_kernel<F_, LM_, P_>), grid, dim3(256), 0, as_stream(stream), xyz, table, g, plan, out, n_cap, n, n_ptr)
-    const bool pair = (variant & 1) != 0;
     if (g.F == 1) { if (level_major) ARCN_BAL(1, true, false); else ARCN_BAL(1, false, false); }
-    else if (pair && (variant & 12) && level_major) {   // experiments: non-temporal position loads (4) / feature stores (8)
-        if ((variant & 12) == 4) hipLaunchKernelGGL((hashgrid_fwd_bal_kernel<2, true, true, 1>), grid, dim3(256), 0, as_stream(stream), xyz, table, g, plan, out, n_cap, n, n_ptr);
-        else if ((variant & 12) == 8) hipLaunchKernelGGL((hashgrid_fwd_bal_kernel<2, true, true, 2>), grid, dim3(256), 0, as_stream(stream), xyz, table, g, plan, out, n_cap, n, n_ptr);
-        else hipLaunchKernelGGL((hashgrid_fwd_bal_kernel<2, true, true, 3>), grid, dim3(256), 0, as_stream(stream), xyz, table, g, plan, out, n_cap, n, n_ptr);
-    }
-    else if (pair) { if (level_major) ARCN_BAL(2, true, true); else ARCN_BAL(2, false, true); }
-    else { if (level_major) ARCN_BAL(2, true, false); else ARCN_BAL(2, false, false); }
+    else { if (level_major) ARCN_BAL(2, true, true); else ARCN_BAL(2, false, true); }
 #undef ARCN_BAL
-    }
     return check_launch("hashgrid_fwd_xcd");
 }

@@ -23,10 +23,6 @@
 #include "common.hpp"
 #include "adam.hpp"
 
-#ifndef ARCN_MLP_PREFETCH
-#define ARCN_MLP_PREFETCH 1   // forward nets: a tile's input requested one tile ahead (0: loaded where it is consumed)
-#endif
-
 namespace arcn {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -52,6 +48,8 @@ __device__ __forceinline__ float act_grad_from_y(float y, int act, float beta) {
     case ARCN_ACT_SIGMOID: return y * (1.0f - y);
     case ARCN_ACT_TRUNCEXP: { float c = y < 3.0590232e-7f ? 3.0590232e-7f : (y > 3269017.4f ? 3269017.4f : y); return c; }
     case ARCN_ACT_SOFTPLUS: return 1.0f - expf(-beta * y);
+    case ARCN_ACT_SQUAREPLUS: { float Y = 10.f * y, t = Y * Y; return t / (t + 1.f); }
+    // (ARCN_ACT_SINE has no derivative in terms of y: build_mlp_params refuses it for the backward)
     default: return 1.f;
     }
 }
@@ -478,16 +476,6 @@ mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
         else if (XMODE == 1) load_tiles_lm2<T0, NT>(dst, x, x_stride, s0, cnt, g, j);
         else load_tiles_fast<T0, NT>(dst, x, P.dims[0], s0, cnt, g, j);
     };
-#if ARCN_MLP_PREFETCH
-    // A workgroup lives for 2 - 3 tiles, and a tile is ~1.5 us of MFMA work behind ~2 us of load latency (the concat input is a
-    // dependent chain: ray id -> that ray's harmonics): the input of a tile is requested one tile AHEAD - the first one before the
-    // weights are staged - so the loads travel under the previous tile's products instead of in front of this one's
-    f4 hn[4][NT];
-    {
-        const int64_t s0 = (int64_t)blockIdx.x * SPW * 4 + (int64_t)wave * SPW;
-        if (blockIdx.x < n_tiles && s0 < cnt) load_x(hn, s0);
-    }
-#endif
     for (int l = 0; l < NL; ++l) stage_fragments<false>(lds + P.lds_off[l], weights + P.w_off[l], P.dims[l + 1], P.dims[l]);
     __syncthreads();
     const float *w0 = lds + P.lds_off[0], *w1 = lds + P.lds_off[1], *w2 = lds + P.lds_off[NL - 1];
@@ -495,18 +483,9 @@ mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
         const int64_t s0 = tile * SPW * 4 + (int64_t)wave * SPW;
         if (s0 >= cnt) continue;
         f4 h[4][NT], o[4][NT];
-#if ARCN_MLP_PREFETCH
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) h[t][nt] = hn[t][nt];
-        {
-            const int64_t tn = tile + gridDim.x, sn = tn * SPW * 4 + (int64_t)wave * SPW;
-            if (tn < n_tiles && sn < cnt) load_x(hn, sn);
-        }
-#else
+        // (requesting a tile's input one tile ahead - the first before the weights are staged - was built and measured: no change of
+        // the forward nets or the step in three alternations, +18 VGPRs; round 4)
         load_x(h, s0);
-#endif
         auto zero = [&](f4 (&a)[4][NT]) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
@@ -1085,7 +1064,10 @@ static int build_mlp_params(const arcn_mlp_desc *d, MlpParams &P, bool transpose
         boff += d->dims[l + 1];
         loff += tiles16(d->dims[l]) * tiles16(d->dims[l + 1]) * kFragTile;
     }
-    (void)transposed;
+    // transposed = a backward pass: it differentiates the activations through the POST-activations the forward saved, which Sine does not
+    // allow (cos(x) is not a function of sin(x)); tiny-cuda-nn's fused MLP has the same restriction
+    if (transposed && (d->act_hidden == ARCN_ACT_SINE || d->act_out == ARCN_ACT_SINE))
+        return einval("mlp_bwd: the Sine activation needs the pre-activations, which the fused MLP does not keep (forward / inference only)");
     P.act_hidden = d->act_hidden;
     P.act_out = d->act_out;
     P.has_bias = d->has_bias;
@@ -1161,14 +1143,13 @@ static int mlp_fwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
     const size_t lds_bytes = sizeof(float) * (size_t)lds_floats;
     if (lds_bytes > 144 * 1024) return einval("mlp_fwd: network too large for the LDS-resident fused kernel");
     static const int fwd_nt = 2;  // 4 waves/SIMD beat 2 with wider tiles
-    static const int fixed_ok = getenv("ARCN_MLP_FIXED_FWD") ? atoi(getenv("ARCN_MLP_FIXED_FWD")) : 1;
     MlpCat cat = {};
     if (cat_in) cat = *cat_in;
     if (x_stride || cat_in) {   // these entry points save the hidden activations in tile order: full 16-wide tiles only
         for (int l = 1; l < P.n_layers; ++l)
             if (P.dims[l] & 15) return einval("mlp_fwd_lm / mlp_fwd_cat: hidden widths must be multiples of 16");
     }
-    if ((fixed_ok || x_stride || cat_in) && !P.has_bias && (P.n_layers == 2 || P.n_layers == 3) && md <= 64) {
+    if (!P.has_bias && (P.n_layers == 2 || P.n_layers == 3) && md <= 64) {
         const int sig = tiles16(P.dims[0]) * 1000 + tiles16(P.dims[1]) * 100 + tiles16(P.dims[2]) * 10 +
                         (P.n_layers == 3 ? tiles16(P.dims[3]) : 0);
 #define ARCN_FIXED_A(T0, T1, T2, T3, XMODE, AH, AO, CAP)                                                                          \
@@ -1264,14 +1245,13 @@ static int mlp_bwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
     const size_t lds_bytes = sizeof(float) * (size_t)lds_floats;
     if (lds_bytes > 144 * 1024) return einval("mlp_bwd: network too large for the LDS-resident fused kernel");
     static const int bwd_nt = 2;
-    static const int fused_ok = getenv("ARCN_MLP_FUSED_BWD") ? atoi(getenv("ARCN_MLP_FUSED_BWD")) : 1;
     MlpCat cat = {};
     if (cat_in) cat = *cat_in;
     if (x_stride || cat_in) {   // tile-order activations from arcn_mlp_fwd_lm / arcn_mlp_fwd_cat
         for (int l = 1; l < P.n_layers; ++l)
             if (P.dims[l] & 15) return einval("mlp_bwd_lm / mlp_bwd_cat: hidden widths must be multiples of 16");
     }
-    if (dweights && (fused_ok || x_stride || cat_in) && !P.has_bias && (P.n_layers == 2 || P.n_layers == 3) && md <= 64) {
+    if (dweights && !P.has_bias && (P.n_layers == 2 || P.n_layers == 3) && md <= 64) {
         // fused dx + dW for the tile shapes of the NGP nets; anything else takes the two-kernel path below
         const int t0 = tiles16(P.dims[0]), t1 = tiles16(P.dims[1]), t2 = tiles16(P.dims[2]);
         const int t3 = P.n_layers == 3 ? tiles16(P.dims[3]) : 0;

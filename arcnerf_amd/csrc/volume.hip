@@ -552,15 +552,12 @@ __global__ void __launch_bounds__(256) reduce_max_kernel(const float *__restrict
 //   2. evaluates in parallel, for its 64 points, `alive` (t <= far && inside the box), `occupied` and the skip distance,
 //   3. REPLAYS the reference's control flow: an unoccupied visited point k jumps to the first lattice point m > k with
 //      t_m >= t_k + dist_k (exactly the reference's `do t += dt while (t < t_target)`), an occupied one is emitted and steps
-//      to k + 1; a target beyond the chunk is carried into the next chunk.  Three implementations (ARCN_MARCH_JUMP_TABLE):
-//      0 = a scalar loop over the visited points with one vector compare + ballot per jump; 1 = landing lanes of all 64 points
-//      by bisection first, the scalar loop only chases pointers; 2 (default) = no scalar loop at all, the visited set is the
-//      orbit of the entry lane under the jump table, by pointer doubling and a binary-lifting walk (172 / 150 / 108 us),
+//      to k + 1; a target beyond the chunk is carried into the next chunk.  No scalar loop: landing lanes of all 64 points by
+//      bisection, then the visited set is the orbit of the entry lane under that jump table, by pointer doubling and a
+//      binary-lifting walk (rounds 1-2 replayed the loop with one ballot per jump, then with a scalar pointer chase: 172 / 150 us
+//      against 108),
 //   4. writes the emitted t's compacted by popcount.
 // Same arithmetic, same decisions => bit-identical zvals / counts (tests compare against the serial CPU oracle).
-#ifndef ARCN_MARCH_JUMP_TABLE
-#define ARCN_MARCH_JUMP_TABLE 2   // 0: ballot search per jump, 1: per-lane jump table + scalar pointer chase, 2: no scalar loop (orbit by binary lifting)
-#endif
 // FUSED (round 2, `arcn_march_packed`): the packed outputs come straight out of this kernel.  A wave keeps its ray's emitted t in LDS
 // (n_pts <= 1024: 4 KiB per wave) instead of a dense (n_rays, n_pts) scratch in HBM; the workgroup's 4 counts enter a chained scan
 // over the workgroups ("decoupled look-back": publish the local sum, walk back over the predecessors' status words until one carries
@@ -692,7 +689,7 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
             // point with t >= target.  t grows with the lane, so every lane finds its landing lane by bisection over the wave
             // (6 cross-lane reads, all lanes at once) and the replay below only follows pointers.  64 = beyond this trip.
             int next_lane = 64;
-            if (ARCN_MARCH_JUMP_TABLE) {
+            {
                 int lo = lane + 1, hi = 64;
 #pragma unroll
                 for (int it = 0; it < 6; ++it) {
@@ -714,7 +711,7 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
                 k = __builtin_ctzll(ge);
                 have_pending = false;
             }
-            if (ARCN_MARCH_JUMP_TABLE == 2) {
+            {
                 // The visited points are the orbit of k under J: occupied -> the next lane, empty -> its landing lane, not alive ->
                 // itself (the walk ends there), 64 = beyond this trip.  No scalar loop: J^(2^r) by pointer doubling (5 cross-lane
                 // reads), then every lane y finds the last orbit element <= y by binary lifting from k (6 reads): y is visited iff
@@ -750,31 +747,6 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
                         const int last = 63 - __builtin_clzll(visited_m);   // leaves the trip from here
                         if (!((occ_m >> last) & 1)) { have_pending = true; pending = __shfl(target, last, 64); }
                     }
-                }
-                k = 64;
-            }
-            while (k < 64) {
-                if (!((alive_m >> k) & 1)) { done = true; break; }
-                if ((occ_m >> k) & 1) {
-                    // run of occupied, alive points starting at k
-                    const uint64_t stop = ~(occ_m & alive_m) >> k;           // first 0 ends the run
-                    int run = stop ? __builtin_ctzll(stop) : 64 - k;
-                    const int room = (int)(n_pts - j);
-                    if (run >= room) { run = room; done = true; }
-                    emit_m |= (run >= 64 ? ~0ull : ((1ull << run) - 1ull)) << k;
-                    j += (uint32_t)run;
-                    k += run;
-                    if (done) break;
-                } else if (ARCN_MARCH_JUMP_TABLE) {
-                    const int nx = __builtin_amdgcn_readlane(next_lane, k);
-                    if (nx >= 64) { have_pending = true; pending = __shfl(target, k, 64); }
-                    k = nx;
-                } else {
-                    const float tgt = __shfl(target, k, 64);
-                    const uint64_t after = (k >= 63) ? 0ull : (~0ull << (k + 1));
-                    const uint64_t ge = __ballot(t >= tgt) & after;
-                    if (ge == 0) { have_pending = true; pending = tgt; k = 64; }
-                    else k = __builtin_ctzll(ge);
                 }
             }
             // 4. compacted store of this chunk's emitted samples

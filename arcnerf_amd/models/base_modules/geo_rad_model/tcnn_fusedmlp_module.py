@@ -22,7 +22,10 @@ def get_tcnn_activation_from_cfgs(cfg, default='None'):
     return names[cfg.type.lower()]
 
 
-_KERNEL_ACT = {'ReLU': 'relu', 'None': None, 'Sigmoid': 'sigmoid', 'Exponential': 'truncexp', 'Softplus': 'softplus'}
+# tiny-cuda-nn's activation names -> the kernels' table.  Sine: forward / inference only in a fused net (its derivative needs the pre-activation,
+# which neither this fused MLP nor tiny-cuda-nn's keeps); the backward entry points refuse it with that message
+_KERNEL_ACT = {'ReLU': 'relu', 'None': None, 'Sigmoid': 'sigmoid', 'Exponential': 'truncexp', 'Softplus': 'softplus', 'Squareplus': 'squareplus',
+               'Sine': 'sine'}
 
 
 class FusedLayers(nn.Module):

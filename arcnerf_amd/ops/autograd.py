@@ -154,6 +154,40 @@ class TruncExpFn(torch.autograd.Function):
         return F.act_bwd(x, y, g.contiguous(), 'truncexp')
 
 
+class ActGradFn(torch.autograd.Function):
+    """dx = dy f'(x) of an elementwise activation, itself differentiable in dy and x (arcn_act_bwd_bwd)"""
+
+    @staticmethod
+    def forward(ctx, x, dy, act, beta):
+        ctx.save_for_backward(x, dy)
+        ctx.act, ctx.beta = act, beta
+        return F.act_bwd(x, None, dy.contiguous(), act, beta)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, dy = ctx.saved_tensors
+        ddy, d2x = F.act_bwd_bwd(x, dy, g.contiguous(), ctx.act, ctx.beta, want_ddy=ctx.needs_input_grad[1], want_d2x=ctx.needs_input_grad[0])
+        return d2x, ddy, None, None
+
+
+class ActFn(torch.autograd.Function):
+    """y = f(x) for an activation of the kernels' table (relu / sigmoid / truncexp / softplus / squareplus / sine), twice differentiable:
+    the elementwise forms of the activations the reference's fused-MLP map names (tcnn_fusedmlp_module.py:195-213)"""
+
+    @staticmethod
+    def forward(ctx, x, act, beta=1.0):
+        x = x.contiguous().float()
+        ctx.save_for_backward(x)
+        ctx.act, ctx.beta = act, beta
+        return F.act_fwd(x, act, beta)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        return ActGradFn.apply(x, g, ctx.act, ctx.beta), None, None
+
+
 class FusedMlpFn(torch.autograd.Function):
     """y = MLP(x; flat weights[, flat biases]) on the f32-MFMA fused kernel."""
 

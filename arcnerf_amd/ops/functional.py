@@ -633,9 +633,19 @@ def softplus_grad2(z, g, h, beta, want_dg=True, want_dz=True, from_y=False):
     return dg, dz
 
 
+def act_bwd_bwd(x, dy, g, act, beta=1.0, want_ddy=True, want_d2x=True):
+    """second backward of an elementwise activation: (ddy, d2x) = (g f'(x), g dy f''(x))"""
+    _req(x, dy, g)
+    x, dy, g = _f32(x), _f32(dy), _f32(g)
+    ddy = torch.empty_like(x) if want_ddy else None
+    d2x = torch.empty_like(x) if want_d2x else None
+    N.check(N.lib().arcn_act_bwd_bwd(N.ptr(x), N.ptr(dy), N.ptr(g), N.ptr(ddy), N.ptr(d2x), x.numel(), N.ACT[act], float(beta), N.stream()), 'act_bwd_bwd')
+    return ddy, d2x
+
+
 def act_bwd(x, y, dy, act, beta=1.0):
     _req(x, dy)
-    x, y, dy = _f32(x), _f32(y), _f32(dy)
+    x, y, dy = _f32(x), (None if y is None else _f32(y)), _f32(dy)     # y None: the kernel evaluates the activation itself
     dx = torch.empty_like(x)
     N.check(N.lib().arcn_act_bwd(N.ptr(x), N.ptr(y), N.ptr(dy), N.ptr(dx), x.numel(), N.ACT[act], float(beta), N.stream()),
             'act_bwd')

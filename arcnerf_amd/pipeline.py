@@ -219,9 +219,6 @@ class NgpPipeline:
         # to the backward kernels; a refreshed occupancy takes effect two steps later instead of one
         env_depth = os.environ.get('ARCN_PREFETCH_DEPTH')
         self.prefetch_depth = max(1, int(env_depth if env_depth is not None else (prefetch_depth or 1)))
-        # arcn_march_packed (one launch: marching + chained look-back scan + compaction, no dense scratch) is bit-identical but measured
-        # slower - 107 vs 87 us alone, step 0.725 vs 0.669 ms (workgroups hold their slots while they wait for their predecessors): opt-in
-        self.march_fused = bool(int(os.environ.get('ARCN_MARCH_FUSED', '0'))) and cfg.n_sample <= 1024
         self._sets = []
         for _ in range(1 + self.prefetch_depth):
             self._sets.append({
@@ -234,9 +231,7 @@ class NgpPipeline:
                 # when prefetched): sample positions / directions, per-ray harmonics, the density noise of a training step
                 'xyz': torch.zeros((S, 3), dtype=f32, device=dev), 'dirs': torch.zeros((S, 3), dtype=f32, device=dev),
                 'sh_ray': torch.zeros((R, max(1, cfg.sh_degree ** 2)), dtype=f32, device=dev),
-                'noise': torch.zeros(S, dtype=f32, device=dev),
-                # ticket + status words of the fused marcher's chained scan (arcn_march_packed)
-                'march_ws': torch.zeros(max(16, int(N.lib().arcn_march_packed_workspace_bytes(R))), dtype=torch.uint8, device=dev)})
+                'noise': torch.zeros(S, dtype=f32, device=dev)})
         self._noise_ready = [False] * len(self._sets)
         b.update(self._sets[0])
         self._cur_set = 0
@@ -302,18 +297,12 @@ class NgpPipeline:
         gd = [field.geo_desc.dims[i] for i in range(field.geo_desc.n_layers + 1)]
         self.level_major = bool(level_major and xcd_scatter and cfg.n_feat_per_entry == 2 and field.geo_desc.n_layers == 2 and
                                 not field.geo_desc.has_bias and gd[0] in (32, 64) and 48 < gd[1] <= 64 and gd[2] <= 16)
-        # optional: issue the two dW reductions after the scatter instead of right behind their nets (measured: slower, 0.833 vs 0.822 ms)
-        # dW partial reductions of the fused MLP backward: 0 = inside the backward entry points, 1 = after the scatter, 2 = on their own
-        # stream next to the following backward kernels (they are latency-bound: 128 / 192 workgroups, ~16 us each)
-        self.defer_dw = int(os.environ.get('ARCN_DEFER_DW', '0')) if self.level_major else 0
-        self.red_stream = torch.cuda.Stream(device=dev) if (dev.type == 'cuda' and self.defer_dw == 2) else None
-        self._red_event = None
         # single-GPU step with the optimiser inside the scatter: the two dW reductions, the optimiser on the rest of the flat buffer and
         # the clearing of the scatter's bin counters as ONE launch at the end of the step (arcn_ngp_step_tail; ARCN_STEP_TAIL=0: four)
         self._tail = None
         self._tail_step = False
         self._ws_clear = False
-        if (self._adam_rest is not None and self.level_major and self.fused_glue and self.defer_dw == 0 and not cfg.has_bias and
+        if (self._adam_rest is not None and self.level_major and self.fused_glue and not cfg.has_bias and
                 bool(int(os.environ.get('ARCN_STEP_TAIL', '1')))):
             gw, rw = field._seg['geo_w'], field._seg['rad_w']
             inside = lambda run, seg: seg[0] >= run[0] and seg[0] + seg[1] <= run[1]
@@ -547,15 +536,7 @@ class NgpPipeline:
         assert R <= self.max_rays
         L = N.lib()
         st = N.stream()
-        if self.march_fused:
-            # bounds + marching + chained scan + compaction in one launch, no dense (R, n_sample) scratch
-            N.check(L.arcn_march_packed(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
-                                        int(self.packed_bits), cfg.n_sample, cfg.dt, cfg.near_distance, int(self.torch_aabb),
-                                        self.rng.state, self.rng.inc, N.ptr(b['counts']), N.ptr(b['near']), N.ptr(b['far']),
-                                        N.ptr(b['offsets']), N.ptr(b['t']), N.ptr(b['ray_id']), self.cap, N.ptr(b['p_dense']),
-                                        N.ptr(b['march_ws']), R, st), 'march_packed')
-            self.rng.advance()
-        elif self.replay is not None and torch.cuda.is_current_stream_capturing():
+        if self.replay is not None and torch.cuda.is_current_stream_capturing():
             # being recorded: the generator state comes from device memory (prepare_replay), nothing on the host moves
             coarse = getattr(self, '_coarse', None)
             N.check(L.arcn_march_count_replay(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
@@ -680,10 +661,8 @@ class NgpPipeline:
             N.check(L.arcn_mlp_bwd_cat(N.ptr(b['geo_out']), N.ptr(b['sh_ray']), N.ptr(b['ray_id']), int(cfg.rad_mode == 'fv'),
                                        N.ptr(self._p('rad_w')), N.C.addressof(fld.rad_desc), N.ptr(b['rgb_s']), N.ptr(b['rad_acts']),
                                        N.ptr(b['d_rgb_s']), N.ptr(b['d_geo_out']), N.ptr(b['d_sigma']), N.ACT[cfg.sigma_act],
-                                       N.ptr(self._g('rad_w')), N.ptr(b['rad_scratch']), int(self.defer_dw > 0 or tail), S, S, n_dev.data_ptr(), st),
+                                       N.ptr(self._g('rad_w')), N.ptr(b['rad_scratch']), int(tail), S, S, n_dev.data_ptr(), st),
                     'mlp_bwd_cat(rad)')
-            if self.red_stream is not None:
-                self._reduce_on_side(fld.rad_desc, b['rad_scratch'], self._g('rad_w'), S)
         else:
             N.check(L.arcn_mlp_bwd(N.ptr(b['rad_in']), N.ptr(self._p('rad_w')), N.ptr(self._p('rad_b')), N.C.addressof(fld.rad_desc),
                                    N.ptr(b['rgb_s']), N.ptr(b['rad_acts']), N.ptr(b['d_rgb_s']), N.ptr(b['d_rad_in']),
@@ -695,9 +674,7 @@ class NgpPipeline:
         if self.level_major:
             N.check(L.arcn_mlp_bwd_lm(N.ptr(b['feat']), S, N.ptr(self._p('geo_w')), N.C.addressof(fld.geo_desc), N.ptr(b['geo_out']),
                                       N.ptr(b['geo_acts']), N.ptr(b['d_geo_out']), N.ptr(b['d_feat']), N.ptr(self._g('geo_w')),
-                                      N.ptr(b['geo_scratch']), int(self.defer_dw > 0 or tail), S, S, n_dev.data_ptr(), st), 'mlp_bwd_lm(geo)')
-            if self.red_stream is not None:
-                self._reduce_on_side(fld.geo_desc, b['geo_scratch'], self._g('geo_w'), S)
+                                      N.ptr(b['geo_scratch']), int(tail), S, S, n_dev.data_ptr(), st), 'mlp_bwd_lm(geo)')
             self._prefetch_point(2)
             if self._fuse_next and self._adam_rest is not None and self._pb is None and self._gb is None and self.ema is fld.params:
                 # scatter + optimiser of the one-owner levels in one pass (the refresh on its own stream still reads the parameters)
@@ -727,8 +704,6 @@ class NgpPipeline:
                     N.check(L.arcn_hashgrid_bwd_lm_levels(N.ptr(b['xyz']), N.ptr(b['d_feat']), S, N.C.addressof(fld.grid_desc), N.ptr(self._g('table')),
                                                           N.ptr(self.hash_ws), self.hash_ws.numel(), S, n_dev.data_ptr(), int(mask), int(gi > 0), st),
                             'hashgrid_bwd_lm_levels')
-                    if gi == 0:
-                        self._join_reductions()      # the first slice carries the MLP weights' gradients
                     sync.launch_group(gi, fld.grads)
                 self._ws_clear = False
             else:
@@ -738,15 +713,6 @@ class NgpPipeline:
                                                N.ptr(self.hash_ws), self.hash_ws.numel(), S, n_dev.data_ptr(), st), 'hashgrid_bwd_lm')
                 self._ws_clear = False
             self._fuse_next = False
-            if self.defer_dw == 1:
-                # the two tiny dW reductions run here, after the scatter, instead of between the big backward kernels where
-                # they queue behind the overlapped marching (27 us each there, 6 us here)
-                N.check(L.arcn_mlp_bwd_reduce(N.C.addressof(fld.geo_desc), N.ptr(b['geo_scratch']), N.ptr(self._g('geo_w')), S, S, st),
-                        'mlp_bwd_reduce(geo)')
-                if self.fused_glue:
-                    N.check(L.arcn_mlp_bwd_reduce(N.C.addressof(fld.rad_desc), N.ptr(b['rad_scratch']), N.ptr(self._g('rad_w')), S, S,
-                                                  st), 'mlp_bwd_reduce(rad)')
-            self._join_reductions()
             return
         N.check(L.arcn_mlp_bwd(N.ptr(b['feat']), N.ptr(self._p('geo_w')), N.ptr(self._p('geo_b')), N.C.addressof(fld.geo_desc),
                                N.ptr(b['geo_out']), N.ptr(b['geo_acts']), N.ptr(b['d_geo_out']), N.ptr(b['d_feat']),
@@ -757,21 +723,6 @@ class NgpPipeline:
                                     N.ptr(self._g('table')), None, N.ptr(self.hash_ws),
                                     0 if self.hash_ws is None else self.hash_ws.numel(), S, n_dev.data_ptr(), st),
                 'hashgrid_bwd')
-
-    def _reduce_on_side(self, desc, scratch, dweights, S):
-        """queue one net's dW partial reduction on the reduction stream, behind the backward kernel just launched"""
-        main = torch.cuda.current_stream()
-        self.red_stream.wait_stream(main)
-        with torch.cuda.stream(self.red_stream):
-            N.check(N.lib().arcn_mlp_bwd_reduce(N.C.addressof(desc), N.ptr(scratch), N.ptr(dweights), S, S, N.stream()),
-                    'mlp_bwd_reduce')
-            self._red_event = torch.cuda.Event()
-            self._red_event.record(self.red_stream)
-
-    def _join_reductions(self):
-        if self._red_event is not None:
-            torch.cuda.current_stream().wait_event(self._red_event)
-            self._red_event = None
 
     def huber_grad(self, rgb, target):
         """ImgLoss(Huber, delta, weight) of arcnerf/loss/img_loss.py:60-100: loss value and d loss / d rgb (mean over R*3)."""
@@ -862,7 +813,7 @@ class NgpPipeline:
         # one GPU: nothing has to be summed across ranks between the scatter and the optimiser, so the scatter applies it (see backward)
         self._fuse_next = grad_sync is None and all_reduce is None and world_size == 1
         grouped = grad_sync is not None and hasattr(grad_sync, 'launch_group')
-        if grouped and not (self.level_major and self._pb is None and self._gb is None and self.defer_dw != 1):
+        if grouped and not (self.level_major and self._pb is None and self._gb is None):
             raise RuntimeError('LevelGroupedGradSync needs the level-major scatter on the field\'s own flat buffers')
         self._level_sync = grad_sync if grouped else None
         self.backward(rays_o, rays_d, d_rgb)

@@ -791,17 +791,26 @@ def cpu_baseline(cfg, field, bf, n_rays):
     cores = orc.get_max_threads()
     P = field.export_numpy()
     legs = []
+    from oracle.ngp_reference import oracle_train_step_sharded
+    # all cores: the batch in ray shards run concurrently (each shard: the C kernels on its OpenMP threads + its own numpy glue), gradients
+    # summed at the end - the single-call form keeps the glue (mask compaction, padded scatter) on ONE core and stopped at ~3x one thread
+    shards = max(1, min(32, cores // 4))
     for threads, rays in ((cores, n_rays), (1, max(256, n_rays // 64))):
-        orc.set_num_threads(threads)
         o, d = synthetic_rays(rays, seed=4242, device='cpu')
         o, d = o.numpy(), d.numpy()
         rng = orc.Pcg32(9121)
         t0 = time.perf_counter()
-        n = oracle_train_step(orc, field, cfg, P, o, d, bf, rng.state, rng.inc)
+        if threads > 1:
+            n, _ = oracle_train_step_sharded(orc, field, cfg, P, o, d, bf, rng.state, rng.inc, shards, max(1, threads // shards))
+            how = '{} ray shards x {} OpenMP threads, gradients summed'.format(shards, max(1, threads // shards))
+        else:
+            orc.set_num_threads(1)
+            n = oracle_train_step(orc, field, cfg, P, o, d, bf, rng.state, rng.inc)
+            how = 'one call'
         dt = time.perf_counter() - t0
         legs.append({'value': n / dt, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
-                     'sample': 'fwd+bwd of one NGP training step for {} rays = {} valid samples ({:.1f} s), C oracle with OpenMP '
-                               '(numpy glue between the kernels; hash-grid scatter parallel over levels x row slices)'.format(rays, n, dt)})
+                     'sample': 'fwd+bwd of one NGP training step for {} rays = {} valid samples ({:.1f} s), C oracle with OpenMP + numpy glue '
+                               '({})'.format(rays, n, dt, how)})
     orc.set_num_threads(cores)
     out = dict(legs[0])
     out['threads_1'] = legs[1]

@@ -34,6 +34,10 @@ extern "C" {
 #define ARCN_ACT_SIGMOID 2
 #define ARCN_ACT_TRUNCEXP 3 /* fwd exp(x); bwd g*exp(clamp(x,-15,15))  (arcnerf/ops/trunc_exp.py:7-37) */
 #define ARCN_ACT_SOFTPLUS 4
+/* the remaining two activations of the reference's fused-MLP map (tcnn_fusedmlp_module.py:195-213), tiny-cuda-nn's definitions: */
+#define ARCN_ACT_SQUAREPLUS 5 /* y = (X + sqrt(X^2 + 4)) / 2 / 10 with X = 10 x; dy/dx = Y^2 / (Y^2 + 1), Y = 10 y */
+#define ARCN_ACT_SINE 6       /* y = sin(x); dy/dx = cos(x) needs the PRE-activation: elementwise ops and forward passes only - the fused
+                               * MLP backward works from the post-activations it saved and refuses Sine (tiny-cuda-nn's fused MLP does too) */
 
 const char *arcn_last_error(void);
 int arcn_version(void);
@@ -445,6 +449,9 @@ int arcn_softplus_grad_sum(const float *z, const float *g, const float *g2, floa
 int arcn_softplus_grad2(const float *z, const float *g, const float *h, float *dg, float *dz, int64_t n, float beta, int from_y, void *stream);
 int arcn_act_bwd(const float *x, const float *y, const float *dy, float *dx, int64_t n, int act, float beta,
                  void *stream);
+/* second backward of an elementwise activation, given the pre-activation x, the incoming dy of the first backward (dx = dy f'(x)) and
+ * g = d loss / d dx:  ddy = g f'(x),  d2x = g dy f''(x)  (either output may be NULL).  Makes ops.autograd.ActFn twice differentiable. */
+int arcn_act_bwd_bwd(const float *x, const float *dy, const float *g, float *ddy, float *d2x, int64_t n, int act, float beta, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Compositing (arcnerf/render/ray_helper.py:476-620)

@@ -136,6 +136,40 @@ def oracle_train_step(orc, fld, cfg, P, o, d, bf, rng_state, rng_inc):
     return res['n_samples']
 
 
+def oracle_train_step_sharded(orc, fld, cfg, P, o, d, bf, rng_state, rng_inc, shards, threads_per_shard=1):
+    """oracle_train_step over `shards` contiguous ray shards run CONCURRENTLY (Python threads: the C kernels and numpy's heavy operations
+    release the interpreter lock), each with `threads_per_shard` OpenMP threads, then the shards' flat gradients are summed - the same
+    work as one call (rays are independent; a shard's sampler stream starts at its first ray's position, pcg32 advanced 8 per ray like
+    the kernel does).  The single-call form keeps its numpy glue (boolean-mask compaction, dense padded scatter) on ONE core and stopped
+    scaling at ~3x (round 3); this is the all-core form bench.py's cpu_baseline times.  Returns (valid samples, summed flat gradient)."""
+    from concurrent.futures import ThreadPoolExecutor
+    R = o.shape[0]
+    rng = np.random.default_rng(0)
+    tgt = rng.random((R, 3)).astype(np.float32)
+    bkg = rng.random((R, 3)).astype(np.float32)
+    bounds = [R * k // shards for k in range(shards + 1)]
+
+    def work(k):
+        lo, hi = bounds[k], bounds[k + 1]
+        if hi <= lo:
+            return 0, None
+        orc.set_num_threads(threads_per_shard)          # (an OpenMP setting of the calling thread)
+        st = orc.Pcg32(9121)
+        st.si[0] = np.uint64(rng_state)
+        st.advance(8 * lo)
+        res = oracle_step(orc, fld, cfg, P, o[lo:hi], d[lo:hi], bkg[lo:hi], bf, st.state, rng_inc, huber_target=tgt[lo:hi])
+        # (the loss is a mean over the shard's rays: weight the gradient back to the whole batch's mean)
+        return res['n_samples'], res['grads'] * np.float32((hi - lo) / R)
+    with ThreadPoolExecutor(max_workers=shards) as ex:
+        outs = list(ex.map(work, range(shards)))
+    total = sum(n for n, _ in outs)
+    grads = None
+    for _, g in outs:
+        if g is not None:
+            grads = g if grads is None else grads + g
+    return total, grads
+
+
 def compare(ref, rgb, depth, mask, grads, fld):
     """max abs errors of GPU results against an oracle_step() result"""
     valid = ref['valid']

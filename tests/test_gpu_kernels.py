@@ -1662,3 +1662,62 @@ def test_radiance_chain_equals_the_layer_by_layer_module(mode, W, D, wn, bias, p
             continue
         assert a.shape == b.shape
         assert (a - b).abs().max() <= 1e-5 * float(b.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize('act', ['squareplus', 'sine', 'softplus', 'sigmoid'])
+def test_activation_table_forward_and_both_derivatives_vs_torch(F, act):
+    """The last two activations of the reference's fused-MLP map (tcnn_fusedmlp_module.py:195-213: Squareplus, Sine - tiny-cuda-nn's
+    definitions) and two older ones through ops.autograd.ActFn: value, first derivative and the second backward (both outputs of
+    arcn_act_bwd_bwd) against torch autograd on the same formula in float64."""
+    from arcnerf_amd.ops.autograd import ActFn
+    torch.manual_seed(3)
+    x = (torch.randn(4096, device='cuda') * 1.5).requires_grad_(True)
+    w = torch.randn(4096, device='cuda')
+    beta = 1.0
+
+    def ref(t):
+        if act == 'squareplus':
+            X = 10.0 * t
+            return 0.5 * (X + torch.sqrt(X * X + 4.0)) / 10.0
+        if act == 'sine':
+            return torch.sin(t)
+        if act == 'softplus':
+            return torch.nn.functional.softplus(t, beta=beta)
+        return torch.sigmoid(t)
+    y = ActFn.apply(x, act, beta)
+    xd = x.detach().double().requires_grad_(True)
+    yd = ref(xd)
+    assert float((y.double() - yd).abs().max()) < 2e-6
+    g, = torch.autograd.grad((y * w).sum(), x, create_graph=True)
+    gd, = torch.autograd.grad((yd * w.double()).sum(), xd, create_graph=True)
+    assert float((g.double() - gd).abs().max()) < 1e-5
+    # second order: differentiate a function of the first gradient wrt x
+    h, = torch.autograd.grad((g * g).sum(), x)
+    hd, = torch.autograd.grad((gd * gd).sum(), xd)
+    assert float((h.double() - hd).abs().max()) <= 2e-5 * max(1.0, float(hd.abs().max()))
+
+
+def test_fused_mlp_squareplus_trains_and_sine_is_forward_only(F):
+    """FusedLayers with tiny-cuda-nn's activation names: Squareplus hidden / output activations against a torch MLP (values, dX, dW);
+    Sine evaluates (inference) and its backward is refused with the reason (cos(x) is not a function of the saved sin(x) - tiny-cuda-nn's
+    fused MLP has the same restriction)."""
+    from arcnerf_amd.models.base_modules.geo_rad_model.tcnn_fusedmlp_module import FusedLayers
+    torch.manual_seed(4)
+    layers = FusedLayers([32, 64, 16], 'Squareplus', 'Squareplus').cuda()
+    x = torch.randn(777, 32, device='cuda', requires_grad=True)
+    sq = lambda t: 0.5 * (10.0 * t + torch.sqrt(100.0 * t * t + 4.0)) / 10.0   # noqa: E731
+    W0, W1 = layers.params[:32 * 64].view(64, 32), layers.params[32 * 64:].view(16, 64)
+    y = layers(x)
+    ref = sq(sq(x @ W0.t()) @ W1.t())
+    assert float((y - ref).abs().max()) < 1e-5
+    g = torch.randn_like(y)
+    dx, dw = torch.autograd.grad((y * g).sum(), [x, layers.params])
+    rdx, rdw = torch.autograd.grad((ref * g).sum(), [x, layers.params])
+    assert float((dx - rdx).abs().max()) <= 1e-4 * float(rdx.abs().max()) and float((dw - rdw).abs().max()) <= 1e-4 * float(rdw.abs().max())
+    sine = FusedLayers([32, 64, 16], 'Sine', 'None').cuda()
+    with torch.no_grad():
+        ys = sine(x)
+        V0, V1 = sine.params[:32 * 64].view(64, 32), sine.params[32 * 64:].view(16, 64)
+        assert float((ys - torch.sin(x @ V0.t()) @ V1.t()).abs().max()) < 1e-5
+    with pytest.raises(RuntimeError, match='Sine'):
+        sine(x).sum().backward()

@@ -1,8 +1,10 @@
 """Every ARCN_* environment switch (README.md) at its NON-default value: the code behind it must still give the default path's results.
 The switches are read once per process, so each group runs tests/switch_smoke.py in a subprocess; groups combine switches that act on
-different kernels.  (ARCN_GRAD_SEGMENTS / ARCN_DIST_BACKEND are exercised by tests/test_gpu_distributed.py; ARCN_GATHER_ONE_XCD /
-ARCN_GATHER_ONLY_XCD / ARCN_SCATTER_LEVELS restrict the hash kernels to a subset of the chip / levels for the counter passes of
-tools/pmc_gather.sh and tools/scatter_levels.sh - they change the result by design and are only run, not compared.)"""
+different kernels.  (ARCN_GRAD_SEGMENTS / ARCN_GRAD_LEVEL_CUTS / ARCN_DIST_BACKEND are exercised by tests/test_gpu_distributed.py;
+ARCN_GATHER_ONE_XCD / ARCN_GATHER_ONLY_XCD restrict the hash gather to a part of the chip for the counter passes of tools/pmc_gather.sh
+- they change the result by design and are only run, not compared.  Round 4 removed the switches whose non-default value was a slower
+variant with no other role: the round-1 gather, the non-temporal gather variants, the bit-lock consumer for two-feature tables, the
+deferred dW reductions, the single-launch marcher behind an environment variable, the generic MLP kernels forced onto the NGP shapes.)"""
 import os
 import subprocess
 import sys
@@ -17,10 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 GROUPS = {
     'ngp': [
-        {'ARCN_OCC_ASYNC': '0', 'ARCN_FUSED_COMPOSITE': '0', 'ARCN_EMA_ALIAS': '0', 'ARCN_GATHER_VARIANT': '0',
-         'ARCN_SCATTER_CAS': '0', 'ARCN_MLP_FIXED_FWD': '0', 'ARCN_MLP_FUSED_BWD': '0'},
-        {'ARCN_MARCH_FUSED': '1', 'ARCN_DEFER_DW': '1', 'ARCN_PREFETCH_AT': '1', 'ARCN_SCATTER_LOCK': '0'},
-        {'ARCN_DEFER_DW': '2', 'ARCN_PREFETCH_AT': '2', 'ARCN_SCATTER_LOCK': '0xffffffff', 'ARCN_MAIN_PRIORITY': '0'},
+        {'ARCN_OCC_ASYNC': '0', 'ARCN_FUSED_COMPOSITE': '0', 'ARCN_EMA_ALIAS': '0'},
+        {'ARCN_PREFETCH_AT': '1'},
+        {'ARCN_PREFETCH_AT': '2', 'ARCN_MAIN_PRIORITY': '0'},
         # one batch in flight instead of two: the batches meet the sampler's pcg32 launches in a different order (jitter of the ray
         # starts), so the trajectory is another draw of the same training - compared through the loss it reaches, not bit by bit
         {'ARCN_PREFETCH_DEPTH': '1'},
@@ -88,6 +89,6 @@ def test_profiling_aids_run():
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     with tempfile.TemporaryDirectory() as tmp:
-        for env in ({'ARCN_SCATTER_LEVELS': '0x00f0'}, {'ARCN_GATHER_ONE_XCD': '1'}, {'ARCN_GATHER_ONLY_XCD': '3'}):
+        for env in ({'ARCN_GATHER_ONE_XCD': '1'}, {'ARCN_GATHER_ONLY_XCD': '3'}):
             out = _run('ngp', env, tmp)
             assert np.isfinite(out['ngp_params']).all()

@@ -86,3 +86,25 @@ def test_torch_cpu_nerf_matches_reference_full_width():
     gw = m.coarse.rad[1].weight.grad.numpy()
     ref = g['grad.fg_model.coarse_radiance_net.layers.1.weight']
     assert np.abs(gw - ref).max() <= 1e-3 * np.abs(ref).max()
+
+
+def test_sharded_oracle_step_equals_the_single_call(oracle):
+    """oracle_train_step_sharded (the all-core form bench.py's cpu_baseline times: ray shards run concurrently, gradients summed) does the
+    work of ONE oracle_step over the whole batch: same samples (a shard's sampler stream starts at its first ray's position), the summed
+    flat gradient equal to the single call's to summation order."""
+    from arcnerf_amd.pipeline import NgpConfig, NgpField, synthetic_bitfield, synthetic_rays
+    from oracle.ngp_reference import oracle_step, oracle_train_step_sharded
+    cfg = NgpConfig(n_levels=8, hashmap_size=14, max_res=256, n_grid=32, n_sample=256, noise_std=0.0)
+    fld = NgpField(cfg, device='cpu', seed=1)
+    fld.view('table').mul_(2000.0)
+    P = fld.export_numpy()
+    bf = synthetic_bitfield(cfg.n_grid, 0.08, seed=2)
+    o, d = synthetic_rays(1000, seed=3, device='cpu')
+    o, d = o.numpy(), d.numpy()
+    rng = oracle.Pcg32(9121)
+    g = np.random.default_rng(0)                       # (the targets oracle_train_step_sharded draws)
+    tgt, bkg = g.random((1000, 3)).astype(np.float32), g.random((1000, 3)).astype(np.float32)
+    one = oracle_step(oracle, fld, cfg, P, o, d, bkg, bf, rng.state, rng.inc, huber_target=tgt)
+    n, grads = oracle_train_step_sharded(oracle, fld, cfg, P, o, d, bf, rng.state, rng.inc, shards=3, threads_per_shard=2)
+    assert n == one['n_samples'] and n > 5000
+    assert np.abs(grads - one['grads']).max() <= 1e-4 * np.abs(one['grads']).max()
