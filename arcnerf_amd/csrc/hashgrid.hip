@@ -475,6 +475,9 @@ hashgrid_fwd_bal_kernel(const float *__restrict__ xyz, const float *__restrict__
         }
         float *o = LM ? out + ((int64_t)l * n_cap + s) * F : out + (s * g.L + l) * F;
         if (F == 2) {
+#ifdef ARCN_EXP_GATHER_NOSTORE   // experiment: the gather without its feature store (values kept live)
+            if (acc[0] + acc[1 % F] == 123.456f)
+#endif
             *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1 % F]);
         } else {
 #pragma unroll
@@ -626,8 +629,14 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
             np_[0] = xyz[3 * s]; np_[1] = xyz[3 * s + 1]; np_[2] = xyz[3 * s + 2];
             // level-major gradients (dout_lm_stride > 0): the lanes of a wave read consecutive 8-byte words
             const float *gp = dout_lm_stride ? dout + ((int64_t)l * dout_lm_stride + s) * F : dout + (s * g.L + l) * F;
+#ifdef ARCN_EXP_BIN_NOLOAD   // experiment: what the producer would gain if the gradient came out of LDS / registers instead of HBM
+            ng0 = 0.25f + 1e-3f * (float)(s & 15);
+            ng1 = -0.5f;
+            (void)gp;
+#else
             ng0 = gp[0];
             ng1 = F > 1 ? gp[F > 1 ? 1 : 0] : 0.f;
+#endif
         }
     };
     fetch((int64_t)blockIdx.x * kBinThreads + t);

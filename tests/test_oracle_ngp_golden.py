@@ -94,7 +94,9 @@ def test_sharded_oracle_step_equals_the_single_call(oracle):
     flat gradient equal to the single call's to summation order."""
     from arcnerf_amd.pipeline import NgpConfig, NgpField, synthetic_bitfield, synthetic_rays
     from oracle.ngp_reference import oracle_step, oracle_train_step_sharded
-    cfg = NgpConfig(n_levels=8, hashmap_size=14, max_res=256, n_grid=32, n_sample=256, noise_std=0.0)
+    # (add_inf_z: without it the reference's dense view drops the sample in its LAST column, and the dense width is the largest count of
+    # the batch - the result would depend on which rays share a batch, i.e. on the sharding)
+    cfg = NgpConfig(n_levels=8, hashmap_size=14, max_res=256, n_grid=32, n_sample=256, noise_std=0.0, add_inf_z=True)
     fld = NgpField(cfg, device='cpu', seed=1)
     fld.view('table').mul_(2000.0)
     P = fld.export_numpy()
