@@ -317,3 +317,52 @@ def test_host_value_caches_follow_their_tensors():
     assert s.get_radius(in_float=True) == 2.5 and s.get_origin(in_tuple=True) == (1.0, 2.0, 3.0)
     a, b = F.scalar_tensor(64.0, 'cpu'), F.scalar_tensor(64, 'cpu')
     assert a is b and float(a) == 64.0 and F.scalar_tensor(128.0, 'cpu') is not a
+
+
+def test_trainer_mirror_rules_on_cpu():
+    """arcnerf_amd.trainer: the dynamic batch size (trainer/pipeline.py:222-241: only when epoch % update_epoch == 0 AND epoch > 500; float
+    div_round_up to a multiple of 128; capped), the measurement behind it (fg_model.py:105-130), the reference's Huber (loss/img_loss.py:80-100:
+    torch's divided by delta), AllLoss' dict, and EMA.ema_step's de-biased write-back (trainer/ema.py:29-43) with set_n_step."""
+    import torch
+    from arcnerf_amd import trainer as T
+    m = T.DynamicBsMeter(1 << 15)
+    for n in (52005, 47096, 51134):
+        m.add(n)
+    want = sum(float(1 << 15) / (float(n) + 1) for n in (52005, 47096, 51134)) / 3
+    p = T.Pipeline()
+    p.set_info('n_rays', 256)
+    p.set_info('dynamic_batch_size', 4)
+    p.set_info('dynamic_max_batch_size', 1024)
+    assert p.fetch_step_update_dynamic_bs(500, m) == 256 and m.measured_count == 3       # epoch > 500 is strict: nothing read, nothing reset
+    assert p.fetch_step_update_dynamic_bs(503, m) == 256
+    n = p.fetch_step_update_dynamic_bs(504, m)
+    assert n == min(int((256 * want + 127) // 128 * 128), 1024) == 256 and m.measured_count == 0
+    m.add(3000)
+    assert p.fetch_step_update_dynamic_bs(508, m) == 1024                                  # 256 * 10.9 -> capped
+    assert T.DynamicBsMeter(-1).factor() == 1
+    # Huber / ImgLoss / AllLoss
+    x, y = torch.tensor([[0.0, 0.05, 0.5]]), torch.tensor([[0.0, 0.0, 0.0]])
+    h = T.HuberLoss(0.1)(x, y)
+    assert torch.allclose(h, torch.tensor([[0.0, 0.5 / 0.1 * 0.05 ** 2, 0.5 - 0.05]]))
+    assert torch.allclose(h, torch.nn.functional.huber_loss(x, y, delta=0.1, reduction='none') / 0.1)
+    cfg = type('C', (), {})()
+    cfg.loss = type('C', (), {})()
+    cfg.loss.ImgLoss = type('C', (), dict(keys=['rgb_coarse'], loss_type='Huber', delta=0.1, weight=3000.0))()
+    out = T.build_loss(cfg)({'img': y[None]}, {'rgb_coarse': x[None]})
+    assert out['names'] == ['ImgLoss'] and abs(float(out['sum']) - 3000.0 * float(h.mean())) < 1e-3
+    # EMA (the eager form, any optimiser): three steps from n_step 496
+    lin = torch.nn.Linear(3, 2)
+    ema = T.EMA(lin, 0.95)
+    ema.set_n_step(496)
+    old = {k: v.clone() for k, v in lin.named_parameters()}
+    for step in range(3):
+        with torch.no_grad():
+            for q in lin.parameters():
+                q.add_(0.1 * (step + 1))
+        cur = {k: v.clone() for k, v in lin.named_parameters()}
+        ema.ema_step()
+        n_ = 497 + step
+        for k, q in lin.named_parameters():
+            ref = ((1 - 0.95) * cur[k] + 0.95 * old[k] * (1 - 0.95 ** (n_ - 1))) * (1.0 / (1 - 0.95 ** n_))
+            assert torch.allclose(q, ref, atol=1e-6)
+            old[k] = ref
