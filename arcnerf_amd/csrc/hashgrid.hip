@@ -898,6 +898,8 @@ scatter_bin_dir_kernel(const float *__restrict__ xyz, const float *__restrict__ 
     }
 }
 
+__device__ __forceinline__ uint4 ld_rec(const uint4 *p) { return *p; }
+
 // Optimiser fused into the consumer (arcn_hashgrid_bwd_lm_adam): the owner of a chunk holds the chunk's COMPLETE gradient in LDS, so it
 // applies Adam (+ EMA write-back) to its rows right there - parameter and moments read and written once, the gradient never goes to
 // HBM (the separate pass re-reads it and clears it: 28 B/param; here 24 B/param and no launch) - while the other owners are still in
@@ -1002,7 +1004,7 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
     uint32_t i = threadIdx.x;
     uint4 nxt[kUnroll];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) nxt[u] = (i + u * kTiledThreads < len) ? pr[i + u * kTiledThreads] : none;
+    for (int u = 0; u < kUnroll; ++u) nxt[u] = (i + u * kTiledThreads < len) ? ld_rec(pr + i + u * kTiledThreads) : none;
     for (uint32_t trip = 0; trip < trips; ++trip) {
         uint4 cur[kUnroll];
 #pragma unroll
@@ -1010,7 +1012,7 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
         i += kTiledThreads * kUnroll;
         if (trip + 1 < trips) {
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) nxt[u] = (i + u * kTiledThreads < len) ? pr[i + u * kTiledThreads] : none;
+            for (int u = 0; u < kUnroll; ++u) nxt[u] = (i + u * kTiledThreads < len) ? ld_rec(pr + i + u * kTiledThreads) : none;
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {

@@ -322,7 +322,10 @@ __device__ __forceinline__ void store_tiles_frag(const f4 (&v)[4][NT], float *__
         if (s0 + 16 * nt + (lane & 15) >= cnt) continue;
         float *p = dst + (((s0 >> 4) + nt) * TT * 64 + lane) * 4;
 #pragma unroll
-        for (int t = 0; t < TT; ++t) *reinterpret_cast<f4 *>(p + t * 256) = v[t][nt];
+        // non-temporal: the saved activations (134 MB per radiance-net pass) are written once and read once by the matching backward -
+        // marked as streaming they do not displace the table's lines (step -1.2 % in three alternations, scatter -5 us, gather -1.5 us;
+        // profiles/r4_ab_nontemporal.txt.  The same hint on the scatter's 16-byte RECORDS doubled the scatter: partial lines)
+        for (int t = 0; t < TT; ++t) __builtin_nontemporal_store(v[t][nt], reinterpret_cast<f4 *>(p + t * 256));
     }
 }
 
@@ -335,7 +338,7 @@ __device__ __forceinline__ void load_tiles_frag(f4 (&v)[4][NT], const float *__r
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             f4 r = {0.f, 0.f, 0.f, 0.f};
-            if (t < TT && ok) r = *reinterpret_cast<const f4 *>(p + t * 256);
+            if (t < TT && ok) r = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p + t * 256));
             v[t][nt] = r;
         }
     }
