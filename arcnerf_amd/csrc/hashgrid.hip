@@ -634,8 +634,9 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
             ng1 = -0.5f;
             (void)gp;
 #else
-            ng0 = gp[0];
-            ng1 = F > 1 ? gp[F > 1 ? 1 : 0] : 0.f;
+            // (non-temporal: this is the gradient's only reader - step -1.9 % in three alternations, profiles/r4_ab_nontemporal.txt)
+            ng0 = __builtin_nontemporal_load(gp);
+            ng1 = F > 1 ? __builtin_nontemporal_load(gp + (F > 1 ? 1 : 0)) : 0.f;
 #endif
         }
     };
@@ -898,7 +899,14 @@ scatter_bin_dir_kernel(const float *__restrict__ xyz, const float *__restrict__ 
     }
 }
 
-__device__ __forceinline__ uint4 ld_rec(const uint4 *p) { return *p; }
+// a record is read exactly once: a non-temporal load keeps the 230 MB of records from displacing the table's lines on their way through
+// (step -2.3 % in three alternations, scatter 0.220 -> 0.208 ms, the gather of the next step -2 us; profiles/r4_ab_nontemporal.txt.  The
+// same hint on the record STORES doubles the scatter: scattered 16-byte writes lose their write combining)
+__device__ __forceinline__ uint4 ld_rec(const uint4 *p) {
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 
 // Optimiser fused into the consumer (arcn_hashgrid_bwd_lm_adam): the owner of a chunk holds the chunk's COMPLETE gradient in LDS, so it
 // applies Adam (+ EMA write-back) to its rows right there - parameter and moments read and written once, the gradient never goes to
