@@ -188,6 +188,24 @@ class ActFn(torch.autograd.Function):
         return ActGradFn.apply(x, g, ctx.act, ctx.beta), None, None
 
 
+class HuberMeanFn(torch.autograd.Function):
+    """mean(Huber_delta(x - y)) of the reference's ImgLoss (arcnerf/loss/img_loss.py:80-100: 0.5 / delta d^2 inside the band, |d| - 0.5 delta
+    outside) with its gradient in the same kernel (arcn_huber_loss_grad): three launches for what the elementwise chain does in fourteen"""
+
+    @staticmethod
+    def forward(ctx, x, y, delta):
+        loss, dx = F.huber_loss_grad(x.contiguous(), y.contiguous(), delta, 1.0)
+        ctx.save_for_backward(dx)
+        ctx.shape = x.shape
+        return loss[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        dx, = ctx.saved_tensors
+        return (dx * g).view(ctx.shape), None, None
+
+
 class FusedMlpFn(torch.autograd.Function):
     """y = MLP(x; flat weights[, flat biases]) on the f32-MFMA fused kernel."""
 

@@ -37,6 +37,16 @@ class ImgLoss(nn.Module):
 
     def forward(self, data, output):
         gt = data['img'].to(output[self.keys[0]].device)
+        if (isinstance(self.loss, HuberLoss) and self.do_mean and not self.use_mask and self.internal_weights is None and gt.is_cuda
+                and gt.dtype == torch.float32 and all(output[k].is_cuda and output[k].dtype == torch.float32 and output[k].shape == gt.shape
+                                                      for k in self.keys)):
+            # the NGP recipe (Huber, plain mean): value and gradient from one kernel per key
+            from ..ops.autograd import HuberMeanFn
+            total = None
+            for k in self.keys:
+                v = HuberMeanFn.apply(output[k], gt, float(self.loss.delta))
+                total = v if total is None else total + v
+            return total
         loss = 0.0
         for i, k in enumerate(self.keys):
             w = 1.0 if self.internal_weights is None else self.internal_weights[i]

@@ -1721,3 +1721,19 @@ def test_fused_mlp_squareplus_trains_and_sine_is_forward_only(F):
         assert float((ys - torch.sin(x @ V0.t()) @ V1.t()).abs().max()) < 1e-5
     with pytest.raises(RuntimeError, match='Sine'):
         sine(x).sum().backward()
+
+
+def test_imgloss_huber_fused_equals_the_elementwise_form(F):
+    """trainer.ImgLoss (Huber, plain mean) takes value and gradient from one kernel on CUDA tensors (ops.autograd.HuberMeanFn); the
+    masked / weighted forms keep the reference's elementwise chain (loss/img_loss.py:60-100).  Same loss and gradient."""
+    from arcnerf_amd import trainer as T
+    torch.manual_seed(2)
+    x = torch.rand(1, 777, 3, device='cuda', requires_grad=True)
+    y = torch.rand(1, 777, 3, device='cuda')
+    cfg = type('C', (), dict(keys=['rgb_coarse'], loss_type='Huber', delta=0.1, weight=3000.0))()
+    fused = T.ImgLoss(cfg)({'img': y}, {'rgb_coarse': x})
+    gf, = torch.autograd.grad(fused * 3000.0, x)
+    a = (x - y).abs()
+    ref = torch.where(a < 0.1, 0.5 / 0.1 * a ** 2, a - 0.05).mean()
+    gr, = torch.autograd.grad(ref * 3000.0, x)
+    assert abs(float(fused) - float(ref)) <= 1e-6 * float(ref) and float((gf - gr).abs().max()) <= 1e-5 * float(gr.abs().max())
