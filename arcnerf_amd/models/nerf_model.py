@@ -253,10 +253,17 @@ class NeRF(FgModel):
         g, r = self.coarse_geo_net, self.coarse_radiance_net
         rgb, depth, mask, counts = _PackedRenderFn.apply(rays_o, rays_d, bkg, g.embed_fn.embeddings, g.layers.params,
                                                         r.layers.params, pipe, train, noise_std)
-        hit = counts > 0
         if not inference_only and not torch.cuda.is_current_stream_capturing():   # (a recorded step: the recorder adds the measurement after each replay)
             self.adjust_dynamicbs_factor(n_valid=pipe.n_dev[0])
-        # defaults of FgModel.update_values_for_invalid_rays for rays without samples
+        rgb, depth = self._packed_defaults(rgb, depth, counts, bkg)
+        out = {'rgb': rgb, 'depth': depth, 'mask': mask}
+        if inference_only:
+            return out
+        return {k + '_coarse': v for k, v in out.items()}
+
+    def _packed_defaults(self, rgb, depth, counts, bkg):
+        """defaults of FgModel.update_values_for_invalid_rays for rays without samples"""
+        hit = counts > 0
         far = getattr(self, '_depth_far_dev', None)    # (a one-element tensor kept on the device: no fill launch per call)
         if far is None or far.device != depth.device or float(self.render_cfgs['depth_far']) != self._depth_far_val:
             self._depth_far_val = float(self.render_cfgs['depth_far'])
@@ -265,10 +272,7 @@ class NeRF(FgModel):
         if bkg is None:
             dflt = torch.tensor(self.render_cfgs['bkg_color'], dtype=rgb.dtype, device=rgb.device)[None]
             rgb = torch.where(hit[:, None], rgb, dflt.expand_as(rgb))
-        out = {'rgb': rgb, 'depth': depth, 'mask': mask}
-        if inference_only:
-            return out
-        return {k + '_coarse': v for k, v in out.items()}
+        return rgb, depth
 
     def forward(self, inputs, inference_only=False, get_progress=False, cur_epoch=0, total_epoch=300000):
         if not get_progress and self.packed_path_eligible() and inputs['rays_o'].is_cuda:

@@ -191,6 +191,9 @@ class StepLoss:
 
     __float__ = item
 
+    def detach(self):
+        return self.tensor().detach()
+
     def __repr__(self):
         return 'StepLoss({})'.format(self.item())
 
@@ -784,16 +787,18 @@ class NgpPipeline:
                 self._ws_clear = True
                 return
             if 1 < len(self._adam_rest) <= 4:      # the small levels in front of the fused ones and the MLP weights behind them: one launch
-                F.adam_ema_step_runs(fld.params, fld.grads, self.exp_avg, self.exp_avg_sq, self.ema, self._adam_rest, self.step_count, lr=cfg.lr,
-                                     betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, ema_decay=cfg.ema_decay, grad_scale=1.0,
+                F.adam_ema_step_runs(fld.params, fld.grads, self.exp_avg, self.exp_avg_sq, self.ema if cfg.ema_decay is not None else None, self._adam_rest,
+                                     self.step_count, lr=cfg.lr, betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay,
+                                     ema_decay=cfg.ema_decay if cfg.ema_decay is not None else 0.0, grad_scale=1.0,
                                      ema_step=self.ema_n_step, zero_grad=True)
                 return
             slices = [slice(a, b_) for a, b_ in self._adam_rest]
         else:
             slices = [slice(lo, hi)]
+        with_ema = cfg.ema_decay is not None      # (None: plain Adam - the drop-in step of an optimiser built without an EMA)
         for sl in slices:
-            F.adam_ema_step(fld.params[sl], fld.grads[sl], self.exp_avg[sl], self.exp_avg_sq[sl], self.ema[sl], self.step_count, lr=cfg.lr,
-                            betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, ema_decay=cfg.ema_decay,
+            F.adam_ema_step(fld.params[sl], fld.grads[sl], self.exp_avg[sl], self.exp_avg_sq[sl], self.ema[sl] if with_ema else None, self.step_count,
+                            lr=cfg.lr, betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, ema_decay=cfg.ema_decay if with_ema else 0.0,
                             grad_scale=1.0 / world_size, ema_step=self.ema_n_step, zero_grad=True)
 
     def train_step(self, rays_o, rays_d, target_rgb, bkg_color=None, all_reduce=None, world_size=1, next_rays=None, grad_sync=None):

@@ -4,9 +4,10 @@
 checkpoint rotation and evaluation are the caller's (out of scope)."""
 from .dynamic_bs import DynamicBsMeter
 from .ema import EMA
+from .fused_step import FusedNgpStep
 from .graph import GraphedTrainStep
 from .loss import AllLoss, HuberLoss, ImgLoss, build_loss
 from .pipeline import Pipeline
 from .step import step_optimize, train_epoch
 
-__all__ = ['AllLoss', 'DynamicBsMeter', 'EMA', 'GraphedTrainStep', 'HuberLoss', 'ImgLoss', 'build_loss', 'Pipeline', 'step_optimize', 'train_epoch']
+__all__ = ['AllLoss', 'DynamicBsMeter', 'EMA', 'FusedNgpStep', 'GraphedTrainStep', 'HuberLoss', 'ImgLoss', 'build_loss', 'Pipeline', 'step_optimize', 'train_epoch']

@@ -1,0 +1,228 @@
+"""The drop-in NGP training step on the packed pipeline's FUSED step.
+
+`build_model(configs/nerf_ngp.yaml)` + `FusedAdam(...).flatten()` + the reference's ImgLoss(Huber) describe exactly what
+`NgpPipeline.train_step` computes - the module path just spells it as ~45 launches (model.forward, the loss chain, autograd, the
+optimiser) where the pipeline has 14: compositing + Huber loss + their backward in one kernel, the optimiser inside the scatter's
+consumer, the step's tail as one launch, the marching of the NEXT batch on a second stream.  The flattened optimiser already keeps the
+parameters, gradients and moments in the pipeline's flat layout [table | geometry weights | radiance weights], so this class binds an
+NgpPipeline to THOSE buffers and runs the step there: the model, its state_dict, the optimiser's state_dict and `model.optimize` (the
+occupancy refresh of the module's own Volume) stay what they are, inference goes through the module as before.
+
+    stepper = FusedNgpStep(model, loss_factory, optimizer, ema)          # raises if the combination is not the NGP recipe
+    output, loss = stepper(feed_in, epoch, next_feed_in=batch_of_the_next_step)   # in place of trainer.step_optimize
+
+The first steps (an all-ones bitfield asks for R x n_sample samples) run through the module path, which sizes the sample buffers;
+a step that would overflow them is detected a step later (the sample total travels to pinned memory) and the buffers grow.
+"""
+import copy
+import warnings
+
+import torch
+
+from ..models.nerf_model import NeRF
+from ..ops.volume_func import sampler_rng
+from ..optim import FusedAdam
+from ..pipeline import NgpField, NgpPipeline
+from ..utils.replay import copy_words
+from .loss import AllLoss, HuberLoss, ImgLoss
+from .step import step_optimize
+
+
+class FusedNgpStep:
+    SENTINEL = -(1 << 30)
+
+    @staticmethod
+    def why_not(model, loss_factory, optimizer):
+        """None when the combination is the NGP recipe this step implements, else the reason"""
+        fg = model.fg_model
+        if not (isinstance(fg, NeRF) and fg.packed_path_eligible() and model.bkg_model is None):
+            return 'the model is not the packed instant-ngp NeRF without a background model'
+        if not hasattr(fg.obj_bound, 'volume'):
+            return 'the object bound is not a VolumeBound'
+        if not (isinstance(optimizer, FusedAdam) and optimizer._flat is not None and len(optimizer._flat) == 1):
+            return 'the optimiser is not a FusedAdam with ONE flattened parameter group'
+        want = [fg.coarse_geo_net.embed_fn.embeddings, fg.coarse_geo_net.layers.params, fg.coarse_radiance_net.layers.params]
+        have = optimizer._flat[0]['list']
+        if len(have) != 3 or any(a is not b for a, b in zip(have, want)):
+            return 'the optimiser does not hold exactly [hash table, geometry weights, radiance weights]'
+        if not (isinstance(loss_factory, AllLoss) and len(loss_factory.funcs) == 1 and isinstance(loss_factory.funcs[0], ImgLoss)):
+            return 'the loss is not a single ImgLoss'
+        il = loss_factory.funcs[0]
+        if not (isinstance(il.loss, HuberLoss) and list(il.keys) == ['rgb_coarse'] and il.do_mean and not il.use_mask and il.internal_weights is None):
+            return 'the ImgLoss is not the plain Huber mean on rgb_coarse'
+        if optimizer.ema_decay is not None and not optimizer.ema_in_param and optimizer._flat[0]['ema'] is None:
+            return 'the optimiser has an EMA decay but no shadow'
+        return None
+
+    def __init__(self, model, loss_factory, optimizer, ema=None, warmup=2, total_epoch=300000, max_rays=None):
+        reason = self.why_not(model, loss_factory, optimizer)
+        if reason is not None:
+            raise RuntimeError('FusedNgpStep: ' + reason)
+        self.model, self.fg, self.loss_factory, self.opt, self.ema = model, model.fg_model, loss_factory, optimizer, ema
+        self.total_epoch = total_epoch
+        self._eager_left = int(warmup)
+        self.pipe = None
+        self._bits_key = None
+        self._pending = []
+        self._host_total = torch.zeros(256, dtype=torch.int32).pin_memory()
+        self._np_total = self._host_total.numpy()
+        self._slot = 0
+        self.steps = 0
+        self.max_rays = max_rays        # ray capacity of the buffers (default: the model's chunk_rays, else 32768; grows with the batches)
+        if self.max_rays is None:
+            self.max_rays = int(self.fg.chunk_rays) if getattr(self.fg, 'chunk_rays', None) and self.fg.chunk_rays > 0 else 32768
+        self._ahead = None              # (epoch, feed_in) drawn one step early by trainer.train_epoch, its marching already issued
+        self._ahead_marched = False
+        self.rebuilds = 0
+
+    # ---- the pipeline on the optimiser's flat buffers --------------------------------------------------------------------------------
+    def _build(self, device, n_rays, min_samples=0):
+        fg, fb = self.fg, self.opt._flat[0]
+        mp = fg._packed_pipeline(device)                      # the module's own pipeline: configuration + descriptors + sized buffers
+        cfg = copy.copy(mp.cfg)
+        il = self.loss_factory.funcs[0]
+        cfg.huber_delta, cfg.loss_weight = float(il.loss.delta), float(self.loss_factory.weights[0])
+        fld = NgpField.__new__(NgpField)
+        src = mp.field
+        fld.cfg, fld.device = cfg, device
+        for k in ('resolutions', 'offsets', 'min_xyz', 'max_xyz', 'grid_desc', 'geo_desc', 'rad_desc', 'geo_dims', 'rad_dims', 'geo_out_dim', 'feat_off'):
+            setattr(fld, k, getattr(src, k))
+        slots = fb['slots']
+        fld._seg = {'table': slots[0], 'geo_w': slots[1], 'rad_w': slots[2], 'geo_b': (0, 0), 'rad_b': (0, 0)}
+        fld.n_table, fld.n_geo_w, fld.n_rad_w, fld.n_geo_b, fld.n_rad_b = slots[0][1], slots[1][1], slots[2][1], 0, 0
+        fld.n_params = fb['params'].numel()
+        fld.params, fld.grads = fb['params'], fb['grads']
+        # (the module's own pipeline keeps >= 2^20 sample slots for 32768-ray inference chunks; every launch of the step is sized by the
+        # capacity, so this one holds 1.5 x what the last steps asked for and is rebuilt when the demand leaves [cap / 4, cap])
+        max_rays = max(int(n_rays), int(self.max_rays or 0))
+        cap = max(int(min_samples), 2 * max_rays, 1 << 16)
+        if self.pipe is not None and self._ahead_marched:
+            # the batch of the coming step was marched ahead into the buffers being dropped: it is marched again, as the same launch of the
+            # sampler's stream (volume_func_kernel.cu:283-289: one 2^32 jump per launch)
+            sampler_rng().advance((1 << 64) - (1 << 32))
+            self._ahead_marched = False
+        pipe = NgpPipeline(fld, max_rays=max_rays, max_samples=cap, packed_bits=True, prefetch_depth=1)
+        pipe.exp_avg, pipe.exp_avg_sq = fb['exp_avg'], fb['exp_avg_sq']
+        if self.opt.ema_decay is None:
+            cfg.ema_decay = None
+            pipe.ema = fld.params
+        else:
+            cfg.ema_decay = float(self.opt.ema_decay)
+            pipe.ema = fld.params if self.opt.ema_in_param else fb['ema']
+        pipe.rng = sampler_rng()                                # the process-wide sampler stream, shared with the module path
+        self.pipe, self._bits_key = pipe, None
+        self._pending.clear()
+        self.rebuilds += 1
+
+    def _sync_occupancy(self):
+        bf = self.fg.obj_bound.volume.get_voxel_bitfield(flatten=True)
+        key = (id(self.pipe), bf.data_ptr(), bf._version)
+        if self._bits_key != key:
+            self.pipe.set_bitfield(bf)
+            self._bits_key = key
+
+    @staticmethod
+    def _slots_for(need):
+        return (int(need * 1.5) + 1023) // 1024 * 1024
+
+    def _check_capacity(self, n_rays):
+        """the sample totals of the steps that have finished (pinned memory, written by a kernel at the end of each step): the rate that
+        sizes the buffers, and the report of a step that filled them"""
+        while self._pending:
+            slot, cap, rays = self._pending[0]
+            need = int(self._np_total[slot])
+            if need == self.SENTINEL:
+                if len(self._pending) <= 8:
+                    break
+                torch.cuda.current_stream().synchronize()
+                need = int(self._np_total[slot])
+            self._pending.pop(0)
+            self.fg._samples_per_ray = need / max(1, rays)
+            if need >= cap:
+                warnings.warn('FusedNgpStep: a training step filled the sample buffers ({} slots for {} rays): the rays past the capacity were '
+                              'rendered with truncated sample sets in that step; the buffers grow now'.format(cap, rays))
+                self.fg._samples_per_ray = max(self.fg._samples_per_ray, 2.0 * cap / max(1, rays))
+        rate = getattr(self.fg, '_samples_per_ray', None)
+        pipe = self.pipe
+        if pipe is None or pipe.max_rays < n_rays:
+            return True
+        if rate is None:
+            return False
+        want = min(self._slots_for(rate * n_rays), max(n_rays * pipe.cfg.n_sample, 1 << 16))
+        return want > pipe.cap or 4 * want < pipe.cap
+
+    # ---- the batch drawn one step early (trainer.train_epoch) ----------------------------------------------------------------------------
+    def can_run_ahead(self, epoch):
+        """True when nothing the trainer does at `epoch` before the step can change what that step's marching reads: no refresh of the
+        bound's occupancy (VolumeBound.optimize: epoch % epoch_optim == 0) - then the batch can be drawn and marched a step early"""
+        if self._eager_left > 0 or self.pipe is None:
+            return False
+        every = self.fg.obj_bound.get_optim_cfgs('epoch_optim')
+        return not (epoch > 0 and every is not None and epoch % every == 0)
+
+    def hold_ahead(self, epoch, feed_in):
+        self._ahead = (epoch, feed_in)
+
+    def take_ahead(self, epoch):
+        ahead, self._ahead = self._ahead, None
+        return ahead[1] if ahead is not None and ahead[0] == epoch else None
+
+    # ---- the iteration --------------------------------------------------------------------------------------------------------------------
+    def __call__(self, feed_in, epoch=0, next_feed_in=None):
+        """one training iteration on `feed_in` ((B, N, 3) rays_o / rays_d / img [/ bkg_color]), like trainer.step_optimize: -> (output, loss).
+        next_feed_in: the batch of the FOLLOWING call (the same tensors must be passed then): marched on the second stream meanwhile."""
+        dev = feed_in['rays_o'].device
+        n_rays = feed_in['rays_o'].shape[0] * feed_in['rays_o'].shape[1]
+        if self._eager_left > 0:      # the module path: its exact first step sizes everything (all-ones bitfield: R x n_sample samples)
+            self._eager_left -= 1
+            return step_optimize(self.model, feed_in, self.loss_factory, self.opt, self.ema, epoch, self.total_epoch)
+        if self.pipe is None:
+            self.fg._check_deferred_overflow(dev)          # (the sample total of the last eager step)
+            if not self.opt.zero_grad_on_step:
+                self.opt.zero_grad()                       # the step accumulates into the flat gradient and clears it in the optimiser pass
+        if self._check_capacity(n_rays):
+            rate = getattr(self.fg, '_samples_per_ray', None)
+            n_sample = self.fg.get_n_coarse_sample()
+            need = n_rays * n_sample if rate is None else min(self._slots_for(rate * n_rays), n_rays * n_sample)
+            if self.pipe is not None:
+                torch.cuda.synchronize()
+            self._build(dev, n_rays, min_samples=need)
+        pipe, fb, group = self.pipe, self.opt._flat[0], self.opt.param_groups[0]
+        for p, (o, n) in zip(fb['list'], fb['slots']):
+            if p.data_ptr() != fb['params'].data_ptr() + 4 * o:
+                raise RuntimeError('FusedNgpStep: a parameter was re-assigned after FusedAdam.flatten()')
+        cfg = pipe.cfg
+        cfg.lr, cfg.betas, cfg.eps, cfg.weight_decay = float(group['lr']), tuple(group['betas']), float(group['eps']), float(group['weight_decay'])
+        if abs(float(self.opt.grad_scale) - 1.0) > 0:
+            raise RuntimeError('FusedNgpStep is the single-GPU step (FusedAdam.grad_scale must be 1)')
+        pipe.step_count = int(fb['step'])
+        pipe.ema_n_step = int(fb['step']) if self.opt.ema_n_step is None else int(self.opt.ema_n_step)
+        self._sync_occupancy()
+        o, d, img = feed_in['rays_o'].reshape(-1, 3), feed_in['rays_d'].reshape(-1, 3), feed_in['img'].reshape(-1, 3)
+        bkg = feed_in['bkg_color'].reshape(-1, 3) if feed_in.get('bkg_color') is not None else None
+        nxt = None
+        if next_feed_in is not None and next_feed_in['rays_o'].shape[0] * next_feed_in['rays_o'].shape[1] <= pipe.max_rays:
+            nxt = (next_feed_in['rays_o'].reshape(-1, 3), next_feed_in['rays_d'].reshape(-1, 3))
+        loss = pipe.train_step(o, d, img, bkg_color=bkg, next_rays=nxt)
+        self._ahead_marched = nxt is not None
+        # the counters the optimiser / EMA objects expose
+        fb['step'] = pipe.step_count
+        for p in fb['list']:
+            self.opt.state[p]['step'] = fb['step']
+        if self.opt.ema_n_step is not None:
+            self.opt.ema_n_step = pipe.ema_n_step
+        if self.ema is not None:
+            self.ema.n_step += 1
+        self.steps += 1
+        # the measurement of the dynamic batch size + this step's sample total (a kernel writing pinned memory, read a step later)
+        self.fg.adjust_dynamicbs_factor(n_valid=pipe.n_dev[0])
+        slot = self._slot
+        self._slot = (slot + 1) % self._host_total.numel()
+        self._np_total[slot] = self.SENTINEL
+        copy_words(pipe.n_dev, self._host_total[slot:slot + 1])
+        self._pending.append((slot, pipe.cap, n_rays))
+        b, n = feed_in['rays_o'].shape[:2]
+        rgb, depth = self.fg._packed_defaults(pipe.buf['rgb'][:n_rays], pipe.buf['depth'][:n_rays], pipe.buf['counts'][:n_rays], bkg)
+        out = {'rgb_coarse': rgb.view(b, n, 3), 'depth_coarse': depth.view(b, n), 'mask_coarse': pipe.buf['mask'][:n_rays].view(b, n)}
+        name = self.loss_factory.names[0] if hasattr(self.loss_factory, 'names') else 'ImgLoss'
+        return out, {'sum': loss, 'names': [name], name: loss}

@@ -29,6 +29,11 @@ class Pipeline(object):
         else:
             self.set_info('dynamic_batch_size', 0)
 
+    def will_update_dynamic_bs(self, epoch):
+        """the condition of fetch_step_update_dynamic_bs (pipeline.py:226-228) alone"""
+        every = self.get_info('dynamic_batch_size')
+        return every > 0 and epoch % every == 0 and epoch > 500
+
     def fetch_step_update_dynamic_bs(self, epoch, model):
         """pipeline.py:222-241: every `update_epoch` epochs AFTER epoch 500 the batch becomes n_rays x (the model's measured factor),
         rounded up to a multiple of 128 (on the float product, as the reference's `div_round_up` does) and capped.  `model`: anything with

@@ -19,9 +19,25 @@ def step_optimize(model, feed_in, loss_factory, optimizer, ema=None, epoch=0, to
     return output, loss
 
 
-def train_epoch(model, get_batch, loss_factory, optimizer, ema, pipeline, epoch, total_epoch=300000):
+def train_epoch(model, get_batch, loss_factory, optimizer, ema, pipeline, epoch, total_epoch=300000, stepper=None):
     """train_epoch's order: model.optimize(epoch) (the bound's periodic refresh), the dynamic batch size, then the step.
-    get_batch(n_rays) -> feed_in dict."""
-    model.optimize(epoch)
-    n_rays = pipeline.fetch_step_update_dynamic_bs(epoch, model)
-    return step_optimize(model, get_batch(n_rays), loss_factory, optimizer, ema, epoch, total_epoch)
+    get_batch(n_rays) -> feed_in dict.
+    stepper: a trainer.FusedNgpStep / GraphedTrainStep in place of step_optimize.  A FusedNgpStep is also handed the batch of epoch + 1
+    when neither model.optimize(epoch + 1) nor the batch-size rule can act at that epoch (then the order "optimize, batch size, batch"
+    of epoch + 1 commutes with this step): its marching runs on the second stream during this step's backward."""
+    if stepper is None:
+        model.optimize(epoch)
+        n_rays = pipeline.fetch_step_update_dynamic_bs(epoch, model)
+        return step_optimize(model, get_batch(n_rays), loss_factory, optimizer, ema, epoch, total_epoch)
+    feed_in = stepper.take_ahead(epoch) if hasattr(stepper, 'take_ahead') else None
+    if feed_in is None:
+        model.optimize(epoch)
+        n_rays = pipeline.fetch_step_update_dynamic_bs(epoch, model)
+        feed_in = get_batch(n_rays)
+    if not hasattr(stepper, 'can_run_ahead'):
+        return stepper(feed_in, epoch)
+    nxt = None
+    if epoch + 1 < total_epoch and stepper.can_run_ahead(epoch + 1) and not pipeline.will_update_dynamic_bs(epoch + 1):
+        nxt = get_batch(pipeline.get_info('n_rays'))
+        stepper.hold_ahead(epoch + 1, nxt)
+    return stepper(feed_in, epoch, next_feed_in=nxt)

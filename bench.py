@@ -303,14 +303,22 @@ def bench_module(args, name, emit=True):
             return r
         Fn.pack_dense_samples_end = counting_pack
 
-    # the drop-in NGP step as ONE HIP-graph launch (trainer.GraphedTrainStep; ARCN_MODULE_GRAPH=0: every kernel issued eagerly)
-    graphed = None
-    if name == 'ngp_module' and not use_dist and os.environ.get('ARCN_MODULE_GRAPH', '1') != '0':
+    # the drop-in NGP step (ARCN_MODULE_STEP): `fused` (default) = trainer.FusedNgpStep, the module API on the pipeline's fused step (loss in the
+    # compositor, optimiser in the scatter, the next batch marched a step early); `graph` = trainer.GraphedTrainStep, the module path's own
+    # launches as one HIP-graph replay; `eager` = every kernel of the module path issued eagerly
+    graphed = fused = None
+    mode = os.environ.get('ARCN_MODULE_STEP', 'fused' if os.environ.get('ARCN_MODULE_GRAPH', '1') != '0' else 'eager')
+    if name == 'ngp_module' and not use_dist and mode == 'graph':
         from arcnerf_amd.trainer import GraphedTrainStep
         graphed = GraphedTrainStep(m, lambda inp, out: {'sum': loss_of(out, inp)}, opt)
+    if name == 'ngp_module' and not use_dist and mode == 'fused':
+        from arcnerf_amd.trainer import FusedNgpStep
+        fused = FusedNgpStep(m, ngp_loss, opt, None, max_rays=n_rays)
 
     def step(i):
         inp = pool[i % len(pool)]
+        if fused is not None:
+            return fused(inp, 20000 + i, next_feed_in=pool[(i + 1) % len(pool)])[1]['sum']
         if graphed is not None:
             return graphed({k: v for k, v in inp.items()}, 20000 + i)[1]['sum']
         out = m({k: v for k, v in inp.items()}, inference_only=False, cur_epoch=20000 + i)
@@ -390,8 +398,10 @@ def bench_module(args, name, emit=True):
         ach = alg / (wall / args.steps)
         roofline = {'kernel': 'hash-grid gather + binned scatter, over the WHOLE step of the module path', 'bound': 'hbm', 'achieved': ach / 1e9,
                     'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': None,
-                    'note': 'the same kernels as the headline step behind the reference-shaped API: marching inline on the step\'s stream, '
-                            'scatter and optimiser as two passes (FusedAdam over the flat buffer, no EMA pass), VolumeBound.optimize at its cadence'}
+                    'note': ('the headline step behind the reference-shaped API (build_model + FusedAdam.flatten + ImgLoss -> trainer.FusedNgpStep): plain Adam '
+                             '(no EMA in this config)' if fused is not None else
+                             'the same kernels as the headline step behind the reference-shaped API: marching inline on the step\'s stream, '
+                             'scatter and optimiser as two passes (FusedAdam over the flat buffer, no EMA pass)')}
     cpu = None
     if world == 1 and not args.no_cpu_baseline and name == 'nerf' and emit:
         cpu = cpu_baseline_nerf()
@@ -404,7 +414,9 @@ def bench_module(args, name, emit=True):
                'chunk_pts': int(m.get_chunk_pts()), 'occupancy': args.occupancy, 'bkg_occupancy': bkg_occ,
                'graph_host_ms_per_replay': ({k: round(v / max(1, graphed.replays) * 1e3, 4) for k, v in graphed.host_s.items()} if graphed is not None else None),
                'launch': ('one HIP-graph replay per step (trainer.GraphedTrainStep, {} replays in this run)'.format(graphed.replays) if graphed is not None
-                          else 'every kernel issued eagerly')},
+                          else ('trainer.FusedNgpStep: the module API on NgpPipeline.train_step over the flattened optimiser\'s buffers, next batch marched a step '
+                                'early ({} steps in this run, {} eager warm-up steps before)'.format(fused.steps, 2) if fused is not None
+                                else 'every kernel of the module path issued eagerly'))},
            'rccl': dist_report(dist, world, LAUNCH, flat_grads.numel() * 4, 1, per_rank, rccl_extra),
            'roofline': roofline, 'cpu_baseline': cpu}
     if emit:

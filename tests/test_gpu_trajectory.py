@@ -306,3 +306,84 @@ def test_graphed_module_step_equals_eager_steps(gpu):
     assert max(abs(a - b) / abs(a) for a, b in zip(la, lb)) < 1e-5, (la, lb)
     far = ((pa - pb).abs() > 1e-3 * float(pa.abs().max())).float().mean()
     assert float(far) < 1e-3, float(far)
+
+
+# ---- the drop-in step on the pipeline's fused step ----------------------------------------------------------------------------------
+def test_fused_module_step_equals_eager_steps(gpu):
+    """trainer.FusedNgpStep runs `model(feed_in) -> ImgLoss -> backward -> FusedAdam.step (+ fused EMA)` of configs/nerf_ngp.yaml as
+    NgpPipeline.train_step on the flattened optimiser's buffers (loss inside the compositor, optimiser inside the scatter, the next
+    batch marched a step early by trainer.train_epoch).  Against the same model trained through trainer.train_epoch's eager form, over
+    epochs 496 .. 519: five occupancy refreshes (every 4 epochs: the step after each marches inline), four changes of the dynamic batch
+    size (epoch > 500), equal ray counts, equal sample counts, the sampler's generator in the same state, losses to 1e-5, the
+    parameters and the optimiser's counters at the end."""
+    from arcnerf_amd import trainer as T
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    from arcnerf_amd.optim import FusedAdam
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    ov = ['--model.rays.noise_std', '0.0', '--model.obj_bound.volume.n_grid', '32', '--model.obj_bound.epoch_optim', '4',
+          '--model.obj_bound.epoch_optim_warmup', '8']
+    loss_cfg = type('C', (), {})()
+    loss_cfg.loss = type('C', (), {})()
+    loss_cfg.loss.ImgLoss = type('C', (), dict(keys=['rgb_coarse'], loss_type='Huber', delta=0.1, weight=3000.0))()
+    epochs = list(range(496, 520))
+    runs = {}
+    for mode in ('eager', 'fused'):
+        torch.manual_seed(5)
+        m = build_model(load_configs(os.path.join(CFG, 'nerf_ngp.yaml'), ov)).to(gpu)
+        fg = m.fg_model
+        assert fg.packed_path_eligible()
+        with torch.no_grad():
+            fg.coarse_geo_net.embed_fn.embeddings.mul_(1000.0)
+        opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=1e-2, eps=1e-15, weight_decay=1e-6, ema_decay=0.95, ema_in_param=True).flatten()
+        ema = T.EMA(m, 0.95, opt)
+        ema.set_n_step(epochs[0])
+        loss_factory = T.build_loss(loss_cfg)
+        tp = T.Pipeline()
+        tp.set_info('n_rays', 256)
+        tp.set_info('dynamic_batch_size', 4)
+        tp.set_info('dynamic_max_batch_size', 1024)
+        sampler_rng(reset=True)
+        m.train()
+        stepper = T.FusedNgpStep(m, loss_factory, opt, ema, max_rays=512) if mode == 'fused' else None
+        drawn = []
+
+        def get_batch(n_rays):
+            k = epochs[0] + len(drawn)          # batches are drawn in epoch order, one per epoch (a step early or not)
+            drawn.append(n_rays)
+            inp = U.step_inputs(k, n_rays)
+            return {'rays_o': torch.from_numpy(inp['rays_o'])[None].to(gpu), 'rays_d': torch.from_numpy(inp['rays_d'])[None].to(gpu),
+                    'rays_r': torch.zeros(1, n_rays, 1, device=gpu), 'img': torch.from_numpy(inp['img'])[None].to(gpu),
+                    'bkg_color': torch.from_numpy(inp['bkg_color'])[None].to(gpu)}
+
+        losses, counts, ahead = [], [], 0
+        for epoch in epochs:
+            if stepper is not None and stepper._ahead is not None:
+                ahead += 1
+                if epoch == 510:    # buffers rebuilt while the batch marched ahead sits in the old ones: marched again, same generator launch
+                    assert stepper._ahead_marched
+                    stepper._build(gpu, 1024, min_samples=stepper.pipe.cap + 1024)
+            out, loss = T.train_epoch(m, get_batch, loss_factory, opt, ema, tp, epoch, total_epoch=epochs[-1] + 1, stepper=stepper)
+            losses.append(float(loss['sum']))
+            pipe = stepper.pipe if stepper is not None and stepper.pipe is not None else fg._pipe
+            counts.append(int(pipe.n_dev.item()))
+        torch.cuda.synchronize()
+        runs[mode] = dict(losses=losses, counts=counts, drawn=drawn, params=opt.flat_params().clone(), rng=sampler_rng().state, step=opt._flat[0]['step'],
+                          ema=(ema.n_step, opt.ema_n_step), occ=float(fg.obj_bound.volume.get_voxel_bitfield().float().mean()),
+                          out={k: v.detach().clone() for k, v in out.items()}, grads=float(opt.flat_grads().abs().max()), ahead=ahead,
+                          steps=stepper.steps if stepper is not None else 0, rebuilds=stepper.rebuilds if stepper is not None else 0)
+    a, b = runs['eager'], runs['fused']
+    assert b['steps'] == len(epochs) - 2 and b['rebuilds'] >= 3      # first build, 256 -> more rays than max_rays, the forced one
+    # a batch is drawn a step early unless its epoch refreshes the occupancy (496 + 4 i) - the batch-size rule acts at the same epochs
+    assert b['ahead'] == sum(1 for e in epochs[4:] if e % 4 != 0), b['ahead']
+    assert a['drawn'] == b['drawn'] and len(set(a['drawn'])) >= 2, (a['drawn'], b['drawn'])
+    assert a['counts'] == b['counts'], (a['counts'], b['counts'])
+    assert a['rng'] == b['rng'] and a['step'] == b['step'] == len(epochs) and a['ema'] == b['ema'] == (epochs[-1] + 1, epochs[-1] + 1)
+    assert 0.0 < a['occ'] < 1.0 and a['occ'] == b['occ']
+    assert max(abs(x - y) / abs(x) for x, y in zip(a['losses'], b['losses'])) < 1e-5, (a['losses'], b['losses'])
+    far = ((a['params'] - b['params']).abs() > 1e-3 * float(a['params'].abs().max())).float().mean()
+    assert float(far) < 1e-3, float(far)
+    assert b['grads'] == 0.0                     # the fused step leaves the flat gradient cleared
+    for k in ('rgb_coarse', 'depth_coarse', 'mask_coarse'):
+        assert a['out'][k].shape == b['out'][k].shape
+        assert torch.allclose(a['out'][k], b['out'][k], rtol=1e-4, atol=1e-4), k
