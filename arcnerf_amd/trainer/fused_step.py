@@ -93,9 +93,10 @@ class FusedNgpStep:
         fld.n_params = fb['params'].numel()
         fld.params, fld.grads = fb['params'], fb['grads']
         # (the module's own pipeline keeps >= 2^20 sample slots for 32768-ray inference chunks; every launch of the step is sized by the
-        # capacity, so this one holds 1.5 x what the last steps asked for and is rebuilt when the demand leaves [cap / 4, cap])
+        # capacity: this one holds twice what the last step asked for; _check_capacity says when it is rebuilt)
         max_rays = max(int(n_rays), int(self.max_rays or 0))
         cap = max(int(min_samples), 2 * max_rays, 1 << 16)
+        self.max_rays = max_rays
         if self.pipe is not None and self._ahead_marched:
             # the batch of the coming step was marched ahead into the buffers being dropped: it is marched again, as the same launch of the
             # sampler's stream (volume_func_kernel.cu:283-289: one 2^32 jump per launch)
@@ -123,7 +124,9 @@ class FusedNgpStep:
 
     @staticmethod
     def _slots_for(need):
-        return (int(need * 1.5) + 1023) // 1024 * 1024
+        """capacity built for a demand of `need` samples: twice that (the launches are sized by the capacity, but their idle workgroups
+        leave at once - the headline bench runs 2.6e5 samples in 2^20 slots - while a rebuild costs milliseconds)"""
+        return (int(need * 2.0) + 4095) // 4096 * 4096
 
     def _check_capacity(self, n_rays):
         """the sample totals of the steps that have finished (pinned memory, written by a kernel at the end of each step): the rate that
@@ -148,8 +151,15 @@ class FusedNgpStep:
             return True
         if rate is None:
             return False
-        want = min(self._slots_for(rate * n_rays), max(n_rays * pipe.cfg.n_sample, 1 << 16))
-        return want > pipe.cap or 4 * want < pipe.cap
+        # grow before a step that could come within 25 % of the capacity (the batches of one run differ by a few percent in samples per
+        # ray), shrink when an eighth would do (the all-ones bitfield of a fresh model against the pruned one a few hundred steps later)
+        full = n_rays * pipe.cfg.n_sample
+        return min(1.25 * rate * n_rays, full) > pipe.cap or 8 * self._target_cap(rate, n_rays, pipe.max_rays) <= pipe.cap
+
+    def _target_cap(self, rate, n_rays, max_rays):
+        full = n_rays * self.fg.get_n_coarse_sample()
+        need = full if rate is None else min(self._slots_for(rate * n_rays), full)
+        return max(int(need), 2 * int(max_rays), 1 << 16)
 
     # ---- the batch drawn one step early (trainer.train_epoch) ----------------------------------------------------------------------------
     def can_run_ahead(self, epoch):
@@ -182,8 +192,7 @@ class FusedNgpStep:
                 self.opt.zero_grad()                       # the step accumulates into the flat gradient and clears it in the optimiser pass
         if self._check_capacity(n_rays):
             rate = getattr(self.fg, '_samples_per_ray', None)
-            n_sample = self.fg.get_n_coarse_sample()
-            need = n_rays * n_sample if rate is None else min(self._slots_for(rate * n_rays), n_rays * n_sample)
+            need = self._target_cap(rate, n_rays, max(n_rays, self.max_rays))
             if self.pipe is not None:
                 torch.cuda.synchronize()
             self._build(dev, n_rays, min_samples=need)
