@@ -23,10 +23,10 @@ from arcnerf_amd.ops import functional as F
 from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline
 from arcnerf_amd.render.ray_helper import get_rays
 
-def run(MAX_IT=10000, seed=0, verbose=True):
-    """train the NGP pipeline on the analytic scene for MAX_IT iterations -> dict (see the module docstring)"""
+def build_scene():
+    """the analytic scene's data on cuda:0 -> dict(dev, train [(rays_o, rays_d, rgb, white bkg)] x 100 views of R_MAX rays, test [(rays_o, rays_d,
+    rgb)] x 4 held-out views, R_MAX, seconds, sha)"""
     dev = torch.device('cuda:0')
-    REPORT = [i for i in (100, 500, 2000, 10000, 30000, 50000) if i <= MAX_IT]
     HW, ANGLE, RADIUS = 800, 0.6911, 3.0 / 1.05
     g = torch.Generator(device='cpu').manual_seed(0)
 
@@ -103,6 +103,14 @@ def run(MAX_IT=10000, seed=0, verbose=True):
     import hashlib as _hh
     DATA_SHA = _hh.sha256(b''.join(t[2].cpu().numpy().tobytes() for t in train[:8]) + b''.join(t[0].cpu().numpy().tobytes() + t[1].cpu().numpy().tobytes() for t in train[:8])).hexdigest()[:12]
     print('data sha', DATA_SHA, file=sys.stderr)
+    return {'dev': dev, 'train': train, 'test': test, 'R_MAX': R_MAX, 'seconds': t_data, 'sha': DATA_SHA}
+
+
+def run(MAX_IT=10000, seed=0, verbose=True):
+    """train the NGP pipeline on the analytic scene for MAX_IT iterations -> dict (see the module docstring)"""
+    REPORT = [i for i in (100, 500, 2000, 10000, 30000, 50000) if i <= MAX_IT]
+    sc = build_scene()
+    dev, train, test, R_MAX, t_data = sc['dev'], sc['train'], sc['test'], sc['R_MAX'], sc['seconds']
 
     cfg = NgpConfig(white_bkg=True)
     fld = NgpField(cfg, device=dev, seed=0)
