@@ -54,8 +54,10 @@ class FusedNgpStep:
             return 'the optimiser has an EMA decay but no shadow'
         return None
 
-    def __init__(self, model, loss_factory, optimizer, ema=None, warmup=2, total_epoch=300000, max_rays=None):
+    def __init__(self, model, loss_factory, optimizer, ema=None, warmup=2, total_epoch=300000, max_rays=None, clip_value=0.0):
         reason = self.why_not(model, loss_factory, optimizer)
+        if reason is None and clip_value > 0.0:
+            reason = 'gradient clipping (clip_value > 0) needs the gradients between backward and the optimiser: use trainer.step_optimize'
         if reason is not None:
             raise RuntimeError('FusedNgpStep: ' + reason)
         self.model, self.fg, self.loss_factory, self.opt, self.ema = model, model.fg_model, loss_factory, optimizer, ema
@@ -73,6 +75,7 @@ class FusedNgpStep:
             self.max_rays = int(self.fg.chunk_rays) if getattr(self.fg, 'chunk_rays', None) and self.fg.chunk_rays > 0 else 32768
         self._ahead = None              # (epoch, feed_in) drawn one step early by trainer.train_epoch, its marching already issued
         self._ahead_marched = False
+        self._after_eager = False
         self.rebuilds = 0
 
     # ---- the pipeline on the optimiser's flat buffers --------------------------------------------------------------------------------
@@ -149,6 +152,8 @@ class FusedNgpStep:
         pipe = self.pipe
         if pipe is None or pipe.max_rays < n_rays:
             return True
+        if pipe.field.params is not self.opt._flat[0]['params']:      # FusedAdam.flatten() ran again (load_state_dict): new flat buffers
+            return True
         if rate is None:
             return False
         # grow before a step that could come within 25 % of the capacity (the batches of one run differ by a few percent in samples per
@@ -178,18 +183,21 @@ class FusedNgpStep:
         return ahead[1] if ahead is not None and ahead[0] == epoch else None
 
     # ---- the iteration --------------------------------------------------------------------------------------------------------------------
-    def __call__(self, feed_in, epoch=0, next_feed_in=None):
+    def __call__(self, feed_in, epoch=0, next_feed_in=None, get_progress=False):
         """one training iteration on `feed_in` ((B, N, 3) rays_o / rays_d / img [/ bkg_color]), like trainer.step_optimize: -> (output, loss).
-        next_feed_in: the batch of the FOLLOWING call (the same tensors must be passed then): marched on the second stream meanwhile."""
+        next_feed_in: the batch of the FOLLOWING call (the same tensors must be passed then): marched on the second stream meanwhile.
+        get_progress: the per-sample outputs of the reference's progress dumps exist on the module path only - that iteration runs there."""
         dev = feed_in['rays_o'].device
         n_rays = feed_in['rays_o'].shape[0] * feed_in['rays_o'].shape[1]
-        if self._eager_left > 0:      # the module path: its exact first step sizes everything (all-ones bitfield: R x n_sample samples)
-            self._eager_left -= 1
-            return step_optimize(self.model, feed_in, self.loss_factory, self.opt, self.ema, epoch, self.total_epoch)
-        if self.pipe is None:
+        if self._eager_left > 0 or get_progress:      # the module path: its exact first step sizes everything (all-ones bitfield: R x n_sample samples)
+            self._eager_left = max(0, self._eager_left - 1)
+            self._after_eager = True
+            return step_optimize(self.model, feed_in, self.loss_factory, self.opt, self.ema, epoch, self.total_epoch, get_progress=get_progress)
+        if self.pipe is None or self._after_eager:
             self.fg._check_deferred_overflow(dev)          # (the sample total of the last eager step)
             if not self.opt.zero_grad_on_step:
                 self.opt.zero_grad()                       # the step accumulates into the flat gradient and clears it in the optimiser pass
+            self._after_eager = False
         if self._check_capacity(n_rays):
             rate = getattr(self.fg, '_samples_per_ray', None)
             need = self._target_cap(rate, n_rays, max(n_rays, self.max_rays))

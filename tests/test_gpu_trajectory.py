@@ -387,3 +387,57 @@ def test_fused_module_step_equals_eager_steps(gpu):
     for k in ('rgb_coarse', 'depth_coarse', 'mask_coarse'):
         assert a['out'][k].shape == b['out'][k].shape
         assert torch.allclose(a['out'][k], b['out'][k], rtol=1e-4, atol=1e-4), k
+
+
+def test_fused_module_step_after_a_reflatten_and_around_a_progress_step(gpu):
+    """FusedAdam.load_state_dict re-homes the flat buffers (the stepper binds the new ones); an iteration with get_progress=True runs on
+    the module path (the per-sample outputs exist there only) with the fused steps continuing after it; gradient clipping is refused"""
+    from arcnerf_amd import trainer as T
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    from arcnerf_amd.optim import FusedAdam
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    ov = ['--model.rays.noise_std', '0.0', '--model.obj_bound.volume.n_grid', '32', '--model.obj_bound.epoch_optim', '4',
+          '--model.obj_bound.epoch_optim_warmup', '8']
+    loss_cfg = type('C', (), {})()
+    loss_cfg.loss = type('C', (), {})()
+    loss_cfg.loss.ImgLoss = type('C', (), dict(keys=['rgb_coarse'], loss_type='Huber', delta=0.1, weight=3000.0))()
+    runs = {}
+    for mode in ('eager', 'fused'):
+        torch.manual_seed(5)
+        m = build_model(load_configs(os.path.join(CFG, 'nerf_ngp.yaml'), ov)).to(gpu)
+        with torch.no_grad():
+            m.fg_model.coarse_geo_net.embed_fn.embeddings.mul_(1000.0)
+        opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=1e-2, eps=1e-15, weight_decay=1e-6, ema_decay=0.95).flatten()   # (a separate EMA shadow)
+        ema = T.EMA(m, 0.95, opt)
+        loss_factory = T.build_loss(loss_cfg)
+        sampler_rng(reset=True)
+        m.train()
+        stepper = T.FusedNgpStep(m, loss_factory, opt, ema) if mode == 'fused' else None
+        if stepper is not None:
+            with pytest.raises(RuntimeError, match='clipping'):
+                T.FusedNgpStep(m, loss_factory, opt, ema, clip_value=0.1)
+        losses = []
+        for k in range(12):
+            m.optimize(k)
+            inp = U.step_inputs(k, 256)
+            feed_in = {'rays_o': torch.from_numpy(inp['rays_o'])[None].to(gpu), 'rays_d': torch.from_numpy(inp['rays_d'])[None].to(gpu),
+                       'rays_r': torch.zeros(1, 256, 1, device=gpu), 'img': torch.from_numpy(inp['img'])[None].to(gpu),
+                       'bkg_color': torch.from_numpy(inp['bkg_color'])[None].to(gpu)}
+            if k == 6:
+                opt.load_state_dict(opt.state_dict())
+            progress = k == 8
+            if stepper is not None:
+                out, loss = stepper(feed_in, k, get_progress=progress)
+            else:
+                out, loss = T.step_optimize(m, feed_in, loss_factory, opt, ema, k, get_progress=progress)
+            if progress:
+                assert any(key.startswith('progress') for key in out), list(out)
+            losses.append(float(loss['sum']))
+        torch.cuda.synchronize()
+        runs[mode] = (losses, opt.flat_params().clone(), opt._flat[0]['step'], ema.n_step, stepper.steps if stepper else 0, stepper.rebuilds if stepper else 0)
+    (la, pa, sa, ea, _, _), (lb, pb, sb, eb, n_fused, rebuilds) = runs['eager'], runs['fused']
+    assert n_fused == 9 and rebuilds == 2 and sa == sb == 12 and ea == eb == 12
+    assert max(abs(a - b) / abs(a) for a, b in zip(la, lb)) < 1e-5, (la, lb)
+    far = ((pa - pb).abs() > 1e-3 * float(pa.abs().max())).float().mean()
+    assert float(far) < 1e-3, float(far)
