@@ -19,6 +19,7 @@ import warnings
 
 import torch
 
+from ..models.base_modules.obj_bound.volume_bound import VolumeBound
 from ..models.nerf_model import NeRF
 from ..ops.volume_func import sampler_rng
 from ..optim import FusedAdam
@@ -37,7 +38,7 @@ class FusedNgpStep:
         fg = model.fg_model
         if not (isinstance(fg, NeRF) and fg.packed_path_eligible() and model.bkg_model is None):
             return 'the model is not the packed instant-ngp NeRF without a background model'
-        if not hasattr(fg.obj_bound, 'volume'):
+        if not isinstance(fg.obj_bound, VolumeBound):       # (a BitfieldBound keeps Morton bits and refreshes them itself: the module path)
             return 'the object bound is not a VolumeBound'
         if not (isinstance(optimizer, FusedAdam) and optimizer._flat is not None and len(optimizer._flat) == 1):
             return 'the optimiser is not a FusedAdam with ONE flattened parameter group'

@@ -366,3 +366,74 @@ def test_trainer_mirror_rules_on_cpu():
             ref = ((1 - 0.95) * cur[k] + 0.95 * old[k] * (1 - 0.95 ** (n_ - 1))) * (1.0 / (1 - 0.95 ** n_))
             assert torch.allclose(q, ref, atol=1e-6)
             old[k] = ref
+
+
+def test_fused_step_refuses_what_it_does_not_implement_and_train_epoch_draws_ahead_only_when_it_commutes():
+    """trainer.FusedNgpStep.why_not names the reason for every combination that is not the NGP recipe (no silent detour); trainer.train_epoch
+    hands a stepper the batch of epoch + 1 only when neither the bound's refresh nor the batch-size rule acts at that epoch"""
+    import os
+    import torch
+    from arcnerf_amd import trainer as T
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    from conftest import ROOT
+    m = build_model(load_configs(os.path.join(ROOT, 'configs', 'nerf_ngp.yaml'), ['--model.obj_bound.volume.n_grid', '16']))
+    cfg = type('C', (), {})()
+    cfg.loss = type('C', (), {})()
+    cfg.loss.ImgLoss = type('C', (), dict(keys=['rgb_coarse'], loss_type='Huber', delta=0.1, weight=3000.0))()
+    lf = T.build_loss(cfg)
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-2)
+    assert 'FusedAdam' in T.FusedNgpStep.why_not(m, lf, opt)
+    with pytest.raises(RuntimeError, match='FusedAdam'):
+        T.FusedNgpStep(m, lf, opt)
+    m2 = build_model(load_configs(os.path.join(ROOT, 'configs', 'nerf.yaml'), []))
+    assert 'packed instant-ngp' in T.FusedNgpStep.why_not(m2, lf, opt)
+
+    # train_epoch's look-ahead: a stand-in stepper records what it is handed
+    class Stepper:
+        def __init__(self):
+            self.calls, self._ahead = [], None
+
+        def can_run_ahead(self, epoch):
+            return epoch % 4 != 0            # (the bound refreshes every 4 epochs)
+
+        def hold_ahead(self, epoch, feed_in):
+            self._ahead = (epoch, feed_in)
+
+        def take_ahead(self, epoch):
+            a, self._ahead = self._ahead, None
+            return a[1] if a is not None and a[0] == epoch else None
+
+        def __call__(self, feed_in, epoch, next_feed_in=None):
+            self.calls.append((epoch, feed_in, next_feed_in))
+            return {}, {'sum': 0.0}
+
+    class Model:
+        def __init__(self):
+            self.optimized = []
+
+        def optimize(self, epoch):
+            self.optimized.append(epoch)
+
+        def get_dynamicbs_factor(self):
+            return 2.0
+
+    tp = T.Pipeline()
+    tp.set_info('n_rays', 128)
+    tp.set_info('dynamic_batch_size', 2)
+    tp.set_info('dynamic_max_batch_size', 1024)
+    st, mdl, drawn = Stepper(), Model(), []
+
+    def get_batch(n):
+        drawn.append(n)
+        return ('batch', len(drawn), n)
+
+    for epoch in range(500, 509):
+        T.train_epoch(mdl, get_batch, lf, None, None, tp, epoch, total_epoch=509, stepper=st)
+    # every epoch's batch is drawn exactly once, in order, with the ray count the rule gives AT that epoch (x 2 at 502, 504, 506, 508)
+    assert [c[1][1] for c in st.calls] == list(range(1, 10))
+    assert drawn == [128, 128, 256, 256, 512, 512, 1024, 1024, 1024]
+    # handed ahead: epoch + 1 odd (no rule, no refresh) and inside the run; model.optimize ran for every epoch whose batch was not drawn ahead
+    assert [c[0] for c in st.calls if c[2] is not None] == [500, 502, 504, 506]
+    assert all(c[2] is st.calls[i + 1][1] for i, c in enumerate(st.calls[:-1]) if c[2] is not None)
+    assert mdl.optimized == [500, 502, 504, 506, 508]
