@@ -249,7 +249,14 @@ class NgpPipeline:
         # multi-rank: the compute units idle while the gradient all-reduce is on the wire - march the next batch there
         self.prefetch_at_dist = 3
         self._prefetch_now = self.prefetch_at
-        self.aux_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+        self.aux_stream = None
+        if dev.type == 'cuda':
+            # ONE batch ahead, the marching chain has exactly the backward of the current step to finish in: on a lower priority than the
+            # step's stream it only gets what the step's kernels leave, and every step then waits for it (measured under a priority -1
+            # current stream: 1.05 ms per step against 0.58) - so it takes the priority of the stream the pipeline is built on.  Two
+            # batches ahead it has a whole step of slack, and a lower priority is what one wants (bench.py's headline: -1 %).
+            prio = torch.cuda.current_stream(dev).priority if self.prefetch_depth == 1 else 0
+            self.aux_stream = torch.cuda.Stream(device=dev, priority=prio) if prio != 0 else torch.cuda.Stream(device=dev)
         self.use_streams = self.aux_stream is not None
         b['feat'] = torch.zeros((S, E), dtype=f32, device=dev)
         b['geo_out'] = torch.zeros((S, field.geo_out_dim), dtype=f32, device=dev)

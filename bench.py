@@ -339,13 +339,21 @@ def bench_module(args, name, emit=True):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    trace, ev_trace = [], [torch.cuda.Event(enable_timing=True)]
+    ev_trace[0].record()
     for i in range(args.steps):
         step(args.warmup + i)
+        if os.environ.get('ARCN_BENCH_TRACE'):
+            trace.append(time.perf_counter() - t0)
+            ev_trace.append(torch.cuda.Event(enable_timing=True))
+            ev_trace[-1].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if trace:
+        print('TRACE', name, [round(t * 1e3, 3) for t in trace], round(dt * 1e3, 3), 'gpu', [round(a.elapsed_time(b), 3) for a, b in zip(ev_trace[:-1], ev_trace[1:])], 'rebuilds', fused.rebuilds if fused is not None else None, file=sys.stderr, flush=True)
     if spec['evals'] is None:
         meter = fg._meter()
         k = int(meter._pending)
@@ -739,7 +747,11 @@ def main():
         import copy
         others = {}
         timers.reset(())           # no event brackets around the module-path configs' launches
-        for name in ('ngp_module', 'nerf', 'neus', 'neus_ngp_multivol', 'hdrnerf'):
+        # (the headline's step runs on a high-priority stream, above; these legs run the way `bench.py --config <name>` does and a trainer would:
+        # on the default stream.  The drop-in NGP step marches ONE batch ahead on a second stream of the same priority - under a high-priority
+        # main stream that chain starves and every step waits for it: 1.05 ms instead of 0.58)
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        for name in (os.environ.get('ARCN_OTHER_CONFIGS', 'ngp_module,nerf,neus,neus_ngp_multivol,hdrnerf').split(',')):
             a2 = copy.copy(args)
             a2.steps, a2.warmup, a2.rays, a2.chunk_pts, a2.no_cpu_baseline = 8, 3, 0, 0, True
             try:
