@@ -256,6 +256,7 @@ class NgpPipeline:
             # current stream: 1.05 ms per step against 0.58) - so it takes the priority of the stream the pipeline is built on.  Two
             # batches ahead it has a whole step of slack, and a lower priority is what one wants (bench.py's headline: -1 %).
             prio = torch.cuda.current_stream(dev).priority if self.prefetch_depth == 1 else 0
+            prio = int(os.environ.get('ARCN_AUX_PRIORITY', prio))
             self.aux_stream = torch.cuda.Stream(device=dev, priority=prio) if prio != 0 else torch.cuda.Stream(device=dev)
         self.use_streams = self.aux_stream is not None
         b['feat'] = torch.zeros((S, E), dtype=f32, device=dev)
