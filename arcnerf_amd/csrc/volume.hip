@@ -583,13 +583,15 @@ struct MarchCull {
     int32_t cn;              // blocks per axis (n_grid / 4); 0: no culling
     const uint64_t *rng_dev; // {state, inc} of the sampler's pcg32 in DEVICE memory (arcn_march_count_replay): a launch recorded in a
                              // HIP graph reads the generator of the replay, not of the capture; nullptr: the by-value state
+    int32_t persist_waves;   // > 0: the launch has this many wavefronts in all and wave w marches the rays w, w + persist_waves, ... (a bounded
+                             // number of resident marcher waves beside the training step's kernels); 0: one wavefront per ray
 };
 
 template <int MODE, bool FUSED>
 __global__ void __launch_bounds__(256)
 march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ aabb,
                    const uint8_t *__restrict__ bf, uint32_t n_grid, uint32_t n_pts, float dt, float near_distance,
-                   int torch_sem, Pcg32 rng, float *__restrict__ scratch_t, int32_t *__restrict__ counts,
+                   int torch_sem, Pcg32 rng0, float *__restrict__ scratch_t, int32_t *__restrict__ counts,
                    float *__restrict__ near_out, float *__restrict__ far_out, const float *__restrict__ near_in,
                    const float *__restrict__ far_in, uint8_t *__restrict__ mask_out, int64_t n_rays, MarchPacked pk, MarchCull cull) {
     const int lane = threadIdx.x & 63;
@@ -604,11 +606,13 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
         blk = s_ticket;
     }
     const int wave_id = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blk * 4 + wave_id;
+    // (persistent form: the same body once per ray of this wave; every ray's jitter comes from the launch's generator advanced by ITS index)
+    const int64_t ray_stride = (!FUSED && cull.persist_waves > 0) ? (int64_t)cull.persist_waves : (int64_t)1 << 40;
+    for (int64_t i = (int64_t)blk * 4 + wave_id; FUSED || i < n_rays; i += ray_stride) {
     const bool in_range = i < n_rays;
-    if (!FUSED && !in_range) return;
     uint32_t j = 0;
     if (in_range) {
+    Pcg32 rng = rng0;
     if (cull.rng_dev) { rng.state = cull.rng_dev[0]; rng.inc = cull.rng_dev[1]; }
     rng.advance((int64_t)(uint32_t)((uint32_t)i * 8u));
     const Aabb b = load_aabb(aabb);
@@ -848,6 +852,7 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
             else zr[k] = last;
         }
     }
+    }   // rays of this wave
 }
 
 // pass 2: exclusive scan of int32 counts, single workgroup (n_rays is a few 10^4..10^6): 1024 threads, each owning a
@@ -1133,6 +1138,13 @@ static int march_count_impl(const float *rays_o, const float *rays_d, const floa
         return einval("march_count: missing/invalid argument");
     Pcg32 rng{rng_state, rng_inc};
     dim3 grid((unsigned)ceil_div<int64_t>(n_rays, 4));
+    // cull.persist_waves = P: P wavefronts in all, wave w marches the rays w, w + P, ... (arcn_march_count_waves)
+    if (cull.persist_waves >= 4 && n_rays > cull.persist_waves) {
+        cull.persist_waves &= ~3;
+        grid = dim3((unsigned)(cull.persist_waves / 4));
+    } else {
+        cull.persist_waves = 0;
+    }
     if (bitfield_is_packed == 2 && (n_grid > 1024 || (n_grid & (n_grid - 1))))
         return einval("march_count: a Morton bitfield needs a power-of-two n_grid <= 1024");
     if (bitfield_is_packed == 2)
@@ -1209,6 +1221,16 @@ ARCN_EXPORT int arcn_march_count_culled(const float *rays_o, const float *rays_d
     if (!coarse || n_grid < 16 || (n_grid & 3)) return einval("march_count_culled: coarse grid missing or n_grid not a multiple of 4 (>= 16)");
     return march_count_impl(rays_o, rays_d, aabb, n_grid, bitfield, bitfield_is_packed, n_pts, dt, near_distance, aabb_torch_semantics, rng_state,
                             rng_inc, scratch_t, counts, near_out, far_out, n_rays, stream, MarchCull{coarse, n_grid / 4, nullptr});
+}
+
+ARCN_EXPORT int arcn_march_count_waves(const float *rays_o, const float *rays_d, const float *aabb, int n_grid,
+                                       const uint8_t *bitfield, int bitfield_is_packed, const uint8_t *coarse, int n_pts, float dt,
+                                       float near_distance, int aabb_torch_semantics, uint64_t rng_state, uint64_t rng_inc,
+                                       float *scratch_t, int32_t *counts, float *near_out, float *far_out, int64_t n_rays, int n_waves,
+                                       void *stream) {
+    if (coarse && (n_grid < 16 || (n_grid & 3))) return einval("march_count_waves: culling needs n_grid a multiple of 4 (>= 16)");
+    return march_count_impl(rays_o, rays_d, aabb, n_grid, bitfield, bitfield_is_packed, n_pts, dt, near_distance, aabb_torch_semantics, rng_state,
+                            rng_inc, scratch_t, counts, near_out, far_out, n_rays, stream, MarchCull{coarse, coarse ? n_grid / 4 : 0, nullptr, n_waves > 0 ? n_waves : 0});
 }
 
 /* arcn_march_count[_culled] for a launch that is RECORDED (HIP graph capture) and replayed: every by-value argument is frozen at capture,

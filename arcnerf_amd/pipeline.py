@@ -246,6 +246,11 @@ class NgpPipeline:
         self._occ_bits_event = None     # the refreshed bitfield is ready: the marcher waits for it
         self._occ_state_event = None    # last refresh finished: readers of .bitfield / .opafield wait for it
         self.prefetch_at = int(os.environ.get('ARCN_PREFETCH_AT', '1' if self.prefetch_depth == 1 else '3'))
+        # two batches ahead the marching has a whole step of slack: it runs as 4096 PERSISTENT wavefronts (arcn_march_count_waves: wave w takes
+        # the rays w, w + 4096, ...) - half as many long-lived marcher waves on every SIMD beside the step's kernels, for twice as long: the
+        # step loses 2 % less to them (0.569 -> 0.556 - 0.558 ms, three alternations; 3072: the same, 2048 / 5120 / 6144: less, 1024: the chain
+        # is late and the step waits).  One batch ahead (or inline) the chain's latency is on the clock: +3 %, so not there.
+        self.march_waves = int(os.environ.get('ARCN_MARCH_WAVES', '4096' if self.prefetch_depth >= 2 else '0'))
         # multi-rank: the compute units idle while the gradient all-reduce is on the wire - march the next batch there
         self.prefetch_at_dist = 3
         self._prefetch_now = self.prefetch_at
@@ -506,7 +511,7 @@ class NgpPipeline:
         busy = {self._cur_set} | {pf[3] for pf in self._prefetched}
         spare = next(i for i in range(len(self._sets)) if i not in busy)
         with torch.cuda.stream(self.aux_stream):
-            self._sample_into(self._sets[spare], rays_o, rays_d)
+            self._sample_into(self._sets[spare], rays_o, rays_d, waves=self.march_waves)
             self._noise_ready[spare] = bool(noise and self.cfg.noise_std > 0)
             if self._noise_ready[spare]:
                 self._sets[spare]['noise'].normal_(0.0, self.cfg.noise_std)
@@ -540,7 +545,7 @@ class NgpPipeline:
         self.n_dev = self.buf['offsets'][R:R + 1]  # device-side sample count (view, no sync)
         return self.n_dev
 
-    def _sample_into(self, b, rays_o, rays_d):
+    def _sample_into(self, b, rays_o, rays_d, waves=0):
         cfg = self.cfg
         self._wait_occupancy_bits()
         R = rays_o.shape[0]
@@ -558,7 +563,12 @@ class NgpPipeline:
             N.check(L.arcn_march_write(N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['offsets']), cfg.n_sample, N.ptr(b['t']),
                                        N.ptr(b['ray_id']), R, self.cap, st), 'march_write')
         else:
-            if getattr(self, '_coarse', None) is not None:     # rays that pass no occupied block leave before they march (same outputs)
+            if waves > 0 and R > waves:     # a launch with time to spare beside other kernels: persistent wavefronts (same outputs)
+                N.check(L.arcn_march_count_waves(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
+                                                 int(self.packed_bits), N.ptr(getattr(self, '_coarse', None)), cfg.n_sample, cfg.dt, cfg.near_distance,
+                                                 int(self.torch_aabb), self.rng.state, self.rng.inc, N.ptr(b['scratch_t']),
+                                                 N.ptr(b['counts']), N.ptr(b['near']), N.ptr(b['far']), R, int(waves), st), 'march_count_waves')
+            elif getattr(self, '_coarse', None) is not None:     # rays that pass no occupied block leave before they march (same outputs)
                 N.check(L.arcn_march_count_culled(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
                                                   int(self.packed_bits), N.ptr(self._coarse), cfg.n_sample, cfg.dt, cfg.near_distance,
                                                   int(self.torch_aabb), self.rng.state, self.rng.inc, N.ptr(b['scratch_t']),

@@ -173,6 +173,16 @@ int arcn_march_count_culled(const float *rays_o, const float *rays_d, const floa
                             int bitfield_is_packed, const uint8_t *coarse, int n_pts, float dt, float near_distance,
                             int aabb_torch_semantics, uint64_t rng_state, uint64_t rng_inc, float *scratch_t, int32_t *counts,
                             float *near_out, float *far_out, int64_t n_rays, void *stream);
+/* arcn_march_count_culled (coarse may be NULL: arcn_march_count) as n_waves PERSISTENT wavefronts: wave w marches the rays w, w + n_waves, ...
+ * instead of one wavefront per ray (n_waves <= 0 or >= n_rays: one wavefront per ray).  Same samples, bit for bit (a ray's jitter comes
+ * from the launch's generator advanced by the ray's index).  For a launch that runs BESIDE other work with time to spare - the marching of a
+ * batch two training steps ahead on a second stream: 8 320 one-ray wavefronts hold ~2.3 long-lived waves on every SIMD for 60 us, 4 096
+ * persistent ones half of that for twice as long, and the step's kernels lose 2 % less to them.  Alone, or with one step
+ * to finish in, the one-wavefront-per-ray form is the faster one. */
+int arcn_march_count_waves(const float *rays_o, const float *rays_d, const float *aabb, int n_grid, const uint8_t *bitfield,
+                            int bitfield_is_packed, const uint8_t *coarse, int n_pts, float dt, float near_distance,
+                            int aabb_torch_semantics, uint64_t rng_state, uint64_t rng_inc, float *scratch_t, int32_t *counts,
+                            float *near_out, float *far_out, int64_t n_rays, int n_waves, void *stream);
 /* arcn_march_count / _culled for a launch RECORDED in a HIP graph and replayed: the sampler's pcg32 {state, inc} is read from device
  * memory (rng_dev: two 64-bit words the caller rewrites before each replay, the state advanced 2^32 per launch like the by-value
  * form, ops/src/volume_func/volume_func_kernel.cu:283-289) instead of by-value arguments frozen at capture.  coarse may be NULL. */

@@ -1737,3 +1737,46 @@ def test_imgloss_huber_fused_equals_the_elementwise_form(F):
     ref = torch.where(a < 0.1, 0.5 / 0.1 * a ** 2, a - 0.05).mean()
     gr, = torch.autograd.grad(ref * 3000.0, x)
     assert abs(float(fused) - float(ref)) <= 1e-6 * float(ref) and float((gf - gr).abs().max()) <= 1e-5 * float(gr.abs().max())
+
+
+@pytest.mark.gpu
+def test_persistent_marcher_gives_the_samples_of_the_one_wave_per_ray_marcher():
+    """arcn_march_count_waves (wave w marches the rays w, w + n_waves, ...: the launch of a batch marched two steps ahead) against
+    arcn_march_count_culled: counts, bounds and every emitted t bit for bit, with and without the culling grid, for wave counts that divide
+    the batch, do not divide it, exceed it (falls back to one wave per ray) and for a batch with a ragged last workgroup"""
+    import numpy as np
+    from arcnerf_amd import _native as N
+    from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline, synthetic_bitfield, synthetic_rays
+    dev = torch.device('cuda:0')
+    cfg = NgpConfig()
+    fld = NgpField(cfg, device=dev, seed=0)
+    pipe = NgpPipeline(fld, max_rays=4096, max_samples=1 << 19, packed_bits=True)
+    pipe.set_bitfield(torch.from_numpy(synthetic_bitfield(cfg.n_grid, 0.05, seed=3)))
+    L = N.lib()
+    for R in (4096, 1023):
+        o, d = synthetic_rays(R, seed=41, device=dev)
+
+        def march(waves, coarse):
+            out = {k: torch.zeros_like(pipe.buf[k]) for k in ('scratch_t', 'counts', 'near', 'far')}
+            out['scratch_t'].fill_(-1.0)
+            N.check(L.arcn_march_count_waves(N.ptr(o), N.ptr(d), N.ptr(pipe.aabb23), cfg.n_grid, N.ptr(pipe._occ()), int(pipe.packed_bits),
+                                             N.ptr(coarse), cfg.n_sample, cfg.dt, cfg.near_distance, 0, 12345, 67, N.ptr(out['scratch_t']),
+                                             N.ptr(out['counts']), N.ptr(out['near']), N.ptr(out['far']), R, waves, N.stream()), 'march_count_waves')
+            torch.cuda.synchronize()
+            return out
+        ref = {k: torch.zeros_like(pipe.buf[k]) for k in ('scratch_t', 'counts', 'near', 'far')}
+        ref['scratch_t'].fill_(-1.0)
+        N.check(L.arcn_march_count_culled(N.ptr(o), N.ptr(d), N.ptr(pipe.aabb23), cfg.n_grid, N.ptr(pipe._occ()), int(pipe.packed_bits),
+                                          N.ptr(pipe._coarse), cfg.n_sample, cfg.dt, cfg.near_distance, 0, 12345, 67, N.ptr(ref['scratch_t']),
+                                          N.ptr(ref['counts']), N.ptr(ref['near']), N.ptr(ref['far']), R, N.stream()), 'march_count_culled')
+        torch.cuda.synchronize()
+        cnt = ref['counts'][:R].cpu().numpy()
+        assert cnt.sum() > 10 * R and (cnt == 0).mean() > 0.3
+        for waves in (0, 64, 256, 1000, 2048, 100000):
+            for coarse in (pipe._coarse, None):
+                got = march(waves, coarse)
+                assert torch.equal(got['counts'][:R], ref['counts'][:R]), (R, waves)
+                assert torch.equal(got['near'][:R], ref['near'][:R]) and torch.equal(got['far'][:R], ref['far'][:R])
+                t_got, t_ref = got['scratch_t'][:R].cpu().numpy(), ref['scratch_t'][:R].cpu().numpy()
+                valid = np.arange(t_ref.shape[1])[None, :] < cnt[:, None]
+                assert np.array_equal(t_got[valid], t_ref[valid]), (R, waves)

@@ -323,7 +323,7 @@ def test_prefetched_marching_equals_inline_marching(gpu, depth):
     # (2) training loop, `depth` batches ahead
     marched = []
     real = ahead._sample_into
-    ahead._sample_into = lambda b, o, d: (marched.append(o.data_ptr()), real(b, o, d))[1]
+    ahead._sample_into = lambda b, o, d, **kw: (marched.append(o.data_ptr()), real(b, o, d, **kw))[1]
     tgt = torch.rand(R, 3, device=gpu)
     steps = 12
     losses = []
