@@ -1,8 +1,8 @@
 #!/bin/bash
-# ARCN_MARCH_PERSIST=P: the marcher as P persistent wavefronts (wave w marches rays w, w + P, ...) instead of one wavefront per ray, alternating
-# usage: tools/ab_march_persist.sh [P ...]
-run() { echo -n "$*: "; env "$@" python bench.py --steps 192 --warmup 32 --no-cpu-baseline --no-other-configs --no-psnr 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(round(d['ms_per_step'],4), 'p50', round(d['step_ms_spread']['p50'],4), 'gather in step', round(d['roofline_lookup']['avg_launch_ms'],4), 'samples', d['config']['samples_per_step_per_gpu'])"; }
-PS=${@:-"0 4096 2048 1024 512"}
-for rep in 1 2 3; do
-for p in $PS; do run ARCN_MARCH_PERSIST=$p; done
+# ARCN_MARCH_WAVES=P: the marcher of the batch two steps ahead as P persistent wavefronts (wave w marches rays w, w + P, ...; 0: one wavefront
+# per ray), alternating in one session.   usage: tools/ab_march_persist.sh [P ...]
+run() { echo -n "$*: "; env "$@" python bench.py --steps 192 --warmup 32 --no-cpu-baseline --no-other-configs --no-psnr 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(round(d['ms_per_step'],4), 'p50', round(d['step_ms_spread']['p50'],4), 'gather in step', round(d['roofline_lookup']['avg_launch_ms'],4), 'scatter', round(d['roofline']['avg_launch_ms'],4), 'frac', round(d['roofline']['frac'],4))"; }
+PS=${@:-"0 4096"}
+for rep in 1 2 3 4; do
+for p in $PS; do run ARCN_MARCH_WAVES=$p; done
 done
