@@ -610,6 +610,11 @@ class NgpPipeline:
             # the net's tile loads read 128 contiguous bytes per level
             N.check(L.arcn_hashgrid_fwd_xcd(N.ptr(b['xyz']), N.ptr(self._p('table')), N.C.addressof(fld.grid_desc), N.ptr(b['feat']),
                                             1, S, S, n_dev.data_ptr(), st), 'hashgrid_fwd_xcd')
+            if train and getattr(self, '_carry_rays', None) is not None:
+                # prefetch point 5 (two batches ahead only): the marching handed over by the PREVIOUS train_step starts behind this step's
+                # gather instead of beside it
+                carry, self._carry_rays = self._carry_rays, None
+                self.prefetch_samples(*carry, noise=True)
             N.check(L.arcn_mlp_fwd_lm(N.ptr(b['feat']), S, N.ptr(self._p('geo_w')), N.C.addressof(fld.geo_desc), N.ptr(b['geo_out']),
                                       N.ptr(b['geo_acts']) if train else None, S, S, n_dev.data_ptr(), st), 'mlp_fwd_lm(geo)')
         else:
@@ -826,8 +831,12 @@ class NgpPipeline:
         cfg, b = self.cfg, self.buf
         fused = self.fused_composite
         rgb, _, _ = self.forward(rays_o, rays_d, bkg_color, train=True, noise='auto', huber_target=target_rgb if fused else None)
+        if self.prefetch_at == 5 and self.prefetch_depth >= 2 and grad_sync is None and all_reduce is None:
+            self._carry_rays = next_rays
         self._next_rays = next_rays
         self._prefetch_now = self.prefetch_at if (grad_sync is None and all_reduce is None) else self.prefetch_at_dist
+        if self._prefetch_now == 5 and self.prefetch_depth >= 2:
+            self._next_rays = None          # issued inside the NEXT step's forward, behind its gather (see forward)
         self._prefetch_point(0)
         if fused:
             loss, d_rgb = self.last_loss, b['d_rgb'][:rays_o.shape[0]]
