@@ -55,7 +55,7 @@ class FusedNgpStep:
             return 'the optimiser has an EMA decay but no shadow'
         return None
 
-    def __init__(self, model, loss_factory, optimizer, ema=None, warmup=2, total_epoch=300000, max_rays=None, clip_value=0.0):
+    def __init__(self, model, loss_factory, optimizer, ema=None, warmup=2, total_epoch=300000, max_rays=None, clip_value=0.0, ahead=2):
         reason = self.why_not(model, loss_factory, optimizer)
         if reason is None and clip_value > 0.0:
             reason = 'gradient clipping (clip_value > 0) needs the gradients between backward and the optimiser: use trainer.step_optimize'
@@ -74,8 +74,10 @@ class FusedNgpStep:
         self.max_rays = max_rays        # ray capacity of the buffers (default: the model's chunk_rays, else 32768; grows with the batches)
         if self.max_rays is None:
             self.max_rays = int(self.fg.chunk_rays) if getattr(self.fg, 'chunk_rays', None) and self.fg.chunk_rays > 0 else 32768
-        self._ahead = None              # (epoch, feed_in) drawn one step early by trainer.train_epoch, its marching already issued
-        self._ahead_marched = False
+        # batches in flight: trainer.train_epoch draws up to `ahead` batches early (FIFO of (epoch, feed_in)), their marching runs on the second
+        # stream.  Two ahead, the chain has a whole step of slack: lower stream priority, persistent wavefronts (NgpPipeline.march_waves)
+        self.depth = max(1, int(ahead))
+        self._queue = []
         self._after_eager = False
         self.rebuilds = 0
 
@@ -101,12 +103,13 @@ class FusedNgpStep:
         max_rays = max(int(n_rays), int(self.max_rays or 0))
         cap = max(int(min_samples), 2 * max_rays, 1 << 16)
         self.max_rays = max_rays
-        if self.pipe is not None and self._ahead_marched:
-            # the batch of the coming step was marched ahead into the buffers being dropped: it is marched again, as the same launch of the
-            # sampler's stream (volume_func_kernel.cu:283-289: one 2^32 jump per launch)
-            sampler_rng().advance((1 << 64) - (1 << 32))
-            self._ahead_marched = False
-        pipe = NgpPipeline(fld, max_rays=max_rays, max_samples=cap, packed_bits=True, prefetch_depth=1)
+        if self.pipe is not None:
+            # batches marched ahead into the buffers being dropped are marched again, as the same launches of the sampler's stream
+            # (volume_func_kernel.cu:283-289: one 2^32 jump per launch)
+            for _ in self.pipe._prefetched:
+                sampler_rng().advance((1 << 64) - (1 << 32))
+            self.pipe._prefetched = []
+        pipe = NgpPipeline(fld, max_rays=max_rays, max_samples=cap, packed_bits=True, prefetch_depth=self.depth)
         pipe.exp_avg, pipe.exp_avg_sq = fb['exp_avg'], fb['exp_avg_sq']
         if self.opt.ema_decay is None:
             cfg.ema_decay = None
@@ -167,26 +170,39 @@ class FusedNgpStep:
         need = full if rate is None else min(self._slots_for(rate * n_rays), full)
         return max(int(need), 2 * int(max_rays), 1 << 16)
 
-    # ---- the batch drawn one step early (trainer.train_epoch) ----------------------------------------------------------------------------
+    # ---- the batches drawn early (trainer.train_epoch) -----------------------------------------------------------------------------------------
     def can_run_ahead(self, epoch):
         """True when nothing the trainer does at `epoch` before the step can change what that step's marching reads: no refresh of the
-        bound's occupancy (VolumeBound.optimize: epoch % epoch_optim == 0) - then the batch can be drawn and marched a step early"""
+        bound's occupancy (VolumeBound.optimize: epoch % epoch_optim == 0) - then the batch can be drawn and marched early"""
         if self._eager_left > 0 or self.pipe is None:
             return False
         every = self.fg.obj_bound.get_optim_cfgs('epoch_optim')
         return not (epoch > 0 and every is not None and epoch % every == 0)
 
+    def ahead_room(self):
+        return self.depth - len(self._queue)
+
+    def next_ahead_epoch(self, epoch):
+        """the epoch whose batch would be drawn next, given that the step of `epoch` is about to run"""
+        return self._queue[-1][0] + 1 if self._queue else epoch + 1
+
     def hold_ahead(self, epoch, feed_in):
-        self._ahead = (epoch, feed_in)
+        self._queue.append((epoch, feed_in))
 
     def take_ahead(self, epoch):
-        ahead, self._ahead = self._ahead, None
-        return ahead[1] if ahead is not None and ahead[0] == epoch else None
+        if self._queue and self._queue[0][0] == epoch:
+            return self._queue.pop(0)[1]
+        self._queue = []        # (a trainer that left the epoch order: the batches drawn early are dropped, the pipeline forgets their samples)
+        return None
+
+    def ahead(self):
+        return [f for _, f in self._queue]
 
     # ---- the iteration --------------------------------------------------------------------------------------------------------------------
     def __call__(self, feed_in, epoch=0, next_feed_in=None, get_progress=False):
         """one training iteration on `feed_in` ((B, N, 3) rays_o / rays_d / img [/ bkg_color]), like trainer.step_optimize: -> (output, loss).
-        next_feed_in: the batch of the FOLLOWING call (the same tensors must be passed then): marched on the second stream meanwhile.
+        next_feed_in: the batch of the FOLLOWING call, or the batches of the following `ahead` calls in order (the same tensors must be passed
+        then): marched on the second stream meanwhile.
         get_progress: the per-sample outputs of the reference's progress dumps exist on the module path only - that iteration runs there."""
         dev = feed_in['rays_o'].device
         n_rays = feed_in['rays_o'].shape[0] * feed_in['rays_o'].shape[1]
@@ -218,11 +234,20 @@ class FusedNgpStep:
         self._sync_occupancy()
         o, d, img = feed_in['rays_o'].reshape(-1, 3), feed_in['rays_d'].reshape(-1, 3), feed_in['img'].reshape(-1, 3)
         bkg = feed_in['bkg_color'].reshape(-1, 3) if feed_in.get('bkg_color') is not None else None
-        nxt = None
-        if next_feed_in is not None and next_feed_in['rays_o'].shape[0] * next_feed_in['rays_o'].shape[1] <= pipe.max_rays:
-            nxt = (next_feed_in['rays_o'].reshape(-1, 3), next_feed_in['rays_d'].reshape(-1, 3))
-        loss = pipe.train_step(o, d, img, bkg_color=bkg, next_rays=nxt)
-        self._ahead_marched = nxt is not None
+        # the batches of the following calls, in order: those not marched yet are marched now - the first at the step's own prefetch point, a
+        # second one (the step after a refresh, when two are drawn at once) behind the optimiser.  Marching order = call order: every batch
+        # is the launch of the sampler's stream it would have been in the eager loop.
+        ahead = [] if next_feed_in is None else (list(next_feed_in) if isinstance(next_feed_in, (list, tuple)) else [next_feed_in])
+        todo = []
+        for f in ahead[:pipe.prefetch_depth]:
+            fo, fd = f['rays_o'].reshape(-1, 3), f['rays_d'].reshape(-1, 3)
+            if fo.shape[0] > pipe.max_rays:
+                break
+            if not any(pf[0] == fo.data_ptr() and pf[1] == fd.data_ptr() and pf[2] == fo.shape[0] for pf in pipe._prefetched):
+                todo.append((fo, fd))
+        loss = pipe.train_step(o, d, img, bkg_color=bkg, next_rays=todo[0] if todo else None)
+        for fo, fd in todo[1:]:
+            pipe.prefetch_samples(fo, fd, noise=True)
         # the counters the optimiser / EMA objects expose
         fb['step'] = pipe.step_count
         for p in fb['list']:

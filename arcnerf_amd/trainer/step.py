@@ -22,9 +22,9 @@ def step_optimize(model, feed_in, loss_factory, optimizer, ema=None, epoch=0, to
 def train_epoch(model, get_batch, loss_factory, optimizer, ema, pipeline, epoch, total_epoch=300000, stepper=None):
     """train_epoch's order: model.optimize(epoch) (the bound's periodic refresh), the dynamic batch size, then the step.
     get_batch(n_rays) -> feed_in dict.
-    stepper: a trainer.FusedNgpStep / GraphedTrainStep in place of step_optimize.  A FusedNgpStep is also handed the batch of epoch + 1
-    when neither model.optimize(epoch + 1) nor the batch-size rule can act at that epoch (then the order "optimize, batch size, batch"
-    of epoch + 1 commutes with this step): its marching runs on the second stream during this step's backward."""
+    stepper: a trainer.FusedNgpStep / GraphedTrainStep in place of step_optimize.  A FusedNgpStep is also handed the batches of the next
+    epochs (two by default) as long as neither model.optimize nor the batch-size rule can act at those epochs (then their "optimize,
+    batch size, batch" commutes with this step): their marching runs on the second stream meanwhile."""
     if stepper is None:
         model.optimize(epoch)
         n_rays = pipeline.fetch_step_update_dynamic_bs(epoch, model)
@@ -36,8 +36,10 @@ def train_epoch(model, get_batch, loss_factory, optimizer, ema, pipeline, epoch,
         feed_in = get_batch(n_rays)
     if not hasattr(stepper, 'can_run_ahead'):
         return stepper(feed_in, epoch)
-    nxt = None
-    if epoch + 1 < total_epoch and stepper.can_run_ahead(epoch + 1) and not pipeline.will_update_dynamic_bs(epoch + 1):
-        nxt = get_batch(pipeline.get_info('n_rays'))
-        stepper.hold_ahead(epoch + 1, nxt)
-    return stepper(feed_in, epoch, next_feed_in=nxt)
+    # batches are drawn in epoch order, each exactly once, as far ahead as the stepper holds and the loop allows
+    while stepper.ahead_room() > 0:
+        e = stepper.next_ahead_epoch(epoch)
+        if e >= total_epoch or not stepper.can_run_ahead(e) or pipeline.will_update_dynamic_bs(e):
+            break
+        stepper.hold_ahead(e, get_batch(pipeline.get_info('n_rays')))
+    return stepper(feed_in, epoch, next_feed_in=stepper.ahead())

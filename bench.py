@@ -313,12 +313,12 @@ def bench_module(args, name, emit=True):
         graphed = GraphedTrainStep(m, lambda inp, out: {'sum': loss_of(out, inp)}, opt)
     if name == 'ngp_module' and not use_dist and mode == 'fused':
         from arcnerf_amd.trainer import FusedNgpStep
-        fused = FusedNgpStep(m, ngp_loss, opt, None, max_rays=n_rays)
+        fused = FusedNgpStep(m, ngp_loss, opt, None, max_rays=n_rays, ahead=int(os.environ.get('ARCN_MODULE_AHEAD', '2')))
 
     def step(i):
         inp = pool[i % len(pool)]
         if fused is not None:
-            return fused(inp, 20000 + i, next_feed_in=pool[(i + 1) % len(pool)])[1]['sum']
+            return fused(inp, 20000 + i, next_feed_in=[pool[(i + k) % len(pool)] for k in range(1, fused.depth + 1)])[1]['sum']
         if graphed is not None:
             return graphed({k: v for k, v in inp.items()}, 20000 + i)[1]['sum']
         out = m({k: v for k, v in inp.items()}, inference_only=False, cur_epoch=20000 + i)
@@ -422,8 +422,8 @@ def bench_module(args, name, emit=True):
                'chunk_pts': int(m.get_chunk_pts()), 'occupancy': args.occupancy, 'bkg_occupancy': bkg_occ,
                'graph_host_ms_per_replay': ({k: round(v / max(1, graphed.replays) * 1e3, 4) for k, v in graphed.host_s.items()} if graphed is not None else None),
                'launch': ('one HIP-graph replay per step (trainer.GraphedTrainStep, {} replays in this run)'.format(graphed.replays) if graphed is not None
-                          else ('trainer.FusedNgpStep: the module API on NgpPipeline.train_step over the flattened optimiser\'s buffers, next batch marched a step '
-                                'early ({} steps in this run, {} eager warm-up steps before)'.format(fused.steps, 2) if fused is not None
+                          else ('trainer.FusedNgpStep: the module API on NgpPipeline.train_step over the flattened optimiser\'s buffers, next {} batches marched '
+                                'early ({} steps in this run, {} eager warm-up steps before)'.format(fused.depth, fused.steps, 2) if fused is not None
                                 else 'every kernel of the module path issued eagerly'))},
            'rccl': dist_report(dist, world, LAUNCH, flat_grads.numel() * 4, 1, per_rank, rccl_extra),
            'roofline': roofline, 'cpu_baseline': cpu}

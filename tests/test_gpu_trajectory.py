@@ -311,8 +311,8 @@ def test_graphed_module_step_equals_eager_steps(gpu):
 # ---- the drop-in step on the pipeline's fused step ----------------------------------------------------------------------------------
 def test_fused_module_step_equals_eager_steps(gpu):
     """trainer.FusedNgpStep runs `model(feed_in) -> ImgLoss -> backward -> FusedAdam.step (+ fused EMA)` of configs/nerf_ngp.yaml as
-    NgpPipeline.train_step on the flattened optimiser's buffers (loss inside the compositor, optimiser inside the scatter, the next
-    batch marched a step early by trainer.train_epoch).  Against the same model trained through trainer.train_epoch's eager form, over
+    NgpPipeline.train_step on the flattened optimiser's buffers (loss inside the compositor, optimiser inside the scatter, the next two
+    batches marched early by trainer.train_epoch).  Against the same model trained through trainer.train_epoch's eager form, over
     epochs 496 .. 519: five occupancy refreshes (every 4 epochs: the step after each marches inline), four changes of the dynamic batch
     size (epoch > 500), equal ray counts, equal sample counts, the sampler's generator in the same state, losses to 1e-5, the
     parameters and the optimiser's counters at the end."""
@@ -358,10 +358,10 @@ def test_fused_module_step_equals_eager_steps(gpu):
 
         losses, counts, ahead = [], [], 0
         for epoch in epochs:
-            if stepper is not None and stepper._ahead is not None:
+            if stepper is not None and stepper._queue and stepper._queue[0][0] == epoch:
                 ahead += 1
-                if epoch == 510:    # buffers rebuilt while the batch marched ahead sits in the old ones: marched again, same generator launch
-                    assert stepper._ahead_marched
+                if epoch == 510:    # buffers rebuilt while TWO batches marched ahead sit in the old ones: marched again, the same generator launches
+                    assert len(stepper.pipe._prefetched) == 2 and [e for e, _ in stepper._queue] == [510, 511]
                     stepper._build(gpu, 1024, min_samples=stepper.pipe.cap + 1024)
             out, loss = T.train_epoch(m, get_batch, loss_factory, opt, ema, tp, epoch, total_epoch=epochs[-1] + 1, stepper=stepper)
             losses.append(float(loss['sum']))

@@ -389,23 +389,34 @@ def test_fused_step_refuses_what_it_does_not_implement_and_train_epoch_draws_ahe
     m2 = build_model(load_configs(os.path.join(ROOT, 'configs', 'nerf.yaml'), []))
     assert 'packed instant-ngp' in T.FusedNgpStep.why_not(m2, lf, opt)
 
-    # train_epoch's look-ahead: a stand-in stepper records what it is handed
+    # train_epoch's look-ahead: a stand-in stepper (two batches in flight) records what it is handed
     class Stepper:
         def __init__(self):
-            self.calls, self._ahead = [], None
+            self.calls, self._queue = [], []
 
         def can_run_ahead(self, epoch):
             return epoch % 4 != 0            # (the bound refreshes every 4 epochs)
 
+        def ahead_room(self):
+            return 2 - len(self._queue)
+
+        def next_ahead_epoch(self, epoch):
+            return self._queue[-1][0] + 1 if self._queue else epoch + 1
+
         def hold_ahead(self, epoch, feed_in):
-            self._ahead = (epoch, feed_in)
+            self._queue.append((epoch, feed_in))
 
         def take_ahead(self, epoch):
-            a, self._ahead = self._ahead, None
-            return a[1] if a is not None and a[0] == epoch else None
+            if self._queue and self._queue[0][0] == epoch:
+                return self._queue.pop(0)[1]
+            self._queue = []
+            return None
+
+        def ahead(self):
+            return [f for _, f in self._queue]
 
         def __call__(self, feed_in, epoch, next_feed_in=None):
-            self.calls.append((epoch, feed_in, next_feed_in))
+            self.calls.append((epoch, feed_in, list(next_feed_in or [])))
             return {}, {'sum': 0.0}
 
     class Model:
@@ -420,7 +431,7 @@ def test_fused_step_refuses_what_it_does_not_implement_and_train_epoch_draws_ahe
 
     tp = T.Pipeline()
     tp.set_info('n_rays', 128)
-    tp.set_info('dynamic_batch_size', 2)
+    tp.set_info('dynamic_batch_size', 4)
     tp.set_info('dynamic_max_batch_size', 1024)
     st, mdl, drawn = Stepper(), Model(), []
 
@@ -430,10 +441,10 @@ def test_fused_step_refuses_what_it_does_not_implement_and_train_epoch_draws_ahe
 
     for epoch in range(500, 509):
         T.train_epoch(mdl, get_batch, lf, None, None, tp, epoch, total_epoch=509, stepper=st)
-    # every epoch's batch is drawn exactly once, in order, with the ray count the rule gives AT that epoch (x 2 at 502, 504, 506, 508)
+    # every epoch's batch is drawn exactly once, in order, with the ray count the rule gives AT that epoch (x 2 at 504 and 508: epoch > 500)
     assert [c[1][1] for c in st.calls] == list(range(1, 10))
-    assert drawn == [128, 128, 256, 256, 512, 512, 1024, 1024, 1024]
-    # handed ahead: epoch + 1 odd (no rule, no refresh) and inside the run; model.optimize ran for every epoch whose batch was not drawn ahead
-    assert [c[0] for c in st.calls if c[2] is not None] == [500, 502, 504, 506]
-    assert all(c[2] is st.calls[i + 1][1] for i, c in enumerate(st.calls[:-1]) if c[2] is not None)
-    assert mdl.optimized == [500, 502, 504, 506, 508]
+    assert drawn == [128, 128, 128, 128, 256, 256, 256, 256, 512]
+    # handed ahead: up to two, never across an epoch at which the refresh or the rule acts, never past the end of the run
+    assert [[b[1] for b in c[2]] for c in st.calls] == [[2, 3], [3, 4], [4], [], [6, 7], [7, 8], [8], [], []]
+    # model.optimize ran for every epoch whose batch was not drawn early (where it is a no-op by the stepper's word)
+    assert mdl.optimized == [500, 504, 508]
