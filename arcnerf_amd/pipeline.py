@@ -240,6 +240,7 @@ class NgpPipeline:
         self._cur_set = 0
         self._prefetched = []   # FIFO of (rays_o ptr, rays_d ptr, R, set index, event), oldest first
         self._next_rays = None
+        self._carry_rays = None  # prefetch point 5: rays handed over by the previous train_step, marched behind this step's gather
         self.occ_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
         self.occ_async = bool(int(os.environ.get('ARCN_OCC_ASYNC', '1'))) and self.occ_stream is not None
         self._occ_params_event = None   # the refresh still reads the parameters: the optimiser waits for it
@@ -610,7 +611,7 @@ class NgpPipeline:
             # the net's tile loads read 128 contiguous bytes per level
             N.check(L.arcn_hashgrid_fwd_xcd(N.ptr(b['xyz']), N.ptr(self._p('table')), N.C.addressof(fld.grid_desc), N.ptr(b['feat']),
                                             1, S, S, n_dev.data_ptr(), st), 'hashgrid_fwd_xcd')
-            if train and getattr(self, '_carry_rays', None) is not None:
+            if train and self._carry_rays is not None:
                 # prefetch point 5 (two batches ahead only): the marching handed over by the PREVIOUS train_step starts behind this step's
                 # gather instead of beside it
                 carry, self._carry_rays = self._carry_rays, None
@@ -877,7 +878,9 @@ class NgpPipeline:
         geometry-net backward, 2 before the hash-grid scatter, 3 before the optimiser, 4 after it.  The marcher is pure VALU work with
         a 256 KiB working set; it costs least next to the LDS / HBM-bound kernels.  One batch ahead (prefetch_depth 1) its chain has
         to be done when the next forward starts, so it goes next to the backward (1); two batches ahead it goes next to the
-        optimiser pass (3): 0.711 vs 0.722 ms/step, A/B in one session (`tools/ab_prefetch.sh`)."""
+        optimiser pass (3): 0.711 vs 0.722 ms/step, A/B in one session (`tools/ab_prefetch.sh`); with the step tail, behind it (4).
+        5 (two batches ahead, an experiment): handed to the NEXT step, which issues it behind its gather (forward): the gather then runs at
+        its alone time, the forward nets pay more than it gains."""
         if getattr(self, '_next_rays', None) is not None and where == self._prefetch_now:
             self.prefetch_samples(*self._next_rays, noise=True)
             self._next_rays = None
