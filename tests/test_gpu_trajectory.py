@@ -2,13 +2,15 @@
 reference's build_model + torch.optim.Adam from create_optimizer + its EMA class + ImgLoss Huber + VolumeBound.optimize +
 Pipeline.fetch_step_update_dynamic_bs for 2 x 20 steps, K2 / K3 / K4 on the oracle, every random draw fed from tests/g26_utils.py).
 
-Three reproductions, each over both legs (`a`: fresh start, warm-up refresh + post-warm-up refreshes, EMA de-bias from 0; `b`: a job
+Four reproductions, each over both legs (`a`: fresh start, warm-up refresh + post-warm-up refreshes, EMA de-bias from 0; `b`: a job
 started at epoch 496: EMA n_step 496 with Adam at step 1, `epoch > 500` rule of the dynamic batch size):
   1. the module path: build_model(configs/nerf_ngp.yaml + the fixture's overrides) + trainer.train_epoch + FusedAdam (fused EMA);
   2. NgpPipeline.train_step / update_occupancy with the reference's net semantics (geometry output = [sigma | 15 features]): the
      scatter-fused optimiser of the single-GPU step;
   3. NgpPipeline with the config's FUSED nets (the bench's path: fused glue, step tail) against oracle/ngp_trainer.py, the CPU
-     restatement of the loop that tests/test_oracle_trajectory_golden.py pins to the same fixture.
+     restatement of the loop that tests/test_oracle_trajectory_golden.py pins to the same fixture;
+  4. the drop-in API at full speed: build_model(configs/nerf_ngp.yaml, fused nets) + trainer.train_epoch + trainer.FusedNgpStep (two batches
+     in flight, VolumeBound.optimize of the module) against the same oracle loop as 3.
 
 Bars (g26_utils.loss_bars): losses within 1e-4 relative until a refresh has had cells within 1e-4 of its threshold to decide (the threshold is the MEAN
 opacity; the reference's own two runs decide them differently), from then on 5 x the distance between the reference's two runs; sample
@@ -209,21 +211,18 @@ def test_pipeline_train_step_reproduces_reference_loop(gpu, tape, leg):
     assert pipe._adam_rest is not None, 'the single-GPU step is expected to run the scatter-fused optimiser'
 
 
-@pytest.mark.parametrize('leg', ['a', 'b'])
-def test_fused_net_pipeline_follows_the_oracle_loop(gpu, tape, oracle, leg):
-    """the bench's path (fused 32 -> 64 -> 16 geometry net whose whole output feeds the radiance net, fused glue, step tail): no CPU run of
-    the reference exists for it (tiny-cuda-nn), so the trajectory comes from oracle/ngp_trainer.py - pinned to G26 for the reference's
-    semantics by tests/test_oracle_trajectory_golden.py - switched to the fused semantics"""
+def oracle_fused_run(oracle, g, leg):
+    """the leg's start state for the config's FUSED nets (seeded, torch.nn.Linear's range, density row x the leg's scale) and the run of
+    oracle/ngp_trainer.py from it: -> (cfg, flat, ref, trainer)"""
     from arcnerf_amd.pipeline import NgpField
     from oracle.ngp_trainer import OracleNgpTrainer
-    g = U.golden()
     cfg = make_cfg(geo_fused_semantics=True, W_feat=16)
     fld = NgpField(cfg, device='cpu', seed=0)
     rng = np.random.default_rng(2690)
     flat = fld.params.numpy().copy()
     off, n = fld._seg['table']
     flat[off:off + n] = U.table(g, leg, fld.offsets[-1]).reshape(-1)
-    for name in ('geo_w', 'rad_w'):          # seeded nets (torch.nn.Linear's range), density row x the leg's scale
+    for name in ('geo_w', 'rad_w'):
         off, n = fld._seg[name]
         flat[off:off + n] = ((rng.random(n, dtype=np.float32) * 2 - 1) * np.float32(0.125)).astype(np.float32)
     off, _ = fld._seg['geo_w']
@@ -243,10 +242,82 @@ def test_fused_net_pipeline_follows_the_oracle_loop(gpu, tape, oracle, leg):
         ref['n_rays'].append(n_rays)
         ref['n_valid'].append(res['n_samples'])
         ref['loss'].append(res['loss'])
+    return cfg, flat, ref, tr
+
+
+@pytest.mark.parametrize('leg', ['a', 'b'])
+def test_fused_net_pipeline_follows_the_oracle_loop(gpu, tape, oracle, leg):
+    """the bench's path (fused 32 -> 64 -> 16 geometry net whose whole output feeds the radiance net, fused glue, step tail): no CPU run of
+    the reference exists for it (tiny-cuda-nn), so the trajectory comes from oracle/ngp_trainer.py - pinned to G26 for the reference's
+    semantics by tests/test_oracle_trajectory_golden.py - switched to the fused semantics"""
+    g = U.golden()
+    cfg, flat, ref, tr = oracle_fused_run(oracle, g, leg)
     pipe = run_pipeline(gpu, cfg, flat, leg, Checker(g, leg, ref))
     assert pipe._tail is not None and pipe.fused_glue and pipe.level_major, 'expected the bench configuration of the step'
     # end state: the oracle's parameters, through the same summary
     p = pipe.field.params.cpu().numpy()
+    la = np.abs(tr.p).astype(np.float64).sum()
+    assert abs(np.abs(p).astype(np.float64).sum() - la) <= 2e-2 * la
+
+
+@pytest.mark.parametrize('leg', ['a', 'b'])
+def test_fused_module_step_follows_the_oracle_loop(gpu, tape, oracle, leg):
+    """4. the drop-in API at full speed - build_model(configs/nerf_ngp.yaml, the fused nets UNCHANGED) + FusedAdam(ema_in_param).flatten() +
+    trainer.train_epoch with trainer.FusedNgpStep (two batches in flight, the refresh through the module's own VolumeBound.optimize) -
+    against the same oracle loop as 3., from the same start state (the flattened optimiser's buffer IS the pipeline's flat layout)"""
+    from arcnerf_amd import trainer as T
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    from arcnerf_amd.optim import FusedAdam
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    g = U.golden()
+    cfg, flat, ref, tr = oracle_fused_run(oracle, g, leg)
+    ov = ['--model.rays.noise_std', '0.0', '--model.rays.white_bkg', 'True', '--model.obj_bound.volume.n_grid', str(U.N_GRID),
+          '--model.obj_bound.epoch_optim', str(U.EPOCH_OPTIM), '--model.obj_bound.epoch_optim_warmup', str(U.EPOCH_WARMUP),
+          '--model.obj_bound.log_max_allowance', str(U.LOG_MAX_ALLOWANCE)]
+    m = build_model(load_configs(os.path.join(CFG, 'nerf_ngp.yaml'), ov)).to(gpu)
+    fg = m.fg_model
+    assert fg.packed_path_eligible() and fg.get_n_coarse_sample() == cfg.n_sample
+    lr, eps, wd, decay = [float(v) for v in g['optim']]
+    opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=lr, eps=eps, weight_decay=wd, ema_decay=decay, ema_in_param=True).flatten()
+    assert opt.flat_params().numel() == flat.shape[0]
+    with torch.no_grad():
+        opt.flat_params().copy_(torch.from_numpy(flat))
+    ema = T.EMA(m, decay, opt)
+    epochs = U.LEGS[leg]['epochs']
+    ema.set_n_step(epochs[0])
+    loss_cfg = type('C', (), {})()
+    loss_cfg.loss = type('C', (), {})()
+    loss_cfg.loss.ImgLoss = type('C', (), dict(keys=['rgb_coarse'], loss_type='Huber', delta=float(g['loss_cfg'][0]), weight=float(g['loss_cfg'][1])))()
+    loss_factory = T.build_loss(loss_cfg)
+    tp = T.Pipeline()
+    tp.set_info('n_rays', U.N_RAYS0)
+    tp.set_info('dynamic_batch_size', U.UPDATE_EPOCH)
+    tp.set_info('dynamic_max_batch_size', U.N_RAYS_MAX)
+    sampler_rng(reset=True)
+    m.train()
+    stepper = T.FusedNgpStep(m, loss_factory, opt, ema, max_rays=U.N_RAYS_MAX)
+    drawn = []
+
+    def get_batch(n_rays):
+        epoch = epochs[len(drawn)]
+        drawn.append(n_rays)
+        inp = U.step_inputs(epoch, n_rays)
+        return {'rays_o': torch.from_numpy(inp['rays_o'])[None].to(gpu), 'rays_d': torch.from_numpy(inp['rays_d'])[None].to(gpu),
+                'img': torch.from_numpy(inp['img'])[None].to(gpu), 'bkg_color': torch.from_numpy(inp['bkg_color'])[None].to(gpu)}
+
+    chk = Checker(g, leg, ref)
+    vol = fg.obj_bound.volume
+    for k, epoch in enumerate(epochs):
+        before = vol.get_voxel_opafield(flatten=True).clone()
+        out, loss = T.train_epoch(m, get_batch, loss_factory, opt, ema, tp, epoch, total_epoch=epochs[-1] + 1, stepper=stepper)
+        refreshed = not torch.equal(before, vol.get_voxel_opafield(flatten=True))
+        chk.refresh(k, refreshed, vol.get_voxel_bitfield(flatten=True).cpu().numpy())
+        pipe = stepper.pipe if stepper.pipe is not None and stepper.steps > 0 else fg._pipe
+        chk.step(k, drawn[k], int(pipe.n_dev.item()), float(loss['sum']))
+    chk.done()
+    assert stepper.steps == len(epochs) - 2 and drawn == ref['n_rays']
+    p = opt.flat_params().cpu().numpy()
     la = np.abs(tr.p).astype(np.float64).sum()
     assert abs(np.abs(p).astype(np.float64).sum() - la) <= 2e-2 * la
 
