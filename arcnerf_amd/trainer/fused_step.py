@@ -55,7 +55,8 @@ class FusedNgpStep:
             return 'the optimiser has an EMA decay but no shadow'
         return None
 
-    def __init__(self, model, loss_factory, optimizer, ema=None, warmup=2, total_epoch=300000, max_rays=None, clip_value=0.0, ahead=2):
+    def __init__(self, model, loss_factory, optimizer, ema=None, warmup=2, total_epoch=300000, max_rays=None, clip_value=0.0, ahead=2,
+                 world_size=1, grad_level_cuts=(8,), sync_occupancy=True):
         reason = self.why_not(model, loss_factory, optimizer)
         if reason is None and clip_value > 0.0:
             reason = 'gradient clipping (clip_value > 0) needs the gradients between backward and the optimiser: use trainer.step_optimize'
@@ -78,6 +79,14 @@ class FusedNgpStep:
         # stream.  Two ahead, the chain has a whole step of slack: lower stream priority, persistent wavefronts (NgpPipeline.march_waves)
         self.depth = max(1, int(ahead))
         self._queue = []
+        # data parallel (one process per GPU, every rank its shard of the rays; the reference wraps the model in DistributedDataParallel,
+        # common/trainer/basic_trainer.py:197-198): the flat gradient is summed over the ranks in level groups overlapped with the scatter
+        # (distributed.LevelGroupedGradSync), the optimiser divides by the world size (FusedAdam.grad_scale = 1 / world_size, DDP's average),
+        # and a refreshed occupancy is rank 0's on every rank (DDP's broadcast_buffers)
+        self.world = max(1, int(world_size))
+        self.grad_level_cuts = tuple(grad_level_cuts)
+        self.sync_occupancy = bool(sync_occupancy)
+        self._sync = None
         self._after_eager = False
         self.rebuilds = 0
 
@@ -118,6 +127,10 @@ class FusedNgpStep:
             cfg.ema_decay = float(self.opt.ema_decay)
             pipe.ema = fld.params if self.opt.ema_in_param else fb['ema']
         pipe.rng = sampler_rng()                                # the process-wide sampler stream, shared with the module path
+        self._sync = None
+        if self.world > 1 and pipe.level_major:
+            from .. import distributed as D
+            self._sync = D.LevelGroupedGradSync(fld, self.grad_level_cuts)
         self.pipe, self._bits_key = pipe, None
         self._pending.clear()
         self.rebuilds += 1
@@ -126,6 +139,10 @@ class FusedNgpStep:
         bf = self.fg.obj_bound.volume.get_voxel_bitfield(flatten=True)
         key = (id(self.pipe), bf.data_ptr(), bf._version)
         if self._bits_key != key:
+            if self.world > 1 and self.sync_occupancy:
+                from .. import distributed as D
+                D.broadcast_occupancy(self.fg.obj_bound.volume.get_voxel_opafield(flatten=True), bf)     # in place: the Volume's own buffers
+                key = (id(self.pipe), bf.data_ptr(), bf._version)
             self.pipe.set_bitfield(bf)
             self._bits_key = key
 
@@ -198,6 +215,22 @@ class FusedNgpStep:
     def ahead(self):
         return [f for _, f in self._queue]
 
+    def _module_step(self, feed_in, epoch, get_progress):
+        """an iteration on the module path (the first steps of a run, progress iterations); data parallel: the flat gradient summed over the
+        ranks between backward and the optimiser, which divides by the world size - what DistributedDataParallel amounts to"""
+        if self.world == 1:
+            return step_optimize(self.model, feed_in, self.loss_factory, self.opt, self.ema, epoch, self.total_epoch, get_progress=get_progress)
+        from .. import distributed as D
+        output = self.model(feed_in, get_progress=get_progress, cur_epoch=epoch, total_epoch=self.total_epoch)
+        loss = self.loss_factory(feed_in, output)
+        self.opt.zero_grad()
+        loss['sum'].backward()
+        D.allreduce_grads(self.opt.flat_grads(), self.world)
+        self.opt.step()
+        if self.ema is not None:
+            self.ema.ema_step()
+        return output, loss
+
     # ---- the iteration --------------------------------------------------------------------------------------------------------------------
     def __call__(self, feed_in, epoch=0, next_feed_in=None, get_progress=False):
         """one training iteration on `feed_in` ((B, N, 3) rays_o / rays_d / img [/ bkg_color]), like trainer.step_optimize: -> (output, loss).
@@ -209,7 +242,7 @@ class FusedNgpStep:
         if self._eager_left > 0 or get_progress:      # the module path: its exact first step sizes everything (all-ones bitfield: R x n_sample samples)
             self._eager_left = max(0, self._eager_left - 1)
             self._after_eager = True
-            return step_optimize(self.model, feed_in, self.loss_factory, self.opt, self.ema, epoch, self.total_epoch, get_progress=get_progress)
+            return self._module_step(feed_in, epoch, get_progress)
         if self.pipe is None or self._after_eager:
             self.fg._check_deferred_overflow(dev)          # (the sample total of the last eager step)
             if not self.opt.zero_grad_on_step:
@@ -227,8 +260,9 @@ class FusedNgpStep:
                 raise RuntimeError('FusedNgpStep: a parameter was re-assigned after FusedAdam.flatten()')
         cfg = pipe.cfg
         cfg.lr, cfg.betas, cfg.eps, cfg.weight_decay = float(group['lr']), tuple(group['betas']), float(group['eps']), float(group['weight_decay'])
-        if abs(float(self.opt.grad_scale) - 1.0) > 0:
-            raise RuntimeError('FusedNgpStep is the single-GPU step (FusedAdam.grad_scale must be 1)')
+        if abs(float(self.opt.grad_scale) - 1.0 / self.world) > 1e-12:
+            raise RuntimeError('FusedNgpStep(world_size={}): FusedAdam.grad_scale must be 1 / world_size (the gradients are SUMMED over the '
+                               'ranks), it is {}'.format(self.world, self.opt.grad_scale))
         pipe.step_count = int(fb['step'])
         pipe.ema_n_step = int(fb['step']) if self.opt.ema_n_step is None else int(self.opt.ema_n_step)
         self._sync_occupancy()
@@ -245,7 +279,14 @@ class FusedNgpStep:
                 break
             if not any(pf[0] == fo.data_ptr() and pf[1] == fd.data_ptr() and pf[2] == fo.shape[0] for pf in pipe._prefetched):
                 todo.append((fo, fd))
-        loss = pipe.train_step(o, d, img, bkg_color=bkg, next_rays=todo[0] if todo else None)
+        if self.world == 1:
+            loss = pipe.train_step(o, d, img, bkg_color=bkg, next_rays=todo[0] if todo else None)
+        elif self._sync is not None:
+            loss = pipe.train_step(o, d, img, bkg_color=bkg, next_rays=todo[0] if todo else None, world_size=self.world, grad_sync=self._sync)
+        else:
+            from .. import distributed as D
+            loss = pipe.train_step(o, d, img, bkg_color=bkg, next_rays=todo[0] if todo else None, world_size=self.world,
+                                   all_reduce=lambda t: D.allreduce_grads(t, self.world))
         for fo, fd in todo[1:]:
             pipe.prefetch_samples(fo, fd, noise=True)
         # the counters the optimiser / EMA objects expose

@@ -311,9 +311,10 @@ def bench_module(args, name, emit=True):
     if name == 'ngp_module' and not use_dist and mode == 'graph':
         from arcnerf_amd.trainer import GraphedTrainStep
         graphed = GraphedTrainStep(m, lambda inp, out: {'sum': loss_of(out, inp)}, opt)
-    if name == 'ngp_module' and not use_dist and mode == 'fused':
+    if name == 'ngp_module' and mode == 'fused' and (not use_dist or world > 1):
+        # (N > 1: every rank its rays through the same stepper, the gradient summed in level groups overlapped with the scatter)
         from arcnerf_amd.trainer import FusedNgpStep
-        fused = FusedNgpStep(m, ngp_loss, opt, None, max_rays=n_rays, ahead=int(os.environ.get('ARCN_MODULE_AHEAD', '2')))
+        fused = FusedNgpStep(m, ngp_loss, opt, None, max_rays=n_rays, ahead=int(os.environ.get('ARCN_MODULE_AHEAD', '2')), world_size=world)
 
     def step(i):
         inp = pool[i % len(pool)]

@@ -272,3 +272,94 @@ def test_bench_under_torchrun_on_a_one_rank_rccl_communicator(config, segments):
             assert rc['exposed_ms'] >= 0.0 and ('level groups' in rc['grad_sync']) == (segments is None)
         # a one-rank SUM is the identity: the step trains like the single-GPU step (two-pass optimiser form)
         assert 1e8 < out['value'] < 1e9
+
+
+# ---- the drop-in module API, data parallel ---------------------------------------------------------------------------------------------
+def _module_ddp_worker(rank, world, port, path):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    import g26_utils as U
+    import torch.distributed as dist
+    from arcnerf_amd import distributed as D
+    from arcnerf_amd import trainer as T
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    from arcnerf_amd.optim import FusedAdam
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    D.init_from_env(backend='gloo')
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ov = ['--model.rays.noise_std', '0.0', '--model.obj_bound.volume.n_grid', '32', '--model.obj_bound.epoch_optim', '4',
+          '--model.obj_bound.epoch_optim_warmup', '8']
+    lc = type('C', (), {})()
+    lc.loss = type('C', (), {})()
+    lc.loss.ImgLoss = type('C', (), dict(keys=['rgb_coarse'], loss_type='Huber', delta=0.1, weight=3000.0))()
+    R, half, steps = 512, 256, 10
+    out = {}
+    for mode in ('eager', 'fused'):
+        torch.manual_seed(5)
+        m = build_model(load_configs(os.path.join(root, 'configs', 'nerf_ngp.yaml'), ov)).to(dev)
+        with torch.no_grad():
+            m.fg_model.coarse_geo_net.embed_fn.embeddings.mul_(1000.0)
+        opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=1e-2, eps=1e-15, weight_decay=1e-6, ema_decay=0.95, ema_in_param=True).flatten()
+        opt.grad_scale = 1.0 / world
+        D.broadcast_params(opt.flat_params(), src=0)
+        ema = T.EMA(m, 0.95, opt)
+        lf = T.build_loss(lc)
+        sampler_rng(reset=True)
+        m.train()
+        stepper = T.FusedNgpStep(m, lf, opt, ema, world_size=world, grad_level_cuts=(11, 5)) if mode == 'fused' else None
+        losses = []
+        for k in range(steps):
+            m.optimize(k)
+            inp = U.step_inputs(k, R)
+            sl = slice(rank * half, (rank + 1) * half)
+            feed = {'rays_o': torch.from_numpy(inp['rays_o'][sl])[None].to(dev), 'rays_d': torch.from_numpy(inp['rays_d'][sl])[None].to(dev),
+                    'rays_r': torch.zeros(1, half, 1, device=dev), 'img': torch.from_numpy(inp['img'][sl])[None].to(dev),
+                    'bkg_color': torch.from_numpy(inp['bkg_color'][sl])[None].to(dev)}
+            if stepper is not None:
+                _, loss = stepper(feed, k)
+            else:       # the module path the way DistributedDataParallel runs it: backward, SUM of the flat gradient, optimiser with 1 / world
+                o = m(feed, cur_epoch=k)
+                loss = lf(feed, o)
+                opt.zero_grad()
+                loss['sum'].backward()
+                dist.all_reduce(opt.flat_grads())
+                opt.step()
+                ema.ema_step()
+            losses.append(float(loss['sum']))
+        torch.cuda.synchronize()
+        out[mode + '_params'] = opt.flat_params().cpu().numpy()
+        out[mode + '_losses'] = np.array(losses)
+        out[mode + '_bits'] = m.fg_model.obj_bound.volume.get_voxel_bitfield(flatten=True).cpu().numpy()
+        if stepper is not None:
+            out['fused_steps'] = np.array(stepper.steps)
+            out['groups'] = np.array(len(stepper._sync.groups))
+    np.savez(path + '.rank{}'.format(rank), **out)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_through_the_module_api_fused_step_equal_the_eager_ddp_form():
+    """trainer.FusedNgpStep(world_size=2): every rank its shard of the rays through NgpPipeline.train_step on the flattened optimiser's buffers,
+    the gradient summed in level groups overlapped with the scatter, FusedAdam.grad_scale = 1 / 2, a refreshed occupancy broadcast from rank 0 -
+    against the same two ranks on the module path with ONE all-reduce of the flat gradient between backward and FusedAdam.step (what the
+    reference's DistributedDataParallel amounts to, common/trainer/basic_trainer.py:197-198).  Both forms leave bit-identical parameters on
+    the two ranks; the two forms agree to the float scatter's order noise; ten steps, two applied refreshes."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'out')
+        mp.spawn(_module_ddp_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+        r0, r1 = dict(np.load(path + '.rank0.npz')), dict(np.load(path + '.rank1.npz'))
+    for mode in ('eager', 'fused'):
+        assert np.array_equal(r0[mode + '_params'], r1[mode + '_params']), mode
+        assert np.array_equal(r0[mode + '_bits'], r1[mode + '_bits']) and 0.0 < r0[mode + '_bits'].mean() < 1.0
+    assert int(r0['fused_steps']) == 8 and int(r0['groups']) == 3
+    assert np.array_equal(r0['eager_bits'], r0['fused_bits'])
+    a, b = r0['eager_params'], r0['fused_params']
+    far = np.abs(a - b) > 1e-3 * np.abs(a).max()
+    assert far.mean() < 1e-3, far.mean()
+    for r in (r0, r1):
+        assert np.max(np.abs(r['eager_losses'] - r['fused_losses']) / np.abs(r['eager_losses'])) < 1e-4, (r['eager_losses'], r['fused_losses'])
