@@ -193,7 +193,7 @@ def _run_bench(extra, timeout=900):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize('config', ['ngp', 'neus_ngp_multivol'])
+@pytest.mark.parametrize('config', ['ngp', 'neus_ngp_multivol', 'ngp_module'])
 def test_bench_gpus_flag_spawns_the_ranks_itself(config):
     """`python bench.py --gpus 2` with no launcher around it (the driver's command form) must start two ranks itself (the reference:
     scripts/gpu.sh:9-21 -> basic_trainer.py:73-111 mp.spawn), report n_gpus = 2, the collective backend / world size it saw, the bytes
