@@ -87,6 +87,7 @@ class FusedNgpStep:
         self.grad_level_cuts = tuple(grad_level_cuts)
         self.sync_occupancy = bool(sync_occupancy)
         self._sync = None
+        self._bits_seen = None
         self._after_eager = False
         self.rebuilds = 0
 
@@ -137,12 +138,14 @@ class FusedNgpStep:
 
     def _sync_occupancy(self):
         bf = self.fg.obj_bound.volume.get_voxel_bitfield(flatten=True)
+        if self.world > 1 and self.sync_occupancy and self._bits_seen != (bf.data_ptr(), bf._version):
+            # a collective: decided by the Volume's state alone (every rank refreshes at the same epochs), never by this rank's buffers
+            # (a rebuild of the sample buffers happens on one rank at a time)
+            from .. import distributed as D
+            D.broadcast_occupancy(self.fg.obj_bound.volume.get_voxel_opafield(flatten=True), bf)     # in place: the Volume's own buffers
+            self._bits_seen = (bf.data_ptr(), bf._version)
         key = (id(self.pipe), bf.data_ptr(), bf._version)
         if self._bits_key != key:
-            if self.world > 1 and self.sync_occupancy:
-                from .. import distributed as D
-                D.broadcast_occupancy(self.fg.obj_bound.volume.get_voxel_opafield(flatten=True), bf)     # in place: the Volume's own buffers
-                key = (id(self.pipe), bf.data_ptr(), bf._version)
             self.pipe.set_bitfield(bf)
             self._bits_key = key
 
