@@ -1750,10 +1750,10 @@ def test_persistent_marcher_gives_the_samples_of_the_one_wave_per_ray_marcher():
     dev = torch.device('cuda:0')
     cfg = NgpConfig()
     fld = NgpField(cfg, device=dev, seed=0)
-    pipe = NgpPipeline(fld, max_rays=4096, max_samples=1 << 19, packed_bits=True)
+    pipe = NgpPipeline(fld, max_rays=32768, max_samples=1 << 19, packed_bits=True)
     pipe.set_bitfield(torch.from_numpy(synthetic_bitfield(cfg.n_grid, 0.05, seed=3)))
     L = N.lib()
-    for R in (4096, 1023):
+    for R in (4096, 1023, 32768):      # (32768 rays x 4096 waves: the headline's launch at the largest batch of the dynamic batch size)
         o, d = synthetic_rays(R, seed=41, device=dev)
 
         def march(waves, coarse):
@@ -1772,7 +1772,7 @@ def test_persistent_marcher_gives_the_samples_of_the_one_wave_per_ray_marcher():
         torch.cuda.synchronize()
         cnt = ref['counts'][:R].cpu().numpy()
         assert cnt.sum() > 10 * R and (cnt == 0).mean() > 0.3
-        for waves in (0, 64, 256, 1000, 2048, 100000):
+        for waves in ((0, 64, 256, 1000, 2048, 100000) if R <= 4096 else (4096, 5000)):
             for coarse in (pipe._coarse, None):
                 got = march(waves, coarse)
                 assert torch.equal(got['counts'][:R], ref['counts'][:R]), (R, waves)
