@@ -547,7 +547,13 @@ template <int F>
 __device__ __forceinline__ void emit_record(uint4 *__restrict__ lrecs, float *__restrict__ dtable, const LevelParams &lp, int bin,
                                             uint32_t pos, uint32_t cap, int shift, const uint4 &rec, uint32_t *ovf_flag = nullptr) {
     if (pos < cap) {
+#if defined(ARCN_EXP_BIN_SEQSTORE)      // experiment: what the producer would take if its record stores were coalesced (garbage results)
+        lrecs[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = rec;
+#elif defined(ARCN_EXP_BIN_NOSTORE)     // ... and with no record stores at all
+        if (rec.x == 0x12345678u && rec.y == 0x9abcdef0u) lrecs[0] = rec;
+#else
         lrecs[(int64_t)bin * cap + pos] = rec;
+#endif
     } else {
         if (ovf_flag) *ovf_flag = 1u;   // deterministic mode: these float atomics are not order-independent - say so (arcn_hashgrid_bwd_status)
         const uint32_t base_row = (uint32_t)bin << shift;
