@@ -39,6 +39,7 @@ struct DenseView {
     __device__ float z(int64_t r, int k) const { return zvals[r * P + k]; }
     __device__ void zero_dropped(int64_t, float *, float *) const {}  // the host wrapper clears the dropped last column
     __device__ void begin_ray(int64_t) {}
+    __device__ void zero_truncated(int, float *, float *) const {}
 };
 
 // Packed (offsets, t) form reproducing the reference's padded dense (R, P_dense) tensors: valid samples first, the
@@ -59,9 +60,24 @@ struct PackedView {
     // per-ray segment, loaded ONCE by begin_ray (the accessors below are called per sample; re-reading offsets[] there costs a
     // dependent global load each time because the compiler cannot prove the kernel's stores do not alias it)
     int32_t seg_off = 0, seg_n = 0;
+    // counts (optional): the samples the marcher emitted per ray.  The packed buffers hold min(total, capacity) samples, the offsets are
+    // clamped to the capacity: a ray behind the point where they filled up has a TRUNCATED segment.  Such a ray is never rendered from
+    // its partial sample set: it is treated as a ray without samples (background colour, no gradient; the samples it left in the
+    // buffers receive zero gradients), so an overflowed training step is the correct step of a smaller batch.
+    const int32_t *counts = nullptr;
+    int32_t trunc_n = 0;
     __device__ void begin_ray(int64_t r) {
         seg_off = offsets[r];
         seg_n = offsets[r + 1] - seg_off;
+        trunc_n = 0;
+        if (counts && seg_n < counts[r]) { trunc_n = seg_n; seg_n = 0; }
+    }
+    __device__ void zero_truncated(int lane, float *d_geo, float *d_radiance) const {
+        for (int k = lane; k < trunc_n; k += 64) {
+            const int64_t si = (int64_t)seg_off + k;
+            if (d_geo) d_geo[si] = 0.f;
+            if (d_radiance) { d_radiance[si * 3] = 0.f; d_radiance[si * 3 + 1] = 0.f; d_radiance[si * 3 + 2] = 0.f; }
+        }
     }
     __device__ int count(int64_t) const { return seg_n; }
     __device__ int ncol(int64_t r) const {
@@ -311,6 +327,7 @@ composite_bwd_kernel(View v, const int32_t *p_dense_ptr, const float *__restrict
     const int nchunk = (nc + 63) >> 6;
     bool neg = false;
     if (lane == 0) v.zero_dropped(r, d_geo, d_radiance);
+    v.zero_truncated(lane, d_geo, d_radiance);
     // pass 1: transmittance at every chunk start
     float carry = 1.0f;
     for (int c = 0; c < nchunk; ++c) {
@@ -356,6 +373,7 @@ composite_train_kernel(View v, const int32_t *p_dense_ptr, const float *__restri
         const int nc = v.ncol(r);
         bool neg = false;
         if (lane == 0) v.zero_dropped(r, d_geo, d_radiance);
+        v.zero_truncated(lane, d_geo, d_radiance);
         const RayOut o = composite_fwd_ray(v, r, lane, nc, bkg, bkg_rows, white_bkg, (float *)nullptr, (float *)nullptr,
                                            (float *)nullptr, s_carry[wv], neg);
         __builtin_amdgcn_wave_barrier();
@@ -622,12 +640,13 @@ ARCN_EXPORT int arcn_composite_packed_fwd(const float *sigma, const float *radia
                                           const int32_t *offsets, const float *noise, const float *bkg,
                                           int64_t bkg_rows, int64_t R, int p_dense, const int32_t *p_dense_ptr,
                                           int add_inf_z, int white_bkg, float *rgb, float *depth, float *mask,
-                                          float *weights_out, void *stream) {
+                                          float *weights_out, const int32_t *counts, void *stream) {
     if (R <= 0) return ARCN_OK;
     if (!sigma || !t_packed || !offsets) return einval("composite_packed_fwd: missing argument");
     if (!(bkg_rows == 0 || bkg_rows == 1 || bkg_rows == R)) return einval("composite_packed_fwd: bkg rows must be 0/1/R");
     if (p_dense < 2) p_dense = 2;
     PackedView v{sigma, nullptr, radiance, t_packed, noise, offsets, p_dense, add_inf_z ? p_dense : p_dense - 1, add_inf_z};
+    v.counts = counts;
     dim3 grid((unsigned)ceil_div<int64_t>(R, kRaysPerBlock));
     hipLaunchKernelGGL(composite_fwd_kernel<PackedView>, grid, dim3(256), 0, as_stream(stream), v, p_dense_ptr, bkg,
                        bkg_rows, R, white_bkg, rgb, depth, mask, nullptr, nullptr, weights_out, nullptr);
@@ -638,7 +657,8 @@ ARCN_EXPORT int arcn_composite_packed_train(const float *sigma, const float *rad
                                             const float *noise, const float *bkg, int64_t bkg_rows, int64_t R, int p_dense,
                                             const int32_t *p_dense_ptr, int add_inf_z, int white_bkg, const float *target,
                                             float huber_delta, float loss_weight, float *rgb, float *depth, float *mask,
-                                            float *d_rgb, float *loss_partials, float *d_sigma, float *d_radiance, void *stream) {
+                                            float *d_rgb, float *loss_partials, float *d_sigma, float *d_radiance, const int32_t *counts,
+                                            void *stream) {
     if (R <= 0) return ARCN_OK;
     if (!sigma || !radiance || !t_packed || !offsets || !target || !d_sigma || !d_radiance)
         return einval("composite_packed_train: missing argument");
@@ -647,6 +667,7 @@ ARCN_EXPORT int arcn_composite_packed_train(const float *sigma, const float *rad
     if (p_dense < 2) p_dense = 2;
     if ((add_inf_z ? p_dense : p_dense - 1) > 64 * kMaxChunks) return einval("composite_packed_train: at most 4096 samples per ray");
     PackedView v{sigma, nullptr, radiance, t_packed, noise, offsets, p_dense, add_inf_z ? p_dense : p_dense - 1, add_inf_z};
+    v.counts = counts;
     dim3 grid((unsigned)ceil_div<int64_t>(R, kRaysPerBlock));
     hipLaunchKernelGGL(composite_train_kernel<PackedView>, grid, dim3(256), 0, as_stream(stream), v, p_dense_ptr, bkg, bkg_rows, R,
                        white_bkg, target, huber_delta, loss_weight, rgb, depth, mask, d_rgb, loss_partials, d_sigma, d_radiance);
@@ -657,11 +678,13 @@ ARCN_EXPORT int arcn_composite_packed_bwd(const float *sigma, const float *radia
                                           const int32_t *offsets, const float *noise, const float *bkg,
                                           int64_t bkg_rows, int64_t R, int p_dense, const int32_t *p_dense_ptr,
                                           int add_inf_z, int white_bkg, const float *d_rgb, const float *d_depth,
-                                          const float *d_mask, float *d_sigma, float *d_radiance, void *stream) {
+                                          const float *d_mask, float *d_sigma, float *d_radiance, const int32_t *counts,
+                                          void *stream) {
     if (R <= 0) return ARCN_OK;
     if (!sigma || !t_packed || !offsets || !d_sigma) return einval("composite_packed_bwd: missing argument");
     if (p_dense < 2) p_dense = 2;
     PackedView v{sigma, nullptr, radiance, t_packed, noise, offsets, p_dense, add_inf_z ? p_dense : p_dense - 1, add_inf_z};
+    v.counts = counts;
     dim3 grid((unsigned)ceil_div<int64_t>(R, kRaysPerBlock));
     hipLaunchKernelGGL(composite_bwd_kernel<PackedView>, grid, dim3(256), 0, as_stream(stream), v, p_dense_ptr, bkg,
                        bkg_rows, R, white_bkg, d_rgb, d_depth, d_mask, static_cast<const float *>(nullptr), d_sigma, d_radiance);

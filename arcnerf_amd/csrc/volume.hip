@@ -5,6 +5,7 @@
 // multiply-by-reciprocal; the instant-ngp style `distance_to_next_voxel` with world-space centre/half-length; whole-dt
 // stepping) and this file is compiled with -ffp-contract=off so every t and every voxel index is bit-identical to the
 // CPU oracle.  Every kernel runs on the caller's stream; nothing synchronises.
+#include "camera.hpp"
 #include "common.hpp"
 #include "morton.hpp"
 
@@ -457,60 +458,13 @@ multivol_sampling_kernel(const float *__restrict__ rays_o, const float *__restri
 // ---- ray generation (arcnerf/render/ray_helper.py:12-153, geometry/projection.py:8-66) ------------------------------------
 // One lane per ray: pixel -> camera (z = 1, skew included) -> world -> direction, normalised or warped to NDC, plus the mip-nerf
 // radius in full-image mode (the lane recomputes its right neighbour's direction instead of a second pass over a (W,H,3) tensor).
-struct CamParams {
-    float fx, skew, cx, fy, cy;
-    float r[3][4];  // c2w rows
-};
-
-__device__ __forceinline__ void ray_dir(const CamParams &c, float pi, float pj, bool normalise, float out[3]) {
-    float cam[3];
-    cam[0] = (pi - (c.skew * (pj - c.cy) / c.fy) - c.cx) / c.fx * 1.0f;
-    cam[1] = (pj - c.cy) / c.fy * 1.0f;
-    cam[2] = 1.0f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        float w = c.r[k][0] * cam[0];
-        w = w + c.r[k][1] * cam[1];
-        w = w + c.r[k][2] * cam[2];
-        w = w + c.r[k][3];
-        out[k] = w - c.r[k][3];
-    }
-    if (normalise) {
-        const float nrm = sqrtf(out[0] * out[0] + out[1] * out[1] + out[2] * out[2]) + 1e-8f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) out[k] = out[k] / nrm;
-    }
-}
-
-// origin and direction of pixel (pi, pj) as the reference returns them: normalised, or warped to NDC (get_ndc_rays)
-__device__ __forceinline__ void pixel_ray(const CamParams &c, int W, int H, float pi, float pj, bool normalise, bool ndc,
-                                          float ndc_near, float o[3], float d[3]) {
-    o[0] = c.r[0][3]; o[1] = c.r[1][3]; o[2] = c.r[2][3];
-    ray_dir(c, pi, pj, normalise && !ndc, d);
-    if (ndc) {
-        const float t = -(ndc_near + o[2]) / d[2];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) o[k] = o[k] + t * d[k];
-        const float ax = -1.0f / ((float)W / (2.0f * c.fx)), ay = -1.0f / ((float)H / (2.0f * c.fy));
-        const float no[3] = {ax * o[0] / o[2], ay * o[1] / o[2], 1.0f + 2.0f * ndc_near / o[2]};
-        const float nd[3] = {ax * (d[0] / d[2] - o[0] / o[2]), ay * (d[1] / d[2] - o[1] / o[2]), -2.0f * ndc_near / o[2]};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { o[k] = no[k]; d[k] = nd[k]; }
-    }
-}
-
 __global__ void __launch_bounds__(256)
 get_rays_kernel(int W, int H, const float *__restrict__ K, const float *__restrict__ c2w, int wh_order,
                 const int64_t *__restrict__ index, int64_t n, int center_pixel, int normalise, int ndc, float ndc_near,
                 float *__restrict__ rays_o, float *__restrict__ rays_d, float *__restrict__ rays_r) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    CamParams c;
-    c.fx = K[0]; c.skew = K[1]; c.cx = K[2]; c.fy = K[4]; c.cy = K[5];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) c.r[k][m] = c2w[4 * k + m];
+    const CamParams c = load_camera(K, c2w);
     int64_t i, j;
     if (index) { i = index[p] / H; j = index[p] % H; }
     else if (wh_order) { i = p / H; j = p % H; }
@@ -564,6 +518,49 @@ __global__ void __launch_bounds__(256) reduce_max_kernel(const float *__restrict
 // an inclusive prefix, publish the own inclusive prefix); then the waves copy their samples to t_packed / ray_id at their final
 // offsets.  Ray blocks are handed out by a ticket (atomic counter) so that a workgroup only ever waits for workgroups that have
 // already started.  Replaces march_count + exclusive_scan (ONE 1024-thread workgroup) + march_write and 2 x 34 MB of scratch traffic.
+// The 64 lattice values t_base, fl(t_base + dt), fl(fl(t_base + dt) + dt), ... WITHOUT the 63 dependent adds, bit for bit.
+// Inside one binade [2^e, 2^(e+1)) every float is a multiple of u = 2^(e-23): t = m u with an integer m in [2^23, 2^24), and
+// dt = D u with D real (dt < t has finer bits than u).  fl(t + dt) is the multiple of u nearest to (m + D) u, i.e. (m + q) u with
+// q = rn(D) - the SAME q at every step of the binade, unless frac(D) is exactly 1/2 (then round-to-even alternates with the parity of
+// m: not handled here).  So lane l holds (m0 + l q) u: one integer multiply-add and the exponent field.  A trip that crosses into the
+// next binade does it once (64 dt < t): the crossing value is ONE real float add from the last lane of the first segment, and the
+// lanes behind it run in the new binade with q' = rn(D / 2).  Returns false (wave uniform; the caller runs the systolic chain) for a
+// tie in either binade, a second crossing, denormals or a dt that rounds away.
+__device__ __forceinline__ bool lattice_closed_form(float t_base_v, float dt, int lane, float &t_out) {
+#ifdef ARCN_EXP_LATTICE_CHAIN
+    return false;
+#endif
+    const uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t_base_v));
+    const int ef = (int)((tb >> 23) & 0xffu);
+    if ((tb >> 31) || ef < 1 || ef > 200) return false;
+    const float D = ldexpf(dt, 150 - ef);                       // dt / u: a power-of-two scaling, exact
+    if (!(D >= 0.75f && D < 4194304.0f)) return false;
+    const float fl = floorf(D);
+    if (D - fl == 0.5f) return false;                           // tie: the sequential sums alternate
+    const uint32_t q = (uint32_t)rintf(D);
+    const uint32_t m0 = (tb & 0x7fffffu) | 0x800000u;
+    const uint32_t m = m0 + (uint32_t)lane * q;
+    const uint64_t in_first = __ballot(m < 0x1000000u);         // monotone in the lane: a prefix of the wave
+    t_out = __builtin_bit_cast(float, ((uint32_t)ef << 23) | (m & 0x7fffffu));
+    if (in_first == ~0ull) return true;
+    const int c = __builtin_popcountll(in_first);               // first lane of the next binade (>= 1: lane 0 is t_base itself)
+    const float t_prev = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_out), c - 1));
+    const float t_c = t_prev + dt;                              // the crossing step: a real, correctly rounded add
+    const uint32_t cb = __builtin_bit_cast(uint32_t, t_c);
+    const int ef2 = (int)((cb >> 23) & 0xffu);
+    if (ef2 != ef + 1) return false;
+    const float D2 = D * 0.5f;
+    const float fl2 = floorf(D2);
+    if (D2 - fl2 == 0.5f || !(D2 >= 0.75f)) return false;
+    const uint32_t q2 = (uint32_t)rintf(D2);
+    const uint32_t mc = (cb & 0x7fffffu) | 0x800000u;
+    const uint32_t m2 = mc + (uint32_t)(lane - c) * q2;         // (lanes < c wrap around: masked below)
+    const bool second = lane >= c;
+    if (__ballot(second && m2 >= 0x1000000u)) return false;     // a second crossing inside one trip
+    if (second) t_out = __builtin_bit_cast(float, ((uint32_t)ef2 << 23) | (m2 & 0x7fffffu));
+    return true;
+}
+
 struct MarchPacked {
     int32_t *offsets;        // (n_rays + 1), clamped to capacity
     float *t_packed;
@@ -674,11 +671,14 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
             // Systolic: every step each lane takes its left neighbour's value (DPP wave_shr:1, free on the add) and adds dt;
             // lane 0 has no neighbour, keeps its own value and adds 0.  After k steps lanes 0..k hold the exact sequential
             // sums and keep reproducing them, so 63 single-instruction steps replace a 63-trip divergent loop.
-            float t = t_base;
+            float t;
+            if (!lattice_closed_form(t_base, dt, lane, t)) {
+                t = t_base;
 #pragma unroll
-            for (int k = 0; k < 63; ++k) {
-                const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0x138, 0xf, 0xf, false));
-                t = left + dt_lane;
+                for (int k = 0; k < 63; ++k) {
+                    const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0x138, 0xf, 0xf, false));
+                    t = left + dt_lane;
+                }
             }
             const float t_next_base = __shfl(t, 63, 64) + dt;
             // 2. per-point state

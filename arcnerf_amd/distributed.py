@@ -84,40 +84,87 @@ def allreduce_grads(flat_grads, world=None, group=None):
     return flat_grads
 
 
-def grad_segments(n_total, k, align=4096):
-    """k contiguous [lo, hi) segments covering n_total elements, boundaries aligned to `align` elements (last one ragged)."""
-    k = max(1, int(k))
-    per = -(-int(n_total) // k)
-    per = -(-per // align) * align
-    segs, lo = [], 0
-    while lo < n_total:
-        hi = min(int(n_total), lo + per)
-        segs.append((lo, hi))
-        lo = hi
-    return segs
+class ShardedGradSync:
+    """The N > 1 step without a replicated optimiser: reduce-scatter of the flat gradient, every rank runs Adam + EMA on ITS 1/N of the
+    parameters (only that shard's moments are ever touched), all-gather of the updated shards.
 
+    Same wire bytes as the all-reduce it replaces (a ring all-reduce IS a reduce-scatter followed by an all-gather: 2 (N-1)/N x 48.8 MB
+    per GPU); what goes away is the optimiser pass over the whole buffer on every rank (62 us for the NGP parameter set -> 8 us at 8
+    ranks) between the two halves of the exchange.  The flat buffer [hash table | geometry weights | radiance weights] is cut into N equal
+    16-byte aligned shards [r * per, (r + 1) * per) plus a tail of fewer than 4 N floats, which is all-reduced and updated on every rank.
+    Both collectives run in place on the flat buffers (the shard of rank r is where reduce_scatter / all_gather expect it).
+    Same arithmetic as the flat form: every gradient element is summed over the ranks once, every parameter sees the same update
+    (tests/test_distributed_gloo.py: bit-identical parameters on 2 and 4 ranks)."""
 
-class PipelinedGradSync:
-    """The per-step gradient all-reduce in K segments, each launched asynchronously (`async_op=True`: the collective waits for the
-    kernels already queued on the current stream and then runs on the communicator's own stream), so the optimiser can update
-    segment i while segments i+1.. are still on the wire: the fused Adam/EMA pass (HBM-bound, ~70 us for the NGP parameter
-    set) hides behind the ring instead of following it.  Same arithmetic as one flat all-reduce: a SUM per element."""
-
-    def __init__(self, n_total, n_segments=4, group=None):
+    def __init__(self, n_params, world=None, rank=None, group=None, align=4):
         self.group = group
-        self.segments = grad_segments(n_total, n_segments)
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world, self.rank, self.n = int(world), int(rank), int(n_params)
+        self.per = (self.n // self.world) // align * align
+        self.body = self.per * self.world
+        self.lo, self.hi = self.rank * self.per, (self.rank + 1) * self.per
+        # what this rank's optimiser updates: its shard, and the replicated tail
+        self.segments = [(self.lo, self.hi)] + ([(self.body, self.n)] if self.body < self.n else [])
         self.works = []
+        self.timing = False
+        self._marks = None
 
     def launch(self, flat_grads):
+        """after the backward: the sums of this rank's shard land in flat_grads[lo:hi] (in place), the tail is all-reduced"""
         self.works = []
+        if self.timing and flat_grads.is_cuda:
+            import collections
+            if self._marks is None:
+                self._marks = collections.deque(maxlen=1024)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._marks.append([e0, None])
         if not _active(self.group):
             return
-        for lo, hi in self.segments:
-            self.works.append(dist.all_reduce(flat_grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.per > 0:
+            self.works.append(dist.reduce_scatter_tensor(flat_grads[self.lo:self.hi], flat_grads[:self.body], op=dist.ReduceOp.SUM,
+                                                         group=self.group, async_op=True))
+        if self.body < self.n:
+            self.works.append(dist.all_reduce(flat_grads[self.body:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def wait(self, i):
-        if self.works:
-            self.works[i].wait()
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+    def clear_foreign(self, flat_grads):
+        """the other ranks' shards of the gradient buffer hold this rank's partial sums: cleared for the next backward (the optimiser
+        clears what it reads)"""
+        if self.lo > 0:
+            flat_grads[:self.lo].zero_()
+        if self.hi < self.body:
+            flat_grads[self.hi:self.body].zero_()
+
+    def gather(self, *flat_buffers):
+        """the updated shards of every rank, in place (parameters; the EMA shadow when it is kept beside them); the current stream
+        continues behind the collective (the next forward reads every shard)"""
+        if _active(self.group) and self.per > 0:
+            for b in flat_buffers:
+                self.works.append(dist.all_gather_into_tensor(b[:self.body], b[self.lo:self.hi], group=self.group, async_op=True))
+        self.wait()
+        if self.timing and self._marks and self._marks[-1][1] is None and flat_buffers and flat_buffers[0].is_cuda:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._marks[-1][1] = e1
+
+    def exposed_ms(self, last_n=None):
+        """per step: launch of the reduce-scatter -> end of the all-gather, minus nothing: the sharded optimiser sits between the two (host
+        read: synchronises); needs timing=True"""
+        marks = [m for m in (self._marks or []) if m[1] is not None]
+        marks = marks if last_n is None else marks[-last_n:]
+        out = []
+        for e0, e1 in marks:
+            e1.synchronize()
+            out.append(max(0.0, e0.elapsed_time(e1)))
+        return out
 
 
 class LevelGroupedGradSync:
@@ -166,7 +213,8 @@ class LevelGroupedGradSync:
         # (a probe stream that only waits for it) - whose distance is the part of the exchange nothing hid (exposed_ms)
         self.timing = False
         self._probe = None
-        self._marks = []
+        import collections
+        self._marks = collections.deque(maxlen=1024)      # (bounded: a long run with timing on keeps the last 1024 steps)
 
     def launch_group(self, i, flat_grads):
         _, lo, hi = self.groups[i]
@@ -192,7 +240,7 @@ class LevelGroupedGradSync:
     def exposed_ms(self, last_n=None):
         """per step: time from the end of the compute that produced the last group's gradient to the end of the last collective
         (host read: synchronises); needs timing=True"""
-        marks = self._marks if last_n is None else self._marks[-last_n:]
+        marks = list(self._marks) if last_n is None else list(self._marks)[-last_n:]
         out = []
         for t0, t1 in marks:
             t1.synchronize()
@@ -215,7 +263,11 @@ def broadcast_bitfield(bits, src=0, group=None):
 def broadcast_occupancy(opafield, bitfield, src=0, group=None):
     """NgpPipeline.occupancy_sync: rank `src`'s opacity field and bool bitfield to every rank before a refreshed occupancy is applied
     (the reference's DDP re-broadcasts these buffers on every forward, common/trainer/basic_trainer.py:198).  With the same refresh seed
-    and bit-identical parameters the ranks compute the same fields anyway; this makes it hold by construction."""
+    and bit-identical parameters the ranks compute the same fields anyway; this makes it hold by construction.
+    ORDER: these are collectives on the default communicator, which the (asynchronous) gradient collectives of the step share - every rank
+    must issue them at the same point of its program.  They do when the refresh is driven by the step count (`update_occupancy(epoch,
+    apply=True)` / `VolumeBound.optimize(epoch)` at `epoch % epoch_optim == 0`, the same epoch on every rank) and never by rank-local
+    state such as a buffer rebuild; pass a dedicated `group` if a caller cannot guarantee that."""
     if _active(group):
         dist.broadcast(opafield, src=src, group=group)
         as_bytes = bitfield.view(torch.uint8) if bitfield.dtype == torch.bool else bitfield

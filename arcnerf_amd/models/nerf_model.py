@@ -234,7 +234,8 @@ class NeRF(FgModel):
         if need > cap:
             import warnings
             warnings.warn('packed NGP path: the previous training step asked for {} samples for {} rays but the buffers hold {}; the '
-                          'rays past the capacity were rendered with truncated sample sets in that step.  Growing the buffers to '
+                          'rays behind the fill point were left out of that step (background colour, no gradient: never a ray rendered from a '
+                          'truncated sample set).  Growing the buffers to '
                           '{} samples now (set model.chunk_rays lower, or render with inference_only=True for the exact '
                           'path).'.format(need, R, cap, (need * 5 // 4 + 1023) // 1024 * 1024))
             self._packed_pipeline(device, min_samples=(need * 5 // 4 + 1023) // 1024 * 1024)

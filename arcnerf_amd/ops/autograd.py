@@ -10,13 +10,11 @@ from . import functional as F
 
 
 def _accumulate_node(p):
-    """the AccumulateGrad node of a leaf parameter (cached on the tensor; autograd keeps one per leaf)"""
-    node = getattr(p, '_arcn_acc_node', None)
-    if node is None:
-        with torch.enable_grad():
-            node = p.view_as(p).grad_fn.next_functions[0][0]
-        p._arcn_acc_node = node
-    return node
+    """the AccumulateGrad node of a leaf parameter (autograd keeps one per leaf and hands the same one out while it lives).  Looked up
+    per call, NOT cached on the tensor: the node holds the parameter strongly, so parameter -> node -> parameter would be a cycle through
+    C++ that Python's collector cannot see - the flat optimiser storage behind the parameter (200 MB for the NGP set) would never be freed."""
+    with torch.enable_grad():
+        return p.view_as(p).grad_fn.next_functions[0][0]
 
 
 def direct_grad(p):

@@ -124,6 +124,61 @@ def get_rays(W, H, intrinsic, c2w, wh_order=True, flat_index=None, center_pixel=
     return o, d, r
 
 
+def fetch_train_batch(ids, n_img, H, W, window=None, rgba=None, img=None, mask=None, intrinsic=None, c2w=None, center_pixel=True,
+                      normalize_rays_d=True, bkg_rand=None, bkg_const=None, want_rays_r=True, want_src=False, bad_ids=None):
+    """One launch for a training batch (arcn_fetch_train_batch): ids (n,) int64 rows of the (cropped) dataset -> dict with `rays_o`,
+    `rays_d` (n,3), `rays_r` (n,1) when cameras are given; `img` (n,3) (blended with the background colour when the data has a mask and a
+    colour is given), `mask` (n,), `bkg_color` (n,3) when colours are given; `src` (n,) int64 rows of the uncropped tensors on request.
+    window = (y0, x0, Hc, Wc) of the centre crop (default: the whole image).  bad_ids: int32 device counter of ids outside the dataset."""
+    _req(ids, rgba, img, mask, intrinsic, c2w, bkg_rand, bad_ids)
+    ids = ids.contiguous()
+    if ids.dtype != torch.int64:
+        raise RuntimeError('fetch_train_batch: ids must be int64')
+    n, dev = ids.shape[0], ids.device
+    y0, x0, Hc, Wc = (0, 0, int(H), int(W)) if window is None else [int(v) for v in window]
+    if rgba is not None and (rgba.dtype != torch.uint8 or rgba.numel() != n_img * H * W * 4):
+        raise RuntimeError('fetch_train_batch: rgba must be (n_img, H, W, 4) bytes')
+    if img is not None and img.numel() != n_img * H * W * 3:
+        raise RuntimeError('fetch_train_batch: img must be (n_img, H, W, 3)')
+    if mask is not None and mask.numel() != n_img * H * W:
+        raise RuntimeError('fetch_train_batch: mask must be (n_img, H, W)')
+    out = {}
+    has_cam = intrinsic is not None and c2w is not None
+    if has_cam:
+        Kc, Mc = _f32(intrinsic), _f32(c2w)
+        if Kc.numel() != n_img * 9 or Mc.numel() != n_img * 16:
+            raise RuntimeError('fetch_train_batch: intrinsic must be (n_img, 3, 3) and c2w (n_img, 4, 4)')
+        out['rays_o'] = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        out['rays_d'] = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        if want_rays_r:
+            out['rays_r'] = torch.empty((n, 1), dtype=torch.float32, device=dev)
+    else:
+        Kc = Mc = None
+    has_col = rgba is not None or img is not None
+    has_mask = rgba is not None or mask is not None
+    imgc, maskc = _f32(img), _f32(mask)
+    rgbac = rgba.contiguous() if rgba is not None else None
+    blend = has_col and has_mask and (bkg_rand is not None or bkg_const is not None)
+    if has_col:
+        out['img'] = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        if has_mask:
+            out['mask'] = torch.empty((n,), dtype=torch.float32, device=dev)
+        if blend:
+            out['bkg_color'] = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    if want_src:
+        out['src'] = torch.empty((n,), dtype=torch.int64, device=dev)
+    br = _f32(bkg_rand) if blend and bkg_rand is not None else None
+    if br is not None and br.numel() != 3 * n:
+        raise RuntimeError('fetch_train_batch: bkg_rand must be (n, 3)')
+    bc = (C.c_float * 3)(*[float(v) for v in bkg_const]) if blend and br is None else None
+    N.check(N.lib().arcn_fetch_train_batch(N.ptr(rgbac), N.ptr(imgc), N.ptr(maskc), N.ptr(Kc), N.ptr(Mc), int(n_img), int(H), int(W), y0, x0, Hc, Wc,
+                                          N.ptr(ids), n, int(bool(center_pixel)), int(bool(normalize_rays_d)), N.ptr(br),
+                                          C.addressof(bc) if bc is not None else None, N.ptr(out.get('rays_o')), N.ptr(out.get('rays_d')),
+                                          N.ptr(out.get('rays_r')), N.ptr(out.get('img')), N.ptr(out.get('mask')), N.ptr(out.get('bkg_color')),
+                                          N.ptr(out.get('src')), N.ptr(bad_ids), N.stream()), 'fetch_train_batch')
+    return out
+
+
 def sparse_volume_sampling(rays_o, rays_d, near, far, n_pts, dt, aabb23, n_grid, bitfield, near_distance, rng_state,
                            rng_inc, want_counts=False):
     _req(rays_o, rays_d, near, far, aabb23, bitfield)
@@ -972,8 +1027,8 @@ def ray_marching_bwd(sigma, radiance, zvals, d_rgb, d_depth=None, d_mask=None, a
 
 
 def composite_packed_fwd(sigma, radiance, t, offsets, p_dense=2, p_dense_dev=None, add_inf_z=False, white_bkg=False,
-                         bkg_color=None, noise=None, want_weights=False):
-    _req(sigma, radiance, t, offsets, bkg_color, noise)
+                         bkg_color=None, noise=None, want_weights=False, counts=None):
+    _req(sigma, radiance, t, offsets, bkg_color, noise, counts)
     sg, rad, t, ns = _f32(sigma), _f32(radiance), _f32(t), _f32(noise)
     R = offsets.shape[0] - 1
     bk, bk_rows = _bkg(bkg_color, R)
@@ -984,13 +1039,13 @@ def composite_packed_fwd(sigma, radiance, t, offsets, p_dense=2, p_dense_dev=Non
     w = torch.zeros(sg.shape[0], dtype=torch.float32, device=dev) if want_weights else None
     N.check(N.lib().arcn_composite_packed_fwd(N.ptr(sg), N.ptr(rad), N.ptr(t), N.ptr(offsets), N.ptr(ns), N.ptr(bk), bk_rows,
                                              R, int(p_dense), _nptr(p_dense_dev), int(add_inf_z), int(white_bkg), N.ptr(rgb),
-                                             N.ptr(depth), N.ptr(mask), N.ptr(w), N.stream()), 'composite_packed_fwd')
+                                             N.ptr(depth), N.ptr(mask), N.ptr(w), N.ptr(counts), N.stream()), 'composite_packed_fwd')
     return {'rgb': rgb, 'depth': depth, 'mask': mask, 'weights': w}
 
 
 def composite_packed_bwd(sigma, radiance, t, offsets, d_rgb, d_depth=None, d_mask=None, p_dense=2, p_dense_dev=None,
-                         add_inf_z=False, white_bkg=False, bkg_color=None, noise=None):
-    _req(sigma, radiance, t, offsets, bkg_color, noise, d_rgb, d_depth, d_mask)
+                         add_inf_z=False, white_bkg=False, bkg_color=None, noise=None, counts=None):
+    _req(sigma, radiance, t, offsets, bkg_color, noise, d_rgb, d_depth, d_mask, counts)
     sg, rad, t, ns = _f32(sigma), _f32(radiance), _f32(t), _f32(noise)
     R = offsets.shape[0] - 1
     bk, bk_rows = _bkg(bkg_color, R)
@@ -999,7 +1054,7 @@ def composite_packed_bwd(sigma, radiance, t, offsets, d_rgb, d_depth=None, d_mas
     N.check(N.lib().arcn_composite_packed_bwd(N.ptr(sg), N.ptr(rad), N.ptr(t), N.ptr(offsets), N.ptr(ns), N.ptr(bk), bk_rows,
                                              R, int(p_dense), _nptr(p_dense_dev), int(add_inf_z), int(white_bkg),
                                              N.ptr(_f32(d_rgb)), N.ptr(_f32(d_depth)), N.ptr(_f32(d_mask)), N.ptr(d_sigma),
-                                             N.ptr(d_rad), N.stream()), 'composite_packed_bwd')
+                                             N.ptr(d_rad), N.ptr(counts), N.stream()), 'composite_packed_bwd')
     return d_sigma, d_rad
 
 

@@ -360,6 +360,8 @@ class NgpPipeline:
         self._occ_scratch = None
         self._pb = self._gb = None
         self.generation = 0
+        NgpPipeline._built += 1
+        self.generation_id = NgpPipeline._built      # (unlike id(): never handed out twice in a process)
         self.occupancy_sync = None      # callable(opafield, new_bitfield) run on the refresh stream before a refreshed bitfield is applied
         # HIP-graph replay (trainer.GraphedTrainStep): the sampler reads its pcg32 state from device memory (rewritten before every
         # replay) and a refreshed occupancy is written INTO the packed bits / culling grid the recorded marcher points at
@@ -651,16 +653,16 @@ class NgpPipeline:
             N.check(L.arcn_composite_packed_train(N.ptr(b['sigma']), N.ptr(b['rgb_s']), N.ptr(b['t']), N.ptr(b['offsets']), N.ptr(noise),
                                                   N.ptr(bk), bk_rows, R, 2, b['p_dense'].data_ptr(), int(cfg.add_inf_z),
                                                   int(cfg.white_bkg), N.ptr(huber_target.contiguous().float()), cfg.huber_delta,
-                                                  cfg.loss_weight, N.ptr(b['rgb']), N.ptr(b['depth']), N.ptr(b['mask']), N.ptr(b['d_rgb']),
+                                                  cfg.loss_weight * self.loss_scale, N.ptr(b['rgb']), N.ptr(b['depth']), N.ptr(b['mask']), N.ptr(b['d_rgb']),
                                                   ring[k].data_ptr(),
-                                                  N.ptr(b['d_sigma']), N.ptr(b['d_rgb_s']), st), 'composite_packed_train')
+                                                  N.ptr(b['d_sigma']), N.ptr(b['d_rgb_s']), N.ptr(b['counts']), st), 'composite_packed_train')
             self.last_loss = StepLoss(self, k, self.generation, (R + 3) // 4)
             self._composite_bwd_done = True
             return b['rgb'][:R], b['depth'][:R], b['mask'][:R]
         N.check(L.arcn_composite_packed_fwd(N.ptr(b['sigma']), N.ptr(b['rgb_s']), N.ptr(b['t']), N.ptr(b['offsets']),
                                             N.ptr(noise), N.ptr(bk), bk_rows, R, 2, b['p_dense'].data_ptr(),
                                             int(cfg.add_inf_z), int(cfg.white_bkg), N.ptr(b['rgb']), N.ptr(b['depth']),
-                                            N.ptr(b['mask']), None, st), 'composite_packed_fwd')
+                                            N.ptr(b['mask']), None, N.ptr(b['counts']), st), 'composite_packed_fwd')
         return b['rgb'][:R], b['depth'][:R], b['mask'][:R]
 
     # ---- backward + optimiser -----------------------------------------------------------------------
@@ -676,7 +678,7 @@ class NgpPipeline:
             N.check(L.arcn_composite_packed_bwd(N.ptr(b['sigma']), N.ptr(b['rgb_s']), N.ptr(b['t']), N.ptr(b['offsets']),
                                                 N.ptr(self._noise), N.ptr(bk), bk_rows, R, 2, b['p_dense'].data_ptr(),
                                                 int(cfg.add_inf_z), int(cfg.white_bkg), N.ptr(d_rgb), N.ptr(d_depth), N.ptr(d_mask),
-                                                N.ptr(b['d_sigma']), N.ptr(b['d_rgb_s']), st), 'composite_packed_bwd')
+                                                N.ptr(b['d_sigma']), N.ptr(b['d_rgb_s']), N.ptr(b['counts']), st), 'composite_packed_bwd')
         self._composite_bwd_done = False
         S = self.cap
         # the step's tail launch (optimizer_step) sums the dW partials and applies the optimiser: the nets leave them in their scratch
@@ -751,11 +753,14 @@ class NgpPipeline:
                                     0 if self.hash_ws is None else self.hash_ws.numel(), S, n_dev.data_ptr(), st),
                 'hashgrid_bwd')
 
+    loss_scale = 1.0
+    _built = 0
+
     def huber_grad(self, rgb, target):
         """ImgLoss(Huber, delta, weight) of arcnerf/loss/img_loss.py:60-100: loss value and d loss / d rgb (mean over R*3)."""
         cfg, b = self.cfg, self.buf
         R = rgb.shape[0]
-        loss, d = F.huber_loss_grad(rgb, target, cfg.huber_delta, cfg.loss_weight, dx=b['d_rgb'][:R], loss=b['loss'])
+        loss, d = F.huber_loss_grad(rgb, target, cfg.huber_delta, cfg.loss_weight * self.loss_scale, dx=b['d_rgb'][:R], loss=b['loss'])
         return loss[0], d
 
     def _plan_fused_adam(self, S):
@@ -825,11 +830,16 @@ class NgpPipeline:
                             lr=cfg.lr, betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, ema_decay=cfg.ema_decay if with_ema else 0.0,
                             grad_scale=1.0 / world_size, ema_step=self.ema_n_step, zero_grad=True)
 
-    def train_step(self, rays_o, rays_d, target_rgb, bkg_color=None, all_reduce=None, world_size=1, next_rays=None, grad_sync=None):
+    def train_step(self, rays_o, rays_d, target_rgb, bkg_color=None, all_reduce=None, world_size=1, next_rays=None, grad_sync=None, loss_scale=1.0):
         """fwd + loss + bwd (+ one gradient all-reduce) + Adam/EMA.  Returns the loss tensor (device, no sync).
         next_rays = (rays_o, rays_d) of the FOLLOWING step: their marching is overlapped with this step's backward.
-        grad_sync: a distributed.PipelinedGradSync (takes precedence over the flat `all_reduce` callable)."""
+        grad_sync: a distributed.LevelGroupedGradSync or ShardedGradSync (takes precedence over the flat `all_reduce` callable).
+        loss_scale: factor on the loss weight of THIS step.  The loss is a mean over this rank's rays and the optimiser divides the summed
+        gradients by the world size: with UNEQUAL ray shards (distributed.balanced_shards) a rank passes
+        loss_scale = R_local * world_size / R_global so that the step optimises the mean over the GLOBAL batch (every ray the same weight,
+        as in one process on the whole batch); equal shards: 1."""
         cfg, b = self.cfg, self.buf
+        self.loss_scale = float(loss_scale)
         fused = self.fused_composite
         rgb, _, _ = self.forward(rays_o, rays_d, bkg_color, train=True, noise='auto', huber_target=target_rgb if fused else None)
         if self.prefetch_at == 5 and self.prefetch_depth >= 2 and grad_sync is None and all_reduce is None:
@@ -859,12 +869,21 @@ class NgpPipeline:
                 self.optimizer_step(world_size, lo, hi, advance=(i == 0))
             return loss
         if grad_sync is not None:
-            # segmented all-reduce pipelined with the optimiser (distributed.PipelinedGradSync)
+            # distributed.ShardedGradSync: reduce-scatter, Adam + EMA on this rank's shard (and the replicated tail), all-gather
+            if not hasattr(grad_sync, 'gather'):
+                raise RuntimeError('grad_sync must be a distributed.LevelGroupedGradSync or a distributed.ShardedGradSync')
+            if self._pb is not None or self._gb is not None:
+                raise RuntimeError('ShardedGradSync needs the step on the field\'s own flat buffers')
             grad_sync.launch(self.field.grads)
             self._prefetch_point(3)
+            grad_sync.wait()
             for i, (lo, hi) in enumerate(grad_sync.segments):
-                grad_sync.wait(i)
                 self.optimizer_step(world_size, lo, hi, advance=(i == 0))
+            grad_sync.clear_foreign(self.field.grads)
+            if cfg.ema_decay is not None and self.ema is not self.field.params:
+                grad_sync.gather(self.field.params, self.ema)
+            else:
+                grad_sync.gather(self.field.params)
             return loss
         self._prefetch_point(3)  # before a blocking collective is queued: the second stream only waits for the backward
         if all_reduce is not None:

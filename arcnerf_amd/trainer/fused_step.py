@@ -12,7 +12,9 @@ occupancy refresh of the module's own Volume) stay what they are, inference goes
     output, loss = stepper(feed_in, epoch, next_feed_in=batch_of_the_next_step)   # in place of trainer.step_optimize
 
 The first steps (an all-ones bitfield asks for R x n_sample samples) run through the module path, which sizes the sample buffers;
-a step that would overflow them is detected a step later (the sample total travels to pinned memory) and the buffers grow.
+a step that overflows them is detected a step later (the sample total travels to pinned memory) and the buffers grow.  Such a step is
+never a step on truncated rays: the compositor leaves the rays behind the fill point out (arcn_composite_packed_train, `counts`), its
+update is the exact update of the rays that fit.
 """
 import copy
 import warnings
@@ -56,7 +58,7 @@ class FusedNgpStep:
         return None
 
     def __init__(self, model, loss_factory, optimizer, ema=None, warmup=2, total_epoch=300000, max_rays=None, clip_value=0.0, ahead=2,
-                 world_size=1, grad_level_cuts=(8,), sync_occupancy=True):
+                 world_size=1, grad_sync='flat', grad_level_cuts=(8,), sync_occupancy=True):
         reason = self.why_not(model, loss_factory, optimizer)
         if reason is None and clip_value > 0.0:
             reason = 'gradient clipping (clip_value > 0) needs the gradients between backward and the optimiser: use trainer.step_optimize'
@@ -80,10 +82,15 @@ class FusedNgpStep:
         self.depth = max(1, int(ahead))
         self._queue = []
         # data parallel (one process per GPU, every rank its shard of the rays; the reference wraps the model in DistributedDataParallel,
-        # common/trainer/basic_trainer.py:197-198): the flat gradient is summed over the ranks in level groups overlapped with the scatter
-        # (distributed.LevelGroupedGradSync), the optimiser divides by the world size (FusedAdam.grad_scale = 1 / world_size, DDP's average),
-        # and a refreshed occupancy is rank 0's on every rank (DDP's broadcast_buffers)
+        # common/trainer/basic_trainer.py:197-198): the flat gradient is summed over the ranks - grad_sync 'flat': ONE all-reduce after the
+        # backward (the default); 'levels': in level groups overlapped with the scatter (distributed.LevelGroupedGradSync); 'sharded':
+        # reduce-scatter, the optimiser on this rank's 1/N, all-gather (distributed.ShardedGradSync) -, the optimiser divides by the world
+        # size (FusedAdam.grad_scale = 1 / world_size, DDP's average), and a refreshed occupancy is rank 0's on every rank (DDP's
+        # broadcast_buffers)
         self.world = max(1, int(world_size))
+        if grad_sync not in ('flat', 'levels', 'sharded'):
+            raise RuntimeError('FusedNgpStep: grad_sync must be flat, levels or sharded')
+        self.grad_sync = grad_sync
         self.grad_level_cuts = tuple(grad_level_cuts)
         self.sync_occupancy = bool(sync_occupancy)
         self._sync = None
@@ -129,9 +136,12 @@ class FusedNgpStep:
             pipe.ema = fld.params if self.opt.ema_in_param else fb['ema']
         pipe.rng = sampler_rng()                                # the process-wide sampler stream, shared with the module path
         self._sync = None
-        if self.world > 1 and pipe.level_major:
+        if self.world > 1 and self.grad_sync == 'levels' and pipe.level_major:
             from .. import distributed as D
             self._sync = D.LevelGroupedGradSync(fld, self.grad_level_cuts)
+        elif self.world > 1 and self.grad_sync == 'sharded':
+            from .. import distributed as D
+            self._sync = D.ShardedGradSync(fld.n_params, self.world)
         self.pipe, self._bits_key = pipe, None
         self._pending.clear()
         self.rebuilds += 1
@@ -169,8 +179,10 @@ class FusedNgpStep:
             self._pending.pop(0)
             self.fg._samples_per_ray = need / max(1, rays)
             if need >= cap:
-                warnings.warn('FusedNgpStep: a training step filled the sample buffers ({} slots for {} rays): the rays past the capacity were '
-                              'rendered with truncated sample sets in that step; the buffers grow now'.format(cap, rays))
+                # (the compositor never renders a ray from a truncated sample set: the rays behind the fill point took no part in that
+                # step - background colour, zero gradient - so its update was the exact step of the rays that fit)
+                warnings.warn('FusedNgpStep: a training step filled the sample buffers ({} slots for {} rays): the rays behind the fill point '
+                              'were left out of that step (no gradient from them); the buffers grow now'.format(cap, rays))
                 self.fg._samples_per_ray = max(self.fg._samples_per_ray, 2.0 * cap / max(1, rays))
         rate = getattr(self.fg, '_samples_per_ray', None)
         pipe = self.pipe

@@ -112,7 +112,14 @@ class GraphedTrainStep:
         pipe = self.fg._packed_pipeline(dev)      # applies a refreshed occupancy (in place once enable_replay() ran)
         if pipe.replay is None:
             pipe.enable_replay()
-        key = (tuple(sorted((k, tuple(v.shape)) for k, v in feed_in.items() if torch.is_tensor(v))), id(pipe), pipe.cap)
+        # a recorded launch is bound to the pipeline's buffers AND to the optimiser's flat buffers (FusedAdam.load_state_dict flattens
+        # again into new ones): either moving invalidates every graph
+        fb0 = self.opt._flat[0] if getattr(self.opt, '_flat', None) else None
+        home = (getattr(pipe, 'generation_id', None) or id(pipe), pipe.cap, None if fb0 is None else (fb0['params'].data_ptr(), fb0['grads'].data_ptr()))
+        if getattr(self, '_home', home) != home:
+            self.graphs.clear()
+        self._home = home
+        key = tuple(sorted((k, tuple(v.shape)) for k, v in feed_in.items() if torch.is_tensor(v)))
         rec = self.graphs.get(key)
         self.opt.prepare_step()
         pipe.prepare_replay()

@@ -21,19 +21,21 @@ def step_optimize(model, feed_in, loss_factory, optimizer, ema=None, epoch=0, to
 
 def train_epoch(model, get_batch, loss_factory, optimizer, ema, pipeline, epoch, total_epoch=300000, stepper=None):
     """train_epoch's order: model.optimize(epoch) (the bound's periodic refresh), the dynamic batch size, then the step.
-    get_batch(n_rays) -> feed_in dict.
+    get_batch(n_rays) -> feed_in dict; a callable with `wants_epoch = True` (trainer.TrainBatches: the Pipeline's crop / shuffle / batch
+    fetch) is called as get_batch(n_rays, epoch).
     stepper: a trainer.FusedNgpStep / GraphedTrainStep in place of step_optimize.  A FusedNgpStep is also handed the batches of the next
     epochs (two by default) as long as neither model.optimize nor the batch-size rule can act at those epochs (then their "optimize,
     batch size, batch" commutes with this step): their marching runs on the second stream meanwhile."""
+    draw = (lambda n, e: get_batch(n, e)) if getattr(get_batch, 'wants_epoch', False) else (lambda n, e: get_batch(n))
     if stepper is None:
         model.optimize(epoch)
         n_rays = pipeline.fetch_step_update_dynamic_bs(epoch, model)
-        return step_optimize(model, get_batch(n_rays), loss_factory, optimizer, ema, epoch, total_epoch)
+        return step_optimize(model, draw(n_rays, epoch), loss_factory, optimizer, ema, epoch, total_epoch)
     feed_in = stepper.take_ahead(epoch) if hasattr(stepper, 'take_ahead') else None
     if feed_in is None:
         model.optimize(epoch)
         n_rays = pipeline.fetch_step_update_dynamic_bs(epoch, model)
-        feed_in = get_batch(n_rays)
+        feed_in = draw(n_rays, epoch)
     if not hasattr(stepper, 'can_run_ahead'):
         return stepper(feed_in, epoch)
     # batches are drawn in epoch order, each exactly once, as far ahead as the stepper holds and the loop allows
@@ -41,5 +43,5 @@ def train_epoch(model, get_batch, loss_factory, optimizer, ema, pipeline, epoch,
         e = stepper.next_ahead_epoch(epoch)
         if e >= total_epoch or not stepper.can_run_ahead(e) or pipeline.will_update_dynamic_bs(e):
             break
-        stepper.hold_ahead(e, get_batch(pipeline.get_info('n_rays')))
+        stepper.hold_ahead(e, draw(pipeline.get_info('n_rays'), e))
     return stepper(feed_in, epoch, next_feed_in=stepper.ahead())

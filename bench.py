@@ -314,7 +314,8 @@ def bench_module(args, name, emit=True):
     if name == 'ngp_module' and mode == 'fused' and (not use_dist or world > 1):
         # (N > 1: every rank its rays through the same stepper, the gradient summed in level groups overlapped with the scatter)
         from arcnerf_amd.trainer import FusedNgpStep
-        fused = FusedNgpStep(m, ngp_loss, opt, None, max_rays=n_rays, ahead=int(os.environ.get('ARCN_MODULE_AHEAD', '2')), world_size=world)
+        fused = FusedNgpStep(m, ngp_loss, opt, None, max_rays=n_rays, ahead=int(os.environ.get('ARCN_MODULE_AHEAD', '2')), world_size=world,
+                             grad_sync=os.environ.get('ARCN_GRAD_SYNC', 'flat'))
 
     def step(i):
         inp = pool[i % len(pool)]
@@ -516,22 +517,27 @@ def main():
 
     timers = KernelTimers()
     instrument(timers)
-    # gradient sync of the N > 1 step.  Default: the scatter in two level groups, each group's slice on the wire while the
-    # next is scattered and the optimiser per group as it arrives (distributed.LevelGroupedGradSync; ARCN_GRAD_LEVEL_CUTS=8 / =11,5).
-    # ARCN_GRAD_SEGMENTS=0: ONE flat all-reduce after the backward (the A/B partner); =K: K equal async segments behind the backward.
-    seg_env = os.environ.get('ARCN_GRAD_SEGMENTS')
+    # gradient sync of the N > 1 step, ARCN_GRAD_SYNC:
+    #   flat (default, north_star's "single RCCL all-reduce of gradients"): ONE all-reduce of the flat buffer after the backward;
+    #   levels: the scatter in level groups, each group's slice on the wire while the next is scattered, the optimiser per group as it
+    #           arrives (distributed.LevelGroupedGradSync; ARCN_GRAD_LEVEL_CUTS=8 / =11,5);
+    #   sharded: reduce-scatter, Adam + EMA on this rank's 1/N of the buffer, all-gather (distributed.ShardedGradSync).
+    sync_mode = os.environ.get('ARCN_GRAD_SYNC', 'flat')
+    if sync_mode not in ('flat', 'levels', 'sharded'):
+        raise SystemExit('ARCN_GRAD_SYNC must be flat, levels or sharded')
     exposed_marks = []
     all_reduce, grad_sync, sync_name = None, None, None
     if use_dist:
-        if seg_env is None and pipe.level_major:
+        if sync_mode == 'levels' and pipe.level_major:
             cuts = tuple(int(v) for v in os.environ.get('ARCN_GRAD_LEVEL_CUTS', '8').split(',') if v.strip())
             grad_sync = D.LevelGroupedGradSync(field, cuts)
             grad_sync.timing = True
             spans = ['{}-{}'.format(min(l for l in range(32) if (m >> l) & 1), max(l for l in range(32) if (m >> l) & 1)) for m, _, _ in grad_sync.groups]
             sync_name = 'level groups {} overlapped with the scatter, optimiser per group'.format(spans)
-        elif seg_env is not None and int(seg_env) > 0:
-            grad_sync = D.PipelinedGradSync(field.n_params, int(seg_env))
-            sync_name = '{} async segments pipelined with the optimiser pass'.format(len(grad_sync.segments))
+        elif sync_mode == 'sharded':
+            grad_sync = D.ShardedGradSync(field.n_params, world, rank)
+            grad_sync.timing = True
+            sync_name = 'reduce-scatter + optimiser on 1/{} of the buffer + all-gather'.format(world)
         else:
             def all_reduce(t):      # the flat form: everything between these two events is exposed
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -799,7 +805,7 @@ def main():
         'timed_region_ms': wall * 1e3,
         'step_ms_spread': {'slowest_step': slowest, 'min': per_step[0], 'p50': per_step[len(per_step) // 2], 'p90': per_step[min(len(per_step) - 1, int(0.9 * len(per_step)))],
                            'max': per_step[-1]},
-        'rccl': dist_report(dist, world, LAUNCH, field.n_params * 4, len(grad_sync.segments) if grad_sync is not None else 1, per_rank, rccl_extra),
+        'rccl': dist_report(dist, world, LAUNCH, field.n_params * 4, (len(grad_sync.groups) if hasattr(grad_sync, 'groups') else 1 + len(grad_sync.segments)) if grad_sync is not None else 1, per_rank, rccl_extra),
         'roofline': roofline,
         'roofline_lookup': lookup,
         'cpu_baseline': cpu,

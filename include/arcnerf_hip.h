@@ -75,6 +75,25 @@ int arcn_get_rays(int W, int H, const float *intrinsic, const float *c2w, int wh
                   int center_pixel, int normalize_rays_d, int ndc, float ndc_near, float *rays_o, float *rays_d, float *rays_r,
                   void *stream);
 
+/* The training batch: Pipeline.fetch_step_ray_sample + fetch_step_bkg_color (arcnerf/trainer/pipeline.py:243-300) on a dataset kept
+ * as IMAGES + CAMERAS instead of the per-pixel tensors arcnerf_trainer.py:188-219 concat_train_batch collects (img, mask, rays_o,
+ * rays_d, rays_r per pixel: 44 B) and step_crop_center_image / step_ray_sample (pipeline.py:95-118,150-168) crop and shuffle.
+ *   rgba (n_img,H,W,4) bytes as a Blender PNG holds them (colours = bytes / 255.0, mask = alpha / 255.0, nerf_dataset.py:107-119)
+ *   OR img (n_img,H,W,3) floats with mask (n_img,H,W) floats or NULL; intrinsic (n_img,3,3), c2w (n_img,4,4) row-major; all DEVICE.
+ *   ids (n) int64 DEVICE: row ids of the reference's (cropped) dataset tensor, id = view * Hc * Wc + (y - y0) * Wc + (x - x0) for the
+ *   window [y0, y0 + Hc) x [x0, x0 + Wc) (no crop: 0, 0, H, W); the shuffle is a permutation of them.  An id outside [0, n_img*Hc*Wc)
+ *   is counted into *bad_ids (DEVICE int32, optional) and replaced by 0.
+ *   bkg_rand (n,3) DEVICE (the draw of torch.rand_like, pipeline.py:286) or bkg_const_host[3] HOST or neither (no blend); the blend
+ *   img * mask + (1 - mask) * bkg happens only when the data has a mask (pipeline.py:281-283).
+ * Outputs, each optional, (n, .): rays_o, rays_d (get_rays of the pixel, wh_order=False: y * W + x), rays_r (mip-nerf radius as in
+ * full-image mode), img_out (blended target), mask_out, bkg_out (the colour blended in), src_out int64 (row of the UNCROPPED
+ * (n_img*H*W, .) tensors: for gathering further per-pixel data such as bounds). */
+int arcn_fetch_train_batch(const uint8_t *rgba, const float *img, const float *mask, const float *intrinsic, const float *c2w, int n_img,
+                           int H, int W, int y0, int x0, int Hc, int Wc, const int64_t *ids, int64_t n, int center_pixel,
+                           int normalize_rays_d, const float *bkg_rand, const float *bkg_const_host, float *rays_o, float *rays_d,
+                           float *rays_r, float *img_out, float *mask_out, float *bkg_out, int64_t *src_out, int32_t *bad_ids,
+                           void *stream);
+
 /* K3 sparse_volume_sampling (volume_func_kernel.cu:174-291). zvals/mask (n_rays,n_pts) zero-initialised by the
  * caller.  (rng_state, rng_inc) is the host pcg32 BEFORE the call (reference: file-static `pcg32 rng{9121}`,
  * include/common.h:22-23, advanced 2^32 after every launch); the caller owns that bookkeeping (arcn_pcg32_*).
@@ -489,18 +508,24 @@ int arcn_composite_packed_train(const float *sigma, const float *radiance, const
                                 const float *noise, const float *bkg, int64_t bkg_rows, int64_t R, int p_dense,
                                 const int32_t *p_dense_ptr, int add_inf_z, int white_bkg, const float *target, float huber_delta,
                                 float loss_weight, float *rgb, float *depth, float *mask, float *d_rgb, float *loss_partials,
-                                float *d_sigma, float *d_radiance, void *stream);
+                                float *d_sigma, float *d_radiance, const int32_t *counts, void *stream);
 /* packed form over (offsets, t): identical numbers to the dense form applied to the reference's padded (R,P') view
  * (mask rows [T..T F..F], padded z = last z): P_dense = the dense column count the reference would have used
- * (max(2, max count), fg_model.py:251-262) read from *p_dense_ptr (device) or p_dense if the pointer is NULL. */
+ * (max(2, max count), fg_model.py:251-262) read from *p_dense_ptr (device) or p_dense if the pointer is NULL.
+ * counts (R, optional; all three packed entry points): the samples the marcher emitted per ray.  The reference never drops samples
+ * (fg_model.py:264-318 sizes its tensors from the mask); packed buffers have a capacity, and offsets are clamped to it.  A ray whose
+ * segment is shorter than its count (it lies behind the point where the buffers filled up) is NOT rendered from the partial set: it is
+ * a ray without samples (background colour, zero gradient to its leftover samples) - an overflowed training step is the exact step of
+ * the rays that fit, never a step on truncated rays. */
 int arcn_composite_packed_fwd(const float *sigma, const float *radiance, const float *t_packed, const int32_t *offsets,
                               const float *noise, const float *bkg, int64_t bkg_rows, int64_t R, int p_dense,
                               const int32_t *p_dense_ptr, int add_inf_z, int white_bkg, float *rgb, float *depth,
-                              float *mask, float *weights_out, void *stream);
+                              float *mask, float *weights_out, const int32_t *counts, void *stream);
 int arcn_composite_packed_bwd(const float *sigma, const float *radiance, const float *t_packed, const int32_t *offsets,
                               const float *noise, const float *bkg, int64_t bkg_rows, int64_t R, int p_dense,
                               const int32_t *p_dense_ptr, int add_inf_z, int white_bkg, const float *d_rgb,
-                              const float *d_depth, const float *d_mask, float *d_sigma, float *d_radiance, void *stream);
+                              const float *d_depth, const float *d_mask, float *d_sigma, float *d_radiance, const int32_t *counts,
+                              void *stream);
 
 /* ImgLoss with loss_type Huber (arcnerf/loss/img_loss.py:60-100): loss[0] = weight * mean(huber_delta(x - y)) over n
  * elements, dx = d loss / d x.  dx and loss are optional. */

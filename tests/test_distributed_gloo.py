@@ -101,47 +101,74 @@ def test_single_process_helpers_are_noops():
     assert D.max_over_ranks(3.5) == 3.5
 
 
-def _sync_worker(rank, world, port, ret):
+def _adam(p, g, m, v, step, scale):
+    """elementwise Adam on (views of) flat buffers, clearing the gradient it reads - what the fused optimiser kernel does per element"""
+    g = g * scale
+    m.mul_(0.9).add_(g, alpha=0.1)
+    v.mul_(0.999).addcmul_(g, g, value=0.001)
+    p.sub_(0.01 * (m / (1 - 0.9 ** step)) / ((v / (1 - 0.999 ** step)).sqrt() + 1e-8))
+
+
+def _sharded_worker(rank, world, port, ret):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     D.init_from_env(backend='gloo')
     n = 100003
-    g = torch.Generator().manual_seed(100 + rank)
-    grads = torch.randn(n, generator=g)
-    flat = grads.clone()
-    D.allreduce_grads(flat, world)
-    sync = D.PipelinedGradSync(n, n_segments=4)
-    seg = grads.clone()
-    sync.launch(seg)
-    updated = torch.zeros(n)
-    for i, (lo, hi) in enumerate(sync.segments):      # what train_step does: wait for segment i, update it, go on
-        sync.wait(i)
-        updated[lo:hi] = -0.1 * seg[lo:hi]
-    ret[rank] = (flat.numpy(), seg.numpy(), updated.numpy(), sync.segments)
+    sync = D.ShardedGradSync(n)
+    assert (sync.world, sync.rank) == (world, rank) and sync.per % 4 == 0 and 0 <= n - sync.body < 4 * world
+    runs = {}
+    for form in ('flat', 'sharded'):
+        p = torch.linspace(-1, 1, n)
+        m, v, grads = torch.zeros(n), torch.zeros(n), torch.zeros(n)
+        for step in range(1, 41):
+            g = torch.Generator().manual_seed(1000 * rank + step)
+            grads += torch.randn(n, generator=g) * (1.0 + p.abs())          # this rank's contribution depends on the parameters: a divergence would grow
+            if form == 'flat':
+                D.allreduce_grads(grads, world)
+                _adam(p, grads, m, v, step, 1.0 / world)
+                grads.zero_()
+            else:       # what NgpPipeline.train_step(grad_sync=ShardedGradSync) does
+                sync.launch(grads)
+                sync.wait()
+                for lo, hi in sync.segments:
+                    _adam(p[lo:hi], grads[lo:hi], m[lo:hi], v[lo:hi], step, 1.0 / world)
+                    grads[lo:hi].zero_()
+                sync.clear_foreign(grads)
+                sync.gather(p)
+                assert float(grads.abs().max()) == 0.0
+        runs[form] = (p.numpy().copy(), float(m[:sync.lo].abs().sum() + m[sync.hi:sync.body].abs().sum()))
+    ret[rank] = (runs, sync.segments, sync.body)
     dist.destroy_process_group()
 
 
-def test_pipelined_gradient_sync_equals_flat_allreduce():
-    """K asynchronous segment all-reduces (the multi-GPU step's gradient sync) give bit-identical sums to the single flat
-    collective, the segments tile the buffer exactly once, and every rank ends with the same update."""
-    segs = D.grad_segments(12215736, 4)
-    assert segs[0][0] == 0 and segs[-1][1] == 12215736 and all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
-    assert all(lo % 4096 == 0 for lo, _ in segs) and len(segs) == 4
-    assert D.grad_segments(10, 4) == [(0, 10)]
-    world = 2
+@pytest.mark.parametrize('world', [2, 4])
+def test_sharded_gradient_sync_equals_flat_allreduce(world):
+    """distributed.ShardedGradSync (reduce-scatter, the optimiser on this rank's shard, all-gather): after 40 steps every rank holds the
+    SAME parameters; on two ranks they are the flat all-reduce form's bit for bit (a + b in either order), on four the two forms sum an
+    element's four contributions in different orders (the ring's chunk boundaries move with the buffer length) and agree to the rounding of
+    those sums; the shards tile the buffer once, and a rank never touches the moments of another rank's shard"""
     ctx = mp.get_context('spawn')
     ret = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_sync_worker, args=(r, world, port, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, ret)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
     assert all(p.exitcode == 0 for p in procs)
-    f0, s0, u0, segs0 = ret[0]
-    f1, s1, u1, _ = ret[1]
-    assert np.array_equal(f0, s0) and np.array_equal(f1, s1) and np.array_equal(s0, s1)
-    assert np.array_equal(u0, u1) and np.array_equal(u0, -0.1 * s0)
-    assert len(segs0) == 4
+    ref = ret[0][0]['flat'][0]
+    spans = []
+    for r in range(world):
+        runs, segments, body = ret[r]
+        assert np.array_equal(runs['flat'][0], ref) and np.array_equal(runs['sharded'][0], ret[0][0]['sharded'][0]), r
+        if world == 2:
+            assert np.array_equal(runs['sharded'][0], ref), r
+        else:
+            assert np.abs(runs['sharded'][0] - ref).max() <= 1e-4 and np.mean(runs['sharded'][0] != ref) < 0.5
+        assert runs['sharded'][1] == 0.0 and runs['flat'][1] > 0.0
+        spans.append(segments[0])
+        assert segments[1:] == ([(body, 100003)] if body < 100003 else [])
+    spans.sort()
+    assert spans[0][0] == 0 and spans[-1][1] == ret[0][2] and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
 
 
 def _level_sync_worker(rank, world, port, ret):

@@ -1,6 +1,6 @@
 """Pipeline-level data parallelism on the GPU: two ranks (gloo over 127.0.0.1, both on cuda:0 - the RCCL path needs
 several GPUs and is the driver's to run) each run `NgpPipeline.train_step` on their shard of the rays, with the flat gradient
-all-reduce and with the 4-segment pipelined sync, and must end with the parameters a single process gets when it accumulates the two
+all-reduce, with the level-grouped exchange and with the sharded form (reduce-scatter, optimiser on 1/N, all-gather), and must end with the parameters a single process gets when it accumulates the two
 shards' gradients itself and applies the optimiser with grad_scale 1/world - the averaging semantics of the reference's DDP
 (common/trainer/basic_trainer.py:197-198)."""
 import os
@@ -48,7 +48,7 @@ def _worker(rank, world, port, mode, path):
     torch.cuda.set_device(dev)
     cfg, fld, pipe, batches = _setup(dev, mode)
     D.broadcast_params(fld.params, src=0)
-    sync = D.PipelinedGradSync(fld.n_params, 4) if mode == 'pipelined' else None
+    sync = D.ShardedGradSync(fld.n_params) if mode == 'sharded' else None
     if mode == 'levels':
         assert pipe.level_major
         sync = D.LevelGroupedGradSync(fld, (11, 5))
@@ -83,7 +83,7 @@ def _rank_rng_state(pipe, rank):
     return F.Pcg32Host(9121 + rank).state
 
 
-@pytest.mark.parametrize('mode', ['flat', 'pipelined', 'levels'])
+@pytest.mark.parametrize('mode', ['flat', 'sharded', 'levels'])
 def test_two_ranks_train_like_one_process_accumulating_both_shards(mode):
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
@@ -228,11 +228,11 @@ def test_bench_refuses_more_rccl_ranks_than_gpus():
     assert r.returncode != 0 and 'one GPU per rank' in r.stderr
 
 
-@pytest.mark.parametrize('config,segments', [('ngp', None), ('ngp', '4'), ('ngp', '0'), ('neus_ngp_multivol', '4')])
-def test_bench_under_torchrun_on_a_one_rank_rccl_communicator(config, segments):
+@pytest.mark.parametrize('config,sync', [('ngp', None), ('ngp', 'levels'), ('ngp', 'sharded'), ('neus_ngp_multivol', None)])
+def test_bench_under_torchrun_on_a_one_rank_rccl_communicator(config, sync):
     """The driver's N > 1 command form (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
     bench.py --gpus N`) with N = 1 and ARCN_DIST_FORCE=1: the process group is built on RCCL (backend "nccl"), and the gradient
-    exchange (segmented / flat), the parameter broadcast, the barriers around the timed region, the max-over-ranks reduction and the
+    exchange (ARCN_GRAD_SYNC: flat = the default, levels, sharded), the parameter broadcast, the barriers around the timed region, the max-over-ranks reduction and the
     all-gather of the per-rank samples all run through a real RCCL communicator on this box's one GPU - everything of the multi-GPU
     path except a second rank."""
     import json
@@ -247,8 +247,9 @@ def test_bench_under_torchrun_on_a_one_rank_rccl_communicator(config, segments):
         env.pop(k, None)
     env.update({'ARCN_DIST_FORCE': '1', 'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
     env.pop('ARCN_GRAD_SEGMENTS', None)
-    if segments is not None:        # None: the default of the N > 1 step, the level-grouped exchange overlapped with the scatter
-        env['ARCN_GRAD_SEGMENTS'] = segments
+    env.pop('ARCN_GRAD_SYNC', None)
+    if sync is not None:        # None: the default of the N > 1 step, ONE flat all-reduce (north_star's form)
+        env['ARCN_GRAD_SYNC'] = sync
     sock = socket.socket()
     sock.bind(('127.0.0.1', 0))
     port = sock.getsockname()[1]
@@ -267,9 +268,8 @@ def test_bench_under_torchrun_on_a_one_rank_rccl_communicator(config, segments):
     assert out['n_gpus'] == 1 and rc is not None and rc['backend'] == 'nccl' and rc['world_size_seen'] == 1
     assert rc['allreduce_alone_ms'] > 0 and out['value'] > 0
     if config == 'ngp':
-        assert rc['collectives_per_step'] == (2 if segments is None else (1 if segments == '0' else int(segments)))
-        if segments in (None, '0'):
-            assert rc['exposed_ms'] >= 0.0 and ('level groups' in rc['grad_sync']) == (segments is None)
+        assert rc['collectives_per_step'] == {None: 1, 'levels': 2, 'sharded': 3}[sync]
+        assert rc['exposed_ms'] >= 0.0 and ('level groups' in rc['grad_sync']) == (sync == 'levels') and ('reduce-scatter' in rc['grad_sync']) == (sync == 'sharded')
         # a one-rank SUM is the identity: the step trains like the single-GPU step (two-pass optimiser form)
         assert 1e8 < out['value'] < 1e9
 
@@ -310,7 +310,7 @@ def _module_ddp_worker(rank, world, port, path):
         lf = T.build_loss(lc)
         sampler_rng(reset=True)
         m.train()
-        stepper = T.FusedNgpStep(m, lf, opt, ema, world_size=world, grad_level_cuts=(11, 5)) if mode == 'fused' else None
+        stepper = T.FusedNgpStep(m, lf, opt, ema, world_size=world, grad_sync='levels', grad_level_cuts=(11, 5)) if mode == 'fused' else None
         losses = []
         for k in range(steps):
             m.optimize(k)

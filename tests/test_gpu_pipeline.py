@@ -166,8 +166,7 @@ def test_full_size_properties(gpu):
 
 
 def test_optimizer_by_segments_is_bit_identical(gpu):
-    """The pipelined gradient sync updates the flat parameter buffer segment by segment: same bits as one whole-buffer pass."""
-    from arcnerf_amd import distributed as D
+    """The level-grouped / sharded gradient syncs update the flat parameter buffer slice by slice: same bits as one whole-buffer pass."""
     from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline
     cfg = NgpConfig(n_levels=4, hashmap_size=14, max_res=128)
     outs = []
@@ -178,7 +177,8 @@ def test_optimizer_by_segments_is_bit_identical(gpu):
         for step in range(3):
             fld.grads.copy_(torch.randn(fld.n_params, device=gpu, generator=g))
             if segmented:
-                for i, (lo, hi) in enumerate(D.grad_segments(fld.n_params, 4, align=4096)):
+                cuts = [0, 4096, 3 * 4096 + 4, fld.n_params // 2 // 4 * 4, fld.n_params]
+                for i, (lo, hi) in enumerate(zip(cuts, cuts[1:])):
                     pipe.optimizer_step(2, lo, hi, advance=(i == 0))
             else:
                 pipe.optimizer_step(2)
@@ -224,6 +224,62 @@ def test_edge_batches_no_samples_and_capacity_overflow(gpu):
     assert int(small.buf['offsets'][R].item()) == (1 << 12)         # ... and the packed segments were clamped to them
     assert small.buf['sigma'].shape[0] == guard and torch.isfinite(fld2.params).all() and bool(torch.isfinite(loss.tensor()))
     assert torch.isfinite(small.buf['rgb'][:R]).all()
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_overflowed_step_is_the_step_of_the_rays_that_fit(gpu, fused):
+    """The packed buffers have a capacity (the reference's tensors are sized from the mask, fg_model.py:264-318: it never drops a sample).
+    A batch that asks for more leaves the rays behind the fill point with truncated segments; the compositor (all three packed entry
+    points, `counts`) treats such a ray as a ray WITHOUT samples: background colour, zero colour gradient, zero gradients to the samples
+    it left in the buffers.  So the parameter gradient of an overflowed step is the gradient of the complete rays alone - never of rays
+    rendered from partial sample sets (round-4 ADVICE: the fused step learns of an overflow a step late)."""
+    from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline, synthetic_bitfield, synthetic_rays
+    cfg = NgpConfig(n_levels=8, hashmap_size=14, max_res=256, n_grid=32, n_sample=256, noise_std=0.0, white_bkg=False)
+    bits = torch.from_numpy(synthetic_bitfield(32, 0.1, seed=4))
+    R = 3000
+    o, d = synthetic_rays(R, seed=5, device=gpu)
+    g = torch.Generator().manual_seed(9)
+    tgt, bkg = torch.rand(R, 3, generator=g).to(gpu), torch.rand(R, 3, generator=g).to(gpu)
+
+    def make(cap):
+        fld = NgpField(cfg, device=gpu, seed=1)
+        with torch.no_grad():
+            fld.view('table').mul_(3000.0)
+        pipe = NgpPipeline(fld, max_rays=4096, max_samples=cap)
+        pipe.fused_composite = fused
+        pipe.set_bitfield(bits)
+        return fld, pipe
+
+    # A: everything fits; the rays B will truncate get a zero colour gradient by hand
+    fa, pa = make(1 << 18)
+    rgb_a, _, _ = pa.forward(o, d, bkg, train=True, noise=None)
+    total = int(pa.n_dev.item())
+    counts = pa.buf['counts'][:R].clone()
+    cap = int(total * 0.6) // 1024 * 1024
+    # B: 60 % of the samples fit
+    fb, pb = make(cap)
+    assert pb.cap == cap
+    rgb_b, _, _ = pb.forward(o, d, bkg, train=True, noise=None, huber_target=tgt if fused else None)
+    assert int(pb.n_dev.item()) == cap and torch.equal(pb.buf['counts'][:R], counts)
+    off = pb.buf['offsets'][:R + 1]
+    trunc = (off[1:] - off[:-1]) < counts
+    assert 0.2 * R < int(trunc.sum()) < 0.8 * R
+    if fused:
+        loss_b, d_rgb_b = pb.last_loss, pb.buf['d_rgb'][:R]
+    else:
+        loss_b, d_rgb_b = pb.huber_grad(rgb_b, tgt)
+    pb.backward(o, d, d_rgb_b)
+    _, d_rgb_a = pa.huber_grad(rgb_a, tgt)
+    d_rgb_a[trunc] = 0.0
+    d_rgb_a[trunc] = pa.huber_grad(bkg, tgt)[1][trunc] * 0.0            # (no-op: makes the intent explicit - those rays carry no gradient)
+    pa.backward(o, d, d_rgb_a)
+    torch.cuda.synchronize()
+    assert torch.equal(rgb_b[~trunc], rgb_a[~trunc])                    # complete rays: the same colours, bit for bit
+    assert torch.equal(rgb_b[trunc], bkg[trunc])                        # truncated rays: the background colour, as rays without samples
+    if fused:
+        assert torch.equal(d_rgb_b[~trunc], pa.huber_grad(rgb_a, tgt)[1][~trunc])
+    ga, gb = fa.grads, fb.grads
+    assert float(ga.abs().max()) > 0 and float((ga - gb).abs().max()) <= 2e-6 * float(ga.abs().max()), float((ga - gb).abs().max() / ga.abs().max())
 
 
 @pytest.mark.parametrize('add_inf_z,white_bkg,use_bkg', [(False, False, True), (True, False, False), (False, True, False)])

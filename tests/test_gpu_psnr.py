@@ -1,0 +1,332 @@
+"""PSNR@iter against the reference (golden G27, tests/golden/make_golden_psnr.py: the reference's own training loop WITH ITS OWN Pipeline - centre
+precrop, cross-view shuffle, random background colours, dynamic batch size - 600 iterations x 4 seeds on a 100 x 100 analytic scene, held-out
+PSNR after 50 / 100 / 200 / 400 / 600 iterations).
+
+  1. the batch-fetch kernel (arcn_fetch_train_batch) against oracle/batch.py: windows, both dataset forms, every background mode, bad ids;
+  2. trainer.Pipeline on the GPU hands out the reference's 600 batches (checksums of the fixture);
+  3. the module path with the reference's net semantics - build_model(configs/nerf_ngp.yaml + the fixture's overrides) + trainer.train_epoch +
+     trainer.TrainBatches + FusedAdam - from the run's own initial weights and draws: the reference's losses and sample counts while the
+     occupancy decisions agree, then the held-out PSNR of every seed inside the reference's seed-to-seed band at every checkpoint;
+  4. the drop-in API at full speed - the yaml's FUSED nets + trainer.FusedNgpStep (two batches in flight) + trainer.TrainBatches: the first
+     iterations against oracle/ngp_trainer.py on the same batches, the PSNR of every seed inside the same band, the same seeds train."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import g27_utils as U
+from conftest import ROOT
+from test_oracle_psnr_golden import FactorTape, check_sums, dataset, scheduler_cfg, start_state
+
+pytestmark = pytest.mark.gpu
+CFG = os.path.join(ROOT, 'configs')
+REPORT = os.environ.get('ARCN_TRAJ_REPORT') == '1'
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def g():
+    return U.golden()
+
+
+def to_dev(d, dev):
+    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+# ---- 1. the kernel ---------------------------------------------------------------------------------------------------------------------------
+def test_fetch_train_batch_kernel_vs_oracle(gpu, oracle, g):
+    from arcnerf_amd.ops import functional as F
+    from oracle import batch as OB
+    rgba = g['rgba_train']
+    n_img = rgba.shape[0]
+    img, mask = U.dataset_tensors(rgba)
+    K, M = g['K_train'], g['c2w_train']
+    rays = OB.dataset_rays(U.H, U.W, K, M)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    rng = np.random.default_rng(5)
+    for window in (None, (25, 25, 50, 50), (0, 3, 100, 97), (99, 99, 1, 1)):
+        per = (window[2] * window[3]) if window else U.H * U.W
+        ids = rng.integers(0, n_img * per, 4097)
+        ids[:4] = [0, n_img * per - 1, per - 1, per]
+        for colours in ('rgba', 'float', 'nomask'):
+            for bkg in ('rand', 'const', None):
+                br = rng.random((ids.shape[0], 3), dtype=np.float32) if bkg == 'rand' else None
+                bc = [0.25, 1.0, 0.0] if bkg == 'const' else None
+                kw = dict(rgba=rgba) if colours == 'rgba' else (dict(img=img, mask=mask) if colours == 'float' else dict(img=img))
+                want = OB.fetch_train_batch(ids, n_img, U.H, U.W, window, bkg_rand=br, bkg_const=bc, rays=rays, **kw)
+                got = F.fetch_train_batch(t(ids), n_img, U.H, U.W, window=window, intrinsic=t(K), c2w=t(M), bkg_rand=None if br is None else t(br),
+                                          bkg_const=bc, want_src=True, **{k: t(v) for k, v in kw.items()})
+                assert set(got) == set(want) | {'src'}, (colours, bkg, sorted(got), sorted(want))
+                for k in ('img', 'mask', 'bkg_color'):
+                    if k in want:
+                        assert np.array_equal(got[k].cpu().numpy(), want[k]), (window, colours, bkg, k)     # byte -> float, the blend: bit-exact
+                assert np.array_equal(got['rays_o'].cpu().numpy(), want['rays_o'])
+                assert np.abs(got['rays_d'].cpu().numpy() - want['rays_d']).max() <= 1e-6
+                assert np.allclose(got['rays_r'].cpu().numpy(), want['rays_r'], rtol=1e-5, atol=1e-7)
+                y0, x0, hc, wc = window or (0, 0, U.H, U.W)
+                v, rem = ids // per, ids % per
+                assert np.array_equal(got['src'].cpu().numpy(), (v * U.H + y0 + rem // wc) * U.W + x0 + rem % wc)
+    # ids outside the dataset are counted and do not leave it; empty batches are a no-op; bad arguments are refused
+    bad = torch.zeros(1, dtype=torch.int32, device=gpu)
+    got = F.fetch_train_batch(t(np.array([-1, n_img * U.H * U.W, 5], np.int64)), n_img, U.H, U.W, rgba=t(rgba), bad_ids=bad)
+    assert int(bad) == 2 and torch.equal(got['img'][0], got['img'][1])
+    assert F.fetch_train_batch(t(np.zeros(0, np.int64)), n_img, U.H, U.W, rgba=t(rgba))['img'].shape == (0, 3)
+    with pytest.raises(RuntimeError, match='crop window'):
+        F.fetch_train_batch(t(ids), n_img, U.H, U.W, window=(60, 0, 50, 50), rgba=t(rgba))
+    with pytest.raises(RuntimeError, match='not both'):
+        F.fetch_train_batch(t(ids), n_img, U.H, U.W, rgba=t(rgba), img=t(img))
+
+
+# ---- 2. the Pipeline on the GPU -------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('form', ['rgba', 'rays'])
+def test_pipeline_hands_out_the_reference_batches(gpu, oracle, g, form):
+    """`rays`: the reference's own dataset form (precomputed per-pixel rays, float img + mask) through the same launch + row gathers"""
+    from arcnerf_amd import trainer as T
+    from oracle import batch as OB
+    data = to_dev(dataset(g, 'rgba' if form == 'rgba' else 'float'), gpu)
+    if form == 'rays':
+        o, d, r = OB.dataset_rays(U.H, U.W, g['K_train'], g['c2w_train'])
+        data.update(rays_o=torch.from_numpy(o).to(gpu), rays_d=torch.from_numpy(d).to(gpu), rays_r=torch.from_numpy(r).to(gpu))
+        del data['intrinsic'], data['c2w']
+    seed = U.SEEDS[1]
+    tag = 's{}_'.format(seed)
+    p = T.Pipeline(tape=U.Tape(seed))
+    p.set_n_rays(None, U.N_RAYS0)
+    p.setup_cfgs(scheduler_cfg(g))
+    batches = T.TrainBatches(p, lambda: data)
+    model = FactorTape(g, seed)
+    want_n, sums = g[tag + 'n_rays'], g[tag + 'batch_sums']
+    for epoch in range(len(want_n)):
+        model.epoch = epoch
+        feed_in = batches(p.fetch_step_update_dynamic_bs(epoch, model), epoch)
+        assert feed_in['rays_o'].shape == (1, int(want_n[epoch]), 3) and feed_in['rays_o'].is_cuda
+        check_sums({k: feed_in[k][0].cpu().numpy() for k in U.BATCH_KEYS}, sums[epoch], (seed, epoch))
+    assert p._n_shuffle == len(g[tag + 'shuffle_at']) and int(data_bad(batches)) == 0
+
+
+def data_bad(batches):
+    return batches.data['_view'].bad
+
+
+# ---- 3. / 4. training -------------------------------------------------------------------------------------------------------------------------------
+def psnr_band(g, c):
+    """the reference's held-out PSNR over its seeds after checkpoint c: (lo, hi) = the seed-to-seed range widened by itself (at least 1.5 dB)"""
+    p = np.array([float(g['s{}_psnr'.format(s)][c]) for s in U.SEEDS])
+    w = max(1.5, float(p.max() - p.min()))
+    return float(p.min()) - w, float(p.max()) + w
+
+
+def white_psnr(g):
+    return U.psnr(np.ones_like(U.white_targets(g['rgba_test'])), U.white_targets(g['rgba_test']))
+
+
+def loss_cfg(g):
+    c = type('C', (), {})()
+    c.loss = type('C', (), {})()
+    c.loss.ImgLoss = type('C', (), dict(keys=['rgb_coarse'], loss_type='Huber', delta=float(g['loss_cfg'][0]), weight=float(g['loss_cfg'][1])))()
+    return c
+
+
+def held_out(g, gpu):
+    from oracle import batch as OB
+    o, d, r = OB.dataset_rays(U.H, U.W, g['K_test'], g['c2w_test'])
+    return [torch.from_numpy(a).to(gpu) for a in (o, d, r)], U.white_targets(g['rgba_test'])
+
+
+def evaluate(m, rays, target):
+    m.eval()
+    preds = []
+    with torch.no_grad():
+        for v in range(target.shape[0]):
+            out = m({'rays_o': rays[0][v][None], 'rays_d': rays[1][v][None], 'rays_r': rays[2][v][None]}, inference_only=True)
+            preds.append(out['rgb'][0].cpu().numpy())
+    m.train()
+    preds = np.stack(preds)
+    return U.psnr(preds, target), float(np.mean(1.0 - preds.min(-1) < 0.02))
+
+
+def run_module_api(g, gpu, seed, fused, n_epoch=U.N_EPOCH, on_step=None, flat=None):
+    """the loop of tests/golden/make_golden_psnr.py on the product: -> dict(psnr, white_share, losses, n_valid, n_rays, bitfields, stepper)"""
+    import arcnerf_amd.geometry.volume as V
+    from arcnerf_amd import trainer as T
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    from arcnerf_amd.optim import FusedAdam
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    ov = [str(v) for v in g['overrides']] if not fused else \
+        ['--model.obj_bound.volume.n_grid', str(U.N_GRID), '--model.obj_bound.epoch_optim', str(U.EPOCH_OPTIM), '--model.obj_bound.epoch_optim_warmup', str(U.EPOCH_WARMUP),
+         '--model.obj_bound.log_max_allowance', str(U.LOG_MAX_ALLOWANCE), '--model.rays.n_sample', str(U.N_SAMPLE)]
+    ov += ['--model.rays.noise_std', '0.0', '--model.rays.white_bkg', 'True']          # (the expr yaml's model block)
+    torch.manual_seed(2700 + seed)
+    m = build_model(load_configs(os.path.join(CFG, 'nerf_ngp.yaml'), ov)).to(gpu)
+    fg = m.fg_model
+    assert fg.packed_path_eligible() == fused and fg.get_n_coarse_sample() == U.N_SAMPLE
+    emb = fg.coarse_geo_net.embed_fn
+    lr, eps, wd, decay = [float(v) for v in g['optim']]
+    opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=lr, eps=eps, weight_decay=wd, ema_decay=decay, ema_in_param=fused).flatten()
+    if not fused:
+        tag = 's{}_'.format(seed)
+        sd = {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + 'sd.')}
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected and all(k.endswith(('embeddings', 'bitfield', 'opafield')) for k in missing), (missing, unexpected)
+        with torch.no_grad():
+            emb.embeddings.copy_(torch.from_numpy(U.table_from_seed(emb.embeddings.shape[0], 2, seed)))
+    elif flat is not None:
+        with torch.no_grad():
+            opt.flat_params().copy_(torch.from_numpy(flat))
+    else:
+        with torch.no_grad():
+            emb.embeddings.copy_(torch.from_numpy(U.table_from_seed(emb.embeddings.shape[0], 2, seed)))
+    ema = T.EMA(m, decay, opt)
+    ema.set_n_step(0)
+    loss_factory = T.build_loss(loss_cfg(g))
+    tape = U.Tape(seed)
+    V.set_refresh_tape(tape)
+    try:
+        p = T.Pipeline(tape=tape)
+        p.set_n_rays(None, U.N_RAYS0)
+        p.setup_cfgs(scheduler_cfg(g))
+        data = to_dev(dataset(g), gpu)
+        batches = T.TrainBatches(p, lambda: data)
+        stepper = T.FusedNgpStep(m, loss_factory, opt, ema, max_rays=U.N_RAYS_MAX, total_epoch=n_epoch) if fused else None
+        rays, target = held_out(g, gpu)
+        sampler_rng(reset=True)
+        m.train()
+        vol = fg.obj_bound.volume
+        res = {k: [] for k in ('psnr', 'white_share', 'occupied', 'loss', 'n_valid', 'bitfields')}
+        for epoch in range(n_epoch):
+            before = vol.get_voxel_opafield(flatten=True).clone()
+            out, loss = T.train_epoch(m, batches, loss_factory, opt, ema, p, epoch, total_epoch=n_epoch, stepper=stepper)
+            if not torch.equal(before, vol.get_voxel_opafield(flatten=True)):
+                res['bitfields'].append(vol.get_voxel_bitfield(flatten=True).cpu().numpy())
+            if on_step is not None or epoch < 64:
+                if fused:
+                    pipe = stepper.pipe if stepper.pipe is not None and stepper.steps > 0 else fg._pipe
+                    res['n_valid'].append(int(pipe.n_dev.item()))
+                else:
+                    res['n_valid'].append(int(fg._meter()._ring[fg._meter()._pending - 1]) if fg._meter()._pending else -1)
+                res['loss'].append(float(loss['sum']))
+                if on_step is not None:
+                    on_step(epoch, res)
+            if (epoch + 1) in U.CHECKPOINTS:
+                ps, ws = evaluate(m, rays, target)
+                res['psnr'].append(ps), res['white_share'].append(ws)
+                res['occupied'].append(float(vol.get_voxel_bitfield(flatten=True).float().mean()))
+        res['n_rays'] = [n for _, n in batches.drawn]
+        res['stepper'] = stepper
+        return res
+    finally:
+        V.set_refresh_tape(None)
+
+
+def check_training(g, runs, what):
+    """every seed's PSNR inside the reference's band at every checkpoint; the seeds that leave the all-white start are the reference's"""
+    wp = white_psnr(g)
+    report = []
+    for c, cp in enumerate(U.CHECKPOINTS):
+        lo, hi = psnr_band(g, c)
+        ref = [float(g['s{}_psnr'.format(s)][c]) for s in U.SEEDS]
+        got = [runs[s]['psnr'][c] for s in U.SEEDS]
+        report.append((cp, 'reference', [round(v, 2) for v in ref], what, [round(v, 2) for v in got], 'band', (round(lo, 2), round(hi, 2))))
+    if REPORT:
+        print('\n'.join(str(r) for r in report), '\nall-white PSNR', round(wp, 2))
+    for c, cp in enumerate(U.CHECKPOINTS):
+        lo, hi = psnr_band(g, c)
+        for s in U.SEEDS:
+            assert lo <= runs[s]['psnr'][c] <= hi, (what, 'seed', s, 'after', cp, runs[s]['psnr'][c], (lo, hi), report)
+    trained_ref = [bool(g['s{}_psnr'.format(s)][-1] > wp + 3.0) for s in U.SEEDS]
+    trained = [bool(runs[s]['psnr'][-1] > wp + 3.0) for s in U.SEEDS]
+    assert trained == trained_ref, (what, trained, trained_ref, report)
+
+
+def test_module_path_trains_like_the_reference_loop(gpu, oracle, g):
+    runs = {}
+    for seed in U.SEEDS:
+        tag = 's{}_'.format(seed)
+        r = runs[seed] = run_module_api(g, gpu, seed, fused=False)
+        assert r['n_rays'][:500] == g[tag + 'n_rays'].tolist()[:500]        # (from epoch 504 on the batch follows the run's own sample counts)
+        # the reference's trajectory while the occupancy decisions agree (bitfields equal outside the near-threshold band)
+        flips, n_ref, k_eq = 0, 0, 0
+        refreshed = g[tag + 'refreshed']
+        for epoch in range(64):
+            if refreshed[epoch]:
+                if n_ref < U.N_KEEP_REFRESH and flips == 0:
+                    ref = np.unpackbits(g[tag + 'bitfields'][n_ref], bitorder='little').astype(bool)
+                    near = np.unpackbits(g[tag + 'near'][n_ref], bitorder='little').astype(bool)
+                    diff = r['bitfields'][n_ref] != ref
+                    assert not (diff & ~near).any(), (seed, epoch, int((diff & ~near).sum()))
+                    flips += int(diff.sum())
+                n_ref += 1
+            if flips:
+                break
+            want_n, want_l = int(g[tag + 'n_valid'][epoch]), float(g[tag + 'loss'][epoch])
+            # (the rays come from the kernel's get_rays: 1e-6 from the reference's, a sample on a cell face may fall either way)
+            assert abs(r['n_valid'][epoch] - want_n) <= max(4, 2e-4 * want_n), (seed, epoch, r['n_valid'][epoch], want_n)
+            assert abs(r['loss'][epoch] - want_l) <= 2e-4 * want_l, (seed, epoch, r['loss'][epoch], want_l)
+            k_eq = epoch + 1
+        assert k_eq >= 8, (seed, k_eq)
+        if REPORT:
+            print('seed', seed, 'followed the reference for', k_eq, 'iterations; PSNR', r['psnr'], 'reference', g[tag + 'psnr'].tolist())
+    check_training(g, runs, 'module path')
+
+
+def test_fused_step_trains_like_the_reference_loop(gpu, oracle, g):
+    """the drop-in API at full speed; its first iterations against the oracle loop with the FUSED net semantics on the same batches"""
+    from arcnerf_amd.pipeline import NgpConfig, NgpField
+    from oracle import batch as OB
+    from oracle.ngp_trainer import OracleNgpTrainer
+    rgba = g['rgba_train']
+    n_img = rgba.shape[0]
+    rays = OB.dataset_rays(U.H, U.W, g['K_train'], g['c2w_train'])
+    dh = int((1 - U.PRECROP_RATIO) * U.H / 2.0)
+    crop = (dh, dh, U.H - 2 * dh, U.W - 2 * dh)
+    runs = {}
+    for seed in U.SEEDS:
+        flat = None
+        if seed == U.SEEDS[0]:
+            cfg = NgpConfig(geo_fused_semantics=True, W_feat=16, add_inf_z=False, noise_std=0.0, white_bkg=True, n_grid=U.N_GRID, n_sample=U.N_SAMPLE,
+                            epoch_optim=U.EPOCH_OPTIM, epoch_optim_warmup=U.EPOCH_WARMUP)
+            fld = NgpField(cfg, device='cpu', seed=0)
+            rng = np.random.default_rng(2790)
+            flat = fld.params.numpy().copy()
+            off, n = fld._seg['table']
+            flat[off:off + n] = U.table_from_seed(fld.offsets[-1], 2, seed).reshape(-1)
+            for name in ('geo_w', 'rad_w'):
+                off, n = fld._seg[name]
+                flat[off:off + n] = ((rng.random(n, dtype=np.float32) * 2 - 1) * np.float32(0.125)).astype(np.float32)
+            tr = OracleNgpTrainer(oracle, fld, cfg, flat, 1 << U.LOG_MAX_ALLOWANCE, U.N_RAYS0, U.UPDATE_EPOCH, U.N_RAYS_MAX).start_ema()
+            perm = U.shuffle_perm(seed, 0, n_img * crop[2] * crop[3])
+            ref = {'loss': [], 'n_valid': [], 'bitfields': [], 'near': []}
+            for epoch in range(20):
+                pm, uni = U.refresh_draws(seed, epoch, cfg.n_grid ** 3)
+                if tr.optimize(epoch, pm, uni):
+                    ref['bitfields'].append(tr.bitfield.copy())
+                    ref['near'].append(np.abs(tr.opafield - tr.last['thres']) <= U.NEAR_BAND * tr.last['thres'])
+                b = OB.fetch_train_batch(perm[epoch * U.N_RAYS0:(epoch + 1) * U.N_RAYS0], n_img, U.H, U.W, crop, rgba=rgba,
+                                         bkg_rand=U.bkg_draw(seed, epoch, U.N_RAYS0), rays=rays)
+                res = tr.step(b['rays_o'], b['rays_d'], b['bkg_color'], b['img'])
+                ref['loss'].append(res['loss']), ref['n_valid'].append(res['n_samples'])
+        r = runs[seed] = run_module_api(g, gpu, seed, fused=True, flat=flat)
+        assert r['stepper'].steps >= U.N_EPOCH - 2 - len(U.CHECKPOINTS)
+        if flat is not None:
+            flips, n_ref = 0, 0
+            for epoch in range(20):
+                if epoch > 0 and epoch % U.EPOCH_OPTIM == 0:
+                    diff = r['bitfields'][n_ref] != ref['bitfields'][n_ref]
+                    assert int((diff & ~ref['near'][n_ref]).sum()) <= 4, (seed, epoch, int(diff.sum()))
+                    flips += int(diff.sum())
+                    n_ref += 1
+                if flips:
+                    break
+                assert abs(r['n_valid'][epoch] - ref['n_valid'][epoch]) <= max(4, 2e-4 * ref['n_valid'][epoch]), (epoch, r['n_valid'][epoch], ref['n_valid'][epoch])
+                assert abs(r['loss'][epoch] - ref['loss'][epoch]) <= 2e-4 * ref['loss'][epoch], (epoch, r['loss'][epoch], ref['loss'][epoch])
+            assert epoch >= 8
+    check_training(g, runs, 'fused step')

@@ -16,7 +16,7 @@ L, st = N.lib(), N.stream()
 def run(R):
     N.check(L.arcn_composite_packed_train(N.ptr(b['sigma']), N.ptr(b['rgb_s']), N.ptr(b['t']), N.ptr(b['offsets']), N.ptr(b['noise']), None, 0, R, 2,
                                           b['p_dense'].data_ptr(), 0, 0, N.ptr(tgt), 0.1, 3000.0, N.ptr(b['rgb']), N.ptr(b['depth']), N.ptr(b['mask']),
-                                          N.ptr(b['d_rgb']), b['loss_ring'][0].data_ptr(), N.ptr(b['d_sigma']), N.ptr(b['d_rgb_s']), st), 'x')
+                                          N.ptr(b['d_rgb']), b['loss_ring'][0].data_ptr(), N.ptr(b['d_sigma']), N.ptr(b['d_rgb_s']), N.ptr(b['counts']), st), 'x')
 for R in (64, 512, 2048, 8320):
     run(R); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

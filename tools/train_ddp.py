@@ -2,7 +2,8 @@
 DistributedDataParallel + image-level DistributedSampler (common/trainer/basic_trainer.py:197-198, arcnerf/trainer/arcnerf_trainer.py:243-246)
 for this path.  Per step: every rank takes its shard of the global ray batch - balanced by the per-ray sample counts of the batch's previous
 visit (distributed.balanced_shards) once they are known, equal ray counts before - runs NgpPipeline.train_step with the level-grouped
-gradient exchange overlapped with the scatter (distributed.LevelGroupedGradSync; ARCN_GRAD_SEGMENTS=0: one flat all-reduce), and applies
+gradient exchange chosen by ARCN_GRAD_SYNC (flat: one all-reduce, the default; levels: distributed.LevelGroupedGradSync overlapped with the
+scatter; sharded: distributed.ShardedGradSync), and applies
 the occupancy refresh every `epoch_optim` steps with rank 0's fields broadcast to all (distributed.broadcast_occupancy).
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_ddp.py [steps=200] [rays=8192]
@@ -49,6 +50,8 @@ def train(cfg, dev, rank, world, steps, n_rays, n_batches=4, sync='levels', bala
     if world > 1 or D.forced():
         if sync == 'levels' and pipe.level_major:
             grad_sync = D.LevelGroupedGradSync(fld, level_cuts)
+        elif sync == 'sharded':
+            grad_sync = D.ShardedGradSync(fld.n_params, world, rank)
         else:
             all_reduce = lambda t: D.allreduce_grads(t, world)   # noqa: E731
     shard_log, loss = [], None
@@ -62,8 +65,9 @@ def train(cfg, dev, rank, world, steps, n_rays, n_batches=4, sync='levels', bala
             lo, hi = D.shard_range(n_rays, rank, world)
         hi = max(hi, lo + 1) if lo < n_rays else hi
         shard_log.append((lo, hi))
+        # unequal shards: the rank's mean over its rays, weighted by its share of the global batch (the optimiser divides the SUM by `world`)
         loss = pipe.train_step(o[lo:hi].contiguous(), d[lo:hi].contiguous(), tgt[lo:hi].contiguous(), bkg_color=bkg[lo:hi].contiguous(),
-                               all_reduce=all_reduce, world_size=world, grad_sync=grad_sync)
+                               all_reduce=all_reduce, world_size=world, grad_sync=grad_sync, loss_scale=(hi - lo) * world / float(n_rays))
         if balance and world > 1:
             # this step's per-ray counts of the GLOBAL batch: every rank contributes its shard's (rays it did not march: 0)
             full = torch.zeros(n_rays, dtype=torch.int32, device=dev)
@@ -90,7 +94,7 @@ def main():
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     D.init_from_env(device=dev)
-    out = train(NgpConfig(white_bkg=True), dev, rank, world, steps, n_rays, sync='flat' if os.environ.get('ARCN_GRAD_SEGMENTS') == '0' else 'levels')
+    out = train(NgpConfig(white_bkg=True), dev, rank, world, steps, n_rays, sync=os.environ.get('ARCN_GRAD_SYNC', 'flat'))
     digest = float(out['params'].double().abs().sum())
     agree = D.max_over_ranks(digest, device=dev) == digest
     if rank == 0:
