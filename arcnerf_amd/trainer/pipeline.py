@@ -26,8 +26,9 @@ POTENTIAL_KEYS = ['img', 'mask', 'rays_o', 'rays_d', 'rays_r', 'bounds', 'bkg_co
 _CAMERA_KEYS = ('intrinsic', 'c2w')
 
 
-def get_model_feed_in(inputs, device='gpu'):
-    """arcnerf/datasets/__init__.py:44-61: the model's keys of a batch (-> feed_in, batch_size)"""
+def get_model_feed_in(inputs, device=None):
+    """arcnerf/datasets/__init__.py:44-61: the model's keys of a batch (-> feed_in, batch_size); device 'gpu' moves host tensors to the
+    GPU as the reference does, None leaves them where the dataset lives (a batch of this Pipeline is born on the dataset's device)"""
     feed_in = {}
     for key in POTENTIAL_KEYS:
         if key in inputs:

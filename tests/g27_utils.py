@@ -18,7 +18,8 @@ N_GRID, N_SAMPLE = 32, 256
 EPOCH_OPTIM, EPOCH_WARMUP, UPDATE_EPOCH = 8, 32, 8
 LOG_MAX_ALLOWANCE = 14
 N_RAYS0, N_RAYS_MAX = 1024, 2048
-PRECROP_RATIO, PRECROP_MAX_EPOCH = 0.5, 100
+PRECROP_RATIO, PRECROP_MAX_EPOCH = 0.5, 50
+QUIRK_MAX_EPOCH, QUIRK_EPOCHS = 100, 130                         # the data-only leg: a pass over the cropped rays (59 batches) ends before precrop.max_epoch
 N_EPOCH = 600
 CHECKPOINTS = (50, 100, 200, 400, 600)                           # held-out PSNR after this many iterations
 SEEDS = (0, 1, 2, 3)

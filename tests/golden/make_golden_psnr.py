@@ -23,7 +23,9 @@ VolumeBound.optimize - is FED from tests/g27_utils.py (numpy PCG64) so that the 
 
 A quirk the fixture pins (trainer/pipeline.py:95-118): the SECOND call of process_train_data clears `crop_max_epoch`; when a full pass over
 the cropped rays ends before precrop.max_epoch (cropped rays / n_rays < max_epoch) the reshuffle is that second call and the crop never
-ends.  The Lego recipe is on the safe side (16 M cropped rays / 4096 = 3906 > 500) and so is this fixture (60 000 / 1024 = 58.6 > 50).
+ends.  The Lego recipe is on the safe side (16 M cropped rays / 4096 = 3906 > 500) and so are the training runs here (60 000 / 1024 =
+58.6 > 50); the leg `quirk_*` is the data side alone (no model) with precrop.max_epoch 100 for 130 iterations: a pass ends at iteration
+59, the reshuffle clears the crop's end, iteration 100 and everything after it still draws from the centre windows.
 
 usage: python tests/golden/make_golden_psnr.py            (G27_EPOCHS / G27_SEEDS override the sizes for a dry run: no fixture is written)
 """
@@ -332,6 +334,52 @@ def run(seed, rgba_train, rgba_test, out, verbose=True):
     out[tag + 'sampler_state'] = np.array([_state['rng'].state, _state['rng'].inc], np.uint64)
 
 
+def run_data_only(rgba_train, out, seed=0):
+    """the reference's Pipeline alone, precrop.max_epoch = U.QUIRK_MAX_EPOCH: batches of U.QUIRK_EPOCHS iterations"""
+    ov = list(OVERRIDES)
+    ov[ov.index('--dataset.train.scheduler.precrop.max_epoch') + 1] = str(U.QUIRK_MAX_EPOCH)
+    cfgs = load_configs(EXPR, ov)
+    log = Log()
+    pipe = Pipeline()
+    pipe.set_n_rays(log, get_value_from_cfgs_field(cfgs, 'n_rays', 1024))
+    pipe.setup_cfgs(get_value_from_cfgs_field(cfgs.dataset.train, 'scheduler', None))
+    img, mask = (torch.from_numpy(a) for a in U.dataset_tensors(rgba_train))
+    rays_o, rays_d, rays_r = view_rays(U.TRAIN_VIEWS[0], U.N_TRAIN)
+
+    def set_train_dataset():
+        return {'img': img.clone(), 'mask': mask.clone(), 'rays_o': rays_o.clone(), 'rays_d': rays_d.clone(), 'rays_r': rays_r.clone(), 'H': U.H, 'W': U.W}
+
+    n_shuffle = [0]
+
+    def process(data):
+        k = n_shuffle[0]
+        with Fed(perm=lambda n: U.shuffle_perm(seed, k, n)):
+            data = pipe.process_train_data(log, data)
+        n_shuffle[0] += 1
+        return data
+
+    data = process(set_train_dataset())
+    n_rays, sums, shuffle_at, crop_state = [], [], [], []
+    for epoch in range(U.QUIRK_EPOCHS):
+        crop_shuffle, full_shuffle = pipe.check_crop_shuffle(epoch), pipe.check_full_shuffle()
+        if crop_shuffle:
+            data = process(set_train_dataset())
+        elif full_shuffle:
+            data = process(data)
+        if crop_shuffle or full_shuffle:
+            shuffle_at.append(epoch)
+        with Fed(uni=lambda shape: U.bkg_draw(seed, epoch, shape[1])[None]):
+            batch = pipe.get_train_batch(data, epoch, None)
+        feed_in, _ = get_model_feed_in(batch, 'cpu')
+        n_rays.append(feed_in['rays_o'].shape[1])
+        sums.append(U.batch_summary({k: feed_in[k][0].numpy() for k in U.BATCH_KEYS}))
+        crop_state.append(-1 if pipe.crop_max_epoch is None else int(pipe.crop_max_epoch))
+    out['quirk_n_rays'], out['quirk_batch_sums'], out['quirk_shuffle_at'] = np.array(n_rays), np.array(sums), np.array(shuffle_at)
+    out['quirk_crop_max_epoch'] = np.array(crop_state)
+    out['quirk_total_samples'] = np.array(pipe.get_info('total_samples'))
+    print('quirk leg: reshuffles at', shuffle_at, 'total samples at the end', pipe.get_info('total_samples'), 'crop_max_epoch', crop_state[0], '->', crop_state[-1])
+
+
 def main():
     """no argument: every seed in this process; `part <seed>`: one seed -> /tmp/g27_part_<seed>.npz (run the seeds side by side);
     `merge`: the parts -> the fixture"""
@@ -357,6 +405,7 @@ def main():
     else:
         for seed in SEEDS:
             run(seed, rgba_train, rgba_test, out)
+    run_data_only(rgba_train, out)
     if DRY:
         print('dry run: nothing written')
         return

@@ -268,7 +268,7 @@ def test_bench_under_torchrun_on_a_one_rank_rccl_communicator(config, sync):
     assert out['n_gpus'] == 1 and rc is not None and rc['backend'] == 'nccl' and rc['world_size_seen'] == 1
     assert rc['allreduce_alone_ms'] > 0 and out['value'] > 0
     if config == 'ngp':
-        assert rc['collectives_per_step'] == {None: 1, 'levels': 2, 'sharded': 3}[sync]
+        assert rc['collectives_per_step'] in {None: (1,), 'levels': (2,), 'sharded': (2, 3)}[sync]      # (sharded: + the tail's all-reduce when n % 4 N != 0)
         assert rc['exposed_ms'] >= 0.0 and ('level groups' in rc['grad_sync']) == (sync == 'levels') and ('reduce-scatter' in rc['grad_sync']) == (sync == 'sharded')
         # a one-rank SUM is the identity: the step trains like the single-GPU step (two-pass optimiser form)
         assert 1e8 < out['value'] < 1e9

@@ -263,21 +263,21 @@ def test_overflowed_step_is_the_step_of_the_rays_that_fit(gpu, fused):
     assert int(pb.n_dev.item()) == cap and torch.equal(pb.buf['counts'][:R], counts)
     off = pb.buf['offsets'][:R + 1]
     trunc = (off[1:] - off[:-1]) < counts
-    assert 0.2 * R < int(trunc.sum()) < 0.8 * R
+    assert int(trunc.sum()) > 100 and int((~trunc & (counts > 0)).sum()) > 100      # (many of the synthetic rays miss the occupancy altogether)
     if fused:
         loss_b, d_rgb_b = pb.last_loss, pb.buf['d_rgb'][:R]
     else:
         loss_b, d_rgb_b = pb.huber_grad(rgb_b, tgt)
     pb.backward(o, d, d_rgb_b)
     _, d_rgb_a = pa.huber_grad(rgb_a, tgt)
-    d_rgb_a[trunc] = 0.0
-    d_rgb_a[trunc] = pa.huber_grad(bkg, tgt)[1][trunc] * 0.0            # (no-op: makes the intent explicit - those rays carry no gradient)
+    d_rgb_full = d_rgb_a.clone()
+    d_rgb_a[trunc] = 0.0                                                # those rays carry no gradient
     pa.backward(o, d, d_rgb_a)
     torch.cuda.synchronize()
     assert torch.equal(rgb_b[~trunc], rgb_a[~trunc])                    # complete rays: the same colours, bit for bit
     assert torch.equal(rgb_b[trunc], bkg[trunc])                        # truncated rays: the background colour, as rays without samples
     if fused:
-        assert torch.equal(d_rgb_b[~trunc], pa.huber_grad(rgb_a, tgt)[1][~trunc])
+        assert torch.equal(d_rgb_b[~trunc], d_rgb_full[~trunc])
     ga, gb = fa.grads, fb.grads
     assert float(ga.abs().max()) > 0 and float((ga - gb).abs().max()) <= 2e-6 * float(ga.abs().max()), float((ga - gb).abs().max() / ga.abs().max())
 
