@@ -526,39 +526,78 @@ __global__ void __launch_bounds__(256) reduce_max_kernel(const float *__restrict
 // next binade does it once (64 dt < t): the crossing value is ONE real float add from the last lane of the first segment, and the
 // lanes behind it run in the new binade with q' = rn(D / 2).  Returns false (wave uniform; the caller runs the systolic chain) for a
 // tie in either binade, a second crossing, denormals or a dt that rounds away.
-__device__ __forceinline__ bool lattice_closed_form(float t_base_v, float dt, int lane, float &t_out) {
-#ifdef ARCN_EXP_LATTICE_CHAIN
-    return false;
-#endif
+struct Lattice {      // everything wave uniform
+    bool ok;          // the trip's 64 values were written in closed form
+    int ef, ef2, c;   // exponent fields of the two binades; first lane of the second (64: the trip stays in one)
+    uint32_t m0, q, mc, q2;
+    float t_c;        // value of lane c (the crossing step)
+};
+
+__device__ __forceinline__ Lattice lattice_closed_form(float t_base_v, float dt, int lane, float &t_out) {
+    Lattice L;
+    L.ok = false; L.c = 64; L.ef2 = 0; L.mc = 0; L.q2 = 1; L.t_c = 0.f;
     const uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t_base_v));
     const int ef = (int)((tb >> 23) & 0xffu);
-    if ((tb >> 31) || ef < 1 || ef > 200) return false;
+    L.ef = ef;
+    if ((tb >> 31) || ef < 1 || ef > 200) return L;
     const float D = ldexpf(dt, 150 - ef);                       // dt / u: a power-of-two scaling, exact
-    if (!(D >= 0.75f && D < 4194304.0f)) return false;
+    if (!(D >= 0.75f && D < 4194304.0f)) return L;
     const float fl = floorf(D);
-    if (D - fl == 0.5f) return false;                           // tie: the sequential sums alternate
+    if (D - fl == 0.5f) return L;                               // tie: the sequential sums alternate
     const uint32_t q = (uint32_t)rintf(D);
     const uint32_t m0 = (tb & 0x7fffffu) | 0x800000u;
+    L.q = q; L.m0 = m0;
     const uint32_t m = m0 + (uint32_t)lane * q;
     const uint64_t in_first = __ballot(m < 0x1000000u);         // monotone in the lane: a prefix of the wave
     t_out = __builtin_bit_cast(float, ((uint32_t)ef << 23) | (m & 0x7fffffu));
-    if (in_first == ~0ull) return true;
+    if (in_first == ~0ull) { L.ok = true; return L; }
     const int c = __builtin_popcountll(in_first);               // first lane of the next binade (>= 1: lane 0 is t_base itself)
     const float t_prev = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_out), c - 1));
     const float t_c = t_prev + dt;                              // the crossing step: a real, correctly rounded add
     const uint32_t cb = __builtin_bit_cast(uint32_t, t_c);
     const int ef2 = (int)((cb >> 23) & 0xffu);
-    if (ef2 != ef + 1) return false;
+    if (ef2 != ef + 1) return L;
     const float D2 = D * 0.5f;
     const float fl2 = floorf(D2);
-    if (D2 - fl2 == 0.5f || !(D2 >= 0.75f)) return false;
+    if (D2 - fl2 == 0.5f || !(D2 >= 0.75f)) return L;
     const uint32_t q2 = (uint32_t)rintf(D2);
     const uint32_t mc = (cb & 0x7fffffu) | 0x800000u;
     const uint32_t m2 = mc + (uint32_t)(lane - c) * q2;         // (lanes < c wrap around: masked below)
     const bool second = lane >= c;
-    if (__ballot(second && m2 >= 0x1000000u)) return false;     // a second crossing inside one trip
+    if (__ballot(second && m2 >= 0x1000000u)) return L;         // a second crossing inside one trip
     if (second) t_out = __builtin_bit_cast(float, ((uint32_t)ef2 << 23) | (m2 & 0x7fffffu));
-    return true;
+    L.ok = true; L.c = c; L.ef2 = ef2; L.mc = mc; L.q2 = q2; L.t_c = t_c;
+    return L;
+}
+
+// ceil(n / q) for the landing lane, exact whenever the quotient is below ~100 (larger ones only need to be >= 64): float estimate
+// (relative error 2^-22) corrected by one integer multiply
+__device__ __forceinline__ uint32_t ceil_div_small(uint32_t n, uint32_t q, float rq) {
+    const uint32_t nn = n + q - 1u;
+    uint32_t k = (uint32_t)((float)nn * rq);
+    k = k > 100u ? 100u : k;
+    const int32_t r = (int32_t)(nn - k * q);
+    if (r < 0) k -= 1u;
+    else if ((uint32_t)r >= q && k < 100u) k += 1u;
+    return k;
+}
+
+// landing lane of an empty point in a closed-form trip: the first lane m with t_m >= target (t_m ascending), without looking at the
+// other lanes - inside a binade "t_m >= target" is a comparison of mantissas, the count of lattice values below target a division.
+// target >= t_base; target's ulp is at least the segment's, so its scaled value is an integer.
+__device__ __forceinline__ int lattice_landing(const Lattice &L, float target, float rq, float rq2) {
+    uint32_t k;
+    if (L.c == 64 || !(target > L.t_c)) {
+        const float Tf = ldexpf(target, 150 - L.ef);            // < 2^26 or far beyond the trip
+        const uint32_t T = Tf < 67108864.0f ? (uint32_t)Tf : 67108864u;
+        k = T > L.m0 ? ceil_div_small(T - L.m0, L.q, rq) : 0u;
+        k = k < (uint32_t)L.c ? k : (uint32_t)L.c;              // (lane c itself is >= target in this branch)
+    } else {
+        const float Tf = ldexpf(target, 150 - L.ef2);
+        const uint32_t T = Tf < 67108864.0f ? (uint32_t)Tf : 67108864u;
+        k = (uint32_t)L.c + (T > L.mc ? ceil_div_small(T - L.mc, L.q2, rq2) : 0u);
+    }
+    return k < 64u ? (int)k : 64;
 }
 
 struct MarchPacked {
@@ -672,7 +711,8 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
             // lane 0 has no neighbour, keeps its own value and adds 0.  After k steps lanes 0..k hold the exact sequential
             // sums and keep reproducing them, so 63 single-instruction steps replace a 63-trip divergent loop.
             float t;
-            if (!lattice_closed_form(t_base, dt, lane, t)) {
+            const Lattice lat = lattice_closed_form(t_base, dt, lane, t);
+            if (!lat.ok) {
                 t = t_base;
 #pragma unroll
                 for (int k = 0; k < 63; ++k) {
@@ -693,7 +733,10 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
             // point with t >= target.  t grows with the lane, so every lane finds its landing lane by bisection over the wave
             // (6 cross-lane reads, all lanes at once) and the replay below only follows pointers.  64 = beyond this trip.
             int next_lane = 64;
-            {
+            if (lat.ok) {
+                const int land = lattice_landing(lat, target, 1.0f / (float)lat.q, 1.0f / (float)lat.q2);
+                next_lane = land > lane + 1 ? land : lane + 1;
+            } else {
                 int lo = lane + 1, hi = 64;
 #pragma unroll
                 for (int it = 0; it < 6; ++it) {
