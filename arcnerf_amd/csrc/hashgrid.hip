@@ -1455,6 +1455,51 @@ ARCN_EXPORT int arcn_hashgrid_bwd_bwd(const float *xyz, const float *gdx, const 
     return check_launch("hashgrid_bwd_bwd");
 }
 
+// First- and second-order table gradients of ONE batch in one consumer pass (NeuS on the hash grid: the table receives d loss / d enc
+// through the encoding AND d loss / d normal through the encoding's input gradient).  Both producers append their records to the same
+// bins - scatter_bin_dir_kernel 8 single-row records per (sample, level), scatter_bin_kernel its pair / run records - of a plan sized
+// for 3 n samples, and every owner chunk is accumulated and written back ONCE: one scatter_accum pass (the dominant kernel of the
+// scatter: 114 us for the 16-level table whatever the sample count) instead of two.
+ARCN_EXPORT int arcn_hashgrid_bwd_first_second(const float *xyz, const float *dout, const float *gdx, const float *dout_dx,
+                                               const arcn_hashgrid_desc *desc_host, float *dtable, float *workspace, int64_t workspace_floats,
+                                               int64_t n, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!xyz || !dout || !gdx || !dout_dx || !dtable || !workspace) return einval("hashgrid_bwd_first_second: missing argument");
+    GridParams g;
+    int rc = build_params(desc_host, g);
+    if (rc) return rc;
+    if (g.F > 2) return einval("hashgrid_bwd_first_second: n_feat 1 or 2");
+    if (workspace_floats < arcn_hashgrid_bwd_workspace_floats(desc_host, 3 * n))
+        return einval("hashgrid_bwd_first_second: workspace smaller than arcn_hashgrid_bwd_workspace_floats(desc, 3 * n)");
+    BinPlan plan;
+    rc = build_bin_plan(g, 3 * n, plan);
+    if (rc) return rc;
+    uint32_t *counters = reinterpret_cast<uint32_t *>(workspace);
+    uint4 *recs = reinterpret_cast<uint4 *>(workspace + bin_counter_floats(plan));
+    hipError_t e = hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)bin_counter_floats(plan), as_stream(stream));
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
+    const size_t lds = plan.det ? sizeof(unsigned long long) * (size_t)plan.chunk_floats
+                                : sizeof(float) * (size_t)plan.chunk_floats + sizeof(uint32_t) * (size_t)(plan.chunk_floats / 32);
+    e = g.F == 1
+        ? hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_accum_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+        : hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_accum_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
+    int64_t bx = ceil_div<int64_t>(n, 1024);
+    if (bx > 32) bx = 32;
+    dim3 bgrid((unsigned)bx, (unsigned)g.L), agrid((unsigned)plan.item_first[g.L]);
+    const int32_t *no_count = nullptr;
+    if (g.F == 1) {
+        hipLaunchKernelGGL(scatter_bin_dir_kernel<1>, bgrid, dim3(1024), 0, as_stream(stream), xyz, gdx, dout_dx, g, plan, counters, recs, dtable, n, no_count);
+        hipLaunchKernelGGL((scatter_bin_kernel<1, 1024>), bgrid, dim3(1024), 0, as_stream(stream), xyz, dout, (int64_t)0, g, plan, counters, recs, dtable, n, no_count);
+        hipLaunchKernelGGL(scatter_accum_kernel<1>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable, AdamFuse{});
+    } else {
+        hipLaunchKernelGGL(scatter_bin_dir_kernel<2>, bgrid, dim3(1024), 0, as_stream(stream), xyz, gdx, dout_dx, g, plan, counters, recs, dtable, n, no_count);
+        hipLaunchKernelGGL((scatter_bin_kernel<2, 1024>), bgrid, dim3(1024), 0, as_stream(stream), xyz, dout, (int64_t)0, g, plan, counters, recs, dtable, n, no_count);
+        hipLaunchKernelGGL(scatter_accum_kernel<2>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable, AdamFuse{});
+    }
+    return check_launch("hashgrid_bwd_first_second");
+}
+
 ARCN_EXPORT int arcn_hashgrid_bwd_lm(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host,
                                      float *dtable, float *workspace, int64_t workspace_floats, int64_t n, const int32_t *n_ptr,
                                      void *stream) {

@@ -1206,6 +1206,7 @@ static int mlp_fwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
             case 2410: ARCN_FIXED(2, 4, 1, 0, 0);
             case 4410: ARCN_FIXED(4, 4, 1, 0, 0);
             case 2441: ARCN_FIXED(2, 4, 4, 1, 0);
+            case 3441: ARCN_FIXED(3, 4, 4, 1, 0);      // 33..48 inputs (the pvnf radiance net of NeuS-NGP: 3 + 16 + 3 + 16 = 38), ragged last tile
             case 4441: ARCN_FIXED(4, 4, 4, 1, 0);
             default: break;
             }
@@ -1279,7 +1280,7 @@ static int mlp_bwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
         const int t3 = P.n_layers == 3 ? tiles16(P.dims[3]) : 0;
         const int sig = t0 * 1000 + t1 * 100 + t2 * 10 + t3;
         if (cat_in ? ((sig == 2441 || sig == 2410) && P.dims[0] == 32)
-                   : x_stride ? (sig == 2410 || sig == 4410) : (sig == 2410 || sig == 2441 || sig == 4410 || sig == 4441)) {
+                   : x_stride ? (sig == 2410 || sig == 4410) : (sig == 2410 || sig == 2441 || sig == 3441 || sig == 4410 || sig == 4441)) {
             // + one 8 KiB transposition area per wave + the forward fragments of W_0 (<= 16 tiles) for the recomputed layer-0 activations
             const size_t fused_lds = lds_bytes + sizeof(float) * (8192 + 16 * kFragTile);
             int64_t grid = tile_grid(n, 64);
@@ -1314,6 +1315,7 @@ static int mlp_bwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
             case 2410: ARCN_FUSED(2, 4, 1, 0, 2, 0); break;
             case 4410: ARCN_FUSED(4, 4, 1, 0, 2, 0); break;
             case 2441: if (fused_nt3 == 2) ARCN_FUSED(2, 4, 4, 1, 2, 0); else ARCN_FUSED(2, 4, 4, 1, 1, 0); break;
+            case 3441: ARCN_FUSED(3, 4, 4, 1, 1, 0); break;
             default: ARCN_FUSED(4, 4, 4, 1, 1, 0); break;
             }
 #undef ARCN_FUSED

@@ -71,7 +71,7 @@ class MultiVol(BkgModel, MortonDensityGrid):
             rays_o, rays_d, near, far, n_pts, self.cone_angle, self.min_step, self.max_step,
             self.basic_volume.get_range().permute(1, 0).contiguous(), self.max_volume.get_range().permute(1, 0).contiguous(),
             self.n_grid, self.n_cascade, self.density_bitfield, self.get_optim_cfgs('near_distance'), self.inclusive, rng.state,
-            rng.inc, want_counts=True)
+            rng.inc, want_counts=True, dense=False)
         rng.advance()
         return Fn.pack_dense_samples_begin(zvals, counts)
 
@@ -95,6 +95,14 @@ class MultiVol(BkgModel, MortonDensityGrid):
         pre, self._presampled = getattr(self, '_presampled', None), None
         if pre is None or pre[0] != (rays_o.data_ptr(), rays_d.data_ptr(), n_rays, rays_o._version, rays_d._version):
             pre = (None, self._sample_begin(rays_o, rays_d))
+        else:
+            # (possibly queued on the sampling stream a step ago - FullModel.prefetch_samples: order this stream behind it and keep its
+            # tensors from being handed out again while this stream still reads them)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(pre[1]['event'])
+            for t_ in pre[1].values():
+                if isinstance(t_, torch.Tensor) and t_.is_cuda:
+                    t_.record_stream(cur)
         with torch.no_grad():
             t, ray_id, offsets, p_dense, total = Fn.pack_dense_samples_end(pre[1])
             if total > 0:

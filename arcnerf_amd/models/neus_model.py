@@ -64,25 +64,49 @@ class Neus(SdfModel):
             return self._forward_packed(inputs, inference_only, get_progress == 't_last', cur_epoch)
         return super().forward(inputs, inference_only, bool(get_progress), cur_epoch, total_epoch)
 
+    @torch.no_grad()
+    def _sample_begin(self, rays_o, rays_d):
+        """bounds + occupancy marcher + the scans of the section layout queued, the totals on their way to the host (no wait here)"""
+        from ..ops.volume_func import sampler_rng
+        vol, n_pts = self.obj_bound.volume, self.get_n_coarse_sample()
+        rng = sampler_rng()
+        zd, counts, _, _ = Fn.march_count(rays_o, rays_d, vol.get_range().permute(1, 0).contiguous(), vol.get_n_grid(),
+                                          vol.get_voxel_bitfield(), n_pts, vol.get_diag_len() / n_pts,
+                                          self.obj_bound.get_optim_cfgs('near_distance'), rng.state, rng.inc)
+        rng.advance()
+        return Fn.neus_pack_begin(zd, counts)
+
+    def presample(self, inputs):
+        """March the rays of a LATER forward now (FullModel.prefetch_samples calls this on the sampling stream while the current step's
+        backward runs): that forward, on the same ray tensors, picks the samples up and reads totals that arrived long ago - no marcher
+        and no host wait on its critical path.  One sampler launch per batch in batch order, as without it: the same samples."""
+        rays_o, rays_d = inputs['rays_o'], inputs['rays_d']
+        if not (self.packed_path_eligible() and rays_o.is_cuda and rays_o.is_contiguous() and rays_d.is_contiguous()
+                and rays_o.dtype == torch.float32 and rays_d.dtype == torch.float32):
+            return
+        self._presampled = ((rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], rays_o._version, rays_d._version),
+                            self._sample_begin(rays_o, rays_d))
+
     def _forward_packed(self, inputs, inference_only, want_t_last, cur_epoch):
         """March (K2 + K3 in one launch) -> section layout of the marched samples (arcn_neus_sections) -> the nets on the packed mid
         points (the same autograd graph as the dense path: hash encoder, sdf net with its input Jacobian, radiance net) -> ONE render
         kernel per direction (slope, cos annealing, sdf_to_alpha, weights, sums, invalid-ray defaults).  One host read (the number of
         points and the longest ray) where the dense path has five; no boolean-mask gathers, no padded scatters, no (rays, P) tensor
         except the `normal_pts` output the Eikonal loss consumes (a gather of the packed normals, padded slots included)."""
-        from ..ops.volume_func import sampler_rng
         rays_o, rays_d = inputs['rays_o'].contiguous().float(), inputs['rays_d'].contiguous().float()
         bkg_color = inputs['bkg_color']
         n_rays = rays_o.shape[0]
-        vol, n_pts = self.obj_bound.volume, self.get_n_coarse_sample()
         train = not inference_only
         with torch.no_grad():
-            rng = sampler_rng()
-            zd, counts, _, _ = Fn.march_count(rays_o, rays_d, vol.get_range().permute(1, 0).contiguous(), vol.get_n_grid(),
-                                              vol.get_voxel_bitfield(), n_pts, vol.get_diag_len() / n_pts,
-                                              self.obj_bound.get_optim_cfgs('near_distance'), rng.state, rng.inc)
-            rng.advance()
-            pk = Fn.neus_pack(zd, counts, float(self.get_ray_cfgs('n_sample')))
+            pre, self._presampled = getattr(self, '_presampled', None), None
+            if pre is not None and pre[0] == (rays_o.data_ptr(), rays_d.data_ptr(), n_rays, rays_o._version, rays_d._version):
+                handle = pre[1]
+                torch.cuda.current_stream().wait_event(handle['event'])       # marched on the sampling stream while the previous step ran
+                for t_ in (handle['z'], handle['counts'], handle['offsets'], handle['kmax'], handle['n_eval']) + handle['keep']:
+                    t_.record_stream(torch.cuda.current_stream())
+            else:
+                handle = self._sample_begin(rays_o, rays_d)
+            pk = Fn.neus_pack_end(handle, float(self.get_ray_cfgs('n_sample')))
             total = pk['total']
             if total > 0:
                 pts, dirs = Fn.packed_points(rays_o, rays_d, pk['t_mid'], pk['ray_id'])

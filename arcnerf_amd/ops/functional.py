@@ -187,8 +187,9 @@ def sparse_volume_sampling(rays_o, rays_d, near, far, n_pts, dt, aabb23, n_grid,
     aabb = _f32(aabb23)
     bf = bitfield.contiguous().view(torch.uint8)
     R = o.shape[0]
-    zvals = torch.zeros((R, n_pts), dtype=torch.float32, device=o.device)
-    mask = torch.zeros((R, n_pts), dtype=torch.bool, device=o.device)
+    alloc = torch.zeros if (dense or not want_counts) else torch.empty
+    zvals = alloc((R, n_pts), dtype=torch.float32, device=o.device)
+    mask = alloc((R, n_pts), dtype=torch.bool, device=o.device)
     counts = torch.zeros(R, dtype=torch.int32, device=o.device) if want_counts else None
     N.check(N.lib().arcn_sparse_volume_sampling(N.ptr(o), N.ptr(d), N.ptr(nr), N.ptr(fr), int(n_pts), float(dt),
                                                N.ptr(aabb), int(n_grid), N.ptr(bf), float(near_distance),
@@ -220,8 +221,9 @@ def sparse_volume_sampling_bit(rays_o, rays_d, near, far, n_pts, dt, aabb23, n_g
         raise RuntimeError('bitfield should be uint8 in (n_grid**3/8,)')
     bf = bitfield.contiguous()
     R = o.shape[0]
-    zvals = torch.zeros((R, n_pts), dtype=torch.float32, device=o.device)
-    mask = torch.zeros((R, n_pts), dtype=torch.bool, device=o.device)
+    alloc = torch.zeros if (dense or not want_counts) else torch.empty
+    zvals = alloc((R, n_pts), dtype=torch.float32, device=o.device)
+    mask = alloc((R, n_pts), dtype=torch.bool, device=o.device)
     counts = torch.zeros(R, dtype=torch.int32, device=o.device) if want_counts else None
     N.check(N.lib().arcn_sparse_volume_sampling_bit(N.ptr(o), N.ptr(d), N.ptr(nr), N.ptr(fr), int(n_pts), float(dt),
                                                    N.ptr(aabb), int(n_grid), N.ptr(bf), float(near_distance),
@@ -304,15 +306,18 @@ def _multivol_levels(n_cascade, inclusive):
 
 def sparse_sampling_in_multivol_bitfield(rays_o, rays_d, near, far, n_pts, cone_angle, min_step, max_step, min_aabb23, aabb23,
                                          n_grid, n_cascade, bitfield, near_distance, inclusive, rng_state, rng_inc,
-                                         want_counts=False):
+                                         want_counts=False, dense=True):
+    """dense=False (with want_counts): only the first counts[r] entries of a row of zvals are meaningful - the form the packed paths
+    compact (pack_dense_samples); the (rays, n_pts) outputs are then not zero-filled first (21 MB of fills per 4096-ray batch)"""
     _req(rays_o, rays_d, near, far, min_aabb23, aabb23, bitfield)
     o, d = _f32(rays_o), _f32(rays_d)
     nr, fr = _f32(near).view(-1), _f32(far).view(-1)
     if bitfield.dtype != torch.uint8 or bitfield.numel() != int(n_grid) ** 3 // 8 * _multivol_levels(n_cascade, inclusive):
         raise RuntimeError('bitfield should be uint8 in (n_grid**3/8 * levels,)')
     R = o.shape[0]
-    zvals = torch.zeros((R, n_pts), dtype=torch.float32, device=o.device)
-    mask = torch.zeros((R, n_pts), dtype=torch.bool, device=o.device)
+    alloc = torch.zeros if (dense or not want_counts) else torch.empty
+    zvals = alloc((R, n_pts), dtype=torch.float32, device=o.device)
+    mask = alloc((R, n_pts), dtype=torch.bool, device=o.device)
     counts = torch.zeros(R, dtype=torch.int32, device=o.device) if want_counts else None
     N.check(N.lib().arcn_sparse_sampling_in_multivol_bitfield(
         N.ptr(o), N.ptr(d), N.ptr(nr), N.ptr(fr), int(n_pts), float(cone_angle), float(min_step), float(max_step),
@@ -540,6 +545,17 @@ def hashgrid_bwd_bwd(xyz, gdx, table, dout, desc, want_ddout=True, want_dtable=T
     return ddout, dtable, d2xyz
 
 
+def hashgrid_bwd_first_second(xyz, dout, gdx, dout_dx, desc, dtable, workspace):
+    """dtable += the table gradient through the encoding (dout) AND through its input gradient (gdx on J^T dout_dx): both binned scatters
+    with ONE accumulation pass; workspace from hashgrid_bwd_workspace(desc, 3 * n)"""
+    _req(xyz, dout, gdx, dout_dx, dtable, workspace)
+    xyz, dout, gdx, dout_dx = _f32(xyz), _f32(dout), _f32(gdx), _f32(dout_dx)
+    n = xyz.shape[0]
+    N.check(N.lib().arcn_hashgrid_bwd_first_second(N.ptr(xyz), N.ptr(dout), N.ptr(gdx), N.ptr(dout_dx), C.addressof(desc), N.ptr(dtable),
+                                                  N.ptr(workspace), workspace.numel(), n, N.stream()), 'hashgrid_bwd_first_second')
+    return dtable
+
+
 def freq_fwd(x, n_freqs, include_input=True):
     _req(x)
     x = _f32(x)
@@ -603,6 +619,24 @@ def sh_fwd(dirs, degree, include_input=False):
     n = dirs.shape[0]
     out = torch.empty((n, degree * degree + (3 if include_input else 0)), dtype=torch.float32, device=dirs.device)
     N.check(N.lib().arcn_sh_fwd(N.ptr(dirs), int(degree), int(include_input), N.ptr(out), n, N.stream()), 'sh_fwd')
+    return out
+
+
+def radiance_inputs(mode, pts=None, dirs=None, normals=None, feat=None, sh_degree=4):
+    """[p | v | n | f] blocks of a radiance net's input in the order of `mode`, one kernel (v = SH(normalize(dirs))); feat may be a column
+    slice of a wider row-major tensor"""
+    _req(pts, dirs, normals, feat)
+    ref = next(t for t in (pts, dirs, normals, feat) if t is not None)
+    n = ref.shape[0]
+    ld, nf = 0, 0
+    if feat is not None:
+        assert feat.dim() == 2 and feat.stride(1) == 1 and feat.dtype == torch.float32
+        ld, nf = feat.stride(0), feat.shape[1]
+    width = sum({'p': 3, 'v': sh_degree * sh_degree, 'n': 3, 'f': nf}[c] for c in mode)
+    out = torch.empty((n, width), dtype=torch.float32, device=ref.device)
+    N.check(N.lib().arcn_radiance_inputs(mode.encode(), N.ptr(_f32(pts)), N.ptr(_f32(dirs)), N.ptr(_f32(normals)),
+                                        None if feat is None else feat.data_ptr(), int(ld), int(nf), int(sh_degree), N.ptr(out), n, N.stream()),
+            'radiance_inputs')
     return out
 
 
@@ -1139,9 +1173,9 @@ def march_count(rays_o, rays_d, aabb23, n_grid, bitfield, n_pts, dt, near_distan
     return z, counts, near, far
 
 
-def neus_pack(zvals_dense, counts, n_sample_cfg, want_map=False):
-    """The section layout of NeuS for marched samples (see csrc/neus.hip) -> dict(t_mid, lo, hi, ray_id (total), offsets (R+1) int32,
-    kmax (1) int32 device, p_dense int, total int, slot_map (R, p_dense) int64 | None).  ONE host read (total and the longest ray)."""
+def neus_pack_begin(zvals_dense, counts):
+    """First half of neus_pack: the scans, and (total, longest ray) on their way to pinned host memory (asynchronous copy + event) -
+    the caller may queue other work, or run this on a side stream for the NEXT batch, before neus_pack_end waits for it."""
     _req(zvals_dense, counts)
     R, n_pts = zvals_dense.shape
     dev = zvals_dense.device
@@ -1153,22 +1187,42 @@ def neus_pack(zvals_dense, counts, n_sample_cfg, want_map=False):
     N.check(L.arcn_neus_count(N.ptr(counts), N.ptr(kmax), R, N.ptr(n_eval), N.stream()), 'neus_count')
     offsets = torch.empty(R + 1, dtype=torch.int32, device=dev)
     N.check(L.arcn_exclusive_scan_i32(N.ptr(n_eval), N.ptr(offsets), R, int(R * (n_pts + 1)), None, N.stream()), 'exclusive_scan_i32')
-    total, k_h = torch.stack([offsets[R], kmax[0]]).tolist()
+    both = torch.stack([offsets[R], kmax[0]])
+    host = torch.empty(2, dtype=torch.int32).pin_memory()
+    host.copy_(both, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return {'z': zvals_dense, 'counts': counts, 'offsets': offsets, 'kmax': kmax, 'n_eval': n_eval, 'host': host, 'event': ev, 'keep': (tmp, both)}
+
+
+def neus_pack_end(h, n_sample_cfg, want_map=False):
+    """Second half: wait for the totals (the ONE host read), size the section tensors, lay the sections out."""
+    h['event'].synchronize()
+    total, k_h = int(h['host'][0]), int(h['host'][1])
+    zvals_dense, counts, offsets = h['z'], h['counts'], h['offsets']
+    R, n_pts = zvals_dense.shape
+    dev = zvals_dense.device
     p_dense = max(2, int(k_h))
-    out = {'offsets': offsets, 'kmax': kmax, 'p_dense': p_dense, 'total': int(total), 'n_eval': n_eval}
+    out = {'offsets': offsets, 'kmax': h['kmax'], 'p_dense': p_dense, 'total': int(total), 'n_eval': h['n_eval']}
     n_alloc = max(1, int(total))
     out['t_mid'] = torch.empty(n_alloc, dtype=torch.float32, device=dev)
     out['lo'] = torch.empty(n_alloc, dtype=torch.float32, device=dev)
     out['hi'] = torch.empty(n_alloc, dtype=torch.float32, device=dev)
     out['ray_id'] = torch.empty(n_alloc, dtype=torch.int32, device=dev)
     out['slot_map'] = torch.empty((R, p_dense), dtype=torch.int64, device=dev) if want_map else None
-    N.check(L.arcn_neus_sections(N.ptr(zvals_dense), N.ptr(counts), N.ptr(offsets), int(n_pts), float(n_sample_cfg), R, p_dense,
-                                 N.ptr(out['t_mid']), N.ptr(out['lo']), N.ptr(out['hi']), N.ptr(out['ray_id']), N.ptr(out['slot_map']),
-                                 N.stream()), 'neus_sections')
+    N.check(N.lib().arcn_neus_sections(N.ptr(zvals_dense), N.ptr(counts), N.ptr(offsets), int(n_pts), float(n_sample_cfg), R, p_dense,
+                                       N.ptr(out['t_mid']), N.ptr(out['lo']), N.ptr(out['hi']), N.ptr(out['ray_id']), N.ptr(out['slot_map']),
+                                       N.stream()), 'neus_sections')
     if total > 0:      # (total == 0: the one-element buffers stay, nothing reads them)
         for k in ('t_mid', 'lo', 'hi', 'ray_id'):
             out[k] = out[k][:int(total)]
     return out
+
+
+def neus_pack(zvals_dense, counts, n_sample_cfg, want_map=False):
+    """The section layout of NeuS for marched samples (see csrc/neus.hip) -> dict(t_mid, lo, hi, ray_id (total), offsets (R+1) int32,
+    kmax (1) int32 device, p_dense int, total int, slot_map (R, p_dense) int64 | None).  ONE host read (total and the longest ray)."""
+    return neus_pack_end(neus_pack_begin(zvals_dense, counts), n_sample_cfg, want_map)
 
 
 def neus_slots_fwd(packed, offsets, p_dense, dflt):
@@ -1189,6 +1243,22 @@ def neus_slots_bwd(d_dense, offsets, p_dense, n_points):
 
 def _vec3(v):
     return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def eikonal_packed(normal, pk, n_rays, weight, d_normal=None, loss=None):
+    """EikonalLoss on the dense `normal_pts` of a packed NeuS batch without building it: -> (loss (1,) device, d_normal (S,3)); a given
+    d_normal is ADDED to"""
+    _req(normal, d_normal, loss)
+    normal = _f32(normal)
+    S = normal.shape[0]
+    acc = d_normal is not None
+    if d_normal is None:
+        d_normal = torch.empty_like(normal)
+    if loss is None:
+        loss = torch.empty(1, dtype=torch.float32, device=normal.device)
+    N.check(N.lib().arcn_eikonal_packed(N.ptr(normal), N.ptr(pk['ray_id']), N.ptr(pk['offsets']), S, int(n_rays), int(pk['p_dense']), float(weight),
+                                       int(acc), N.ptr(d_normal), N.ptr(loss), N.stream()), 'eikonal_packed')
+    return loss, d_normal
 
 
 def neus_render_fwd(sdf, radiance, normal, pk, rays_d, s_dev, cos_anneal, bkg_color, depth_far, dflt_rgb, dflt_nrm):

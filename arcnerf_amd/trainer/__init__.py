@@ -4,10 +4,11 @@
 checkpoint rotation and evaluation are the caller's (out of scope)."""
 from .dynamic_bs import DynamicBsMeter
 from .ema import EMA
+from .fused_neus_step import FusedNeusNgpStep
 from .fused_step import FusedNgpStep
 from .graph import GraphedTrainStep
-from .loss import AllLoss, HuberLoss, ImgLoss, build_loss
+from .loss import AllLoss, EikonalLoss, HuberLoss, ImgLoss, build_loss
 from .pipeline import Pipeline, TrainBatches, get_model_feed_in
 from .step import step_optimize, train_epoch
 
-__all__ = ['AllLoss', 'DynamicBsMeter', 'EMA', 'FusedNgpStep', 'GraphedTrainStep', 'HuberLoss', 'ImgLoss', 'build_loss', 'Pipeline', 'TrainBatches', 'get_model_feed_in', 'step_optimize', 'train_epoch']
+__all__ = ['AllLoss', 'DynamicBsMeter', 'EMA', 'EikonalLoss', 'FusedNeusNgpStep', 'FusedNgpStep', 'GraphedTrainStep', 'HuberLoss', 'ImgLoss', 'build_loss', 'Pipeline', 'TrainBatches', 'get_model_feed_in', 'step_optimize', 'train_epoch']

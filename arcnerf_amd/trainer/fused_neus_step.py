@@ -1,0 +1,330 @@
+"""The drop-in training step of BASELINE config 4 - NeuS on the hash grid in a pruned volume + the MultiVol background
+(configs/neus_ngp_multivol.yaml, the model block of the reference's capture_qqtiger_neusngp_multivol.yaml) - as a hand-ordered chain of
+the HIP kernels, without the autograd engine between them.
+
+`build_model(configs/neus_ngp_multivol.yaml)` + `FusedAdam(...).flatten()` + the yaml's losses (ImgLoss Huber on `rgb`, EikonalLoss on
+`normal_pts`) describe a fixed computation; the module path spells it as ~200 launches per step (a third of them torch fills, adds, copies
+and concatenations between the kernels, 25 % of the kernel time) issued through autograd, and the step is HOST bound: 2.9 ms for 1.75 ms
+of hand-written kernels on the critical path.  This class runs the same kernels in the same order on the same tensors - the forward
+chain, the loss gradients, then every node's backward by hand - writes the parameter gradients straight into the flattened optimiser's
+buffers and calls the optimiser: the model, its state_dict, `model.optimize` and inference through the module stay what they are.
+
+    stepper = FusedNeusNgpStep(model, loss_factory, optimizer)           # raises if the combination is not the config-4 recipe
+    output, loss = stepper(feed_in, epoch, next_feed_in=batch_of_the_next_step)   # in place of trainer.step_optimize
+
+What the chain is (reference: neus_model.py:63-104, sdf_model.py:42-101, base_network.py:30-44, multivol_bkg_model.py:74-148,
+full_model.py:278-330):
+  foreground   march (K2 + K3) -> section layout -> hash encode -> sdf net 32 -> 64 (softplus 100) -> 1 + 16 WITH the Jacobian row of its first
+               output (ops.autograd.SdfMlpJacFn's arithmetic) -> normals = (d enc / d x)^T J -> radiance net [p | SH(v) | n | f] 38 -> 64 -> 64 -> 3 ->
+               the NeuS render kernel (slope, cos annealing, sdf_to_alpha, weights, sums, defaults) with the last transmittance
+  background   cascade march (K11) -> compaction -> hash encode (side 24) -> density net 32 -> 64 (ReLU) -> 1 + 16 (TruncExp density) -> radiance net
+               [f | SH(v)] 32 -> 64 -> 64 -> 3 -> packed compositor
+  blend        rgb = rgb_fg + T_last rgb_bkg, depth likewise (`rgb` blending)
+  loss         ImgLoss (Huber | MSE, plain mean) on rgb + EikonalLoss (MSE, plain mean) on the dense normal_pts - the latter evaluated on the
+               PACKED normals with the dense layout's weights (arcn_eikonal_packed): the (rays, P, 3) tensor is never built
+  backward     every node in reverse, second-order pieces included: the normals' gradient reaches the table through arcn_hashgrid_bwd_bwd and
+               the sdf net's weights through the gradient of J.
+The samplers of the NEXT batch run on a second stream meanwhile (FullModel.prefetch_samples).
+`output` holds rgb / depth / mask / normal and params like the module's; `normal_pts` is not materialised (the loss it exists for is inside).
+"""
+import torch
+
+from ..models.base_modules.encoding.hashgrid_encoder import HashGridEmbedder
+from ..models.multivol_bkg_model import MultiVol
+from ..models.neus_model import Neus
+from ..ops import functional as F
+from ..optim import FusedAdam
+from .loss import AllLoss, EikonalLoss, HuberLoss, ImgLoss
+
+
+def _sdf_net_form(geo):
+    """(embedder, first layer, last layer) when the geometry net is the one GeoNet._jacobian_path handles, else None"""
+    import torch.nn as nn
+    from ..models.base_modules.geo_rad_model.linear_network_module import DenseLayer, GeoNet
+    from ..models.base_modules.linear import Linear
+    if not isinstance(geo, GeoNet) or geo.D != 1 or geo.skips or geo.W_feat <= 0 or geo.out_act is not None:
+        return None
+    emb, l0, l1 = geo.embed_fn, geo.layers[0], geo.layers[1]
+    if type(emb) is not HashGridEmbedder or emb.include_input:
+        return None
+    if type(l0) is not DenseLayer or type(l0.activation) is not nn.Softplus or l0.activation.threshold != 20 or type(l1) is not Linear:
+        return None
+    if l0.bias is not None or l1.bias is not None or hasattr(l0, 'weight_g') or hasattr(l1, 'weight_g'):
+        return None
+    return emb, l0, l1
+
+
+def _density_net_form(geo):
+    """(embedder, first layer, last layer) when the geometry net is hash grid -> one ReLU layer -> linear [sigma | feat] with a TruncExp
+    density, without biases (the background nets of configs/neus_ngp_multivol.yaml), else None"""
+    import torch.nn as nn
+    from ..models.base_modules.geo_rad_model.linear_network_module import DenseLayer, GeoNet
+    from ..models.base_modules.linear import Linear
+    if not isinstance(geo, GeoNet) or geo.D != 1 or geo.skips or geo.W_feat <= 0 or type(geo.out_act).__name__ != 'TruncExp':
+        return None
+    emb, l0, l1 = geo.embed_fn, geo.layers[0], geo.layers[1]
+    if type(emb) is not HashGridEmbedder or emb.include_input:
+        return None
+    if type(l0) is not DenseLayer or type(l0.activation) is not nn.ReLU or type(l1) is not Linear:
+        return None
+    if l0.bias is not None or l1.bias is not None or hasattr(l0, 'weight_g') or hasattr(l1, 'weight_g'):
+        return None
+    return emb, l0, l1
+
+
+def _flat_view(tensors):
+    """the tensors as ONE flat tensor when they sit back to back in memory (consecutive parameters of a flattened optimiser whose sizes
+    are multiples of four floats), else None"""
+    t0 = tensors[0]
+    ptr = t0.data_ptr()
+    for t in tensors:
+        if t.data_ptr() != ptr or not t.is_contiguous():
+            return None
+        ptr += 4 * t.numel()
+    n = sum(t.numel() for t in tensors)
+    try:
+        return t0.as_strided((n,), (1,), t0.storage_offset())
+    except RuntimeError:
+        return None
+
+
+class FusedNeusNgpStep:
+    @staticmethod
+    def why_not(model, loss_factory, optimizer):
+        from ..models.base_modules.encoding.sh_encoder import SHEmbedder
+        from ..models.base_modules.geo_rad_model.linear_network_module import RadianceNet
+        fg, bkg = model.fg_model, model.bkg_model
+        if not (isinstance(fg, Neus) and fg.packed_path_eligible()):
+            return 'the foreground is not the packed NeuS (occupancy-marched volume, no importance sampling)'
+        if _sdf_net_form(fg.geo_net) is None:
+            return 'the sdf net is not hash grid -> one softplus layer -> linear, without biases'
+        r = fg.radiance_net
+        if not (isinstance(r, RadianceNet) and r._fused_desc is not None and r.mode == 'pvnf' and isinstance(r.embed_fn_view, SHEmbedder)
+                and not r.embed_fn_view.include_input and r.embed_fn_pts.get_output_dim() == 3):
+            return 'the radiance net is not the bias-free pvnf stack of widths <= 64 on [p | SH(v) | n | f]'
+        if not (isinstance(bkg, MultiVol) and bkg.use_packed_path and model.bkg_blend == 'rgb' and not model.fg_only):
+            return 'the background is not a MultiVol blended by rgb'
+        rb = bkg.radiance_net
+        if not (_density_net_form(bkg.geo_net) is not None and isinstance(rb, RadianceNet) and rb._fused_desc is not None and rb.mode == 'fv'
+                and isinstance(rb.embed_fn_view, SHEmbedder) and not rb.embed_fn_view.include_input):
+            return 'the background nets are not hash grid -> ReLU layer -> [TruncExp density | features] + the bias-free fv radiance stack of widths <= 64'
+        if float(bkg.get_ray_cfgs('noise_std') or 0.0) > 0 or float(fg.get_ray_cfgs('noise_std') or 0.0) > 0:
+            return 'density noise is on'
+        if not (isinstance(optimizer, FusedAdam) and optimizer._flat is not None):
+            return 'the optimiser is not a flattened FusedAdam'
+        if any(p.grad is None for p in model.parameters() if p.requires_grad):
+            return 'a parameter has no gradient buffer (FusedAdam.flatten() gives every parameter a view of the flat one)'
+        if not isinstance(loss_factory, AllLoss) or sorted(type(f).__name__ for f in loss_factory.funcs) != ['EikonalLoss', 'ImgLoss']:
+            return 'the loss is not ImgLoss + EikonalLoss'
+        il = next(f for f in loss_factory.funcs if isinstance(f, ImgLoss))
+        el = next(f for f in loss_factory.funcs if isinstance(f, EikonalLoss))
+        if not (list(il.keys) == ['rgb'] and il.do_mean and not il.use_mask and il.internal_weights is None
+                and (isinstance(il.loss, HuberLoss) or type(il.loss).__name__ == 'MSELoss')):
+            return 'the ImgLoss is not the plain Huber / MSE mean on rgb'
+        if not (el.key == 'normal_pts' and el.do_mean and not el.use_mask and type(el.loss).__name__ == 'MSELoss'):
+            return 'the EikonalLoss is not the plain MSE mean on normal_pts'
+        return None
+
+    def __init__(self, model, loss_factory, optimizer, ema=None, total_epoch=300000, prefetch=True):
+        reason = self.why_not(model, loss_factory, optimizer)
+        if reason is not None:
+            raise RuntimeError('FusedNeusNgpStep: ' + reason)
+        self.model, self.fg, self.bkg, self.opt, self.ema = model, model.fg_model, model.bkg_model, optimizer, ema
+        self.loss_factory, self.total_epoch, self.prefetch = loss_factory, total_epoch, bool(prefetch)
+        il = next(i for i, f in enumerate(loss_factory.funcs) if isinstance(f, ImgLoss))
+        el = 1 - il
+        self.img_loss, self.img_w, self.img_name = loss_factory.funcs[il], float(loss_factory.weights[il]), loss_factory.names[il]
+        self.eik_w, self.eik_name = float(loss_factory.weights[el]), loss_factory.names[el]
+        self.steps = 0
+        self._ws = {}
+        self.apply_optimizer = True      # (False: the gradients stay in the flat buffer - tests compare them with autograd's)
+
+    def _zeros(self, n, device):
+        """n read-only zero floats (kept: no fill kernel per step)"""
+        z = self._ws.get('zeros')
+        if z is None or z.numel() < n or z.device != device:
+            z = self._ws['zeros'] = torch.zeros(max(int(n * 1.25), 1 << 16), dtype=torch.float32, device=device)
+        return z[:n]
+
+    def _scatter_ws(self, key, desc, n, device):
+        """scratch of a binned table scatter, kept while it is large enough (the library knows the size for n samples)"""
+        w = self._ws.get(key)
+        need = int(F.N.lib().arcn_hashgrid_bwd_workspace_floats(F.C.addressof(desc), int(n)))
+        if w is None or w.numel() < need or w.device != device:
+            w = self._ws[key] = torch.empty(max(1, int(need * 1.25)), dtype=torch.float32, device=device)
+        return w
+
+    # ---- the iteration ----------------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, feed_in, epoch=0, next_feed_in=None):
+        model, fg, bkg = self.model, self.fg, self.bkg
+        rays_o = feed_in['rays_o'].reshape(-1, 3).contiguous().float()
+        rays_d = feed_in['rays_d'].reshape(-1, 3).contiguous().float()
+        img = feed_in['img'].reshape(-1, 3).contiguous().float()
+        bkg_color = feed_in['bkg_color'].reshape(-1, 3).contiguous().float() if feed_in.get('bkg_color') is not None else None
+        b, n = feed_in['rays_o'].shape[:2]
+        R, dev = rays_o.shape[0], rays_o.device
+        if not self.opt.zero_grad_on_step:
+            self.opt.zero_grad()
+        cur = torch.cuda.current_stream()
+        key = (rays_o.data_ptr(), rays_d.data_ptr(), R, rays_o._version, rays_d._version)
+
+        def take(mdl):
+            pre, mdl._presampled = getattr(mdl, '_presampled', None), None
+            if pre is not None and pre[0] == key:
+                h = pre[1]
+                cur.wait_event(h['event'])
+                for t_ in h.values():
+                    for u in (t_ if isinstance(t_, tuple) else (t_,)):
+                        if isinstance(u, torch.Tensor) and u.is_cuda:
+                            u.record_stream(cur)
+                return h
+            return mdl._sample_begin(rays_o, rays_d)
+
+        # ---- samples of both models (marched a step ago on the sampling stream, or now)
+        h_bkg = take(bkg) if getattr(bkg, '_presampled', None) is not None else None
+        h_fg = take(fg)
+        if h_bkg is None:
+            h_bkg = bkg._sample_begin(rays_o, rays_d)
+        pk = F.neus_pack_end(h_fg, float(fg.get_ray_cfgs('n_sample')))
+        t_b, ray_b, off_b, pd_b, total_b = F.pack_dense_samples_end(h_bkg)
+        S = pk['total']
+        # ---- foreground forward
+        emb, l0, l1 = _sdf_net_form(fg.geo_net)
+        rad = fg.radiance_net
+        table = emb.embeddings
+        beta = float(l0.activation.beta)
+        n_out = l1.weight.shape[0]
+        scale = fg.forward_scale()
+        s_dev = scale.detach().reshape(1).contiguous()
+        cos_anneal = fg.get_cos_anneal(epoch)
+        nv = torch.tensor(fg.render_cfgs['normal'], dtype=torch.float32)
+        dflt_nrm = (nv / (nv.norm() + 1e-8)).tolist()
+        dflt_rgb = fg.render_cfgs['bkg_color']
+        if S > 0:
+            fg.adjust_dynamicbs_factor(n_valid=pk['offsets'][R])
+            pts, dirs = F.packed_points(rays_o, rays_d, pk['t_mid'], pk['ray_id'])
+            enc = F.hashgrid_fwd(pts, table, emb.desc)
+            w1 = l0.weight
+            w2 = torch.nn.functional.pad(l1.weight, (0, 0, 0, (-n_out) % 4))
+            hid = F.gemm_nt(enc, w1, None, act='softplus', beta=beta)
+            out = F.gemm_nt(hid, w2, None)
+            sg = F.softplus_grad(hid, None, beta, from_y=True)
+            jac = F.gemm_nn(sg, (w1 * w2[0][:, None]).contiguous())
+            _, normal = F.hashgrid_bwd(pts, table, jac, emb.desc, want_dtable=False, want_dxyz=True)
+            sdf = out[:, 0].contiguous()
+            n_sh = rad.embed_fn_view.n_freqs ** 2
+            rad_in = F.radiance_inputs('pvnf', pts, dirs, normal, out[:, 1:n_out], rad.embed_fn_view.n_freqs)       # [p | SH(normalize(v)) | n | f], one pass
+            rad_w = _flat_view([layer.weight for layer in rad.layers])
+            rad_g = _flat_view([layer.weight.grad for layer in rad.layers]) if rad_w is not None else None
+            if rad_w is None:
+                rad_w = torch.cat([layer.weight.reshape(-1) for layer in rad.layers])
+            rgb_s, rad_acts = F.mlp_fwd(rad_in, rad_w, None, rad._fused_desc, save_acts=True)
+        else:
+            sdf = rays_o.new_zeros((1,))
+            rgb_s = normal = rays_o.new_zeros((1, 3))
+        rgb_f, depth_f, mask_f, nrm_f, t_last = F.neus_render_fwd(sdf, rgb_s, normal, pk, rays_d, s_dev, cos_anneal, bkg_color,
+                                                                 float(fg.render_cfgs['depth_far']), dflt_rgb, dflt_nrm)
+        # ---- background forward
+        emb_b, b0, b1 = _density_net_form(bkg.geo_net)
+        rb = bkg.radiance_net
+        tb = emb_b.embeddings
+        nb_out = b1.weight.shape[0]
+        if total_b > 0:
+            xyz_b, dirs_b = F.packed_points(rays_o, rays_d, t_b, ray_b)
+            enc_b = F.hashgrid_fwd(xyz_b, tb, emb_b.desc)
+            wb1 = torch.nn.functional.pad(b1.weight, (0, 0, 0, (-nb_out) % 4))
+            hid_b = F.gemm_nt(enc_b, b0.weight, None, act='relu')
+            out_b = F.gemm_nt(hid_b, wb1, None)
+            pre_b = out_b[:, 0].contiguous()
+            sigma_b = F.act_fwd(pre_b, 'truncexp')
+            rin_b = F.radiance_inputs('fv', None, dirs_b, None, out_b[:, 1:nb_out], rb.embed_fn_view.n_freqs)
+            rb_w = _flat_view([layer.weight for layer in rb.layers])
+            rb_g = _flat_view([layer.weight.grad for layer in rb.layers]) if rb_w is not None else None
+            if rb_w is None:
+                rb_w = torch.cat([layer.weight.reshape(-1) for layer in rb.layers])
+            rgb_sb, rb_acts = F.mlp_fwd(rin_b, rb_w, None, rb._fused_desc, save_acts=True)
+            comp = F.composite_packed_fwd(sigma_b, rgb_sb, t_b, off_b, p_dense_dev=pd_b, add_inf_z=bool(bkg.add_inf_z),
+                                          white_bkg=bool(bkg.get_ray_cfgs('white_bkg')))
+            rgb_b, depth_b = comp['rgb'], comp['depth']
+        else:
+            rgb_b = rays_o.new_ones((R, 3)) if bkg.get_ray_cfgs('white_bkg') else rays_o.new_zeros((R, 3))
+            depth_b = rays_o.new_zeros((R,))
+        # the samplers of the next batch, beside everything that follows
+        if self.prefetch and next_feed_in is not None:
+            model.prefetch_samples(next_feed_in)
+        # ---- blend + losses
+        rgb = rgb_f + t_last[:, None] * rgb_b
+        depth = depth_f + t_last * depth_b
+        il = self.img_loss
+        if isinstance(il.loss, HuberLoss):
+            loss_img, d_rgb = F.huber_loss_grad(rgb, img, float(il.loss.delta), self.img_w)
+            loss_img = loss_img[0]
+        else:
+            diff = rgb - img
+            loss_img = (diff * diff).mean() * self.img_w
+            d_rgb = diff * (2.0 * self.img_w / diff.numel())
+        d_tlast = (d_rgb * rgb_b).sum(-1)
+        d_rgb_b = d_rgb * t_last[:, None]
+        # ---- background backward
+        if total_b > 0:
+            d_sig_b, d_rad_b = F.composite_packed_bwd(sigma_b, rgb_sb, t_b, off_b, d_rgb_b.contiguous(), None, None, p_dense_dev=pd_b,
+                                                      add_inf_z=bool(bkg.add_inf_z), white_bkg=bool(bkg.get_ray_cfgs('white_bkg')))
+            dx_b, dw_b, _ = F.mlp_bwd(rin_b, rb_w, None, rb._fused_desc, rgb_sb, rb_acts, d_rad_b, want_dx=True, dweights=rb_g)     # (added into rb_g)
+            if rb_g is None:
+                k = 0
+                for layer in rb.layers:
+                    m_ = layer.weight.numel()
+                    layer.weight.grad.add_(dw_b[k:k + m_].view_as(layer.weight))
+                    k += m_
+            d_pre = F.act_bwd(pre_b, sigma_b, d_sig_b, 'truncexp')
+            g_out_b = torch.cat([d_pre[:, None], dx_b[:, :nb_out - 1], self._zeros(total_b * (wb1.shape[0] - nb_out), dev).view(total_b, -1)], dim=-1)
+            b1.weight.grad.add_(F.gemm_tn(g_out_b, hid_b)[:nb_out])
+            d_hid_b = F.gemm_nn(g_out_b, wb1)
+            F.gemm_tn(d_hid_b, enc_b, mask=hid_b, out=b0.weight.grad, accumulate=True)
+            d_enc_b = F.gemm_nn(d_hid_b, b0.weight, mask=hid_b)
+            F.hashgrid_bwd(xyz_b, tb, d_enc_b, emb_b.desc, dtable=tb.grad, workspace=self._scatter_ws('bkg', emb_b.desc, total_b, dev))
+        # ---- foreground backward
+        loss_eik = rays_o.new_zeros((1,))
+        if S > 0:
+            zr = self._zeros(4 * R, dev)       # (read-only zero upstream gradients)
+            d_sdf, d_rad, d_normal, d_s_ray = F.neus_render_bwd(sdf, rgb_s, normal, pk, rays_d, s_dev, cos_anneal, bkg_color, d_rgb.contiguous(),
+                                                                zr[:R], zr[:R], zr[R:4 * R].view(R, 3), d_tlast.contiguous())
+            dx_r, dw_r, _ = F.mlp_bwd(rad_in, rad_w, None, rad._fused_desc, rgb_s, rad_acts, d_rad, want_dx=True, dweights=rad_g)
+            if rad_g is None:     # (the radiance weights are separate nn.Linear tensors: not back to back, the kernel's flat gradient is split back)
+                k = 0
+                for layer in rad.layers:
+                    m_ = layer.weight.numel()
+                    layer.weight.grad.add_(dw_r[k:k + m_].view_as(layer.weight))
+                    k += m_
+            d_normal.add_(dx_r[:, 3 + n_sh:6 + n_sh])
+            loss_eik, _ = F.eikonal_packed(normal, pk, R, self.eik_w, d_normal=d_normal)       # value + gradient, added into d_normal
+            # the normals' gradient: to the Jacobian row they were built from (its table part joins the first-order scatter below)
+            d_jac, _, _ = F.hashgrid_bwd_bwd(pts, d_normal, table, jac, emb.desc, want_ddout=True, want_dtable=False, want_d2xyz=False)
+            # the sdf net, first output's Jacobian included (ops.autograd.SdfMlpJacFn.backward)
+            g_out = torch.cat([d_sdf[:, None], dx_r[:, 6 + n_sh:6 + n_sh + n_out - 1], self._zeros(S * (w2.shape[0] - n_out), dev).view(S, -1)], dim=-1)
+            w20 = w2[0]
+            dz = F.gemm_nn(g_out, w2)
+            dw2 = F.gemm_tn(g_out, hid)
+            u = F.gemm_nt(d_jac, w1, None)
+            dz, su = F.sdf_jac_dz(dz, u, sg, (beta * w20).contiguous())
+            dw2[0] += su.sum(0)
+            dw1 = F.gemm_tn(sg, d_jac) * w20[:, None]
+            d_enc = F.gemm_nn(dz, w1)
+            l0.weight.grad.add_(dw1)
+            F.gemm_tn(dz, enc, out=l0.weight.grad, accumulate=True)
+            l1.weight.grad.add_(dw2[:n_out])
+            # the table: through the encoding (d_enc) and through its input gradient (d_normal on J^T jac), ONE accumulation pass for both
+            F.hashgrid_bwd_first_second(pts, d_enc, d_normal, jac, emb.desc, table.grad, self._scatter_ws('fg', emb.desc, 3 * S, dev))
+            # scale = exp(inv_s * speed)
+            fg.inv_s.grad.add_((d_s_ray.sum() * scale.detach().reshape(()) * float(fg.speed_factor)).reshape(fg.inv_s.shape))
+        # ---- optimiser
+        if self.apply_optimizer:
+            self.opt.step()
+            if self.ema is not None:
+                self.ema.ema_step()
+        self.steps += 1
+        total = loss_img + loss_eik[0]
+        out = {'rgb': rgb.view(b, n, 3), 'depth': depth.view(b, n), 'mask': mask_f.view(b, n), 'normal': nrm_f.view(b, n, 3),
+               'params': {'scale': scale.detach().reshape(())}}
+        return out, {'sum': total, 'names': [self.img_name, self.eik_name], self.img_name: loss_img, self.eik_name: loss_eik[0]}

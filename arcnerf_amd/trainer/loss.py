@@ -1,4 +1,5 @@
-"""The image loss of the training step (arcnerf/loss/img_loss.py:11-100 ImgLoss + HuberLoss, arcnerf/loss/__init__.py:41-66 AllLoss):
+"""The losses of the training steps on the path (arcnerf/loss/img_loss.py:11-100 ImgLoss + HuberLoss, arcnerf/loss/geo_loss.py:12-70 EikonalLoss,
+arcnerf/loss/__init__.py:41-66 AllLoss):
 `loss['sum'] = weight * mean(loss_fn(output[key], data['img']))` summed over the configured keys.  Note the reference's Huber is
 0.5 / delta * d^2 inside the band and |d| - 0.5 delta outside - torch.nn.functional.huber_loss DIVIDED by delta."""
 import torch
@@ -62,10 +63,43 @@ class ImgLoss(nn.Module):
         return loss
 
 
+class EikonalLoss(nn.Module):
+    """arcnerf/loss/geo_loss.py:12-70: loss_type(|n|, 1) over `key` ('normal' (B, N, 3) or 'normal_pts' (B, N, P, 3)), mean (by mask if
+    `use_mask`)"""
+
+    def __init__(self, cfgs=None):
+        super().__init__()
+        self.key = get_value_from_cfgs_field(cfgs, 'key', 'normal')
+        t = get_value_from_cfgs_field(cfgs, 'loss_type', 'MSE')
+        if t == 'MSE':
+            self.loss = nn.MSELoss(reduction='none')
+        elif t == 'L1':
+            self.loss = nn.L1Loss(reduction='none')
+        else:
+            raise NotImplementedError('Loss type {} not support in geo loss...'.format(t))
+        self.use_mask = get_value_from_cfgs_field(cfgs, 'use_mask', False)
+        self.do_mean = get_value_from_cfgs_field(cfgs, 'do_mean', True)
+
+    def forward(self, data, output):
+        out = output[self.key]
+        norm = torch.norm(out, dim=-1)
+        loss = self.loss(norm, torch.ones_like(norm))
+        if self.do_mean:
+            if self.use_mask:
+                mask = data['mask'].to(out.device)
+                if loss.dim() == 3:
+                    mask = torch.repeat_interleave(mask.unsqueeze(-1), loss.shape[-1], -1)
+                dims = tuple(range(1, loss.dim()))
+                loss = ((loss * mask).sum(dim=dims) / (mask.sum(dim=dims) + 1e-5)).mean()       # mean_tensor_by_mask (torch_utils.py:223-247)
+            else:
+                loss = loss.mean()
+        return loss
+
+
 class AllLoss(object):
     """build_loss(cfgs): every entry of cfgs.loss, multiplied by its `weight`; returns {'sum', 'names', <name>: value}"""
 
-    REGISTRY = {'ImgLoss': ImgLoss}
+    REGISTRY = {'ImgLoss': ImgLoss, 'EikonalLoss': EikonalLoss}
 
     def __init__(self, loss_cfgs):
         self.funcs, self.names, self.weights = [], [], []

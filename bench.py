@@ -274,7 +274,17 @@ def bench_module(args, name, emit=True):
         lc.loss.ImgLoss = type('C', (), dict(keys=['rgb_coarse'], loss_type='Huber', delta=0.1, weight=3000.0))()
         ngp_loss = T_.build_loss(lc)
 
+    neus_loss = None
+    if name == 'neus_ngp_multivol':
+        # the loss block of the reference's capture_qqtiger_neusngp_multivol.yaml:262-269: ImgLoss Huber 0.1 x 5 on rgb + EikonalLoss x 0.1 on normal_pts
+        from arcnerf_amd import trainer as T_
+        from arcnerf_amd.utils.cfgs_utils import dict_to_obj
+        neus_loss = T_.build_loss(dict_to_obj({'loss': {'ImgLoss': {'loss_type': 'Huber', 'delta': 0.1, 'weight': 5.0},
+                                                        'EikonalLoss': {'key': 'normal_pts', 'weight': 0.1}}}))
+
     def loss_of(out, inp):
+        if neus_loss is not None:
+            return neus_loss(inp, out)['sum']
         if name == 'ngp_module':      # ImgLoss(Huber, delta 0.1, weight 3000) of the reference's NGP recipe (arcnerf/loss/img_loss.py:60-100, nerf_lego_nerf_ngp.yaml:192-197)
             return ngp_loss(inp, out)['sum']
         if name in ('nerf', 'hdrnerf'):
@@ -317,13 +327,26 @@ def bench_module(args, name, emit=True):
         fused = FusedNgpStep(m, ngp_loss, opt, None, max_rays=n_rays, ahead=int(os.environ.get('ARCN_MODULE_AHEAD', '2')), world_size=world,
                              grad_sync=os.environ.get('ARCN_GRAD_SYNC', 'flat'))
 
+    prefetch = name == 'neus_ngp_multivol' and os.environ.get('ARCN_PREFETCH_SAMPLES', '1') != '0'
+
+    fused_neus = None
+    if name == 'neus_ngp_multivol' and mode == 'fused' and not use_dist:
+        # config 4 as a hand-ordered kernel chain (trainer.FusedNeusNgpStep): no autograd engine between the kernels, the next batch's samplers
+        # on a second stream; ARCN_MODULE_STEP=eager: the module path
+        from arcnerf_amd.trainer import FusedNeusNgpStep
+        fused_neus = FusedNeusNgpStep(m, neus_loss, opt)
+
     def step(i):
         inp = pool[i % len(pool)]
+        if fused_neus is not None:
+            return fused_neus(inp, 20000 + i, next_feed_in=pool[(i + 1) % len(pool)] if prefetch else None)[1]['sum']
         if fused is not None:
             return fused(inp, 20000 + i, next_feed_in=[pool[(i + k) % len(pool)] for k in range(1, fused.depth + 1)])[1]['sum']
         if graphed is not None:
             return graphed({k: v for k, v in inp.items()}, 20000 + i)[1]['sum']
         out = m({k: v for k, v in inp.items()}, inference_only=False, cur_epoch=20000 + i)
+        if prefetch:      # the samplers of the NEXT batch on the sampling stream, beside this step's backward (FullModel.prefetch_samples)
+            m.prefetch_samples(pool[(i + 1) % len(pool)])
         loss = loss_of(out, inp)
         loss.backward()
         if use_dist:   # DDP semantics (average of the ranks' gradients): SUM all-reduce of the flat buffer, 1 / world in the optimiser
@@ -424,9 +447,10 @@ def bench_module(args, name, emit=True):
                'chunk_pts': int(m.get_chunk_pts()), 'occupancy': args.occupancy, 'bkg_occupancy': bkg_occ,
                'graph_host_ms_per_replay': ({k: round(v / max(1, graphed.replays) * 1e3, 4) for k, v in graphed.host_s.items()} if graphed is not None else None),
                'launch': ('one HIP-graph replay per step (trainer.GraphedTrainStep, {} replays in this run)'.format(graphed.replays) if graphed is not None
+                          else ('trainer.FusedNeusNgpStep: the step as a hand-ordered kernel chain (no autograd engine), the next batch\'s samplers on a second stream ({} steps)'.format(fused_neus.steps) if fused_neus is not None
                           else ('trainer.FusedNgpStep: the module API on NgpPipeline.train_step over the flattened optimiser\'s buffers, next {} batches marched '
                                 'early ({} steps in this run, {} eager warm-up steps before)'.format(fused.depth, fused.steps, 2) if fused is not None
-                                else 'every kernel of the module path issued eagerly'))},
+                                else 'every kernel of the module path issued eagerly')))},
            'rccl': dist_report(dist, world, LAUNCH, flat_grads.numel() * 4, 1, per_rank, rccl_extra),
            'roofline': roofline, 'cpu_baseline': cpu}
     if emit:

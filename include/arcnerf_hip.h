@@ -257,6 +257,12 @@ int arcn_hashgrid_fwd(const float *xyz, const float *table, const arcn_hashgrid_
 int arcn_hashgrid_bwd_bwd(const float *xyz, const float *gdx, const float *table, const float *dout,
                           const arcn_hashgrid_desc *desc_host, float *ddout, float *dtable, float *d2xyz, float *workspace,
                           int64_t workspace_floats, int64_t n, const int32_t *n_ptr, void *stream);
+/* The table's FIRST- and SECOND-order gradients of one batch in one consumer pass: dtable += d/d table of <dout, enc(xyz)> (what
+ * arcn_hashgrid_bwd adds) + d/d table of <gdx, J(xyz; table)^T dout_dx> (what arcn_hashgrid_bwd_bwd adds) - both producers fill the same
+ * bins, one accumulation pass over the table instead of two.  workspace: at least arcn_hashgrid_bwd_workspace_floats(desc, 3 * n). */
+int arcn_hashgrid_bwd_first_second(const float *xyz, const float *dout, const float *gdx, const float *dout_dx,
+                                   const arcn_hashgrid_desc *desc_host, float *dtable, float *workspace, int64_t workspace_floats, int64_t n,
+                                   void *stream);
 /* Same result as arcn_hashgrid_fwd (bit-identical), scheduled so that each of the chip's 8 XCDs gathers only its own
  * 2 of 16 levels (a level's table slice then stays in that XCD's L2); n_feat 1 or 2.
  * level_major = 0: out (n, L*F) row-major; level_major = 1: out[(l * n_cap + s) * F + f]. */
@@ -327,6 +333,12 @@ int arcn_freq_bwd(const float *x, const float *dout, int D, int n_freqs, int inc
                   void *stream);
 /* SHEmbedder torch branch (encoding/sh_encoder.py:101-185): out (n, degree^2 + 3*include_input). */
 int arcn_sh_fwd(const float *dirs, int degree, int include_input, float *out, int64_t n, void *stream);
+/* fuse_radiance_inputs (arcnerf/models/base_modules/geo_rad_model/encoder_mlp_network.py:93-118) for an identity position block and an SH
+ * view block, one pass: out (n, W) = the blocks of mode_host (HOST string over p, v, n, f) in that order - p: pts (3); v: SH of
+ * normalize(dirs) = dirs / (|dirs| + 1e-8) (degree^2 columns); n: normals (3); f: n_feat features per row at stride ld_feat (a column slice of
+ * the geometry net's padded output).  W = the sum of the block widths. */
+int arcn_radiance_inputs(const char *mode_host, const float *pts, const float *dirs, const float *normals, const float *feat, int64_t ld_feat,
+                         int n_feat, int sh_degree, float *out, int64_t n, void *stream);
 
 /* geo -> radiance glue of Base3dModel._forward_pts_dir (arcnerf/models/base_3d_model.py:233-254):
  * sigma (n) = sigma_act(geo_out[:,0]) (EncoderMLPGeoNet.handle_output, encoder_mlp_network.py:38-50);
@@ -563,6 +575,12 @@ int arcn_neus_sections(const float *zvals_dense, const int32_t *counts, const in
                        void *stream);
 /* the dense (n_rays, p_dense, 3) view of a packed (total, 3) per-point quantity the reference returns (`normal_pts`): slot j of a ray =
  * its point min(j, n - 1), rays without points = dflt_host[0..2]; bwd = its transpose (the aliased tail summed by the ray's wave). */
+/* EikonalLoss (arcnerf/loss/geo_loss.py:12-70, MSE on |n| over `normal_pts`, plain mean) evaluated on the PACKED normals with the dense
+ * layout's weights: loss[0] = weight * mean over the (n_rays, p_dense) slots of (|n| - 1)^2 where slot j of a ray = its point
+ * min(j, n - 1) and rays without points hold a unit default normal; d_normal (n_pts,3) = its gradient (accumulate: added).  The dense
+ * (n_rays, p_dense, 3) tensor the reference's loss reads is never built.  loss (DEVICE, optional) is cleared by the call. */
+int arcn_eikonal_packed(const float *normal, const int32_t *ray_id, const int32_t *offsets, int64_t n_pts, int64_t n_rays, int p_dense,
+                        float weight, int accumulate, float *d_normal, float *loss, void *stream);
 int arcn_neus_slots_fwd(const float *packed, const int32_t *offsets, int64_t n_rays, int p_dense, const float *dflt_host, float *dense,
                         void *stream);
 int arcn_neus_slots_bwd(const float *d_dense, const int32_t *offsets, int64_t n_rays, int p_dense, float *d_packed, void *stream);

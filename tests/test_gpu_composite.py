@@ -260,3 +260,80 @@ def test_neus_with_nerfpp_background_matches_reference_composite(gpu):
         ['fg_model.geo_net.layers.0.weight_v', 'fg_model.geo_net.layers.5.weight_v']
     n_full, n_sum = _check_all_grads(m, g)
     assert n_full >= 35 and n_sum >= 20
+
+
+def test_fused_neus_ngp_step_equals_the_module_path(gpu):
+    """trainer.FusedNeusNgpStep (config 4 as a hand-ordered kernel chain: no autograd engine, the Eikonal loss on the packed normals, the next
+    batch's samplers on a second stream) against the module path on the same batch from the same state: the same losses, the same flat
+    gradient - second-order pieces included - and, stepping, the same parameters after three iterations with prefetched samplers."""
+    from arcnerf_amd import trainer as T
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.ops.multivol_func import multivol_rng
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    from arcnerf_amd.optim import FusedAdam
+    from arcnerf_amd.pipeline import synthetic_bitfield, synthetic_cascade_bits, synthetic_rays
+    from arcnerf_amd.utils.cfgs_utils import dict_to_obj, load_configs
+    n_rays = 1024
+    loss_cfg = dict_to_obj({'loss': {'ImgLoss': {'loss_type': 'Huber', 'delta': 0.1, 'weight': 5.0}, 'EikonalLoss': {'key': 'normal_pts', 'weight': 0.1}}})
+    pool = []
+    g = torch.Generator().manual_seed(3)
+    for i in range(3):
+        o, d = synthetic_rays(n_rays, seed=20 + i, device=gpu, radius=2.2)
+        pool.append({'rays_o': o.view(1, -1, 3), 'rays_d': d.view(1, -1, 3), 'rays_r': torch.zeros(1, n_rays, 1, device=gpu),
+                     'bkg_color': torch.rand(1, n_rays, 3, generator=g).to(gpu), 'img': torch.rand(1, n_rays, 3, generator=g).to(gpu)})
+
+    def make():
+        torch.manual_seed(0)
+        m = build_model(load_configs(os.path.join(ROOT, 'configs', 'neus_ngp_multivol.yaml'), [])).to(gpu)
+        m.fg_model.obj_bound.volume.update_bitfield(torch.from_numpy(synthetic_bitfield(128, 0.05, seed=0)).to(gpu), ops='overwrite')
+        m.bkg_model.density_bitfield.copy_(torch.from_numpy(synthetic_cascade_bits(128, m.bkg_model.n_levels, 0.05, seed=5)).to(gpu))
+        with torch.no_grad():      # away from the all-zero features of a fresh table: every gradient path carries signal
+            m.fg_model.geo_net.embed_fn.embeddings.mul_(200.0)
+            m.bkg_model.geo_net.embed_fn.embeddings.mul_(2000.0)
+        opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=5e-4, eps=1e-15).flatten()
+        sampler_rng(reset=True)
+        multivol_rng(reset=True)
+        m.train()
+        return m, opt, T.build_loss(loss_cfg)
+
+    # (a) one batch, gradients only
+    m, opt, lf = make()
+    out = m(dict(pool[0]), inference_only=False, cur_epoch=20000)
+    la = lf(pool[0], out)
+    opt.zero_grad()
+    la['sum'].backward()
+    g_a = opt.flat_grads().clone()
+    m, opt, lf = make()
+    st = T.FusedNeusNgpStep(m, lf, opt)
+    st.apply_optimizer = False
+    opt.zero_grad()
+    out_b, lb = st(pool[0], 20000)
+    g_b = opt.flat_grads().clone()
+    for k in ('ImgLoss', 'EikonalLoss', 'sum'):
+        assert abs(float(la[k]) - float(lb[k])) <= 2e-5 * abs(float(la[k])) + 1e-7, (k, float(la[k]), float(lb[k]))
+    for k in ('rgb', 'depth', 'mask', 'normal'):
+        assert torch.allclose(out[k], out_b[k], rtol=1e-5, atol=1e-5), k
+    scale = float(g_a.abs().max())
+    assert scale > 0 and float((g_a - g_b).abs().max()) <= 2e-5 * scale, float((g_a - g_b).abs().max() / scale)
+    # every parameter tensor received its gradient (table x 2, sdf net, radiance nets, inv_s)
+    for name, p in m.named_parameters():
+        if p.requires_grad:
+            assert float(p.grad.abs().max()) > 0, name
+    # (b) three iterations with the optimiser, the next batch's samplers prefetched: the module path's parameters
+    runs = {}
+    for mode in ('eager', 'fused'):
+        m, opt, lf = make()
+        st = T.FusedNeusNgpStep(m, lf, opt) if mode == 'fused' else None
+        losses = []
+        for i in range(3):
+            if st is not None:
+                _, l = st(pool[i], 20000 + i, next_feed_in=pool[i + 1] if i < 2 else None)
+            else:
+                _, l = T.step_optimize(m, dict(pool[i]), lf, opt, None, 20000 + i)
+            losses.append(float(l['sum']))
+        torch.cuda.synchronize()
+        runs[mode] = (losses, opt.flat_params().clone(), sampler_rng().state, multivol_rng().state)
+    (la_, pa, ra, rma), (lb_, pb, rb_, rmb) = runs['eager'], runs['fused']
+    assert ra == rb_ and rma == rmb
+    assert max(abs(x - y) / abs(x) for x, y in zip(la_, lb_)) < 1e-4, (la_, lb_)
+    assert float(((pa - pb).abs() > 1e-3 * float(pa.abs().max())).float().mean()) < 1e-3
