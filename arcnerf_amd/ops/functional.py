@@ -180,7 +180,7 @@ def fetch_train_batch(ids, n_img, H, W, window=None, rgba=None, img=None, mask=N
 
 
 def sparse_volume_sampling(rays_o, rays_d, near, far, n_pts, dt, aabb23, n_grid, bitfield, near_distance, rng_state,
-                           rng_inc, want_counts=False):
+                           rng_inc, want_counts=False, dense=True):
     _req(rays_o, rays_d, near, far, aabb23, bitfield)
     o, d = _f32(rays_o), _f32(rays_d)
     nr, fr = _f32(near).view(-1), _f32(far).view(-1)
@@ -212,7 +212,7 @@ def tensor_reduce_max(full, idx, n_group):
 # `_bitfield_func` family (K5-K10): Morton-order density grid + packed bitfield
 # ------------------------------------------------------------------------------------------------
 def sparse_volume_sampling_bit(rays_o, rays_d, near, far, n_pts, dt, aabb23, n_grid, bitfield, near_distance, rng_state,
-                               rng_inc, want_counts=False):
+                               rng_inc, want_counts=False, dense=True):
     _req(rays_o, rays_d, near, far, aabb23, bitfield)
     o, d = _f32(rays_o), _f32(rays_d)
     nr, fr = _f32(near).view(-1), _f32(far).view(-1)

@@ -116,7 +116,9 @@ def test_neus_on_hashgrid_with_multivol_background_matches_reference_composite(g
 
     def rec_k11(*a, **k):
         r = real_k11(*a, **k)
-        seen['k11'].append((r[0].clone(), r[1].clone() if r[1] is not None else None, r[2].clone() if len(r) > 2 and r[2] is not None else None))
+        # (the packed path asks for dense=False: only the first counts[r] entries of a row are written, the mask is not filled in)
+        msk = r[1].clone() if (r[1] is not None and k.get('dense', True)) else None
+        seen['k11'].append((r[0].clone(), msk, r[2].clone() if len(r) > 2 and r[2] is not None else None))
         return r
     VB.sparse_volume_sampling, Fn.sparse_sampling_in_multivol_bitfield = rec_k3, rec_k11
     sampler_rng(reset=True)
