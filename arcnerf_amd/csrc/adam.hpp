@@ -48,12 +48,6 @@ struct AdamArgs {
     int zero_grad, ema_in_param;
 };
 
-// the eleven step-dependent floats of AdamArgs in DEVICE memory (arcn_adam_ema_step_replay): a launch recorded in a HIP graph takes the
-// learning rate and the bias / de-bias corrections of the replay's step, not of the capture's
-__device__ __forceinline__ AdamArgs adam_args_from(const float *__restrict__ h, int zero_grad, int ema_in_param) {
-    return AdamArgs{h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], zero_grad, ema_in_param};
-}
-
 // workgroup `bid` of `nblocks` over one contiguous run of n parameters
 __device__ __forceinline__ void adam_ema_run(float *__restrict__ param, float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v,
                                              float *__restrict__ ema, int64_t n, int bid, int nblocks, const AdamArgs &a) {

@@ -475,9 +475,6 @@ hashgrid_fwd_bal_kernel(const float *__restrict__ xyz, const float *__restrict__
         }
         float *o = LM ? out + ((int64_t)l * n_cap + s) * F : out + (s * g.L + l) * F;
         if (F == 2) {
-#ifdef ARCN_EXP_GATHER_NOSTORE   // experiment: the gather without its feature store (values kept live)
-            if (acc[0] + acc[1 % F] == 123.456f)
-#endif
             *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1 % F]);
         } else {
 #pragma unroll
@@ -547,13 +544,7 @@ template <int F>
 __device__ __forceinline__ void emit_record(uint4 *__restrict__ lrecs, float *__restrict__ dtable, const LevelParams &lp, int bin,
                                             uint32_t pos, uint32_t cap, int shift, const uint4 &rec, uint32_t *ovf_flag = nullptr) {
     if (pos < cap) {
-#if defined(ARCN_EXP_BIN_SEQSTORE)      // experiment: what the producer would take if its record stores were coalesced (garbage results)
-        lrecs[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = rec;
-#elif defined(ARCN_EXP_BIN_NOSTORE)     // ... and with no record stores at all
-        if (rec.x == 0x12345678u && rec.y == 0x9abcdef0u) lrecs[0] = rec;
-#else
         lrecs[(int64_t)bin * cap + pos] = rec;
-#endif
     } else {
         if (ovf_flag) *ovf_flag = 1u;   // deterministic mode: these float atomics are not order-independent - say so (arcn_hashgrid_bwd_status)
         const uint32_t base_row = (uint32_t)bin << shift;
@@ -635,15 +626,9 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
             np_[0] = xyz[3 * s]; np_[1] = xyz[3 * s + 1]; np_[2] = xyz[3 * s + 2];
             // level-major gradients (dout_lm_stride > 0): the lanes of a wave read consecutive 8-byte words
             const float *gp = dout_lm_stride ? dout + ((int64_t)l * dout_lm_stride + s) * F : dout + (s * g.L + l) * F;
-#ifdef ARCN_EXP_BIN_NOLOAD   // experiment: what the producer would gain if the gradient came out of LDS / registers instead of HBM
-            ng0 = 0.25f + 1e-3f * (float)(s & 15);
-            ng1 = -0.5f;
-            (void)gp;
-#else
             // (non-temporal: this is the gradient's only reader - step -1.9 % in three alternations, profiles/r4_ab_nontemporal.txt)
             ng0 = __builtin_nontemporal_load(gp);
             ng1 = F > 1 ? __builtin_nontemporal_load(gp + (F > 1 ? 1 : 0)) : 0.f;
-#endif
         }
     };
     fetch((int64_t)blockIdx.x * kBinThreads + t);

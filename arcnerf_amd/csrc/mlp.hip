@@ -476,16 +476,7 @@ mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
     const int64_t n_tiles = ceil_div_dev(cnt, (int64_t)SPW * 4);
     auto load_x = [&](f4 (&dst)[4][NT], int64_t s0) {
         if (XMODE == 2) load_tiles_cat<NT>(dst, x, cat, s0, cnt, g, j, true);
-#ifdef ARCN_EXP_GEO_NOLOAD   // experiment: the geometry net's forward without its feature loads
-        else if (XMODE == 1) {
-#pragma unroll
-            for (int t_ = 0; t_ < 4; ++t_)
-#pragma unroll
-                for (int n_ = 0; n_ < NT; ++n_) dst[t_][n_] = f4{1e-3f * (float)(s0 & 7), 2e-3f * (float)j, -1e-3f * (float)g, 0.5f};
-        }
-#else
         else if (XMODE == 1) load_tiles_lm2<T0, NT>(dst, x, x_stride, s0, cnt, g, j);
-#endif
         else load_tiles_fast<T0, NT>(dst, x, P.dims[0], s0, cnt, g, j);
     };
     for (int l = 0; l < NL; ++l) stage_fragments<false>(lds + P.lds_off[l], weights + P.w_off[l], P.dims[l + 1], P.dims[l]);
@@ -787,16 +778,6 @@ mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
                 }
             } else {
                 back(d, 0, T0, T1);
-#ifdef ARCN_EXP_GEO_NOSTORE   // experiment: the geometry net's backward without its d_feat store (one column kept so the chain stays live)
-                if (XMODE == 1) {
-                    float keep = 0.f;   // every value stays live, nothing goes to memory
-#pragma unroll
-                    for (int t_ = 0; t_ < T0; ++t_)
-#pragma unroll
-                        for (int n_ = 0; n_ < NT; ++n_) keep += d[t_][n_].x + d[t_][n_].y + d[t_][n_].z + d[t_][n_].w;
-                    if (keep == 123.456f) dx[0] = keep;
-                } else
-#endif
                 if (XMODE == 1) store_tiles_lm2<T0, NT>(d, dx, x_stride, s0, cnt, g, j);  // dx in the layout of x
                 else store_tiles_fast<T0, NT>(d, dx, P.dims[0], s0, cnt, g, j);
             }

@@ -24,12 +24,6 @@ __global__ void __launch_bounds__(256) adam_ema_runs_kernel(float *__restrict__ 
     adam_ema_run(param + lo, grad + lo, m + lo, v + lo, ema ? ema + lo : nullptr, r.n[k], bid, r.b[k], a);
 }
 
-__global__ void __launch_bounds__(256) adam_ema_replay_kernel(float *__restrict__ param, float *__restrict__ grad, float *__restrict__ m,
-                                                              float *__restrict__ v, float *__restrict__ ema, int64_t n,
-                                                              const float *__restrict__ hyper, int zero_grad, int ema_in_param) {
-    adam_ema_run(param, grad, m, v, ema, n, blockIdx.x, gridDim.x, adam_args_from(hyper, zero_grad, ema_in_param));
-}
-
 __global__ void __launch_bounds__(256) copy_words_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
@@ -39,10 +33,9 @@ __global__ void __launch_bounds__(256) copy_words_kernel(const uint32_t *__restr
 using namespace arcn;
 
 /* dst[0..n_words) = src[0..n_words) as a KERNEL (32-bit words; src / dst: device memory or pinned host memory, which the device addresses
- * directly).  For the small per-step copies around a recorded training step - the step's scalars host -> device, the batch into the
- * graph's static inputs, the sample total device -> pinned host: issued as hipMemcpyAsync between graph launches they made every step
- * take 4.9 ms instead of 0.75 once the host ran a few dozen operations ahead (the runtime's copy path needs the host's attention;
- * tools/exp_graph_module.py), as kernels they cost 2 us each. */
+ * directly).  For the small per-step copies of an asynchronous training step (the sample total device -> pinned host, trainer.FusedNgpStep):
+ * issued as hipMemcpyAsync between kernel launches they made a step take 4.9 ms instead of 0.75 once the host ran a few dozen operations
+ * ahead (the runtime's copy path needs the host's attention; measured in round 4), as kernels they cost 2 us each. */
 ARCN_EXPORT int arcn_copy_words(const void *src, void *dst, int64_t n_words, void *stream) {
     if (n_words <= 0) return ARCN_OK;
     if (!src || !dst || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3)) return einval("copy_words: missing or misaligned argument");
@@ -51,36 +44,6 @@ ARCN_EXPORT int arcn_copy_words(const void *src, void *dst, int64_t n_words, voi
     hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), static_cast<const uint32_t *>(src),
                        static_cast<uint32_t *>(dst), n_words);
     return check_launch("copy_words");
-}
-
-/* The eleven floats arcn_adam_ema_step_replay reads from device memory, for step / ema_step (1-based): {lr, beta1, beta2, eps,
- * weight_decay, ema_decay, grad_scale, 1 - beta1^step, sqrt(1 - beta2^step), 1 - d^(ema_step - 1), 1 / (1 - d^ema_step)} - the same
- * double-precision corrections arcn_adam_ema_step computes.  hyper_host: 11 floats (e.g. pinned memory the caller then copies over). */
-ARCN_EXPORT int arcn_adam_hyper(float lr, float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale, int step,
-                                int ema_step, int with_ema, float *hyper_host) {
-    if (!hyper_host || step < 1 || (with_ema && ema_step < 1)) return einval("adam_hyper: missing/invalid argument");
-    const AdamHyper h = make_adam_hyper(lr, beta1, beta2, eps, weight_decay, ema_decay, grad_scale, step, ema_step, with_ema != 0);
-    const float v[11] = {h.lr, h.b1, h.b2, h.eps, h.wd, h.ema_decay, h.gscale, h.bc1, h.bc2_sqrt, h.deb_old, h.deb_new};
-    for (int i = 0; i < 11; ++i) hyper_host[i] = v[i];
-    return ARCN_OK;
-}
-
-/* arcn_adam_ema_step for a launch that is RECORDED in a HIP graph and replayed: the step-dependent scalars come from device memory
- * (hyper_dev: the 11 floats of arcn_adam_hyper, rewritten by the caller before each replay) instead of by-value arguments frozen at
- * capture.  Same arithmetic, same bits.  ema: NULL (plain Adam), a shadow buffer, or == param. */
-ARCN_EXPORT int arcn_adam_ema_step_replay(float *param, float *grad, float *exp_avg, float *exp_avg_sq, float *ema, int64_t n,
-                                          const float *hyper_dev, int zero_grad, void *stream) {
-    if (n <= 0) return ARCN_OK;
-    if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper_dev) return einval("adam_ema_step_replay: missing argument");
-    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
-         reinterpret_cast<uintptr_t>(exp_avg_sq) | reinterpret_cast<uintptr_t>(ema)) & 15)
-        return einval("adam_ema_step_replay: buffers must be 16-byte aligned");
-    int64_t blocks = ceil_div<int64_t>((n >> 2) + 1, 256);
-    if (blocks > 2048) blocks = 2048;
-    const int ema_in_param = ema == param;
-    hipLaunchKernelGGL(adam_ema_replay_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq,
-                       ema_in_param ? static_cast<float *>(nullptr) : ema, n, hyper_dev, zero_grad, ema_in_param);
-    return check_launch("adam_ema_step_replay");
 }
 
 ARCN_EXPORT int arcn_adam_ema_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, float *ema, int64_t n,

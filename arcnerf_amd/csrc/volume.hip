@@ -617,8 +617,6 @@ struct MarchPacked {
 struct MarchCull {
     const uint8_t *coarse;
     int32_t cn;              // blocks per axis (n_grid / 4); 0: no culling
-    const uint64_t *rng_dev; // {state, inc} of the sampler's pcg32 in DEVICE memory (arcn_march_count_replay): a launch recorded in a
-                             // HIP graph reads the generator of the replay, not of the capture; nullptr: the by-value state
     int32_t persist_waves;   // > 0: the launch has this many wavefronts in all and wave w marches the rays w, w + persist_waves, ... (a bounded
                              // number of resident marcher waves beside the training step's kernels); 0: one wavefront per ray
 };
@@ -649,7 +647,6 @@ march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ r
     uint32_t j = 0;
     if (in_range) {
     Pcg32 rng = rng0;
-    if (cull.rng_dev) { rng.state = cull.rng_dev[0]; rng.inc = cull.rng_dev[1]; }
     rng.advance((int64_t)(uint32_t)((uint32_t)i * 8u));
     const Aabb b = load_aabb(aabb);
     float o[3] = {rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2]};
@@ -1263,7 +1260,7 @@ ARCN_EXPORT int arcn_march_count_culled(const float *rays_o, const float *rays_d
                                         void *stream) {
     if (!coarse || n_grid < 16 || (n_grid & 3)) return einval("march_count_culled: coarse grid missing or n_grid not a multiple of 4 (>= 16)");
     return march_count_impl(rays_o, rays_d, aabb, n_grid, bitfield, bitfield_is_packed, n_pts, dt, near_distance, aabb_torch_semantics, rng_state,
-                            rng_inc, scratch_t, counts, near_out, far_out, n_rays, stream, MarchCull{coarse, n_grid / 4, nullptr});
+                            rng_inc, scratch_t, counts, near_out, far_out, n_rays, stream, MarchCull{coarse, n_grid / 4});
 }
 
 ARCN_EXPORT int arcn_march_count_waves(const float *rays_o, const float *rays_d, const float *aabb, int n_grid,
@@ -1273,21 +1270,7 @@ ARCN_EXPORT int arcn_march_count_waves(const float *rays_o, const float *rays_d,
                                        void *stream) {
     if (coarse && (n_grid < 16 || (n_grid & 3))) return einval("march_count_waves: culling needs n_grid a multiple of 4 (>= 16)");
     return march_count_impl(rays_o, rays_d, aabb, n_grid, bitfield, bitfield_is_packed, n_pts, dt, near_distance, aabb_torch_semantics, rng_state,
-                            rng_inc, scratch_t, counts, near_out, far_out, n_rays, stream, MarchCull{coarse, coarse ? n_grid / 4 : 0, nullptr, n_waves > 0 ? n_waves : 0});
-}
-
-/* arcn_march_count[_culled] for a launch that is RECORDED (HIP graph capture) and replayed: every by-value argument is frozen at capture,
- * so the sampler's pcg32 {state, inc} is read from device memory (rng_dev, two 64-bit words the caller rewrites before each replay -
- * state advanced 2^32 per launch like the by-value form).  coarse may be NULL (no culling). */
-ARCN_EXPORT int arcn_march_count_replay(const float *rays_o, const float *rays_d, const float *aabb, int n_grid,
-                                        const uint8_t *bitfield, int bitfield_is_packed, const uint8_t *coarse, int n_pts, float dt,
-                                        float near_distance, int aabb_torch_semantics, const uint64_t *rng_dev,
-                                        float *scratch_t, int32_t *counts, float *near_out, float *far_out, int64_t n_rays,
-                                        void *stream) {
-    if (!rng_dev) return einval("march_count_replay: rng_dev missing");
-    if (coarse && (n_grid < 16 || (n_grid & 3))) return einval("march_count_replay: culling needs n_grid a multiple of 4 (>= 16)");
-    return march_count_impl(rays_o, rays_d, aabb, n_grid, bitfield, bitfield_is_packed, n_pts, dt, near_distance, aabb_torch_semantics, 0, 1,
-                            scratch_t, counts, near_out, far_out, n_rays, stream, MarchCull{coarse, coarse ? n_grid / 4 : 0, rng_dev});
+                            rng_inc, scratch_t, counts, near_out, far_out, n_rays, stream, MarchCull{coarse, coarse ? n_grid / 4 : 0, n_waves > 0 ? n_waves : 0});
 }
 
 /* bounds + occupancy marching + compaction in ONE launch (round 2): what arcn_march_count + arcn_exclusive_scan_i32 + arcn_march_write

@@ -173,15 +173,6 @@ class NeRF(FgModel):
             reports a step that overflowed all the same (samples per ray more than 1.5x the previous step's) with a warning.  The
             FIRST training step has no history and takes the exact path (one host read): with the all-ones bitfield of a fresh model
             it needs R * n_sample samples, four times the default capacity at 4096 rays, and nothing is dropped."""
-        if torch.cuda.is_current_stream_capturing():
-            # being recorded in a HIP graph (trainer.GraphedTrainStep): no host decision can be part of a replay - the pipeline is the one
-            # the eager warm-up steps sized, the generator state comes from device memory, and the recorder checks the capacity after
-            # every replay (the same one-step-late read as below, outside the graph)
-            pipe = self._pipe
-            if pipe is None or pipe.replay is None:
-                raise RuntimeError('graph capture of the packed path needs an eager warm-up step and NgpPipeline.enable_replay() first')
-            pipe.sample(rays_o, rays_d)
-            return pipe
         self._check_deferred_overflow(rays_o.device)
         pipe = self._packed_pipeline(rays_o.device)
         R = rays_o.shape[0]
@@ -254,7 +245,7 @@ class NeRF(FgModel):
         g, r = self.coarse_geo_net, self.coarse_radiance_net
         rgb, depth, mask, counts = _PackedRenderFn.apply(rays_o, rays_d, bkg, g.embed_fn.embeddings, g.layers.params,
                                                         r.layers.params, pipe, train, noise_std)
-        if not inference_only and not torch.cuda.is_current_stream_capturing():   # (a recorded step: the recorder adds the measurement after each replay)
+        if not inference_only:
             self.adjust_dynamicbs_factor(n_valid=pipe.n_dev[0])
         rgb, depth = self._packed_defaults(rgb, depth, counts, bkg)
         out = {'rgb': rgb, 'depth': depth, 'mask': mask}

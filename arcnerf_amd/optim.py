@@ -28,7 +28,6 @@ class FusedAdam(torch.optim.Optimizer):
         self.ema_in_param = bool(ema_in_param and ema_decay is not None)
         self.grad_scale = 1.0     # multiplies every gradient as it is read: 1 / world after a SUM all-reduce (DDP's average, no extra pass)
         self.ema_n_step = None    # EMA.n_step when it differs from Adam's step count (set_ema_n_step: a resumed job); None = Adam's
-        self._replay = None       # per flat group: utils.replay.ReplayScalars (the 11 step-dependent floats) once enable_replay() ran
         self._flat = None         # per param group: dict(params, grads, exp_avg, exp_avg_sq, ema, slots) once flatten() ran
 
     # ---- one flat buffer per parameter group --------------------------------------------------------------------------------------
@@ -97,36 +96,6 @@ class FusedAdam(torch.optim.Optimizer):
         self.ema_n_step += 1
         return self.ema_n_step
 
-    # ---- HIP-graph replay ------------------------------------------------------------------------------------------------------------
-    def enable_replay(self):
-        """Let `step()` be RECORDED in a HIP graph (trainer.GraphedTrainStep): a recorded launch freezes its by-value arguments, so the
-        step-dependent scalars (bias corrections, de-bias factors of the EMA, the learning rate - a scheduler may move it) are read from
-        device memory that `prepare_step()` rewrites before every replay.  Needs flatten()."""
-        if self._flat is None:
-            raise RuntimeError('FusedAdam.enable_replay() needs flatten() first')
-        if self._replay is None:
-            from .utils.replay import ReplayScalars
-            self._replay = [ReplayScalars(fb['params'].device, 44) for fb in self._flat]
-        return self
-
-    def prepare_step(self):
-        """Call before the capture and before every replay: advances the step counters on the host (state_dict stays right) and
-        queues this step's scalars for the recorded kernels."""
-        import ctypes as C
-        import numpy as np
-        from . import _native as N
-        ema_step = self._next_ema_step()
-        for group, fb, rs in zip(self.param_groups, self._flat, self._replay):
-            fb['step'] += 1
-            for p in fb['list']:
-                self.state[p]['step'] = fb['step']
-            h = (C.c_float * 11)()
-            with_ema = self.ema_decay is not None
-            N.check(N.lib().arcn_adam_hyper(float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']),
-                                            float(group['weight_decay']), float(self.ema_decay if with_ema else 0.0), float(self.grad_scale),
-                                            int(fb['step']), int(fb['step'] if ema_step is None else ema_step), int(with_ema), h), 'adam_hyper')
-            rs.push(np.frombuffer(h, dtype=np.float32).copy())
-
     def flat_grads(self, group=0):
         """The flat gradient buffer of a parameter group (after flatten()): the tensor to all-reduce."""
         if self._flat is None:
@@ -152,15 +121,6 @@ class FusedAdam(torch.optim.Optimizer):
     def _step_flat(self):
         if len(self.param_groups) != len(self._flat):
             raise RuntimeError('FusedAdam (flat): a parameter group was added after flatten(); call flatten() again')
-        if self._replay is not None and torch.cuda.is_current_stream_capturing():
-            # being recorded: counters and scalars are prepare_step()'s business, the kernel reads them from device memory
-            from . import _native as N
-            for fb, rs in zip(self._flat, self._replay):
-                ema = fb['params'] if self.ema_in_param else fb['ema']
-                N.check(N.lib().arcn_adam_ema_step_replay(N.ptr(fb['params']), N.ptr(fb['grads']), N.ptr(fb['exp_avg']), N.ptr(fb['exp_avg_sq']),
-                                                          N.ptr(ema) if self.ema_decay is not None else None, fb['params'].numel(), N.ptr(rs.dev),
-                                                          int(self.zero_grad_on_step), N.stream()), 'adam_ema_step_replay')
-            return
         ema_step = self._next_ema_step()
         for group, fb in zip(self.param_groups, self._flat):
             for p, (o, n) in zip(fb['list'], fb['slots']):

@@ -363,30 +363,12 @@ class NgpPipeline:
         NgpPipeline._built += 1
         self.generation_id = NgpPipeline._built      # (unlike id(): never handed out twice in a process)
         self.occupancy_sync = None      # callable(opafield, new_bitfield) run on the refresh stream before a refreshed bitfield is applied
-        # HIP-graph replay (trainer.GraphedTrainStep): the sampler reads its pcg32 state from device memory (rewritten before every
-        # replay) and a refreshed occupancy is written INTO the packed bits / culling grid the recorded marcher points at
-        self.replay = None              # utils.replay.ReplayScalars (16 bytes: pcg32 state, inc) once enable_replay() ran
-        self.persistent_occupancy = False
         self.set_bitfield(self.bitfield)
 
     def set_ema_n_step(self, n_step):
         """EMA.set_n_step (arcnerf/trainer/ema.py:25-27): the trainer calls it with progress.start_epoch (arcnerf_trainer.py:70), so the
         running average of a resumed job is de-biased with the epoch count while Adam's own step count comes from its state"""
         self.ema_n_step = int(n_step)
-
-    def enable_replay(self):
-        """Prepare for being recorded in a HIP graph: see `replay` / `persistent_occupancy` above.  (Not for the asynchronous schedule of
-        train_step(next_rays=...): a marcher of a later batch may be reading the bits while a refresh rewrites them in place.)"""
-        if self.replay is None:
-            from .utils.replay import ReplayScalars
-            self.replay = ReplayScalars(self.field.device, 16)
-        self.persistent_occupancy = True
-
-    def prepare_replay(self):
-        """before each replay (and before the capture): hand the sampler's generator state of THIS launch to the device and advance
-        the host generator like an eager launch would have (ops/src/volume_func/volume_func_kernel.cu:283-289: 2^32 per launch)"""
-        self.replay.push(np.array([self.rng.state, self.rng.inc], dtype=np.uint64))
-        self.rng.advance()
 
     def sample_count(self):
         """Valid samples of the batch marched LAST (with prefetch: the batch marched ahead on the sampling stream) as a python int.
@@ -440,10 +422,7 @@ class NgpPipeline:
             assert ng3 % 8 == 0
             w = (2 ** torch.arange(8, device=self.field.device, dtype=torch.int32))
             bits = (self.bitfield.view(-1, 8).to(torch.int32) * w).sum(-1).to(torch.uint8).contiguous()
-            if self.persistent_occupancy and self._bits is not None and self._bits.shape == bits.shape and self._bits.device == bits.device:
-                self._bits.copy_(bits)      # a recorded marcher keeps pointing at this buffer
-            else:
-                self._bits = bits
+            self._bits = bits
             self._share_bits_with_aux()
 
     def set_occupancy_bits(self, bits, mode):
@@ -475,14 +454,10 @@ class NgpPipeline:
                 os.environ.get('ARCN_MARCH_CULL', '1') == '0'):
             return
         cells = (ng // 4) ** 3
-        prev = getattr(self, '_coarse_keep', None)
-        if self.persistent_occupancy and prev is not None and prev.numel() == cells and prev.device == self._bits.device:
-            coarse = prev
-        else:
-            coarse = torch.empty(cells, dtype=torch.uint8, device=self._bits.device)
+        coarse = torch.empty(cells, dtype=torch.uint8, device=self._bits.device)
         tmp = torch.empty(cells, dtype=torch.uint8, device=self._bits.device)
         N.check(N.lib().arcn_march_cull_grid(N.ptr(self._bits), int(self.packed_bits), ng, N.ptr(coarse), N.ptr(tmp), N.stream()), 'march_cull_grid')
-        self._coarse = self._coarse_keep = coarse
+        self._coarse = coarse
 
     def _occ(self):
         return self._bits if self.packed_bits else self._bitfield
@@ -555,37 +530,26 @@ class NgpPipeline:
         assert R <= self.max_rays
         L = N.lib()
         st = N.stream()
-        if self.replay is not None and torch.cuda.is_current_stream_capturing():
-            # being recorded: the generator state comes from device memory (prepare_replay), nothing on the host moves
-            coarse = getattr(self, '_coarse', None)
-            N.check(L.arcn_march_count_replay(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
-                                              int(self.packed_bits), N.ptr(coarse), cfg.n_sample, cfg.dt, cfg.near_distance,
-                                              int(self.torch_aabb), N.ptr(self.replay.dev), N.ptr(b['scratch_t']),
-                                              N.ptr(b['counts']), N.ptr(b['near']), N.ptr(b['far']), R, st), 'march_count_replay')
-            N.check(L.arcn_exclusive_scan_i32(N.ptr(b['counts']), N.ptr(b['offsets']), R, self.cap, N.ptr(b['p_dense']), st), 'scan')
-            N.check(L.arcn_march_write(N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['offsets']), cfg.n_sample, N.ptr(b['t']),
-                                       N.ptr(b['ray_id']), R, self.cap, st), 'march_write')
+        if waves > 0 and R > waves:     # a launch with time to spare beside other kernels: persistent wavefronts (same outputs)
+            N.check(L.arcn_march_count_waves(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
+                                             int(self.packed_bits), N.ptr(getattr(self, '_coarse', None)), cfg.n_sample, cfg.dt, cfg.near_distance,
+                                             int(self.torch_aabb), self.rng.state, self.rng.inc, N.ptr(b['scratch_t']),
+                                             N.ptr(b['counts']), N.ptr(b['near']), N.ptr(b['far']), R, int(waves), st), 'march_count_waves')
+        elif getattr(self, '_coarse', None) is not None:     # rays that pass no occupied block leave before they march (same outputs)
+            N.check(L.arcn_march_count_culled(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
+                                              int(self.packed_bits), N.ptr(self._coarse), cfg.n_sample, cfg.dt, cfg.near_distance,
+                                              int(self.torch_aabb), self.rng.state, self.rng.inc, N.ptr(b['scratch_t']),
+                                              N.ptr(b['counts']), N.ptr(b['near']), N.ptr(b['far']), R, st), 'march_count_culled')
         else:
-            if waves > 0 and R > waves:     # a launch with time to spare beside other kernels: persistent wavefronts (same outputs)
-                N.check(L.arcn_march_count_waves(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
-                                                 int(self.packed_bits), N.ptr(getattr(self, '_coarse', None)), cfg.n_sample, cfg.dt, cfg.near_distance,
-                                                 int(self.torch_aabb), self.rng.state, self.rng.inc, N.ptr(b['scratch_t']),
-                                                 N.ptr(b['counts']), N.ptr(b['near']), N.ptr(b['far']), R, int(waves), st), 'march_count_waves')
-            elif getattr(self, '_coarse', None) is not None:     # rays that pass no occupied block leave before they march (same outputs)
-                N.check(L.arcn_march_count_culled(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
-                                                  int(self.packed_bits), N.ptr(self._coarse), cfg.n_sample, cfg.dt, cfg.near_distance,
-                                                  int(self.torch_aabb), self.rng.state, self.rng.inc, N.ptr(b['scratch_t']),
-                                                  N.ptr(b['counts']), N.ptr(b['near']), N.ptr(b['far']), R, st), 'march_count_culled')
-            else:
-                N.check(L.arcn_march_count(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
-                                           int(self.packed_bits), cfg.n_sample, cfg.dt, cfg.near_distance, int(self.torch_aabb),
-                                           self.rng.state, self.rng.inc, N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['near']),
-                                           N.ptr(b['far']), R, st), 'march_count')
-            self.rng.advance()
-            # offsets (clamped to the capacity) and the dense width the reference would have used, max(2, max count)
-            N.check(L.arcn_exclusive_scan_i32(N.ptr(b['counts']), N.ptr(b['offsets']), R, self.cap, N.ptr(b['p_dense']), st), 'scan')
-            N.check(L.arcn_march_write(N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['offsets']), cfg.n_sample, N.ptr(b['t']),
-                                       N.ptr(b['ray_id']), R, self.cap, st), 'march_write')
+            N.check(L.arcn_march_count(N.ptr(rays_o), N.ptr(rays_d), N.ptr(self.aabb23), cfg.n_grid, N.ptr(self._occ()),
+                                       int(self.packed_bits), cfg.n_sample, cfg.dt, cfg.near_distance, int(self.torch_aabb),
+                                       self.rng.state, self.rng.inc, N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['near']),
+                                       N.ptr(b['far']), R, st), 'march_count')
+        self.rng.advance()
+        # offsets (clamped to the capacity) and the dense width the reference would have used, max(2, max count)
+        N.check(L.arcn_exclusive_scan_i32(N.ptr(b['counts']), N.ptr(b['offsets']), R, self.cap, N.ptr(b['p_dense']), st), 'scan')
+        N.check(L.arcn_march_write(N.ptr(b['scratch_t']), N.ptr(b['counts']), N.ptr(b['offsets']), cfg.n_sample, N.ptr(b['t']),
+                                   N.ptr(b['ray_id']), R, self.cap, st), 'march_write')
         N.check(L.arcn_packed_points(N.ptr(rays_o), N.ptr(rays_d), N.ptr(b['t']), N.ptr(b['ray_id']), N.ptr(b['xyz']),
                                      N.ptr(b['dirs']), self.cap, b['offsets'][R:R + 1].data_ptr(), st), 'packed_points')
         if self.ray_sh:

@@ -26,7 +26,7 @@ from ..models.nerf_model import NeRF
 from ..ops.volume_func import sampler_rng
 from ..optim import FusedAdam
 from ..pipeline import NgpField, NgpPipeline
-from ..utils.replay import copy_words
+from ..utils.device_copy import copy_words
 from .loss import AllLoss, HuberLoss, ImgLoss
 from .step import step_optimize
 

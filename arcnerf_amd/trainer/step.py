@@ -23,7 +23,7 @@ def train_epoch(model, get_batch, loss_factory, optimizer, ema, pipeline, epoch,
     """train_epoch's order: model.optimize(epoch) (the bound's periodic refresh), the dynamic batch size, then the step.
     get_batch(n_rays) -> feed_in dict; a callable with `wants_epoch = True` (trainer.TrainBatches: the Pipeline's crop / shuffle / batch
     fetch) is called as get_batch(n_rays, epoch).
-    stepper: a trainer.FusedNgpStep / GraphedTrainStep in place of step_optimize.  A FusedNgpStep is also handed the batches of the next
+    stepper: a trainer.FusedNgpStep (or any callable (feed_in, epoch) -> (output, loss)) in place of step_optimize.  A FusedNgpStep is also handed the batches of the next
     epochs (two by default) as long as neither model.optimize nor the batch-size rule can act at those epochs (then their "optimize,
     batch size, batch" commutes with this step): their marching runs on the second stream meanwhile."""
     draw = (lambda n, e: get_batch(n, e)) if getattr(get_batch, 'wants_epoch', False) else (lambda n, e: get_batch(n))

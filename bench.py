@@ -314,13 +314,9 @@ def bench_module(args, name, emit=True):
         Fn.pack_dense_samples_end = counting_pack
 
     # the drop-in NGP step (ARCN_MODULE_STEP): `fused` (default) = trainer.FusedNgpStep, the module API on the pipeline's fused step (loss in the
-    # compositor, optimiser in the scatter, the next batch marched a step early); `graph` = trainer.GraphedTrainStep, the module path's own
-    # launches as one HIP-graph replay; `eager` = every kernel of the module path issued eagerly
-    graphed = fused = None
-    mode = os.environ.get('ARCN_MODULE_STEP', 'fused' if os.environ.get('ARCN_MODULE_GRAPH', '1') != '0' else 'eager')
-    if name == 'ngp_module' and not use_dist and mode == 'graph':
-        from arcnerf_amd.trainer import GraphedTrainStep
-        graphed = GraphedTrainStep(m, lambda inp, out: {'sum': loss_of(out, inp)}, opt)
+    # compositor, optimiser in the scatter, the next batch marched a step early); `eager` = every kernel of the module path issued eagerly
+    fused = None
+    mode = os.environ.get('ARCN_MODULE_STEP', 'fused')
     if name == 'ngp_module' and mode == 'fused' and (not use_dist or world > 1):
         # (N > 1: every rank its rays through the same stepper, the gradient summed in level groups overlapped with the scatter)
         from arcnerf_amd.trainer import FusedNgpStep
@@ -342,8 +338,6 @@ def bench_module(args, name, emit=True):
             return fused_neus(inp, 20000 + i, next_feed_in=pool[(i + 1) % len(pool)] if prefetch else None)[1]['sum']
         if fused is not None:
             return fused(inp, 20000 + i, next_feed_in=[pool[(i + k) % len(pool)] for k in range(1, fused.depth + 1)])[1]['sum']
-        if graphed is not None:
-            return graphed({k: v for k, v in inp.items()}, 20000 + i)[1]['sum']
         out = m({k: v for k, v in inp.items()}, inference_only=False, cur_epoch=20000 + i)
         if prefetch:      # the samplers of the NEXT batch on the sampling stream, beside this step's backward (FullModel.prefetch_samples)
             m.prefetch_samples(pool[(i + 1) % len(pool)])
@@ -445,12 +439,10 @@ def bench_module(args, name, emit=True):
                name, spec['desc'], n_rays, evals_per_step, spec['yaml']), 'rays_per_step_per_gpu': n_rays,
                'samples_per_step_per_gpu': evals_per_step, 'n_params': flat_numel, 'parallelism': 'ray-sharded dp{}'.format(world),
                'chunk_pts': int(m.get_chunk_pts()), 'occupancy': args.occupancy, 'bkg_occupancy': bkg_occ,
-               'graph_host_ms_per_replay': ({k: round(v / max(1, graphed.replays) * 1e3, 4) for k, v in graphed.host_s.items()} if graphed is not None else None),
-               'launch': ('one HIP-graph replay per step (trainer.GraphedTrainStep, {} replays in this run)'.format(graphed.replays) if graphed is not None
-                          else ('trainer.FusedNeusNgpStep: the step as a hand-ordered kernel chain (no autograd engine), the next batch\'s samplers on a second stream ({} steps)'.format(fused_neus.steps) if fused_neus is not None
+               'launch': ('trainer.FusedNeusNgpStep: the step as a hand-ordered kernel chain (no autograd engine), the next batch\'s samplers on a second stream ({} steps)'.format(fused_neus.steps) if fused_neus is not None
                           else ('trainer.FusedNgpStep: the module API on NgpPipeline.train_step over the flattened optimiser\'s buffers, next {} batches marched '
                                 'early ({} steps in this run, {} eager warm-up steps before)'.format(fused.depth, fused.steps, 2) if fused is not None
-                                else 'every kernel of the module path issued eagerly')))},
+                                else 'every kernel of the module path issued eagerly'))},
            'rccl': dist_report(dist, world, LAUNCH, flat_grads.numel() * 4, 1, per_rank, rccl_extra),
            'roofline': roofline, 'cpu_baseline': cpu}
     if emit:
@@ -785,9 +777,11 @@ def main():
         for name in (os.environ.get('ARCN_OTHER_CONFIGS', 'ngp_module,nerf,neus,neus_ngp_multivol,hdrnerf').split(',')):
             a2 = copy.copy(args)
             a2.steps, a2.warmup, a2.rays, a2.chunk_pts, a2.no_cpu_baseline = 8, 3, 0, 0, True
+            if name == 'ngp_module':    # the headline's model through the drop-in API: the driver's own K / W (+ the stepper's two eager steps)
+                a2.steps, a2.warmup = min(args.steps, 2000), min(args.warmup, 500) + 2
             try:
                 r = bench_module(a2, name, emit=False)
-                others[name] = {'ms_per_step': r['ms_per_step'], 'samples_per_s': r['value'], 'steps': 8, 'warmup': 3,
+                others[name] = {'ms_per_step': r['ms_per_step'], 'samples_per_s': r['value'], 'steps': a2.steps, 'warmup': a2.warmup,
                                 'rays_per_step': r['config']['rays_per_step_per_gpu'], 'samples_per_step': r['config']['samples_per_step_per_gpu'],
                                 'roofline_frac': (r['roofline'] or {}).get('frac_of_split_peak', (r['roofline'] or {}).get('frac')), 'roofline_peak': 'dense bf16 MFMA / 6 terms (417 TFLOP/s of f32-accurate work)' if 'frac_of_split_peak' in (r['roofline'] or {}) else 'HBM 8 TB/s',
                                 'roofline_frac_of_f32_mfma_peak': (r['roofline'] or {}).get('frac') if 'frac_of_split_peak' in (r['roofline'] or {}) else None, 'roofline_bound': (r['roofline'] or {}).get('bound'), 'bkg_samples_per_step': (r['roofline'] or {}).get('bkg_samples_per_step'),

@@ -202,13 +202,6 @@ int arcn_march_count_waves(const float *rays_o, const float *rays_d, const float
                             int bitfield_is_packed, const uint8_t *coarse, int n_pts, float dt, float near_distance,
                             int aabb_torch_semantics, uint64_t rng_state, uint64_t rng_inc, float *scratch_t, int32_t *counts,
                             float *near_out, float *far_out, int64_t n_rays, int n_waves, void *stream);
-/* arcn_march_count / _culled for a launch RECORDED in a HIP graph and replayed: the sampler's pcg32 {state, inc} is read from device
- * memory (rng_dev: two 64-bit words the caller rewrites before each replay, the state advanced 2^32 per launch like the by-value
- * form, ops/src/volume_func/volume_func_kernel.cu:283-289) instead of by-value arguments frozen at capture.  coarse may be NULL. */
-int arcn_march_count_replay(const float *rays_o, const float *rays_d, const float *aabb, int n_grid, const uint8_t *bitfield,
-                            int bitfield_is_packed, const uint8_t *coarse, int n_pts, float dt, float near_distance,
-                            int aabb_torch_semantics, const uint64_t *rng_dev, float *scratch_t, int32_t *counts,
-                            float *near_out, float *far_out, int64_t n_rays, void *stream);
 /* The three passes above in ONE launch (no dense scratch): a wave keeps its ray's samples in LDS, the workgroups' counts go through a
  * chained scan (decoupled look-back, ray blocks handed out by ticket), the waves copy their samples to their final offsets.
  * Same outputs as the three-pass form, bit for bit (offsets clamped to `capacity`, p_dense = largest per-ray count).
@@ -650,18 +643,8 @@ int arcn_refresh_cells_points(const uint8_t *bitfield_bool, int n_grid, const ui
 int arcn_adam_ema_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, float *ema, int64_t n, float lr,
                        float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale,
                        int step, int ema_step, int zero_grad, void *stream);
-/* HIP-graph replay forms.  A launch recorded during stream capture freezes its by-value arguments; the two step-dependent inputs of a
- * training step - the optimiser's bias corrections (+ learning rate) and the sampler's generator state - are therefore read from
- * DEVICE memory that the caller rewrites before each replay (one small host-to-device copy per step).
- *   arcn_adam_hyper: the 11 floats {lr, beta1, beta2, eps, weight_decay, ema_decay, grad_scale, 1 - beta1^step, sqrt(1 - beta2^step),
- *     1 - d^(ema_step - 1), 1 / (1 - d^ema_step)} for a step, written to HOST memory (the corrections in double like torch);
- *   arcn_adam_ema_step_replay: arcn_adam_ema_step with those floats at hyper_dev - same arithmetic, same bits. */
-int arcn_adam_hyper(float lr, float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale, int step,
-                    int ema_step, int with_ema, float *hyper_host);
-int arcn_adam_ema_step_replay(float *param, float *grad, float *exp_avg, float *exp_avg_sq, float *ema, int64_t n,
-                              const float *hyper_dev, int zero_grad, void *stream);
-/* dst = src (n_words 32-bit words) as a kernel; src / dst: device memory or pinned host memory.  The small per-step copies around a
- * recorded step (scalars host -> device, the batch into the graph's static inputs, the sample total -> pinned host) - see optim.hip. */
+/* dst = src (n_words 32-bit words) as a kernel; src / dst: device memory or pinned host memory.  The small per-step copies of an
+ * asynchronous training step (the sample total -> pinned host, trainer.FusedNgpStep) - see optim.hip. */
 int arcn_copy_words(const void *src, void *dst, int64_t n_words, void *stream);
 /* arcn_adam_ema_step on up to four runs [lo, lo + n) of the SAME flat buffers in one launch (runs_host: lo0, n0, lo1, n1, ...; every lo a
  * multiple of 4 floats): what is left of the flat parameter buffer of a single-GPU step once the scatter's chunk owners have applied

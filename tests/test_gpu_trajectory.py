@@ -322,63 +322,6 @@ def test_fused_module_step_follows_the_oracle_loop(gpu, tape, oracle, leg):
     assert abs(np.abs(p).astype(np.float64).sum() - la) <= 2e-2 * la
 
 
-# ---- the drop-in step as one HIP-graph launch --------------------------------------------------------------------------------------
-def test_graphed_module_step_equals_eager_steps(gpu):
-    """trainer.GraphedTrainStep records `model(feed_in) -> ImgLoss -> backward -> FusedAdam.step (+ fused EMA)` of configs/nerf_ngp.yaml
-    (the yaml UNCHANGED but for noise_std 0 and a 32^3 grid refreshed every 4 steps) once and replays it.  Against the same model trained
-    eagerly, step for step: equal sample counts (the recorded marcher reads its pcg32 state from device memory, the host generator ends in
-    the same state), losses to 1e-5, parameters after 12 steps to the float scatter's order noise - across three occupancy refreshes
-    (applied IN PLACE to the buffers the recorded marcher reads) and a change of the batch size (a second graph)."""
-    from arcnerf_amd import trainer as T
-    from arcnerf_amd.models import build_model
-    from arcnerf_amd.ops.volume_func import sampler_rng
-    from arcnerf_amd.optim import FusedAdam
-    from arcnerf_amd.utils.cfgs_utils import load_configs
-    ov = ['--model.rays.noise_std', '0.0', '--model.obj_bound.volume.n_grid', '32', '--model.obj_bound.epoch_optim', '4',
-          '--model.obj_bound.epoch_optim_warmup', '8']
-    loss_cfg = type('C', (), {})()
-    loss_cfg.loss = type('C', (), {})()
-    loss_cfg.loss.ImgLoss = type('C', (), dict(keys=['rgb_coarse'], loss_type='Huber', delta=0.1, weight=3000.0))()
-    runs = {}
-    for mode in ('eager', 'graph'):
-        torch.manual_seed(5)
-        m = build_model(load_configs(os.path.join(CFG, 'nerf_ngp.yaml'), ov)).to(gpu)
-        fg = m.fg_model
-        assert fg.packed_path_eligible()
-        with torch.no_grad():
-            fg.coarse_geo_net.embed_fn.embeddings.mul_(1000.0)
-        opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=1e-2, eps=1e-15, weight_decay=1e-6, ema_decay=0.95).flatten()
-        ema = T.EMA(m, 0.95, opt)
-        loss_factory = T.build_loss(loss_cfg)
-        sampler_rng(reset=True)
-        m.train()
-        stepper = T.GraphedTrainStep(m, loss_factory, opt, ema) if mode == 'graph' else None
-        losses, counts = [], []
-        for k in range(12):
-            m.optimize(k)
-            n_rays = 256 if k < 8 else 384
-            inp = U.step_inputs(k, n_rays)
-            feed_in = {'rays_o': torch.from_numpy(inp['rays_o'])[None].to(gpu), 'rays_d': torch.from_numpy(inp['rays_d'])[None].to(gpu),
-                       'rays_r': torch.zeros(1, n_rays, 1, device=gpu), 'img': torch.from_numpy(inp['img'])[None].to(gpu),
-                       'bkg_color': torch.from_numpy(inp['bkg_color'])[None].to(gpu)}
-            if stepper is not None:
-                _, loss = stepper(feed_in, k)
-            else:
-                _, loss = T.step_optimize(m, feed_in, loss_factory, opt, ema, k)
-            losses.append(float(loss['sum']))
-            counts.append(int(fg._pipe.n_dev.item()))
-        torch.cuda.synchronize()
-        runs[mode] = (losses, counts, opt.flat_params().clone(), sampler_rng().state, opt._flat[0]['step'], float(fg.obj_bound.volume.get_voxel_bitfield().float().mean()),
-                      stepper.replays if stepper is not None else 0, len(stepper.graphs) if stepper is not None else 0)
-    (la, ca, pa, ra, sa, oa, _, _), (lb, cb, pb, rb, sb, ob, n_replay, n_graphs) = runs['eager'], runs['graph']
-    assert n_replay == 10 and n_graphs == 2            # two eager warm-up steps, then one graph per batch shape
-    assert ca == cb and ra == rb and sa == sb == 12
-    assert 0.0 < oa < 1.0 and oa == ob                 # the refreshes pruned, identically
-    assert max(abs(a - b) / abs(a) for a, b in zip(la, lb)) < 1e-5, (la, lb)
-    far = ((pa - pb).abs() > 1e-3 * float(pa.abs().max())).float().mean()
-    assert float(far) < 1e-3, float(far)
-
-
 # ---- the drop-in step on the pipeline's fused step ----------------------------------------------------------------------------------
 def test_fused_module_step_equals_eager_steps(gpu):
     """trainer.FusedNgpStep runs `model(feed_in) -> ImgLoss -> backward -> FusedAdam.step (+ fused EMA)` of configs/nerf_ngp.yaml as
