@@ -985,9 +985,9 @@ ARCN_EXPORT int64_t arcn_gemm_tn_scratch_floats(int64_t n_rows, int N, int K) {
 
 /* dW (N,K) (+)= dY (S,N)^T . X (S,K): weight gradient, reduced over all rows in a fixed order (slab partials in `scratch`, at least
  * arcn_gemm_tn_scratch_floats(n_rows, N, K) floats). */
-ARCN_EXPORT int arcn_gemm_tn(const float *dy, const float *mask, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *scratch,
-                             int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate, void *stream) {
-    if (!dy || !x || !dw || !scratch || N < 1 || K < 1) return einval("gemm_tn: missing / invalid argument");
+static int gemm_tn_impl(const float *dy, const float *mask, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *scratch,
+                        int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int n_head, int accumulate, void *stream) {
+    if (!dy || !x || !dw || !scratch || N < 1 || K < 1 || n_head < 1 || n_head > N) return einval("gemm_tn: missing / invalid argument");
     if (scratch_floats < arcn_gemm_tn_scratch_floats(n_rows, N, K)) return einval("gemm_tn: scratch smaller than arcn_gemm_tn_scratch_floats");
     const int aa = is_aligned(dy, ld_dy), ba = is_aligned(x, ld_x);
     const bool al = aa && ba && (N & 3) == 0 && (K & 3) == 0;
@@ -1009,10 +1009,24 @@ ARCN_EXPORT int arcn_gemm_tn(const float *dy, const float *mask, int64_t ld_dy, 
         else if (al) hipLaunchKernelGGL((gemm_tn_kernel<4, 4, true, false>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, aa, ba);
         else hipLaunchKernelGGL((gemm_tn_kernel<4, 4, false, false>), grid, dim3(256), 0, as_stream(stream), dy, mask, ld_dy, x, ld_x, scratch, n_rows, n_ptr, N, K, slabs, aa, ba);
     }
-    const int64_t n_elem = (int64_t)N * K;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ceil_div<int64_t>(n_elem, 64)), dim3(256), 0, as_stream(stream), scratch, dw,
-                       n_elem, n_elem, slabs, accumulate, n_elem, (float *)nullptr);
+    const int64_t n_elem = (int64_t)N * K, n_write = (int64_t)n_head * K;     // (the slabs hold N rows; the first n_head of them are summed and written)
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ceil_div<int64_t>(n_write, 64)), dim3(256), 0, as_stream(stream), scratch, dw,
+                       n_write, n_elem, slabs, accumulate, n_write, (float *)nullptr);
     return check_launch("gemm_tn");
+}
+
+ARCN_EXPORT int arcn_gemm_tn(const float *dy, const float *mask, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *scratch,
+                             int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate, void *stream) {
+    return gemm_tn_impl(dy, mask, ld_dy, x, ld_x, dw, scratch, scratch_floats, n_rows, n_ptr, N, K, N, accumulate, stream);
+}
+
+/* arcn_gemm_tn whose result keeps only the first n_head of the N rows: dw (n_head, K) (+)= (dy^T x)[:n_head].  For a layer whose output is
+ * padded to a multiple of 4 columns (the 1 + 16 outputs of a geometry net as 20): the product runs on the aligned 20-column operand, the
+ * weight gradient of the 17 real rows lands - accumulated - in the layer's own gradient buffer. */
+ARCN_EXPORT int arcn_gemm_tn_head(const float *dy, const float *mask, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *scratch,
+                                  int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int n_head, int accumulate,
+                                  void *stream) {
+    return gemm_tn_impl(dy, mask, ld_dy, x, ld_x, dw, scratch, scratch_floats, n_rows, n_ptr, N, K, n_head, accumulate, stream);
 }
 
 /* arcn_gemm_tn on the bf16 matrix rate (split form, see arcn_gemm_nt_split): same arguments and scratch; dy, mask and x rows 16-byte

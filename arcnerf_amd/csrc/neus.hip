@@ -336,7 +336,8 @@ neus_render_bwd_kernel(NeusIn p, const float *__restrict__ g_rgb, const float *_
 // is added) the gradient; loss[0] is added the loss (cleared by the launcher).
 __global__ void __launch_bounds__(256)
 eikonal_packed_kernel(const float *__restrict__ normal, const int32_t *__restrict__ ray_id, const int32_t *__restrict__ offsets, int64_t n_pts,
-                      int p_dense, float scale, int accumulate, float *__restrict__ d_normal, float *__restrict__ loss) {
+                      int p_dense, float scale, int accumulate, const float *__restrict__ add_src, int64_t ld_add, float *__restrict__ d_normal,
+                      float *__restrict__ loss) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float term = 0.f;
     if (i < n_pts) {
@@ -348,10 +349,12 @@ eikonal_packed_kernel(const float *__restrict__ normal, const int32_t *__restric
         const float e = len - 1.0f;
         term = mult * e * e * scale;
         const float g = len > 0.f ? mult * 2.0f * e * scale / len : 0.f;
+        float gx = g * x, gy = g * y, gz = g * z;
+        if (add_src) { gx += add_src[i * ld_add]; gy += add_src[i * ld_add + 1]; gz += add_src[i * ld_add + 2]; }   // (a second incoming gradient)
         if (accumulate) {
-            d_normal[3 * i] += g * x; d_normal[3 * i + 1] += g * y; d_normal[3 * i + 2] += g * z;
+            d_normal[3 * i] += gx; d_normal[3 * i + 1] += gy; d_normal[3 * i + 2] += gz;
         } else {
-            d_normal[3 * i] = g * x; d_normal[3 * i + 1] = g * y; d_normal[3 * i + 2] = g * z;
+            d_normal[3 * i] = gx; d_normal[3 * i + 1] = gy; d_normal[3 * i + 2] = gz;
         }
     }
     // one atomic per workgroup (every wave adding to the ONE scalar serialised 2 000 same-address atomics: 27 us for a 2 us kernel)
@@ -406,13 +409,14 @@ ARCN_EXPORT int arcn_neus_slots_bwd(const float *d_dense, const int32_t *offsets
 }
 
 ARCN_EXPORT int arcn_eikonal_packed(const float *normal, const int32_t *ray_id, const int32_t *offsets, int64_t n_pts, int64_t n_rays, int p_dense,
-                                    float weight, int accumulate, float *d_normal, float *loss, void *stream) {
-    if (loss && hipMemsetAsync(loss, 0, sizeof(float), as_stream(stream)) != hipSuccess) return check_launch("memset");
+                                    float weight, int accumulate, const float *add_src, int64_t ld_add, float *d_normal, float *loss,
+                                    void *stream) {
+    if (loss && !(accumulate & 2) && hipMemsetAsync(loss, 0, sizeof(float), as_stream(stream)) != hipSuccess) return check_launch("memset");
     if (n_pts <= 0 || n_rays <= 0) return ARCN_OK;
-    if (!normal || !ray_id || !offsets || !d_normal || p_dense < 1) return einval("eikonal_packed: missing argument");
+    if (!normal || !ray_id || !offsets || !d_normal || p_dense < 1 || (add_src && ld_add < 3)) return einval("eikonal_packed: missing argument");
     const float scale = weight / ((float)n_rays * (float)p_dense);
     hipLaunchKernelGGL(eikonal_packed_kernel, dim3((unsigned)ceil_div<int64_t>(n_pts, 256)), dim3(256), 0, as_stream(stream), normal, ray_id,
-                       offsets, n_pts, p_dense, scale, accumulate, d_normal, loss);
+                       offsets, n_pts, p_dense, scale, accumulate & 1, add_src, ld_add, d_normal, loss);
     return check_launch("eikonal_packed");
 }
 

@@ -21,12 +21,12 @@ def normalize(vec):
 
 
 @torch.no_grad()
-def aabb_ray_intersection(rays_o, rays_d, aabb_range, eps=1e-7, force_torch=False):
-    """aabb_range (N_v, 3, 2) -> near, far (N_rays, N_v), pts (N_rays, N_v, 2, 3), mask (N_rays, N_v) bool"""
+def aabb_ray_intersection(rays_o, rays_d, aabb_range, eps=1e-7, force_torch=False, want_pts=True):
+    """aabb_range (N_v, 3, 2) -> near, far (N_rays, N_v), pts (N_rays, N_v, 2, 3) (None without want_pts), mask (N_rays, N_v) bool"""
     assert aabb_range.shape[1] == 3 and aabb_range.shape[2] == 2, 'AABB range must be (N, 3, 2)'
     if force_torch:
-        return F.aabb_intersection_torch(rays_o, rays_d, aabb_range, eps)
-    return F.aabb_intersection(rays_o, rays_d, aabb_range.permute(0, 2, 1).contiguous())
+        return F.aabb_intersection_torch(rays_o, rays_d, aabb_range, eps, want_pts=want_pts)
+    return F.aabb_intersection(rays_o, rays_d, aabb_range.permute(0, 2, 1).contiguous(), want_pts=want_pts)
 
 
 @torch.no_grad()

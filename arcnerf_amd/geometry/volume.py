@@ -124,6 +124,15 @@ class Volume(nn.Module):
     def get_range(self):
         return self.range
 
+    def get_range23(self):
+        """the (2, 3) [min | max] form of the range the sampling kernels take, kept while the range tensor is the same object at the same
+        version (a (3, 2) -> (2, 3) transposed copy per sampler launch otherwise)"""
+        r = self.range
+        c = getattr(self, '_range23', None)
+        if c is None or c[0] is not r or c[1] != r._version or c[2].device != r.device:
+            c = self._range23 = (r, r._version, r.permute(1, 0).contiguous())
+        return c[2]
+
     def get_device(self):
         return self.origin.device
 

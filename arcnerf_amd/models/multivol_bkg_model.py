@@ -48,7 +48,7 @@ class MultiVol(BkgModel, MortonDensityGrid):
     def get_near_far_from_rays(self, rays_o, rays_d):
         """near, far (B,1) against the outermost volume, torch semantics: the cameras sit inside it"""
         box = self.max_volume.get_range()[None].to(rays_o.device)
-        near, far, _, _ = aabb_ray_intersection(rays_o, rays_d, box, force_torch=True)
+        near, far, _, _ = aabb_ray_intersection(rays_o, rays_d, box, force_torch=True, want_pts=False)
         return near, far
 
     def get_zvals_from_near_far(self, near, far, n_pts, rays_o, rays_d, **kwargs):
@@ -69,7 +69,7 @@ class MultiVol(BkgModel, MortonDensityGrid):
         rng = multivol_rng()
         zvals, _, counts = Fn.sparse_sampling_in_multivol_bitfield(
             rays_o, rays_d, near, far, n_pts, self.cone_angle, self.min_step, self.max_step,
-            self.basic_volume.get_range().permute(1, 0).contiguous(), self.max_volume.get_range().permute(1, 0).contiguous(),
+            self.basic_volume.get_range23(), self.max_volume.get_range23(),
             self.n_grid, self.n_cascade, self.density_bitfield, self.get_optim_cfgs('near_distance'), self.inclusive, rng.state,
             rng.inc, want_counts=True, dense=False)
         rng.advance()

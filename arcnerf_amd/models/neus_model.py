@@ -70,7 +70,7 @@ class Neus(SdfModel):
         from ..ops.volume_func import sampler_rng
         vol, n_pts = self.obj_bound.volume, self.get_n_coarse_sample()
         rng = sampler_rng()
-        zd, counts, _, _ = Fn.march_count(rays_o, rays_d, vol.get_range().permute(1, 0).contiguous(), vol.get_n_grid(),
+        zd, counts, _, _ = Fn.march_count(rays_o, rays_d, vol.get_range23(), vol.get_n_grid(),
                                           vol.get_voxel_bitfield(), n_pts, vol.get_diag_len() / n_pts,
                                           self.obj_bound.get_optim_cfgs('near_distance'), rng.state, rng.inc)
         rng.advance()

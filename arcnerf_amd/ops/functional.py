@@ -31,6 +31,23 @@ def _nptr(n_dev):
     return n_dev.data_ptr()
 
 
+_POISON = os.environ.get('ARCN_POISON_OUTPUTS') == '1'
+
+
+def _fresh(shape, dtype, device):
+    """an output buffer its kernel writes EVERY element of: torch.empty - or, with ARCN_POISON_OUTPUTS=1 (the test suite's check that no kernel
+    leaves an element of such a buffer unwritten), filled with NaN / 0x7f bytes first"""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if _POISON:
+        if t.dtype.is_floating_point:
+            t.fill_(float('nan'))
+        elif t.dtype == torch.bool:
+            t.fill_(True)
+        else:
+            t.fill_(0x7f7f7f7f if t.dtype in (torch.int32, torch.int64) else 0x7f)
+    return t
+
+
 # ------------------------------------------------------------------------------------------------
 # _volume_func
 # ------------------------------------------------------------------------------------------------
@@ -50,10 +67,10 @@ def aabb_intersection(rays_o, rays_d, aabb_v23, want_pts=True):
     _req(rays_o, rays_d, aabb_v23)
     o, d, bb = _f32(rays_o), _f32(rays_d), _f32(aabb_v23)
     R, V = o.shape[0], bb.shape[0]
-    near = torch.zeros((R, V), dtype=torch.float32, device=o.device)
-    far = torch.zeros((R, V), dtype=torch.float32, device=o.device)
-    pts = torch.zeros((R, V, 2, 3), dtype=torch.float32, device=o.device) if want_pts else None
-    mask = torch.zeros((R, V), dtype=torch.bool, device=o.device)
+    near = _fresh((R, V), torch.float32, o.device)       # (the kernel writes every (ray, volume) entry of the four outputs)
+    far = _fresh((R, V), torch.float32, o.device)
+    pts = _fresh((R, V, 2, 3), torch.float32, o.device) if want_pts else None
+    mask = _fresh((R, V), torch.bool, o.device)
     N.check(N.lib().arcn_aabb_intersection(N.ptr(o), N.ptr(d), N.ptr(bb), N.ptr(near), N.ptr(far), N.ptr(pts),
                                           mask.data_ptr(), R, V, N.stream()), 'aabb_intersection')
     return near, far, pts, mask
@@ -64,10 +81,10 @@ def aabb_intersection_torch(rays_o, rays_d, aabb_v32, eps=1e-7, want_pts=True):
     _req(rays_o, rays_d, aabb_v32)
     o, d, bb = _f32(rays_o), _f32(rays_d), _f32(aabb_v32)
     R, V = o.shape[0], bb.shape[0]
-    near = torch.zeros((R, V), dtype=torch.float32, device=o.device)
-    far = torch.zeros((R, V), dtype=torch.float32, device=o.device)
-    pts = torch.zeros((R, V, 2, 3), dtype=torch.float32, device=o.device) if want_pts else None
-    mask = torch.zeros((R, V), dtype=torch.bool, device=o.device)
+    near = _fresh((R, V), torch.float32, o.device)       # (the kernel writes every (ray, volume) entry of the four outputs)
+    far = _fresh((R, V), torch.float32, o.device)
+    pts = _fresh((R, V, 2, 3), torch.float32, o.device) if want_pts else None
+    mask = _fresh((R, V), torch.bool, o.device)
     N.check(N.lib().arcn_aabb_intersection_torch(N.ptr(o), N.ptr(d), N.ptr(bb), float(eps), N.ptr(near), N.ptr(far),
                                                 N.ptr(pts), mask.data_ptr(), R, V, N.stream()), 'aabb_intersection_torch')
     return near, far, pts, mask
@@ -318,7 +335,7 @@ def sparse_sampling_in_multivol_bitfield(rays_o, rays_d, near, far, n_pts, cone_
     alloc = torch.zeros if (dense or not want_counts) else torch.empty
     zvals = alloc((R, n_pts), dtype=torch.float32, device=o.device)
     mask = alloc((R, n_pts), dtype=torch.bool, device=o.device)
-    counts = torch.zeros(R, dtype=torch.int32, device=o.device) if want_counts else None
+    counts = _fresh((R,), torch.int32, o.device) if want_counts else None      # (every ray's wave writes its count)
     N.check(N.lib().arcn_sparse_sampling_in_multivol_bitfield(
         N.ptr(o), N.ptr(d), N.ptr(nr), N.ptr(fr), int(n_pts), float(cone_angle), float(min_step), float(max_step),
         N.ptr(_f32(min_aabb23)), N.ptr(_f32(aabb23)), int(n_grid), int(n_cascade), N.ptr(bitfield.contiguous()),
@@ -429,7 +446,7 @@ def pack_dense_samples_begin(zvals, counts):
     R, n_pts = z.shape
     cnt = counts.contiguous().to(torch.int32)
     offsets = torch.empty(R + 1, dtype=torch.int32, device=z.device)
-    p_dense = torch.zeros(1, dtype=torch.int32, device=z.device)
+    p_dense = (_fresh if R > 0 else torch.zeros)((1,), dtype=torch.int32, device=z.device)       # (the scan's one workgroup writes it)
     N.check(N.lib().arcn_exclusive_scan_i32(N.ptr(cnt), N.ptr(offsets), R, int(R * n_pts), N.ptr(p_dense), N.stream()), 'exclusive_scan_i32')
     host = torch.empty(1, dtype=torch.int32).pin_memory()
     host.copy_(offsets[R:R + 1], non_blocking=True)
@@ -939,11 +956,12 @@ def gemm_nn(dy, w, mask=None, mask_bits=None, ws=None):
     return dx
 
 
-def gemm_tn(dy, x, mask=None, want_colsum=False, mask_bits=None, out=None, db_out=None, accumulate=False):
+def gemm_tn(dy, x, mask=None, want_colsum=False, mask_bits=None, out=None, db_out=None, accumulate=False, head=None):
     """dw (N,K) = (dy * (mask > 0)) (S,N).T @ x (S,K), reduced over the rows in a fixed order; want_colsum: also the column sums (N) of
     dy * (mask > 0) - a layer's bias gradient - from the same pass where the split kernel runs, else from a second product with ones;
     mask_bits: the forward's ReLU bit words instead of the float mask.  dy (+ float mask, same stride) and x may be column slices.
-    out / db_out (contiguous) receive the results; accumulate: they are ADDED to (a caller that sums a layer's gradient over chunks)"""
+    out / db_out (contiguous) receive the results; accumulate: they are ADDED to (a caller that sums a layer's gradient over chunks);
+    head: only the first `head` of the N rows are kept, dw is (head, K) (a layer with padded output columns; plain product only)"""
     _req(dy, x, mask, mask_bits)
     (dy, ld), (x, ld_x) = _rows(dy), _rows(x)
     if mask is not None:
@@ -954,6 +972,15 @@ def gemm_tn(dy, x, mask=None, want_colsum=False, mask_bits=None, out=None, db_ou
     S, Nn = dy.shape
     K = x.shape[1]
     assert x.shape[0] == S
+    if head is not None:
+        assert not want_colsum and mask_bits is None and 1 <= head <= Nn
+        dw = torch.empty((head, K), dtype=torch.float32, device=dy.device) if out is None else out
+        assert dw.shape == (head, K) and dw.is_contiguous() and dw.dtype == torch.float32 and (out is not None or not accumulate)
+        nf = max(1, int(N.lib().arcn_gemm_tn_scratch_floats(S, Nn, K)))
+        scratch = torch.empty(nf, dtype=torch.float32, device=dy.device)
+        N.check(N.lib().arcn_gemm_tn_head(dy.data_ptr(), None if mask is None else mask.data_ptr(), ld, x.data_ptr(), ld_x, N.ptr(dw), N.ptr(scratch), nf,
+                                         S, None, Nn, K, int(head), 1 if accumulate else 0, N.stream()), 'gemm_tn_head')
+        return dw
     dw = torch.empty((Nn, K), dtype=torch.float32, device=dy.device) if out is None else out
     assert dw.shape == (Nn, K) and dw.is_contiguous() and dw.dtype == torch.float32 and (out is not None or not accumulate)
     acc = 1 if accumulate else 0
@@ -1083,8 +1110,9 @@ def composite_packed_bwd(sigma, radiance, t, offsets, d_rgb, d_depth=None, d_mas
     sg, rad, t, ns = _f32(sigma), _f32(radiance), _f32(t), _f32(noise)
     R = offsets.shape[0] - 1
     bk, bk_rows = _bkg(bkg_color, R)
-    d_sigma = torch.zeros_like(sg)
-    d_rad = torch.zeros_like(rad) if rad is not None else None
+    # (every sample of every segment is written: the visited columns, the dropped last column, the samples of a truncated ray - render.hip)
+    d_sigma = _fresh(sg.shape, torch.float32, sg.device)
+    d_rad = _fresh(rad.shape, torch.float32, rad.device) if rad is not None else None
     N.check(N.lib().arcn_composite_packed_bwd(N.ptr(sg), N.ptr(rad), N.ptr(t), N.ptr(offsets), N.ptr(ns), N.ptr(bk), bk_rows,
                                              R, int(p_dense), _nptr(p_dense_dev), int(add_inf_z), int(white_bkg),
                                              N.ptr(_f32(d_rgb)), N.ptr(_f32(d_depth)), N.ptr(_f32(d_mask)), N.ptr(d_sigma),
@@ -1180,7 +1208,7 @@ def neus_pack_begin(zvals_dense, counts):
     R, n_pts = zvals_dense.shape
     dev = zvals_dense.device
     L = N.lib()
-    kmax = torch.zeros(1, dtype=torch.int32, device=dev)
+    kmax = (_fresh if R > 0 else torch.zeros)((1,), dtype=torch.int32, device=dev)       # (the scan's one workgroup writes it)
     tmp = torch.empty(R + 1, dtype=torch.int32, device=dev)
     N.check(L.arcn_exclusive_scan_i32(N.ptr(counts), N.ptr(tmp), R, int(R * n_pts), N.ptr(kmax), N.stream()), 'exclusive_scan_i32')
     n_eval = torch.empty(R, dtype=torch.int32, device=dev)
@@ -1245,20 +1273,107 @@ def _vec3(v):
     return (C.c_float * 3)(*[float(x) for x in v])
 
 
-def eikonal_packed(normal, pk, n_rays, weight, d_normal=None, loss=None):
+def eikonal_packed(normal, pk, n_rays, weight, d_normal=None, loss=None, add_src=None, loss_is_clear=False):
     """EikonalLoss on the dense `normal_pts` of a packed NeuS batch without building it: -> (loss (1,) device, d_normal (S,3)); a given
-    d_normal is ADDED to"""
-    _req(normal, d_normal, loss)
+    d_normal is ADDED to; add_src ((S, 3) column slice of a row-major tensor): a second incoming gradient joined in the same pass;
+    loss_is_clear: the given loss buffer is an accumulator already cleared (arcn_neus_blend_loss's loss[1]) - no clearing launch"""
+    _req(normal, d_normal, loss, add_src)
     normal = _f32(normal)
     S = normal.shape[0]
-    acc = d_normal is not None
+    acc = (1 if d_normal is not None else 0) | (2 if (loss is not None and loss_is_clear) else 0)
     if d_normal is None:
         d_normal = torch.empty_like(normal)
     if loss is None:
         loss = torch.empty(1, dtype=torch.float32, device=normal.device)
+    ld = 0
+    if add_src is not None:
+        assert add_src.shape == (S, 3) and add_src.dtype == torch.float32 and add_src.stride(1) == 1
+        ld = add_src.stride(0)
     N.check(N.lib().arcn_eikonal_packed(N.ptr(normal), N.ptr(pk['ray_id']), N.ptr(pk['offsets']), S, int(n_rays), int(pk['p_dense']), float(weight),
-                                       int(acc), N.ptr(d_normal), N.ptr(loss), N.stream()), 'eikonal_packed')
+                                       int(acc), None if add_src is None else add_src.data_ptr(), int(ld), N.ptr(d_normal), N.ptr(loss),
+                                       N.stream()), 'eikonal_packed')
     return loss, d_normal
+
+
+# ---- the passes between the kernels of trainer.FusedNeusNgpStep (csrc/step_glue.hip) ----------------------------------------------------------
+def neus_step_prep(w1, l1w, beta, inv_s=None, speed=1.0, bkg_l1w=None, pad_to=4):
+    """the per-step derived weights of the sdf net (first layer w1 (H, E), last layer l1w (n_out, H)) and of a background density net's last
+    layer, one launch -> dict(w2p (n_pad, H), w1j (H, E) = w1 * l1w[0][:, None], bw20 (H) = beta * l1w[0], scale (1) = exp(inv_s * speed) |
+    None, wb1p (nb_pad, Hb) | None)"""
+    _req(w1, l1w, inv_s, bkg_l1w)
+    w1, l1w = _f32(w1), _f32(l1w)
+    H, E = w1.shape
+    n_out = l1w.shape[0]
+    assert l1w.shape[1] == H
+    n_pad = (n_out + pad_to - 1) // pad_to * pad_to
+    dev = w1.device
+    flat = torch.empty(n_pad * H + H * E + H + 4, dtype=torch.float32, device=dev)       # (one allocation, every piece 16-byte aligned when H % 4 == 0)
+    o = {'w2p': flat[:n_pad * H].view(n_pad, H), 'w1j': flat[n_pad * H:n_pad * H + H * E].view(H, E),
+         'bw20': flat[n_pad * H + H * E:n_pad * H + H * E + H], 'scale': flat[n_pad * H + H * E + H:n_pad * H + H * E + H + 1] if inv_s is not None else None,
+         'wb1p': None}
+    Hb = nb_out = nb_pad = 0
+    if bkg_l1w is not None:
+        bkg_l1w = _f32(bkg_l1w)
+        nb_out, Hb = bkg_l1w.shape
+        nb_pad = (nb_out + pad_to - 1) // pad_to * pad_to
+        o['wb1p'] = torch.empty((nb_pad, Hb), dtype=torch.float32, device=dev)
+    N.check(N.lib().arcn_neus_step_prep(N.ptr(w1), N.ptr(l1w), H, E, n_out, n_pad, float(beta), N.ptr(_f32(inv_s)), float(speed), N.ptr(o['w2p']),
+                                       N.ptr(o['w1j']), N.ptr(o['bw20']), N.ptr(o['scale']), N.ptr(bkg_l1w), Hb, nb_out, nb_pad, N.ptr(o['wb1p']),
+                                       N.stream()), 'neus_step_prep')
+    return o
+
+
+def geo_out_grad(d_col0, d_feat, n_pad, out=None, act=None, beta=1.0, y_col0=None):
+    """g_out (n, n_pad) = [d_col0 * act'(out[:, 0]) | d_feat | 0]: d_feat (n, n_feat) and out (n, >= 1) may be column slices of wider row-major
+    tensors; act None: column 0 = d_col0"""
+    _req(d_col0, d_feat, out, y_col0)
+    n = d_col0.shape[0]
+    assert d_col0.is_contiguous() and d_col0.dtype == torch.float32 and d_feat.dtype == torch.float32 and d_feat.stride(1) == 1 and d_feat.shape[0] == n
+    g = torch.empty((n, int(n_pad)), dtype=torch.float32, device=d_col0.device)
+    ld_out = 0
+    if N.ACT[act] != 0:
+        assert out is not None and out.dtype == torch.float32 and out.shape[0] == n and (out.dim() == 1 or out.stride(1) == 1)
+        ld_out = out.stride(0)
+    N.check(N.lib().arcn_geo_out_grad(N.ptr(d_col0), None if out is None else out.data_ptr(), int(ld_out), N.ptr(y_col0), N.ACT[act], float(beta),
+                                     d_feat.data_ptr(), int(d_feat.stride(0)), int(d_feat.shape[1]), int(n_pad), N.ptr(g), n, N.stream()), 'geo_out_grad')
+    return g
+
+
+_BLEND_WS = {}
+
+
+def neus_blend_loss(rgb_f, depth_f, t_last, rgb_b, depth_b, target, huber_delta, weight):
+    """rgb = rgb_f + T rgb_b, depth likewise, the image loss (Huber: huber_delta > 0, MSE: None / <= 0; plain mean x weight) and the gradients, one
+    launch -> dict(rgb, depth, loss (2,): [image loss, 0 = the cleared accumulator of the next loss pass], d_rgb, d_tlast, d_rgb_b)"""
+    _req(rgb_f, depth_f, t_last, rgb_b, depth_b, target)
+    R = rgb_f.shape[0]
+    dev = rgb_f.device
+    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    o = {'rgb': f(R, 3), 'depth': f(R), 'loss': f(2), 'd_rgb': f(R, 3), 'd_tlast': f(R), 'd_rgb_b': f(R, 3)}
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)      # (ticket + partials: one per stream, zeroed once - the kernel leaves the ticket zero)
+    ws = _BLEND_WS.get(key)
+    if ws is None:
+        ws = _BLEND_WS[key] = torch.zeros(int(N.lib().arcn_neus_blend_loss_workspace_words()), dtype=torch.int32, device=dev)
+    N.check(N.lib().arcn_neus_blend_loss(N.ptr(_f32(rgb_f)), N.ptr(_f32(depth_f)), N.ptr(_f32(t_last)), N.ptr(_f32(rgb_b)), N.ptr(_f32(depth_b)),
+                                        N.ptr(_f32(target)), R, float(huber_delta or 0.0), float(weight), N.ptr(o['rgb']), N.ptr(o['depth']),
+                                        N.ptr(o['d_rgb']), N.ptr(o['d_tlast']), N.ptr(o['d_rgb_b']), N.ptr(o['loss']), N.ptr(ws), N.stream()), 'neus_blend_loss')
+    return o
+
+
+def sdf_jac_dz2(dh, u, s, c, w, colsum):
+    """(dh s + c u s (1 - s), s * w) written over dh and u; colsum (H) += the column sums of s u"""
+    _req(dh, u, s, c, w, colsum)
+    n, H = dh.shape
+    assert colsum.numel() == H and colsum.is_contiguous()
+    N.check(N.lib().arcn_sdf_jac_dz2(N.ptr(dh), N.ptr(u), N.ptr(s), N.ptr(c), N.ptr(w), N.ptr(dh), N.ptr(u), N.ptr(colsum), n, H, N.stream()), 'sdf_jac_dz2')
+    return dh, u
+
+
+def sum_scale_add(src, dst, factor=1.0, scale_dev=None):
+    """dst[0] += factor * scale_dev[0] * sum(src), one launch"""
+    _req(src, dst, scale_dev)
+    N.check(N.lib().arcn_sum_scale_add(N.ptr(_f32(src)), src.numel(), N.ptr(scale_dev), float(factor), N.ptr(dst), N.stream()), 'sum_scale_add')
+    return dst
 
 
 def neus_render_fwd(sdf, radiance, normal, pk, rays_d, s_dev, cos_anneal, bkg_color, depth_far, dflt_rgb, dflt_nrm):

@@ -139,6 +139,14 @@ class FusedNeusNgpStep:
         self._ws = {}
         self.apply_optimizer = True      # (False: the gradients stay in the flat buffer - tests compare them with autograd's)
 
+    def _default_normal(self):
+        """the unit default normal of rays without samples (render_cfgs, neus_model.py) as three floats, computed once"""
+        d = self._ws.get('dflt_nrm')
+        if d is None:
+            nv = torch.tensor(self.fg.render_cfgs['normal'], dtype=torch.float32)
+            d = self._ws['dflt_nrm'] = (nv / (nv.norm() + 1e-8)).tolist()
+        return d
+
     def _zeros(self, n, device):
         """n read-only zero floats (kept: no fill kernel per step)"""
         z = self._ws.get('zeros')
@@ -195,24 +203,25 @@ class FusedNeusNgpStep:
         table = emb.embeddings
         beta = float(l0.activation.beta)
         n_out = l1.weight.shape[0]
-        scale = fg.forward_scale()
-        s_dev = scale.detach().reshape(1).contiguous()
+        emb_b, b0, b1 = _density_net_form(bkg.geo_net)
+        # the weights both geometry nets' kernels take this step - the padded last layers, the Jacobian row's folded first layer, beta W2[0] -
+        # and the NeuS scale exp(inv_s * speed): one launch (arcn_neus_step_prep)
+        prep = F.neus_step_prep(l0.weight, l1.weight, beta, fg.inv_s.detach().reshape(1), float(fg.speed_factor), b1.weight)
+        w1, w2, wb1 = l0.weight, prep['w2p'], prep['wb1p']
+        s_dev = prep['scale']
         cos_anneal = fg.get_cos_anneal(epoch)
-        nv = torch.tensor(fg.render_cfgs['normal'], dtype=torch.float32)
-        dflt_nrm = (nv / (nv.norm() + 1e-8)).tolist()
+        dflt_nrm = self._default_normal()
         dflt_rgb = fg.render_cfgs['bkg_color']
         if S > 0:
             fg.adjust_dynamicbs_factor(n_valid=pk['offsets'][R])
             pts, dirs = F.packed_points(rays_o, rays_d, pk['t_mid'], pk['ray_id'])
             enc = F.hashgrid_fwd(pts, table, emb.desc)
-            w1 = l0.weight
-            w2 = torch.nn.functional.pad(l1.weight, (0, 0, 0, (-n_out) % 4))
             hid = F.gemm_nt(enc, w1, None, act='softplus', beta=beta)
             out = F.gemm_nt(hid, w2, None)
             sg = F.softplus_grad(hid, None, beta, from_y=True)
-            jac = F.gemm_nn(sg, (w1 * w2[0][:, None]).contiguous())
+            jac = F.gemm_nn(sg, prep['w1j'])
             _, normal = F.hashgrid_bwd(pts, table, jac, emb.desc, want_dtable=False, want_dxyz=True)
-            sdf = out[:, 0].contiguous()
+            sdf = F.act_col_scale(out, None, 1.0)       # (column 0 of the padded output)
             n_sh = rad.embed_fn_view.n_freqs ** 2
             rad_in = F.radiance_inputs('pvnf', pts, dirs, normal, out[:, 1:n_out], rad.embed_fn_view.n_freqs)       # [p | SH(normalize(v)) | n | f], one pass
             rad_w = _flat_view([layer.weight for layer in rad.layers])
@@ -226,18 +235,15 @@ class FusedNeusNgpStep:
         rgb_f, depth_f, mask_f, nrm_f, t_last = F.neus_render_fwd(sdf, rgb_s, normal, pk, rays_d, s_dev, cos_anneal, bkg_color,
                                                                  float(fg.render_cfgs['depth_far']), dflt_rgb, dflt_nrm)
         # ---- background forward
-        emb_b, b0, b1 = _density_net_form(bkg.geo_net)
         rb = bkg.radiance_net
         tb = emb_b.embeddings
         nb_out = b1.weight.shape[0]
         if total_b > 0:
             xyz_b, dirs_b = F.packed_points(rays_o, rays_d, t_b, ray_b)
             enc_b = F.hashgrid_fwd(xyz_b, tb, emb_b.desc)
-            wb1 = torch.nn.functional.pad(b1.weight, (0, 0, 0, (-nb_out) % 4))
             hid_b = F.gemm_nt(enc_b, b0.weight, None, act='relu')
             out_b = F.gemm_nt(hid_b, wb1, None)
-            pre_b = out_b[:, 0].contiguous()
-            sigma_b = F.act_fwd(pre_b, 'truncexp')
+            sigma_b = F.act_col_scale(out_b, 'truncexp', 1.0)       # (the density from column 0 of the padded output)
             rin_b = F.radiance_inputs('fv', None, dirs_b, None, out_b[:, 1:nb_out], rb.embed_fn_view.n_freqs)
             rb_w = _flat_view([layer.weight for layer in rb.layers])
             rb_g = _flat_view([layer.weight.grad for layer in rb.layers]) if rb_w is not None else None
@@ -254,21 +260,13 @@ class FusedNeusNgpStep:
         if self.prefetch and next_feed_in is not None:
             model.prefetch_samples(next_feed_in)
         # ---- blend + losses
-        rgb = rgb_f + t_last[:, None] * rgb_b
-        depth = depth_f + t_last * depth_b
         il = self.img_loss
-        if isinstance(il.loss, HuberLoss):
-            loss_img, d_rgb = F.huber_loss_grad(rgb, img, float(il.loss.delta), self.img_w)
-            loss_img = loss_img[0]
-        else:
-            diff = rgb - img
-            loss_img = (diff * diff).mean() * self.img_w
-            d_rgb = diff * (2.0 * self.img_w / diff.numel())
-        d_tlast = (d_rgb * rgb_b).sum(-1)
-        d_rgb_b = d_rgb * t_last[:, None]
+        bl = F.neus_blend_loss(rgb_f, depth_f, t_last, rgb_b, depth_b, img, float(il.loss.delta) if isinstance(il.loss, HuberLoss) else None, self.img_w)
+        rgb, depth, d_rgb, d_tlast, d_rgb_b = bl['rgb'], bl['depth'], bl['d_rgb'], bl['d_tlast'], bl['d_rgb_b']
+        losses = bl['loss']          # [image loss, 0 = the Eikonal pass's accumulator]
         # ---- background backward
         if total_b > 0:
-            d_sig_b, d_rad_b = F.composite_packed_bwd(sigma_b, rgb_sb, t_b, off_b, d_rgb_b.contiguous(), None, None, p_dense_dev=pd_b,
+            d_sig_b, d_rad_b = F.composite_packed_bwd(sigma_b, rgb_sb, t_b, off_b, d_rgb_b, None, None, p_dense_dev=pd_b,
                                                       add_inf_z=bool(bkg.add_inf_z), white_bkg=bool(bkg.get_ray_cfgs('white_bkg')))
             dx_b, dw_b, _ = F.mlp_bwd(rin_b, rb_w, None, rb._fused_desc, rgb_sb, rb_acts, d_rad_b, want_dx=True, dweights=rb_g)     # (added into rb_g)
             if rb_g is None:
@@ -277,19 +275,18 @@ class FusedNeusNgpStep:
                     m_ = layer.weight.numel()
                     layer.weight.grad.add_(dw_b[k:k + m_].view_as(layer.weight))
                     k += m_
-            d_pre = F.act_bwd(pre_b, sigma_b, d_sig_b, 'truncexp')
-            g_out_b = torch.cat([d_pre[:, None], dx_b[:, :nb_out - 1], self._zeros(total_b * (wb1.shape[0] - nb_out), dev).view(total_b, -1)], dim=-1)
-            b1.weight.grad.add_(F.gemm_tn(g_out_b, hid_b)[:nb_out])
+            # [d density through TruncExp | d features | 0] of the padded output, one pass
+            g_out_b = F.geo_out_grad(d_sig_b, dx_b[:, :nb_out - 1], wb1.shape[0], out=out_b, act='truncexp', y_col0=sigma_b)
+            F.gemm_tn(g_out_b, hid_b, out=b1.weight.grad, accumulate=True, head=nb_out)
             d_hid_b = F.gemm_nn(g_out_b, wb1)
             F.gemm_tn(d_hid_b, enc_b, mask=hid_b, out=b0.weight.grad, accumulate=True)
             d_enc_b = F.gemm_nn(d_hid_b, b0.weight, mask=hid_b)
             F.hashgrid_bwd(xyz_b, tb, d_enc_b, emb_b.desc, dtable=tb.grad, workspace=self._scatter_ws('bkg', emb_b.desc, total_b, dev))
         # ---- foreground backward
-        loss_eik = rays_o.new_zeros((1,))
         if S > 0:
             zr = self._zeros(4 * R, dev)       # (read-only zero upstream gradients)
-            d_sdf, d_rad, d_normal, d_s_ray = F.neus_render_bwd(sdf, rgb_s, normal, pk, rays_d, s_dev, cos_anneal, bkg_color, d_rgb.contiguous(),
-                                                                zr[:R], zr[:R], zr[R:4 * R].view(R, 3), d_tlast.contiguous())
+            d_sdf, d_rad, d_normal, d_s_ray = F.neus_render_bwd(sdf, rgb_s, normal, pk, rays_d, s_dev, cos_anneal, bkg_color, d_rgb,
+                                                                zr[:R], zr[:R], zr[R:4 * R].view(R, 3), d_tlast)
             dx_r, dw_r, _ = F.mlp_bwd(rad_in, rad_w, None, rad._fused_desc, rgb_s, rad_acts, d_rad, want_dx=True, dweights=rad_g)
             if rad_g is None:     # (the radiance weights are separate nn.Linear tensors: not back to back, the kernel's flat gradient is split back)
                 k = 0
@@ -297,34 +294,32 @@ class FusedNeusNgpStep:
                     m_ = layer.weight.numel()
                     layer.weight.grad.add_(dw_r[k:k + m_].view_as(layer.weight))
                     k += m_
-            d_normal.add_(dx_r[:, 3 + n_sh:6 + n_sh])
-            loss_eik, _ = F.eikonal_packed(normal, pk, R, self.eik_w, d_normal=d_normal)       # value + gradient, added into d_normal
+            # Eikonal value + gradient and the radiance net's gradient of its normal inputs, both added into d_normal in one pass
+            F.eikonal_packed(normal, pk, R, self.eik_w, d_normal=d_normal, loss=losses[1:2], add_src=dx_r[:, 3 + n_sh:6 + n_sh], loss_is_clear=True)
             # the normals' gradient: to the Jacobian row they were built from (its table part joins the first-order scatter below)
             d_jac, _, _ = F.hashgrid_bwd_bwd(pts, d_normal, table, jac, emb.desc, want_ddout=True, want_dtable=False, want_d2xyz=False)
             # the sdf net, first output's Jacobian included (ops.autograd.SdfMlpJacFn.backward)
-            g_out = torch.cat([d_sdf[:, None], dx_r[:, 6 + n_sh:6 + n_sh + n_out - 1], self._zeros(S * (w2.shape[0] - n_out), dev).view(S, -1)], dim=-1)
-            w20 = w2[0]
+            g_out = F.geo_out_grad(d_sdf, dx_r[:, 6 + n_sh:6 + n_sh + n_out - 1], w2.shape[0])       # [d sdf | d features | 0]
             dz = F.gemm_nn(g_out, w2)
-            dw2 = F.gemm_tn(g_out, hid)
+            F.gemm_tn(g_out, hid, out=l1.weight.grad, accumulate=True, head=n_out)
             u = F.gemm_nt(d_jac, w1, None)
-            dz, su = F.sdf_jac_dz(dz, u, sg, (beta * w20).contiguous())
-            dw2[0] += su.sum(0)
-            dw1 = F.gemm_tn(sg, d_jac) * w20[:, None]
+            # dz through the softplus + the Jacobian path's curvature term; s * W2[0] (the operand of that path's first-layer gradient) in u's place;
+            # the path's gradient of W2[0] - the column sums of s u - straight into the last layer's gradient row
+            dz, sw = F.sdf_jac_dz2(dz, u, sg, prep['bw20'], w2[0], l1.weight.grad[0])
+            F.gemm_tn(sw, d_jac, out=l0.weight.grad, accumulate=True)
             d_enc = F.gemm_nn(dz, w1)
-            l0.weight.grad.add_(dw1)
             F.gemm_tn(dz, enc, out=l0.weight.grad, accumulate=True)
-            l1.weight.grad.add_(dw2[:n_out])
             # the table: through the encoding (d_enc) and through its input gradient (d_normal on J^T jac), ONE accumulation pass for both
             F.hashgrid_bwd_first_second(pts, d_enc, d_normal, jac, emb.desc, table.grad, self._scatter_ws('fg', emb.desc, 3 * S, dev))
             # scale = exp(inv_s * speed)
-            fg.inv_s.grad.add_((d_s_ray.sum() * scale.detach().reshape(()) * float(fg.speed_factor)).reshape(fg.inv_s.shape))
+            F.sum_scale_add(d_s_ray, fg.inv_s.grad, float(fg.speed_factor), s_dev)
         # ---- optimiser
         if self.apply_optimizer:
             self.opt.step()
             if self.ema is not None:
                 self.ema.ema_step()
         self.steps += 1
-        total = loss_img + loss_eik[0]
+        total = losses.sum()
         out = {'rgb': rgb.view(b, n, 3), 'depth': depth.view(b, n), 'mask': mask_f.view(b, n), 'normal': nrm_f.view(b, n, 3),
-               'params': {'scale': scale.detach().reshape(())}}
-        return out, {'sum': total, 'names': [self.img_name, self.eik_name], self.img_name: loss_img, self.eik_name: loss_eik[0]}
+               'params': {'scale': s_dev.reshape(())}}
+        return out, {'sum': total, 'names': [self.img_name, self.eik_name], self.img_name: losses[0], self.eik_name: losses[1]}

@@ -398,6 +398,10 @@ int arcn_gemm_nn(const float *dy, const float *mask, int64_t ld_dy, const float 
 int64_t arcn_gemm_tn_scratch_floats(int64_t n_rows, int N, int K);
 int arcn_gemm_tn(const float *dy, const float *mask, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *scratch,
                  int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int accumulate, void *stream);
+/* arcn_gemm_tn keeping only the first n_head of the N rows: dw (n_head, K) (+)= (dy^T x)[:n_head] - the weight gradient of a layer whose
+ * output is padded to a multiple of 4 columns, straight into the layer's own (unpadded) gradient buffer. */
+int arcn_gemm_tn_head(const float *dy, const float *mask, int64_t ld_dy, const float *x, int64_t ld_x, float *dw, float *scratch,
+                      int64_t scratch_floats, int64_t n_rows, const int32_t *n_ptr, int N, int K, int n_head, int accumulate, void *stream);
 /* The same three products on the bf16 matrix rate at f32 accuracy ("split" forms): every f32 operand is EXACTLY hi + mid + lo in three
  * bf16 numbers, and the six partial products down to 2^-16 are accumulated in f32 (what is dropped is < 2^-24 of the product, below an
  * f32 multiply's own rounding); 6 v_mfma_f32_16x16x32_bf16 replace 8 v_mfma_f32_16x16x4_f32 per 32 reduction elements (2.67 x the
@@ -462,6 +466,35 @@ int arcn_act_col_scale(const float *x, int64_t ld, float *y, int64_t n, const in
 /* One elementwise pass of ops.autograd.SdfMlpJacFn's backward (the NeuS-on-hash-grid sdf net with its Jacobian as an explicit output):
  * dz = dh s + c_j u s (1 - s), su = s u over an (n, H) hidden layer, c (H) = beta W2[0]; dz / su may alias dh / u. */
 int arcn_sdf_jac_dz(const float *dh, const float *u, const float *s, const float *c, float *dz, float *su, int64_t n, int H, void *stream);
+/* The passes BETWEEN the kernels of the NeuS-on-hash-grid + MultiVol training step (trainer.FusedNeusNgpStep; csrc/step_glue.hip), each
+ * one group of the reference's elementwise torch expressions in one launch:
+ *   arcn_neus_step_prep  the per-step derived weights of the two geometry nets (sdf_model.py:42-101, base_network.py:30-44, neus_model.py:221-228):
+ *     w2p (n_pad, H) = the sdf net's last layer l1w (n_out, H) padded with zero rows; w1j (H, E) = w1 * l1w[0][:, None] (the weight the Jacobian
+ *     row of the first output is a product with); bw20 (H) = beta * l1w[0]; scale_out[0] = exp(inv_s[0] * speed) (optional);
+ *     wb1p (nb_pad, Hb) = the background density net's last layer padded (bkg_l1w NULL: none).
+ *   arcn_geo_out_grad    g_out (n, n_pad) = [d_col0 * act'(out[:, 0]) | d_feat (n_feat columns at row stride ld_feat) | 0]: the gradient of a
+ *     geometry net's padded output row from the gradients of its first column THROUGH its activation (act 0: as it is; y_col0 optional =
+ *     act(out[:, 0])) and of its feature columns (linear_network_module.py GeoNet.forward).
+ *   arcn_neus_blend_loss rgb = rgb_f + T rgb_b, depth = depth_f + T depth_b (full_model.py:278-330, `rgb` blending), loss[0] = weight * mean
+ *     Huber_delta(rgb - target) (huber_delta <= 0: weight * mean squared error; img_loss.py:60-100), loss[1] = 0 (the accumulator of the pass
+ *     that follows, arcn_eikonal_packed with accumulate bit 1), d_rgb, d_tlast = sum_c d_rgb rgb_b, d_rgb_b = T d_rgb.  workspace:
+ *     arcn_neus_blend_loss_workspace_words() 32-bit words of device memory, word 0 ZERO before the first call (the call leaves it zero): the
+ *     workgroups' partial losses are added by the last of them in index order - no float atomics, the same bits every run.
+ *   arcn_sdf_jac_dz2     arcn_sdf_jac_dz with the by-products of the weight gradients: dz as there, sw = s * w (w (H) = l1w[0]; sw^T d_jac is the
+ *     Jacobian path's gradient of the first layer), colsum[j] += sum_i s u (the Jacobian path's gradient of l1w[0]); dz / sw may alias dh / u.
+ *   arcn_sum_scale_add   dst[0] += factor * scale_dev[0] * sum(src[0..n)) (scale_dev optional): the gradient of inv_s from the per-ray d scale. */
+int arcn_neus_step_prep(const float *w1, const float *l1w, int H, int E, int n_out, int n_pad, float beta, const float *inv_s, float speed,
+                        float *w2p, float *w1j, float *bw20, float *scale_out, const float *bkg_l1w, int Hb, int nb_out, int nb_pad, float *wb1p,
+                        void *stream);
+int arcn_geo_out_grad(const float *d_col0, const float *out, int64_t ld_out, const float *y_col0, int act, float beta, const float *d_feat,
+                      int64_t ld_feat, int n_feat, int n_pad, float *g_out, int64_t n, void *stream);
+int64_t arcn_neus_blend_loss_workspace_words(void);
+int arcn_neus_blend_loss(const float *rgb_f, const float *depth_f, const float *t_last, const float *rgb_b, const float *depth_b,
+                         const float *target, int64_t n_rays, float huber_delta, float weight, float *rgb, float *depth, float *d_rgb,
+                         float *d_tlast, float *d_rgb_b, float *loss, uint32_t *workspace, void *stream);
+int arcn_sdf_jac_dz2(const float *dh, const float *u, const float *s, const float *c, const float *w, float *dz, float *sw, float *colsum,
+                     int64_t n, int H, void *stream);
+int arcn_sum_scale_add(const float *src, int64_t n, const float *scale_dev, float factor, float *dst, void *stream);
 /* The tone mappers of HDR-NeRF (arcnerf/models/hdrnerf_model.py:44-75: per colour channel DenseLayer(1, W) + ReLU, DenseLayer(W, 1) +
  * sigmoid on ln(exposure) + log radiance) with the hidden layer in registers.  x / y / dy / dx (n, C) row-major, params / dparams
  * (C, 3 W + 1) = per channel [w1 (W) | b1 (W) | w2 (W) | b2], W <= 128.  bwd: dx may be NULL; dparams is overwritten (workgroup partials
@@ -571,9 +604,11 @@ int arcn_neus_sections(const float *zvals_dense, const int32_t *counts, const in
 /* EikonalLoss (arcnerf/loss/geo_loss.py:12-70, MSE on |n| over `normal_pts`, plain mean) evaluated on the PACKED normals with the dense
  * layout's weights: loss[0] = weight * mean over the (n_rays, p_dense) slots of (|n| - 1)^2 where slot j of a ray = its point
  * min(j, n - 1) and rays without points hold a unit default normal; d_normal (n_pts,3) = its gradient (accumulate: added).  The dense
- * (n_rays, p_dense, 3) tensor the reference's loss reads is never built.  loss (DEVICE, optional) is cleared by the call. */
+ * (n_rays, p_dense, 3) tensor the reference's loss reads is never built.  accumulate bit 0: the gradient is ADDED to d_normal; bit 1: the
+ * loss is added to loss[0] as it stands (else loss - DEVICE, optional - is cleared by the call).  add_src (optional, rows of 3 floats at
+ * row stride ld_add): a second incoming gradient of the normals joined in the same pass (the radiance net's input gradient). */
 int arcn_eikonal_packed(const float *normal, const int32_t *ray_id, const int32_t *offsets, int64_t n_pts, int64_t n_rays, int p_dense,
-                        float weight, int accumulate, float *d_normal, float *loss, void *stream);
+                        float weight, int accumulate, const float *add_src, int64_t ld_add, float *d_normal, float *loss, void *stream);
 int arcn_neus_slots_fwd(const float *packed, const int32_t *offsets, int64_t n_rays, int p_dense, const float *dflt_host, float *dense,
                         void *stream);
 int arcn_neus_slots_bwd(const float *d_dense, const int32_t *offsets, int64_t n_rays, int p_dense, float *d_packed, void *stream);

@@ -1,0 +1,157 @@
+"""The passes between the kernels of trainer.FusedNeusNgpStep (csrc/step_glue.hip) against the torch expressions they replace - the reference's
+own elementwise code (sdf_model.py:42-101, base_network.py:30-44, full_model.py:278-330, img_loss.py:60-100, geo_loss.py:12-70) - plus the
+output-poison check: the buffers this round stopped zero-filling are written in full by their kernels."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def test_neus_step_prep(gpu):
+    from arcnerf_amd.ops import functional as F
+    g = torch.Generator().manual_seed(0)
+    w1, l1w, bl1 = torch.randn(64, 32, generator=g).to(gpu), torch.randn(17, 64, generator=g).to(gpu), torch.randn(17, 64, generator=g).to(gpu)
+    inv_s = torch.tensor([0.3], device=gpu)
+    o = F.neus_step_prep(w1, l1w, 100.0, inv_s, 10.0, bl1)
+    assert o['w2p'].shape == (20, 64) and torch.equal(o['w2p'][:17], l1w) and float(o['w2p'][17:].abs().max()) == 0
+    assert torch.equal(o['wb1p'][:17], bl1) and float(o['wb1p'][17:].abs().max()) == 0
+    assert torch.equal(o['w1j'], w1 * l1w[0][:, None]) and torch.equal(o['bw20'], 100.0 * l1w[0])
+    assert abs(float(o['scale']) - float(torch.exp(inv_s * 10.0))) <= 2e-6 * float(torch.exp(inv_s * 10.0))
+    for k in ('w2p', 'w1j', 'bw20'):
+        assert o[k].data_ptr() % 16 == 0
+    o = F.neus_step_prep(w1, l1w, 100.0)       # no scale, no background net
+    assert o['scale'] is None and o['wb1p'] is None and torch.equal(o['w2p'][:17], l1w)
+
+
+@pytest.mark.parametrize('act', [None, 'truncexp', 'relu'])
+def test_geo_out_grad(gpu, act):
+    from arcnerf_amd.ops import functional as F
+    g = torch.Generator().manual_seed(1)
+    n = 5003
+    out = torch.randn(n, 20, generator=g).to(gpu) * 3
+    out[:5, 0] = torch.tensor([-20.0, 20.0, 14.9, 15.1, 0.0], device=gpu)
+    dx = torch.randn(n, 38, generator=g).to(gpu)
+    d0 = torch.randn(n, generator=g).to(gpu)
+    got = F.geo_out_grad(d0, dx[:, 22:38], 20, out=out, act=act)
+    if act is None:
+        c0 = d0
+    else:
+        x = out[:, 0].contiguous()
+        c0 = F.act_bwd(x, F.act_fwd(x, act), d0, act)
+    want = torch.cat([c0[:, None], dx[:, 22:38], torch.zeros(n, 3, device=gpu)], dim=-1)
+    assert torch.equal(got, want)
+    if act is not None:     # with the forward's own output handed over
+        y = F.act_col_scale(out, act, 1.0)
+        assert torch.equal(F.geo_out_grad(d0, dx[:, 22:38], 20, out=out, act=act, y_col0=y), want)
+
+
+@pytest.mark.parametrize('delta', [0.1, None])
+def test_neus_blend_loss(gpu, delta):
+    from arcnerf_amd.ops import functional as F
+    g = torch.Generator().manual_seed(2)
+    for R in (1, 777, 4096, 9001):
+        rf, rb, img = (torch.rand(R, 3, generator=g).to(gpu) for _ in range(3))
+        df, db, T = (torch.rand(R, generator=g).to(gpu) for _ in range(3))
+        o = F.neus_blend_loss(rf, df, T, rb, db, img, delta, 5.0)
+        rgb = rf + T[:, None] * rb
+        assert torch.equal(o['rgb'], rgb) and torch.equal(o['depth'], df + T * db)
+        if delta is not None:
+            loss, d_rgb = F.huber_loss_grad(rgb, img, delta, 5.0)
+            loss = float(loss[0])
+        else:
+            diff = rgb - img
+            loss, d_rgb = float((diff.double() ** 2).mean() * 5.0), diff * (2.0 * 5.0 / diff.numel())
+        assert abs(float(o['loss'][0]) - loss) <= 2e-6 * abs(loss) and float(o['loss'][1]) == 0.0
+        assert torch.allclose(o['d_rgb'], d_rgb, rtol=1e-6, atol=0)
+        assert torch.allclose(o['d_tlast'], (d_rgb * rb).sum(-1), rtol=1e-5, atol=1e-9)
+        assert torch.allclose(o['d_rgb_b'], d_rgb * T[:, None], rtol=1e-6, atol=0)
+        o2 = F.neus_blend_loss(rf, df, T, rb, db, img, delta, 5.0)       # one workgroup, fixed order: the same bits
+        assert torch.equal(o['loss'], o2['loss'])
+
+
+@pytest.mark.parametrize('H', [64, 128, 256])
+def test_sdf_jac_dz2(gpu, H):
+    from arcnerf_amd.ops import functional as F
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 333, 70001):
+        dh, u = torch.randn(n, H, generator=g).to(gpu), torch.randn(n, H, generator=g).to(gpu)
+        s = torch.rand(n, H, generator=g).to(gpu)
+        c, w = torch.randn(H, generator=g).to(gpu), torch.randn(H, generator=g).to(gpu)
+        dz0, su = F.sdf_jac_dz(dh.clone(), u.clone(), s, c)
+        acc0 = torch.randn(H, generator=g).to(gpu)
+        acc = acc0.clone()
+        dz, sw = F.sdf_jac_dz2(dh.clone(), u.clone(), s, c, w, acc)
+        assert torch.equal(dz, dz0) and torch.equal(sw, s * w)
+        want = su.double().sum(0)
+        assert float((acc.double() - acc0.double() - want).abs().max()) <= 1e-5 * max(1.0, float(su.double().abs().sum(0).max()))
+
+
+def test_sum_scale_add_and_gemm_tn_head(gpu):
+    from arcnerf_amd.ops import functional as F
+    g = torch.Generator().manual_seed(4)
+    src = torch.randn(4096, generator=g).to(gpu)
+    dst = torch.tensor([0.25], device=gpu)
+    sc = torch.tensor([3.0], device=gpu)
+    F.sum_scale_add(src, dst, 10.0, sc)
+    assert abs(float(dst) - (0.25 + 30.0 * float(src.double().sum()))) <= 1e-4 * (1 + abs(30.0 * float(src.double().abs().sum())) * 1e-2)
+    for n in (100, 50001):
+        dy, x = torch.randn(n, 20, generator=g).to(gpu), torch.randn(n, 64, generator=g).to(gpu)
+        full = F.gemm_tn(dy, x)
+        base = torch.randn(17, 64, generator=g).to(gpu)
+        out = base.clone()
+        guard = torch.cat([out.reshape(-1), torch.full((3 * 64,), 7.0, device=gpu)])      # the rows behind the head must stay untouched
+        view = guard[:17 * 64].view(17, 64)
+        F.gemm_tn(dy, x, out=view, accumulate=True, head=17)
+        assert torch.allclose(view, base + full[:17], rtol=1e-6, atol=1e-6) and float((guard[17 * 64:] - 7.0).abs().max()) == 0
+        assert torch.equal(F.gemm_tn(dy, x, head=17), full[:17])
+
+
+def test_eikonal_packed_joins_a_second_gradient(gpu):
+    from arcnerf_amd.ops import functional as F
+    g = torch.Generator().manual_seed(5)
+    R = 300
+    cnt = torch.randint(0, 40, (R,), generator=g)
+    cnt[::7] = 0
+    off = torch.zeros(R + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(cnt, 0)
+    S = int(off[-1])
+    ray_id = torch.repeat_interleave(torch.arange(R, dtype=torch.int32), cnt)
+    pk = {'ray_id': ray_id.to(gpu), 'offsets': off.to(gpu), 'p_dense': int(cnt.max())}
+    normal = torch.randn(S, 3, generator=g).to(gpu)
+    wide = torch.randn(S, 38, generator=g).to(gpu)
+    d0 = torch.randn(S, 3, generator=g).to(gpu)
+    loss_a, d_a = F.eikonal_packed(normal, pk, R, 0.1, d_normal=(d0 + wide[:, 19:22]).contiguous())
+    acc = torch.tensor([123.0, 0.0], device=gpu)
+    loss_b, d_b = F.eikonal_packed(normal, pk, R, 0.1, d_normal=d0.clone(), loss=acc[1:2], add_src=wide[:, 19:22], loss_is_clear=True)
+    assert torch.allclose(d_a, d_b, rtol=1e-6, atol=1e-7)
+    assert abs(float(loss_a) - float(acc[1])) <= 1e-5 * abs(float(loss_a)) and float(acc[0]) == 123.0
+    F.eikonal_packed(normal, pk, R, 0.1, d_normal=d0.clone(), loss=acc[1:2], loss_is_clear=True)      # an accumulator: twice the value now
+    assert abs(float(acc[1]) - 2 * float(loss_a)) <= 2e-5 * abs(float(loss_a))
+
+
+def test_unfilled_outputs_are_written_in_full():
+    """ARCN_POISON_OUTPUTS=1 fills every buffer that ops.functional hands to a kernel WITHOUT clearing it (the box intersections, the
+    cascade marcher's counts, the scans' maxima, the packed compositor's gradients) with NaN / 0x7f first: the tests that consume them -
+    samplers against the oracle, the packed compositor, the fused config-4 step against the module path - still pass"""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    env = dict(os.environ, ARCN_POISON_OUTPUTS='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', 'tests/test_gpu_composite.py', 'tests/test_gpu_models.py', 'tests/test_gpu_kernels.py',
+                        '-k', 'fused_neus or packed or multivol or aabb or neus'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout or '')[-1500:]
+    assert r.returncode == 0, tail
+    assert ' passed' in tail and 'no tests ran' not in tail, tail
