@@ -303,6 +303,89 @@ __global__ void __launch_bounds__(256) softplus_grad2_kernel(const float *__rest
     }
 }
 
+// softplus_grad / softplus_grad2 for a gradient that is ONE ROW broadcast over the samples (the last hidden layer of the sdf net's normal
+// chain: g = W_D[0], ops/sdf_chain.py).  The plain kernels wanted the row expanded to (n, H) first (a 134 MB copy per pass at 131072 x 256).
+//   softplus_grad_row : out = g_row[col] * s
+//   softplus_grad2_row: dz = h * g_row[col] * ds, colsum[col] += sum over the rows of h * s - the adjoint of the row itself, which is all the
+//                       caller needs of dg (no (n, H) write, no column-sum pass).  Column-stationary threads like sdf_jac_dz2_kernel.
+__global__ void __launch_bounds__(256) softplus_grad_row_kernel(const float *__restrict__ z, const float *__restrict__ g_row, float *__restrict__ out,
+                                                                int64_t n, int H, float beta, int from_y) {
+    const int64_t total = n * H;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        const f4v zv = *reinterpret_cast<const f4v *>(z + i), gv = *reinterpret_cast<const f4v *>(g_row + (int)(i % H));
+        f4v o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float sv, ds;
+            softplus_s(zv[k], beta, from_y, sv, ds);
+            o[k] = gv[k] * sv;
+        }
+        *reinterpret_cast<f4v *>(out + i) = o;
+    }
+}
+
+__global__ void __launch_bounds__(256) softplus_grad2_row_kernel(const float *__restrict__ z, const float *__restrict__ g_row, const float *__restrict__ h,
+                                                                 float *__restrict__ dz, float *__restrict__ colsum, int64_t n, int H, float beta,
+                                                                 int from_y) {
+    __shared__ float s_sum[256 * 4];
+    const int tpr = H >> 2, rows_per_trip = 256 / tpr;
+    const int col = (threadIdx.x % tpr) * 4, sub = threadIdx.x / tpr;
+    const f4v gv = *reinterpret_cast<const f4v *>(g_row + col);
+    f4v sum = {0.f, 0.f, 0.f, 0.f};
+    const int64_t step = (int64_t)gridDim.x * rows_per_trip;
+    for (int64_t row0 = (int64_t)blockIdx.x * rows_per_trip + sub; row0 < n; row0 += 4 * step) {
+        f4v zv[4], hv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t row = row0 + q * step;
+            if (row < n) {
+                zv[q] = *reinterpret_cast<const f4v *>(z + row * H + col);
+                hv[q] = *reinterpret_cast<const f4v *>(h + row * H + col);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t row = row0 + q * step;
+            if (row < n) {
+                f4v o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float sv, ds;
+                    softplus_s(zv[q][k], beta, from_y, sv, ds);
+                    sum[k] += hv[q][k] * sv;
+                    o[k] = hv[q][k] * gv[k] * ds;
+                }
+                *reinterpret_cast<f4v *>(dz + row * H + col) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_sum[threadIdx.x * 4 + k] = sum[k];
+    __syncthreads();
+    for (int j = threadIdx.x; j < H; j += 256) {
+        float t = 0.f;
+        for (int q = 0; q < rows_per_trip; ++q) t += s_sum[((j >> 2) + q * tpr) * 4 + (j & 3)];
+        if (t != 0.f) atomicAdd(colsum + j, t);
+    }
+}
+
+// out (n, n_cols) = [a[:, :na] / div | b[:, :nb] / div | 0]: the input of the layer behind a skip connection ([h | e] / sqrt2,
+// linear_network_module.py:174-197) and its adjoints, from two row-major sources read where they lie (row strides ld_a, ld_b; b may be NULL).
+// "/ div" is torch's CUDA division by a python scalar - a product with the float reciprocal (BinaryDivTrueKernel.cu: a * (1 / b) when b is a
+// CPU scalar) - so the result equals the module path's `x / math.sqrt(2)` bit for bit (inv = 1: the values themselves).  One thread per element.
+__global__ void __launch_bounds__(256) concat2_div_kernel(const float *__restrict__ a, int64_t ld_a, int na, const float *__restrict__ b, int64_t ld_b,
+                                                          int nb, float inv, float *__restrict__ out, int n_cols, int64_t n) {
+    const int64_t total = n * n_cols;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / n_cols;
+        const int c = (int)(e - i * n_cols);
+        float v = 0.f;
+        if (c < na) v = a[i * ld_a + c] * inv;
+        else if (c < na + nb) v = b[i * ld_b + (c - na)] * inv;
+        out[e] = v;
+    }
+}
+
 // backward of the sdf net with an explicit Jacobian output (ops.autograd.SdfMlpJacFn): per element of the (n, H) hidden layer
 //   dz = dh s + c_j u s (1 - s),  su = s u      (c = beta W2[0]; dz and su may alias dh and u)
 __global__ void __launch_bounds__(256) sdf_jac_dz_kernel(const float *__restrict__ dh, const float *__restrict__ u, const float *__restrict__ s,
@@ -695,6 +778,37 @@ ARCN_EXPORT int arcn_softplus_grad2(const float *z, const float *g, const float 
     else
         hipLaunchKernelGGL(softplus_grad2_kernel<false>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), z, g, h, dg, dz, n, beta, from_y);
     return check_launch("softplus_grad2");
+}
+
+ARCN_EXPORT int arcn_softplus_grad_row(const float *z, const float *g_row, float *out, int64_t n, int H, float beta, int from_y, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!z || !g_row || !out || H < 4 || (H & 3) != 0) return einval("softplus_grad_row: missing argument or width not a multiple of 4");
+    if (((uintptr_t)z | (uintptr_t)g_row | (uintptr_t)out) & 15u) return einval("softplus_grad_row: 16-byte aligned tensors");
+    hipLaunchKernelGGL(softplus_grad_row_kernel, dim3(grid_for(n * H / 4)), dim3(256), 0, as_stream(stream), z, g_row, out, n, H, beta, from_y);
+    return check_launch("softplus_grad_row");
+}
+
+ARCN_EXPORT int arcn_softplus_grad2_row(const float *z, const float *g_row, const float *h, float *dz, float *colsum, int64_t n, int H, float beta,
+                                        int from_y, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!z || !g_row || !h || !dz || !colsum || H < 4 || (H & 3) != 0 || H > 1024 || 256 % (H >> 2) != 0)
+        return einval("softplus_grad2_row: missing argument or width not 4 * (a divisor of 256)");
+    if (((uintptr_t)z | (uintptr_t)g_row | (uintptr_t)h | (uintptr_t)dz) & 15u) return einval("softplus_grad2_row: 16-byte aligned tensors");
+    const int rows_per_trip = 256 / (H >> 2);
+    int64_t blocks = ceil_div<int64_t>(n, rows_per_trip * 8);
+    if (blocks > 256) blocks = 256;      // (one same-address float atomic per column and workgroup, see arcn_sdf_jac_dz2)
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(softplus_grad2_row_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, g_row, h, dz, colsum, n, H, beta, from_y);
+    return check_launch("softplus_grad2_row");
+}
+
+ARCN_EXPORT int arcn_concat2_div(const float *a, int64_t ld_a, int na, const float *b, int64_t ld_b, int nb, float div, float *out, int n_cols,
+                                 int64_t n, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!a || !out || na < 1 || ld_a < na || nb < 0 || (nb > 0 && (!b || ld_b < nb)) || n_cols < na + nb || !(div != 0.f))
+        return einval("concat2_div: missing / invalid argument");
+    hipLaunchKernelGGL(concat2_div_kernel, dim3(grid_for(n * n_cols)), dim3(256), 0, as_stream(stream), a, ld_a, na, b, ld_b, nb, 1.0f / div, out, n_cols, n);
+    return check_launch("concat2_div");
 }
 
 ARCN_EXPORT int arcn_sdf_jac_dz(const float *dh, const float *u, const float *s, const float *c, float *dz, float *su, int64_t n, int H, void *stream) {

@@ -105,6 +105,13 @@ class GeoNet(EncoderMLPGeoNet):
         return geo, feat, grad
 
     def forward(self, x):
+        if not torch.is_grad_enabled() and os.environ.get('ARCN_SDF_NOGRAD_FAST', '1') != '0':
+            # a graph-free pass of the softplus sdf net (NeuS evaluates it in every importance-sampling round): the cached weight-normed, padded
+            # weights, activations in the products' epilogues, the skip concatenation as one kernel - no hooks, pads, cat or div launches
+            from ....ops.sdf_chain import sdf_forward_nograd
+            r = sdf_forward_nograd(self, x)
+            if r is not None:
+                return r
         x_embed = self.embed_fn(x)
         if all(self.layers[i].out_features % 4 == 0 for i in self.skips if i <= self.D):
             # (63 -> 64 columns ONCE where the layers run on the HIP products: layer 0 and the skip concat both take the padded

@@ -718,6 +718,45 @@ def softplus_grad(z, g, beta, from_y=False):
     return out
 
 
+def softplus_grad_row(z, g_row, beta, from_y=False):
+    """g_row[col] * sigmoid(beta z) for z (n, H) and ONE gradient row (H) shared by all samples"""
+    _req(z, g_row)
+    z, g_row = _f32(z), _f32(g_row)
+    n, H = z.shape
+    assert g_row.numel() == H
+    out = torch.empty_like(z)
+    N.check(N.lib().arcn_softplus_grad_row(N.ptr(z), N.ptr(g_row), N.ptr(out), n, H, float(beta), int(from_y), N.stream()), 'softplus_grad_row')
+    return out
+
+
+def softplus_grad2_row(z, g_row, h, colsum, beta, from_y=False):
+    """backward of softplus_grad_row for an incoming h (n, H): -> dz = h * g_row * ds; colsum (H) += the column sums of h * s"""
+    _req(z, g_row, h, colsum)
+    z, g_row, h = _f32(z), _f32(g_row), _f32(h)
+    n, H = z.shape
+    assert g_row.numel() == H and colsum.numel() == H and colsum.is_contiguous() and colsum.dtype == torch.float32
+    dz = torch.empty_like(z)
+    N.check(N.lib().arcn_softplus_grad2_row(N.ptr(z), N.ptr(g_row), N.ptr(h), N.ptr(dz), N.ptr(colsum), n, H, float(beta), int(from_y), N.stream()),
+            'softplus_grad2_row')
+    return dz
+
+
+def concat2_div(a, b, div, n_cols):
+    """(n, n_cols) = [a / div | b / div | 0]; a (n, na), b (n, nb) | None: column slices of row-major tensors; `/ div` as torch's CUDA kernels
+    divide by a python scalar (a product with the float reciprocal)"""
+    _req(a, b)
+    n = a.shape[0]
+    assert a.dim() == 2 and a.dtype == torch.float32 and a.stride(1) == 1
+    nb, ld_b = 0, 0
+    if b is not None:
+        assert b.dim() == 2 and b.dtype == torch.float32 and b.stride(1) == 1 and b.shape[0] == n
+        nb, ld_b = b.shape[1], b.stride(0)
+    out = torch.empty((n, int(n_cols)), dtype=torch.float32, device=a.device)
+    N.check(N.lib().arcn_concat2_div(a.data_ptr(), int(a.stride(0)), int(a.shape[1]), None if b is None else b.data_ptr(), int(ld_b), int(nb), float(div),
+                                    N.ptr(out), int(n_cols), n, N.stream()), 'concat2_div')
+    return out
+
+
 def softplus_grad_sum(z, g, g2, beta, from_y=False):
     """(g + g2) * sigmoid(beta z) in one pass (softplus_grad of the sum of two incoming gradients)"""
     _req(z, g, g2)

@@ -83,6 +83,64 @@ def effective_params(geo):
 _SQ2 = math.sqrt(2)
 
 
+def padded_params(geo):
+    """(ws, bs, w_sdf): the effective (weight-normed) weights and biases of every layer as the kernels take them - input columns and output
+    rows padded to multiples of 4 (63 -> 64 / 319 -> 320 columns, 257 -> 260 rows; zero rows and columns that never leave the node) - and the
+    first row of the last layer, under no_grad.  Built ONCE per parameter state: the key is every parameter's (pointer, version) plus
+    utils.param_epoch (the optimiser kernels write through raw pointers).  A NeuS step evaluates this net in seven graph-free passes and one
+    differentiated one; per pass it was 9 weight-norm launches + 18 pads."""
+    from ..utils import param_epoch
+    key = (param_epoch.current(),) + tuple((p.data_ptr(), p._version) for p in geo.layers.parameters())
+    c = getattr(geo, '_padded_cache', None)
+    if c is not None and c[0] == key:
+        return c[1]
+    pad = torch.nn.functional.pad
+    with torch.no_grad():
+        params = effective_params(geo)
+        D = geo.D
+        ws = [pad(params[2 * i], (0, (-params[2 * i].shape[1]) % 4, 0, (-params[2 * i].shape[0]) % 4)).contiguous() for i in range(D)]
+        bs = [None if params[2 * i + 1] is None else pad(params[2 * i + 1], (0, (-params[2 * i + 1].shape[0]) % 4)) for i in range(D)]
+        n_last = params[2 * D].shape[0]
+        ws.append(pad(params[2 * D], (0, (-params[2 * D].shape[1]) % 4, 0, (-n_last) % 4)).contiguous())
+        bs.append(None if params[2 * D + 1] is None else pad(params[2 * D + 1], (0, (-n_last) % 4)))
+        w_sdf = ws[D][0].contiguous()
+    val = (ws, bs, w_sdf)
+    object.__setattr__(geo, '_padded_cache', (key, val))
+    return val
+
+
+def sdf_forward_nograd(geo, x):
+    """GeoNet.forward (linear_network_module.py:174-197) -> (sdf (..., 1), feature (..., W_feat)) for a pass that builds no graph, on the
+    cached padded weights: encoding, D softplus layers with the activation in the product's epilogue, the skip concatenation [h | e] / sqrt2
+    as one kernel, the last layer - no module hooks (weight norm), no per-layer pads, no torch cat / div.  None where it does not apply."""
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in geo.layers.parameters())):
+        return None
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.numel() > 0 and x.shape[-1] == 3):
+        return None
+    from .autograd import _hip_linear_enabled
+    if not _hip_linear_enabled() or os.environ.get('ARCN_SOFTPLUS_FUSED', '1') == '0' or os.environ.get('ARCN_LINEAR_SOFTPLUS', '1') == '0':
+        return None
+    spec = make_sdf_spec(geo, 0)
+    if spec is None or any(p.dtype != torch.float32 or not p.is_cuda for p in geo.layers.parameters()):
+        return None
+    ws, bs, _ = padded_params(geo)
+    shp = x.shape
+    xc = x.detach().reshape(-1, 3).contiguous()
+    S, dev = xc.shape[0], xc.device
+    div = _SQ2 if spec.norm_skip else 1.0
+    with torch.no_grad(), F.split_weight_scope():
+        a0 = torch.empty((S, ws[0].shape[1]), dtype=torch.float32, device=dev)
+        F.freq_fwd_cols(xc, spec.pos_freqs, spec.pos_input, a0)
+        cur = a0
+        for i in range(spec.D):
+            h = F.gemm_nt(cur, ws[i], bs[i], act='softplus', beta=spec.beta)
+            cur = F.concat2_div(h[:, :spec.out_dims[i]], a0[:, :spec.ed], div, ws[i + 1].shape[1]) if i in spec.skips else h
+        out = F.gemm_nt(cur, ws[spec.D], bs[spec.D])
+    n_out = 1 + spec.W_feat
+    out = out[:, :n_out].reshape(*shp[:-1], n_out)
+    return out[..., :1], out[..., 1:]
+
+
 class SdfChainFn(torch.autograd.Function):
     """(out (n, r4(1 + W_feat)) = [sdf | feature | 0 ...], normal (n, 3)) = sdf net and its input gradient at x (n, 3)"""
 
@@ -91,15 +149,10 @@ class SdfChainFn(torch.autograd.Function):
         n, dev = x.shape[0], x.device
         D, skips, ed, beta = spec.D, spec.skips, spec.ed, spec.beta
         want = any(ctx.needs_input_grad[2:])
-        pad = torch.nn.functional.pad
-        with torch.no_grad():
-            # (63 -> 64 / 319 -> 320 input columns; a reduced skip layer's 193 -> 196 output rows, zero rows whose columns never leave the node)
-            ws = [pad(params[2 * i], (0, (-params[2 * i].shape[1]) % 4, 0, (-params[2 * i].shape[0]) % 4)).contiguous() for i in range(D)]
-            bs = [None if params[2 * i + 1] is None else pad(params[2 * i + 1], (0, (-params[2 * i + 1].shape[0]) % 4)) for i in range(D)]
-            n_last = params[2 * D].shape[0]
-            ws.append(pad(params[2 * D], (0, (-params[2 * D].shape[1]) % 4, 0, (-n_last) % 4)).contiguous())  # (257 -> 260 output rows)
-            bs.append(None if params[2 * D + 1] is None else pad(params[2 * D + 1], (0, (-n_last) % 4)))
-            w_sdf = ws[D][0].contiguous()                                                                      # g of the last hidden layer
+        # (63 -> 64 / 319 -> 320 input columns; a reduced skip layer's 193 -> 196 output rows, 257 -> 260 rows of the last layer: zero rows whose
+        # columns never leave the node; w_sdf = g of the last hidden layer.  The values of `params`, padded once per parameter state)
+        ws, bs, w_sdf = spec.padded
+        div = _SQ2 if spec.norm_skip else 1.0
         No = ws[D].shape[0]
         out_all = torch.empty((n, No), dtype=torch.float32, device=dev)
         normal = torch.empty((n, 3), dtype=torch.float32, device=dev)
@@ -118,17 +171,8 @@ class SdfChainFn(torch.autograd.Function):
                     h = F.gemm_nt(cur, ws[i], bs[i], act='softplus', beta=beta)
                     ins.append(cur)
                     hs.append(h)
-                    if i in skips:      # [h | e] (/ sqrt2) at the next layer's padded input width
-                        cat = torch.empty((S, ws[i + 1].shape[1]), dtype=torch.float32, device=dev)
-                        wo = spec.out_dims[i]
-                        if spec.norm_skip:
-                            torch.div(h[:, :wo], _SQ2, out=cat[:, :wo])
-                        else:
-                            cat[:, :wo].copy_(h[:, :wo])
-                        F.freq_fwd_cols(xc, spec.pos_freqs, spec.pos_input, cat[:, wo:])
-                        if spec.norm_skip:
-                            cat[:, wo:wo + ed].div_(_SQ2)
-                        cur = cat
+                    if i in skips:      # [h | e] (/ sqrt2) at the next layer's padded input width, one pass (e = the first layer's input)
+                        cur = F.concat2_div(h[:, :spec.out_dims[i]], a0[:, :ed], div, ws[i + 1].shape[1])
                     else:
                         cur = h
                 F.gemm_nt(cur, ws[D], bs[D], out=out_all[lo:hi])
@@ -139,8 +183,7 @@ class SdfChainFn(torch.autograd.Function):
                 g = None
                 for i in range(D - 1, -1, -1):
                     if i == D - 1:
-                        s = F.softplus_grad(hs[i], None, beta, True)
-                        p = s * w_sdf[:s.shape[1]]
+                        p = F.softplus_grad_row(hs[i], w_sdf[:hs[i].shape[1]], beta, True)      # (s * W_D[0], the row broadcast inside the kernel)
                         gs[i] = None      # (the row W_D[0] itself, kept implicit)
                     else:
                         gs[i] = g
@@ -152,14 +195,8 @@ class SdfChainFn(torch.autograd.Function):
                         ebar = e0.contiguous() if ebar is None else ebar + e0
                     elif (i - 1) in skips:
                         wo = spec.out_dims[i - 1]
-                        g = torch.empty((S, ws[i - 1].shape[0]), dtype=torch.float32, device=dev)
-                        g[:, wo:].zero_()
-                        if spec.norm_skip:      # (the division the module path's autograd performs, not a multiplication by the reciprocal)
-                            torch.div(abar[:, :wo], _SQ2, out=g[:, :wo])
-                            tail = abar[:, wo:wo + ed] / _SQ2
-                        else:
-                            g[:, :wo].copy_(abar[:, :wo])
-                            tail = abar[:, wo:wo + ed].contiguous()
+                        g = F.concat2_div(abar[:, :wo], None, div, ws[i - 1].shape[0])      # (the head / sqrt2, zero pad behind it)
+                        tail = abar[:, wo:wo + ed] / _SQ2 if spec.norm_skip else abar[:, wo:wo + ed].contiguous()
                         ebar = tail if ebar is None else ebar + tail
                     else:
                         g = abar
@@ -205,18 +242,13 @@ class SdfChainFn(torch.autograd.Function):
                     phat = F.gemm_nt(ahat, ws[i], None, ws=ctx.ws_nt[i])
                     tn(ps[i], ahat, i, False)
                     if i == D - 1:
-                        g_i = ctx.w_sdf[:hs[i].shape[1]].unsqueeze(0).expand(S, -1).contiguous()
-                    else:
-                        g_i = gs[i]
-                    ghat, dys[i] = F.softplus_grad2(hs[i], g_i, phat, beta, from_y=True)
-                    if i == D - 1:
-                        d_row0[:ghat.shape[1]] += ghat.sum(0)
-                    elif i in skips:
-                        wo = spec.out_dims[i]
-                        ahat = torch.empty((S, ws[i + 1].shape[1]), dtype=torch.float32, device=dev)
-                        ahat[:, wo + ed:].zero_()
-                        torch.div(ghat[:, :wo], div, out=ahat[:, :wo])
-                        torch.div(ehat[:, :ed], div, out=ahat[:, wo:wo + ed])
+                        # g is the row W_D[0]: its adjoint (the column sums of phat * s) goes straight into d_row0, ghat itself is not needed
+                        H = hs[i].shape[1]
+                        dys[i] = F.softplus_grad2_row(hs[i], ctx.w_sdf[:H], phat, d_row0[:H], beta, True)
+                        continue
+                    ghat, dys[i] = F.softplus_grad2(hs[i], gs[i], phat, beta, from_y=True)
+                    if i in skips:
+                        ahat = F.concat2_div(ghat[:, :spec.out_dims[i]], ehat[:, :ed], div, ws[i + 1].shape[1])
                     else:
                         ahat = ghat
             # DOWN: the ordinary backward with the second-order term joined in
@@ -225,10 +257,7 @@ class SdfChainFn(torch.autograd.Function):
             abar = F.gemm_nn(obar, ws[D], ws=ctx.ws_nn[D])
             for i in range(D - 1, -1, -1):
                 if i in skips:
-                    wo = spec.out_dims[i]
-                    hbar = torch.empty((S, ws[i].shape[0]), dtype=torch.float32, device=dev)
-                    hbar[:, wo:].zero_()
-                    torch.div(abar[:, :wo], div, out=hbar[:, :wo])
+                    hbar = F.concat2_div(abar[:, :spec.out_dims[i]], None, div, ws[i].shape[0])
                 else:
                     hbar = abar
                 zbar = F.softplus_grad(hs[i], hbar, beta, True) if dys[i] is None else F.softplus_grad_sum(hs[i], hbar, dys[i], beta, True)
@@ -261,6 +290,7 @@ def sdf_chain(geo_net, pts, chunk_pts):
     params = effective_params(geo_net)
     if any(p is not None and (p.dtype != torch.float32 or not p.is_cuda) for p in params):
         return None
+    spec.padded = padded_params(geo_net)
     out, normal = SdfChainFn.apply(pts.detach().contiguous(), spec, *params)
     # (one split node: its backward is one concatenation of the two gradients and the zero pad)
     geo, feat, _ = torch.split(out, [1, spec.W_feat, out.shape[1] - 1 - spec.W_feat], dim=-1)

@@ -9,6 +9,7 @@ parameters: same update rule (L2 weight decay added to the gradient, bias correc
 import torch
 
 from .ops import functional as F
+from .utils import param_epoch
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -141,6 +142,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        param_epoch.bump()      # (the kernels write the parameters through raw pointers: caches keyed on tensor versions must hear of it)
         if self._flat is not None:
             self._step_flat()
             return loss

@@ -26,6 +26,7 @@ import torch
 
 from . import _native as N
 from .ops import functional as F
+from .utils import param_epoch
 
 
 class NgpConfig:
@@ -804,6 +805,7 @@ class NgpPipeline:
         as in one process on the whole batch); equal shards: 1."""
         cfg, b = self.cfg, self.buf
         self.loss_scale = float(loss_scale)
+        param_epoch.bump()      # (this step's kernels rewrite the parameters through raw pointers)
         fused = self.fused_composite
         rgb, _, _ = self.forward(rays_o, rays_d, bkg_color, train=True, noise='auto', huber_target=target_rgb if fused else None)
         if self.prefetch_at == 5 and self.prefetch_depth >= 2 and grad_sync is None and all_reduce is None:

@@ -514,6 +514,19 @@ int arcn_softplus_grad(const float *z, const float *g, float *out, int64_t n, fl
  * term of a normal's second differentiation (base_network.py:30-44) - without a pass that adds them first */
 int arcn_softplus_grad_sum(const float *z, const float *g, const float *g2, float *out, int64_t n, float beta, int from_y, void *stream);
 int arcn_softplus_grad2(const float *z, const float *g, const float *h, float *dg, float *dz, int64_t n, float beta, int from_y, void *stream);
+/* The two softplus passes for a gradient that is ONE ROW g_row (H) broadcast over the n samples (the last hidden layer of the wide sdf net's
+ * normal chain, g = W_D[0]; base_network.py:30-44 through linear_network_module.py:174-197), z (n, H):
+ *   arcn_softplus_grad_row : out = g_row[col] * s
+ *   arcn_softplus_grad2_row: dz = h * g_row[col] * ds, colsum[col] += sum over the samples of h * s (the adjoint of the row: all a caller
+ *                            needs of dg); H = 4 * (a divisor of 256).
+ * arcn_concat2_div: out (n, n_cols) = [a[:, :na] / div | b[:, :nb] / div | 0] from two row-major sources at row strides ld_a / ld_b (b may be
+ * NULL with nb = 0): the skip concatenation [h | e] / sqrt2 of linear_network_module.py:174-197 and its adjoints; `/ div` = a product with the
+ * float reciprocal, the arithmetic of torch's CUDA division by a python scalar (bit-identical to the expression it replaces). */
+int arcn_softplus_grad_row(const float *z, const float *g_row, float *out, int64_t n, int H, float beta, int from_y, void *stream);
+int arcn_softplus_grad2_row(const float *z, const float *g_row, const float *h, float *dz, float *colsum, int64_t n, int H, float beta, int from_y,
+                            void *stream);
+int arcn_concat2_div(const float *a, int64_t ld_a, int na, const float *b, int64_t ld_b, int nb, float div, float *out, int n_cols, int64_t n,
+                     void *stream);
 int arcn_act_bwd(const float *x, const float *y, const float *dy, float *dx, int64_t n, int act, float beta,
                  void *stream);
 /* second backward of an elementwise activation, given the pre-activation x, the incoming dy of the first backward (dx = dy f'(x)) and

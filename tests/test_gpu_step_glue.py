@@ -155,3 +155,83 @@ def test_unfilled_outputs_are_written_in_full():
     tail = (r.stdout or '')[-1500:]
     assert r.returncode == 0, tail
     assert ' passed' in tail and 'no tests ran' not in tail, tail
+
+
+# ---- the wide sdf net's glue (ops/sdf_chain.py) ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('from_y', [True, False])
+def test_softplus_row_kernels(gpu, from_y):
+    from arcnerf_amd.ops import functional as F
+    g = torch.Generator().manual_seed(6)
+    for n, H in ((1, 256), (4099, 256), (1000, 64), (70001, 128)):
+        z = (torch.randn(n, H, generator=g) * 0.05).to(gpu)
+        if from_y:
+            z = torch.nn.functional.softplus(z, beta=100.0)
+        z[0, :4] = torch.tensor([0.0, 0.3, 1e-4, 0.21], device=gpu)       # beta z = 0 / 30 (beyond torch's threshold) / 0.01 / 21
+        row, h = torch.randn(H, generator=g).to(gpu), torch.randn(n, H, generator=g).to(gpu)
+        full = row.unsqueeze(0).expand(n, -1).contiguous()
+        assert torch.equal(F.softplus_grad_row(z, row, 100.0, from_y), F.softplus_grad(z, full, 100.0, from_y))
+        dg, dz = F.softplus_grad2(z, full, h, 100.0, from_y=from_y)
+        acc0 = torch.randn(H, generator=g).to(gpu)
+        acc = acc0.clone()
+        got = F.softplus_grad2_row(z, row, h, acc, 100.0, from_y)
+        assert torch.equal(got, dz)
+        want = dg.double().sum(0)
+        assert float((acc.double() - acc0.double() - want).abs().max()) <= 1e-5 * max(1.0, float(dg.double().abs().sum(0).max()))
+
+
+def test_concat2_div_is_torchs_scalar_division(gpu):
+    import math
+    from arcnerf_amd.ops import functional as F
+    g = torch.Generator().manual_seed(7)
+    n = 5003
+    a, b = torch.randn(n, 260, generator=g).to(gpu), torch.randn(n, 64, generator=g).to(gpu)
+    for div in (math.sqrt(2), 1.0):
+        got = F.concat2_div(a[:, :193], b[:, :63], div, 260)
+        want = torch.cat([a[:, :193] / div, b[:, :63] / div, torch.zeros(n, 4, device=gpu)], dim=-1)
+        assert torch.equal(got, want)          # bit for bit: torch's CUDA kernel multiplies by the float reciprocal too
+        got = F.concat2_div(a[:, :193], None, div, 196)
+        assert torch.equal(got[:, :193], a[:, :193] / div) and float(got[:, 193:].abs().max()) == 0
+
+
+def test_sdf_net_graph_free_pass_and_its_weight_cache(gpu, monkeypatch):
+    """GeoNet.forward under no_grad (ops.sdf_chain.sdf_forward_nograd: cached weight-normed padded weights, one-kernel skip concatenation)
+    against the module path of the same net; the cache follows the parameters - through an optimiser that writes them by raw pointer
+    (FusedAdam -> utils.param_epoch) and through torch's own in-place updates (tensor versions)"""
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.ops import sdf_chain
+    from arcnerf_amd.optim import FusedAdam
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    torch.manual_seed(0)
+    m = build_model(load_configs(os.path.join(ROOT, 'configs', 'neus.yaml'), [])).to(gpu)
+    geo = m.fg_model.geo_net
+    x = (torch.rand(10007, 3, device=gpu) - 0.5) * 2.0
+
+    def both():
+        with torch.no_grad():
+            monkeypatch.setenv('ARCN_SDF_NOGRAD_FAST', '0')
+            ref = geo(x)
+            monkeypatch.setenv('ARCN_SDF_NOGRAD_FAST', '1')
+            assert sdf_chain.sdf_forward_nograd(geo, x) is not None
+            got = geo(x)
+        for r, o in zip(ref, got):
+            assert r.shape == o.shape and torch.allclose(r, o, rtol=1e-5, atol=1e-5), float((r - o).abs().max())
+        return got[0].clone()
+
+    s0 = both()
+    key0 = geo._padded_cache[0]
+    with torch.no_grad():
+        geo(x)
+    assert geo._padded_cache[0] == key0                      # the same parameter state: the cached weights are reused
+    opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=1e-2, eps=1e-15).flatten()
+    for _ in range(2):
+        opt.zero_grad()
+        sdf, _ = geo(x)
+        (sdf ** 2).mean().backward()
+        opt.step()
+        s1 = both()
+        assert float((s1 - s0).abs().max()) > 1e-4           # the parameters moved, and both paths saw it
+        s0 = s1
+    with torch.no_grad():
+        for p in geo.layers.parameters():
+            p.mul_(1.01)                                      # a torch in-place update: the tensors' own versions
+    both()
