@@ -1291,6 +1291,13 @@ static int build_bin_plan(const GridParams &g, int64_t n, BinPlan &plan) {
     return ARCN_OK;
 }
 
+// a level the scatter's chunk owners may apply the optimiser to: one owner per chunk, and its rows start and end on 16-byte boundaries of the
+// flat buffers - the caller's plain Adam pass on the REST of the buffer works in float4 (arcn_adam_ema_step_runs: every run 4-float aligned)
+static inline bool level_fusable(const GridParams &g, const BinPlan &plan, int l) {
+    const int64_t lo = (int64_t)g.lv[l].offset * g.F, hi = ((int64_t)g.lv[l].offset + g.lv[l].size) * g.F;
+    return plan.n_splits[l] == 1 && ((plan.active_levels >> l) & 1u) && (lo & 3) == 0 && (hi & 3) == 0;
+}
+
 static inline int64_t bin_counter_floats(const BinPlan &plan) { return ((int64_t)plan.n_bins + 2 + 63) / 64 * 64; }
 
 }  // namespace arcn
@@ -1361,7 +1368,7 @@ static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *
             fz = *fuse;
             fz.fuse_levels = 0u;
             for (int l = 0; l < g.L; ++l)
-                if (plan.n_splits[l] == 1 && ((plan.active_levels >> l) & 1u)) fz.fuse_levels |= 1u << l;
+                if (level_fusable(g, plan, l)) fz.fuse_levels |= 1u << l;
         }
         if (fused_levels_out) *fused_levels_out = fz.fuse_levels;
         if (g.F == 1) {
@@ -1445,9 +1452,9 @@ ARCN_EXPORT int arcn_hashgrid_bwd_bwd(const float *xyz, const float *gdx, const 
 // bins - scatter_bin_dir_kernel 8 single-row records per (sample, level), scatter_bin_kernel its pair / run records - of a plan sized
 // for 3 n samples, and every owner chunk is accumulated and written back ONCE: one scatter_accum pass (the dominant kernel of the
 // scatter: 114 us for the 16-level table whatever the sample count) instead of two.
-ARCN_EXPORT int arcn_hashgrid_bwd_first_second(const float *xyz, const float *dout, const float *gdx, const float *dout_dx,
-                                               const arcn_hashgrid_desc *desc_host, float *dtable, float *workspace, int64_t workspace_floats,
-                                               int64_t n, void *stream) {
+static int hashgrid_bwd_first_second_impl(const float *xyz, const float *dout, const float *gdx, const float *dout_dx,
+                                          const arcn_hashgrid_desc *desc_host, float *dtable, float *workspace, int64_t workspace_floats,
+                                          int64_t n, void *stream, const AdamFuse *fuse, uint32_t *fused_levels_out) {
     if (n <= 0) return ARCN_OK;
     if (!xyz || !dout || !gdx || !dout_dx || !dtable || !workspace) return einval("hashgrid_bwd_first_second: missing argument");
     GridParams g;
@@ -1473,16 +1480,30 @@ ARCN_EXPORT int arcn_hashgrid_bwd_first_second(const float *xyz, const float *do
     if (bx > 32) bx = 32;
     dim3 bgrid((unsigned)bx, (unsigned)g.L), agrid((unsigned)plan.item_first[g.L]);
     const int32_t *no_count = nullptr;
+    AdamFuse fz{};
+    if (fuse && !plan.det) {      // the chunk owners apply the optimiser to the levels they own alone (see hashgrid_bwd_impl)
+        fz = *fuse;
+        fz.fuse_levels = 0u;
+        for (int l = 0; l < g.L; ++l)
+            if (level_fusable(g, plan, l)) fz.fuse_levels |= 1u << l;
+    }
+    if (fused_levels_out) *fused_levels_out = fz.fuse_levels;
     if (g.F == 1) {
         hipLaunchKernelGGL(scatter_bin_dir_kernel<1>, bgrid, dim3(1024), 0, as_stream(stream), xyz, gdx, dout_dx, g, plan, counters, recs, dtable, n, no_count);
         hipLaunchKernelGGL((scatter_bin_kernel<1, 1024>), bgrid, dim3(1024), 0, as_stream(stream), xyz, dout, (int64_t)0, g, plan, counters, recs, dtable, n, no_count);
-        hipLaunchKernelGGL(scatter_accum_kernel<1>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable, AdamFuse{});
+        hipLaunchKernelGGL(scatter_accum_kernel<1>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable, fz);
     } else {
         hipLaunchKernelGGL(scatter_bin_dir_kernel<2>, bgrid, dim3(1024), 0, as_stream(stream), xyz, gdx, dout_dx, g, plan, counters, recs, dtable, n, no_count);
         hipLaunchKernelGGL((scatter_bin_kernel<2, 1024>), bgrid, dim3(1024), 0, as_stream(stream), xyz, dout, (int64_t)0, g, plan, counters, recs, dtable, n, no_count);
-        hipLaunchKernelGGL(scatter_accum_kernel<2>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable, AdamFuse{});
+        hipLaunchKernelGGL(scatter_accum_kernel<2>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable, fz);
     }
     return check_launch("hashgrid_bwd_first_second");
+}
+
+ARCN_EXPORT int arcn_hashgrid_bwd_first_second(const float *xyz, const float *dout, const float *gdx, const float *dout_dx,
+                                               const arcn_hashgrid_desc *desc_host, float *dtable, float *workspace, int64_t workspace_floats,
+                                               int64_t n, void *stream) {
+    return hashgrid_bwd_first_second_impl(xyz, dout, gdx, dout_dx, desc_host, dtable, workspace, workspace_floats, n, stream, nullptr, nullptr);
 }
 
 ARCN_EXPORT int arcn_hashgrid_bwd_lm(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host,
@@ -1511,8 +1532,32 @@ ARCN_EXPORT int64_t arcn_hashgrid_bwd_fusable_levels(const arcn_hashgrid_desc *d
     if (build_bin_plan(g, n, plan) || plan.det) return 0;
     int64_t mask = 0;
     for (int l = 0; l < g.L; ++l)
-        if (plan.n_splits[l] == 1 && ((plan.active_levels >> l) & 1u)) mask |= (int64_t)1 << l;
+        if (level_fusable(g, plan, l)) mask |= (int64_t)1 << l;
     return mask;
+}
+
+static int make_adam_fuse(AdamFuse &fz, const char *who, const float *workspace, float *table, float *exp_avg, float *exp_avg_sq, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, float ema_decay, float grad_scale, int step, int ema_step,
+                          uint32_t *fused_levels_host) {
+    static thread_local char msg[160];
+    if (!workspace || !table || !exp_avg || !exp_avg_sq || !fused_levels_host || step < 1) {
+        snprintf(msg, sizeof(msg), "%s: missing / invalid argument", who);
+        return einval(msg);
+    }
+    if ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) {
+        snprintf(msg, sizeof(msg), "%s: parameter and moment buffers must be 16-byte aligned", who);
+        return einval(msg);
+    }
+    const bool ema = ema_decay >= 0.f;
+    if (ema && ema_step < 1) {
+        snprintf(msg, sizeof(msg), "%s: ema_step is 1-based", who);
+        return einval(msg);
+    }
+    fz.param = table; fz.m = exp_avg; fz.v = exp_avg_sq;
+    fz.h = make_adam_hyper(lr, beta1, beta2, eps, weight_decay, ema ? ema_decay : 0.f, grad_scale, step, ema_step, ema);
+    fz.ema_in_param = ema ? 1 : 0;
+    *fused_levels_host = 0u;
+    return ARCN_OK;
 }
 
 ARCN_EXPORT int arcn_hashgrid_bwd_lm_adam(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host,
@@ -1520,20 +1565,25 @@ ARCN_EXPORT int arcn_hashgrid_bwd_lm_adam(const float *xyz, const float *dout_lm
                                           float eps, float weight_decay, float ema_decay, float grad_scale, int step, int ema_step,
                                           float *workspace, int64_t workspace_floats, int counters_clear, int64_t n, const int32_t *n_ptr,
                                           uint32_t *fused_levels_host, void *stream) {
-    if (dout_stride < n) return einval("hashgrid_bwd_lm_adam: level stride smaller than n");
-    if (!workspace || !table || !exp_avg || !exp_avg_sq || !fused_levels_host || step < 1)
-        return einval("hashgrid_bwd_lm_adam: missing / invalid argument");
-    if ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
-        return einval("hashgrid_bwd_lm_adam: parameter and moment buffers must be 16-byte aligned");
-    const bool ema = ema_decay >= 0.f;
-    if (ema && ema_step < 1) return einval("hashgrid_bwd_lm_adam: ema_step is 1-based");
+    if (dout_stride != 0 && dout_stride < n) return einval("hashgrid_bwd_lm_adam: level stride smaller than n");
     AdamFuse fz{};
-    fz.param = table; fz.m = exp_avg; fz.v = exp_avg_sq;
-    fz.h = make_adam_hyper(lr, beta1, beta2, eps, weight_decay, ema ? ema_decay : 0.f, grad_scale, step, ema_step, ema);
-    fz.ema_in_param = ema ? 1 : 0;
-    *fused_levels_host = 0u;
+    int rc = make_adam_fuse(fz, "hashgrid_bwd_lm_adam", workspace, table, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, ema_decay, grad_scale,
+                            step, ema_step, fused_levels_host);
+    if (rc) return rc;
     return hashgrid_bwd_impl(xyz, nullptr, dout_lm, dout_stride, desc_host, dtable, nullptr, workspace, workspace_floats, n, n_ptr, stream, &fz,
                              fused_levels_host, counters_clear != 0);
+}
+
+ARCN_EXPORT int arcn_hashgrid_bwd_first_second_adam(const float *xyz, const float *dout, const float *gdx, const float *dout_dx,
+                                                    const arcn_hashgrid_desc *desc_host, float *dtable, float *table, float *exp_avg,
+                                                    float *exp_avg_sq, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                                    float ema_decay, float grad_scale, int step, int ema_step, float *workspace,
+                                                    int64_t workspace_floats, int64_t n, uint32_t *fused_levels_host, void *stream) {
+    AdamFuse fz{};
+    int rc = make_adam_fuse(fz, "hashgrid_bwd_first_second_adam", workspace, table, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, ema_decay,
+                            grad_scale, step, ema_step, fused_levels_host);
+    if (rc) return rc;
+    return hashgrid_bwd_first_second_impl(xyz, dout, gdx, dout_dx, desc_host, dtable, workspace, workspace_floats, n, stream, &fz, fused_levels_host);
 }
 
 ARCN_EXPORT int64_t arcn_hashgrid_bwd_counter_words(const arcn_hashgrid_desc *desc_host, int64_t n) {

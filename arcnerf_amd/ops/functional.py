@@ -573,6 +573,38 @@ def hashgrid_bwd_first_second(xyz, dout, gdx, dout_dx, desc, dtable, workspace):
     return dtable
 
 
+def _adam_args(h):
+    """(lr, beta1, beta2, eps, weight_decay, ema_decay (< 0: none), grad_scale, step, ema_step) of a FusedAdam.begin_step() record"""
+    return (float(h['lr']), float(h['betas'][0]), float(h['betas'][1]), float(h['eps']), float(h['weight_decay']),
+            float(h['ema_decay']) if h.get('ema_decay') is not None else -1.0, float(h.get('grad_scale', 1.0)), int(h['step']), int(h['ema_step'] or h['step']))
+
+
+def hashgrid_bwd_adam(xyz, dout, desc, dtable, table, exp_avg, exp_avg_sq, hyper, workspace):
+    """the binned table scatter of hashgrid_bwd (dout (n, L F) sample-major) whose chunk owners also apply Adam (+ the EMA aliased onto the
+    parameter) to the table levels they own alone: table / exp_avg / exp_avg_sq = the table's views of a flattened FusedAdam's buffers, hyper =
+    FusedAdam.begin_step().  -> the bit mask of the levels done (their gradient never reaches dtable); the rest is accumulated into dtable"""
+    _req(xyz, dout, dtable, table, exp_avg, exp_avg_sq, workspace)
+    xyz, dout = _f32(xyz), _f32(dout)
+    n = xyz.shape[0]
+    mask = C.c_uint32(0)
+    N.check(N.lib().arcn_hashgrid_bwd_lm_adam(N.ptr(xyz), N.ptr(dout), 0, C.addressof(desc), N.ptr(dtable), N.ptr(table), N.ptr(exp_avg), N.ptr(exp_avg_sq),
+                                             *_adam_args(hyper), N.ptr(workspace), workspace.numel(), 0, n, None, C.cast(C.pointer(mask), C.c_void_p),
+                                             N.stream()), 'hashgrid_bwd_lm_adam')
+    return int(mask.value)
+
+
+def hashgrid_bwd_first_second_adam(xyz, dout, gdx, dout_dx, desc, dtable, table, exp_avg, exp_avg_sq, hyper, workspace):
+    """hashgrid_bwd_first_second with the optimiser applied by the chunk owners (see hashgrid_bwd_adam) -> mask of the levels done"""
+    _req(xyz, dout, gdx, dout_dx, dtable, table, exp_avg, exp_avg_sq, workspace)
+    xyz, dout, gdx, dout_dx = _f32(xyz), _f32(dout), _f32(gdx), _f32(dout_dx)
+    n = xyz.shape[0]
+    mask = C.c_uint32(0)
+    N.check(N.lib().arcn_hashgrid_bwd_first_second_adam(N.ptr(xyz), N.ptr(dout), N.ptr(gdx), N.ptr(dout_dx), C.addressof(desc), N.ptr(dtable), N.ptr(table),
+                                                       N.ptr(exp_avg), N.ptr(exp_avg_sq), *_adam_args(hyper), N.ptr(workspace), workspace.numel(), n,
+                                                       C.cast(C.pointer(mask), C.c_void_p), N.stream()), 'hashgrid_bwd_first_second_adam')
+    return int(mask.value)
+
+
 def freq_fwd(x, n_freqs, include_input=True):
     _req(x)
     x = _f32(x)

@@ -119,6 +119,56 @@ class FusedAdam(torch.optim.Optimizer):
         if self._flat is not None:   # the loaded per-parameter tensors replaced the views: fold them back into the flat buffers
             self.flatten()
 
+    # ---- a step in two halves: for callers whose table scatters apply the optimiser to part of the buffer themselves ----------------------
+    def begin_step(self):
+        """First half of step() for a flattened single-group optimiser: the checks and the counters of THIS step, and the numbers a kernel that
+        applies the update itself needs (ops.functional.hashgrid_bwd_adam: the scatter's chunk owners on the table levels they own) ->
+        dict(step, ema_step, lr, betas, eps, weight_decay, ema_decay | None, grad_scale).  finish_step(exclude) must follow."""
+        if self._flat is None or len(self._flat) != 1 or len(self.param_groups) != 1:
+            raise RuntimeError('FusedAdam.begin_step() needs flatten() and a single parameter group')
+        if self.ema_decay is not None and not self.ema_in_param:
+            raise RuntimeError('FusedAdam.begin_step(): a fused EMA needs ema_in_param (the shadow aliased onto the parameter)')
+        param_epoch.bump()
+        group, fb = self.param_groups[0], self._flat[0]
+        for p, (o, n) in zip(fb['list'], fb['slots']):
+            if p.grad is None or p.grad.data_ptr() != fb['grads'].data_ptr() + 4 * o or p.data_ptr() != fb['params'].data_ptr() + 4 * o:
+                raise RuntimeError('FusedAdam (flat): a parameter or its .grad was re-assigned after flatten(); '
+                                   'use zero_grad(set_to_none=False) and in-place updates, or call flatten() again')
+        ema_step = self._next_ema_step()
+        fb['step'] += 1
+        for p in fb['list']:
+            self.state[p]['step'] = fb['step']
+        return dict(step=fb['step'], ema_step=ema_step, lr=group['lr'], betas=group['betas'], eps=group['eps'], weight_decay=group['weight_decay'],
+                    ema_decay=self.ema_decay, grad_scale=self.grad_scale)
+
+    def finish_step(self, hyper, exclude=()):
+        """Second half: Adam (+ EMA) on everything of the flat buffer OUTSIDE the float ranges `exclude` = [(lo, hi), ...] (already updated by
+        the caller's kernels with the numbers of begin_step()); ranges start and end on multiples of 4 floats."""
+        fb = self._flat[0]
+        total = fb['params'].numel()
+        runs, at = [], 0
+        for lo, hi in sorted((int(a), int(b)) for a, b in exclude if b > a):
+            if lo % 4 or hi % 4 or lo < at:
+                raise RuntimeError('FusedAdam.finish_step(): excluded ranges must be disjoint and 4-float aligned')
+            if lo > at:
+                runs.append((at, lo))
+            at = hi
+        if at < total:
+            runs.append((at, total))
+        for k in range(0, len(runs), 4):
+            F.adam_ema_step_runs(fb['params'], fb['grads'], fb['exp_avg'], fb['exp_avg_sq'], fb['params'] if self.ema_in_param else None, runs[k:k + 4],
+                                 hyper['step'], lr=hyper['lr'], betas=hyper['betas'], eps=hyper['eps'], weight_decay=hyper['weight_decay'],
+                                 ema_decay=self.ema_decay if self.ema_decay is not None else 0.0, grad_scale=hyper['grad_scale'],
+                                 ema_step=hyper['ema_step'], zero_grad=self.zero_grad_on_step)
+
+    def table_views(self, p):
+        """(exp_avg, exp_avg_sq, first float of p in the flat buffers) of a parameter of the flattened group"""
+        fb = self._flat[0]
+        for q, (o, n) in zip(fb['list'], fb['slots']):
+            if q is p:
+                return fb['exp_avg'][o:o + n], fb['exp_avg_sq'][o:o + n], o
+        raise KeyError('not a parameter of this optimiser')
+
     def _step_flat(self):
         if len(self.param_groups) != len(self._flat):
             raise RuntimeError('FusedAdam (flat): a parameter group was added after flatten(); call flatten() again')

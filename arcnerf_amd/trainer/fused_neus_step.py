@@ -138,6 +138,11 @@ class FusedNeusNgpStep:
         self.steps = 0
         self._ws = {}
         self.apply_optimizer = True      # (False: the gradients stay in the flat buffer - tests compare them with autograd's)
+        # the table scatters' chunk owners apply Adam to the levels they own alone (arcn_hashgrid_bwd_lm_adam / _first_second_adam): those levels'
+        # gradients never go to HBM and the optimiser pass shrinks to the rest of the flat buffer.  ARCN_FUSE_ADAM=0: scatter, then one pass
+        import os
+        self.fuse_adam = (os.environ.get('ARCN_FUSE_ADAM', '1') != '0' and len(optimizer._flat) == 1 and len(optimizer.param_groups) == 1
+                          and (optimizer.ema_decay is None or optimizer.ema_in_param))
 
     def _default_normal(self):
         """the unit default normal of rays without samples (render_cfgs, neus_model.py) as three floats, computed once"""
@@ -153,6 +158,20 @@ class FusedNeusNgpStep:
         if z is None or z.numel() < n or z.device != device:
             z = self._ws['zeros'] = torch.zeros(max(int(n * 1.25), 1 << 16), dtype=torch.float32, device=device)
         return z[:n]
+
+    @staticmethod
+    def _level_ranges(emb, mask, first):
+        """float ranges [lo, hi) in the flat buffers of the table levels in `mask` (first = the table's first float), neighbours merged"""
+        F_, offs = int(emb.desc.n_feat), emb.desc.offsets
+        out = []
+        for l in range(int(emb.desc.n_levels)):
+            if (mask >> l) & 1:
+                lo, hi = first + int(offs[l]) * F_, first + int(offs[l + 1]) * F_
+                if out and out[-1][1] == lo:
+                    out[-1] = (out[-1][0], hi)
+                else:
+                    out.append((lo, hi))
+        return out
 
     def _scatter_ws(self, key, desc, n, device):
         """scratch of a binned table scatter, kept while it is large enough (the library knows the size for n samples)"""
@@ -174,6 +193,8 @@ class FusedNeusNgpStep:
         R, dev = rays_o.shape[0], rays_o.device
         if not self.opt.zero_grad_on_step:
             self.opt.zero_grad()
+        hyper = self.opt.begin_step() if (self.apply_optimizer and self.fuse_adam) else None      # this step's optimiser numbers, for the scatters
+        done = []                                                                                 # float ranges the scatters' owners have updated
         cur = torch.cuda.current_stream()
         key = (rays_o.data_ptr(), rays_d.data_ptr(), R, rays_o._version, rays_d._version)
 
@@ -281,7 +302,12 @@ class FusedNeusNgpStep:
             d_hid_b = F.gemm_nn(g_out_b, wb1)
             F.gemm_tn(d_hid_b, enc_b, mask=hid_b, out=b0.weight.grad, accumulate=True)
             d_enc_b = F.gemm_nn(d_hid_b, b0.weight, mask=hid_b)
-            F.hashgrid_bwd(xyz_b, tb, d_enc_b, emb_b.desc, dtable=tb.grad, workspace=self._scatter_ws('bkg', emb_b.desc, total_b, dev))
+            ws_b = self._scatter_ws('bkg', emb_b.desc, total_b, dev)
+            if hyper is not None:
+                m_, v_, o_ = self.opt.table_views(tb)
+                done += self._level_ranges(emb_b, F.hashgrid_bwd_adam(xyz_b, d_enc_b, emb_b.desc, tb.grad, tb, m_, v_, hyper, ws_b), o_)
+            else:
+                F.hashgrid_bwd(xyz_b, tb, d_enc_b, emb_b.desc, dtable=tb.grad, workspace=ws_b)
         # ---- foreground backward
         if S > 0:
             zr = self._zeros(4 * R, dev)       # (read-only zero upstream gradients)
@@ -310,12 +336,20 @@ class FusedNeusNgpStep:
             d_enc = F.gemm_nn(dz, w1)
             F.gemm_tn(dz, enc, out=l0.weight.grad, accumulate=True)
             # the table: through the encoding (d_enc) and through its input gradient (d_normal on J^T jac), ONE accumulation pass for both
-            F.hashgrid_bwd_first_second(pts, d_enc, d_normal, jac, emb.desc, table.grad, self._scatter_ws('fg', emb.desc, 3 * S, dev))
+            ws_f = self._scatter_ws('fg', emb.desc, 3 * S, dev)
+            if hyper is not None:
+                m_, v_, o_ = self.opt.table_views(table)
+                done += self._level_ranges(emb, F.hashgrid_bwd_first_second_adam(pts, d_enc, d_normal, jac, emb.desc, table.grad, table, m_, v_, hyper, ws_f), o_)
+            else:
+                F.hashgrid_bwd_first_second(pts, d_enc, d_normal, jac, emb.desc, table.grad, ws_f)
             # scale = exp(inv_s * speed)
             F.sum_scale_add(d_s_ray, fg.inv_s.grad, float(fg.speed_factor), s_dev)
         # ---- optimiser
         if self.apply_optimizer:
-            self.opt.step()
+            if hyper is not None:
+                self.opt.finish_step(hyper, done)      # Adam on what the scatters' owners did not update: the coarse levels, the nets, inv_s
+            else:
+                self.opt.step()
             if self.ema is not None:
                 self.ema.ema_step()
         self.steps += 1

@@ -256,6 +256,14 @@ int arcn_hashgrid_bwd_bwd(const float *xyz, const float *gdx, const float *table
 int arcn_hashgrid_bwd_first_second(const float *xyz, const float *dout, const float *gdx, const float *dout_dx,
                                    const arcn_hashgrid_desc *desc_host, float *dtable, float *workspace, int64_t workspace_floats, int64_t n,
                                    void *stream);
+/* arcn_hashgrid_bwd_first_second whose chunk owners ALSO apply the optimiser to the table levels they own alone - the arguments and the
+ * contract of arcn_hashgrid_bwd_lm_adam below (table / exp_avg / exp_avg_sq at row 0 of level 0, *fused_levels_host = the levels done;
+ * the other levels' gradient lands in dtable).  The NeuS-on-hash-grid step: neither of the table's two gradients goes to HBM. */
+int arcn_hashgrid_bwd_first_second_adam(const float *xyz, const float *dout, const float *gdx, const float *dout_dx,
+                                        const arcn_hashgrid_desc *desc_host, float *dtable, float *table, float *exp_avg, float *exp_avg_sq,
+                                        float lr, float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale,
+                                        int step, int ema_step, float *workspace, int64_t workspace_floats, int64_t n,
+                                        uint32_t *fused_levels_host, void *stream);
 /* Same result as arcn_hashgrid_fwd (bit-identical), scheduled so that each of the chip's 8 XCDs gathers only its own
  * 2 of 16 levels (a level's table slice then stays in that XCD's L2); n_feat 1 or 2.
  * level_major = 0: out (n, L*F) row-major; level_major = 1: out[(l * n_cap + s) * F + f]. */
@@ -299,7 +307,8 @@ int arcn_hashgrid_bwd_lm_levels(const float *xyz, const float *dout_lm, int64_t 
  * Applies to the levels with one owner per chunk; *fused_levels_host (HOST pointer) receives their bit mask, the other levels' gradient is
  * accumulated into dtable as usual and the caller runs arcn_adam_ema_step on their rows (and on every other parameter).
  * ema_decay < 0: plain Adam; >= 0: the EMA with its shadow aliased onto the parameter (the ema == param form of arcn_adam_ema_step).
- * Not available with ARCN_DETERMINISTIC=1 (mask 0: nothing fused, plain scatter).  counters_clear: see arcn_hashgrid_bwd_counter_words. */
+ * Not available with ARCN_DETERMINISTIC=1 (mask 0: nothing fused, plain scatter).  counters_clear: see arcn_hashgrid_bwd_counter_words.
+ * dout_stride = 0: dout is the sample-major (n, L F) gradient of arcn_hashgrid_bwd instead of the level-major one. */
 /* bit mask of the levels arcn_hashgrid_bwd_lm_adam would apply the optimiser to for a workspace plan of n samples (0: none) */
 int64_t arcn_hashgrid_bwd_fusable_levels(const arcn_hashgrid_desc *desc_host, int64_t n);
 int arcn_hashgrid_bwd_lm_adam(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host, float *dtable,

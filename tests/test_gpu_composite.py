@@ -323,9 +323,13 @@ def test_fused_neus_ngp_step_equals_the_module_path(gpu):
             assert float(p.grad.abs().max()) > 0, name
     # (b) three iterations with the optimiser, the next batch's samplers prefetched: the module path's parameters
     runs = {}
-    for mode in ('eager', 'fused'):
+    for mode in ('eager', 'fused', 'fused_two_pass'):
         m, opt, lf = make()
-        st = T.FusedNeusNgpStep(m, lf, opt) if mode == 'fused' else None
+        st = T.FusedNeusNgpStep(m, lf, opt) if mode != 'eager' else None
+        if mode == 'fused':
+            assert st.fuse_adam           # the scatters' chunk owners apply Adam to the table levels they own
+        if mode == 'fused_two_pass':
+            st.fuse_adam = False          # scatter into .grad, then one optimiser pass over the whole buffer
         losses = []
         for i in range(3):
             if st is not None:
@@ -335,6 +339,13 @@ def test_fused_neus_ngp_step_equals_the_module_path(gpu):
             losses.append(float(l['sum']))
         torch.cuda.synchronize()
         runs[mode] = (losses, opt.flat_params().clone(), sampler_rng().state, multivol_rng().state)
+    # the optimiser inside the scatter is the optimiser after it: the same accumulated gradient (up to the order the records of a row arrive
+    # in, which differs from run to run in either form), the same update arithmetic
+    lf_, pf = runs['fused'][:2]
+    lt_, pt = runs['fused_two_pass'][:2]
+    assert max(abs(x - y) / abs(x) for x, y in zip(lf_, lt_)) < 1e-5, (lf_, lt_)
+    assert float(((pf - pt).abs() > 1e-3 * float(pf.abs().max())).float().mean()) < 1e-3
+    assert runs['fused'][2:] == runs['fused_two_pass'][2:]
     (la_, pa, ra, rma), (lb_, pb, rb_, rmb) = runs['eager'], runs['fused']
     assert ra == rb_ and rma == rmb
     assert max(abs(x - y) / abs(x) for x, y in zip(la_, lb_)) < 1e-4, (la_, lb_)
