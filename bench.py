@@ -18,6 +18,12 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# This process builds SIX models one after another (the headline pipeline and five side legs), each with its own side streams.  The HIP
+# runtime hands streams to GPU_MAX_HW_QUEUES (default 4) hardware queues round robin: by the fourth leg the sampling stream of config 4
+# lands on the queue of the stream it is meant to run BESIDE and the prefetched samplers serialise with the step (1.96 instead of 1.82 ms;
+# a process that builds one model does not see it - DESIGN.md 12c).  Eight queues keep them apart; the headline step is unchanged by it
+# (0.564 - 0.567 ms with 4 and with 8, alternated).  Must be set before the runtime initialises.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
