@@ -597,6 +597,58 @@ __device__ __forceinline__ Cell locate_fastcell(const float p[3], const GridPara
     return cell;
 }
 
+// Runs of consecutive samples (lanes of a wave) in the same cell, summed: va / vb (the 8 corners' contributions of every lane, F = 1: va only)
+// become, in the FIRST lane of every run (`true_head`), the sums over the run.  `head` = true_head or the start of a 16-lane row: the doubling
+// steps work inside rows (DPP row shifts on the VALU instead of ds_bpermute, which queued on the LDS pipeline next to the histogram atomics),
+// the pieces of a run that crosses rows are joined afterwards through v_readlane.  Wave uniform control flow; every lane calls it.
+template <int F>
+__device__ __forceinline__ void sum_cell_runs(float (&va)[8], float (&vb)[8], bool head, bool true_head, int lane) {
+    // segmented suffix sum by doubling over the 8 corners x F values
+    const uint64_t all_heads = __ballot(head);
+    const uint64_t above = lane == 63 ? 0ull : (all_heads & ~((2ull << lane) - 1ull));
+    const int tail = above ? (int)__builtin_ctzll(above) - 1 : 63;  // <= the last lane of this lane's row
+    // one doubling step with the row shift as a template constant; false once no lane has anything left to take
+#define ARCN_RUN_STEP(D)                                                              \
+    {                                                                                 \
+        const bool take = lane + (D) <= tail;                                         \
+        more = __ballot(take) != 0ull;                                                \
+        if (more) {                                                                   \
+            /* va += (lane i + D's va) * m, m = 1 inside the run, 0 past its end: ONE v_fmac_f32_dpp per value (m = 1 is the plain */ \
+            /* sum bit for bit; a select + add were three instructions and a DPP hazard stall) */                                     \
+            const float m = take ? 1.0f : 0.0f;                                       \
+            _Pragma("unroll") for (int q = 0; q < 8; ++q) {                           \
+                va[q] = __builtin_fmaf(dpp_zero<0x100 + (D)>(va[q]), m, va[q]);       \
+                if (F > 1) vb[q] = __builtin_fmaf(dpp_zero<0x100 + (D)>(vb[q]), m, vb[q]); \
+            }                                                                         \
+        }                                                                             \
+    }
+    bool more = true;
+    ARCN_RUN_STEP(1)
+    if (more) ARCN_RUN_STEP(2)
+    if (more) ARCN_RUN_STEP(4)
+    if (more) ARCN_RUN_STEP(8)
+#undef ARCN_RUN_STEP
+    // join the pieces of runs that cross a row start, top row first so that a run spanning several rows chains up: lane b holds
+    // the sum of its piece, the lanes of the last piece of the row below take it
+    const uint64_t true_heads = __ballot(true_head);
+#pragma unroll
+    for (int b = 48; b >= 16; b -= 16) {
+        if ((true_heads >> b) & 1ull) continue;
+        const uint64_t below = all_heads & ((1ull << b) - 1ull);  // never empty: lane b-16 is a head
+        const int piece = 63 - (int)__builtin_clzll(below);
+        const float mj = (lane >= piece && lane < b) ? 1.0f : 0.0f;     // (the same masked multiply-add as in the steps above)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float ua = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, va[q]), b));
+            va[q] = __builtin_fmaf(ua, mj, va[q]);
+            if (F > 1) {
+                const float ub = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vb[q]), b));
+                vb[q] = __builtin_fmaf(ub, mj, vb[q]);
+            }
+        }
+    }
+}
+
 template <int F, int kBinThreads>
 __global__ void __launch_bounds__(kBinThreads)
 scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout, int64_t dout_lm_stride, GridParams g,
@@ -717,10 +769,7 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
             }
         }
     } else {
-        // segmented suffix sum by doubling over the 8 corners x F values; only the head lane of a run emits its 8 singles
-        const uint64_t all_heads = __ballot(head);
-        const uint64_t above = lane == 63 ? 0ull : (all_heads & ~((2ull << lane) - 1ull));
-        const int tail = above ? (int)__builtin_ctzll(above) - 1 : 63;  // <= the last lane of this lane's row
+        // the runs' sums (sum_cell_runs); only the head lane of a run emits its 8 singles
         float va[8], vb[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -730,46 +779,7 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
             va[q] = g0 * wt;
             vb[q] = g1 * wt;
         }
-        // one doubling step with the row shift as a template constant; false once no lane has anything left to take
-#define ARCN_RUN_STEP(D)                                                              \
-        {                                                                             \
-            const bool take = lane + (D) <= tail;                                     \
-            more = __ballot(take) != 0ull;                                            \
-            if (more) {                                                               \
-                /* va += (lane i + D's va) * m, m = 1 inside the run, 0 past its end: ONE v_fmac_f32_dpp per value (m = 1 is the plain */ \
-                /* sum bit for bit; a select + add were three instructions and a DPP hazard stall) */                                     \
-                const float m = take ? 1.0f : 0.0f;                                   \
-                _Pragma("unroll") for (int q = 0; q < 8; ++q) {                       \
-                    va[q] = __builtin_fmaf(dpp_zero<0x100 + (D)>(va[q]), m, va[q]);   \
-                    if (F > 1) vb[q] = __builtin_fmaf(dpp_zero<0x100 + (D)>(vb[q]), m, vb[q]); \
-                }                                                                     \
-            }                                                                         \
-        }
-        bool more = true;
-        ARCN_RUN_STEP(1)
-        if (more) ARCN_RUN_STEP(2)
-        if (more) ARCN_RUN_STEP(4)
-        if (more) ARCN_RUN_STEP(8)
-#undef ARCN_RUN_STEP
-        // join the pieces of runs that cross a row start, top row first so that a run spanning several rows chains up: lane b holds
-        // the sum of its piece, the lanes of the last piece of the row below take it
-        const uint64_t true_heads = __ballot(true_head);
-#pragma unroll
-        for (int b = 48; b >= 16; b -= 16) {
-            if ((true_heads >> b) & 1ull) continue;
-            const uint64_t below = all_heads & ((1ull << b) - 1ull);  // never empty: lane b-16 is a head
-            const int piece = 63 - (int)__builtin_clzll(below);
-            const float mj = (lane >= piece && lane < b) ? 1.0f : 0.0f;     // (the same masked multiply-add as in the steps above)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float ua = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, va[q]), b));
-                va[q] = __builtin_fmaf(ua, mj, va[q]);
-                if (F > 1) {
-                    const float ub = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vb[q]), b));
-                    vb[q] = __builtin_fmaf(ub, mj, vb[q]);
-                }
-            }
-        }
+        sum_cell_runs<F>(va, vb, head, true_head, lane);
         if (true_head && cell.valid) {
             uint32_t rows[8];
             corner_rows(cell.c, lp, plan.lowbits[l], rows);
@@ -832,14 +842,18 @@ scatter_bin_dir_kernel(const float *__restrict__ xyz, const float *__restrict__ 
     for (int64_t tile0 = (int64_t)blockIdx.x * 1024; tile0 < cnt; tile0 += (int64_t)gridDim.x * 1024, buf ^= 1) {
         uint32_t *hist = hist2[buf], *gbase = gbase2[buf];
         const int64_t s = tile0 + threadIdx.x;
+        const int lane = threadIdx.x & 63;
         int sbin[8];
         uint32_t sidx[8], rank[8];
         float sa[8], sb[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) sbin[q] = -1;
+        for (int q = 0; q < 8; ++q) { sbin[q] = -1; sa[q] = 0.f; sb[q] = 0.f; }
+        Cell cell;
+        cell.valid = false;
+        cell.c[0] = cell.c[1] = cell.c[2] = 0u;
         if (s < cnt) {
             const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
-            const Cell cell = locate(p, g, lp);
+            cell = locate(p, g, lp);
             if (cell.valid) {
                 const float gd[3] = {gdx[3 * s], gdx[3 * s + 1], gdx[3 * s + 2]};
                 const float *gp = dout + (s * g.L + l) * F;
@@ -847,7 +861,6 @@ scatter_bin_dir_kernel(const float *__restrict__ xyz, const float *__restrict__ 
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const uint32_t o[3] = {(uint32_t)((q >> 1) & 1), (uint32_t)(q & 1), (uint32_t)(q >> 2)};
-                    const uint32_t r = hash_row(cell.c[0] + o[0], cell.c[1] + o[1], cell.c[2] + o[2], lp);
                     float a[3], sd[3];
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
@@ -857,8 +870,6 @@ scatter_bin_dir_kernel(const float *__restrict__ xyz, const float *__restrict__ 
                     float D = gd[0] * sd[0] * a[1] * a[2];
                     D = D + gd[1] * a[0] * sd[1] * a[2];
                     D = D + gd[2] * a[0] * a[1] * sd[2];
-                    sbin[q] = (int)(r >> shift);
-                    sidx[q] = (r & cmask) | 0xffff0000u;
                     sa[q] = g0 * D;
                     sb[q] = g1 * D;
                 }
@@ -868,6 +879,25 @@ scatter_bin_dir_kernel(const float *__restrict__ xyz, const float *__restrict__ 
                     for (int q = 0; q < 8; ++q) m = fmaxf(m, fmaxf(fabsf(sa[q]), fabsf(sb[q])));
                     if (m == m && m > 0.f) atomicMax(&counters[plan.aux_first], __float_as_uint(m));
                 }
+            }
+        }
+        // Runs of consecutive samples in one cell (a ray's neighbours on the coarse and middle levels) are summed in the wave first, like the
+        // first-order producer does: without it every sample sent 8 single-row records per level, neighbouring lanes of the consumer fought over
+        // the same rows (compare-and-swap retries) and the NeuS-on-hash-grid step's first + second order pass took 245 us for 125 K points
+        const uint32_t kxy = cell.valid ? (cell.c[0] | (cell.c[1] << 16)) : 0xffffffffu;
+        const uint32_t kz = cell.valid ? cell.c[2] : (uint32_t)lane;
+        const uint32_t pxy = (uint32_t)dpp_take_i<0x138>(-1, (int)kxy), pz = (uint32_t)dpp_take_i<0x138>(-1, (int)kz);
+        const bool true_head = lane == 0 || kxy != pxy || kz != pz;
+        const bool head = true_head || (lane & 15) == 0;
+        const uint64_t heads = __ballot(true_head && cell.valid), valid = __ballot(cell.valid);
+        const bool reduce = 3 * __popcll(heads) <= 2 * __popcll(valid);      // wave uniform: an average run of >= 1.5 samples
+        if (reduce) sum_cell_runs<F>(sa, sb, head, true_head, lane);
+        if (cell.valid && (!reduce || true_head)) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t r = hash_row(cell.c[0] + ((q >> 1) & 1), cell.c[1] + (q & 1), cell.c[2] + (q >> 2), lp);
+                sbin[q] = (int)(r >> shift);
+                sidx[q] = (r & cmask) | 0xffff0000u;
             }
         }
 #pragma unroll
