@@ -940,8 +940,12 @@ struct AdamFuse {
     int32_t ema_in_param;      // EMA shadow aliased onto the parameter (else no EMA)
 };
 
+// Two workgroups per CU: the 8192-row chunk (64 KiB of accumulators) was sized for it in round 2, but at 96 VGPRs the 16 waves of ONE workgroup
+// filled the register file (4 waves x 96 of 512 per SIMD lane) and the second never came.  8 waves per SIMD = 64 VGPRs: the optimiser phase
+// takes one float4 per array and trip instead of four (55 VGPRs, no spill; four: 63 + 5 spilled dwords, same speed; the bound alone with four:
+// 31 spilled dwords, slower) - consumer 100 -> 91 us, scatter 0.195 -> 0.188 ms per launch, four alternations.
 template <int F>
-__global__ void __launch_bounds__(kTiledThreads)
+__global__ void __launch_bounds__(kTiledThreads, 8)
 scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict__ counters, GridParams g, BinPlan plan,
                      float *__restrict__ dtable, AdamFuse fz) {
     extern __shared__ __attribute__((aligned(16))) float acc[];
@@ -1135,7 +1139,7 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
         }
         if ((base & 3) == 0) {
             const int n4 = nf >> 2;
-            constexpr int kB = 4;
+            constexpr int kB = 1;      // (registers: see the kernel's launch bounds)
             for (int j0 = threadIdx.x; j0 < n4; j0 += kTiledThreads * kB) {
                 float4 p4[kB], m4[kB], v4[kB];
 #pragma unroll
