@@ -82,11 +82,14 @@ __device__ __forceinline__ Cell locate(const float p[3], const GridParams &g, co
     return cell;
 }
 
+// corners (optional): the 8 gathered table rows of every (sample, level), corners[((s * L + l) * 8 + q) * F + f] (zeros outside the grid) - what
+// the two second-order gathers of NeuS on the hash grid (the normal d enc / d x . jac, and the gradient of that with respect to jac) need of
+// the table: they then STREAM 64 bytes per lane instead of repeating eight random 8-byte reads (arcn_hashgrid_dxyz_corners / _ddout_corners)
 template <int F>
 __global__ void __launch_bounds__(256) hashgrid_fwd_kernel(const float *__restrict__ xyz, const float *__restrict__ table,
                                                            GridParams g, float *__restrict__ out,
                                                            int32_t *__restrict__ hash_idx, int64_t n,
-                                                           const int32_t *n_ptr) {
+                                                           const int32_t *n_ptr, float *__restrict__ corners = nullptr) {
     const int64_t cnt = dev_count(n, n_ptr);
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= cnt * g.L) return;
@@ -133,9 +136,23 @@ __global__ void __launch_bounds__(256) hashgrid_fwd_kernel(const float *__restri
             for (int f = 0; f < F; ++f) { float a = vals[q][f] * wt; acc[f] = acc[f] + a; }
             if (hash_idx) hash_idx[gid * 8 + q] = (int32_t)((int64_t)rows[q] + lp.offset);
         }
-    } else if (hash_idx) {
+        if (corners) {
+            float *c = corners + gid * 8 * F;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) hash_idx[gid * 8 + q] = -1;
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int f = 0; f < F; ++f) c[q * F + f] = vals[q][f];
+        }
+    } else {
+        if (hash_idx) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) hash_idx[gid * 8 + q] = -1;
+        }
+        if (corners) {
+            float *c = corners + gid * 8 * F;
+#pragma unroll
+            for (int q = 0; q < 8 * F; ++q) c[q] = 0.f;
+        }
     }
     float *o = out + gid * F;
     if (F == 2) *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1 % F]);
@@ -170,7 +187,7 @@ template <int F>
 __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(const float *__restrict__ xyz, const float *__restrict__ table,
                                                            const float *__restrict__ dout, GridParams g,
                                                            float *__restrict__ dtable, float *__restrict__ dxyz, int64_t n,
-                                                           const int32_t *n_ptr) {
+                                                           const int32_t *n_ptr, const float *__restrict__ corners = nullptr) {
     const int64_t cnt = dev_count(n, n_ptr);
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= cnt * g.L) return;
@@ -183,11 +200,13 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(const float *__restri
 #pragma unroll
     for (int f = 0; f < F; ++f) go[f] = dout[gid * F + f];
     float gx[3] = {0.f, 0.f, 0.f};
+    // (corners: the forward's gathered rows of this lane, arcn_hashgrid_fwd_corners - no hash, no table read; dxyz only)
+    const float *cv = corners ? corners + gid * 8 * F : nullptr;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         if (!cell.valid) break;
         const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
-        const int64_t row = (int64_t)hash_row(cell.c[0] + ox, cell.c[1] + oy, cell.c[2] + oz, lp) + lp.offset;
+        const int64_t row = cv ? 0 : (int64_t)hash_row(cell.c[0] + ox, cell.c[1] + oy, cell.c[2] + oz, lp) + lp.offset;
         float wx = ox ? cell.w[0] : 1.0f - cell.w[0];
         float wy = oy ? cell.w[1] : 1.0f - cell.w[1];
         float wz = oz ? cell.w[2] : 1.0f - cell.w[2];
@@ -199,7 +218,7 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(const float *__restri
         if (dxyz) {
             float dot = 0.f;
 #pragma unroll
-            for (int f = 0; f < F; ++f) dot += go[f] * table[row * F + f];
+            for (int f = 0; f < F; ++f) dot += go[f] * (cv ? cv[q * F + f] : table[row * F + f]);
             float sx = ox ? 1.0f : -1.0f, sy = oy ? 1.0f : -1.0f, sz = oz ? 1.0f : -1.0f;
             gx[0] += dot * sx * wy * wz * cell.dw[0];
             gx[1] += dot * wx * sy * wz * cell.dw[1];
@@ -221,7 +240,7 @@ template <int F>
 __global__ void __launch_bounds__(256)
 hashgrid_bwd_bwd_kernel(const float *__restrict__ xyz, const float *__restrict__ gdx, const float *__restrict__ table,
                         const float *__restrict__ dout, GridParams g, float *__restrict__ ddout, float *__restrict__ dtable,
-                        float *__restrict__ d2xyz, int64_t n, const int32_t *n_ptr) {
+                        float *__restrict__ d2xyz, int64_t n, const int32_t *n_ptr, const float *__restrict__ corners = nullptr) {
     const int64_t cnt = dev_count(n, n_ptr);
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= cnt * g.L) return;
@@ -238,12 +257,14 @@ hashgrid_bwd_bwd_kernel(const float *__restrict__ xyz, const float *__restrict__
         const float gd[3] = {gdx[3 * s], gdx[3 * s + 1], gdx[3 * s + 2]};
         float go[F];
 #pragma unroll
-        for (int f = 0; f < F; ++f) go[f] = dout[gid * F + f];
+        for (int f = 0; f < F; ++f) go[f] = dout ? dout[gid * F + f] : 0.f;
         float hx[3] = {0.f, 0.f, 0.f};
+        // (corners: the forward's gathered rows of this lane - no hash, no table read; for ddout alone, arcn_hashgrid_ddout_corners)
+        const float *cv = corners ? corners + gid * 8 * F : nullptr;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const uint32_t o[3] = {(uint32_t)((q >> 1) & 1), (uint32_t)(q & 1), (uint32_t)(q >> 2)};
-            const int64_t row = (int64_t)hash_row(cell.c[0] + o[0], cell.c[1] + o[1], cell.c[2] + o[2], lp) + lp.offset;
+            const int64_t row = cv ? 0 : (int64_t)hash_row(cell.c[0] + o[0], cell.c[1] + o[1], cell.c[2] + o[2], lp) + lp.offset;
             float a[3], sd[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -256,7 +277,7 @@ hashgrid_bwd_bwd_kernel(const float *__restrict__ xyz, const float *__restrict__
             float dot = 0.f;
 #pragma unroll
             for (int f = 0; f < F; ++f) {
-                const float t = table[row * F + f];
+                const float t = cv ? cv[q * F + f] : table[row * F + f];
                 acc[f] = acc[f] + t * D;
                 dot += go[f] * t;
                 if (dtable) unsafeAtomicAdd(&dtable[row * F + f], go[f] * D);
@@ -1352,6 +1373,64 @@ ARCN_EXPORT int arcn_hashgrid_fwd(const float *xyz, const float *table, const ar
     default: hipLaunchKernelGGL(hashgrid_fwd_kernel<4>, grid, dim3(256), 0, as_stream(stream), xyz, table, g, out, hash_idx, n, n_ptr); break;
     }
     return check_launch("hashgrid_fwd");
+}
+
+/* arcn_hashgrid_fwd that also keeps the gathered rows: corners (n, L, 8, F) floats (see hashgrid_fwd_kernel) */
+ARCN_EXPORT int arcn_hashgrid_fwd_corners(const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out, float *corners,
+                                          int64_t n, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!xyz || !table || !out || !corners) return einval("hashgrid_fwd_corners: missing argument");
+    GridParams g;
+    int rc = build_params(desc_host, g);
+    if (rc) return rc;
+    dim3 grid((unsigned)ceil_div<int64_t>(n * g.L, 256));
+    const int32_t *nc = nullptr;
+    switch (g.F) {
+    case 1: hipLaunchKernelGGL(hashgrid_fwd_kernel<1>, grid, dim3(256), 0, as_stream(stream), xyz, table, g, out, (int32_t *)nullptr, n, nc, corners); break;
+    case 2: hipLaunchKernelGGL(hashgrid_fwd_kernel<2>, grid, dim3(256), 0, as_stream(stream), xyz, table, g, out, (int32_t *)nullptr, n, nc, corners); break;
+    default: hipLaunchKernelGGL(hashgrid_fwd_kernel<4>, grid, dim3(256), 0, as_stream(stream), xyz, table, g, out, (int32_t *)nullptr, n, nc, corners); break;
+    }
+    return check_launch("hashgrid_fwd_corners");
+}
+
+/* dxyz (n, 3) += d <dout, enc(x)> / d x (what arcn_hashgrid_bwd adds with dxyz alone) from the forward's corners instead of the table: the
+ * same arithmetic in the same order on the same values - bit-identical - as a streaming read (caller zeroes dxyz) */
+ARCN_EXPORT int arcn_hashgrid_dxyz_corners(const float *xyz, const float *corners, const float *dout, const arcn_hashgrid_desc *desc_host,
+                                           float *dxyz, int64_t n, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!xyz || !corners || !dout || !dxyz) return einval("hashgrid_dxyz_corners: missing argument");
+    GridParams g;
+    int rc = build_params(desc_host, g);
+    if (rc) return rc;
+    dim3 grid((unsigned)ceil_div<int64_t>(n * g.L, 256));
+    const int32_t *nc = nullptr;
+    const float *no_table = nullptr;
+    switch (g.F) {
+    case 1: hipLaunchKernelGGL(hashgrid_bwd_kernel<1>, grid, dim3(256), 0, as_stream(stream), xyz, no_table, dout, g, (float *)nullptr, dxyz, n, nc, corners); break;
+    case 2: hipLaunchKernelGGL(hashgrid_bwd_kernel<2>, grid, dim3(256), 0, as_stream(stream), xyz, no_table, dout, g, (float *)nullptr, dxyz, n, nc, corners); break;
+    default: hipLaunchKernelGGL(hashgrid_bwd_kernel<4>, grid, dim3(256), 0, as_stream(stream), xyz, no_table, dout, g, (float *)nullptr, dxyz, n, nc, corners); break;
+    }
+    return check_launch("hashgrid_dxyz_corners");
+}
+
+/* ddout (n, L F) = d <gdx, J(x; table)^T dout> / d dout (the ddout of arcn_hashgrid_bwd_bwd) from the forward's corners: bit-identical,
+ * streaming */
+ARCN_EXPORT int arcn_hashgrid_ddout_corners(const float *xyz, const float *gdx, const float *corners, const arcn_hashgrid_desc *desc_host,
+                                            float *ddout, int64_t n, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!xyz || !gdx || !corners || !ddout) return einval("hashgrid_ddout_corners: missing argument");
+    GridParams g;
+    int rc = build_params(desc_host, g);
+    if (rc) return rc;
+    dim3 grid((unsigned)ceil_div<int64_t>(n * g.L, 256));
+    const int32_t *nc = nullptr;
+    const float *none = nullptr;
+    switch (g.F) {
+    case 1: hipLaunchKernelGGL(hashgrid_bwd_bwd_kernel<1>, grid, dim3(256), 0, as_stream(stream), xyz, gdx, none, none, g, ddout, (float *)nullptr, (float *)nullptr, n, nc, corners); break;
+    case 2: hipLaunchKernelGGL(hashgrid_bwd_bwd_kernel<2>, grid, dim3(256), 0, as_stream(stream), xyz, gdx, none, none, g, ddout, (float *)nullptr, (float *)nullptr, n, nc, corners); break;
+    default: hipLaunchKernelGGL(hashgrid_bwd_bwd_kernel<4>, grid, dim3(256), 0, as_stream(stream), xyz, gdx, none, none, g, ddout, (float *)nullptr, (float *)nullptr, n, nc, corners); break;
+    }
+    return check_launch("hashgrid_ddout_corners");
 }
 
 ARCN_EXPORT int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc *desc_host, int64_t n);

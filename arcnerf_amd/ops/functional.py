@@ -562,6 +562,37 @@ def hashgrid_bwd_bwd(xyz, gdx, table, dout, desc, want_ddout=True, want_dtable=T
     return ddout, dtable, d2xyz
 
 
+def hashgrid_fwd_corners(xyz, table, desc):
+    """hashgrid_fwd that also returns the gathered rows: -> (enc (n, L F), corners (n, L, 8, F)) for hashgrid_dxyz_corners / hashgrid_ddout_corners"""
+    _req(xyz, table)
+    xyz, table = _f32(xyz), _f32(table)
+    n, L, Fq = xyz.shape[0], int(desc.n_levels), int(desc.n_feat)
+    out = torch.empty((n, L * Fq), dtype=torch.float32, device=xyz.device)
+    corners = torch.empty((n, L, 8, Fq), dtype=torch.float32, device=xyz.device)
+    N.check(N.lib().arcn_hashgrid_fwd_corners(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(out), N.ptr(corners), n, N.stream()), 'hashgrid_fwd_corners')
+    return out, corners
+
+
+def hashgrid_dxyz_corners(xyz, corners, dout, desc):
+    """d <dout, enc(x)> / d x (n, 3) from the forward's corners: the dxyz of hashgrid_bwd, bit for bit, without the table reads"""
+    _req(xyz, corners, dout)
+    xyz, dout = _f32(xyz), _f32(dout)
+    n = xyz.shape[0]
+    dxyz = torch.zeros((n, 3), dtype=torch.float32, device=xyz.device)
+    N.check(N.lib().arcn_hashgrid_dxyz_corners(N.ptr(xyz), N.ptr(corners), N.ptr(dout), C.addressof(desc), N.ptr(dxyz), n, N.stream()), 'hashgrid_dxyz_corners')
+    return dxyz
+
+
+def hashgrid_ddout_corners(xyz, gdx, corners, desc):
+    """the ddout (n, L F) of hashgrid_bwd_bwd from the forward's corners, bit for bit, without the table reads"""
+    _req(xyz, gdx, corners)
+    xyz, gdx = _f32(xyz), _f32(gdx)
+    n = xyz.shape[0]
+    ddout = torch.empty((n, int(desc.n_levels) * int(desc.n_feat)), dtype=torch.float32, device=xyz.device)
+    N.check(N.lib().arcn_hashgrid_ddout_corners(N.ptr(xyz), N.ptr(gdx), N.ptr(corners), C.addressof(desc), N.ptr(ddout), n, N.stream()), 'hashgrid_ddout_corners')
+    return ddout
+
+
 def hashgrid_bwd_first_second(xyz, dout, gdx, dout_dx, desc, dtable, workspace):
     """dtable += the table gradient through the encoding (dout) AND through its input gradient (gdx on J^T dout_dx): both binned scatters
     with ONE accumulation pass; workspace from hashgrid_bwd_workspace(desc, 3 * n)"""

@@ -141,6 +141,7 @@ class FusedNeusNgpStep:
         # the table scatters' chunk owners apply Adam to the levels they own alone (arcn_hashgrid_bwd_lm_adam / _first_second_adam): those levels'
         # gradients never go to HBM and the optimiser pass shrinks to the rest of the flat buffer.  ARCN_FUSE_ADAM=0: scatter, then one pass
         import os
+        self.keep_corners = os.environ.get('ARCN_NEUS_CORNERS', '1') != '0'
         self.fuse_adam = (os.environ.get('ARCN_FUSE_ADAM', '1') != '0' and len(optimizer._flat) == 1 and len(optimizer.param_groups) == 1
                           and (optimizer.ema_decay is None or optimizer.ema_in_param))
 
@@ -236,12 +237,20 @@ class FusedNeusNgpStep:
         if S > 0:
             fg.adjust_dynamicbs_factor(n_valid=pk['offsets'][R])
             pts, dirs = F.packed_points(rays_o, rays_d, pk['t_mid'], pk['ray_id'])
-            enc = F.hashgrid_fwd(pts, table, emb.desc)
+            # (the gathered rows are kept: the normals and the gradient of the Jacobian row stream them instead of gathering again;
+            # ARCN_NEUS_CORNERS=0: three gathers from the table)
+            if self.keep_corners:
+                enc, corners = F.hashgrid_fwd_corners(pts, table, emb.desc)
+            else:
+                enc, corners = F.hashgrid_fwd(pts, table, emb.desc), None
             hid = F.gemm_nt(enc, w1, None, act='softplus', beta=beta)
             out = F.gemm_nt(hid, w2, None)
             sg = F.softplus_grad(hid, None, beta, from_y=True)
             jac = F.gemm_nn(sg, prep['w1j'])
-            _, normal = F.hashgrid_bwd(pts, table, jac, emb.desc, want_dtable=False, want_dxyz=True)
+            if corners is not None:
+                normal = F.hashgrid_dxyz_corners(pts, corners, jac, emb.desc)
+            else:
+                _, normal = F.hashgrid_bwd(pts, table, jac, emb.desc, want_dtable=False, want_dxyz=True)
             sdf = F.act_col_scale(out, None, 1.0)       # (column 0 of the padded output)
             n_sh = rad.embed_fn_view.n_freqs ** 2
             rad_in = F.radiance_inputs('pvnf', pts, dirs, normal, out[:, 1:n_out], rad.embed_fn_view.n_freqs)       # [p | SH(normalize(v)) | n | f], one pass
@@ -323,7 +332,10 @@ class FusedNeusNgpStep:
             # Eikonal value + gradient and the radiance net's gradient of its normal inputs, both added into d_normal in one pass
             F.eikonal_packed(normal, pk, R, self.eik_w, d_normal=d_normal, loss=losses[1:2], add_src=dx_r[:, 3 + n_sh:6 + n_sh], loss_is_clear=True)
             # the normals' gradient: to the Jacobian row they were built from (its table part joins the first-order scatter below)
-            d_jac, _, _ = F.hashgrid_bwd_bwd(pts, d_normal, table, jac, emb.desc, want_ddout=True, want_dtable=False, want_d2xyz=False)
+            if corners is not None:
+                d_jac = F.hashgrid_ddout_corners(pts, d_normal, corners, emb.desc)
+            else:
+                d_jac, _, _ = F.hashgrid_bwd_bwd(pts, d_normal, table, jac, emb.desc, want_ddout=True, want_dtable=False, want_d2xyz=False)
             # the sdf net, first output's Jacobian included (ops.autograd.SdfMlpJacFn.backward)
             g_out = F.geo_out_grad(d_sdf, dx_r[:, 6 + n_sh:6 + n_sh + n_out - 1], w2.shape[0])       # [d sdf | d features | 0]
             dz = F.gemm_nn(g_out, w2)

@@ -250,6 +250,19 @@ int arcn_hashgrid_fwd(const float *xyz, const float *table, const arcn_hashgrid_
 int arcn_hashgrid_bwd_bwd(const float *xyz, const float *gdx, const float *table, const float *dout,
                           const arcn_hashgrid_desc *desc_host, float *ddout, float *dtable, float *d2xyz, float *workspace,
                           int64_t workspace_floats, int64_t n, const int32_t *n_ptr, void *stream);
+/* The second-order gathers of NeuS on the hash grid WITHOUT their random reads.  The normal (d enc / d x)^T jac and the gradient of that
+ * product with respect to jac (hashgrid_encoder.py through base_network.py:30-44, create_graph = True) read the SAME eight table rows per
+ * (sample, level) the forward gathered.  arcn_hashgrid_fwd_corners keeps them - corners (n, L, 8, F) floats, 64 B per (sample, level) at
+ * F = 2, zeros outside the grid - and the two consumers stream them:
+ *   arcn_hashgrid_dxyz_corners : dxyz (n, 3) += what arcn_hashgrid_bwd adds to dxyz (caller zeroes it)
+ *   arcn_hashgrid_ddout_corners: ddout (n, L F) = the ddout of arcn_hashgrid_bwd_bwd
+ * The same arithmetic in the same order on the same values: bit-identical to the table forms. */
+int arcn_hashgrid_fwd_corners(const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out, float *corners, int64_t n,
+                              void *stream);
+int arcn_hashgrid_dxyz_corners(const float *xyz, const float *corners, const float *dout, const arcn_hashgrid_desc *desc_host, float *dxyz,
+                               int64_t n, void *stream);
+int arcn_hashgrid_ddout_corners(const float *xyz, const float *gdx, const float *corners, const arcn_hashgrid_desc *desc_host, float *ddout,
+                                int64_t n, void *stream);
 /* The table's FIRST- and SECOND-order gradients of one batch in one consumer pass: dtable += d/d table of <dout, enc(xyz)> (what
  * arcn_hashgrid_bwd adds) + d/d table of <gdx, J(xyz; table)^T dout_dx> (what arcn_hashgrid_bwd_bwd adds) - both producers fill the same
  * bins, one accumulation pass over the table instead of two.  workspace: at least arcn_hashgrid_bwd_workspace_floats(desc, 3 * n). */

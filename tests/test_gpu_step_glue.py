@@ -234,3 +234,29 @@ def test_sdf_net_graph_free_pass_and_its_weight_cache(gpu, monkeypatch):
         for p in geo.layers.parameters():
             p.mul_(1.01)                                      # a torch in-place update: the tensors' own versions
     both()
+
+
+def test_second_order_gathers_from_the_forwards_corners(gpu):
+    """arcn_hashgrid_fwd_corners keeps the eight gathered rows of every (sample, level); the normal's gather and the gradient of the Jacobian
+    row computed from them are the table forms bit for bit (points outside the grid included)"""
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.ops import functional as F
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    torch.manual_seed(0)
+    m = build_model(load_configs(os.path.join(ROOT, 'configs', 'neus_ngp_multivol.yaml'), [])).to(gpu)
+    emb = m.fg_model.geo_net.embed_fn
+    table = (torch.randn_like(emb.embeddings) * 0.1).contiguous()
+    g = torch.Generator().manual_seed(8)
+    for n in (1, 1000, 50021):
+        lo, hi = torch.tensor(list(emb.desc.min_xyz)), torch.tensor(list(emb.desc.max_xyz))
+        x = (lo + (hi - lo) * (torch.rand(n, 3, generator=g) * 1.1 - 0.05)).to(gpu)       # 5 % beyond the box on every side
+        enc0 = F.hashgrid_fwd(x, table, emb.desc)
+        enc, corners = F.hashgrid_fwd_corners(x, table, emb.desc)
+        assert torch.equal(enc, enc0) and corners.shape == (n, emb.desc.n_levels, 8, emb.desc.n_feat)
+        jac = torch.randn(n, enc.shape[1], generator=g).to(gpu)
+        _, dx0 = F.hashgrid_bwd(x, table, jac, emb.desc, want_dtable=False, want_dxyz=True)
+        assert torch.equal(F.hashgrid_dxyz_corners(x, corners, jac, emb.desc), dx0)
+        gdx = torch.randn(n, 3, generator=g).to(gpu)
+        dd0, _, _ = F.hashgrid_bwd_bwd(x, gdx, table, jac, emb.desc, want_ddout=True, want_dtable=False, want_d2xyz=False)
+        assert torch.equal(F.hashgrid_ddout_corners(x, gdx, corners, emb.desc), dd0)
+        assert float(dx0.abs().max()) > 0 and float(dd0.abs().max()) > 0
