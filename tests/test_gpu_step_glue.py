@@ -260,3 +260,41 @@ def test_second_order_gathers_from_the_forwards_corners(gpu):
         dd0, _, _ = F.hashgrid_bwd_bwd(x, gdx, table, jac, emb.desc, want_ddout=True, want_dtable=False, want_d2xyz=False)
         assert torch.equal(F.hashgrid_ddout_corners(x, gdx, corners, emb.desc), dd0)
         assert float(dx0.abs().max()) > 0 and float(dd0.abs().max()) > 0
+
+
+def test_fused_adam_step_in_two_halves(gpu):
+    """FusedAdam.begin_step() / finish_step(exclude): the ranges a caller's kernels updated with the step's own numbers + the rest of the flat
+    buffer = one step() (same bits, same counters, EMA aliased onto the parameter included); misaligned or overlapping ranges are refused"""
+    from arcnerf_amd.ops import functional as F
+    from arcnerf_amd.optim import FusedAdam
+
+    def make():
+        torch.manual_seed(1)
+        ps = [torch.nn.Parameter(torch.randn(n, device=gpu)) for n in (1, 4096, 333, 20000, 64)]
+        opt = FusedAdam(ps, lr=1e-2, eps=1e-15, weight_decay=1e-6, ema_decay=0.95, ema_in_param=True, zero_grad_on_step=True).flatten()
+        return ps, opt
+
+    (pa, oa), (pb, ob) = make(), make()
+    g = torch.Generator().manual_seed(2)
+    for it in range(3):
+        grads = [torch.randn(p.numel(), generator=g).to(gpu) for p in pa]
+        for ps in (pa, pb):
+            for p, gr in zip(ps, grads):
+                p.grad.copy_(gr.view_as(p))
+        oa.step()
+        h = ob.begin_step()
+        fb = ob._flat[0]
+        _, _, o1 = ob.table_views(pb[1])
+        _, _, o3 = ob.table_views(pb[3])
+        mine = [(o1 + 1024, o1 + 4096), (o3, o3 + 8000)]            # "the caller's kernels": the same Adam on two ranges, by hand
+        F.adam_ema_step_runs(fb['params'], fb['grads'], fb['exp_avg'], fb['exp_avg_sq'], fb['params'], mine, h['step'], lr=h['lr'], betas=h['betas'],
+                             eps=h['eps'], weight_decay=h['weight_decay'], ema_decay=h['ema_decay'], grad_scale=h['grad_scale'], ema_step=h['ema_step'],
+                             zero_grad=True)
+        ob.finish_step(h, mine)
+        assert torch.equal(oa.flat_params(), ob.flat_params()) and torch.equal(oa._flat[0]['exp_avg_sq'], ob._flat[0]['exp_avg_sq'])
+        assert oa._flat[0]['step'] == ob._flat[0]['step'] == it + 1 and float(ob.flat_grads().abs().max()) == 0
+    h = ob.begin_step()
+    with pytest.raises(RuntimeError, match='aligned'):
+        ob.finish_step(h, [(6, 10)])
+    with pytest.raises(RuntimeError, match='disjoint'):
+        ob.finish_step(h, [(8, 64), (32, 128)])
