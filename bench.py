@@ -368,16 +368,16 @@ def bench_module(args, name, emit=True):
     ev_trace[0].record()
     for i in range(args.steps):
         step(args.warmup + i)
-        if os.environ.get('ARCN_BENCH_TRACE'):
-            trace.append(time.perf_counter() - t0)
-            ev_trace.append(torch.cuda.Event(enable_timing=True))
-            ev_trace[-1].record()
+        trace.append(time.perf_counter() - t0)
+        ev_trace.append(torch.cuda.Event(enable_timing=True))      # (one event per step: the per-step device times below, ~2 us each)
+        ev_trace[-1].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if trace:
+    step_gpu_ms = sorted(a.elapsed_time(b) for a, b in zip(ev_trace[:-1], ev_trace[1:]))
+    if os.environ.get('ARCN_BENCH_TRACE'):
         print('TRACE', name, [round(t * 1e3, 3) for t in trace], round(dt * 1e3, 3), 'gpu', [round(a.elapsed_time(b), 3) for a, b in zip(ev_trace[:-1], ev_trace[1:])], 'rebuilds', fused.rebuilds if fused is not None else None, file=sys.stderr, flush=True)
     if spec['evals'] is None:
         meter = fg._meter()
@@ -445,6 +445,9 @@ def bench_module(args, name, emit=True):
                name, spec['desc'], n_rays, evals_per_step, spec['yaml']), 'rays_per_step_per_gpu': n_rays,
                'samples_per_step_per_gpu': evals_per_step, 'n_params': flat_numel, 'parallelism': 'ray-sharded dp{}'.format(world),
                'chunk_pts': int(m.get_chunk_pts()), 'occupancy': args.occupancy, 'bkg_occupancy': bkg_occ,
+               # device time between the steps' end events, median / slowest: a step whose HOST side was stalled (shared hosts: this step is ~65 %
+               # host time on a quiet machine) shows in ms_per_step and in the maximum, not in the median
+               'step_ms_device': {'p50': step_gpu_ms[len(step_gpu_ms) // 2], 'max': step_gpu_ms[-1]} if step_gpu_ms else None,
                'launch': ('trainer.FusedNeusNgpStep: the step as a hand-ordered kernel chain (no autograd engine), the next batch\'s samplers on a second stream ({} steps)'.format(fused_neus.steps) if fused_neus is not None
                           else ('trainer.FusedNgpStep: the module API on NgpPipeline.train_step over the flattened optimiser\'s buffers, next {} batches marched '
                                 'early ({} steps in this run, {} eager warm-up steps before)'.format(fused.depth, fused.steps, 2) if fused is not None
@@ -789,7 +792,7 @@ def main():
                 a2.steps, a2.warmup = 32, 8
             try:
                 r = bench_module(a2, name, emit=False)
-                others[name] = {'ms_per_step': r['ms_per_step'], 'samples_per_s': r['value'], 'steps': a2.steps, 'warmup': a2.warmup,
+                others[name] = {'ms_per_step': r['ms_per_step'], 'ms_per_step_p50': (r['config'].get('step_ms_device') or {}).get('p50'), 'samples_per_s': r['value'], 'steps': a2.steps, 'warmup': a2.warmup,
                                 'rays_per_step': r['config']['rays_per_step_per_gpu'], 'samples_per_step': r['config']['samples_per_step_per_gpu'],
                                 'roofline_frac': (r['roofline'] or {}).get('frac_of_split_peak', (r['roofline'] or {}).get('frac')), 'roofline_peak': 'dense bf16 MFMA / 6 terms (417 TFLOP/s of f32-accurate work)' if 'frac_of_split_peak' in (r['roofline'] or {}) else 'HBM 8 TB/s',
                                 'roofline_frac_of_f32_mfma_peak': (r['roofline'] or {}).get('frac') if 'frac_of_split_peak' in (r['roofline'] or {}) else None, 'roofline_bound': (r['roofline'] or {}).get('bound'), 'bkg_samples_per_step': (r['roofline'] or {}).get('bkg_samples_per_step'),
