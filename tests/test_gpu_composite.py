@@ -350,3 +350,59 @@ def test_fused_neus_ngp_step_equals_the_module_path(gpu):
     assert ra == rb_ and rma == rmb
     assert max(abs(x - y) / abs(x) for x, y in zip(la_, lb_)) < 1e-4, (la_, lb_)
     assert float(((pa - pb).abs() > 1e-3 * float(pa.abs().max())).float().mean()) < 1e-3
+
+
+def test_fused_neus_ngp_step_at_the_bench_size(gpu):
+    """BASELINE config 4 at bench.py's size (4096 rays, ~1.25e5 foreground points + ~0.76e5 background samples, both occupancy structures at 5 %):
+    the hand-ordered chain's losses, outputs and flat gradient against the module path on the same batch from the same state, and the kept
+    corners against the table gathers (ARCN_NEUS_CORNERS): the properties that do not depend on the size, at the size the metric is quoted on"""
+    from arcnerf_amd import trainer as T
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.ops.multivol_func import multivol_rng
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    from arcnerf_amd.optim import FusedAdam
+    from arcnerf_amd.pipeline import synthetic_bitfield, synthetic_cascade_bits, synthetic_rays
+    from arcnerf_amd.utils.cfgs_utils import dict_to_obj, load_configs
+    n_rays = 4096
+    loss_cfg = dict_to_obj({'loss': {'ImgLoss': {'loss_type': 'Huber', 'delta': 0.1, 'weight': 5.0}, 'EikonalLoss': {'key': 'normal_pts', 'weight': 0.1}}})
+    g = torch.Generator().manual_seed(11)
+    o, d = synthetic_rays(n_rays, seed=0, device=gpu, radius=2.2)
+    batch = {'rays_o': o.view(1, -1, 3), 'rays_d': d.view(1, -1, 3), 'rays_r': torch.zeros(1, n_rays, 1, device=gpu),
+             'bkg_color': torch.rand(1, n_rays, 3, generator=g).to(gpu), 'img': torch.rand(1, n_rays, 3, generator=g).to(gpu)}
+
+    def make():
+        torch.manual_seed(0)
+        m = build_model(load_configs(os.path.join(ROOT, 'configs', 'neus_ngp_multivol.yaml'), [])).to(gpu)
+        m.fg_model.obj_bound.volume.update_bitfield(torch.from_numpy(synthetic_bitfield(128, 0.05, seed=0)).to(gpu), ops='overwrite')
+        m.bkg_model.density_bitfield.copy_(torch.from_numpy(synthetic_cascade_bits(128, m.bkg_model.n_levels, 0.05, seed=5)).to(gpu))
+        with torch.no_grad():
+            m.fg_model.geo_net.embed_fn.embeddings.mul_(200.0)
+            m.bkg_model.geo_net.embed_fn.embeddings.mul_(2000.0)
+        opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=5e-4, eps=1e-15).flatten()
+        sampler_rng(reset=True)
+        multivol_rng(reset=True)
+        m.train()
+        return m, opt, T.build_loss(loss_cfg)
+
+    m, opt, lf = make()
+    out = m(dict(batch), inference_only=False, cur_epoch=20000)
+    la = lf(batch, out)
+    opt.zero_grad()
+    la['sum'].backward()
+    g_a = opt.flat_grads().clone()
+    grads = {}
+    for corners in (True, False):
+        m, opt, lf = make()
+        st = T.FusedNeusNgpStep(m, lf, opt)
+        st.apply_optimizer, st.keep_corners = False, corners
+        opt.zero_grad()
+        out_b, lb = st(batch, 20000)
+        grads[corners] = opt.flat_grads().clone()
+        for k in ('ImgLoss', 'EikonalLoss', 'sum'):
+            assert abs(float(la[k].detach()) - float(lb[k])) <= 2e-5 * abs(float(la[k].detach())) + 1e-7, (k, float(la[k].detach()), float(lb[k]))
+        for k in ('rgb', 'depth', 'mask', 'normal'):
+            assert torch.allclose(out[k], out_b[k], rtol=1e-5, atol=1e-5), k
+        scale = float(g_a.abs().max())
+        assert scale > 0 and float((g_a - grads[corners]).abs().max()) <= 2e-5 * scale, float((g_a - grads[corners]).abs().max() / scale)
+    # the corners are the table's rows: every non-table gradient is the same bits; the tables' differ by the order their records arrive in
+    assert float((grads[True] - grads[False]).abs().max()) <= 2e-6 * float(g_a.abs().max())
