@@ -155,6 +155,7 @@ class FusedAdam(torch.optim.Optimizer):
             at = hi
         if at < total:
             runs.append((at, total))
+        param_epoch.bump()      # (again: anything cached between begin_step() and here was computed from the old parameters)
         for k in range(0, len(runs), 4):
             F.adam_ema_step_runs(fb['params'], fb['grads'], fb['exp_avg'], fb['exp_avg_sq'], fb['params'] if self.ema_in_param else None, runs[k:k + 4],
                                  hyper['step'], lr=hyper['lr'], betas=hyper['betas'], eps=hyper['eps'], weight_decay=hyper['weight_decay'],

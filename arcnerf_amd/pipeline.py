@@ -756,6 +756,7 @@ class NgpPipeline:
         """fused Adam + EMA (+ gradient clear) on the whole flat buffer or on its slice [lo, hi) (pipelined gradient sync:
         one call per segment, `advance` only on the first so every segment sees the same step count)."""
         cfg, fld = self.cfg, self.field
+        param_epoch.bump()      # (the parameters change here: whatever was cached from them since train_step() began is old)
         if self._occ_params_event is not None:
             torch.cuda.current_stream().wait_event(self._occ_params_event)
             self._occ_params_event = None
