@@ -785,7 +785,8 @@ def main():
         torch.cuda.set_stream(torch.cuda.default_stream())
         for name in (os.environ.get('ARCN_OTHER_CONFIGS', 'ngp_module,nerf,neus,neus_ngp_multivol,hdrnerf').split(',')):
             a2 = copy.copy(args)
-            a2.steps, a2.warmup, a2.rays, a2.chunk_pts, a2.no_cpu_baseline = 8, 3, 0, 0, True
+            # (24 steps after 6: the 8-after-3 legs of rounds 2 - 4 read the wide configs 1 - 3 % high - allocator growth and clocks still settling)
+            a2.steps, a2.warmup, a2.rays, a2.chunk_pts, a2.no_cpu_baseline = 24, 6, 0, 0, True
             if name == 'ngp_module':    # the headline's model through the drop-in API: the driver's own K / W (+ the stepper's two eager steps)
                 a2.steps, a2.warmup = min(args.steps, 2000), min(args.warmup, 500) + 2
             elif name == 'neus_ngp_multivol':     # 2 ms steps: eight of them are not a steady state (buffers still growing, 2.19 vs 1.96 ms stand-alone)
