@@ -10,7 +10,7 @@ chain, the loss gradients, then every node's backward by hand - writes the param
 buffers and calls the optimiser: the model, its state_dict, `model.optimize` and inference through the module stay what they are.
 
     stepper = FusedNeusNgpStep(model, loss_factory, optimizer)           # raises if the combination is not the config-4 recipe
-    output, loss = stepper(feed_in, epoch, next_feed_in=batch_of_the_next_step)   # in place of trainer.step_optimize
+    output, loss = stepper(feed_in, epoch, next_feed_in=batch_of_the_next_step)   # in place of trainer.step_optimize (or a list: the next TWO batches)
 
 What the chain is (reference: neus_model.py:63-104, sdf_model.py:42-101, base_network.py:30-44, multivol_bkg_model.py:74-148,
 full_model.py:278-330):
@@ -24,7 +24,7 @@ full_model.py:278-330):
                PACKED normals with the dense layout's weights (arcn_eikonal_packed): the (rays, P, 3) tensor is never built
   backward     every node in reverse, second-order pieces included: the normals' gradient reaches the table through arcn_hashgrid_bwd_bwd and
                the sdf net's weights through the gradient of J.
-The samplers of the NEXT batch run on a second stream meanwhile (FullModel.prefetch_samples).
+The samplers of the next one or two batches run on a second stream meanwhile (_march_ahead).
 `output` holds rgb / depth / mask / normal and params like the module's; `normal_pts` is not materialised (the loss it exists for is inside).
 """
 import torch
@@ -137,6 +137,7 @@ class FusedNeusNgpStep:
         self.eik_w, self.eik_name = float(loss_factory.weights[el]), loss_factory.names[el]
         self.steps = 0
         self._ws = {}
+        self._ahead = []                 # batches marched ahead: (rays key, occupancy key, foreground handle, background handle), oldest first
         self.apply_optimizer = True      # (False: the gradients stay in the flat buffer - tests compare them with autograd's)
         # the table scatters' chunk owners apply Adam to the levels they own alone (arcn_hashgrid_bwd_lm_adam / _first_second_adam): those levels'
         # gradients never go to HBM and the optimiser pass shrinks to the rest of the flat buffer.  ARCN_FUSE_ADAM=0: scatter, then one pass
@@ -159,6 +160,49 @@ class FusedNeusNgpStep:
         if z is None or z.numel() < n or z.device != device:
             z = self._ws['zeros'] = torch.zeros(max(int(n * 1.25), 1 << 16), dtype=torch.float32, device=device)
         return z[:n]
+
+    # ---- the samplers of coming batches, on a second stream ---------------------------------------------------------------------------------
+    @staticmethod
+    def _rays_key(rays_o, rays_d):
+        return (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], rays_o._version, rays_d._version)
+
+    def _occupancy_key(self):
+        """what the two samplers read besides the rays: (pointer, version) of the foreground volume's bitfield and of the cascade's"""
+        bf = self.fg.obj_bound.volume.get_voxel_bitfield()
+        db = self.bkg.density_bitfield
+        # (the cascade's bits are rewritten by a kernel, behind torch's version counter: MortonDensityGrid counts its refreshes in ema_step)
+        return (bf.data_ptr(), bf._version, db.data_ptr(), db._version, int(getattr(self.bkg, 'ema_step', 0)))
+
+    def _march_ahead(self, feeds):
+        """Queue both samplers (+ their scans, the totals on their way to pinned memory) for the batches of `feeds` that are not marched yet, in
+        order, on the sampling stream - behind everything the main stream has been given so far.  One batch ahead the step's start finds totals
+        that arrived half a step ago; TWO batches ahead (a list of two) the host can issue a whole step while the device is still in the one
+        before - a host that stalls for a millisecond (shared machines) no longer stalls the device.  Each sampler advances its generator once
+        per batch in batch order, as without any of this: the same samples."""
+        have = {e[0] for e in self._ahead}
+        todo = []
+        for f in feeds:
+            o = f['rays_o'].reshape(-1, 3)
+            d = f['rays_d'].reshape(-1, 3)
+            if not (o.is_cuda and o.is_contiguous() and d.is_contiguous() and o.dtype == torch.float32 and d.dtype == torch.float32):
+                break
+            k = self._rays_key(o, d)
+            if k in have:
+                continue
+            todo.append((k, o, d))
+            have.add(k)
+        if not todo:
+            return
+        st = getattr(self.model, '_sample_stream', None)
+        if st is None or st.device != todo[0][1].device:
+            st = self.model._sample_stream = torch.cuda.Stream(device=todo[0][1].device)
+        st.wait_stream(torch.cuda.current_stream())
+        occ = self._occupancy_key()
+        with torch.cuda.stream(st):
+            for k, o, d in todo:
+                hb = self.bkg._sample_begin(o, d)
+                hf = self.fg._sample_begin(o, d)
+                self._ahead.append((k, occ, hf, hb))
 
     @staticmethod
     def _level_ranges(emb, mask, first):
@@ -197,25 +241,25 @@ class FusedNeusNgpStep:
         hyper = self.opt.begin_step() if (self.apply_optimizer and self.fuse_adam) else None      # this step's optimiser numbers, for the scatters
         done = []                                                                                 # float ranges the scatters' owners have updated
         cur = torch.cuda.current_stream()
-        key = (rays_o.data_ptr(), rays_d.data_ptr(), R, rays_o._version, rays_d._version)
-
-        def take(mdl):
-            pre, mdl._presampled = getattr(mdl, '_presampled', None), None
-            if pre is not None and pre[0] == key:
-                h = pre[1]
-                cur.wait_event(h['event'])
-                for t_ in h.values():
-                    for u in (t_ if isinstance(t_, tuple) else (t_,)):
-                        if isinstance(u, torch.Tensor) and u.is_cuda:
-                            u.record_stream(cur)
-                return h
-            return mdl._sample_begin(rays_o, rays_d)
-
-        # ---- samples of both models (marched a step ago on the sampling stream, or now)
-        h_bkg = take(bkg) if getattr(bkg, '_presampled', None) is not None else None
-        h_fg = take(fg)
-        if h_bkg is None:
-            h_bkg = bkg._sample_begin(rays_o, rays_d)
+        # ---- samples of both models: marched one or two steps ago on the sampling stream (self._ahead, oldest first), or now
+        h_fg = h_bkg = None
+        key, occ = self._rays_key(rays_o, rays_d), self._occupancy_key()
+        while self._ahead:
+            k_, occ_, hf_, hb_ = self._ahead.pop(0)
+            if k_ == key and occ_ == occ:
+                for h in (hf_, hb_):
+                    cur.wait_event(h['event'])
+                    for t_ in h.values():
+                        for u in (t_ if isinstance(t_, tuple) else (t_,)):
+                            if isinstance(u, torch.Tensor) and u.is_cuda:
+                                u.record_stream(cur)
+                h_fg, h_bkg = hf_, hb_
+                break
+            # (another batch, or an occupancy structure changed since: what was marched ahead is dropped, like FullModel's one-slot form does)
+        if h_fg is None:
+            self._ahead = []
+            h_bkg = bkg._sample_begin(rays_o, rays_d)      # (the order FullModel runs the two samplers in: each has its own generator anyway)
+            h_fg = fg._sample_begin(rays_o, rays_d)
         pk = F.neus_pack_end(h_fg, float(fg.get_ray_cfgs('n_sample')))
         t_b, ray_b, off_b, pd_b, total_b = F.pack_dense_samples_end(h_bkg)
         S = pk['total']
@@ -288,7 +332,7 @@ class FusedNeusNgpStep:
             depth_b = rays_o.new_zeros((R,))
         # the samplers of the next batch, beside everything that follows
         if self.prefetch and next_feed_in is not None:
-            model.prefetch_samples(next_feed_in)
+            self._march_ahead(next_feed_in if isinstance(next_feed_in, (list, tuple)) else [next_feed_in])
         # ---- blend + losses
         il = self.img_loss
         bl = F.neus_blend_loss(rgb_f, depth_f, t_last, rgb_b, depth_b, img, float(il.loss.delta) if isinstance(il.loss, HuberLoss) else None, self.img_w)

@@ -341,7 +341,9 @@ def bench_module(args, name, emit=True):
     def step(i):
         inp = pool[i % len(pool)]
         if fused_neus is not None:
-            return fused_neus(inp, 20000 + i, next_feed_in=pool[(i + 1) % len(pool)] if prefetch else None)[1]['sum']
+            # (the samplers of the next TWO batches on the sampling stream: the host can issue a whole step ahead of the device, ARCN_NEUS_AHEAD=1: one)
+            ahead = [pool[(i + k) % len(pool)] for k in range(1, 1 + int(os.environ.get('ARCN_NEUS_AHEAD', '2')))]
+            return fused_neus(inp, 20000 + i, next_feed_in=ahead if prefetch else None)[1]['sum']
         if fused is not None:
             return fused(inp, 20000 + i, next_feed_in=[pool[(i + k) % len(pool)] for k in range(1, fused.depth + 1)])[1]['sum']
         out = m({k: v for k, v in inp.items()}, inference_only=False, cur_epoch=20000 + i)

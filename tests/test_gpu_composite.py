@@ -323,7 +323,7 @@ def test_fused_neus_ngp_step_equals_the_module_path(gpu):
             assert float(p.grad.abs().max()) > 0, name
     # (b) three iterations with the optimiser, the next batch's samplers prefetched: the module path's parameters
     runs = {}
-    for mode in ('eager', 'fused', 'fused_two_pass'):
+    for mode in ('eager', 'fused', 'fused_two_pass', 'fused_two_ahead'):
         m, opt, lf = make()
         st = T.FusedNeusNgpStep(m, lf, opt) if mode != 'eager' else None
         if mode == 'fused':
@@ -332,7 +332,10 @@ def test_fused_neus_ngp_step_equals_the_module_path(gpu):
             st.fuse_adam = False          # scatter into .grad, then one optimiser pass over the whole buffer
         losses = []
         for i in range(3):
-            if st is not None:
+            if st is not None and mode == 'fused_two_ahead':       # the samplers of the next TWO batches queued ahead
+                _, l = st(pool[i], 20000 + i, next_feed_in=pool[i + 1:i + 3] or None)
+                assert len(st._ahead) == min(2, 2 - i)
+            elif st is not None:
                 _, l = st(pool[i], 20000 + i, next_feed_in=pool[i + 1] if i < 2 else None)
             else:
                 _, l = T.step_optimize(m, dict(pool[i]), lf, opt, None, 20000 + i)
@@ -346,6 +349,11 @@ def test_fused_neus_ngp_step_equals_the_module_path(gpu):
     assert max(abs(x - y) / abs(x) for x, y in zip(lf_, lt_)) < 1e-5, (lf_, lt_)
     assert float(((pf - pt).abs() > 1e-3 * float(pf.abs().max())).float().mean()) < 1e-3
     assert runs['fused'][2:] == runs['fused_two_pass'][2:]
+    # two batches ahead: the same samples (both generators in the same state), the same trajectory up to the same summation-order noise
+    la2, pa2 = runs['fused_two_ahead'][:2]
+    assert runs['fused_two_ahead'][2:] == runs['fused'][2:]
+    assert max(abs(x - y) / abs(x) for x, y in zip(lf_, la2)) < 1e-5, (lf_, la2)
+    assert float(((pf - pa2).abs() > 1e-3 * float(pf.abs().max())).float().mean()) < 1e-3
     (la_, pa, ra, rma), (lb_, pb, rb_, rmb) = runs['eager'], runs['fused']
     assert ra == rb_ and rma == rmb
     assert max(abs(x - y) / abs(x) for x, y in zip(la_, lb_)) < 1e-4, (la_, lb_)

@@ -28,9 +28,15 @@ m.train()
 stepper = T.FusedNeusNgpStep(m, loss, opt)
 
 
+AHEAD = int(os.environ.get('AHEAD', '2'))
+STALL_MS = float(os.environ.get('STALL_MS', '0'))      # a host that disappears for this long before every 4th step (a busy shared machine)
+
+
 def run(lo, hi):
     for i in range(lo, hi):
-        stepper(pool[i % 4], 20000 + i, next_feed_in=pool[(i + 1) % 4])
+        if STALL_MS > 0 and i % 4 == 0:
+            time.sleep(STALL_MS * 1e-3)
+        stepper(pool[i % 4], 20000 + i, next_feed_in=[pool[(i + k) % 4] for k in range(1, AHEAD + 1)])
 
 
 run(0, 16)
@@ -38,7 +44,9 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 run(16, 76)
 torch.cuda.synchronize()
-print('wall per step: %.3f ms (%d rays)' % ((time.perf_counter() - t0) / 60 * 1e3, n_rays))
+print('wall per step: %.3f ms (%d rays, %d batches ahead, host stall %.1f ms every 4th step)' % ((time.perf_counter() - t0) / 60 * 1e3, n_rays, AHEAD, STALL_MS))
+if os.environ.get('NO_PROFILE'):
+    sys.exit(0)
 pr = cProfile.Profile()
 pr.enable()
 run(76, 136)
