@@ -82,14 +82,11 @@ __device__ __forceinline__ Cell locate(const float p[3], const GridParams &g, co
     return cell;
 }
 
-// corners (optional): the 8 gathered table rows of every (sample, level), corners[((s * L + l) * 8 + q) * F + f] (zeros outside the grid) - what
-// the two second-order gathers of NeuS on the hash grid (the normal d enc / d x . jac, and the gradient of that with respect to jac) need of
-// the table: they then STREAM 64 bytes per lane instead of repeating eight random 8-byte reads (arcn_hashgrid_dxyz_corners / _ddout_corners)
 template <int F>
 __global__ void __launch_bounds__(256) hashgrid_fwd_kernel(const float *__restrict__ xyz, const float *__restrict__ table,
                                                            GridParams g, float *__restrict__ out,
                                                            int32_t *__restrict__ hash_idx, int64_t n,
-                                                           const int32_t *n_ptr, float *__restrict__ corners = nullptr) {
+                                                           const int32_t *n_ptr) {
     const int64_t cnt = dev_count(n, n_ptr);
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= cnt * g.L) return;
@@ -136,22 +133,10 @@ __global__ void __launch_bounds__(256) hashgrid_fwd_kernel(const float *__restri
             for (int f = 0; f < F; ++f) { float a = vals[q][f] * wt; acc[f] = acc[f] + a; }
             if (hash_idx) hash_idx[gid * 8 + q] = (int32_t)((int64_t)rows[q] + lp.offset);
         }
-        if (corners) {
-            float *c = corners + gid * 8 * F;
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-#pragma unroll
-                for (int f = 0; f < F; ++f) c[q * F + f] = vals[q][f];
-        }
     } else {
         if (hash_idx) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) hash_idx[gid * 8 + q] = -1;
-        }
-        if (corners) {
-            float *c = corners + gid * 8 * F;
-#pragma unroll
-            for (int q = 0; q < 8 * F; ++q) c[q] = 0.f;
         }
     }
     float *o = out + gid * F;
@@ -187,7 +172,7 @@ template <int F>
 __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(const float *__restrict__ xyz, const float *__restrict__ table,
                                                            const float *__restrict__ dout, GridParams g,
                                                            float *__restrict__ dtable, float *__restrict__ dxyz, int64_t n,
-                                                           const int32_t *n_ptr, const float *__restrict__ corners = nullptr) {
+                                                           const int32_t *n_ptr) {
     const int64_t cnt = dev_count(n, n_ptr);
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= cnt * g.L) return;
@@ -200,13 +185,11 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(const float *__restri
 #pragma unroll
     for (int f = 0; f < F; ++f) go[f] = dout[gid * F + f];
     float gx[3] = {0.f, 0.f, 0.f};
-    // (corners: the forward's gathered rows of this lane, arcn_hashgrid_fwd_corners - no hash, no table read; dxyz only)
-    const float *cv = corners ? corners + gid * 8 * F : nullptr;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         if (!cell.valid) break;
         const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
-        const int64_t row = cv ? 0 : (int64_t)hash_row(cell.c[0] + ox, cell.c[1] + oy, cell.c[2] + oz, lp) + lp.offset;
+        const int64_t row = (int64_t)hash_row(cell.c[0] + ox, cell.c[1] + oy, cell.c[2] + oz, lp) + lp.offset;
         float wx = ox ? cell.w[0] : 1.0f - cell.w[0];
         float wy = oy ? cell.w[1] : 1.0f - cell.w[1];
         float wz = oz ? cell.w[2] : 1.0f - cell.w[2];
@@ -218,7 +201,7 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(const float *__restri
         if (dxyz) {
             float dot = 0.f;
 #pragma unroll
-            for (int f = 0; f < F; ++f) dot += go[f] * (cv ? cv[q * F + f] : table[row * F + f]);
+            for (int f = 0; f < F; ++f) dot += go[f] * table[row * F + f];
             float sx = ox ? 1.0f : -1.0f, sy = oy ? 1.0f : -1.0f, sz = oz ? 1.0f : -1.0f;
             gx[0] += dot * sx * wy * wz * cell.dw[0];
             gx[1] += dot * wx * sy * wz * cell.dw[1];
@@ -240,7 +223,7 @@ template <int F>
 __global__ void __launch_bounds__(256)
 hashgrid_bwd_bwd_kernel(const float *__restrict__ xyz, const float *__restrict__ gdx, const float *__restrict__ table,
                         const float *__restrict__ dout, GridParams g, float *__restrict__ ddout, float *__restrict__ dtable,
-                        float *__restrict__ d2xyz, int64_t n, const int32_t *n_ptr, const float *__restrict__ corners = nullptr) {
+                        float *__restrict__ d2xyz, int64_t n, const int32_t *n_ptr) {
     const int64_t cnt = dev_count(n, n_ptr);
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= cnt * g.L) return;
@@ -259,12 +242,10 @@ hashgrid_bwd_bwd_kernel(const float *__restrict__ xyz, const float *__restrict__
 #pragma unroll
         for (int f = 0; f < F; ++f) go[f] = dout ? dout[gid * F + f] : 0.f;
         float hx[3] = {0.f, 0.f, 0.f};
-        // (corners: the forward's gathered rows of this lane - no hash, no table read; for ddout alone, arcn_hashgrid_ddout_corners)
-        const float *cv = corners ? corners + gid * 8 * F : nullptr;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const uint32_t o[3] = {(uint32_t)((q >> 1) & 1), (uint32_t)(q & 1), (uint32_t)(q >> 2)};
-            const int64_t row = cv ? 0 : (int64_t)hash_row(cell.c[0] + o[0], cell.c[1] + o[1], cell.c[2] + o[2], lp) + lp.offset;
+            const int64_t row = (int64_t)hash_row(cell.c[0] + o[0], cell.c[1] + o[1], cell.c[2] + o[2], lp) + lp.offset;
             float a[3], sd[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -277,7 +258,7 @@ hashgrid_bwd_bwd_kernel(const float *__restrict__ xyz, const float *__restrict__
             float dot = 0.f;
 #pragma unroll
             for (int f = 0; f < F; ++f) {
-                const float t = cv ? cv[q * F + f] : table[row * F + f];
+                const float t = table[row * F + f];
                 acc[f] = acc[f] + t * D;
                 dot += go[f] * t;
                 if (dtable) unsafeAtomicAdd(&dtable[row * F + f], go[f] * D);
@@ -384,10 +365,13 @@ static int level_lowbits(const LevelParams &lp) {
     return (1ull << kb) > (uint64_t)lp.size ? 0 : kb;
 }
 
-template <int F, bool LM, bool PAIR>
+// CORNERS: the gathered rows are kept for the second-order gathers (arcn_hashgrid_dxyz_corners / _ddout_corners), level-major in 16-byte
+// quads: quad j of (sample s, level l) = rows 2j, 2j + 1 (F = 2) | rows 4j .. 4j + 3 (F = 1) at corners[((l * NJ + j) * n_cap + s) * 4],
+// NJ = 2 F - store j of a wave is 64 consecutive quads, one contiguous KiB, like the level-major features; zeros outside the grid.
+template <int F, bool LM, bool PAIR, bool CORNERS = false>
 __global__ void __launch_bounds__(256)
 hashgrid_fwd_bal_kernel(const float *__restrict__ xyz, const float *__restrict__ table, GridParams g, FwdPlan plan,
-                        float *__restrict__ out, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
+                        float *__restrict__ out, int64_t n_cap, int64_t n, const int32_t *n_ptr, float *__restrict__ corners = nullptr) {
     const int64_t cnt = dev_count(n, n_ptr);
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;
@@ -429,6 +413,13 @@ hashgrid_fwd_bal_kernel(const float *__restrict__ xyz, const float *__restrict__
         float acc[F];
 #pragma unroll
         for (int f = 0; f < F; ++f) acc[f] = 0.f;
+        float vals[8][F];
+        if (CORNERS) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int f = 0; f < F; ++f) vals[q][f] = 0.f;
+        }
         if (ok) {
             uint32_t c[3];
             float w[3];
@@ -443,7 +434,6 @@ hashgrid_fwd_bal_kernel(const float *__restrict__ xyz, const float *__restrict__
             }
             uint32_t rows[8];   // corner q: x = (q>>1)&1, y = q&1, z = q>>2
             corner_rows(c, lp, kb, rows);
-            float vals[8][F];
             const float *lt = table + lp.offset * F;
             // (a level whose first row is not 16-byte aligned - an odd row offset after dense levels of odd size, or a table segment at
             // an odd 8-byte offset of a flat parameter buffer - takes the 8-byte loads: the dwordx4 below must not straddle)
@@ -501,6 +491,167 @@ hashgrid_fwd_bal_kernel(const float *__restrict__ xyz, const float *__restrict__
 #pragma unroll
             for (int f = 0; f < F; ++f) o[f] = acc[f];
         }
+        if (CORNERS) {
+            constexpr int NJ = 2 * F;
+            const float *vf = &vals[0][0];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                *reinterpret_cast<float4 *>(corners + (((int64_t)l * NJ + j) * n_cap + s) * 4) = make_float4(vf[4 * j], vf[4 * j + 1], vf[4 * j + 2], vf[4 * j + 3]);
+        }
+    }
+}
+
+// ---- the second-order gathers of NeuS on the hash grid from the forward's corners ----------------------------------------------------------
+// One lane per SAMPLE, the levels in a loop: the corner quads of a level are 64 consecutive 16-byte words per wave (streaming, coalesced),
+// the per-sample operands (dout / ddout rows of L F floats) are one cache line a lane walks through.  The arithmetic per (sample, level) is
+// that of hashgrid_bwd_kernel (dxyz) / hashgrid_bwd_bwd_kernel (ddout) above on the same values in the same order, and the sum over the
+// levels of dxyz follows add_over_levels' butterfly (L a power of two): the results are the table forms' bit for bit.
+template <int F>
+__device__ __forceinline__ void load_corner_quads(const float *__restrict__ corners, int l, int64_t n_cap, int64_t s, float cv[8 * F]) {
+    constexpr int NJ = 2 * F;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const float4 t = *reinterpret_cast<const float4 *>(corners + (((int64_t)l * NJ + j) * n_cap + s) * 4);
+        cv[4 * j] = t.x; cv[4 * j + 1] = t.y; cv[4 * j + 2] = t.z; cv[4 * j + 3] = t.w;
+    }
+}
+
+template <int F>
+__global__ void __launch_bounds__(256)
+hashgrid_dxyz_corners_kernel(const float *__restrict__ xyz, const float *__restrict__ corners, const float *__restrict__ dout, GridParams g,
+                             float *__restrict__ dxyz, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cnt) return;
+    const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
+    const bool tree = (g.L & (g.L - 1)) == 0;
+    // add_over_levels' butterfly as a binary counter: st[d] = the finished sum of an aligned group of 2^d levels waiting for its right-hand
+    // neighbour; level l merges upwards through its trailing one bits - (v0 + v1) + (v2 + v3) ... in the butterfly's own order
+    float st[6][3];
+    float seq[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int l = 0; l < g.L; ++l) {
+        const LevelParams lp = g.lv[l];
+        const Cell cell = locate(p, g, lp);
+        float gx[3] = {0.f, 0.f, 0.f};
+        if (cell.valid) {
+            float go[F];
+            if (F == 2) {
+                const float2 t2 = *reinterpret_cast<const float2 *>(dout + (s * g.L + l) * F);
+                go[0] = t2.x; go[1 % F] = t2.y;
+            } else {
+#pragma unroll
+                for (int f = 0; f < F; ++f) go[f] = dout[(s * g.L + l) * F + f];
+            }
+            float cv[8 * F];
+            load_corner_quads<F>(corners, l, n_cap, s, cv);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
+                float wx = ox ? cell.w[0] : 1.0f - cell.w[0];
+                float wy = oy ? cell.w[1] : 1.0f - cell.w[1];
+                float wz = oz ? cell.w[2] : 1.0f - cell.w[2];
+                float dot = 0.f;
+#pragma unroll
+                for (int f = 0; f < F; ++f) dot += go[f] * cv[q * F + f];
+                float sx = ox ? 1.0f : -1.0f, sy = oy ? 1.0f : -1.0f, sz = oz ? 1.0f : -1.0f;
+                gx[0] += dot * sx * wy * wz * cell.dw[0];
+                gx[1] += dot * wx * sy * wz * cell.dw[1];
+                gx[2] += dot * wx * wy * sz * cell.dw[2];
+            }
+        }
+        if (tree) {
+            bool placed = false;
+#pragma unroll
+            for (int d = 0; d < 6; ++d) {
+                if (placed) continue;
+                if ((l >> d) & 1) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) gx[k] = st[d][k] + gx[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) st[d][k] = gx[k];
+                    placed = true;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) seq[k] += gx[k];
+        }
+    }
+    if (tree) {
+        int top = 0;
+        while ((1 << top) < g.L) ++top;
+#pragma unroll
+        for (int d = 0; d < 6; ++d)
+            if (d == top) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) seq[k] = st[d][k];
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dxyz[3 * s + k] = 0.f + seq[k];      // (the table form adds into a cleared buffer: -0 becomes +0 there too)
+}
+
+template <int F>
+__global__ void __launch_bounds__(256)
+hashgrid_ddout_corners_kernel(const float *__restrict__ xyz, const float *__restrict__ gdx, const float *__restrict__ corners, GridParams g,
+                              float *__restrict__ ddout, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cnt) return;
+    const float p[3] = {xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]};
+    const float gd[3] = {gdx[3 * s], gdx[3 * s + 1], gdx[3 * s + 2]};
+#pragma unroll 1
+    for (int l = 0; l < g.L; ++l) {
+        const LevelParams lp = g.lv[l];
+        const Cell cell = locate(p, g, lp);
+        float acc[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f] = 0.f;
+        if (cell.valid) {
+            float cv[8 * F];
+            load_corner_quads<F>(corners, l, n_cap, s, cv);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t o[3] = {(uint32_t)((q >> 1) & 1), (uint32_t)(q & 1), (uint32_t)(q >> 2)};
+                float a[3], sd[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    a[k] = o[k] ? cell.w[k] : 1.0f - cell.w[k];
+                    sd[k] = o[k] ? cell.dw[k] : -cell.dw[k];
+                }
+                float D = gd[0] * sd[0] * a[1] * a[2];
+                D = D + gd[1] * a[0] * sd[1] * a[2];
+                D = D + gd[2] * a[0] * a[1] * sd[2];
+#pragma unroll
+                for (int f = 0; f < F; ++f) acc[f] = acc[f] + cv[q * F + f] * D;
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) ddout[(s * g.L + l) * F + f] = acc[f];
+    }
+}
+
+// level-major features (L, n_cap, F) -> rows (n, ld) through an LDS tile: what the dense products (csrc/gemm.hip) read.  A workgroup moves 256
+// samples: per level 256 F consecutive floats in, L F consecutive floats per sample out - both sides whole cache lines.
+template <int F>
+__global__ void __launch_bounds__(256)
+lm_to_rows_kernel(const float *__restrict__ lm, int L, int64_t n_cap, float *__restrict__ rows, int64_t ld, int64_t n, const int32_t *n_ptr) {
+    extern __shared__ float tile[];      // [256][L F + 1]
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int64_t s0 = (int64_t)blockIdx.x * 256;
+    if (s0 >= cnt) return;
+    const int W = L * F, pitch = W + 1;
+    const int m = (int)((cnt - s0) < 256 ? (cnt - s0) : 256);
+    for (int i = threadIdx.x; i < L * 256 * F; i += 256) {
+        const int l = i / (256 * F), r = i - l * 256 * F, sl = r / F, f = r - sl * F;
+        if (sl < m) tile[sl * pitch + l * F + f] = lm[((int64_t)l * n_cap + s0 + sl) * F + f];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < m * W; i += 256) {
+        const int sl = i / W, c = i - sl * W;
+        rows[(s0 + sl) * ld + c] = tile[sl * pitch + c];
     }
 }
 
@@ -1375,64 +1526,6 @@ ARCN_EXPORT int arcn_hashgrid_fwd(const float *xyz, const float *table, const ar
     return check_launch("hashgrid_fwd");
 }
 
-/* arcn_hashgrid_fwd that also keeps the gathered rows: corners (n, L, 8, F) floats (see hashgrid_fwd_kernel) */
-ARCN_EXPORT int arcn_hashgrid_fwd_corners(const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out, float *corners,
-                                          int64_t n, void *stream) {
-    if (n <= 0) return ARCN_OK;
-    if (!xyz || !table || !out || !corners) return einval("hashgrid_fwd_corners: missing argument");
-    GridParams g;
-    int rc = build_params(desc_host, g);
-    if (rc) return rc;
-    dim3 grid((unsigned)ceil_div<int64_t>(n * g.L, 256));
-    const int32_t *nc = nullptr;
-    switch (g.F) {
-    case 1: hipLaunchKernelGGL(hashgrid_fwd_kernel<1>, grid, dim3(256), 0, as_stream(stream), xyz, table, g, out, (int32_t *)nullptr, n, nc, corners); break;
-    case 2: hipLaunchKernelGGL(hashgrid_fwd_kernel<2>, grid, dim3(256), 0, as_stream(stream), xyz, table, g, out, (int32_t *)nullptr, n, nc, corners); break;
-    default: hipLaunchKernelGGL(hashgrid_fwd_kernel<4>, grid, dim3(256), 0, as_stream(stream), xyz, table, g, out, (int32_t *)nullptr, n, nc, corners); break;
-    }
-    return check_launch("hashgrid_fwd_corners");
-}
-
-/* dxyz (n, 3) += d <dout, enc(x)> / d x (what arcn_hashgrid_bwd adds with dxyz alone) from the forward's corners instead of the table: the
- * same arithmetic in the same order on the same values - bit-identical - as a streaming read (caller zeroes dxyz) */
-ARCN_EXPORT int arcn_hashgrid_dxyz_corners(const float *xyz, const float *corners, const float *dout, const arcn_hashgrid_desc *desc_host,
-                                           float *dxyz, int64_t n, void *stream) {
-    if (n <= 0) return ARCN_OK;
-    if (!xyz || !corners || !dout || !dxyz) return einval("hashgrid_dxyz_corners: missing argument");
-    GridParams g;
-    int rc = build_params(desc_host, g);
-    if (rc) return rc;
-    dim3 grid((unsigned)ceil_div<int64_t>(n * g.L, 256));
-    const int32_t *nc = nullptr;
-    const float *no_table = nullptr;
-    switch (g.F) {
-    case 1: hipLaunchKernelGGL(hashgrid_bwd_kernel<1>, grid, dim3(256), 0, as_stream(stream), xyz, no_table, dout, g, (float *)nullptr, dxyz, n, nc, corners); break;
-    case 2: hipLaunchKernelGGL(hashgrid_bwd_kernel<2>, grid, dim3(256), 0, as_stream(stream), xyz, no_table, dout, g, (float *)nullptr, dxyz, n, nc, corners); break;
-    default: hipLaunchKernelGGL(hashgrid_bwd_kernel<4>, grid, dim3(256), 0, as_stream(stream), xyz, no_table, dout, g, (float *)nullptr, dxyz, n, nc, corners); break;
-    }
-    return check_launch("hashgrid_dxyz_corners");
-}
-
-/* ddout (n, L F) = d <gdx, J(x; table)^T dout> / d dout (the ddout of arcn_hashgrid_bwd_bwd) from the forward's corners: bit-identical,
- * streaming */
-ARCN_EXPORT int arcn_hashgrid_ddout_corners(const float *xyz, const float *gdx, const float *corners, const arcn_hashgrid_desc *desc_host,
-                                            float *ddout, int64_t n, void *stream) {
-    if (n <= 0) return ARCN_OK;
-    if (!xyz || !gdx || !corners || !ddout) return einval("hashgrid_ddout_corners: missing argument");
-    GridParams g;
-    int rc = build_params(desc_host, g);
-    if (rc) return rc;
-    dim3 grid((unsigned)ceil_div<int64_t>(n * g.L, 256));
-    const int32_t *nc = nullptr;
-    const float *none = nullptr;
-    switch (g.F) {
-    case 1: hipLaunchKernelGGL(hashgrid_bwd_bwd_kernel<1>, grid, dim3(256), 0, as_stream(stream), xyz, gdx, none, none, g, ddout, (float *)nullptr, (float *)nullptr, n, nc, corners); break;
-    case 2: hipLaunchKernelGGL(hashgrid_bwd_bwd_kernel<2>, grid, dim3(256), 0, as_stream(stream), xyz, gdx, none, none, g, ddout, (float *)nullptr, (float *)nullptr, n, nc, corners); break;
-    default: hipLaunchKernelGGL(hashgrid_bwd_bwd_kernel<4>, grid, dim3(256), 0, as_stream(stream), xyz, gdx, none, none, g, ddout, (float *)nullptr, (float *)nullptr, n, nc, corners); break;
-    }
-    return check_launch("hashgrid_ddout_corners");
-}
-
 ARCN_EXPORT int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc *desc_host, int64_t n);
 
 static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *dout, int64_t dout_lm_stride,
@@ -1854,15 +1947,20 @@ static int build_fwd_plan(const GridParams &g, int64_t n, FwdPlan &plan, int &wg
 }
 
 // XCD-affine forward (n_feat 1 or 2).  level_major = 0: out (n, L*F) row-major like arcn_hashgrid_fwd;
-// level_major = 1: out[(l * n_cap + s) * F + f].
-ARCN_EXPORT int arcn_hashgrid_fwd_xcd(const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out,
-                                      int level_major, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+// level_major = 1: out[(l * n_cap + s) * F + f].  corners (optional): the gathered rows in level-major quads (hashgrid_fwd_bal_kernel).
+static int hashgrid_fwd_xcd_impl(const char *who, const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out,
+                                 int level_major, float *corners, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
     if (n <= 0) return ARCN_OK;
-    if (!xyz || !table || !out || n_cap < n) return einval("hashgrid_fwd_xcd: missing/invalid argument");
+    auto bad = [&](const char *what) {
+        char msg[160];
+        snprintf(msg, sizeof(msg), "%s: %s", who, what);
+        return einval(msg);
+    };
+    if (!xyz || !table || !out || n_cap < n) return bad("missing/invalid argument");
     GridParams g;
     int rc = build_params(desc_host, g);
     if (rc) return rc;
-    if (g.F > 2) return einval("hashgrid_fwd_xcd: n_feat 1 or 2");
+    if (g.F > 2) return bad("n_feat 1 or 2");
     FwdPlan plan;
     int wg_per_xcd = 0;
     rc = build_fwd_plan(g, n, plan, wg_per_xcd);
@@ -1872,9 +1970,71 @@ ARCN_EXPORT int arcn_hashgrid_fwd_xcd(const float *xyz, const float *table, cons
         if (only >= 0) for (int x = 0; x < 8; ++x) if (x != only) plan.n_seg[x] = 0;
     }
     dim3 grid((unsigned)(8 * wg_per_xcd));
-#define ARCN_BAL(F_, LM_, P_) hipLaunchKernelGGL((hashgrid_fwd_bal_kernel<F_, LM_, P_>), grid, dim3(256), 0, as_stream(stream), xyz, table, g, plan, out, n_cap, n, n_ptr)
-    if (g.F == 1) { if (level_major) ARCN_BAL(1, true, false); else ARCN_BAL(1, false, false); }
-    else { if (level_major) ARCN_BAL(2, true, true); else ARCN_BAL(2, false, true); }
+#define ARCN_BAL(F_, LM_, P_, C_) hipLaunchKernelGGL((hashgrid_fwd_bal_kernel<F_, LM_, P_, C_>), grid, dim3(256), 0, as_stream(stream), xyz, table, g, plan, out, n_cap, n, n_ptr, corners)
+    if (corners) {
+        if (g.F == 1) { if (level_major) ARCN_BAL(1, true, false, true); else ARCN_BAL(1, false, false, true); }
+        else { if (level_major) ARCN_BAL(2, true, true, true); else ARCN_BAL(2, false, true, true); }
+    } else {
+        if (g.F == 1) { if (level_major) ARCN_BAL(1, true, false, false); else ARCN_BAL(1, false, false, false); }
+        else { if (level_major) ARCN_BAL(2, true, true, false); else ARCN_BAL(2, false, true, false); }
+    }
 #undef ARCN_BAL
-    return check_launch("hashgrid_fwd_xcd");
+    return check_launch(who);
+}
+
+ARCN_EXPORT int arcn_hashgrid_fwd_xcd(const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out,
+                                      int level_major, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+    return hashgrid_fwd_xcd_impl("hashgrid_fwd_xcd", xyz, table, desc_host, out, level_major, nullptr, n_cap, n, n_ptr, stream);
+}
+
+/* arcn_hashgrid_fwd_xcd that also keeps the gathered rows (level-major quads, 8 F n_cap L floats) */
+ARCN_EXPORT int arcn_hashgrid_fwd_corners(const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out, int level_major,
+                                          float *corners, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+    if (n > 0 && !corners) return einval("hashgrid_fwd_corners: missing argument");
+    return hashgrid_fwd_xcd_impl("hashgrid_fwd_corners", xyz, table, desc_host, out, level_major, corners, n_cap, n, n_ptr, stream);
+}
+
+/* dxyz (n, 3) = d <dout, enc(x)> / d x (what arcn_hashgrid_bwd adds to a cleared dxyz) from the forward's corners instead of the table: the
+ * same arithmetic in the same order on the same values - bit-identical - as a streaming read */
+ARCN_EXPORT int arcn_hashgrid_dxyz_corners(const float *xyz, const float *corners, const float *dout, const arcn_hashgrid_desc *desc_host,
+                                           float *dxyz, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!xyz || !corners || !dout || !dxyz || n_cap < n) return einval("hashgrid_dxyz_corners: missing/invalid argument");
+    GridParams g;
+    int rc = build_params(desc_host, g);
+    if (rc) return rc;
+    if (g.F > 2) return einval("hashgrid_dxyz_corners: n_feat 1 or 2");
+    dim3 grid((unsigned)ceil_div<int64_t>(n, 256));
+    if (g.F == 1) hipLaunchKernelGGL(hashgrid_dxyz_corners_kernel<1>, grid, dim3(256), 0, as_stream(stream), xyz, corners, dout, g, dxyz, n_cap, n, n_ptr);
+    else hipLaunchKernelGGL(hashgrid_dxyz_corners_kernel<2>, grid, dim3(256), 0, as_stream(stream), xyz, corners, dout, g, dxyz, n_cap, n, n_ptr);
+    return check_launch("hashgrid_dxyz_corners");
+}
+
+/* ddout (n, L F) = d <gdx, J(x; table)^T dout> / d dout (the ddout of arcn_hashgrid_bwd_bwd) from the forward's corners: bit-identical,
+ * streaming */
+ARCN_EXPORT int arcn_hashgrid_ddout_corners(const float *xyz, const float *gdx, const float *corners, const arcn_hashgrid_desc *desc_host,
+                                            float *ddout, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!xyz || !gdx || !corners || !ddout || n_cap < n) return einval("hashgrid_ddout_corners: missing/invalid argument");
+    GridParams g;
+    int rc = build_params(desc_host, g);
+    if (rc) return rc;
+    if (g.F > 2) return einval("hashgrid_ddout_corners: n_feat 1 or 2");
+    dim3 grid((unsigned)ceil_div<int64_t>(n, 256));
+    if (g.F == 1) hipLaunchKernelGGL(hashgrid_ddout_corners_kernel<1>, grid, dim3(256), 0, as_stream(stream), xyz, gdx, corners, g, ddout, n_cap, n, n_ptr);
+    else hipLaunchKernelGGL(hashgrid_ddout_corners_kernel<2>, grid, dim3(256), 0, as_stream(stream), xyz, gdx, corners, g, ddout, n_cap, n, n_ptr);
+    return check_launch("hashgrid_ddout_corners");
+}
+
+/* level-major features lm[(l * n_cap + s) * F + f] (what arcn_hashgrid_fwd_xcd writes with level_major = 1) -> rows[s * ld + l * F + f] */
+ARCN_EXPORT int arcn_hashgrid_lm_to_rows(const float *lm, int n_levels, int n_feat, int64_t n_cap, float *rows, int64_t ld, int64_t n,
+                                         const int32_t *n_ptr, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!lm || !rows || n_cap < n || n_levels < 1 || n_levels > ARCN_MAX_LEVELS || (n_feat != 1 && n_feat != 2) || ld < n_levels * n_feat)
+        return einval("hashgrid_lm_to_rows: missing/invalid argument");
+    dim3 grid((unsigned)ceil_div<int64_t>(n, 256));
+    const size_t lds = (size_t)256 * (n_levels * n_feat + 1) * sizeof(float);
+    if (n_feat == 1) hipLaunchKernelGGL(lm_to_rows_kernel<1>, grid, dim3(256), lds, as_stream(stream), lm, n_levels, n_cap, rows, ld, n, n_ptr);
+    else hipLaunchKernelGGL(lm_to_rows_kernel<2>, grid, dim3(256), lds, as_stream(stream), lm, n_levels, n_cap, rows, ld, n, n_ptr);
+    return check_launch("hashgrid_lm_to_rows");
 }

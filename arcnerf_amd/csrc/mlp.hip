@@ -461,7 +461,7 @@ __device__ __forceinline__ void zero_padded_rows(f4 (&h)[4][NT], int N, int g) {
 // AH / AO >= 0: the hidden / output activation as a compile-time constant (the level-major and concat entry points with ReLU hidden
 // layers and a linear or sigmoid output: the NGP nets).  With the runtime switch the compiler clones the tile loop per activation: the
 // radiance forward was 90 KB of code and 160 registers, 11.5 KB and 104 with the constants - room for a third workgroup per CU.
-template <int T0, int T1, int T2, int T3, int NT, int XMODE, int AH = -1, int AO = -1>  // XMODE: 0 row-major x, 1 level-major x, 2 concat (MlpCat)
+template <int T0, int T1, int T2, int T3, int NT, int XMODE, int AH = -1, int AO = -1, bool RC3 = false>  // XMODE: 0 row-major x, 1 level-major x, 2 concat (MlpCat); RC3: see below
 __global__ void __launch_bounds__(256)
 mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, const float *__restrict__ weights, MlpParams P,
                      float *__restrict__ out, float *__restrict__ acts, int64_t n_cap, int64_t n, const int32_t *n_ptr) {
@@ -502,7 +502,8 @@ mlp_fwd_fixed_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
         // the two-layer tile-order nets get no activations at all: their backward recomputes layer 0 from x (32 x 64 MACs per sample
         // against 256 B written here and read there: geometry net forward 40 -> 32 us, backward +1 us; for the three-layer net the
         // backward is MFMA-bound and the same trade loses, 58 -> 55 forward but 86 -> 96 us backward)
-        if (acts && !(FRAG && NL == 2)) {
+        // (RC3: the same trade for the three-layer tile-order net, an A/B instance - ARCN_RAD_RECOMP=1)
+        if (acts && !(FRAG && (NL == 2 || RC3))) {
             if (FRAG) store_tiles_frag<T1, NT>(o, acts, s0, cnt, lane);
             else store_tiles_fast<T1, NT>(o, acts, P.dims[1], s0, cnt, g, j);
         }
@@ -604,7 +605,7 @@ mlp_bwd_dx_kernel(const float *__restrict__ weights, MlpParams P, const float *_
 // waves are summed through LDS and the workgroup writes ONE partial per layer for mlp_dw_reduce_kernel.
 // T0..T3 = 16-wide tiles per layer boundary (T3 = 0: two layers); the dims themselves stay run-time (ragged widths are zero
 // padded by load_tiles / stage_fragments, so e.g. the 3-wide RGB output uses the T3 = 1 instance).
-template <int T0, int T1, int T2, int T3, int NT, int XMODE, int AH = -1, int AO = -1>   // AH / AO: see mlp_fwd_fixed_kernel
+template <int T0, int T1, int T2, int T3, int NT, int XMODE, int AH = -1, int AO = -1, bool RC3 = false>   // AH / AO / RC3: see mlp_fwd_fixed_kernel
 __global__ void __launch_bounds__(256, 2)  // 2 workgroups per CU = 2 waves per SIMD: at most 256 VGPR + AGPR per lane
 mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, const float *__restrict__ weights, MlpParams P, const float *__restrict__ out,
                      const float *__restrict__ acts, const float *__restrict__ dout, float *__restrict__ dx,
@@ -619,7 +620,7 @@ mlp_bwd_fused_kernel(const float *__restrict__ x, int64_t x_stride, MlpCat cat, 
         lds_w = P.lds_off[l] + tiles16(P.dims[l]) * tiles16(P.dims[l + 1]) * kFragTile;
     }
     constexpr bool FRAG = XMODE != 0;        // tile-order activations from the matching forward (store_tiles_frag)
-    constexpr bool RECOMP = FRAG && NL == 2;  // ... which saved none for a two-layer net: layer 0 is recomputed from x
+    constexpr bool RECOMP = FRAG && (NL == 2 || RC3);  // ... which saved none for a two-layer net: layer 0 is recomputed from x
     const int act_h = AH >= 0 ? AH : P.act_hidden, act_o = AO >= 0 ? AO : P.act_out;
     // forward fragments of W_0 behind the transposition tiles
     const float *w0_fwd = lds + lds_w + 8192;
@@ -1133,6 +1134,12 @@ ARCN_EXPORT int64_t arcn_mlp_scratch_floats(const arcn_mlp_desc *d, int64_t n_ca
 }
 
 // x_stride = 0: x is (n, dims[0]) row-major; > 0: level-major, 2 features per level, level stride x_stride samples
+// A/B switch (read once): the three-layer concat net of the NGP step recomputes its layer-0 activations in the backward instead of saving them
+static bool rad_recomp() {
+    static const bool on = [] { const char *e = getenv("ARCN_RAD_RECOMP"); return e && atoi(e) != 0; }();
+    return on;
+}
+
 static int mlp_fwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, const float *weights, const float *biases,
                         const arcn_mlp_desc *desc_host, float *out, float *acts, int64_t n_cap, int64_t n, const int32_t *n_ptr,
                         void *stream) {
@@ -1168,6 +1175,12 @@ static int mlp_fwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
         const bool relu_sig = P.act_hidden == ARCN_ACT_RELU && P.act_out == ARCN_ACT_SIGMOID;
         if (cat_in) {
             if (P.dims[0] != 32) return einval("mlp_fwd_cat: the input must be 16 + 16 columns");
+            if (sig == 2441 && relu_sig && rad_recomp()) {
+                if ((rc = set_lds(mlp_fwd_fixed_kernel<2, 4, 4, 1, 2, 2, ARCN_ACT_RELU, ARCN_ACT_SIGMOID, true>, lds_bytes))) return rc;
+                hipLaunchKernelGGL((mlp_fwd_fixed_kernel<2, 4, 4, 1, 2, 2, ARCN_ACT_RELU, ARCN_ACT_SIGMOID, true>), dim3(tile_grid(n, 128, kSlimGrid)), dim3(256), lds_bytes,
+                                   as_stream(stream), x, x_stride, cat, weights, P, out, acts, n_cap, n, n_ptr);
+                return check_launch("mlp_fwd_fixed");
+            }
             if (sig == 2441 && relu_sig) ARCN_FIXED_A(2, 4, 4, 1, 2, ARCN_ACT_RELU, ARCN_ACT_SIGMOID, kSlimGrid);
             switch (sig) {
             case 2441: ARCN_FIXED(2, 4, 4, 1, 2);
@@ -1285,7 +1298,11 @@ static int mlp_bwd_impl(const float *x, int64_t x_stride, const MlpCat *cat_in, 
             const bool relu_lin = P.act_hidden == ARCN_ACT_RELU && P.act_out == ARCN_ACT_NONE;
             const bool relu_sig = P.act_hidden == ARCN_ACT_RELU && P.act_out == ARCN_ACT_SIGMOID;
             if (cat_in) {
-                if (sig == 2441 && relu_sig) ARCN_FUSED_A(2, 4, 4, 1, 1, 2, ARCN_ACT_RELU, ARCN_ACT_SIGMOID);
+                if (sig == 2441 && relu_sig && rad_recomp()) {
+                    if ((rc = set_lds(mlp_bwd_fused_kernel<2, 4, 4, 1, 1, 2, ARCN_ACT_RELU, ARCN_ACT_SIGMOID, true>, fused_lds))) return rc;
+                    hipLaunchKernelGGL((mlp_bwd_fused_kernel<2, 4, 4, 1, 1, 2, ARCN_ACT_RELU, ARCN_ACT_SIGMOID, true>), dim3((unsigned)grid), dim3(256), fused_lds,
+                                       as_stream(stream), x, x_stride, cat, weights, P, out, acts, dout, dx, partials, (int)grid, n_cap, n, n_ptr);
+                } else if (sig == 2441 && relu_sig) ARCN_FUSED_A(2, 4, 4, 1, 1, 2, ARCN_ACT_RELU, ARCN_ACT_SIGMOID);
                 else if (sig == 2441) ARCN_FUSED(2, 4, 4, 1, 1, 2);
                 else ARCN_FUSED(2, 4, 1, 0, 2, 2);
             } else if (x_stride) {

@@ -122,8 +122,10 @@ typedef float g4v __attribute__((ext_vector_type(4)));
 // threads per row, 1024 / H rows per trip), so every thread stays in ITS four columns: the column sums are four registers per thread,
 // folded through LDS once at the end - one float atomic per column and workgroup.
 __global__ void __launch_bounds__(256)
-sdf_jac_dz2_kernel(const float *__restrict__ dh, const float *__restrict__ u, const float *__restrict__ s, const float *__restrict__ c,
-                   const float *__restrict__ w, float *__restrict__ dz, float *__restrict__ sw, float *__restrict__ colsum, int64_t n, int H) {
+sdf_jac_dz2_kernel(const float *dh, const float *u, const float *__restrict__ s, const float *__restrict__ c,
+                   const float *__restrict__ w, float *dz, float *sw, float *__restrict__ colsum, int64_t n, int H) {
+    // (dh / dz and u / sw carry no __restrict__: the in-place form passes dz = dh and sw = u - every thread loads its own elements of a trip
+    // before it stores them)
     __shared__ float s_sum[256 * 4];
     const int tpr = H >> 2;                       // threads per row (H <= 1024, a multiple of 4; 256 % tpr == 0 checked by the launcher)
     const int rows_per_trip = 256 / tpr;

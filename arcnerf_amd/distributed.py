@@ -94,7 +94,12 @@ class ShardedGradSync:
     16-byte aligned shards [r * per, (r + 1) * per) plus a tail of fewer than 4 N floats, which is all-reduced and updated on every rank.
     Both collectives run in place on the flat buffers (the shard of rank r is where reduce_scatter / all_gather expect it).
     Same arithmetic as the flat form: every gradient element is summed over the ranks once, every parameter sees the same update
-    (tests/test_distributed_gloo.py: bit-identical parameters on 2 and 4 ranks)."""
+    (tests/test_distributed_gloo.py: bit-identical parameters on 2 and 4 ranks).
+
+    CHECKPOINTS: a rank's Adam moments are current for ITS shard only (the other shards hold zeros or what the last gather_moments()
+    brought).  Before an optimiser state is saved - the reference saves on rank 0 only (common/trainer/basic_trainer.py:416-440) - EVERY
+    rank calls gather_moments(exp_avg, exp_avg_sq) (a collective; FusedAdam.gather_sharded_state() does it for an attached optimiser);
+    FusedAdam.state_dict() refuses to hand out moments that are not current (`moments_current`)."""
 
     def __init__(self, n_params, world=None, rank=None, group=None, align=4):
         self.group = group
@@ -111,10 +116,21 @@ class ShardedGradSync:
         self.works = []
         self.timing = False
         self._marks = None
+        self.moments_current = True     # no sharded step since the last gather_moments(): every rank holds every shard's moments
+
+    def gather_moments(self, *flat_moments):
+        """all-gather of the shards of the optimiser's moment buffers, in place (exp_avg, exp_avg_sq of the flat layout): afterwards every
+        rank holds the complete state - what a checkpoint needs.  A collective: every rank calls it at the same point of its program."""
+        if _active(self.group) and self.per > 0:
+            works = [dist.all_gather_into_tensor(b[:self.body], b[self.lo:self.hi], group=self.group, async_op=True) for b in flat_moments]
+            for w in works:
+                w.wait()
+        self.moments_current = True
 
     def launch(self, flat_grads):
         """after the backward: the sums of this rank's shard land in flat_grads[lo:hi] (in place), the tail is all-reduced"""
         self.works = []
+        self.moments_current = self.world == 1
         if self.timing and flat_grads.is_cuda:
             import collections
             if self._marks is None:

@@ -65,7 +65,6 @@ class EncoderMLPRadainceNet(BaseRadianceNet):
         assert sum(p.shape[-1] for p in parts) == self.init_input_dim, 'Shape not match'
         kp = (-self.init_input_dim) % 4
         if pad4 and kp and parts[0].is_cuda and parts[0].dtype == torch.float32:
-            from ....ops.autograd import _hip_linear_enabled
-            if _hip_linear_enabled():     # the first layer's padded input width (283 -> 284) from the concat itself, not a second copy
-                parts.append(parts[0].new_zeros(parts[0].shape[:-1] + (kp,)))
+            # the first layer's padded input width (283 -> 284) from the concat itself, not a second copy
+            parts.append(parts[0].new_zeros(parts[0].shape[:-1] + (kp,)))
         return torch.cat(parts, dim=-1)

@@ -3,7 +3,6 @@
 gradients run on the hand-written f32-MFMA kernels of csrc/gemm.hip (base_modules/linear.py); parameter names
 (`layers.{i}.weight/bias`, `embed_fn...`) match the reference's state_dict."""
 import math
-import os
 
 import numpy as np
 import torch
@@ -80,9 +79,11 @@ class GeoNet(EncoderMLPGeoNet):
         fast = self._jacobian_path(x)
         return fast if fast is not None else super().forward_with_grad(x)
 
+    nograd_fast = True      # graph-free passes take ops.sdf_chain.sdf_forward_nograd where it applies (False: the layer-by-layer modules - the tests' reference)
+
     def _jacobian_path(self, x):
         from ..encoding.hashgrid_encoder import HashGridEmbedder
-        if os.environ.get('ARCN_SDF_JACOBIAN', '1') == '0' or not (x.is_cuda and x.dtype == torch.float32 and x.numel() > 0):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.numel() > 0):
             return None
         if x.requires_grad or self.D != 1 or self.skips or self.W_feat <= 0 or self.out_act is not None:
             return None
@@ -105,7 +106,7 @@ class GeoNet(EncoderMLPGeoNet):
         return geo, feat, grad
 
     def forward(self, x):
-        if not torch.is_grad_enabled() and os.environ.get('ARCN_SDF_NOGRAD_FAST', '1') != '0':
+        if not torch.is_grad_enabled() and self.nograd_fast:
             # a graph-free pass of the softplus sdf net (NeuS evaluates it in every importance-sampling round): the cached weight-normed, padded
             # weights, activations in the products' epilogues, the skip concatenation as one kernel - no hooks, pads, cat or div launches
             from ....ops.sdf_chain import sdf_forward_nograd
@@ -168,8 +169,8 @@ class RadianceNet(EncoderMLPRadainceNet):
         """MLP descriptor of the fused HIP kernel when this stack is one it computes exactly like the nn.Linear chain: two or three
         bias-free DenseLayers (no weight norm, no SIREN), ReLU inside, sigmoid out, every width <= 64 (the reference's hash-grid
         configurations, e.g. the radiance net of NeuS-NGP).  The parameters stay the layers' own `weight`s (same state_dict); only
-        the arithmetic moves from three library GEMMs + activations per direction to one kernel.  ARCN_LINEAR_FUSED=0 disables."""
-        if not int(os.environ.get('ARCN_LINEAR_FUSED', '1')) or len(self.layers) not in (2, 3):
+        the arithmetic moves from three library GEMMs + activations per direction to one kernel."""
+        if len(self.layers) not in (2, 3):
             return None
         for i, layer in enumerate(self.layers):
             last = i == len(self.layers) - 1

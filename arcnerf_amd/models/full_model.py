@@ -4,7 +4,6 @@ background model, when `model.background` is configured) in `chunk_rays` chunks,
 Blending (full_model.py:141-349): `rgb` mode adds the background colour / depth scaled by the transmittance left after the
 foreground's last sample; `sigma` mode concatenates the per-sample densities and colours of both models along the ray and
 composites them again in one pass.  The foreground mask stays the foreground's."""
-import os
 
 import torch
 import torch.nn as nn
@@ -223,8 +222,7 @@ class FullModel(nn.Module):
             # ... of which `rgb` blending reads one number per ray, trans_shift[:, -1] (blend_bkg_rgb): a foreground with a packed path
             # may return just that (truthy, so every other model gives its full progress as before)
             get_progress_fg = 't_last'
-        if (bkg_model is not None and not self.fg_only and self.bkg_blend != 'sigma' and hasattr(bkg_model, 'presample')
-                and os.environ.get('ARCN_BKG_PRESAMPLE', '1') != '0'):
+        if bkg_model is not None and not self.fg_only and self.bkg_blend != 'sigma' and hasattr(bkg_model, 'presample'):
             if getattr(bkg_model, '_presampled', None) is None or bkg_model._presampled[0][:3] != (flat_inputs['rays_o'].data_ptr(), flat_inputs['rays_d'].data_ptr(), flat_inputs['rays_o'].shape[0]):
                 bkg_model.presample(flat_inputs)   # its sampler runs (and its sample count travels) while the foreground works
         fg_output = fg_model.forward(flat_inputs, inference_only, get_progress_fg, cur_epoch, total_epoch)

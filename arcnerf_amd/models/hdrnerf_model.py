@@ -18,8 +18,7 @@ def _fused_tone_mappers(mlps, x):
     """the three 1 -> W -> 1 tone mappers (ReLU inside, sigmoid out, biases, W <= 128) in ONE kernel per direction with the hidden layer
     in registers (ops.autograd.ToneMapFn): as dense layers each channel moved a (samples, W) tensor through HBM four times per step.
     Same parameters (the layers' own weight / bias, packed per call: 3 x 385 floats).  None where that shape does not apply."""
-    import os
-    if os.environ.get('ARCN_TONEMAP_FUSED', '1') == '0' or not (x.is_cuda and x.dtype == torch.float32 and x.numel() > 0):
+    if not (x.is_cuda and x.dtype == torch.float32 and x.numel() > 0):
         return None
     rows = []
     for layers in mlps:

@@ -29,3 +29,14 @@ def nets_on_valid_samples(forward_pts_dir, chunk_pts, geo_net, radiance_net, ray
     sigma = sigma.view(-1).index_copy(0, flat, s_valid.reshape(-1)).view(n_rays, n_pts)
     radiance = radiance.view(-1, 3).index_copy(0, flat, r_valid.reshape(-1, 3)).view(n_rays, n_pts, 3)
     return sigma, radiance
+
+
+def hold_rays(handle, rays_o, rays_d):
+    """A sampler handle that may be picked up by a LATER forward is matched by the rays' (pointer, size, version): it keeps the ray tensors
+    alive - the caching allocator cannot hand their addresses to another batch while the entry exists - and tells the allocator that the
+    stream the sampler was queued on (the sampling stream, FullModel.prefetch_samples) reads them."""
+    handle['rays'] = (rays_o, rays_d)
+    if rays_o.is_cuda:
+        cur = torch.cuda.current_stream(rays_o.device)
+        rays_o.record_stream(cur)
+        rays_d.record_stream(cur)

@@ -16,7 +16,7 @@ from ..utils.registry import MODEL_REGISTRY
 from ..utils.torch_utils import chunk_processing
 from .base_modules import build_geo_model, build_radiance_model
 from .bkg_model import BkgModel
-from .masked_samples import nets_on_valid_samples
+from .masked_samples import hold_rays, nets_on_valid_samples
 
 
 @MODEL_REGISTRY.register()
@@ -73,7 +73,9 @@ class MultiVol(BkgModel, MortonDensityGrid):
             self.n_grid, self.n_cascade, self.density_bitfield, self.get_optim_cfgs('near_distance'), self.inclusive, rng.state,
             rng.inc, want_counts=True, dense=False)
         rng.advance()
-        return Fn.pack_dense_samples_begin(zvals, counts)
+        h = Fn.pack_dense_samples_begin(zvals, counts)
+        hold_rays(h, rays_o, rays_d)
+        return h
 
     def presample(self, inputs):
         """FullModel calls this BEFORE the foreground model runs (same rays): the background's sampler is queued and its sample count

@@ -6,7 +6,6 @@ fused geo/radiance MLPs, SH view encoding, no hierarchical stage) `forward` bypa
 host decisions of FgModel.forward and runs the packed, device-count-driven kernel sequence of arcnerf_amd.pipeline on the
 module's own parameters.  Outputs (keys, shapes, values) are the same; tests compare both paths.
 """
-import os
 
 import torch
 from torch.autograd.function import once_differentiable
@@ -176,7 +175,7 @@ class NeRF(FgModel):
         self._check_deferred_overflow(rays_o.device)
         pipe = self._packed_pipeline(rays_o.device)
         R = rays_o.shape[0]
-        check = R * pipe.cfg.n_sample > pipe.cap and os.environ.get('ARCN_PACKED_OVERFLOW_CHECK', '1') != '0'
+        check = R * pipe.cfg.n_sample > pipe.cap
         if check and not exact:
             # training: no sample may be dropped either (the reference's dense tensors hold them all, fg_model.py:252-262).  The last
             # step's samples-per-ray (read back a step late, no stall) bounds this one: grow BEFORE marching when 1.5x that rate does not

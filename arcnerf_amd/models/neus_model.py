@@ -7,7 +7,6 @@ csrc/gemm.hip (ops.autograd.linear: closed under differentiation), whose input g
 create_graph=True, so the Eikonal term and everything downstream of the normals differentiate a second time.  The hash-grid + fused-MLP variant
 (NeuS-NGP) needs a second-order backward of those kernels and is not built yet."""
 import math
-import os
 
 import numpy as np
 import torch
@@ -22,11 +21,8 @@ from ..utils.cfgs_utils import get_value_from_cfgs_field
 from ..utils.registry import MODEL_REGISTRY
 from ..utils.torch_utils import chunk_processing
 from .base_modules import build_geo_model, build_radiance_model
+from .masked_samples import hold_rays
 from .sdf_model import SdfModel
-
-
-# ARCN_NEUS_UPSAMPLE_GRAPH=1: build the (unused) autograd graph of the importance-sampling rounds as the reference does (A/B)
-_UPSAMPLE_WITH_GRAPH = os.environ.get('ARCN_NEUS_UPSAMPLE_GRAPH', '0') == '1'
 
 
 @MODEL_REGISTRY.register()
@@ -74,7 +70,9 @@ class Neus(SdfModel):
                                           vol.get_voxel_bitfield(), n_pts, vol.get_diag_len() / n_pts,
                                           self.obj_bound.get_optim_cfgs('near_distance'), rng.state, rng.inc)
         rng.advance()
-        return Fn.neus_pack_begin(zd, counts)
+        h = Fn.neus_pack_begin(zd, counts)
+        hold_rays(h, rays_o, rays_d)        # (keeps the rays alive while a later forward may still match this handle by their pointers)
+        return h
 
     def presample(self, inputs):
         """March the rays of a LATER forward now (FullModel.prefetch_samples calls this on the sampling stream while the current step's
@@ -193,7 +191,7 @@ class Neus(SdfModel):
         for rnd in range(rounds):
             # (the new depths are detached from the net - the reference detaches `weights` - so the sdf evaluations of these rounds need
             # no graph: no saved activations, and the dense layers take their activation-in-the-epilogue form)
-            with torch.set_grad_enabled(_UPSAMPLE_WITH_GRAPH and torch.is_grad_enabled()):
+            with torch.no_grad():
                 pts = get_ray_points_by_zvals(rays_o, rays_d, zvals)
                 sdf = self.forward_pts(pts.view(-1, 3)).view(zvals.shape)
                 weights = self._crossing_weights(zvals, sdf, torch.norm(pts, dim=-1), s * 2 ** (rnd + 1))

@@ -538,8 +538,7 @@ class LinearSoftplusFn(torch.autograd.Function):
 
 def linear_softplus(x, weight, bias, beta):
     """softplus(F.linear(x, weight, bias), beta) as one fused, twice-differentiable layer; None where the HIP products do not apply"""
-    import os
-    if not _use_hip_linear(x, weight) or os.environ.get('ARCN_SOFTPLUS_FUSED', '1') == '0' or os.environ.get('ARCN_LINEAR_SOFTPLUS', '1') == '0':
+    if not _use_hip_linear(x, weight):
         return None
     shp = x.shape
     x2, w, b, n_out, npad = _padded_operands(x, weight, bias)
@@ -550,9 +549,9 @@ def linear_softplus(x, weight, bias, beta):
 
 
 def softplus(z, beta):
-    """softplus on the fused twice-differentiable kernels for fp32 CUDA tensors (ARCN_SOFTPLUS_FUSED=0: torch), torch otherwise"""
-    import os
-    if not (z.is_cuda and z.dtype == torch.float32 and z.numel() > 0) or os.environ.get('ARCN_SOFTPLUS_FUSED', '1') == '0':
+    """softplus on the fused twice-differentiable kernels for fp32 CUDA tensors; CPU tensors (host-side tests) and empty ones: torch"""
+    _no_silent_cuda_fallback(z)
+    if not (z.is_cuda and z.numel() > 0):
         return torch.nn.functional.softplus(z, beta=beta)
     return SoftplusFn.apply(z.contiguous(), float(beta))
 
@@ -721,9 +720,8 @@ class LinearReluCatFn(torch.autograd.Function):
 def linear_relu_cat(x, weight, bias, tail):
     """cat([relu(F.linear(x, weight, bias)), tail], -1) with the layer's product writing straight into the concatenated buffer
     (LinearReluCatFn); None where that form does not apply (the caller then concatenates as the reference does)"""
-    import os
     n_out, k_in = weight.shape
-    if not _use_hip_linear(x, weight) or os.environ.get('ARCN_LINEAR_FUSED_RELU', '1') == '0' or os.environ.get('ARCN_SKIP_CAT_FUSED', '1') == '0':
+    if not _use_hip_linear(x, weight):
         return None
     if x.dim() != 2 or tail.dim() != 2 or tail.dtype != torch.float32 or n_out % 4 or (n_out + tail.shape[1]) % 4 or tail.shape[0] != x.shape[0]:
         return None
@@ -753,26 +751,30 @@ def pad_cols4(x):
     """x with zero columns appended up to a multiple of 4 where the dense layers run on the HIP products (their padded input width),
     x itself otherwise: lets a module pad ONCE what it feeds to several layers / concatenations instead of one pad copy per layer"""
     kp = (-x.shape[-1]) % 4
-    if not kp or not (x.is_cuda and x.dtype == torch.float32) or not _hip_linear_enabled():
+    if not kp or not (x.is_cuda and x.dtype == torch.float32):
         return x
     return torch.nn.functional.pad(x, (0, kp))
 
 
-def _hip_linear_enabled():
-    import os
-    return os.environ.get('ARCN_LINEAR_GEMM', '1') != '0'
+def _no_silent_cuda_fallback(*tensors):
+    """The dense layers of the product path are the hand-written MFMA products, for float32.  A CUDA tensor of another dtype used to take
+    torch's route (hipBLASLt) without a word - a dtype slip would then measure the library, not the product: it raises instead.  CPU
+    tensors (the host-side tests that run the module logic without a GPU) go to torch."""
+    for t in tensors:
+        if t is not None and t.is_cuda and t.dtype != torch.float32:
+            raise RuntimeError('arcnerf_amd: a {} CUDA tensor reached a dense layer of the product path - the HIP kernels compute in float32 and '
+                               'there is no library fallback (cast the input / parameters to float32)'.format(t.dtype))
 
 
 def _use_hip_linear(x, weight):
-    import os
-    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.numel() > 0 and
-            os.environ.get('ARCN_LINEAR_GEMM', '1') != '0')
+    """True: the HIP products run.  False: CPU tensors (torch, host-side tests) or an empty batch.  CUDA tensors that are not float32 raise."""
+    _no_silent_cuda_fallback(x, weight)
+    return x.is_cuda and weight.is_cuda and x.numel() > 0
 
 
 def linear_relu(x, weight, bias=None):
-    """relu(torch.nn.functional.linear(x, weight, bias)) as one fused layer (LinearReluFn); torch for anything but fp32 CUDA tensors"""
-    import os
-    if not _use_hip_linear(x, weight) or os.environ.get('ARCN_LINEAR_FUSED_RELU', '1') == '0':
+    """relu(torch.nn.functional.linear(x, weight, bias)) as one fused layer (LinearReluFn); torch for CPU tensors (host-side tests)"""
+    if not _use_hip_linear(x, weight):
         return torch.relu(linear(x, weight, bias))
     shp = x.shape
     x2, w, b, n_out, npad = _padded_operands(x, weight, bias)
@@ -798,9 +800,9 @@ def linear_act_nograd(x, weight, bias, act, beta=1.0):
 
 
 def linear(x, weight, bias=None, keep_pad=False):
-    """torch.nn.functional.linear for fp32 CUDA tensors on the MFMA products; anything else (CPU tensors of the host-side tests, other
-    dtypes) goes to torch.  ARCN_LINEAR_GEMM=0 routes everything to torch (A/B against the library GEMMs).  keep_pad: return the
-    product's own (rows, out + pad) tensor (zero columns up to a multiple of 4) for a caller that splits it itself."""
+    """torch.nn.functional.linear on the MFMA products (fp32 CUDA tensors); CPU tensors (the host-side tests) and empty batches go to
+    torch, a CUDA tensor of another dtype raises (no silent library route).  keep_pad: return the product's own (rows, out + pad) tensor
+    (zero columns up to a multiple of 4) for a caller that splits it itself."""
     if not _use_hip_linear(x, weight):
         return torch.nn.functional.linear(x[..., :weight.shape[1]], weight, bias)    # (a pad_cols4 input on an empty batch)
     shp = x.shape

@@ -16,7 +16,6 @@ Column permutations reorder the k-sum of the first radiance layer, so the output
 (1e-6), not bit for bit; tests/test_gpu_kernels.py::test_field_chain_equals_the_layer_by_layer_modules, G22 / G24.
 First order only, inputs without gradient; anything else (NeuS: softplus + double backward, weight norm, other modes) keeps the
 module-by-module path.  ARCN_FIELD_CHAIN=0 turns the node off."""
-import os
 
 import torch
 import torch.nn as nn
@@ -53,7 +52,7 @@ def make_spec(geo, rad, chunk):
     from ..models.base_modules.encoding.freq_encoder import FreqEmbedder
     from ..models.base_modules.geo_rad_model.linear_network_module import GeoNet, RadianceNet
     from ..models.base_modules.linear import DenseLayer, Linear
-    if os.environ.get('ARCN_FIELD_CHAIN', '1') == '0' or type(geo) is not GeoNet or type(rad) is not RadianceNet:
+    if type(geo) is not GeoNet or type(rad) is not RadianceNet:
         return None
     if type(geo.embed_fn) is not FreqEmbedder or geo.embed_fn.n_freqs < 1:      # (any input width: NeRF++ feeds (x / r, 1 / r))
         return None
@@ -254,9 +253,6 @@ def field_chain(geo_net, radiance_net, pts, dirs, chunk_pts):
     if dirs is None or dirs.dim() != 2 or dirs.shape[0] != pts.shape[0] or dirs.shape[1] != 3 or dirs.dtype != torch.float32:
         return None
     if pts.requires_grad or dirs.requires_grad:
-        return None
-    from .autograd import _hip_linear_enabled
-    if not _hip_linear_enabled() or os.environ.get('ARCN_LINEAR_FUSED_RELU', '1') == '0':
         return None
     spec = make_spec(geo_net, radiance_net, chunk_pts)
     if spec is None or pts.shape[1] != geo_net.embed_fn.input_dim:

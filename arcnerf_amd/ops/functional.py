@@ -490,17 +490,49 @@ def packed_points(rays_o, rays_d, t, ray_id, n=None, n_dev=None, want_dirs=True)
 # ------------------------------------------------------------------------------------------------
 # encoders
 # ------------------------------------------------------------------------------------------------
+_LM_ROWS_MIN = 16384      # below this many points the XCD-affine gather writes its rows itself (one launch; strided 8-byte stores)
+
+
+def hashgrid_lm_to_rows(lm, desc, n, n_cap, n_dev=None, out=None):
+    """level-major features (L, n_cap, F) -> rows (n, L F) (arcn_hashgrid_lm_to_rows)"""
+    LF = int(desc.n_levels) * int(desc.n_feat)
+    if out is None:
+        out = torch.empty((n, LF), dtype=torch.float32, device=lm.device)
+    N.check(N.lib().arcn_hashgrid_lm_to_rows(N.ptr(lm), int(desc.n_levels), int(desc.n_feat), int(n_cap), N.ptr(out), LF, n, _nptr(n_dev), N.stream()),
+            'hashgrid_lm_to_rows')
+    return out
+
+
 def hashgrid_fwd(xyz, table, desc, want_idx=False, n_dev=None, out=None):
+    """HashGridEmbedder.forward's (n, L F) features.  n_feat 1 | 2: the XCD-affine cost-balanced gather (arcn_hashgrid_fwd_xcd, bit-identical to
+    the plain one) - level-major + one transposing pass for large launches; want_idx (debug rows) or n_feat 4: the plain kernel"""
     _req(xyz, table)
     xyz, table = _f32(xyz), _f32(table)
     n = xyz.shape[0]
     LF = desc.n_levels * desc.n_feat
     if out is None:
         out = torch.empty((n, LF), dtype=torch.float32, device=xyz.device)
+    if not want_idx and desc.n_feat <= 2:
+        if n >= _LM_ROWS_MIN:
+            lm = torch.empty(n * LF, dtype=torch.float32, device=xyz.device)
+            N.check(N.lib().arcn_hashgrid_fwd_xcd(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(lm), 1, n, n, _nptr(n_dev), N.stream()), 'hashgrid_fwd_xcd')
+            return hashgrid_lm_to_rows(lm, desc, n, n, n_dev=n_dev, out=out)
+        N.check(N.lib().arcn_hashgrid_fwd_xcd(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(out), 0, n, n, _nptr(n_dev), N.stream()), 'hashgrid_fwd_xcd')
+        return out
     idx = torch.empty((n, desc.n_levels, 8), dtype=torch.int32, device=xyz.device) if want_idx else None
     N.check(N.lib().arcn_hashgrid_fwd(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(out), N.ptr(idx), n, _nptr(n_dev),
                                      N.stream()), 'hashgrid_fwd')
     return (out, idx) if want_idx else out
+
+
+def hashgrid_fwd_plain(xyz, table, desc, n_dev=None):
+    """the plain one-lane-per-(sample, level) gather (arcn_hashgrid_fwd): what the XCD-affine kernel is checked against"""
+    _req(xyz, table)
+    xyz, table = _f32(xyz), _f32(table)
+    n = xyz.shape[0]
+    out = torch.empty((n, desc.n_levels * desc.n_feat), dtype=torch.float32, device=xyz.device)
+    N.check(N.lib().arcn_hashgrid_fwd(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(out), None, n, _nptr(n_dev), N.stream()), 'hashgrid_fwd')
+    return out
 
 
 def hashgrid_bwd_workspace(desc, n, device):
@@ -562,34 +594,44 @@ def hashgrid_bwd_bwd(xyz, gdx, table, dout, desc, want_ddout=True, want_dtable=T
     return ddout, dtable, d2xyz
 
 
-def hashgrid_fwd_corners(xyz, table, desc):
-    """hashgrid_fwd that also returns the gathered rows: -> (enc (n, L F), corners (n, L, 8, F)) for hashgrid_dxyz_corners / hashgrid_ddout_corners"""
+def hashgrid_fwd_corners(xyz, table, desc, n_dev=None):
+    """hashgrid_fwd that also keeps the gathered rows: -> (enc (n, L F), corners) for hashgrid_dxyz_corners / hashgrid_ddout_corners.
+    corners: (L, 2 F, n, 4) floats - level-major 16-byte quads of the eight rows of every (sample, level), see arcn_hashgrid_fwd_corners"""
     _req(xyz, table)
     xyz, table = _f32(xyz), _f32(table)
     n, L, Fq = xyz.shape[0], int(desc.n_levels), int(desc.n_feat)
     out = torch.empty((n, L * Fq), dtype=torch.float32, device=xyz.device)
-    corners = torch.empty((n, L, 8, Fq), dtype=torch.float32, device=xyz.device)
-    N.check(N.lib().arcn_hashgrid_fwd_corners(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(out), N.ptr(corners), n, N.stream()), 'hashgrid_fwd_corners')
+    corners = torch.empty((L, 2 * Fq, n, 4), dtype=torch.float32, device=xyz.device)
+    if n >= _LM_ROWS_MIN:
+        lm = torch.empty(n * L * Fq, dtype=torch.float32, device=xyz.device)
+        N.check(N.lib().arcn_hashgrid_fwd_corners(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(lm), 1, N.ptr(corners), n, n, _nptr(n_dev), N.stream()),
+                'hashgrid_fwd_corners')
+        hashgrid_lm_to_rows(lm, desc, n, n, n_dev=n_dev, out=out)
+    else:
+        N.check(N.lib().arcn_hashgrid_fwd_corners(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(out), 0, N.ptr(corners), n, n, _nptr(n_dev), N.stream()),
+                'hashgrid_fwd_corners')
     return out, corners
 
 
-def hashgrid_dxyz_corners(xyz, corners, dout, desc):
+def hashgrid_dxyz_corners(xyz, corners, dout, desc, n_dev=None):
     """d <dout, enc(x)> / d x (n, 3) from the forward's corners: the dxyz of hashgrid_bwd, bit for bit, without the table reads"""
     _req(xyz, corners, dout)
     xyz, dout = _f32(xyz), _f32(dout)
     n = xyz.shape[0]
-    dxyz = torch.zeros((n, 3), dtype=torch.float32, device=xyz.device)
-    N.check(N.lib().arcn_hashgrid_dxyz_corners(N.ptr(xyz), N.ptr(corners), N.ptr(dout), C.addressof(desc), N.ptr(dxyz), n, N.stream()), 'hashgrid_dxyz_corners')
+    dxyz = _fresh((n, 3), torch.float32, xyz.device)
+    N.check(N.lib().arcn_hashgrid_dxyz_corners(N.ptr(xyz), N.ptr(corners), N.ptr(dout), C.addressof(desc), N.ptr(dxyz), int(corners.shape[2]), n,
+                                              _nptr(n_dev), N.stream()), 'hashgrid_dxyz_corners')
     return dxyz
 
 
-def hashgrid_ddout_corners(xyz, gdx, corners, desc):
+def hashgrid_ddout_corners(xyz, gdx, corners, desc, n_dev=None):
     """the ddout (n, L F) of hashgrid_bwd_bwd from the forward's corners, bit for bit, without the table reads"""
     _req(xyz, gdx, corners)
     xyz, gdx = _f32(xyz), _f32(gdx)
     n = xyz.shape[0]
-    ddout = torch.empty((n, int(desc.n_levels) * int(desc.n_feat)), dtype=torch.float32, device=xyz.device)
-    N.check(N.lib().arcn_hashgrid_ddout_corners(N.ptr(xyz), N.ptr(gdx), N.ptr(corners), C.addressof(desc), N.ptr(ddout), n, N.stream()), 'hashgrid_ddout_corners')
+    ddout = _fresh((n, int(desc.n_levels) * int(desc.n_feat)), torch.float32, xyz.device)
+    N.check(N.lib().arcn_hashgrid_ddout_corners(N.ptr(xyz), N.ptr(gdx), N.ptr(corners), C.addressof(desc), N.ptr(ddout), int(corners.shape[2]), n,
+                                               _nptr(n_dev), N.stream()), 'hashgrid_ddout_corners')
     return ddout
 
 
@@ -915,14 +957,13 @@ def mlp_fwd(x, weights, biases, desc, save_acts=False, n_dev=None, out=None, act
 # ------------------------------------------------------------------------------------------------
 # dense layers of the wide nets: the three f32-MFMA products of csrc/gemm.hip
 # ------------------------------------------------------------------------------------------------
-# ARCN_GEMM_SPLIT=0: the exact-f32 MFMA kernels everywhere; 1 (default): layers with more than 64 outputs run on the bf16 matrix rate
-# with every operand split into three bf16 planes (six products, f32 accuracy; csrc/gemm.hip)
-_GEMM_SPLIT = os.environ.get('ARCN_GEMM_SPLIT', '1') != '0'
+# layers with more than 64 outputs run on the bf16 matrix rate with every operand split into three bf16 planes (six products, f32
+# accuracy; csrc/gemm.hip); narrower ones on the exact-f32 MFMA kernels
 _GEMM_SPLIT_MIN_OUT = 65
 
 
 def _use_split(rows, k_red, n_out):
-    return _GEMM_SPLIT and n_out >= _GEMM_SPLIT_MIN_OUT and k_red % 4 == 0 and k_red >= 32 and rows.data_ptr() % 16 == 0
+    return n_out >= _GEMM_SPLIT_MIN_OUT and k_red % 4 == 0 and k_red >= 32 and rows.data_ptr() % 16 == 0
 
 
 def _split_ws(n_out, k_red, device):
@@ -935,13 +976,12 @@ def _split_ws(n_out, k_red, device):
 # handed out again) together with the zero-padded forms ops.autograd makes of odd-width layers; outside nothing is cached and every
 # product splits for itself.
 _SPLIT_SCOPE = None
-_SPLIT_SCOPE_ON = os.environ.get('ARCN_SPLIT_SCOPE', '1') != '0'     # 0: every product splits its weights itself (A/B)
 
 
 @contextlib.contextmanager
 def split_weight_scope():
     global _SPLIT_SCOPE
-    opened = _SPLIT_SCOPE is None and _SPLIT_SCOPE_ON
+    opened = _SPLIT_SCOPE is None
     if opened:
         _SPLIT_SCOPE = {}
     try:
@@ -982,7 +1022,7 @@ def in_split_scope():
 
 def relu_bits_supported(rows, k_red, n_out):
     """whether gemm_nt(..., want_bits=True) can write the ReLU mask of its output as bits (split kernels, outputs in multiples of 32)"""
-    return _use_split(rows, k_red, n_out) and n_out % 4 == 0 and os.environ.get('ARCN_RELU_BITS', '1') != '0'
+    return _use_split(rows, k_red, n_out) and n_out % 4 == 0
 
 
 def _rows(t):

@@ -7,7 +7,6 @@ gradients of normal and feature - what the sdf node of NeuS differentiates a sec
 first layer's input gradient.  Weight norm stays outside (the node takes the effective weights).  config 3 of BASELINE.json (mode
 'pvnf', 4 x 256, weight norm); the NeRF family's 'vf' nets take ops/field_chain.py together with their geometry net.
 ARCN_RADIANCE_CHAIN=0 turns the node off.  tests/test_gpu_kernels.py::test_radiance_chain_equals_the_layer_by_layer_module."""
-import os
 
 import torch
 import torch.nn as nn
@@ -40,7 +39,7 @@ def make_rad_spec(rad, chunk):
     from ..models.base_modules.encoding.freq_encoder import FreqEmbedder
     from ..models.base_modules.geo_rad_model.linear_network_module import RadianceNet
     from ..models.base_modules.linear import DenseLayer
-    if os.environ.get('ARCN_RADIANCE_CHAIN', '1') == '0' or type(rad) is not RadianceNet or rad._fused_desc is not None:
+    if type(rad) is not RadianceNet or rad._fused_desc is not None:
         return None
     if len(set(rad.mode)) != len(rad.mode) or len(rad.layers) < 2:
         return None
@@ -176,9 +175,6 @@ class RadianceChainFn(torch.autograd.Function):
 def radiance_chain(radiance_net, x, view_dirs, normals, geo_feat, chunk_pts):
     """radiance (n, 3) of RadianceNet.forward(x, view_dirs, normals, geo_feat) over all points through RadianceChainFn, or None where the
     node does not apply"""
-    from .autograd import _hip_linear_enabled
-    if not _hip_linear_enabled() or os.environ.get('ARCN_LINEAR_FUSED_RELU', '1') == '0':
-        return None
     spec = make_rad_spec(radiance_net, chunk_pts)
     if spec is None:
         return None

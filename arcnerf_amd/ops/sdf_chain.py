@@ -17,7 +17,6 @@ parameters stay outside (the node takes the effective weights, torch differentia
 are not learnable); inputs that need one keep the module path.  ARCN_SDF_CHAIN=0 turns the node off.
 tests/test_gpu_kernels.py::test_sdf_chain_equals_the_double_backward_of_the_modules, golden G23."""
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -45,7 +44,7 @@ def make_sdf_spec(geo, chunk):
     from ..models.base_modules.encoding.freq_encoder import FreqEmbedder
     from ..models.base_modules.geo_rad_model.linear_network_module import GeoNet
     from ..models.base_modules.linear import DenseLayer, Linear
-    if os.environ.get('ARCN_SDF_CHAIN', '1') == '0' or type(geo) is not GeoNet or geo.use_siren:
+    if type(geo) is not GeoNet or geo.use_siren:
         return None
     if type(geo.embed_fn) is not FreqEmbedder or geo.embed_fn.input_dim != 3 or geo.embed_fn.n_freqs < 1:
         return None
@@ -116,9 +115,6 @@ def sdf_forward_nograd(geo, x):
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in geo.layers.parameters())):
         return None
     if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.numel() > 0 and x.shape[-1] == 3):
-        return None
-    from .autograd import _hip_linear_enabled
-    if not _hip_linear_enabled() or os.environ.get('ARCN_SOFTPLUS_FUSED', '1') == '0' or os.environ.get('ARCN_LINEAR_SOFTPLUS', '1') == '0':
         return None
     spec = make_sdf_spec(geo, 0)
     if spec is None or any(p.dtype != torch.float32 or not p.is_cuda for p in geo.layers.parameters()):
@@ -280,9 +276,6 @@ def sdf_chain(geo_net, pts, chunk_pts):
     if not (torch.is_tensor(pts) and pts.is_cuda and pts.dtype == torch.float32 and pts.dim() == 2 and pts.shape[0] > 0):
         return None
     if pts.requires_grad and pts.grad_fn is not None:      # positions that depend on something learnable want d / d x as well
-        return None
-    from .autograd import _hip_linear_enabled
-    if not _hip_linear_enabled() or os.environ.get('ARCN_SOFTPLUS_FUSED', '1') == '0' or os.environ.get('ARCN_LINEAR_SOFTPLUS', '1') == '0':
         return None
     spec = make_sdf_spec(geo_net, chunk_pts)
     if spec is None:

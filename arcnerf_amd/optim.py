@@ -30,6 +30,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.grad_scale = 1.0     # multiplies every gradient as it is read: 1 / world after a SUM all-reduce (DDP's average, no extra pass)
         self.ema_n_step = None    # EMA.n_step when it differs from Adam's step count (set_ema_n_step: a resumed job); None = Adam's
         self._flat = None         # per param group: dict(params, grads, exp_avg, exp_avg_sq, ema, slots) once flatten() ran
+        self.shard_sync = None    # a distributed.ShardedGradSync whose steps update only this rank's shard of the moments (set by the stepper)
 
     # ---- one flat buffer per parameter group --------------------------------------------------------------------------------------
     def flatten(self, direct_grads=None):
@@ -43,10 +44,9 @@ class FusedAdam(torch.optim.Optimizer):
         render) add their gradient straight into the flat buffer instead of handing autograd a zero-filled temporary for AccumulateGrad
         to add (tensor hooks on such a parameter do not see that contribution; pass False when hooks must).  Returns self."""
         if direct_grads is None:
-            import os
             direct_grads = getattr(self, '_direct_grads', None)
             if direct_grads is None:
-                direct_grads = os.environ.get('ARCN_DIRECT_GRADS', '1') != '0'
+                direct_grads = True
         self._direct_grads = bool(direct_grads)      # a later re-flatten (load_state_dict) keeps the caller's choice
         self._flat = []
         for group in self.param_groups:
@@ -113,6 +113,22 @@ class FusedAdam(torch.optim.Optimizer):
             return super().zero_grad(set_to_none=set_to_none)
         for fb in self._flat:      # the views stay in place (set_to_none would detach them from the flat buffer)
             fb['grads'].zero_()
+
+    def gather_sharded_state(self):
+        """Under sharded gradient sync (distributed.ShardedGradSync: every rank runs Adam on its 1/N of the flat buffer) a rank's moments are
+        current for its own shard only.  Call this on EVERY rank (a collective) before any rank takes state_dict(): all-gather of the
+        moment shards, in place.  No-op without an attached sharded sync."""
+        if self.shard_sync is None or self._flat is None:
+            return
+        fb = self._flat[0]
+        self.shard_sync.gather_moments(fb['exp_avg'], fb['exp_avg_sq'])
+
+    def state_dict(self):
+        if self.shard_sync is not None and not self.shard_sync.moments_current:
+            raise RuntimeError('FusedAdam.state_dict(): the steps since the last gather ran with sharded gradient sync - this rank holds the '
+                               'Adam moments of its own 1/{} of the parameters only.  Call optimizer.gather_sharded_state() on EVERY rank first '
+                               '(a collective), then save on whichever rank saves.'.format(self.shard_sync.world))
+        return super().state_dict()
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)

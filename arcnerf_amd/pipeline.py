@@ -19,7 +19,6 @@ device-side count, so the whole step issues no host synchronisation.  All parame
 [hash table | geo W | radiance W] so the optimiser is one kernel and data-parallel training needs one collective.
 """
 import math
-import os
 
 import numpy as np
 import torch
@@ -203,7 +202,13 @@ class NgpPipeline:
     """Pre-allocated buffers + the kernel sequence of one render / train step for a fixed ray capacity."""
 
     def __init__(self, field, max_rays=32768, max_samples=1 << 19, packed_bits=True, torch_aabb=False, xcd_scatter=True, level_major=True, fused_glue=True,
-                 prefetch_depth=None):
+                 prefetch_depth=None, prefetch_at=None, march_waves=None, aux_priority=None, occ_async=True, fused_composite=True, fuse_adam=True,
+                 step_tail=True, march_cull=True):
+        """The keyword switches select the measured alternatives of the step's schedule (defaults = the product path): prefetch_depth
+        batches marched ahead, prefetch_at = where in the step the next marching is issued (_prefetch_point), march_waves = persistent
+        wavefronts of a marching launch with slack, aux_priority = priority of the sampling stream, occ_async = the occupancy refresh on its
+        own stream, fused_composite = compositing + loss + their backward as one kernel, fuse_adam = the scatter's chunk owners apply the
+        optimiser, step_tail = the end of the step as one launch, march_cull = the marcher's ray-culling grid."""
         cfg = field.cfg
         self.field, self.cfg = field, cfg
         dev = field.device
@@ -218,11 +223,11 @@ class NgpPipeline:
         b = self.buf = {}
         # sample buffers exist twice: the marcher of step i+1 (it depends only on rays + occupancy) can run on a second
         # HIP stream while step i's backward is still scattering (prefetch_samples)
-        # prefetch_depth 2 (ARCN_PREFETCH_DEPTH overrides): three sets, two batches in flight - train_step(next_rays=) is then
+        # prefetch_depth 2: three sets, two batches in flight - train_step(next_rays=) is then
         # given the rays of step i+2 and marches them next to step i's optimiser pass (pure HBM streaming, idle VALUs) instead of next
         # to the backward kernels; a refreshed occupancy takes effect two steps later instead of one
-        env_depth = os.environ.get('ARCN_PREFETCH_DEPTH')
-        self.prefetch_depth = max(1, int(env_depth if env_depth is not None else (prefetch_depth or 1)))
+        self.prefetch_depth = max(1, int(prefetch_depth or 1))
+        self.march_cull = bool(march_cull)
         self._sets = []
         for _ in range(1 + self.prefetch_depth):
             self._sets.append({
@@ -243,16 +248,16 @@ class NgpPipeline:
         self._next_rays = None
         self._carry_rays = None  # prefetch point 5: rays handed over by the previous train_step, marched behind this step's gather
         self.occ_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
-        self.occ_async = bool(int(os.environ.get('ARCN_OCC_ASYNC', '1'))) and self.occ_stream is not None
+        self.occ_async = bool(occ_async) and self.occ_stream is not None
         self._occ_params_event = None   # the refresh still reads the parameters: the optimiser waits for it
         self._occ_bits_event = None     # the refreshed bitfield is ready: the marcher waits for it
         self._occ_state_event = None    # last refresh finished: readers of .bitfield / .opafield wait for it
-        self.prefetch_at = int(os.environ.get('ARCN_PREFETCH_AT', '1' if self.prefetch_depth == 1 else '3'))
+        self.prefetch_at = int(prefetch_at) if prefetch_at is not None else (1 if self.prefetch_depth == 1 else 3)
         # two batches ahead the marching has a whole step of slack: it runs as 4096 PERSISTENT wavefronts (arcn_march_count_waves: wave w takes
         # the rays w, w + 4096, ...) - half as many long-lived marcher waves on every SIMD beside the step's kernels, for twice as long: the
         # step loses 2 % less to them (0.569 -> 0.556 - 0.558 ms, three alternations; 3072: the same, 2048 / 5120 / 6144: less, 1024: the chain
         # is late and the step waits).  One batch ahead (or inline) the chain's latency is on the clock: +3 %, so not there.
-        self.march_waves = int(os.environ.get('ARCN_MARCH_WAVES', '4096' if self.prefetch_depth >= 2 else '0'))
+        self.march_waves = int(march_waves) if march_waves is not None else (4096 if self.prefetch_depth >= 2 else 0)
         # multi-rank: the compute units idle while the gradient all-reduce is on the wire - march the next batch there
         self.prefetch_at_dist = 3
         self._prefetch_now = self.prefetch_at
@@ -263,7 +268,7 @@ class NgpPipeline:
             # current stream: 1.05 ms per step against 0.58) - so it takes the priority of the stream the pipeline is built on.  Two
             # batches ahead it has a whole step of slack, and a lower priority is what one wants (bench.py's headline: -1 %).
             prio = torch.cuda.current_stream(dev).priority if self.prefetch_depth == 1 else 0
-            prio = int(os.environ.get('ARCN_AUX_PRIORITY', prio))
+            prio = int(aux_priority) if aux_priority is not None else prio
             self.aux_stream = torch.cuda.Stream(device=dev, priority=prio) if prio != 0 else torch.cuda.Stream(device=dev)
         self.use_streams = self.aux_stream is not None
         b['feat'] = torch.zeros((S, E), dtype=f32, device=dev)
@@ -294,7 +299,7 @@ class NgpPipeline:
         b['loss_ring'] = torch.zeros((64, self._loss_wgs), dtype=f32, device=dev)
         self._loss_slot = 0
         self._loss_step = [-1] * 64
-        self.fused_composite = bool(int(os.environ.get('ARCN_FUSED_COMPOSITE', '1')))
+        self.fused_composite = bool(fused_composite)
         # XCD-owned-levels scatter workspace (owner + tile counters); None selects the plain agent-scope kernel
         self.hash_ws = F.hashgrid_bwd_workspace(self.field.grid_desc, S, dev) if xcd_scatter else None  # scatter bins
         # single-GPU step: the optimiser of the table levels whose chunks have ONE owner is applied by that owner inside the scatter
@@ -302,7 +307,7 @@ class NgpPipeline:
         self._adam_rest = None
         self._fused_step = False
         self._fuse_next = False
-        if xcd_scatter and self.hash_ws is not None and bool(int(os.environ.get('ARCN_FUSE_ADAM', '1'))) and field.n_params > 0:
+        if xcd_scatter and self.hash_ws is not None and fuse_adam and field.n_params > 0:
             self._adam_rest = self._plan_fused_adam(S)
         # level-major features between the hash grid and the geometry net (XCD-affine gather, coalesced everywhere): the shapes
         # the *_lm entry points are wired for; anything else keeps the row-major buffers
@@ -316,12 +321,11 @@ class NgpPipeline:
         self.level_major = bool(level_major and xcd_scatter and cfg.n_feat_per_entry == 2 and field.geo_desc.n_layers == 2 and
                                 not field.geo_desc.has_bias and gd[0] in (32, 64) and 48 < gd[1] <= 64 and gd[2] <= 16)
         # single-GPU step with the optimiser inside the scatter: the two dW reductions, the optimiser on the rest of the flat buffer and
-        # the clearing of the scatter's bin counters as ONE launch at the end of the step (arcn_ngp_step_tail; ARCN_STEP_TAIL=0: four)
+        # the clearing of the scatter's bin counters as ONE launch at the end of the step (arcn_ngp_step_tail; step_tail=False: four)
         self._tail = None
         self._tail_step = False
         self._ws_clear = False
-        if (self._adam_rest is not None and self.level_major and self.fused_glue and not cfg.has_bias and
-                bool(int(os.environ.get('ARCN_STEP_TAIL', '1')))):
+        if self._adam_rest is not None and self.level_major and self.fused_glue and not cfg.has_bias and step_tail:
             gw, rw = field._seg['geo_w'], field._seg['rad_w']
             inside = lambda run, seg: seg[0] >= run[0] and seg[0] + seg[1] <= run[1]
             rest, ok = [], True
@@ -341,16 +345,16 @@ class NgpPipeline:
                               'clear_words': int(N.lib().arcn_hashgrid_bwd_counter_words(N.C.addressof(field.grid_desc), int(S)))}
                 # the tail launch is pure load latency (13 us alone, 50 us with the marcher's waves resident next to it): the next batch's
                 # marching is issued behind it, not in front (0.607 against 0.609 ms per step, 0.618 with the four launches)
-                if 'ARCN_PREFETCH_AT' not in os.environ and self.prefetch_depth != 1:
+                if prefetch_at is None and self.prefetch_depth != 1:
                     self.prefetch_at = 4
         # optimiser state
         n = field.n_params
         self.exp_avg = torch.zeros(n, dtype=f32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=f32, device=dev)
         # EMA shadow (ema.py's old_avg): equal to the parameters after every step because the average is written back, and this
-        # pipeline is the only writer of the flat buffer -> the shadow IS the buffer (arcn_adam_ema_step with ema == param);
-        # ARCN_EMA_ALIAS=0 keeps the separate copy
-        self.ema = field.params if bool(int(os.environ.get('ARCN_EMA_ALIAS', '1'))) else field.params.clone()
+        # pipeline is the only writer of the flat buffer -> the shadow IS the buffer (arcn_adam_ema_step with ema == param); a caller
+        # that keeps a separate shadow (FusedAdam without ema_in_param) assigns its buffer to `.ema`
+        self.ema = field.params
         self.step_count = 0
         self.ema_n_step = 0     # EMA.n_step (ema.py:14,25-27): equal to step_count unless a resumed job set it (set_ema_n_step)
         # occupancy (Volume bitfield/opafield, volume.py:741-760,959-969)
@@ -446,13 +450,12 @@ class NgpPipeline:
                 self._coarse.record_stream(aux)
 
     def _build_cull_grid(self):
-        """the marcher's ray-culling grid (arcn_march_cull_grid) of the occupancy just handed over; ARCN_MARCH_CULL=0: none"""
+        """the marcher's ray-culling grid (arcn_march_cull_grid) of the occupancy just handed over; march_cull=False: none"""
         self._coarse = None
         ng = self.cfg.n_grid
         # (only for the bits this pipeline packs itself, set_bitfield: a Morton bitfield handed over by set_occupancy_bits is updated in
         # place by its owner's kernels, behind any version counter - a stale culling grid would drop samples)
-        if (self._bits is None or not self._bits.is_cuda or self.packed_bits != 1 or ng < 16 or ng % 4 or
-                os.environ.get('ARCN_MARCH_CULL', '1') == '0'):
+        if self._bits is None or not self._bits.is_cuda or self.packed_bits != 1 or ng < 16 or ng % 4 or not getattr(self, 'march_cull', True):
             return
         cells = (ng // 4) ** 3
         coarse = torch.empty(cells, dtype=torch.uint8, device=self._bits.device)

@@ -125,10 +125,20 @@ class FusedNeusNgpStep:
             return 'the EikonalLoss is not the plain MSE mean on normal_pts'
         return None
 
-    def __init__(self, model, loss_factory, optimizer, ema=None, total_epoch=300000, prefetch=True):
+    def __init__(self, model, loss_factory, optimizer, ema=None, total_epoch=300000, prefetch=True, world_size=1, grad_sync='flat',
+                 sync_occupancy=True, keep_corners=True, fuse_adam=True):
+        """world_size > 1: data parallel, one process per GPU, every rank its shard of the rays (the reference wraps the model in
+        DistributedDataParallel, common/trainer/basic_trainer.py:192-198).  The flat gradient is SUMMED over the ranks between the backward
+        and the optimiser - grad_sync 'flat': ONE all-reduce of the flattened optimiser's gradient buffer, then FusedAdam.step() on every
+        rank; 'sharded': reduce-scatter, Adam on this rank's 1/N of the buffer, all-gather of the parameters (distributed.ShardedGradSync) -,
+        FusedAdam.grad_scale must be 1 / world_size (DDP's average), and a refreshed occupancy (the foreground Volume's fields, the
+        background cascade's grid and bits) is rank 0's on every rank (DDP's broadcast_buffers).  The scatters' chunk owners cannot apply
+        the optimiser then (the summed gradient only exists after the exchange): scatter, exchange, one optimiser pass."""
         reason = self.why_not(model, loss_factory, optimizer)
         if reason is not None:
             raise RuntimeError('FusedNeusNgpStep: ' + reason)
+        if grad_sync not in ('flat', 'sharded'):
+            raise RuntimeError('FusedNeusNgpStep: grad_sync must be flat or sharded')
         self.model, self.fg, self.bkg, self.opt, self.ema = model, model.fg_model, model.bkg_model, optimizer, ema
         self.loss_factory, self.total_epoch, self.prefetch = loss_factory, total_epoch, bool(prefetch)
         il = next(i for i, f in enumerate(loss_factory.funcs) if isinstance(f, ImgLoss))
@@ -139,11 +149,23 @@ class FusedNeusNgpStep:
         self._ws = {}
         self._ahead = []                 # batches marched ahead: (rays key, occupancy key, foreground handle, background handle), oldest first
         self.apply_optimizer = True      # (False: the gradients stay in the flat buffer - tests compare them with autograd's)
+        from .. import distributed as D
+        self.world = max(1, int(world_size))
+        # (ARCN_DIST_FORCE=1 with an initialised process group: a ONE-rank communicator runs the multi-rank form, collectives included)
+        self.dist_step = self.world > 1 or D._active()
+        self.grad_sync, self.sync_occupancy = grad_sync, bool(sync_occupancy)
+        self._sync = None
+        self._occ_seen = None
+        if self.dist_step and grad_sync == 'sharded':
+            self._sync = D.ShardedGradSync(optimizer._flat[0]['params'].numel(), self.world)
+            optimizer.shard_sync = self._sync      # (state_dict() then insists on gather_sharded_state() first)
+        # the gathered table rows of the forward are kept for the two second-order gathers (keep_corners=False: three gathers from the table;
+        # measured in round 5, DESIGN.md: -46 us per step with the rows kept)
+        self.keep_corners = bool(keep_corners)
         # the table scatters' chunk owners apply Adam to the levels they own alone (arcn_hashgrid_bwd_lm_adam / _first_second_adam): those levels'
-        # gradients never go to HBM and the optimiser pass shrinks to the rest of the flat buffer.  ARCN_FUSE_ADAM=0: scatter, then one pass
-        import os
-        self.keep_corners = os.environ.get('ARCN_NEUS_CORNERS', '1') != '0'
-        self.fuse_adam = (os.environ.get('ARCN_FUSE_ADAM', '1') != '0' and len(optimizer._flat) == 1 and len(optimizer.param_groups) == 1
+        # gradients never go to HBM and the optimiser pass shrinks to the rest of the flat buffer.  fuse_adam=False (and every multi-rank
+        # step): scatter, then one pass
+        self.fuse_adam = (bool(fuse_adam) and not self.dist_step and len(optimizer._flat) == 1 and len(optimizer.param_groups) == 1
                           and (optimizer.ema_decay is None or optimizer.ema_in_param))
 
     def _default_normal(self):
@@ -173,6 +195,21 @@ class FusedNeusNgpStep:
         # (the cascade's bits are rewritten by a kernel, behind torch's version counter: MortonDensityGrid counts its refreshes in ema_step)
         return (bf.data_ptr(), bf._version, db.data_ptr(), db._version, int(getattr(self.bkg, 'ema_step', 0)))
 
+    def _sync_occupancy(self):
+        """data parallel: when either occupancy structure has changed since the last step (model.optimize refreshed it - at the same epochs
+        on every rank), rank 0's state replaces every rank's, in place: the foreground Volume's opacity field + bitfield, the background
+        cascade's density grid + packed bits.  A collective decided by the model's state alone, never by rank-local buffers."""
+        if not self.dist_step or not self.sync_occupancy:
+            return
+        key = self._occupancy_key()
+        if key == self._occ_seen:
+            return
+        from .. import distributed as D
+        vol = self.fg.obj_bound.volume
+        D.broadcast_occupancy(vol.get_voxel_opafield(flatten=True), vol.get_voxel_bitfield(flatten=True))
+        D.broadcast_occupancy(self.bkg.density_grid, self.bkg.density_bitfield)
+        self._occ_seen = self._occupancy_key()
+
     def _march_ahead(self, feeds):
         """Queue both samplers (+ their scans, the totals on their way to pinned memory) for the batches of `feeds` that are not marched yet, in
         order, on the sampling stream - behind everything the main stream has been given so far.  One batch ahead the step's start finds totals
@@ -200,8 +237,8 @@ class FusedNeusNgpStep:
         occ = self._occupancy_key()
         with torch.cuda.stream(st):
             for k, o, d in todo:
-                hb = self.bkg._sample_begin(o, d)
-                hf = self.fg._sample_begin(o, d)
+                hb = self.bkg._sample_begin(o, d)       # (the handles hold o and d: their addresses cannot be handed to another batch while
+                hf = self.fg._sample_begin(o, d)        # an entry waits here, and the allocator knows the sampling stream reads them)
                 self._ahead.append((k, occ, hf, hb))
 
     @staticmethod
@@ -238,7 +275,14 @@ class FusedNeusNgpStep:
         R, dev = rays_o.shape[0], rays_o.device
         if not self.opt.zero_grad_on_step:
             self.opt.zero_grad()
-        hyper = self.opt.begin_step() if (self.apply_optimizer and self.fuse_adam) else None      # this step's optimiser numbers, for the scatters
+        if self.world > 1 and abs(float(self.opt.grad_scale) - 1.0 / self.world) > 1e-12:
+            raise RuntimeError('FusedNeusNgpStep(world_size={}): FusedAdam.grad_scale must be 1 / world_size (the gradients are SUMMED over the '
+                               'ranks), it is {}'.format(self.world, self.opt.grad_scale))
+        self._sync_occupancy()
+        # this step's optimiser numbers, for the scatters whose owners apply it: asked for right before the first of them (begin_step advances the
+        # Adam / EMA counters - an exception in the forward or the sampler must not leave them a step ahead of the parameters)
+        fuse = bool(self.apply_optimizer and self.fuse_adam)
+        hyper = None
         done = []                                                                                 # float ranges the scatters' owners have updated
         cur = torch.cuda.current_stream()
         # ---- samples of both models: marched one or two steps ago on the sampling stream (self._ahead, oldest first), or now
@@ -356,7 +400,8 @@ class FusedNeusNgpStep:
             F.gemm_tn(d_hid_b, enc_b, mask=hid_b, out=b0.weight.grad, accumulate=True)
             d_enc_b = F.gemm_nn(d_hid_b, b0.weight, mask=hid_b)
             ws_b = self._scatter_ws('bkg', emb_b.desc, total_b, dev)
-            if hyper is not None:
+            if fuse:
+                hyper = hyper or self.opt.begin_step()
                 m_, v_, o_ = self.opt.table_views(tb)
                 done += self._level_ranges(emb_b, F.hashgrid_bwd_adam(xyz_b, d_enc_b, emb_b.desc, tb.grad, tb, m_, v_, hyper, ws_b), o_)
             else:
@@ -393,7 +438,8 @@ class FusedNeusNgpStep:
             F.gemm_tn(dz, enc, out=l0.weight.grad, accumulate=True)
             # the table: through the encoding (d_enc) and through its input gradient (d_normal on J^T jac), ONE accumulation pass for both
             ws_f = self._scatter_ws('fg', emb.desc, 3 * S, dev)
-            if hyper is not None:
+            if fuse:
+                hyper = hyper or self.opt.begin_step()
                 m_, v_, o_ = self.opt.table_views(table)
                 done += self._level_ranges(emb, F.hashgrid_bwd_first_second_adam(pts, d_enc, d_normal, jac, emb.desc, table.grad, table, m_, v_, hyper, ws_f), o_)
             else:
@@ -402,9 +448,30 @@ class FusedNeusNgpStep:
             F.sum_scale_add(d_s_ray, fg.inv_s.grad, float(fg.speed_factor), s_dev)
         # ---- optimiser
         if self.apply_optimizer:
-            if hyper is not None:
+            if fuse:
+                hyper = hyper or self.opt.begin_step()
                 self.opt.finish_step(hyper, done)      # Adam on what the scatters' owners did not update: the coarse levels, the nets, inv_s
+            elif self._sync is not None:
+                # reduce-scatter of the flat gradient, Adam on this rank's shard (+ the replicated tail), all-gather of the parameters
+                fb = self.opt._flat[0]
+                self._sync.launch(fb['grads'])
+                self._sync.wait()
+                hyper = self.opt.begin_step()
+                n_all = fb['params'].numel()
+                keep, at = [], 0
+                for lo, hi in sorted(self._sync.segments):
+                    if lo > at:
+                        keep.append((at, lo))
+                    at = hi
+                if at < n_all:
+                    keep.append((at, n_all))
+                self.opt.finish_step(hyper, keep)      # (`keep` = everything that is NOT this rank's: left to its owner)
+                self._sync.clear_foreign(fb['grads'])
+                self._sync.gather(fb['params'])
             else:
+                if self.dist_step:
+                    from .. import distributed as D
+                    D.allreduce_grads(self.opt.flat_grads(), self.world)       # ONE collective on the flat buffer; 1 / world is the optimiser's grad_scale
                 self.opt.step()
             if self.ema is not None:
                 self.ema.ema_step()

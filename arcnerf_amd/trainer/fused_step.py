@@ -13,8 +13,11 @@ occupancy refresh of the module's own Volume) stay what they are, inference goes
 
 The first steps (an all-ones bitfield asks for R x n_sample samples) run through the module path, which sizes the sample buffers;
 a step that overflows them is detected a step later (the sample total travels to pinned memory) and the buffers grow.  Such a step is
-never a step on truncated rays: the compositor leaves the rays behind the fill point out (arcn_composite_packed_train, `counts`), its
-update is the exact update of the rays that fit.
+never a step on truncated rays: the compositor leaves the rays behind the fill point out (arcn_composite_packed_train, `counts`): they
+render as background and send no gradient.  The loss stays the mean over ALL R rays of the batch - the left-out rays contribute their
+(background vs target) term to the reported value, and the rays that fit keep the 1 / (3 R) weight they have in a complete step: the
+update is the gradient of that batch mean with the left-out rays' terms constant, i.e. the fitting rays' exact gradients scaled by
+R_fit / R relative to a batch made of them alone.
 """
 import copy
 import warnings
@@ -142,6 +145,7 @@ class FusedNgpStep:
         elif self.world > 1 and self.grad_sync == 'sharded':
             from .. import distributed as D
             self._sync = D.ShardedGradSync(fld.n_params, self.world)
+            self.opt.shard_sync = self._sync       # (state_dict() then insists on gather_sharded_state() first)
         self.pipe, self._bits_key = pipe, None
         self._pending.clear()
         self.rebuilds += 1
@@ -180,7 +184,8 @@ class FusedNgpStep:
             self.fg._samples_per_ray = need / max(1, rays)
             if need >= cap:
                 # (the compositor never renders a ray from a truncated sample set: the rays behind the fill point took no part in that
-                # step - background colour, zero gradient - so its update was the exact step of the rays that fit)
+                # step - background colour, zero gradient; the loss of that step is still the mean over all its rays, so the rays that
+                # fit kept their 1 / (3 R) weight and the reported loss includes the left-out rays' background term)
                 warnings.warn('FusedNgpStep: a training step filled the sample buffers ({} slots for {} rays): the rays behind the fill point '
                               'were left out of that step (no gradient from them); the buffers grow now'.format(cap, rays))
                 self.fg._samples_per_ray = max(self.fg._samples_per_ray, 2.0 * cap / max(1, rays))

@@ -92,6 +92,7 @@ class Pipeline(object):
         """pipeline.py:54-93.  train_data: a dataset dict (see the module docstring) or the dict a previous call returned (the reshuffle of
         a finished pass, arcnerf_trainer.py:536-540).  Returns the dict with 'H' / 'W' = [0] and the view under '_view'."""
         logger = logger or _Log()
+        self.check_bad_ids(train_data)
         self.set_info('sample_img_count', 0)
         self.set_info('sample_total_count', 0)
         train_data = self.step_crop_center_image(logger, train_data)
@@ -103,6 +104,18 @@ class Pipeline(object):
         train_data['H'] = [0]
         train_data['W'] = [0]
         return train_data
+
+    @staticmethod
+    def check_bad_ids(train_data):
+        """arcn_fetch_train_batch clamps a ray id outside [0, n_img * window) to ray 0 and counts it (TrainView.bad): a wrong permutation or
+        window would otherwise train on copies of pixel 0 without a word.  Read here - once per pass over the data (the reshuffle, the end of
+        the crop), one host read - and raised."""
+        view = train_data.get('_view') if isinstance(train_data, dict) else None
+        if view is not None and view.bad is not None:
+            n_bad = int(view.bad.item())
+            if n_bad:
+                raise RuntimeError('Pipeline: {} ray ids of the last pass were outside the dataset window (clamped to ray 0 by the batch fetch): '
+                                   'the permutation or the crop window is wrong'.format(n_bad))
 
     @staticmethod
     def _view_of(train_data):

@@ -332,11 +332,13 @@ def bench_module(args, name, emit=True):
     prefetch = name == 'neus_ngp_multivol' and os.environ.get('ARCN_PREFETCH_SAMPLES', '1') != '0'
 
     fused_neus = None
-    if name == 'neus_ngp_multivol' and mode == 'fused' and not use_dist:
+    if name == 'neus_ngp_multivol' and mode == 'fused':
         # config 4 as a hand-ordered kernel chain (trainer.FusedNeusNgpStep): no autograd engine between the kernels, the next batch's samplers
-        # on a second stream; ARCN_MODULE_STEP=eager: the module path
+        # on a second stream; N > 1: every rank its rays through the same chain, the flat gradient summed between the scatters and the
+        # optimiser (ARCN_GRAD_SYNC=flat: one all-reduce, the default | sharded); ARCN_MODULE_STEP=eager: the module path
         from arcnerf_amd.trainer import FusedNeusNgpStep
-        fused_neus = FusedNeusNgpStep(m, neus_loss, opt)
+        gs = os.environ.get('ARCN_GRAD_SYNC', 'flat')
+        fused_neus = FusedNeusNgpStep(m, neus_loss, opt, world_size=world, grad_sync=gs if gs in ('flat', 'sharded') else 'flat')
 
     def step(i):
         inp = pool[i % len(pool)]
@@ -450,7 +452,8 @@ def bench_module(args, name, emit=True):
                # device time between the steps' end events, median / slowest: a step whose HOST side was stalled (shared hosts: this step is ~65 %
                # host time on a quiet machine) shows in ms_per_step and in the maximum, not in the median
                'step_ms_device': {'p50': step_gpu_ms[len(step_gpu_ms) // 2], 'max': step_gpu_ms[-1]} if step_gpu_ms else None,
-               'launch': ('trainer.FusedNeusNgpStep: the step as a hand-ordered kernel chain (no autograd engine), the next batch\'s samplers on a second stream ({} steps)'.format(fused_neus.steps) if fused_neus is not None
+               'launch': ('trainer.FusedNeusNgpStep: the step as a hand-ordered kernel chain (no autograd engine), the next batch\'s samplers on a second stream ({} steps{})'.format(
+                              fused_neus.steps, ', gradient exchange: ' + fused_neus.grad_sync if fused_neus.dist_step else '') if fused_neus is not None
                           else ('trainer.FusedNgpStep: the module API on NgpPipeline.train_step over the flattened optimiser\'s buffers, next {} batches marched '
                                 'early ({} steps in this run, {} eager warm-up steps before)'.format(fused.depth, fused.steps, 2) if fused is not None
                                 else 'every kernel of the module path issued eagerly'))},

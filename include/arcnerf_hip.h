@@ -252,17 +252,24 @@ int arcn_hashgrid_bwd_bwd(const float *xyz, const float *gdx, const float *table
                           int64_t workspace_floats, int64_t n, const int32_t *n_ptr, void *stream);
 /* The second-order gathers of NeuS on the hash grid WITHOUT their random reads.  The normal (d enc / d x)^T jac and the gradient of that
  * product with respect to jac (hashgrid_encoder.py through base_network.py:30-44, create_graph = True) read the SAME eight table rows per
- * (sample, level) the forward gathered.  arcn_hashgrid_fwd_corners keeps them - corners (n, L, 8, F) floats, 64 B per (sample, level) at
- * F = 2, zeros outside the grid - and the two consumers stream them:
- *   arcn_hashgrid_dxyz_corners : dxyz (n, 3) += what arcn_hashgrid_bwd adds to dxyz (caller zeroes it)
- *   arcn_hashgrid_ddout_corners: ddout (n, L F) = the ddout of arcn_hashgrid_bwd_bwd
- * The same arithmetic in the same order on the same values: bit-identical to the table forms. */
-int arcn_hashgrid_fwd_corners(const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out, float *corners, int64_t n,
-                              void *stream);
+ * (sample, level) the forward gathered.  arcn_hashgrid_fwd_corners is arcn_hashgrid_fwd_xcd (below: the XCD-affine gather, same `out`,
+ * same level_major / n_cap / n_ptr) that also keeps those rows, LEVEL-major in 16-byte quads - quad j of (sample s, level l) holds rows
+ * 2j, 2j + 1 at F = 2 (rows 4j .. 4j + 3 at F = 1) at corners[((l * 2 F + j) * n_cap + s) * 4], zeros outside the grid: 8 F n_cap L floats,
+ * every store and every later read one contiguous KiB per wavefront - and the two consumers stream them, one lane per sample:
+ *   arcn_hashgrid_dxyz_corners : dxyz (n, 3)    = what arcn_hashgrid_bwd adds to a cleared dxyz        (dout (n, L F) row-major)
+ *   arcn_hashgrid_ddout_corners: ddout (n, L F) = the ddout of arcn_hashgrid_bwd_bwd                   (gdx (n, 3))
+ * The same arithmetic in the same order on the same values: bit-identical to the table forms.  n_feat 1 or 2. */
+int arcn_hashgrid_fwd_corners(const float *xyz, const float *table, const arcn_hashgrid_desc *desc_host, float *out, int level_major,
+                              float *corners, int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream);
 int arcn_hashgrid_dxyz_corners(const float *xyz, const float *corners, const float *dout, const arcn_hashgrid_desc *desc_host, float *dxyz,
-                               int64_t n, void *stream);
+                               int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream);
 int arcn_hashgrid_ddout_corners(const float *xyz, const float *gdx, const float *corners, const arcn_hashgrid_desc *desc_host, float *ddout,
-                                int64_t n, void *stream);
+                                int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream);
+/* level-major features lm[(l * n_cap + s) * n_feat + f] (arcn_hashgrid_fwd_xcd / _fwd_corners with level_major = 1) -> row-major
+ * rows[s * ld + l * n_feat + f], the operand layout of the dense products (arcn_gemm_*): one LDS-tiled pass, whole cache lines on both
+ * sides.  HashGridEmbedder.forward's (n, L F) output (hashgrid_encoder.py:160-189) = the XCD-affine gather + this. */
+int arcn_hashgrid_lm_to_rows(const float *lm, int n_levels, int n_feat, int64_t n_cap, float *rows, int64_t ld, int64_t n,
+                             const int32_t *n_ptr, void *stream);
 /* The table's FIRST- and SECOND-order gradients of one batch in one consumer pass: dtable += d/d table of <dout, enc(xyz)> (what
  * arcn_hashgrid_bwd adds) + d/d table of <gdx, J(xyz; table)^T dout_dx> (what arcn_hashgrid_bwd_bwd adds) - both producers fill the same
  * bins, one accumulation pass over the table instead of two.  workspace: at least arcn_hashgrid_bwd_workspace_floats(desc, 3 * n). */

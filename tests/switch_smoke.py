@@ -1,8 +1,9 @@
-"""Run by tests/test_gpu_switches.py in a subprocess with some ARCN_* switches at their non-default values: three small workloads that
-between them reach every switched code path, results to an .npz for the parent to compare with the default run.
-  ngp    : NgpPipeline, 4 training steps with prefetch + occupancy refresh (pipeline / scatter / gather / MLP-kernel switches)
-  nets   : the module path of vanilla NeRF, NeuS and HDR-NeRF at reduced size, one forward + backward each (dense-layer switches)
-  neusngp: NeuS on the hash grid + the packed NGP module path (explicit-Jacobian node, fused radiance route, overflow check)"""
+"""Run by tests/test_gpu_switches.py in a subprocess with one of the remaining switches at its non-default value (NgpPipeline keyword
+switches as a JSON third argument, the library's ARCN_DETERMINISTIC in the environment): small workloads that reach the switched code paths,
+results to an .npz for the parent to compare with the default run.
+  ngp    : NgpPipeline, 4 training steps with prefetch + occupancy refresh (schedule / scatter switches)
+  neusngp: NeuS on the hash grid + the packed NGP module path (first- and second-order table scatters)"""
+import json
 import os
 import sys
 
@@ -15,12 +16,12 @@ CFG = os.path.join(ROOT, 'configs')
 dev = torch.device('cuda:0')
 
 
-def ngp(out):
+def ngp(out, kw):
     from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline, synthetic_bitfield, synthetic_rays
     cfg = NgpConfig(n_levels=8, hashmap_size=15, max_res=512, n_grid=64, n_sample=512, noise_std=0.0, lr=1e-2)
     fld = NgpField(cfg, device=dev, seed=3)
     fld.view('table').mul_(1000.0)
-    pipe = NgpPipeline(fld, max_rays=2048, max_samples=1 << 17, packed_bits=True, prefetch_depth=2)
+    pipe = NgpPipeline(fld, max_rays=2048, max_samples=1 << 17, packed_bits=True, **dict({'prefetch_depth': 2}, **kw))
     pipe.set_bitfield(torch.from_numpy(synthetic_bitfield(cfg.n_grid, 0.1, seed=5)))
     g = torch.Generator().manual_seed(11)
     batches = []
@@ -56,27 +57,7 @@ def _module(name, overrides, n_rays, radius, seed, extra=None):
     return m, inp
 
 
-def nets(out):
-    # (chunk_pts below the number of points: the chunk loops - weight splits shared across chunks, gradients summed over them - are run)
-    m, inp = _module('nerf', ['--model.rays.perturb', 'False', '--model.rays.noise_std', '0.0', '--model.chunk_pts', '20000'], 256, 4.0, 1)
-    r = m(dict(inp), inference_only=False)
-    (((r['rgb_fine'] - inp['img']) ** 2).mean() + ((r['rgb_coarse'] - inp['img']) ** 2).mean()).backward()
-    out['nerf_rgb'] = r['rgb_fine'].detach().cpu().numpy()
-    out['nerf_grad'] = torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None]).cpu().numpy()
-    m, inp = _module('neus', ['--model.rays.perturb', 'False', '--model.chunk_pts', '6000'], 128, 3.0, 2)
-    r = m(dict(inp), inference_only=False, cur_epoch=20000)
-    (((r['rgb'] - inp['img']) ** 2).mean() + 0.1 * ((r['normal_pts'].norm(dim=-1) - 1.0) ** 2).mean()).backward()
-    out['neus_rgb'] = r['rgb'].detach().cpu().numpy()
-    out['neus_grad'] = torch.cat([p.grad.reshape(-1) for n, p in m.named_parameters() if p.grad is not None and not n.endswith(('layers.0.weight_v', 'layers.5.weight_v'))]).cpu().numpy()
-    m, inp = _module('hdrnerf', ['--model.rays.perturb', 'False', '--model.rays.noise_std', '0.0'], 256, 4.0, 3,
-                     extra=lambda g, n: {'exp_time': (torch.rand(1, n, 1, generator=g) * 4.0 + 0.1).to(dev)})
-    r = m(dict(inp), inference_only=False)
-    ((r['rgb_fine'] - inp['img']) ** 2).mean().backward()
-    out['hdr_rgb'] = r['rgb_fine'].detach().cpu().numpy()
-    out['hdr_grad'] = torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None]).cpu().numpy()
-
-
-def neusngp(out):
+def neusngp(out, kw):
     from arcnerf_amd.ops.multivol_func import multivol_rng
     from arcnerf_amd.ops.volume_func import sampler_rng
     from arcnerf_amd.pipeline import synthetic_bitfield
@@ -114,7 +95,8 @@ def neusngp(out):
 
 if __name__ == '__main__':
     which, path = sys.argv[1], sys.argv[2]
+    kw = json.loads(sys.argv[3]) if len(sys.argv) > 3 else {}
     out = {}
-    {'ngp': ngp, 'nets': nets, 'neusngp': neusngp}[which](out)
+    {'ngp': ngp, 'neusngp': neusngp}[which](out, kw)
     torch.cuda.synchronize()
     np.savez(path, **out)

@@ -135,7 +135,15 @@ def _sharded_worker(rank, world, port, ret):
                 sync.clear_foreign(grads)
                 sync.gather(p)
                 assert float(grads.abs().max()) == 0.0
-        runs[form] = (p.numpy().copy(), float(m[:sync.lo].abs().sum() + m[sync.hi:sync.body].abs().sum()))
+        foreign = float(m[:sync.lo].abs().sum() + m[sync.hi:sync.body].abs().sum())
+        if form == 'sharded':
+            # a checkpoint needs every shard's moments: not current after sharded steps, complete after the collective gather
+            was_current = sync.moments_current
+            sync.gather_moments(m, v)
+            runs['moments'] = (was_current, sync.moments_current, m.numpy().copy(), v.numpy().copy())
+        else:
+            runs['flat_moments'] = (m.numpy().copy(), v.numpy().copy())
+        runs[form] = (p.numpy().copy(), foreign)
     ret[rank] = (runs, sync.segments, sync.body)
     dist.destroy_process_group()
 
@@ -165,6 +173,14 @@ def test_sharded_gradient_sync_equals_flat_allreduce(world):
         else:
             assert np.abs(runs['sharded'][0] - ref).max() <= 1e-4 and np.mean(runs['sharded'][0] != ref) < 0.5
         assert runs['sharded'][1] == 0.0 and runs['flat'][1] > 0.0
+        was_current, now_current, m_all, v_all = runs['moments']
+        assert not was_current and now_current
+        assert np.array_equal(m_all, ret[0][0]['moments'][2]) and np.array_equal(v_all, ret[0][0]['moments'][3]), r     # the same complete state on every rank
+        fm, fv = runs['flat_moments']
+        if world == 2:
+            assert np.array_equal(m_all, fm) and np.array_equal(v_all, fv)      # ... and it is the replicated optimiser's
+        else:
+            assert np.abs(m_all - fm).max() <= 1e-4 * max(1.0, np.abs(fm).max()) and np.abs(v_all - fv).max() <= 1e-4 * max(1.0, np.abs(fv).max())
         spans.append(segments[0])
         assert segments[1:] == ([(body, 100003)] if body < 100003 else [])
     spans.sort()

@@ -213,6 +213,9 @@ def test_bench_gpus_flag_spawns_the_ranks_itself(config):
     assert abs(out['value'] - total / (out['ms_per_step'] * 1e-3 * out['steps'])) <= 1e-3 * out['value']
     # weak scaling: both ranks carry a full batch (rank-local rays), so the job's samples are about twice one rank's
     assert 1.6 <= sum(rc['per_rank_samples_per_step']) / max(rc['per_rank_samples_per_step']) <= 2.0
+    if config == 'neus_ngp_multivol':      # the hand-ordered chain ran on both ranks (not the module path), with its gradient exchange
+        assert 'trainer.FusedNeusNgpStep' in out['config']['launch'] and 'gradient exchange: flat' in out['config']['launch']
+        assert '({} steps'.format(out['steps'] + out['warmup']) in out['config']['launch']
 
 
 def test_bench_refuses_more_rccl_ranks_than_gpus():
@@ -363,3 +366,95 @@ def test_two_ranks_through_the_module_api_fused_step_equal_the_eager_ddp_form():
     assert far.mean() < 1e-3, far.mean()
     for r in (r0, r1):
         assert np.max(np.abs(r['eager_losses'] - r['fused_losses']) / np.abs(r['eager_losses'])) < 1e-4, (r['eager_losses'], r['fused_losses'])
+
+
+# ---- config 4 (NeuS on the hash grid + MultiVol background), data parallel ------------------------------------------------------------------
+def _neus_ddp_worker(rank, world, port, path):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from arcnerf_amd import distributed as D
+    from arcnerf_amd import trainer as T
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.ops.multivol_func import multivol_rng
+    from arcnerf_amd.ops.volume_func import sampler_rng
+    from arcnerf_amd.optim import FusedAdam
+    from arcnerf_amd.pipeline import synthetic_bitfield, synthetic_cascade_bits, synthetic_rays
+    from arcnerf_amd.utils.cfgs_utils import dict_to_obj, load_configs
+    D.init_from_env(backend='gloo')
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    loss_cfg = dict_to_obj({'loss': {'ImgLoss': {'loss_type': 'Huber', 'delta': 0.1, 'weight': 5.0}, 'EikonalLoss': {'key': 'normal_pts', 'weight': 0.1}}})
+    R, steps = 512, 4
+    pool = []
+    g = torch.Generator().manual_seed(3)
+    for i in range(steps):
+        o, d = synthetic_rays(2 * R, seed=20 + i, device=dev, radius=2.2)
+        bk, im = torch.rand(1, 2 * R, 3, generator=g).to(dev), torch.rand(1, 2 * R, 3, generator=g).to(dev)
+        sl = slice(rank * R, (rank + 1) * R)      # every rank its half of the global batch
+        pool.append({'rays_o': o[sl].contiguous().view(1, -1, 3), 'rays_d': d[sl].contiguous().view(1, -1, 3), 'rays_r': torch.zeros(1, R, 1, device=dev),
+                     'bkg_color': bk[:, sl].contiguous(), 'img': im[:, sl].contiguous()})
+    out = {}
+    for mode in ('eager', 'flat', 'sharded'):
+        torch.manual_seed(0)
+        m = build_model(load_configs(os.path.join(root, 'configs', 'neus_ngp_multivol.yaml'), [])).to(dev)
+        m.fg_model.obj_bound.volume.update_bitfield(torch.from_numpy(synthetic_bitfield(128, 0.05, seed=0)).to(dev), ops='overwrite')
+        m.bkg_model.density_bitfield.copy_(torch.from_numpy(synthetic_cascade_bits(128, m.bkg_model.n_levels, 0.05, seed=5)).to(dev))
+        with torch.no_grad():
+            m.fg_model.geo_net.embed_fn.embeddings.mul_(200.0)
+            m.bkg_model.geo_net.embed_fn.embeddings.mul_(2000.0)
+        opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=5e-4, eps=1e-15).flatten()
+        opt.grad_scale = 1.0 / world
+        D.broadcast_params(opt.flat_params(), src=0)
+        lf = T.build_loss(loss_cfg)
+        sampler_rng(reset=True)
+        multivol_rng(reset=True)
+        m.train()
+        st = T.FusedNeusNgpStep(m, lf, opt, world_size=world, grad_sync=mode) if mode != 'eager' else None
+        if st is not None:
+            assert st.dist_step and not st.fuse_adam
+        losses = []
+        for k in range(steps):
+            feed = pool[k]
+            if st is not None:
+                _, loss = st(feed, 20000 + k, next_feed_in=pool[k + 1] if k + 1 < steps else None)
+            else:       # the module path the way DistributedDataParallel runs it: backward, SUM of the flat gradient, optimiser with 1 / world
+                o_ = m(dict(feed), inference_only=False, cur_epoch=20000 + k)
+                loss = lf(feed, o_)
+                opt.zero_grad()
+                loss['sum'].backward()
+                dist.all_reduce(opt.flat_grads())
+                opt.step()
+            losses.append(float(loss['sum']))
+        torch.cuda.synchronize()
+        out[mode + '_params'] = opt.flat_params().cpu().numpy()
+        out[mode + '_losses'] = np.array(losses)
+        if st is not None:
+            out[mode + '_steps'] = np.array(st.steps)
+    np.savez(path + '.rank{}'.format(rank), **out)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_through_the_fused_neus_ngp_step_equal_the_eager_ddp_form():
+    """trainer.FusedNeusNgpStep(world_size=2): BASELINE config 4's hand-ordered chain on every rank's shard of the rays, the flat gradient summed
+    between the scatters and the optimiser (one all-reduce | reduce-scatter + sharded Adam + all-gather), FusedAdam.grad_scale = 1 / 2 - against
+    the same two ranks on the module path with ONE all-reduce of the flat gradient between backward and FusedAdam.step (what the reference's
+    DistributedDataParallel amounts to, common/trainer/basic_trainer.py:192-198).  Every form leaves bit-identical parameters on the two
+    ranks; the forms agree to the float scatter's order noise."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'out')
+        mp.spawn(_neus_ddp_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+        r0, r1 = dict(np.load(path + '.rank0.npz')), dict(np.load(path + '.rank1.npz'))
+    for mode in ('eager', 'flat', 'sharded'):
+        assert np.array_equal(r0[mode + '_params'], r1[mode + '_params']), mode
+    assert int(r0['flat_steps']) == 4 and int(r0['sharded_steps']) == 4
+    a = r0['eager_params']
+    for mode in ('flat', 'sharded'):
+        b = r0[mode + '_params']
+        far = np.abs(a - b) > 1e-3 * np.abs(a).max()
+        assert far.mean() < 1e-3, (mode, far.mean())
+        for r in (r0, r1):
+            assert np.max(np.abs(r['eager_losses'] - r[mode + '_losses']) / np.abs(r['eager_losses'])) < 1e-4, (mode, r['eager_losses'], r[mode + '_losses'])
+    assert not np.array_equal(r0['eager_losses'], r1['eager_losses'])      # (the ranks saw different rays)

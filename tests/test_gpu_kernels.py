@@ -357,7 +357,7 @@ def test_level_major_variants_match_row_major(F):
     S, cap = 9001, 9216   # ragged count, level stride = capacity
     xyz = dev(((rng.random((S, 3)).astype(np.float32) - 0.5) * 2.05).astype(np.float32))
     lib, st = N.lib(), N.stream()
-    ref = F.hashgrid_fwd(xyz, table, desc)
+    ref = F.hashgrid_fwd_plain(xyz, table, desc)
     rm = torch.zeros(S, 32, device='cuda')
     lm = torch.zeros(16, cap, 2, device='cuda')
     N.check(lib.arcn_hashgrid_fwd_xcd(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(rm), 0, S, S, None, st))
@@ -1332,7 +1332,8 @@ def test_balanced_gather_is_bit_identical_for_any_launch_size(side):
         xyz = ((torch.rand(n, 3, generator=g) - 0.5) * side * 1.05).cuda()
         if n >= 5:
             xyz[:5] = torch.tensor([[-h, -h, -h], [h, h, h], [0, 0, 0], [h - 1e-7, 0, 0], [-h + 1e-7, 0.1, 0.2]], device='cuda')
-        ref = Fn.hashgrid_fwd(xyz, table, desc)
+        ref = Fn.hashgrid_fwd_plain(xyz, table, desc)
+        assert torch.equal(Fn.hashgrid_fwd(xyz, table, desc), ref), n      # (the front end: level-major + transposing pass for the large launches)
         rm = torch.zeros(n, 32, device='cuda')
         lm = torch.zeros(16, n, 2, device='cuda')
         N.check(lib.arcn_hashgrid_fwd_xcd(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(rm), 0, n, n, None, st))
@@ -1780,3 +1781,23 @@ def test_persistent_marcher_gives_the_samples_of_the_one_wave_per_ray_marcher():
                 t_got, t_ref = got['scratch_t'][:R].cpu().numpy(), ref['scratch_t'][:R].cpu().numpy()
                 valid = np.arange(t_ref.shape[1])[None, :] < cnt[:, None]
                 assert np.array_equal(t_got[valid], t_ref[valid]), (R, waves)
+
+
+@pytest.mark.gpu
+def test_dense_layers_refuse_non_float32_cuda_tensors_instead_of_the_library():
+    """the product path has no library fallback: a CUDA tensor that is not float32 used to slip to torch.nn.functional.linear (hipBLASLt)
+    silently - a dtype slip would have benchmarked the library.  Every dense-layer front end raises instead (the extension of
+    tests/test_host_api.py::test_product_path_has_no_cpu_fallback to the dtype case); float32 takes the hand-written products."""
+    from arcnerf_amd.ops import autograd as A
+    x, w = torch.randn(64, 32, device='cuda'), torch.randn(16, 32, device='cuda')
+    for bad_x, bad_w in ((x.half(), w.half()), (x.double(), w.double()), (x.bfloat16(), w), (x, w.half())):
+        for fn in (lambda: A.linear(bad_x, bad_w), lambda: A.linear_relu(bad_x, bad_w), lambda: A.linear_softplus(bad_x, bad_w, None, 100.0),
+                   lambda: A.linear_act_nograd(bad_x, bad_w, None, 'relu')):
+            with pytest.raises(RuntimeError, match='float32'):
+                fn()
+    with pytest.raises(RuntimeError, match='float32'):
+        A.softplus(x.double(), 100.0)
+    y = A.linear(x, w)
+    assert torch.allclose(y, x @ w.t(), rtol=1e-5, atol=1e-5) and A._use_hip_linear(x, w)
+    # CPU tensors (the host-side tests of the module logic) still go to torch
+    assert not A._use_hip_linear(x.cpu(), w.cpu())

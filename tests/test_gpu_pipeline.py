@@ -105,7 +105,8 @@ def test_full_size_properties(gpu):
     table, desc = fld.view('table'), fld.grid_desc
     lib, st = N.lib(), N.stream()
     # (1)
-    ref = F.hashgrid_fwd(xyz, table, desc)
+    ref = F.hashgrid_fwd_plain(xyz, table, desc)
+    assert torch.equal(F.hashgrid_fwd(xyz, table, desc), ref)
     lm = torch.zeros(16, S, 2, device=gpu)
     rm = torch.zeros(S, 32, device=gpu)
     N.check(lib.arcn_hashgrid_fwd_xcd(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(lm), 1, S, S, None, st))
@@ -436,13 +437,9 @@ def test_scatter_with_fused_optimiser_equals_scatter_then_adam():
     cfg = NgpConfig(noise_std=0.0, lr=1e-2)
     res = {}
     for fused in (True, False):
-        os.environ['ARCN_FUSE_ADAM'] = '1' if fused else '0'
-        try:
-            fld = NgpField(cfg, device=dev, seed=3)
-            fld.view('table').mul_(1000.0)
-            pipe = NgpPipeline(fld, max_rays=4096, max_samples=1 << 19)
-        finally:
-            os.environ.pop('ARCN_FUSE_ADAM')
+        fld = NgpField(cfg, device=dev, seed=3)
+        fld.view('table').mul_(1000.0)
+        pipe = NgpPipeline(fld, max_rays=4096, max_samples=1 << 19, fuse_adam=fused)
         assert (pipe._adam_rest is not None) == fused
         pipe.set_bitfield(torch.from_numpy(synthetic_bitfield(cfg.n_grid, 0.05, seed=5)))
         g = torch.Generator().manual_seed(11)
@@ -524,7 +521,7 @@ def test_step_tail_launch_equals_the_four_launches_it_replaces():
     """arcn_ngp_step_tail (two dW reductions with the optimiser applied by each element's owner + the optimiser on the remaining runs +
     the scatter's counter block cleared, ONE launch) against arcn_mlp_bwd_reduce x 2, arcn_adam_ema_step_runs and a memset on the same
     partials and state: bit-identical parameters, moments and (cleared) gradients, three steps so the bias corrections move.  Then the
-    pipeline: ARCN_STEP_TAIL=1 (default) and =0 train three steps from the same state; everything that does not come out of the float
+    pipeline: step_tail=True (default) and False train three steps from the same state; everything that does not come out of the float
     scatter's summation order - the MLP weights' first step - agrees to rounding, and the counters are clear when the scatter says so."""
     import ctypes as C
     import os
@@ -573,13 +570,9 @@ def test_step_tail_launch_equals_the_four_launches_it_replaces():
 
     res = {}
     for tail in ('1', '0'):
-        os.environ['ARCN_STEP_TAIL'] = tail
-        try:
-            f2 = NgpField(cfg, device=dev, seed=3)
-            f2.view('table').mul_(1000.0)
-            pipe = NgpPipeline(f2, max_rays=4096, max_samples=1 << 19)
-        finally:
-            os.environ.pop('ARCN_STEP_TAIL')
+        f2 = NgpField(cfg, device=dev, seed=3)
+        f2.view('table').mul_(1000.0)
+        pipe = NgpPipeline(f2, max_rays=4096, max_samples=1 << 19, step_tail=(tail == '1'))
         assert (pipe._tail is not None) == (tail == '1')
         pipe.set_bitfield(torch.from_numpy(synthetic_bitfield(cfg.n_grid, 0.05, seed=5)))
         gg = torch.Generator().manual_seed(11)

@@ -207,9 +207,9 @@ def test_sdf_net_graph_free_pass_and_its_weight_cache(gpu, monkeypatch):
 
     def both():
         with torch.no_grad():
-            monkeypatch.setenv('ARCN_SDF_NOGRAD_FAST', '0')
+            geo.nograd_fast = False          # the layer-by-layer modules
             ref = geo(x)
-            monkeypatch.setenv('ARCN_SDF_NOGRAD_FAST', '1')
+            geo.nograd_fast = True
             assert sdf_chain.sdf_forward_nograd(geo, x) is not None
             got = geo(x)
         for r, o in zip(ref, got):
@@ -237,29 +237,42 @@ def test_sdf_net_graph_free_pass_and_its_weight_cache(gpu, monkeypatch):
 
 
 def test_second_order_gathers_from_the_forwards_corners(gpu):
-    """arcn_hashgrid_fwd_corners keeps the eight gathered rows of every (sample, level); the normal's gather and the gradient of the Jacobian
-    row computed from them are the table forms bit for bit (points outside the grid included)"""
+    """arcn_hashgrid_fwd_corners (the XCD-affine gather) keeps the eight gathered rows of every (sample, level) in level-major quads; the
+    normal's gather and the gradient of the Jacobian row computed from them are the table forms bit for bit (points outside the grid
+    included), for launches on both sides of the level-major threshold, with a device-side count, and for both table geometries of config 4"""
     from arcnerf_amd.models import build_model
     from arcnerf_amd.ops import functional as F
     from arcnerf_amd.utils.cfgs_utils import load_configs
     torch.manual_seed(0)
     m = build_model(load_configs(os.path.join(ROOT, 'configs', 'neus_ngp_multivol.yaml'), [])).to(gpu)
-    emb = m.fg_model.geo_net.embed_fn
-    table = (torch.randn_like(emb.embeddings) * 0.1).contiguous()
     g = torch.Generator().manual_seed(8)
-    for n in (1, 1000, 50021):
-        lo, hi = torch.tensor(list(emb.desc.min_xyz)), torch.tensor(list(emb.desc.max_xyz))
-        x = (lo + (hi - lo) * (torch.rand(n, 3, generator=g) * 1.1 - 0.05)).to(gpu)       # 5 % beyond the box on every side
-        enc0 = F.hashgrid_fwd(x, table, emb.desc)
-        enc, corners = F.hashgrid_fwd_corners(x, table, emb.desc)
-        assert torch.equal(enc, enc0) and corners.shape == (n, emb.desc.n_levels, 8, emb.desc.n_feat)
-        jac = torch.randn(n, enc.shape[1], generator=g).to(gpu)
-        _, dx0 = F.hashgrid_bwd(x, table, jac, emb.desc, want_dtable=False, want_dxyz=True)
-        assert torch.equal(F.hashgrid_dxyz_corners(x, corners, jac, emb.desc), dx0)
-        gdx = torch.randn(n, 3, generator=g).to(gpu)
-        dd0, _, _ = F.hashgrid_bwd_bwd(x, gdx, table, jac, emb.desc, want_ddout=True, want_dtable=False, want_d2xyz=False)
-        assert torch.equal(F.hashgrid_ddout_corners(x, gdx, corners, emb.desc), dd0)
-        assert float(dx0.abs().max()) > 0 and float(dd0.abs().max()) > 0
+    for emb in (m.fg_model.geo_net.embed_fn, m.bkg_model.geo_net.embed_fn):
+        table = (torch.randn_like(emb.embeddings) * 0.1).contiguous()
+        L, Fq = int(emb.desc.n_levels), int(emb.desc.n_feat)
+        for n in (1, 1000, 50021):
+            lo, hi = torch.tensor(list(emb.desc.min_xyz)), torch.tensor(list(emb.desc.max_xyz))
+            x = (lo + (hi - lo) * (torch.rand(n, 3, generator=g) * 1.1 - 0.05)).to(gpu)       # 5 % beyond the box on every side
+            enc0 = F.hashgrid_fwd_plain(x, table, emb.desc)
+            enc, corners = F.hashgrid_fwd_corners(x, table, emb.desc)
+            assert torch.equal(enc, enc0) and corners.shape == (L, 2 * Fq, n, 4)
+            jac = torch.randn(n, enc.shape[1], generator=g).to(gpu)
+            _, dx0 = F.hashgrid_bwd(x, table, jac, emb.desc, want_dtable=False, want_dxyz=True)
+            assert torch.equal(F.hashgrid_dxyz_corners(x, corners, jac, emb.desc), dx0)
+            gdx = torch.randn(n, 3, generator=g).to(gpu)
+            dd0, _, _ = F.hashgrid_bwd_bwd(x, gdx, table, jac, emb.desc, want_ddout=True, want_dtable=False, want_d2xyz=False)
+            assert torch.equal(F.hashgrid_ddout_corners(x, gdx, corners, emb.desc), dd0)
+            assert float(dx0.abs().max()) > 0 and float(dd0.abs().max()) > 0
+            # the quads hold the table's rows: rebuilt from the debug indices of the plain kernel
+            _, idx = F.hashgrid_fwd(x, table, emb.desc, want_idx=True)
+            rows = table.view(-1, Fq)[idx.clamp(min=0).long()] * (idx >= 0).unsqueeze(-1)          # (n, L, 8, F)
+            assert torch.equal(corners.permute(2, 0, 1, 3).reshape(n, L, 8, Fq), rows)
+            # a device-side count: the rows behind it stay untouched
+            k = max(1, n // 3)
+            n_dev = torch.tensor([k], dtype=torch.int32, device=gpu)
+            enc_k, corners_k = F.hashgrid_fwd_corners(x, table, emb.desc, n_dev=n_dev)
+            assert torch.equal(enc_k[:k], enc0[:k]) and torch.equal(corners_k[:, :, :k], corners[:, :, :k])
+            assert torch.equal(F.hashgrid_dxyz_corners(x, corners, jac, emb.desc, n_dev=n_dev)[:k], dx0[:k])
+            assert torch.equal(F.hashgrid_ddout_corners(x, gdx, corners, emb.desc, n_dev=n_dev)[:k], dd0[:k])
 
 
 def test_fused_adam_step_in_two_halves(gpu):

@@ -448,3 +448,23 @@ def test_fused_step_refuses_what_it_does_not_implement_and_train_epoch_draws_ahe
     assert [[b[1] for b in c[2]] for c in st.calls] == [[2, 3], [3, 4], [4], [], [6, 7], [7, 8], [8], [], []]
     # model.optimize ran for every epoch whose batch was not drawn early (where it is a no-op by the stepper's word)
     assert mdl.optimized == [500, 504, 508]
+
+
+def test_fused_adam_state_dict_refuses_stale_sharded_moments():
+    """Under distributed.ShardedGradSync a rank's Adam moments are current for its own shard only: state_dict() must not hand out a state
+    whose other shards are stale - it asks for the collective gather first (FusedAdam.gather_sharded_state on every rank)."""
+    import pytest
+    import torch
+    from arcnerf_amd import distributed as D
+    from arcnerf_amd.optim import FusedAdam
+    p = torch.nn.Parameter(torch.zeros(8))
+    opt = FusedAdam([p], lr=1e-3)
+    sync = D.ShardedGradSync(8, world=2, rank=0)
+    opt.shard_sync = sync
+    assert 'state' in opt.state_dict()              # nothing stepped yet: current
+    sync.launch(torch.zeros(8))                      # (no process group: no collective is issued; the step marks the moments as sharded)
+    assert not sync.moments_current
+    with pytest.raises(RuntimeError, match='gather_sharded_state'):
+        opt.state_dict()
+    sync.gather_moments(torch.zeros(8), torch.zeros(8))
+    assert sync.moments_current and 'state' in opt.state_dict()
