@@ -1129,7 +1129,7 @@ def gemm_tn(dy, x, mask=None, want_colsum=False, mask_bits=None, out=None, db_ou
     nf = max(1, int(N.lib().arcn_gemm_tn_scratch_floats(S, Nn, K)))
     scratch = torch.empty(nf, dtype=torch.float32, device=dy.device)
     mptr = None if mask is None else mask.data_ptr()
-    split = _GEMM_SPLIT and (Nn > 64 or K > 64) and Nn % 4 == 0 and K % 4 == 0 and _aligned_rows(dy, ld) and _aligned_rows(x, ld_x)
+    split = (Nn > 64 or K > 64) and Nn % 4 == 0 and K % 4 == 0 and _aligned_rows(dy, ld) and _aligned_rows(x, ld_x)
     if split:
         db = (torch.empty(Nn, dtype=torch.float32, device=dy.device) if db_out is None else db_out) if want_colsum else None
         N.check(N.lib().arcn_gemm_tn_split(dy.data_ptr(), mptr, N.ptr(mask_bits), ld, x.data_ptr(), ld_x, N.ptr(dw), N.ptr(db), N.ptr(scratch), nf, S,

@@ -77,6 +77,7 @@ class FusedNgpStep:
         self._np_total = self._host_total.numpy()
         self._slot = 0
         self.steps = 0
+        self.samples_total = 0
         self.max_rays = max_rays        # ray capacity of the buffers (default: the model's chunk_rays, else 32768; grows with the batches)
         if self.max_rays is None:
             self.max_rays = int(self.fg.chunk_rays) if getattr(self.fg, 'chunk_rays', None) and self.fg.chunk_rays > 0 else 32768
@@ -181,6 +182,7 @@ class FusedNgpStep:
                 torch.cuda.current_stream().synchronize()
                 need = int(self._np_total[slot])
             self._pending.pop(0)
+            self.samples_total += min(need, cap)
             self.fg._samples_per_ray = need / max(1, rays)
             if need >= cap:
                 # (the compositor never renders a ray from a truncated sample set: the rays behind the fill point took no part in that
@@ -201,6 +203,14 @@ class FusedNgpStep:
         # ray), shrink when an eighth would do (the all-ones bitfield of a fresh model against the pruned one a few hundred steps later)
         full = n_rays * pipe.cfg.n_sample
         return min(1.25 * rate * n_rays, full) > pipe.cap or 8 * self._target_cap(rate, n_rays, pipe.max_rays) <= pipe.cap
+
+    def drain(self):
+        """wait for the steps issued so far and take their sample totals in: -> samples_total, the valid samples (mask_pts.sum() of the
+        reference's metric) of every fused step since construction"""
+        torch.cuda.synchronize()
+        if self.pipe is not None:
+            self._check_capacity(1)
+        return self.samples_total
 
     def _target_cap(self, rate, n_rays, max_rays):
         full = n_rays * self.fg.get_n_coarse_sample()

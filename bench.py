@@ -466,6 +466,91 @@ def bench_module(args, name, emit=True):
     return out
 
 
+def dist1_leg(sync, steps, warmup):
+    """The N > 1 code path at its single-GPU price: the headline command re-run in a child with a ONE-rank RCCL communicator (ARCN_DIST_FORCE=1) -
+    scatter -> collective on the 48.8 MB flat gradient -> optimiser pass, instead of the optimiser fused into the scatter's consumer.  The only
+    multi-GPU number a one-GPU box can give (common/trainer/basic_trainer.py:192-198 wraps the model in DDP: this is that step's per-GPU cost)."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.update({'ARCN_DIST_FORCE': '1', 'ARCN_GRAD_SYNC': sync, 'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '1', 'MASTER_ADDR': '127.0.0.1',
+                'MASTER_PORT': str(port), 'HSA_ENABLE_IPC_MODE_LEGACY': env.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')})
+    cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(steps), '--warmup', str(warmup), '--no-cpu-baseline', '--no-other-configs', '--no-psnr']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    if r.returncode != 0 or not line:
+        return {'error': 'rc {}: {}'.format(r.returncode, r.stderr[-400:])}
+    j = json.loads(line[-1])
+    rc = j.get('rccl') or {}
+    return {'ms_per_step': j['ms_per_step'], 'ms_per_step_p50': j['step_ms_spread']['p50'], 'samples_per_s': j['value'], 'steps': steps, 'warmup': warmup,
+            'grad_sync': rc.get('grad_sync'), 'backend': rc.get('backend'), 'world_size_seen': rc.get('world_size_seen'),
+            'exposed_ms': rc.get('exposed_ms'), 'exposed_ms_max': rc.get('exposed_ms_max'), 'allreduce_alone_ms': rc.get('allreduce_alone_ms'),
+            'allreduce_bytes_per_step': rc.get('allreduce_bytes_per_step'),
+            'workload': 'the headline step through the N > 1 path on a one-rank RCCL communicator (ARCN_DIST_FORCE=1, ARCN_GRAD_SYNC={})'.format(sync)}
+
+
+def inference_leg(dev, occupancy, images=4):
+    """Inference / eval of the path (arcnerf/eval/infer_func.py:355-446, arcnerf_trainer.py:363): one 800 x 800 view = 640 000 rays through
+    the drop-in module, model(inputs, inference_only=True) in eval mode - FullModel chunks them by the yaml's chunk_rays - on the same 5 %
+    occupancy as the headline.  Rays from get_rays (on the GPU) are part of the timed image."""
+    import math
+    from arcnerf_amd.models import build_model
+    from arcnerf_amd.pipeline import synthetic_bitfield
+    from arcnerf_amd.render.ray_helper import get_rays
+    from arcnerf_amd.utils.cfgs_utils import load_configs
+    torch.manual_seed(0)
+    m = build_model(load_configs(os.path.join(ROOT, 'configs', 'nerf_ngp.yaml'), ['--model.rays.white_bkg', 'True', '--model.obj_bound.bkg_color', '[1.0,1.0,1.0]'])).to(dev)
+    fg = m.fg_model
+    fg.obj_bound.volume.update_bitfield(torch.from_numpy(synthetic_bitfield(128, occupancy, seed=0)).to(dev), ops='overwrite')
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if 'embeddings' in n_:
+                p_.mul_(3000.0)     # a table with features of order 0.3 instead of the 1e-4 init: densities that vary over the volume
+    m.eval()
+    HW = 800
+    focal = 0.5 * HW / math.tan(0.5 * 0.6911)
+    K = torch.tensor([[focal, 0, HW / 2], [0, focal, HW / 2], [0, 0, 1.0]], device=dev)
+
+    def cam(v):
+        gg = torch.Generator(device='cpu').manual_seed(100 + v)
+        c = torch.randn(3, generator=gg)
+        c = c / c.norm() * (3.0 / 1.05)
+        fwd = -c / c.norm()
+        right = torch.linalg.cross(fwd, torch.tensor([0.0, 0.0, 1.0]))
+        right = right / right.norm()
+        up = torch.linalg.cross(right, fwd)
+        c2w = torch.eye(4)
+        c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, -up, fwd, c
+        return c2w.to(dev)
+    cams = [cam(v) for v in range(images)]
+
+    @torch.no_grad()
+    def render(c2w):
+        o, d, _, r = get_rays(HW, HW, K, c2w, wh_order=False, center_pixel=True)
+        return m({'rays_o': o[None], 'rays_d': d[None], 'rays_r': r[None]}, inference_only=True)
+
+    fg.reset_measurement() if hasattr(fg, 'reset_measurement') else None
+    out = render(cams[0])
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(images + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for v in range(images):
+        out = render(cams[v])
+        ev[v + 1].record()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / images
+    dev_ms = sorted(a.elapsed_time(b) for a, b in zip(ev[:-1], ev[1:]))
+    return {'ms_per_image': dt * 1e3, 'ms_per_image_device_p50': dev_ms[len(dev_ms) // 2], 'rays_per_s': HW * HW / dt, 'images': images, 'rays_per_image': HW * HW,
+            'finite': bool(torch.isfinite(out['rgb']).all()), 'keys': sorted(k for k in out.keys() if not k.startswith('progress'))[:8],
+            'workload': 'one 800 x 800 view (640 000 rays: get_rays + FullModel.forward(inference_only=True), chunk_rays 32768) of build_model(nerf_ngp.yaml) in '
+                        'eval mode, occupancy {:.0%}, white background'.format(occupancy)}
+
+
 def cpu_baseline_nerf(rays_all=4096):
     """BASELINE.md section 3 for config 1: (a) the PyTorch-CPU-eager restatement of the reference modules (oracle/torch_cpu_nerf.py, the
     stand-in for scripts/cpu.sh) on all host cores and on one; bounded samples."""
@@ -806,6 +891,21 @@ def main():
             except Exception as e:      # never lose the headline line to a side leg
                 others[name] = {'error': repr(e)}
             torch.cuda.empty_cache()
+        try:
+            others['inference'] = inference_leg(dev, args.occupancy)
+        except Exception as e:
+            others['inference'] = {'error': repr(e)}
+        torch.cuda.empty_cache()
+        # the N > 1 step at world 1 (children of this process, after everything timed here): `flat` = north_star's single all-reduce, `sharded` =
+        # reduce-scatter + 1/N optimiser + all-gather; 'delta_ms_to_fused_step' = what the exchange-shaped step costs a GPU before any wire time
+        for sync in ('flat', 'sharded'):
+            try:
+                leg = dist1_leg(sync, args.steps, args.warmup)
+                if 'ms_per_step' in leg:
+                    leg['delta_ms_to_fused_step'] = leg['ms_per_step'] - wall / args.steps * 1e3
+                others['ngp_dist1_' + sync] = leg
+            except Exception as e:
+                others['ngp_dist1_' + sync] = {'error': repr(e)}
 
     # PSNR@iter, the second half of BASELINE's metric, with the reference's RECIPE through the drop-in API (tools/psnr_recipe.py): no dataset
     # on the box, so the scene is analytic - six soft textured blobs rendered once to 100 training views of 320 x 320 RGBA bytes + 4 held
@@ -822,13 +922,18 @@ def main():
             spec.loader.exec_module(pc)
             timers.reset(())
             torch.cuda.empty_cache()
-            r = pc.run(2000, seed=0, verbose=False)
-            psnr = {'scene': r['scene'] + ' (analytic: there is no dataset on the box)', 'recipe': r['recipe'], 'path': r['path'], 'seed': 0,
+            r = pc.run(3000, seed=0, verbose=False, window=(2488, 2988))
+            psnr = {'metric': 'PSNR@iter, scene: analytic (NOT Lego - there is no dataset on the box; not comparable with docs/benchmark.md:50-54)',
+                    'scene': r['scene'] + ' (analytic: there is no dataset on the box)', 'recipe': r['recipe'], 'path': r['path'], 'seed': 0,
                     'psnr_at_iter': {str(p_['iter']): round(p_['psnr'], 2) for p_ in r['points']},
                     'train_seconds_at_iter': {str(p_['iter']): round(p_['train_seconds'], 2) for p_ in r['points']},
                     'rays_per_step_at_iter': {str(p_['iter']): p_['rays_per_step'] for p_ in r['points']},
                     'occupied_at_iter': {str(p_['iter']): round(p_['occupied'], 4) for p_ in r['points']},
                     'data_seconds': round(r['data_seconds'], 2),
+                    # the same loop, iterations 2488 - 2988, between two device synchronisations: every refresh of the occupancy grid APPLIED, a fresh
+                    # shuffled batch against the scene's pixels every step, dynamic batch size - the headline's timed loop computes its refreshes
+                    # without applying them (a random-init field has no stationary occupancy) and cycles eight ray batches against random targets
+                    'training_loop': r.get('training_loop'),
                     'anchor': 'golden G27 (tests/golden/make_golden_psnr.py): the reference\'s own loop + Pipeline, 600 iterations x 4 seeds on 100 x 100 views reach '
                               '33.6 - 34.3 dB; the module path reproduces every seed to 0.02 - 0.5 dB at 50 / 100 / 200 / 400 / 600 iterations, this '
                               'stepper stays inside the seed band (tests/test_gpu_psnr.py); profiles/r5_psnr_recipe.json: three seeds of this leg'}

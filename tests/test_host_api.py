@@ -468,3 +468,16 @@ def test_fused_adam_state_dict_refuses_stale_sharded_moments():
         opt.state_dict()
     sync.gather_moments(torch.zeros(8), torch.zeros(8))
     assert sync.moments_current and 'state' in opt.state_dict()
+
+
+def test_no_name_in_the_package_is_read_without_being_bound_anywhere():
+    """A removed module-level switch must not leave a reader behind (a NameError that only the GPU suite would meet):
+    tools/check_undefined_names.py walks every module of the package, the bench and the entry points."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_undefined_names.py'), os.path.join(root, 'arcnerf_amd'),
+                          os.path.join(root, 'bench.py'), os.path.join(root, '__graft_entry__.py'), os.path.join(root, 'oracle')],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == '', out.stdout + out.stderr

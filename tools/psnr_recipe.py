@@ -112,7 +112,9 @@ def build_image_scene(dev=None):
     return sc
 
 
-def run(max_it=2000, seed=0, verbose=False, stepper='fused', report=(100, 500, 2000, 10000, 30000, 50000)):
+def run(max_it=2000, seed=0, verbose=False, stepper='fused', report=(100, 500, 2000, 10000, 30000, 50000), window=None):
+    """window = (first, last): those iterations of THIS loop (applied occupancy refreshes, fresh shuffled batches against the scene's pixels,
+    dynamic batch size) are timed between two device synchronisations and their valid samples counted: -> 'training_loop'"""
     sc = build_image_scene()
     dev = sc['rgba'].device
     from arcnerf_amd.ops.volume_func import sampler_rng
@@ -148,9 +150,22 @@ def run(max_it=2000, seed=0, verbose=False, stepper='fused', report=(100, 500, 2
     base_lr = 1e-1
     points, t_train, samples = [], 0.0, 0
     t_last = time.perf_counter()
+    win = None
     for epoch in range(max_it):
+        if window is not None and step is not None and epoch == window[0]:
+            s_before = step.drain()
+            win = {'t0': time.perf_counter(), 'rays0': pipe.get_info('n_rays')}
         opt.param_groups[0]['lr'] = base_lr * (0.33 ** sum(1 for s in (20000, 30000, 40000, 50000) if epoch >= s))      # MultiStepLR of the yaml
         T.train_epoch(m, batches, loss_factory, opt, ema, pipe, epoch, total_epoch=max_it, stepper=step)
+        if win is not None and 't1' not in win and epoch + 1 == window[1]:
+            s_after = step.drain()
+            win['t1'] = time.perf_counter()
+            n_it = window[1] - window[0]
+            every = fg.obj_bound.get_optim_cfgs('epoch_optim')
+            win = {'iterations': [window[0], window[1]], 'ms_per_step': (win['t1'] - win['t0']) * 1e3 / n_it, 'samples_per_step': (s_after - s_before) / n_it,
+                   'samples_per_s': (s_after - s_before) / (win['t1'] - win['t0']), 'rays_per_step': [win['rays0'], pipe.get_info('n_rays')],
+                   'occupancy_refreshes_applied': len([e for e in range(window[0], window[1]) if every and e > 0 and e % every == 0]),
+                   'occupied': float(fg.obj_bound.volume.get_voxel_bitfield().float().mean()), 't1': win['t1']}
         if (epoch + 1) in report or epoch + 1 == max_it:
             torch.cuda.synchronize()
             t_train += time.perf_counter() - t_last
@@ -164,6 +179,7 @@ def run(max_it=2000, seed=0, verbose=False, stepper='fused', report=(100, 500, 2
             'recipe': 'nerf_lego_nerf_ngp.yaml: precrop 0.5 / 500, random bkg colour, cross-view shuffle, dynamic batch size 16 from 4096 rays, Adam 1e-1 + EMA 0.95',
             'path': 'build_model(nerf_ngp.yaml) + trainer.train_epoch + trainer.TrainBatches + ' + ('trainer.FusedNgpStep' if step is not None else 'trainer.step_optimize'),
             'seed': int(seed), 'data_seconds': sc['seconds'], 'pixels_covered': sc['covered'], 'points': points,
+            'training_loop': {k: v for k, v in win.items() if k != 't1'} if win is not None and 't1' in win else None,
             'fused_steps': step.steps if step is not None else 0, 'buffer_rebuilds': step.rebuilds if step is not None else 0}
 
 
