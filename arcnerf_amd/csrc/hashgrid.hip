@@ -821,15 +821,28 @@ __device__ __forceinline__ void sum_cell_runs(float (&va)[8], float (&vb)[8], bo
     }
 }
 
-template <int F, int kBinThreads>
+// PLAN = true (arcn_hashgrid_bwd_plan): the half of this kernel that depends on the sample POSITIONS only - cells, run structure, rows, bins,
+// ranks - run ahead of the step on the sampling stream (the samples of step i are marched two steps earlier).  It writes the index half
+// {i0 | i1 << 16, wx} of every record to its final slot (ridx) and, per (level, sample), the slots its value halves belong to
+// (pos4: two uint4 per sample, global record indices; kPosNone = no record, kPosOvf = the bin was full: scatter_fill_kernel applies that one to
+// dtable directly).  What is left between the geometry net's backward and the chunk owners is scatter_fill_kernel: a streaming pass
+// without barriers, histograms, atomics or the 64-bit modulo of the dense levels.
+constexpr uint32_t kPosNone = 0xffffffffu, kPosOvf = 0xfffffffeu;
+constexpr uint32_t kLposNone = 0xffffu, kLposOvf = 0xfffeu;     // 16-bit tile-local positions (< kTileSlots)
+constexpr int kTileSlots = 8192;                                // records of one 1024-sample tile of one level: at most 8 per sample
+
+template <int F, int kBinThreads, bool PLAN = false>
 __global__ void __launch_bounds__(kBinThreads)
 scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout, int64_t dout_lm_stride, GridParams g,
                    BinPlan plan, uint32_t *__restrict__ counters, uint4 *__restrict__ recs, float *__restrict__ dtable, int64_t n,
-                   const int32_t *n_ptr) {
+                   const int32_t *n_ptr, uint2 *__restrict__ ridx = nullptr, uint4 *__restrict__ pos4 = nullptr, int64_t pos_stride = 0,
+                   uint32_t *__restrict__ gslot = nullptr, uint32_t *__restrict__ tile_count = nullptr, int64_t n_tiles = 0) {
     // hist: records of this tile per bin; gbase: first position of the tile's run in every bin.  Both double-buffered over the
     // tiles: the other buffer's histogram is cleared while this tile reserves its runs, so a tile costs two barriers, not four.
     __shared__ uint32_t hist2[2][kMaxChunks];
     __shared__ uint32_t gbase2[2][kMaxChunks];
+    __shared__ uint32_t lbase2[PLAN ? 2 : 1][PLAN ? kMaxChunks : 1];      // PLAN: first tile-local position of every bin (exclusive scan of the tile's histogram)
+    __shared__ uint32_t wsum[16];
     const int64_t cnt = dev_count(n, n_ptr);
     const int l = blockIdx.y;
     if (!((plan.active_levels >> l) & 1u)) return;
@@ -849,10 +862,12 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
         if (s < cnt) {
             np_[0] = xyz[3 * s]; np_[1] = xyz[3 * s + 1]; np_[2] = xyz[3 * s + 2];
             // level-major gradients (dout_lm_stride > 0): the lanes of a wave read consecutive 8-byte words
+            if (!PLAN) {
             const float *gp = dout_lm_stride ? dout + ((int64_t)l * dout_lm_stride + s) * F : dout + (s * g.L + l) * F;
             // (non-temporal: this is the gradient's only reader - step -1.9 % in three alternations, profiles/r4_ab_nontemporal.txt)
             ng0 = __builtin_nontemporal_load(gp);
             ng1 = F > 1 ? __builtin_nontemporal_load(gp + (F > 1 ? 1 : 0)) : 0.f;
+            }
         }
     };
     fetch((int64_t)blockIdx.x * kBinThreads + t);
@@ -867,7 +882,7 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
     const float p[3] = {np_[0], np_[1], np_[2]};
     const Cell cell = locate_fastcell(p, g, lp, s < cnt);
     const float g0 = cell.valid ? ng0 : 0.f, g1 = cell.valid ? ng1 : 0.f;
-    if (plan.det) {
+    if (!PLAN && plan.det) {
         // the fixed-point scale of the consumer comes from the largest |gradient| of the launch: a max is order-independent
         float m = fmaxf(fabsf(g0), fabsf(g1));
         if (!(m == m)) m = 0.f;
@@ -951,7 +966,7 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
             va[q] = g0 * wt;
             vb[q] = g1 * wt;
         }
-        sum_cell_runs<F>(va, vb, head, true_head, lane);
+        if (!PLAN) sum_cell_runs<F>(va, vb, head, true_head, lane);
         if (true_head && cell.valid) {
             uint32_t rows[8];
             corner_rows(cell.c, lp, plan.lowbits[l], rows);
@@ -972,13 +987,59 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
     __syncthreads();
     // reserve the tile's run in every bin: one global integer atomic per (bin, tile); clear the NEXT tile's histogram
     fetch(tile0 + (int64_t)gridDim.x * kBinThreads + t);
+    uint32_t my_hist = 0u;
     for (int i = threadIdx.x; i < nc; i += kBinThreads) {
         const uint32_t h = hist[i];
+        my_hist = h;
         gbase[i] = h ? atomicAdd(&counters[plan.bin_first[l] + i], h) : 0u;
         hist2[buf ^ 1][i] = 0u;
     }
+    if (PLAN) {
+        // tile-local positions: the tile's records sorted by bin (nc <= kBinThreads: thread i holds bin i).  The fill pass stages its values in
+        // LDS in this order and copies them out as whole lines - a (bin, tile) run is contiguous in the tile AND in its bin.
+        uint32_t inc = my_hist;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (nc > 64) {      // (workgroup uniform)
+            if (lane == 63) wsum[t >> 6] = inc;
+            __syncthreads();
+            uint32_t off = 0u;
+            for (int w = 0; w < (t >> 6); ++w) off += wsum[w];
+            inc += off;
+        }
+        if (t < nc) lbase2[buf][t] = inc - my_hist;
+        if (t == nc - 1) tile_count[(int64_t)l * n_tiles + tile0 / kBinThreads] = inc;
+    }
     __syncthreads();
     const uint32_t cap = (uint32_t)plan.cap[l];
+    if (PLAN) {
+        uint32_t P[8];
+        uint32_t *gs = gslot + ((int64_t)l * n_tiles + tile0 / kBinThreads) * kTileSlots;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            P[k] = kLposNone;
+            if (k >= n_slots || sbin[k] < 0) continue;
+            const uint32_t pos = gbase[sbin[k]] + rank[k];
+            const uint32_t lpos = lbase2[buf][sbin[k]] + rank[k];
+            if (pos < cap) {
+                const int64_t gi = plan.rec_first[l] + (int64_t)sbin[k] * cap + pos;
+                ridx[gi] = make_uint2(sidx[k], __float_as_uint(swx[k]));
+                gs[lpos] = (uint32_t)gi;
+                P[k] = lpos;
+            } else {
+                gs[lpos] = kPosNone;      // (its place in the tile stays empty: the fill pass applies this one to dtable itself)
+                P[k] = kLposOvf;
+                counters[plan.aux_first + 1] = 1u;
+            }
+        }
+        // (lanes without records of their own - invalid samples, the followers of a summed run - write nothing: the fill pass decides from the
+        // same cells which lanes read)
+        if (cell.valid && (!reduce || true_head))
+            pos4[(int64_t)l * pos_stride + s] = make_uint4(P[0] | (P[1] << 16), P[2] | (P[3] << 16), P[4] | (P[5] << 16), P[6] | (P[7] << 16));
+    } else {
     uint4 *lrecs = recs + plan.rec_first[l];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -986,8 +1047,176 @@ scatter_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ dout
         const uint4 rec = make_uint4(sidx[k], __float_as_uint(swx[k]), __float_as_uint(sa[k]), __float_as_uint(sb[k]));
         emit_record<F>(lrecs, dtable, lp, sbin[k], gbase[sbin[k]] + rank[k], cap, shift, rec, &counters[plan.aux_first + 1]);
     }
+    }
     // no barrier here: the next tile counts into the other histogram and reserves into the other gbase; this tile's gbase is
     // overwritten two tiles later, behind two more barriers
+    }
+}
+
+// The value half of the planned scatter (see scatter_bin_kernel<.., PLAN = true>): one lane per (level, sample) again, the SAME waves of 64
+// consecutive samples - so every wave re-derives the plan's decisions (valid, run heads, `reduce`) from the same cells - and the gradient
+// times the weights goes to the slots the plan reserved: vals[slot] = {a0, a1}.  Runs are summed exactly as the one-pass producer sums them
+// (sum_cell_runs).  A slot the plan marked kPosOvf (its bin was full) is applied to dtable directly, with the rows recomputed here.
+template <int F>
+// (every argument BY VALUE: a reference to the caller's Cell or LevelParams pins that object in scratch memory for the whole kernel - ten scratch
+// stores per lane and tile, 170 MB of extra HBM writes per launch, the fill pass at 150 us instead of 106)
+__device__ __noinline__ void fill_overflow(float *dtable, uint32_t lv_mask, uint32_t lv_size, double lv_inv_size, int64_t lv_offset, int lowbits,
+                                           uint32_t c0, uint32_t c1, uint32_t c2, float w0, int path, int k, float a0, float a1) {
+    LevelParams lp;
+    lp.mask = lv_mask; lp.size = lv_size; lp.inv_size = lv_inv_size; lp.offset = lv_offset; lp.res = 0; lp.pad = 0;
+    Cell cell;
+    cell.c[0] = c0; cell.c[1] = c1; cell.c[2] = c2; cell.w[0] = w0; cell.valid = true;
+    if (path == 0) {            // hashed level, pair record pr = k
+        const uint32_t hy = (cell.c[1] + (uint32_t)(k & 1)) * 2654435761u, hz = (cell.c[2] + (uint32_t)(k >> 1)) * 805459861u;
+        const uint32_t hyz = hy ^ hz;
+        const uint32_t r0 = (cell.c[0] ^ hyz) & lp.mask, r1 = ((cell.c[0] + 1u) ^ hyz) & lp.mask;
+        const float wx = cell.w[0], wl = 1.0f - wx;
+        overflow_add<F>(dtable, lp, r0, a0 * wl, a1 * wl);
+        overflow_add<F>(dtable, lp, r1, a0 * wx, a1 * wx);
+        return;
+    }
+    uint32_t rows[8];
+    corner_rows(cell.c, lp, lowbits, rows);
+    if (path == 3) {            // a run's single-row record of corner q = k
+        overflow_add<F>(dtable, lp, rows[k], a0, a1);
+    } else {                    // general path, slot 2 pr (+ 1): path 1 = an unsplit pair, path 2 = one row of a split pair
+        const int pr = k >> 1;
+        const uint32_t oy = pr & 1, oz = pr >> 1;
+        const uint32_t r0 = rows[oy + (oz << 2)], r1 = rows[2 + oy + (oz << 2)];
+        if (path == 1) {
+            const float wx = cell.w[0], wl = 1.0f - wx;
+            overflow_add<F>(dtable, lp, r0, a0 * wl, a1 * wl);
+            overflow_add<F>(dtable, lp, r1, a0 * wx, a1 * wx);
+        } else {
+            overflow_add<F>(dtable, lp, (k & 1) ? r1 : r0, a0, a1);
+        }
+    }
+}
+
+constexpr int kFillThreads = 1024;
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+template <int F>
+__global__ void __launch_bounds__(kFillThreads)
+scatter_fill_kernel(const float *__restrict__ xyz, const float *__restrict__ dout, int64_t dout_lm_stride, GridParams g, BinPlan plan,
+                    const uint4 *__restrict__ pos4, int64_t pos_stride, const uint32_t *__restrict__ gslot, const uint32_t *__restrict__ tile_count,
+                    int64_t n_tiles, float2 *__restrict__ vals, uint32_t *__restrict__ counters, float *__restrict__ dtable, int64_t n,
+                    const int32_t *n_ptr) {
+    // Scattered stores are what the one-pass producer and the first form of this pass both cost: ~10 M 8- or 16-byte stores to as many
+    // different lines are ~65 us of L2 write requests whatever is computed around them (this pass without its stores: 38 us; measured,
+    // DESIGN.md).  So the values of a tile are staged in LDS at the tile-local positions the plan assigned - the tile's records sorted by bin -
+    // and copied out by consecutive lanes: a (bin, tile) run is contiguous in both orders, a store instruction then covers a few whole lines.
+    extern __shared__ __attribute__((aligned(16))) f2v stage[];      // 2 x kTileSlots
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int l = blockIdx.y;
+    if (!((plan.active_levels >> l) & 1u)) return;
+    const LevelParams lp = g.lv[l];
+    const int lane = threadIdx.x & 63;
+    const bool nosplit = (plan.nosplit_levels >> l) & 1u;
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));      // (HIP's uint4 struct, assigned under a condition inside a lambda, stayed in scratch memory)
+    float np_[3] = {0.f, 0.f, 0.f}, ng0 = 0.f, ng1 = 0.f;
+    u4v nP = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    uint32_t n_rec_next = 0u;
+    const int64_t stride = (int64_t)gridDim.x * kFillThreads;
+    auto fetch = [&](int64_t t0) {       // inputs, slots and record count of the tile at t0, one trip ahead
+        const int64_t sn = t0 + threadIdx.x;
+        if (t0 < cnt) n_rec_next = tile_count[(int64_t)l * n_tiles + t0 / kFillThreads];
+        if (sn < cnt) {
+            np_[0] = xyz[3 * sn]; np_[1] = xyz[3 * sn + 1]; np_[2] = xyz[3 * sn + 2];
+            const float *gp = dout_lm_stride ? dout + ((int64_t)l * dout_lm_stride + sn) * F : dout + (sn * g.L + l) * F;
+            ng0 = __builtin_nontemporal_load(gp);
+            ng1 = F > 1 ? __builtin_nontemporal_load(gp + (F > 1 ? 1 : 0)) : 0.f;
+            nP = reinterpret_cast<const u4v *>(pos4)[(int64_t)l * pos_stride + sn];
+        }
+    };
+    int buf = 0;
+    fetch((int64_t)blockIdx.x * kFillThreads);
+    for (int64_t tile0 = (int64_t)blockIdx.x * kFillThreads; tile0 < cnt; tile0 += stride, buf ^= 1) {
+        const int64_t s = tile0 + threadIdx.x;
+        const float p[3] = {np_[0], np_[1], np_[2]};
+        float g0 = ng0, g1 = ng1;
+        const u4v Pw = nP;
+        const uint32_t n_rec = n_rec_next;
+        // the global slots of the tile's records, in tile order: consecutive lanes, consecutive words (needed behind the barrier)
+        const uint32_t *gs = gslot + ((int64_t)l * n_tiles + tile0 / kFillThreads) * kTileSlots;
+        uint32_t G[kTileSlots / kFillThreads];
+#pragma unroll
+        for (int j = 0; j < kTileSlots / kFillThreads; ++j) {
+            const uint32_t i = threadIdx.x + j * kFillThreads;
+            G[j] = i < n_rec ? gs[i] : kPosNone;
+        }
+        fetch(tile0 + stride);
+        f2v *st = stage + buf * kTileSlots;
+        const Cell cell = locate_fastcell(p, g, lp, s < cnt);
+        if (!cell.valid) { g0 = 0.f; g1 = 0.f; }
+        if (plan.det) {
+            float m = fmaxf(fabsf(g0), fabsf(g1));
+            if (!(m == m)) m = 0.f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            if (lane == 0 && m > 0.f) atomicMax(&counters[plan.aux_first], __float_as_uint(m));
+        }
+        const uint32_t kxy = cell.valid ? (cell.c[0] | (cell.c[1] << 16)) : 0xffffffffu;
+        const uint32_t kz = cell.valid ? cell.c[2] : (uint32_t)lane;
+        const uint32_t pxy = (uint32_t)dpp_take_i<0x138>(-1, (int)kxy), pz = (uint32_t)dpp_take_i<0x138>(-1, (int)kz);
+        const bool true_head = lane == 0 || kxy != pxy || kz != pz;
+        const bool head = true_head || (lane & 15) == 0;
+        const uint64_t heads = __ballot(true_head && cell.valid), valid = __ballot(cell.valid);
+        const bool reduce = 3 * __popcll(heads) <= 2 * __popcll(valid);
+        const uint32_t Ps[8] = {Pw.x & 0xffffu, Pw.x >> 16, Pw.y & 0xffffu, Pw.y >> 16, Pw.z & 0xffffu, Pw.z >> 16, Pw.w & 0xffffu, Pw.w >> 16};
+        auto put = [&](uint32_t lpos, float a0, float a1, int path, int k) {
+            if (lpos < kLposOvf) st[lpos] = f2v{a0, a1};
+            else if (lpos == kLposOvf) fill_overflow<F>(dtable, lp.mask, lp.size, lp.inv_size, lp.offset, plan.lowbits[l], cell.c[0], cell.c[1], cell.c[2], cell.w[0], path, k, a0, a1);
+        };
+        if (!reduce && nosplit) {
+            if (cell.valid) {
+                const float wy1 = cell.w[1], wy0 = 1.0f - wy1, wz1 = cell.w[2], wz0 = 1.0f - wz1;
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const float wyz = ((pr & 1) ? wy1 : wy0) * ((pr >> 1) ? wz1 : wz0);
+                    put(Ps[pr], g0 * wyz, g1 * wyz, 0, pr);
+                }
+            }
+        } else if (!reduce) {
+            if (cell.valid) {
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const uint32_t oy = pr & 1, oz = pr >> 1;
+                    const float wyz = (oy ? cell.w[1] : 1.0f - cell.w[1]) * (oz ? cell.w[2] : 1.0f - cell.w[2]);
+                    const float a0 = g0 * wyz, a1 = g1 * wyz;
+                    if (Ps[2 * pr + 1] == kLposNone) {
+                        put(Ps[2 * pr], a0, a1, 1, 2 * pr);
+                    } else {
+                        const float wl = 1.0f - cell.w[0];
+                        put(Ps[2 * pr], a0 * wl, a1 * wl, 2, 2 * pr);
+                        put(Ps[2 * pr + 1], a0 * cell.w[0], a1 * cell.w[0], 2, 2 * pr + 1);
+                    }
+                }
+            }
+        } else {
+            float va[8], vb[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t ox = (q >> 1) & 1, oy = q & 1, oz = q >> 2;
+                float wt = 0.f;
+                if (cell.valid) wt = ((ox ? cell.w[0] : 1.0f - cell.w[0]) * (oy ? cell.w[1] : 1.0f - cell.w[1])) * (oz ? cell.w[2] : 1.0f - cell.w[2]);
+                va[q] = g0 * wt;
+                vb[q] = g1 * wt;
+            }
+            sum_cell_runs<F>(va, vb, head, true_head, lane);
+            if (true_head && cell.valid) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) put(Ps[q], va[q], vb[q], 3, q);
+            }
+        }
+        // ONE barrier per tile: the stage is double-buffered - the next tile writes the other half, and this half is written again two tiles on,
+        // behind the next tile's barrier, which every wave reaches only after its copy-out here
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kTileSlots / kFillThreads; ++j) {
+            const uint32_t i = threadIdx.x + j * kFillThreads;
+            if (i < n_rec && G[j] != kPosNone) *reinterpret_cast<f2v *>(vals + G[j]) = st[i];
+        }
     }
 }
 
@@ -1116,10 +1345,18 @@ struct AdamFuse {
 // filled the register file (4 waves x 96 of 512 per SIMD lane) and the second never came.  8 waves per SIMD = 64 VGPRs: the optimiser phase
 // takes one float4 per array and trip instead of four (55 VGPRs, no spill; four: 63 + 5 spilled dwords, same speed; the bound alone with four:
 // 31 spilled dwords, slower) - consumer 100 -> 91 us, scatter 0.195 -> 0.188 ms per launch, four alternations.
-template <int F>
+// SPLIT: the records of the planned scatter - index halves (ridx, written by the plan pass) and value halves (vals, by the fill pass)
+__device__ __forceinline__ uint4 ld_rec_split(const uint2 *pi, const float2 *pv) {
+    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+    const u2v a = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(pi));
+    const u2v b = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(pv));
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+
+template <int F, bool SPLIT = false>
 __global__ void __launch_bounds__(kTiledThreads, 8)
 scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict__ counters, GridParams g, BinPlan plan,
-                     float *__restrict__ dtable, AdamFuse fz) {
+                     float *__restrict__ dtable, AdamFuse fz, const uint2 *__restrict__ ridx = nullptr, const float2 *__restrict__ vals = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float acc[];
     int k = 0;
     while (k + 1 < g.L && (int)blockIdx.x >= plan.item_first[k + 1]) ++k;
@@ -1158,7 +1395,8 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
         if (k2 > 127) k2 = 127;
         if (k2 < -126) k2 = -126;
         const float scale = __uint_as_float((uint32_t)(k2 + 127) << 23);
-        const uint4 *prd = recs + plan.rec_first[l] + (int64_t)chunk * cap + lo;
+        const int64_t rbase = plan.rec_first[l] + (int64_t)chunk * cap + lo;
+        const uint4 *prd = recs + rbase;
         // four records per thread and trip, all loads issued before the first atomic (a bin is ~32 records per thread: one load in
         // flight per thread would run at memory latency)
         const uint32_t lend = hi - lo;
@@ -1166,7 +1404,9 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
         for (uint32_t i0g = threadIdx.x; i0g < lend; i0g += kTiledThreads * 4) {
             uint4 rr[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rr[u] = (i0g + u * kTiledThreads < lend) ? prd[i0g + u * kTiledThreads] : none;
+            for (int u = 0; u < 4; ++u)
+                rr[u] = (i0g + u * kTiledThreads < lend) ? (SPLIT ? ld_rec_split(ridx + rbase + i0g + u * kTiledThreads, vals + rbase + i0g + u * kTiledThreads)
+                                                                  : prd[i0g + u * kTiledThreads]) : none;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint4 r = rr[u];
@@ -1199,7 +1439,11 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
     for (int i = threadIdx.x; i < plan.chunk_floats / F / 32; i += kTiledThreads) locks[i] = 0u;
     __syncthreads();
     const bool locked = (plan.lock_levels >> l) & 1u;
-    const uint4 *pr = recs + plan.rec_first[l] + (int64_t)chunk * cap + lo;
+    const int64_t rbase = plan.rec_first[l] + (int64_t)chunk * cap + lo;
+    const uint4 *pr = recs + rbase;
+    const uint2 *pri = ridx + rbase;
+    const float2 *prv = vals + rbase;
+    auto ld = [&](uint32_t at) { return SPLIT ? ld_rec_split(pri + at, prv + at) : ld_rec(pr + at); };
     const uint32_t len = hi > lo ? hi - lo : 0u;
     // A bin is only ~32 records per thread: with one load in flight per thread the loop would be bound by memory latency.
     // Each trip takes kUnroll records per thread (the next group's loads are issued before the current group is applied).
@@ -1209,7 +1453,7 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
     uint32_t i = threadIdx.x;
     uint4 nxt[kUnroll];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) nxt[u] = (i + u * kTiledThreads < len) ? ld_rec(pr + i + u * kTiledThreads) : none;
+    for (int u = 0; u < kUnroll; ++u) nxt[u] = (i + u * kTiledThreads < len) ? ld(i + u * kTiledThreads) : none;
     for (uint32_t trip = 0; trip < trips; ++trip) {
         uint4 cur[kUnroll];
 #pragma unroll
@@ -1217,7 +1461,7 @@ scatter_accum_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict_
         i += kTiledThreads * kUnroll;
         if (trip + 1 < trips) {
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) nxt[u] = (i + u * kTiledThreads < len) ? ld_rec(pr + i + u * kTiledThreads) : none;
+            for (int u = 0; u < kUnroll; ++u) nxt[u] = (i + u * kTiledThreads < len) ? ld(i + u * kTiledThreads) : none;
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
@@ -1506,6 +1750,17 @@ static inline bool level_fusable(const GridParams &g, const BinPlan &plan, int l
 
 static inline int64_t bin_counter_floats(const BinPlan &plan) { return ((int64_t)plan.n_bins + 2 + 63) / 64 * 64; }
 
+// the plan workspace of the planned scatter (one per batch in flight): [bin counters | index halves, 8 B per record slot | tile-local positions,
+// eight 16-bit words per (level, sample) with the level stride n | global slots in tile order, kTileSlots words per (level, 1024-sample tile) |
+// records per (level, tile)]
+constexpr int kFillWgs = 32;       // persistent workgroups per level of scatter_fill_kernel, as many as the plan pass
+static inline int64_t plan_ridx_first(const BinPlan &plan) { return bin_counter_floats(plan); }
+static inline int64_t plan_pos_first(const BinPlan &plan) { return (plan_ridx_first(plan) + 2 * plan.n_recs + 3) / 4 * 4; }
+static inline int64_t plan_tiles(int64_t n) { return (n + kFillThreads - 1) / kFillThreads; }
+static inline int64_t plan_gslot_first(const BinPlan &plan, const GridParams &g, int64_t n) { return plan_pos_first(plan) + (int64_t)g.L * n * 4; }
+static inline int64_t plan_count_first(const BinPlan &plan, const GridParams &g, int64_t n) { return plan_gslot_first(plan, g, n) + (int64_t)g.L * plan_tiles(n) * kTileSlots; }
+static inline int64_t plan_ws_floats_for(const BinPlan &plan, const GridParams &g, int64_t n) { return plan_count_first(plan, g, n) + (int64_t)g.L * plan_tiles(n); }
+
 }  // namespace arcn
 
 using namespace arcn;
@@ -1531,7 +1786,8 @@ ARCN_EXPORT int64_t arcn_hashgrid_bwd_workspace_floats(const arcn_hashgrid_desc 
 static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *dout, int64_t dout_lm_stride,
                              const arcn_hashgrid_desc *desc_host, float *dtable, float *dxyz, float *workspace,
                              int64_t workspace_floats, int64_t n, const int32_t *n_ptr, void *stream, const AdamFuse *fuse = nullptr,
-                             uint32_t *fused_levels_out = nullptr, bool counters_clear = false, uint32_t level_mask = 0xffffffffu) {
+                             uint32_t *fused_levels_out = nullptr, bool counters_clear = false, uint32_t level_mask = 0xffffffffu,
+                             float *plan_ws = nullptr, int64_t plan_ws_floats = 0) {
     if (n <= 0) return ARCN_OK;
     if (!xyz || !dout || (!dtable && !dxyz) || (dxyz && !table)) return einval("hashgrid_bwd: missing argument");
     GridParams g;
@@ -1547,8 +1803,21 @@ static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *
         plan.active_levels &= level_mask;      // arcn_hashgrid_bwd_lm_levels: the workgroups of the other levels leave at once
         uint32_t *counters = reinterpret_cast<uint32_t *>(workspace);
         uint4 *recs = reinterpret_cast<uint4 *>(workspace + bin_counter_floats(plan));
+        // planned scatter (arcn_hashgrid_bwd_plan ran on these samples): the plan's counters, index halves and slots; the value halves go
+        // where the records would have gone
+        const uint2 *p_ridx = nullptr;
+        const uint4 *p_pos = nullptr;
+        const uint32_t *p_gslot = nullptr, *p_count = nullptr;
+        if (plan_ws) {
+            if (plan_ws_floats < plan_ws_floats_for(plan, g, n)) return einval("hashgrid_bwd_planned: plan workspace smaller than arcn_hashgrid_plan_workspace_floats(desc, n)");
+            counters = reinterpret_cast<uint32_t *>(plan_ws);
+            p_ridx = reinterpret_cast<const uint2 *>(plan_ws + plan_ridx_first(plan));
+            p_pos = reinterpret_cast<const uint4 *>(plan_ws + plan_pos_first(plan));
+            p_gslot = reinterpret_cast<const uint32_t *>(plan_ws + plan_gslot_first(plan, g, n));
+            p_count = reinterpret_cast<const uint32_t *>(plan_ws + plan_count_first(plan, g, n));
+        }
         // (the whole 256-byte padded block: ONE fill launch, an odd size is two; none when the caller's previous pass left it clear)
-        hipError_t e = counters_clear ? hipSuccess : hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)bin_counter_floats(plan), as_stream(stream));
+        hipError_t e = (counters_clear || plan_ws) ? hipSuccess : hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)bin_counter_floats(plan), as_stream(stream));
         if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
         const size_t lds = plan.det ? sizeof(unsigned long long) * (size_t)plan.chunk_floats
                                     : sizeof(float) * (size_t)plan.chunk_floats + sizeof(uint32_t) * (size_t)(plan.chunk_floats / 32);
@@ -1566,8 +1835,8 @@ static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *
         if (bx > wgs) bx = wgs;  // persistent workgroups per level
         dim3 bgrid((unsigned)bx, (unsigned)g.L);
         dim3 agrid((unsigned)plan.item_first[g.L]);
-#define ARCN_BIN(F_, T_) hipLaunchKernelGGL((scatter_bin_kernel<F_, T_>), bgrid, dim3(T_), 0, st_bin, xyz, dout, dout_lm_stride, g, plan, counters, recs, dtable, n, n_ptr)
-#define ARCN_ACC(F_) hipLaunchKernelGGL(scatter_accum_kernel<F_>, agrid, dim3(kTiledThreads), lds, st_acc, recs, counters, g, plan, dtable, fz)
+#define ARCN_BIN(F_, T_) hipLaunchKernelGGL((scatter_bin_kernel<F_, T_>), bgrid, dim3(T_), 0, st_bin, xyz, dout, dout_lm_stride, g, plan, counters, recs, dtable, n, n_ptr, (uint2 *)nullptr, (uint4 *)nullptr, (int64_t)0, (uint32_t *)nullptr, (uint32_t *)nullptr, (int64_t)0)
+#define ARCN_ACC(F_) hipLaunchKernelGGL(scatter_accum_kernel<F_>, agrid, dim3(kTiledThreads), lds, st_acc, recs, counters, g, plan, dtable, fz, (const uint2 *)nullptr, (const float2 *)nullptr)
         hipStream_t st_bin = as_stream(stream), st_acc = as_stream(stream);
         AdamFuse fz{};
         if (fuse && !plan.det) {
@@ -1577,6 +1846,28 @@ static int hashgrid_bwd_impl(const float *xyz, const float *table, const float *
                 if (level_fusable(g, plan, l)) fz.fuse_levels |= 1u << l;
         }
         if (fused_levels_out) *fused_levels_out = fz.fuse_levels;
+        if (plan_ws) {
+            e = g.F == 1
+                ? hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_accum_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                : hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_accum_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
+            float2 *vals = reinterpret_cast<float2 *>(recs);
+            int64_t fx = ceil_div<int64_t>(n, kFillThreads);
+            if (fx > kFillWgs) fx = kFillWgs;
+            dim3 fgrid((unsigned)fx, (unsigned)g.L);
+            const size_t flds = 2 * (size_t)kTileSlots * sizeof(float2);
+            e = g.F == 1 ? hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_fill_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds)
+                         : hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_fill_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds);
+            if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
+            if (g.F == 1) {
+                hipLaunchKernelGGL(scatter_fill_kernel<1>, fgrid, dim3(kFillThreads), flds, st_bin, xyz, dout, dout_lm_stride, g, plan, p_pos, n, p_gslot, p_count, plan_tiles(n), vals, counters, dtable, n, n_ptr);
+                hipLaunchKernelGGL((scatter_accum_kernel<1, true>), agrid, dim3(kTiledThreads), lds, st_acc, recs, counters, g, plan, dtable, fz, p_ridx, (const float2 *)vals);
+            } else {
+                hipLaunchKernelGGL(scatter_fill_kernel<2>, fgrid, dim3(kFillThreads), flds, st_bin, xyz, dout, dout_lm_stride, g, plan, p_pos, n, p_gslot, p_count, plan_tiles(n), vals, counters, dtable, n, n_ptr);
+                hipLaunchKernelGGL((scatter_accum_kernel<2, true>), agrid, dim3(kTiledThreads), lds, st_acc, recs, counters, g, plan, dtable, fz, p_ridx, (const float2 *)vals);
+            }
+            return check_launch("hashgrid_bwd_planned");
+        }
         if (g.F == 1) {
             ARCN_BIN(1, 1024);
             ARCN_ACC(1);
@@ -1635,10 +1926,10 @@ ARCN_EXPORT int arcn_hashgrid_bwd_bwd(const float *xyz, const float *gdx, const 
         dim3 bgrid((unsigned)bx, (unsigned)g.L), agrid((unsigned)plan.item_first[g.L]);
         if (g.F == 1) {
             hipLaunchKernelGGL(scatter_bin_dir_kernel<1>, bgrid, dim3(1024), 0, as_stream(stream), xyz, gdx, dout, g, plan, counters, recs, dtable, n, n_ptr);
-            hipLaunchKernelGGL(scatter_accum_kernel<1>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable, AdamFuse{});
+            hipLaunchKernelGGL(scatter_accum_kernel<1>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable, AdamFuse{}, (const uint2 *)nullptr, (const float2 *)nullptr);
         } else {
             hipLaunchKernelGGL(scatter_bin_dir_kernel<2>, bgrid, dim3(1024), 0, as_stream(stream), xyz, gdx, dout, g, plan, counters, recs, dtable, n, n_ptr);
-            hipLaunchKernelGGL(scatter_accum_kernel<2>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable, AdamFuse{});
+            hipLaunchKernelGGL(scatter_accum_kernel<2>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable, AdamFuse{}, (const uint2 *)nullptr, (const float2 *)nullptr);
         }
         if ((rc = check_launch("hashgrid_bwd_bwd_binned"))) return rc;
         if (!ddout && !d2xyz) return ARCN_OK;
@@ -1696,12 +1987,12 @@ static int hashgrid_bwd_first_second_impl(const float *xyz, const float *dout, c
     if (fused_levels_out) *fused_levels_out = fz.fuse_levels;
     if (g.F == 1) {
         hipLaunchKernelGGL(scatter_bin_dir_kernel<1>, bgrid, dim3(1024), 0, as_stream(stream), xyz, gdx, dout_dx, g, plan, counters, recs, dtable, n, no_count);
-        hipLaunchKernelGGL((scatter_bin_kernel<1, 1024>), bgrid, dim3(1024), 0, as_stream(stream), xyz, dout, (int64_t)0, g, plan, counters, recs, dtable, n, no_count);
-        hipLaunchKernelGGL(scatter_accum_kernel<1>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable, fz);
+        hipLaunchKernelGGL((scatter_bin_kernel<1, 1024>), bgrid, dim3(1024), 0, as_stream(stream), xyz, dout, (int64_t)0, g, plan, counters, recs, dtable, n, no_count, (uint2 *)nullptr, (uint4 *)nullptr, (int64_t)0, (uint32_t *)nullptr, (uint32_t *)nullptr, (int64_t)0);
+        hipLaunchKernelGGL(scatter_accum_kernel<1>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable, fz, (const uint2 *)nullptr, (const float2 *)nullptr);
     } else {
         hipLaunchKernelGGL(scatter_bin_dir_kernel<2>, bgrid, dim3(1024), 0, as_stream(stream), xyz, gdx, dout_dx, g, plan, counters, recs, dtable, n, no_count);
-        hipLaunchKernelGGL((scatter_bin_kernel<2, 1024>), bgrid, dim3(1024), 0, as_stream(stream), xyz, dout, (int64_t)0, g, plan, counters, recs, dtable, n, no_count);
-        hipLaunchKernelGGL(scatter_accum_kernel<2>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable, fz);
+        hipLaunchKernelGGL((scatter_bin_kernel<2, 1024>), bgrid, dim3(1024), 0, as_stream(stream), xyz, dout, (int64_t)0, g, plan, counters, recs, dtable, n, no_count, (uint2 *)nullptr, (uint4 *)nullptr, (int64_t)0, (uint32_t *)nullptr, (uint32_t *)nullptr, (int64_t)0);
+        hipLaunchKernelGGL(scatter_accum_kernel<2>, agrid, dim3(kTiledThreads), lds, as_stream(stream), recs, counters, g, plan, dtable, fz, (const uint2 *)nullptr, (const float2 *)nullptr);
     }
     return check_launch("hashgrid_bwd_first_second");
 }
@@ -1778,6 +2069,74 @@ ARCN_EXPORT int arcn_hashgrid_bwd_lm_adam(const float *xyz, const float *dout_lm
     if (rc) return rc;
     return hashgrid_bwd_impl(xyz, nullptr, dout_lm, dout_stride, desc_host, dtable, nullptr, workspace, workspace_floats, n, n_ptr, stream, &fz,
                              fused_levels_host, counters_clear != 0);
+}
+
+ARCN_EXPORT int64_t arcn_hashgrid_plan_workspace_floats(const arcn_hashgrid_desc *desc_host, int64_t n) {
+    if (!desc_host || n <= 0) return 0;
+    GridParams g;
+    if (build_params(desc_host, g) || g.F > 2) return 0;
+    BinPlan plan;
+    if (build_bin_plan(g, n, plan) || plan.n_recs >= (int64_t)kPosOvf) return 0;
+    return plan_ws_floats_for(plan, g, n);
+}
+
+/* The position-only half of the binned scatter for the samples xyz (n slots, *n_ptr of them in use), into plan_ws: to be followed - any time
+ * later, on any stream ordered behind this one - by ONE arcn_hashgrid_bwd_lm_planned / _adam_planned on the same xyz, n and n_ptr. */
+ARCN_EXPORT int arcn_hashgrid_bwd_plan(const float *xyz, const arcn_hashgrid_desc *desc_host, float *plan_ws, int64_t plan_ws_floats, int64_t n,
+                                       const int32_t *n_ptr, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!xyz || !plan_ws) return einval("hashgrid_bwd_plan: missing argument");
+    GridParams g;
+    int rc = build_params(desc_host, g);
+    if (rc) return rc;
+    if (g.F > 2) return einval("hashgrid_bwd_plan: n_feat 1 or 2");
+    BinPlan plan;
+    rc = build_bin_plan(g, n, plan);
+    if (rc) return rc;
+    if (plan.n_recs >= (int64_t)kPosOvf) return einval("hashgrid_bwd_plan: too many record slots for 32-bit slot indices");
+    if (plan_ws_floats < plan_ws_floats_for(plan, g, n)) return einval("hashgrid_bwd_plan: workspace smaller than arcn_hashgrid_plan_workspace_floats(desc, n)");
+    uint32_t *counters = reinterpret_cast<uint32_t *>(plan_ws);
+    uint2 *ridx = reinterpret_cast<uint2 *>(plan_ws + plan_ridx_first(plan));
+    uint4 *pos4 = reinterpret_cast<uint4 *>(plan_ws + plan_pos_first(plan));
+    hipError_t e = hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)bin_counter_floats(plan), as_stream(stream));
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ARCN_ELAUNCH; }
+    int64_t bx = ceil_div<int64_t>(n, 1024);
+    if (bx > 32) bx = 32;
+    dim3 bgrid((unsigned)bx, (unsigned)g.L);
+    const float *no_dout = nullptr;
+    uint4 *no_recs = nullptr;
+    float *no_dtable = nullptr;
+    uint32_t *gslot = reinterpret_cast<uint32_t *>(plan_ws + plan_gslot_first(plan, g, n));
+    uint32_t *tcount = reinterpret_cast<uint32_t *>(plan_ws + plan_count_first(plan, g, n));
+    if (g.F == 1) hipLaunchKernelGGL((scatter_bin_kernel<1, 1024, true>), bgrid, dim3(1024), 0, as_stream(stream), xyz, no_dout, (int64_t)0, g, plan, counters, no_recs, no_dtable, n, n_ptr, ridx, pos4, n, gslot, tcount, plan_tiles(n));
+    else hipLaunchKernelGGL((scatter_bin_kernel<2, 1024, true>), bgrid, dim3(1024), 0, as_stream(stream), xyz, no_dout, (int64_t)0, g, plan, counters, no_recs, no_dtable, n, n_ptr, ridx, pos4, n, gslot, tcount, plan_tiles(n));
+    return check_launch("hashgrid_bwd_plan");
+}
+
+/* arcn_hashgrid_bwd_lm on a batch whose plan exists: fill pass + chunk owners */
+ARCN_EXPORT int arcn_hashgrid_bwd_lm_planned(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host,
+                                             float *dtable, float *plan_ws, int64_t plan_ws_floats, float *workspace, int64_t workspace_floats,
+                                             int64_t n, const int32_t *n_ptr, void *stream) {
+    if (dout_stride != 0 && dout_stride < n) return einval("hashgrid_bwd_lm_planned: level stride smaller than n");
+    if (!workspace || !plan_ws) return einval("hashgrid_bwd_lm_planned: workspace and plan workspace required");
+    return hashgrid_bwd_impl(xyz, nullptr, dout_lm, dout_stride, desc_host, dtable, nullptr, workspace, workspace_floats, n, n_ptr, stream, nullptr, nullptr,
+                             false, 0xffffffffu, plan_ws, plan_ws_floats);
+}
+
+/* arcn_hashgrid_bwd_lm_adam on a batch whose plan exists */
+ARCN_EXPORT int arcn_hashgrid_bwd_lm_adam_planned(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host,
+                                                  float *dtable, float *table, float *exp_avg, float *exp_avg_sq, float lr, float beta1, float beta2,
+                                                  float eps, float weight_decay, float ema_decay, float grad_scale, int step, int ema_step,
+                                                  float *plan_ws, int64_t plan_ws_floats, float *workspace, int64_t workspace_floats, int64_t n,
+                                                  const int32_t *n_ptr, uint32_t *fused_levels_host, void *stream) {
+    if (dout_stride != 0 && dout_stride < n) return einval("hashgrid_bwd_lm_adam_planned: level stride smaller than n");
+    if (!plan_ws) return einval("hashgrid_bwd_lm_adam_planned: plan workspace required");
+    AdamFuse fz{};
+    int rc = make_adam_fuse(fz, "hashgrid_bwd_lm_adam_planned", workspace, table, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, ema_decay,
+                            grad_scale, step, ema_step, fused_levels_host);
+    if (rc) return rc;
+    return hashgrid_bwd_impl(xyz, nullptr, dout_lm, dout_stride, desc_host, dtable, nullptr, workspace, workspace_floats, n, n_ptr, stream, &fz,
+                             fused_levels_host, false, 0xffffffffu, plan_ws, plan_ws_floats);
 }
 
 ARCN_EXPORT int arcn_hashgrid_bwd_first_second_adam(const float *xyz, const float *dout, const float *gdx, const float *dout_dx,

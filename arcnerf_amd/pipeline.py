@@ -203,12 +203,15 @@ class NgpPipeline:
 
     def __init__(self, field, max_rays=32768, max_samples=1 << 19, packed_bits=True, torch_aabb=False, xcd_scatter=True, level_major=True, fused_glue=True,
                  prefetch_depth=None, prefetch_at=None, march_waves=None, aux_priority=None, occ_async=True, fused_composite=True, fuse_adam=True,
-                 step_tail=True, march_cull=True):
+                 step_tail=True, march_cull=True, planned_scatter=False):
         """The keyword switches select the measured alternatives of the step's schedule (defaults = the product path): prefetch_depth
         batches marched ahead, prefetch_at = where in the step the next marching is issued (_prefetch_point), march_waves = persistent
         wavefronts of a marching launch with slack, aux_priority = priority of the sampling stream, occ_async = the occupancy refresh on its
         own stream, fused_composite = compositing + loss + their backward as one kernel, fuse_adam = the scatter's chunk owners apply the
-        optimiser, step_tail = the end of the step as one launch, march_cull = the marcher's ray-culling grid."""
+        optimiser, step_tail = the end of the step as one launch, march_cull = the marcher's ray-culling grid, planned_scatter = the
+        position-only half of the table scatter (arcn_hashgrid_bwd_plan) computed with a batch marched ahead, on the sampling stream (OFF:
+        the scatter's own bracket drops from 0.178 to 0.145 ms, but on one GPU the plan pass shares the chip with the step's kernels and the
+        step is 0.655 against 0.540 ms - DESIGN.md; it pays where the sampling stream has idle compute units beside it)."""
         cfg = field.cfg
         self.field, self.cfg = field, cfg
         dev = field.device
@@ -320,6 +323,15 @@ class NgpPipeline:
         gd = [field.geo_desc.dims[i] for i in range(field.geo_desc.n_layers + 1)]
         self.level_major = bool(level_major and xcd_scatter and cfg.n_feat_per_entry == 2 and field.geo_desc.n_layers == 2 and
                                 not field.geo_desc.has_bias and gd[0] in (32, 64) and 48 < gd[1] <= 64 and gd[2] <= 16)
+        # planned scatter: a batch marched AHEAD (prefetch_samples, sampling stream) also gets the scatter's position-only half - cells, runs,
+        # rows, bins, ranks, the records' index halves - into a plan workspace of its own (one per sample-buffer set); the step then runs the
+        # fill pass + the chunk owners (arcn_hashgrid_bwd_lm[_adam]_planned).  A batch sampled inline keeps the one-pass scatter.
+        self._plan_floats = 0
+        if planned_scatter and self.level_major and self.hash_ws is not None and self.use_streams and not F.deterministic():
+            self._plan_floats = int(N.lib().arcn_hashgrid_plan_workspace_floats(N.C.addressof(field.grid_desc), int(S)))
+        for st_ in self._sets:
+            st_['plan_ws'] = torch.empty(self._plan_floats, dtype=f32, device=dev) if self._plan_floats else None
+        self._planned = [False] * len(self._sets)
         # single-GPU step with the optimiser inside the scatter: the two dW reductions, the optimiser on the rest of the flat buffer and
         # the clearing of the scatter's bin counters as ONE launch at the end of the step (arcn_ngp_step_tail; step_tail=False: four)
         self._tail = None
@@ -494,6 +506,13 @@ class NgpPipeline:
         spare = next(i for i in range(len(self._sets)) if i not in busy)
         with torch.cuda.stream(self.aux_stream):
             self._sample_into(self._sets[spare], rays_o, rays_d, waves=self.march_waves)
+            self._planned[spare] = False
+            if noise and self._plan_floats and self.level_major:      # (noise: the batch of a training step - its samples will be scattered)
+                bs = self._sets[spare]
+                R_ = rays_o.shape[0]
+                N.check(N.lib().arcn_hashgrid_bwd_plan(N.ptr(bs['xyz']), N.C.addressof(self.field.grid_desc), N.ptr(bs['plan_ws']), self._plan_floats,
+                                                       self.cap, bs['offsets'][R_:R_ + 1].data_ptr(), N.stream()), 'hashgrid_bwd_plan')
+                self._planned[spare] = True
             self._noise_ready[spare] = bool(noise and self.cfg.noise_std > 0)
             if self._noise_ready[spare]:
                 self._sets[spare]['noise'].normal_(0.0, self.cfg.noise_std)
@@ -521,6 +540,7 @@ class NgpPipeline:
             elif any(pf[3] == self._cur_set for pf in self._prefetched):   # cannot happen: the current set is never handed out
                 raise RuntimeError('sample buffer set in use by a prefetch')
             self._noise_ready[self._cur_set] = False
+            self._planned[self._cur_set] = False
             self._sample_into(self._sets[self._cur_set], rays_o, rays_d)
             self.buf.update(self._sets[self._cur_set])
         R = rays_o.shape[0]
@@ -680,12 +700,23 @@ class NgpPipeline:
                     self._occ_params_event = None
                 fused = N.C.c_uint32(0)
                 t_lo = fld._seg['table'][0]
-                N.check(L.arcn_hashgrid_bwd_lm_adam(N.ptr(b['xyz']), N.ptr(b['d_feat']), S, N.C.addressof(fld.grid_desc), N.ptr(self._g('table')),
-                                                    N.ptr(fld.view('table')), self.exp_avg[t_lo:].data_ptr(), self.exp_avg_sq[t_lo:].data_ptr(),
-                                                    float(cfg.lr), float(cfg.betas[0]), float(cfg.betas[1]), float(cfg.eps),
-                                                    float(cfg.weight_decay), -1.0 if cfg.ema_decay is None else float(cfg.ema_decay), 1.0, self.step_count + 1,
-                                                    self.ema_n_step + 1, N.ptr(self.hash_ws), self.hash_ws.numel(), int(self._ws_clear), S,
-                                                    n_dev.data_ptr(), N.C.byref(fused), st), 'hashgrid_bwd_lm_adam')
+                planned = self._planned[self._cur_set]
+                self._planned[self._cur_set] = False      # (one plan serves one scatter)
+                if planned:
+                    N.check(L.arcn_hashgrid_bwd_lm_adam_planned(N.ptr(b['xyz']), N.ptr(b['d_feat']), S, N.C.addressof(fld.grid_desc), N.ptr(self._g('table')),
+                                                                N.ptr(fld.view('table')), self.exp_avg[t_lo:].data_ptr(), self.exp_avg_sq[t_lo:].data_ptr(),
+                                                                float(cfg.lr), float(cfg.betas[0]), float(cfg.betas[1]), float(cfg.eps),
+                                                                float(cfg.weight_decay), -1.0 if cfg.ema_decay is None else float(cfg.ema_decay), 1.0,
+                                                                self.step_count + 1, self.ema_n_step + 1, N.ptr(self._sets[self._cur_set]['plan_ws']),
+                                                                self._plan_floats, N.ptr(self.hash_ws), self.hash_ws.numel(), S, n_dev.data_ptr(),
+                                                                N.C.byref(fused), st), 'hashgrid_bwd_lm_adam_planned')
+                else:
+                    N.check(L.arcn_hashgrid_bwd_lm_adam(N.ptr(b['xyz']), N.ptr(b['d_feat']), S, N.C.addressof(fld.grid_desc), N.ptr(self._g('table')),
+                                                        N.ptr(fld.view('table')), self.exp_avg[t_lo:].data_ptr(), self.exp_avg_sq[t_lo:].data_ptr(),
+                                                        float(cfg.lr), float(cfg.betas[0]), float(cfg.betas[1]), float(cfg.eps),
+                                                        float(cfg.weight_decay), -1.0 if cfg.ema_decay is None else float(cfg.ema_decay), 1.0, self.step_count + 1,
+                                                        self.ema_n_step + 1, N.ptr(self.hash_ws), self.hash_ws.numel(), int(self._ws_clear), S,
+                                                        n_dev.data_ptr(), N.C.byref(fused), st), 'hashgrid_bwd_lm_adam')
                 if fused.value != self._fused_mask:
                     raise RuntimeError('hashgrid_bwd_lm_adam fused levels {:#x}, the optimiser plan expects {:#x}'.format(fused.value, self._fused_mask))
                 self._fused_step = True
@@ -706,8 +737,15 @@ class NgpPipeline:
             else:
                 if tail:
                     raise RuntimeError('the step tail was planned for a step whose scatter does not apply the optimiser')
-                N.check(L.arcn_hashgrid_bwd_lm(N.ptr(b['xyz']), N.ptr(b['d_feat']), S, N.C.addressof(fld.grid_desc), N.ptr(self._g('table')),
-                                               N.ptr(self.hash_ws), self.hash_ws.numel(), S, n_dev.data_ptr(), st), 'hashgrid_bwd_lm')
+                planned = self._planned[self._cur_set]
+                self._planned[self._cur_set] = False
+                if planned:
+                    N.check(L.arcn_hashgrid_bwd_lm_planned(N.ptr(b['xyz']), N.ptr(b['d_feat']), S, N.C.addressof(fld.grid_desc), N.ptr(self._g('table')),
+                                                           N.ptr(self._sets[self._cur_set]['plan_ws']), self._plan_floats, N.ptr(self.hash_ws),
+                                                           self.hash_ws.numel(), S, n_dev.data_ptr(), st), 'hashgrid_bwd_lm_planned')
+                else:
+                    N.check(L.arcn_hashgrid_bwd_lm(N.ptr(b['xyz']), N.ptr(b['d_feat']), S, N.C.addressof(fld.grid_desc), N.ptr(self._g('table')),
+                                                   N.ptr(self.hash_ws), self.hash_ws.numel(), S, n_dev.data_ptr(), st), 'hashgrid_bwd_lm')
                 self._ws_clear = False
             self._fuse_next = False
             return

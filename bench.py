@@ -122,7 +122,7 @@ TABLE_KERNELS = ROOFLINE_KERNELS + ('mlp_fwd', 'mlp_bwd', 'mlp_bwd_dw', 'march_c
 
 
 # entry points of the level-major path are reported under the name of the op they implement
-ALIASES = {'hashgrid_fwd_xcd': 'hashgrid_fwd', 'hashgrid_bwd_lm': 'hashgrid_bwd', 'hashgrid_bwd_lm_adam': 'hashgrid_bwd', 'adam_ema_step_runs': 'adam_ema_step', 'ngp_step_tail': 'adam_ema_step', 'mlp_fwd_lm': 'mlp_fwd', 'mlp_bwd_lm': 'mlp_bwd',
+ALIASES = {'hashgrid_fwd_xcd': 'hashgrid_fwd', 'hashgrid_bwd_lm': 'hashgrid_bwd', 'hashgrid_bwd_lm_adam': 'hashgrid_bwd', 'hashgrid_bwd_lm_adam_planned': 'hashgrid_bwd', 'hashgrid_bwd_lm_planned': 'hashgrid_bwd', 'adam_ema_step_runs': 'adam_ema_step', 'ngp_step_tail': 'adam_ema_step', 'mlp_fwd_lm': 'mlp_fwd', 'mlp_bwd_lm': 'mlp_bwd',
            'mlp_fwd_cat': 'mlp_fwd', 'mlp_bwd_cat': 'mlp_bwd', 'march_count_culled': 'march_count', 'march_count_waves': 'march_count'}
 
 
@@ -614,7 +614,8 @@ def main():
     cfg = NgpConfig()  # configs/models/nerf_ngp.yaml + nerf_lego_nerf_ngp.yaml
     field = NgpField(cfg, device=dev, seed=0)  # identical init on every rank (DDP broadcasts rank 0's, same effect)
     # the ray batches of a run are known in advance (the reference precaches and shuffles them on the GPU): march two steps ahead
-    pipe = NgpPipeline(field, max_rays=32768, max_samples=1 << 20, packed_bits=True, prefetch_depth=2)
+    pipe = NgpPipeline(field, max_rays=32768, max_samples=1 << 20, packed_bits=True, prefetch_depth=2,
+                       planned_scatter=os.environ.get('ARCN_PLANNED_SCATTER', '0') == '1')      # (=1: the planned scatter, the A/B of DESIGN.md)
     bf = synthetic_bitfield(cfg.n_grid, args.occupancy, seed=0)
     pipe.set_bitfield(torch.from_numpy(bf))
 

@@ -336,6 +336,26 @@ int arcn_hashgrid_bwd_lm_adam(const float *xyz, const float *dout_lm, int64_t do
                               float weight_decay, float ema_decay, float grad_scale, int step, int ema_step, float *workspace,
                               int64_t workspace_floats, int counters_clear, int64_t n, const int32_t *n_ptr, uint32_t *fused_levels_host,
                               void *stream);
+/* The PLANNED form of the binned scatter.  Everything the scatter's producer derives from the sample positions alone - cells, the runs of
+ * samples sharing a cell, the 64-bit modulo of the dense levels, owner bins, ranks, the index half {i0 | i1 << 16, wx} of every record - is
+ * computed by arcn_hashgrid_bwd_plan as soon as the samples exist (the training step marches its batches two steps early: on the sampling
+ * stream, off the step's critical path) into a plan workspace of arcn_hashgrid_plan_workspace_floats(desc, n) floats (0: no planned form for
+ * this table / n).  The step itself then runs arcn_hashgrid_bwd_lm_planned / arcn_hashgrid_bwd_lm_adam_planned on the SAME xyz, n and n_ptr:
+ * a streaming fill pass (gradient x weights into the slots the plan reserved: no barriers, no atomics) and the chunk owners of
+ * arcn_hashgrid_bwd_lm / _lm_adam.  Same sums as the one-pass form (the order of a row's contributions differs, as it does between two runs
+ * of the one-pass form); one plan serves one scatter.  HashGridEmbedder's backward (hashgrid_encoder.py:191-249, torch autograd's
+ * index_add of the trilinear weights) is what all of them compute. */
+int64_t arcn_hashgrid_plan_workspace_floats(const arcn_hashgrid_desc *desc_host, int64_t n);
+int arcn_hashgrid_bwd_plan(const float *xyz, const arcn_hashgrid_desc *desc_host, float *plan_ws, int64_t plan_ws_floats, int64_t n,
+                           const int32_t *n_ptr, void *stream);
+int arcn_hashgrid_bwd_lm_planned(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host,
+                                 float *dtable, float *plan_ws, int64_t plan_ws_floats, float *workspace, int64_t workspace_floats,
+                                 int64_t n, const int32_t *n_ptr, void *stream);
+int arcn_hashgrid_bwd_lm_adam_planned(const float *xyz, const float *dout_lm, int64_t dout_stride, const arcn_hashgrid_desc *desc_host,
+                                      float *dtable, float *table, float *exp_avg, float *exp_avg_sq, float lr, float beta1, float beta2,
+                                      float eps, float weight_decay, float ema_decay, float grad_scale, int step, int ema_step,
+                                      float *plan_ws, int64_t plan_ws_floats, float *workspace, int64_t workspace_floats, int64_t n,
+                                      const int32_t *n_ptr, uint32_t *fused_levels_host, void *stream);
 /* The scatter starts from a cleared block of bin counters: the first arcn_hashgrid_bwd_counter_words(desc, n) 32-bit words of its
  * workspace.  counters_clear = 1 above says the caller has cleared them since the previous scatter on this workspace
  * (arcn_ngp_step_tail does, in the launch that ends the step), so the scatter skips its own fill launch. */

@@ -709,3 +709,100 @@ def test_culled_marcher_is_bit_identical(mode):
             assert int(res[True][0].sum()) > 0
         culled_rays.append(int((res[True][0] == 0).sum()))
     assert culled_rays[0] == R and culled_rays[1] > 0.8 * R and culled_rays[4] < 0.5 * R
+
+
+def _planned_vs_one_pass(xyz, d_feat, desc, n_table, S, n_dev=None):
+    """dtable of arcn_hashgrid_bwd_lm and of arcn_hashgrid_bwd_plan + arcn_hashgrid_bwd_lm_planned on the same level-major gradient"""
+    import ctypes as C
+    from arcnerf_amd import _native as N
+    from arcnerf_amd.ops import functional as F
+    L, dev = N.lib(), xyz.device
+    ws = F.hashgrid_bwd_workspace(desc, S, dev)
+    pf = int(L.arcn_hashgrid_plan_workspace_floats(C.addressof(desc), S))
+    assert pf > 0
+    pws = torch.empty(pf, dtype=torch.float32, device=dev)
+    a, b = torch.zeros(n_table, device=dev), torch.zeros(n_table, device=dev)
+    nd = None if n_dev is None else n_dev.data_ptr()
+    N.check(L.arcn_hashgrid_bwd_lm(N.ptr(xyz), N.ptr(d_feat), S, C.addressof(desc), N.ptr(a), N.ptr(ws), ws.numel(), S, nd, N.stream()), 'bwd_lm')
+    torch.cuda.synchronize()
+    status = F.hashgrid_bwd_status(desc, S, ws)
+    ws.fill_(float('nan'))          # (the value halves go where the one-pass records were: nothing of them may be read)
+    N.check(L.arcn_hashgrid_bwd_plan(N.ptr(xyz), C.addressof(desc), N.ptr(pws), pf, S, nd, N.stream()), 'plan')
+    N.check(L.arcn_hashgrid_bwd_lm_planned(N.ptr(xyz), N.ptr(d_feat), S, C.addressof(desc), N.ptr(b), N.ptr(pws), pf, N.ptr(ws), ws.numel(), S, nd,
+                                           N.stream()), 'bwd_lm_planned')
+    torch.cuda.synchronize()
+    return a, b, status
+
+
+def test_planned_scatter_equals_the_one_pass_scatter():
+    """arcn_hashgrid_bwd_plan (positions only, ahead of the step) + arcn_hashgrid_bwd_lm_planned (fill pass + chunk owners) against
+    arcn_hashgrid_bwd_lm through the C ABI: the same entries touched, the same sums to the order noise of float accumulation - on the
+    samples of a marched batch (runs on the coarse levels, pairs on the fine ones, a device-side count below the capacity), on uniform
+    random points (no runs), on two alternating points (every multi-bin level overflows its bins: the fill pass applies those records to
+    dtable itself) and on one cell (one run per wave)."""
+    from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline, synthetic_bitfield, synthetic_rays
+    dev = torch.device('cuda:0')
+    cfg = NgpConfig()
+    fld = NgpField(cfg, device=dev, seed=3)
+    pipe = NgpPipeline(fld, max_rays=4096, max_samples=1 << 18)
+    pipe.set_bitfield(torch.from_numpy(synthetic_bitfield(cfg.n_grid, 0.05, seed=5)))
+    o, d = synthetic_rays(4096, seed=1, device=dev)
+    pipe.forward(o, d, None, train=True)
+    S = pipe.cap
+    n = int(pipe.n_dev.item())
+    assert 1000 < n < S
+    g = torch.Generator().manual_seed(4)
+    d_feat = torch.randn(cfg.n_levels, S, 2, generator=g).to(dev).contiguous()
+    a, b, _ = _planned_vs_one_pass(pipe.buf['xyz'], d_feat, fld.grid_desc, fld.n_table, S, n_dev=pipe.n_dev)
+    assert torch.equal(a != 0, b != 0) and float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+    S2 = 1 << 15
+    d2 = torch.randn(cfg.n_levels, S2, 2, generator=g).to(dev).contiguous()
+    uni = ((torch.rand(S2, 3, generator=g) - 0.5) * 2.02).to(dev).contiguous()            # some outside the volume
+    a, b, _ = _planned_vs_one_pass(uni, d2, fld.grid_desc, fld.n_table, S2)
+    assert torch.equal(a != 0, b != 0) and float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+    pts = torch.tensor([[0.3123, -0.2291, 0.1377], [-0.4411, 0.5172, -0.0923]])
+    alt = pts[torch.arange(S2) % 2].to(dev).contiguous()
+    a, b, (_, overflowed) = _planned_vs_one_pass(alt, d2, fld.grid_desc, fld.n_table, S2)
+    assert overflowed, 'the alternating points must overflow a bin'
+    assert torch.equal(a != 0, b != 0) and float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())       # sums of 1.6e4 terms per row
+    one = (pts[0] + (torch.rand(S2, 3, generator=g) - 0.5) * 2e-4).to(dev).contiguous()
+    a, b, _ = _planned_vs_one_pass(one, d2, fld.grid_desc, fld.n_table, S2)
+    assert torch.equal(a != 0, b != 0) and float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+
+
+def test_training_steps_with_the_planned_scatter_equal_the_one_pass_steps():
+    """NgpPipeline(planned_scatter=True) - batches marched ahead get their scatter plan on the sampling stream, the step runs the fill pass
+    and the chunk owners with the fused optimiser - against planned_scatter=False from the same state and batches: the moments after
+    the first step to the scatter's order noise, the parameters after six steps like two runs of the one-pass form differ
+    (test_scatter_with_fused_optimiser_equals_scatter_then_adam's bars).  Five batches are marched ahead (planned), the last is sampled inline (no plan: one-pass) -
+    both forms inside one run."""
+    from arcnerf_amd.pipeline import NgpConfig, NgpField, NgpPipeline, synthetic_bitfield, synthetic_rays
+    dev = torch.device('cuda:0')
+    cfg = NgpConfig(noise_std=0.0, lr=1e-2)
+    res = {}
+    for planned in (True, False):
+        fld = NgpField(cfg, device=dev, seed=3)
+        fld.view('table').mul_(1000.0)
+        pipe = NgpPipeline(fld, max_rays=4096, max_samples=1 << 19, prefetch_depth=2, planned_scatter=planned)
+        assert bool(pipe._plan_floats) == planned
+        pipe.set_bitfield(torch.from_numpy(synthetic_bitfield(cfg.n_grid, 0.05, seed=5)))
+        g = torch.Generator().manual_seed(11)
+        rays = [synthetic_rays(4096, seed=40 + i, device=dev) for i in range(6)]
+        p0 = fld.params.clone()
+        pipe.prefetch_samples(*rays[0], noise=True)         # (the stepper hands the first two batches ahead like this)
+        pipe.prefetch_samples(*rays[1], noise=True)
+        assert all(pipe._planned[pf[3]] for pf in pipe._prefetched) == planned and len(pipe._prefetched) == 2
+        for i in range(6):
+            o, d = rays[i]
+            tgt, bkg = torch.rand(4096, 3, generator=g).to(dev), torch.rand(4096, 3, generator=g).to(dev)
+            pipe.train_step(o, d, tgt, bkg_color=bkg, next_rays=rays[i + 2] if i + 2 < 5 else None)      # (the last batch is sampled inline: one-pass)
+            if i == 1:
+                first = (pipe.exp_avg.clone(), pipe.exp_avg_sq.clone())
+        torch.cuda.synchronize()
+        assert pipe.step_count == 6 and float(fld.grads.abs().max()) == 0.0 and not any(pipe._planned)
+        res[planned] = (first, fld.params.clone(), p0)
+    (m_a, v_a), (m_b, v_b) = res[True][0], res[False][0]
+    step = float((res[False][1] - res[False][2]).abs().max())
+    far = ((res[True][1] - res[False][1]).abs() > 0.05 * step).float().mean()
+    assert step > 1e-3 and float(far) < 5e-3
+    assert float((m_a - m_b).abs().max()) <= 0.05 * float(m_b.abs().max())       # (two steps in: order noise through Adam once)
