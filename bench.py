@@ -47,7 +47,7 @@ def parse():
     ap.add_argument('--no-psnr', action='store_true', help='skip the short PSNR@iter run on the analytic scene appended to the default line')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the short runs of BASELINE configs 1 / 3 / 4 / 5 appended to the default line')
     ap.add_argument('--cpu-rays', type=int, default=131072)
-    ap.add_argument('--config', default='ngp', choices=['ngp', 'ngp_module', 'nerf', 'neus', 'neus_ngp_multivol', 'hdrnerf'],
+    ap.add_argument('--config', default='ngp', choices=['ngp', 'ngp_module', 'nerf', 'neus', 'neus_ngp_multivol', 'neus_ngp_nerfpp', 'hdrnerf'],
                     help='BASELINE.json configs: ngp = config 2 (default, the headline; ngp_module = the same model through the drop-in module path build_model(nerf_ngp.yaml)), nerf = 1, neus = 3, neus_ngp_multivol = 4, hdrnerf = 5')
     ap.add_argument('--rays', type=int, default=0, help='rays per step per GPU for the module-path configs (0 = the config default)')
     ap.add_argument('--chunk-pts', type=int, default=0, help='points per net evaluation chunk of the module-path configs (0 = the yaml value, the reference\'s 4096*32: a memory knob sized for an 11 GB card; the chunks are independent, so it changes launch sizes only)')
@@ -209,6 +209,10 @@ MODULE_CONFIGS = {
                        desc='instant-ngp of config 2 through the drop-in module path (hash grid + fused MLPs + volume prune 128^3, packed samples inside NeRF._forward_packed), Adam'),
     'neus_ngp_multivol': dict(yaml='neus_ngp_multivol.yaml', rays=4096, evals=None, flop=None,
                               desc='NeuS on the hash grid in the pruned volume + MultiVol background (hash grid + fused MLPs), Adam'),
+    # BASELINE.json's own wording of config 4: the same foreground with the NeRF++ inverted-sphere background (8 x 256 + 128 nets on 32 shell
+    # samples per ray) - through the module path (the hand-ordered stepper covers the MultiVol background only)
+    'neus_ngp_nerfpp': dict(yaml='neus_ngp_nerfpp.yaml', rays=4096, evals=None, flop=None,
+                            desc='NeuS on the hash grid in the pruned volume + NeRF++ background (freq encoder, 8x256 + 128 nets, 32 samples/ray), Adam'),
 }
 
 
@@ -249,9 +253,9 @@ def bench_module(args, name, emit=True):
         if bkg_occ < 1.0:
             bits = synthetic_cascade_bits(m.bkg_model.n_grid, m.bkg_model.n_levels, bkg_occ, seed=5)
             m.bkg_model.density_bitfield.copy_(torch.from_numpy(bits).to(dev))
-    if name == 'ngp_module':
+    if name in ('ngp_module', 'neus_ngp_nerfpp'):
         fg.obj_bound.volume.update_bitfield(torch.from_numpy(synthetic_bitfield(128, args.occupancy, seed=0)).to(dev), ops='overwrite')
-    radius = 2.2 if name == 'neus_ngp_multivol' else (3.0 if name == 'neus' else (3.0 / 1.05 if name == 'ngp_module' else 4.0))
+    radius = 2.2 if name in ('neus_ngp_multivol', 'neus_ngp_nerfpp') else (3.0 if name == 'neus' else (3.0 / 1.05 if name == 'ngp_module' else 4.0))
     pool = []
     g = torch.Generator(device='cpu').manual_seed(77 + rank)
     for i in range(4):
@@ -281,7 +285,7 @@ def bench_module(args, name, emit=True):
         ngp_loss = T_.build_loss(lc)
 
     neus_loss = None
-    if name == 'neus_ngp_multivol':
+    if name in ('neus_ngp_multivol', 'neus_ngp_nerfpp'):
         # the loss block of the reference's capture_qqtiger_neusngp_multivol.yaml:262-269: ImgLoss Huber 0.1 x 5 on rgb + EikonalLoss x 0.1 on normal_pts
         from arcnerf_amd import trainer as T_
         from arcnerf_amd.utils.cfgs_utils import dict_to_obj
@@ -329,7 +333,7 @@ def bench_module(args, name, emit=True):
         fused = FusedNgpStep(m, ngp_loss, opt, None, max_rays=n_rays, ahead=int(os.environ.get('ARCN_MODULE_AHEAD', '2')), world_size=world,
                              grad_sync=os.environ.get('ARCN_GRAD_SYNC', 'flat'))
 
-    prefetch = name == 'neus_ngp_multivol' and os.environ.get('ARCN_PREFETCH_SAMPLES', '1') != '0'
+    prefetch = name in ('neus_ngp_multivol', 'neus_ngp_nerfpp') and os.environ.get('ARCN_PREFETCH_SAMPLES', '1') != '0'
 
     fused_neus = None
     if name == 'neus_ngp_multivol' and mode == 'fused':
@@ -430,6 +434,14 @@ def bench_module(args, name, emit=True):
                     'fg_points_per_step': evals_per_step, 'bkg_samples_per_step': s_bkg,
                     'note': 'a module-path step: 2.7 ms of kernels in 3.6 ms, of which the hash passes are ~1.2 ms (profiles/r3d_*); the step is '
                             'launch / host bound, not bandwidth bound - the fraction says how far, it is not a kernel figure'}
+    if name == 'neus_ngp_nerfpp':
+        alg = (2 * BYTES_HASH_FWD + 2 * BYTES_HASH_BWD) * evals_per_step
+        ach = alg / (wall / args.steps)
+        roofline = {'kernel': 'hash-grid gathers + binned scatters of the foreground (first and second order), over the WHOLE step', 'bound': 'hbm',
+                    'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': None, 'fg_points_per_step': evals_per_step,
+                    'bkg_samples_per_step': n_rays * 32,
+                    'note': 'a module-path step (autograd engine between the kernels); the background is 4096 x 32 evaluations of the 8 x 256 + 128 NeRF++ nets '
+                            '(split-bf16 MFMA products): the fraction says how far the step is from the foreground\'s HBM bound, it is not a kernel figure'}
     if name == 'ngp_module':
         alg = (BYTES_HASH_FWD + BYTES_HASH_BWD) * evals_per_step
         ach = alg / (wall / args.steps)
@@ -722,6 +734,8 @@ def main():
     per_step_raw = [step_events[i].elapsed_time(step_events[i + 1]) for i in range(args.steps)]
     per_step = sorted(per_step_raw)
     slowest = int(np.argmax(per_step_raw))
+    every = cfg.epoch_optim
+    refresh_next = [] if (args.no_occ_update or not every) else [i + 1 for i in range(args.steps - 1) if (epoch0 + args.warmup + i) % every == 0]
     if os.environ.get('ARCN_BENCH_TRACE'):   # where a slow step lost its time: GPU span vs host enqueue span per step
         print(json.dumps({'gpu_ms': [round(v, 3) for v in per_step_raw], 'host_ms': [round((b - a) * 1e3, 3) for a, b in zip(cpu_marks[:-1], cpu_marks[1:])]}), file=sys.stderr)
 
@@ -874,13 +888,13 @@ def main():
         # on the default stream.  The drop-in NGP step marches ONE batch ahead on a second stream of the same priority - under a high-priority
         # main stream that chain starves and every step waits for it: 1.05 ms instead of 0.58)
         torch.cuda.set_stream(torch.cuda.default_stream())
-        for name in (os.environ.get('ARCN_OTHER_CONFIGS', 'ngp_module,nerf,neus,neus_ngp_multivol,hdrnerf').split(',')):
+        for name in (os.environ.get('ARCN_OTHER_CONFIGS', 'ngp_module,nerf,neus,neus_ngp_multivol,neus_ngp_nerfpp,hdrnerf').split(',')):
             a2 = copy.copy(args)
             # (24 steps after 6: the 8-after-3 legs of rounds 2 - 4 read the wide configs 1 - 3 % high - allocator growth and clocks still settling)
             a2.steps, a2.warmup, a2.rays, a2.chunk_pts, a2.no_cpu_baseline = 24, 6, 0, 0, True
             if name == 'ngp_module':    # the headline's model through the drop-in API: the driver's own K / W (+ the stepper's two eager steps)
                 a2.steps, a2.warmup = min(args.steps, 2000), min(args.warmup, 500) + 2
-            elif name == 'neus_ngp_multivol':     # 2 ms steps: eight of them are not a steady state (buffers still growing, 2.19 vs 1.96 ms stand-alone)
+            elif name in ('neus_ngp_multivol', 'neus_ngp_nerfpp'):     # 2 ms steps: eight of them are not a steady state (buffers still growing, 2.19 vs 1.96 ms stand-alone)
                 a2.steps, a2.warmup = 32, 8
             try:
                 r = bench_module(a2, name, emit=False)
@@ -952,8 +966,13 @@ def main():
                    'rays_per_step_per_gpu': n_rays, 'samples_per_step_per_gpu': s_per_launch, 'cold_start_steps': COLD_STEPS,
                    'parallelism': 'ray-sharded dp{}'.format(world)},
         'timed_region_ms': wall * 1e3,
+        # the steps behind an occupancy refresh (VolumeBound.optimize's cadence, cfg.epoch_optim = 16: the refresh of step i is queued on its own stream
+        # and shares the chip with step i + 1 - ~0.3 ms of geometry-net work on 2^19 cells every sixteenth step) are the slow ones: part of the
+        # workload, inside `value`; 'max_other' is the slowest step that has no refresh beside it
         'step_ms_spread': {'slowest_step': slowest, 'min': per_step[0], 'p50': per_step[len(per_step) // 2], 'p90': per_step[min(len(per_step) - 1, int(0.9 * len(per_step)))],
-                           'max': per_step[-1]},
+                           'max': per_step[-1], 'steps_beside_a_refresh': refresh_next,
+                           'p50_beside_a_refresh': (sorted(per_step_raw[i] for i in refresh_next)[len(refresh_next) // 2] if refresh_next else None),
+                           'max_other': max([v for i, v in enumerate(per_step_raw) if i not in refresh_next] or [None])},
         'rccl': dist_report(dist, world, LAUNCH, field.n_params * 4, (len(grad_sync.groups) if hasattr(grad_sync, 'groups') else 1 + len(grad_sync.segments)) if grad_sync is not None else 1, per_rank, rccl_extra),
         'roofline': roofline,
         'roofline_lookup': lookup,
