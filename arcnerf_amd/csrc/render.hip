@@ -63,7 +63,9 @@ struct PackedView {
     // counts (optional): the samples the marcher emitted per ray.  The packed buffers hold min(total, capacity) samples, the offsets are
     // clamped to the capacity: a ray behind the point where they filled up has a TRUNCATED segment.  Such a ray is never rendered from
     // its partial sample set: it is treated as a ray without samples (background colour, no gradient; the samples it left in the
-    // buffers receive zero gradients), so an overflowed training step is the correct step of a smaller batch.
+    // buffers receive zero gradients).  The rays that fit keep their 1 / (3 R) weight of the FULL batch and the step's reported loss still
+    // carries the left-out rays' background-vs-target term: an overflowed step is a down-weighted step of the rays that fit, not the step of a
+    // smaller batch (the steppers warn and grow the buffers, trainer/fused_step.py).
     const int32_t *counts = nullptr;
     int32_t trunc_n = 0;
     __device__ void begin_ray(int64_t r) {

@@ -79,10 +79,10 @@ class FgModel(Base3dModel):
         self._meter().reset()
         self._sync_measurement()
 
-    def adjust_dynamicbs_factor(self, mask_pts=None, n_valid=None):
+    def adjust_dynamicbs_factor(self, mask_pts=None, n_valid=None, stream=None):
         if self.render_cfgs['max_allowance'] <= 0 or (mask_pts is None and n_valid is None):
             return
-        self._meter().add(mask_pts.sum() if n_valid is None else n_valid)
+        self._meter().add(mask_pts.sum() if n_valid is None else n_valid, stream=stream)
         self.render_cfgs['measured_count'] = self._meter().measured_count
 
     def get_dynamicbs_factor(self):

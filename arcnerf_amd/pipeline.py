@@ -248,6 +248,8 @@ class NgpPipeline:
         b.update(self._sets[0])
         self._cur_set = 0
         self._prefetched = []   # FIFO of (rays_o ptr, rays_d ptr, R, set index, event), oldest first
+        self.sampled_ahead = False     # the batch of the last sample() was marched ahead on the sampling stream (its count was produced there)
+        self.sample_event = None       # ... or inline on the caller's stream: recorded behind its marcher
         self._next_rays = None
         self._carry_rays = None  # prefetch point 5: rays handed over by the previous train_step, marched behind this step's gather
         self.occ_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
@@ -534,7 +536,9 @@ class NgpPipeline:
             torch.cuda.current_stream().wait_event(pf[4])
             self._cur_set = pf[3]
             self.buf.update(self._sets[self._cur_set])
+            self.sampled_ahead = True
         else:
+            self.sampled_ahead = False
             if self.prefetch_depth == 1:
                 self._prefetched = []
             elif any(pf[3] == self._cur_set for pf in self._prefetched):   # cannot happen: the current set is never handed out
@@ -543,6 +547,9 @@ class NgpPipeline:
             self._planned[self._cur_set] = False
             self._sample_into(self._sets[self._cur_set], rays_o, rays_d)
             self.buf.update(self._sets[self._cur_set])
+            if self.use_streams:      # (whoever reads this batch's count on the sampling stream waits for this, not for the step behind it)
+                self.sample_event = torch.cuda.Event()
+                self.sample_event.record()
         R = rays_o.shape[0]
         self.n_dev = self.buf['offsets'][R:R + 1]  # device-side sample count (view, no sync)
         return self.n_dev

@@ -329,7 +329,15 @@ class FusedNgpStep:
             self.ema.n_step += 1
         self.steps += 1
         # the measurement of the dynamic batch size + this step's sample total (a kernel writing pinned memory, read a step later)
-        self.fg.adjust_dynamicbs_factor(n_valid=pipe.n_dev[0])
+        # (the count of a batch marched ahead was final steps ago, on the sampling stream: recorded and later read there, the batch-size
+        # update every 16 steps does not drain the step's stream)
+        aux = pipe.aux_stream if pipe.use_streams else None
+        if aux is not None and not pipe.sampled_ahead:
+            if pipe.sample_event is not None:
+                aux.wait_event(pipe.sample_event)      # (marched inline: behind its marcher on this stream, not behind the step)
+            else:
+                aux = None
+        self.fg.adjust_dynamicbs_factor(n_valid=pipe.n_dev[0], stream=aux)
         slot = self._slot
         self._slot = (slot + 1) % self._host_total.numel()
         self._np_total[slot] = self.SENTINEL

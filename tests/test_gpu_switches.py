@@ -31,6 +31,7 @@ GROUPS = {
         {'kw': {'fuse_adam': False}},             # scatter and optimiser as two passes (what several ranks run) instead of the fused consumer
         {'kw': {'step_tail': False, 'march_cull': False}},   # dW reductions, rest of the optimiser and the counter fill as four launches instead of one; no ray culling
         {'kw': {'march_waves': 256}},             # the marching of the batches in flight as 256 persistent wavefronts (4 rays each here): the same samples
+        {'kw': {'planned_scatter': True}},        # the scatter's position-only half with the batches marched ahead (arcn_hashgrid_bwd_plan), fill pass + owners in the step
         {'kw': {'prefetch_at': 5, 'aux_priority': -1}},   # the marching chain issued behind the NEXT step's gather; the sampling stream at the high priority
     ],
     'neusngp': [

@@ -156,13 +156,16 @@ def run(max_it=2000, seed=0, verbose=False, stepper='fused', report=(100, 500, 2
             s_before = step.drain()
             win = {'t0': time.perf_counter(), 'rays0': pipe.get_info('n_rays')}
         opt.param_groups[0]['lr'] = base_lr * (0.33 ** sum(1 for s in (20000, 30000, 40000, 50000) if epoch >= s))      # MultiStepLR of the yaml
+        t_call = time.perf_counter()
         T.train_epoch(m, batches, loss_factory, opt, ema, pipe, epoch, total_epoch=max_it, stepper=step)
+        if win is not None and 't1' not in win:
+            win['host'] = win.get('host', 0.0) + time.perf_counter() - t_call
         if win is not None and 't1' not in win and epoch + 1 == window[1]:
             s_after = step.drain()
             win['t1'] = time.perf_counter()
             n_it = window[1] - window[0]
             every = fg.obj_bound.get_optim_cfgs('epoch_optim')
-            win = {'iterations': [window[0], window[1]], 'ms_per_step': (win['t1'] - win['t0']) * 1e3 / n_it, 'samples_per_step': (s_after - s_before) / n_it,
+            win = {'iterations': [window[0], window[1]], 'ms_per_step': (win['t1'] - win['t0']) * 1e3 / n_it, 'host_ms_per_step': win.get('host', 0.0) * 1e3 / n_it, 'samples_per_step': (s_after - s_before) / n_it,
                    'samples_per_s': (s_after - s_before) / (win['t1'] - win['t0']), 'rays_per_step': [win['rays0'], pipe.get_info('n_rays')],
                    'occupancy_refreshes_applied': len([e for e in range(window[0], window[1]) if every and e > 0 and e % every == 0]),
                    'occupied': float(fg.obj_bound.volume.get_voxel_bitfield().float().mean()), 't1': win['t1']}
