@@ -1050,6 +1050,258 @@ ngp_step_tail_kernel(TailNet na, TailNet nb, float *__restrict__ param, float *_
     adam_ema_run(param + lo, grad + lo, m + lo, v + lo, ema ? ema + lo : nullptr, cnt, bid - first, nb_run, a);
 }
 
+// ---- the two-layer geometry nets of the NeuS-on-hash-grid + MultiVol step (BASELINE config 4), fused ----------------------------------------
+// hash features (32, level-major) -> 64 (softplus beta | ReLU) -> n_out <= 32 = [sdf | features] or [log density | features], bias-free
+// (configs/neus_ngp_multivol.yaml; reference sdf_model.py:42-101, base_network.py:30-44, linear_network_module.py:174-197).  trainer.
+// FusedNeusNgpStep spelled each net as a chain of the generic dense products - level-major -> rows, two forward products, the activation
+// derivative, the Jacobian-row product, three weight-gradient products with their reductions, three input-gradient products, the curvature
+// pass: 16 launches and ~280 us for 1.25e5 foreground samples, every intermediate (n, 64) through HBM.  Here a net is ONE forward and ONE
+// backward kernel in the transposed-MFMA form of the kernels above: the hidden layer never leaves registers and the backward recomputes it
+// from the features (nothing is saved), all weight-gradient tiles stay in accumulators.
+//   JAC (the sdf net): the forward also emits the Jacobian row of output 0,  jac = W1^T (s * W2[0]),  s = softplus'(z) = 1 - exp(-beta h)
+//   (GeoNet.forward_with_grad's d sdf / d features, base_network.py:30-44), and the backward takes jac's gradient d_jac as a second
+//   input:  u = W1 d_jac,  dz = dh s + beta W2[0] (s u)(1 - s),  dW1 += dz^T x + (s W2[0])^T d_jac,  dW2 += g^T h,  dW2[0] += sum_s s u
+//   (ops.autograd.SdfMlpJacFn.backward's arithmetic; arcn_sdf_jac_dz2).
+//   !JAC (the background density net): ReLU hidden layer, head = exp(out[0]) (TruncExp), its gradient through exp(clamp(out[0], +-15)).
+template <int MT, int T, int NT>
+__device__ __forceinline__ void dw_accumulate(f4 (&acc)[MT][T], const f4 (&dpre)[4][NT], const f4 (&yprev)[4][NT], float *trA, float *trB,
+                                              int tr_wr, const int (&tr_rd)[4]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f4 *>(trA + mt * 256 + tr_wr) = dpre[mt][nt];
+#pragma unroll
+        for (int t = 0; t < T; ++t) *reinterpret_cast<f4 *>(trB + t * 256 + tr_wr) = yprev[t][nt];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float av[MT], bv[T];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = trA[mt * 256 + tr_rd[q]];
+#pragma unroll
+            for (int t = 0; t < T; ++t) bv[t] = trB[t * 256 + tr_rd[q]];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[t], acc[mt][t], 0, 0, 0);
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_tiles(f4 (&a)[4][NT]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) a[mt][nt] = f4{0.f, 0.f, 0.f, 0.f};
+}
+
+constexpr int kGeo2Frag = 8 * kFragTile;   // floats of one staged 64 x 32 (or 32 x 64) weight: 8 fragments
+
+template <bool JAC>
+__global__ void __launch_bounds__(256)
+geo2_fwd_kernel(const float *__restrict__ x, int64_t x_stride, const float *__restrict__ w1, const float *__restrict__ w2, int n_out, int n_pad,
+                float beta, float *__restrict__ out, float *__restrict__ head, float *__restrict__ jac, int64_t n, const int32_t *n_ptr) {
+    constexpr int NT = 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *f_w1 = lds, *f_w2 = lds + kGeo2Frag, *f_w1t = lds + 2 * kGeo2Frag;
+    const int MT2 = tiles16(n_out);
+    stage_fragments<false>(f_w1, w1, 64, 32);
+    stage_fragments<false>(f_w2, w2, n_out, 64);
+    if (JAC) stage_fragments<true>(f_w1t, w1, 32, 64);
+    __syncthreads();
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+    f4 w20[4];   // W2[0] at this lane's hidden neurons 16 t + 4 g ..
+#pragma unroll
+    for (int t = 0; t < 4; ++t) w20[t] = JAC ? *reinterpret_cast<const f4 *>(w2 + 16 * t + 4 * g) : f4{0.f, 0.f, 0.f, 0.f};
+    constexpr int SPW = 16 * NT;
+    const int64_t n_tiles = ceil_div_dev(cnt, (int64_t)SPW * 4);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t s0 = tile * SPW * 4 + (int64_t)wave * SPW;
+        if (s0 >= cnt) continue;
+        f4 h[4][NT], o[4][NT];
+        load_tiles_lm2<2, NT>(h, x, x_stride, s0, cnt, g, j);
+        zero_tiles<NT>(o);
+        gemm_tiles<4, NT>(o, h, f_w1, 4, 2, lane);
+        act_tiles<4, NT>(o, JAC ? ARCN_ACT_SOFTPLUS : ARCN_ACT_RELU, beta);
+        zero_tiles<NT>(h);
+        gemm_tiles<4, NT>(h, o, f_w2, MT2, 4, lane);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int64_t s = s0 + 16 * nt + j;
+            if (s >= cnt) continue;
+            float *p = out + s * n_pad + 4 * g;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int col = 16 * t + 4 * g;
+                const f4 r = h[t][nt];
+                if (col + 3 < n_pad) *reinterpret_cast<f4 *>(p + 16 * t) = r;     // (n_pad is a multiple of 4: whole quads or nothing)
+            }
+            if (g == 0 && head) head[s] = JAC ? h[0][nt].x : expf(h[0][nt].x);
+        }
+        if (JAC) {
+            // p = s * W2[0] over the hidden layer, jac = W1^T p
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    o[t][nt].x = (1.0f - expf(-beta * o[t][nt].x)) * w20[t].x;
+                    o[t][nt].y = (1.0f - expf(-beta * o[t][nt].y)) * w20[t].y;
+                    o[t][nt].z = (1.0f - expf(-beta * o[t][nt].z)) * w20[t].z;
+                    o[t][nt].w = (1.0f - expf(-beta * o[t][nt].w)) * w20[t].w;
+                }
+            zero_tiles<NT>(h);
+            gemm_tiles<4, NT>(h, o, f_w1t, 2, 4, lane);
+            store_tiles_fast<2, NT>(h, jac, 32, s0, cnt, g, j);
+        }
+    }
+}
+
+template <bool JAC, int NT>
+__global__ void __launch_bounds__(256, 2)
+geo2_bwd_kernel(const float *__restrict__ x, int64_t x_stride, const float *__restrict__ w1, const float *__restrict__ w2, int n_out, float beta,
+                const float *__restrict__ d_col0, const float *__restrict__ out_col0, int64_t ld_out, const float *__restrict__ d_feat,
+                int64_t ld_feat, const float *__restrict__ d_jac, float *__restrict__ dx, int64_t dx_stride, float *__restrict__ partials,
+                int n_slots, int64_t n, const int32_t *n_ptr) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *f_w1 = lds, *f_w1t = lds + kGeo2Frag, *f_w2t = lds + 2 * kGeo2Frag;
+    const int MT2 = tiles16(n_out);
+    stage_fragments<false>(f_w1, w1, 64, 32);
+    stage_fragments<true>(f_w1t, w1, 32, 64);
+    stage_fragments<true>(f_w2t, w2, 64, n_out);
+    float *s_w20 = lds + 3 * kGeo2Frag + 8192;       // W2[0] (the Jacobian row's weights), behind the transposition tiles
+    if (JAC && threadIdx.x < 64) s_w20[threadIdx.x] = w2[threadIdx.x];
+    __syncthreads();
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+    float *trA = lds + 3 * kGeo2Frag + wave * 2048, *trB = trA + 1024;
+    const int tr_wr = j * 16 + ((g ^ ((j >> 1) & 3)) << 2);
+    int tr_rd[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tr_rd[q] = (4 * q + g) * 16 + (((j >> 2) ^ ((2 * q + (g >> 1)) & 3)) << 2) + (j & 3);
+    f4 acc1[4][2], acc2[2][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { acc1[a][b] = f4{0.f, 0.f, 0.f, 0.f}; acc2[b][a] = f4{0.f, 0.f, 0.f, 0.f}; }
+    const float e0 = j == 0 ? 1.0f : 0.0f;      // the A operand of "row 0 += column sums": neuron i = lane & 15 of every sample
+    constexpr int SPW = 16 * NT;
+    const int64_t n_tiles = ceil_div_dev(cnt, (int64_t)SPW * 4);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t s0 = tile * SPW * 4 + (int64_t)wave * SPW;
+        if (s0 >= cnt) continue;
+        f4 xt[4][NT], h[4][NT], gt[4][NT], d[4][NT];
+        load_tiles_lm2<2, NT>(xt, x, x_stride, s0, cnt, g, j);
+        // the output gradient from its pieces: column 0 (through the head's activation), the feature columns, zeros behind them
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int64_t s = s0 + 16 * nt + j;
+            const bool ok = s < cnt;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * t + 4 * g + r;
+                    v[r] = 0.f;
+                    if (ok && c < n_out) {
+                        if (c == 0) {
+                            v[r] = d_col0[s];
+                            if (!JAC) { float pre = out_col0[s * ld_out]; pre = pre < -15.f ? -15.f : (pre > 15.f ? 15.f : pre); v[r] *= expf(pre); }
+                        } else {
+                            v[r] = d_feat[s * ld_feat + (c - 1)];
+                        }
+                    }
+                }
+                gt[t][nt] = f4{v[0], v[1], v[2], v[3]};
+            }
+            gt[2][nt] = gt[3][nt] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+        // the hidden layer again: the fragments and the MFMA order of the forward
+        zero_tiles<NT>(h);
+        gemm_tiles<4, NT>(h, xt, f_w1, 4, 2, lane);
+        act_tiles<4, NT>(h, JAC ? ARCN_ACT_SOFTPLUS : ARCN_ACT_RELU, beta);
+        dw_accumulate<2, 4, NT>(acc2, gt, h, trA, trB, tr_wr, tr_rd);
+        zero_tiles<NT>(d);
+        gemm_tiles<4, NT>(d, gt, f_w2t, 4, MT2, lane);            // dh = W2^T g
+        if (JAC) {
+            f4 dj[4][NT], u[4][NT];
+            load_tiles_fast<2, NT>(dj, d_jac, 32, s0, cnt, g, j);
+            zero_tiles<NT>(u);
+            gemm_tiles<4, NT>(u, dj, f_w1, 4, 2, lane);           // u = W1 d_jac
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f4 w20 = *reinterpret_cast<const f4 *>(s_w20 + 16 * t + 4 * g);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sv = 1.0f - expf(-beta * h[t][nt][r]);
+                        const float su = sv * u[t][nt][r];
+                        d[t][nt][r] = d[t][nt][r] * sv + (beta * w20[r]) * su * (1.0f - sv);
+                        h[t][nt][r] = sv * w20[r];        // sw: the operand of the Jacobian path's first-layer gradient
+                        u[t][nt][r] = su;
+                    }
+                }
+            }
+            // dW2[0] += sum over the samples of s u: one more K pass with the constant row selector as its A operand
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) *reinterpret_cast<f4 *>(trB + t * 256 + tr_wr) = u[t][nt];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float bv[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) bv[t] = trB[t * 256 + tr_rd[q]];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc2[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(e0, bv[t], acc2[0][t], 0, 0, 0);
+                }
+            }
+            dw_accumulate<4, 2, NT>(acc1, h, dj, trA, trB, tr_wr, tr_rd);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d[t][nt][r] = h[t][nt][r] > 0.f ? d[t][nt][r] : 0.f;
+        }
+        dw_accumulate<4, 2, NT>(acc1, d, xt, trA, trB, tr_wr, tr_rd);
+        if (dx) {
+            zero_tiles<NT>(gt);
+            gemm_tiles<4, NT>(gt, d, f_w1t, 2, 4, lane);          // dx = W1^T dz
+            if (dx_stride) store_tiles_lm2<2, NT>(gt, dx, dx_stride, s0, cnt, g, j);
+            else store_tiles_fast<2, NT>(gt, dx, 32, s0, cnt, g, j);
+        }
+    }
+    // the four waves' tiles summed through LDS, one partial per layer and workgroup in the order mlp_dw_reduce_kernel reads
+    __syncthreads();
+    float *red = lds + 3 * kGeo2Frag;
+    for (int l = 0; l < 2; ++l) {
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        f4 *dst = reinterpret_cast<f4 *>(red + (l == 0 ? a * 4 + b : b * 4 + a) * 256 + lane * 4);
+                        const f4 v = l == 0 ? acc1[a][b] : acc2[b][a];
+                        *dst = (w == 0) ? v : (*dst + v);
+                    }
+            }
+            __syncthreads();
+        }
+        f4 *part = reinterpret_cast<f4 *>(partials + ((int64_t)l * n_slots + blockIdx.x) * 4096);
+        const f4 *src4 = reinterpret_cast<const f4 *>(red);
+        for (int e = threadIdx.x; e < 1024; e += 256) {
+            const int tl = e >> 6, a = tl >> 2, b = tl & 3;
+            if (l == 0 ? (b < 2) : (a < 2)) part[e] = src4[e];
+        }
+        __syncthreads();
+    }
+}
+
 static int build_mlp_params(const arcn_mlp_desc *d, MlpParams &P, bool transposed, int *lds_floats, int *max_dim) {
     if (!d) return einval("mlp: desc is NULL");
     if (d->n_layers < 1 || d->n_layers > kMaxLayers) return einval("mlp: 1..8 layers supported");
@@ -1498,4 +1750,75 @@ ARCN_EXPORT int arcn_mlp_bwd_dw(const float *x, const arcn_mlp_desc *desc_host, 
         if ((rc = check_launch("mlp_bwd_dw"))) return rc;
     }
     return ARCN_OK;
+}
+
+/* see include/arcnerf_hip.h */
+static int geo2_check(const float *x_lm, int64_t x_stride, const float *w1, const float *w2, int n_out, int64_t n, const char *who) {
+    (void)who;
+    if (!x_lm || !w1 || !w2) return einval("geo2: missing argument");
+    if (n_out < 1 || n_out > 32) return einval("geo2: 1..32 outputs");
+    if (x_stride < n) return einval("geo2: level stride smaller than n");
+    if ((reinterpret_cast<uintptr_t>(x_lm) & 7) || (reinterpret_cast<uintptr_t>(w2) & 15)) return einval("geo2: features 8-byte, last layer 16-byte aligned");
+    return ARCN_OK;
+}
+
+ARCN_EXPORT int arcn_geo2_fwd(const float *x_lm, int64_t x_stride, const float *w1, const float *w2, int n_out, int n_pad, int jac_mode, float beta,
+                              float *out, float *head, float *jac, int64_t n, const int32_t *n_ptr, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    int rc;
+    if ((rc = geo2_check(x_lm, x_stride, w1, w2, n_out, n, "geo2_fwd"))) return rc;
+    if (!out || n_pad < n_out || (n_pad & 3) || n_pad > 32 || (jac_mode && !jac)) return einval("geo2_fwd: out (n, n_pad), n_pad a multiple of 4 in n_out..32; jac in Jacobian mode");
+    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(jac)) & 15) return einval("geo2_fwd: 16-byte aligned outputs");
+    const size_t lds_bytes = sizeof(float) * 3 * kGeo2Frag;
+    const unsigned grid = tile_grid(n, 128, kSlimGrid);
+    if (jac_mode)
+        hipLaunchKernelGGL(geo2_fwd_kernel<true>, dim3(grid), dim3(256), lds_bytes, as_stream(stream), x_lm, x_stride, w1, w2, n_out, n_pad, beta, out, head,
+                           jac, n, n_ptr);
+    else
+        hipLaunchKernelGGL(geo2_fwd_kernel<false>, dim3(grid), dim3(256), lds_bytes, as_stream(stream), x_lm, x_stride, w1, w2, n_out, n_pad, beta, out, head,
+                           jac, n, n_ptr);
+    return check_launch("geo2_fwd");
+}
+
+static int64_t geo2_slots(int64_t n) {
+    int64_t grid = tile_grid(n, 64);
+    return grid;
+}
+
+ARCN_EXPORT int64_t arcn_geo2_bwd_scratch_floats(int64_t n) { return n <= 0 ? 0 : 2 * geo2_slots(n) * 4096; }
+
+ARCN_EXPORT int arcn_geo2_bwd(const float *x_lm, int64_t x_stride, const float *w1, const float *w2, int n_out, int jac_mode, float beta,
+                              const float *d_col0, const float *out_col0, int64_t ld_out, const float *d_feat, int64_t ld_feat, const float *d_jac,
+                              float *dx, int64_t dx_stride, float *dw1, float *dw2, float *scratch, int64_t n, const int32_t *n_ptr, void *stream) {
+    if (n <= 0) return ARCN_OK;
+    int rc;
+    if ((rc = geo2_check(x_lm, x_stride, w1, w2, n_out, n, "geo2_bwd"))) return rc;
+    if (!d_col0 || (n_out > 1 && (!d_feat || ld_feat < n_out - 1)) || !dw1 || !dw2 || !scratch) return einval("geo2_bwd: missing argument");
+    if (jac_mode ? !d_jac : (!out_col0 || ld_out < 1)) return einval("geo2_bwd: d_jac (Jacobian mode) or the forward's output column 0 (density mode) missing");
+    if (dx_stride && dx_stride < n) return einval("geo2_bwd: level stride of dx smaller than n");
+    if ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(d_jac)) & 15) return einval("geo2_bwd: 16-byte aligned dx / d_jac");
+    const int64_t off2 = dw2 - dw1;
+    if (off2 > INT32_MAX || off2 < INT32_MIN) return einval("geo2_bwd: the two weight gradients must lie within 2^31 floats of each other (one flat buffer)");
+    const size_t lds_bytes = sizeof(float) * (3 * kGeo2Frag + 8192 + 64);
+    const int64_t grid = geo2_slots(n);
+    float *partials = scratch;
+    if (jac_mode) {
+        if ((rc = set_lds(geo2_bwd_kernel<true, 1>, lds_bytes))) return rc;
+        hipLaunchKernelGGL((geo2_bwd_kernel<true, 1>), dim3((unsigned)grid), dim3(256), lds_bytes, as_stream(stream), x_lm, x_stride, w1, w2, n_out, beta,
+                           d_col0, out_col0, ld_out, d_feat, ld_feat, d_jac, dx, dx_stride, partials, (int)grid, n, n_ptr);
+    } else {
+        if ((rc = set_lds(geo2_bwd_kernel<false, 1>, lds_bytes))) return rc;
+        hipLaunchKernelGGL((geo2_bwd_kernel<false, 1>), dim3((unsigned)grid), dim3(256), lds_bytes, as_stream(stream), x_lm, x_stride, w1, w2, n_out, beta,
+                           d_col0, out_col0, ld_out, d_feat, ld_feat, d_jac, dx, dx_stride, partials, (int)grid, n, n_ptr);
+    }
+    DwParams D;
+    D.n_layers = 2;
+    D.has_bias = 0;
+    D.dims[0] = 32; D.dims[1] = 64; D.dims[2] = n_out;
+    D.w_off[0] = 0; D.w_off[1] = (int32_t)off2;
+    D.b_off[0] = D.b_off[1] = 0;
+    D.quad_first[0] = 0; D.quad_first[1] = 1; D.quad_first[2] = 2;
+    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(4096 / kReduceElems, 2u), dim3(kReduceElems * kReduceSlices), 0, as_stream(stream), partials,
+                       static_cast<const float *>(nullptr), D, (int)grid, dw1, static_cast<float *>(nullptr));
+    return check_launch("geo2_bwd");
 }

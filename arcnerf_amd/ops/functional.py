@@ -554,8 +554,9 @@ def hashgrid_bwd_status(desc, n, workspace):
     return float(words[:1].view(torch.float32)[0]), bool(int(words[1]) != 0)
 
 
-def hashgrid_bwd(xyz, table, dout, desc, want_dtable=True, want_dxyz=False, n_dev=None, dtable=None, workspace=None):
-    """workspace: True (allocate) or a float tensor from hashgrid_bwd_workspace -> owner-computes scatter; None -> atomics"""
+def hashgrid_bwd(xyz, table, dout, desc, want_dtable=True, want_dxyz=False, n_dev=None, dtable=None, workspace=None, level_stride=0):
+    """workspace: True (allocate) or a float tensor from hashgrid_bwd_workspace -> owner-computes scatter; None -> atomics.
+    level_stride > 0: dout is LEVEL-major with that many samples per level (binned scatter only, no dxyz: arcn_hashgrid_bwd_lm)"""
     _req(xyz, table, dout)
     xyz, table, dout = _f32(xyz), _f32(table), _f32(dout)
     n = xyz.shape[0]
@@ -565,6 +566,11 @@ def hashgrid_bwd(xyz, table, dout, desc, want_dtable=True, want_dxyz=False, n_de
         assert workspace.dtype == torch.float32
     if want_dtable and dtable is None:
         dtable = torch.zeros_like(table)
+    if level_stride:
+        assert workspace is not None and want_dtable and not want_dxyz
+        N.check(N.lib().arcn_hashgrid_bwd_lm(N.ptr(xyz), N.ptr(dout), int(level_stride), C.addressof(desc), N.ptr(dtable), N.ptr(workspace), workspace.numel(),
+                                            n, _nptr(n_dev), N.stream()), 'hashgrid_bwd_lm')
+        return dtable, None
     dxyz = torch.zeros((n, 3), dtype=torch.float32, device=xyz.device) if want_dxyz else None
     N.check(N.lib().arcn_hashgrid_bwd(N.ptr(xyz), N.ptr(table), N.ptr(dout), C.addressof(desc),
                                      N.ptr(dtable) if want_dtable else None, N.ptr(dxyz), N.ptr(workspace),
@@ -652,7 +658,7 @@ def _adam_args(h):
             float(h['ema_decay']) if h.get('ema_decay') is not None else -1.0, float(h.get('grad_scale', 1.0)), int(h['step']), int(h['ema_step'] or h['step']))
 
 
-def hashgrid_bwd_adam(xyz, dout, desc, dtable, table, exp_avg, exp_avg_sq, hyper, workspace):
+def hashgrid_bwd_adam(xyz, dout, desc, dtable, table, exp_avg, exp_avg_sq, hyper, workspace, level_stride=0):
     """the binned table scatter of hashgrid_bwd (dout (n, L F) sample-major) whose chunk owners also apply Adam (+ the EMA aliased onto the
     parameter) to the table levels they own alone: table / exp_avg / exp_avg_sq = the table's views of a flattened FusedAdam's buffers, hyper =
     FusedAdam.begin_step().  -> the bit mask of the levels done (their gradient never reaches dtable); the rest is accumulated into dtable"""
@@ -660,7 +666,8 @@ def hashgrid_bwd_adam(xyz, dout, desc, dtable, table, exp_avg, exp_avg_sq, hyper
     xyz, dout = _f32(xyz), _f32(dout)
     n = xyz.shape[0]
     mask = C.c_uint32(0)
-    N.check(N.lib().arcn_hashgrid_bwd_lm_adam(N.ptr(xyz), N.ptr(dout), 0, C.addressof(desc), N.ptr(dtable), N.ptr(table), N.ptr(exp_avg), N.ptr(exp_avg_sq),
+    # (level_stride > 0: dout is LEVEL-major with that many samples per level - geo2_bwd(dx_level_major=True) - instead of (n, L F) rows)
+    N.check(N.lib().arcn_hashgrid_bwd_lm_adam(N.ptr(xyz), N.ptr(dout), int(level_stride), C.addressof(desc), N.ptr(dtable), N.ptr(table), N.ptr(exp_avg), N.ptr(exp_avg_sq),
                                              *_adam_args(hyper), N.ptr(workspace), workspace.numel(), 0, n, None, C.cast(C.pointer(mask), C.c_void_p),
                                              N.stream()), 'hashgrid_bwd_lm_adam')
     return int(mask.value)
@@ -1479,6 +1486,66 @@ def geo_out_grad(d_col0, d_feat, n_pad, out=None, act=None, beta=1.0, y_col0=Non
     N.check(N.lib().arcn_geo_out_grad(N.ptr(d_col0), None if out is None else out.data_ptr(), int(ld_out), N.ptr(y_col0), N.ACT[act], float(beta),
                                      d_feat.data_ptr(), int(d_feat.stride(0)), int(d_feat.shape[1]), int(n_pad), N.ptr(g), n, N.stream()), 'geo_out_grad')
     return g
+
+
+def hashgrid_fwd_lm(xyz, table, desc, want_corners=False, n_dev=None):
+    """the XCD-affine gather leaving its features LEVEL-major: -> (lm (L * n * F,) = lm[(l * n + s) * F + f], corners | None); the operand layout
+    of geo2_fwd / geo2_bwd and of the fused MLP's level-major entry points (level stride = n)"""
+    _req(xyz, table)
+    xyz, table = _f32(xyz), _f32(table)
+    n, L, Fq = xyz.shape[0], int(desc.n_levels), int(desc.n_feat)
+    lm = torch.empty(n * L * Fq, dtype=torch.float32, device=xyz.device)
+    if want_corners:
+        corners = torch.empty((L, 2 * Fq, n, 4), dtype=torch.float32, device=xyz.device)
+        N.check(N.lib().arcn_hashgrid_fwd_corners(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(lm), 1, N.ptr(corners), n, n, _nptr(n_dev), N.stream()),
+                'hashgrid_fwd_corners')
+        return lm, corners
+    N.check(N.lib().arcn_hashgrid_fwd_xcd(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(lm), 1, n, n, _nptr(n_dev), N.stream()), 'hashgrid_fwd_xcd')
+    return lm, None
+
+
+def geo2_fwd(x_lm, n, w1, w2, jac, beta=1.0, pad_to=4):
+    """a two-layer geometry net on level-major hash features (level stride n) in one launch (arcn_geo2_fwd): w1 (64, 32), w2 (n_out, 64).
+    jac True: the sdf net - softplus(beta) hidden layer -> (out (n, n_pad), sdf (n) = out[:, 0], jac (n, 32) = d sdf / d features);
+    jac False: a density net - ReLU hidden layer -> (out, exp(out[:, 0]), None)"""
+    _req(x_lm, w1, w2)
+    assert tuple(w1.shape) == (64, 32) and w2.shape[1] == 64 and w1.is_contiguous() and w2.is_contiguous()
+    n_out = int(w2.shape[0])
+    n_pad = (n_out + pad_to - 1) // pad_to * pad_to
+    dev = x_lm.device
+    out = torch.empty((n, n_pad), dtype=torch.float32, device=dev)
+    head = torch.empty(n, dtype=torch.float32, device=dev)
+    jc = torch.empty((n, 32), dtype=torch.float32, device=dev) if jac else None
+    N.check(N.lib().arcn_geo2_fwd(N.ptr(x_lm), int(n), N.ptr(_f32(w1)), N.ptr(_f32(w2)), n_out, n_pad, int(bool(jac)), float(beta), N.ptr(out), N.ptr(head),
+                                 N.ptr(jc), int(n), None, N.stream()), 'geo2_fwd')
+    return out, head, jc
+
+
+def geo2_bwd(x_lm, n, w1, w2, jac, beta, d_col0, d_feat, dw1, dw2, d_jac=None, out=None, dx_level_major=False, scratch=None):
+    """the backward of geo2_fwd in one launch + its weight-gradient reduction (arcn_geo2_bwd): d_col0 (n) = the gradient of the head (sdf, or the
+    density through its exp), d_feat (n, n_out - 1) = the gradient of the feature columns (may be a column slice of a wider row-major tensor),
+    d_jac (n, 32) = the gradient of the Jacobian row (jac True), out = the forward's output (jac False: its column 0 is the TruncExp's input).
+    dw1 (64, 32) += and dw2 (n_out, 64) += (views of one flat gradient buffer).  -> dx: (n, 32) rows, or level-major (32 n,) with dx_level_major"""
+    _req(x_lm, w1, w2, d_col0, d_feat, dw1, dw2, d_jac, out)
+    n_out = int(w2.shape[0])
+    assert d_col0.is_contiguous() and d_col0.dtype == torch.float32 and d_col0.numel() == n
+    assert d_feat.dtype == torch.float32 and d_feat.stride(1) == 1 and d_feat.shape == (n, n_out - 1)
+    assert dw1.is_contiguous() and dw2.is_contiguous() and tuple(dw1.shape) == (64, 32) and tuple(dw2.shape) == (n_out, 64)
+    dev = x_lm.device
+    dx = torch.empty(n * 32, dtype=torch.float32, device=dev) if dx_level_major else torch.empty((n, 32), dtype=torch.float32, device=dev)
+    need = int(N.lib().arcn_geo2_bwd_scratch_floats(int(n)))
+    if scratch is None or scratch.numel() < need:
+        scratch = torch.empty(max(1, need), dtype=torch.float32, device=dev)
+    ld_out = 0
+    if not jac:
+        assert out is not None and out.dtype == torch.float32 and out.stride(1) == 1 and out.shape[0] == n
+        ld_out = out.stride(0)
+    else:
+        assert d_jac is not None and d_jac.is_contiguous() and tuple(d_jac.shape) == (n, 32)
+    N.check(N.lib().arcn_geo2_bwd(N.ptr(x_lm), int(n), N.ptr(_f32(w1)), N.ptr(_f32(w2)), n_out, int(bool(jac)), float(beta), N.ptr(d_col0),
+                                 None if out is None else out.data_ptr(), int(ld_out), d_feat.data_ptr(), int(d_feat.stride(0)), N.ptr(d_jac), N.ptr(dx),
+                                 int(n) if dx_level_major else 0, N.ptr(dw1), N.ptr(dw2), N.ptr(scratch), int(n), None, N.stream()), 'geo2_bwd')
+    return dx
 
 
 _BLEND_WS = {}

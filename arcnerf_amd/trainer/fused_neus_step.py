@@ -126,7 +126,7 @@ class FusedNeusNgpStep:
         return None
 
     def __init__(self, model, loss_factory, optimizer, ema=None, total_epoch=300000, prefetch=True, world_size=1, grad_sync='flat',
-                 sync_occupancy=True, keep_corners=True, fuse_adam=True):
+                 sync_occupancy=True, keep_corners=True, fuse_adam=True, fused_geo=True):
         """world_size > 1: data parallel, one process per GPU, every rank its shard of the rays (the reference wraps the model in
         DistributedDataParallel, common/trainer/basic_trainer.py:192-198).  The flat gradient is SUMMED over the ranks between the backward
         and the optimiser - grad_sync 'flat': ONE all-reduce of the flattened optimiser's gradient buffer, then FusedAdam.step() on every
@@ -162,6 +162,9 @@ class FusedNeusNgpStep:
         # the gathered table rows of the forward are kept for the two second-order gathers (keep_corners=False: three gathers from the table;
         # measured in round 5, DESIGN.md: -46 us per step with the rows kept)
         self.keep_corners = bool(keep_corners)
+        # both two-layer geometry nets as one forward and one backward kernel each on the gather's level-major features (arcn_geo2_fwd / _bwd);
+        # fused_geo=False: the chain of dense products + glue passes they replace (round 5's form, the A/B reference)
+        self.fused_geo = bool(fused_geo) and self.keep_corners
         # the table scatters' chunk owners apply Adam to the levels they own alone (arcn_hashgrid_bwd_lm_adam / _first_second_adam): those levels'
         # gradients never go to HBM and the optimiser pass shrinks to the rest of the flat buffer.  fuse_adam=False (and every multi-rank
         # step): scatter, then one pass
@@ -255,6 +258,14 @@ class FusedNeusNgpStep:
                     out.append((lo, hi))
         return out
 
+    def _geo_scratch(self, n, device):
+        """the weight-gradient partials of arcn_geo2_bwd, kept (both nets' calls are stream-ordered: one buffer)"""
+        need = int(F.N.lib().arcn_geo2_bwd_scratch_floats(int(n)))
+        w = self._ws.get('geo2')
+        if w is None or w.numel() < need or w.device != device:
+            w = self._ws['geo2'] = torch.empty(max(1, need), dtype=torch.float32, device=device)
+        return w
+
     def _scatter_ws(self, key, desc, n, device):
         """scratch of a binned table scatter, kept while it is large enough (the library knows the size for n samples)"""
         w = self._ws.get(key)
@@ -327,19 +338,24 @@ class FusedNeusNgpStep:
             pts, dirs = F.packed_points(rays_o, rays_d, pk['t_mid'], pk['ray_id'])
             # (the gathered rows are kept: the normals and the gradient of the Jacobian row stream them instead of gathering again;
             # ARCN_NEUS_CORNERS=0: three gathers from the table)
-            if self.keep_corners:
+            if self.fused_geo:
+                enc, corners = F.hashgrid_fwd_lm(pts, table, emb.desc, want_corners=True)     # (level-major features: what the net's kernels read)
+                out, sdf, jac = F.geo2_fwd(enc, S, w1, l1.weight, True, beta)
+            elif self.keep_corners:
                 enc, corners = F.hashgrid_fwd_corners(pts, table, emb.desc)
             else:
                 enc, corners = F.hashgrid_fwd(pts, table, emb.desc), None
-            hid = F.gemm_nt(enc, w1, None, act='softplus', beta=beta)
-            out = F.gemm_nt(hid, w2, None)
-            sg = F.softplus_grad(hid, None, beta, from_y=True)
-            jac = F.gemm_nn(sg, prep['w1j'])
+            if not self.fused_geo:
+                hid = F.gemm_nt(enc, w1, None, act='softplus', beta=beta)
+                out = F.gemm_nt(hid, w2, None)
+                sg = F.softplus_grad(hid, None, beta, from_y=True)
+                jac = F.gemm_nn(sg, prep['w1j'])
             if corners is not None:
                 normal = F.hashgrid_dxyz_corners(pts, corners, jac, emb.desc)
             else:
                 _, normal = F.hashgrid_bwd(pts, table, jac, emb.desc, want_dtable=False, want_dxyz=True)
-            sdf = F.act_col_scale(out, None, 1.0)       # (column 0 of the padded output)
+            if not self.fused_geo:
+                sdf = F.act_col_scale(out, None, 1.0)       # (column 0 of the padded output)
             n_sh = rad.embed_fn_view.n_freqs ** 2
             rad_in = F.radiance_inputs('pvnf', pts, dirs, normal, out[:, 1:n_out], rad.embed_fn_view.n_freqs)       # [p | SH(normalize(v)) | n | f], one pass
             rad_w = _flat_view([layer.weight for layer in rad.layers])
@@ -358,10 +374,14 @@ class FusedNeusNgpStep:
         nb_out = b1.weight.shape[0]
         if total_b > 0:
             xyz_b, dirs_b = F.packed_points(rays_o, rays_d, t_b, ray_b)
-            enc_b = F.hashgrid_fwd(xyz_b, tb, emb_b.desc)
-            hid_b = F.gemm_nt(enc_b, b0.weight, None, act='relu')
-            out_b = F.gemm_nt(hid_b, wb1, None)
-            sigma_b = F.act_col_scale(out_b, 'truncexp', 1.0)       # (the density from column 0 of the padded output)
+            if self.fused_geo:
+                enc_b, _ = F.hashgrid_fwd_lm(xyz_b, tb, emb_b.desc)
+                out_b, sigma_b, _ = F.geo2_fwd(enc_b, total_b, b0.weight, b1.weight, False)
+            else:
+                enc_b = F.hashgrid_fwd(xyz_b, tb, emb_b.desc)
+                hid_b = F.gemm_nt(enc_b, b0.weight, None, act='relu')
+                out_b = F.gemm_nt(hid_b, wb1, None)
+                sigma_b = F.act_col_scale(out_b, 'truncexp', 1.0)       # (the density from column 0 of the padded output)
             rin_b = F.radiance_inputs('fv', None, dirs_b, None, out_b[:, 1:nb_out], rb.embed_fn_view.n_freqs)
             rb_w = _flat_view([layer.weight for layer in rb.layers])
             rb_g = _flat_view([layer.weight.grad for layer in rb.layers]) if rb_w is not None else None
@@ -394,18 +414,25 @@ class FusedNeusNgpStep:
                     layer.weight.grad.add_(dw_b[k:k + m_].view_as(layer.weight))
                     k += m_
             # [d density through TruncExp | d features | 0] of the padded output, one pass
-            g_out_b = F.geo_out_grad(d_sig_b, dx_b[:, :nb_out - 1], wb1.shape[0], out=out_b, act='truncexp', y_col0=sigma_b)
-            F.gemm_tn(g_out_b, hid_b, out=b1.weight.grad, accumulate=True, head=nb_out)
-            d_hid_b = F.gemm_nn(g_out_b, wb1)
-            F.gemm_tn(d_hid_b, enc_b, mask=hid_b, out=b0.weight.grad, accumulate=True)
-            d_enc_b = F.gemm_nn(d_hid_b, b0.weight, mask=hid_b)
+            lm_b = 0
+            if self.fused_geo:
+                # [d density through TruncExp | d features] enters the net's backward in pieces; d_enc_b level-major, as the scatter reads it
+                d_enc_b = F.geo2_bwd(enc_b, total_b, b0.weight, b1.weight, False, 1.0, d_sig_b, dx_b[:, :nb_out - 1], b0.weight.grad, b1.weight.grad,
+                                     out=out_b, dx_level_major=True, scratch=self._geo_scratch(total_b, dev))
+                lm_b = total_b
+            else:
+                g_out_b = F.geo_out_grad(d_sig_b, dx_b[:, :nb_out - 1], wb1.shape[0], out=out_b, act='truncexp', y_col0=sigma_b)
+                F.gemm_tn(g_out_b, hid_b, out=b1.weight.grad, accumulate=True, head=nb_out)
+                d_hid_b = F.gemm_nn(g_out_b, wb1)
+                F.gemm_tn(d_hid_b, enc_b, mask=hid_b, out=b0.weight.grad, accumulate=True)
+                d_enc_b = F.gemm_nn(d_hid_b, b0.weight, mask=hid_b)
             ws_b = self._scatter_ws('bkg', emb_b.desc, total_b, dev)
             if fuse:
                 hyper = hyper or self.opt.begin_step()
                 m_, v_, o_ = self.opt.table_views(tb)
-                done += self._level_ranges(emb_b, F.hashgrid_bwd_adam(xyz_b, d_enc_b, emb_b.desc, tb.grad, tb, m_, v_, hyper, ws_b), o_)
+                done += self._level_ranges(emb_b, F.hashgrid_bwd_adam(xyz_b, d_enc_b, emb_b.desc, tb.grad, tb, m_, v_, hyper, ws_b, level_stride=lm_b), o_)
             else:
-                F.hashgrid_bwd(xyz_b, tb, d_enc_b, emb_b.desc, dtable=tb.grad, workspace=ws_b)
+                F.hashgrid_bwd(xyz_b, tb, d_enc_b, emb_b.desc, dtable=tb.grad, workspace=ws_b, level_stride=lm_b)
         # ---- foreground backward
         if S > 0:
             zr = self._zeros(4 * R, dev)       # (read-only zero upstream gradients)
@@ -426,16 +453,21 @@ class FusedNeusNgpStep:
             else:
                 d_jac, _, _ = F.hashgrid_bwd_bwd(pts, d_normal, table, jac, emb.desc, want_ddout=True, want_dtable=False, want_d2xyz=False)
             # the sdf net, first output's Jacobian included (ops.autograd.SdfMlpJacFn.backward)
-            g_out = F.geo_out_grad(d_sdf, dx_r[:, 6 + n_sh:6 + n_sh + n_out - 1], w2.shape[0])       # [d sdf | d features | 0]
-            dz = F.gemm_nn(g_out, w2)
-            F.gemm_tn(g_out, hid, out=l1.weight.grad, accumulate=True, head=n_out)
-            u = F.gemm_nt(d_jac, w1, None)
-            # dz through the softplus + the Jacobian path's curvature term; s * W2[0] (the operand of that path's first-layer gradient) in u's place;
-            # the path's gradient of W2[0] - the column sums of s u - straight into the last layer's gradient row
-            dz, sw = F.sdf_jac_dz2(dz, u, sg, prep['bw20'], w2[0], l1.weight.grad[0])
-            F.gemm_tn(sw, d_jac, out=l0.weight.grad, accumulate=True)
-            d_enc = F.gemm_nn(dz, w1)
-            F.gemm_tn(dz, enc, out=l0.weight.grad, accumulate=True)
+            if self.fused_geo:
+                # [d sdf | d features] and d_jac in, d_enc and both layers' gradients (ordinary + Jacobian path) out: one kernel + its reduction
+                d_enc = F.geo2_bwd(enc, S, w1, l1.weight, True, beta, d_sdf, dx_r[:, 6 + n_sh:6 + n_sh + n_out - 1], l0.weight.grad, l1.weight.grad,
+                                   d_jac=d_jac, scratch=self._geo_scratch(S, dev))
+            else:
+                g_out = F.geo_out_grad(d_sdf, dx_r[:, 6 + n_sh:6 + n_sh + n_out - 1], w2.shape[0])       # [d sdf | d features | 0]
+                dz = F.gemm_nn(g_out, w2)
+                F.gemm_tn(g_out, hid, out=l1.weight.grad, accumulate=True, head=n_out)
+                u = F.gemm_nt(d_jac, w1, None)
+                # dz through the softplus + the Jacobian path's curvature term; s * W2[0] (the operand of that path's first-layer gradient) in u's
+                # place; the path's gradient of W2[0] - the column sums of s u - straight into the last layer's gradient row
+                dz, sw = F.sdf_jac_dz2(dz, u, sg, prep['bw20'], w2[0], l1.weight.grad[0])
+                F.gemm_tn(sw, d_jac, out=l0.weight.grad, accumulate=True)
+                d_enc = F.gemm_nn(dz, w1)
+                F.gemm_tn(dz, enc, out=l0.weight.grad, accumulate=True)
             # the table: through the encoding (d_enc) and through its input gradient (d_normal on J^T jac), ONE accumulation pass for both
             ws_f = self._scatter_ws('fg', emb.desc, 3 * S, dev)
             if fuse:

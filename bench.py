@@ -342,7 +342,9 @@ def bench_module(args, name, emit=True):
         # optimiser (ARCN_GRAD_SYNC=flat: one all-reduce, the default | sharded); ARCN_MODULE_STEP=eager: the module path
         from arcnerf_amd.trainer import FusedNeusNgpStep
         gs = os.environ.get('ARCN_GRAD_SYNC', 'flat')
-        fused_neus = FusedNeusNgpStep(m, neus_loss, opt, world_size=world, grad_sync=gs if gs in ('flat', 'sharded') else 'flat')
+        # (ARCN_NEUS_FUSED_GEO=0: both geometry nets as round 5's chains of dense products instead of arcn_geo2_fwd / _bwd - the A/B switch)
+        fused_neus = FusedNeusNgpStep(m, neus_loss, opt, world_size=world, grad_sync=gs if gs in ('flat', 'sharded') else 'flat',
+                                      fused_geo=os.environ.get('ARCN_NEUS_FUSED_GEO', '1') != '0')
 
     def step(i):
         inp = pool[i % len(pool)]

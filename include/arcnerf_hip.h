@@ -515,6 +515,28 @@ int arcn_act_col_scale(const float *x, int64_t ld, float *y, int64_t n, const in
 /* One elementwise pass of ops.autograd.SdfMlpJacFn's backward (the NeuS-on-hash-grid sdf net with its Jacobian as an explicit output):
  * dz = dh s + c_j u s (1 - s), su = s u over an (n, H) hidden layer, c (H) = beta W2[0]; dz / su may alias dh / u. */
 int arcn_sdf_jac_dz(const float *dh, const float *u, const float *s, const float *c, float *dz, float *su, int64_t n, int H, void *stream);
+/* The two-layer geometry nets of the NeuS-on-hash-grid + MultiVol step, each as ONE forward and ONE backward kernel (csrc/mlp.hip, the
+ * transposed-MFMA form of arcn_mlp_fwd_lm): hash features x (32 columns, LEVEL-major as arcn_hashgrid_fwd_xcd / _fwd_corners write them with
+ * level_major = 1: x_lm[(l * x_stride + s) * 2 + f]) -> 64 hidden -> n_out <= 32 outputs, bias-free, w1 (64, 32), w2 (n_out, 64) row-major like
+ * torch.nn.Linear.weight.  Replaces, per net, the chain lm_to_rows + arcn_gemm_* + arcn_softplus_grad + arcn_sdf_jac_dz2 + arcn_geo_out_grad +
+ * arcn_act_col_scale of trainer.FusedNeusNgpStep (16 launches, every (n, 64) intermediate through HBM); nothing is saved between the two calls
+ * - the backward recomputes the hidden layer.
+ *   jac_mode 1 - the sdf net (GeoNet with a softplus-beta DenseLayer evaluated through forward_with_grad: sdf_model.py:42-101,
+ *     base_network.py:30-44): out (n, n_pad) = W2 softplus(W1 x) (columns n_out .. n_pad - 1 zero), head (n) = out[:, 0] (optional),
+ *     jac (n, 32) row-major = d out[:, 0] / d x = W1^T (s W2[0]), s = 1 - exp(-beta h).  Backward inputs: d_col0 (n) = d out[:, 0],
+ *     d_feat (row stride ld_feat) = d out[:, 1 .. n_out), d_jac (n, 32) = the gradient of jac; outputs dx (n, 32) row-major (dx_stride 0) or
+ *     level-major (dx_stride >= n), dw1 += and dw2 += the weight gradients of BOTH paths (ops.autograd.SdfMlpJacFn.backward's arithmetic).
+ *   jac_mode 0 - a density net (ReLU hidden layer, TruncExp on column 0: linear_network_module.py:174-197 with out_act_cfg TruncExp):
+ *     head (n) = exp(out[:, 0]); the backward takes d_col0 = d head and multiplies it by exp(clamp(out_col0[s * ld_out], -15, 15)) (the
+ *     reference's TruncExp backward, arcnerf/ops/trunc_exp.py), out_col0 = the forward's out.
+ * scratch: arcn_geo2_bwd_scratch_floats(n) floats (per-workgroup weight-gradient tiles, summed by the reduction the call ends with in a fixed
+ * order).  dw1 and dw2 must be views of one buffer (|dw2 - dw1| < 2^31 floats: a flattened optimiser's gradient buffer). */
+int arcn_geo2_fwd(const float *x_lm, int64_t x_stride, const float *w1, const float *w2, int n_out, int n_pad, int jac_mode, float beta,
+                  float *out, float *head, float *jac, int64_t n, const int32_t *n_ptr, void *stream);
+int64_t arcn_geo2_bwd_scratch_floats(int64_t n);
+int arcn_geo2_bwd(const float *x_lm, int64_t x_stride, const float *w1, const float *w2, int n_out, int jac_mode, float beta,
+                  const float *d_col0, const float *out_col0, int64_t ld_out, const float *d_feat, int64_t ld_feat, const float *d_jac,
+                  float *dx, int64_t dx_stride, float *dw1, float *dw2, float *scratch, int64_t n, const int32_t *n_ptr, void *stream);
 /* The passes BETWEEN the kernels of the NeuS-on-hash-grid + MultiVol training step (trainer.FusedNeusNgpStep; csrc/step_glue.hip), each
  * one group of the reference's elementwise torch expressions in one launch:
  *   arcn_neus_step_prep  the per-step derived weights of the two geometry nets (sdf_model.py:42-101, base_network.py:30-44, neus_model.py:221-228):

@@ -1,0 +1,103 @@
+"""arcn_geo2_fwd / arcn_geo2_bwd - the two-layer geometry nets of config 4 (NeuS on the hash grid + MultiVol background) as one forward and one
+backward kernel - against float64 torch autograd of the reference's own expressions: GeoNet.forward_with_grad on a softplus DenseLayer
+(sdf_model.py:42-101, base_network.py:30-44: the Jacobian row of the first output differentiated again) and the density net with TruncExp
+(linear_network_module.py:174-197, arcnerf/ops/trunc_exp.py).  Bars: 1e-4 of each tensor's max for the forward, 2e-4 for the gradients (f32
+MFMA chains against float64)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def _lm(rows):
+    n = rows.shape[0]
+    return rows.view(n, 16, 2).permute(1, 0, 2).contiguous().reshape(-1)
+
+
+def _rel(a, b):
+    return float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize('n,beta,n_out', [(5003, 100.0, 17), (128, 5.0, 17), (40000, 100.0, 16), (777, 20.0, 5)])
+def test_sdf_net_with_its_jacobian_row(gpu, n, beta, n_out):
+    from arcnerf_amd.ops import functional as F
+    g = torch.Generator().manual_seed(n)
+    x = (torch.randn(n, 32, generator=g) * 0.5).to(gpu)
+    w1 = (torch.randn(64, 32, generator=g) * 0.05).to(gpu)
+    w2 = (torch.randn(n_out, 64, generator=g) * 0.3).to(gpu)
+    d0 = torch.randn(n, generator=g).to(gpu)
+    wide = torch.randn(n, n_out + 6, generator=g).to(gpu)          # d_feat as a column slice of a wider tensor
+    dfeat = wide[:, 3:3 + n_out - 1]
+    dj = torch.randn(n, 32, generator=g).to(gpu)
+    lm = _lm(x)
+    out, sdf, jac = F.geo2_fwd(lm, n, w1, w2, True, beta)
+    n_pad = (n_out + 3) // 4 * 4
+    assert out.shape == (n, n_pad) and jac.shape == (n, 32)
+    # float64 reference
+    xd, w1d, w2d = x.double().requires_grad_(), w1.double().requires_grad_(), w2.double().requires_grad_()
+    h = torch.nn.functional.softplus(xd @ w1d.t(), beta=beta)
+    o = h @ w2d.t()
+    jr, = torch.autograd.grad(o[:, 0].sum(), xd, create_graph=True)
+    assert _rel(out[:, :n_out], o.detach()) <= 1e-4 and float(out[:, n_out:].abs().max() if n_pad > n_out else 0.0) == 0.0
+    assert torch.equal(sdf, out[:, 0])
+    assert _rel(jac, jr.detach()) <= 1e-4
+    loss = (o[:, 0] * d0.double()).sum() + (o[:, 1:] * dfeat.double()).sum() + (jr * dj.double()).sum()
+    gx, gw1, gw2 = torch.autograd.grad(loss, [xd, w1d, w2d])
+    flat = torch.full((64 * 32 + n_out * 64 + 8,), 0.25, device=gpu)       # the gradients are ADDED into views of one flat buffer
+    dw1, dw2 = flat[:2048].view(64, 32), flat[2052:2052 + n_out * 64].view(n_out, 64)
+    dx = F.geo2_bwd(lm, n, w1, w2, True, beta, d0, dfeat, dw1, dw2, d_jac=dj)
+    assert _rel(dx, gx) <= 2e-4, _rel(dx, gx)
+    assert _rel(dw1 - 0.25, gw1) <= 2e-4, _rel(dw1 - 0.25, gw1)
+    assert _rel(dw2 - 0.25, gw2) <= 2e-4, _rel(dw2 - 0.25, gw2)
+    assert float((flat[2048:2052] - 0.25).abs().max()) == 0 and float((flat[2052 + n_out * 64:] - 0.25).abs().max()) == 0
+    # level-major dx = the rows transposed, bit for bit
+    flat2 = torch.zeros_like(flat)
+    dx_lm = F.geo2_bwd(lm, n, w1, w2, True, beta, d0, dfeat, flat2[:2048].view(64, 32), flat2[2052:2052 + n_out * 64].view(n_out, 64), d_jac=dj, dx_level_major=True)
+    assert torch.equal(dx_lm, _lm(dx))
+
+
+@pytest.mark.parametrize('n,n_out', [(6001, 17), (64, 17), (33333, 9)])
+def test_density_net_with_truncexp_head(gpu, n, n_out):
+    from arcnerf_amd.ops import functional as F
+    g = torch.Generator().manual_seed(n + 1)
+    x = (torch.randn(n, 32, generator=g) * 0.5).to(gpu)
+    w1 = (torch.randn(64, 32, generator=g) * 0.3).to(gpu)
+    w2 = (torch.randn(n_out, 64, generator=g) * 0.2).to(gpu)
+    w2[0] *= 8.0                                                    # some pre-activations beyond the +-15 clamp of the TruncExp backward
+    d0 = torch.randn(n, generator=g).to(gpu)
+    dfeat = torch.randn(n, n_out - 1, generator=g).to(gpu)
+    lm = _lm(x)
+    out, sigma, none = F.geo2_fwd(lm, n, w1, w2, False)
+    assert none is None
+    xd, w1d, w2d = x.double(), w1.double(), w2.double()
+    h = torch.relu(xd @ w1d.t())
+    o = h @ w2d.t()
+    assert _rel(out[:, :n_out], o) <= 1e-4
+    assert torch.allclose(sigma, torch.exp(out[:, 0]), rtol=2e-6, atol=0)
+    assert n < 1000 or float(out[:, 0].abs().max()) > 15.0
+    go = torch.cat([(d0.double() * torch.exp(out[:, 0].double().clamp(-15, 15)))[:, None], dfeat.double()], dim=1)
+    gw2 = go.t() @ h
+    dz = (go @ w2d) * (h > 0)
+    gw1 = dz.t() @ xd
+    gx = dz @ w1d
+    flat = torch.zeros(64 * 32 + n_out * 64, device=gpu)
+    dw1, dw2 = flat[:2048].view(64, 32), flat[2048:].view(n_out, 64)
+    dx = F.geo2_bwd(lm, n, w1, w2, False, 1.0, d0, dfeat, dw1, dw2, out=out, dx_level_major=True)
+    # (a sample whose float32 hidden pre-activation has the other sign than the float64 one flips a ReLU gate: bars on the sums, looser per row)
+    assert _rel(dw1, gw1) <= 2e-4 and _rel(dw2, gw2) <= 2e-4, (_rel(dw1, gw1), _rel(dw2, gw2))
+    assert _rel(dx, _lm(gx.float()).double()) <= 1e-3
+
+
+def test_geo2_argument_checks(gpu):
+    from arcnerf_amd.ops import functional as F
+    x = torch.zeros(32 * 16, device=gpu)
+    w1, w2 = torch.zeros(64, 32, device=gpu), torch.zeros(40, 64, device=gpu)
+    with pytest.raises(RuntimeError):
+        F.geo2_fwd(x, 16, w1, w2, True, 1.0)          # more than 32 outputs
