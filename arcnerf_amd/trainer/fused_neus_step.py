@@ -126,7 +126,7 @@ class FusedNeusNgpStep:
         return None
 
     def __init__(self, model, loss_factory, optimizer, ema=None, total_epoch=300000, prefetch=True, world_size=1, grad_sync='flat',
-                 sync_occupancy=True, keep_corners=True, fuse_adam=True, fused_geo=True):
+                 sync_occupancy=True, keep_corners=True, fuse_adam=True, fused_geo=True, march_at='opt'):
         """world_size > 1: data parallel, one process per GPU, every rank its shard of the rays (the reference wraps the model in
         DistributedDataParallel, common/trainer/basic_trainer.py:192-198).  The flat gradient is SUMMED over the ranks between the backward
         and the optimiser - grad_sync 'flat': ONE all-reduce of the flattened optimiser's gradient buffer, then FusedAdam.step() on every
@@ -165,6 +165,14 @@ class FusedNeusNgpStep:
         # both two-layer geometry nets as one forward and one backward kernel each on the gather's level-major features (arcn_geo2_fwd / _bwd);
         # fused_geo=False: the chain of dense products + glue passes they replace (round 5's form, the A/B reference)
         self.fused_geo = bool(fused_geo) and self.keep_corners
+        # where in the step the coming batches' samplers are queued on the sampling stream (they share the chip with whatever follows):
+        # 'start' (before the foreground forward) | 'blend' (after both forwards: round 5's place) | 'fg_bwd' (after the background's backward) |
+        # 'opt' (behind the last scatter, beside the optimiser pass and the NEXT step's forward).  Measured (profiles/r6_ab_cfg4_march_at.txt):
+        # 1.36 / 1.34 / 1.38 / 1.26 ms - the cascade marcher (275 us of long serial waves) costs the MFMA-bound backward kernels it runs beside
+        # more than it costs the gathers
+        if march_at not in ('start', 'blend', 'fg_bwd', 'opt'):
+            raise RuntimeError('FusedNeusNgpStep: march_at must be start | blend | fg_bwd | opt')
+        self.march_at = march_at
         # the table scatters' chunk owners apply Adam to the levels they own alone (arcn_hashgrid_bwd_lm_adam / _first_second_adam): those levels'
         # gradients never go to HBM and the optimiser pass shrinks to the rest of the flat buffer.  fuse_adam=False (and every multi-rank
         # step): scatter, then one pass
@@ -315,9 +323,14 @@ class FusedNeusNgpStep:
             self._ahead = []
             h_bkg = bkg._sample_begin(rays_o, rays_d)      # (the order FullModel runs the two samplers in: each has its own generator anyway)
             h_fg = fg._sample_begin(rays_o, rays_d)
+        def ahead():
+            if self.prefetch and next_feed_in is not None:
+                self._march_ahead(next_feed_in if isinstance(next_feed_in, (list, tuple)) else [next_feed_in])
         pk = F.neus_pack_end(h_fg, float(fg.get_ray_cfgs('n_sample')))
         t_b, ray_b, off_b, pd_b, total_b = F.pack_dense_samples_end(h_bkg)
         S = pk['total']
+        if self.march_at == 'start':
+            ahead()
         # ---- foreground forward
         emb, l0, l1 = _sdf_net_form(fg.geo_net)
         rad = fg.radiance_net
@@ -395,8 +408,8 @@ class FusedNeusNgpStep:
             rgb_b = rays_o.new_ones((R, 3)) if bkg.get_ray_cfgs('white_bkg') else rays_o.new_zeros((R, 3))
             depth_b = rays_o.new_zeros((R,))
         # the samplers of the next batch, beside everything that follows
-        if self.prefetch and next_feed_in is not None:
-            self._march_ahead(next_feed_in if isinstance(next_feed_in, (list, tuple)) else [next_feed_in])
+        if self.march_at == 'blend':
+            ahead()
         # ---- blend + losses
         il = self.img_loss
         bl = F.neus_blend_loss(rgb_f, depth_f, t_last, rgb_b, depth_b, img, float(il.loss.delta) if isinstance(il.loss, HuberLoss) else None, self.img_w)
@@ -433,6 +446,8 @@ class FusedNeusNgpStep:
                 done += self._level_ranges(emb_b, F.hashgrid_bwd_adam(xyz_b, d_enc_b, emb_b.desc, tb.grad, tb, m_, v_, hyper, ws_b, level_stride=lm_b), o_)
             else:
                 F.hashgrid_bwd(xyz_b, tb, d_enc_b, emb_b.desc, dtable=tb.grad, workspace=ws_b, level_stride=lm_b)
+        if self.march_at == 'fg_bwd':
+            ahead()
         # ---- foreground backward
         if S > 0:
             zr = self._zeros(4 * R, dev)       # (read-only zero upstream gradients)
@@ -478,6 +493,8 @@ class FusedNeusNgpStep:
                 F.hashgrid_bwd_first_second(pts, d_enc, d_normal, jac, emb.desc, table.grad, ws_f)
             # scale = exp(inv_s * speed)
             F.sum_scale_add(d_s_ray, fg.inv_s.grad, float(fg.speed_factor), s_dev)
+        if self.march_at == 'opt':
+            ahead()
         # ---- optimiser
         if self.apply_optimizer:
             if fuse:
