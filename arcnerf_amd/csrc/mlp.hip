@@ -1050,6 +1050,82 @@ ngp_step_tail_kernel(TailNet na, TailNet nb, float *__restrict__ param, float *_
     adam_ema_run(param + lo, grad + lo, m + lo, v + lo, ema ? ema + lo : nullptr, cnt, bid - first, nb_run, a);
 }
 
+// ---- both NGP nets' forward in one kernel -----------------------------------------------------------------------------------------------
+// arcn_mlp_fwd_lm (geometry net 32 -> 64 -> 16 on level-major hash features) followed by arcn_mlp_fwd_cat (radiance net [geo_out | SH(ray)]
+// 32 -> 64 -> 64 -> 3) is the forward of EncoderMLP geometry + radiance (base_3d_model.py:233-254) in two launches with geo_out written by one
+// and read back by the other.  In the transposed-MFMA form the geometry net's output tile IS the radiance net's first operand tile (the same
+// K-permutation that keeps activations in registers between layers holds between the nets): one kernel, the weights of both staged once, 64
+// bytes per sample less read traffic and one launch + prologue less.  The same fragments and the same MFMA order as the two kernels:
+// bit-identical geo_out, sigma, saved activations and rgb.  ReLU hidden layers, linear geometry output, sigmoid radiance output compiled in
+// (the NGP nets of nerf_ngp.yaml).  Measured (profiles/r6_ab_fused_nets.txt): the step 0.547 -> 0.543 ms - these kernels are bound by the
+// f32 MFMA issue of waves that wait on their loads, not by their prologue.
+template <int NT>
+__global__ void __launch_bounds__(256)
+ngp_nets_fwd_kernel(const float *__restrict__ x, int64_t x_stride, const float *__restrict__ geo_w, MlpParams G, float *__restrict__ geo_out,
+                    MlpCat cat, const float *__restrict__ rad_w, MlpParams Rp, int rad_lds0, float *__restrict__ rgb, float *__restrict__ acts,
+                    int64_t n_cap, int64_t n, const int32_t *n_ptr) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int l = 0; l < 2; ++l) stage_fragments<false>(lds + G.lds_off[l], geo_w + G.w_off[l], G.dims[l + 1], G.dims[l]);
+    for (int l = 0; l < 3; ++l) stage_fragments<false>(lds + rad_lds0 + Rp.lds_off[l], rad_w + Rp.w_off[l], Rp.dims[l + 1], Rp.dims[l]);
+    __syncthreads();
+    const float *g0 = lds + G.lds_off[0], *g1 = lds + G.lds_off[1];
+    const float *r0 = lds + rad_lds0 + Rp.lds_off[0], *r1 = lds + rad_lds0 + Rp.lds_off[1], *r2 = lds + rad_lds0 + Rp.lds_off[2];
+    const int64_t cnt = dev_count(n, n_ptr);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+    constexpr int SPW = 16 * NT;
+    const int64_t n_tiles = ceil_div_dev(cnt, (int64_t)SPW * 4);
+    // (Tiles drawn from a ticket counter instead of striding were measured in round 6, profiles/r6_exp_sched.txt / r6_exp_sched_wave.txt: per
+    // workgroup - two barriers per tile - the step goes 0.534 -> 0.562 ms at 768 workgroups, worse at 512 and 1024: the barriers put the four
+    // waves in lockstep, and one wave's loads under another's MFMAs is what these kernels live on; per WAVE, no barriers: 0.54 -> 0.69 ms.)
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t s0 = tile * SPW * 4 + (int64_t)wave * SPW;
+        if (s0 >= cnt) continue;
+        f4 h[4][NT], o[4][NT];
+        load_tiles_lm2<2, NT>(h, x, x_stride, s0, cnt, g, j);
+        auto zero = [&](f4 (&a)[4][NT]) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) a[mt][nt] = f4{0.f, 0.f, 0.f, 0.f};
+        };
+        // geometry net: 2 -> 4 -> 1 tiles (its backward recomputes the hidden layer: nothing saved)
+        zero(o);
+        gemm_tiles<4, NT>(o, h, g0, 4, 2, lane);
+        act_tiles<4, NT>(o, ARCN_ACT_RELU, 0.f);
+        zero(h);
+        gemm_tiles<4, NT>(h, o, g1, 1, 4, lane);
+        // geo_out (n, 16) for the backward passes; sigma on the way; [geo_out | SH(ray)] as the radiance net's operand, straight from registers
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int64_t s = s0 + 16 * nt + j;
+            f4 fb = {0.f, 0.f, 0.f, 0.f};
+            const f4 fa = h[0][nt];
+            if (s < cnt) {
+                *reinterpret_cast<f4 *>(geo_out + s * 16 + 4 * g) = fa;
+                fb = *reinterpret_cast<const f4 *>(cat.b_table + (int64_t)cat.b_index[s] * 16 + 4 * g);
+                if (cat.head_out && g == 0) cat.head_out[s] = act_fwd(fa.x, cat.head_act, 1.0f);
+            }
+            h[0][nt] = cat.a_first ? fa : fb;
+            h[1][nt] = cat.a_first ? fb : fa;
+            h[2][nt] = f4{0.f, 0.f, 0.f, 0.f};
+            h[3][nt] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+        // radiance net: 2 -> 4 -> 4 -> 1 tiles, hidden activations saved in tile order
+        zero(o);
+        gemm_tiles<4, NT>(o, h, r0, 4, 2, lane);
+        act_tiles<4, NT>(o, ARCN_ACT_RELU, 0.f);
+        if (acts) store_tiles_frag<4, NT>(o, acts, s0, cnt, lane);
+        zero(h);
+        gemm_tiles<4, NT>(h, o, r1, 4, 4, lane);
+        act_tiles<4, NT>(h, ARCN_ACT_RELU, 0.f);
+        if (acts) store_tiles_frag<4, NT>(h, acts + pad16(n_cap) * 64, s0, cnt, lane);
+        zero(o);
+        gemm_tiles<4, NT>(o, h, r2, 1, 4, lane);
+        act_tiles<1, NT>(o, ARCN_ACT_SIGMOID, 0.f);
+        store_tiles_fast<1, NT>(o, rgb, Rp.dims[3], s0, cnt, g, j);
+    }
+}
+
 // ---- the two-layer geometry nets of the NeuS-on-hash-grid + MultiVol step (BASELINE config 4), fused ----------------------------------------
 // hash features (32, level-major) -> 64 (softplus beta | ReLU) -> n_out <= 32 = [sdf | features] or [log density | features], bias-free
 // (configs/neus_ngp_multivol.yaml; reference sdf_model.py:42-101, base_network.py:30-44, linear_network_module.py:174-197).  trainer.
@@ -1821,4 +1897,29 @@ ARCN_EXPORT int arcn_geo2_bwd(const float *x_lm, int64_t x_stride, const float *
     hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(4096 / kReduceElems, 2u), dim3(kReduceElems * kReduceSlices), 0, as_stream(stream), partials,
                        static_cast<const float *>(nullptr), D, (int)grid, dw1, static_cast<float *>(nullptr));
     return check_launch("geo2_bwd");
+}
+
+/* see include/arcnerf_hip.h */
+ARCN_EXPORT int arcn_ngp_nets_fwd(const float *x_lm, int64_t x_stride, const float *geo_w, const arcn_mlp_desc *geo_desc, float *geo_out,
+                                  const float *b_table, const int32_t *b_index, int a_first, const float *rad_w, const arcn_mlp_desc *rad_desc,
+                                  float *rgb, float *rad_acts, float *head_out, int head_act, int64_t n_cap, int64_t n, const int32_t *n_ptr,
+                                  void *stream) {
+    if (n <= 0) return ARCN_OK;
+    if (!x_lm || !geo_w || !geo_out || !b_table || !b_index || !rad_w || !rgb) return einval("ngp_nets_fwd: missing argument");
+    if (x_stride < n) return einval("ngp_nets_fwd: level stride smaller than n");
+    MlpParams G, R;
+    int lg, lr, md, rc;
+    if ((rc = build_mlp_params(geo_desc, G, false, &lg, &md))) return rc;
+    if ((rc = build_mlp_params(rad_desc, R, false, &lr, &md))) return rc;
+    const bool geo_ok = G.n_layers == 2 && !G.has_bias && G.dims[0] == 32 && G.dims[1] == 64 && G.dims[2] == 16 && G.act_hidden == ARCN_ACT_RELU &&
+                        G.act_out == ARCN_ACT_NONE;
+    const bool rad_ok = R.n_layers == 3 && !R.has_bias && R.dims[0] == 32 && R.dims[1] == 64 && R.dims[2] == 64 && R.dims[3] >= 1 && R.dims[3] <= 16 &&
+                        R.act_hidden == ARCN_ACT_RELU && R.act_out == ARCN_ACT_SIGMOID;
+    if (!geo_ok || !rad_ok)
+        return einval("ngp_nets_fwd: wired for the bias-free NGP nets (32 -> 64 ReLU -> 16 linear; 32 -> 64 -> 64 ReLU -> <= 16 sigmoid)");
+    MlpCat cat = {b_table, b_index, head_out, nullptr, a_first ? 1 : 0, head_act};
+    const size_t lds_bytes = sizeof(float) * (size_t)(lg + lr);
+    hipLaunchKernelGGL((ngp_nets_fwd_kernel<2>), dim3(tile_grid(n, 128, kSlimGrid)), dim3(256), lds_bytes, as_stream(stream), x_lm, x_stride, geo_w, G,
+                       geo_out, cat, rad_w, R, lg, rgb, rad_acts, n_cap, n, n_ptr);
+    return check_launch("ngp_nets_fwd");
 }

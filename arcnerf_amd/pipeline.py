@@ -203,7 +203,7 @@ class NgpPipeline:
 
     def __init__(self, field, max_rays=32768, max_samples=1 << 19, packed_bits=True, torch_aabb=False, xcd_scatter=True, level_major=True, fused_glue=True,
                  prefetch_depth=None, prefetch_at=None, march_waves=None, aux_priority=None, occ_async=True, fused_composite=True, fuse_adam=True,
-                 step_tail=True, march_cull=True, planned_scatter=False):
+                 step_tail=True, march_cull=True, planned_scatter=False, fused_nets=True):
         """The keyword switches select the measured alternatives of the step's schedule (defaults = the product path): prefetch_depth
         batches marched ahead, prefetch_at = where in the step the next marching is issued (_prefetch_point), march_waves = persistent
         wavefronts of a marching launch with slack, aux_priority = priority of the sampling stream, occ_async = the occupancy refresh on its
@@ -211,7 +211,8 @@ class NgpPipeline:
         optimiser, step_tail = the end of the step as one launch, march_cull = the marcher's ray-culling grid, planned_scatter = the
         position-only half of the table scatter (arcn_hashgrid_bwd_plan) computed with a batch marched ahead, on the sampling stream (OFF:
         the scatter's own bracket drops from 0.178 to 0.145 ms, but on one GPU the plan pass shares the chip with the step's kernels and the
-        step is 0.655 against 0.540 ms - DESIGN.md; it pays where the sampling stream has idle compute units beside it)."""
+        step is 0.655 against 0.540 ms - DESIGN.md; it pays where the sampling stream has idle compute units beside it), fused_nets = both
+        nets' forward as one kernel (arcn_ngp_nets_fwd: bit-identical to the two launches it replaces)."""
         cfg = field.cfg
         self.field, self.cfg = field, cfg
         dev = field.device
@@ -323,8 +324,13 @@ class NgpPipeline:
                                not field.rad_desc.has_bias and field.rad_desc.n_layers in (2, 3) and rd[0] == 32 and
                                all(48 < w <= 64 for w in rd[1:-1]) and rd[-1] <= 16)
         gd = [field.geo_desc.dims[i] for i in range(field.geo_desc.n_layers + 1)]
+        self._want_fused_nets = bool(fused_nets)
         self.level_major = bool(level_major and xcd_scatter and cfg.n_feat_per_entry == 2 and field.geo_desc.n_layers == 2 and
                                 not field.geo_desc.has_bias and gd[0] in (32, 64) and 48 < gd[1] <= 64 and gd[2] <= 16)
+        gdsc, rdsc = field.geo_desc, field.rad_desc
+        self.fused_nets = bool(self._want_fused_nets and self.level_major and self.fused_glue and gd == [32, 64, 16] and rd[:3] == [32, 64, 64] and
+                               len(rd) == 4 and gdsc.act_hidden == N.ACT['relu'] and gdsc.act_out == N.ACT[None] and
+                               rdsc.act_hidden == N.ACT['relu'] and rdsc.act_out == N.ACT['sigmoid'])
         # planned scatter: a batch marched AHEAD (prefetch_samples, sampling stream) also gets the scatter's position-only half - cells, runs,
         # rows, bins, ranks, the records' index halves - into a plan workspace of its own (one per sample-buffer set); the step then runs the
         # fill pass + the chunk owners (arcn_hashgrid_bwd_lm[_adam]_planned).  A batch sampled inline keeps the one-pass scatter.
@@ -613,13 +619,22 @@ class NgpPipeline:
                 # gather instead of beside it
                 carry, self._carry_rays = self._carry_rays, None
                 self.prefetch_samples(*carry, noise=True)
-            N.check(L.arcn_mlp_fwd_lm(N.ptr(b['feat']), S, N.ptr(self._p('geo_w')), N.C.addressof(fld.geo_desc), N.ptr(b['geo_out']),
-                                      N.ptr(b['geo_acts']) if train else None, S, S, n_dev.data_ptr(), st), 'mlp_fwd_lm(geo)')
+            if self.fused_nets:
+                # both nets in one kernel: the geometry net's output tile is the radiance net's operand without leaving the registers
+                N.check(L.arcn_ngp_nets_fwd(N.ptr(b['feat']), S, N.ptr(self._p('geo_w')), N.C.addressof(fld.geo_desc), N.ptr(b['geo_out']),
+                                            N.ptr(b['sh_ray']), N.ptr(b['ray_id']), int(cfg.rad_mode == 'fv'), N.ptr(self._p('rad_w')),
+                                            N.C.addressof(fld.rad_desc), N.ptr(b['rgb_s']), N.ptr(b['rad_acts']) if train else None, N.ptr(b['sigma']),
+                                            N.ACT[cfg.sigma_act], S, S, n_dev.data_ptr(), st), 'ngp_nets_fwd')
+            else:
+                N.check(L.arcn_mlp_fwd_lm(N.ptr(b['feat']), S, N.ptr(self._p('geo_w')), N.C.addressof(fld.geo_desc), N.ptr(b['geo_out']),
+                                          N.ptr(b['geo_acts']) if train else None, S, S, n_dev.data_ptr(), st), 'mlp_fwd_lm(geo)')
         else:
             F.hashgrid_fwd(b['xyz'], self._p('table'), fld.grid_desc, n_dev=n_dev, out=b['feat'])
             F.mlp_fwd(b['feat'], self._p('geo_w'), self._p('geo_b'), fld.geo_desc, save_acts=train, n_dev=n_dev, out=b['geo_out'],
                       acts=b['geo_acts'])
-        if self.fused_glue:
+        if self.level_major and self.fused_nets:
+            pass
+        elif self.fused_glue:
             # view-direction harmonics once per ray; the radiance net assembles [geo features | SH(ray)] in its operand load and
             # writes sigma = act(geo_out[:, 0]) on the way: no rad_in buffer, no glue kernel
             N.check(L.arcn_mlp_fwd_cat(N.ptr(b['geo_out']), N.ptr(b['sh_ray']), N.ptr(b['ray_id']), int(cfg.rad_mode == 'fv'),

@@ -629,7 +629,8 @@ def main():
     field = NgpField(cfg, device=dev, seed=0)  # identical init on every rank (DDP broadcasts rank 0's, same effect)
     # the ray batches of a run are known in advance (the reference precaches and shuffles them on the GPU): march two steps ahead
     pipe = NgpPipeline(field, max_rays=32768, max_samples=1 << 20, packed_bits=True, prefetch_depth=2,
-                       planned_scatter=os.environ.get('ARCN_PLANNED_SCATTER', '0') == '1')      # (=1: the planned scatter, the A/B of DESIGN.md)
+                       planned_scatter=os.environ.get('ARCN_PLANNED_SCATTER', '0') == '1',      # (=1: the planned scatter, the A/B of DESIGN.md)
+                       fused_nets=os.environ.get('ARCN_FUSED_NETS', '1') != '0')                # (=0: the two nets' forward as two launches)
     bf = synthetic_bitfield(cfg.n_grid, args.occupancy, seed=0)
     pipe.set_bitfield(torch.from_numpy(bf))
 

@@ -487,6 +487,16 @@ int arcn_mlp_fwd_lm(const float *x_lm, int64_t x_stride, const float *weights, c
 int arcn_mlp_bwd_lm(const float *x_lm, int64_t x_stride, const float *weights, const arcn_mlp_desc *desc_host, const float *out,
                     const float *acts, const float *dout, float *dx_lm, float *dweights, float *scratch, int defer_reduce,
                     int64_t n_cap, int64_t n, const int32_t *n_ptr, void *stream);
+/* arcn_mlp_fwd_lm (the geometry net) followed by arcn_mlp_fwd_cat (the radiance net on [geo_out | b_table[b_index]] / [b_table[b_index] |
+ * geo_out]) in ONE kernel for the NGP nets of nerf_ngp.yaml - bias-free 32 -> 64 (ReLU) -> 16 (linear) and 32 -> 64 -> 64 (ReLU) -> <= 16
+ * (sigmoid): the geometry net's output tile is the radiance net's first operand without leaving the registers.  The same arguments, the same
+ * outputs BIT FOR BIT as the two calls (geo_out (n, 16), head_out = act(geo_out[:, 0]), rgb, rad_acts in the opaque tile order of
+ * arcn_mlp_fwd_cat; the geometry net saves nothing - arcn_mlp_bwd_lm recomputes its hidden layer).  -1 for any other pair of nets.
+ * Reference: Base3dModel._forward_pts_dir (base_3d_model.py:233-254) on tcnn_fusedmlp_module.py:66-77,162-192. */
+int arcn_ngp_nets_fwd(const float *x_lm, int64_t x_stride, const float *geo_w, const arcn_mlp_desc *geo_desc, float *geo_out,
+                      const float *b_table, const int32_t *b_index, int a_first, const float *rad_w, const arcn_mlp_desc *rad_desc,
+                      float *rgb, float *rad_acts, float *head_out, int head_act, int64_t n_cap, int64_t n, const int32_t *n_ptr,
+                      void *stream);
 /* The radiance net of Base3dModel._forward_pts_dir (base_3d_model.py:233-254) with fuse_radiance_inputs
  * (encoder_mlp_network.py:93-118) folded into the first layer's operand load: x = [a | b] (a_first) or [b | a], 16 columns each,
  * a (n,16) row-major per sample (the geometry net's output), b = b_table[b_index[s]] (arcn_ngp_ray_sh rows by ray id).

@@ -101,3 +101,45 @@ def test_geo2_argument_checks(gpu):
     w1, w2 = torch.zeros(64, 32, device=gpu), torch.zeros(40, 64, device=gpu)
     with pytest.raises(RuntimeError):
         F.geo2_fwd(x, 16, w1, w2, True, 1.0)          # more than 32 outputs
+
+
+@pytest.mark.parametrize('S,feat_first,rgb_w', [(7001, True, 3), (128, False, 3), (50000, True, 16)])
+def test_both_ngp_nets_in_one_kernel_equal_the_two_launches_bit_for_bit(gpu, S, feat_first, rgb_w):
+    """arcn_ngp_nets_fwd = arcn_mlp_fwd_lm (geometry net) + arcn_mlp_fwd_cat (radiance net on [geo_out | SH(ray)]): the same fragments in the
+    same MFMA order, the geometry net's output tile handed over in registers - geo_out, sigma, the saved activations and rgb must be the SAME
+    BITS (base_3d_model.py:233-254 on the fused MLPs of tcnn_fusedmlp_module.py:66-77)."""
+    import ctypes as C
+    from arcnerf_amd import _native as N
+    from arcnerf_amd.ops import functional as F
+    g = torch.Generator().manual_seed(S)
+    R = 97
+    cap = S + 13                                      # capacity above the count: the level stride and the activation layout follow the capacity
+    lm = (torch.randn(16 * cap * 2, generator=g) * 0.5).to(gpu)
+    ray_id = torch.sort(torch.randint(0, R, (cap,), generator=g)).values.int().to(gpu)
+    sh_ray = torch.randn(R, 16, generator=g).to(gpu)
+    gd, rd = N.make_mlp_desc([32, 64, 16], 'relu', None), N.make_mlp_desc([32, 64, 64, rgb_w], 'relu', 'sigmoid')
+    gw = (torch.randn(32 * 64 + 64 * 16, generator=g) * 0.2).to(gpu)
+    rw = (torch.randn(32 * 64 + 64 * 64 + 64 * rgb_w, generator=g) * 0.2).to(gpu)
+    n_dev = torch.tensor([S], dtype=torch.int32, device=gpu)
+    lib, st = N.lib(), N.stream()
+
+    def bufs():
+        return (torch.full((cap, 16), 7.0, device=gpu), torch.full((cap, rgb_w), 7.0, device=gpu), torch.full((F.mlp_acts_floats(rd, cap),), 7.0, device=gpu),
+                torch.full((cap,), 7.0, device=gpu))
+    geo_a, rgb_a, acts_a, sig_a = bufs()
+    N.check(lib.arcn_mlp_fwd_lm(N.ptr(lm), cap, N.ptr(gw), C.addressof(gd), N.ptr(geo_a), None, cap, cap, N.ptr(n_dev), st))
+    N.check(lib.arcn_mlp_fwd_cat(N.ptr(geo_a), N.ptr(sh_ray), N.ptr(ray_id), int(feat_first), N.ptr(rw), C.addressof(rd), N.ptr(rgb_a), N.ptr(acts_a),
+                                 N.ptr(sig_a), N.ACT['truncexp'], cap, cap, N.ptr(n_dev), st))
+    geo_b, rgb_b, acts_b, sig_b = bufs()
+    N.check(lib.arcn_ngp_nets_fwd(N.ptr(lm), cap, N.ptr(gw), C.addressof(gd), N.ptr(geo_b), N.ptr(sh_ray), N.ptr(ray_id), int(feat_first), N.ptr(rw),
+                                  C.addressof(rd), N.ptr(rgb_b), N.ptr(acts_b), N.ptr(sig_b), N.ACT['truncexp'], cap, cap, N.ptr(n_dev), st))
+    assert torch.equal(geo_a, geo_b) and torch.equal(sig_a, sig_b) and torch.equal(rgb_a, rgb_b) and torch.equal(acts_a, acts_b)
+    assert float(geo_b[S:].min()) == 7.0 and float(rgb_b[S:].min()) == 7.0          # rows behind the device-side count are left alone
+    # inference: no saved activations; other nets are refused
+    rgb_c = torch.zeros_like(rgb_b)
+    N.check(lib.arcn_ngp_nets_fwd(N.ptr(lm), cap, N.ptr(gw), C.addressof(gd), N.ptr(geo_b), N.ptr(sh_ray), N.ptr(ray_id), int(feat_first), N.ptr(rw),
+                                  C.addressof(rd), N.ptr(rgb_c), None, None, 0, cap, S, None, st))
+    assert torch.equal(rgb_c[:S], rgb_a[:S])
+    bad = N.make_mlp_desc([32, 64, 16], 'softplus', None)
+    assert lib.arcn_ngp_nets_fwd(N.ptr(lm), cap, N.ptr(gw), C.addressof(bad), N.ptr(geo_b), N.ptr(sh_ray), N.ptr(ray_id), 1, N.ptr(rw), C.addressof(rd),
+                                 N.ptr(rgb_c), None, None, 0, cap, S, None, st) == -1

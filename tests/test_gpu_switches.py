@@ -32,6 +32,7 @@ GROUPS = {
         {'kw': {'step_tail': False, 'march_cull': False}},   # dW reductions, rest of the optimiser and the counter fill as four launches instead of one; no ray culling
         {'kw': {'march_waves': 256}},             # the marching of the batches in flight as 256 persistent wavefronts (4 rays each here): the same samples
         {'kw': {'planned_scatter': True}},        # the scatter's position-only half with the batches marched ahead (arcn_hashgrid_bwd_plan), fill pass + owners in the step
+        {'kw': {'fused_nets': False}},            # the two nets' forward as two launches (arcn_mlp_fwd_lm + arcn_mlp_fwd_cat) instead of arcn_ngp_nets_fwd
         {'kw': {'prefetch_at': 5, 'aux_priority': -1}},   # the marching chain issued behind the NEXT step's gather; the sampling stream at the high priority
     ],
     'neusngp': [
