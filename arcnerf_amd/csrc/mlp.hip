@@ -1173,6 +1173,23 @@ __device__ __forceinline__ void zero_tiles(f4 (&a)[4][NT]) {
 
 constexpr int kGeo2Frag = 8 * kFragTile;   // floats of one staged 64 x 32 (or 32 x 64) weight: 8 fragments
 
+// softplus_beta(z) AND its derivative sigmoid(beta z) from ONE exponential: with t = beta z, e = exp(-|t|), u = 1 + e,
+//   h = (max(t, 0) + log(u)) / beta,   s = 1 / u (t >= 0) or e / u (t < 0)        [= 1 - exp(-beta h), the from_y derivative]
+// on the hardware exp2 / log2 / rcp (1 ulp each); the rounding of u = 1 + e is put back to first order ((e - (u - 1)) / u), so log1p keeps
+// its accuracy for small e.  |error| <= ~2e-7 of the values (the libm chain expf -> log1pf -> expf it replaces: 3e-8), a fifth of the
+// instructions: the sdf net's kernels were bound by that chain, not by their MFMAs (5.7 K VALU instructions around 192 MFMAs per tile);
+// config 4's step 1.259 -> 1.191 ms in three alternations on one box (profiles/r6_ab_cfg4_softplus.txt).
+// torch's threshold (beta z > 20: y = z) is what the formula gives there to the last bit or one ulp (log(u) < 2.1e-9).
+__device__ __forceinline__ void softplus_and_slope(float z, float beta, float inv_beta, float &h, float &sl) {
+    const float t = beta * z;
+    const float e = __builtin_amdgcn_exp2f(-fabsf(t) * 1.44269504088896341f);
+    const float u = 1.0f + e;
+    const float r = __builtin_amdgcn_rcpf(u);
+    const float l = __builtin_amdgcn_logf(u) * 0.693147180559945309f + (e - (u - 1.0f)) * r;
+    h = (fmaxf(t, 0.f) + l) * inv_beta;
+    sl = t >= 0.f ? r : e * r;
+}
+
 template <bool JAC>
 __global__ void __launch_bounds__(256)
 geo2_fwd_kernel(const float *__restrict__ x, int64_t x_stride, const float *__restrict__ w1, const float *__restrict__ w2, int n_out, int n_pad,
@@ -1190,6 +1207,7 @@ geo2_fwd_kernel(const float *__restrict__ x, int64_t x_stride, const float *__re
     f4 w20[4];   // W2[0] at this lane's hidden neurons 16 t + 4 g ..
 #pragma unroll
     for (int t = 0; t < 4; ++t) w20[t] = JAC ? *reinterpret_cast<const f4 *>(w2 + 16 * t + 4 * g) : f4{0.f, 0.f, 0.f, 0.f};
+    const float inv_beta = 1.0f / beta;
     constexpr int SPW = 16 * NT;
     const int64_t n_tiles = ceil_div_dev(cnt, (int64_t)SPW * 4);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -1199,7 +1217,22 @@ geo2_fwd_kernel(const float *__restrict__ x, int64_t x_stride, const float *__re
         load_tiles_lm2<2, NT>(h, x, x_stride, s0, cnt, g, j);
         zero_tiles<NT>(o);
         gemm_tiles<4, NT>(o, h, f_w1, 4, 2, lane);
-        act_tiles<4, NT>(o, JAC ? ARCN_ACT_SOFTPLUS : ARCN_ACT_RELU, beta);
+        f4 pj[4][NT];      // (JAC) s * W2[0]: the Jacobian row's operand, from the same exponential as the activation
+        if (JAC) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float hv, sv;
+                        softplus_and_slope(o[t][nt][r], beta, inv_beta, hv, sv);
+                        o[t][nt][r] = hv;
+                        pj[t][nt][r] = sv * w20[t][r];
+                    }
+        } else {
+            act_tiles<4, NT>(o, ARCN_ACT_RELU, beta);
+        }
         zero_tiles<NT>(h);
         gemm_tiles<4, NT>(h, o, f_w2, MT2, 4, lane);
 #pragma unroll
@@ -1216,18 +1249,9 @@ geo2_fwd_kernel(const float *__restrict__ x, int64_t x_stride, const float *__re
             if (g == 0 && head) head[s] = JAC ? h[0][nt].x : expf(h[0][nt].x);
         }
         if (JAC) {
-            // p = s * W2[0] over the hidden layer, jac = W1^T p
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    o[t][nt].x = (1.0f - expf(-beta * o[t][nt].x)) * w20[t].x;
-                    o[t][nt].y = (1.0f - expf(-beta * o[t][nt].y)) * w20[t].y;
-                    o[t][nt].z = (1.0f - expf(-beta * o[t][nt].z)) * w20[t].z;
-                    o[t][nt].w = (1.0f - expf(-beta * o[t][nt].w)) * w20[t].w;
-                }
+            // jac = W1^T (s * W2[0])
             zero_tiles<NT>(h);
-            gemm_tiles<4, NT>(h, o, f_w1t, 2, 4, lane);
+            gemm_tiles<4, NT>(h, pj, f_w1t, 2, 4, lane);
             store_tiles_fast<2, NT>(h, jac, 32, s0, cnt, g, j);
         }
     }
@@ -1261,6 +1285,7 @@ geo2_bwd_kernel(const float *__restrict__ x, int64_t x_stride, const float *__re
 #pragma unroll
         for (int b = 0; b < 2; ++b) { acc1[a][b] = f4{0.f, 0.f, 0.f, 0.f}; acc2[b][a] = f4{0.f, 0.f, 0.f, 0.f}; }
     const float e0 = j == 0 ? 1.0f : 0.0f;      // the A operand of "row 0 += column sums": neuron i = lane & 15 of every sample
+    const float inv_beta = 1.0f / beta;
     constexpr int SPW = 16 * NT;
     const int64_t n_tiles = ceil_div_dev(cnt, (int64_t)SPW * 4);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -1296,7 +1321,22 @@ geo2_bwd_kernel(const float *__restrict__ x, int64_t x_stride, const float *__re
         // the hidden layer again: the fragments and the MFMA order of the forward
         zero_tiles<NT>(h);
         gemm_tiles<4, NT>(h, xt, f_w1, 4, 2, lane);
-        act_tiles<4, NT>(h, JAC ? ARCN_ACT_SOFTPLUS : ARCN_ACT_RELU, beta);
+        f4 sl[4][NT];      // (JAC) the activation's slope, from the same exponential as the activation (the forward's arithmetic)
+        if (JAC) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float hv, sv;
+                        softplus_and_slope(h[t][nt][r], beta, inv_beta, hv, sv);
+                        h[t][nt][r] = hv;
+                        sl[t][nt][r] = sv;
+                    }
+        } else {
+            act_tiles<4, NT>(h, ARCN_ACT_RELU, beta);
+        }
         dw_accumulate<2, 4, NT>(acc2, gt, h, trA, trB, tr_wr, tr_rd);
         zero_tiles<NT>(d);
         gemm_tiles<4, NT>(d, gt, f_w2t, 4, MT2, lane);            // dh = W2^T g
@@ -1312,7 +1352,7 @@ geo2_bwd_kernel(const float *__restrict__ x, int64_t x_stride, const float *__re
                 for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float sv = 1.0f - expf(-beta * h[t][nt][r]);
+                        const float sv = sl[t][nt][r];
                         const float su = sv * u[t][nt][r];
                         d[t][nt][r] = d[t][nt][r] * sv + (beta * w20[r]) * su * (1.0f - sv);
                         h[t][nt][r] = sv * w20[r];        // sw: the operand of the Jacobian path's first-layer gradient
@@ -1846,7 +1886,7 @@ ARCN_EXPORT int arcn_geo2_fwd(const float *x_lm, int64_t x_stride, const float *
     if (!out || n_pad < n_out || (n_pad & 3) || n_pad > 32 || (jac_mode && !jac)) return einval("geo2_fwd: out (n, n_pad), n_pad a multiple of 4 in n_out..32; jac in Jacobian mode");
     if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(jac)) & 15) return einval("geo2_fwd: 16-byte aligned outputs");
     const size_t lds_bytes = sizeof(float) * 3 * kGeo2Frag;
-    const unsigned grid = tile_grid(n, 128, kSlimGrid);
+    const unsigned grid = tile_grid(n, 128, kSlimGrid);      // (512 .. 2048 workgroups measured: 35 - 39 us, flat)
     if (jac_mode)
         hipLaunchKernelGGL(geo2_fwd_kernel<true>, dim3(grid), dim3(256), lds_bytes, as_stream(stream), x_lm, x_stride, w1, w2, n_out, n_pad, beta, out, head,
                            jac, n, n_ptr);
@@ -1857,7 +1897,7 @@ ARCN_EXPORT int arcn_geo2_fwd(const float *x_lm, int64_t x_stride, const float *
 }
 
 static int64_t geo2_slots(int64_t n) {
-    int64_t grid = tile_grid(n, 64);
+    int64_t grid = tile_grid(n, 64);      // (at most 512 workgroups = two per CU; 1024 / 2048 measured: 58 -> 66 / 78 us)
     return grid;
 }
 
