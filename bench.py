@@ -480,7 +480,7 @@ def bench_module(args, name, emit=True):
     return out
 
 
-def dist1_leg(sync, steps, warmup):
+def dist1_leg(sync, steps, warmup, config=None):
     """The N > 1 code path at its single-GPU price: the headline command re-run in a child with a ONE-rank RCCL communicator (ARCN_DIST_FORCE=1) -
     scatter -> collective on the 48.8 MB flat gradient -> optimiser pass, instead of the optimiser fused into the scatter's consumer.  The only
     multi-GPU number a one-GPU box can give (common/trainer/basic_trainer.py:192-198 wraps the model in DDP: this is that step's per-GPU cost)."""
@@ -494,17 +494,20 @@ def dist1_leg(sync, steps, warmup):
     env.update({'ARCN_DIST_FORCE': '1', 'ARCN_GRAD_SYNC': sync, 'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '1', 'MASTER_ADDR': '127.0.0.1',
                 'MASTER_PORT': str(port), 'HSA_ENABLE_IPC_MODE_LEGACY': env.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')})
     cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(steps), '--warmup', str(warmup), '--no-cpu-baseline', '--no-other-configs', '--no-psnr']
+    if config is not None:      # (a module config: BASELINE config 4 through trainer.FusedNeusNgpStep(world_size, grad_sync) on the one-rank communicator)
+        cmd += ['--config', config]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     line = [l for l in r.stdout.splitlines() if l.startswith('{')]
     if r.returncode != 0 or not line:
         return {'error': 'rc {}: {}'.format(r.returncode, r.stderr[-400:])}
     j = json.loads(line[-1])
     rc = j.get('rccl') or {}
-    return {'ms_per_step': j['ms_per_step'], 'ms_per_step_p50': j['step_ms_spread']['p50'], 'samples_per_s': j['value'], 'steps': steps, 'warmup': warmup,
+    p50 = (j.get('step_ms_spread') or {}).get('p50') or ((j.get('config') or {}).get('step_ms_device') or {}).get('p50')
+    return {'ms_per_step': j['ms_per_step'], 'ms_per_step_p50': p50, 'samples_per_s': j['value'], 'steps': steps, 'warmup': warmup,
             'grad_sync': rc.get('grad_sync'), 'backend': rc.get('backend'), 'world_size_seen': rc.get('world_size_seen'),
             'exposed_ms': rc.get('exposed_ms'), 'exposed_ms_max': rc.get('exposed_ms_max'), 'allreduce_alone_ms': rc.get('allreduce_alone_ms'),
             'allreduce_bytes_per_step': rc.get('allreduce_bytes_per_step'),
-            'workload': 'the headline step through the N > 1 path on a one-rank RCCL communicator (ARCN_DIST_FORCE=1, ARCN_GRAD_SYNC={})'.format(sync)}
+            'workload': 'the {} step through the N > 1 path on a one-rank RCCL communicator (ARCN_DIST_FORCE=1, ARCN_GRAD_SYNC={})'.format(config or 'headline', sync)}
 
 
 def inference_leg(dev, occupancy, images=4):
@@ -924,6 +927,15 @@ def main():
                 others['ngp_dist1_' + sync] = leg
             except Exception as e:
                 others['ngp_dist1_' + sync] = {'error': repr(e)}
+        # BASELINE config 4 - the 8-GPU config - likewise: trainer.FusedNeusNgpStep(world_size, grad_sync='flat') on the one-rank communicator
+        # (scatters -> ONE all-reduce of the 97.6 MB flat gradient -> one optimiser pass) against the fused single-GPU step of the leg above
+        try:
+            leg = dist1_leg('flat', 32, 8, config='neus_ngp_multivol')
+            if 'ms_per_step' in leg and 'ms_per_step' in others.get('neus_ngp_multivol', {}):
+                leg['delta_ms_to_fused_step'] = leg['ms_per_step'] - others['neus_ngp_multivol']['ms_per_step']
+            others['neus_ngp_multivol_dist1_flat'] = leg
+        except Exception as e:
+            others['neus_ngp_multivol_dist1_flat'] = {'error': repr(e)}
 
     # PSNR@iter, the second half of BASELINE's metric, with the reference's RECIPE through the drop-in API (tools/psnr_recipe.py): no dataset
     # on the box, so the scene is analytic - six soft textured blobs rendered once to 100 training views of 320 x 320 RGBA bytes + 4 held
