@@ -1214,7 +1214,8 @@ geo2_fwd_kernel(const float *__restrict__ x, int64_t x_stride, const float *__re
         const int64_t s0 = tile * SPW * 4 + (int64_t)wave * SPW;
         if (s0 >= cnt) continue;
         f4 h[4][NT], o[4][NT];
-        load_tiles_lm2<2, NT>(h, x, x_stride, s0, cnt, g, j);
+        if (x_stride) load_tiles_lm2<2, NT>(h, x, x_stride, s0, cnt, g, j);
+        else load_tiles_fast<2, NT>(h, x, 32, s0, cnt, g, j);      // (x_stride 0: (n, 32) rows - HashGridEmbedder.forward's output, the module path)
         zero_tiles<NT>(o);
         gemm_tiles<4, NT>(o, h, f_w1, 4, 2, lane);
         f4 pj[4][NT];      // (JAC) s * W2[0]: the Jacobian row's operand, from the same exponential as the activation
@@ -1260,7 +1261,7 @@ geo2_fwd_kernel(const float *__restrict__ x, int64_t x_stride, const float *__re
 template <bool JAC, int NT>
 __global__ void __launch_bounds__(256, 2)
 geo2_bwd_kernel(const float *__restrict__ x, int64_t x_stride, const float *__restrict__ w1, const float *__restrict__ w2, int n_out, float beta,
-                const float *__restrict__ d_col0, const float *__restrict__ out_col0, int64_t ld_out, const float *__restrict__ d_feat,
+                const float *__restrict__ d_col0, int64_t ld_col0, const float *__restrict__ out_col0, int64_t ld_out, const float *__restrict__ d_feat,
                 int64_t ld_feat, const float *__restrict__ d_jac, float *__restrict__ dx, int64_t dx_stride, float *__restrict__ partials,
                 int n_slots, int64_t n, const int32_t *n_ptr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1292,7 +1293,8 @@ geo2_bwd_kernel(const float *__restrict__ x, int64_t x_stride, const float *__re
         const int64_t s0 = tile * SPW * 4 + (int64_t)wave * SPW;
         if (s0 >= cnt) continue;
         f4 xt[4][NT], h[4][NT], gt[4][NT], d[4][NT];
-        load_tiles_lm2<2, NT>(xt, x, x_stride, s0, cnt, g, j);
+        if (x_stride) load_tiles_lm2<2, NT>(xt, x, x_stride, s0, cnt, g, j);
+        else load_tiles_fast<2, NT>(xt, x, 32, s0, cnt, g, j);
         // the output gradient from its pieces: column 0 (through the head's activation), the feature columns, zeros behind them
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -1307,7 +1309,7 @@ geo2_bwd_kernel(const float *__restrict__ x, int64_t x_stride, const float *__re
                     v[r] = 0.f;
                     if (ok && c < n_out) {
                         if (c == 0) {
-                            v[r] = d_col0[s];
+                            v[r] = d_col0[s * ld_col0];
                             if (!JAC) { float pre = out_col0[s * ld_out]; pre = pre < -15.f ? -15.f : (pre > 15.f ? 15.f : pre); v[r] *= expf(pre); }
                         } else {
                             v[r] = d_feat[s * ld_feat + (c - 1)];
@@ -1873,8 +1875,9 @@ static int geo2_check(const float *x_lm, int64_t x_stride, const float *w1, cons
     (void)who;
     if (!x_lm || !w1 || !w2) return einval("geo2: missing argument");
     if (n_out < 1 || n_out > 32) return einval("geo2: 1..32 outputs");
-    if (x_stride < n) return einval("geo2: level stride smaller than n");
-    if ((reinterpret_cast<uintptr_t>(x_lm) & 7) || (reinterpret_cast<uintptr_t>(w2) & 15)) return einval("geo2: features 8-byte, last layer 16-byte aligned");
+    if (x_stride != 0 && x_stride < n) return einval("geo2: level stride smaller than n (0: row-major features)");
+    if ((reinterpret_cast<uintptr_t>(x_lm) & (x_stride ? 7 : 15)) || (reinterpret_cast<uintptr_t>(w2) & 15))
+        return einval("geo2: level-major features 8-byte, row-major features and the last layer 16-byte aligned");
     return ARCN_OK;
 }
 
@@ -1904,12 +1907,13 @@ static int64_t geo2_slots(int64_t n) {
 ARCN_EXPORT int64_t arcn_geo2_bwd_scratch_floats(int64_t n) { return n <= 0 ? 0 : 2 * geo2_slots(n) * 4096; }
 
 ARCN_EXPORT int arcn_geo2_bwd(const float *x_lm, int64_t x_stride, const float *w1, const float *w2, int n_out, int jac_mode, float beta,
-                              const float *d_col0, const float *out_col0, int64_t ld_out, const float *d_feat, int64_t ld_feat, const float *d_jac,
-                              float *dx, int64_t dx_stride, float *dw1, float *dw2, float *scratch, int64_t n, const int32_t *n_ptr, void *stream) {
+                              const float *d_col0, int64_t ld_col0, const float *out_col0, int64_t ld_out, const float *d_feat, int64_t ld_feat,
+                              const float *d_jac, float *dx, int64_t dx_stride, float *dw1, float *dw2, float *scratch, int64_t n, const int32_t *n_ptr,
+                              void *stream) {
     if (n <= 0) return ARCN_OK;
     int rc;
     if ((rc = geo2_check(x_lm, x_stride, w1, w2, n_out, n, "geo2_bwd"))) return rc;
-    if (!d_col0 || (n_out > 1 && (!d_feat || ld_feat < n_out - 1)) || !dw1 || !dw2 || !scratch) return einval("geo2_bwd: missing argument");
+    if (!d_col0 || ld_col0 < 1 || (n_out > 1 && (!d_feat || ld_feat < n_out - 1)) || !dw1 || !dw2 || !scratch) return einval("geo2_bwd: missing argument");
     if (jac_mode ? !d_jac : (!out_col0 || ld_out < 1)) return einval("geo2_bwd: d_jac (Jacobian mode) or the forward's output column 0 (density mode) missing");
     if (dx_stride && dx_stride < n) return einval("geo2_bwd: level stride of dx smaller than n");
     if ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(d_jac)) & 15) return einval("geo2_bwd: 16-byte aligned dx / d_jac");
@@ -1921,11 +1925,11 @@ ARCN_EXPORT int arcn_geo2_bwd(const float *x_lm, int64_t x_stride, const float *
     if (jac_mode) {
         if ((rc = set_lds(geo2_bwd_kernel<true, 1>, lds_bytes))) return rc;
         hipLaunchKernelGGL((geo2_bwd_kernel<true, 1>), dim3((unsigned)grid), dim3(256), lds_bytes, as_stream(stream), x_lm, x_stride, w1, w2, n_out, beta,
-                           d_col0, out_col0, ld_out, d_feat, ld_feat, d_jac, dx, dx_stride, partials, (int)grid, n, n_ptr);
+                           d_col0, ld_col0, out_col0, ld_out, d_feat, ld_feat, d_jac, dx, dx_stride, partials, (int)grid, n, n_ptr);
     } else {
         if ((rc = set_lds(geo2_bwd_kernel<false, 1>, lds_bytes))) return rc;
         hipLaunchKernelGGL((geo2_bwd_kernel<false, 1>), dim3((unsigned)grid), dim3(256), lds_bytes, as_stream(stream), x_lm, x_stride, w1, w2, n_out, beta,
-                           d_col0, out_col0, ld_out, d_feat, ld_feat, d_jac, dx, dx_stride, partials, (int)grid, n, n_ptr);
+                           d_col0, ld_col0, out_col0, ld_out, d_feat, ld_feat, d_jac, dx, dx_stride, partials, (int)grid, n, n_ptr);
     }
     DwParams D;
     D.n_layers = 2;

@@ -556,6 +556,9 @@ def softplus(z, beta):
     return SoftplusFn.apply(z.contiguous(), float(beta))
 
 
+FUSED_SDF_NET = True      # (False: SdfMlpJacFn as its chain of dense products - the reference the fused kernels are tested against)
+
+
 class SdfMlpJacFn(torch.autograd.Function):
     """The two-layer softplus sdf net of NeuS on the hash grid (GeoNet D = 1, no bias: out = W2 softplus_beta(W1 f)) together with the
     Jacobian row of its first output, J = d out[:, 0] / d f = W1^T (s * W2[0]) with s = sigmoid(beta W1 f) - as EXPLICIT outputs of a
@@ -566,8 +569,22 @@ class SdfMlpJacFn(torch.autograd.Function):
         dz = dh s + W2[0] u beta s (1 - s),   df = dz W1,   dW1 = dz^T f + diag(W2[0]) s^T g_J,   dW2 = g_out^T h,  dW2[0] += sum_s s u"""
 
     @staticmethod
+    def _fused(f, w1, w2):
+        """the NGP shape - 32 features, 64 hidden, <= 32 outputs, f32 on the GPU: one forward and one backward kernel (arcn_geo2_fwd / _bwd on the
+        row-major features), the hidden layer in registers; anything else keeps the chain of dense products below"""
+        return (FUSED_SDF_NET and tuple(w1.shape) == (64, 32) and w2.shape[1] == 64 and w2.shape[0] <= 32 and f.shape[0] > 0 and f.is_cuda
+                and f.dtype == w1.dtype == w2.dtype == torch.float32 and f.data_ptr() % 16 == 0)
+
+    @staticmethod
     def forward(ctx, f, w1, w2, beta):
         f = f.contiguous()
+        ctx.fused = SdfMlpJacFn._fused(f, w1, w2)
+        if ctx.fused:
+            w1c, w2c = w1.contiguous(), w2.contiguous()
+            out, _, jac = F.geo2_fwd(f, f.shape[0], w1c, w2c, True, beta, rows=True)
+            ctx.save_for_backward(f, w1c, w2c)
+            ctx.beta = beta
+            return out[:, :w2.shape[0]], jac
         h = F.gemm_nt(f, w1, None, act='softplus', beta=beta)             # (S, H)
         out = F.gemm_nt(h, w2, None)                                      # (S, O)
         s = F.softplus_grad(h, None, beta, from_y=True)                   # sigmoid(beta z) from y = softplus(z), one pass
@@ -579,6 +596,16 @@ class SdfMlpJacFn(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g_out, g_jac):
+        if ctx.fused:
+            f, w1, w2 = ctx.saved_tensors
+            n, n_out = f.shape[0], w2.shape[0]
+            g_out = g_out if (g_out.dim() == 2 and g_out.stride(1) == 1) else g_out.contiguous()
+            if g_jac is None:
+                g_jac = torch.zeros((n, 32), dtype=torch.float32, device=f.device)
+            flat = torch.zeros(64 * 32 + n_out * 64, dtype=torch.float32, device=f.device)      # the kernel ADDS both layers' gradients into views of one buffer
+            dw1, dw2 = flat[:2048].view(64, 32), flat[2048:].view(n_out, 64)
+            df = F.geo2_bwd(f, n, w1, w2, True, ctx.beta, g_out[:, 0], g_out[:, 1:], dw1, dw2, d_jac=g_jac.contiguous(), rows=True)
+            return (df if ctx.needs_input_grad[0] else None), dw1, dw2, None
         f, w1, w2, h = ctx.saved_tensors
         beta = ctx.beta
         s = F.softplus_grad(h, None, beta, from_y=True)

@@ -1504,7 +1504,7 @@ def hashgrid_fwd_lm(xyz, table, desc, want_corners=False, n_dev=None):
     return lm, None
 
 
-def geo2_fwd(x_lm, n, w1, w2, jac, beta=1.0, pad_to=4):
+def geo2_fwd(x_lm, n, w1, w2, jac, beta=1.0, pad_to=4, rows=False):
     """a two-layer geometry net on level-major hash features (level stride n) in one launch (arcn_geo2_fwd): w1 (64, 32), w2 (n_out, 64).
     jac True: the sdf net - softplus(beta) hidden layer -> (out (n, n_pad), sdf (n) = out[:, 0], jac (n, 32) = d sdf / d features);
     jac False: a density net - ReLU hidden layer -> (out, exp(out[:, 0]), None)"""
@@ -1516,19 +1516,20 @@ def geo2_fwd(x_lm, n, w1, w2, jac, beta=1.0, pad_to=4):
     out = torch.empty((n, n_pad), dtype=torch.float32, device=dev)
     head = torch.empty(n, dtype=torch.float32, device=dev)
     jc = torch.empty((n, 32), dtype=torch.float32, device=dev) if jac else None
-    N.check(N.lib().arcn_geo2_fwd(N.ptr(x_lm), int(n), N.ptr(_f32(w1)), N.ptr(_f32(w2)), n_out, n_pad, int(bool(jac)), float(beta), N.ptr(out), N.ptr(head),
+    # (rows: x_lm is the (n, 32) row-major feature tensor instead of the level-major one)
+    N.check(N.lib().arcn_geo2_fwd(N.ptr(x_lm), 0 if rows else int(n), N.ptr(_f32(w1)), N.ptr(_f32(w2)), n_out, n_pad, int(bool(jac)), float(beta), N.ptr(out), N.ptr(head),
                                  N.ptr(jc), int(n), None, N.stream()), 'geo2_fwd')
     return out, head, jc
 
 
-def geo2_bwd(x_lm, n, w1, w2, jac, beta, d_col0, d_feat, dw1, dw2, d_jac=None, out=None, dx_level_major=False, scratch=None):
+def geo2_bwd(x_lm, n, w1, w2, jac, beta, d_col0, d_feat, dw1, dw2, d_jac=None, out=None, dx_level_major=False, scratch=None, rows=False):
     """the backward of geo2_fwd in one launch + its weight-gradient reduction (arcn_geo2_bwd): d_col0 (n) = the gradient of the head (sdf, or the
     density through its exp), d_feat (n, n_out - 1) = the gradient of the feature columns (may be a column slice of a wider row-major tensor),
     d_jac (n, 32) = the gradient of the Jacobian row (jac True), out = the forward's output (jac False: its column 0 is the TruncExp's input).
     dw1 (64, 32) += and dw2 (n_out, 64) += (views of one flat gradient buffer).  -> dx: (n, 32) rows, or level-major (32 n,) with dx_level_major"""
     _req(x_lm, w1, w2, d_col0, d_feat, dw1, dw2, d_jac, out)
     n_out = int(w2.shape[0])
-    assert d_col0.is_contiguous() and d_col0.dtype == torch.float32 and d_col0.numel() == n
+    assert d_col0.dtype == torch.float32 and d_col0.dim() == 1 and d_col0.numel() == n        # (may be column 0 of a wider row-major gradient)
     assert d_feat.dtype == torch.float32 and d_feat.stride(1) == 1 and d_feat.shape == (n, n_out - 1)
     assert dw1.is_contiguous() and dw2.is_contiguous() and tuple(dw1.shape) == (64, 32) and tuple(dw2.shape) == (n_out, 64)
     dev = x_lm.device
@@ -1542,8 +1543,8 @@ def geo2_bwd(x_lm, n, w1, w2, jac, beta, d_col0, d_feat, dw1, dw2, d_jac=None, o
         ld_out = out.stride(0)
     else:
         assert d_jac is not None and d_jac.is_contiguous() and tuple(d_jac.shape) == (n, 32)
-    N.check(N.lib().arcn_geo2_bwd(N.ptr(x_lm), int(n), N.ptr(_f32(w1)), N.ptr(_f32(w2)), n_out, int(bool(jac)), float(beta), N.ptr(d_col0),
-                                 None if out is None else out.data_ptr(), int(ld_out), d_feat.data_ptr(), int(d_feat.stride(0)), N.ptr(d_jac), N.ptr(dx),
+    N.check(N.lib().arcn_geo2_bwd(N.ptr(x_lm), 0 if rows else int(n), N.ptr(_f32(w1)), N.ptr(_f32(w2)), n_out, int(bool(jac)), float(beta), d_col0.data_ptr(),
+                                 max(1, int(d_col0.stride(0))), None if out is None else out.data_ptr(), int(ld_out), d_feat.data_ptr(), int(d_feat.stride(0)), N.ptr(d_jac), N.ptr(dx),
                                  int(n) if dx_level_major else 0, N.ptr(dw1), N.ptr(dw2), N.ptr(scratch), int(n), None, N.stream()), 'geo2_bwd')
     return dx
 

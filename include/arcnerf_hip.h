@@ -536,6 +536,8 @@ int arcn_sdf_jac_dz(const float *dh, const float *u, const float *s, const float
  *     jac (n, 32) row-major = d out[:, 0] / d x = W1^T (s W2[0]), s = 1 - exp(-beta h).  Backward inputs: d_col0 (n) = d out[:, 0],
  *     d_feat (row stride ld_feat) = d out[:, 1 .. n_out), d_jac (n, 32) = the gradient of jac; outputs dx (n, 32) row-major (dx_stride 0) or
  *     level-major (dx_stride >= n), dw1 += and dw2 += the weight gradients of BOTH paths (ops.autograd.SdfMlpJacFn.backward's arithmetic).
+ *     d_col0 is read at row stride ld_col0 (1: a contiguous vector; the width of a (n, n_out) gradient whose column 0 it is).
+ *   x_stride 0: the features are (n, 32) ROWS (HashGridEmbedder.forward's output, hashgrid_encoder.py:160-189) instead of level-major.
  *   jac_mode 0 - a density net (ReLU hidden layer, TruncExp on column 0: linear_network_module.py:174-197 with out_act_cfg TruncExp):
  *     head (n) = exp(out[:, 0]); the backward takes d_col0 = d head and multiplies it by exp(clamp(out_col0[s * ld_out], -15, 15)) (the
  *     reference's TruncExp backward, arcnerf/ops/trunc_exp.py), out_col0 = the forward's out.
@@ -545,8 +547,9 @@ int arcn_geo2_fwd(const float *x_lm, int64_t x_stride, const float *w1, const fl
                   float *out, float *head, float *jac, int64_t n, const int32_t *n_ptr, void *stream);
 int64_t arcn_geo2_bwd_scratch_floats(int64_t n);
 int arcn_geo2_bwd(const float *x_lm, int64_t x_stride, const float *w1, const float *w2, int n_out, int jac_mode, float beta,
-                  const float *d_col0, const float *out_col0, int64_t ld_out, const float *d_feat, int64_t ld_feat, const float *d_jac,
-                  float *dx, int64_t dx_stride, float *dw1, float *dw2, float *scratch, int64_t n, const int32_t *n_ptr, void *stream);
+                  const float *d_col0, int64_t ld_col0, const float *out_col0, int64_t ld_out, const float *d_feat, int64_t ld_feat,
+                  const float *d_jac, float *dx, int64_t dx_stride, float *dw1, float *dw2, float *scratch, int64_t n, const int32_t *n_ptr,
+                  void *stream);
 /* The passes BETWEEN the kernels of the NeuS-on-hash-grid + MultiVol training step (trainer.FusedNeusNgpStep; csrc/step_glue.hip), each
  * one group of the reference's elementwise torch expressions in one launch:
  *   arcn_neus_step_prep  the per-step derived weights of the two geometry nets (sdf_model.py:42-101, base_network.py:30-44, neus_model.py:221-228):

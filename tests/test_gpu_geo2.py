@@ -143,3 +143,29 @@ def test_both_ngp_nets_in_one_kernel_equal_the_two_launches_bit_for_bit(gpu, S, 
     bad = N.make_mlp_desc([32, 64, 16], 'softplus', None)
     assert lib.arcn_ngp_nets_fwd(N.ptr(lm), cap, N.ptr(gw), C.addressof(bad), N.ptr(geo_b), N.ptr(sh_ray), N.ptr(ray_id), 1, N.ptr(rw), C.addressof(rd),
                                  N.ptr(rgb_c), None, None, 0, cap, S, None, st) == -1
+
+
+def test_module_path_sdf_node_on_the_fused_kernels_equals_its_chain_of_products(gpu):
+    """ops.autograd.SdfMlpJacFn (what GeoNet.forward_with_grad runs for NeuS on the hash grid, sdf_model.py:42-101) routes the NGP shape through
+    arcn_geo2_fwd / _bwd on row-major features; FUSED_SDF_NET = False keeps the chain of dense products it replaces: same outputs and gradients
+    (the fused kernels take softplus and its slope from one hardware exponential: 2e-6 of each tensor's max, not bits)."""
+    from arcnerf_amd.ops import autograd as A
+    g = torch.Generator().manual_seed(11)
+    S, O, beta = 4099, 20, 100.0
+    f0 = (torch.randn(S, 32, generator=g) * 0.3).to(gpu)
+    w10 = (torch.randn(64, 32, generator=g) / 32 ** 0.5 * 0.3).to(gpu)
+    w20 = (torch.randn(O, 64, generator=g) / 8.0).to(gpu)
+    go, gj = torch.randn(S, O, generator=g).to(gpu), torch.randn(S, 32, generator=g).to(gpu)
+    res = {}
+    for fused in (True, False):
+        A.FUSED_SDF_NET = fused
+        try:
+            f, w1, w2 = (t.clone().requires_grad_(True) for t in (f0, w10, w20))
+            out, jac = A.SdfMlpJacFn.apply(f, w1, w2, beta)
+            loss = (out * go).sum() + (jac * gj).sum()
+            res[fused] = (out.detach(), jac.detach()) + torch.autograd.grad(loss, (f, w1, w2))
+        finally:
+            A.FUSED_SDF_NET = True
+    for a, b, name in zip(res[True], res[False], ('out', 'jac', 'df', 'dw1', 'dw2')):
+        assert a.shape == b.shape, name
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (name, float((a - b).abs().max() / b.abs().max()))
