@@ -126,7 +126,7 @@ class FusedNeusNgpStep:
         return None
 
     def __init__(self, model, loss_factory, optimizer, ema=None, total_epoch=300000, prefetch=True, world_size=1, grad_sync='flat',
-                 sync_occupancy=True, keep_corners=True, fuse_adam=True, fused_geo=True, march_at='opt'):
+                 sync_occupancy=True, keep_corners=True, fuse_adam=True, fused_geo=True, march_at='opt', bkg_stream=True):
         """world_size > 1: data parallel, one process per GPU, every rank its shard of the rays (the reference wraps the model in
         DistributedDataParallel, common/trainer/basic_trainer.py:192-198).  The flat gradient is SUMMED over the ranks between the backward
         and the optimiser - grad_sync 'flat': ONE all-reduce of the flattened optimiser's gradient buffer, then FusedAdam.step() on every
@@ -170,6 +170,7 @@ class FusedNeusNgpStep:
         # 'opt' (behind the last scatter, beside the optimiser pass and the NEXT step's forward).  Measured (profiles/r6_ab_cfg4_march_at.txt):
         # 1.36 / 1.34 / 1.38 / 1.26 ms - the cascade marcher (275 us of long serial waves) costs the MFMA-bound backward kernels it runs beside
         # more than it costs the gathers
+        self.bkg_stream = bool(bkg_stream)      # (the background's forward and backward chains beside the foreground's, on a stream of their own)
         if march_at not in ('start', 'blend', 'fg_bwd', 'opt'):
             raise RuntimeError('FusedNeusNgpStep: march_at must be start | blend | fg_bwd | opt')
         self.march_at = march_at
@@ -266,13 +267,30 @@ class FusedNeusNgpStep:
                     out.append((lo, hi))
         return out
 
-    def _geo_scratch(self, n, device):
-        """the weight-gradient partials of arcn_geo2_bwd, kept (both nets' calls are stream-ordered: one buffer)"""
+    def _geo_scratch(self, n, device, key='geo2_fg'):
+        """the weight-gradient partials of arcn_geo2_bwd, kept - one buffer per net (the two backward chains may run on two streams)"""
         need = int(F.N.lib().arcn_geo2_bwd_scratch_floats(int(n)))
-        w = self._ws.get('geo2')
+        w = self._ws.get(key)
         if w is None or w.numel() < need or w.device != device:
-            w = self._ws['geo2'] = torch.empty(max(1, need), dtype=torch.float32, device=device)
+            w = self._ws[key] = torch.empty(max(1, int(need * 1.25)), dtype=torch.float32, device=device)
         return w
+
+    def _bkg_side(self, cur):
+        """the context the background model's chains are issued in: its own stream behind everything `cur` has been given so far (bkg_stream), or
+        nothing.  The two models meet at the blend (forward) and at the optimiser (backward) only: different tables, nets and gradient
+        segments in between - and most of their kernels are too small to fill the chip alone (512 - 768 workgroups at two per CU)."""
+        import contextlib
+        if not self.bkg_stream:
+            return contextlib.nullcontext()
+        st = self._ws.get('bkg_stream')
+        if st is None or st.device != cur.device:
+            st = self._ws['bkg_stream'] = torch.cuda.Stream(device=cur.device)
+        st.wait_stream(cur)
+        return torch.cuda.stream(st)
+
+    def _bkg_join(self, cur):
+        if self.bkg_stream and self._ws.get('bkg_stream') is not None:
+            cur.wait_stream(self._ws['bkg_stream'])
 
     def _scatter_ws(self, key, desc, n, device):
         """scratch of a binned table scatter, kept while it is large enough (the library knows the size for n samples)"""
@@ -346,6 +364,34 @@ class FusedNeusNgpStep:
         cos_anneal = fg.get_cos_anneal(epoch)
         dflt_nrm = self._default_normal()
         dflt_rgb = fg.render_cfgs['bkg_color']
+        # ---- background forward: issued FIRST so that, on its own stream (bkg_stream), it runs beside the foreground's forward
+        rb = bkg.radiance_net
+        tb = emb_b.embeddings
+        nb_out = b1.weight.shape[0]
+        with self._bkg_side(cur):      # (bkg_stream: beside the foreground's forward, on the background's own stream)
+            if total_b > 0:
+                xyz_b, dirs_b = F.packed_points(rays_o, rays_d, t_b, ray_b)
+                if self.fused_geo:
+                    enc_b, _ = F.hashgrid_fwd_lm(xyz_b, tb, emb_b.desc)
+                    out_b, sigma_b, _ = F.geo2_fwd(enc_b, total_b, b0.weight, b1.weight, False)
+                else:
+                    enc_b = F.hashgrid_fwd(xyz_b, tb, emb_b.desc)
+                    hid_b = F.gemm_nt(enc_b, b0.weight, None, act='relu')
+                    out_b = F.gemm_nt(hid_b, wb1, None)
+                    sigma_b = F.act_col_scale(out_b, 'truncexp', 1.0)       # (the density from column 0 of the padded output)
+                rin_b = F.radiance_inputs('fv', None, dirs_b, None, out_b[:, 1:nb_out], rb.embed_fn_view.n_freqs)
+                rb_w = _flat_view([layer.weight for layer in rb.layers])
+                rb_g = _flat_view([layer.weight.grad for layer in rb.layers]) if rb_w is not None else None
+                if rb_w is None:
+                    rb_w = torch.cat([layer.weight.reshape(-1) for layer in rb.layers])
+                rgb_sb, rb_acts = F.mlp_fwd(rin_b, rb_w, None, rb._fused_desc, save_acts=True)
+                comp = F.composite_packed_fwd(sigma_b, rgb_sb, t_b, off_b, p_dense_dev=pd_b, add_inf_z=bool(bkg.add_inf_z),
+                                              white_bkg=bool(bkg.get_ray_cfgs('white_bkg')))
+                rgb_b, depth_b = comp['rgb'], comp['depth']
+            else:
+                rgb_b = rays_o.new_ones((R, 3)) if bkg.get_ray_cfgs('white_bkg') else rays_o.new_zeros((R, 3))
+                depth_b = rays_o.new_zeros((R,))
+        # ---- foreground forward (continued)
         if S > 0:
             fg.adjust_dynamicbs_factor(n_valid=pk['offsets'][R])
             pts, dirs = F.packed_points(rays_o, rays_d, pk['t_mid'], pk['ray_id'])
@@ -381,32 +427,8 @@ class FusedNeusNgpStep:
             rgb_s = normal = rays_o.new_zeros((1, 3))
         rgb_f, depth_f, mask_f, nrm_f, t_last = F.neus_render_fwd(sdf, rgb_s, normal, pk, rays_d, s_dev, cos_anneal, bkg_color,
                                                                  float(fg.render_cfgs['depth_far']), dflt_rgb, dflt_nrm)
-        # ---- background forward
-        rb = bkg.radiance_net
-        tb = emb_b.embeddings
-        nb_out = b1.weight.shape[0]
-        if total_b > 0:
-            xyz_b, dirs_b = F.packed_points(rays_o, rays_d, t_b, ray_b)
-            if self.fused_geo:
-                enc_b, _ = F.hashgrid_fwd_lm(xyz_b, tb, emb_b.desc)
-                out_b, sigma_b, _ = F.geo2_fwd(enc_b, total_b, b0.weight, b1.weight, False)
-            else:
-                enc_b = F.hashgrid_fwd(xyz_b, tb, emb_b.desc)
-                hid_b = F.gemm_nt(enc_b, b0.weight, None, act='relu')
-                out_b = F.gemm_nt(hid_b, wb1, None)
-                sigma_b = F.act_col_scale(out_b, 'truncexp', 1.0)       # (the density from column 0 of the padded output)
-            rin_b = F.radiance_inputs('fv', None, dirs_b, None, out_b[:, 1:nb_out], rb.embed_fn_view.n_freqs)
-            rb_w = _flat_view([layer.weight for layer in rb.layers])
-            rb_g = _flat_view([layer.weight.grad for layer in rb.layers]) if rb_w is not None else None
-            if rb_w is None:
-                rb_w = torch.cat([layer.weight.reshape(-1) for layer in rb.layers])
-            rgb_sb, rb_acts = F.mlp_fwd(rin_b, rb_w, None, rb._fused_desc, save_acts=True)
-            comp = F.composite_packed_fwd(sigma_b, rgb_sb, t_b, off_b, p_dense_dev=pd_b, add_inf_z=bool(bkg.add_inf_z),
-                                          white_bkg=bool(bkg.get_ray_cfgs('white_bkg')))
-            rgb_b, depth_b = comp['rgb'], comp['depth']
-        else:
-            rgb_b = rays_o.new_ones((R, 3)) if bkg.get_ray_cfgs('white_bkg') else rays_o.new_zeros((R, 3))
-            depth_b = rays_o.new_zeros((R,))
+        # ---- (the background's forward was issued above, before the foreground's)
+        self._bkg_join(cur)
         # the samplers of the next batch, beside everything that follows
         if self.march_at == 'blend':
             ahead()
@@ -416,36 +438,37 @@ class FusedNeusNgpStep:
         rgb, depth, d_rgb, d_tlast, d_rgb_b = bl['rgb'], bl['depth'], bl['d_rgb'], bl['d_tlast'], bl['d_rgb_b']
         losses = bl['loss']          # [image loss, 0 = the Eikonal pass's accumulator]
         # ---- background backward
-        if total_b > 0:
-            d_sig_b, d_rad_b = F.composite_packed_bwd(sigma_b, rgb_sb, t_b, off_b, d_rgb_b, None, None, p_dense_dev=pd_b,
-                                                      add_inf_z=bool(bkg.add_inf_z), white_bkg=bool(bkg.get_ray_cfgs('white_bkg')))
-            dx_b, dw_b, _ = F.mlp_bwd(rin_b, rb_w, None, rb._fused_desc, rgb_sb, rb_acts, d_rad_b, want_dx=True, dweights=rb_g)     # (added into rb_g)
-            if rb_g is None:
-                k = 0
-                for layer in rb.layers:
-                    m_ = layer.weight.numel()
-                    layer.weight.grad.add_(dw_b[k:k + m_].view_as(layer.weight))
-                    k += m_
-            # [d density through TruncExp | d features | 0] of the padded output, one pass
-            lm_b = 0
-            if self.fused_geo:
-                # [d density through TruncExp | d features] enters the net's backward in pieces; d_enc_b level-major, as the scatter reads it
-                d_enc_b = F.geo2_bwd(enc_b, total_b, b0.weight, b1.weight, False, 1.0, d_sig_b, dx_b[:, :nb_out - 1], b0.weight.grad, b1.weight.grad,
-                                     out=out_b, dx_level_major=True, scratch=self._geo_scratch(total_b, dev))
-                lm_b = total_b
-            else:
-                g_out_b = F.geo_out_grad(d_sig_b, dx_b[:, :nb_out - 1], wb1.shape[0], out=out_b, act='truncexp', y_col0=sigma_b)
-                F.gemm_tn(g_out_b, hid_b, out=b1.weight.grad, accumulate=True, head=nb_out)
-                d_hid_b = F.gemm_nn(g_out_b, wb1)
-                F.gemm_tn(d_hid_b, enc_b, mask=hid_b, out=b0.weight.grad, accumulate=True)
-                d_enc_b = F.gemm_nn(d_hid_b, b0.weight, mask=hid_b)
-            ws_b = self._scatter_ws('bkg', emb_b.desc, total_b, dev)
-            if fuse:
-                hyper = hyper or self.opt.begin_step()
-                m_, v_, o_ = self.opt.table_views(tb)
-                done += self._level_ranges(emb_b, F.hashgrid_bwd_adam(xyz_b, d_enc_b, emb_b.desc, tb.grad, tb, m_, v_, hyper, ws_b, level_stride=lm_b), o_)
-            else:
-                F.hashgrid_bwd(xyz_b, tb, d_enc_b, emb_b.desc, dtable=tb.grad, workspace=ws_b, level_stride=lm_b)
+        with self._bkg_side(cur):      # (bkg_stream: the background's whole backward, its table scatter + optimiser included, beside the foreground's)
+            if total_b > 0:
+                d_sig_b, d_rad_b = F.composite_packed_bwd(sigma_b, rgb_sb, t_b, off_b, d_rgb_b, None, None, p_dense_dev=pd_b,
+                                                          add_inf_z=bool(bkg.add_inf_z), white_bkg=bool(bkg.get_ray_cfgs('white_bkg')))
+                dx_b, dw_b, _ = F.mlp_bwd(rin_b, rb_w, None, rb._fused_desc, rgb_sb, rb_acts, d_rad_b, want_dx=True, dweights=rb_g)     # (added into rb_g)
+                if rb_g is None:
+                    k = 0
+                    for layer in rb.layers:
+                        m_ = layer.weight.numel()
+                        layer.weight.grad.add_(dw_b[k:k + m_].view_as(layer.weight))
+                        k += m_
+                # [d density through TruncExp | d features | 0] of the padded output, one pass
+                lm_b = 0
+                if self.fused_geo:
+                    # [d density through TruncExp | d features] enters the net's backward in pieces; d_enc_b level-major, as the scatter reads it
+                    d_enc_b = F.geo2_bwd(enc_b, total_b, b0.weight, b1.weight, False, 1.0, d_sig_b, dx_b[:, :nb_out - 1], b0.weight.grad, b1.weight.grad,
+                                         out=out_b, dx_level_major=True, scratch=self._geo_scratch(total_b, dev, 'geo2_bkg'))
+                    lm_b = total_b
+                else:
+                    g_out_b = F.geo_out_grad(d_sig_b, dx_b[:, :nb_out - 1], wb1.shape[0], out=out_b, act='truncexp', y_col0=sigma_b)
+                    F.gemm_tn(g_out_b, hid_b, out=b1.weight.grad, accumulate=True, head=nb_out)
+                    d_hid_b = F.gemm_nn(g_out_b, wb1)
+                    F.gemm_tn(d_hid_b, enc_b, mask=hid_b, out=b0.weight.grad, accumulate=True)
+                    d_enc_b = F.gemm_nn(d_hid_b, b0.weight, mask=hid_b)
+                ws_b = self._scatter_ws('bkg', emb_b.desc, total_b, dev)
+                if fuse:
+                    hyper = hyper or self.opt.begin_step()
+                    m_, v_, o_ = self.opt.table_views(tb)
+                    done += self._level_ranges(emb_b, F.hashgrid_bwd_adam(xyz_b, d_enc_b, emb_b.desc, tb.grad, tb, m_, v_, hyper, ws_b, level_stride=lm_b), o_)
+                else:
+                    F.hashgrid_bwd(xyz_b, tb, d_enc_b, emb_b.desc, dtable=tb.grad, workspace=ws_b, level_stride=lm_b)
         if self.march_at == 'fg_bwd':
             ahead()
         # ---- foreground backward
@@ -493,6 +516,7 @@ class FusedNeusNgpStep:
                 F.hashgrid_bwd_first_second(pts, d_enc, d_normal, jac, emb.desc, table.grad, ws_f)
             # scale = exp(inv_s * speed)
             F.sum_scale_add(d_s_ray, fg.inv_s.grad, float(fg.speed_factor), s_dev)
+        self._bkg_join(cur)
         if self.march_at == 'opt':
             ahead()
         # ---- optimiser

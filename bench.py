@@ -344,7 +344,7 @@ def bench_module(args, name, emit=True):
         gs = os.environ.get('ARCN_GRAD_SYNC', 'flat')
         # (ARCN_NEUS_FUSED_GEO=0: both geometry nets as round 5's chains of dense products instead of arcn_geo2_fwd / _bwd - the A/B switch)
         fused_neus = FusedNeusNgpStep(m, neus_loss, opt, world_size=world, grad_sync=gs if gs in ('flat', 'sharded') else 'flat',
-                                      fused_geo=os.environ.get('ARCN_NEUS_FUSED_GEO', '1') != '0', march_at=os.environ.get('ARCN_NEUS_MARCH_AT', 'opt'))
+                                      fused_geo=os.environ.get('ARCN_NEUS_FUSED_GEO', '1') != '0', march_at=os.environ.get('ARCN_NEUS_MARCH_AT', 'opt'), bkg_stream=os.environ.get('ARCN_NEUS_BKG_STREAM', '1') != '0')
 
     def step(i):
         inp = pool[i % len(pool)]

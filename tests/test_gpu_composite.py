@@ -323,14 +323,18 @@ def test_fused_neus_ngp_step_equals_the_module_path(gpu):
             assert float(p.grad.abs().max()) > 0, name
     # (b) three iterations with the optimiser, the next batch's samplers prefetched: the module path's parameters
     runs = {}
-    for mode in ('eager', 'fused', 'fused_two_pass', 'fused_two_ahead', 'fused_geo_chains', 'fused_march_blend'):
+    for mode in ('eager', 'fused', 'fused_two_pass', 'fused_two_ahead', 'fused_geo_chains', 'fused_march_blend', 'fused_one_stream'):
         m, opt, lf = make()
         # (fused_geo_chains: both geometry nets as round 5's chains of dense products instead of arcn_geo2_*; fused_march_blend: the coming
         # batches' samplers queued after the forwards instead of behind the last scatter)
+        # fused_one_stream: the background's chains on the foreground's stream instead of beside them on their own
         kw = {'fused_geo': False} if mode == 'fused_geo_chains' else ({'march_at': 'blend'} if mode == 'fused_march_blend' else {})
+        if mode == 'fused_one_stream':
+            kw = {'bkg_stream': False}
         st = T.FusedNeusNgpStep(m, lf, opt, **kw) if mode != 'eager' else None
         if st is not None:
             assert st.fused_geo == (mode != 'fused_geo_chains') and st.march_at == ('blend' if mode == 'fused_march_blend' else 'opt')
+            assert st.bkg_stream == (mode != 'fused_one_stream')
         if mode == 'fused':
             assert st.fuse_adam           # the scatters' chunk owners apply Adam to the table levels they own
         if mode == 'fused_two_pass':
@@ -359,7 +363,7 @@ def test_fused_neus_ngp_step_equals_the_module_path(gpu):
     assert runs['fused_two_ahead'][2:] == runs['fused'][2:]
     assert max(abs(x - y) / abs(x) for x, y in zip(lf_, la2)) < 1e-5, (lf_, la2)
     assert float(((pf - pa2).abs() > 1e-3 * float(pf.abs().max())).float().mean()) < 1e-3
-    for other in ('fused_geo_chains', 'fused_march_blend'):
+    for other in ('fused_geo_chains', 'fused_march_blend', 'fused_one_stream'):
         lo_, po = runs[other][:2]
         assert runs[other][2:] == runs['fused'][2:]
         assert max(abs(x - y) / abs(x) for x, y in zip(lf_, lo_)) < 1e-5, (other, lf_, lo_)
