@@ -123,7 +123,7 @@ TABLE_KERNELS = ROOFLINE_KERNELS + ('mlp_fwd', 'mlp_bwd', 'mlp_bwd_dw', 'march_c
 
 # entry points of the level-major path are reported under the name of the op they implement
 ALIASES = {'hashgrid_fwd_xcd': 'hashgrid_fwd', 'hashgrid_bwd_lm': 'hashgrid_bwd', 'hashgrid_bwd_lm_adam': 'hashgrid_bwd', 'hashgrid_bwd_lm_adam_planned': 'hashgrid_bwd', 'hashgrid_bwd_lm_planned': 'hashgrid_bwd', 'adam_ema_step_runs': 'adam_ema_step', 'ngp_step_tail': 'adam_ema_step', 'mlp_fwd_lm': 'mlp_fwd', 'mlp_bwd_lm': 'mlp_bwd',
-           'mlp_fwd_cat': 'mlp_fwd', 'mlp_bwd_cat': 'mlp_bwd', 'march_count_culled': 'march_count', 'march_count_waves': 'march_count'}
+           'mlp_fwd_cat': 'mlp_fwd', 'mlp_bwd_cat': 'mlp_bwd', 'ngp_nets_fwd': 'mlp_fwd', 'march_count_culled': 'march_count', 'march_count_waves': 'march_count'}
 
 
 class KernelTimers:

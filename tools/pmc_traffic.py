@@ -13,7 +13,7 @@ ENTRY = {  # C entry point -> device kernels it launches (substring match on the
     'hashgrid_fwd': ['hashgrid_fwd_bal_kernel', 'hashgrid_fwd_xcd_kernel'],
     'adam_ema_step': ['adam_ema_kernel', 'adam_ema_runs_kernel', 'ngp_step_tail_kernel'],
     'mlp_bwd': ['mlp_bwd_fused_kernel'],
-    'mlp_fwd': ['mlp_fwd_fixed_kernel'],
+    'mlp_fwd': ['mlp_fwd_fixed_kernel', 'ngp_nets_fwd_kernel'],
 }
 
 
