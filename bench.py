@@ -647,7 +647,8 @@ def main():
     # the ray batches of a run are known in advance (the reference precaches and shuffles them on the GPU): march two steps ahead
     pipe = NgpPipeline(field, max_rays=32768, max_samples=1 << 20, packed_bits=True, prefetch_depth=2,
                        planned_scatter=os.environ.get('ARCN_PLANNED_SCATTER', '0') == '1',      # (=1: the planned scatter, the A/B of DESIGN.md)
-                       fused_nets=os.environ.get('ARCN_FUSED_NETS', '1') != '0')                # (=0: the two nets' forward as two launches)
+                       fused_nets=os.environ.get('ARCN_FUSED_NETS', '1') != '0',                # (=0: the two nets' forward as two launches)
+                       prefetch_at=(int(os.environ['ARCN_PREFETCH_AT']) if os.environ.get('ARCN_PREFETCH_AT') else None))   # (where the step queues the coming batch's marching)
     bf = synthetic_bitfield(cfg.n_grid, args.occupancy, seed=0)
     pipe.set_bitfield(torch.from_numpy(bf))
 
