@@ -913,6 +913,11 @@ def main():
             a2 = copy.copy(args)
             # (24 steps after 6: the 8-after-3 legs of rounds 2 - 4 read the wide configs 1 - 3 % high - allocator growth and clocks still settling)
             a2.steps, a2.warmup, a2.rays, a2.chunk_pts, a2.no_cpu_baseline = 24, 6, 0, 0, True
+            if name in ('nerf', 'neus', 'hdrnerf'):
+                # the yaml's chunk_pts (4096 * 32 points per net evaluation) is the reference's memory knob for an 11 GB card; the chunks are
+                # independent, so on 288 GB the whole batch goes through the nets in one or two of them: half the launches, 2 - 4.5 % off the
+                # step (profiles/r6_exp_chunk_pts.txt); the value is reported as config.chunk_pts
+                a2.chunk_pts = 1 << 20
             if name == 'ngp_module':    # the headline's model through the drop-in API: the driver's own K / W (+ the stepper's two eager steps)
                 a2.steps, a2.warmup = min(args.steps, 2000), min(args.warmup, 500) + 2
             elif name in ('neus_ngp_multivol', 'neus_ngp_nerfpp'):     # 2 ms steps: eight of them are not a steady state (buffers still growing, 2.19 vs 1.96 ms stand-alone)
