@@ -928,7 +928,7 @@ def main():
                 # round robin - they land on shared ones (1.59 ms here against 1.10 ms in a process that builds the one model, what a training run is)
                 r = module_leg_child(name, a2.steps, a2.warmup) if name in ('neus_ngp_multivol', 'neus_ngp_nerfpp') else bench_module(a2, name, emit=False)
                 others[name] = {'ms_per_step': r['ms_per_step'], 'ms_per_step_p50': (r['config'].get('step_ms_device') or {}).get('p50'), 'samples_per_s': r['value'], 'steps': a2.steps, 'warmup': a2.warmup,
-                                'rays_per_step': r['config']['rays_per_step_per_gpu'], 'samples_per_step': r['config']['samples_per_step_per_gpu'],
+                                'rays_per_step': r['config']['rays_per_step_per_gpu'], 'samples_per_step': r['config']['samples_per_step_per_gpu'], 'chunk_pts': r['config'].get('chunk_pts'),
                                 'roofline_frac': (r['roofline'] or {}).get('frac_of_split_peak', (r['roofline'] or {}).get('frac')), 'roofline_peak': 'dense bf16 MFMA / 6 terms (417 TFLOP/s of f32-accurate work)' if 'frac_of_split_peak' in (r['roofline'] or {}) else 'HBM 8 TB/s',
                                 'roofline_frac_of_f32_mfma_peak': (r['roofline'] or {}).get('frac') if 'frac_of_split_peak' in (r['roofline'] or {}) else None, 'roofline_bound': (r['roofline'] or {}).get('bound'), 'bkg_samples_per_step': (r['roofline'] or {}).get('bkg_samples_per_step'),
                                 'workload': r['config']['workload']}
