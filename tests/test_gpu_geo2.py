@@ -169,3 +169,21 @@ def test_module_path_sdf_node_on_the_fused_kernels_equals_its_chain_of_products(
     for a, b, name in zip(res[True], res[False], ('out', 'jac', 'df', 'dw1', 'dw2')):
         assert a.shape == b.shape, name
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (name, float((a - b).abs().max() / b.abs().max()))
+
+
+@pytest.mark.parametrize('n', [0, 1, 5, 4095, 4096, 4097, 32768, 100003])
+def test_exclusive_scan_tiles(gpu, n):
+    """arcn_exclusive_scan_i32 (the packed samplers' offsets: the reference's boolean-mask compaction order, fg_model.py:289-292) on sizes around
+    its 4096-count tiles: offsets, the total in offsets[n], the clamp to a capacity and the largest count, against torch.cumsum"""
+    from arcnerf_amd import _native as N
+    g = torch.Generator().manual_seed(n)
+    counts = torch.randint(0, 70, (max(n, 1),), generator=g, dtype=torch.int32)[:n].to(gpu)
+    ref = torch.zeros(n + 1, dtype=torch.int64)
+    ref[1:] = torch.cumsum(counts.cpu().long(), 0)
+    for cap in (0, int(ref[-1]) // 2 + 1):
+        off = torch.full((n + 1,), -7, dtype=torch.int32, device=gpu)
+        mx = torch.full((1,), -7, dtype=torch.int32, device=gpu)
+        N.check(N.lib().arcn_exclusive_scan_i32(N.ptr(counts) if n else N.ptr(off), N.ptr(off), n, cap, N.ptr(mx), N.stream()))
+        want = ref.clamp(max=cap) if cap > 0 else ref
+        assert torch.equal(off.cpu().long(), want), (n, cap)
+        assert int(mx) == (int(counts.max()) if n else 0)
