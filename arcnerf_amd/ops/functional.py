@@ -1494,9 +1494,9 @@ def hashgrid_fwd_lm(xyz, table, desc, want_corners=False, n_dev=None):
     _req(xyz, table)
     xyz, table = _f32(xyz), _f32(table)
     n, L, Fq = xyz.shape[0], int(desc.n_levels), int(desc.n_feat)
-    lm = torch.empty(n * L * Fq, dtype=torch.float32, device=xyz.device)
+    lm = _fresh((n * L * Fq,), torch.float32, xyz.device)
     if want_corners:
-        corners = torch.empty((L, 2 * Fq, n, 4), dtype=torch.float32, device=xyz.device)
+        corners = _fresh((L, 2 * Fq, n, 4), torch.float32, xyz.device)
         N.check(N.lib().arcn_hashgrid_fwd_corners(N.ptr(xyz), N.ptr(table), C.addressof(desc), N.ptr(lm), 1, N.ptr(corners), n, n, _nptr(n_dev), N.stream()),
                 'hashgrid_fwd_corners')
         return lm, corners
@@ -1513,9 +1513,9 @@ def geo2_fwd(x_lm, n, w1, w2, jac, beta=1.0, pad_to=4, rows=False):
     n_out = int(w2.shape[0])
     n_pad = (n_out + pad_to - 1) // pad_to * pad_to
     dev = x_lm.device
-    out = torch.empty((n, n_pad), dtype=torch.float32, device=dev)
-    head = torch.empty(n, dtype=torch.float32, device=dev)
-    jc = torch.empty((n, 32), dtype=torch.float32, device=dev) if jac else None
+    out = _fresh((n, n_pad), torch.float32, dev)
+    head = _fresh((n,), torch.float32, dev)
+    jc = _fresh((n, 32), torch.float32, dev) if jac else None
     # (rows: x_lm is the (n, 32) row-major feature tensor instead of the level-major one)
     N.check(N.lib().arcn_geo2_fwd(N.ptr(x_lm), 0 if rows else int(n), N.ptr(_f32(w1)), N.ptr(_f32(w2)), n_out, n_pad, int(bool(jac)), float(beta), N.ptr(out), N.ptr(head),
                                  N.ptr(jc), int(n), None, N.stream()), 'geo2_fwd')
@@ -1533,7 +1533,7 @@ def geo2_bwd(x_lm, n, w1, w2, jac, beta, d_col0, d_feat, dw1, dw2, d_jac=None, o
     assert d_feat.dtype == torch.float32 and d_feat.stride(1) == 1 and d_feat.shape == (n, n_out - 1)
     assert dw1.is_contiguous() and dw2.is_contiguous() and tuple(dw1.shape) == (64, 32) and tuple(dw2.shape) == (n_out, 64)
     dev = x_lm.device
-    dx = torch.empty(n * 32, dtype=torch.float32, device=dev) if dx_level_major else torch.empty((n, 32), dtype=torch.float32, device=dev)
+    dx = _fresh((n * 32,), torch.float32, dev) if dx_level_major else _fresh((n, 32), torch.float32, dev)
     need = int(N.lib().arcn_geo2_bwd_scratch_floats(int(n)))
     if scratch is None or scratch.numel() < need:
         scratch = torch.empty(max(1, need), dtype=torch.float32, device=dev)

@@ -150,7 +150,7 @@ def test_unfilled_outputs_are_written_in_full():
         pytest.skip('needs a GPU')
     env = dict(os.environ, ARCN_POISON_OUTPUTS='1')
     r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', 'tests/test_gpu_composite.py', 'tests/test_gpu_models.py', 'tests/test_gpu_kernels.py',
-                        '-k', 'fused_neus or packed or multivol or aabb or neus'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+                        'tests/test_gpu_geo2.py', '-k', 'fused_neus or packed or multivol or aabb or neus or sdf_net or density_net or module_path_sdf'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     tail = (r.stdout or '')[-1500:]
     assert r.returncode == 0, tail
     assert ' passed' in tail and 'no tests ran' not in tail, tail
