@@ -278,7 +278,10 @@ class FusedNeusNgpStep:
     def _bkg_side(self, cur):
         """the context the background model's chains are issued in: its own stream behind everything `cur` has been given so far (bkg_stream), or
         nothing.  The two models meet at the blend (forward) and at the optimiser (backward) only: different tables, nets and gradient
-        segments in between - and most of their kernels are too small to fill the chip alone (512 - 768 workgroups at two per CU)."""
+        segments in between - and most of their kernels are too small to fill the chip alone (512 - 768 workgroups at two per CU).
+        Memory: every tensor of the step stays referenced until __call__ returns, and by then `cur` has been told to wait for the background
+        stream (_bkg_join in front of the optimiser); a block freed there is only handed out again to work that is queued behind that wait (the
+        step's own stream) or behind the next step's `st.wait_stream(cur)` (the background stream's pool) - no record_stream needed."""
         import contextlib
         if not self.bkg_stream:
             return contextlib.nullcontext()
