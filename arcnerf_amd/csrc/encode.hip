@@ -233,16 +233,21 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 // one float4 per lane (n a multiple of 4 and 16-byte aligned pointers on the vector path)
 // from_y: the argument is y = softplus(z) itself (a layer that applies the activation in its product's epilogue keeps no z):
 // s = 1 - e^(-beta y) exactly, and ds is then d s / d y = beta (1 - s) (the chain through y supplies the second factor s).
+// (Round 6: on the hardware exponential - v_exp_f32, 1 ulp; the argument's rounding adds <= 1e-7 |beta z| relative, invisible in s and ds -
+// instead of libm's expf + expm1f: ~65 VALU instructions per element made these passes, three to five (S, 256) tensors each, run at 4.8 TB/s
+// where the same traffic streams at 6.5.  s = -expm1(-x) keeps its RELATIVE accuracy for small x through the series below 1/8.)
 __device__ __forceinline__ void softplus_s(float z, float beta, int from_y, float &s, float &ds) {
     const float bv = beta * z;
     if (bv > 20.f) { s = 1.f; ds = 0.f; return; }
     if (from_y) {
-        const float q = expf(-bv);       // 1 - s
-        s = -expm1f(-bv);
+        const float q = __builtin_amdgcn_exp2f(-bv * 1.44269504088896341f);       // 1 - s
+        const float x = bv;
+        const float ser = x * (1.0f - x * 0.5f * (1.0f - x * (1.0f / 3.0f) * (1.0f - x * 0.25f * (1.0f - x * 0.2f * (1.0f - x * (1.0f / 6.0f))))));
+        s = (x < 0.125f && x > -0.125f) ? ser : 1.0f - q;
         ds = beta * q;
         return;
     }
-    const float e = expf(bv), r = 1.f / (e + 1.f);
+    const float e = __builtin_amdgcn_exp2f(bv * 1.44269504088896341f), r = __builtin_amdgcn_rcpf(e + 1.f);
     s = e * r;
     ds = beta * s * r;
 }
